@@ -1,0 +1,297 @@
+"""Synthetic GGUF v3 writer (tests / bench tooling, not product code).
+
+There is no network and no real checkpoint on either box, so models are
+synthesised: exact hparams / tensor names / shapes / `*_K_M` type mix of the named config
+(SURVEY.md §A.4, §A.5), weights = seeded random *valid* quant blocks.  The files are ordinary
+GGUF v3 and are loaded through the same loader as any unmodified GGUF.
+
+Reference behaviour this feeds: `/loadmodel` -> LoadModelImpl (src/llama_engine.cc:547-732) ->
+common_init_from_params (src/llama_server_context.cc:207).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# ggml type ids
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 0, 1, 2, 8, 12, 13, 14
+TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K"}
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210}
+
+DT_Q4_0 = np.dtype([("d", "<f2"), ("qs", "u1", 16)])
+DT_Q8_0 = np.dtype([("d", "<f2"), ("qs", "i1", 32)])
+DT_Q4_K = np.dtype([("d", "<f2"), ("dmin", "<f2"), ("scales", "u1", 12), ("qs", "u1", 128)])
+DT_Q5_K = np.dtype([("d", "<f2"), ("dmin", "<f2"), ("scales", "u1", 12), ("qh", "u1", 32), ("qs", "u1", 128)])
+DT_Q6_K = np.dtype([("ql", "u1", 128), ("qh", "u1", 64), ("scales", "i1", 16), ("d", "<f2")])
+BLOCK_DTYPE = {Q4_0: DT_Q4_0, Q8_0: DT_Q8_0, Q4_K: DT_Q4_K, Q5_K: DT_Q5_K, Q6_K: DT_Q6_K}
+for _t, _dt in BLOCK_DTYPE.items():
+    assert _dt.itemsize == BLOCK_BYTES[_t], (_t, _dt.itemsize)
+
+# std of (dequantised weight / d) for uniformly random block payloads (derived in DESIGN.md)
+_UNIT_STD = {Q4_0: 4.6, Q8_0: 73.9, Q4_K: 258.0, Q5_K: 527.0, Q6_K: 1367.0}
+# dmin/d ratio that centres the weights of a random block on zero
+_DMIN_RATIO = {Q4_K: 7.5, Q5_K: 15.5}
+
+
+def row_bytes(t: int, n: int) -> int:
+    assert n % BLOCK_ELEMS[t] == 0, (t, n)
+    return n // BLOCK_ELEMS[t] * BLOCK_BYTES[t]
+
+
+def random_blocks(rng: np.random.Generator, t: int, n_elems: int, std: float) -> np.ndarray:
+    """n_elems weights of ggml type t as raw bytes; dequantised std ~= `std`, mean ~= 0."""
+    if t == F32:
+        return (rng.standard_normal(n_elems, dtype=np.float32) * std).view(np.uint8)
+    if t == F16:
+        return (rng.standard_normal(n_elems, dtype=np.float32) * std).astype("<f2").view(np.uint8)
+    nb = n_elems // BLOCK_ELEMS[t]
+    raw = rng.integers(0, 256, size=nb * BLOCK_BYTES[t], dtype=np.uint8)
+    blk = raw.view(BLOCK_DTYPE[t])
+    d = (rng.uniform(0.5, 1.5, size=nb) * (std / _UNIT_STD[t])).astype(np.float32)
+    blk["d"] = d.astype("<f2")
+    if t in _DMIN_RATIO:
+        blk["dmin"] = (d * _DMIN_RATIO[t]).astype("<f2")
+    return raw
+
+
+# ---------------------------------------------------------------- container
+_GT = {"u8": 0, "i8": 1, "u16": 2, "i16": 3, "u32": 4, "i32": 5, "f32": 6, "bool": 7, "str": 8, "arr": 9,
+       "u64": 10, "i64": 11, "f64": 12}
+_FMT = {0: "<B", 1: "<b", 2: "<H", 3: "<h", 4: "<I", 5: "<i", 6: "<f", 7: "<?", 10: "<Q", 11: "<q", 12: "<d"}
+
+
+def _s(b: str | bytes) -> bytes:
+    if isinstance(b, str):
+        b = b.encode("utf-8")
+    return struct.pack("<Q", len(b)) + b
+
+
+class GGUFWriter:
+    """Streaming GGUF v3 writer: metadata first, tensor payloads generated one at a time."""
+
+    def __init__(self, alignment: int = 32):
+        self.alignment = alignment
+        self.kv: list[bytes] = []
+        self.tensors: list[tuple[str, tuple[int, ...], int, object]] = []
+
+    def add(self, key: str, kind: str, value) -> None:
+        t = _GT[kind]
+        if kind == "str":
+            payload = _s(value)
+        else:
+            payload = struct.pack(_FMT[t], value)
+        self.kv.append(_s(key) + struct.pack("<I", t) + payload)
+
+    def add_array(self, key: str, kind: str, values) -> None:
+        et = _GT[kind]
+        if kind == "str":
+            body = b"".join(_s(v) for v in values)
+        else:
+            body = np.asarray(values).astype(np.dtype(_FMT[et][1:]).newbyteorder("<")).tobytes()
+        self.kv.append(_s(key) + struct.pack("<I", 9) + struct.pack("<IQ", et, len(values)) + body)
+
+    def add_tensor(self, name: str, ne: tuple[int, ...], t: int, data) -> None:
+        """data: bytes-like / uint8 ndarray, or a zero-arg callable returning one (lazy)."""
+        self.tensors.append((name, tuple(int(x) for x in ne), t, data))
+
+    def write(self, path: str) -> int:
+        al = self.alignment
+        sizes, offs, off = [], [], 0
+        for _, ne, t, _ in self.tensors:
+            n = int(np.prod(ne))
+            sz = row_bytes(t, ne[0]) * (n // ne[0])
+            sizes.append(sz)
+            offs.append(off)
+            off += (sz + al - 1) // al * al
+        with open(path, "wb") as f:
+            f.write(struct.pack("<IIQQ", 0x46554747, 3, len(self.tensors), len(self.kv)))
+            for kv in self.kv:
+                f.write(kv)
+            for (name, ne, t, _), o in zip(self.tensors, offs):
+                f.write(_s(name) + struct.pack("<I", len(ne)) + b"".join(struct.pack("<Q", x) for x in ne))
+                f.write(struct.pack("<IQ", t, o))
+            pos = f.tell()
+            f.write(b"\0" * ((-pos) % al))
+            for (name, ne, t, data), sz in zip(self.tensors, sizes):
+                buf = data() if callable(data) else data
+                buf = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
+                assert buf.size == sz, (name, buf.size, sz)
+                f.write(memoryview(buf))
+                f.write(b"\0" * ((-sz) % al))
+            return f.tell()
+
+
+# ---------------------------------------------------------------- model configs
+@dataclass
+class LlamaConfig:
+    name: str
+    n_embd: int
+    n_layer: int
+    n_head: int
+    n_head_kv: int
+    n_ff: int
+    n_vocab: int
+    rope_base: float = 10000.0
+    eps: float = 1e-5
+    n_ctx_train: int = 4096
+    n_expert: int = 0
+    n_expert_used: int = 0
+    big_model: bool = False          # 70B-class rule: attn_v Q4_K -> Q5_K on the non-Q6_K layers
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def head_dim(self) -> int:
+        return self.n_embd // self.n_head
+
+
+CONFIGS = {
+    # BASELINE.json configs (SURVEY.md §8a sizes)
+    "tinyllama-1.1b": LlamaConfig("TinyLlama-1.1B-Chat", 2048, 22, 32, 4, 5632, 32000, 10000.0, 1e-5, 2048),
+    "llama-2-7b": LlamaConfig("Llama-2-7B-Chat", 4096, 32, 32, 32, 11008, 32000, 10000.0, 1e-5, 4096),
+    "llama-3-8b": LlamaConfig("Llama-3-8B-Instruct", 4096, 32, 32, 8, 14336, 128256, 500000.0, 1e-5, 8192),
+    "mixtral-8x7b": LlamaConfig("Mixtral-8x7B-Instruct", 4096, 32, 32, 8, 14336, 32000, 1e6, 1e-5, 32768, 8, 2),
+    "llama-3-70b": LlamaConfig("Llama-3-70B-Instruct", 8192, 80, 64, 8, 28672, 128256, 500000.0, 1e-5, 8192,
+                               big_model=True),
+    # test-sized
+    "tiny": LlamaConfig("tiny-test", 256, 2, 4, 2, 512, 512, 10000.0, 1e-5, 512),
+    "tiny-gqa4": LlamaConfig("tiny-gqa4", 512, 3, 8, 2, 1024, 768, 500000.0, 1e-5, 1024),
+    "tiny-moe": LlamaConfig("tiny-moe", 256, 2, 4, 2, 512, 512, 1e6, 1e-5, 512, 8, 2),
+}
+
+FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17}
+
+
+def use_more_bits(i: int, n: int) -> bool:
+    return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
+
+
+def tensor_type(cfg: LlamaConfig, ftype: str, kind: str, il: int) -> int:
+    """ggml type of a 2-D weight per llama-quantize's `*_K_M` mix."""
+    if ftype == "f16":
+        return F16
+    if ftype == "q8_0":
+        return Q8_0
+    base = {"q4_k_m": Q4_K, "q5_k_m": Q5_K}[ftype]
+    if kind == "output":
+        return Q6_K
+    if kind in ("attn_v", "ffn_down") and use_more_bits(il, cfg.n_layer):
+        return Q6_K
+    if cfg.n_expert == 8 and kind in ("attn_k", "attn_v"):
+        return Q8_0
+    if cfg.big_model and kind == "attn_v" and base == Q4_K:
+        return Q5_K
+    return base
+
+
+def model_tensors(cfg: LlamaConfig, ftype: str):
+    """[(name, ne, type, fan_in)] in file order."""
+    E, F, V = cfg.n_embd, cfg.n_ff, cfg.n_vocab
+    kv = cfg.n_head_kv * cfg.head_dim
+    out = [("token_embd.weight", (E, V), tensor_type(cfg, ftype, "token_embd", 0), None)]
+    for il in range(cfg.n_layer):
+        p = f"blk.{il}."
+        out.append((p + "attn_norm.weight", (E,), F32, None))
+        out.append((p + "attn_q.weight", (E, E), tensor_type(cfg, ftype, "attn_q", il), E))
+        out.append((p + "attn_k.weight", (E, kv), tensor_type(cfg, ftype, "attn_k", il), E))
+        out.append((p + "attn_v.weight", (E, kv), tensor_type(cfg, ftype, "attn_v", il), E))
+        out.append((p + "attn_output.weight", (E, E), tensor_type(cfg, ftype, "attn_output", il), E))
+        out.append((p + "ffn_norm.weight", (E,), F32, None))
+        if cfg.n_expert:
+            X = cfg.n_expert
+            out.append((p + "ffn_gate_inp.weight", (E, X), F32, E))
+            out.append((p + "ffn_gate_exps.weight", (E, F, X), tensor_type(cfg, ftype, "ffn_gate", il), E))
+            out.append((p + "ffn_down_exps.weight", (F, E, X), tensor_type(cfg, ftype, "ffn_down", il), F))
+            out.append((p + "ffn_up_exps.weight", (E, F, X), tensor_type(cfg, ftype, "ffn_up", il), E))
+        else:
+            out.append((p + "ffn_gate.weight", (E, F), tensor_type(cfg, ftype, "ffn_gate", il), E))
+            out.append((p + "ffn_down.weight", (F, E), tensor_type(cfg, ftype, "ffn_down", il), F))
+            out.append((p + "ffn_up.weight", (E, F), tensor_type(cfg, ftype, "ffn_up", il), E))
+    out.append(("output_norm.weight", (E,), F32, None))
+    out.append(("output.weight", (E, V), tensor_type(cfg, ftype, "output", 0), E))
+    return out
+
+
+def weight_bytes_per_token(cfg: LlamaConfig, ftype: str) -> int:
+    """Algorithmic weight bytes one decoded token reads: every tensor once, one
+    token_embd row, and n_expert_used of n_expert experts."""
+    total = 0
+    for name, ne, t, _ in model_tensors(cfg, ftype):
+        n = int(np.prod(ne))
+        b = row_bytes(t, ne[0]) * (n // ne[0])
+        if name == "token_embd.weight":
+            b = row_bytes(t, ne[0])
+        elif "_exps." in name:
+            b = b // cfg.n_expert * cfg.n_expert_used
+        total += b
+    return total
+
+
+def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_m", seed: int = 0xC0FFEE,
+                          with_vocab: bool = True, gain: float = 1.0) -> int:
+    """Write a synthetic llama-arch GGUF; returns the file size in bytes."""
+    if isinstance(cfg, str):
+        cfg = CONFIGS[cfg]
+    w = GGUFWriter()
+    a = "llama"
+    w.add("general.architecture", "str", a)
+    w.add("general.name", "str", cfg.name + " (synthetic)")
+    w.add("general.file_type", "u32", FTYPE_ID[ftype])
+    w.add(f"{a}.context_length", "u32", cfg.n_ctx_train)
+    w.add(f"{a}.embedding_length", "u32", cfg.n_embd)
+    w.add(f"{a}.block_count", "u32", cfg.n_layer)
+    w.add(f"{a}.feed_forward_length", "u32", cfg.n_ff)
+    w.add(f"{a}.attention.head_count", "u32", cfg.n_head)
+    w.add(f"{a}.attention.head_count_kv", "u32", cfg.n_head_kv)
+    w.add(f"{a}.attention.layer_norm_rms_epsilon", "f32", cfg.eps)
+    w.add(f"{a}.rope.dimension_count", "u32", cfg.head_dim)
+    w.add(f"{a}.rope.freq_base", "f32", cfg.rope_base)
+    w.add(f"{a}.vocab_size", "u32", cfg.n_vocab)
+    if cfg.n_expert:
+        w.add(f"{a}.expert_count", "u32", cfg.n_expert)
+        w.add(f"{a}.expert_used_count", "u32", cfg.n_expert_used)
+    if with_vocab:
+        # synthetic SentencePiece-style vocab: <unk>,<s>,</s>, 256 byte tokens, then printable pieces
+        toks, scores, types = ["<unk>", "<s>", "</s>"], [0.0, 0.0, 0.0], [2, 3, 3]
+        for b in range(256):
+            toks.append(f"<0x{b:02X}>")
+            scores.append(0.0)
+            types.append(6)
+        i = 0
+        alphabet = "abcdefghijklmnopqrstuvwxyz"
+        while len(toks) < cfg.n_vocab:
+            s, k = "", i
+            while True:
+                s = alphabet[k % 26] + s
+                k //= 26
+                if k == 0:
+                    break
+            toks.append(("▁" + s) if i % 2 == 0 else s)
+            scores.append(-float(len(toks)))
+            types.append(1)
+            i += 1
+        w.add("tokenizer.ggml.model", "str", "llama")
+        w.add_array("tokenizer.ggml.tokens", "str", toks[: cfg.n_vocab])
+        w.add_array("tokenizer.ggml.scores", "f32", scores[: cfg.n_vocab])
+        w.add_array("tokenizer.ggml.token_type", "i32", types[: cfg.n_vocab])
+        w.add("tokenizer.ggml.bos_token_id", "u32", 1)
+        w.add("tokenizer.ggml.eos_token_id", "u32", 2)
+        w.add("tokenizer.ggml.unknown_token_id", "u32", 0)
+        w.add("tokenizer.ggml.add_bos_token", "bool", True)
+        w.add("tokenizer.ggml.add_eos_token", "bool", False)
+
+    for idx, (name, ne, t, fan_in) in enumerate(model_tensors(cfg, ftype)):
+        n = int(np.prod(ne))
+
+        def gen(idx=idx, name=name, ne=ne, t=t, fan_in=fan_in, n=n):
+            rng = np.random.default_rng([seed, idx])
+            if len(ne) == 1:  # norm weights
+                return rng.uniform(0.9, 1.1, size=n).astype("<f4").view(np.uint8)
+            if name == "token_embd.weight":
+                return random_blocks(rng, t, n, 1.0)
+            return random_blocks(rng, t, n, gain / np.sqrt(fan_in))
+
+        w.add_tensor(name, ne, t, gen)
+    return w.write(path)
