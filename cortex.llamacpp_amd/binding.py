@@ -1,0 +1,351 @@
+"""ctypes binding of include/mi355_llama.h (same names, same argument meaning)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
+
+
+class MI355Error(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "lib", "libmi355_llama.so")
+
+
+class ModelParams(C.Structure):
+    _fields_ = [("n_gpu_layers", C.c_int32), ("main_gpu", C.c_int32), ("use_mmap", C.c_int32), ("use_mlock", C.c_int32),
+                ("tp_rank", C.c_int32), ("tp_size", C.c_int32)]
+
+
+class ContextParams(C.Structure):
+    _fields_ = [("n_ctx", C.c_uint32), ("n_batch", C.c_uint32), ("n_ubatch", C.c_uint32), ("n_seq_max", C.c_uint32),
+                ("type_k", C.c_int32), ("type_v", C.c_int32), ("flash_attn", C.c_int32), ("embeddings", C.c_int32),
+                ("use_graphs", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_tokens", C.c_int32), ("token", C.POINTER(C.c_int32)), ("embd", C.POINTER(C.c_float)),
+                ("pos", C.POINTER(C.c_int32)), ("n_seq_id", C.POINTER(C.c_int32)),
+                ("seq_id", C.POINTER(C.POINTER(C.c_int32))), ("logits", C.POINTER(C.c_int8))]
+
+
+# every symbol include/mi355_llama.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u32, _u64, _f32, _sz, _cp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t, C.c_char_p
+SYMBOLS = {
+    "mi355_backend_init": (C.c_int, []),
+    "mi355_backend_free": (None, []),
+    "mi355_device_count": (C.c_int, []),
+    "mi355_last_error": (_cp, []),
+    "mi355_time_us": (_i64, []),
+    "mi355_print_system_info": (_cp, []),
+    "mi355_model_default_params": (ModelParams, []),
+    "mi355_model_load_from_file": (_vp, [_cp, ModelParams]),
+    "mi355_model_free": (None, [_vp]),
+    "mi355_model_n_vocab": (_i32, [_vp]),
+    "mi355_model_n_embd": (_i32, [_vp]),
+    "mi355_model_n_layer": (_i32, [_vp]),
+    "mi355_model_n_head": (_i32, [_vp]),
+    "mi355_model_n_head_kv": (_i32, [_vp]),
+    "mi355_model_n_ctx_train": (_i32, [_vp]),
+    "mi355_model_size": (_u64, [_vp]),
+    "mi355_model_cpu_buffer": (_u64, [_vp]),
+    "mi355_model_other_buffer": (_u64, [_vp]),
+    "mi355_model_bytes_per_token": (_u64, [_vp]),
+    "mi355_model_desc": (_cp, [_vp]),
+    "mi355_model_meta_str": (C.c_int, [_vp, _cp, _cp, _sz]),
+    "mi355_context_default_params": (ContextParams, []),
+    "mi355_context_new": (_vp, [_vp, ContextParams]),
+    "mi355_context_free": (None, [_vp]),
+    "mi355_n_ctx": (_u32, [_vp]),
+    "mi355_n_batch": (_u32, [_vp]),
+    "mi355_n_ubatch": (_u32, [_vp]),
+    "mi355_context_device_bytes": (_u64, [_vp]),
+    "mi355_batch_init": (Batch, [_i32, _i32, _i32]),
+    "mi355_batch_free": (None, [Batch]),
+    "mi355_decode": (_i32, [_vp, Batch]),
+    "mi355_get_logits_ith": (C.POINTER(C.c_float), [_vp, _i32]),
+    "mi355_get_argmax_ith": (_i32, [_vp, _i32]),
+    "mi355_set_embeddings": (None, [_vp, _i32]),
+    "mi355_synchronize": (None, [_vp]),
+    "mi355_kv_cache_clear": (None, [_vp]),
+    "mi355_kv_cache_seq_rm": (_i32, [_vp, _i32, _i32, _i32]),
+    "mi355_kv_cache_seq_cp": (None, [_vp, _i32, _i32, _i32, _i32]),
+    "mi355_kv_cache_seq_add": (None, [_vp, _i32, _i32, _i32, _i32]),
+    "mi355_kv_cache_used_cells": (_i32, [_vp]),
+    "mi355_debug_enable_taps": (None, [_vp, _i32]),
+    "mi355_debug_layer_out": (_i32, [_vp, _i32, _vp, _sz]),
+    "mi355_op_quantize_act": (C.c_int, [_i32, _vp, _i64, _i64, _vp]),
+    "mi355_op_mul_mat": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "mi355_op_rms_norm_mul": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
+    "mi355_op_rope": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _i32]),
+    "mi355_op_get_rows": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "mi355_op_swiglu": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mi355_op_soft_max": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
+    "mi355_op_flash_attn": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp]),
+    "mi355_bench_hbm_read": (C.c_double, [_sz, C.c_int]),
+    "mi355_profile_last_decode": (_i32, [_vp, C.POINTER(_cp), C.POINTER(_f32), _i32]),
+    "mi355_profile_enable": (None, [_vp, _i32]),
+    "mi355_bench_weight_sweep": (C.c_double, [_vp, C.c_int, C.POINTER(_u64)]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen the native library and type every exported entry point.  Raises if it is missing:
+    there is no Python / CPU fallback for the compute path."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise MI355Error(f"{p} not found: build it with `python cortex.llamacpp_amd/build.py` (hipcc, gfx950)")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _err(lib) -> str:
+    return (lib.mi355_last_error() or b"").decode("utf-8", "replace")
+
+
+class Backend:
+    """mi355_backend_init / per-op entry points."""
+
+    def __init__(self):
+        self.lib = load_library()
+        rc = self.lib.mi355_backend_init()
+        if rc != 0:
+            raise MI355Error(f"mi355_backend_init failed ({rc}): {_err(self.lib)}")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MI355Error(f"{what} failed ({rc}): {_err(self.lib)}")
+
+    def system_info(self) -> str:
+        return self.lib.mi355_print_system_info().decode()
+
+    def quantize_act(self, act_type: int, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        rows, n = (1, x.size) if x.ndim == 1 else x.shape
+        bb = 292 * (n // 256) if act_type == Q8_K else 34 * (n // 32)
+        out = np.zeros(rows * bb, np.uint8)
+        self._chk(self.lib.mi355_op_quantize_act(act_type, _ptr(x), n, rows, _ptr(out)), "op_quantize_act")
+        return out.reshape(rows, bb)
+
+    def mul_mat(self, t: int, W: np.ndarray, N: int, K: int, x: np.ndarray, want_ints: bool = False):
+        W = np.ascontiguousarray(W.view(np.uint8).reshape(-1))
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, K)
+        T = x.shape[0]
+        y = np.zeros((T, N), np.float32)
+        isum = msum = None
+        if want_ints:
+            nblk = K // 32 if t == Q8_0 else K // 256
+            isum = np.zeros((T, N, nblk), np.int32)
+            msum = np.zeros((T, N, nblk), np.int32)
+        self._chk(self.lib.mi355_op_mul_mat(t, _ptr(W), N, K, _ptr(x), T, _ptr(y), _ptr(isum), _ptr(msum)), "op_mul_mat")
+        return (y, isum, msum) if want_ints else y
+
+    def rms_norm_mul(self, x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        T, n = (1, x.size) if x.ndim == 1 else x.shape
+        y = np.zeros_like(x)
+        self._chk(self.lib.mi355_op_rms_norm_mul(_ptr(x), _ptr(w), n, T, eps, _ptr(y)), "op_rms_norm_mul")
+        return y
+
+    def rope(self, x: np.ndarray, n_head: int, head_dim: int, pos, base: float, neox: bool = False, n_rot=None,
+             freq_scale: float = 1.0, freq_factors=None) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, np.int32).reshape(-1)
+        y = np.array(x, np.float32, copy=True).reshape(pos.size, n_head * head_dim)
+        ff = None if freq_factors is None else np.ascontiguousarray(freq_factors, np.float32)
+        self._chk(self.lib.mi355_op_rope(_ptr(y), n_head, head_dim, n_rot or head_dim, _ptr(pos), pos.size, base, freq_scale,
+                                         _ptr(ff), int(neox)), "op_rope")
+        return y.reshape(pos.size, n_head, head_dim)
+
+    def get_rows(self, t: int, table: np.ndarray, K: int, n_rows: int, ids) -> np.ndarray:
+        table = np.ascontiguousarray(table.view(np.uint8).reshape(-1))
+        ids = np.ascontiguousarray(ids, np.int32)
+        out = np.zeros((ids.size, K), np.float32)
+        self._chk(self.lib.mi355_op_get_rows(t, _ptr(table), K, n_rows, _ptr(ids), ids.size, _ptr(out)), "op_get_rows")
+        return out
+
+    def swiglu(self, g: np.ndarray, u: np.ndarray) -> np.ndarray:
+        g = np.ascontiguousarray(g, np.float32)
+        u = np.ascontiguousarray(u, np.float32)
+        y = np.zeros_like(g)
+        self._chk(self.lib.mi355_op_swiglu(_ptr(g), _ptr(u), g.size, _ptr(y)), "op_swiglu")
+        return y
+
+    def soft_max(self, x: np.ndarray, mask, scale: float) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        rows, n = (1, x.size) if x.ndim == 1 else x.shape
+        m = None if mask is None else np.ascontiguousarray(mask, np.float32)
+        y = np.zeros_like(x)
+        self._chk(self.lib.mi355_op_soft_max(_ptr(x), _ptr(m), n, rows, scale, _ptr(y)), "op_soft_max")
+        return y
+
+    def flash_attn(self, q: np.ndarray, n_head: int, n_head_kv: int, hd: int, type_k: int, k_rows: np.ndarray, type_v: int,
+                   v_rows: np.ndarray, cell_pos, q_pos, scale: float) -> np.ndarray:
+        q = np.ascontiguousarray(q, np.float32)
+        q_pos = np.ascontiguousarray(q_pos, np.int32).reshape(-1)
+        cell_pos = np.ascontiguousarray(cell_pos, np.int32)
+        k_rows = np.ascontiguousarray(k_rows.view(np.uint8))
+        v_rows = np.ascontiguousarray(v_rows.view(np.uint8))
+        out = np.zeros((q_pos.size, n_head, hd), np.float32)
+        self._chk(self.lib.mi355_op_flash_attn(_ptr(q), q_pos.size, n_head, n_head_kv, hd, type_k, _ptr(k_rows), type_v,
+                                               _ptr(v_rows), cell_pos.size, _ptr(cell_pos), _ptr(q_pos), scale, _ptr(out)),
+                  "op_flash_attn")
+        return out
+
+    def hbm_read_gbps(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
+        return float(self.lib.mi355_bench_hbm_read(nbytes, iters))
+
+
+class Model:
+    def __init__(self, path: str, n_gpu_layers: int = 300, main_gpu: int = 0):
+        self.lib = load_library()
+        mp = self.lib.mi355_model_default_params()
+        mp.n_gpu_layers = n_gpu_layers
+        mp.main_gpu = main_gpu
+        self.h = self.lib.mi355_model_load_from_file(path.encode(), mp)
+        if not self.h:
+            raise MI355Error(f"mi355_model_load_from_file({path}) failed: {_err(self.lib)}")
+        L = self.lib
+        self.n_vocab = L.mi355_model_n_vocab(self.h)
+        self.n_embd = L.mi355_model_n_embd(self.h)
+        self.n_layer = L.mi355_model_n_layer(self.h)
+        self.n_head = L.mi355_model_n_head(self.h)
+        self.n_head_kv = L.mi355_model_n_head_kv(self.h)
+        self.bytes_per_token = L.mi355_model_bytes_per_token(self.h)
+        self.size = L.mi355_model_size(self.h)
+        self.vram = L.mi355_model_other_buffer(self.h)
+        self.ram = L.mi355_model_cpu_buffer(self.h)
+        self.desc = L.mi355_model_desc(self.h).decode()
+
+    def meta(self, key: str):
+        buf = C.create_string_buffer(512)
+        if self.lib.mi355_model_meta_str(self.h, key.encode(), buf, 512):
+            return buf.value.decode()
+        return None
+
+    def close(self):
+        if self.h:
+            self.lib.mi355_model_free(self.h)
+            self.h = None
+
+
+class Context:
+    def __init__(self, model: Model, n_ctx: int = 512, n_batch: int = 2048, n_ubatch: int = 512, n_seq_max: int = 1,
+                 type_k: int = F16, type_v: int = F16, flash_attn: bool = True, use_graphs: bool = True):
+        self.lib = model.lib
+        self.model = model
+        cp = self.lib.mi355_context_default_params()
+        cp.n_ctx, cp.n_batch, cp.n_ubatch, cp.n_seq_max = n_ctx, n_batch, n_ubatch, n_seq_max
+        cp.type_k, cp.type_v, cp.flash_attn, cp.use_graphs = type_k, type_v, int(flash_attn), int(use_graphs)
+        self.h = self.lib.mi355_context_new(model.h, cp)
+        if not self.h:
+            raise MI355Error(f"mi355_context_new failed: {_err(self.lib)}")
+        self.n_ctx = n_ctx
+        self._batch_cap = 0
+        self._b = None
+
+    def _batch(self, n: int) -> Batch:
+        if n > self._batch_cap:
+            if self._b is not None:
+                self.lib.mi355_batch_free(self._b)
+            self._batch_cap = max(n, 64)
+            self._b = self.lib.mi355_batch_init(self._batch_cap, 0, 1)
+        return self._b
+
+    def decode(self, tokens, pos, seq=None, logits=None) -> int:
+        """llama_decode on one batch; logits=None flags only the last token."""
+        tokens = np.asarray(tokens, np.int32).reshape(-1)
+        pos = np.asarray(pos, np.int32).reshape(-1)
+        n = tokens.size
+        b = self._batch(n)
+        b.n_tokens = n
+        C.memmove(b.token, tokens.ctypes.data, 4 * n)
+        C.memmove(b.pos, pos.ctypes.data, 4 * n)
+        for i in range(n):
+            b.n_seq_id[i] = 1
+            b.seq_id[i][0] = 0 if seq is None else int(seq[i] if np.ndim(seq) else seq)
+            b.logits[i] = (1 if i == n - 1 else 0) if logits is None else int(bool(logits[i]))
+        rc = self.lib.mi355_decode(self.h, b)
+        if rc < 0:
+            raise MI355Error(f"mi355_decode failed ({rc}): {_err(self.lib)}")
+        return rc
+
+    def logits(self, i: int = -1) -> np.ndarray:
+        p = self.lib.mi355_get_logits_ith(self.h, i)
+        if not p:
+            raise MI355Error("no logits for that batch row")
+        return np.ctypeslib.as_array(p, shape=(self.model.n_vocab,)).copy()
+
+    def argmax(self, i: int = -1) -> int:
+        return int(self.lib.mi355_get_argmax_ith(self.h, i))
+
+    def synchronize(self):
+        self.lib.mi355_synchronize(self.h)
+
+    def kv_clear(self):
+        self.lib.mi355_kv_cache_clear(self.h)
+
+    def kv_seq_rm(self, seq, p0, p1) -> bool:
+        return bool(self.lib.mi355_kv_cache_seq_rm(self.h, seq, p0, p1))
+
+    def kv_seq_cp(self, s, d, p0, p1):
+        self.lib.mi355_kv_cache_seq_cp(self.h, s, d, p0, p1)
+
+    def kv_seq_add(self, seq, p0, p1, delta):
+        self.lib.mi355_kv_cache_seq_add(self.h, seq, p0, p1, delta)
+
+    def kv_used(self) -> int:
+        return int(self.lib.mi355_kv_cache_used_cells(self.h))
+
+    def enable_taps(self, on: bool = True):
+        self.lib.mi355_debug_enable_taps(self.h, int(on))
+
+    def layer_out(self, il: int, n_tokens: int) -> np.ndarray:
+        out = np.zeros((n_tokens, self.model.n_embd), np.float32)
+        n = self.lib.mi355_debug_layer_out(self.h, il, _ptr(out), out.size)
+        if n < 0:
+            raise MI355Error("debug taps not enabled")
+        return out[:n]
+
+    def profile(self, on: bool = True):
+        self.lib.mi355_profile_enable(self.h, int(on))
+
+    def last_profile(self) -> dict:
+        names = (_cp * 64)()
+        us = (_f32 * 64)()
+        n = self.lib.mi355_profile_last_decode(self.h, names, us, 64)
+        return {names[i].decode(): float(us[i]) for i in range(n)}
+
+    def weight_sweep_us(self, iters: int = 5):
+        b = _u64(0)
+        us = self.lib.mi355_bench_weight_sweep(self.h, iters, C.byref(b))
+        return float(us), int(b.value)
+
+    def close(self):
+        if self._b is not None:
+            self.lib.mi355_batch_free(self._b)
+            self._b = None
+        if self.h:
+            self.lib.mi355_context_free(self.h)
+            self.h = None

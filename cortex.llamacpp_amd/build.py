@@ -1,0 +1,70 @@
+"""Builds the native library (HIP kernels + C++ host runtime + C-ABI) for gfx950 with hipcc.
+
+    python cortex.llamacpp_amd/build.py            # -> cortex.llamacpp_amd/lib/libmi355_llama.so
+
+hipcc cross-compiles without a GPU.  The .so is kept in-tree (git-ignored) so it travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [
+    "csrc/mmvq.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/attn.hip",
+    "host/gguf.cc", "host/runtime.cc", "csrc/c_api.cc",
+]
+HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "host/gguf.h", "host/runtime.h", "../include/mi355_llama.h"]
+LIB = os.path.join(HERE, "lib", "libmi355_llama.so")
+# -ffp-contract=off: the CPU restatement this backend is checked against does not fuse mul+add
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hdr_m = max(os.path.getmtime(os.path.join(HERE, h)) for h in HDRS)
+    hipcc = _hipcc()
+    jobs = []
+    for s in SRC:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(objdir, s.replace("/", "_") + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(cc, jobs):
+            if verbose and warn:
+                print(warn)
+    objs = [os.path.join(objdir, s.replace("/", "_") + ".o") for s in SRC]
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

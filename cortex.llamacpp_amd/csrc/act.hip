@@ -1,0 +1,207 @@
+// act.hip — activation-side kernels: RMSNorm(+weight) fused with Q8_K / Q8_0 quantisation, plain
+// quantisation, SwiGLU, residual add, row softmax.
+//
+// Stand in for ggml_rms_norm + ggml_mul, quantize_row_q8_K / quantize_row_q8_0 (the CPU backend's
+// activation formats), ggml_silu*ggml_mul, ggml_add, ggml_soft_max_ext — all
+// reached from the reference through llama_decode (src/llama_server_context.cc:1635); rows a9, a12, a14,
+// a17 of SURVEY.md §8a.  Quantised codes and scales are bit-identical to the CPU restatement; only the
+// f64 sum-of-squares is tree-ordered instead of sequential.
+#include "kernels.h"
+
+namespace mi355 {
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// One workgroup per row.  do_norm: y = (x * rsqrt(mean(x^2)+eps)) * w, else y = x.
+__global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         int n, float eps, int do_norm, float *__restrict__ yf,
+                                                         ActQuant q, int want_q8k, int want_q80) {
+    __shared__ double red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *xr = x + (size_t)row * n;
+    float scale = 1.0f;
+    if (do_norm) {
+        double s = 0.0;
+        for (int i = tid * 4; i < n; i += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+            s += (double)(v.x * v.x); s += (double)(v.y * v.y); s += (double)(v.z * v.z); s += (double)(v.w * v.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const double tot = red[0] + red[1] + red[2] + red[3];
+        const float mean = (float)(tot / (double)n);
+        scale = 1.0f / sqrtf(mean + eps);
+    }
+    const int nblk = n >> 8;
+    for (int b = wave; b < nblk; b += 4) {
+        const int e0 = b * 256 + lane * 4;
+        float4 v = *reinterpret_cast<const float4 *>(xr + e0);
+        if (do_norm) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + e0);
+            v.x = (v.x * scale) * ww.x; v.y = (v.y * scale) * ww.y; v.z = (v.z * scale) * ww.z; v.w = (v.w * scale) * ww.w;
+        }
+        if (yf) *reinterpret_cast<float4 *>(yf + (size_t)row * n + e0) = v;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if (want_q8k) {
+            // first element (lowest index) with the largest magnitude decides sign and scale
+            unsigned long long key = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(fabsf(vv[i])) << 32) |
+                                             (unsigned long long)(0xffffffffu - (unsigned)(lane * 4 + i));
+                key = k > key ? k : key;
+            }
+            key = wave_max_u64(key);
+            const float amax = __uint_as_float((unsigned)(key >> 32));
+            const int imax = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            const int isel = imax & 3;
+            const float vsrc = isel == 0 ? vv[0] : isel == 1 ? vv[1] : isel == 2 ? vv[2] : vv[3];
+            const float vmax = __shfl(vsrc, imax >> 2, 64);
+            int qi[4] = {0, 0, 0, 0};
+            float dq = 0.0f;
+            if (amax != 0.0f) {
+                const float iscale = -127.0f / vmax;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int t = __float2int_rn(iscale * vv[i]);
+                    qi[i] = t > 127 ? 127 : t;
+                }
+                dq = 1.0f / iscale;
+            }
+            const uint32_t packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) |
+                                    ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+            *reinterpret_cast<uint32_t *>(q.qs + (size_t)row * n + e0) = packed;
+            int bs = qi[0] + qi[1] + qi[2] + qi[3];
+            bs += __shfl_xor(bs, 1, 64);
+            bs += __shfl_xor(bs, 2, 64);
+            if ((lane & 3) == 0) q.bsums[(size_t)row * (n >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+            if (lane == 0) q.d[(size_t)row * nblk + b] = dq;
+        }
+        if (want_q80) {
+            float am = fmaxf(fmaxf(fabsf(vv[0]), fabsf(vv[1])), fmaxf(fabsf(vv[2]), fabsf(vv[3])));
+            am = fmaxf(am, __shfl_xor(am, 1, 64));
+            am = fmaxf(am, __shfl_xor(am, 2, 64));
+            am = fmaxf(am, __shfl_xor(am, 4, 64));
+            const float d = am / 127.0f;
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            int qi[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) qi[i] = (int)roundf(vv[i] * id);
+            const uint32_t packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) |
+                                    ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+            *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)row * n + e0) = packed;
+            if ((lane & 7) == 0) q.d0[(size_t)row * (n >> 5) + b * 8 + (lane >> 3)] = f2h(d);
+        }
+    }
+}
+
+hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, float eps, float *y_f32,
+                                const ActQuant *q, bool want_q8k, bool want_q80, hipStream_t st) {
+    ActQuant qq;
+    if (q) qq = *q;
+    hipLaunchKernelGGL(norm_quant_kernel, dim3(T), dim3(256), 0, st, x, w, n, eps, 1, y_f32, qq,
+                       (int)(q && want_q8k), (int)(q && want_q80));
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st) {
+    hipLaunchKernelGGL(norm_quant_kernel, dim3(T), dim3(256), 0, st, x, (const float *)nullptr, n, 0.0f, 0,
+                       (float *)nullptr, q, (int)want_q8k, (int)want_q80);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- elementwise
+__global__ void swiglu_kernel(const float *g, const float *u, float *y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float a = g[i];
+        y[i] = (a / (1.0f + expf(-a))) * u[i];
+    }
+}
+hipError_t launch_swiglu(const float *g, const float *u, float *y, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, u, y, n);
+    return hipGetLastError();
+}
+__global__ void add_kernel(const float *a, const float *b, float *y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+hipError_t launch_add(const float *a, const float *b, float *y, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, y, n);
+    return hipGetLastError();
+}
+
+// row softmax: y = softmax(x*scale + mask)   (ggml_soft_max_ext, max_bias = 0)
+__global__ __launch_bounds__(256) void soft_max_kernel(const float *x, const float *mask, float *y, int n, float scale) {
+    __shared__ float redf[4];
+    __shared__ double redd[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *xr = x + (size_t)row * n;
+    const float *mr = mask ? mask + (size_t)row * n : nullptr;
+    float *yr = y + (size_t)row * n;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, xr[i] * scale + (mr ? mr[i] : 0.0f));
+    mx = wave_max(mx);
+    if (lane == 0) redf[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const float e = expf((xr[i] * scale + (mr ? mr[i] : 0.0f)) - mx);
+        yr[i] = e;
+        s += (double)e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) redd[wave] = s;
+    __syncthreads();
+    const float inv = (float)(1.0 / (redd[0] + redd[1] + redd[2] + redd[3]));
+    for (int i = tid; i < n; i += 256) yr[i] *= inv;
+}
+hipError_t launch_soft_max(const float *x, const float *mask, float *y, int n, int rows, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(soft_max_kernel, dim3(rows), dim3(256), 0, st, x, mask, y, n, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- planes -> ggml blocks (tests only)
+__global__ void pack_q8k_kernel(ActQuant q, int n, uint8_t *blocks) {
+    const int row = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;   // 256 threads
+    const int nblk = n >> 8;
+    uint8_t *dst = blocks + ((size_t)row * nblk + b) * 292;
+    if (tid == 0) *reinterpret_cast<float *>(dst) = q.d[(size_t)row * nblk + b];
+    dst[4 + tid] = (uint8_t)q.qs[(size_t)row * n + b * 256 + tid];
+    if (tid < 16) {
+        const int16_t v = q.bsums[(size_t)row * (n >> 4) + b * 16 + tid];
+        dst[260 + 2 * tid] = (uint8_t)(v & 0xff);
+        dst[261 + 2 * tid] = (uint8_t)((v >> 8) & 0xff);
+    }
+}
+hipError_t launch_pack_q8k_blocks(const ActQuant &q, int n, int T, uint8_t *blocks, hipStream_t st) {
+    hipLaunchKernelGGL(pack_q8k_kernel, dim3(n >> 8, T), dim3(256), 0, st, q, n, blocks);
+    return hipGetLastError();
+}
+__global__ void pack_q80_kernel(ActQuant q, int n, uint8_t *blocks) {
+    const int row = blockIdx.y, b = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;  // 256 threads = 8 blocks
+    const int nblk = n >> 5;
+    if (b >= nblk) return;
+    uint8_t *dst = blocks + ((size_t)row * nblk + b) * 34;
+    if (j == 0) {
+        const uint16_t d = q.d0[(size_t)row * nblk + b];
+        dst[0] = (uint8_t)(d & 0xff);
+        dst[1] = (uint8_t)(d >> 8);
+    }
+    dst[2 + j] = (uint8_t)q.qs0[(size_t)row * n + b * 32 + j];
+}
+hipError_t launch_pack_q80_blocks(const ActQuant &q, int n, int T, uint8_t *blocks, hipStream_t st) {
+    hipLaunchKernelGGL(pack_q80_kernel, dim3(((n >> 5) + 7) / 8, T), dim3(256), 0, st, q, n, blocks);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -1,0 +1,440 @@
+// attn.hip — RoPE + KV-cache store, flash attention over an f16 / q8_0 / q4_0 cache, K re-rotation.
+//
+// Stand in for ggml_rope_ext (mode NORM / NEOX), ggml_cpy f32->{f16,q8_0,q4_0} into the cache views,
+// ggml_flash_attn_ext (ggml-cpu flash_attn_ext_f16: Q converted to the K cache's vec_dot type, online
+// softmax, F32 accumulation) and the K-shift graph — SURVEY.md §8a rows a11, a13, a15, a4; reached from the
+// reference through llama_decode (src/llama_server_context.cc:1635) and llama_kv_cache_seq_add (:1290).
+//
+// Cache layout in HBM is head-major per layer: plane[g][cell][...] so that one kv-head's cells are a
+// contiguous stream; quantised caches keep int8/int4 codes and f16 block scales in separate planes
+// (same values as ggml block_q8_0 / block_q4_0, regrouped for 16-byte aligned coalesced loads).
+#include "kernels.h"
+
+namespace mi355 {
+
+// ------------------------------------------------------------------------------------------
+// cos/sin table of one position: theta_0 = pos, theta_{i+1} = theta_i * theta_scale, iterated in f32
+// exactly like ggml_rope_cache_init, so the angles match the CPU path bit for bit (cosf/sinf within libm ulp).
+__device__ __forceinline__ void rope_angle(int i_pair, int32_t pos, float theta_scale, float freq_scale, const float *ff,
+                                           float &c, float &s) {
+    float theta = (float)pos;
+    for (int k = 0; k < i_pair; k++) theta *= theta_scale;
+    const float f = ff ? ff[i_pair] : 1.0f;
+    const float th = freq_scale * (theta / f);
+    c = cosf(th);
+    s = sinf(th);
+}
+
+__device__ __forceinline__ void rope_heads_lds(float *buf, int n_head, int D, int n_rot, int neox, const float *cs, int tid, int nthr) {
+    const int half = n_rot >> 1;
+    for (int idx = tid; idx < n_head * half; idx += nthr) {
+        const int h = idx / half, i = idx - h * half;
+        float *p = buf + (size_t)h * D;
+        const int a = neox ? i : 2 * i, b = neox ? i + half : 2 * i + 1;
+        const float x0 = p[a], x1 = p[b], c = cs[2 * i], s = cs[2 * i + 1];
+        p[a] = x0 * c - x1 * s;
+        p[b] = x0 * s + x1 * c;
+    }
+}
+
+// store one row of n = G*D f32 values (LDS or global) into cache planes at `cell`; 32 consecutive threads per block
+__device__ __forceinline__ void store_row(const float *src, int G, int D, int type, uint8_t *plane, uint16_t *dplane,
+                                          int n_ctx, int cell, int tid, int nthr) {
+    const int n = G * D;
+    for (int e0 = 0; e0 < n; e0 += nthr) {
+        const int e = e0 + tid;
+        const bool ok = e < n;
+        const float v = ok ? src[e] : 0.0f;
+        const int g = ok ? e / D : 0, dd = ok ? e - g * D : 0;
+        const size_t rowi = (size_t)g * n_ctx + cell;
+        if (type == T_F16) {
+            if (ok) reinterpret_cast<uint16_t *>(plane)[rowi * D + dd] = f2h(v);
+        } else if (type == T_Q8_0) {
+            float am = fabsf(v);
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+            const float d = am / 127.0f;
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            if (ok) {
+                reinterpret_cast<int8_t *>(plane)[rowi * D + dd] = (int8_t)roundf(v * id);
+                if ((dd & 31) == 0) dplane[rowi * (D >> 5) + (dd >> 5)] = f2h(d);
+            }
+        } else {  // T_Q4_0: first element with the largest magnitude sets d = max / -8
+            unsigned long long key = ((unsigned long long)__float_as_uint(fabsf(v)) << 32) | (unsigned long long)(0xffffffffu - (unsigned)(dd & 31));
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const unsigned long long w = __shfl_xor(key, o, 64);
+                key = w > key ? w : key;
+            }
+            const int imax = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            const float vmax = __shfl(v, (threadIdx.x & 32) + imax, 64);
+            const float d = vmax / -8.0f;
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            int qv = (int)(int8_t)(v * id + 8.5f);
+            qv = qv > 15 ? 15 : qv;
+            const int other = __shfl_xor(qv, 16, 64);   // element j pairs with j+16 in one byte
+            if (ok) {
+                const int j = dd & 31;
+                if (j < 16) plane[rowi * (D >> 1) + (dd >> 5) * 16 + j] = (uint8_t)(qv | (other << 4));
+                if (j == 0) dplane[rowi * (D >> 5) + (dd >> 5)] = f2h(d);
+            }
+        }
+    }
+}
+
+// One workgroup per token: rope(q) in place; rope(k) -> cache; v -> cache.
+__global__ __launch_bounds__(256) void rope_kv_store_kernel(float *q, const float *k, const float *v, int n_head, int G, int D,
+                                                            const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra,
+                                                            float theta_scale, KVLayerView kv, int type_k, int type_v, int n_ctx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *cs = sm;                 // [n_rot]
+    float *kbuf = sm + ra.n_rot;    // [G*D]
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int32_t pos = tok_pos[t];
+    for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, pos, theta_scale, ra.freq_scale, ra.freq_factors, cs[2 * i], cs[2 * i + 1]);
+    if (k) for (int e = tid; e < G * D; e += 256) kbuf[e] = k[(size_t)t * G * D + e];
+    __syncthreads();
+    float *qr = q + (size_t)t * n_head * D;
+    rope_heads_lds(qr, n_head, D, ra.n_rot, ra.neox, cs, tid, 256);   // q rotated in global memory
+    if (k) {
+        rope_heads_lds(kbuf, G, D, ra.n_rot, ra.neox, cs, tid, 256);
+        __syncthreads();
+        const int cell = tok_cell[t];
+        store_row(kbuf, G, D, type_k, kv.k, kv.kd, n_ctx, cell, tid, 256);
+        store_row(v + (size_t)t * G * D, G, D, type_v, kv.v, kv.vd, n_ctx, cell, tid, 256);
+    }
+}
+
+hipError_t launch_rope_kv_store(float *q, const float *k, const float *v, int T, int n_head, int G, int D,
+                                const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra, KVLayerView kv,
+                                int type_k, int type_v, int n_ctx, hipStream_t st) {
+    const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
+    const size_t lds = sizeof(float) * ((size_t)ra.n_rot + (size_t)G * D);
+    hipLaunchKernelGGL(rope_kv_store_kernel, dim3(T), dim3(256), lds, st, q, k, v, n_head, G, D, tok_pos, tok_cell, ra,
+                       theta_scale, kv, type_k, type_v, n_ctx);
+    return hipGetLastError();
+}
+
+hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t *tok_pos, RopeArgs ra, hipStream_t st) {
+    KVLayerView kv{};
+    const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
+    const size_t lds = sizeof(float) * ((size_t)ra.n_rot);
+    hipLaunchKernelGGL(rope_kv_store_kernel, dim3(T), dim3(256), lds, st, x, (const float *)nullptr, (const float *)nullptr,
+                       n_head, 0, D, tok_pos, (const int32_t *)nullptr, ra, theta_scale, kv, T_F16, T_F16, 0);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K-shift: re-rotate every cached K row whose position moved by delta (dequantise, rope(delta), requantise)
+__global__ __launch_bounds__(256) void k_shift_kernel(KVLayerView kv, int type_k, int G, int D, int n_ctx, const int32_t *delta,
+                                                      RopeArgs ra, float theta_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    const int32_t dl = delta[cell];
+    if (dl == 0) return;
+    float *cs = sm, *kbuf = sm + ra.n_rot;
+    for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, dl, theta_scale, ra.freq_scale, ra.freq_factors, cs[2 * i], cs[2 * i + 1]);
+    for (int e = tid; e < G * D; e += 256) {
+        const int g = e / D, dd = e - g * D;
+        const size_t rowi = (size_t)g * n_ctx + cell;
+        float v;
+        if (type_k == T_F16) v = h2f(reinterpret_cast<const uint16_t *>(kv.k)[rowi * D + dd]);
+        else if (type_k == T_Q8_0) v = (float)reinterpret_cast<const int8_t *>(kv.k)[rowi * D + dd] * h2f(kv.kd[rowi * (D >> 5) + (dd >> 5)]);
+        else {
+            const int j = dd & 31;
+            const uint8_t b = kv.k[rowi * (D >> 1) + (dd >> 5) * 16 + (j & 15)];
+            v = (float)((j < 16 ? (b & 0x0f) : (b >> 4)) - 8) * h2f(kv.kd[rowi * (D >> 5) + (dd >> 5)]);
+        }
+        kbuf[e] = v;
+    }
+    __syncthreads();
+    rope_heads_lds(kbuf, G, D, ra.n_rot, ra.neox, cs, tid, 256);
+    __syncthreads();
+    store_row(kbuf, G, D, type_k, kv.k, kv.kd, n_ctx, cell, tid, 256);
+}
+hipError_t launch_k_shift(KVLayerView kv, int type_k, int G, int D, int n_ctx, const int32_t *delta, RopeArgs ra, hipStream_t st) {
+    const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
+    const size_t lds = sizeof(float) * ((size_t)ra.n_rot + (size_t)G * D);
+    hipLaunchKernelGGL(k_shift_kernel, dim3(n_ctx), dim3(256), lds, st, kv, type_k, G, D, n_ctx, delta, ra, theta_scale);
+    return hipGetLastError();
+}
+
+__global__ void kv_meta_set_kernel(int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell, const int32_t *tok_pos,
+                                   const uint64_t *tok_seqmask, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) {
+        cell_pos[tok_cell[t]] = tok_pos[t];
+        cell_seq[tok_cell[t]] = tok_seqmask[t];
+    }
+}
+hipError_t launch_kv_meta_set(int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell, const int32_t *tok_pos,
+                              const uint64_t *tok_seqmask, int T, hipStream_t st) {
+    hipLaunchKernelGGL(kv_meta_set_kernel, dim3((T + 255) / 256), dim3(256), 0, st, cell_pos, cell_seq, tok_cell, tok_pos, tok_seqmask, T);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Flash attention, split over the KV axis.  Workgroup = (kv head g, token t, split s), 4 waves.
+//   pass 1: scores of this split's cells for the R = H/G query heads that share g  -> LDS
+//           (8 lanes per cell for D = 128: every lane loads 16 codes = 16 contiguous bytes of the row)
+//   pass 2: m = max, p = exp(s - m), l = sum p   (whole split at once, so no in-loop rescale)
+//   pass 3: acc[r][d] += p[r][c] * V[c][d]; thread = (4 consecutive d, one of 8 cell groups)
+// then a combine kernel merges the splits with their (m, l).
+constexpr int ATT_MAX_CHUNK = 1024;   // cells per split (LDS: R * chunk floats)
+
+template <int D, int R>
+__global__ __launch_bounds__(256) void flash_attn_split_kernel(const AttnArgs a) {
+    constexpr int LPC = D / 16;          // lanes per cell in the score pass
+    constexpr int CPW = 64 / LPC;        // cells per wave iteration
+    constexpr int NB = D / 32;           // 32-element blocks per head row
+    constexpr int DQ = D / 4;            // threads along d in the PV pass
+    constexpr int NCG = 256 / DQ;        // cell groups in the PV pass
+    extern __shared__ __attribute__((aligned(16))) uint8_t smraw[];
+    float *S = reinterpret_cast<float *>(smraw);                         // [R][chunk]
+    const int g = blockIdx.x, t = blockIdx.y, sp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_kv = *a.n_kv_dev;
+    int chunk = (n_kv + a.splits - 1) / a.splits;
+    chunk = (chunk + 31) & ~31;
+    if (chunk > ATT_MAX_CHUNK) chunk = ATT_MAX_CHUNK;   // host guarantees splits * ATT_MAX_CHUNK >= n_kv
+    const int c_lo = sp * chunk;
+    int c_hi = c_lo + chunk;
+    if (c_hi > n_kv) c_hi = n_kv;
+    const int ncell = c_hi > c_lo ? c_hi - c_lo : 0;
+    float *qf = S + (size_t)R * chunk;                                   // [R][D]  q as the dot sees it (f16-rounded) / unused
+    int8_t *qc = reinterpret_cast<int8_t *>(qf + R * D);                 // [R][D]  q8_0 codes
+    float *qd = reinterpret_cast<float *>(qc + R * D);                   // [R][NB] q8_0 scales (f16-rounded)
+    int *qs16 = reinterpret_cast<int *>(qd + R * NB);                    // [R][D/16] sums of 16 codes (q4_0 K)
+    float *red = reinterpret_cast<float *>(qs16 + R * (D / 16));         // [R][2] m, l  then reduction scratch
+    float *accs = red + 2 * R;                                           // [NCG][R][D]
+
+    const int32_t tpos = a.tok_pos[t];
+    const int tseq = a.tok_seq[t];
+    const int H = a.H, n_ctx = a.n_ctx;
+    const float *qrow = a.q + ((size_t)t * H + (size_t)g * R) * D;
+
+    // ---- Q in the K cache's vec_dot type
+    if (a.type_k == T_F16) {
+        for (int e = tid; e < R * D; e += 256) qf[e] = h2f(f2h(qrow[e]));
+    } else {
+        for (int e0 = 0; e0 < R * D; e0 += 256) {       // R*D is a multiple of 32; 32 consecutive threads per block
+            const int e = e0 + tid;
+            const bool ok = e < R * D;
+            const float v = ok ? qrow[e] : 0.0f;
+            float am = fabsf(v);
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+            const float d = am / 127.0f;
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            const int qv = (int)roundf(v * id);
+            int s16 = qv;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s16 += __shfl_xor(s16, o, 64);
+            if (ok) {
+                qc[e] = (int8_t)qv;
+                if ((e & 31) == 0) qd[e >> 5] = h2f(f2h(d));
+                if ((e & 15) == 0) qs16[e >> 4] = s16;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: scores
+    const int sub = lane % LPC;            // which 16-element slice of the row
+    const int cw = lane / LPC;             // cell within the wave iteration
+    for (int c0 = wave * CPW; c0 < ncell; c0 += 4 * CPW) {
+        const int cl = c0 + cw;
+        const int c = c_lo + cl;
+        bool vis = cl < ncell;
+        if (vis) {
+            const int32_t cp = a.cell_pos[c];
+            vis = cp >= 0 && cp <= tpos && ((a.cell_seq[c] >> tseq) & 1ull);
+        }
+        float sc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) sc[r] = 0.0f;
+        const size_t rowi = (size_t)g * n_ctx + c;
+        if (vis) {
+            if (a.type_k == T_F16) {
+                const uint4 *kp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + sub * 16);
+                const uint4 k0 = kp[0], k1 = kp[1];
+                const uint32_t kw[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float *qq = qf + r * D + sub * 16;
+                    float s = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        s += h2f((uint16_t)(kw[i] & 0xffff)) * qq[2 * i];
+                        s += h2f((uint16_t)(kw[i] >> 16)) * qq[2 * i + 1];
+                    }
+                    sc[r] = s;
+                }
+            } else if (a.type_k == T_Q8_0) {
+                const uint4 kq = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * D + sub * 16);
+                const float dk = h2f(a.kv.kd[rowi * NB + (sub >> 1)]);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint4 qq = *reinterpret_cast<const uint4 *>(qc + r * D + sub * 16);
+                    int s = 0;
+                    s = dot4(kq.x, qq.x, s); s = dot4(kq.y, qq.y, s); s = dot4(kq.z, qq.z, s); s = dot4(kq.w, qq.w, s);
+                    // pair the two halves of the 32-block in integer, then scale: sumi(32) * (dk * dq)
+                    const int full = s + __shfl_xor(s, 1, 64);
+                    sc[r] = (sub & 1) ? 0.0f : (float)full * (dk * qd[r * NB + (sub >> 1)]);
+                }
+            } else {  // T_Q4_0: 16 bytes per 32-block; low nibbles = elements 0..15, high = 16..31
+                const uint4 kq = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * (D >> 1) + (sub >> 1) * 16);
+                const float dk = h2f(a.kv.kd[rowi * NB + (sub >> 1)]);
+                const int shift = (sub & 1) * 4;
+                const uint32_t n0 = (kq.x >> shift) & 0x0f0f0f0f, n1 = (kq.y >> shift) & 0x0f0f0f0f,
+                               n2 = (kq.z >> shift) & 0x0f0f0f0f, n3 = (kq.w >> shift) & 0x0f0f0f0f;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint4 qq = *reinterpret_cast<const uint4 *>(qc + r * D + sub * 16);
+                    int s = 0;
+                    s = dot4(n0, qq.x, s); s = dot4(n1, qq.y, s); s = dot4(n2, qq.z, s); s = dot4(n3, qq.w, s);
+                    s -= 8 * qs16[r * (D / 16) + sub];
+                    const int full = s + __shfl_xor(s, 1, 64);
+                    sc[r] = (sub & 1) ? 0.0f : (float)full * dk * qd[r * NB + (sub >> 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float s = sc[r];
+#pragma unroll
+            for (int o = 1; o < LPC; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (sub == 0 && cl < ncell) S[r * chunk + cl] = vis ? s * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: m, p, l per query head (wave w handles heads w, w+4, ...)
+    for (int r = wave; r < R; r += 4) {
+        float m = -INFINITY;
+        for (int c = lane; c < ncell; c += 64) m = fmaxf(m, S[r * chunk + c]);
+        m = wave_max(m);
+        float l = 0.0f;
+        for (int c = lane; c < ncell; c += 64) {
+            const float s = S[r * chunk + c];
+            const float p = (s == -INFINITY) ? 0.0f : expf(s - m);
+            S[r * chunk + c] = p;
+            l += p;
+        }
+        l = wave_sum(l);
+        if (lane == 0) { red[2 * r] = m; red[2 * r + 1] = l; }
+    }
+    __syncthreads();
+
+    // ---- pass 3: P.V
+    const int dq = tid % DQ, cg = tid / DQ;
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
+    for (int cl = cg; cl < ncell; cl += NCG) {
+        float p[R];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) { p[r] = S[r * chunk + cl]; any |= p[r] != 0.0f; }
+        if (!any) continue;
+        const size_t rowi = (size_t)g * n_ctx + (c_lo + cl);
+        float v4[4];
+        if (a.type_v == T_F16) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+            v4[0] = h2f((uint16_t)(w.x & 0xffff)); v4[1] = h2f((uint16_t)(w.x >> 16));
+            v4[2] = h2f((uint16_t)(w.y & 0xffff)); v4[3] = h2f((uint16_t)(w.y >> 16));
+        } else if (a.type_v == T_Q8_0) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4);
+            const float dv = h2f(a.kv.vd[rowi * NB + (dq >> 3)]);
+            v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
+            v4[2] = (float)(int8_t)((w >> 16) & 0xff) * dv; v4[3] = (float)(int8_t)(w >> 24) * dv;
+        } else {
+            const int i = (dq * 4) & 31;
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * (D >> 1) + (dq >> 3) * 16 + (i & 15));
+            const float dv = h2f(a.kv.vd[rowi * NB + (dq >> 3)]);
+            const uint32_t nb4 = (i < 16 ? w : (w >> 4)) & 0x0f0f0f0f;
+            v4[0] = (float)((int)(nb4 & 0xff) - 8) * dv; v4[1] = (float)((int)((nb4 >> 8) & 0xff) - 8) * dv;
+            v4[2] = (float)((int)((nb4 >> 16) & 0xff) - 8) * dv; v4[3] = (float)((int)(nb4 >> 24) - 8) * dv;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            acc[r][0] += v4[0] * p[r]; acc[r][1] += v4[1] * p[r]; acc[r][2] += v4[2] * p[r]; acc[r][3] += v4[3] * p[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        *reinterpret_cast<float4 *>(accs + ((size_t)cg * R + r) * D + dq * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    __syncthreads();
+    // partial record per (t, h, split): [D acc][m][l]
+    for (int e = tid; e < R * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NCG; j++) s += accs[((size_t)j * R + r) * D + d];
+        const int h = g * R + r;
+        float *dst = a.part + (((size_t)t * H + h) * a.splits + sp) * (D + 2);
+        dst[d] = s;
+        if (d == 0) { dst[D] = red[2 * r]; dst[D + 1] = red[2 * r + 1]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits) {
+    const int t = blockIdx.y;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < H * D; e += gridDim.x * 256) {
+        const int h = e / D, d = e - h * D;
+        const float *p = part + ((size_t)t * H + h) * splits * (D + 2);
+        float M = -INFINITY;
+        for (int s = 0; s < splits; s++) M = fmaxf(M, p[(size_t)s * (D + 2) + D]);
+        float num = 0.0f, den = 0.0f;
+        for (int s = 0; s < splits; s++) {
+            const float m = p[(size_t)s * (D + 2) + D];
+            if (m == -INFINITY) continue;
+            const float w = expf(m - M);
+            num += w * p[(size_t)s * (D + 2) + d];
+            den += w * p[(size_t)s * (D + 2) + D + 1];
+        }
+        out[(size_t)t * H * D + e] = num * (1.0f / den);
+    }
+}
+
+size_t flash_attn_workspace_floats(int T, int H, int D, int splits) { return (size_t)T * H * splits * (D + 2); }
+
+int flash_attn_pick_splits(int T, int G, int n_kv_max) {
+    int min_splits = (n_kv_max + ATT_MAX_CHUNK - 1) / ATT_MAX_CHUNK;
+    if (min_splits < 1) min_splits = 1;
+    // enough workgroups to cover the chip, at least 64 cells per split
+    int want = (num_cu() * 2) / (T * G > 0 ? T * G : 1);
+    int by_len = (n_kv_max + 63) / 64;
+    if (want > by_len) want = by_len;
+    if (want < min_splits) want = min_splits;
+    if (want < 1) want = 1;
+    return want;
+}
+
+template <int D, int R>
+static hipError_t launch_fa(const AttnArgs &a, hipStream_t st) {
+    int chunk = (a.n_kv_max + a.splits - 1) / a.splits;
+    chunk = (chunk + 31) & ~31;
+    if (chunk > ATT_MAX_CHUNK) chunk = ATT_MAX_CHUNK;
+    constexpr int DQ = D / 4, NCG = 256 / DQ;
+    const size_t lds = sizeof(float) * ((size_t)R * chunk + (size_t)R * D) + (size_t)R * D + sizeof(float) * R * (D / 32) +
+                       sizeof(int) * R * (D / 16) + sizeof(float) * 2 * R + sizeof(float) * (size_t)NCG * R * D;
+    hipLaunchKernelGGL((flash_attn_split_kernel<D, R>), dim3(a.G, a.T, a.splits), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
+    const int R = a.H / a.G;
+    hipError_t e = hipErrorInvalidValue;
+    if ((size_t)a.splits * ATT_MAX_CHUNK < (size_t)a.n_kv_max) return hipErrorInvalidValue;
+#define FA_CASE(DD, RR) if (a.D == DD && R == RR) e = launch_fa<DD, RR>(a, st);
+    FA_CASE(128, 1) FA_CASE(128, 2) FA_CASE(128, 4) FA_CASE(128, 8)
+    FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 4) FA_CASE(64, 8)
+#undef FA_CASE
+    if (e != hipSuccess) return e;
+    int bx = (a.H * a.D + 255) / 256;
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(bx, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

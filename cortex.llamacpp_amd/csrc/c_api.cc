@@ -1,0 +1,433 @@
+// c_api.cc — the C-ABI declared in include/mi355_llama.h, over host/runtime.{h,cc}.
+#include "../../include/mi355_llama.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../host/runtime.h"
+
+namespace mi355 {
+const std::string &last_error_string();
+}
+
+using namespace mi355;
+
+struct mi355_model { Model *m; };
+struct mi355_context {
+    Context *c;
+    std::vector<const char *> prof_names;
+};
+
+static thread_local std::string t_err;
+static bool g_backend_ok = false;
+
+static void fail(const std::string &s) { t_err = s; }
+
+extern "C" {
+
+int mi355_backend_init(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fail("no HIP device visible: this backend has no CPU fallback");
+        g_backend_ok = false;
+        return MI355_ERR_NO_DEVICE;
+    }
+    g_backend_ok = true;
+    return MI355_OK;
+}
+void mi355_backend_free(void) { g_backend_ok = false; }
+int mi355_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char *mi355_last_error(void) {
+    if (t_err.empty() && !last_error_string().empty()) return last_error_string().c_str();
+    return t_err.c_str();
+}
+int64_t mi355_time_us(void) {
+    using namespace std::chrono;
+    return duration_cast<microseconds>(steady_clock::now().time_since_epoch()).count();
+}
+const char *mi355_print_system_info(void) {
+    static std::string s;
+    int n = mi355_device_count();
+    s = "mi355-llama | HIP devices = " + std::to_string(n);
+    if (n > 0) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, 0) == hipSuccess)
+            s += std::string(" | ") + p.name + " | " + p.gcnArchName + " | CUs = " + std::to_string(p.multiProcessorCount) +
+                 " | HBM = " + std::to_string(p.totalGlobalMem >> 30) + " GiB";
+    }
+    return s.c_str();
+}
+
+mi355_model_params mi355_model_default_params(void) {
+    mi355_model_params p{};
+    p.n_gpu_layers = 300; p.main_gpu = 0; p.use_mmap = 1; p.use_mlock = 0; p.tp_rank = 0; p.tp_size = 1;
+    return p;
+}
+
+mi355_model *mi355_model_load_from_file(const char *path, mi355_model_params params) {
+    if (!path) { fail("null path"); return nullptr; }
+    if (!g_backend_ok && mi355_backend_init() != MI355_OK) return nullptr;
+    if (params.n_gpu_layers <= 0) { fail("ngl=0 requested: this backend is device-only (no CPU path)"); return nullptr; }
+    if (params.tp_size > 1) { fail("tp_size > 1 is not available in this build"); return nullptr; }
+    std::string err;
+    int status = 0;
+    Model *m = model_load(path, params.main_gpu, err, status);
+    if (!m) { fail(err); return nullptr; }
+    return new mi355_model{m};
+}
+void mi355_model_free(mi355_model *model) {
+    if (!model) return;
+    delete model->m;
+    delete model;
+}
+int32_t mi355_model_n_vocab(const mi355_model *m) { return m->m->hp.n_vocab; }
+int32_t mi355_model_n_embd(const mi355_model *m) { return m->m->hp.n_embd; }
+int32_t mi355_model_n_layer(const mi355_model *m) { return m->m->hp.n_layer; }
+int32_t mi355_model_n_head(const mi355_model *m) { return m->m->hp.n_head; }
+int32_t mi355_model_n_head_kv(const mi355_model *m) { return m->m->hp.n_head_kv; }
+int32_t mi355_model_n_ctx_train(const mi355_model *m) { return m->m->hp.n_ctx_train; }
+uint64_t mi355_model_size(const mi355_model *m) { return m->m->file_tensor_bytes; }
+uint64_t mi355_model_cpu_buffer(const mi355_model *m) { return m->m->host_bytes; }
+uint64_t mi355_model_other_buffer(const mi355_model *m) { return m->m->device_bytes; }
+uint64_t mi355_model_bytes_per_token(const mi355_model *m) { return m->m->bytes_per_token; }
+const char *mi355_model_desc(const mi355_model *m) { return m->m->desc.c_str(); }
+int mi355_model_meta_str(const mi355_model *m, const char *key, char *buf, size_t buf_size) {
+    if (!m || !key || !buf || !buf_size) return 0;
+    const GGUFValue *v = m->m->file->find(key);
+    if (!v || v->type == GV_ARR) return 0;
+    std::string s;
+    if (v->type == GV_STR) s = v->s;
+    else if (v->type == GV_F32 || v->type == GV_F64) { char t[64]; snprintf(t, sizeof t, "%g", v->f); s = t; }
+    else if (v->type == GV_BOOL) s = v->u ? "true" : "false";
+    else s = std::to_string((long long)(int64_t)v->u);
+    snprintf(buf, buf_size, "%s", s.c_str());
+    return 1;
+}
+
+mi355_context_params mi355_context_default_params(void) {
+    mi355_context_params p{};
+    p.n_ctx = 2048; p.n_batch = 2048; p.n_ubatch = 512; p.n_seq_max = 1;
+    p.type_k = MI355_TYPE_F16; p.type_v = MI355_TYPE_F16; p.flash_attn = 1; p.embeddings = 0; p.use_graphs = 1;
+    return p;
+}
+
+mi355_context *mi355_context_new(mi355_model *model, mi355_context_params params) {
+    if (!model) { fail("null model"); return nullptr; }
+    ContextParams cp;
+    cp.n_ctx = params.n_ctx; cp.n_batch = params.n_batch; cp.n_ubatch = params.n_ubatch ? params.n_ubatch : params.n_batch;
+    cp.n_seq_max = params.n_seq_max ? params.n_seq_max : 1;
+    cp.type_k = params.type_k; cp.type_v = params.type_v;
+    cp.flash_attn = params.flash_attn != 0 || params.type_k != MI355_TYPE_F16 || params.type_v != MI355_TYPE_F16;
+    cp.embeddings = params.embeddings != 0;
+    cp.use_graphs = params.use_graphs != 0;
+    Context *c = new Context(model->m, cp);
+    std::string err;
+    if (!c->init(err)) { fail(err); delete c; return nullptr; }
+    return new mi355_context{c, {}};
+}
+void mi355_context_free(mi355_context *ctx) {
+    if (!ctx) return;
+    delete ctx->c;
+    delete ctx;
+}
+uint32_t mi355_n_ctx(const mi355_context *ctx) { return ctx->c->cp.n_ctx; }
+uint32_t mi355_n_batch(const mi355_context *ctx) { return ctx->c->cp.n_batch; }
+uint32_t mi355_n_ubatch(const mi355_context *ctx) { return ctx->c->cp.n_ubatch; }
+uint64_t mi355_context_device_bytes(const mi355_context *ctx) { return ctx->c->device_bytes; }
+
+mi355_batch mi355_batch_init(int32_t n_tokens, int32_t embd, int32_t n_seq_max) {
+    mi355_batch b{};
+    (void)embd;
+    b.token = (mi355_token *)calloc((size_t)n_tokens, sizeof(mi355_token));
+    b.pos = (mi355_pos *)calloc((size_t)n_tokens, sizeof(mi355_pos));
+    b.n_seq_id = (int32_t *)calloc((size_t)n_tokens, sizeof(int32_t));
+    b.seq_id = (mi355_seq_id **)calloc((size_t)n_tokens + 1, sizeof(mi355_seq_id *));
+    for (int i = 0; i < n_tokens; i++) b.seq_id[i] = (mi355_seq_id *)calloc((size_t)(n_seq_max > 0 ? n_seq_max : 1), sizeof(mi355_seq_id));
+    b.seq_id[n_tokens] = nullptr;
+    b.logits = (int8_t *)calloc((size_t)n_tokens, 1);
+    return b;
+}
+void mi355_batch_free(mi355_batch b) {
+    free(b.token); free(b.pos); free(b.n_seq_id); free(b.logits);
+    if (b.seq_id) {
+        for (int i = 0; b.seq_id[i]; i++) free(b.seq_id[i]);
+        free(b.seq_id);
+    }
+}
+
+int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
+    if (!ctx) return MI355_ERR_ARG;
+    const int rc = ctx->c->decode(batch.n_tokens, batch.token, batch.pos, batch.n_seq_id, batch.seq_id, batch.logits);
+    if (rc < 0) fail(ctx->c->last_error);
+    return rc;
+}
+float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
+int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
+void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0; }
+void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
+
+void mi355_kv_cache_clear(mi355_context *ctx) { ctx->c->kv_clear(); }
+int32_t mi355_kv_cache_seq_rm(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1) { return ctx->c->kv_seq_rm(seq, p0, p1) ? 1 : 0; }
+void mi355_kv_cache_seq_cp(mi355_context *ctx, mi355_seq_id src, mi355_seq_id dst, mi355_pos p0, mi355_pos p1) { ctx->c->kv_seq_cp(src, dst, p0, p1); }
+void mi355_kv_cache_seq_add(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1, mi355_pos delta) { ctx->c->kv_seq_add(seq, p0, p1, delta); }
+int32_t mi355_kv_cache_used_cells(const mi355_context *ctx) { return ctx->c->kv_used_cells(); }
+
+void mi355_debug_enable_taps(mi355_context *ctx, int32_t enabled) { ctx->c->set_debug_taps(enabled != 0); }
+int32_t mi355_debug_layer_out(mi355_context *ctx, int32_t il, float *dst, size_t dst_floats) { return ctx->c->debug_layer_out(il, dst, dst_floats); }
+
+void mi355_profile_enable(mi355_context *ctx, int32_t enabled) { ctx->c->set_profile(enabled != 0); }
+int32_t mi355_profile_last_decode(mi355_context *ctx, const char **names, float *us, int32_t cap) {
+    const auto &p = ctx->c->last_profile();
+    int n = 0;
+    for (const auto &e : p) {
+        if (n >= cap) break;
+        names[n] = e.name.c_str();
+        us[n] = e.us;
+        n++;
+    }
+    return n;
+}
+double mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep) { return ctx->c->bench_weight_sweep(iters, bytes_per_sweep); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ per-op wrappers
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    size_t n = 0;
+    explicit DevBuf(size_t bytes) : n(bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) p = nullptr; else (void)hipMemset(p, 0, bytes ? bytes : 16); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+    bool up(const void *src, size_t bytes) { return p && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess; }
+    bool down(void *dst, size_t bytes) { return p && hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+};
+bool need_device() {
+    if (g_backend_ok) return true;
+    return mi355_backend_init() == MI355_OK;
+}
+struct ActBufs {
+    DevBuf qs, d, bs, qs0, d0;
+    ActQuant q;
+    ActBufs(size_t K, size_t T) : qs(T * K), d(T * (K / 256 + 1) * 4), bs(T * (K / 16 + 1) * 2), qs0(T * K), d0(T * (K / 32 + 1) * 2) {
+        q.qs = qs.as<int8_t>(); q.d = d.as<float>(); q.bsums = bs.as<int16_t>(); q.qs0 = qs0.as<int8_t>(); q.d0 = d0.as<uint16_t>();
+    }
+    bool ok() const { return qs.p && d.p && bs.p && qs0.p && d0.p; }
+};
+int hip_fail(hipError_t e, const char *what) {
+    fail(std::string(what) + ": " + hipGetErrorString(e));
+    return MI355_ERR_HIP;
+}
+}  // namespace
+
+extern "C" double hbm_read_probe(size_t bytes, int iters);
+
+extern "C" {
+
+int mi355_op_quantize_act(int32_t act_type, const float *x, int64_t n, int64_t rows, void *out_blocks) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    if ((act_type != MI355_TYPE_Q8_K && act_type != MI355_TYPE_Q8_0) || n % 256) { fail("bad args"); return MI355_ERR_ARG; }
+    DevBuf dx((size_t)n * rows * 4);
+    ActBufs ab((size_t)n, (size_t)rows);
+    const size_t ob = act_type == MI355_TYPE_Q8_K ? (size_t)(n / 256) * 292 * rows : (size_t)(n / 32) * 34 * rows;
+    DevBuf dout(ob);
+    if (!dx.up(x, (size_t)n * rows * 4) || !ab.ok() || !dout.p) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }
+    hipError_t e = launch_quantize(dx.as<float>(), (int)n, (int)rows, ab.q, act_type == MI355_TYPE_Q8_K, act_type == MI355_TYPE_Q8_0, nullptr);
+    if (e == hipSuccess) e = act_type == MI355_TYPE_Q8_K ? launch_pack_q8k_blocks(ab.q, (int)n, (int)rows, dout.as<uint8_t>(), nullptr)
+                                                         : launch_pack_q80_blocks(ab.q, (int)n, (int)rows, dout.as<uint8_t>(), nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "quantize_act");
+    return dout.down(out_blocks, ob) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const float *x, int64_t T, float *y, int32_t *isum, int32_t *msum) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    const size_t grow = ggml_row_bytes(type, K), drow = dev_row_bytes(type, K);
+    if (!grow || K % 256) { fail("bad type / K"); return MI355_ERR_ARG; }
+    DevBuf wsrc(grow * N), wdev(drow * N), dx((size_t)K * T * 4), dy((size_t)N * T * 4);
+    ActBufs ab((size_t)K, (size_t)T);
+    if (!wsrc.up(W, grow * N) || !wdev.p || !dx.up(x, (size_t)K * T * 4) || !dy.p || !ab.ok()) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }
+    hipError_t e = launch_repack_rows(type, wsrc.as<uint8_t>(), wdev.as<uint8_t>(), K, N, nullptr);
+    if (e != hipSuccess) return hip_fail(e, "repack");
+    const bool quant = type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q8_0;
+    if (quant) {
+        e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, type != T_Q8_0, type == T_Q8_0, nullptr);
+        if (e != hipSuccess) return hip_fail(e, "quantize");
+        for (int64_t t0 = 0; t0 < T;) {
+            const int64_t rem = T - t0;
+            const int nt = rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+            MMVQArgs a{};
+            a.n_seg = 1; a.K = (int)K; a.T = nt; a.epi = EPI_STORE;
+            a.seg[0].W = wdev.as<uint8_t>(); a.seg[0].out = dy.as<float>() + t0 * N; a.seg[0].type = type; a.seg[0].n_rows = (int)N;
+            a.seg[0].ld_out = (int)N; a.seg[0].row_bytes = drow;
+            a.aq = ab.q.qs + t0 * K; a.ad = ab.q.d + t0 * (K / 256); a.abs = ab.q.bsums + t0 * (K / 16);
+            a.aq0 = ab.q.qs0 + t0 * K; a.ad0 = ab.q.d0 + t0 * (K / 32);
+            e = launch_mmvq(a, nullptr);
+            if (e != hipSuccess) return hip_fail(e, "mmvq");
+            t0 += nt;
+        }
+        if (isum && msum) {
+            const int64_t nblk = type == T_Q8_0 ? K / 32 : K / 256;
+            DevBuf di((size_t)N * nblk * 4), dm((size_t)N * nblk * 4);
+            for (int64_t t = 0; t < T; t++) {
+                MMVQArgs a{};
+                a.n_seg = 1; a.K = (int)K; a.T = 1; a.epi = EPI_STORE;
+                a.seg[0].W = wdev.as<uint8_t>(); a.seg[0].type = type; a.seg[0].n_rows = (int)N; a.seg[0].row_bytes = drow;
+                a.aq = ab.q.qs + t * K; a.ad = ab.q.d + t * (K / 256); a.abs = ab.q.bsums + t * (K / 16);
+                a.aq0 = ab.q.qs0 + t * K; a.ad0 = ab.q.d0 + t * (K / 32);
+                e = launch_mmvq_ints(a, di.as<int32_t>(), dm.as<int32_t>(), nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) return hip_fail(e, "mmvq_ints");
+                di.down(isum + t * N * nblk, (size_t)N * nblk * 4);
+                dm.down(msum + t * N * nblk, (size_t)N * nblk * 4);
+            }
+        }
+    } else {
+        e = launch_mmv_float(type, wdev.as<uint8_t>(), (int)N, (int)K, dx.as<float>(), (int)T, dy.as<float>(), (int)N, nullptr, nullptr);
+        if (e != hipSuccess) return hip_fail(e, "mmv_float");
+    }
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "mul_mat");
+    return dy.down(y, (size_t)N * T * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_rms_norm_mul(const float *x, const float *w, int64_t n, int64_t T, float eps, float *y) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    if (n % 256) { fail("n must be a multiple of 256"); return MI355_ERR_ARG; }
+    DevBuf dx((size_t)n * T * 4), dw((size_t)n * 4), dy((size_t)n * T * 4);
+    if (!dx.up(x, (size_t)n * T * 4) || !dw.up(w, (size_t)n * 4) || !dy.p) return MI355_ERR_OOM;
+    hipError_t e = launch_rmsnorm_quant(dx.as<float>(), dw.as<float>(), (int)n, (int)T, eps, dy.as<float>(), nullptr, false, false, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "rms_norm");
+    return dy.down(y, (size_t)n * T * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_rope(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, const int32_t *pos, int64_t T,
+                  float freq_base, float freq_scale, const float *freq_factors, int32_t neox) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    const size_t nb = (size_t)T * n_head * head_dim * 4;
+    DevBuf dx(nb), dp((size_t)T * 4), dff(freq_factors ? (size_t)n_rot * 2 : 16);
+    if (!dx.up(x, nb) || !dp.up(pos, (size_t)T * 4)) return MI355_ERR_OOM;
+    if (freq_factors) dff.up(freq_factors, (size_t)(n_rot / 2) * 4);
+    RopeArgs ra{n_rot, freq_base, freq_scale, freq_factors ? dff.as<float>() : nullptr, neox};
+    hipError_t e = launch_rope_inplace(dx.as<float>(), (int)T, n_head, head_dim, dp.as<int32_t>(), ra, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "rope");
+    return dx.down(x, nb) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_get_rows(int32_t type, const void *table, int64_t K, int64_t n_rows, const int32_t *ids, int64_t n_ids, float *dst) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    const size_t grow = ggml_row_bytes(type, K), drow = dev_row_bytes(type, K);
+    if (!grow) return MI355_ERR_ARG;
+    DevBuf src(grow * n_rows), dev(drow * n_rows), di((size_t)n_ids * 4), dd((size_t)n_ids * K * 4);
+    if (!src.up(table, grow * n_rows) || !dev.p || !di.up(ids, (size_t)n_ids * 4) || !dd.p) return MI355_ERR_OOM;
+    hipError_t e = launch_repack_rows(type, src.as<uint8_t>(), dev.as<uint8_t>(), K, n_rows, nullptr);
+    if (e == hipSuccess) e = launch_get_rows(type, dev.as<uint8_t>(), K, di.as<int32_t>(), (int)n_ids, dd.as<float>(), nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "get_rows");
+    return dd.down(dst, (size_t)n_ids * K * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_swiglu(const float *gate, const float *up, int64_t n, float *y) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    DevBuf g((size_t)n * 4), u((size_t)n * 4), o((size_t)n * 4);
+    if (!g.up(gate, (size_t)n * 4) || !u.up(up, (size_t)n * 4) || !o.p) return MI355_ERR_OOM;
+    hipError_t e = launch_swiglu(g.as<float>(), u.as<float>(), o.as<float>(), n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "swiglu");
+    return o.down(y, (size_t)n * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_soft_max(const float *x, const float *mask, int64_t n, int64_t rows, float scale, float *y) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    const size_t nb = (size_t)n * rows * 4;
+    DevBuf dx(nb), dm(nb), dy(nb);
+    if (!dx.up(x, nb) || !dy.p) return MI355_ERR_OOM;
+    if (mask) dm.up(mask, nb);
+    hipError_t e = launch_soft_max(dx.as<float>(), mask ? dm.as<float>() : nullptr, dy.as<float>(), (int)n, (int)rows, scale, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "soft_max");
+    return dy.down(y, nb) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_op_flash_attn(const float *q, int64_t T, int32_t H, int32_t G, int32_t D, int32_t type_k, const void *k, int32_t type_v,
+                        const void *v, int32_t n_cells, const int32_t *cell_pos, const int32_t *q_pos, float scale, float *out) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    if ((D != 64 && D != 128) || H % G) { fail("unsupported head geometry"); return MI355_ERR_ARG; }
+    // Build cache planes by running the store kernel on dequantised rows is not possible bit-exactly, so the
+    // planes are filled from the ggml-layout rows directly on the host.
+    const size_t kv_dim = (size_t)G * D;
+    auto fill = [&](int type, const void *rows, std::vector<uint8_t> &codes, std::vector<uint16_t> &scales) {
+        const uint8_t *src = (const uint8_t *)rows;
+        const size_t rb = ggml_row_bytes(type, (int64_t)kv_dim);
+        if (type == T_F16) {
+            codes.resize((size_t)G * n_cells * D * 2);
+            for (int c = 0; c < n_cells; c++)
+                for (int g = 0; g < G; g++)
+                    memcpy(&codes[(((size_t)g * n_cells + c) * D) * 2], src + (size_t)c * rb + (size_t)g * D * 2, (size_t)D * 2);
+        } else if (type == T_Q8_0) {
+            codes.resize((size_t)G * n_cells * D);
+            scales.resize((size_t)G * n_cells * (D / 32));
+            for (int c = 0; c < n_cells; c++)
+                for (int g = 0; g < G; g++)
+                    for (int b = 0; b < D / 32; b++) {
+                        const uint8_t *blk = src + (size_t)c * rb + ((size_t)g * (D / 32) + b) * 34;
+                        memcpy(&scales[((size_t)g * n_cells + c) * (D / 32) + b], blk, 2);
+                        memcpy(&codes[((size_t)g * n_cells + c) * D + (size_t)b * 32], blk + 2, 32);
+                    }
+        } else {
+            codes.resize((size_t)G * n_cells * D / 2);
+            scales.resize((size_t)G * n_cells * (D / 32));
+            for (int c = 0; c < n_cells; c++)
+                for (int g = 0; g < G; g++)
+                    for (int b = 0; b < D / 32; b++) {
+                        const uint8_t *blk = src + (size_t)c * rb + ((size_t)g * (D / 32) + b) * 18;
+                        memcpy(&scales[((size_t)g * n_cells + c) * (D / 32) + b], blk, 2);
+                        memcpy(&codes[((size_t)g * n_cells + c) * (D / 2) + (size_t)b * 16], blk + 2, 16);
+                    }
+        }
+    };
+    std::vector<uint8_t> kc, vc;
+    std::vector<uint16_t> ks, vs;
+    fill(type_k, k, kc, ks);
+    fill(type_v, v, vc, vs);
+    DevBuf dk(kc.size()), dks(ks.size() * 2 + 16), dv(vc.size()), dvs(vs.size() * 2 + 16);
+    DevBuf dq((size_t)T * H * D * 4), dout((size_t)T * H * D * 4), dcp((size_t)n_cells * 4), dcs((size_t)n_cells * 8), dtp((size_t)T * 4), dts((size_t)T * 4), dn(16);
+    if (!dk.up(kc.data(), kc.size()) || !dv.up(vc.data(), vc.size()) || !dq.up(q, (size_t)T * H * D * 4)) return MI355_ERR_OOM;
+    if (!ks.empty()) dks.up(ks.data(), ks.size() * 2);
+    if (!vs.empty()) dvs.up(vs.data(), vs.size() * 2);
+    std::vector<uint64_t> seqm((size_t)n_cells, 1ull);
+    std::vector<int32_t> tseq((size_t)T, 0);
+    int32_t nkv = n_cells;
+    dcp.up(cell_pos, (size_t)n_cells * 4); dcs.up(seqm.data(), (size_t)n_cells * 8); dtp.up(q_pos, (size_t)T * 4); dts.up(tseq.data(), (size_t)T * 4);
+    dn.up(&nkv, 4);
+    AttnArgs a{};
+    a.q = dq.as<float>(); a.out = dout.as<float>();
+    a.kv.k = dk.as<uint8_t>(); a.kv.kd = dks.as<uint16_t>(); a.kv.v = dv.as<uint8_t>(); a.kv.vd = dvs.as<uint16_t>();
+    a.type_k = type_k; a.type_v = type_v; a.T = (int)T; a.H = H; a.G = G; a.D = D; a.n_ctx = n_cells;
+    a.cell_pos = dcp.as<int32_t>(); a.cell_seq = dcs.as<uint64_t>(); a.tok_pos = dtp.as<int32_t>(); a.tok_seq = dts.as<int32_t>();
+    a.n_kv_dev = dn.as<int32_t>(); a.n_kv_max = n_cells; a.scale = scale;
+    a.splits = flash_attn_pick_splits((int)T, G, n_cells);
+    DevBuf part(flash_attn_workspace_floats((int)T, H, D, a.splits) * 4);
+    a.part = part.as<float>();
+    hipError_t e = launch_flash_attn(a, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "flash_attn");
+    return dout.down(out, (size_t)T * H * D * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
+// simple read-bandwidth probe: sum-reduce `bytes` of device memory
+double mi355_bench_hbm_read(size_t bytes, int iters) {
+    if (!need_device()) return -1.0;
+    return hbm_read_probe(bytes, iters);
+}
+
+}  // extern "C"

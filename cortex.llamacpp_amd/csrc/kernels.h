@@ -1,0 +1,129 @@
+// kernels.h — host-visible launch interface of the gfx950 kernels (internal; the public C-ABI is
+// include/mi355_llama.h).
+#pragma once
+
+#include "dev_common.h"
+
+namespace mi355 {
+
+// ---------------------------------------------------------------- quantised activations (device)
+// Q8_K: codes + one f32 scale per 256 + int16 sums per 16 (ggml block_q8_K split into planes);
+// Q8_0: codes + one f16 scale per 32 (ggml block_q8_0 split into planes).
+struct ActQuant {
+    int8_t *qs = nullptr;      // [T][K]   q8_K
+    float *d = nullptr;        // [T][K/256]
+    int16_t *bsums = nullptr;  // [T][K/16]
+    int8_t *qs0 = nullptr;     // [T][K]   q8_0
+    uint16_t *d0 = nullptr;    // [T][K/32]
+};
+
+// ---------------------------------------------------------------- mmvq
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_SWIGLU = 2 };
+
+struct MMVQSeg {
+    const uint8_t *W;     // device-layout rows
+    float *out;           // out[t * ld_out + row]
+    const float *resid;   // EPI_ADD: out = resid + y (same indexing)
+    int type;
+    int n_rows;
+    int ld_out;
+    size_t row_bytes;
+    const int32_t *expert_sel;   // MoE: device pointer to the expert index (nullptr = dense)
+    size_t expert_stride;        // bytes between experts
+};
+
+struct MMVQArgs {
+    MMVQSeg seg[3];
+    int seg_block0[4];    // blocks [seg_block0[s], seg_block0[s+1]) serve segment s
+    int n_seg;
+    int K;
+    int T;                // tokens in this launch (1, 2 or 4)
+    int epi;
+    int need_q8k, need_q80;
+    const int8_t *aq; const float *ad; const int16_t *abs;   // q8_K planes for the T tokens
+    const int8_t *aq0; const uint16_t *ad0;                  // q8_0 planes
+};
+
+hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);
+hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_t st);
+void set_num_cu(int n);
+int num_cu();
+
+// ---------------------------------------------------------------- activation-side kernels (act.hip)
+// y = rms_norm(x) * w  for T rows of n; optionally f32 out and/or q8_K / q8_0 planes
+hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, float eps,
+                                float *y_f32 /*nullable*/, const ActQuant *q /*nullable*/, bool want_q8k, bool want_q80,
+                                hipStream_t st);
+// quantise f32 rows
+hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st);
+hipError_t launch_swiglu(const float *g, const float *u, float *y, int64_t n, hipStream_t st);
+hipError_t launch_add(const float *a, const float *b, float *y, int64_t n, hipStream_t st);
+hipError_t launch_soft_max(const float *x, const float *mask, float *y, int n, int rows, float scale, hipStream_t st);
+// pack device planes back into ggml blocks (parity tests)
+hipError_t launch_pack_q8k_blocks(const ActQuant &q, int n, int T, uint8_t *blocks, hipStream_t st);
+hipError_t launch_pack_q80_blocks(const ActQuant &q, int n, int T, uint8_t *blocks, hipStream_t st);
+
+// ---------------------------------------------------------------- layout / lookup kernels (misc.hip)
+// regroup ggml rows into the device row layout (Q6_K, Q8_0); other types are byte copies
+hipError_t launch_repack_rows(int type, const uint8_t *src_ggml, uint8_t *dst_dev, int64_t K, int64_t n_rows, hipStream_t st);
+// dst[i][:] = dequant(table row ids[i]) from device-layout rows
+hipError_t launch_get_rows(int type, const uint8_t *table_dev, int64_t K, const int32_t *ids, int n_ids, float *dst, hipStream_t st);
+hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, hipStream_t st);
+// f32 / f16 weight mat-vec (router, unquantised models): y[t][r] = dot(W[r], x[t])
+hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,
+                            const float *resid, hipStream_t st);
+
+// MoE router: softmax over n_expert logits per token, top-k (first index wins ties), weights renormalised
+hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, hipStream_t st);
+// x[t][d] += sum_j eo[j][t][d] * w[t][j]   (experts added in rank order, then the residual)
+hipError_t launch_moe_combine(float *x, const float *eo, const float *w, int T, int E, int k, size_t eo_stride, hipStream_t st);
+hipError_t launch_gather_rows_f32(const float *src, const int32_t *rows, int n_rows, int n, float *dst, hipStream_t st);
+
+// ---------------------------------------------------------------- attention side (attn.hip)
+struct KVLayerView {
+    // head-major cache planes of one layer: cell c of kv-head g
+    //   f16 : k + ((g*n_ctx + c) * D) * 2
+    //   q8_0: codes k + (g*n_ctx + c) * D ; scales kd + (g*n_ctx + c) * (D/32)
+    //   q4_0: codes k + (g*n_ctx + c) * D/2 ; scales kd likewise
+    uint8_t *k; uint16_t *kd;
+    uint8_t *v; uint16_t *vd;
+};
+
+struct RopeArgs {
+    int n_rot; float freq_base; float freq_scale; const float *freq_factors; int neox;
+};
+
+// rope(q) in place, rope(k) -> K cache, v -> V cache for T tokens
+hipError_t launch_rope_kv_store(float *q, const float *k, const float *v, int T, int n_head, int n_head_kv, int D,
+                                const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra,
+                                KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);
+hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t *tok_pos, RopeArgs ra, hipStream_t st);
+
+struct AttnArgs {
+    const float *q;          // [T][H][D] (already rotated)
+    float *out;              // [T][H][D]
+    KVLayerView kv;
+    int type_k, type_v;
+    int T, H, G, D, n_ctx;
+    const int32_t *cell_pos;   // [n_ctx]  -1 = empty
+    const uint64_t *cell_seq;  // [n_ctx]  bitmask of sequence ids
+    const int32_t *tok_pos;    // [T]
+    const int32_t *tok_seq;    // [T]
+    const int32_t *n_kv_dev;   // device scalar: cells to scan (high-water mark)
+    int n_kv_max;              // host upper bound used to size the grid
+    float scale;
+    float *part;               // workspace [T][H][splits][D+2]
+    int splits;
+};
+hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
+size_t flash_attn_workspace_floats(int T, int H, int D, int splits);
+int flash_attn_pick_splits(int T, int G, int n_kv_max);
+
+// re-rotate cached K rows after seq_add (K-shift): for each cell with delta[c] != 0
+hipError_t launch_k_shift(KVLayerView kv, int type_k, int G, int D, int n_ctx, const int32_t *delta, RopeArgs ra, hipStream_t st);
+
+// cell metadata update inside the decode graph: cell_pos[cell] = pos, cell_seq[cell] = mask
+hipError_t launch_kv_meta_set(int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell, const int32_t *tok_pos,
+                              const uint64_t *tok_seqmask, int T, hipStream_t st);
+
+}  // namespace mi355

@@ -1,0 +1,810 @@
+// runtime.cc — GGUF -> HBM residency, KV cells, and the per-batch executor for the `llama` architecture
+// (op order of upstream llm_build_llama / build_attn / build_ffn / build_moe_ffn).
+// Reference caller: LlamaServerContext::UpdateSlots -> llama_decode (src/llama_server_context.cc:1628-1635).
+#include "runtime.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace mi355 {
+
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const std::string &last_error_string() { return g_err; }
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ model
+Model::~Model() {
+    for (uint8_t *p : arenas) (void)hipFree(p);
+}
+
+static bool type_supported(int t) {
+    return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K;
+}
+
+Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status) {
+    status = 0;
+    std::unique_ptr<Model> m(new Model());
+    m->file.reset(new GGUFFile());
+    m->path = path;
+    err = m->file->open(path);
+    if (!err.empty()) { status = err.rfind("cannot", 0) == 0 ? -101 : -102; return nullptr; }
+    GGUFFile &f = *m->file;
+    HParams &hp = m->hp;
+    hp.arch = f.get_s("general.architecture", "");
+    if (hp.arch.empty()) { err = "general.architecture missing"; status = -102; return nullptr; }
+    const std::string a = hp.arch + ".";
+    hp.n_embd = (int)f.get_u(a + "embedding_length", 0);
+    hp.n_layer = (int)f.get_u(a + "block_count", 0);
+    hp.n_ff = (int)f.get_u(a + "feed_forward_length", 0);
+    hp.n_head = (int)f.get_u(a + "attention.head_count", 0);
+    hp.n_head_kv = (int)f.get_u(a + "attention.head_count_kv", (uint64_t)hp.n_head);
+    hp.eps = (float)f.get_f(a + "attention.layer_norm_rms_epsilon", 1e-5);
+    hp.rope_base = (float)f.get_f(a + "rope.freq_base", 10000.0);
+    hp.n_expert = (int)f.get_u(a + "expert_count", 0);
+    hp.n_expert_used = (int)f.get_u(a + "expert_used_count", 0);
+    hp.n_ctx_train = (int)f.get_u(a + "context_length", 0);
+    if (!hp.n_embd || !hp.n_layer || !hp.n_head) { err = "missing hyper-parameters for arch " + hp.arch; status = -102; return nullptr; }
+    hp.head_dim = hp.n_embd / hp.n_head;
+    hp.n_rot = (int)f.get_u(a + "rope.dimension_count", (uint64_t)hp.head_dim);
+    hp.rope_neox = hp.arch != "llama";
+    const std::string scaling = f.get_s(a + "rope.scaling.type", "none");
+    if (scaling == "linear") hp.rope_scale = 1.0f / (float)f.get_f(a + "rope.scaling.factor", 1.0);
+    if (hp.head_dim != 64 && hp.head_dim != 128) { err = "unsupported head_dim " + std::to_string(hp.head_dim); status = -102; return nullptr; }
+    if (hp.n_embd % 256) { err = "n_embd must be a multiple of 256"; status = -102; return nullptr; }
+
+    if (hipSetDevice(main_gpu) != hipSuccess) { err = "hipSetDevice failed"; status = -100; return nullptr; }
+    m->device = main_gpu;
+
+    // plan the arena
+    struct Plan { const GGUFTensorInfo *ti; DevTensor *dst; size_t off; };
+    std::vector<Plan> plan;
+    size_t total = 0, max_stage = 0;
+    bool fail = false;
+    auto want = [&](const std::string &name, DevTensor &dst, bool required) {
+        const GGUFTensorInfo *ti = f.tensor(name);
+        if (!ti) {
+            if (required) { err = "missing tensor " + name; fail = true; }
+            return;
+        }
+        if (!type_supported(ti->type)) {
+            err = "tensor " + name + " has unsupported type " + ggml_type_name(ti->type);
+            fail = true;
+            return;
+        }
+        dst.name = name;
+        dst.type = ti->type;
+        dst.K = ti->ne[0];
+        dst.N = ti->ne[1];
+        dst.n_expert = ti->ne[2];
+        if (ggml_block_elems(dst.type) > 1 && dst.K % ggml_block_elems(dst.type)) { err = "tensor " + name + ": row length not a block multiple"; fail = true; return; }
+        dst.row_bytes = ti->n_dims == 1 ? ggml_row_bytes(dst.type, dst.K) : dev_row_bytes(dst.type, dst.K);
+        const int64_t rows = ti->n_dims == 1 ? 1 : dst.N * dst.n_expert;
+        dst.bytes = dst.row_bytes * (size_t)rows;
+        dst.ggml_bytes = ti->bytes;
+        plan.push_back({ti, &dst, total});
+        total += (dst.bytes + 255) & ~(size_t)255;
+        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, ti->bytes);
+    };
+    want("token_embd.weight", m->tok_embd, true);
+    want("output_norm.weight", m->out_norm, true);
+    want("output.weight", m->output, false);
+    want("rope_freqs.weight", m->rope_freqs, false);
+    m->layers.resize((size_t)hp.n_layer);
+    for (int il = 0; il < hp.n_layer && !fail; il++) {
+        LayerWeights &L = m->layers[(size_t)il];
+        const std::string p = "blk." + std::to_string(il) + ".";
+        want(p + "attn_norm.weight", L.attn_norm, true);
+        want(p + "attn_q.weight", L.wq, true);
+        want(p + "attn_k.weight", L.wk, true);
+        want(p + "attn_v.weight", L.wv, true);
+        want(p + "attn_output.weight", L.wo, true);
+        want(p + "attn_q.bias", L.bq, false);
+        want(p + "attn_k.bias", L.bk, false);
+        want(p + "attn_v.bias", L.bv, false);
+        want(p + "ffn_norm.weight", L.ffn_norm, true);
+        if (hp.n_expert > 0) {
+            want(p + "ffn_gate_inp.weight", L.gate_inp, true);
+            want(p + "ffn_gate_exps.weight", L.gate_exps, true);
+            want(p + "ffn_up_exps.weight", L.up_exps, true);
+            want(p + "ffn_down_exps.weight", L.down_exps, true);
+        } else {
+            want(p + "ffn_gate.weight", L.gate, true);
+            want(p + "ffn_up.weight", L.up, true);
+            want(p + "ffn_down.weight", L.down, true);
+        }
+    }
+    if (fail) { status = -102; return nullptr; }
+    hp.n_vocab = (int)m->tok_embd.N;
+    if (!hp.n_ff) hp.n_ff = (int)(hp.n_expert ? m->layers[0].gate_exps.N : m->layers[0].gate.N);
+
+    uint8_t *arena = nullptr, *stage = nullptr;
+    if (hipMalloc(&arena, total) != hipSuccess) { err = "hipMalloc of " + std::to_string(total) + " weight bytes failed"; status = -104; return nullptr; }
+    m->arenas.push_back(arena);
+    if (max_stage && hipMalloc(&stage, max_stage) != hipSuccess) { err = "hipMalloc of staging buffer failed"; status = -104; return nullptr; }
+    hipStream_t st = nullptr;
+    (void)hipStreamCreate(&st);
+    for (const Plan &pl : plan) {
+        DevTensor &d = *pl.dst;
+        d.data = arena + pl.off;
+        const bool direct = !(d.type == T_Q6_K || d.type == T_Q8_0) && (pl.ti->n_dims == 1 || d.row_bytes == ggml_row_bytes(d.type, d.K));
+        hipError_t e;
+        if (direct) {
+            e = hipMemcpyAsync(d.data, pl.ti->data, pl.ti->bytes, hipMemcpyHostToDevice, st);
+        } else {
+            e = hipMemcpyAsync(stage, pl.ti->data, pl.ti->bytes, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = launch_repack_rows(d.type, stage, d.data, d.K, d.N * d.n_expert, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            err = std::string("upload of ") + d.name + " failed: " + hipGetErrorString(e);
+            status = -105;
+            if (stage) (void)hipFree(stage);
+            (void)hipStreamDestroy(st);
+            return nullptr;
+        }
+        m->file_tensor_bytes += pl.ti->bytes;
+    }
+    if (stage) (void)hipFree(stage);
+    (void)hipStreamDestroy(st);
+    if (!m->output.valid()) m->output = m->tok_embd;   // tied embeddings
+    m->device_bytes = total;
+    m->host_bytes = 0;
+
+    // algorithmic bytes per decoded token: each tensor once, one embedding row, used experts only
+    uint64_t bpt = 0;
+    for (const Plan &pl : plan) {
+        const DevTensor &d = *pl.dst;
+        uint64_t b = pl.ti->bytes;
+        if (&d == &m->tok_embd) b = ggml_row_bytes(d.type, d.K);
+        else if (d.n_expert > 1 && hp.n_expert_used > 0) b = b / (uint64_t)d.n_expert * (uint64_t)hp.n_expert_used;
+        bpt += b;
+    }
+    if (m->output.data == m->tok_embd.data) bpt += m->tok_embd.ggml_bytes;
+    m->bytes_per_token = bpt;
+    char desc[256];
+    snprintf(desc, sizeof desc, "%s %dL E%d H%d/%d FF%d V%d%s", hp.arch.c_str(), hp.n_layer, hp.n_embd, hp.n_head, hp.n_head_kv, hp.n_ff,
+             hp.n_vocab, hp.n_expert ? " MoE" : "");
+    m->desc = desc;
+    return m.release();
+}
+
+// ------------------------------------------------------------------------------------------ context
+Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
+
+Context::~Context() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    for (auto &pe : prof_events_) (void)hipEventDestroy(pe.second);
+    for (void *p : allocs_) (void)hipFree(p);
+    if (h_stage_) (void)hipHostFree(h_stage_);
+    if (h_logits_) (void)hipHostFree(h_logits_);
+    if (h_argmax_) (void)hipHostFree(h_argmax_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void *Context::dalloc(size_t bytes) {
+    void *p = nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, bytes);
+    allocs_.push_back(p);
+    device_bytes += bytes;
+    return p;
+}
+
+static void alloc_actq(ActQuant &q, size_t K, size_t T, bool k, bool z, std::vector<void *> &track, uint64_t &tot, bool &ok) {
+    auto al = [&](size_t b) -> void * {
+        void *p = nullptr;
+        b = (b + 255) & ~(size_t)255;
+        if (hipMalloc(&p, b) != hipSuccess) { ok = false; return nullptr; }
+        track.push_back(p);
+        tot += b;
+        return p;
+    };
+    if (k) {
+        q.qs = (int8_t *)al(T * K);
+        q.d = (float *)al(T * (K / 256) * 4);
+        q.bsums = (int16_t *)al(T * (K / 16) * 2);
+    }
+    if (z) {
+        q.qs0 = (int8_t *)al(T * K);
+        q.d0 = (uint16_t *)al(T * (K / 32) * 2);
+    }
+}
+
+bool Context::init(std::string &err) {
+    const HParams &hp = model->hp;
+    if (hipSetDevice(model->device) != hipSuccess) { err = "hipSetDevice failed"; return false; }
+    if (cp.n_ubatch > cp.n_batch) cp.n_ubatch = cp.n_batch;
+    if (cp.n_ubatch == 0 || cp.n_ctx == 0) { err = "n_ctx / n_ubatch must be > 0"; return false; }
+    if (cp.n_seq_max > 64) { err = "n_seq_max > 64 unsupported"; return false; }
+    auto kv_ok = [](int t) { return t == T_F16 || t == T_Q8_0 || t == T_Q4_0; };
+    if (!kv_ok(cp.type_k) || !kv_ok(cp.type_v)) { err = "unsupported KV cache type"; return false; }
+    if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, model->device) == hipSuccess) set_num_cu(prop.multiProcessorCount);
+
+    const size_t T = cp.n_ubatch, E = hp.n_embd, FF = hp.n_ff, G = hp.n_head_kv, D = hp.head_dim, NC = cp.n_ctx;
+    cells_.assign(NC, KVCell());
+    kv_.resize((size_t)hp.n_layer);
+    auto plane_bytes = [&](int type, size_t &codes, size_t &scales) {
+        if (type == T_F16) { codes = G * NC * D * 2; scales = 0; }
+        else if (type == T_Q8_0) { codes = G * NC * D; scales = G * NC * (D / 32) * 2; }
+        else { codes = G * NC * D / 2; scales = G * NC * (D / 32) * 2; }
+    };
+    for (int il = 0; il < hp.n_layer; il++) {
+        size_t c, s;
+        plane_bytes(cp.type_k, c, s);
+        kv_[(size_t)il].k = (uint8_t *)dalloc(c);
+        kv_[(size_t)il].kd = s ? (uint16_t *)dalloc(s) : nullptr;
+        plane_bytes(cp.type_v, c, s);
+        kv_[(size_t)il].v = (uint8_t *)dalloc(c);
+        kv_[(size_t)il].vd = s ? (uint16_t *)dalloc(s) : nullptr;
+        if (!kv_[(size_t)il].k || !kv_[(size_t)il].v) { err = "KV cache allocation failed"; return false; }
+    }
+    d_cell_pos_ = (int32_t *)dalloc(NC * 4);
+    d_cell_seq_ = (uint64_t *)dalloc(NC * 8);
+    d_delta_ = (int32_t *)dalloc(NC * 4);
+    // token staging block: [nkv x4][tok][pos][seq][cell][outrow][seqmask]
+    stage_bytes_ = 16 + T * 4 * 5 + T * 8;
+    stage_bytes_ = (stage_bytes_ + 15) & ~(size_t)15;
+    d_stage_ = (uint8_t *)dalloc(stage_bytes_);
+    if (hipHostMalloc((void **)&h_stage_, stage_bytes_, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
+    d_nkv_ = (int32_t *)d_stage_;
+    d_tok_ = (int32_t *)(d_stage_ + 16);
+    d_pos_ = d_tok_ + T;
+    d_seq_ = d_pos_ + T;
+    d_cell_ = d_seq_ + T;
+    d_outrow_ = d_cell_ + T;
+    d_seqmask_ = (uint64_t *)(d_outrow_ + T);
+
+    x_ = (float *)dalloc(T * E * 4);
+    xn_ = (float *)dalloc(T * E * 4);
+    q_ = (float *)dalloc(T * E * 4);
+    k_ = (float *)dalloc(T * G * D * 4);
+    v_ = (float *)dalloc(T * G * D * 4);
+    att_ = (float *)dalloc(T * E * 4);
+    ffn_ = (float *)dalloc(T * FF * 4);
+    ffn_u_ = (float *)dalloc(T * FF * 4);
+    xo_ = (float *)dalloc(T * E * 4);
+    if (hp.n_expert > 0) {
+        router_ = (float *)dalloc(T * hp.n_expert * 4);
+        moe_ids_ = (int32_t *)dalloc(T * hp.n_expert_used * 4);
+        moe_w_ = (float *)dalloc(T * hp.n_expert_used * 4);
+        moe_out_ = (float *)dalloc((size_t)hp.n_expert_used * T * E * 4);
+    }
+    bool ok = true;
+    alloc_actq(aq_e_, E, T, true, true, allocs_, device_bytes, ok);
+    alloc_actq(aq_o_, E, T, true, true, allocs_, device_bytes, ok);
+    alloc_actq(aq_ff_, FF, T, true, true, allocs_, device_bytes, ok);
+    if (!ok || !x_ || !ffn_u_) { err = "activation buffer allocation failed"; return false; }
+
+    size_t ws = 0;
+    for (int t = 1; t <= (int)T; t++) {
+        const int sp = flash_attn_pick_splits(t, (int)G, (int)NC);
+        ws = std::max(ws, flash_attn_workspace_floats(t, hp.n_head, (int)D, sp));
+    }
+    att_part_ = (float *)dalloc(ws * 4);
+    if (!att_part_) { err = "attention workspace allocation failed"; return false; }
+    d_argmax_ = (int32_t *)dalloc(T * 4);
+    if (hipHostMalloc((void **)&h_argmax_, T * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
+    embeddings_enabled = cp.embeddings;
+    kv_clear();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ KV cells
+void Context::kv_clear() {
+    for (auto &c : cells_) c = KVCell();
+    head_ = 0;
+    has_shift_ = false;
+    meta_dirty_ = true;
+}
+bool Context::kv_seq_rm(int seq, int p0, int p1) {
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = 0x7fffffff;
+    int new_head = (int)cells_.size();
+    for (int i = 0; i < (int)cells_.size(); i++) {
+        KVCell &c = cells_[(size_t)i];
+        if (c.pos < p0 || c.pos >= p1) continue;
+        if (seq < 0) c.seqs = 0;
+        else if (c.seqs & (1ull << seq)) c.seqs &= ~(1ull << seq);
+        else continue;
+        if (!c.seqs) { c.pos = -1; c.delta = 0; if (i < new_head) new_head = i; }
+    }
+    if (new_head < (int)cells_.size() && new_head < head_) head_ = new_head;
+    meta_dirty_ = true;
+    return true;
+}
+void Context::kv_seq_cp(int src, int dst, int p0, int p1) {
+    if (src == dst) return;
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = 0x7fffffff;
+    for (auto &c : cells_)
+        if ((c.seqs & (1ull << src)) && c.pos >= p0 && c.pos < p1) c.seqs |= 1ull << dst;
+    meta_dirty_ = true;
+}
+void Context::kv_seq_add(int seq, int p0, int p1, int delta) {
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = 0x7fffffff;
+    if (p0 == p1 || delta == 0) return;
+    for (auto &c : cells_) {
+        if (!(c.seqs & (1ull << seq)) || c.pos < p0 || c.pos >= p1) continue;
+        has_shift_ = true;
+        c.pos += delta;
+        c.delta += delta;
+        if (c.pos < 0) { c.pos = -1; c.seqs = 0; c.delta = 0; }
+    }
+    meta_dirty_ = true;
+}
+int Context::kv_used_cells() const {
+    int n = 0;
+    for (const auto &c : cells_) n += c.pos >= 0;
+    return n;
+}
+
+int Context::find_slot(int n) {
+    const int NC = (int)cells_.size();
+    if (n > NC) return -1;
+    int head = head_, tested = 0;
+    while (true) {
+        if (head + n > NC) { tested += NC - head; head = 0; if (tested >= NC) return -1; continue; }
+        bool ok = true;
+        for (int i = 0; i < n; i++)
+            if (cells_[(size_t)(head + i)].pos >= 0) { ok = false; head += i + 1; tested += i + 1; break; }
+        if (ok) return head;
+        if (tested >= NC) return -1;
+    }
+}
+
+void Context::apply_k_shift() {
+    const HParams &hp = model->hp;
+    std::vector<int32_t> delta(cells_.size());
+    for (size_t i = 0; i < cells_.size(); i++) { delta[i] = cells_[i].delta; cells_[i].delta = 0; }
+    (void)hipMemcpyAsync(d_delta_, delta.data(), delta.size() * 4, hipMemcpyHostToDevice, stream_);
+    (void)hipStreamSynchronize(stream_);
+    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, model->rope_freqs.valid() ? (const float *)model->rope_freqs.data : nullptr, hp.rope_neox};
+    for (int il = 0; il < hp.n_layer; il++)
+        (void)launch_k_shift(kv_[(size_t)il], cp.type_k, hp.n_head_kv, hp.head_dim, (int)cp.n_ctx, d_delta_, ra, stream_);
+    has_shift_ = false;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+void Context::prof_begin() {
+    if (!profile_) return;
+    for (auto &pe : prof_events_) (void)hipEventDestroy(pe.second);
+    prof_events_.clear();
+    prof_mark("begin");
+}
+void Context::prof_mark(const char *name) {
+    if (!profile_) return;
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    (void)hipEventRecord(ev, stream_);
+    prof_events_.emplace_back(name, ev);
+}
+void Context::prof_end() {
+    if (!profile_) return;
+    (void)hipStreamSynchronize(stream_);
+    last_profile_.clear();
+    for (size_t i = 1; i < prof_events_.size(); i++) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, prof_events_[i - 1].second, prof_events_[i].second);
+        bool found = false;
+        for (auto &e : last_profile_)
+            if (e.name == prof_events_[i].first) { e.us += ms * 1000.0f; found = true; break; }
+        if (!found) last_profile_.push_back({prof_events_[i].first, ms * 1000.0f});
+    }
+}
+
+// ------------------------------------------------------------------------------------------ linear layers
+static bool is_quant(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
+
+static MMVQSeg make_seg(const DevTensor &w, float *out, int ld_out, const float *resid, const int32_t *esel) {
+    MMVQSeg s{};
+    s.W = w.data; s.out = out; s.resid = resid; s.type = w.type; s.n_rows = (int)w.N; s.ld_out = ld_out; s.row_bytes = w.row_bytes;
+    s.expert_sel = esel; s.expert_stride = w.row_bytes * (size_t)w.N;
+    return s;
+}
+
+static void chunk_act(MMVQArgs &a, const ActQuant &aq, int K, int t0) {
+    a.aq = aq.qs ? aq.qs + (size_t)t0 * K : nullptr;
+    a.ad = aq.d ? aq.d + (size_t)t0 * (K / 256) : nullptr;
+    a.abs = aq.bsums ? aq.bsums + (size_t)t0 * (K / 16) : nullptr;
+    a.aq0 = aq.qs0 ? aq.qs0 + (size_t)t0 * K : nullptr;
+    a.ad0 = aq.d0 ? aq.d0 + (size_t)t0 * (K / 32) : nullptr;
+}
+
+// up to 3 quantised weight tensors sharing one activation (fused Q/K/V), or one tensor with an epilogue
+static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, const ActQuant &aq, hipStream_t st) {
+    for (int t0 = 0; t0 < T;) {
+        const int rem = T - t0, nt = rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+        MMVQArgs a{};
+        a.n_seg = n_seg; a.K = K; a.T = nt; a.epi = epi;
+        for (int s = 0; s < n_seg; s++) {
+            a.seg[s] = segs[s];
+            a.seg[s].out = segs[s].out + (size_t)t0 * segs[s].ld_out;
+            if (segs[s].resid) a.seg[s].resid = segs[s].resid + (size_t)t0 * segs[s].ld_out;
+        }
+        chunk_act(a, aq, K, t0);
+        hipError_t e = launch_mmvq(a, st);
+        if (e != hipSuccess) return e;
+        t0 += nt;
+    }
+    return hipSuccess;
+}
+
+hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
+                           const float *resid, int epi) {
+    if (is_quant(w.type)) {
+        MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
+        return mmvq_tokens(&s, 1, K, T, epi, aq, stream_);
+    }
+    return launch_mmv_float(w.type, w.data, (int)w.N, K, x_f32, T, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+}
+
+hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs, int n, const ActQuant &aq, const float *x_f32, int T) {
+    bool all_q = true;
+    for (int i = 0; i < n; i++) all_q &= is_quant(ws[i]->type);
+    const int K = (int)ws[0]->K;
+    if (all_q && n <= 3) {
+        MMVQSeg segs[3];
+        for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
+        return mmvq_tokens(segs, n, K, T, EPI_STORE, aq, stream_);
+    }
+    for (int i = 0; i < n; i++) {
+        hipError_t e = linear(*ws[i], aq, x_f32, K, T, outs[i], (int)ws[i]->N, nullptr, EPI_STORE);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------ the forward pass
+hipError_t Context::run_layers(int T, bool graph_mode) {
+    const HParams &hp = model->hp;
+    const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
+    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, model->rope_freqs.valid() ? (const float *)model->rope_freqs.data : nullptr, hp.rope_neox};
+    const float kq_scale = 1.0f / sqrtf((float)D);
+    const int n_kv_max = graph_mode ? (int)cp.n_ctx : n_kv_;
+    att_splits_ = flash_attn_pick_splits(T, G, graph_mode ? (int)cp.n_ctx : std::max(n_kv_, 1));
+
+    HIP_TRY(launch_kv_meta_set(d_cell_pos_, d_cell_seq_, d_cell_, d_pos_, d_seqmask_, T, stream_));
+    HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
+    prof_mark("embed");
+
+    for (int il = 0; il < hp.n_layer; il++) {
+        const LayerWeights &L = model->layers[(size_t)il];
+        // --- attention block
+        const bool any_f = !is_quant(L.wq.type) || !is_quant(L.wk.type) || !is_quant(L.wv.type);
+        const bool need_k = is_quant(L.wq.type) && L.wq.type != T_Q8_0 || is_quant(L.wk.type) && L.wk.type != T_Q8_0 || is_quant(L.wv.type) && L.wv.type != T_Q8_0;
+        const bool need_0 = L.wq.type == T_Q8_0 || L.wk.type == T_Q8_0 || L.wv.type == T_Q8_0;
+        HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_));
+        prof_mark("norm_quant");
+        const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
+        float *outs[3] = {q_, k_, v_};
+        HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
+        for (int t = 0; t < T; t++) {   // biases are rare on this architecture (one tiny launch per token when present)
+            if (L.bq.valid()) HIP_TRY(launch_add(q_ + (size_t)t * E, (const float *)L.bq.data, q_ + (size_t)t * E, (int64_t)E, stream_));
+            if (L.bk.valid()) HIP_TRY(launch_add(k_ + (size_t)t * G * D, (const float *)L.bk.data, k_ + (size_t)t * G * D, (int64_t)G * D, stream_));
+            if (L.bv.valid()) HIP_TRY(launch_add(v_ + (size_t)t * G * D, (const float *)L.bv.data, v_ + (size_t)t * G * D, (int64_t)G * D, stream_));
+        }
+        prof_mark("qkv");
+        HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
+        prof_mark("rope_kv");
+        AttnArgs aa{};
+        aa.q = q_; aa.out = att_; aa.kv = kv_[(size_t)il]; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
+        aa.T = T; aa.H = H; aa.G = G; aa.D = D; aa.n_ctx = (int)cp.n_ctx;
+        aa.cell_pos = d_cell_pos_; aa.cell_seq = d_cell_seq_; aa.tok_pos = d_pos_; aa.tok_seq = d_seq_;
+        aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_; aa.splits = att_splits_;
+        HIP_TRY(launch_flash_attn(aa, stream_));
+        prof_mark("attn");
+        const bool o_q = is_quant(L.wo.type);
+        if (o_q) HIP_TRY(launch_quantize(att_, E, T, aq_o_, L.wo.type != T_Q8_0, L.wo.type == T_Q8_0, stream_));
+        prof_mark("quant");
+        HIP_TRY(linear(L.wo, aq_o_, att_, E, T, x_, E, x_, EPI_ADD));
+        prof_mark("attn_out");
+
+        // --- feed-forward block
+        if (hp.n_expert > 0) {
+            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, xn_, &aq_e_,
+                                         L.gate_exps.type != T_Q8_0 || L.up_exps.type != T_Q8_0, L.gate_exps.type == T_Q8_0 || L.up_exps.type == T_Q8_0, stream_));
+            prof_mark("norm_quant");
+            HIP_TRY(launch_mmv_float(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, router_, hp.n_expert, nullptr, stream_));
+            HIP_TRY(launch_moe_route(router_, T, hp.n_expert, hp.n_expert_used, moe_ids_, moe_w_, stream_));
+            prof_mark("moe_route");
+            const int KU = hp.n_expert_used;
+            for (int t = 0; t < T; t++) {
+                for (int j = 0; j < KU; j++) {
+                    const int32_t *esel = moe_ids_ + (size_t)t * KU + j;
+                    MMVQArgs a{};
+                    a.n_seg = 2; a.K = E; a.T = 1; a.epi = EPI_SWIGLU;
+                    a.seg[0] = make_seg(L.gate_exps, ffn_ + (size_t)t * FF, FF, nullptr, esel);
+                    a.seg[1] = make_seg(L.up_exps, ffn_u_ + (size_t)t * FF, FF, nullptr, esel);
+                    chunk_act(a, aq_e_, E, t);
+                    if (L.gate_exps.type == L.up_exps.type) {
+                        HIP_TRY(launch_mmvq(a, stream_));
+                    } else {
+                        a.n_seg = 2; a.epi = EPI_STORE;
+                        HIP_TRY(launch_mmvq(a, stream_));
+                        HIP_TRY(launch_swiglu(ffn_ + (size_t)t * FF, ffn_u_ + (size_t)t * FF, ffn_ + (size_t)t * FF, FF, stream_));
+                    }
+                    HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                    MMVQArgs d{};
+                    d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE;
+                    d.seg[0] = make_seg(L.down_exps, moe_out_ + ((size_t)j * T + t) * E, E, nullptr, esel);
+                    chunk_act(d, aq_ff_, FF, 0);
+                    HIP_TRY(launch_mmvq(d, stream_));
+                }
+            }
+            HIP_TRY(launch_moe_combine(x_, moe_out_, moe_w_, T, E, KU, (size_t)T * E, stream_));
+            prof_mark("moe_ffn");
+        } else {
+            const bool gq = is_quant(L.gate.type), uq = is_quant(L.up.type);
+            const bool fk = (gq && L.gate.type != T_Q8_0) || (uq && L.up.type != T_Q8_0);
+            const bool f0 = L.gate.type == T_Q8_0 || L.up.type == T_Q8_0;
+            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
+            prof_mark("norm_quant");
+            if (gq && uq && L.gate.type == L.up.type) {
+                MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
+                HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_));
+            } else {
+                HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
+                HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
+                HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
+            }
+            prof_mark("ffn_gate_up");
+            if (is_quant(L.down.type)) HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
+            prof_mark("quant");
+            HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, T, x_, E, x_, EPI_ADD));
+            prof_mark("ffn_down");
+        }
+        if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
+    }
+    return hipSuccess;
+}
+
+hipError_t Context::run_output(int n_out, int out_base) {
+    if (n_out <= 0) return hipSuccess;
+    const HParams &hp = model->hp;
+    const int E = hp.n_embd, V = hp.n_vocab;
+    HIP_TRY(launch_gather_rows_f32(x_, d_outrow_, n_out, E, xo_, stream_));
+    const bool oq = is_quant(model->output.type);
+    HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
+                                 oq && model->output.type != T_Q8_0, model->output.type == T_Q8_0, stream_));
+    prof_mark("norm_quant");
+    float *lg = d_logits_ + (size_t)out_base * V;
+    HIP_TRY(linear(model->output, aq_e_, xn_, E, n_out, lg, V, nullptr, EPI_STORE));
+    prof_mark("lm_head");
+    HIP_TRY(launch_argmax_rows(lg, V, n_out, d_argmax_ + out_base, stream_));
+    prof_mark("argmax");
+    return hipSuccess;
+}
+
+int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
+                           const int8_t *flags, int out_base) {
+    const int slot = find_slot(n);
+    if (slot < 0) return 1;
+    for (int i = 0; i < n; i++) {
+        KVCell &c = cells_[(size_t)(slot + i)];
+        c.pos = pos[i]; c.seqs = seqmask[i]; c.delta = 0;
+    }
+    head_ = slot + n;
+    if (head_ >= (int)cells_.size()) head_ = 0;
+    int hi = 0;
+    for (int i = (int)cells_.size() - 1; i >= 0; i--) if (cells_[(size_t)i].pos >= 0) { hi = i + 1; break; }
+    n_kv_ = std::min((int)cp.n_ctx, (hi + 31) & ~31);
+
+    if (meta_dirty_) {   // sequence ops since the last batch: re-upload the whole cell table
+        std::vector<int32_t> cpos(cells_.size());
+        std::vector<uint64_t> cseq(cells_.size());
+        for (size_t i = 0; i < cells_.size(); i++) { cpos[i] = cells_[i].pos; cseq[i] = cells_[i].seqs; }
+        if (hipMemcpyAsync(d_cell_pos_, cpos.data(), cpos.size() * 4, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+            hipMemcpyAsync(d_cell_seq_, cseq.data(), cseq.size() * 8, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+            hipStreamSynchronize(stream_) != hipSuccess) { last_error = "cell table upload failed"; return -1; }
+        meta_dirty_ = false;
+    }
+    // stage token arrays
+    const size_t T = cp.n_ubatch;
+    int32_t *h_nkv = (int32_t *)h_stage_;
+    int32_t *h_tok = (int32_t *)(h_stage_ + 16), *h_pos = h_tok + T, *h_seq = h_pos + T, *h_cell = h_seq + T, *h_out = h_cell + T;
+    uint64_t *h_mask = (uint64_t *)(h_out + T);
+    h_nkv[0] = n_kv_;
+    int n_out = 0;
+    for (int i = 0; i < n; i++) {
+        h_tok[i] = tokens[i]; h_pos[i] = pos[i]; h_seq[i] = seq[i]; h_cell[i] = slot + i; h_mask[i] = seqmask[i];
+        if (flags[i]) h_out[n_out++] = i;
+    }
+    if (hipMemcpyAsync(d_stage_, h_stage_, stage_bytes_, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "token upload failed"; return -1; }
+
+    const int V = model->hp.n_vocab;
+    const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_;
+    hipError_t e = hipSuccess;
+    if (graph_ok) {
+        if (!graph_ready_) {
+            hipGraph_t g = nullptr;
+            e = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                hipError_t e2 = run_layers(1, true);
+                if (e2 == hipSuccess) e2 = run_output(1, 0);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, stream_);
+                e = hipStreamEndCapture(stream_, &g);
+                if (e2 != hipSuccess) e = e2;
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
+            graph_ready_ = true;
+        }
+        e = hipGraphLaunch(graph_exec_, stream_);
+    } else {
+        prof_begin();
+        e = run_layers(n, false);
+        if (e == hipSuccess) e = run_output(n_out, out_base);
+        if (e == hipSuccess && n_out > 0) e = hipMemcpyAsync(h_argmax_ + out_base, d_argmax_ + out_base, (size_t)n_out * 4, hipMemcpyDeviceToHost, stream_);
+        prof_end();
+    }
+    if (e != hipSuccess) { last_error = std::string("decode failed: ") + hipGetErrorString(e) + " / " + last_error_string(); return -1; }
+    dbg_tokens_ = n;
+    (void)V;
+    return 0;
+}
+
+int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, const int32_t *n_seq_id, int32_t *const *seq_id,
+                    const int8_t *logits_flags) {
+    if (n_tokens <= 0) { last_error = "empty batch"; return -1; }
+    if (hipSetDevice(model->device) != hipSuccess) return -1;
+    const HParams &hp = model->hp;
+    if (has_shift_) apply_k_shift();
+    if (debug_taps_ && !dbg_) dbg_ = (float *)dalloc((size_t)hp.n_layer * cp.n_ubatch * hp.n_embd * 4);
+
+    std::vector<int32_t> seq((size_t)n_tokens);
+    std::vector<uint64_t> mask((size_t)n_tokens);
+    std::vector<int8_t> flags((size_t)n_tokens);
+    int n_out = 0;
+    out_row_of_batch_.assign((size_t)n_tokens, -1);
+    for (int i = 0; i < n_tokens; i++) {
+        if (tokens[i] < 0 || tokens[i] >= hp.n_vocab) { last_error = "token id out of range"; return -1; }
+        uint64_t mk = 0;
+        const int ns = n_seq_id ? n_seq_id[i] : 1;
+        for (int j = 0; j < ns; j++) {
+            const int s = seq_id ? seq_id[i][j] : 0;
+            if (s < 0 || s >= 64) { last_error = "seq id out of range"; return -1; }
+            mk |= 1ull << s;
+        }
+        seq[(size_t)i] = seq_id ? seq_id[i][0] : 0;
+        mask[(size_t)i] = mk;
+        // llama_decode: logits == NULL -> only the last token
+        flags[(size_t)i] = logits_flags ? (logits_flags[i] != 0) : (i == n_tokens - 1);
+        if (flags[(size_t)i]) out_row_of_batch_[(size_t)i] = n_out++;
+    }
+    // logits buffers
+    if ((size_t)n_out > logits_cap_rows_) {
+        (void)hipStreamSynchronize(stream_);
+        if (d_logits_) { (void)hipFree(d_logits_); allocs_.erase(std::find(allocs_.begin(), allocs_.end(), (void *)d_logits_)); }
+        if (h_logits_) (void)hipHostFree(h_logits_);
+        if (d_argmax_) { /* sized n_ubatch; regrow below if needed */ }
+        const size_t rows = std::max<size_t>((size_t)n_out, 1);
+        d_logits_ = (float *)dalloc(rows * hp.n_vocab * 4);
+        if (!d_logits_ || hipHostMalloc((void **)&h_logits_, rows * hp.n_vocab * 4, hipHostMallocDefault) != hipSuccess) { last_error = "logits alloc failed"; return -1; }
+        if (rows > cp.n_ubatch) {
+            d_argmax_ = (int32_t *)dalloc(rows * 4);
+            (void)hipHostFree(h_argmax_);
+            if (hipHostMalloc((void **)&h_argmax_, rows * 4, hipHostMallocDefault) != hipSuccess) return -1;
+        }
+        logits_cap_rows_ = rows;
+        graph_ready_ = false;
+        if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    }
+    n_out_last_ = n_out;
+    logits_fetched_ = false;
+    argmax_fetched_ = false;
+
+    const std::vector<KVCell> saved = cells_;
+    const int saved_head = head_;
+    int out_base = 0;
+    for (int i0 = 0; i0 < n_tokens; i0 += (int)cp.n_ubatch) {
+        const int n = std::min((int)cp.n_ubatch, n_tokens - i0);
+        const int rc = decode_ubatch(n, tokens + i0, pos + i0, seq.data() + i0, mask.data() + i0, flags.data() + i0, out_base);
+        if (rc != 0) {
+            cells_ = saved; head_ = saved_head; meta_dirty_ = true;
+            return rc;
+        }
+        for (int i = 0; i < n; i++) out_base += flags[(size_t)(i0 + i)] ? 1 : 0;
+    }
+    return 0;
+}
+
+void Context::synchronize() { (void)hipStreamSynchronize(stream_); }
+
+float *Context::logits_ith(int i) {
+    if (i < 0) i += (int)out_row_of_batch_.size();
+    if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return nullptr;
+    if (!logits_fetched_) {
+        if (hipMemcpyAsync(h_logits_, d_logits_, (size_t)n_out_last_ * model->hp.n_vocab * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return nullptr;
+        if (hipStreamSynchronize(stream_) != hipSuccess) return nullptr;
+        logits_fetched_ = true;
+    }
+    return h_logits_ + (size_t)out_row_of_batch_[(size_t)i] * model->hp.n_vocab;
+}
+
+int32_t Context::argmax_ith(int i) {
+    if (i < 0) i += (int)out_row_of_batch_.size();
+    if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return -1;
+    if (!argmax_fetched_) {
+        if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
+        argmax_fetched_ = true;
+    }
+    return h_argmax_[out_row_of_batch_[(size_t)i]];
+}
+
+int Context::debug_layer_out(int il, float *dst, size_t cap) {
+    const HParams &hp = model->hp;
+    if (!dbg_ || il < 0 || il >= hp.n_layer) return -1;
+    const size_t n = (size_t)dbg_tokens_ * hp.n_embd;
+    if (cap < n) return -1;
+    (void)hipStreamSynchronize(stream_);
+    if (hipMemcpy(dst, dbg_ + (size_t)il * cp.n_ubatch * hp.n_embd, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return dbg_tokens_;
+}
+
+// every weight tensor once, as one decoded token reads them (no attention, no norms): the dominant kernel
+double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
+    const HParams &hp = model->hp;
+    const int E = hp.n_embd, FF = hp.n_ff;
+    (void)hipMemsetAsync(x_, 0, (size_t)E * 4, stream_);
+    uint64_t bytes = 0;
+    auto sweep = [&](bool count) -> hipError_t {
+        for (int il = 0; il < hp.n_layer; il++) {
+            const LayerWeights &L = model->layers[(size_t)il];
+            if (hp.n_expert > 0) continue;
+            const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
+            float *outs[3] = {q_, k_, v_};
+            HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
+            HIP_TRY(linear(L.wo, aq_o_, att_, E, 1, xo_, E, nullptr, EPI_STORE));
+            if (is_quant(L.gate.type) && L.gate.type == L.up.type) {
+                MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
+                HIP_TRY(mmvq_tokens(segs, 2, E, 1, EPI_SWIGLU, aq_e_, stream_));
+            }
+            HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, nullptr, EPI_STORE));
+            if (count) bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + L.wo.ggml_bytes + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
+        }
+        HIP_TRY(linear(model->output, aq_e_, xn_, E, 1, d_logits_, hp.n_vocab, nullptr, EPI_STORE));
+        if (count) bytes += model->output.ggml_bytes;
+        return hipSuccess;
+    };
+    if (!d_logits_) { d_logits_ = (float *)dalloc((size_t)hp.n_vocab * 4); logits_cap_rows_ = 0; }
+    if (sweep(true) != hipSuccess) return -1.0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipStreamSynchronize(stream_);
+    (void)hipEventRecord(e0, stream_);
+    for (int i = 0; i < iters; i++) if (sweep(false) != hipSuccess) return -1.0;
+    (void)hipEventRecord(e1, stream_);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (bytes_out) *bytes_out = bytes;
+    return (double)ms * 1000.0 / iters;
+}
+
+}  // namespace mi355

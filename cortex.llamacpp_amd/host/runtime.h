@@ -1,0 +1,168 @@
+// runtime.h — model residency and the decode executor (host C++ above the HIP kernels).
+//
+// Plays the role of the llama.cpp objects the reference holds through common_init_result
+// (src/llama_server_context.cc:207-209): llama_model (weights on device), llama_context (KV cache,
+// batch execution, logits), llama_kv_cache (cells with positions and sequence sets).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../csrc/kernels.h"
+#include "gguf.h"
+
+namespace mi355 {
+
+struct DevTensor {
+    std::string name;
+    int type = 0;
+    int64_t K = 0;          // ne[0]: contraction / row length
+    int64_t N = 0;          // rows per expert (ne[1])
+    int64_t n_expert = 1;   // ne[2] for *_exps tensors
+    uint8_t *data = nullptr;
+    size_t row_bytes = 0;   // device row stride
+    size_t bytes = 0;       // device bytes
+    size_t ggml_bytes = 0;  // on-disk bytes
+    bool valid() const { return data != nullptr; }
+};
+
+struct LayerWeights {
+    DevTensor attn_norm, wq, wk, wv, wo, bq, bk, bv;
+    DevTensor ffn_norm, gate, up, down;
+    DevTensor gate_inp, gate_exps, up_exps, down_exps;
+};
+
+struct HParams {
+    std::string arch;
+    int n_embd = 0, n_layer = 0, n_ff = 0, n_head = 0, n_head_kv = 0, n_rot = 0, n_vocab = 0;
+    int n_expert = 0, n_expert_used = 0, head_dim = 0, n_ctx_train = 0;
+    float eps = 1e-5f, rope_base = 10000.0f, rope_scale = 1.0f;
+    int rope_neox = 0;
+};
+
+struct Model {
+    HParams hp;
+    std::unique_ptr<GGUFFile> file;
+    std::string path, desc;
+    int device = 0;
+    std::vector<uint8_t *> arenas;      // hipMalloc'd blocks
+    DevTensor tok_embd, out_norm, output, rope_freqs;
+    std::vector<LayerWeights> layers;
+    uint64_t device_bytes = 0, host_bytes = 0, file_tensor_bytes = 0, bytes_per_token = 0;
+    ~Model();
+};
+
+Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status);
+
+struct KVCell {
+    int32_t pos = -1;
+    int32_t delta = 0;
+    uint64_t seqs = 0;
+};
+
+struct ContextParams {
+    uint32_t n_ctx = 512, n_batch = 2048, n_ubatch = 512, n_seq_max = 1;
+    int type_k = T_F16, type_v = T_F16;
+    bool flash_attn = true, embeddings = false, use_graphs = true;
+};
+
+struct ProfileEntry { std::string name; float us; };
+
+class Context {
+  public:
+    Context(Model *m, const ContextParams &p);
+    ~Context();
+    bool init(std::string &err);
+
+    // llama_decode semantics: 0 ok, 1 no KV slot, <0 error
+    int decode(int n_tokens, const int32_t *tokens, const int32_t *pos, const int32_t *n_seq_id, int32_t *const *seq_id,
+               const int8_t *logits_flags);
+    float *logits_ith(int i);
+    int32_t argmax_ith(int i);
+    void synchronize();
+
+    void kv_clear();
+    bool kv_seq_rm(int seq, int p0, int p1);
+    void kv_seq_cp(int src, int dst, int p0, int p1);
+    void kv_seq_add(int seq, int p0, int p1, int delta);
+    int kv_used_cells() const;
+
+    int debug_layer_out(int il, float *dst, size_t cap);
+    void set_debug_taps(bool on) { debug_taps_ = on; }
+    void set_profile(bool on) { profile_ = on; }
+    const std::vector<ProfileEntry> &last_profile() const { return last_profile_; }
+    double bench_weight_sweep(int iters, uint64_t *bytes);
+
+    Model *model;
+    ContextParams cp;
+    uint64_t device_bytes = 0;
+    std::string last_error;
+    bool embeddings_enabled = false;
+
+  private:
+    struct Bufs;
+    int decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
+                      const int8_t *flags, int out_base);
+    int find_slot(int n);
+    void apply_k_shift();
+    hipError_t run_layers(int T, bool graph_mode);
+    hipError_t run_output(int n_out, int out_base);
+    hipError_t linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
+                      const float *resid, int epi);
+    hipError_t linear_multi(const DevTensor *const *ws, float *const *outs, int n, const ActQuant &aq, const float *x_f32, int T);
+    void prof_mark(const char *name);
+    void prof_begin();
+    void prof_end();
+    void *dalloc(size_t bytes);
+
+    hipStream_t stream_ = nullptr;
+    std::vector<void *> allocs_;
+    std::vector<KVCell> cells_;
+    int head_ = 0;
+    bool has_shift_ = false;
+    bool meta_dirty_ = true;
+
+    // device state
+    std::vector<KVLayerView> kv_;
+    int32_t *d_cell_pos_ = nullptr;
+    uint64_t *d_cell_seq_ = nullptr;
+    int32_t *d_delta_ = nullptr;
+    // per-ubatch token arrays (device) + pinned host staging
+    int32_t *d_tok_ = nullptr, *d_pos_ = nullptr, *d_seq_ = nullptr, *d_cell_ = nullptr, *d_nkv_ = nullptr, *d_outrow_ = nullptr;
+    uint64_t *d_seqmask_ = nullptr;
+    uint8_t *h_stage_ = nullptr;    // pinned
+    size_t stage_bytes_ = 0;
+    uint8_t *d_stage_ = nullptr;
+    // activations
+    float *x_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *ffn_ = nullptr, *ffn_u_ = nullptr;
+    float *xo_ = nullptr, *router_ = nullptr, *moe_out_ = nullptr;
+    int32_t *moe_ids_ = nullptr;
+    float *moe_w_ = nullptr;
+    ActQuant aq_e_, aq_ff_, aq_o_;
+    float *att_part_ = nullptr;
+    int att_splits_ = 1;
+    float *dbg_ = nullptr;
+    bool debug_taps_ = false;
+    int dbg_tokens_ = 0;
+    // outputs
+    float *d_logits_ = nullptr, *h_logits_ = nullptr;
+    int32_t *d_argmax_ = nullptr, *h_argmax_ = nullptr;
+    size_t logits_cap_rows_ = 0;
+    std::vector<int> out_row_of_batch_;   // batch index -> output row or -1
+    int n_out_last_ = 0;
+    bool logits_fetched_ = false, argmax_fetched_ = false;
+    // graph for the single-token decode step
+    hipGraphExec_t graph_exec_ = nullptr;
+    bool graph_ready_ = false;
+    // profiling
+    bool profile_ = false;
+    std::vector<std::pair<std::string, hipEvent_t>> prof_events_;
+    std::vector<ProfileEntry> last_profile_;
+    int n_kv_ = 0;
+};
+
+}  // namespace mi355

@@ -1,0 +1,194 @@
+/*
+ * include/mi355_llama.h — C-ABI of the MI355X-native GGUF inference backend.
+ *
+ * This is the drop-in boundary for the ONE hot path of cortex.llamacpp: everything the
+ * reference's continuous-batching loop (src/llama_server_context.cc, LlamaServerContext) calls
+ * in llama.cpp's `llama.h` to run a transformer forward on a GGUF model.  Each entry point
+ * below names the upstream symbol it stands in for and the reference call site that consumes it
+ * (file:line under /root/reference).  Plain C types, opaque handles, int status codes, no
+ * exceptions, caller-owned buffers.  All arithmetic behind it is hand-written HIP for gfx950;
+ * there is no CPU fallback: every call fails with MI355_ERR_NO_DEVICE when no GPU is present.
+ *
+ * Thread-safety: like llama.h — a context must be driven from one thread at a time (the
+ * reference drives it from the single DoBackgroundTasks thread, llama_server_context.cc:280).
+ */
+#ifndef MI355_LLAMA_H
+#define MI355_LLAMA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_API __attribute__((visibility("default")))
+
+typedef struct mi355_model   mi355_model;
+typedef struct mi355_context mi355_context;
+
+typedef int32_t mi355_token;
+typedef int32_t mi355_pos;
+typedef int32_t mi355_seq_id;
+
+enum mi355_status {
+    MI355_OK            = 0,
+    MI355_ERR_NO_DEVICE = -100,  /* no MI355X / HIP runtime unavailable */
+    MI355_ERR_IO        = -101,
+    MI355_ERR_FORMAT    = -102,  /* not a GGUF v2/v3 file, or unsupported arch / tensor type */
+    MI355_ERR_ARG       = -103,
+    MI355_ERR_OOM       = -104,
+    MI355_ERR_HIP       = -105,
+};
+
+/* ggml type ids as stored in GGUF (upstream ggml.h enum ggml_type; used at llama_engine.cc:272-281) */
+enum mi355_type {
+    MI355_TYPE_F32 = 0, MI355_TYPE_F16 = 1, MI355_TYPE_Q4_0 = 2, MI355_TYPE_Q8_0 = 8,
+    MI355_TYPE_Q4_K = 12, MI355_TYPE_Q5_K = 13, MI355_TYPE_Q6_K = 14, MI355_TYPE_Q8_K = 15,
+};
+
+/* ------------------------------------------------------------------ backend */
+/* llama_backend_init (llama_engine.cc:688).  Returns MI355_OK or MI355_ERR_NO_DEVICE. */
+MI355_API int         mi355_backend_init(void);
+MI355_API void        mi355_backend_free(void);
+MI355_API int         mi355_device_count(void);
+/* last error text of the calling thread ("" if none) */
+MI355_API const char *mi355_last_error(void);
+/* ggml_time_us (llama_client_slot.cc:57; llama_server_context.cc:417,1314,1378,1685) */
+MI355_API int64_t     mi355_time_us(void);
+/* llama_print_system_info (llama_engine.cc:702) */
+MI355_API const char *mi355_print_system_info(void);
+
+/* ------------------------------------------------------------------ model */
+typedef struct mi355_model_params {
+    int32_t n_gpu_layers;   /* `ngl` (llama_engine.cc:609-611); this backend is device-only: must be > 0 */
+    int32_t main_gpu;       /* HIP device ordinal */
+    int32_t use_mmap;       /* `use_mmap` (llama_engine.cc:649) */
+    int32_t use_mlock;      /* `mlock` (llama_engine.cc:569-571); accepted, ignored */
+    /* row-split tensor parallelism over RCCL (new keys proposed in SURVEY.md §2b) */
+    int32_t tp_rank;        /* 0 when tp_size <= 1 */
+    int32_t tp_size;        /* 1 = whole model on this GPU */
+} mi355_model_params;
+
+MI355_API mi355_model_params mi355_model_default_params(void);
+/* common_init_from_params -> llama_model_load_from_file (llama_server_context.cc:207) */
+MI355_API mi355_model *mi355_model_load_from_file(const char *path_gguf, mi355_model_params params);
+MI355_API void         mi355_model_free(mi355_model *model);
+
+MI355_API int32_t  mi355_model_n_vocab(const mi355_model *m);       /* llama_vocab_n_tokens (ctx.cc:512) */
+MI355_API int32_t  mi355_model_n_embd(const mi355_model *m);        /* llama_n_embd (ctx.cc:218,1033,1098) */
+MI355_API int32_t  mi355_model_n_layer(const mi355_model *m);
+MI355_API int32_t  mi355_model_n_head(const mi355_model *m);
+MI355_API int32_t  mi355_model_n_head_kv(const mi355_model *m);
+MI355_API int32_t  mi355_model_n_ctx_train(const mi355_model *m);
+MI355_API uint64_t mi355_model_size(const mi355_model *m);          /* llama_model_size (llama_engine.cc:482) */
+/* patches/0001-Add-API-query-buffer-size.patch:14-15,46-64 (used at llama_engine.cc:475-476) */
+MI355_API uint64_t mi355_model_cpu_buffer(const mi355_model *m);    /* llama_get_cpu_buffer  -> `ram`  */
+MI355_API uint64_t mi355_model_other_buffer(const mi355_model *m);  /* llama_get_other_buffer -> `vram` */
+/* algorithmic weight bytes one decoded token reads; for roofline reporting */
+MI355_API uint64_t mi355_model_bytes_per_token(const mi355_model *m);
+MI355_API const char *mi355_model_desc(const mi355_model *m);
+/* GGUF metadata lookup: returns 1 and fills buf if `key` exists and is a string/scalar */
+MI355_API int mi355_model_meta_str(const mi355_model *m, const char *key, char *buf, size_t buf_size);
+
+/* ------------------------------------------------------------------ context */
+typedef struct mi355_context_params {
+    uint32_t n_ctx;        /* `ctx_len` total KV cells (llama_engine.cc:612) */
+    uint32_t n_batch;      /* `n_batch` (llama_engine.cc:617) */
+    uint32_t n_ubatch;     /* `n_ubatch` (llama_engine.cc:618) */
+    uint32_t n_seq_max;    /* `n_parallel` (llama_engine.cc:620) */
+    int32_t  type_k;       /* `cache_type` -> mi355_type {F16,Q8_0,Q4_0} (llama_engine.cc:628-637) */
+    int32_t  type_v;
+    int32_t  flash_attn;   /* `flash_attn`, forced on for quantised caches (llama_engine.cc:639-647) */
+    int32_t  embeddings;   /* `embedding` (llama_engine.cc:613-616) */
+    int32_t  use_graphs;   /* capture the single-token decode step in a hipGraph (default 1) */
+} mi355_context_params;
+
+MI355_API mi355_context_params mi355_context_default_params(void);
+/* common_init_from_params -> llama_init_from_model (llama_server_context.cc:207-209) */
+MI355_API mi355_context *mi355_context_new(mi355_model *model, mi355_context_params params);
+MI355_API void           mi355_context_free(mi355_context *ctx);
+
+MI355_API uint32_t mi355_n_ctx(const mi355_context *ctx);      /* llama_n_ctx   (ctx.cc:236) */
+MI355_API uint32_t mi355_n_batch(const mi355_context *ctx);    /* llama_n_batch (ctx.cc:1351) */
+MI355_API uint32_t mi355_n_ubatch(const mi355_context *ctx);   /* llama_n_ubatch(ctx.cc:1352) */
+MI355_API uint64_t mi355_context_device_bytes(const mi355_context *ctx); /* KV + activations on device */
+
+/* llama_batch exactly as the reference fills it (llama_server_context.cc:265,1630-1635) */
+typedef struct mi355_batch {
+    int32_t        n_tokens;
+    mi355_token   *token;     /* [n_tokens] */
+    float         *embd;      /* unused (NULL) on this path */
+    mi355_pos     *pos;       /* [n_tokens] */
+    int32_t       *n_seq_id;  /* [n_tokens] */
+    mi355_seq_id **seq_id;    /* [n_tokens][n_seq_id] */
+    int8_t        *logits;    /* [n_tokens] != 0 => produce logits for that row */
+} mi355_batch;
+
+MI355_API mi355_batch mi355_batch_init(int32_t n_tokens, int32_t embd, int32_t n_seq_max); /* llama_batch_init (ctx.cc:265) */
+MI355_API void        mi355_batch_free(mi355_batch batch);
+
+/* llama_decode (llama_server_context.cc:654,1085,1103,1635).
+ * Returns 0 on success, 1 if no KV slot could be found for the batch (caller halves n_batch and
+ * retries, ctx.cc:1636-1663), < 0 on a fatal error.  Logits rows are host-visible afterwards. */
+MI355_API int32_t mi355_decode(mi355_context *ctx, mi355_batch batch);
+/* llama_get_logits_ith as used through common_sampler_sample(ctx, idx) (ctx.cc:1679-1680).
+ * i indexes the batch of the last mi355_decode; NULL if that row had logits[i] == 0. */
+MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);
+/* device-side greedy front end: argmax token of row i without copying the row */
+MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
+/* llama_set_embeddings (ctx.cc:299) */
+MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
+MI355_API void    mi355_synchronize(mi355_context *ctx);
+
+/* KV cache bookkeeping (ctx.cc:287; 661,1547; 1288,1540,1542; 1290) */
+MI355_API void    mi355_kv_cache_clear(mi355_context *ctx);
+MI355_API int32_t mi355_kv_cache_seq_rm(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1); /* 1 = ok */
+MI355_API void    mi355_kv_cache_seq_cp(mi355_context *ctx, mi355_seq_id src, mi355_seq_id dst, mi355_pos p0, mi355_pos p1);
+MI355_API void    mi355_kv_cache_seq_add(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1, mi355_pos delta);
+MI355_API int32_t mi355_kv_cache_used_cells(const mi355_context *ctx);
+
+/* debugging taps for parity tests (enable before decode): residual stream after layer `il` for the last
+ * decoded micro-batch, copied to dst[n_tokens * n_embd]; returns n_tokens or < 0 */
+MI355_API void    mi355_debug_enable_taps(mi355_context *ctx, int32_t enabled);
+MI355_API int32_t mi355_debug_layer_out(mi355_context *ctx, int32_t il, float *dst, size_t dst_floats);
+
+/* ------------------------------------------------------------------ per-op entry points
+ * Host-buffer wrappers around the individual HIP kernels, for parity tests and rocprof.
+ * Each copies inputs to the device, runs the same kernel the decode graph uses, copies back. */
+
+/* quantize_row_q8_K / quantize_row_q8_0 (activation side).  out receives ggml-layout blocks. */
+MI355_API int mi355_op_quantize_act(int32_t act_type, const float *x, int64_t n_per_row, int64_t n_rows, void *out_blocks);
+/* y[T][N] = W[N][K] . x[T][K]; W is ggml-layout blocks of `type`.  isum/msum (nullable):
+ * per (token, row, block) integer partial sums for bit-exact checks. */
+MI355_API int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const float *x, int64_t T,
+                               float *y, int32_t *isum, int32_t *msum);
+MI355_API int mi355_op_rms_norm_mul(const float *x, const float *w, int64_t n, int64_t T, float eps, float *y);
+MI355_API int mi355_op_rope(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, const int32_t *pos, int64_t T,
+                            float freq_base, float freq_scale, const float *freq_factors, int32_t neox);
+MI355_API int mi355_op_get_rows(int32_t type, const void *table, int64_t row_elems, int64_t n_rows_table,
+                                const int32_t *ids, int64_t n_ids, float *dst);
+MI355_API int mi355_op_swiglu(const float *gate, const float *up, int64_t n, float *y);
+MI355_API int mi355_op_soft_max(const float *x, const float *mask, int64_t n, int64_t rows, float scale, float *y);
+/* flash_attn_ext for T query tokens: K/V given as ggml-layout rows [n_cells][n_head_kv*head_dim] of type_k/type_v;
+ * visibility: cell c is visible to token t iff cell_pos[c] >= 0 && cell_pos[c] <= q_pos[t]. */
+MI355_API int mi355_op_flash_attn(const float *q, int64_t T, int32_t n_head, int32_t n_head_kv, int32_t head_dim,
+                                  int32_t type_k, const void *k, int32_t type_v, const void *v, int32_t n_cells,
+                                  const int32_t *cell_pos, const int32_t *q_pos, float scale, float *out);
+
+/* ------------------------------------------------------------------ measurement hooks (bench.py) */
+/* Streams `bytes` through a read-only reduction kernel `iters` times; returns achieved GB/s (HIP events). */
+MI355_API double mi355_bench_hbm_read(size_t bytes, int iters);
+/* Per-kernel-class device time of the LAST decode call in microseconds, measured with HIP events on the
+ * context's stream (eager mode only).  names/us arrays of capacity cap; returns count. */
+MI355_API int32_t mi355_profile_last_decode(mi355_context *ctx, const char **names, float *us, int32_t cap);
+MI355_API void    mi355_profile_enable(mi355_context *ctx, int32_t enabled);
+/* Runs the dominant decode kernel (quantised mat-vec over every weight tensor of the model, one token)
+ * `iters` times on the context's stream, timed with HIP events; returns mean microseconds per sweep and
+ * writes the algorithmic bytes of one sweep. */
+MI355_API double  mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_LLAMA_H */
