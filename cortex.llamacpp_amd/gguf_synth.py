@@ -44,9 +44,9 @@ def row_bytes(t: int, n: int) -> int:
 def random_blocks(rng: np.random.Generator, t: int, n_elems: int, std: float) -> np.ndarray:
     """n_elems weights of ggml type t as raw bytes; dequantised std ~= `std`, mean ~= 0."""
     if t == F32:
-        return (rng.standard_normal(n_elems, dtype=np.float32) * std).view(np.uint8)
+        return (rng.standard_normal(n_elems, dtype=np.float32) * np.float32(std)).astype("<f4").view(np.uint8)
     if t == F16:
-        return (rng.standard_normal(n_elems, dtype=np.float32) * std).astype("<f2").view(np.uint8)
+        return (rng.standard_normal(n_elems, dtype=np.float32) * np.float32(std)).astype("<f2").view(np.uint8)
     nb = n_elems // BLOCK_ELEMS[t]
     raw = rng.integers(0, 256, size=nb * BLOCK_BYTES[t], dtype=np.uint8)
     blk = raw.view(BLOCK_DTYPE[t])

@@ -192,6 +192,7 @@ Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
 Context::~Context() {
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (stage_event_) (void)hipEventDestroy(stage_event_);
     for (auto &pe : prof_events_) (void)hipEventDestroy(pe.second);
     for (void *p : allocs_) (void)hipFree(p);
     if (h_stage_) (void)hipHostFree(h_stage_);
@@ -265,17 +266,18 @@ bool Context::init(std::string &err) {
     d_cell_seq_ = (uint64_t *)dalloc(NC * 8);
     d_delta_ = (int32_t *)dalloc(NC * 4);
     // token staging block: [nkv x4][tok][pos][seq][cell][outrow][seqmask]
-    stage_bytes_ = 16 + T * 4 * 5 + T * 8;
+    const size_t Tp = (T + 1) & ~(size_t)1;   // keeps the u64 seqmask array 8-byte aligned
+    stage_bytes_ = 16 + Tp * 4 * 5 + Tp * 8;
     stage_bytes_ = (stage_bytes_ + 15) & ~(size_t)15;
     d_stage_ = (uint8_t *)dalloc(stage_bytes_);
     if (hipHostMalloc((void **)&h_stage_, stage_bytes_, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     d_nkv_ = (int32_t *)d_stage_;
     d_tok_ = (int32_t *)(d_stage_ + 16);
-    d_pos_ = d_tok_ + T;
-    d_seq_ = d_pos_ + T;
-    d_cell_ = d_seq_ + T;
-    d_outrow_ = d_cell_ + T;
-    d_seqmask_ = (uint64_t *)(d_outrow_ + T);
+    d_pos_ = d_tok_ + Tp;
+    d_seq_ = d_pos_ + Tp;
+    d_cell_ = d_seq_ + Tp;
+    d_outrow_ = d_cell_ + Tp;
+    d_seqmask_ = (uint64_t *)(d_outrow_ + Tp);
 
     x_ = (float *)dalloc(T * E * 4);
     xn_ = (float *)dalloc(T * E * 4);
@@ -622,8 +624,9 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
             hipStreamSynchronize(stream_) != hipSuccess) { last_error = "cell table upload failed"; return -1; }
         meta_dirty_ = false;
     }
-    // stage token arrays
-    const size_t T = cp.n_ubatch;
+    // stage token arrays (the pinned block may still be in flight from the previous micro-batch)
+    if (stage_event_) (void)hipEventSynchronize(stage_event_);
+    const size_t T = ((size_t)cp.n_ubatch + 1) & ~(size_t)1;
     int32_t *h_nkv = (int32_t *)h_stage_;
     int32_t *h_tok = (int32_t *)(h_stage_ + 16), *h_pos = h_tok + T, *h_seq = h_pos + T, *h_cell = h_seq + T, *h_out = h_cell + T;
     uint64_t *h_mask = (uint64_t *)(h_out + T);
@@ -634,6 +637,8 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         if (flags[i]) h_out[n_out++] = i;
     }
     if (hipMemcpyAsync(d_stage_, h_stage_, stage_bytes_, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "token upload failed"; return -1; }
+    if (!stage_event_) (void)hipEventCreateWithFlags(&stage_event_, hipEventDisableTiming);
+    if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
     const int V = model->hp.n_vocab;
     const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_;

@@ -137,6 +137,7 @@ class Context {
     uint8_t *h_stage_ = nullptr;    // pinned
     size_t stage_bytes_ = 0;
     uint8_t *d_stage_ = nullptr;
+    hipEvent_t stage_event_ = nullptr;
     // activations
     float *x_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *ffn_ = nullptr, *ffn_u_ = nullptr;
     float *xo_ = nullptr, *router_ = nullptr, *moe_out_ = nullptr;

