@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py — decode (and prefill) throughput of the MI355X-native GGUF backend on BASELINE.json's headline config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): Llama-3-8B-Instruct Q4_K_M, flash_attn,
+KV cache q8_0, n_ctx 4096, synthetic GGUF (exact shapes / type mix, seeded random valid blocks), synthetic prompt
+(seeded uniform token ids).  One "step" = one mi355_decode (llama_decode) call on a single new token with its logits
+row made host-visible, i.e. one pass of the hot path; the prompt is prefilled (and timed separately) first.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a full replica and decodes its own
+sequence; no data-path collective (weak scaling, "replicas").  value = N*K tokens / max-over-ranks time.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--config", default="llama-3-8b")
+    ap.add_argument("--ftype", default="q4_k_m")
+    ap.add_argument("--ctx", type=int, default=4096)
+    ap.add_argument("--prompt", type=int, default=512)
+    ap.add_argument("--cache-type", default="q8_0", choices=["f16", "q8_0", "q4_0"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--model-dir", default=os.environ.get("MI355_BENCH_DIR", "/tmp"))
+    ap.add_argument("--keep-model", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge.load_pkg()
+    gs = pkg.gguf_synth
+    pkg.Backend()
+
+    cfg = gs.CONFIGS[args.config]
+    path = os.path.join(args.model_dir, f"mi355-bench-{args.config}-{args.ftype}.gguf")
+    t0 = time.time()
+    if rank == 0 and not os.path.exists(path):
+        gs.write_synthetic_llama(path + ".tmp", cfg, args.ftype, seed=0xC0FFEE, with_vocab=False)
+        os.replace(path + ".tmp", path)
+    if dist is not None:
+        dist.barrier()
+    t_gen = time.time() - t0
+
+    KV = {"f16": 1, "q8_0": 8, "q4_0": 2}[args.cache_type]
+    t0 = time.time()
+    model = pkg.Model(path, main_gpu=local_rank if world > 1 else 0)
+    t_load = time.time() - t0
+    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=512, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
+
+    rng = np.random.default_rng(1234 + rank)
+    prompt = rng.integers(0, model.n_vocab, args.prompt)
+
+    # ---- prefill (timed separately; the reference's prompt_per_second, llama_client_slot.cc:62-76)
+    def prefill():
+        ctx.kv_clear()
+        t = time.perf_counter()
+        for i0 in range(0, args.prompt, 2048):           # n_batch chunks like UpdateSlots (ctx.cc:1628)
+            chunk = prompt[i0:i0 + 2048]
+            rc = ctx.decode(chunk, np.arange(i0, i0 + chunk.size))
+            assert rc == 0, rc
+        tok = ctx.argmax()
+        return time.perf_counter() - t, tok
+
+    prefill()                                            # warm (first-touch, graph capture happens on first decode step)
+    t_prefill, tok = prefill()
+
+    def step(tok, pos):
+        rc = ctx.decode([tok], [pos])
+        assert rc == 0, rc
+        ctx.logits_ready()                               # logits row host-visible = llama_decode's contract
+        return ctx.argmax()
+
+    pos = args.prompt
+    for _ in range(args.warmup):
+        tok = step(tok, pos)
+        pos += 1
+
+    def sync_all():
+        ctx.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tok = step(tok, pos)
+        pos += 1
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    sync_all()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank != 0:
+        ctx.close(); model.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    # ---- device-greedy variant: logits stay on the device, only the argmax crosses
+    ctx.close()
+    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=512, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True,
+                      logits_to_host=False)
+    _, tok = prefill()
+    pos = args.prompt
+    for _ in range(args.warmup):
+        ctx.decode([tok], [pos]); tok = ctx.argmax(); pos += 1
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.decode([tok], [pos])
+        tok = ctx.argmax()
+        pos += 1
+    ctx.synchronize()
+    dt_greedy = time.perf_counter() - t0
+
+    # ---- roofline of the dominant kernel (quantised mat-vec), HIP events on the kernel's own stream
+    sweep_us, sweep_bytes = ctx.weight_sweep_us(iters=5)
+    n_launch = cfg.n_layer * 4 + 1                        # qkv, attn_output, gate+up, down per layer + lm-head
+    achieved = sweep_bytes / (sweep_us * 1e-6) / 1e9
+    hbm_read = pkg.Backend().hbm_read_gbps(2 << 30, 5)
+
+    kv_pos_mid = args.prompt + args.warmup + args.steps // 2
+    b_per = {"f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.cache_type]
+    kv_bytes = 2 * cfg.n_layer * cfg.n_head_kv * cfg.head_dim * kv_pos_mid * b_per
+    tok_s = n_gpus * args.steps / dt
+    decode_frac = (model.bytes_per_token + kv_bytes) * (args.steps / dt) / (HBM_PEAK_GBPS * 1e9)
+
+    out = {
+        "metric": "decode tok/s, Llama-3-8B Q4_K_M GGUF (prefill tok/s in `prefill_tok_s`)",
+        "value": round(tok_s, 2),
+        "unit": "tok/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8 dot (Q4_K/Q6_K x Q8_K), f32 accumulate",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{cfg.name} {args.ftype.upper()} synthetic GGUF, flash_attn, cache_type={args.cache_type}, "
+                        f"n_ctx={args.ctx}, prompt={args.prompt}, greedy decode at pos {args.prompt + args.warmup}..{pos}",
+            "parallelism": "single GPU" if n_gpus == 1 else f"{n_gpus} replicas (one sequence per GPU, no collective)",
+            "weight_bytes_per_token": int(model.bytes_per_token),
+            "kv_bytes_per_token_mid": int(kv_bytes),
+        },
+        "prefill_tok_s": round(args.prompt / t_prefill, 1),
+        "prefill_ms": round(t_prefill * 1e3, 2),
+        "decode_tok_s_device_greedy": round(args.steps / dt_greedy, 2),
+        "decode_hbm_fraction_of_8TBps": round(decode_frac, 4),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "mmvq_kernel<1> (quantised mat-vec, all weight tensors of one token)",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "bytes_per_sweep": int(sweep_bytes),
+            "launches_per_sweep": n_launch,
+            "avg_launch_us": round(sweep_us / n_launch, 3),
+            "measured_stream_read_GBps": round(hbm_read, 1),
+        },
+        "load_s": round(t_load, 2),
+        "synth_s": round(t_gen, 2),
+    }
+
+    # ---- CPU baseline: the oracle (a port, not the reference binary) on the host cores, bounded sample
+    if not args.no_cpu_baseline and world == 1:
+        import oracle_py as oq
+        nth = os.cpu_count() or 1
+        om = oq.OracleModel(path)
+        oc = oq.OracleContext(om, 64, KV, KV, True, nth)
+        oc.decode(prompt[:4], np.arange(4))              # untimed warm-up (page-in of the mmap'd weights)
+        t0 = time.perf_counter()
+        t_ = int(prompt[4])
+        for s in range(args.cpu_steps):
+            r = oc.decode([t_], [4 + s])[0]
+            t_ = int(r.argmax())
+        dt_cpu = time.perf_counter() - t0
+        oc.close(); om.close()
+        out["cpu_baseline"] = {
+            "value": round(args.cpu_steps / dt_cpu, 3), "unit": "tok/s", "cores": nth, "kind": "port",
+            "sample": f"{args.cpu_steps} greedy decode steps at pos 4.. of the same GGUF with the scalar CPU restatement "
+                      f"(oracle/, OpenMP over weight rows, {nth} threads)",
+        }
+    else:
+        out["cpu_baseline"] = None
+
+    ctx.close(); model.close()
+    if not args.keep_model and world == 1 and os.environ.get("MI355_BENCH_KEEP") is None:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

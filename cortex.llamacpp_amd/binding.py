@@ -26,7 +26,7 @@ class ModelParams(C.Structure):
 class ContextParams(C.Structure):
     _fields_ = [("n_ctx", C.c_uint32), ("n_batch", C.c_uint32), ("n_ubatch", C.c_uint32), ("n_seq_max", C.c_uint32),
                 ("type_k", C.c_int32), ("type_v", C.c_int32), ("flash_attn", C.c_int32), ("embeddings", C.c_int32),
-                ("use_graphs", C.c_int32)]
+                ("use_graphs", C.c_int32), ("logits_to_host", C.c_int32)]
 
 
 class Batch(C.Structure):
@@ -252,12 +252,14 @@ class Model:
 
 class Context:
     def __init__(self, model: Model, n_ctx: int = 512, n_batch: int = 2048, n_ubatch: int = 512, n_seq_max: int = 1,
-                 type_k: int = F16, type_v: int = F16, flash_attn: bool = True, use_graphs: bool = True):
+                 type_k: int = F16, type_v: int = F16, flash_attn: bool = True, use_graphs: bool = True,
+                 logits_to_host: bool = True):
         self.lib = model.lib
         self.model = model
         cp = self.lib.mi355_context_default_params()
         cp.n_ctx, cp.n_batch, cp.n_ubatch, cp.n_seq_max = n_ctx, n_batch, n_ubatch, n_seq_max
         cp.type_k, cp.type_v, cp.flash_attn, cp.use_graphs = type_k, type_v, int(flash_attn), int(use_graphs)
+        cp.logits_to_host = int(logits_to_host)
         self.h = self.lib.mi355_context_new(model.h, cp)
         if not self.h:
             raise MI355Error(f"mi355_context_new failed: {_err(self.lib)}")
@@ -296,6 +298,11 @@ class Context:
         if not p:
             raise MI355Error("no logits for that batch row")
         return np.ctypeslib.as_array(p, shape=(self.model.n_vocab,)).copy()
+
+    def logits_ready(self, i: int = -1) -> None:
+        """Block until the logits row is host-visible (no numpy copy)."""
+        if not self.lib.mi355_get_logits_ith(self.h, i):
+            raise MI355Error("no logits for that batch row")
 
     def argmax(self, i: int = -1) -> int:
         return int(self.lib.mi355_get_argmax_ith(self.h, i))

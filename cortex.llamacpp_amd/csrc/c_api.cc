@@ -114,7 +114,7 @@ int mi355_model_meta_str(const mi355_model *m, const char *key, char *buf, size_
 mi355_context_params mi355_context_default_params(void) {
     mi355_context_params p{};
     p.n_ctx = 2048; p.n_batch = 2048; p.n_ubatch = 512; p.n_seq_max = 1;
-    p.type_k = MI355_TYPE_F16; p.type_v = MI355_TYPE_F16; p.flash_attn = 1; p.embeddings = 0; p.use_graphs = 1;
+    p.type_k = MI355_TYPE_F16; p.type_v = MI355_TYPE_F16; p.flash_attn = 1; p.embeddings = 0; p.use_graphs = 1; p.logits_to_host = 1;
     return p;
 }
 
@@ -127,6 +127,7 @@ mi355_context *mi355_context_new(mi355_model *model, mi355_context_params params
     cp.flash_attn = params.flash_attn != 0 || params.type_k != MI355_TYPE_F16 || params.type_v != MI355_TYPE_F16;
     cp.embeddings = params.embeddings != 0;
     cp.use_graphs = params.use_graphs != 0;
+    cp.logits_to_host = params.logits_to_host != 0;
     Context *c = new Context(model->m, cp);
     std::string err;
     if (!c->init(err)) { fail(err); delete c; return nullptr; }

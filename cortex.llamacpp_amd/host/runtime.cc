@@ -651,6 +651,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
                 hipError_t e2 = run_layers(1, true);
                 if (e2 == hipSuccess) e2 = run_output(1, 0);
                 if (e2 == hipSuccess) e2 = hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, stream_);
+                if (e2 == hipSuccess && cp.logits_to_host) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
                 e = hipStreamEndCapture(stream_, &g);
                 if (e2 != hipSuccess) e = e2;
             }
@@ -665,11 +666,12 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         e = run_layers(n, false);
         if (e == hipSuccess) e = run_output(n_out, out_base);
         if (e == hipSuccess && n_out > 0) e = hipMemcpyAsync(h_argmax_ + out_base, d_argmax_ + out_base, (size_t)n_out * 4, hipMemcpyDeviceToHost, stream_);
+        if (e == hipSuccess && n_out > 0 && cp.logits_to_host)
+            e = hipMemcpyAsync(h_logits_ + (size_t)out_base * V, d_logits_ + (size_t)out_base * V, (size_t)n_out * V * 4, hipMemcpyDeviceToHost, stream_);
         prof_end();
     }
     if (e != hipSuccess) { last_error = std::string("decode failed: ") + hipGetErrorString(e) + " / " + last_error_string(); return -1; }
     dbg_tokens_ = n;
-    (void)V;
     return 0;
 }
 
@@ -744,7 +746,8 @@ float *Context::logits_ith(int i) {
     if (i < 0) i += (int)out_row_of_batch_.size();
     if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return nullptr;
     if (!logits_fetched_) {
-        if (hipMemcpyAsync(h_logits_, d_logits_, (size_t)n_out_last_ * model->hp.n_vocab * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return nullptr;
+        if (!cp.logits_to_host &&
+            hipMemcpyAsync(h_logits_, d_logits_, (size_t)n_out_last_ * model->hp.n_vocab * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return nullptr;
         if (hipStreamSynchronize(stream_) != hipSuccess) return nullptr;
         logits_fetched_ = true;
     }

@@ -68,6 +68,7 @@ struct ContextParams {
     uint32_t n_ctx = 512, n_batch = 2048, n_ubatch = 512, n_seq_max = 1;
     int type_k = T_F16, type_v = T_F16;
     bool flash_attn = true, embeddings = false, use_graphs = true;
+    bool logits_to_host = true;   // llama_decode contract: flagged logits rows are copied to host memory by the decode itself
 };
 
 struct ProfileEntry { std::string name; float us; };

@@ -102,6 +102,8 @@ typedef struct mi355_context_params {
     int32_t  flash_attn;   /* `flash_attn`, forced on for quantised caches (llama_engine.cc:639-647) */
     int32_t  embeddings;   /* `embedding` (llama_engine.cc:613-616) */
     int32_t  use_graphs;   /* capture the single-token decode step in a hipGraph (default 1) */
+    int32_t  logits_to_host; /* 1 (default): flagged logits rows are copied to host by mi355_decode itself, as llama_decode
+                              * does; 0: rows stay on the device until mi355_get_logits_ith asks (device-side greedy) */
 } mi355_context_params;
 
 MI355_API mi355_context_params mi355_context_default_params(void);
