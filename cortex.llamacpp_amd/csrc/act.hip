@@ -7,23 +7,16 @@
 // a17 of SURVEY.md §8a.  Quantised codes and scales are bit-identical to the CPU restatement; only the
 // f64 sum-of-squares is tree-ordered instead of sequential.
 #include "kernels.h"
+#include "quant_dev.h"
 
 namespace mi355 {
-
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
 
 // One workgroup per row.  do_norm: y = (x * rsqrt(mean(x^2)+eps)) * w, else y = x.
 __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                          int n, float eps, int do_norm, float *__restrict__ yf,
                                                          ActQuant q, int want_q8k, int want_q80) {
     __shared__ double red[4];
+    // grid = (rows, splits): each workgroup re-derives the row scale (cheap, L2-resident) and quantises its share of blocks
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *xr = x + (size_t)row * n;
     float scale = 1.0f;
@@ -41,7 +34,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict
         scale = 1.0f / sqrtf(mean + eps);
     }
     const int nblk = n >> 8;
-    for (int b = wave; b < nblk; b += 4) {
+    for (int b = blockIdx.y * 4 + wave; b < nblk; b += 4 * gridDim.y) {
         const int e0 = b * 256 + lane * 4;
         float4 v = *reinterpret_cast<const float4 *>(xr + e0);
         if (do_norm) {
@@ -51,52 +44,15 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict
         if (yf) *reinterpret_cast<float4 *>(yf + (size_t)row * n + e0) = v;
         const float vv[4] = {v.x, v.y, v.z, v.w};
         if (want_q8k) {
-            // first element (lowest index) with the largest magnitude decides sign and scale
-            unsigned long long key = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const unsigned long long k = ((unsigned long long)__float_as_uint(fabsf(vv[i])) << 32) |
-                                             (unsigned long long)(0xffffffffu - (unsigned)(lane * 4 + i));
-                key = k > key ? k : key;
-            }
-            key = wave_max_u64(key);
-            const float amax = __uint_as_float((unsigned)(key >> 32));
-            const int imax = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-            const int isel = imax & 3;
-            const float vsrc = isel == 0 ? vv[0] : isel == 1 ? vv[1] : isel == 2 ? vv[2] : vv[3];
-            const float vmax = __shfl(vsrc, imax >> 2, 64);
-            int qi[4] = {0, 0, 0, 0};
-            float dq = 0.0f;
-            if (amax != 0.0f) {
-                const float iscale = -127.0f / vmax;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    int t = __float2int_rn(iscale * vv[i]);
-                    qi[i] = t > 127 ? 127 : t;
-                }
-                dq = 1.0f / iscale;
-            }
-            const uint32_t packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) |
-                                    ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+            uint32_t packed; int bs; float dq;
+            wave_quant_q8k(vv, lane, packed, bs, dq);
             *reinterpret_cast<uint32_t *>(q.qs + (size_t)row * n + e0) = packed;
-            int bs = qi[0] + qi[1] + qi[2] + qi[3];
-            bs += __shfl_xor(bs, 1, 64);
-            bs += __shfl_xor(bs, 2, 64);
             if ((lane & 3) == 0) q.bsums[(size_t)row * (n >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
             if (lane == 0) q.d[(size_t)row * nblk + b] = dq;
         }
         if (want_q80) {
-            float am = fmaxf(fmaxf(fabsf(vv[0]), fabsf(vv[1])), fmaxf(fabsf(vv[2]), fabsf(vv[3])));
-            am = fmaxf(am, __shfl_xor(am, 1, 64));
-            am = fmaxf(am, __shfl_xor(am, 2, 64));
-            am = fmaxf(am, __shfl_xor(am, 4, 64));
-            const float d = am / 127.0f;
-            const float id = d != 0.0f ? 1.0f / d : 0.0f;
-            int qi[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) qi[i] = (int)roundf(vv[i] * id);
-            const uint32_t packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) |
-                                    ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+            uint32_t packed; float d;
+            wave_quant_q80(vv, packed, d);
             *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)row * n + e0) = packed;
             if ((lane & 7) == 0) q.d0[(size_t)row * (n >> 5) + b * 8 + (lane >> 3)] = f2h(d);
         }
@@ -107,13 +63,15 @@ hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, fl
                                 const ActQuant *q, bool want_q8k, bool want_q80, hipStream_t st) {
     ActQuant qq;
     if (q) qq = *q;
-    hipLaunchKernelGGL(norm_quant_kernel, dim3(T), dim3(256), 0, st, x, w, n, eps, 1, y_f32, qq,
+    const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
+    hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, w, n, eps, 1, y_f32, qq,
                        (int)(q && want_q8k), (int)(q && want_q80));
     return hipGetLastError();
 }
 
 hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st) {
-    hipLaunchKernelGGL(norm_quant_kernel, dim3(T), dim3(256), 0, st, x, (const float *)nullptr, n, 0.0f, 0,
+    const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
+    hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, (const float *)nullptr, n, 0.0f, 0,
                        (float *)nullptr, q, (int)want_q8k, (int)want_q80);
     return hipGetLastError();
 }

@@ -9,6 +9,7 @@
 // contiguous stream; quantised caches keep int8/int4 codes and f16 block scales in separate planes
 // (same values as ggml block_q8_0 / block_q4_0, regrouped for 16-byte aligned coalesced loads).
 #include "kernels.h"
+#include "quant_dev.h"
 
 namespace mi355 {
 
@@ -82,16 +83,39 @@ __device__ __forceinline__ void store_row(const float *src, int G, int D, int ty
     }
 }
 
-// One workgroup per token: rope(q) in place; rope(k) -> cache; v -> cache.
+// cos/sin table of every token of the micro-batch, computed once and reused by all layers
+__global__ void rope_table_kernel(const int32_t *tok_pos, int T, RopeArgs ra, float theta_scale, float *cs_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = ra.n_rot >> 1;
+    if (idx >= T * half) return;
+    const int t = idx / half, i = idx - t * half;
+    float c, s;
+    rope_angle(i, tok_pos[t], theta_scale, ra.freq_scale, ra.freq_factors, c, s);
+    cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
+    cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
+}
+hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, hipStream_t st) {
+    const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
+    const int n = T * (ra.n_rot >> 1);
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 63) / 64), dim3(64), 0, st, tok_pos, T, ra, theta_scale, cs_out);
+    return hipGetLastError();
+}
+
+// One workgroup per token: rope(q) in place; rope(k) -> cache; v -> cache.  cs_table (nullable): precomputed [T][n_rot].
 __global__ __launch_bounds__(256) void rope_kv_store_kernel(float *q, const float *k, const float *v, int n_head, int G, int D,
                                                             const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra,
-                                                            float theta_scale, KVLayerView kv, int type_k, int type_v, int n_ctx) {
+                                                            float theta_scale, KVLayerView kv, int type_k, int type_v, int n_ctx,
+                                                            const float *cs_table) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *cs = sm;                 // [n_rot]
     float *kbuf = sm + ra.n_rot;    // [G*D]
     const int t = blockIdx.x, tid = threadIdx.x;
-    const int32_t pos = tok_pos[t];
-    for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, pos, theta_scale, ra.freq_scale, ra.freq_factors, cs[2 * i], cs[2 * i + 1]);
+    if (cs_table) {
+        for (int i = tid; i < ra.n_rot; i += 256) cs[i] = cs_table[(size_t)t * ra.n_rot + i];
+    } else {
+        const int32_t pos = tok_pos[t];
+        for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, pos, theta_scale, ra.freq_scale, ra.freq_factors, cs[2 * i], cs[2 * i + 1]);
+    }
     if (k) for (int e = tid; e < G * D; e += 256) kbuf[e] = k[(size_t)t * G * D + e];
     __syncthreads();
     float *qr = q + (size_t)t * n_head * D;
@@ -107,11 +131,11 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(float *q, const floa
 
 hipError_t launch_rope_kv_store(float *q, const float *k, const float *v, int T, int n_head, int G, int D,
                                 const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra, KVLayerView kv,
-                                int type_k, int type_v, int n_ctx, hipStream_t st) {
+                                int type_k, int type_v, int n_ctx, const float *cs_table, hipStream_t st) {
     const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
     const size_t lds = sizeof(float) * ((size_t)ra.n_rot + (size_t)G * D);
     hipLaunchKernelGGL(rope_kv_store_kernel, dim3(T), dim3(256), lds, st, q, k, v, n_head, G, D, tok_pos, tok_cell, ra,
-                       theta_scale, kv, type_k, type_v, n_ctx);
+                       theta_scale, kv, type_k, type_v, n_ctx, cs_table);
     return hipGetLastError();
 }
 
@@ -120,7 +144,7 @@ hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t
     const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
     const size_t lds = sizeof(float) * ((size_t)ra.n_rot);
     hipLaunchKernelGGL(rope_kv_store_kernel, dim3(T), dim3(256), lds, st, x, (const float *)nullptr, (const float *)nullptr,
-                       n_head, 0, D, tok_pos, (const int32_t *)nullptr, ra, theta_scale, kv, T_F16, T_F16, 0);
+                       n_head, 0, D, tok_pos, (const int32_t *)nullptr, ra, theta_scale, kv, T_F16, T_F16, 0, (const float *)nullptr);
     return hipGetLastError();
 }
 
@@ -378,22 +402,44 @@ __global__ __launch_bounds__(256) void flash_attn_split_kernel(const AttnArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits) {
-    const int t = blockIdx.y;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < H * D; e += gridDim.x * 256) {
-        const int h = e / D, d = e - h * D;
-        const float *p = part + ((size_t)t * H + h) * splits * (D + 2);
-        float M = -INFINITY;
-        for (int s = 0; s < splits; s++) M = fmaxf(M, p[(size_t)s * (D + 2) + D]);
-        float num = 0.0f, den = 0.0f;
-        for (int s = 0; s < splits; s++) {
-            const float m = p[(size_t)s * (D + 2) + D];
-            if (m == -INFINITY) continue;
-            const float w = expf(m - M);
-            num += w * p[(size_t)s * (D + 2) + d];
-            den += w * p[(size_t)s * (D + 2) + D + 1];
-        }
-        out[(size_t)t * H * D + e] = num * (1.0f / den);
+// Merge the KV splits; one wave per 256 output elements (lane = 4 consecutive d of one head), and, when asked,
+// quantise the merged row for the attn_output mat-vec in the same pass (saves a launch on the decode path).
+__global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits,
+                                                                 ActQuant q, int want_q8k, int want_q80) {
+    const int t = blockIdx.y, lane = threadIdx.x & 63;
+    const int E = H * D, nblk = E >> 8;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const int e0 = b * 256 + lane * 4;
+    const int h = e0 / D, d = e0 - h * D;
+    const float *p = part + ((size_t)t * H + h) * splits * (D + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < splits; s++) M = fmaxf(M, p[(size_t)s * (D + 2) + D]);
+    float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.0f;
+    for (int s = 0; s < splits; s++) {
+        const float m = p[(size_t)s * (D + 2) + D];
+        if (m == -INFINITY) continue;
+        const float w = expf(m - M);
+        const float *ps = p + (size_t)s * (D + 2) + d;
+        num.x += w * ps[0]; num.y += w * ps[1]; num.z += w * ps[2]; num.w += w * ps[3];
+        den += w * p[(size_t)s * (D + 2) + D + 1];
+    }
+    const float inv = 1.0f / den;
+    const float vv[4] = {num.x * inv, num.y * inv, num.z * inv, num.w * inv};
+    *reinterpret_cast<float4 *>(out + (size_t)t * E + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (want_q8k) {
+        uint32_t packed; int bs; float dq;
+        wave_quant_q8k(vv, lane, packed, bs, dq);
+        *reinterpret_cast<uint32_t *>(q.qs + (size_t)t * E + e0) = packed;
+        if ((lane & 3) == 0) q.bsums[(size_t)t * (E >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+        if (lane == 0) q.d[(size_t)t * nblk + b] = dq;
+    }
+    if (want_q80) {
+        uint32_t packed; float dd;
+        wave_quant_q80(vv, packed, dd);
+        *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)t * E + e0) = packed;
+        if ((lane & 7) == 0) q.d0[(size_t)t * (E >> 5) + b * 8 + (lane >> 3)] = f2h(dd);
     }
 }
 
@@ -432,8 +478,11 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
     FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 4) FA_CASE(64, 8)
 #undef FA_CASE
     if (e != hipSuccess) return e;
-    int bx = (a.H * a.D + 255) / 256;
-    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(bx, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits);
+    const int nblk = (a.H * a.D) >> 8;
+    ActQuant qq;
+    if (a.out_q) qq = *a.out_q;
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3((nblk + 3) / 4, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
     return hipGetLastError();
 }
 

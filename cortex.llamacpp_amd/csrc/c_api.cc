@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -127,6 +128,7 @@ mi355_context *mi355_context_new(mi355_model *model, mi355_context_params params
     cp.flash_attn = params.flash_attn != 0 || params.type_k != MI355_TYPE_F16 || params.type_v != MI355_TYPE_F16;
     cp.embeddings = params.embeddings != 0;
     cp.use_graphs = params.use_graphs != 0;
+    if (const char *ng = getenv("MI355_NO_GRAPHS")) { if (ng[0] == '1') cp.use_graphs = false; }   // e.g. under rocprofv3
     cp.logits_to_host = params.logits_to_host != 0;
     Context *c = new Context(model->m, cp);
     std::string err;

@@ -40,8 +40,13 @@ struct MMVQArgs {
     int T;                // tokens in this launch (1, 2 or 4)
     int epi;
     int need_q8k, need_q80;
+    int nck;              // waves of a workgroup that share one row pair (split over K)
+    int red_off;          // LDS byte offset of the reduction scratch
     const int8_t *aq; const float *ad; const int16_t *abs;   // q8_K planes for the T tokens
     const int8_t *aq0; const uint16_t *ad0;                  // q8_0 planes
+    // fused prologue (T == 1, K <= 8192, K % 1024 == 0): 0 = planes above; 1 = rms_norm(nx)*nw then quantise; 2 = quantise nx
+    int fuse_mode;
+    const float *nx; const float *nw; float neps;
 };
 
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);
@@ -68,7 +73,7 @@ hipError_t launch_pack_q80_blocks(const ActQuant &q, int n, int T, uint8_t *bloc
 hipError_t launch_repack_rows(int type, const uint8_t *src_ggml, uint8_t *dst_dev, int64_t K, int64_t n_rows, hipStream_t st);
 // dst[i][:] = dequant(table row ids[i]) from device-layout rows
 hipError_t launch_get_rows(int type, const uint8_t *table_dev, int64_t K, const int32_t *ids, int n_ids, float *dst, hipStream_t st);
-hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, hipStream_t st);
+hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch /* rows*128 words */, hipStream_t st);
 // f32 / f16 weight mat-vec (router, unquantised models): y[t][r] = dot(W[r], x[t])
 hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,
                             const float *resid, hipStream_t st);
@@ -96,7 +101,9 @@ struct RopeArgs {
 // rope(q) in place, rope(k) -> K cache, v -> V cache for T tokens
 hipError_t launch_rope_kv_store(float *q, const float *k, const float *v, int T, int n_head, int n_head_kv, int D,
                                 const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra,
-                                KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);
+                                KVLayerView kv, int type_k, int type_v, int n_ctx, const float *cs_table, hipStream_t st);
+// cos/sin of every token of the micro-batch: cs_out[T][n_rot] (pairs c,s), reused by all layers
+hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, hipStream_t st);
 hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t *tok_pos, RopeArgs ra, hipStream_t st);
 
 struct AttnArgs {
@@ -114,6 +121,8 @@ struct AttnArgs {
     float scale;
     float *part;               // workspace [T][H][splits][D+2]
     int splits;
+    const ActQuant *out_q;     // nullable: also quantise the merged rows (for attn_output)
+    bool out_q8k, out_q80;
 };
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
 size_t flash_attn_workspace_floats(int T, int H, int D, int splits);

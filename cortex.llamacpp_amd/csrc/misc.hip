@@ -107,18 +107,10 @@ hipError_t launch_get_rows(int type, const uint8_t *table, int64_t K, const int3
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------- argmax per row (lowest index wins ties)
-__global__ __launch_bounds__(256) void argmax_kernel(const float *x, int n, int32_t *out) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *xr = x + (size_t)row * n;
-    float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
-        const float v = xr[i];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
-    }
+// ---------------------------------------------------------------- argmax per row (lowest index wins ties), two stages
+constexpr int ARGMAX_PARTS = 64;
+__device__ __forceinline__ void argmax_block_reduce(float &best, int &idx, float *bv, int *bi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
@@ -127,14 +119,44 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float *x, int n, int3
     }
     if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0)
         for (int w = 1; w < 4; w++)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out[row] = idx;
-    }
 }
-hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, st, x, n, out);
+__global__ __launch_bounds__(256) void argmax_part_kernel(const float *x, int n, float *pv, int *pi) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int row = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const float *xr = x + (size_t)row * n;
+    const int chunk = (n + ARGMAX_PARTS - 1) / ARGMAX_PARTS;
+    const int lo = part * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = lo + tid; i < hi; i += 256) {
+        const float v = xr[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+    argmax_block_reduce(best, idx, bv, bi);
+    if (tid == 0) { pv[row * ARGMAX_PARTS + part] = best; pi[row * ARGMAX_PARTS + part] = idx; }
+}
+__global__ void argmax_final_kernel(const float *pv, const int *pi, int32_t *out) {
+    const int row = blockIdx.x, lane = threadIdx.x;   // 64 threads
+    float best = pv[row * ARGMAX_PARTS + lane];
+    int idx = pi[row * ARGMAX_PARTS + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) out[row] = idx;
+}
+// scratch: rows * 64 floats + rows * 64 ints
+hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch, hipStream_t st) {
+    float *pv = scratch;
+    int *pi = reinterpret_cast<int *>(scratch + (size_t)rows * ARGMAX_PARTS);
+    hipLaunchKernelGGL(argmax_part_kernel, dim3(ARGMAX_PARTS, rows), dim3(256), 0, st, x, n, pv, pi);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, pv, pi, out);
     return hipGetLastError();
 }
 

@@ -16,6 +16,17 @@
 //    f32 summation order differs (lane partials are reduced with a wave butterfly).
 //  * epilogues fuse the residual add (attn_output / ffn_down) and SwiGLU (ffn_gate + ffn_up).
 #include "kernels.h"
+#include "quant_dev.h"
+
+#ifndef MMVQ_RPU
+#define MMVQ_RPU 2      // weight rows per wave unit (x 2 passes): loads in flight per lane = RPU * 2 * loads-per-item
+#endif
+#ifndef MMVQ_WAVES
+#define MMVQ_WAVES 3    // launch bound: waves per SIMD
+#endif
+#ifndef MMVQ_BLOCKS_PER_CU
+#define MMVQ_BLOCKS_PER_CU 4
+#endif
 
 namespace mi355 {
 
@@ -31,27 +42,38 @@ struct ActLds {
 };
 
 __device__ __forceinline__ uint4 ld16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+// weight stream: read once per token by exactly one wave -> non-temporal (does not displace the activations in L2)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16w(const void *p) {
+#ifdef MMVQ_NO_NT
+    return *reinterpret_cast<const uint4 *>(p);
+#else
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+}
 
 template <int TYPE> struct Item;
 
 // ---- Q4_K : ggml super-block  [d f16][dmin f16][scales 12][qs 128]  (144 B, 16-B aligned) ----
 template <> struct Item<T_Q4_K> {
+    uint4 hdr;
     static constexpr int EPP = 2048;  // elements per wave pass
     uint4 q;
     int sc_lo, sc_hi, m_lo, m_hi;
     float d, dmin;
     int sb;
     bool valid;
-    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane, uint4 &hdr) {
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
         sb = pass * 8 + (lane >> 3);
         valid = sb < (K >> 8);
         if (valid) {
             const uint8_t *b = row + (size_t)sb * 144;
-            hdr = ld16(b);
-            q = ld16(b + 16 + (lane & 7) * 16);
+            hdr = ld16w(b);
+            q = ld16w(b + 16 + (lane & 7) * 16);
         }
     }
-    __device__ __forceinline__ void prep(const uint4 &hdr, int lane) {
+    __device__ __forceinline__ void prep(int lane) {
         if (!valid) return;
         const int v = lane & 7, c = v >> 1;
         d = h2f((uint16_t)(hdr.x & 0xffff));
@@ -94,23 +116,24 @@ template <> struct Item<T_Q4_K> {
 
 // ---- Q5_K : [d][dmin][scales 12][qh 32][qs 128]  (176 B, 16-B aligned) ----------------------
 template <> struct Item<T_Q5_K> {
+    uint4 hdr;
     static constexpr int EPP = 2048;
     uint4 q, qh;
     int sc_lo, sc_hi, m_lo, m_hi;
     float d, dmin;
     int sb;
     bool valid;
-    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane, uint4 &hdr) {
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
         sb = pass * 8 + (lane >> 3);
         valid = sb < (K >> 8);
         if (valid) {
             const uint8_t *b = row + (size_t)sb * 176;
-            hdr = ld16(b);
-            qh = ld16(b + 16 + (lane & 1) * 16);
-            q = ld16(b + 48 + (lane & 7) * 16);
+            hdr = ld16w(b);
+            qh = ld16w(b + 16 + (lane & 1) * 16);
+            q = ld16w(b + 48 + (lane & 7) * 16);
         }
     }
-    __device__ __forceinline__ void prep(const uint4 &hdr, int lane) {
+    __device__ __forceinline__ void prep(int lane) {
         if (!valid) return;
         const int v = lane & 7, c = v >> 1;
         d = h2f((uint16_t)(hdr.x & 0xffff));
@@ -127,25 +150,21 @@ template <> struct Item<T_Q5_K> {
         }
         sc_lo = sc & 0xff; sc_hi = sc >> 8;
         m_lo = mn & 0xff;  m_hi = mn >> 8;
-        // fold the 5th bits into the nibble planes once: q.x.. stay packed, qh becomes per-plane masks
-        const int s0 = 2 * c, s1 = 2 * c + 1;
-        uint4 l5, h5;
-        l5.x = ((qh.x >> s0) & 0x01010101u) << 4; h5.x = ((qh.x >> s1) & 0x01010101u) << 4;
-        l5.y = ((qh.y >> s0) & 0x01010101u) << 4; h5.y = ((qh.y >> s1) & 0x01010101u) << 4;
-        l5.z = ((qh.z >> s0) & 0x01010101u) << 4; h5.z = ((qh.z >> s1) & 0x01010101u) << 4;
-        l5.w = ((qh.w >> s0) & 0x01010101u) << 4; h5.w = ((qh.w >> s1) & 0x01010101u) << 4;
-        lo5 = l5; hi5 = h5;
     }
-    uint4 lo5, hi5;
     __device__ __forceinline__ void ints(const ActLds &A, int t, int lane, int &isum, int &msum) const {
         const int v = lane & 7, c = v >> 1, h = v & 1;
         const int8_t *a = A.qs + (size_t)t * A.K + sb * 256 + 64 * c + 16 * h;
         const uint4 lo = ld16(a), hi = ld16(a + 32);
+        const int s0 = 2 * c, s1 = 2 * c + 1;   // bit of qh holding the 5th bit of the low / high nibble plane
         int dl = 0, dh = 0;
-        dl = dot4((q.x & 0x0f0f0f0f) | lo5.x, lo.x, dl); dh = dot4(((q.x >> 4) & 0x0f0f0f0f) | hi5.x, hi.x, dh);
-        dl = dot4((q.y & 0x0f0f0f0f) | lo5.y, lo.y, dl); dh = dot4(((q.y >> 4) & 0x0f0f0f0f) | hi5.y, hi.y, dh);
-        dl = dot4((q.z & 0x0f0f0f0f) | lo5.z, lo.z, dl); dh = dot4(((q.z >> 4) & 0x0f0f0f0f) | hi5.z, hi.z, dh);
-        dl = dot4((q.w & 0x0f0f0f0f) | lo5.w, lo.w, dl); dh = dot4(((q.w >> 4) & 0x0f0f0f0f) | hi5.w, hi.w, dh);
+#define Q5_LO(w, hw) (((w) & 0x0f0f0f0f) | ((((hw) >> s0) & 0x01010101u) << 4))
+#define Q5_HI(w, hw) ((((w) >> 4) & 0x0f0f0f0f) | ((((hw) >> s1) & 0x01010101u) << 4))
+        dl = dot4(Q5_LO(q.x, qh.x), lo.x, dl); dh = dot4(Q5_HI(q.x, qh.x), hi.x, dh);
+        dl = dot4(Q5_LO(q.y, qh.y), lo.y, dl); dh = dot4(Q5_HI(q.y, qh.y), hi.y, dh);
+        dl = dot4(Q5_LO(q.z, qh.z), lo.z, dl); dh = dot4(Q5_HI(q.z, qh.z), hi.z, dh);
+        dl = dot4(Q5_LO(q.w, qh.w), lo.w, dl); dh = dot4(Q5_HI(q.w, qh.w), hi.w, dh);
+#undef Q5_LO
+#undef Q5_HI
         isum = sc_lo * dl + sc_hi * dh;
         const int16_t *bs = A.bs + (size_t)t * (A.K >> 4) + sb * 16 + 4 * c + h;
         msum = m_lo * (int)bs[0] + m_hi * (int)bs[2];
@@ -161,27 +180,28 @@ template <> struct Item<T_Q5_K> {
 
 // ---- Q6_K : device row planes [ql nb*128][qh nb*64][scales nb*16][d nb*2] ---------------------
 template <> struct Item<T_Q6_K> {
+    uint4 hdr;
     static constexpr int EPP = 2048;
     uint4 ql, qh;
     int sc_lo, sc_hi;
     float d;
     int sb;
     bool valid;
-    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane, uint4 &hdr) {
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
         const int nb = K >> 8;
         sb = pass * 8 + (lane >> 3);
         valid = sb < nb;
         if (valid) {
             const int v = lane & 7, n = v >> 2, w = v & 3;
-            ql = ld16(row + (size_t)sb * 128 + v * 16);
-            qh = ld16(row + (size_t)nb * 128 + (size_t)sb * 64 + n * 32 + (w & 1) * 16);
+            ql = ld16w(row + (size_t)sb * 128 + v * 16);
+            qh = ld16w(row + (size_t)nb * 128 + (size_t)sb * 64 + n * 32 + (w & 1) * 16);
             const int8_t *sc = reinterpret_cast<const int8_t *>(row + (size_t)nb * 192 + (size_t)sb * 16 + 8 * n + w);
             hdr.x = (uint32_t)(int)sc[0];
             hdr.y = (uint32_t)(int)sc[4];
             hdr.z = *reinterpret_cast<const uint16_t *>(row + (size_t)nb * 208 + (size_t)sb * 2);
         }
     }
-    __device__ __forceinline__ void prep(const uint4 &hdr, int lane) {
+    __device__ __forceinline__ void prep(int lane) {
         if (!valid) return;
         sc_lo = (int)hdr.x; sc_hi = (int)hdr.y;
         d = h2f((uint16_t)hdr.z);
@@ -218,20 +238,21 @@ template <> struct Item<T_Q6_K> {
 
 // ---- Q8_0 : device row planes [qs K][d K/32 f16] -------------------------------------------------
 template <> struct Item<T_Q8_0> {
+    uint4 hdr;
     static constexpr int EPP = 1024;
     uint4 q;
     float d;
     int e;       // element offset of this lane's 16 codes
     bool valid;
-    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane, uint4 &hdr) {
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
         e = pass * 1024 + lane * 16;
         valid = e < K;
         if (valid) {
-            q = ld16(row + e);
+            q = ld16w(row + e);
             hdr.x = *reinterpret_cast<const uint16_t *>(row + K + (e >> 5) * 2);
         }
     }
-    __device__ __forceinline__ void prep(const uint4 &hdr, int lane) {
+    __device__ __forceinline__ void prep(int lane) {
         if (valid) d = h2f((uint16_t)hdr.x);
     }
     __device__ __forceinline__ void ints(const ActLds &A, int t, int lane, int &isum, int &msum) const {
@@ -253,131 +274,221 @@ template <> struct Item<T_Q8_0> {
 };
 
 // ------------------------------------------------------------------------------------------
-template <int TYPE, int NT>
-__device__ __forceinline__ void row_pair_dot(const uint8_t *r0, const uint8_t *r1, bool has1, int K,
-                                             const ActLds &A, int lane, float (&acc)[2][NT]) {
-    using It = Item<TYPE>;
-    const int npass = (K + It::EPP - 1) / It::EPP;
-    for (int p = 0; p < npass; p += 2) {
-        It a0, a1, b0, b1;
-        uint4 ha0, ha1, hb0, hb1;
-        a0.load(r0, K, p, lane, ha0);
-        if (has1) b0.load(r1, K, p, lane, hb0); else b0.valid = false;
-        if (p + 1 < npass) {
-            a1.load(r0, K, p + 1, lane, ha1);
-            if (has1) b1.load(r1, K, p + 1, lane, hb1); else b1.valid = false;
-        } else {
-            a1.valid = false; b1.valid = false;
-        }
-        a0.prep(ha0, lane); b0.prep(hb0, lane); a1.prep(ha1, lane); b1.prep(hb1, lane);
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acc[0][t] += a0.dot(A, t, lane);
-            acc[1][t] += b0.dot(A, t, lane);
-            acc[0][t] += a1.dot(A, t, lane);
-            acc[1][t] += b1.dot(A, t, lane);
-        }
-    }
-}
-
-// All rows of one segment handled by the waves of the blocks assigned to it (block-uniform TYPE).
-template <int TYPE, int NT>
-__device__ __forceinline__ void run_segment(const MMVQArgs &a, const MMVQSeg &sg, const ActLds &A, int gw, int nw) {
-    const int lane = threadIdx.x & 63;
-    const int K = a.K;
-    // MoE: the expert is picked on the device (no host sync): weight base = W + expert_sel[0] * expert_stride
-    const size_t eoff = sg.expert_sel ? (size_t)sg.expert_sel[0] * sg.expert_stride : 0;
-    if (a.epi == EPI_SWIGLU) {
-        const MMVQSeg &u = a.seg[1];
-        const size_t uoff = u.expert_sel ? (size_t)u.expert_sel[0] * u.expert_stride : 0;
-        for (int p = gw; p < sg.n_rows; p += nw) {
-            float acc[2][NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) { acc[0][t] = 0.0f; acc[1][t] = 0.0f; }
-            row_pair_dot<TYPE, NT>(sg.W + eoff + (size_t)p * sg.row_bytes, u.W + uoff + (size_t)p * u.row_bytes, true, K, A, lane, acc);
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float gv = wave_sum(acc[0][t]), uv = wave_sum(acc[1][t]);
-                if (lane == 0) sg.out[(size_t)t * sg.ld_out + p] = (gv / (1.0f + expf(-gv))) * uv;
-            }
-        }
-        return;
-    }
-    const int npairs = (sg.n_rows + 1) >> 1;
-    for (int p = gw; p < npairs; p += nw) {
-        float acc[2][NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) { acc[0][t] = 0.0f; acc[1][t] = 0.0f; }
-        const int row0 = 2 * p;
-        const bool has1 = row0 + 1 < sg.n_rows;
-        const uint8_t *r0 = sg.W + eoff + (size_t)row0 * sg.row_bytes;
-        row_pair_dot<TYPE, NT>(r0, r0 + sg.row_bytes, has1, K, A, lane, acc);
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const float v0 = wave_sum(acc[0][t]), v1 = wave_sum(acc[1][t]);
-            if (lane == 0) {
-                const size_t o = (size_t)t * sg.ld_out + row0;
-                if (a.epi == EPI_ADD) {
-                    sg.out[o] = sg.resid[o] + v0;
-                    if (has1) sg.out[o + 1] = sg.resid[o + 1] + v1;
-                } else {
-                    sg.out[o] = v0;
-                    if (has1) sg.out[o + 1] = v1;
-                }
-            }
-        }
-    }
-}
-
-// stage the quantised activations of NT tokens into LDS; returns the view
-template <int NT>
+// Activation staging.  mode 0: copy pre-quantised planes of NT tokens into LDS.
+// mode 1 (NT == 1): fused RMSNorm * weight + quantise of a.nx[K] straight into LDS (same arithmetic, same order as
+// norm_quant_kernel in act.hip, so the result is bit-identical to the unfused path).  mode 2: quantise a.nx only.
+template <int NT, int BS>
 __device__ __forceinline__ ActLds stage_act(const MMVQArgs &a, uint8_t *smem) {
     ActLds A;
     const int K = a.K, tid = threadIdx.x, nthr = blockDim.x;
     A.K = K;
     uint8_t *p = smem;
     A.qs = nullptr; A.d = nullptr; A.bs = nullptr; A.qs0 = nullptr; A.d0 = nullptr;
+    int8_t *qs = nullptr, *qs0 = nullptr;
+    float *d = nullptr;
+    int16_t *bs = nullptr;
+    uint16_t *d0 = nullptr;
     if (a.need_q8k) {
-        int8_t *qs = reinterpret_cast<int8_t *>(p);           p += (size_t)NT * K;
-        float *d = reinterpret_cast<float *>(p);              p += (((size_t)NT * (K >> 8) * 4) + 15) & ~15;
-        int16_t *bs = reinterpret_cast<int16_t *>(p);         p += (((size_t)NT * (K >> 4) * 2) + 15) & ~15;
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.aq);
-        for (int i = tid; i < NT * K / 16; i += nthr) reinterpret_cast<uint4 *>(qs)[i] = src[i];
-        for (int i = tid; i < NT * (K >> 8); i += nthr) d[i] = a.ad[i];
-        const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(a.abs);
-        for (int i = tid; i < NT * (K >> 5); i += nthr) reinterpret_cast<uint32_t *>(bs)[i] = bsrc[i];
+        qs = reinterpret_cast<int8_t *>(p);           p += (size_t)NT * K;
+        d = reinterpret_cast<float *>(p);             p += (((size_t)NT * (K >> 8) * 4) + 15) & ~15;
+        bs = reinterpret_cast<int16_t *>(p);          p += (((size_t)NT * (K >> 4) * 2) + 15) & ~15;
         A.qs = qs; A.d = d; A.bs = bs;
     }
     if (a.need_q80) {
-        int8_t *qs0 = reinterpret_cast<int8_t *>(p);          p += (size_t)NT * K;
-        uint16_t *d0 = reinterpret_cast<uint16_t *>(p);       p += (((size_t)NT * (K >> 5) * 2) + 15) & ~15;
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.aq0);
-        for (int i = tid; i < NT * K / 16; i += nthr) reinterpret_cast<uint4 *>(qs0)[i] = src[i];
-        for (int i = tid; i < NT * (K >> 5); i += nthr) d0[i] = a.ad0[i];
+        qs0 = reinterpret_cast<int8_t *>(p);          p += (size_t)NT * K;
+        d0 = reinterpret_cast<uint16_t *>(p);         p += (((size_t)NT * (K >> 5) * 2) + 15) & ~15;
         A.qs0 = qs0; A.d0 = d0;
+    }
+    if (a.fuse_mode == 0 || NT != 1) {
+        if (a.need_q8k) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.aq);
+            for (int i = tid; i < NT * K / 16; i += nthr) reinterpret_cast<uint4 *>(qs)[i] = src[i];
+            for (int i = tid; i < NT * (K >> 8); i += nthr) d[i] = a.ad[i];
+            const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(a.abs);
+            for (int i = tid; i < NT * (K >> 5); i += nthr) reinterpret_cast<uint32_t *>(bs)[i] = bsrc[i];
+        }
+        if (a.need_q80) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.aq0);
+            for (int i = tid; i < NT * K / 16; i += nthr) reinterpret_cast<uint4 *>(qs0)[i] = src[i];
+            for (int i = tid; i < NT * (K >> 5); i += nthr) d0[i] = a.ad0[i];
+        }
+    } else {
+        double *red = reinterpret_cast<double *>(smem + a.red_off);   // 16 doubles after the planes
+        const int lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
+        const int sweep = nthr * 4;                      // elements covered by one sweep of the workgroup
+        constexpr int MAXJ = 8192 / (BS * 4);            // K <= 8192 (host-checked)
+        float4 xv[MAXJ];
+        const int nj = K / sweep;                        // K % sweep == 0 host-checked
+#pragma unroll
+        for (int j = 0; j < MAXJ; j++)
+            if (j < nj) xv[j] = *reinterpret_cast<const float4 *>(a.nx + j * sweep + tid * 4);
+        float scale = 1.0f;
+        if (a.fuse_mode == 1) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < MAXJ; j++)
+                if (j < nj) {
+                    const float4 v = xv[j];
+                    s += (double)(v.x * v.x); s += (double)(v.y * v.y); s += (double)(v.z * v.z); s += (double)(v.w * v.w);
+                }
+            s = wave_sum(s);
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            double tot = 0.0;
+            for (int w = 0; w < nwv; w++) tot += red[w];
+            const float mean = (float)(tot / (double)K);
+            scale = 1.0f / sqrtf(mean + a.neps);
+        }
+#pragma unroll
+        for (int j = 0; j < MAXJ; j++) {
+            if (j >= nj) continue;
+            const int b = wave + nwv * j;                 // 256-block handled by this wave
+            const int e0 = b * 256 + lane * 4;
+            float4 v = xv[j];
+            if (a.fuse_mode == 1) {
+                const float4 ww = *reinterpret_cast<const float4 *>(a.nw + e0);
+                v.x = (v.x * scale) * ww.x; v.y = (v.y * scale) * ww.y; v.z = (v.z * scale) * ww.z; v.w = (v.w * scale) * ww.w;
+            }
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (a.need_q8k) {
+                uint32_t packed; int bsum; float dq;
+                wave_quant_q8k(vv, lane, packed, bsum, dq);
+                *reinterpret_cast<uint32_t *>(qs + e0) = packed;
+                if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum;
+                if (lane == 0) d[b] = dq;
+            }
+            if (a.need_q80) {
+                uint32_t packed; float dd;
+                wave_quant_q80(vv, packed, dd);
+                *reinterpret_cast<uint32_t *>(qs0 + e0) = packed;
+                if ((lane & 7) == 0) d0[b * 8 + (lane >> 3)] = f2h(dd);
+            }
+        }
     }
     __syncthreads();
     return A;
 }
 
+// One segment (block-uniform TYPE), one "unit" per wave and no grid-stride loop: a wave owns a PAIR of weight rows
+// (swiglu: one ffn_gate row + the matching ffn_up row) and a subset of the 2-pass chunks of those rows; nck waves of
+// the workgroup share a pair when the rows are long (K > 4096) and combine their partial sums through LDS in a fixed
+// order.  The weight loads are issued first, then the activations are staged (barrier), then the integer dots run:
+// every byte of the matrix is requested within the first microsecond of the launch.
+template <int TYPE, int NT, int BS>
+__device__ __forceinline__ void run_segment(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int blk_in_seg) {
+    using It = Item<TYPE>;
+    constexpr int NW = BS / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = a.K;
+    const bool swiglu = a.epi == EPI_SWIGLU;
+    // MoE: the expert is picked on the device (no host sync): weight base = W + expert_sel[0] * expert_stride
+    const uint8_t *W0 = sg.W + (sg.expert_sel ? (size_t)sg.expert_sel[0] * sg.expert_stride : 0);
+    const MMVQSeg &ug = a.seg[1];
+    const uint8_t *W1 = swiglu ? ug.W + (ug.expert_sel ? (size_t)ug.expert_sel[0] * ug.expert_stride : 0) : nullptr;
+    const size_t rb0 = sg.row_bytes, rb1 = swiglu ? ug.row_bytes : sg.row_bytes;
+    const int npass = (K + It::EPP - 1) / It::EPP;
+    const int nchunk = (npass + 1) >> 1;
+    const int nck = a.nck;                       // waves sharing one pair (power of two, <= NW, host-chosen)
+    const int cw = wave & (nck - 1);             // first chunk of this wave
+    const int pair = blk_in_seg * (NW / nck) + wave / nck;
+    const int npairs = swiglu ? sg.n_rows : (sg.n_rows + 1) >> 1;
+    const bool have = pair < npairs;
+    const uint8_t *ra = nullptr, *rbp = nullptr;
+    bool hasb = false;
+    if (have) {
+        if (swiglu) { ra = W0 + (size_t)pair * rb0; rbp = W1 + (size_t)pair * rb1; hasb = true; }
+        else { ra = W0 + (size_t)(2 * pair) * rb0; rbp = ra + rb0; hasb = 2 * pair + 1 < sg.n_rows; }
+    }
+    It i0, i1, i2, i3;   // (row a, pass), (row b, pass), (row a, pass+1), (row b, pass+1)
+    auto load_chunk = [&](int c) {
+        const int ps = 2 * c;
+        i0.load(ra, K, ps, lane);
+        if (hasb) i1.load(rbp, K, ps, lane); else i1.valid = false;
+        if (ps + 1 < npass) {
+            i2.load(ra, K, ps + 1, lane);
+            if (hasb) i3.load(rbp, K, ps + 1, lane); else i3.valid = false;
+        } else {
+            i2.valid = false; i3.valid = false;
+        }
+    };
+    bool active = have && cw < nchunk;
+    if (active) load_chunk(cw);
+    const ActLds A = stage_act<NT, BS>(a, smem); // contains the workgroup barrier: reached by every wave
+
+    float acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { acc[0][t] = 0.0f; acc[1][t] = 0.0f; }
+    for (int c = cw; active; ) {
+        // decode + dot one item at a time so only one item's unpacked scales are live
+        i0.prep(lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[0][t] += i0.dot(A, t, lane);
+        i1.prep(lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[1][t] += i1.dot(A, t, lane);
+        i2.prep(lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[0][t] += i2.dot(A, t, lane);
+        i3.prep(lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[1][t] += i3.dot(A, t, lane);
+        c += nck;
+        active = c < nchunk;
+        if (active) load_chunk(c);
+    }
+    float v0[NT], v1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { v0[t] = wave_sum(acc[0][t]); v1[t] = wave_sum(acc[1][t]); }
+    if (nck > 1) {   // combine the chunk partials of the waves that share this pair (fixed order -> deterministic)
+        float *red = reinterpret_cast<float *>(smem + a.red_off);
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) { red[(wave * 2 + 0) * NT + t] = v0[t]; red[(wave * 2 + 1) * NT + t] = v1[t]; }
+        }
+        __syncthreads();
+        if (cw != 0) return;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int j = 0; j < nck; j++) { s0 += red[((wave + j) * 2 + 0) * NT + t]; s1 += red[((wave + j) * 2 + 1) * NT + t]; }
+            v0[t] = s0; v1[t] = s1;
+        }
+    }
+    if (lane == 0 && have) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (swiglu) {
+                sg.out[(size_t)t * sg.ld_out + pair] = (v0[t] / (1.0f + expf(-v0[t]))) * v1[t];
+            } else {
+                const int row0 = 2 * pair;
+                const size_t o = (size_t)t * sg.ld_out + row0;
+                if (a.epi == EPI_ADD) {
+                    sg.out[o] = sg.resid[o] + v0[t];
+                    if (hasb) sg.out[o + 1] = sg.resid[o + 1] + v1[t];
+                } else {
+                    sg.out[o] = v0[t];
+                    if (hasb) sg.out[o + 1] = v1[t];
+                }
+            }
+        }
+    }
+}
+
 // Blocks [seg_block0[s], seg_block0[s+1]) work on segment s, so the weight TYPE is block-uniform and
-// each type's code path keeps its own (small) register footprint.
-template <int NT>
-__global__ __launch_bounds__(256) void mmvq_kernel(const MMVQArgs a) {
+// each type's code path keeps its own register footprint.
+template <int NT, int BS>
+__global__ __launch_bounds__(BS) void mmvq_kernel(const MMVQArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ActLds A = stage_act<NT>(a, smem);
     int s = 0;
     if (a.n_seg > 1 && (int)blockIdx.x >= a.seg_block0[1]) s = 1;
     if (a.n_seg > 2 && (int)blockIdx.x >= a.seg_block0[2]) s = 2;
-    const int nblk = a.seg_block0[s + 1] - a.seg_block0[s];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gw = ((int)blockIdx.x - a.seg_block0[s]) * 4 + wave;
-    const int nw = nblk * 4;
+    const int bis = (int)blockIdx.x - a.seg_block0[s];
     switch (a.seg[s].type) {
-        case T_Q4_K: run_segment<T_Q4_K, NT>(a, a.seg[s], A, gw, nw); break;
-        case T_Q5_K: run_segment<T_Q5_K, NT>(a, a.seg[s], A, gw, nw); break;
-        case T_Q6_K: run_segment<T_Q6_K, NT>(a, a.seg[s], A, gw, nw); break;
-        case T_Q8_0: run_segment<T_Q8_0, NT>(a, a.seg[s], A, gw, nw); break;
+        case T_Q4_K: run_segment<T_Q4_K, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q5_K: run_segment<T_Q5_K, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q6_K: run_segment<T_Q6_K, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q8_0: run_segment<T_Q8_0, NT, BS>(a, a.seg[s], smem, bis); break;
         default: break;
     }
 }
@@ -394,6 +505,12 @@ static int g_num_cu = 256;
 void set_num_cu(int n) { if (n > 0) g_num_cu = n; }
 int num_cu() { return g_num_cu; }
 
+template <int NT>
+static void launch_nt(const MMVQArgs &a, int blocks, int bs, size_t lds, hipStream_t st) {
+    if (bs == 1024) hipLaunchKernelGGL((mmvq_kernel<NT, 1024>), dim3(blocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((mmvq_kernel<NT, 256>), dim3(blocks), dim3(256), lds, st, a);
+}
+
 // host launcher: a.T tokens (1, 2 or 4 per launch; larger T is chunked by the caller).
 // EPI_SWIGLU: seg[0] = ffn_gate, seg[1] = ffn_up (same type), out = silu(gate) * up into seg[0].out.
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
@@ -403,35 +520,44 @@ hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     }
     if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
     const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
-    const int max_blocks = g_num_cu * 8;
-    size_t bytes[3] = {0, 0, 0}, total = 0;
-    int want[3] = {0, 0, 0};
+    // chunks of 2 passes per row; the pass size is the same for every K-quant (2048), 1024 for Q8_0
+    int nchunk = 1;
     for (int s = 0; s < n_work_seg; s++) {
-        bytes[s] = (size_t)a.seg[s].n_rows * a.seg[s].row_bytes;
-        total += bytes[s];
-        const int units = a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
-        want[s] = (units + 3) / 4;               // one unit (row pair) per wave at most
+        const int epp = a.seg[s].type == T_Q8_0 ? 1024 : 2048;
+        const int npass = (a.K + epp - 1) / epp;
+        nchunk = ((npass + 1) >> 1) > nchunk ? ((npass + 1) >> 1) : nchunk;
     }
-    int sum_want = 0;
-    for (int s = 0; s < n_work_seg; s++) sum_want += want[s];
+    int total_pairs = 0;
+    for (int s = 0; s < n_work_seg; s++) total_pairs += a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
+    // waves sharing one pair: spread long rows over waves while the launch is small enough to need it
+    int nck = 1;
+    while (nck * 2 <= nchunk && nck < 4 && (long)total_pairs * nck < (long)g_num_cu * 16) nck *= 2;
+    a.nck = nck;
+    // big launches use 1024-thread workgroups (one activation staging per 16 waves)
+    int bs = ((long)total_pairs * nck >= (long)g_num_cu * 32) ? 1024 : 256;
+    if (a.fuse_mode != 0) {
+        if (a.T != 1 || (a.K % (bs * 4)) != 0 || a.K / (bs * 4) > 8) {
+            if (bs == 1024 && a.T == 1 && (a.K % 1024) == 0 && a.K / 1024 <= 8) bs = 256; else return hipErrorInvalidValue;
+        }
+    }
+    const int nw = bs / 64;
+    const int ppb = nw / nck;                    // pairs per workgroup
     a.seg_block0[0] = 0;
     for (int s = 0; s < n_work_seg; s++) {
-        int nb = want[s];
-        if (sum_want > max_blocks) {            // share the block budget by bytes
-            nb = (int)((double)max_blocks * (double)bytes[s] / (double)total);
-            if (nb < 1) nb = 1;
-            if (nb > want[s]) nb = want[s];
-        }
-        a.seg_block0[s + 1] = a.seg_block0[s] + nb;
+        const int pairs = a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
+        a.seg_block0[s + 1] = a.seg_block0[s] + (pairs + ppb - 1) / ppb;
     }
     for (int s = n_work_seg; s < 3; s++) a.seg_block0[s + 1] = a.seg_block0[n_work_seg];
     const int blocks = a.seg_block0[n_work_seg];
     if (a.epi == EPI_SWIGLU) a.n_seg = 1;       // block->segment lookup sees only the gate segment; seg[1] read directly
-    const size_t lds = mmvq_lds_bytes(a, a.T);
+    size_t lds = mmvq_lds_bytes(a, a.T);
+    lds = (lds + 15) & ~(size_t)15;
+    a.red_off = (int)lds;                        // f64 norm scratch (16 doubles) / f32 chunk partials share this tail
+    lds += 16 * 8 + (size_t)nw * 2 * a.T * 4;
     switch (a.T) {
-        case 1: hipLaunchKernelGGL(mmvq_kernel<1>, dim3(blocks), dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(mmvq_kernel<2>, dim3(blocks), dim3(256), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(mmvq_kernel<4>, dim3(blocks), dim3(256), lds, st, a); break;
+        case 1: launch_nt<1>(a, blocks, bs, lds, st); break;
+        case 2: launch_nt<2>(a, blocks, bs, lds, st); break;
+        case 4: launch_nt<4>(a, blocks, bs, lds, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -442,7 +568,7 @@ hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
 template <int TYPE>
 __global__ __launch_bounds__(256) void mmvq_ints_kernel(const MMVQArgs a, int32_t *isum_out, int32_t *msum_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ActLds A = stage_act<1>(a, smem);
+    const ActLds A = stage_act<1, 256>(a, smem);
     using It = Item<TYPE>;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -455,9 +581,8 @@ __global__ __launch_bounds__(256) void mmvq_ints_kernel(const MMVQArgs a, int32_
         const uint8_t *row = sg.W + (size_t)r * sg.row_bytes;
         for (int p = 0; p < npass; p++) {
             It it;
-            uint4 hdr;
-            it.load(row, K, p, lane, hdr);
-            it.prep(hdr, lane);
+            it.load(row, K, p, lane);
+            it.prep(lane);
             int is = 0, ms = 0;
             if constexpr (TYPE == T_Q8_0) {
                 it.ints(A, 0, lane, is, ms);

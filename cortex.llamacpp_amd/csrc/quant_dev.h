@@ -1,0 +1,67 @@
+// quant_dev.h — wave-level activation quantisation shared by act.hip (stand-alone kernels) and mmvq.hip
+// (fused RMSNorm + quantise prologue).  One wave quantises one 256-element block: lane l holds elements 4l..4l+3.
+// Bit-identical to quantize_row_q8_K / quantize_row_q8_0 of the CPU backend.
+#pragma once
+
+#include "dev_common.h"
+
+namespace mi355 {
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// Q8_K: iscale = -127 / (signed value of the FIRST element with the largest magnitude); codes = min(127, rint(iscale*x));
+// d = 1/iscale; bsum16 = sum of the 16-element group this lane belongs to (valid on every lane).
+__device__ __forceinline__ void wave_quant_q8k(const float (&vv)[4], int lane, uint32_t &packed, int &bsum16, float &d) {
+    unsigned long long key = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(fabsf(vv[i])) << 32) |
+                                     (unsigned long long)(0xffffffffu - (unsigned)(lane * 4 + i));
+        key = k > key ? k : key;
+    }
+    key = wave_max_u64(key);
+    const float amax = __uint_as_float((unsigned)(key >> 32));
+    const int imax = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+    const int isel = imax & 3;
+    const float vsrc = isel == 0 ? vv[0] : isel == 1 ? vv[1] : isel == 2 ? vv[2] : vv[3];
+    const float vmax = __shfl(vsrc, imax >> 2, 64);
+    int qi[4] = {0, 0, 0, 0};
+    d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -127.0f / vmax;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int t = __float2int_rn(iscale * vv[i]);
+            qi[i] = t > 127 ? 127 : t;
+        }
+        d = 1.0f / iscale;
+    }
+    packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) | ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+    int bs = qi[0] + qi[1] + qi[2] + qi[3];
+    bs += __shfl_xor(bs, 1, 64);
+    bs += __shfl_xor(bs, 2, 64);
+    bsum16 = bs;
+}
+
+// Q8_0: per 32 elements (8 lanes): d = amax/127, codes = roundf(x/d); d returned as f32 (store as f16)
+__device__ __forceinline__ void wave_quant_q80(const float (&vv)[4], uint32_t &packed, float &d) {
+    float am = fmaxf(fmaxf(fabsf(vv[0]), fabsf(vv[1])), fmaxf(fabsf(vv[2]), fabsf(vv[3])));
+    am = fmaxf(am, __shfl_xor(am, 1, 64));
+    am = fmaxf(am, __shfl_xor(am, 2, 64));
+    am = fmaxf(am, __shfl_xor(am, 4, 64));
+    d = am / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    int qi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) qi[i] = (int)roundf(vv[i] * id);
+    packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) | ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+}
+
+}  // namespace mi355

@@ -308,6 +308,8 @@ bool Context::init(std::string &err) {
     att_part_ = (float *)dalloc(ws * 4);
     if (!att_part_) { err = "attention workspace allocation failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
+    argmax_scratch_ = (float *)dalloc(T * 128 * 4);
+    rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
     if (hipHostMalloc((void **)&h_argmax_, T * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     embeddings_enabled = cp.embeddings;
     kv_clear();
@@ -437,11 +439,14 @@ static void chunk_act(MMVQArgs &a, const ActQuant &aq, int K, int t0) {
 }
 
 // up to 3 quantised weight tensors sharing one activation (fused Q/K/V), or one tensor with an epilogue
-static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, const ActQuant &aq, hipStream_t st) {
+static bool can_fuse(int K, int T) { return T == 1 && K <= 8192 && (K & 1023) == 0; }
+
+static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, const ActQuant &aq, hipStream_t st, const Fuse &fz = Fuse()) {
     for (int t0 = 0; t0 < T;) {
         const int rem = T - t0, nt = rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
         MMVQArgs a{};
         a.n_seg = n_seg; a.K = K; a.T = nt; a.epi = epi;
+        a.fuse_mode = fz.mode; a.nx = fz.x; a.nw = fz.w; a.neps = fz.eps;
         for (int s = 0; s < n_seg; s++) {
             a.seg[s] = segs[s];
             a.seg[s].out = segs[s].out + (size_t)t0 * segs[s].ld_out;
@@ -459,7 +464,7 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
-        return mmvq_tokens(&s, 1, K, T, epi, aq, stream_);
+        return mmvq_tokens(&s, 1, K, T, epi, aq, stream_, pending_fuse_);
     }
     return launch_mmv_float(w.type, w.data, (int)w.N, K, x_f32, T, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
 }
@@ -471,7 +476,7 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     if (all_q && n <= 3) {
         MMVQSeg segs[3];
         for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
-        return mmvq_tokens(segs, n, K, T, EPI_STORE, aq, stream_);
+        return mmvq_tokens(segs, n, K, T, EPI_STORE, aq, stream_, pending_fuse_);
     }
     for (int i = 0; i < n; i++) {
         hipError_t e = linear(*ws[i], aq, x_f32, K, T, outs[i], (int)ws[i]->N, nullptr, EPI_STORE);
@@ -491,6 +496,7 @@ hipError_t Context::run_layers(int T, bool graph_mode) {
 
     HIP_TRY(launch_kv_meta_set(d_cell_pos_, d_cell_seq_, d_cell_, d_pos_, d_seqmask_, T, stream_));
     HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
+    HIP_TRY(launch_rope_table(d_pos_, T, ra, rope_cs_, stream_));
     prof_mark("embed");
 
     for (int il = 0; il < hp.n_layer; il++) {
@@ -499,29 +505,34 @@ hipError_t Context::run_layers(int T, bool graph_mode) {
         const bool any_f = !is_quant(L.wq.type) || !is_quant(L.wk.type) || !is_quant(L.wv.type);
         const bool need_k = is_quant(L.wq.type) && L.wq.type != T_Q8_0 || is_quant(L.wk.type) && L.wk.type != T_Q8_0 || is_quant(L.wv.type) && L.wv.type != T_Q8_0;
         const bool need_0 = L.wq.type == T_Q8_0 || L.wk.type == T_Q8_0 || L.wv.type == T_Q8_0;
-        HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_));
-        prof_mark("norm_quant");
+        const bool fuse_attn = !any_f && can_fuse(E, T);
+        if (fuse_attn) {
+            pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
+        } else {
+            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_));
+            prof_mark("norm_quant");
+        }
         const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
         float *outs[3] = {q_, k_, v_};
         HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
+        pending_fuse_ = Fuse();
         for (int t = 0; t < T; t++) {   // biases are rare on this architecture (one tiny launch per token when present)
             if (L.bq.valid()) HIP_TRY(launch_add(q_ + (size_t)t * E, (const float *)L.bq.data, q_ + (size_t)t * E, (int64_t)E, stream_));
             if (L.bk.valid()) HIP_TRY(launch_add(k_ + (size_t)t * G * D, (const float *)L.bk.data, k_ + (size_t)t * G * D, (int64_t)G * D, stream_));
             if (L.bv.valid()) HIP_TRY(launch_add(v_ + (size_t)t * G * D, (const float *)L.bv.data, v_ + (size_t)t * G * D, (int64_t)G * D, stream_));
         }
         prof_mark("qkv");
-        HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
+        HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
         prof_mark("rope_kv");
         AttnArgs aa{};
         aa.q = q_; aa.out = att_; aa.kv = kv_[(size_t)il]; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
         aa.T = T; aa.H = H; aa.G = G; aa.D = D; aa.n_ctx = (int)cp.n_ctx;
         aa.cell_pos = d_cell_pos_; aa.cell_seq = d_cell_seq_; aa.tok_pos = d_pos_; aa.tok_seq = d_seq_;
         aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_; aa.splits = att_splits_;
+        const bool o_q = is_quant(L.wo.type);
+        aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
         HIP_TRY(launch_flash_attn(aa, stream_));
         prof_mark("attn");
-        const bool o_q = is_quant(L.wo.type);
-        if (o_q) HIP_TRY(launch_quantize(att_, E, T, aq_o_, L.wo.type != T_Q8_0, L.wo.type == T_Q8_0, stream_));
-        prof_mark("quant");
         HIP_TRY(linear(L.wo, aq_o_, att_, E, T, x_, E, x_, EPI_ADD));
         prof_mark("attn_out");
 
@@ -563,11 +574,17 @@ hipError_t Context::run_layers(int T, bool graph_mode) {
             const bool gq = is_quant(L.gate.type), uq = is_quant(L.up.type);
             const bool fk = (gq && L.gate.type != T_Q8_0) || (uq && L.up.type != T_Q8_0);
             const bool f0 = L.gate.type == T_Q8_0 || L.up.type == T_Q8_0;
-            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
-            prof_mark("norm_quant");
+            const bool fuse_ffn = gq && uq && L.gate.type == L.up.type && can_fuse(E, T);
+            Fuse fz;
+            if (fuse_ffn) {
+                fz.mode = 1; fz.x = x_; fz.w = (const float *)L.ffn_norm.data; fz.eps = hp.eps;
+            } else {
+                HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
+                prof_mark("norm_quant");
+            }
             if (gq && uq && L.gate.type == L.up.type) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
-                HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_));
+                HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_, fz));
             } else {
                 HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
@@ -590,13 +607,21 @@ hipError_t Context::run_output(int n_out, int out_base) {
     const int E = hp.n_embd, V = hp.n_vocab;
     HIP_TRY(launch_gather_rows_f32(x_, d_outrow_, n_out, E, xo_, stream_));
     const bool oq = is_quant(model->output.type);
-    HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
-                                 oq && model->output.type != T_Q8_0, model->output.type == T_Q8_0, stream_));
-    prof_mark("norm_quant");
+    if (oq && can_fuse(E, n_out)) {
+        pending_fuse_.mode = 1; pending_fuse_.x = xo_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps;
+    } else {
+        HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
+                                     oq && model->output.type != T_Q8_0, model->output.type == T_Q8_0, stream_));
+        prof_mark("norm_quant");
+    }
     float *lg = d_logits_ + (size_t)out_base * V;
     HIP_TRY(linear(model->output, aq_e_, xn_, E, n_out, lg, V, nullptr, EPI_STORE));
+    pending_fuse_ = Fuse();
     prof_mark("lm_head");
-    HIP_TRY(launch_argmax_rows(lg, V, n_out, d_argmax_ + out_base, stream_));
+    for (int r0 = 0; r0 < n_out; r0 += (int)cp.n_ubatch) {
+        const int nr = std::min((int)cp.n_ubatch, n_out - r0);
+        HIP_TRY(launch_argmax_rows(lg + (size_t)r0 * V, V, nr, d_argmax_ + out_base + r0, argmax_scratch_, stream_));
+    }
     prof_mark("argmax");
     return hipSuccess;
 }

@@ -73,6 +73,12 @@ struct ContextParams {
 
 struct ProfileEntry { std::string name; float us; };
 
+struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.hip stage_act)
+    int mode = 0;
+    const float *x = nullptr, *w = nullptr;
+    float eps = 0.0f;
+};
+
 class Context {
   public:
     Context(Model *m, const ContextParams &p);
@@ -146,6 +152,8 @@ class Context {
     float *moe_w_ = nullptr;
     ActQuant aq_e_, aq_ff_, aq_o_;
     float *att_part_ = nullptr;
+    float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
+    Fuse pending_fuse_;
     int att_splits_ = 1;
     float *dbg_ = nullptr;
     bool debug_taps_ = false;
