@@ -13,10 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [
-    "csrc/mmvq.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/attn.hip",
+    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/attn.hip",
     "host/gguf.cc", "host/runtime.cc", "csrc/c_api.cc",
 ]
-HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "host/gguf.h", "host/runtime.h", "../include/mi355_llama.h"]
+HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "host/gguf.h", "host/runtime.h", "../include/mi355_llama.h"]
 LIB = os.path.join(HERE, "lib", "libmi355_llama.so")
 # -ffp-contract=off: the CPU restatement this backend is checked against does not fuse mul+add
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",

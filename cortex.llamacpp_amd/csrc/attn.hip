@@ -443,6 +443,284 @@ __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *pa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Decode-step variants (T small, D = 128, NORM rope): everything a workgroup needs is requested in ONE round trip.
+
+// K rope + K/V store, 4 consecutive elements per thread (two rope pairs), q8_0 blocks quantised with 8-lane DPP groups.
+template <int TK, int TV>
+__global__ __launch_bounds__(256) void kv_store_fast_kernel(const float *k, const float *v, int GD, int D, const float *cs_table, int n_rot,
+                                                            const int32_t *tok_cell, KVLayerView kv, int n_ctx) {
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int cell = tok_cell[t];
+    for (int e0 = tid * 4; e0 < GD; e0 += 1024) {
+        float4 kk = *reinterpret_cast<const float4 *>(k + (size_t)t * GD + e0);
+        const float4 vv4 = *reinterpret_cast<const float4 *>(v + (size_t)t * GD + e0);
+        const int g = e0 / D, dd = e0 - g * D;
+        if (dd < n_rot) {
+            const float4 cs = *reinterpret_cast<const float4 *>(cs_table + (size_t)t * n_rot + dd);   // c0 s0 c1 s1
+            const float x0 = kk.x, x1 = kk.y, x2 = kk.z, x3 = kk.w;
+            kk.x = x0 * cs.x - x1 * cs.y; kk.y = x0 * cs.y + x1 * cs.x;
+            kk.z = x2 * cs.z - x3 * cs.w; kk.w = x2 * cs.w + x3 * cs.z;
+        }
+        const size_t rowi = (size_t)g * n_ctx + cell;
+        const float ka[4] = {kk.x, kk.y, kk.z, kk.w}, va[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+        if (TK == T_F16) {
+            uint2 o; o.x = (uint32_t)f2h(ka[0]) | ((uint32_t)f2h(ka[1]) << 16); o.y = (uint32_t)f2h(ka[2]) | ((uint32_t)f2h(ka[3]) << 16);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(kv.k) + rowi * D + dd) = o;
+        } else {
+            uint32_t packed; float d;
+            wave_quant_q80(ka, packed, d);
+            *reinterpret_cast<uint32_t *>(kv.k + rowi * D + dd) = packed;
+            if ((lane & 7) == 0) kv.kd[rowi * (D >> 5) + (dd >> 5)] = f2h(d);
+        }
+        if (TV == T_F16) {
+            uint2 o; o.x = (uint32_t)f2h(va[0]) | ((uint32_t)f2h(va[1]) << 16); o.y = (uint32_t)f2h(va[2]) | ((uint32_t)f2h(va[3]) << 16);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(kv.v) + rowi * D + dd) = o;
+        } else {
+            uint32_t packed; float d;
+            wave_quant_q80(va, packed, d);
+            *reinterpret_cast<uint32_t *>(kv.v + rowi * D + dd) = packed;
+            if ((lane & 7) == 0) kv.vd[rowi * (D >> 5) + (dd >> 5)] = f2h(d);
+        }
+    }
+}
+
+bool kv_store_fast_applicable(int G, int D, int type_k, int type_v, const RopeArgs &ra) {
+    return !ra.neox && (G * D) % 1024 == 0 && D % 32 == 0 && (ra.n_rot % 4) == 0 && (type_k == T_F16 || type_k == T_Q8_0) && (type_v == T_F16 || type_v == T_Q8_0);
+}
+hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, int D, const float *cs_table, RopeArgs ra,
+                                const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st) {
+#define KVS(TK, TV) hipLaunchKernelGGL((kv_store_fast_kernel<TK, TV>), dim3(T), dim3(256), 0, st, k, v, G * D, D, cs_table, ra.n_rot, tok_cell, kv, n_ctx)
+    if (type_k == T_F16 && type_v == T_F16) KVS(T_F16, T_F16);
+    else if (type_k == T_Q8_0 && type_v == T_Q8_0) KVS(T_Q8_0, T_Q8_0);
+    else if (type_k == T_Q8_0 && type_v == T_F16) KVS(T_Q8_0, T_F16);
+    else KVS(T_F16, T_Q8_0);
+#undef KVS
+    return hipGetLastError();
+}
+
+// Decode attention: workgroup = (kv head g, chunk of 64 cells, token t).  The query heads of the group are read
+// un-rotated, rotated with the cos/sin table and converted to the K cache's dot type here (so no separate pass over q),
+// and K / V / scales / cell table of the chunk are all requested before the first wait.
+template <int R, int TK, int TV>
+__global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a, const float *cs_table, int n_rot) {
+    constexpr int D = 128, C = 64, NB = 4;
+    constexpr int KP = TK == T_F16 ? 4 : 2;                 // 16-byte K pieces per thread
+    constexpr int LPC = TK == T_F16 ? 16 : 8;               // lanes per cell in the score pass
+    __shared__ __attribute__((aligned(16))) float qf[R * D];         // rotated q (f16-rounded for an f16 cache)
+    __shared__ __attribute__((aligned(16))) int8_t qc[R * D];        // q8_0 codes of q
+    __shared__ float qd[R * NB];
+    __shared__ float S[R * C];
+    __shared__ float ml[R * 2];
+    __shared__ int vis[C];
+    __shared__ uint32_t ksc[C * NB / 2], vsc[C * NB / 2];           // f16 block scales of the chunk
+    __shared__ __attribute__((aligned(16))) float accs[8 * R * D];
+    const int g = blockIdx.x, sp = blockIdx.y, t = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_ctx = a.n_ctx, H = a.H;
+    const int c_lo = sp * C;
+    const size_t head_row0 = (size_t)g * n_ctx;
+
+    // ---- issue every global load of the workgroup
+    int cpos = -1;
+    unsigned long long cseq = 0;
+    if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
+    const int32_t tpos = a.tok_pos[t];
+    const int tseq = a.tok_seq[t];
+    // q pairs: R*64 pairs, pair pp -> (head r = pp / 64, i = pp % 64); NORM pairing (2i, 2i+1)
+    constexpr int NPAIR = R * 64, PPT = (NPAIR + 255) / 256;
+    float2 qv[PPT], csv[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+        const int pp = tid + 256 * j;
+        if (pp < NPAIR) {
+            const int r = pp >> 6, i = pp & 63;
+            qv[j] = *reinterpret_cast<const float2 *>(a.q + ((size_t)t * H + (size_t)g * R + r) * D + 2 * i);
+            csv[j] = (2 * i < n_rot) ? *reinterpret_cast<const float2 *>(cs_table + (size_t)t * n_rot + 2 * i) : make_float2(1.0f, 0.0f);
+        }
+    }
+    uint4 kreg[KP];
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + 256 * j;
+        int cell = c_lo + p / LPC;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TK == T_F16) kreg[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
+        else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * D + (p % LPC) * 16);
+    }
+    const int dq = tid & 31, cg = tid >> 5;
+    uint2 vreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int cell = c_lo + cg + 8 * i;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+        else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
+    }
+    uint32_t ks2 = 0, vs2 = 0;
+    if (tid < C * NB / 2) {
+        int cell = c_lo + tid / 2;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid & 1) * 2);
+        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid & 1) * 2);
+    }
+
+    // ---- q: rotate, convert
+    if (tid < C) vis[tid] = (cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
+    if (tid < C * NB / 2) { ksc[tid] = ks2; vsc[tid] = vs2; }
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+        const int pp = tid + 256 * j;
+        if (pp < NPAIR) {
+            const float x0 = qv[j].x, x1 = qv[j].y, c = csv[j].x, s = csv[j].y;
+            float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;
+            if (TK == T_F16) { y0 = h2f(f2h(y0)); y1 = h2f(f2h(y1)); }
+            *reinterpret_cast<float2 *>(qf + 2 * pp) = make_float2(y0, y1);
+        }
+    }
+    __syncthreads();
+    if (TK != T_F16) {   // q8_0 of the rotated q: 4 values per thread, 8-lane groups
+        for (int e0 = tid * 4; e0 < R * D; e0 += 1024) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(qf + e0);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            uint32_t packed; float d;
+            wave_quant_q80(vv, packed, d);
+            *reinterpret_cast<uint32_t *>(qc + e0) = packed;
+            if ((lane & 7) == 0) qd[e0 >> 5] = h2f(f2h(d));
+        }
+        __syncthreads();
+    }
+
+    // ---- scores
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + 256 * j;
+        const int cl = p / LPC, piece = p % LPC;
+        float sc[R];
+        if (TK == T_F16) {
+            const uint32_t kw[4] = {kreg[j].x, kreg[j].y, kreg[j].z, kreg[j].w};
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float *qq = qf + r * D + piece * 8;
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    s += h2f((uint16_t)(kw[i] & 0xffff)) * qq[2 * i];
+                    s += h2f((uint16_t)(kw[i] >> 16)) * qq[2 * i + 1];
+                }
+                s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s); s += dpp_f<DPP_MIRROR>(s);
+                sc[r] = s;
+            }
+        } else {
+            const uint32_t kpair = ksc[cl * 2 + (piece >> 2)];
+            const float dk = h2f((uint16_t)(((piece >> 1) & 1) ? (kpair >> 16) : (kpair & 0xffff)));
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint4 qq = *reinterpret_cast<const uint4 *>(qc + r * D + piece * 16);
+                int s = 0;
+                s = dot4(kreg[j].x, qq.x, s); s = dot4(kreg[j].y, qq.y, s); s = dot4(kreg[j].z, qq.z, s); s = dot4(kreg[j].w, qq.w, s);
+                s += dpp_i<DPP_QP_1032>(s);                    // both halves of the 32-block (integer)
+                float f = (piece & 1) ? 0.0f : (float)s * (dk * qd[r * NB + (piece >> 1)]);
+                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f); f += dpp_f<DPP_HALF_MIRROR>(f);   // 8 lanes
+                sc[r] = f;
+            }
+        }
+        if (piece == 0) {
+            const bool v = vis[cl] != 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) S[r * C + cl] = v ? sc[r] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax of the chunk: wave w -> heads w, w+4, ...; lane = cell
+    for (int r = wave; r < R; r += 4) {
+        const float s = S[r * C + lane];
+        const float m = wave_max(s);
+        const float p = (s == -INFINITY) ? 0.0f : expf(s - m);
+        const float l = wave_sum(p);
+        S[r * C + lane] = p;
+        if (lane == 0) { ml[2 * r] = m; ml[2 * r + 1] = l; }
+    }
+    __syncthreads();
+
+    // ---- P.V
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int cl = cg + 8 * i;
+        float v4[4];
+        if (TV == T_F16) {
+            v4[0] = h2f((uint16_t)(vreg[i].x & 0xffff)); v4[1] = h2f((uint16_t)(vreg[i].x >> 16));
+            v4[2] = h2f((uint16_t)(vreg[i].y & 0xffff)); v4[3] = h2f((uint16_t)(vreg[i].y >> 16));
+        } else {
+            const uint32_t vpair = vsc[cl * 2 + (dq >> 4)];
+            const float dv = h2f((uint16_t)(((dq >> 3) & 1) ? (vpair >> 16) : (vpair & 0xffff)));
+            const uint32_t w = vreg[i].x;
+            v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
+            v4[2] = (float)(int8_t)((w >> 16) & 0xff) * dv; v4[3] = (float)(int8_t)(w >> 24) * dv;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float p = S[r * C + cl];
+            acc[r][0] += v4[0] * p; acc[r][1] += v4[1] * p; acc[r][2] += v4[2] * p; acc[r][3] += v4[3] * p;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        *reinterpret_cast<float4 *>(accs + ((size_t)cg * R + r) * D + dq * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    __syncthreads();
+    for (int e = tid; e < R * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += accs[((size_t)j * R + r) * D + d];
+        float *dst = a.part + (((size_t)t * H + (size_t)g * R + r) * a.splits + sp) * (D + 2);
+        dst[d] = s;
+        if (d == 0) { dst[D] = ml[2 * r]; dst[D + 1] = ml[2 * r + 1]; }
+    }
+}
+
+bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
+    const int R = a.H / a.G;
+    return a.D == 128 && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 8 &&
+           (a.type_k == T_F16 || a.type_k == T_Q8_0) && (a.type_v == T_F16 || a.type_v == T_Q8_0);
+}
+int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }
+
+// q is the UN-rotated query; a.splits must be flash_attn_decode_splits(a.n_kv_max)
+hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st) {
+    const int R = a.H / a.G;
+    const dim3 grid(a.G, a.splits, a.T);
+#define FAD(RR, TK, TV) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot)
+#define FAD_T(RR)                                                              \
+    if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
+    else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
+    else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
+    else FAD(RR, T_F16, T_Q8_0);
+    switch (R) {
+        case 1: FAD_T(1) break;
+        case 2: FAD_T(2) break;
+        case 4: FAD_T(4) break;
+        case 8: FAD_T(8) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef FAD_T
+#undef FAD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nblk = (a.H * a.D) >> 8;
+    ActQuant qq;
+    if (a.out_q) qq = *a.out_q;
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3((nblk + 3) / 4, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
+    return hipGetLastError();
+}
+
 size_t flash_attn_workspace_floats(int T, int H, int D, int splits) { return (size_t)T * H * splits * (D + 2); }
 
 int flash_attn_pick_splits(int T, int G, int n_kv_max) {

@@ -40,25 +40,87 @@ __host__ __device__ inline size_t dev_row_bytes(int t, int64_t K) {
 }
 
 // ---- wave-level reductions ---------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// DPP butterflies inside each 16-lane row (VALU speed, no LDS crossbar), then the four row totals are read
+// with v_readlane and combined in a fixed order; the result is wave-uniform (valid in every lane).
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+constexpr int DPP_QP_1032 = 0xB1;    // quad_perm [1,0,3,2]
+constexpr int DPP_QP_2301 = 0x4E;    // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;
+constexpr int DPP_MIRROR = 0x140;
+
+__device__ __forceinline__ float row_sum16(float v) {       // every lane of a 16-lane row gets the row total
+    v += dpp_f<DPP_QP_1032>(v);
+    v += dpp_f<DPP_QP_2301>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i<DPP_QP_1032>(v);
+    v += dpp_i<DPP_QP_2301>(v);
+    v += dpp_i<DPP_HALF_MIRROR>(v);
+    v += dpp_i<DPP_MIRROR>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ double dpp_d(double v, int which) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    switch (which) {
+        case 0: lo = dpp_i<DPP_QP_1032>(lo); hi = dpp_i<DPP_QP_1032>(hi); break;
+        case 1: lo = dpp_i<DPP_QP_2301>(lo); hi = dpp_i<DPP_QP_2301>(hi); break;
+        case 2: lo = dpp_i<DPP_HALF_MIRROR>(lo); hi = dpp_i<DPP_HALF_MIRROR>(hi); break;
+        default: lo = dpp_i<DPP_MIRROR>(lo); hi = dpp_i<DPP_MIRROR>(hi); break;
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_d(v, 0); v += dpp_d(v, 1); v += dpp_d(v, 2); v += dpp_d(v, 3);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_QP_1032>(v));
+    v = fmaxf(v, dpp_f<DPP_QP_2301>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#define MI355_MAX64_STEP(CTRL)                                                                        \
+    {                                                                                                 \
+        const unsigned lo = (unsigned)dpp_i<CTRL>((int)(v & 0xffffffffull));                          \
+        const unsigned hi = (unsigned)dpp_i<CTRL>((int)(v >> 32));                                    \
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;                             \
+        v = w > v ? w : v;                                                                            \
+    }
+    MI355_MAX64_STEP(DPP_QP_1032) MI355_MAX64_STEP(DPP_QP_2301) MI355_MAX64_STEP(DPP_HALF_MIRROR) MI355_MAX64_STEP(DPP_MIRROR)
+#undef MI355_MAX64_STEP
+    unsigned long long r = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int l = 0; l < 64; l += 16) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), l);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        r = w > r ? w : r;
+    }
+    return r;
 }
 
 __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }

@@ -50,6 +50,9 @@ struct MMVQArgs {
 };
 
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);
+// single-token fast path (mmvq_fast.hip): persistent, software-pipelined; K % 2048 == 0, K-quant types
+bool mmvq_fast_applicable(const MMVQArgs &a);
+hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st);
 hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_t st);
 void set_num_cu(int n);
 int num_cu();
@@ -125,6 +128,13 @@ struct AttnArgs {
     bool out_q8k, out_q80;
 };
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
+// decode-step variants (attn.hip): single round trip per workgroup; q passed UN-rotated (rope fused), NORM rope, D = 128
+bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra);
+int flash_attn_decode_splits(int n_kv_max);
+hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st);
+bool kv_store_fast_applicable(int G, int D, int type_k, int type_v, const RopeArgs &ra);
+hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, int D, const float *cs_table, RopeArgs ra,
+                                const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);
 size_t flash_attn_workspace_floats(int T, int H, int D, int splits);
 int flash_attn_pick_splits(int T, int G, int n_kv_max);
 

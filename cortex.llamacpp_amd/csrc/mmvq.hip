@@ -514,6 +514,7 @@ static void launch_nt(const MMVQArgs &a, int blocks, int bs, size_t lds, hipStre
 // host launcher: a.T tokens (1, 2 or 4 per launch; larger T is chunked by the caller).
 // EPI_SWIGLU: seg[0] = ffn_gate, seg[1] = ffn_up (same type), out = silu(gate) * up into seg[0].out.
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
+    if (mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
     a.need_q8k = 0; a.need_q80 = 0;
     for (int s = 0; s < a.n_seg; s++) {
         if (a.seg[s].type == T_Q8_0) a.need_q80 = 1; else a.need_q8k = 1;

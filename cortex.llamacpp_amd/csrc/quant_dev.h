@@ -7,15 +7,6 @@
 
 namespace mi355 {
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
-
 // Q8_K: iscale = -127 / (signed value of the FIRST element with the largest magnitude); codes = min(127, rint(iscale*x));
 // d = 1/iscale; bsum16 = sum of the 16-element group this lane belongs to (valid on every lane).
 __device__ __forceinline__ void wave_quant_q8k(const float (&vv)[4], int lane, uint32_t &packed, int &bsum16, float &d) {
@@ -45,17 +36,17 @@ __device__ __forceinline__ void wave_quant_q8k(const float (&vv)[4], int lane, u
     }
     packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) | ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
     int bs = qi[0] + qi[1] + qi[2] + qi[3];
-    bs += __shfl_xor(bs, 1, 64);
-    bs += __shfl_xor(bs, 2, 64);
+    bs += dpp_i<DPP_QP_1032>(bs);       // 16 codes = 4 lanes = one quad
+    bs += dpp_i<DPP_QP_2301>(bs);
     bsum16 = bs;
 }
 
 // Q8_0: per 32 elements (8 lanes): d = amax/127, codes = roundf(x/d); d returned as f32 (store as f16)
 __device__ __forceinline__ void wave_quant_q80(const float (&vv)[4], uint32_t &packed, float &d) {
     float am = fmaxf(fmaxf(fabsf(vv[0]), fabsf(vv[1])), fmaxf(fabsf(vv[2]), fabsf(vv[3])));
-    am = fmaxf(am, __shfl_xor(am, 1, 64));
-    am = fmaxf(am, __shfl_xor(am, 2, 64));
-    am = fmaxf(am, __shfl_xor(am, 4, 64));
+    am = fmaxf(am, dpp_f<DPP_QP_1032>(am));   // 32 values = 8 lanes
+    am = fmaxf(am, dpp_f<DPP_QP_2301>(am));
+    am = fmaxf(am, dpp_f<DPP_HALF_MIRROR>(am));
     d = am / 127.0f;
     const float id = d != 0.0f ? 1.0f / d : 0.0f;
     int qi[4];

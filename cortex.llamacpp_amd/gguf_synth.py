@@ -158,6 +158,8 @@ CONFIGS = {
     # test-sized
     "tiny": LlamaConfig("tiny-test", 256, 2, 4, 2, 512, 512, 10000.0, 1e-5, 512),
     "tiny-gqa4": LlamaConfig("tiny-gqa4", 512, 3, 8, 2, 1024, 768, 500000.0, 1e-5, 1024),
+    "tiny-d128": LlamaConfig("tiny-d128", 1024, 2, 8, 2, 2048, 512, 500000.0, 1e-5, 1024),      # head_dim 128, GQA 4:1
+    "tiny-d128-mha": LlamaConfig("tiny-d128-mha", 512, 2, 4, 4, 1024, 512, 10000.0, 1e-5, 1024),  # head_dim 128, MHA
     "tiny-moe": LlamaConfig("tiny-moe", 256, 2, 4, 2, 512, 512, 1e6, 1e-5, 512, 8, 2),
 }
 

@@ -191,7 +191,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
 Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
 Context::~Context() {
-    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
     if (stage_event_) (void)hipEventDestroy(stage_event_);
     for (auto &pe : prof_events_) (void)hipEventDestroy(pe.second);
     for (void *p : allocs_) (void)hipFree(p);
@@ -305,6 +305,7 @@ bool Context::init(std::string &err) {
         const int sp = flash_attn_pick_splits(t, (int)G, (int)NC);
         ws = std::max(ws, flash_attn_workspace_floats(t, hp.n_head, (int)D, sp));
     }
+    ws = std::max(ws, flash_attn_workspace_floats(std::min<int>((int)T, 8), hp.n_head, (int)D, flash_attn_decode_splits((int)NC)));
     att_part_ = (float *)dalloc(ws * 4);
     if (!att_part_) { err = "attention workspace allocation failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
@@ -486,13 +487,13 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
 }
 
 // ------------------------------------------------------------------------------------------ the forward pass
-hipError_t Context::run_layers(int T, bool graph_mode) {
+hipError_t Context::run_layers(int T, int n_kv_cap) {
     const HParams &hp = model->hp;
     const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
     RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, model->rope_freqs.valid() ? (const float *)model->rope_freqs.data : nullptr, hp.rope_neox};
     const float kq_scale = 1.0f / sqrtf((float)D);
-    const int n_kv_max = graph_mode ? (int)cp.n_ctx : n_kv_;
-    att_splits_ = flash_attn_pick_splits(T, G, graph_mode ? (int)cp.n_ctx : std::max(n_kv_, 1));
+    const int n_kv_max = std::max(n_kv_cap, 1);   // upper bound of occupied cells the kernels are sized for
+    att_splits_ = flash_attn_pick_splits(T, G, n_kv_max);
 
     HIP_TRY(launch_kv_meta_set(d_cell_pos_, d_cell_seq_, d_cell_, d_pos_, d_seqmask_, T, stream_));
     HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
@@ -522,16 +523,25 @@ hipError_t Context::run_layers(int T, bool graph_mode) {
             if (L.bv.valid()) HIP_TRY(launch_add(v_ + (size_t)t * G * D, (const float *)L.bv.data, v_ + (size_t)t * G * D, (int64_t)G * D, stream_));
         }
         prof_mark("qkv");
-        HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
-        prof_mark("rope_kv");
         AttnArgs aa{};
         aa.q = q_; aa.out = att_; aa.kv = kv_[(size_t)il]; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
         aa.T = T; aa.H = H; aa.G = G; aa.D = D; aa.n_ctx = (int)cp.n_ctx;
         aa.cell_pos = d_cell_pos_; aa.cell_seq = d_cell_seq_; aa.tok_pos = d_pos_; aa.tok_seq = d_seq_;
-        aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_; aa.splits = att_splits_;
+        aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_;
         const bool o_q = is_quant(L.wo.type);
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
-        HIP_TRY(launch_flash_attn(aa, stream_));
+        if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
+            // decode-step path: K rope + KV store in one small kernel; q is rotated inside the attention kernel
+            HIP_TRY(launch_kv_store_fast(k_, v_, T, G, D, rope_cs_, ra, d_cell_, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
+            prof_mark("rope_kv");
+            aa.splits = flash_attn_decode_splits(n_kv_max);
+            HIP_TRY(launch_flash_attn_decode(aa, rope_cs_, ra, stream_));
+        } else {
+            HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
+            prof_mark("rope_kv");
+            aa.splits = att_splits_;
+            HIP_TRY(launch_flash_attn(aa, stream_));
+        }
         prof_mark("attn");
         HIP_TRY(linear(L.wo, aq_o_, att_, E, T, x_, E, x_, EPI_ADD));
         prof_mark("attn_out");
@@ -669,11 +679,15 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_;
     hipError_t e = hipSuccess;
     if (graph_ok) {
-        if (!graph_ready_) {
+        // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
+        const int bucket = std::min((int)cp.n_ctx, (n_kv_ + 255) & ~255);
+        auto git = graphs_.find(bucket);
+        graph_exec_ = git == graphs_.end() ? nullptr : git->second;
+        if (!graph_exec_) {
             hipGraph_t g = nullptr;
             e = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                hipError_t e2 = run_layers(1, true);
+                hipError_t e2 = run_layers(1, bucket);
                 if (e2 == hipSuccess) e2 = run_output(1, 0);
                 if (e2 == hipSuccess) e2 = hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, stream_);
                 if (e2 == hipSuccess && cp.logits_to_host) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
@@ -683,12 +697,12 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
             if (e == hipSuccess) e = hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0);
             if (g) (void)hipGraphDestroy(g);
             if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
-            graph_ready_ = true;
+            graphs_[bucket] = graph_exec_;
         }
         e = hipGraphLaunch(graph_exec_, stream_);
     } else {
         prof_begin();
-        e = run_layers(n, false);
+        e = run_layers(n, n_kv_);
         if (e == hipSuccess) e = run_output(n_out, out_base);
         if (e == hipSuccess && n_out > 0) e = hipMemcpyAsync(h_argmax_ + out_base, d_argmax_ + out_base, (size_t)n_out * 4, hipMemcpyDeviceToHost, stream_);
         if (e == hipSuccess && n_out > 0 && cp.logits_to_host)
@@ -743,8 +757,9 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
             if (hipHostMalloc((void **)&h_argmax_, rows * 4, hipHostMallocDefault) != hipSuccess) return -1;
         }
         logits_cap_rows_ = rows;
-        graph_ready_ = false;
-        if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+        for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
+        graphs_.clear();
+        graph_exec_ = nullptr;
     }
     n_out_last_ = n_out;
     logits_fetched_ = false;

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -116,7 +117,7 @@ class Context {
                       const int8_t *flags, int out_base);
     int find_slot(int n);
     void apply_k_shift();
-    hipError_t run_layers(int T, bool graph_mode);
+    hipError_t run_layers(int T, int n_kv_cap);
     hipError_t run_output(int n_out, int out_base);
     hipError_t linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                       const float *resid, int epi);
@@ -167,7 +168,7 @@ class Context {
     bool logits_fetched_ = false, argmax_fetched_ = false;
     // graph for the single-token decode step
     hipGraphExec_t graph_exec_ = nullptr;
-    bool graph_ready_ = false;
+    std::map<int, hipGraphExec_t> graphs_;   // n_kv bucket -> captured decode step
     // profiling
     bool profile_ = false;
     std::vector<std::pair<std::string, hipEvent_t>> prof_events_;
