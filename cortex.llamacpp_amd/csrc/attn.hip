@@ -402,44 +402,70 @@ __global__ __launch_bounds__(256) void flash_attn_split_kernel(const AttnArgs a)
     }
 }
 
-// Merge the KV splits; one wave per 256 output elements (lane = 4 consecutive d of one head), and, when asked,
-// quantise the merged row for the attn_output mat-vec in the same pass (saves a launch on the decode path).
+// Merge the KV splits.  Workgroup = (256 consecutive output elements = 256/D heads, token t).
+//  1. wave w < heads-per-block: lane = split; M = max m, weight_s = exp(m_s - M) / sum_s exp(m_s - M) l_s  -> LDS
+//  2. every thread owns one output element and sums its split partials (independent loads, all in flight)
+//  3. wave 0 re-reads the 256 merged values from LDS (4 per lane) and, when asked, quantises them for the attn_output
+//     mat-vec (saves a launch on the decode path).
 __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits,
                                                                  ActQuant q, int want_q8k, int want_q80) {
-    const int t = blockIdx.y, lane = threadIdx.x & 63;
+    __shared__ float wgt[4 * 64];
+    __shared__ __attribute__((aligned(16))) float merged[256];
+    const int t = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int E = H * D, nblk = E >> 8;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= nblk) return;
-    const int e0 = b * 256 + lane * 4;
-    const int h = e0 / D, d = e0 - h * D;
-    const float *p = part + ((size_t)t * H + h) * splits * (D + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < splits; s++) M = fmaxf(M, p[(size_t)s * (D + 2) + D]);
-    float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
-    float den = 0.0f;
-    for (int s = 0; s < splits; s++) {
-        const float m = p[(size_t)s * (D + 2) + D];
-        if (m == -INFINITY) continue;
-        const float w = expf(m - M);
-        const float *ps = p + (size_t)s * (D + 2) + d;
-        num.x += w * ps[0]; num.y += w * ps[1]; num.z += w * ps[2]; num.w += w * ps[3];
-        den += w * p[(size_t)s * (D + 2) + D + 1];
+    const int hpb = 256 / D;                       // heads per block (D = 64 -> 4, D = 128 -> 2)
+    const int h0 = b * hpb;
+    if (wave < hpb) {
+        const float *p = part + ((size_t)t * H + h0 + wave) * splits * (D + 2);
+        float M = -INFINITY;
+        for (int s0 = 0; s0 < splits; s0 += 64) {
+            const int sidx = s0 + lane;
+            const float m = sidx < splits ? p[(size_t)sidx * (D + 2) + D] : -INFINITY;
+            M = fmaxf(M, wave_max(m));
+        }
+        float den = 0.0f;
+        for (int s0 = 0; s0 < splits; s0 += 64) {
+            const int sidx = s0 + lane;
+            float w = 0.0f, l = 0.0f;
+            if (sidx < splits) {
+                const float m = p[(size_t)sidx * (D + 2) + D];
+                l = p[(size_t)sidx * (D + 2) + D + 1];
+                w = (m == -INFINITY) ? 0.0f : expf(m - M);
+            }
+            den += wave_sum(w * l);
+            if (sidx < splits && s0 == 0) wgt[wave * 64 + lane] = w;   // splits <= 64 on this path (host-checked)
+        }
+        const float inv = 1.0f / den;
+        if (lane < splits) wgt[wave * 64 + lane] *= inv;
     }
-    const float inv = 1.0f / den;
-    const float vv[4] = {num.x * inv, num.y * inv, num.z * inv, num.w * inv};
-    *reinterpret_cast<float4 *>(out + (size_t)t * E + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    if (want_q8k) {
-        uint32_t packed; int bs; float dq;
-        wave_quant_q8k(vv, lane, packed, bs, dq);
-        *reinterpret_cast<uint32_t *>(q.qs + (size_t)t * E + e0) = packed;
-        if ((lane & 3) == 0) q.bsums[(size_t)t * (E >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
-        if (lane == 0) q.d[(size_t)t * nblk + b] = dq;
+    __syncthreads();
+    {
+        const int e = tid, hl = e / D, d = e - hl * D;
+        const float *p = part + ((size_t)t * H + h0 + hl) * splits * (D + 2) + d;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int s = 0; s < splits; s++) acc += wgt[hl * 64 + s] * p[(size_t)s * (D + 2)];
+        merged[e] = acc;
+        out[(size_t)t * E + b * 256 + e] = acc;
     }
-    if (want_q80) {
-        uint32_t packed; float dd;
-        wave_quant_q80(vv, packed, dd);
-        *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)t * E + e0) = packed;
-        if ((lane & 7) == 0) q.d0[(size_t)t * (E >> 5) + b * 8 + (lane >> 3)] = f2h(dd);
+    __syncthreads();
+    if (wave == 0 && (want_q8k || want_q80)) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(merged + lane * 4);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int e0 = b * 256 + lane * 4;
+        if (want_q8k) {
+            uint32_t packed; int bs; float dq;
+            wave_quant_q8k(vv, lane, packed, bs, dq);
+            *reinterpret_cast<uint32_t *>(q.qs + (size_t)t * E + e0) = packed;
+            if ((lane & 3) == 0) q.bsums[(size_t)t * (E >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+            if (lane == 0) q.d[(size_t)t * nblk + b] = dq;
+        }
+        if (want_q80) {
+            uint32_t packed; float dd;
+            wave_quant_q80(vv, packed, dd);
+            *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)t * E + e0) = packed;
+            if ((lane & 7) == 0) q.d0[(size_t)t * (E >> 5) + b * 8 + (lane >> 3)] = f2h(dd);
+        }
     }
 }
 
@@ -687,10 +713,10 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
 
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
-    return a.D == 128 && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 8 &&
+    return a.D == 128 && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 8 && a.n_kv_max <= 64 * 64 &&
            (a.type_k == T_F16 || a.type_k == T_Q8_0) && (a.type_v == T_F16 || a.type_v == T_Q8_0);
 }
-int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }
+int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }   // <= 64 (applicability check)
 
 // q is the UN-rotated query; a.splits must be flash_attn_decode_splits(a.n_kv_max)
 hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st) {
@@ -716,7 +742,7 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     const int nblk = (a.H * a.D) >> 8;
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
-    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3((nblk + 3) / 4, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
                        qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
     return hipGetLastError();
 }
@@ -730,6 +756,7 @@ int flash_attn_pick_splits(int T, int G, int n_kv_max) {
     int want = (num_cu() * 2) / (T * G > 0 ? T * G : 1);
     int by_len = (n_kv_max + 63) / 64;
     if (want > by_len) want = by_len;
+    if (want > 64) want = 64;                 // the merge kernel holds one split per lane
     if (want < min_splits) want = min_splits;
     if (want < 1) want = 1;
     return want;
@@ -759,7 +786,7 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
     const int nblk = (a.H * a.D) >> 8;
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
-    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3((nblk + 3) / 4, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
                        qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
     return hipGetLastError();
 }

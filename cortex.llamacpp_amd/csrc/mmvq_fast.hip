@@ -176,7 +176,7 @@ __device__ __forceinline__ ActL stage_q8k(const MMVQArgs &a, uint8_t *smem) {
     } else {
         double *red = reinterpret_cast<double *>(smem + a.red_off);
         const int lane = tid & 63, wave = tid >> 6;
-        constexpr int MAXJ = 8;
+        constexpr int MAXJ = 8;                  // K <= 8192
         float4 xv[MAXJ], wv[MAXJ];
         const int nj = K >> 10;
 #pragma unroll
@@ -350,7 +350,21 @@ bool mmvq_fast_applicable(const MMVQArgs &a) {
 hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
     if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
     const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
-    const int max_blocks = num_cu() * 3;             // 3 workgroups of 4 waves per CU (launch bound: 3 waves / SIMD)
+    // persistent grid: k workgroups per CU (k <= 3, launch bound 3 waves / SIMD); pick the k whose unit count per wave
+    // divides most evenly (e.g. 14336 pairs over 2 x 256 x 4 waves = exactly 7 units each), ties -> larger k
+    int total_pairs_all = 0, nchunk_all = 1;
+    for (int s = 0; s < (a.epi == EPI_SWIGLU ? 1 : a.n_seg); s++) total_pairs_all += a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
+    nchunk_all = ((a.K >> 11) + 1) >> 1;
+    int best_k = 3;
+    double best_cost = 1e30;
+    for (int k = 3; k >= 1; k--) {
+        const long waves = (long)num_cu() * k * 4;
+        const long rounds = (total_pairs_all + waves - 1) / waves;          // pairs per wave, rounded up
+        // time ~ rounds * chunks-per-pair, with fewer resident waves costing a little latency hiding
+        const double cost = (double)rounds * nchunk_all * (k == 3 ? 1.0 : k == 2 ? 1.04 : 1.15);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_k = k; }
+    }
+    const int max_blocks = num_cu() * best_k;
     size_t bytes[3] = {0, 0, 0}, total = 0;
     int want[3] = {0, 0, 0}, sum_want = 0;
     for (int s = 0; s < n_work_seg; s++) {

@@ -601,9 +601,15 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
             }
             prof_mark("ffn_gate_up");
-            if (is_quant(L.down.type)) HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
-            prof_mark("quant");
+            const bool fuse_down = false;   // measured: the in-kernel quantise of a 14336-vector costs as much as the separate launch
+            if (fuse_down) {
+                pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
+            } else if (is_quant(L.down.type)) {
+                HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
+                prof_mark("quant");
+            }
             HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, T, x_, E, x_, EPI_ADD));
+            pending_fuse_ = Fuse();
             prof_mark("ffn_down");
         }
         if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));

@@ -63,7 +63,32 @@ int main(int argc, char **argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, gb = (double)wbytes * nmat / 1e9;
-    printf("mmvq type=%d N=%d K=%d epi=%d fuse=%d: %.2f us/launch, %.1f MB, %.0f GB/s\n", type, N, K, epi, fuse, us, gb * 1e3, gb / (us * 1e-6));
+    printf("mmvq type=%d N=%d K=%d epi=%d fuse=%d: %.2f us/launch, %.1f MB, %.0f GB/s", type, N, K, epi, fuse, us, gb * 1e3, gb / (us * 1e-6));
+    {   // the same launches replayed from a hipGraph (what the decode step does): no host launch-rate floor
+        hipStream_t st; hipStreamCreate(&st);
+        hipGraph_t g; hipGraphExec_t ge;
+        auto run_st = [&](int i) {
+            MMVQArgs a{};
+            a.n_seg = nmat; a.K = K; a.T = 1; a.epi = epi;
+            for (int s = 0; s < nmat; s++) {
+                a.seg[s].W = W[(i % nbuf) * nmat + s]; a.seg[s].out = out + (size_t)s * N; a.seg[s].resid = out; a.seg[s].type = type;
+                a.seg[s].n_rows = N; a.seg[s].ld_out = N; a.seg[s].row_bytes = rb;
+            }
+            a.aq = aq; a.ad = ad; a.abs = abs_; a.aq0 = aq; a.ad0 = ad0;
+            a.fuse_mode = fuse; a.nx = x; a.nw = nw; a.neps = 1e-5f;
+            launch_mmvq(a, st);
+        };
+        hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        for (int i = 0; i < 32; i++) run_st(i);
+        hipStreamEndCapture(st, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        for (int i = 0; i < 3; i++) hipGraphLaunch(ge, st);
+        hipStreamSynchronize(st); hipEventRecord(e0, st);
+        for (int i = 0; i < 10; i++) hipGraphLaunch(ge, st);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double usg = ms * 1e3 / 320;
+        printf("   | in hipGraph: %.2f us, %.0f GB/s\n", usg, gb / (usg * 1e-6));
+    }
     // plain streaming read of the same buffers for comparison
     for (int blocks : {1024, 2048, 4096}) {
         hipEventRecord(e0);
