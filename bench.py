@@ -40,7 +40,7 @@ def main() -> int:
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--cache-type", default="q8_0", choices=["f16", "q8_0", "q4_0"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--model-dir", default=os.environ.get("MI355_BENCH_DIR", "/tmp"))
     ap.add_argument("--keep-model", action="store_true")
     args = ap.parse_args()
@@ -189,7 +189,7 @@ def main() -> int:
         "decode_hbm_fraction_of_8TBps": round(decode_frac, 4),
         "roofline": {
             "bound": "hbm",
-            "kernel": "mmvq_kernel<1> (quantised mat-vec, all weight tensors of one token)",
+            "kernel": "mmvq_fast_kernel (single-token quantised mat-vec, every weight tensor of one token)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -207,7 +207,11 @@ def main() -> int:
     # ---- CPU baseline: the oracle (a port, not the reference binary) on the host cores, bounded sample
     if not args.no_cpu_baseline and world == 1:
         import oracle_py as oq
-        nth = os.cpu_count() or 1
+        try:
+            nth = len(os.sched_getaffinity(0))
+        except AttributeError:
+            nth = os.cpu_count() or 1
+        nth = max(1, min(nth, 32))                           # the scalar port stops scaling (and oversubscribes) beyond this
         om = oq.OracleModel(path)
         oc = oq.OracleContext(om, 64, KV, KV, True, nth)
         oc.decode(prompt[:4], np.arange(4))              # untimed warm-up (page-in of the mmap'd weights)
