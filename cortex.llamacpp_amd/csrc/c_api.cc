@@ -265,7 +265,7 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
         if (e != hipSuccess) return hip_fail(e, "quantize");
         for (int64_t t0 = 0; t0 < T;) {
             const int64_t rem = T - t0;
-            const int nt = rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+            const int nt = rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
             MMVQArgs a{};
             a.n_seg = 1; a.K = (int)K; a.T = nt; a.epi = EPI_STORE;
             a.seg[0].W = wdev.as<uint8_t>(); a.seg[0].out = dy.as<float>() + t0 * N; a.seg[0].type = type; a.seg[0].n_rows = (int)N;

@@ -38,7 +38,8 @@ struct ActLds {
     const int16_t *bs;     // [T][K/16]
     const int8_t *qs0;     // [T][K]      q8_0 codes
     const uint16_t *d0;    // [T][K/32]   f16
-    int K;
+    int K;                 // row stride of the staged codes (elements): K, or the chunk length for the tiled kernel;
+                           // for a staged K-chunk the pointers are pre-biased by -k0 so absolute block indices still work
 };
 
 __device__ __forceinline__ uint4 ld16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -101,9 +102,9 @@ template <> struct Item<T_Q4_K> {
         dl = dot4(q.y & 0x0f0f0f0f, lo.y, dl); dh = dot4((q.y >> 4) & 0x0f0f0f0f, hi.y, dh);
         dl = dot4(q.z & 0x0f0f0f0f, lo.z, dl); dh = dot4((q.z >> 4) & 0x0f0f0f0f, hi.z, dh);
         dl = dot4(q.w & 0x0f0f0f0f, lo.w, dl); dh = dot4((q.w >> 4) & 0x0f0f0f0f, hi.w, dh);
-        isum = sc_lo * dl + sc_hi * dh;
+        isum = __mul24(sc_lo, dl) + __mul24(sc_hi, dh);
         const int16_t *bs = A.bs + (size_t)t * (A.K >> 4) + sb * 16 + 4 * c + h;
-        msum = m_lo * (int)bs[0] + m_hi * (int)bs[2];
+        msum = __mul24(m_lo, (int)bs[0]) + __mul24(m_hi, (int)bs[2]);
     }
     __device__ __forceinline__ float dot(const ActLds &A, int t, int lane) const {
         if (!valid) return 0.0f;
@@ -165,9 +166,9 @@ template <> struct Item<T_Q5_K> {
         dl = dot4(Q5_LO(q.w, qh.w), lo.w, dl); dh = dot4(Q5_HI(q.w, qh.w), hi.w, dh);
 #undef Q5_LO
 #undef Q5_HI
-        isum = sc_lo * dl + sc_hi * dh;
+        isum = __mul24(sc_lo, dl) + __mul24(sc_hi, dh);
         const int16_t *bs = A.bs + (size_t)t * (A.K >> 4) + sb * 16 + 4 * c + h;
-        msum = m_lo * (int)bs[0] + m_hi * (int)bs[2];
+        msum = __mul24(m_lo, (int)bs[0]) + __mul24(m_hi, (int)bs[2]);
     }
     __device__ __forceinline__ float dot(const ActLds &A, int t, int lane) const {
         if (!valid) return 0.0f;
@@ -224,7 +225,7 @@ template <> struct Item<T_Q6_K> {
         dl = dot4(ql.z, lo.z, dl); dh = dot4(qh.z, hi.z, dh);
         dl = dot4(ql.w, lo.w, dl); dh = dot4(qh.w, hi.w, dh);
         const int16_t *bs = A.bs + (size_t)t * (A.K >> 4) + sb * 16 + 8 * n + w;
-        isum = sc_lo * (dl - 32 * (int)bs[0]) + sc_hi * (dh - 32 * (int)bs[4]);
+        isum = __mul24(sc_lo, dl - 32 * (int)bs[0]) + __mul24(sc_hi, dh - 32 * (int)bs[4]);
         msum = 0;
     }
     __device__ __forceinline__ float dot(const ActLds &A, int t, int lane) const {
@@ -493,6 +494,150 @@ __global__ __launch_bounds__(BS) void mmvq_kernel(const MMVQArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Prompt-processing variant: NT tokens per launch (8/16), rows owned by a wave for the whole kernel, the K axis walked
+// in chunks of 4096 elements whose Q8_K activations (NT x 4096 codes) are re-staged in LDS per chunk.  Each weight byte
+// is read once per NT tokens.  Integer path identical to the single-token kernels (exact partial sums).
+// (Placeholder for the MFMA mul_mat_q of DESIGN.md section 7: this one is v_dot4 / VALU bound.)
+template <int TYPE, int NT>
+__device__ __forceinline__ void run_tiled(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int blk_in_seg) {
+    using It = Item<TYPE>;
+    constexpr int KC = 4096;
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = a.K;
+    const bool swiglu = a.epi == EPI_SWIGLU;
+    const uint8_t *W0 = sg.W;
+    const MMVQSeg &ug = a.seg[1];
+    const uint8_t *W1 = swiglu ? ug.W : nullptr;
+    const size_t rb0 = sg.row_bytes, rb1 = swiglu ? ug.row_bytes : sg.row_bytes;
+    const int npass = (K + It::EPP - 1) / It::EPP;
+    const int ppc = KC / It::EPP;                      // passes per chunk (2 for K-quants, 4 for Q8_0)
+    const int nchunk = (K + KC - 1) / KC;
+    const int pair = blk_in_seg * 4 + wave;
+    const int npairs = swiglu ? sg.n_rows : (sg.n_rows + 1) >> 1;
+    const bool have = pair < npairs;
+    const uint8_t *ra = nullptr, *rbp = nullptr;
+    bool hasb = false;
+    if (have) {
+        if (swiglu) { ra = W0 + (size_t)pair * rb0; rbp = W1 + (size_t)pair * rb1; hasb = true; }
+        else { ra = W0 + (size_t)(2 * pair) * rb0; rbp = ra + rb0; hasb = 2 * pair + 1 < sg.n_rows; }
+    }
+    int8_t *qs = reinterpret_cast<int8_t *>(smem);
+    float *dd = reinterpret_cast<float *>(smem + (size_t)NT * KC);
+    int16_t *bs = reinterpret_cast<int16_t *>(smem + (size_t)NT * KC + NT * (KC >> 8) * 4);
+    uint16_t *d0 = reinterpret_cast<uint16_t *>(dd);   // Q8_0 activations reuse the scale area (KC/32 halves per token fit: 256 B <= 64+512)
+    float acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { acc[0][t] = 0.0f; acc[1][t] = 0.0f; }
+    for (int c = 0; c < nchunk; c++) {
+        const int k0 = c * KC, kc = (K - k0) < KC ? (K - k0) : KC;
+        __syncthreads();                                   // everyone is done with the previous chunk's LDS image
+        for (int pp = 0; pp < ppc; pp += 2) {
+            const int ps = c * ppc + pp;
+            It i0, i1, i2, i3;
+            if (have && ps < npass) { i0.load(ra, K, ps, lane); if (hasb) i1.load(rbp, K, ps, lane); else i1.valid = false; }
+            else { i0.valid = false; i1.valid = false; }
+            if (have && ps + 1 < npass) { i2.load(ra, K, ps + 1, lane); if (hasb) i3.load(rbp, K, ps + 1, lane); else i3.valid = false; }
+            else { i2.valid = false; i3.valid = false; }
+            if (pp == 0) {                                 // stage this chunk's activations (all waves), loads already in flight
+                if (TYPE == T_Q8_0) {
+                    for (int i = tid; i < NT * (kc >> 4); i += 256) {
+                        const int t = i / (kc >> 4), j = i - t * (kc >> 4);
+                        reinterpret_cast<uint4 *>(qs + (size_t)t * kc)[j] = reinterpret_cast<const uint4 *>(a.aq0 + (size_t)t * K + k0)[j];
+                    }
+                    for (int i = tid; i < NT * (kc >> 5); i += 256) {
+                        const int t = i / (kc >> 5), j = i - t * (kc >> 5);
+                        d0[t * (kc >> 5) + j] = a.ad0[(size_t)t * (K >> 5) + (k0 >> 5) + j];
+                    }
+                } else {
+                    for (int i = tid; i < NT * (kc >> 4); i += 256) {
+                        const int t = i / (kc >> 4), j = i - t * (kc >> 4);
+                        reinterpret_cast<uint4 *>(qs + (size_t)t * kc)[j] = reinterpret_cast<const uint4 *>(a.aq + (size_t)t * K + k0)[j];
+                    }
+                    for (int i = tid; i < NT * (kc >> 8); i += 256) {
+                        const int t = i / (kc >> 8), j = i - t * (kc >> 8);
+                        dd[t * (kc >> 8) + j] = a.ad[(size_t)t * (K >> 8) + (k0 >> 8) + j];
+                    }
+                    for (int i = tid; i < NT * (kc >> 4); i += 256) {
+                        const int t = i / (kc >> 4), j = i - t * (kc >> 4);
+                        bs[t * (kc >> 4) + j] = a.abs[(size_t)t * (K >> 4) + (k0 >> 4) + j];
+                    }
+                }
+                __syncthreads();
+            }
+            ActLds A;
+            A.K = kc;
+            A.qs = qs - k0; A.d = dd - (k0 >> 8); A.bs = bs - (k0 >> 4); A.qs0 = qs - k0; A.d0 = d0 - (k0 >> 5);
+            i0.prep(lane);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[0][t] += i0.dot(A, t, lane);
+            i1.prep(lane);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[1][t] += i1.dot(A, t, lane);
+            i2.prep(lane);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[0][t] += i2.dot(A, t, lane);
+            i3.prep(lane);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[1][t] += i3.dot(A, t, lane);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float v0 = wave_sum(acc[0][t]), v1 = wave_sum(acc[1][t]);
+        if (lane == 0 && have) {
+            if (swiglu) {
+                sg.out[(size_t)t * sg.ld_out + pair] = (v0 / (1.0f + expf(-v0))) * v1;
+            } else {
+                const int row0 = 2 * pair;
+                const size_t o = (size_t)t * sg.ld_out + row0;
+                if (a.epi == EPI_ADD) {
+                    sg.out[o] = sg.resid[o] + v0;
+                    if (hasb) sg.out[o + 1] = sg.resid[o + 1] + v1;
+                } else {
+                    sg.out[o] = v0;
+                    if (hasb) sg.out[o + 1] = v1;
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void mmvq_tiled_kernel(const MMVQArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int s = 0;
+    if (a.n_seg > 1 && (int)blockIdx.x >= a.seg_block0[1]) s = 1;
+    if (a.n_seg > 2 && (int)blockIdx.x >= a.seg_block0[2]) s = 2;
+    const int bis = (int)blockIdx.x - a.seg_block0[s];
+    switch (a.seg[s].type) {
+        case T_Q4_K: run_tiled<T_Q4_K, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q5_K: run_tiled<T_Q5_K, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q6_K: run_tiled<T_Q6_K, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q8_0: run_tiled<T_Q8_0, NT>(a, a.seg[s], smem, bis); break;
+        default: break;
+    }
+}
+
+static hipError_t launch_tiled(MMVQArgs a, hipStream_t st) {
+    if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
+    const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
+    a.seg_block0[0] = 0;
+    for (int s = 0; s < n_work_seg; s++) {
+        const int pairs = a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
+        a.seg_block0[s + 1] = a.seg_block0[s] + (pairs + 3) / 4;
+    }
+    for (int s = n_work_seg; s < 3; s++) a.seg_block0[s + 1] = a.seg_block0[n_work_seg];
+    const int blocks = a.seg_block0[n_work_seg];
+    if (a.epi == EPI_SWIGLU) a.n_seg = 1;
+    const size_t lds = (size_t)a.T * 4096 + (size_t)a.T * 16 * 4 + (size_t)a.T * 256 * 2 + 64;
+    if (a.T == 16) hipLaunchKernelGGL(mmvq_tiled_kernel<16>, dim3(blocks), dim3(256), lds, st, a);
+    else if (a.T == 8) hipLaunchKernelGGL(mmvq_tiled_kernel<8>, dim3(blocks), dim3(256), lds, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 size_t mmvq_lds_bytes(const MMVQArgs &a, int NT) {
     size_t b = 0;
     const size_t K = (size_t)a.K;
@@ -515,6 +660,12 @@ static void launch_nt(const MMVQArgs &a, int blocks, int bs, size_t lds, hipStre
 // EPI_SWIGLU: seg[0] = ffn_gate, seg[1] = ffn_up (same type), out = silu(gate) * up into seg[0].out.
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     if (mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
+    if ((a.T == 16 || a.T == 8) && a.fuse_mode == 0) {
+        bool moe = false;
+        for (int s = 0; s < a.n_seg; s++) moe |= a.seg[s].expert_sel != nullptr;
+        if (!moe) return launch_tiled(a, st);
+        return hipErrorInvalidValue;
+    }
     a.need_q8k = 0; a.need_q80 = 0;
     for (int s = 0; s < a.n_seg; s++) {
         if (a.seg[s].type == T_Q8_0) a.need_q80 = 1; else a.need_q8k = 1;

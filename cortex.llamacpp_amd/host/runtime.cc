@@ -444,7 +444,7 @@ static bool can_fuse(int K, int T) { return T == 1 && K <= 8192 && (K & 1023) ==
 
 static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, const ActQuant &aq, hipStream_t st, const Fuse &fz = Fuse()) {
     for (int t0 = 0; t0 < T;) {
-        const int rem = T - t0, nt = rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
+        const int rem = T - t0, nt = rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;
         MMVQArgs a{};
         a.n_seg = n_seg; a.K = K; a.T = nt; a.epi = epi;
         a.fuse_mode = fz.mode; a.nx = fz.x; a.nw = fz.w; a.neps = fz.eps;
