@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [
-    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/attn.hip",
+    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmq.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/attn.hip",
     "host/gguf.cc", "host/runtime.cc", "csrc/c_api.cc",
 ]
 HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "host/gguf.h", "host/runtime.h", "../include/mi355_llama.h"]

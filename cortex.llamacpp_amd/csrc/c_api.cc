@@ -263,6 +263,14 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
     if (quant) {
         e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, type != T_Q8_0, type == T_Q8_0, nullptr);
         if (e != hipSuccess) return hip_fail(e, "quantize");
+        if (mmq_applicable(type, (int)K, (int)T)) {
+            DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
+            if (!bh.p || !bl.p) return MI355_ERR_OOM;
+            e = launch_mmq_prep(ab.q, (int)K, (int)T, bh.as<int8_t>(), bl.as<int8_t>(), nullptr);
+            if (e == hipSuccess) e = launch_mmq(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_fail(e, "mmq");
+        } else
         for (int64_t t0 = 0; t0 < T;) {
             const int64_t rem = T - t0;
             const int nt = rem >= 16 ? 16 : rem >= 8 ? 8 : rem >= 4 ? 4 : rem >= 2 ? 2 : 1;

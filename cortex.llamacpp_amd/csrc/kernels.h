@@ -57,6 +57,13 @@ hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_
 void set_num_cu(int n);
 int num_cu();
 
+// ---------------------------------------------------------------- batched prefill contraction on MFMA (mmq.hip)
+bool mmq_applicable(int type, int K, int T);
+size_t mmq_prep_bytes(int K, int T);                       // bytes of each of the two block-sum planes
+hipError_t launch_mmq_prep(const ActQuant &q, int K, int T, int8_t *bh, int8_t *bl, hipStream_t st);
+hipError_t launch_mmq(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
+                      const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st);
+
 // ---------------------------------------------------------------- activation-side kernels (act.hip)
 // y = rms_norm(x) * w  for T rows of n; optionally f32 out and/or q8_K / q8_0 planes
 hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, float eps,

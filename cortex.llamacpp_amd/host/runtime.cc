@@ -298,6 +298,8 @@ bool Context::init(std::string &err) {
     alloc_actq(aq_e_, E, T, true, true, allocs_, device_bytes, ok);
     alloc_actq(aq_o_, E, T, true, true, allocs_, device_bytes, ok);
     alloc_actq(aq_ff_, FF, T, true, true, allocs_, device_bytes, ok);
+    mmq_bh_ = (int8_t *)dalloc(T * (std::max(E, FF) / 32));
+    mmq_bl_ = (int8_t *)dalloc(T * (std::max(E, FF) / 32));
     if (!ok || !x_ || !ffn_u_) { err = "activation buffer allocation failed"; return false; }
 
     size_t ws = 0;
@@ -464,6 +466,10 @@ static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, c
 hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
+        if (mmq_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // prompt processing: MFMA path
+            HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+            return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+        }
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
         return mmvq_tokens(&s, 1, K, T, epi, aq, stream_, pending_fuse_);
     }
@@ -474,6 +480,14 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     bool all_q = true;
     for (int i = 0; i < n; i++) all_q &= is_quant(ws[i]->type);
     const int K = (int)ws[0]->K;
+    bool all_mmq = true;
+    for (int i = 0; i < n; i++) all_mmq &= mmq_applicable(ws[i]->type, K, T);
+    if (all_mmq && pending_fuse_.mode == 0) {
+        HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+        for (int i = 0; i < n; i++)
+            HIP_TRY(launch_mmq(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
+        return hipSuccess;
+    }
     if (all_q && n <= 3) {
         MMVQSeg segs[3];
         for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
@@ -592,7 +606,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
                 prof_mark("norm_quant");
             }
-            if (gq && uq && L.gate.type == L.up.type) {
+            const bool ffn_mmq = mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T);
+            if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_, fz));
             } else {

@@ -152,6 +152,7 @@ class Context {
     int32_t *moe_ids_ = nullptr;
     float *moe_w_ = nullptr;
     ActQuant aq_e_, aq_ff_, aq_o_;
+    int8_t *mmq_bh_ = nullptr, *mmq_bl_ = nullptr;   // (hi, lo) planes of the 32-code block sums for the MFMA path
     float *att_part_ = nullptr;
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;
