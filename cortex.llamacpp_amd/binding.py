@@ -37,6 +37,7 @@ class Batch(C.Structure):
 
 # every symbol include/mi355_llama.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u32, _u64, _f32, _sz, _cp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t, C.c_char_p
+ENGINE_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p, C.c_void_p)
 SYMBOLS = {
     "mi355_backend_init": (C.c_int, []),
     "mi355_backend_free": (None, []),
@@ -92,6 +93,21 @@ SYMBOLS = {
     "mi355_profile_last_decode": (_i32, [_vp, C.POINTER(_cp), C.POINTER(_f32), _i32]),
     "mi355_profile_enable": (None, [_vp, _i32]),
     "mi355_bench_weight_sweep": (C.c_double, [_vp, C.c_int, C.POINTER(_u64)]),
+    "mi355_tokenize": (_i32, [_vp, _cp, _i32, C.POINTER(C.c_int32), _i32, _i32, _i32]),
+    "mi355_token_to_piece": (_i32, [_vp, _i32, C.c_char_p, _i32, _i32]),
+    "mi355_token_bos": (_i32, [_vp]),
+    "mi355_token_eos": (_i32, [_vp]),
+    "mi355_token_is_eog": (_i32, [_vp, _i32]),
+    "mi355_engine_create": (_vp, []),
+    "mi355_engine_destroy": (None, [_vp]),
+    "mi355_engine_load_model": (None, [_vp, _cp, ENGINE_CB, _vp]),
+    "mi355_engine_unload_model": (None, [_vp, _cp, ENGINE_CB, _vp]),
+    "mi355_engine_get_model_status": (None, [_vp, _cp, ENGINE_CB, _vp]),
+    "mi355_engine_get_models": (None, [_vp, _cp, ENGINE_CB, _vp]),
+    "mi355_engine_handle_chat_completion": (None, [_vp, _cp, ENGINE_CB, _vp]),
+    "mi355_engine_handle_embedding": (None, [_vp, _cp, ENGINE_CB, _vp]),
+    "mi355_engine_is_supported": (_i32, [_vp, _cp]),
+    "mi355_engine_stop_inferencing": (None, [_vp, _cp]),
 }
 
 _lib = None
@@ -244,6 +260,22 @@ class Model:
             return buf.value.decode()
         return None
 
+    def tokenize(self, text: str, add_special: bool = True, parse_special: bool = False) -> list[int]:
+        raw = text.encode()
+        cap = len(raw) + 8
+        out = (C.c_int32 * cap)()
+        n = self.lib.mi355_tokenize(self.h, raw, len(raw), out, cap, int(add_special), int(parse_special))
+        if n < 0:
+            raise MI355Error(f"mi355_tokenize failed: {_err(self.lib)}")
+        return list(out[:n])
+
+    def token_to_piece(self, tok: int, special: bool = True) -> bytes:
+        buf = C.create_string_buffer(256)
+        n = self.lib.mi355_token_to_piece(self.h, tok, buf, 256, int(special))
+        if n < 0:
+            raise MI355Error(f"mi355_token_to_piece failed: {_err(self.lib)}")
+        return buf.raw[:n]
+
     def close(self):
         if self.h:
             self.lib.mi355_model_free(self.h)
@@ -355,4 +387,64 @@ class Context:
             self._b = None
         if self.h:
             self.lib.mi355_context_free(self.h)
+            self.h = None
+
+
+class Engine:
+    """ctypes view of mi355_engine_* — the reference's EngineI surface (base/cortex-common/enginei.h:13-74) with JSON text
+    bodies.  Every call returns the list of (status, body) pairs the callback received; a streaming chat completion
+    returns one pair per SSE chunk."""
+
+    def __init__(self):
+        import json
+        import threading
+        self._json, self._threading = json, threading
+        self.lib = load_library()
+        self.h = self.lib.mi355_engine_create()
+        if not self.h:
+            raise MI355Error(f"mi355_engine_create failed: {_err(self.lib)}")
+
+    def _call(self, fn, body: dict, wait_done: bool = True, timeout: float = 300.0):
+        out, done = [], self._threading.Event()
+
+        def on(status, payload, _user):
+            st, bd = self._json.loads(status.decode()), self._json.loads(payload.decode())
+            out.append((st, bd))
+            if st.get("is_done", True) or st.get("has_error", False):
+                done.set()
+
+        cb = ENGINE_CB(on)
+        fn(self.h, self._json.dumps(body).encode(), cb, None)
+        if wait_done and not done.wait(timeout):
+            raise MI355Error("engine call timed out")
+        self._keep = cb   # the callback object must outlive the native call
+        return out
+
+    def load_model(self, **body):
+        return self._call(self.lib.mi355_engine_load_model, body)[-1]
+
+    def unload_model(self, **body):
+        return self._call(self.lib.mi355_engine_unload_model, body)[-1]
+
+    def get_model_status(self, **body):
+        return self._call(self.lib.mi355_engine_get_model_status, body)[-1]
+
+    def get_models(self):
+        return self._call(self.lib.mi355_engine_get_models, {})[-1]
+
+    def chat_completion(self, **body):
+        return self._call(self.lib.mi355_engine_handle_chat_completion, body)
+
+    def embedding(self, **body):
+        return self._call(self.lib.mi355_engine_handle_embedding, body)[-1]
+
+    def is_supported(self, feature: str) -> bool:
+        return bool(self.lib.mi355_engine_is_supported(self.h, feature.encode()))
+
+    def stop_inferencing(self, model_id: str) -> None:
+        self.lib.mi355_engine_stop_inferencing(self.h, model_id.encode())
+
+    def close(self):
+        if self.h:
+            self.lib.mi355_engine_destroy(self.h)
             self.h = None

@@ -8,7 +8,10 @@
 #include <string>
 #include <vector>
 
+#include "../host/engine.h"
+#include "../host/hip_backend.h"
 #include "../host/runtime.h"
+#include "../host/vocab.h"
 
 namespace mi355 {
 const std::string &last_error_string();
@@ -16,7 +19,12 @@ const std::string &last_error_string();
 
 using namespace mi355;
 
-struct mi355_model { Model *m; };
+struct mi355_model {
+    Model *m;
+    Vocab vocab;            // loaded on first tokenizer call
+    bool vocab_tried = false, vocab_ok = false;
+};
+struct mi355_engine { LlamaEngine eng{make_hip_backend}; };
 struct mi355_context {
     Context *c;
     std::vector<const char *> prof_names;
@@ -81,7 +89,9 @@ mi355_model *mi355_model_load_from_file(const char *path, mi355_model_params par
     int status = 0;
     Model *m = model_load(path, params.main_gpu, err, status);
     if (!m) { fail(err); return nullptr; }
-    return new mi355_model{m};
+    mi355_model *h = new mi355_model;
+    h->m = m;
+    return h;
 }
 void mi355_model_free(mi355_model *model) {
     if (!model) return;
@@ -128,7 +138,6 @@ mi355_context *mi355_context_new(mi355_model *model, mi355_context_params params
     cp.flash_attn = params.flash_attn != 0 || params.type_k != MI355_TYPE_F16 || params.type_v != MI355_TYPE_F16;
     cp.embeddings = params.embeddings != 0;
     cp.use_graphs = params.use_graphs != 0;
-    if (const char *ng = getenv("MI355_NO_GRAPHS")) { if (ng[0] == '1') cp.use_graphs = false; }   // e.g. under rocprofv3
     cp.logits_to_host = params.logits_to_host != 0;
     Context *c = new Context(model->m, cp);
     std::string err;
@@ -440,5 +449,76 @@ double mi355_bench_hbm_read(size_t bytes, int iters) {
     if (!need_device()) return -1.0;
     return hbm_read_probe(bytes, iters);
 }
+
+// ---------------------------------------------------------------- tokenizer
+static Vocab *model_vocab(mi355_model *m) {
+    if (!m) { fail("null model"); return nullptr; }
+    if (!m->vocab_tried) {
+        m->vocab_tried = true;
+        std::string err;
+        m->vocab_ok = m->vocab.load(*m->m->file, err);
+        if (!m->vocab_ok) fail("tokenizer: " + err);
+    }
+    return m->vocab_ok ? &m->vocab : nullptr;
+}
+int32_t mi355_tokenize(mi355_model *m, const char *text, int32_t text_len, mi355_token *out, int32_t cap, int32_t add_special, int32_t parse_special) {
+    Vocab *v = model_vocab(m);
+    if (!v || !text || text_len < 0) return INT32_MIN;
+    const std::vector<int32_t> ids = v->tokenize(std::string(text, (size_t)text_len), add_special != 0, parse_special != 0);
+    if ((int64_t)ids.size() > cap || !out) return -(int32_t)ids.size();
+    memcpy(out, ids.data(), ids.size() * sizeof(int32_t));
+    return (int32_t)ids.size();
+}
+int32_t mi355_token_to_piece(mi355_model *m, mi355_token tok, char *buf, int32_t cap, int32_t special) {
+    Vocab *v = model_vocab(m);
+    if (!v) return INT32_MIN;
+    const std::string p = v->token_to_piece(tok, special != 0);
+    if ((int64_t)p.size() > cap || !buf) return -(int32_t)p.size();
+    memcpy(buf, p.data(), p.size());
+    return (int32_t)p.size();
+}
+mi355_token mi355_token_bos(mi355_model *m) { Vocab *v = model_vocab(m); return v ? v->bos() : -1; }
+mi355_token mi355_token_eos(mi355_model *m) { Vocab *v = model_vocab(m); return v ? v->eos() : -1; }
+int32_t mi355_token_is_eog(mi355_model *m, mi355_token tok) { Vocab *v = model_vocab(m); return v && v->is_eog(tok) ? 1 : 0; }
+
+// ---------------------------------------------------------------- engine
+static bool parse_body(const char *txt, Json &j, mi355_engine_callback cb, void *user) {
+    std::string err;
+    if (txt && Json::parse(txt, j, &err)) return true;
+    if (cb) {
+        Json st = Json::object(), body = Json::object();
+        st["is_done"] = true; st["has_error"] = true; st["is_stream"] = false; st["status_code"] = 400;
+        body["message"] = "Malformed JSON body: " + err;
+        cb(st.dump().c_str(), body.dump().c_str(), user);
+    }
+    return false;
+}
+static LlamaEngine::Callback wrap_cb(mi355_engine_callback cb, void *user) {
+    return [cb, user](Json &&st, Json &&body) {
+        if (!cb) return;
+        const std::string s = st.dump(), b = body.dump();
+        cb(s.c_str(), b.c_str(), user);
+    };
+}
+mi355_engine *mi355_engine_create(void) {
+    if (!g_backend_ok && mi355_backend_init() != MI355_OK) return nullptr;
+    return new mi355_engine;
+}
+void mi355_engine_destroy(mi355_engine *e) { delete e; }
+#define MI355_ENGINE_FWD(cname, Method)                                                                     \
+    void cname(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user) {              \
+        Json j;                                                                                             \
+        if (!e || !parse_body(body_json, j, cb, user)) return;                                              \
+        e->eng.Method(j, wrap_cb(cb, user));                                                                \
+    }
+MI355_ENGINE_FWD(mi355_engine_load_model, LoadModel)
+MI355_ENGINE_FWD(mi355_engine_unload_model, UnloadModel)
+MI355_ENGINE_FWD(mi355_engine_get_model_status, GetModelStatus)
+MI355_ENGINE_FWD(mi355_engine_get_models, GetModels)
+MI355_ENGINE_FWD(mi355_engine_handle_chat_completion, HandleChatCompletion)
+MI355_ENGINE_FWD(mi355_engine_handle_embedding, HandleEmbedding)
+#undef MI355_ENGINE_FWD
+int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature) { return e && feature && e->eng.IsSupported(feature) ? 1 : 0; }
+void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id) { if (e && model_id) e->eng.StopInferencing(model_id); }
 
 }  // extern "C"

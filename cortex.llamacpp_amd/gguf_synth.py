@@ -261,8 +261,12 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
             toks.append(f"<0x{b:02X}>")
             scores.append(0.0)
             types.append(6)
-        i = 0
         alphabet = "abcdefghijklmnopqrstuvwxyz"
+        for piece in ["▁"] + list(alphabet):
+            toks.append(piece)
+            scores.append(-1000.0)
+            types.append(1)
+        i = 26
         while len(toks) < cfg.n_vocab:
             s, k = "", i
             while True:

@@ -1,0 +1,40 @@
+// backend_iface.h — what the continuous-batching loop needs from the arithmetic backend: exactly the llama.h subset the
+// reference's LlamaServerContext consumes (SURVEY.md §8b "inner boundary").  The product implementation is HipBackend
+// (hip_backend.cc, over the C-ABI objects); host-logic unit tests plug in a deterministic fake.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "vocab.h"
+
+namespace mi355 {
+
+struct BatchView {           // llama_batch as filled at llama_server_context.cc:1630-1635
+    int32_t n_tokens = 0;
+    const int32_t *token = nullptr;
+    const int32_t *pos = nullptr;
+    const int32_t *seq_id = nullptr;   // one sequence id per token (the loop never uses more)
+    const int8_t *logits = nullptr;
+};
+
+class IBackend {
+  public:
+    virtual ~IBackend() = default;
+    virtual int n_ctx() const = 0;
+    virtual int n_batch() const = 0;
+    virtual int n_ubatch() const = 0;
+    virtual int n_vocab() const = 0;
+    virtual int n_embd() const = 0;
+    virtual const Vocab &vocab() const = 0;
+    // llama_decode: 0 ok, 1 no KV slot, < 0 error
+    virtual int decode(const BatchView &b) = 0;
+    // logits row of batch index i of the last decode (llama_get_logits_ith)
+    virtual const float *logits_ith(int i) = 0;
+    virtual void kv_clear() = 0;
+    virtual bool kv_seq_rm(int seq, int p0, int p1) = 0;
+    virtual void kv_seq_add(int seq, int p0, int p1, int delta) = 0;
+    virtual void kv_seq_cp(int src, int dst, int p0, int p1) = 0;
+};
+
+}  // namespace mi355

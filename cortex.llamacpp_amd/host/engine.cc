@@ -1,0 +1,403 @@
+// engine.cc — see engine.h.  Citations are into /root/reference/src/llama_engine.cc unless noted.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <ctime>
+#include <random>
+
+namespace mi355 {
+
+namespace {
+constexpr int k200OK = 200, k400BadRequest = 400, k409Conflict = 409, k500InternalServerError = 500;
+
+Json make_status(bool is_done, bool has_error, bool is_stream, int code) {
+    Json s = Json::object();
+    s["is_done"] = is_done; s["has_error"] = has_error; s["is_stream"] = is_stream; s["status_code"] = code;
+    return s;
+}
+Json message(const std::string &m) { Json j = Json::object(); j["message"] = m; return j; }
+
+std::string rtrim(std::string s) { while (!s.empty() && (s.back() == ' ' || s.back() == '\n' || s.back() == '\t' || s.back() == '\r')) s.pop_back(); return s; }
+void ltrim(std::string &s) { size_t i = 0; while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; s.erase(0, i); }
+
+std::string random_id(size_t n) {   // llama_utils::generate_random_string
+    static const char cs[] = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789";
+    static thread_local std::mt19937 gen{std::random_device{}()};
+    std::uniform_int_distribution<size_t> d(0, sizeof(cs) - 2);
+    std::string s;
+    for (size_t i = 0; i < n; i++) s += cs[d(gen)];
+    return s;
+}
+
+// chat.completion.chunk (CreateReturnJson :220-270)
+std::string chunk_json(const std::string &content, const Json &finish_reason, bool include_usage, const Json *usage, const Json &logprobs) {
+    Json root = Json::object();
+    root["id"] = random_id(20); root["model"] = "_"; root["created"] = (int64_t)std::time(nullptr); root["object"] = "chat.completion.chunk";
+    Json choices = Json::array();
+    if (!usage) {
+        Json choice = Json::object(), delta = Json::object();
+        choice["index"] = 0;
+        delta["content"] = content; delta["role"] = "assistant";
+        choice["delta"] = delta;
+        choice["finish_reason"] = finish_reason;
+        if (!logprobs.empty()) choice["logprobs"] = logprobs;
+        choices.push_back(choice);
+    }
+    root["choices"] = choices;
+    if (include_usage) root["usage"] = usage ? *usage : Json();
+    return root.dump();
+}
+
+// chat.completion (CreateFullReturnJson :180-218)
+Json full_json(const std::string &content, int prompt_tokens, int completion_tokens, const Json &logprobs) {
+    Json root = Json::object();
+    root["id"] = random_id(20); root["model"] = "_"; root["created"] = (int64_t)std::time(nullptr); root["object"] = "chat.completion";
+    root["system_fingerprint"] = "_";
+    Json choice = Json::object(), msg = Json::object();
+    choice["index"] = 0;
+    msg["role"] = "assistant"; msg["content"] = content;
+    choice["message"] = msg;
+    choice["finish_reason"] = "stop";
+    if (!logprobs.empty()) choice["logprobs"] = logprobs;
+    Json choices = Json::array();
+    choices.push_back(choice);
+    root["choices"] = choices;
+    Json usage = Json::object();
+    usage["prompt_tokens"] = prompt_tokens; usage["completion_tokens"] = completion_tokens; usage["total_tokens"] = prompt_tokens + completion_tokens;
+    root["usage"] = usage;
+    return root;
+}
+}  // namespace
+
+// ---------------------------------------------------------------- TaskQueue
+TaskQueue::TaskQueue(int n) {
+    for (int i = 0; i < std::max(n, 1); i++)
+        workers_.emplace_back([this] {
+            while (true) {
+                std::function<void()> f;
+                {
+                    std::unique_lock<std::mutex> lk(m_);
+                    cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                    if (stop_ && q_.empty()) return;
+                    f = std::move(q_.front());
+                    q_.pop();
+                }
+                f();
+            }
+        });
+}
+TaskQueue::~TaskQueue() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &w : workers_) if (w.joinable()) w.join();
+}
+void TaskQueue::run(std::function<void()> f) {
+    { std::lock_guard<std::mutex> lk(m_); q_.push(std::move(f)); }
+    cv_.notify_one();
+}
+
+// ---------------------------------------------------------------- engine
+LlamaEngine::LlamaEngine(BackendFactory f) : factory_(std::move(f)) {}
+
+LlamaEngine::~LlamaEngine() {
+    std::lock_guard<std::mutex> lk(map_mutex_);
+    for (auto &kv : server_map_) {
+        kv.second->q.reset();                       // drain workers first (they hold the context)
+        if (kv.second->ctx) kv.second->ctx->ReleaseResources();
+    }
+    server_map_.clear();
+}
+
+bool LlamaEngine::IsSupported(const std::string &f) const {   // enginei.h:54-62
+    return f == "HandleChatCompletion" || f == "HandleEmbedding" || f == "LoadModel" || f == "UnloadModel" || f == "GetModelStatus" ||
+           f == "GetModels" || f == "SetFileLogger" || f == "SetLogLevel" || f == "StopInferencing";
+}
+
+std::string LlamaEngine::GetModelId(const Json &body) {   // llama_utils.h:153-177
+    if (body["model"].is_string() && !body["model"].as_string().empty()) return body["model"].as_string();
+    if (body["model_alias"].is_string() && !body["model_alias"].as_string().empty()) return body["model_alias"].as_string();
+    for (const char *k : {"llama_model_path", "model_path"}) {
+        if (body[k].is_string() && !body[k].as_string().empty()) {
+            std::string p = body[k].as_string();
+            const size_t sl = p.find_last_of("/\\");
+            if (sl != std::string::npos) p = p.substr(sl + 1);
+            const size_t dot = p.rfind(".gguf");
+            if (dot != std::string::npos && dot + 5 == p.size()) p = p.substr(0, dot);
+            return p;
+        }
+    }
+    return "";
+}
+
+void LlamaEngine::LoadModel(const Json &body, Callback cb) {   // :363-423
+    const std::string model_id = GetModelId(body);
+    if (model_id.empty()) { cb(make_status(false, true, false, k400BadRequest), message("No model id found in request body")); return; }
+    {
+        std::lock_guard<std::mutex> lk(map_mutex_);
+        auto it = server_map_.find(model_id);
+        if (it != server_map_.end() && it->second->ctx && it->second->ctx->model_loaded_external) {
+            cb(make_status(true, false, false, k409Conflict), message("Model already loaded"));
+            return;
+        }
+    }
+    std::string err;
+    if (!LoadModelImpl(body, err)) {
+        Json m = message("Failed to load model");
+        if (!err.empty()) m["error"] = err;
+        cb(make_status(false, true, false, k500InternalServerError), std::move(m));
+    } else {
+        cb(make_status(true, false, false, k200OK), message("Model loaded successfully"));
+    }
+}
+
+bool LlamaEngine::LoadModelImpl(const Json &body, std::string &err) {   // :547-732
+    const std::string model_id = GetModelId(body);
+    auto si = std::make_shared<ServerInfo>();
+    const std::string path = body["llama_model_path"].is_string() ? body["llama_model_path"].as_string() : body["model_path"].str_or("");
+    if (path.empty()) { err = "Missing model path in request"; return false; }
+    si->backend = factory_(body, si->info, err);
+    if (!si->backend) return false;
+    ServerParams sp;
+    sp.n_parallel = std::max(1, body.value<int>("n_parallel", 1));           // :620
+    sp.cont_batching = body.value<bool>("cont_batching", true);               // :625-627
+    sp.n_predict = body.value<int>("n_predict", -1);
+    sp.model_alias = model_id;
+    si->user_prompt = body.value<std::string>("user_prompt", "USER: ");       // :662-669
+    si->ai_prompt = body.value<std::string>("ai_prompt", "ASSISTANT: ");
+    si->system_prompt = body.value<std::string>("system_prompt", "ASSISTANT's RULE: ");
+    si->pre_prompt = body.value<std::string>("pre_prompt", "");
+    si->repeat_last_n = body.value<int>("repeat_last_n", 32);                 // :670-671
+    si->caching_enabled = body.value<bool>("caching_enabled", true);          // :660-661
+    si->stop_words = body["stop"];                                            // :672
+    si->model_type = body.value<std::string>("model_type", "llm");
+    if (body.value<bool>("embedding", false)) si->model_type = "embedding";
+    si->ngl = body.value<int>("ngl", 300);
+    si->start_time = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    si->ctx.reset(new LlamaServerContext(si->backend.get(), sp));
+    si->ctx->Initialize();
+    si->q.reset(new TaskQueue(sp.n_parallel));                                // :720-721
+    if (si->model_type == "llm" && si->backend->vocab().has_vocab()) WarmUpModel(*si);   // :728-730
+    std::lock_guard<std::mutex> lk(map_mutex_);
+    server_map_[model_id] = si;
+    return true;
+}
+
+void LlamaEngine::WarmUpModel(ServerInfo &si) {   // :1247-1267
+    Json d = Json::object();
+    d["prompt"] = "Hello"; d["n_predict"] = 2; d["n_probs"] = 0;
+    const int id = si.ctx->RequestCompletion(d, false, false, -1);
+    (void)si.ctx->NextResult(id);
+}
+
+void LlamaEngine::UnloadModel(const Json &body, Callback cb) {   // :425-445
+    const std::string model_id = GetModelId(body);
+    if (!CheckModelLoaded(cb, model_id)) return;
+    std::shared_ptr<ServerInfo> si;
+    {
+        std::lock_guard<std::mutex> lk(map_mutex_);
+        si = server_map_[model_id];
+        server_map_.erase(model_id);
+    }
+    si->ctx->ReleaseResources();
+    si->q.reset();
+    cb(make_status(true, false, false, k200OK), message("Model unloaded successfully"));
+}
+
+void LlamaEngine::GetModelStatus(const Json &body, Callback cb) {   // :447-466
+    const std::string model_id = GetModelId(body);
+    if (!CheckModelLoaded(cb, model_id)) return;
+    Json j = Json::object();
+    j["model_loaded"] = true;
+    cb(make_status(true, false, false, k200OK), std::move(j));
+}
+
+void LlamaEngine::GetModels(const Json &, Callback cb) {   // :468-500
+    Json arr = Json::array();
+    {
+        std::lock_guard<std::mutex> lk(map_mutex_);
+        for (const auto &kv : server_map_) {
+            if (!kv.second->ctx || !kv.second->ctx->model_loaded_external) continue;
+            Json v = Json::object();
+            v["id"] = kv.first; v["engine"] = "cortex.llamacpp"; v["start_time"] = kv.second->start_time;
+            v["model_size"] = kv.second->info.model_size; v["vram"] = kv.second->info.vram; v["ram"] = kv.second->info.ram;
+            v["object"] = "model";
+            arr.push_back(std::move(v));
+        }
+    }
+    Json root = Json::object();
+    root["object"] = "list";
+    root["data"] = arr;
+    cb(make_status(true, false, false, k200OK), std::move(root));
+}
+
+bool LlamaEngine::CheckModelLoaded(const Callback &cb, const std::string &model_id) {   // :1225-1245
+    std::lock_guard<std::mutex> lk(map_mutex_);
+    auto it = server_map_.find(model_id);
+    if (it == server_map_.end() || !it->second->ctx || !it->second->ctx->model_loaded_external) {
+        Callback c = cb;
+        c(make_status(false, true, false, k409Conflict), message("Model has not been loaded, please load model into cortex.llamacpp"));
+        return false;
+    }
+    return true;
+}
+
+void LlamaEngine::StopInferencing(const std::string &model_id) {   // :502-508
+    std::lock_guard<std::mutex> lk(stop_mutex_);
+    force_stop_.insert(model_id);
+}
+
+void LlamaEngine::HandleEmbedding(const Json &, Callback cb) {
+    cb(make_status(false, true, false, k400BadRequest), message("Embeddings are not available in this build"));
+}
+
+void LlamaEngine::HandleChatCompletion(const Json &body, Callback cb) {   // :341-351
+    if (!CheckModelLoaded(cb, GetModelId(body))) return;
+    HandleInferenceImpl(body, std::move(cb));
+}
+
+void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734-1113
+    const std::string model_id = GetModelId(body);
+    std::shared_ptr<ServerInfo> si;
+    { std::lock_guard<std::mutex> lk(map_mutex_); si = server_map_[model_id]; }
+    if (si->model_type == "embedding") {   // :739-750
+        cb(make_status(false, true, false, k400BadRequest), message("Model type is wrong. Expected to be llm type"));
+        return;
+    }
+    const int request_id = ++no_of_requests_;
+    (void)request_id;
+    // request defaults: chat_completion_request.h:60-92
+    const bool stream = body.value<bool>("stream", false);
+    const bool include_usage = body["stream_options"].value<bool>("include_usage", false);
+    int n_probs = body.value<int>("n_probs", 0);
+    if (body.value<bool>("logprobs", false)) n_probs = std::max(n_probs, body.value<int>("top_logprobs", 1));
+    Json data = Json::object();
+    data["cache_prompt"] = si->caching_enabled;
+    data["n_keep"] = 0;
+    data["stream"] = stream;
+    data["n_predict"] = body.value<int>("max_tokens", 500);
+    data["top_p"] = body.value<float>("top_p", 0.95f);
+    data["temperature"] = body.value<float>("temperature", 0.8f);
+    data["frequency_penalty"] = body.value<float>("frequency_penalty", 0.0f);
+    data["presence_penalty"] = body.value<float>("presence_penalty", 0.0f);
+    data["seed"] = body.value<int64_t>("seed", -1);
+    data["dynatemp_range"] = body.value<float>("dynatemp_range", 0.0f);
+    data["dynatemp_exponent"] = body.value<float>("dynatemp_exponent", 1.0f);
+    data["top_k"] = body.value<int>("top_k", 40);
+    data["min_p"] = body.value<float>("min_p", 0.05f);
+    data["typical_p"] = body.value<float>("typ_p", 1.0f);
+    data["repeat_last_n"] = body.value<int>("repeat_last_n", 64);
+    data["repeat_penalty"] = body.value<float>("repeat_penalty", 1.1f);
+    data["mirostat"] = body.value<int>("mirostat", 0);
+    data["mirostat_tau"] = body.value<float>("mirostat_tau", 5.0f);
+    data["mirostat_eta"] = body.value<float>("mirostat_eta", 0.1f);
+    data["ignore_eos"] = body.value<bool>("ignore_eos", false);
+    data["n_probs"] = n_probs;
+    data["min_keep"] = body.value<int>("min_keep", 0);
+    if (body["logit_bias"].is_array()) data["logit_bias"] = body["logit_bias"];
+    else if (body["logit_bias"].is_object()) {    // {"token": bias} -> [[token, bias]] (chat_completion_request.h:140-160)
+        Json arr = Json::array();
+        for (const auto &kv : body["logit_bias"].members()) { Json e = Json::array(); e.push_back((int64_t)atoll(kv.first.c_str())); e.push_back(kv.second); arr.push_back(e); }
+        data["logit_bias"] = arr;
+    }
+    // prompt = pre_prompt + sum(role_prefix + content) + ai_prompt (:816-852); no Jinja template in the reference
+    std::string formatted = si->pre_prompt;
+    auto get_message = [](const Json &c) -> std::string {
+        if (c.is_array()) { for (const Json &mc : c.items()) if (mc["type"].as_string() == "text") return mc["text"].as_string(); return ""; }
+        return c.as_string();
+    };
+    if (body["prompt"].is_string() && !body["prompt"].as_string().empty()) {
+        formatted = body["prompt"].as_string();
+    } else {
+        for (const Json &msg : body["messages"].items()) {
+            const std::string in_role = msg["role"].as_string();
+            const std::string role = in_role == "user" ? si->user_prompt : in_role == "assistant" ? si->ai_prompt : in_role == "system" ? si->system_prompt : in_role;
+            const std::string content = get_message(msg["content"]);
+            if (!content.empty()) formatted += role + content;
+        }
+        formatted += si->ai_prompt;
+    }
+    data["prompt"] = formatted;
+    Json stop = Json::array();
+    const Json &req_stop = (body["stop"].is_array() && body["stop"].size() > 0) ? body["stop"] : si->stop_words;
+    for (const Json &w : req_stop.items()) if (w.is_string()) stop.push_back(w);
+    stop.push_back("<|im_end|>");                 // :922-929
+    stop.push_back(rtrim(si->user_prompt));
+    data["stop"] = stop;
+    const int n = std::max(1, body.value<int>("n", 1));
+
+    if (stream) {   // :939-1043
+        si->q->run([this, si, cb, data, n_probs, include_usage, model_id]() mutable {
+            LlamaServerContext &llama = *si->ctx;
+            const int task_id = llama.RequestCompletion(data, false, false, -1);
+            bool first = true;
+            while (llama.model_loaded_external) {
+                {
+                    std::lock_guard<std::mutex> lk(stop_mutex_);
+                    if (force_stop_.erase(model_id)) { llama.RequestCancel(task_id); break; }
+                }
+                TaskResult result = llama.NextResult(task_id);
+                if (!result.error) {
+                    std::string to_send = result.result_json["content"].as_string();
+                    if (first) { ltrim(to_send); first = false; }     // trim the leading space of the first token
+                    Json logprobs = n_probs > 0 ? result.result_json["completion_probabilities"] : Json();
+                    Json resp = Json::object();
+                    resp["data"] = "data: " + chunk_json(to_send, Json(""), include_usage, nullptr, logprobs) + "\n\n";
+                    cb(make_status(false, false, true, k200OK), std::move(resp));
+                    if (result.stop) {
+                        llama.RequestCancel(task_id);
+                        Json usage;
+                        if (include_usage) {
+                            usage = Json::object();
+                            const int pt = (int)result.result_json["tokens_evaluated"].as_int(), ct = (int)result.result_json["tokens_predicted"].as_int();
+                            Json details = Json::object();
+                            details["reasoning_tokens"] = 0;
+                            usage["prompt_tokens"] = pt; usage["completion_tokens"] = ct; usage["total_tokens"] = pt + ct;
+                            usage["completion_tokens_details"] = details;
+                        }
+                        Json last = Json::object();
+                        last["data"] = "data: " + chunk_json("", Json("stop"), include_usage, include_usage ? &usage : nullptr, Json()) + "\n\n" + "data: [DONE]" + "\n\n";
+                        cb(make_status(true, false, true, k200OK), std::move(last));
+                        break;
+                    }
+                } else {   // :1017-1024
+                    llama.RequestCancel(task_id);
+                    Json resp = Json::object();
+                    resp["data"] = std::string();
+                    cb(make_status(false, true, true, k200OK), std::move(resp));
+                    break;
+                }
+            }
+        });
+    } else {   // :1044-1112
+        si->q->run([si, cb, data, n, n_probs]() mutable {
+            LlamaServerContext &llama = *si->ctx;
+            std::vector<int> ids;
+            for (int i = 0; i < n; i++) ids.push_back(llama.RequestCompletion(data, false, false, -1));
+            Json resp;
+            bool has_error = false;
+            int prompt_tokens = 0, predicted = 0, index = 0;
+            for (int id : ids) {
+                TaskResult r = llama.NextResult(id);
+                if (!r.error && r.stop) {
+                    prompt_tokens += (int)r.result_json["tokens_evaluated"].as_int();
+                    predicted += (int)r.result_json["tokens_predicted"].as_int();
+                    std::string to_send = r.result_json["content"].as_string();
+                    ltrim(to_send);
+                    Json logprobs = n_probs > 0 ? r.result_json["completion_probabilities"] : Json();
+                    Json one = full_json(to_send, prompt_tokens, predicted, logprobs);
+                    if (resp.is_null()) resp = one;
+                    else { Json choice = one["choices"].at(0); choice["index"] = index; resp["choices"].push_back(choice); resp["usage"] = one["usage"]; }
+                    index++;
+                } else {
+                    has_error = true;
+                    resp = message("Internal error during inference");
+                    break;
+                }
+            }
+            cb(make_status(true, has_error, false, k200OK), std::move(resp));
+        });
+    }
+}
+
+}  // namespace mi355

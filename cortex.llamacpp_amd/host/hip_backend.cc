@@ -1,0 +1,97 @@
+// hip_backend.cc — see hip_backend.h.  Key mapping follows src/llama_engine.cc:587-660:
+//   llama_model_path | model_path, ngl (300), ctx_len (2048), n_batch (2048), n_ubatch (= n_batch), n_parallel (1),
+//   cache_type f16|q8_0|q4_0 (invalid -> f16), flash_attn (true; forced on by a quantised cache), embedding.
+#include "hip_backend.h"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+
+#include "../csrc/dev_common.h"
+#include "gguf.h"
+#include "runtime.h"
+
+namespace mi355 {
+namespace {
+
+class HipBackend : public IBackend {
+  public:
+    HipBackend(std::unique_ptr<Model> m, std::unique_ptr<Context> c, Vocab v) : model_(std::move(m)), ctx_(std::move(c)), vocab_(std::move(v)) {}
+    ~HipBackend() override { ctx_.reset(); model_.reset(); }
+
+    int n_ctx() const override { return (int)ctx_->cp.n_ctx; }
+    int n_batch() const override { return (int)ctx_->cp.n_batch; }
+    int n_ubatch() const override { return (int)ctx_->cp.n_ubatch; }
+    int n_vocab() const override { return model_->hp.n_vocab; }
+    int n_embd() const override { return model_->hp.n_embd; }
+    const Vocab &vocab() const override { return vocab_; }
+
+    int decode(const BatchView &b) override {
+        n_seq_id_.assign((size_t)b.n_tokens, 1);
+        seq_store_.assign(b.seq_id, b.seq_id + b.n_tokens);
+        seq_ptr_.resize((size_t)b.n_tokens);
+        for (int i = 0; i < b.n_tokens; i++) seq_ptr_[(size_t)i] = &seq_store_[(size_t)i];
+        return ctx_->decode(b.n_tokens, b.token, b.pos, n_seq_id_.data(), seq_ptr_.data(), b.logits);
+    }
+    const float *logits_ith(int i) override { return ctx_->logits_ith(i); }
+    void kv_clear() override { ctx_->kv_clear(); }
+    bool kv_seq_rm(int seq, int p0, int p1) override { return ctx_->kv_seq_rm(seq, p0, p1); }
+    void kv_seq_add(int seq, int p0, int p1, int delta) override { ctx_->kv_seq_add(seq, p0, p1, delta); }
+    void kv_seq_cp(int src, int dst, int p0, int p1) override { ctx_->kv_seq_cp(src, dst, p0, p1); }
+
+  private:
+    std::unique_ptr<Model> model_;
+    std::unique_ptr<Context> ctx_;
+    Vocab vocab_;
+    std::vector<int32_t> n_seq_id_, seq_store_;
+    std::vector<int32_t *> seq_ptr_;
+};
+
+int cache_type_from_str(const std::string &s) {   // llama_engine.cc:29-55 (IsValidCacheType / kv_cache_type_from_str)
+    if (s == "q8_0") return T_Q8_0;
+    if (s == "q4_0") return T_Q4_0;
+    return T_F16;
+}
+
+}  // namespace
+
+std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, std::string &err) {
+    std::string path = body.value<std::string>("llama_model_path", "");
+    if (path.empty()) path = body.value<std::string>("model_path", "");
+    if (path.empty()) { err = "Missing model path in request"; return nullptr; }
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { err = "Could not find model in path " + path; return nullptr; }
+    if (body.value<int>("ngl", 300) <= 0) { err = "ngl=0 requested: this engine is device-only (no CPU path)"; return nullptr; }
+
+    int status = 0;
+    std::unique_ptr<Model> model(model_load(path, body.value<int>("main_gpu", 0), err, status));
+    if (!model) return nullptr;
+
+    Vocab vocab;
+    std::string verr;
+    if (!vocab.load(*model->file, verr)) { err = "tokenizer: " + verr; return nullptr; }
+    if (vocab.n_tokens() != model->hp.n_vocab) { err = "tokenizer size does not match the embedding table"; return nullptr; }
+
+    ContextParams cp;
+    const int n_parallel = std::max(1, body.value<int>("n_parallel", 1));
+    cp.n_ctx = (uint32_t)std::max(8, body.value<int>("ctx_len", 2048));
+    cp.n_batch = (uint32_t)std::max(1, body.value<int>("n_batch", 2048));
+    cp.n_ubatch = (uint32_t)std::max(1, body.value<int>("n_ubatch", (int)cp.n_batch));
+    cp.n_batch = std::min(cp.n_batch, cp.n_ctx);
+    cp.n_ubatch = std::min(cp.n_ubatch, cp.n_batch);
+    cp.n_seq_max = (uint32_t)n_parallel;
+    cp.type_k = cp.type_v = cache_type_from_str(body.value<std::string>("cache_type", "f16"));
+    cp.flash_attn = body.value<bool>("flash_attn", true) || cp.type_k != T_F16;
+    cp.embeddings = false;
+    cp.use_graphs = body.value<bool>("use_graphs", true);
+    cp.logits_to_host = true;   // the sampler reads whole logits rows on the host, as common_sampler_sample does
+    std::unique_ptr<Context> ctx(new Context(model.get(), cp));
+    if (!ctx->init(err)) return nullptr;
+
+    info.vram = model->device_bytes + ctx->device_bytes;
+    info.ram = model->host_bytes;
+    info.model_size = model->file_tensor_bytes;
+    return std::unique_ptr<IBackend>(new HipBackend(std::move(model), std::move(ctx), std::move(vocab)));
+}
+
+}  // namespace mi355

@@ -236,6 +236,7 @@ bool Context::init(std::string &err) {
     const HParams &hp = model->hp;
     if (hipSetDevice(model->device) != hipSuccess) { err = "hipSetDevice failed"; return false; }
     if (cp.n_ubatch > cp.n_batch) cp.n_ubatch = cp.n_batch;
+    if (const char *ng = getenv("MI355_NO_GRAPHS")) { if (ng[0] == '1') cp.use_graphs = false; }   // e.g. under rocprofv3
     if (cp.n_ubatch == 0 || cp.n_ctx == 0) { err = "n_ctx / n_ubatch must be > 0"; return false; }
     if (cp.n_seq_max > 64) { err = "n_seq_max > 64 unsupported"; return false; }
     auto kv_ok = [](int t) { return t == T_F16 || t == T_Q8_0 || t == T_Q4_0; };

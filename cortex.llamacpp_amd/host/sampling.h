@@ -1,0 +1,52 @@
+// sampling.h — host sampler chain the slot loop applies to one logits row.  Stands in for common_sampler_{init,reset,
+// accept,sample,get_candidates} (reference call sites src/llama_server_context.cc:626-628,886,1487,1495,1553,1680-1690);
+// chain order per SURVEY.md §A.6: logit_bias -> penalties(last_n, repeat, freq, presence) -> top_k -> typical_p -> top_p
+// -> min_p -> temperature (<= 0 => greedy) -> seeded draw.  Not carried over: grammar, DRY, XTC, mirostat, dynatemp
+// (accepted in the parameter struct, ignored; documented in DESIGN.md).
+#pragma once
+
+#include <cstdint>
+#include <random>
+#include <utility>
+#include <vector>
+
+namespace mi355 {
+
+struct SamplingParams {            // defaults of chat_completion_request.h:60-92 / common_params_sampling
+    uint32_t seed = 0xFFFFFFFFu;   // -1 => random
+    int32_t n_probs = 0;
+    int32_t min_keep = 0;
+    int32_t top_k = 40;
+    float top_p = 0.95f;
+    float min_p = 0.05f;
+    float typ_p = 1.0f;
+    float temp = 0.8f;
+    float dynatemp_range = 0.0f, dynatemp_exponent = 1.0f;
+    int32_t penalty_last_n = 64;
+    float penalty_repeat = 1.0f, penalty_freq = 0.0f, penalty_present = 0.0f;
+    int32_t mirostat = 0;
+    float mirostat_tau = 5.0f, mirostat_eta = 0.1f;
+    bool ignore_eos = false;
+    std::vector<std::pair<int32_t, float>> logit_bias;
+};
+
+struct TokenProb { int32_t tok; float p; };
+
+class Sampler {
+  public:
+    explicit Sampler(const SamplingParams &p = SamplingParams());
+    void reset();
+    void accept(int32_t token);
+    int32_t sample(const float *logits, int n_vocab);
+    // candidates of the last sample(), sorted by probability (descending), probabilities after the chain
+    const std::vector<TokenProb> &candidates() const { return cand_; }
+    const SamplingParams &params() const { return p_; }
+
+  private:
+    SamplingParams p_;
+    std::vector<int32_t> prev_;     // ring of accepted tokens (penalty window)
+    std::vector<TokenProb> cand_;
+    std::mt19937 rng_;
+};
+
+}  // namespace mi355

@@ -1,0 +1,562 @@
+// server_context.cc — see server_context.h.  Behavioural mirror of the reference loop; citations are into
+// /root/reference/src/llama_server_context.cc unless noted.
+#include "server_context.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+namespace mi355 {
+
+int64_t time_us() {
+    using namespace std::chrono;
+    return duration_cast<microseconds>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------- slot (llama_client_slot.cc)
+void LlamaClientSlot::Reset() {           // :3-27
+    num_prompt_tokens = 0;
+    generated_text.clear();
+    truncated = false; stopped_eos = false; stopped_word = false; stopped_limit = false;
+    stopping_word.clear();
+    n_past = 0;
+    sent_count = 0;
+    sent_token_probs_index = 0;
+    generated_token_probs.clear();
+    prompt_ready = false;
+    i_batch = -1;
+}
+
+bool LlamaClientSlot::HasBudget(const ServerParams &global) {   // :29-37
+    n_remaining = -1;
+    if (params.n_predict != -1) n_remaining = params.n_predict - n_decoded;
+    else if (global.n_predict != -1) n_remaining = global.n_predict - n_decoded;
+    return n_remaining > 0 || n_remaining == -1;
+}
+
+void LlamaClientSlot::Release() {          // :55-60
+    if (state == SlotState::kIdle || state == SlotState::kProcessing) {
+        t_token_generation = (double)(time_us() - t_start_genereration) / 1e3;
+        command = SlotCommand::kRelease;
+    }
+}
+
+Json LlamaClientSlot::GetFormatedTimings() const {   // :62-76
+    Json t = Json::object();
+    t["prompt_n"] = num_prompt_tokens_processed;
+    t["prompt_ms"] = t_prompt_processing;
+    t["prompt_per_token_ms"] = t_prompt_processing / std::max(num_prompt_tokens_processed, 1);
+    t["prompt_per_second"] = 1e3 / std::max(t_prompt_processing, 1e-9) * num_prompt_tokens_processed;
+    t["predicted_n"] = n_decoded;
+    t["predicted_ms"] = t_token_generation;
+    t["predicted_per_token_ms"] = t_token_generation / std::max(n_decoded, 1);
+    t["predicted_per_second"] = 1e3 / std::max(t_token_generation, 1e-9) * n_decoded;
+    return t;
+}
+
+// ---------------------------------------------------------------- context
+LlamaServerContext::LlamaServerContext(IBackend *be, const ServerParams &p) : params(p), be_(be) {}
+
+LlamaServerContext::~LlamaServerContext() { ReleaseResources(); }
+
+void LlamaServerContext::Initialize() {    // :244-282
+    id_gen_ = 0;
+    n_ctx = be_->n_ctx();
+    const int n_ctx_slot = n_ctx / std::max(params.n_parallel, 1);
+    slots.clear();
+    slots.resize((size_t)std::max(params.n_parallel, 1));
+    for (int i = 0; i < (int)slots.size(); i++) {
+        slots[(size_t)i].id = i;
+        slots[(size_t)i].n_ctx = n_ctx_slot;
+        slots[(size_t)i].Reset();
+    }
+    b_token_.assign((size_t)n_ctx, 0); b_pos_.assign((size_t)n_ctx, 0); b_seq_.assign((size_t)n_ctx, 0); b_logits_.assign((size_t)n_ctx, 0);
+    model_loaded_external = true;
+    bgr_thread_ = std::thread(&LlamaServerContext::DoBackgroundTasks, this);
+}
+
+void LlamaServerContext::ReleaseResources() {   // :366-380
+    if (model_loaded_external.exchange(false)) {
+        condition_tasks_.notify_all();
+        if (bgr_thread_.joinable()) bgr_thread_.join();
+        condition_results_.notify_all();
+    }
+}
+
+void LlamaServerContext::DoBackgroundTasks() {  // :1239-1246
+    while (model_loaded_external) UpdateSlots();
+    KvCacheClear();
+}
+
+void LlamaServerContext::KvCacheClear() { be_->kv_clear(); clean_kv_cache = false; }
+
+int LlamaServerContext::RequestCompletion(Json data, bool, bool, int) {   // :295-323
+    std::unique_lock<std::mutex> lock(mutex_tasks_);
+    Task t{id_gen_++, -1, false, std::move(data)};
+    const int id = t.id;
+    queue_tasks_.push_back(std::move(t));
+    condition_tasks_.notify_one();
+    return id;
+}
+
+TaskResult LlamaServerContext::NextResult(int task_id) {   // :325-352
+    std::unique_lock<std::mutex> lock(mutex_results_);
+    auto mine = [&]() -> long {
+        for (size_t i = 0; i < queue_results_.size(); i++) if (queue_results_[i].id == task_id) return (long)i;
+        return -1;
+    };
+    condition_results_.wait(lock, [&] { return mine() >= 0 || !model_loaded_external; });
+    const long i = mine();
+    if (i >= 0) {
+        TaskResult r = std::move(queue_results_[(size_t)i]);
+        queue_results_.erase(queue_results_.begin() + i);
+        return r;
+    }
+    TaskResult r;
+    r.id = task_id; r.error = true; r.stop = true;
+    r.result_json = Json::object();
+    r.result_json["content"] = "model unloaded";
+    return r;
+}
+
+void LlamaServerContext::RequestCancel(int task_id) {   // :354-364
+    std::unique_lock<std::mutex> lock(mutex_tasks_);
+    queue_tasks_.push_back(Task{id_gen_++, task_id, true, Json()});
+    condition_tasks_.notify_one();
+}
+
+std::vector<int32_t> LlamaServerContext::Tokenize(const Json &json_prompt, bool add_bos, bool parse_special) const {   // :382-414
+    std::vector<int32_t> out;
+    const Vocab &v = be_->vocab();
+    if (json_prompt.is_array()) {
+        bool first = true;
+        for (const Json &p : json_prompt.items()) {
+            if (p.is_string()) {
+                auto t = v.tokenize(p.as_string(), first && add_bos, parse_special);
+                out.insert(out.end(), t.begin(), t.end());
+                first = false;
+            } else {
+                if (first) first = false;
+                out.push_back((int32_t)p.as_int());
+            }
+        }
+    } else {
+        out = v.tokenize(json_prompt.as_string(), add_bos, parse_special);
+    }
+    return out;
+}
+
+LlamaClientSlot *LlamaServerContext::GetSlot(int id) {   // :416-432 (LRU)
+    int64_t t_last = time_us();
+    LlamaClientSlot *last_used = nullptr;
+    for (auto &slot : slots) {
+        if (slot.id == id && slot.Available()) return &slot;
+        if (slot.Available() && slot.t_last_used < t_last) { last_used = &slot; t_last = slot.t_last_used; }
+    }
+    return last_used;
+}
+
+bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &data) {   // :434-641
+    SlotParams dp;
+    const SamplingParams &ds = params.sampling;
+    if (data.contains("__oaicompat")) { slot->oaicompat = true; slot->oaicompat_model = data.value<std::string>("model", "gpt-3.5-turbo-0613"); }
+    else { slot->oaicompat = false; slot->oaicompat_model.clear(); }
+    slot->params.stream = data.value<bool>("stream", false);
+    slot->params.cache_prompt = data.value<bool>("cache_prompt", false);
+    slot->params.n_predict = data.value<int>("n_predict", dp.n_predict);
+    SamplingParams &sp = slot->sparams;
+    sp = ds;
+    sp.top_k = data.value<int>("top_k", ds.top_k);
+    sp.top_p = data.value<float>("top_p", ds.top_p);
+    sp.min_p = data.value<float>("min_p", ds.min_p);
+    sp.typ_p = data.value<float>("typical_p", ds.typ_p);
+    sp.temp = data.value<float>("temperature", ds.temp);
+    sp.penalty_last_n = data.value<int>("repeat_last_n", ds.penalty_last_n);
+    sp.penalty_repeat = data.value<float>("repeat_penalty", ds.penalty_repeat);
+    sp.penalty_freq = data.value<float>("frequency_penalty", ds.penalty_freq);
+    sp.penalty_present = data.value<float>("presence_penalty", ds.penalty_present);
+    sp.mirostat = data.value<int>("mirostat", ds.mirostat);
+    sp.mirostat_tau = data.value<float>("mirostat_tau", ds.mirostat_tau);
+    sp.mirostat_eta = data.value<float>("mirostat_eta", ds.mirostat_eta);
+    slot->params.n_keep = data.value<int>("n_keep", slot->params.n_keep);
+    sp.seed = (uint32_t)data.value<int64_t>("seed", (int64_t)(int32_t)ds.seed);
+    slot->params.seed = sp.seed;
+    sp.n_probs = data.value<int>("n_probs", ds.n_probs);
+    sp.min_keep = data.value<int>("min_keep", ds.min_keep);
+    sp.dynatemp_range = data.value<float>("dynatemp_range", ds.dynatemp_range);
+    sp.dynatemp_exponent = data.value<float>("dynatemp_exponent", ds.dynatemp_exponent);
+    sp.ignore_eos = data.value<bool>("ignore_eos", ds.ignore_eos);
+
+    slot->prompt_tokens.clear();
+    if (const Json *pt = data.find("prompt_tokens"); pt && pt->is_array())
+        for (const Json &t : pt->items()) slot->prompt_tokens.push_back((int32_t)t.as_int());
+    slot->num_prompt_tokens = (int32_t)slot->prompt_tokens.size();
+    slot->prompt = data.contains("prompt") ? data["prompt"] : Json("");
+
+    sp.logit_bias.clear();
+    const Vocab &vocab = be_->vocab();
+    if (sp.ignore_eos && vocab.eos() >= 0) sp.logit_bias.push_back({vocab.eos(), -INFINITY});
+    if (const Json *lb = data.find("logit_bias"); lb && lb->is_array()) {
+        const int n_vocab = be_->n_vocab();
+        for (const Json &el : lb->items()) {
+            if (!el.is_array() || el.size() != 2) continue;
+            float bias;
+            if (el.at(1).is_number()) bias = (float)el.at(1).as_double();
+            else if (el.at(1).is_bool() && !el.at(1).as_bool()) bias = -INFINITY;
+            else continue;
+            if (el.at(0).is_int()) {
+                const int tok = (int)el.at(0).as_int();
+                if (tok >= 0 && tok < n_vocab) sp.logit_bias.push_back({tok, bias});
+            } else if (el.at(0).is_string()) {
+                for (int32_t tok : vocab.tokenize(el.at(0).as_string(), false)) sp.logit_bias.push_back({tok, bias});
+            }
+        }
+    }
+    slot->params.antiprompt.clear();
+    if (const Json *stop = data.find("stop"); stop && stop->is_array())
+        for (const Json &w : stop->items()) if (w.is_string() && !w.as_string().empty()) slot->params.antiprompt.push_back(w.as_string());
+
+    slot->smpl.reset(new Sampler(sp));
+    slot->command = SlotCommand::kLoadPrompt;
+    all_slots_are_idle = false;
+    return true;
+}
+
+void LlamaServerContext::ProcessTasks() {   // :1152-1237
+    std::unique_lock<std::mutex> lock(mutex_tasks_);
+    std::deque<Task> deferred;
+    while (!queue_tasks_.empty()) {
+        Task task = std::move(queue_tasks_.front());
+        queue_tasks_.pop_front();
+        if (task.cancel) {
+            for (auto &slot : slots) if (slot.task_id == task.target_id) { slot.Release(); break; }
+            // a cancelled task that never got a slot is dropped from the queue
+            deferred.erase(std::remove_if(deferred.begin(), deferred.end(), [&](const Task &t) { return t.id == task.target_id; }), deferred.end());
+            continue;
+        }
+        LlamaClientSlot *slot = GetSlot((int)task.data.value<int>("slot_id", -1));
+        if (!slot) { deferred.push_back(std::move(task)); continue; }     // no free slot: retry on the next tick
+        slot->Reset();
+        slot->task_id = task.id;
+        if (!LaunchSlotWithData(slot, task.data)) {
+            SendError(*slot, "internal_error");
+        }
+    }
+    for (auto &t : deferred) queue_tasks_.push_back(std::move(t));
+}
+
+size_t LlamaServerContext::FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot) {   // :682-714
+    size_t stop_pos = std::string::npos;
+    for (const std::string &word : slot.params.antiprompt) {
+        size_t pos;
+        if (full) {
+            const size_t tmp = word.size() + last_token_size;
+            const size_t from_pos = text.size() > tmp ? text.size() - tmp : 0;
+            pos = text.find(word, from_pos);
+        } else {
+            // partial: does the text end with a prefix of the stop word?
+            pos = std::string::npos;
+            if (!text.empty() && !word.empty()) {
+                const char last = text.back();
+                for (long ci = (long)word.size() - 1; ci >= 0; ci--) {
+                    if (word[(size_t)ci] == last) {
+                        const std::string cur = word.substr(0, (size_t)ci + 1);
+                        if (text.size() >= cur.size() && text.compare(text.size() - cur.size(), cur.size(), cur) == 0) { pos = text.size() - cur.size(); break; }
+                    }
+                }
+            }
+        }
+        if (pos != std::string::npos && (stop_pos == std::string::npos || pos < stop_pos)) {
+            if (full) { slot.stopped_word = true; slot.stopping_word = word; slot.has_next_token = false; }
+            stop_pos = pos;
+        }
+    }
+    return stop_pos;
+}
+
+bool LlamaServerContext::ProcessToken(CompletionTokenOutput &result, LlamaClientSlot &slot) {   // :716-813
+    const std::string token_str = be_->vocab().token_to_piece(result.tok, true);
+    slot.sampled = result.tok;
+    slot.generated_text += token_str;
+    slot.has_next_token = true;
+    // hold back an incomplete UTF-8 sequence at the end of the text
+    bool incomplete = false;
+    for (unsigned i = 1; i < 5 && i <= slot.generated_text.size(); ++i) {
+        const unsigned char c = (unsigned char)slot.generated_text[slot.generated_text.size() - i];
+        if ((c & 0xC0) == 0x80) continue;
+        if ((c & 0xE0) == 0xC0) incomplete = i < 2;
+        else if ((c & 0xF0) == 0xE0) incomplete = i < 3;
+        else if ((c & 0xF8) == 0xF0) incomplete = i < 4;
+        break;
+    }
+    if (!incomplete) {
+        size_t pos = std::min(slot.sent_count, slot.generated_text.size());
+        const std::string str_test = slot.generated_text.substr(pos);
+        bool is_stop_full = false;
+        size_t stop_pos = FindStoppingStrings(str_test, token_str.size(), true, slot);
+        if (stop_pos != std::string::npos) {
+            is_stop_full = true;
+            slot.generated_text.erase(slot.generated_text.begin() + (long)(pos + stop_pos), slot.generated_text.end());
+            pos = std::min(slot.sent_count, slot.generated_text.size());
+        } else {
+            stop_pos = FindStoppingStrings(str_test, token_str.size(), false, slot);
+        }
+        if (stop_pos == std::string::npos || (!slot.has_next_token && !is_stop_full && stop_pos > 0)) {
+            result.text_to_send = slot.generated_text.substr(pos);
+            slot.sent_count += result.text_to_send.size();
+        }
+        slot.AddTokenString(result);
+        if (slot.params.stream) SendPartialResponse(slot, result);
+        else slot.sent_token_probs_index++;
+    }
+    if (incomplete) slot.has_next_token = true;
+    if (slot.n_decoded > 2 && slot.has_next_token && !slot.HasBudget(params)) { slot.stopped_limit = true; slot.has_next_token = false; }
+    if (be_->vocab().is_eog(result.tok)) { slot.stopped_eos = true; slot.has_next_token = false; }
+    return slot.has_next_token;
+}
+
+Json LlamaServerContext::ProbsToJson(const std::vector<CompletionTokenOutput> &probs) const {
+    Json out = Json::array();
+    for (const auto &p : probs) {
+        Json pj = Json::array();
+        for (const auto &tp : p.probs) {
+            Json e = Json::object();
+            e["tok_str"] = be_->vocab().token_to_piece(tp.tok, true);
+            e["prob"] = tp.p;
+            pj.push_back(std::move(e));
+        }
+        Json e = Json::object();
+        e["content"] = be_->vocab().token_to_piece(p.tok, true);
+        e["probs"] = std::move(pj);
+        out.push_back(std::move(e));
+    }
+    return out;
+}
+
+Json LlamaServerContext::GetFormatedGeneration(const LlamaClientSlot &slot) const {   // :878-918
+    Json g = Json::object();
+    g["n_ctx"] = slot.n_ctx; g["model"] = params.model_alias; g["seed"] = (int64_t)slot.sparams.seed;
+    g["temperature"] = slot.sparams.temp; g["dynatemp_range"] = slot.sparams.dynatemp_range; g["dynatemp_exponent"] = slot.sparams.dynatemp_exponent;
+    g["top_k"] = slot.sparams.top_k; g["top_p"] = slot.sparams.top_p; g["min_p"] = slot.sparams.min_p; g["typical_p"] = slot.sparams.typ_p;
+    g["repeat_last_n"] = slot.sparams.penalty_last_n; g["repeat_penalty"] = slot.sparams.penalty_repeat;
+    g["presence_penalty"] = slot.sparams.penalty_present; g["frequency_penalty"] = slot.sparams.penalty_freq;
+    g["mirostat"] = slot.sparams.mirostat; g["mirostat_tau"] = slot.sparams.mirostat_tau; g["mirostat_eta"] = slot.sparams.mirostat_eta;
+    g["stop"] = Json::array_of(slot.params.antiprompt);
+    g["n_predict"] = slot.params.n_predict; g["n_keep"] = params.n_keep; g["ignore_eos"] = slot.sparams.ignore_eos;
+    g["stream"] = slot.params.stream; g["n_probs"] = slot.sparams.n_probs; g["min_keep"] = slot.sparams.min_keep;
+    return g;
+}
+
+void LlamaServerContext::SendPartialResponse(LlamaClientSlot &slot, const CompletionTokenOutput &tkn) {   // :920-962
+    TaskResult res;
+    res.id = slot.task_id; res.error = false; res.stop = false;
+    res.result_json = Json::object();
+    res.result_json["content"] = tkn.text_to_send;
+    res.result_json["stop"] = false;
+    res.result_json["slot_id"] = slot.id;
+    res.result_json["multimodal"] = false;
+    if (slot.sparams.n_probs > 0) {
+        const auto to_send = be_->vocab().tokenize(tkn.text_to_send, false);
+        const size_t p0 = std::min(slot.sent_token_probs_index, slot.generated_token_probs.size());
+        const size_t p1 = std::min(slot.sent_token_probs_index + to_send.size(), slot.generated_token_probs.size());
+        std::vector<CompletionTokenOutput> po;
+        if (p0 < p1) po.assign(slot.generated_token_probs.begin() + (long)p0, slot.generated_token_probs.begin() + (long)p1);
+        slot.sent_token_probs_index = p1;
+        res.result_json["completion_probabilities"] = ProbsToJson(po);
+    }
+    if (slot.oaicompat) { res.result_json["oaicompat_token_ctr"] = slot.n_decoded; res.result_json["model"] = slot.oaicompat_model; }
+    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
+    condition_results_.notify_all();
+}
+
+void LlamaServerContext::SendFinalResponse(LlamaClientSlot &slot) {   // :964-1024
+    TaskResult res;
+    res.id = slot.task_id; res.error = false; res.stop = true;
+    Json &j = res.result_json;
+    j = Json::object();
+    j["content"] = !slot.params.stream ? slot.generated_text : "";
+    j["slot_id"] = slot.id; j["stop"] = true; j["model"] = params.model_alias;
+    j["tokens_predicted"] = slot.n_decoded; j["tokens_evaluated"] = slot.num_prompt_tokens;
+    j["generation_settings"] = GetFormatedGeneration(slot);
+    j["prompt"] = slot.prompt; j["truncated"] = slot.truncated;
+    j["stopped_eos"] = slot.stopped_eos; j["stopped_word"] = slot.stopped_word; j["stopped_limit"] = slot.stopped_limit;
+    j["stopping_word"] = slot.stopping_word; j["tokens_cached"] = slot.n_past;
+    j["timings"] = slot.GetFormatedTimings();
+    if (slot.sparams.n_probs > 0) {
+        std::vector<CompletionTokenOutput> probs;
+        if (!slot.params.stream && slot.stopped_word && !slot.generated_token_probs.empty())
+            probs.assign(slot.generated_token_probs.begin(), slot.generated_token_probs.end() - 1);
+        else
+            probs.assign(slot.generated_token_probs.begin(), slot.generated_token_probs.begin() + (long)std::min(slot.sent_token_probs_index, slot.generated_token_probs.size()));
+        j["completion_probabilities"] = !slot.params.stream ? ProbsToJson(probs) : Json();
+    }
+    if (slot.oaicompat) { j["oaicompat_token_ctr"] = slot.n_decoded; j["model"] = slot.oaicompat_model; }
+    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
+    condition_results_.notify_all();
+}
+
+void LlamaServerContext::SendError(LlamaClientSlot &slot, const std::string &err) {   // :840-853
+    TaskResult res;
+    res.id = slot.task_id; res.stop = false; res.error = true;
+    res.result_json = Json::object();
+    res.result_json["content"] = err;
+    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
+    condition_results_.notify_all();
+}
+
+static size_t common_part(const std::vector<int32_t> &a, const std::vector<int32_t> &b) {
+    size_t i = 0;
+    while (i < a.size() && i < b.size() && a[i] == b[i]) i++;
+    return i;
+}
+
+bool LlamaServerContext::UpdateSlots() {   // :1248-1710
+    ProcessTasks();
+    int n_tokens = 0;       // batch.n_tokens
+    if (all_slots_are_idle) {
+        if (clean_kv_cache) KvCacheClear();
+        std::unique_lock<std::mutex> lock(mutex_tasks_);
+        condition_tasks_.wait(lock, [&] { return (!queue_tasks_.empty() && model_loaded_external) || !model_loaded_external; });
+        if (!model_loaded_external) return true;
+        lock.unlock();
+        ProcessTasks();
+    }
+    // context shift (:1274-1306)
+    for (auto &slot : slots) {
+        if (slot.IsProcessing() && slot.n_past >= slot.n_ctx) {
+            const int n_left = slot.n_past - slot.params.n_keep - 1;
+            const int n_discard = n_left / 2;
+            be_->kv_seq_rm(slot.id, slot.params.n_keep + 1, slot.params.n_keep + n_discard + 1);
+            be_->kv_seq_add(slot.id, slot.params.n_keep + 1 + n_discard, slot.n_past, -n_discard);
+            if (slot.params.cache_prompt) {
+                for (size_t i = (size_t)(slot.params.n_keep + 1 + n_discard); i < slot.cache_tokens.size(); i++) slot.cache_tokens[i - (size_t)n_discard] = slot.cache_tokens[i];
+                slot.cache_tokens.resize(slot.cache_tokens.size() - (size_t)n_discard);
+            }
+            slot.n_past -= n_discard;
+            slot.truncated = true;
+        }
+    }
+    auto batch_add = [&](int32_t tok, int32_t pos, int32_t seq, bool logits) {
+        b_token_[(size_t)n_tokens] = tok; b_pos_[(size_t)n_tokens] = pos; b_seq_[(size_t)n_tokens] = seq; b_logits_[(size_t)n_tokens] = logits ? 1 : 0;
+        n_tokens++;
+    };
+    // decode tokens of the ongoing sequences (:1309-1348)
+    for (auto &slot : slots) {
+        if (slot.command == SlotCommand::kRelease) {
+            slot.state = SlotState::kIdle; slot.command = SlotCommand::kNone; slot.t_last_used = time_us();
+            continue;
+        }
+        if (slot.state == SlotState::kIdle) continue;
+        slot.i_batch = n_tokens;
+        batch_add(slot.sampled, slot.n_past, slot.id, true);
+        slot.n_decoded += 1;
+        slot.n_past += 1;
+        if (slot.params.cache_prompt) slot.cache_tokens.push_back(slot.sampled);
+    }
+    int32_t n_batch = be_->n_batch();
+    // prompt ingestion (:1355-1621)
+    if (params.cont_batching || n_tokens == 0) {
+        for (auto &slot : slots) {
+            const bool has_prompt = slot.prompt.is_array() || (slot.prompt.is_string() && !slot.prompt.as_string().empty()) || !slot.prompt_tokens.empty();
+            if (slot.state == SlotState::kIdle && slot.command == SlotCommand::kLoadPrompt && !has_prompt) {
+                slot.Release();
+                SendFinalResponse(slot);
+                continue;
+            }
+            if (!(slot.state == SlotState::kIdle && slot.command == SlotCommand::kLoadPrompt)) continue;
+            auto &prompt_tokens = slot.prompt_tokens;
+            if (!slot.prompt_ready) {   // first visit of this prompt: tokenise, truncate, find the cached prefix
+                slot.t_start_process_prompt = time_us();
+                slot.t_start_genereration = 0;
+                if (prompt_tokens.empty()) prompt_tokens = Tokenize(slot.prompt, be_->vocab().add_bos(), true);
+                slot.n_past = 0;
+                slot.num_prompt_tokens = (int32_t)prompt_tokens.size();
+                if (slot.params.n_keep < 0) slot.params.n_keep = slot.num_prompt_tokens;
+                slot.params.n_keep = std::min(slot.n_ctx - 4, slot.params.n_keep);
+                if (slot.num_prompt_tokens >= slot.n_ctx) {   // truncate by half-blocks (:1452-1485)
+                    const int n_left = slot.n_ctx - slot.params.n_keep;
+                    const int n_block_size = std::max(n_left / 2, 1);
+                    const int erased_blocks = (slot.num_prompt_tokens - slot.params.n_keep - n_block_size) / n_block_size;
+                    std::vector<int32_t> nt(prompt_tokens.begin(), prompt_tokens.begin() + slot.params.n_keep);
+                    nt.insert(nt.end(), prompt_tokens.begin() + slot.params.n_keep + erased_blocks * n_block_size, prompt_tokens.end());
+                    slot.truncated = true;
+                    prompt_tokens = nt;
+                    slot.num_prompt_tokens = (int32_t)prompt_tokens.size();
+                }
+                slot.smpl->reset();
+                if (!slot.params.cache_prompt) {
+                    slot.n_past = 0;
+                } else {
+                    for (int32_t t : prompt_tokens) slot.smpl->accept(t);
+                    slot.n_past = (int32_t)common_part(slot.cache_tokens, prompt_tokens);
+                }
+                if (slot.n_past == slot.num_prompt_tokens && slot.n_past > 0) slot.n_past--;   // evaluate at least one token
+                slot.num_prompt_tokens_processed = 0;
+                slot.prompt_ready = true;
+            }
+            // keep only the common part of the cache (:1536-1558)
+            if (!be_->kv_seq_rm(slot.id, slot.n_past, -1)) {
+                be_->kv_seq_rm(slot.id, -1, -1);
+                slot.n_past = 0;
+                slot.smpl->reset();
+            }
+            slot.cache_tokens.resize((size_t)slot.n_past);
+            for (; slot.n_past < (int)prompt_tokens.size() && n_tokens < (int)b_token_.size(); ++slot.n_past) {
+                batch_add(prompt_tokens[(size_t)slot.n_past], slot.n_past, slot.id, false);
+                if (slot.params.cache_prompt) slot.cache_tokens.push_back(prompt_tokens[(size_t)slot.n_past]);
+                slot.num_prompt_tokens_processed++;
+            }
+            if (slot.n_past == slot.num_prompt_tokens) {   // whole prompt queued: start decoding
+                slot.state = SlotState::kProcessing;
+                slot.command = SlotCommand::kNone;
+                if (n_tokens > 0) b_logits_[(size_t)n_tokens - 1] = 1;
+                slot.n_decoded = 0;
+                slot.i_batch = n_tokens - 1;
+            }
+        }
+    }
+    if (n_tokens == 0) { all_slots_are_idle = true; return true; }
+
+    for (int32_t i = 0; i < n_tokens; i += n_batch) {   // :1628-1707
+        const int32_t nt = std::min(n_batch, n_tokens - i);
+        BatchView bv{nt, b_token_.data() + i, b_pos_.data() + i, b_seq_.data() + i, b_logits_.data() + i};
+        const int ret = be_->decode(bv);
+        if (ret != 0) {
+            if (n_batch == 1 || ret < 0) {
+                for (auto &slot : slots) {
+                    if (!slot.IsProcessing()) continue;
+                    slot.state = SlotState::kProcessing; slot.command = SlotCommand::kNone;
+                    slot.Release();
+                    SendError(slot, "Input prompt is too big compared to KV size. Please try increasing KV size.");
+                }
+                break;
+            }
+            n_batch /= 2;       // retry with half the batch to find a free KV slot
+            i -= n_batch;
+            continue;
+        }
+        for (auto &slot : slots) {
+            if (slot.i_batch < i || slot.i_batch >= i + nt) continue;
+            CompletionTokenOutput result;
+            const float *logits = be_->logits_ith(slot.i_batch - i);
+            if (!logits) { slot.Release(); SendError(slot, "no logits"); slot.i_batch = -1; continue; }
+            const int32_t id = slot.smpl->sample(logits, be_->n_vocab());
+            slot.smpl->accept(id);
+            if (slot.n_decoded == 1) {
+                slot.t_start_genereration = time_us();
+                slot.t_prompt_processing = (double)(slot.t_start_genereration - slot.t_start_process_prompt) / 1e3;
+            }
+            result.tok = id;
+            const auto &cand = slot.smpl->candidates();
+            for (size_t k = 0; k < (size_t)slot.sparams.n_probs && k < cand.size(); k++) result.probs.push_back(cand[k]);
+            if (!ProcessToken(result, slot)) {
+                slot.Release();
+                SendFinalResponse(slot);
+            }
+            slot.i_batch = -1;
+        }
+    }
+    return true;
+}
+
+}  // namespace mi355

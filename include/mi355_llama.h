@@ -178,6 +178,36 @@ MI355_API int mi355_op_flash_attn(const float *q, int64_t T, int32_t n_head, int
                                   int32_t type_k, const void *k, int32_t type_v, const void *v, int32_t n_cells,
                                   const int32_t *cell_pos, const int32_t *q_pos, float scale, float *out);
 
+/* ------------------------------------------------------------------ tokenizer
+ * llama_tokenize / llama_token_to_piece as reached through common_tokenize / common_token_to_piece
+ * (src/llama_server_context.cc:395-410, 536, 644, 720, 936, 992) and llama_vocab_bos/eos/is_eog (:512-517, 792).
+ * mi355_tokenize returns the token count, or -(count needed) when `cap` is too small. */
+MI355_API int32_t mi355_tokenize(mi355_model *m, const char *text, int32_t text_len, mi355_token *out, int32_t cap,
+                                 int32_t add_special, int32_t parse_special);
+MI355_API int32_t mi355_token_to_piece(mi355_model *m, mi355_token tok, char *buf, int32_t cap, int32_t special);
+MI355_API mi355_token mi355_token_bos(mi355_model *m);
+MI355_API mi355_token mi355_token_eos(mi355_model *m);
+MI355_API int32_t mi355_token_is_eog(mi355_model *m, mi355_token tok);
+
+/* ------------------------------------------------------------------ engine (the reference's plugin surface)
+ * class EngineI (base/cortex-common/enginei.h:13-74) as implemented by LlamaEngine (src/llama_engine.cc): the slot
+ * loop, sampler and request/response shaping run in the host library; bodies cross the boundary as UTF-8 JSON text
+ * instead of std::shared_ptr<Json::Value>.  The callback receives (status, body) exactly as the reference's
+ * std::function<void(Json::Value&&, Json::Value&&)> does: status = {is_done, has_error, is_stream, status_code};
+ * streaming completions call it once per chunk (body = {"data": "data: {...}\n\n"}) from a worker thread. */
+typedef struct mi355_engine mi355_engine;
+typedef void (*mi355_engine_callback)(const char *status_json, const char *body_json, void *user);
+MI355_API mi355_engine *mi355_engine_create(void);                 /* get_engine()  (src/llama_engine.cc:1366) */
+MI355_API void mi355_engine_destroy(mi355_engine *e);
+MI355_API void mi355_engine_load_model(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
+MI355_API void mi355_engine_unload_model(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
+MI355_API void mi355_engine_get_model_status(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
+MI355_API void mi355_engine_get_models(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
+MI355_API void mi355_engine_handle_chat_completion(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
+MI355_API void mi355_engine_handle_embedding(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
+MI355_API int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature);
+MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* Streams `bytes` through a read-only reduction kernel `iters` times; returns achieved GB/s (HIP events). */
 MI355_API double mi355_bench_hbm_read(size_t bytes, int iters);

@@ -1,0 +1,403 @@
+// tests/host/host_tests.cc — CPU unit tests of the host-side mirror (JSON, tokenizer, sampler, slot loop, engine façade)
+// against a deterministic fake arithmetic backend.  Built and run by tests/test_host_logic.py with g++ (no HIP, no GPU).
+#include <cassert>
+#include <cstdio>
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <map>
+#include <set>
+#include <string>
+
+#include "../../cortex.llamacpp_amd/host/engine.h"
+#include "../../cortex.llamacpp_amd/host/gguf.h"
+#include "../../cortex.llamacpp_amd/host/json.h"
+#include "../../cortex.llamacpp_amd/host/sampling.h"
+#include "../../cortex.llamacpp_amd/host/server_context.h"
+#include "../../cortex.llamacpp_amd/host/vocab.h"
+
+using namespace mi355;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); g_fail++; } \
+    } while (0)
+
+// ---------------------------------------------------------------- fake backend
+static Vocab make_vocab() {
+    std::vector<std::string> toks = {"<unk>", "<s>", "</s>"};
+    std::vector<float> sc = {0, 0, 0};
+    std::vector<int> ty = {TT_UNKNOWN, TT_CONTROL, TT_CONTROL};
+    for (int b = 0; b < 256; b++) { char buf[8]; snprintf(buf, sizeof buf, "<0x%02X>", b); toks.push_back(buf); sc.push_back(0); ty.push_back(TT_BYTE); }
+    const char *pieces[] = {"\xE2\x96\x81", "h", "e", "l", "o", "w", "r", "d", "s", "t", "a", "he", "ll", "hell", "hello", "\xE2\x96\x81hello", "wo", "wor", "worl",
+                            "world", "\xE2\x96\x81world", "\xE2\x96\x81s", "\xE2\x96\x81st", "\xE2\x96\x81sto", "p", "\xE2\x96\x81stop", "U", "S", "E", "R", ":", "A", "I", "N", "T", "'", "!", ".", ","};
+    float s = -1.0f;
+    for (const char *p : pieces) { toks.push_back(p); sc.push_back(strlen(p) > 3 ? -s : s); ty.push_back(TT_NORMAL); s -= 1.0f; }
+    // longer pieces get higher scores so merges prefer them
+    for (size_t i = 259; i < toks.size(); i++) sc[i] = (float)toks[i].size();
+    Vocab v;
+    v.init_spm(toks, sc, ty, 1, 2, 0, true);
+    return v;
+}
+
+struct FakeBackend : IBackend {
+    Vocab voc = make_vocab();
+    int ctx = 256, nbatch = 64;
+    int eos_after = -1;           // emit EOS as the preferred token once a sequence reaches this position
+    int decode_sleep_us = 0;
+    int fail_decode_over = -1;    // decode of more than this many tokens returns 1 (no KV slot)
+    std::vector<std::vector<int32_t>> calls_tokens, calls_seq, calls_pos;
+    std::vector<std::string> kv_ops;
+    std::map<int, std::map<int, int>> kv;   // seq -> pos -> token
+    std::vector<std::vector<float>> last_logits;
+    std::vector<int> last_flag_index;
+    int first_normal = 259;
+
+    int n_ctx() const override { return ctx; }
+    int n_batch() const override { return nbatch; }
+    int n_ubatch() const override { return nbatch; }
+    int n_vocab() const override { return voc.n_tokens(); }
+    int n_embd() const override { return 8; }
+    const Vocab &vocab() const override { return voc; }
+    int next_token(int tok, int pos) const {
+        if (eos_after >= 0 && pos >= eos_after) return voc.eos();
+        const int nn = voc.n_tokens() - first_normal;
+        return first_normal + (int)(((unsigned)tok * 31u + (unsigned)pos * 7u + 11u) % (unsigned)nn);
+    }
+    int decode(const BatchView &b) override {
+        if (fail_decode_over >= 0 && b.n_tokens > fail_decode_over) return 1;
+        if (decode_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(decode_sleep_us));
+        calls_tokens.emplace_back(b.token, b.token + b.n_tokens);
+        calls_seq.emplace_back(b.seq_id, b.seq_id + b.n_tokens);
+        calls_pos.emplace_back(b.pos, b.pos + b.n_tokens);
+        last_logits.clear(); last_flag_index.assign((size_t)b.n_tokens, -1);
+        for (int i = 0; i < b.n_tokens; i++) {
+            kv[b.seq_id[i]][b.pos[i]] = b.token[i];
+            if ((int)kv[b.seq_id[i]].size() > ctx) return 1;
+            if (b.logits[i]) {
+                std::vector<float> lg((size_t)n_vocab());
+                for (int v = 0; v < n_vocab(); v++) lg[(size_t)v] = (float)((v * 2654435761u >> 20) & 1023) / 1024.0f;   // background in [0,1)
+                lg[(size_t)next_token(b.token[i], b.pos[i])] = 12.0f;
+                last_flag_index[(size_t)i] = (int)last_logits.size();
+                last_logits.push_back(std::move(lg));
+            }
+        }
+        return 0;
+    }
+    const float *logits_ith(int i) override { return (i >= 0 && i < (int)last_flag_index.size() && last_flag_index[(size_t)i] >= 0) ? last_logits[(size_t)last_flag_index[(size_t)i]].data() : nullptr; }
+    void kv_clear() override { kv.clear(); kv_ops.push_back("clear"); }
+    bool kv_seq_rm(int seq, int p0, int p1) override {
+        kv_ops.push_back("rm " + std::to_string(seq) + " " + std::to_string(p0) + " " + std::to_string(p1));
+        auto &m = kv[seq];
+        for (auto it = m.begin(); it != m.end();) { if (it->first >= (p0 < 0 ? 0 : p0) && (p1 < 0 || it->first < p1)) it = m.erase(it); else ++it; }
+        return true;
+    }
+    void kv_seq_add(int seq, int p0, int p1, int d) override {
+        kv_ops.push_back("add " + std::to_string(seq) + " " + std::to_string(p0) + " " + std::to_string(p1) + " " + std::to_string(d));
+        std::map<int, int> nm;
+        for (auto &e : kv[seq]) nm[(e.first >= p0 && e.first < p1) ? e.first + d : e.first] = e.second;
+        kv[seq] = nm;
+    }
+    void kv_seq_cp(int, int, int, int) override {}
+};
+
+// ---------------------------------------------------------------- tests
+static void test_json() {
+    Json j;
+    std::string err;
+    CHECK(Json::parse("{\"a\": [1, 2.5, \"x\\n\\u00e9\", true, null], \"b\": {\"c\": -3}}", j, &err));
+    CHECK(j["a"].size() == 5 && j["a"].at(0).as_int() == 1 && j["a"].at(1).as_double() == 2.5);
+    CHECK(j["a"].at(2).as_string() == "x\n\xC3\xA9");
+    CHECK(j["b"].value<int>("c", 0) == -3 && j.value<int>("zz", 7) == 7);
+    Json k;
+    CHECK(Json::parse(j.dump(), k) && k.dump() == j.dump());
+    CHECK(!Json::parse("{\"a\": }", k));
+}
+
+static void test_vocab() {
+    Vocab v = make_vocab();
+    auto ids = v.tokenize("hello world", true);
+    CHECK(ids.size() == 3 && ids[0] == v.bos());
+    CHECK(v.token_to_piece(ids[1]) == " hello" && v.token_to_piece(ids[2]) == " world");
+    CHECK(v.detokenize({ids[1], ids[2]}) == " hello world");
+    auto z = v.tokenize("h\xC3\xA9", false);               // 'é' is not in the vocab -> two byte tokens
+    CHECK(z.size() == 4);                                   // "▁" "h" <0xC3> <0xA9>
+    CHECK(v.detokenize(z) == " h\xC3\xA9");
+    auto sp = v.tokenize("hello</s>", false, true);         // parse_special splits on the control token
+    CHECK(!sp.empty() && sp.back() == v.eos());
+    CHECK(v.is_eog(v.eos()) && !v.is_eog(ids[1]));
+}
+
+static void test_sampler() {
+    std::vector<float> lg(100, 0.0f);
+    lg[17] = 5.0f; lg[42] = 4.9f; lg[3] = 4.0f;
+    SamplingParams p;
+    p.temp = 0.0f;
+    Sampler g(p);
+    CHECK(g.sample(lg.data(), 100) == 17);
+    p.temp = 0.8f; p.top_k = 1;
+    Sampler k1(p);
+    CHECK(k1.sample(lg.data(), 100) == 17);
+    p.top_k = 40; p.seed = 123;
+    Sampler a(p), b(p);
+    for (int i = 0; i < 20; i++) { const int x = a.sample(lg.data(), 100), y = b.sample(lg.data(), 100); CHECK(x == y); a.accept(x); b.accept(y); }
+    p.temp = 0.0f; p.penalty_repeat = 2.0f; p.penalty_last_n = 8;
+    Sampler pen(p);
+    pen.accept(17);
+    CHECK(pen.sample(lg.data(), 100) == 42);                // 5.0 / 2 < 4.9
+    p.penalty_repeat = 1.0f; p.logit_bias = {{17, -INFINITY}};
+    Sampler lb(p);
+    CHECK(lb.sample(lg.data(), 100) == 42);
+    p.logit_bias.clear(); p.temp = 1.0f; p.top_k = 0; p.top_p = 0.5f; p.min_p = 0.0f; p.seed = 7;
+    Sampler tp(p);
+    std::set<int> seen;
+    for (int i = 0; i < 200; i++) seen.insert(tp.sample(lg.data(), 100));
+    CHECK(seen.size() <= 2 && seen.count(17));              // nucleus of 0.5 keeps the two dominant tokens at most
+}
+
+// The reference counts n_decoded when a sampled token is fed back (llama_server_context.cc:1335), so the budget check
+// (:787) fires on the (n_predict+1)-th sampled token: n_predict = n yields n + 1 pieces of text and tokens_predicted = n.
+static std::string expected_text(const FakeBackend &be, const std::vector<int32_t> &prompt, int n_predict) {
+    const int n = n_predict + 1;
+    std::string s;
+    int tok = prompt.back(), pos = (int)prompt.size() - 1;
+    for (int i = 0; i < n; i++) { tok = be.next_token(tok, pos); pos++; s += be.voc.token_to_piece(tok); }
+    return s;
+}
+
+static void test_slot_loop() {
+    FakeBackend be;
+    ServerParams sp;
+    sp.n_parallel = 2;
+    LlamaServerContext ctx(&be, sp);
+    ctx.Initialize();
+    Json d = Json::object();
+    d["prompt"] = "hello world"; d["n_predict"] = 8; d["temperature"] = 0.0; d["stream"] = false;
+    const int id = ctx.RequestCompletion(d, false, false, -1);
+    TaskResult r = ctx.NextResult(id);
+    CHECK(!r.error && r.stop);
+    const auto prompt = be.voc.tokenize("hello world", true);
+    CHECK(r.result_json["tokens_evaluated"].as_int() == (int64_t)prompt.size());
+    CHECK(r.result_json["tokens_predicted"].as_int() == 8);
+    CHECK(r.result_json["content"].as_string() == expected_text(be, prompt, 8));
+    CHECK(r.result_json["stopped_limit"].as_bool());
+    for (const char *k : {"prompt_n", "prompt_ms", "prompt_per_second", "predicted_n", "predicted_ms", "predicted_per_second"}) CHECK(r.result_json["timings"].contains(k));
+    ctx.RequestCancel(id);
+
+    // streaming: partial contents concatenate to the full text
+    d["stream"] = true; d["n_predict"] = 6;
+    const int id2 = ctx.RequestCompletion(d, false, false, -1);
+    std::string acc;
+    while (true) {
+        TaskResult pr = ctx.NextResult(id2);
+        CHECK(!pr.error);
+        acc += pr.result_json["content"].as_string();
+        if (pr.stop) break;
+    }
+    CHECK(acc == expected_text(be, prompt, 6));
+
+    // stop word: find a piece that the deterministic model emits at step 3 and use it as the stop string
+    {
+        int tok = prompt.back(), pos = (int)prompt.size() - 1;
+        std::string before;
+        std::string stopw;
+        for (int i = 0; i < 4; i++) { tok = be.next_token(tok, pos); pos++; if (i < 3) before += be.voc.token_to_piece(tok); else stopw = be.voc.token_to_piece(tok); }
+        if (!stopw.empty() && before.find(stopw) == std::string::npos) {
+            Json ds = d;
+            ds["stream"] = false; ds["n_predict"] = 20;
+            Json st = Json::array(); st.push_back(stopw);
+            ds["stop"] = st;
+            const int id3 = ctx.RequestCompletion(ds, false, false, -1);
+            TaskResult sr = ctx.NextResult(id3);
+            CHECK(sr.result_json["stopped_word"].as_bool() && sr.result_json["stopping_word"].as_string() == stopw);
+            CHECK(sr.result_json["content"].as_string() == before);
+        }
+    }
+
+    // EOS ends generation
+    be.eos_after = (int)prompt.size() + 2;
+    Json de = d; de["stream"] = false; de["n_predict"] = 50;
+    const int id4 = ctx.RequestCompletion(de, false, false, -1);
+    TaskResult er = ctx.NextResult(id4);
+    CHECK(er.result_json["stopped_eos"].as_bool() && er.result_json["tokens_predicted"].as_int() <= 5);
+    be.eos_after = -1;
+
+    // two requests at once -> both slots active, decode batches mix sequence ids (continuous batching)
+    be.calls_seq.clear();
+    be.decode_sleep_us = 500;
+    Json a = d, b = d;
+    a["stream"] = false; b["stream"] = false; a["n_predict"] = 60; b["n_predict"] = 60; b["prompt"] = "world hello";
+    const int ia = ctx.RequestCompletion(a, false, false, -1), ib = ctx.RequestCompletion(b, false, false, -1);
+    TaskResult ra = ctx.NextResult(ia), rb = ctx.NextResult(ib);
+    CHECK(ra.stop && rb.stop && !ra.error && !rb.error);
+    bool mixed = false;
+    for (const auto &c : be.calls_seq) { std::set<int> s(c.begin(), c.end()); if (s.size() > 1) mixed = true; }
+    CHECK(mixed);
+    CHECK(ra.result_json["content"].as_string() == expected_text(be, prompt, 60));
+    ctx.ReleaseResources();
+}
+
+static void test_prompt_cache_and_shift() {
+    FakeBackend be;
+    be.ctx = 32;
+    ServerParams sp;
+    LlamaServerContext ctx(&be, sp);
+    ctx.Initialize();
+    Json d = Json::object();
+    d["prompt"] = "hello world hello"; d["n_predict"] = 3; d["temperature"] = 0.0; d["cache_prompt"] = true;
+    TaskResult r1 = ctx.NextResult(ctx.RequestCompletion(d, false, false, -1));
+    CHECK(r1.stop);
+    const size_t ncalls = be.calls_tokens.size();
+    be.kv_ops.clear();
+    d["prompt"] = "hello world hello world";          // shares the first 4 tokens (BOS + 3 words) with the cached sequence
+    TaskResult r2 = ctx.NextResult(ctx.RequestCompletion(d, false, false, -1));
+    CHECK(r2.stop);
+    const auto p2 = be.voc.tokenize("hello world hello world", true);
+    CHECK(be.calls_tokens.size() > ncalls);
+    // only the non-cached suffix was decoded as prompt: first new call holds 1 prompt token (the 5th), not 5
+    CHECK(be.calls_tokens[ncalls].size() == 1 && be.calls_tokens[ncalls][0] == p2.back() && be.calls_pos[ncalls][0] == 4);
+    bool rm4 = false;
+    for (const auto &op : be.kv_ops) if (op == "rm 0 4 -1") rm4 = true;
+    CHECK(rm4);
+    CHECK(r2.result_json["tokens_evaluated"].as_int() == (int64_t)p2.size());
+
+    // context shift: generate past the slot context
+    be.kv_ops.clear();
+    Json g = Json::object();
+    g["prompt"] = "hello"; g["n_predict"] = 45; g["temperature"] = 0.0; g["n_keep"] = 1;
+    TaskResult r3 = ctx.NextResult(ctx.RequestCompletion(g, false, false, -1));
+    CHECK(r3.stop && r3.result_json["truncated"].as_bool());
+    ctx.ReleaseResources();          // joins the loop thread: the fake backend's op log is only read once it is quiescent
+    bool saw_rm = false, saw_add = false;
+    for (const auto &op : be.kv_ops) {
+        if (op.rfind("rm 0 2 ", 0) == 0) saw_rm = true;          // seq_rm(slot, n_keep + 1, n_keep + n_discard + 1)
+        if (op.rfind("add 0 ", 0) == 0 && op.find(" -") != std::string::npos) saw_add = true;
+    }
+    CHECK(saw_rm && saw_add);
+    CHECK(r3.result_json["tokens_predicted"].as_int() == 45);
+}
+
+static void test_kv_full_error() {
+    FakeBackend be;
+    be.fail_decode_over = 0;          // every decode reports "no KV slot"
+    ServerParams sp;
+    LlamaServerContext ctx(&be, sp);
+    ctx.Initialize();
+    Json d = Json::object();
+    d["prompt"] = "hello world"; d["n_predict"] = 4;
+    TaskResult r = ctx.NextResult(ctx.RequestCompletion(d, false, false, -1));
+    CHECK(r.error && r.result_json["content"].as_string().find("too big") != std::string::npos);
+    ctx.ReleaseResources();
+}
+
+static void test_engine() {
+    LlamaEngine eng([](const Json &body, BackendInfo &info, std::string &err) -> std::unique_ptr<IBackend> {
+        if (body["llama_model_path"].as_string() == "/bad") { err = "no such file"; return nullptr; }
+        info.vram = 123; info.model_size = 456;
+        return std::unique_ptr<IBackend>(new FakeBackend());
+    });
+    CHECK(eng.IsSupported("HandleChatCompletion") && !eng.IsSupported("Nope"));
+    Json load = Json::object();
+    load["llama_model_path"] = "/models/tiny-test.gguf"; load["ctx_len"] = 256; load["n_parallel"] = 2;
+    CHECK(LlamaEngine::GetModelId(load) == "tiny-test");
+    int code = 0; std::string msg;
+    auto grab = [&](Json &&st, Json &&body) { code = (int)st["status_code"].as_int(); msg = body["message"].as_string(); };
+    eng.LoadModel(load, grab);
+    CHECK(code == 200 && msg == "Model loaded successfully");
+    eng.LoadModel(load, grab);
+    CHECK(code == 409);
+    Json bad = Json::object(); bad["llama_model_path"] = "/bad";
+    eng.LoadModel(bad, grab);
+    CHECK(code == 500);
+    Json none = Json::object();
+    eng.LoadModel(none, grab);
+    CHECK(code == 400);
+    Json models;
+    eng.GetModels(Json::object(), [&](Json &&, Json &&b) { models = b; });
+    CHECK(models["data"].size() == 1 && models["data"].at(0)["id"].as_string() == "tiny-test" && models["data"].at(0)["vram"].as_int() == 123);
+
+    // non-stream chat completion
+    Json req = Json::object();
+    req["model"] = "tiny-test"; req["max_tokens"] = 6; req["temperature"] = 0.0;
+    Json msgs = Json::array(), m1 = Json::object();
+    m1["role"] = "user"; m1["content"] = "hello world";
+    msgs.push_back(m1);
+    req["messages"] = msgs;
+    std::mutex mu; std::condition_variable cv; bool done = false; Json body, status;
+    eng.HandleChatCompletion(req, [&](Json &&st, Json &&b) { std::lock_guard<std::mutex> lk(mu); status = st; body = b; done = true; cv.notify_all(); });
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+    CHECK(status["status_code"].as_int() == 200 && !status["has_error"].as_bool() && status["is_done"].as_bool());
+    CHECK(body["object"].as_string() == "chat.completion" && body["choices"].at(0)["message"]["role"].as_string() == "assistant");
+    CHECK(body["usage"]["completion_tokens"].as_int() == 6 && body["usage"]["total_tokens"].as_int() == body["usage"]["prompt_tokens"].as_int() + 6);
+
+    // streaming
+    req["stream"] = true;
+    Json so = Json::object(); so["include_usage"] = true; req["stream_options"] = so;
+    std::vector<std::string> chunks; done = false;
+    eng.HandleChatCompletion(req, [&](Json &&st, Json &&b) {
+        std::lock_guard<std::mutex> lk(mu);
+        chunks.push_back(b["data"].as_string());
+        if (st["is_done"].as_bool()) { done = true; cv.notify_all(); }
+    });
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+    CHECK(chunks.size() >= 2);
+    for (const auto &c : chunks) CHECK(c.rfind("data: ", 0) == 0);
+    CHECK(chunks.back().find("data: [DONE]\n\n") != std::string::npos);
+    CHECK(chunks.back().find("\"total_tokens\"") != std::string::npos);
+    Json first;
+    CHECK(Json::parse(chunks[0].substr(6, chunks[0].size() - 8), first) && first["object"].as_string() == "chat.completion.chunk");
+
+    Json un = Json::object(); un["model"] = "tiny-test";
+    eng.UnloadModel(un, grab);
+    CHECK(code == 200);
+    eng.HandleChatCompletion(req, grab);
+    CHECK(code == 409);
+}
+
+// `host_tests --tokenize model.gguf cases.json` : tokenizes every string of the JSON array with the GGUF's tokenizer and
+// prints {"ids": [[...], ...], "pieces": [[...], ...], "bos":, "eos":} — compared against HF `tokenizers` by test_host_logic.py
+static int tokenize_cli(const char *gguf, const char *cases) {
+    GGUFFile f;
+    std::string err;
+    err = f.open(gguf);
+    if (!err.empty()) { fprintf(stderr, "gguf: %s\n", err.c_str()); return 2; }
+    Vocab v;
+    if (!v.load(f, err)) { fprintf(stderr, "vocab: %s\n", err.c_str()); return 2; }
+    FILE *fp = fopen(cases, "rb");
+    if (!fp) return 2;
+    std::string txt;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) txt.append(buf, n);
+    fclose(fp);
+    Json arr;
+    if (!Json::parse(txt, arr, &err)) { fprintf(stderr, "cases: %s\n", err.c_str()); return 2; }
+    Json out = Json::object(), ids = Json::array(), rt = Json::array();
+    for (size_t i = 0; i < arr.size(); i++) {
+        const bool special = arr.at(i).is_object();
+        const std::string text = special ? arr.at(i)["text"].as_string() : arr.at(i).as_string();
+        const auto t = v.tokenize(text, false, special);
+        Json row = Json::array();
+        for (int32_t id : t) row.push_back((int64_t)id);
+        ids.push_back(row);
+        rt.push_back(v.detokenize(t, true));
+    }
+    out["ids"] = ids; out["roundtrip"] = rt; out["bos"] = v.bos(); out["eos"] = v.eos(); out["n"] = v.n_tokens();
+    printf("%s\n", out.dump().c_str());
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc == 4 && std::string(argv[1]) == "--tokenize") return tokenize_cli(argv[2], argv[3]);
+    test_json();
+    test_vocab();
+    test_sampler();
+    test_slot_loop();
+    test_prompt_cache_and_shift();
+    test_kv_full_error();
+    test_engine();
+    if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
+    printf("all host-logic checks passed\n");
+    return 0;
+}

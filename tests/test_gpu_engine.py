@@ -1,0 +1,144 @@
+"""GPU end-to-end tests through the engine surface (mi355_engine_*): what the reference's e2e suite drives over HTTP
+(.github/scripts/e2e-test-server-*.sh: loadmodel -> chat/completions stream + non-stream -> unloadmodel), here through
+the C-ABI with a synthetic tiny GGUF.  The text a greedy request returns is checked against an independent greedy
+loop over mi355_decode + mi355_get_argmax_ith on the same model."""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_vocab_model(pkg, tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("eng") / "tiny-d128.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, "tiny-d128", "q4_k_m", with_vocab=True)
+    return path
+
+
+@pytest.fixture(scope="module")
+def engine(pkg, tiny_vocab_model):
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=512, n_parallel=2, ngl=100, user_prompt="u:",
+                            ai_prompt="a:", system_prompt="s:")
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    yield e
+    e.close()
+
+
+GREEDY = dict(temperature=0.0, repeat_penalty=1.0, frequency_penalty=0.0, presence_penalty=0.0)
+
+
+def _greedy_reference(pkg, path, prompt: str, n_predict: int) -> str:
+    """Independent greedy loop; mirrors the reference's budget rule (n_predict + 1 sampled tokens, see
+    tests/host/host_tests.cc expected_text) and stops at EOS."""
+    m = pkg.Model(path)
+    c = pkg.Context(m, n_ctx=512, n_seq_max=1)
+    toks = m.tokenize(prompt, add_special=True, parse_special=True)
+    assert c.decode(toks, list(range(len(toks)))) == 0
+    out, pos = b"", len(toks)
+    eos = m.lib.mi355_token_eos(m.h)
+    for _ in range(n_predict + 1):
+        t = int(np.argmax(c.logits(-1)))
+        if t == eos:
+            break
+        out += m.token_to_piece(t)
+        assert c.decode([t], [pos]) == 0
+        pos += 1
+    c.close()
+    m.close()
+    return out.decode("utf-8", errors="ignore")
+
+
+def test_model_listing_and_status(engine):
+    st, body = engine.get_models()
+    assert st["status_code"] == 200
+    assert [d["id"] for d in body["data"]] == ["tiny-d128"]
+    d = body["data"][0]
+    assert d["object"] == "model" and d["vram"] > 0 and d["model_size"] > 0 and d["engine"] == "cortex.llamacpp"
+    st, body = engine.get_model_status(model="tiny-d128")
+    assert st["status_code"] == 200
+    st, body = engine.get_model_status(model="nope")
+    assert st["status_code"] == 409
+    assert engine.is_supported("HandleChatCompletion") and engine.is_supported("LoadModel")
+
+
+def test_chat_completion_matches_greedy_decode(pkg, engine, tiny_vocab_model):
+    msgs = [{"role": "system", "content": "be brief"}, {"role": "user", "content": "hello world"}]
+    res = engine.chat_completion(model="tiny-d128", messages=msgs, max_tokens=12, **GREEDY)
+    st, body = res[-1]
+    assert st["status_code"] == 200 and not st["has_error"] and st["is_done"] and not st["is_stream"]
+    assert body["object"] == "chat.completion" and body["model"] == "tiny-d128"
+    content = body["choices"][0]["message"]["content"]
+    want = _greedy_reference(pkg, tiny_vocab_model, "s:be briefu:hello worlda:", 12)
+    if "u:" not in want and "<|im_end|>" not in want:
+        assert content == want.lstrip(" ") or content == want, (content, want)
+    u = body["usage"]
+    assert u["completion_tokens"] <= 12 and u["total_tokens"] == u["prompt_tokens"] + u["completion_tokens"]
+
+    # streaming returns the same text, framed as SSE chunks terminated by [DONE]
+    res = engine.chat_completion(model="tiny-d128", messages=msgs, max_tokens=12, stream=True, **GREEDY)
+    text = ""
+    for st, body in res:
+        assert st["is_stream"]
+        for ev in body["data"].split("\n\n"):
+            if not ev:
+                continue
+            assert ev.startswith("data: ")
+            if ev == "data: [DONE]":
+                continue
+            ch = json.loads(ev[6:])
+            assert ch["object"] == "chat.completion.chunk"
+            text += ch["choices"][0]["delta"].get("content") or ""
+    assert res[-1][0]["is_done"] and "data: [DONE]" in res[-1][1]["data"]
+    assert text == content
+
+
+def test_parallel_requests_share_the_batch(engine):
+    """n_parallel = 2: two concurrent greedy requests both finish, and each equals its own serial run."""
+    prompts = ["abc def", "xyz uvw abc"]
+    serial = [engine.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": p}], max_tokens=24, **GREEDY)[-1][1]
+              ["choices"][0]["message"]["content"] for p in prompts]
+    out = [None, None]
+
+    def run(i):
+        out[i] = engine.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": prompts[i]}], max_tokens=24,
+                                        **GREEDY)[-1][1]["choices"][0]["message"]["content"]
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert out[0] is not None and out[1] is not None
+    # batching two sequences changes f32 summation order nowhere (rows are independent), so the text is identical
+    assert out == serial
+
+
+def test_seeded_sampling_is_reproducible(engine):
+    kw = dict(model="tiny-d128", messages=[{"role": "user", "content": "tell me"}], max_tokens=16, temperature=0.9, top_k=20,
+              top_p=0.9, seed=1234)
+    a = engine.chat_completion(**kw)[-1][1]["choices"][0]["message"]["content"]
+    b = engine.chat_completion(**kw)[-1][1]["choices"][0]["message"]["content"]
+    assert a == b
+
+
+def test_errors_and_unload(pkg, tiny_vocab_model):
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path="/nonexistent/model.gguf")
+    assert st["status_code"] == 500 and st["has_error"]
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ngl=0)
+    assert st["has_error"] and st["status_code"] == 500
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=256, cache_type="q8_0")
+    assert st["status_code"] == 200
+    st, body = e.load_model(llama_model_path=tiny_vocab_model)
+    assert st["status_code"] == 409
+    res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "hi"}], max_tokens=4, **GREEDY)
+    assert res[-1][0]["status_code"] == 200
+    st, body = e.embedding(model="tiny-d128", input="hi")
+    assert st["has_error"]
+    st, body = e.unload_model(model="tiny-d128")
+    assert st["status_code"] == 200
+    res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "hi"}], max_tokens=4)
+    assert res[-1][0]["status_code"] == 409
+    e.close()
