@@ -404,11 +404,11 @@ class Engine:
         if not self.h:
             raise MI355Error(f"mi355_engine_create failed: {_err(self.lib)}")
 
-    def _call(self, fn, body: dict, wait_done: bool = True, timeout: float = 300.0):
+    def _call(self, fn, body: dict, wait_done: bool = True, timeout: float = 120.0):
         out, done = [], self._threading.Event()
 
         def on(status, payload, _user):
-            st, bd = self._json.loads(status.decode()), self._json.loads(payload.decode())
+            st, bd = self._json.loads(status.decode("utf-8", "replace")), self._json.loads(payload.decode("utf-8", "replace"))
             out.append((st, bd))
             if st.get("is_done", True) or st.get("has_error", False):
                 done.set()

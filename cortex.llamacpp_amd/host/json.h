@@ -101,21 +101,43 @@ class Json {
     std::vector<Json> a_;
     Members o_;
 
+    // Strings are emitted as valid UTF-8: a byte that does not start or continue a well-formed sequence is replaced by
+    // U+FFFD (generated text can end in, or contain, stray byte-fallback tokens).
     static void dump_string(const std::string &s, std::string &out) {
         out += '"';
-        for (unsigned char c : s) {
-            switch (c) {
-                case '"': out += "\\\""; break;
-                case '\\': out += "\\\\"; break;
-                case '\n': out += "\\n"; break;
-                case '\r': out += "\\r"; break;
-                case '\t': out += "\\t"; break;
-                case '\b': out += "\\b"; break;
-                case '\f': out += "\\f"; break;
-                default:
-                    if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); out += b; }
-                    else out += (char)c;
+        const size_t n = s.size();
+        for (size_t i = 0; i < n;) {
+            const unsigned char c = (unsigned char)s[i];
+            if (c < 0x80) {
+                switch (c) {
+                    case '"': out += "\\\""; break;
+                    case '\\': out += "\\\\"; break;
+                    case '\n': out += "\\n"; break;
+                    case '\r': out += "\\r"; break;
+                    case '\t': out += "\\t"; break;
+                    case '\b': out += "\\b"; break;
+                    case '\f': out += "\\f"; break;
+                    default:
+                        if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); out += b; }
+                        else out += (char)c;
+                }
+                i++;
+                continue;
             }
+            size_t len = 0;
+            uint32_t cp = 0;
+            if (c >= 0xC2 && c <= 0xDF) { len = 2; cp = c & 0x1Fu; }
+            else if (c >= 0xE0 && c <= 0xEF) { len = 3; cp = c & 0x0Fu; }
+            else if (c >= 0xF0 && c <= 0xF4) { len = 4; cp = c & 0x07u; }
+            bool ok = len != 0 && i + len <= n;
+            for (size_t k = 1; ok && k < len; k++) {
+                const unsigned char cc = (unsigned char)s[i + k];
+                if ((cc & 0xC0) != 0x80) ok = false;
+                cp = (cp << 6) | (cc & 0x3Fu);
+            }
+            if (ok && ((len == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF)))) ok = false;
+            if (ok) { out.append(s, i, len); i += len; }
+            else { out += "\xEF\xBF\xBD"; i++; }
         }
         out += '"';
     }

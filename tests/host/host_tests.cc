@@ -113,6 +113,8 @@ static void test_json() {
     Json k;
     CHECK(Json::parse(j.dump(), k) && k.dump() == j.dump());
     CHECK(!Json::parse("{\"a\": }", k));
+    CHECK(Json(std::string("a\xC1z\xE2\x96")).dump() == "\"a\xEF\xBF\xBDz\xEF\xBF\xBD\xEF\xBF\xBD\"");   // ill-formed bytes -> U+FFFD
+    CHECK(Json(std::string("\xE2\x96\x81ok")).dump() == "\"\xE2\x96\x81ok\"");
 }
 
 static void test_vocab() {
