@@ -528,8 +528,23 @@ hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, in
 // Decode attention: workgroup = (kv head g, chunk of 64 cells, token t).  The query heads of the group are read
 // un-rotated, rotated with the cos/sin table and converted to the K cache's dot type here (so no separate pass over q),
 // and K / V / scales / cell table of the chunk are all requested before the first wait.
-template <int R, int TK, int TV>
-__global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a, const float *cs_table, int n_rot) {
+//
+// FUSED (single-token step, R*D a multiple of 256) folds the two neighbouring launches into this one:
+//  * KV store: the workgroup whose chunk holds the token's cell rotates K, converts K/V to the cache type, writes the
+//    cache row and patches its own registers / LDS scales with the same codes (no other workgroup reads that cell);
+//  * merge: every workgroup publishes its chunk partial, then takes a ticket on a per-kv-head counter; the LAST arriver
+//    merges the splits of its R heads exactly as flash_attn_combine_kernel does, writes the f32 rows and the quantised
+//    activation of the attn_output mat-vec, and re-arms the counter.  Nobody waits: no spin, no co-residency needed.
+struct DecodeFuse {
+    const float *knew, *vnew;      // [G*D] un-rotated K and V of the token
+    const int32_t *tok_cell;       // [1]
+    unsigned *counters;            // [G], zero between launches
+    ActQuant q;
+    int want_q8k, want_q80;
+};
+
+template <int R, int TK, int TV, bool FUSED>
+__global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz) {
     constexpr int D = 128, C = 64, NB = 4;
     constexpr int KP = TK == T_F16 ? 4 : 2;                 // 16-byte K pieces per thread
     constexpr int LPC = TK == T_F16 ? 16 : 8;               // lanes per cell in the score pass
@@ -541,6 +556,9 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     __shared__ int vis[C];
     __shared__ uint32_t ksc[C * NB / 2], vsc[C * NB / 2];           // f16 block scales of the chunk
     __shared__ __attribute__((aligned(16))) float accs[8 * R * D];
+    __shared__ __attribute__((aligned(16))) uint8_t newk[D * 2], newv[D * 2];   // the token's own cache row (codes or f16)
+    __shared__ uint32_t newkd[2], newvd[2];                                      // its f16 block scales, two per word
+    __shared__ int last_flag;
     const int g = blockIdx.x, sp = blockIdx.y, t = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_ctx = a.n_ctx, H = a.H;
@@ -593,6 +611,42 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
         if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid & 1) * 2);
     }
 
+    // ---- FUSED: this token's K/V row (wave 0: lanes 0..31 rotate + convert K, lanes 32..63 convert V; 4 elements each)
+    int own_cl = -1;                                   // chunk-local index of the token's cell, if this chunk holds it
+    if (FUSED) {
+        const int cellnew = fz.tok_cell[0];
+        if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
+        if (own_cl >= 0 && wave == 0) {
+            const bool isk = lane < 32;
+            const int dd = (lane & 31) * 4;
+            float4 x4 = *reinterpret_cast<const float4 *>((isk ? fz.knew : fz.vnew) + (size_t)g * D + dd);
+            if (isk && dd < n_rot) {
+                const float4 cs = *reinterpret_cast<const float4 *>(cs_table + dd);   // c0 s0 c1 s1
+                const float x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
+                x4.x = x0 * cs.x - x1 * cs.y; x4.y = x0 * cs.y + x1 * cs.x;
+                x4.z = x2 * cs.z - x3 * cs.w; x4.w = x2 * cs.w + x3 * cs.z;
+            }
+            const float xa[4] = {x4.x, x4.y, x4.z, x4.w};
+            const size_t rowi = head_row0 + cellnew;
+            const int TT = isk ? TK : TV;              // (TK, TV are compile-time; the select folds per branch below)
+            uint32_t packed = 0; float dsc = 0.0f;
+            if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
+            if (TT == T_F16) {
+                uint2 o; o.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); o.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
+                *reinterpret_cast<uint2 *>((isk ? newk : newv) + dd * 2) = o;
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(isk ? a.kv.k : a.kv.v) + rowi * D + dd) = o;
+            } else {
+                *reinterpret_cast<uint32_t *>((isk ? newk : newv) + dd) = packed;
+                *reinterpret_cast<uint32_t *>((isk ? a.kv.k : a.kv.v) + rowi * D + dd) = packed;
+                if ((lane & 7) == 0) {
+                    const uint16_t hd = f2h(dsc);
+                    (isk ? a.kv.kd : a.kv.vd)[rowi * NB + (dd >> 5)] = hd;
+                    reinterpret_cast<uint16_t *>(isk ? newkd : newvd)[dd >> 5] = hd;
+                }
+            }
+        }
+    }
+
     // ---- q: rotate, convert
     if (tid < C) vis[tid] = (cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
     if (tid < C * NB / 2) { ksc[tid] = ks2; vsc[tid] = vs2; }
@@ -607,6 +661,24 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
         }
     }
     __syncthreads();
+    if (FUSED && own_cl >= 0) {   // workgroup-uniform: use the row just produced instead of what the cache held before
+        if (tid < 2) {
+            if (TK != T_F16) ksc[own_cl * 2 + tid] = newkd[tid];
+            if (TV != T_F16) vsc[own_cl * 2 + tid] = newvd[tid];
+        }
+#pragma unroll
+        for (int j = 0; j < KP; j++) {
+            const int p = tid + 256 * j;
+            if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const uint4 *>(newk + (p % LPC) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (cg + 8 * i == own_cl) {
+                if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(newv + dq * 8);
+                else { vreg[i].x = *reinterpret_cast<const uint32_t *>(newv + dq * 4); vreg[i].y = 0; }
+            }
+        }
+    }
     if (TK != T_F16) {   // q8_0 of the rotated q: 4 values per thread, 8-lane groups
         for (int e0 = tid * 4; e0 < R * D; e0 += 1024) {
             const float4 v4 = *reinterpret_cast<const float4 *>(qf + e0);
@@ -709,6 +781,72 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
         dst[d] = s;
         if (d == 0) { dst[D] = ml[2 * r]; dst[D + 1] = ml[2 * r + 1]; }
     }
+    if (!FUSED) return;
+    if (fz.counters == nullptr) return;               // store-fused only: the merge runs as its own launch
+
+    // ---- FUSED: ticket; the last workgroup of this kv head merges
+    const int splits = a.splits;
+    __threadfence();                                   // release: this thread's partials are visible device-wide
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(fz.counters + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (old == (unsigned)splits - 1u) ? 1 : 0;
+        if (last_flag) __hip_atomic_store(fz.counters + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();                                   // acquire side
+    float *wgt = S;                                    // [R][64] split weights (S is free now: R * C floats)
+    float *merged = accs;                              // [R * D]
+    for (int r = wave; r < R; r += 4) {                // same arithmetic as flash_attn_combine_kernel
+        const float *p = a.part + ((size_t)g * R + r) * splits * (D + 2);
+        float m = -INFINITY, l = 0.0f;
+        if (lane < splits) {
+            m = __hip_atomic_load(p + (size_t)lane * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l = __hip_atomic_load(p + (size_t)lane * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float M = wave_max(m);
+        const float w = (lane < splits && m != -INFINITY) ? expf(m - M) : 0.0f;
+        const float den = wave_sum(w * l);
+        const float inv = 1.0f / den;
+        wgt[r * 64 + lane] = w * inv;
+    }
+    __syncthreads();
+    const int E = H * D;
+    for (int e = tid; e < R * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        const float *p = a.part + ((size_t)g * R + r) * splits * (D + 2) + d;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int s2 = 0; s2 < splits; s2++)
+            acc += wgt[r * 64 + s2] * __hip_atomic_load(p + (size_t)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        merged[e] = acc;
+        a.out[(size_t)g * R * D + e] = acc;
+    }
+    __syncthreads();
+    constexpr int NBLK = (R * D) >> 8;                 // 256-blocks this kv head owns in the H*D row
+    if (wave < NBLK && (fz.want_q8k || fz.want_q80)) {
+        for (int b = wave; b < NBLK; b += 4) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(merged + b * 256 + lane * 4);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            const int gb = ((g * R * D) >> 8) + b;     // global block index
+            const int e0 = gb * 256 + lane * 4;
+            if (fz.want_q8k) {
+                uint32_t packed; int bs; float dq8;
+                wave_quant_q8k(vv, lane, packed, bs, dq8);
+                *reinterpret_cast<uint32_t *>(fz.q.qs + e0) = packed;
+                if ((lane & 3) == 0) fz.q.bsums[gb * 16 + (lane >> 2)] = (int16_t)bs;
+                if (lane == 0) fz.q.d[gb] = dq8;
+            }
+            if (fz.want_q80) {
+                uint32_t packed; float dd;
+                wave_quant_q80(vv, packed, dd);
+                *reinterpret_cast<uint32_t *>(fz.q.qs0 + e0) = packed;
+                if ((lane & 7) == 0) fz.q.d0[gb * 8 + (lane >> 3)] = f2h(dd);
+            }
+        }
+    }
+    (void)E;
 }
 
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
@@ -722,7 +860,8 @@ int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 6
 hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st) {
     const int R = a.H / a.G;
     const dim3 grid(a.G, a.splits, a.T);
-#define FAD(RR, TK, TV) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot)
+    const DecodeFuse nofz{};
+#define FAD(RR, TK, TV) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, false>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz)
 #define FAD_T(RR)                                                              \
     if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
@@ -744,6 +883,41 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     if (a.out_q) qq = *a.out_q;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
                        qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
+    return hipGetLastError();
+}
+
+// Single-token step in ONE launch: K rope + KV store + attention + split merge + quantise (see DecodeFuse).
+bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra) {
+    const int R = a.H / a.G;
+    return a.T == 1 && flash_attn_decode_applicable(a, ra) && (R == 2 || R == 4 || R == 8) && (ra.n_rot % 4) == 0 && a.splits <= 64;
+}
+hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew,
+                                          const int32_t *tok_cell, unsigned *counters, hipStream_t st) {
+    const int R = a.H / a.G;
+    const dim3 grid(a.G, a.splits, 1);
+    DecodeFuse fz{};
+    fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters;
+    if (a.out_q) fz.q = *a.out_q;
+    fz.want_q8k = (int)(a.out_q && a.out_q8k); fz.want_q80 = (int)(a.out_q && a.out_q80);
+#define FAD(RR, TK, TV) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz)
+#define FAD_T(RR)                                                              \
+    if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
+    else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
+    else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
+    else FAD(RR, T_F16, T_Q8_0);
+    switch (R) {
+        case 2: FAD_T(2) break;
+        case 4: FAD_T(4) break;
+        case 8: FAD_T(8) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef FAD_T
+#undef FAD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || counters) return e;
+    const int nblk = (a.H * a.D) >> 8;
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, 1), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+                       fz.q, fz.want_q8k, fz.want_q80);
     return hipGetLastError();
 }
 

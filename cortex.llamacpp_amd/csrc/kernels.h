@@ -51,6 +51,7 @@ struct MMVQArgs {
 
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);
 // single-token fast path (mmvq_fast.hip): persistent, software-pipelined; K % 2048 == 0, K-quant types
+void mmvq_fast_set_threads(int nt);
 bool mmvq_fast_applicable(const MMVQArgs &a);
 hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st);
 hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_t st);
@@ -139,6 +140,10 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra);
 int flash_attn_decode_splits(int n_kv_max);
 hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st);
+// one launch per layer for a single-token step: KV store + attention + split merge + quantise (a.splits set by the caller)
+bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra);
+hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew,
+                                          const int32_t *tok_cell, unsigned *counters, hipStream_t st);
 bool kv_store_fast_applicable(int G, int D, int type_k, int type_v, const RopeArgs &ra);
 hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, int D, const float *cs_table, RopeArgs ra,
                                 const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);

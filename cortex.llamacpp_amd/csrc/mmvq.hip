@@ -15,6 +15,7 @@
 //  * integer work is v_dot4_i32_i8; integer partial sums are exactly the CPU backend's, only the final
 //    f32 summation order differs (lane partials are reduced with a wave butterfly).
 //  * epilogues fuse the residual add (attn_output / ffn_down) and SwiGLU (ffn_gate + ffn_up).
+#include <cstdlib>
 #include "kernels.h"
 #include "quant_dev.h"
 
@@ -659,6 +660,8 @@ static void launch_nt(const MMVQArgs &a, int blocks, int bs, size_t lds, hipStre
 // host launcher: a.T tokens (1, 2 or 4 per launch; larger T is chunked by the caller).
 // EPI_SWIGLU: seg[0] = ffn_gate, seg[1] = ffn_up (same type), out = silu(gate) * up into seg[0].out.
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
+    static const bool fast_init = (mmvq_fast_set_threads(getenv("MI355_MMVQ_NT") ? atoi(getenv("MI355_MMVQ_NT")) : 0), true);
+    (void)fast_init;
     if (mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
     if ((a.T == 16 || a.T == 8) && a.fuse_mode == 0) {
         bool moe = false;

@@ -18,16 +18,15 @@ namespace mi355 {
 namespace {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ldw(const void *p) {   // weight stream: non-temporal
-    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
+__device__ __forceinline__ u32x4_t ldw(const void *p) {   // weight stream: non-temporal
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
 }
-__device__ __forceinline__ uint4 lds16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ u32x4_t lds16(const void *p) { return *reinterpret_cast<const u32x4_t *>(p); }
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
 // activation slice one lane needs for one pass (8 super-blocks per wave, lane -> (sb, 16-code piece))
 struct ActSlice {
-    uint4 lo, hi;      // 16 + 16 int8 codes
+    u32x4_t lo, hi;      // 16 + 16 int8 codes
     float yd;          // Q8_K block scale
     int bs_lo, bs_hi;  // sums of the two 16-code groups
 };
@@ -44,12 +43,13 @@ template <int TYPE> struct Raw;
 
 // ---------------------------------------------------------------- Q4_K
 template <> struct Raw<T_Q4_K> {
-    uint4 hdr, q;
+    u32x4_t hdr, q;
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
         const uint8_t *b = row + (size_t)sb * 144;
         hdr = ldw(b);
         q = ldw(b + 16 + L.v * 16);
     }
+    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ hdr.y ^ hdr.z ^ hdr.w ^ q.x ^ q.y ^ q.z ^ q.w); }
     __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
         const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
         const uint32_t a16 = (hdr.y >> L.sh) & 0xffff, b16 = (hdr.z >> L.sh) & 0xffff, c16 = (hdr.w >> L.sh) & 0xffff;
@@ -68,7 +68,8 @@ template <> struct Raw<T_Q4_K> {
 
 // ---------------------------------------------------------------- Q5_K
 template <> struct Raw<T_Q5_K> {
-    uint4 hdr, qh, q;
+    u32x4_t hdr, qh, q;
+    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ qh.x ^ q.x ^ q.y ^ q.z ^ q.w); }
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
         const uint8_t *b = row + (size_t)sb * 176;
         hdr = ldw(b);
@@ -98,9 +99,10 @@ template <> struct Raw<T_Q5_K> {
 
 // ---------------------------------------------------------------- Q6_K (device row planes: ql | qh | scales | d)
 template <> struct Raw<T_Q6_K> {
-    uint4 ql, qh;
+    u32x4_t ql, qh;
     int sc_lo, sc_hi;
     uint32_t dh16;
+    __device__ __forceinline__ float probe() const { return (float)(ql.x ^ ql.y ^ ql.z ^ ql.w ^ qh.x ^ qh.y ^ qh.z ^ qh.w ^ (uint32_t)sc_lo ^ (uint32_t)sc_hi ^ dh16); }
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
         ql = ldw(row + (size_t)sb * 128 + L.v * 16);
         qh = ldw(row + (size_t)nb * 128 + (size_t)sb * 64 + L.n * 32 + (L.w & 1) * 16);
@@ -155,60 +157,115 @@ __device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const Lane
     return s;
 }
 
-// stage the activation (Q8_K planes) into LDS: copy (fuse_mode 0) or RMSNorm*w + quantise / quantise (1 / 2)
-__device__ __forceinline__ ActL stage_q8k(const MMVQArgs &a, uint8_t *smem) {
-    const int K = a.K, tid = threadIdx.x;
+// ---- activation of the token.  Three ways in, chosen per launch (all wave-uniform):
+//   direct : fuse_mode 0 and K <= 4096 -> each lane loads its own two slices straight from the Q8_K planes in global
+//            memory (L2/L1 hits) into registers: no LDS, no barrier;
+//   copy   : fuse_mode 0, longer K      -> the planes are copied to LDS once per workgroup;
+//   fused  : fuse_mode 1 / 2            -> RMSNorm * w and / or the Q8_K quantisation happen here, result in LDS.
+// Global loads are always ISSUED before the first weight loads and CONSUMED after them: memory returns in order, so
+// waiting for activations that were requested after the weights would also wait for the weights (the first version did
+// exactly that, and its conditional register array went through scratch: 2-6 us per launch, tools/bench_mmvq.hip).
+template <int TYPE>
+__device__ __forceinline__ ActSlice global_slice(const MMVQArgs &a, int sb, const LaneRole &L) {
+    ActSlice s;
+    if (TYPE == T_Q6_K) {
+        const int8_t *q = a.aq + sb * 256 + 128 * L.n + 16 * L.w;
+        s.lo = *reinterpret_cast<const u32x4_t *>(q); s.hi = *reinterpret_cast<const u32x4_t *>(q + 64);
+        const int16_t *b = a.abs + sb * 16 + 8 * L.n + L.w;
+        s.bs_lo = b[0]; s.bs_hi = b[4];
+    } else {
+        const int8_t *q = a.aq + sb * 256 + 64 * L.c + 16 * L.h;
+        s.lo = *reinterpret_cast<const u32x4_t *>(q); s.hi = *reinterpret_cast<const u32x4_t *>(q + 32);
+        const int16_t *b = a.abs + sb * 16 + 4 * L.c + L.h;
+        s.bs_lo = b[0]; s.bs_hi = b[2];
+    }
+    s.yd = a.ad[sb];
+    return s;
+}
+
+template <int KB, int NT> struct StageDims {
+    static constexpr int NW = NT / 64;
+    static constexpr int N16 = KB * 128, NQ = (N16 + NT - 1) / NT;      // u32x4_t words of the code plane, per thread
+    static constexpr int NB32 = (KB * 64 + NT - 1) / NT;                // bsums as 32-bit words, per thread
+    static constexpr int NJW = (KB * 8 + NW - 1) / NW;                  // fused: 256-blocks per wave (wave w owns blocks w, w + NW, ..)
+};
+// the staged values travel in plain local arrays of NATIVE vector types (statically indexed after unrolling, so they stay
+// in registers; arrays of HIP's u32x4_t class under a conditional were placed in scratch by hipcc)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define STAGE_REGS_DECL(KB, NT) u32x4_t sq_[StageDims<KB, NT>::NQ]; uint32_t sb_[StageDims<KB, NT>::NB32]; float sdv_ = 0.0f; \
+                                f32x4_t sxv_[StageDims<KB, NT>::NJW], swv_[StageDims<KB, NT>::NJW]
+#define STAGE_REGS_ARGS sq_, sb_, sdv_, sxv_, swv_
+
+template <int KB, int NT, int FUSE>
+__device__ __forceinline__ void stage_issue(const MMVQArgs &a, u32x4_t (&rq)[StageDims<KB, NT>::NQ], uint32_t (&rb)[StageDims<KB, NT>::NB32], float &rdv,
+                                            f32x4_t (&rxv)[StageDims<KB, NT>::NJW], f32x4_t (&rwv)[StageDims<KB, NT>::NJW]) {
+    using S = StageDims<KB, NT>;
+    const int tid = threadIdx.x;
+    if (FUSE == 0) {
+        const u32x4_t *src = reinterpret_cast<const u32x4_t *>(a.aq);
+#pragma unroll
+        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; rq[j] = src[i < S::N16 ? i : S::N16 - 1]; }
+        const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(a.abs);
+#pragma unroll
+        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; rb[j] = bsrc[i < KB * 64 ? i : KB * 64 - 1]; }
+        rdv = a.ad[tid < KB * 8 ? tid : KB * 8 - 1];
+    } else {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < S::NJW; j++) {
+            const int b = wave + S::NW * j;
+            const int bc = b < KB * 8 ? b : KB * 8 - 1;            // clamped: always a valid address, result unused when b is out of range
+            rxv[j] = *reinterpret_cast<const f32x4_t *>(a.nx + bc * 256 + lane * 4);
+            if (FUSE == 1) rwv[j] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
+        }
+    }
+}
+
+template <int KB, int NT, int FUSE>
+__device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&rq)[StageDims<KB, NT>::NQ], const uint32_t (&rb)[StageDims<KB, NT>::NB32], float rdv,
+                                             const f32x4_t (&rxv)[StageDims<KB, NT>::NJW], const f32x4_t (&rwv)[StageDims<KB, NT>::NJW], uint8_t *smem) {
+    using S = StageDims<KB, NT>;
+    constexpr int K = KB * 2048;
+    const int tid = threadIdx.x;
     int8_t *qs = reinterpret_cast<int8_t *>(smem);
     float *d = reinterpret_cast<float *>(smem + K);
     int16_t *bs = reinterpret_cast<int16_t *>(smem + K + (((K >> 8) * 4 + 15) & ~15));
-    if (a.fuse_mode == 0) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.aq);
-        uint4 t[4];
-        for (int i0 = 0; i0 < K / 16; i0 += 1024) {      // all loads of a sweep issued before any LDS write
+    if (FUSE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const int i = i0 + j * 256 + tid; if (i < K / 16) t[j] = src[i]; }
+        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; if (i < S::N16) reinterpret_cast<u32x4_t *>(qs)[i] = rq[j]; }
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const int i = i0 + j * 256 + tid; if (i < K / 16) reinterpret_cast<uint4 *>(qs)[i] = t[j]; }
-        }
-        for (int i = tid; i < (K >> 8); i += 256) d[i] = a.ad[i];
-        const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(a.abs);
-        for (int i = tid; i < (K >> 5); i += 256) reinterpret_cast<uint32_t *>(bs)[i] = bsrc[i];
+        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; if (i < KB * 64) reinterpret_cast<uint32_t *>(bs)[i] = rb[j]; }
+        if (tid < KB * 8) d[tid] = rdv;
     } else {
         double *red = reinterpret_cast<double *>(smem + a.red_off);
         const int lane = tid & 63, wave = tid >> 6;
-        constexpr int MAXJ = 8;                  // K <= 8192
-        float4 xv[MAXJ], wv[MAXJ];
-        const int nj = K >> 10;
-#pragma unroll
-        for (int j = 0; j < MAXJ; j++)
-            if (j < nj) {
-                xv[j] = *reinterpret_cast<const float4 *>(a.nx + j * 1024 + tid * 4);
-                if (a.fuse_mode == 1) wv[j] = *reinterpret_cast<const float4 *>(a.nw + j * 1024 + tid * 4);
-            }
         float scale = 1.0f;
-        if (a.fuse_mode == 1) {
-            double s = 0.0;
+        if (FUSE == 1) {
+            double sum = 0.0;
 #pragma unroll
-            for (int j = 0; j < MAXJ; j++)
-                if (j < nj) {
-                    const float4 v = xv[j];
-                    s += (double)(v.x * v.x); s += (double)(v.y * v.y); s += (double)(v.z * v.z); s += (double)(v.w * v.w);
-                }
-            s = wave_sum(s);
-            if (lane == 0) red[wave] = s;
+            for (int j = 0; j < S::NJW; j++) {
+                const f32x4_t v = rxv[j];
+                double t = 0.0;
+                t += (double)(v.x * v.x); t += (double)(v.y * v.y); t += (double)(v.z * v.z); t += (double)(v.w * v.w);
+                if (wave + S::NW * j < KB * 8) sum += t;
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) red[wave] = sum;
             __syncthreads();
-            const double tot = red[0] + red[1] + red[2] + red[3];
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < S::NW; w++) tot += red[w];
             const float mean = (float)(tot / (double)K);
             scale = 1.0f / sqrtf(mean + a.neps);
         }
 #pragma unroll
-        for (int j = 0; j < MAXJ; j++) {
-            if (j >= nj) continue;
-            const int b = wave + 4 * j;
+        for (int j = 0; j < S::NJW; j++) {
+            const int b = wave + S::NW * j;
+            if (b >= KB * 8) continue;                             // wave-uniform
             const int e0 = b * 256 + lane * 4;
-            float4 v = xv[j];
-            if (a.fuse_mode == 1) {
-                const float4 ww = wv[j];
+            f32x4_t v = rxv[j];
+            if (FUSE == 1) {
+                const f32x4_t ww = rwv[j];
                 v.x = (v.x * scale) * ww.x; v.y = (v.y * scale) * ww.y; v.z = (v.z * scale) * ww.z; v.w = (v.w * scale) * ww.w;
             }
             const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -224,71 +281,87 @@ __device__ __forceinline__ ActL stage_q8k(const MMVQArgs &a, uint8_t *smem) {
     return A;
 }
 
-// One segment, persistent waves.  unit = (row pair, 2 passes); rows longer than 2 passes are walked chunk by chunk.
-template <int TYPE, bool ACT_REGS>
+// One segment, persistent waves.  A unit is (row pair, PPU passes): PPU = 2 for an even number of passes, 1 otherwise,
+// so that every unit has the same shape and its loads need no condition.  NSETS units (8 Raw blocks in all) are always
+// in flight ahead of the one being decoded.
+//
+// Control flow matters for the memory pipeline: hipcc derives each s_waitcnt vmcnt(N) from the loads issued since, and
+// where a load sits under a condition it must assume the path WITHOUT it (N = 0: wait for everything, including what
+// was just requested).  So everything from the first activation load to the end of the steady-state loop is straight-
+// line: the staging mode is a template parameter, the first NSETS units are loaded unconditionally (waves with fewer
+// units read one shared dummy block that stays in L2), and only the drain after the loop loads under conditions.
+template <int TYPE, int KB, int NT, int FUSE>
 __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int gw, int nw) {
     using R = Raw<TYPE>;
+    constexpr bool ACT_REGS = KB <= 2;
+    constexpr bool DIRECT = ACT_REGS && FUSE == 0;
+    constexpr int nb = KB * 8;
+    constexpr int PPU = (KB % 2 == 0) ? 2 : 1;          // passes per unit
+    constexpr int NCH = KB / PPU;                       // units per row pair
+    constexpr int NSETS = 4 / PPU;                      // register sets in the ring (2 rows x PPU passes each)
     const int lane = threadIdx.x & 63;
     const LaneRole L = make_role<TYPE>(lane);
-    const int K = a.K, nb = K >> 8;
     const bool swiglu = a.epi == EPI_SWIGLU;
     const uint8_t *W0 = sg.W + (sg.expert_sel ? (size_t)sg.expert_sel[0] * sg.expert_stride : 0);
     const MMVQSeg &ug = a.seg[1];
-    const uint8_t *W1 = swiglu ? ug.W + (ug.expert_sel ? (size_t)ug.expert_sel[0] * ug.expert_stride : 0) : nullptr;
+    const uint8_t *W1 = swiglu ? ug.W + (ug.expert_sel ? (size_t)ug.expert_sel[0] * ug.expert_stride : 0) : W0;
     const size_t rb0 = sg.row_bytes, rb1 = swiglu ? ug.row_bytes : sg.row_bytes;
-    const int npass = nb >> 3;                    // K % 2048 == 0
-    const int nchunk = (npass + 1) >> 1;
     const int npairs = swiglu ? sg.n_rows : (sg.n_rows + 1) >> 1;
+    const int my_pairs = gw < npairs ? (npairs - gw + nw - 1) / nw : 0;
+    const int n_units = my_pairs * NCH;                 // unit u: pair = gw + (u / NCH) * nw, chunk = u % NCH
 
-    auto rows_of = [&](int pair, const uint8_t *&ra, const uint8_t *&rbp) {
+    // ---- 1. activation loads first
+    ActSlice S0, S1;                                    // K <= 4096: this lane's slices of pass 0 / pass 1, kept in registers
+    STAGE_REGS_DECL(KB, NT);
+    if (DIRECT) {
+        S0 = global_slice<TYPE>(a, L.sbl, L);
+        if (KB > 1) S1 = global_slice<TYPE>(a, 8 + L.sbl, L);
+    } else {
+        stage_issue<KB, NT, FUSE>(a, STAGE_REGS_ARGS);
+    }
+
+    // ---- 2. weights
+    R W[NSETS][2 * PPU];                                // statically indexed after unrolling
+    auto load_unit = [&](int u, R (&w)[2 * PPU], bool real) {
+        const int pi = u / NCH, ch = u - pi * NCH;
+        const int pair = gw + pi * nw;
+        const uint8_t *ra, *rbp;
         if (swiglu) { ra = W0 + (size_t)pair * rb0; rbp = W1 + (size_t)pair * rb1; }
         else {
             ra = W0 + (size_t)(2 * pair) * rb0;
-            rbp = (2 * pair + 1 < sg.n_rows) ? ra + rb0 : ra;   // odd tail: row b re-reads row a, result discarded
+            rbp = (2 * pair + 1 < sg.n_rows) ? ra + rb0 : ra;       // odd tail: row b re-reads row a, result discarded
+        }
+        int sb0 = ch * PPU * 8 + L.sbl;
+        if (!real) { ra = W0; rbp = W0; sb0 = L.sbl; }              // nothing to fetch: everybody's dummy is row 0, pass 0
+#pragma unroll
+        for (int p = 0; p < PPU; p++) {
+            w[2 * p].load(ra, nb, sb0 + 8 * p, L);
+            w[2 * p + 1].load(rbp, nb, sb0 + 8 * p, L);
         }
     };
-    // unit u of this wave: pair = gw + (u / nchunk) * nw, chunk = u % nchunk
-    const int my_pairs = gw < npairs ? (npairs - gw + nw - 1) / nw : 0;
-    const int n_units = my_pairs * nchunk;
+#pragma unroll
+    for (int s = 0; s < NSETS; s++) load_unit(s, W[s], s < n_units);
 
-    R A0, A1, A2, A3, B0, B1, B2, B3;             // two statically named register sets
-    auto load_unit = [&](int u, R &r0, R &r1, R &r2, R &r3) {
-        const int pi = u / nchunk, ch = u - pi * nchunk;
-        const uint8_t *ra, *rbp;
-        rows_of(gw + pi * nw, ra, rbp);
-        const int p0 = 2 * ch;
-        const int sb0 = p0 * 8 + L.sbl;
-        r0.load(ra, nb, sb0, L);
-        r1.load(rbp, nb, sb0, L);
-        if (p0 + 1 < npass) {                       // wave-uniform
-            r2.load(ra, nb, sb0 + 8, L);
-            r3.load(rbp, nb, sb0 + 8, L);
+    // ---- 3. activations into place (workgroup barrier inside the LDS paths: reached by every wave)
+    ActL AL{nullptr, nullptr, nullptr};
+    if (!DIRECT) {
+        AL = stage_finish<KB, NT, FUSE>(a, STAGE_REGS_ARGS, smem);
+        if (ACT_REGS) {
+            S0 = read_slice<TYPE>(AL, L.sbl, L);
+            if (KB > 1) S1 = read_slice<TYPE>(AL, 8 + L.sbl, L);
         }
-    };
-    if (n_units > 0) load_unit(0, A0, A1, A2, A3);
-
-    const ActL AL = stage_q8k(a, smem);             // workgroup barrier inside: reached by every wave
-    ActSlice S0, S1;                                 // K <= 4096: this lane's slices of pass 0 / pass 1, kept in registers
-    if (ACT_REGS) {
-        S0 = read_slice<TYPE>(AL, L.sbl, L);
-        if (npass > 1) S1 = read_slice<TYPE>(AL, 8 + L.sbl, L);
     }
 
     float acc0 = 0.0f, acc1 = 0.0f;
-    auto compute_unit = [&](int u, const R &r0, const R &r1, const R &r2, const R &r3) {
-        const int pi = u / nchunk, ch = u - pi * nchunk;
-        const int p0 = 2 * ch;
-        {
-            const ActSlice s = ACT_REGS ? S0 : read_slice<TYPE>(AL, p0 * 8 + L.sbl, L);
-            acc0 += r0.dot(s, L);
-            acc1 += r1.dot(s, L);
+    auto compute_unit = [&](int u, const R (&w)[2 * PPU]) {
+        const int pi = u / NCH, ch = u - pi * NCH;
+#pragma unroll
+        for (int p = 0; p < PPU; p++) {
+            const ActSlice sl = ACT_REGS ? (ch * PPU + p == 0 ? S0 : S1) : read_slice<TYPE>(AL, (ch * PPU + p) * 8 + L.sbl, L);
+            acc0 += w[2 * p].dot(sl, L);
+            acc1 += w[2 * p + 1].dot(sl, L);
         }
-        if (p0 + 1 < npass) {
-            const ActSlice s = ACT_REGS ? S1 : read_slice<TYPE>(AL, (p0 + 1) * 8 + L.sbl, L);
-            acc0 += r2.dot(s, L);
-            acc1 += r3.dot(s, L);
-        }
-        if (ch == nchunk - 1) {                      // pair finished
+        if (ch == NCH - 1) {                            // pair finished
             const float v0 = wave_sum(acc0), v1 = wave_sum(acc1);
             acc0 = 0.0f; acc1 = 0.0f;
             if (lane == 0) {
@@ -309,29 +382,44 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
             }
         }
     };
-    for (int u = 0; u < n_units; u += 2) {
-        if (u + 1 < n_units) load_unit(u + 1, B0, B1, B2, B3);
-        compute_unit(u, A0, A1, A2, A3);
-        if (u + 1 >= n_units) break;
-        if (u + 2 < n_units) load_unit(u + 2, A0, A1, A2, A3);
-        compute_unit(u + 1, B0, B1, B2, B3);
+    int u = 0;
+#pragma unroll 1
+    for (; u + 2 * NSETS <= n_units; u += NSETS) {       // steady state: every refill exists
+#pragma unroll
+        for (int s = 0; s < NSETS; s++) {
+            compute_unit(u + s, W[s]);
+            load_unit(u + NSETS + s, W[s], true);
+        }
     }
+    // drain: units u .. n_units-1 (fewer than 2 * NSETS); sets 0 .. NSETS-1 hold u .. u+NSETS-1
+#pragma unroll
+    for (int s = 0; s < NSETS; s++) {
+        if (u + s < n_units) {
+            compute_unit(u + s, W[s]);
+            if (u + NSETS + s < n_units) load_unit(u + NSETS + s, W[s], true);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSETS; s++)
+        if (u + NSETS + s < n_units) compute_unit(u + NSETS + s, W[s]);
 }
 
-template <bool ACT_REGS>
-__global__ __launch_bounds__(256, 3) void mmvq_fast_kernel(const MMVQArgs a) {
+// NT threads per workgroup, ONE workgroup per CU (the activation is staged / normalised / quantised once per CU)
+template <int KB, int NT, int FUSE>
+__global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NW = NT / 64;
     int s = 0;
     if (a.n_seg > 1 && (int)blockIdx.x >= a.seg_block0[1]) s = 1;
     if (a.n_seg > 2 && (int)blockIdx.x >= a.seg_block0[2]) s = 2;
     const int nblk = a.seg_block0[s + 1] - a.seg_block0[s];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gw = ((int)blockIdx.x - a.seg_block0[s]) * 4 + wave;
-    const int nw = nblk * 4;
+    const int gw = ((int)blockIdx.x - a.seg_block0[s]) * NW + wave;
+    const int nw = nblk * NW;
     switch (a.seg[s].type) {
-        case T_Q4_K: run_fast<T_Q4_K, ACT_REGS>(a, a.seg[s], smem, gw, nw); break;
-        case T_Q5_K: run_fast<T_Q5_K, ACT_REGS>(a, a.seg[s], smem, gw, nw); break;
-        case T_Q6_K: run_fast<T_Q6_K, ACT_REGS>(a, a.seg[s], smem, gw, nw); break;
+        case T_Q4_K: run_fast<T_Q4_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw); break;
+        case T_Q5_K: run_fast<T_Q5_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw); break;
+        case T_Q6_K: run_fast<T_Q6_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw); break;
         default: break;
     }
 }
@@ -340,38 +428,41 @@ __global__ __launch_bounds__(256, 3) void mmvq_fast_kernel(const MMVQArgs a) {
 
 bool mmvq_fast_applicable(const MMVQArgs &a) {
     if (a.T != 1 || (a.K % 2048) != 0) return false;
+    const int kb = a.K >> 11;
+    if (kb != 1 && kb != 2 && kb != 4 && kb != 7 && kb != 14) return false;
     const int n = a.epi == EPI_SWIGLU ? 2 : a.n_seg;
     for (int s = 0; s < n; s++)
         if (a.seg[s].type != T_Q4_K && a.seg[s].type != T_Q5_K && a.seg[s].type != T_Q6_K) return false;
-    if (a.fuse_mode != 0 && (a.K > 8192 || (a.K & 1023))) return false;
+    if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;
+    if (a.fuse_mode == 1 && a.K > 8192) return false;          // RMSNorm + quantise: the hidden size; quantise-only (2): any listed K
     return true;
 }
+
+static int g_fast_nt = 0;     // 0 = pick per launch; tools/bench_mmvq.hip forces 512 / 768 to compare
+void mmvq_fast_set_threads(int nt) { g_fast_nt = (nt == 512 || nt == 768) ? nt : 0; }
 
 hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
     if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
     const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
-    // persistent grid: k workgroups per CU (k <= 3, launch bound 3 waves / SIMD); pick the k whose unit count per wave
-    // divides most evenly (e.g. 14336 pairs over 2 x 256 x 4 waves = exactly 7 units each), ties -> larger k
-    int total_pairs_all = 0, nchunk_all = 1;
-    for (int s = 0; s < (a.epi == EPI_SWIGLU ? 1 : a.n_seg); s++) total_pairs_all += a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
-    nchunk_all = ((a.K >> 11) + 1) >> 1;
-    int best_k = 3;
-    double best_cost = 1e30;
-    for (int k = 3; k >= 1; k--) {
-        const long waves = (long)num_cu() * k * 4;
-        const long rounds = (total_pairs_all + waves - 1) / waves;          // pairs per wave, rounded up
-        // time ~ rounds * chunks-per-pair, with fewer resident waves costing a little latency hiding
-        const double cost = (double)rounds * nchunk_all * (k == 3 ? 1.0 : k == 2 ? 1.04 : 1.15);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best_k = k; }
-    }
-    const int max_blocks = num_cu() * best_k;
+    const int kb = a.K >> 11;
+    // persistent grid, one workgroup per CU: 12 waves (768 threads) when the registers allow it (K <= 4096), else 8;
+    // between the two, pick the one whose unit count per wave divides most evenly (e.g. 14336 pairs over 256 x 8
+    // waves = exactly 7 each), fewer resident waves costing a little latency hiding
+    int total_pairs_all = 0;
+    for (int s = 0; s < n_work_seg; s++) total_pairs_all += a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
+    // 8 waves per CU measured better than 12 on the whole decode step (tools/profile_decode.py: 2.05 vs 2.13 ms / token);
+    // MI355_MMVQ_NT=768 selects the 12-wave form for K <= 4096
+    int nt = 512;
+    if (kb <= 2 && g_fast_nt == 768) nt = 768;
+    const int nwv = nt / 64;
+    const int max_blocks = num_cu();
     size_t bytes[3] = {0, 0, 0}, total = 0;
     int want[3] = {0, 0, 0}, sum_want = 0;
     for (int s = 0; s < n_work_seg; s++) {
         bytes[s] = (size_t)a.seg[s].n_rows * a.seg[s].row_bytes;
         total += bytes[s];
         const int pairs = a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
-        want[s] = (pairs + 3) / 4;
+        want[s] = (pairs + nwv - 1) / nwv;
         sum_want += want[s];
     }
     a.seg_block0[0] = 0;
@@ -391,9 +482,19 @@ hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
     size_t lds = K + (((K >> 8) * 4 + 15) & ~(size_t)15) + (((K >> 4) * 2 + 15) & ~(size_t)15);
     lds = (lds + 15) & ~(size_t)15;
     a.red_off = (int)lds;
-    lds += 64;
-    if (a.K <= 4096) hipLaunchKernelGGL(mmvq_fast_kernel<true>, dim3(blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(mmvq_fast_kernel<false>, dim3(blocks), dim3(256), lds, st, a);
+    lds += 128;
+#define FAST(KBV, NTV, FZ) hipLaunchKernelGGL((mmvq_fast_kernel<KBV, NTV, FZ>), dim3(blocks), dim3(NTV), lds, st, a)
+#define FAST_F(KBV, NTV) do { if (a.fuse_mode == 0) FAST(KBV, NTV, 0); else if (a.fuse_mode == 1) FAST(KBV, NTV, 1); else FAST(KBV, NTV, 2); } while (0)
+    switch (kb) {
+        case 1: if (nt == 768) FAST_F(1, 768); else FAST_F(1, 512); break;
+        case 2: if (nt == 768) FAST_F(2, 768); else FAST_F(2, 512); break;
+        case 4: FAST_F(4, 512); break;
+        case 7: if (a.fuse_mode == 2) FAST(7, 512, 2); else FAST(7, 512, 0); break;
+        case 14: if (a.fuse_mode == 2) FAST(14, 512, 2); else FAST(14, 512, 0); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef FAST_F
+#undef FAST
     return hipGetLastError();
 }
 

@@ -10,19 +10,16 @@ namespace mi355 {
 // Q8_K: iscale = -127 / (signed value of the FIRST element with the largest magnitude); codes = min(127, rint(iscale*x));
 // d = 1/iscale; bsum16 = sum of the 16-element group this lane belongs to (valid on every lane).
 __device__ __forceinline__ void wave_quant_q8k(const float (&vv)[4], int lane, uint32_t &packed, int &bsum16, float &d) {
-    unsigned long long key = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned long long k = ((unsigned long long)__float_as_uint(fabsf(vv[i])) << 32) |
-                                     (unsigned long long)(0xffffffffu - (unsigned)(lane * 4 + i));
-        key = k > key ? k : key;
-    }
-    key = wave_max_u64(key);
-    const float amax = __uint_as_float((unsigned)(key >> 32));
-    const int imax = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-    const int isel = imax & 3;
-    const float vsrc = isel == 0 ? vv[0] : isel == 1 ? vv[1] : isel == 2 ? vv[2] : vv[3];
-    const float vmax = __shfl(vsrc, imax >> 2, 64);
+    // largest magnitude of the block (f32 max over the wave), then the FIRST element holding it: lowest lane whose own
+    // first match exists (ballot + find-first-set), its value fetched with one v_readlane
+    const float a0 = fabsf(vv[0]), a1 = fabsf(vv[1]), a2 = fabsf(vv[2]), a3 = fabsf(vv[3]);
+    const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+    const float vsrc = m0 ? vv[0] : m1 ? vv[1] : m2 ? vv[2] : vv[3];
+    const unsigned long long hit = __ballot(m0 || m1 || m2 || m3);
+    const int src_lane = hit ? __builtin_ctzll(hit) : 0;
+    const float vmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vsrc), src_lane));
+    (void)lane;
     int qi[4] = {0, 0, 0, 0};
     d = 0.0f;
     if (amax != 0.0f) {

@@ -310,7 +310,9 @@ bool Context::init(std::string &err) {
     }
     ws = std::max(ws, flash_attn_workspace_floats(std::min<int>((int)T, 8), hp.n_head, (int)D, flash_attn_decode_splits((int)NC)));
     att_part_ = (float *)dalloc(ws * 4);
-    if (!att_part_) { err = "attention workspace allocation failed"; return false; }
+    att_counters_ = (unsigned *)dalloc(256 * sizeof(unsigned));
+    if (!att_part_ || !att_counters_) { err = "attention workspace allocation failed"; return false; }
+    if (hipMemset(att_counters_, 0, 256 * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
     argmax_scratch_ = (float *)dalloc(T * 128 * 4);
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
@@ -546,11 +548,17 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         const bool o_q = is_quant(L.wo.type);
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
         if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
-            // decode-step path: K rope + KV store in one small kernel; q is rotated inside the attention kernel
-            HIP_TRY(launch_kv_store_fast(k_, v_, T, G, D, rope_cs_, ra, d_cell_, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
-            prof_mark("rope_kv");
             aa.splits = flash_attn_decode_splits(n_kv_max);
-            HIP_TRY(launch_flash_attn_decode(aa, rope_cs_, ra, stream_));
+            static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 1;
+            if (attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra)) {
+                // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch
+                HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));
+            } else {
+                // small-batch step: K rope + KV store in one small kernel; q is rotated inside the attention kernel
+                HIP_TRY(launch_kv_store_fast(k_, v_, T, G, D, rope_cs_, ra, d_cell_, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
+                prof_mark("rope_kv");
+                HIP_TRY(launch_flash_attn_decode(aa, rope_cs_, ra, stream_));
+            }
         } else {
             HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
             prof_mark("rope_kv");
@@ -617,7 +625,10 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
             }
             prof_mark("ffn_gate_up");
-            const bool fuse_down = false;   // measured: the in-kernel quantise of a 14336-vector costs as much as the separate launch
+            static const bool fuse_down_env = !(getenv("MI355_FUSE_DOWN") && getenv("MI355_FUSE_DOWN")[0] == '0');
+            // quantise inside the down-projection's prologue (once per CU, overlapped with its first weight loads)
+            const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K) &&
+                                   (FF % 2048) == 0 && (FF / 2048 == 1 || FF / 2048 == 2 || FF / 2048 == 4 || FF / 2048 == 7 || FF / 2048 == 14);
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
             } else if (is_quant(L.down.type)) {

@@ -154,6 +154,7 @@ class Context {
     ActQuant aq_e_, aq_ff_, aq_o_;
     int8_t *mmq_bh_ = nullptr, *mmq_bl_ = nullptr;   // (hi, lo) planes of the 32-code block sums for the MFMA path
     float *att_part_ = nullptr;
+    unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;
     int att_splits_ = 1;

@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
             a.seg[s].n_rows = N; a.seg[s].ld_out = N; a.seg[s].row_bytes = rb;
         }
         a.aq = aq; a.ad = ad; a.abs = abs_; a.aq0 = aq; a.ad0 = ad0;
-        a.fuse_mode = fuse; a.nx = x; a.nw = nw; a.neps = 1e-5f;
+        a.fuse_mode = fuse; a.nx = x; a.nw = nw; a.neps = 1e-5f; a.nck = getenv("MI355_EXP") ? atoi(getenv("MI355_EXP")) : 0;
         hipError_t e = launch_mmvq(a, nullptr);
         if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
     };
@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
                 a.seg[s].n_rows = N; a.seg[s].ld_out = N; a.seg[s].row_bytes = rb;
             }
             a.aq = aq; a.ad = ad; a.abs = abs_; a.aq0 = aq; a.ad0 = ad0;
-            a.fuse_mode = fuse; a.nx = x; a.nw = nw; a.neps = 1e-5f;
+            a.fuse_mode = fuse; a.nx = x; a.nw = nw; a.neps = 1e-5f; a.nck = getenv("MI355_EXP") ? atoi(getenv("MI355_EXP")) : 0;
             launch_mmvq(a, st);
         };
         hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
