@@ -20,7 +20,7 @@ def lib_path() -> str:
 
 class ModelParams(C.Structure):
     _fields_ = [("n_gpu_layers", C.c_int32), ("main_gpu", C.c_int32), ("use_mmap", C.c_int32), ("use_mlock", C.c_int32),
-                ("tp_rank", C.c_int32), ("tp_size", C.c_int32)]
+                ("tp_rank", C.c_int32), ("tp_size", C.c_int32), ("prefill_planes", C.c_int32)]
 
 
 class ContextParams(C.Structure):
@@ -58,6 +58,8 @@ SYMBOLS = {
     "mi355_model_cpu_buffer": (_u64, [_vp]),
     "mi355_model_other_buffer": (_u64, [_vp]),
     "mi355_model_bytes_per_token": (_u64, [_vp]),
+    "mi355_model_planes_bytes": (_u64, [_vp]),
+    "mi355_debug_set_option": (C.c_int, [_cp, _i32]),
     "mi355_model_desc": (_cp, [_vp]),
     "mi355_model_meta_str": (C.c_int, [_vp, _cp, _cp, _sz]),
     "mi355_context_default_params": (ContextParams, []),
@@ -153,6 +155,9 @@ class Backend:
         if rc != 0:
             raise MI355Error(f"{what} failed ({rc}): {_err(self.lib)}")
 
+    def set_option(self, name: str, value: int) -> None:
+        self._chk(self.lib.mi355_debug_set_option(name.encode(), int(value)), f"set_option({name})")
+
     def system_info(self) -> str:
         return self.lib.mi355_print_system_info().decode()
 
@@ -234,11 +239,12 @@ class Backend:
 
 
 class Model:
-    def __init__(self, path: str, n_gpu_layers: int = 300, main_gpu: int = 0):
+    def __init__(self, path: str, n_gpu_layers: int = 300, main_gpu: int = 0, prefill_planes: int = -1):
         self.lib = load_library()
         mp = self.lib.mi355_model_default_params()
         mp.n_gpu_layers = n_gpu_layers
         mp.main_gpu = main_gpu
+        mp.prefill_planes = prefill_planes
         self.h = self.lib.mi355_model_load_from_file(path.encode(), mp)
         if not self.h:
             raise MI355Error(f"mi355_model_load_from_file({path}) failed: {_err(self.lib)}")
@@ -249,6 +255,7 @@ class Model:
         self.n_head = L.mi355_model_n_head(self.h)
         self.n_head_kv = L.mi355_model_n_head_kv(self.h)
         self.bytes_per_token = L.mi355_model_bytes_per_token(self.h)
+        self.planes_bytes = L.mi355_model_planes_bytes(self.h)
         self.size = L.mi355_model_size(self.h)
         self.vram = L.mi355_model_other_buffer(self.h)
         self.ram = L.mi355_model_cpu_buffer(self.h)

@@ -31,6 +31,7 @@ struct mi355_context {
 };
 
 static thread_local std::string t_err;
+static int g_op_mmq_planes = 1;
 static bool g_backend_ok = false;
 
 static void fail(const std::string &s) { t_err = s; }
@@ -76,7 +77,7 @@ const char *mi355_print_system_info(void) {
 
 mi355_model_params mi355_model_default_params(void) {
     mi355_model_params p{};
-    p.n_gpu_layers = 300; p.main_gpu = 0; p.use_mmap = 1; p.use_mlock = 0; p.tp_rank = 0; p.tp_size = 1;
+    p.n_gpu_layers = 300; p.main_gpu = 0; p.use_mmap = 1; p.use_mlock = 0; p.tp_rank = 0; p.tp_size = 1; p.prefill_planes = -1;
     return p;
 }
 
@@ -87,7 +88,7 @@ mi355_model *mi355_model_load_from_file(const char *path, mi355_model_params par
     if (params.tp_size > 1) { fail("tp_size > 1 is not available in this build"); return nullptr; }
     std::string err;
     int status = 0;
-    Model *m = model_load(path, params.main_gpu, err, status);
+    Model *m = model_load(path, params.main_gpu, err, status, params.prefill_planes);
     if (!m) { fail(err); return nullptr; }
     mi355_model *h = new mi355_model;
     h->m = m;
@@ -108,6 +109,7 @@ uint64_t mi355_model_size(const mi355_model *m) { return m->m->file_tensor_bytes
 uint64_t mi355_model_cpu_buffer(const mi355_model *m) { return m->m->host_bytes; }
 uint64_t mi355_model_other_buffer(const mi355_model *m) { return m->m->device_bytes; }
 uint64_t mi355_model_bytes_per_token(const mi355_model *m) { return m->m->bytes_per_token; }
+uint64_t mi355_model_planes_bytes(const mi355_model *m) { return m->m->planes_bytes; }
 const char *mi355_model_desc(const mi355_model *m) { return m->m->desc.c_str(); }
 int mi355_model_meta_str(const mi355_model *m, const char *key, char *buf, size_t buf_size) {
     if (!m || !key || !buf || !buf_size) return 0;
@@ -276,6 +278,13 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
             DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
             if (!bh.p || !bl.p) return MI355_ERR_OOM;
             e = launch_mmq_prep(ab.q, (int)K, (int)T, bh.as<int8_t>(), bl.as<int8_t>(), nullptr);
+            if (g_op_mmq_planes) {
+                DevBuf pl(mmq_planes_bytes(type, N, (int)K));
+                if (!pl.p) return MI355_ERR_OOM;
+                if (e == hipSuccess) e = launch_mmq_expand(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, pl.as<uint8_t>(), nullptr);
+                if (e == hipSuccess) e = launch_mmq_planes(type, pl.as<uint8_t>(), (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            } else
             if (e == hipSuccess) e = launch_mmq(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr);
             if (e == hipSuccess) e = hipDeviceSynchronize();
             if (e != hipSuccess) return hip_fail(e, "mmq");
@@ -442,6 +451,14 @@ int mi355_op_flash_attn(const float *q, int64_t T, int32_t H, int32_t G, int32_t
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return hip_fail(e, "flash_attn");
     return dout.down(out, (size_t)T * H * D * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
+int mi355_debug_set_option(const char *name, int32_t value) {
+    if (!name) return MI355_ERR_ARG;
+    if (!strcmp(name, "mmq_planes")) { g_op_mmq_planes = value != 0; return MI355_OK; }
+    if (!strcmp(name, "mmq_tiles")) { mmq_set_tiles(value); return MI355_OK; }
+    fail(std::string("unknown option ") + name);
+    return MI355_ERR_ARG;
 }
 
 // simple read-bandwidth probe: sum-reduce `bytes` of device memory

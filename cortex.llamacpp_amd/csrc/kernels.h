@@ -60,6 +60,12 @@ int num_cu();
 
 // ---------------------------------------------------------------- batched prefill contraction on MFMA (mmq.hip)
 bool mmq_applicable(int type, int K, int T);
+void mmq_set_tiles(int mt);                                // tools: force 1 / 2 / 4 token tiles per wave (0 = by T)
+// pre-expanded MFMA operand planes of a weight tensor (2 B / weight, built once at load; mmq.hip)
+size_t mmq_planes_bytes(int type, int64_t n_rows, int K);   // 0 if the type has no planes form
+hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *planes, hipStream_t st);
+hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
+                             float *out, int ld_out, const float *resid, hipStream_t st);
 size_t mmq_prep_bytes(int K, int T);                       // bytes of each of the two block-sum planes
 hipError_t launch_mmq_prep(const ActQuant &q, int K, int T, int8_t *bh, int8_t *bl, hipStream_t st);
 hipError_t launch_mmq(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,

@@ -3,17 +3,31 @@
 // Stands in for ggml's mul_mat_q / the CPU backend's chunked mul_mat for prompt processing,
 // reached from the reference through llama_decode with n_tokens > 1 (src/llama_server_context.cc:1568-1607, 1635).
 //
-// Integer-exact by construction: every 32-weight sub-block is ONE v_mfma_i32_32x32x32_i8 (int8 weights unpacked from
-// the 4/5/6-bit codes x int8 Q8_K activation codes -> int32), the 6-bit sub-block scales are applied to the int32
-// tile with 24-bit integer multiply-adds, and the Q4_K/Q5_K "mins" term  sum_j m_j * bsum_j  is two more small MFMAs on
-// the int16 block sums split into (hi, lo) int8 planes (bsum = 64*hi + lo).  So per (token, row, super-block) the
-// integers  isum = sum_j sc_j * (q . q8)  and  msum = sum_j m_j * bsum_j  are bit-identical to ggml_vec_dot_q*_K_q8_K;
-// only the final f32 accumulation order over super-blocks differs.
+// Integer-exact by construction, and MFMA-bound rather than VALU-bound:
+//   ggml_vec_dot_q{4,5,6}_K_q8_K computes, per (row, token, super-block of 256),   isum = sum_g sc_g * sum_{k in g} q_k a_k
+//   with 6-bit (Q4_K/Q5_K, groups of 32) or int8 (Q6_K, groups of 16) group scales sc_g.  Applying sc_g to the int32
+//   MFMA result costs one multiply-add per OUTPUT per group (16 VALU ops per MFMA — as long as the MFMA itself).  Here
+//   the scale is folded into the WEIGHT instead:  p_k = sc_g * q_k  (10..13 bits) is split into two int8 planes
+//   p_k = 2^S * hi_k + lo_k, and  isum = 2^S * (hi . a) + (lo . a)  is two MFMA accumulation chains over the whole
+//   super-block with nothing in between.  The split is exact, so isum is bit-identical to the CPU's integer.
+//   The expansion costs VALU work per WEIGHT (not per output) and is amortised over the wave's token tiles.
+//   * Q4_K / Q5_K: q in [0,15] / [0,31], sc in [0,63]: S = 5, hi <= 29 / 61, lo <= 31.  The "mins" term
+//     msum = sum_j m_j * bsum_j is one more pair of small MFMAs over the 16 per-16 block sums of Q8_K (m_j duplicated),
+//     the int16 sums split into int8 planes bsum = 64 * bh + bl by mmq_prep_kernel.
+//   * Q6_K: the unsigned code q in [0,63] times the signed int8 scale (16-bit signed lanes), S = 6, hi in [-128,126],
+//     lo in [0,63]; the "-32" of the code is the same small MFMA:  isum = 64 H + L - 32 * sum_g sc_g * bsum16_g.
+//     A lane's 16 weights of a K-step are exactly one 16-group, so the scale is a per-lane scalar.
+//   Only the final f32 accumulation order over super-blocks differs from the CPU.
 //
-// Tile mapping (wave64, 32x32x32): M = tokens, N = weight rows.  The MFMA result lane holds ONE weight row
-// (n = lane & 31) and 16 tokens, so the row's d / dmin / sub-block scales are per-lane scalars.  A workgroup = 8 waves
-// = 128 rows x 128 tokens; the activation tile of one super-block (128 x 256 int8, + block sums + scales) is staged in
-// LDS once per workgroup and read as MFMA A operands by all eight waves (4 row tiles x 2 token-tile pairs) (row stride padded against bank conflicts).
+// Tile mapping (wave64, v_mfma_i32_32x32x32_i8): M = tokens (A operand from LDS), N = weight rows (B operand built in
+// registers): lane = (row n = lane & 31, k-half kg = lane >> 5) holds its own row's 16 weights per K-step, so d / dmin /
+// scales are per-lane scalars and weights go global -> registers with no LDS round trip.  Workgroup = 8 waves:
+// RW row-waves x TW token-waves with MT token tiles of 32 per wave (MT = 4: 256 rows x 128 tokens; MT = 2: 128 x 128;
+// MT = 1: 256 rows x 32 tokens).  The activation tile of one super-block (tokens x 256 int8, + block-sum planes + scales) is
+// staged in LDS once per workgroup (row stride 272 B: ds_read_b128 conflict-free), the next tile's global loads are
+// issued before the MFMA work of the current one, and the raw weights of the next super-block likewise.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace mi355 {
@@ -22,285 +36,677 @@ namespace {
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TOK_TILE = 128, ROW_TILE = 128, A_STRIDE = 272;   // 256 codes + 16 B pad per token row
+constexpr int A_STRIDE = 272;          // 256 codes + 16 B pad per token row
+constexpr int NTHREADS = 512;
 
-__device__ __forceinline__ i32x4 as_i32x4(uint4 v) { i32x4 r; r.x = (int)v.x; r.y = (int)v.y; r.z = (int)v.z; r.w = (int)v.w; return r; }
 __device__ __forceinline__ i32x16 mfma_i8(i32x4 a, i32x4 b, i32x16 c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ uint4 ldg16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ u32x4 ldg16(const void *p) { return *reinterpret_cast<const u32x4 *>(p); }
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
-struct Smem {
-    int8_t *aq;        // [TOK_TILE][A_STRIDE]  codes of the current super-block
-    int8_t *bh, *bl;   // [TOK_TILE][8]         block-sum planes (hi, lo) of the 8 sub-blocks
-    float *yd;         // [TOK_TILE]            Q8_K scale of the super-block
-};
+// two int8 planes of  p = scale * code  for four codes held one per byte in `w` (codes < 64, 0 <= scale < 64 for the
+// unsigned form): even / odd bytes are multiplied as 16-bit lanes of one 32-bit product (no carry: p < 2^16)
+template <int S>
+__device__ __forceinline__ void planes_u(uint32_t w, uint32_t sc, uint32_t &hi, uint32_t &lo) {
+    constexpr uint32_t LM = ((1u << S) - 1u) * 0x00010001u;
+    const uint32_t pe = (w & 0x00ff00ffu) * sc;               // products of bytes 0, 2
+    const uint32_t po = ((w >> 8) & 0x00ff00ffu) * sc;        // products of bytes 1, 3
+    hi = ((pe >> S) & 0x00ff00ffu) | (((po >> S) & 0x00ff00ffu) << 8);
+    lo = (pe & LM) | ((po & LM) << 8);
+}
 
-// per-lane weight-row state of one super-block
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+// signed scale (int8, replicated in both 16-bit lanes of scpk): p = sc * code as 16-bit signed lanes, hi = p >> 6 (floor), lo = p & 63
+__device__ __forceinline__ void planes_s6(uint32_t w, uint32_t scpk, uint32_t &hi, uint32_t &lo) {
+    const i16x2 e = __builtin_bit_cast(i16x2, w & 0x00ff00ffu), o = __builtin_bit_cast(i16x2, (w >> 8) & 0x00ff00ffu);
+    const i16x2 s = __builtin_bit_cast(i16x2, scpk);
+    const i16x2 pe = e * s, po = o * s;                       // v_pk_mul_lo_u16: low 16 bits = the signed product
+    const i16x2 six = {6, 6};
+    const uint32_t he = __builtin_bit_cast(uint32_t, pe >> six), ho = __builtin_bit_cast(uint32_t, po >> six);   // v_pk_ashrrev_i16
+    const uint32_t le = __builtin_bit_cast(uint32_t, pe) & 0x003f003fu, lo_ = __builtin_bit_cast(uint32_t, po) & 0x003f003fu;
+    hi = (he & 0x00ff00ffu) | ((ho & 0x00ff00ffu) << 8);
+    lo = le | (lo_ << 8);
+}
+
+// the same for the signed Q6_K code (q - 32) in [-32, 31]
+__device__ __forceinline__ void planes_s6m32(uint32_t w, uint32_t scpk, uint32_t &hi, uint32_t &lo) {
+    const i16x2 k32 = {32, 32};
+    const i16x2 e = __builtin_bit_cast(i16x2, w & 0x00ff00ffu) - k32, o = __builtin_bit_cast(i16x2, (w >> 8) & 0x00ff00ffu) - k32;
+    const i16x2 s = __builtin_bit_cast(i16x2, scpk);
+    const i16x2 pe = e * s, po = o * s;
+    const i16x2 six = {6, 6};
+    const uint32_t he = __builtin_bit_cast(uint32_t, pe >> six), ho = __builtin_bit_cast(uint32_t, po >> six);
+    const uint32_t le = __builtin_bit_cast(uint32_t, pe) & 0x003f003fu, lo_ = __builtin_bit_cast(uint32_t, po) & 0x003f003fu;
+    hi = (he & 0x00ff00ffu) | ((ho & 0x00ff00ffu) << 8);
+    lo = le | (lo_ << 8);
+}
+
+// per-lane weight-row state of one super-block: raw bytes as loaded, then what the K-steps need
 template <int TYPE> struct RowSB;
 
 template <> struct RowSB<T_Q4_K> {
-    uint4 q[4];            // chunk c: 16 bytes holding 16 low nibbles (sub-block 2c) and 16 high nibbles (2c+1)
-    uint32_t sc_lo, sc_hi, mn_lo, mn_hi;   // 8 scales / 8 mins, one byte each
-    float d, dmin;
+    u32x4 q0, q1, q2, q3;      // chunk c: 16 bytes = 16 low nibbles (sub-block 2c) and 16 high nibbles (2c+1) of this lane's k-half
+    u32x4 h;
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, int kg) {
         const uint8_t *b = row + (size_t)sb * 144;
-        const uint4 h = ldg16(b);
-#pragma unroll
-        for (int c = 0; c < 4; c++) q[c] = ldg16(b + 16 + 32 * c + 16 * kg);
-        d = h2f((uint16_t)(h.x & 0xffff)); dmin = h2f((uint16_t)(h.x >> 16));
-        // scales bytes s0..s11 in h.y h.z h.w; j<4: sc = s[j]&63, m = s[j+4]&63; j>=4: sc = (s[j+4]&15)|((s[j-4]>>6)<<4), m = (s[j+4]>>4)|((s[j]>>6)<<4)
+        h = ldg16(b);
+        q0 = ldg16(b + 16 + 16 * kg); q1 = ldg16(b + 48 + 16 * kg); q2 = ldg16(b + 80 + 16 * kg); q3 = ldg16(b + 112 + 16 * kg);
+    }
+    __device__ __forceinline__ float d() const { return h2f((uint16_t)(h.x & 0xffff)); }
+    __device__ __forceinline__ float dmin() const { return h2f((uint16_t)(h.x >> 16)); }
+    // scales bytes s0..s11 in h.y h.z h.w; j<4: sc = s[j]&63, m = s[j+4]&63; j>=4: sc = (s[j+4]&15)|((s[j-4]>>6)<<4), m = (s[j+4]>>4)|((s[j]>>6)<<4)
+    __device__ __forceinline__ void scales(uint32_t &sc_lo, uint32_t &sc_hi, uint32_t &mn_lo, uint32_t &mn_hi) const {
         sc_lo = h.y & 0x3f3f3f3f; mn_lo = h.z & 0x3f3f3f3f;
         sc_hi = (h.w & 0x0f0f0f0f) | ((h.y >> 2) & 0x30303030);
         mn_hi = ((h.w >> 4) & 0x0f0f0f0f) | ((h.z >> 2) & 0x30303030);
     }
-    __device__ __forceinline__ int scale(int j) const { return (int)(((j < 4 ? sc_lo : sc_hi) >> (8 * (j & 3))) & 0xff); }
-    __device__ __forceinline__ i32x4 bop(int j) const {     // MFMA B operand of sub-block j: 16 weights of this lane's row
-        const uint4 v = q[j >> 1];
-        const int sh = (j & 1) * 4;
-        i32x4 r;
-        r.x = (int)((v.x >> sh) & 0x0f0f0f0f); r.y = (int)((v.y >> sh) & 0x0f0f0f0f);
-        r.z = (int)((v.z >> sh) & 0x0f0f0f0f); r.w = (int)((v.w >> sh) & 0x0f0f0f0f);
-        return r;
+    template <int J> __device__ __forceinline__ void bop(uint32_t sc, i32x4 &bh, i32x4 &bl) const {
+        const u32x4 v = (J >> 1) == 0 ? q0 : (J >> 1) == 1 ? q1 : (J >> 1) == 2 ? q2 : q3;
+        constexpr int sh = (J & 1) * 4;
+        uint32_t hx, lx;
+        planes_u<5>((v.x >> sh) & 0x0f0f0f0f, sc, hx, lx); bh.x = (int)hx; bl.x = (int)lx;
+        planes_u<5>((v.y >> sh) & 0x0f0f0f0f, sc, hx, lx); bh.y = (int)hx; bl.y = (int)lx;
+        planes_u<5>((v.z >> sh) & 0x0f0f0f0f, sc, hx, lx); bh.z = (int)hx; bl.z = (int)lx;
+        planes_u<5>((v.w >> sh) & 0x0f0f0f0f, sc, hx, lx); bh.w = (int)hx; bl.w = (int)lx;
     }
 };
 
 template <> struct RowSB<T_Q5_K> {
-    uint4 q[4], qh;
-    uint32_t sc_lo, sc_hi, mn_lo, mn_hi;
-    float d, dmin;
+    u32x4 q0, q1, q2, q3, qh;
+    u32x4 h;
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, int kg) {
         const uint8_t *b = row + (size_t)sb * 176;
-        const uint4 h = ldg16(b);
+        h = ldg16(b);
         qh = ldg16(b + 16 + 16 * kg);
-#pragma unroll
-        for (int c = 0; c < 4; c++) q[c] = ldg16(b + 48 + 32 * c + 16 * kg);
-        d = h2f((uint16_t)(h.x & 0xffff)); dmin = h2f((uint16_t)(h.x >> 16));
+        q0 = ldg16(b + 48 + 16 * kg); q1 = ldg16(b + 80 + 16 * kg); q2 = ldg16(b + 112 + 16 * kg); q3 = ldg16(b + 144 + 16 * kg);
+    }
+    __device__ __forceinline__ float d() const { return h2f((uint16_t)(h.x & 0xffff)); }
+    __device__ __forceinline__ float dmin() const { return h2f((uint16_t)(h.x >> 16)); }
+    __device__ __forceinline__ void scales(uint32_t &sc_lo, uint32_t &sc_hi, uint32_t &mn_lo, uint32_t &mn_hi) const {
         sc_lo = h.y & 0x3f3f3f3f; mn_lo = h.z & 0x3f3f3f3f;
         sc_hi = (h.w & 0x0f0f0f0f) | ((h.y >> 2) & 0x30303030);
         mn_hi = ((h.w >> 4) & 0x0f0f0f0f) | ((h.z >> 2) & 0x30303030);
     }
-    __device__ __forceinline__ int scale(int j) const { return (int)(((j < 4 ? sc_lo : sc_hi) >> (8 * (j & 3))) & 0xff); }
-    __device__ __forceinline__ i32x4 bop(int j) const {
-        const uint4 v = q[j >> 1];
-        const int sh = (j & 1) * 4;
-        i32x4 r;
-        r.x = (int)(((v.x >> sh) & 0x0f0f0f0f) | (((qh.x >> j) & 0x01010101u) << 4));
-        r.y = (int)(((v.y >> sh) & 0x0f0f0f0f) | (((qh.y >> j) & 0x01010101u) << 4));
-        r.z = (int)(((v.z >> sh) & 0x0f0f0f0f) | (((qh.z >> j) & 0x01010101u) << 4));
-        r.w = (int)(((v.w >> sh) & 0x0f0f0f0f) | (((qh.w >> j) & 0x01010101u) << 4));
-        return r;
+    template <int J> __device__ __forceinline__ void bop(uint32_t sc, i32x4 &bh, i32x4 &bl) const {
+        const u32x4 v = (J >> 1) == 0 ? q0 : (J >> 1) == 1 ? q1 : (J >> 1) == 2 ? q2 : q3;
+        constexpr int sh = (J & 1) * 4;
+        uint32_t hx, lx;
+#define Q5W(vv, hh) ((((vv) >> sh) & 0x0f0f0f0f) | ((((hh) >> J) & 0x01010101u) << 4))
+        planes_u<5>(Q5W(v.x, qh.x), sc, hx, lx); bh.x = (int)hx; bl.x = (int)lx;
+        planes_u<5>(Q5W(v.y, qh.y), sc, hx, lx); bh.y = (int)hx; bl.y = (int)lx;
+        planes_u<5>(Q5W(v.z, qh.z), sc, hx, lx); bh.z = (int)hx; bl.z = (int)lx;
+        planes_u<5>(Q5W(v.w, qh.w), sc, hx, lx); bh.w = (int)hx; bl.w = (int)lx;
+#undef Q5W
     }
 };
 
-// Q6_K device row planes: ql | qh | scales | d.  K-step s (0..7) = half n = s>>2, quarter k = s&3: 32 weights whose
-// first 16 (kg = 0) use scale 8n+2k and last 16 (kg = 1) scale 8n+2k+1, so each K-step is issued as TWO MFMAs with the
-// other half of the B operand zeroed.
+// Q6_K device row planes: ql | qh | scales | d.  K-step s (0..7) = half n = s>>2, quarter k = s&3: this lane's 16 weights
+// l = 16kg.. of that quarter are one 16-group with scale sc[8n + 2k + kg].
 template <> struct RowSB<T_Q6_K> {
-    uint4 ql[4], qhv[2];
-    uint4 scv;             // 16 int8 scales
-    float d;
-    int kg;
-    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, int kg_) {
-        kg = kg_;
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            ql[2 * n]     = ldg16(row + (size_t)sb * 128 + 64 * n + 16 * kg);        // l = 16kg..   (quarters 0 / 2)
-            ql[2 * n + 1] = ldg16(row + (size_t)sb * 128 + 64 * n + 32 + 16 * kg);   // l+32         (quarters 1 / 3)
-            qhv[n] = ldg16(row + (size_t)nb * 128 + (size_t)sb * 64 + 32 * n + 16 * kg);
-        }
+    u32x4 l0, l1, l2, l3;      // ql: half 0 (l, l+32), half 1 (l, l+32)
+    u32x4 h0, h1;              // qh: half 0, half 1
+    u32x4 scv;                 // 16 int8 scales
+    uint32_t d16;
+    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, int kg) {
+        l0 = ldg16(row + (size_t)sb * 128 + 16 * kg);      l1 = ldg16(row + (size_t)sb * 128 + 32 + 16 * kg);
+        l2 = ldg16(row + (size_t)sb * 128 + 64 + 16 * kg); l3 = ldg16(row + (size_t)sb * 128 + 96 + 16 * kg);
+        h0 = ldg16(row + (size_t)nb * 128 + (size_t)sb * 64 + 16 * kg);
+        h1 = ldg16(row + (size_t)nb * 128 + (size_t)sb * 64 + 32 + 16 * kg);
         scv = ldg16(row + (size_t)nb * 192 + (size_t)sb * 16);
-        d = h2f(*reinterpret_cast<const uint16_t *>(row + (size_t)nb * 208 + (size_t)sb * 2));
+        d16 = *reinterpret_cast<const uint16_t *>(row + (size_t)nb * 208 + (size_t)sb * 2);
     }
-    __device__ __forceinline__ int scale16(int g) const {   // signed int8 scale of 16-group g
+    __device__ __forceinline__ float d() const { return h2f((uint16_t)d16); }
+    // signed scale of 16-group g, replicated into both 16-bit lanes
+    __device__ __forceinline__ uint32_t scale_pk(int g) const {
         const uint32_t w = g < 4 ? scv.x : g < 8 ? scv.y : g < 12 ? scv.z : scv.w;
-        return (int)(int8_t)((w >> (8 * (g & 3))) & 0xff);
+        const int s = (int)(int8_t)((w >> (8 * (g & 3))) & 0xff);
+        return ((uint32_t)s & 0xffffu) | ((uint32_t)s << 16);
     }
-    __device__ __forceinline__ i32x4 bop(int s) const {     // signed (q - 32) codes of K-step s for this lane's 16 weights
-        const int n = s >> 2, k = s & 3;
-        const uint4 l4 = ql[2 * n + (k & 1)];
-        const uint4 h4 = qhv[n];
-        const int nsh = (k >> 1) * 4, hsh = 2 * k;
-        i32x4 r;
-#define Q6B(lv, hv) (int)((((((lv) >> nsh) & 0x0f0f0f0f) | ((((hv) >> hsh) & 0x03030303u) << 4)) + 0x60606060u) ^ 0x80808080u)
-        r.x = Q6B(l4.x, h4.x); r.y = Q6B(l4.y, h4.y); r.z = Q6B(l4.z, h4.z); r.w = Q6B(l4.w, h4.w);
-#undef Q6B
-        return r;
+    // same with the signed code (q - 32): 64 * hi + lo = sc * (q - 32), no block-sum correction needed afterwards
+    template <int S> __device__ __forceinline__ void bop_signed(uint32_t scpk, i32x4 &bh, i32x4 &bl) const {
+        constexpr int n = S >> 2, k = S & 3;
+        const u32x4 lv = n == 0 ? ((k & 1) ? l1 : l0) : ((k & 1) ? l3 : l2);
+        const u32x4 hv = n == 0 ? h0 : h1;
+        constexpr int nsh = (k >> 1) * 4, hsh = 2 * k;
+        uint32_t hx, lx;
+#define Q6W(lw, hw) ((((lw) >> nsh) & 0x0f0f0f0f) | ((((hw) >> hsh) & 0x03030303u) << 4))
+        planes_s6m32(Q6W(lv.x, hv.x), scpk, hx, lx); bh.x = (int)hx; bl.x = (int)lx;
+        planes_s6m32(Q6W(lv.y, hv.y), scpk, hx, lx); bh.y = (int)hx; bl.y = (int)lx;
+        planes_s6m32(Q6W(lv.z, hv.z), scpk, hx, lx); bh.z = (int)hx; bl.z = (int)lx;
+        planes_s6m32(Q6W(lv.w, hv.w), scpk, hx, lx); bh.w = (int)hx; bl.w = (int)lx;
+#undef Q6W
+    }
+    template <int S> __device__ __forceinline__ void bop(uint32_t scpk, i32x4 &bh, i32x4 &bl) const {
+        constexpr int n = S >> 2, k = S & 3;
+        const u32x4 lv = n == 0 ? ((k & 1) ? l1 : l0) : ((k & 1) ? l3 : l2);
+        const u32x4 hv = n == 0 ? h0 : h1;
+        constexpr int nsh = (k >> 1) * 4, hsh = 2 * k;
+        uint32_t hx, lx;
+#define Q6W(lw, hw) ((((lw) >> nsh) & 0x0f0f0f0f) | ((((hw) >> hsh) & 0x03030303u) << 4))
+        planes_s6(Q6W(lv.x, hv.x), scpk, hx, lx); bh.x = (int)hx; bl.x = (int)lx;
+        planes_s6(Q6W(lv.y, hv.y), scpk, hx, lx); bh.y = (int)hx; bl.y = (int)lx;
+        planes_s6(Q6W(lv.z, hv.z), scpk, hx, lx); bh.z = (int)hx; bl.z = (int)lx;
+        planes_s6(Q6W(lv.w, hv.w), scpk, hx, lx); bh.w = (int)hx; bl.w = (int)lx;
+#undef Q6W
     }
 };
 
-template <int TYPE>
-__global__ __launch_bounds__(512, 1) void mmq_kernel(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T,
-                                                     const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
-                                                     float *out, int ld_out, const float *resid) {
+// MT token tiles of 32 per wave; TW token-waves x RW row-waves = 8 waves
+template <int MT> struct Geo {
+    static constexpr int TW = MT == 2 ? 2 : 1, RW = 8 / TW;
+    static constexpr int TOK_TILE = 32 * MT * TW, ROW_TILE = 32 * RW;
+    static constexpr int LDS_A = TOK_TILE * A_STRIDE, LDS_P = TOK_TILE * 16;
+    static constexpr int LDS_BYTES = LDS_A + 2 * LDS_P + TOK_TILE * 4;
+    static constexpr int NST = (TOK_TILE * 16 + NTHREADS - 1) / NTHREADS;       // 16-byte staging pieces per thread
+};
+
+template <int TYPE, int MT>
+__global__ __launch_bounds__(NTHREADS) void mmq_kernel(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
+                                                       const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
+                                                       float *out, int ld_out, const float *resid) {
+    using G = Geo<MT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Smem S;
-    S.aq = reinterpret_cast<int8_t *>(smem);
-    S.bh = S.aq + TOK_TILE * A_STRIDE;
-    S.bl = S.bh + TOK_TILE * 8;
-    S.yd = reinterpret_cast<float *>(S.bl + TOK_TILE * 8);
+    int8_t *s_aq = reinterpret_cast<int8_t *>(smem);
+    int8_t *s_bh = s_aq + G::LDS_A, *s_bl = s_bh + G::LDS_P;
+    float *s_yd = reinterpret_cast<float *>(s_bl + G::LDS_P);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = K >> 8;
-    const int row0 = blockIdx.x * ROW_TILE + (wave & 3) * 32;   // 8 waves: 4 row tiles x 2 token-tile pairs
-    const int th = wave >> 2;
-    const int tok0 = blockIdx.y * TOK_TILE;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs; the token tiles of one row tile run on ONE
+    // XCD back to back, so its weights are fetched from HBM once and re-read from that XCD's L2
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int tok_tile = loc % n_tok_tiles;
+    const int row_tile = (loc / n_tok_tiles) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    const int rw = wave % G::RW, tw = wave / G::RW;
+    const int row0 = row_tile * G::ROW_TILE + rw * 32;
+    const int tok0 = tok_tile * G::TOK_TILE;
     const int n = lane & 31, kg = lane >> 5;
     int my_row = row0 + n;
     const bool row_ok = my_row < n_rows;
     if (!row_ok) my_row = n_rows - 1;
     const uint8_t *rowp = W + (size_t)my_row * row_bytes;
-    // activation planes are allocated for a whole number of token tiles (rows past T hold stale data whose results are
-    // never stored), so every address below is  uniform base + small 32-bit per-thread offset  (no per-thread 64-bit
-    // pointers for the compiler to hoist and spill)
-    const int8_t *aq_t = aq + (size_t)tok0 * K;
-    const float *ad_t = ad + (size_t)tok0 * nb;
-    const int8_t *bh_t = abh + (size_t)tok0 * nb * 8, *bl_t = abl + (size_t)tok0 * nb * 8;
-    const unsigned st_off = (unsigned)(tid >> 4) * (unsigned)K + (unsigned)(tid & 15) * 16u;   // staging: token tid/16 (+32 i), piece tid%16
-    const unsigned st_lds = (unsigned)(tid >> 4) * A_STRIDE + (unsigned)(tid & 15) * 16u;
 
-    float facc[2][16];
+    // staging roles: piece p = tid + NTHREADS * i -> token p / 16, 16-byte column p % 16; tokens past T re-read token T-1
+    unsigned st_g[G::NST], st_l[G::NST];
 #pragma unroll
-    for (int tt = 0; tt < 2; tt++)
+    for (int i = 0; i < G::NST; i++) {
+        const int p = tid + NTHREADS * i;
+        int tk = p >> 4;
+        if (tk >= G::TOK_TILE) tk = G::TOK_TILE - 1;
+        int gt = tok0 + tk;
+        if (gt >= T) gt = T - 1;
+        st_g[i] = (unsigned)gt * (unsigned)K + (unsigned)(p & 15) * 16u;
+        st_l[i] = (unsigned)tk * A_STRIDE + (unsigned)(p & 15) * 16u;
+    }
+    int ptok = tok0 + (tid < G::TOK_TILE ? tid : 0);
+    if (ptok >= T) ptok = T - 1;
+    const unsigned pl_g = (unsigned)ptok * (unsigned)nb;      // per-token plane / scale index base (x 16 bytes for planes)
+
+    float facc[MT][16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) facc[tt][r] = 0.0f;
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) facc[t][r] = 0.0f;
+
+    // ---- prologue: tile 0 into LDS, raw weights of super-block 0 into registers
+    RowSB<TYPE> R;
+    R.load(rowp, nb, 0, kg);
+    {
+        u32x4 tmp[G::NST];
+#pragma unroll
+        for (int i = 0; i < G::NST; i++) tmp[i] = ldg16(aq + st_g[i]);
+#pragma unroll
+        for (int i = 0; i < G::NST; i++) if (tid + NTHREADS * i < G::TOK_TILE * 16) *reinterpret_cast<u32x4 *>(s_aq + st_l[i]) = tmp[i];
+        if (tid < G::TOK_TILE) {
+            s_yd[tid] = ad[pl_g];
+            *reinterpret_cast<u32x4 *>(s_bh + tid * 16) = ldg16(abh + (size_t)pl_g * 16);
+            *reinterpret_cast<u32x4 *>(s_bl + tid * 16) = ldg16(abl + (size_t)pl_g * 16);
+        }
+    }
+    __syncthreads();
 
     for (int sb = 0; sb < nb; sb++) {
-        RowSB<TYPE> R;
-        R.load(rowp, nb, sb, kg);                    // weight loads in flight while the activation tile is staged
-        __syncthreads();                             // previous super-block fully consumed
-        {   // stage 128 tokens x 256 codes: 2048 x 16 B, 8 per thread, all loads issued before the LDS writes
-            const int8_t *src = aq_t + (size_t)sb * 256;
-            uint4 tmp[4];
+        // ---- next activation tile: request now, park in registers across the MFMA work
+        const bool more = sb + 1 < nb;
+        const int sbn = more ? sb + 1 : sb;
+        u32x4 nxt[G::NST];
 #pragma unroll
-            for (int i = 0; i < 4; i++) tmp[i] = ldg16(src + st_off + (unsigned)i * 32u * (unsigned)K);
-#pragma unroll
-            for (int i = 0; i < 4; i++) *reinterpret_cast<uint4 *>(S.aq + st_lds + i * 32 * A_STRIDE) = tmp[i];
+        for (int i = 0; i < G::NST; i++) nxt[i] = ldg16(aq + st_g[i] + (unsigned)sbn * 256u);
+        float nyd = 0.0f;
+        u32x4 nbh = {0, 0, 0, 0}, nbl = {0, 0, 0, 0};
+        if (tid < G::TOK_TILE) {
+            nyd = ad[pl_g + (unsigned)sbn];
+            nbh = ldg16(abh + ((size_t)pl_g + (unsigned)sbn) * 16);
+            nbl = ldg16(abl + ((size_t)pl_g + (unsigned)sbn) * 16);
         }
-        if (tid < TOK_TILE) {
-            S.yd[tid] = ad_t[(unsigned)tid * (unsigned)nb + (unsigned)sb];
-            if (TYPE != T_Q6_K) {
-                *reinterpret_cast<uint2 *>(S.bh + tid * 8) = *reinterpret_cast<const uint2 *>(bh_t + ((unsigned)tid * (unsigned)nb + (unsigned)sb) * 8u);
-                *reinterpret_cast<uint2 *>(S.bl + tid * 8) = *reinterpret_cast<const uint2 *>(bl_t + ((unsigned)tid * (unsigned)nb + (unsigned)sb) * 8u);
+
+        // ---- this super-block: scales, then 8 K-steps x MT tiles x {hi, lo}
+        i32x16 H[MT], L[MT];
+        const int8_t *abase = s_aq + (tw * MT * 32 + n) * A_STRIDE + 16 * kg;
+        uint32_t sc_lo = 0, sc_hi = 0, mn_lo = 0, mn_hi = 0;
+        if constexpr (TYPE != T_Q6_K) R.scales(sc_lo, sc_hi, mn_lo, mn_hi);
+#define KSTEP(J)                                                                                              \
+        {                                                                                                     \
+            i32x4 bh, bl;                                                                                     \
+            if constexpr (TYPE == T_Q6_K) R.template bop<J>(R.scale_pk(8 * (J >> 2) + 2 * (J & 3) + kg), bh, bl); \
+            else R.template bop<J>(((J < 4 ? sc_lo : sc_hi) >> (8 * (J & 3))) & 0xff, bh, bl);                \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * J);          \
+                if (J == 0) {                                                                                 \
+                    i32x16 z;                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                  \
+                    H[t] = mfma_i8(a, bh, z); L[t] = mfma_i8(a, bl, z);                                       \
+                } else { H[t] = mfma_i8(a, bh, H[t]); L[t] = mfma_i8(a, bl, L[t]); }                          \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);   /* one K-step's operands live at a time (register pressure) */ \
+        }
+        KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
+#undef KSTEP
+        // ---- block-sum term: 16 per-16 sums x (mins duplicated | scales); K = 16 of 32 used (lanes kg == 0)
+        i32x4 bm = {0, 0, 0, 0};
+        if (kg == 0) {
+            if constexpr (TYPE == T_Q6_K) { bm.x = (int)R.scv.x; bm.y = (int)R.scv.y; bm.z = (int)R.scv.z; bm.w = (int)R.scv.w; }
+            else {
+                bm.x = (int)perm(0, mn_lo, 0x01010000u); bm.y = (int)perm(0, mn_lo, 0x03030202u);
+                bm.z = (int)perm(0, mn_hi, 0x01010000u); bm.w = (int)perm(0, mn_hi, 0x03030202u);
+            }
+        }
+        const float dd = R.d();
+        float dm = 0.0f;
+        if constexpr (TYPE != T_Q6_K) dm = R.dmin();
+        // raw weights of the next super-block (R is dead from here on)
+        if (more) R.load(rowp, nb, sb + 1, kg);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int tl = (tw * MT + t) * 32;
+            i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0};
+            if (kg == 0) {
+                ah = *reinterpret_cast<const i32x4 *>(s_bh + (tl + n) * 16);
+                al = *reinterpret_cast<const i32x4 *>(s_bl + (tl + n) * 16);
+            }
+            i32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[r] = 0;
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x16 mh = mfma_i8(ah, bm, z), ml = mfma_i8(al, bm, z);
+#pragma unroll
+            for (int rq = 0; rq < 4; rq++) {
+                const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + tl + 8 * rq + 4 * kg);   // tokens m = 8 rq + 4 kg + (0..3)
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++) {
+                    const int r = rq * 4 + ri;
+                    const float yd = yd4[ri];
+                    const int bsum = 64 * mh[r] + ml[r];
+                    if constexpr (TYPE == T_Q6_K) {
+                        const int isum = 64 * H[t][r] + L[t][r] - 32 * bsum;
+                        facc[t][r] += (dd * yd) * (float)isum;
+                    } else {
+                        const int isum = 32 * H[t][r] + L[t][r];
+                        facc[t][r] += (dd * yd) * (float)isum - (dm * yd) * (float)bsum;
+                    }
+                }
+            }
+        }
+        // ---- swap in the next tile
+        __syncthreads();                             // every wave is done reading this tile
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < G::NST; i++) if (tid + NTHREADS * i < G::TOK_TILE * 16) *reinterpret_cast<u32x4 *>(s_aq + st_l[i]) = nxt[i];
+            if (tid < G::TOK_TILE) {
+                s_yd[tid] = nyd;
+                *reinterpret_cast<u32x4 *>(s_bh + tid * 16) = nbh;
+                *reinterpret_cast<u32x4 *>(s_bl + tid * 16) = nbl;
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++) {
-            const int tq = 2 * th + tt;                                            // token tile of this wave
-            const int8_t *arow = S.aq + (tq * 32 + n) * A_STRIDE + 16 * kg;     // A operand: token m = lane & 31
-            i32x16 isum;
-#pragma unroll
-            for (int r = 0; r < 16; r++) isum[r] = 0;
-            if constexpr (TYPE == T_Q6_K) {
-                const RowSB<T_Q6_K> &R6 = R;
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const i32x4 a = as_i32x4(*reinterpret_cast<const uint4 *>(arow + 32 * s));
-                    const i32x4 b = R6.bop(s);
-                    const i32x4 z = {0, 0, 0, 0};
-                    i32x16 zero;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) zero[r] = 0;
-                    const i32x16 p0 = mfma_i8(a, kg == 0 ? b : z, zero);       // 16-group 2s   (k 0..15)
-                    const i32x16 p1 = mfma_i8(a, kg == 1 ? b : z, zero);       // 16-group 2s+1 (k 16..31)
-                    const int s0 = R6.scale16(2 * s), s1 = R6.scale16(2 * s + 1);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) isum[r] += __mul24(s0, p0[r]) + __mul24(s1, p1[r]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    facc[tt][r] += (R6.d * S.yd[tq * 32 + m]) * (float)isum[r];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const i32x4 a = as_i32x4(*reinterpret_cast<const uint4 *>(arow + 32 * j));
-                    i32x16 zero;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) zero[r] = 0;
-                    const i32x16 p = mfma_i8(a, R.bop(j), zero);
-                    const int sc = R.scale(j);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) isum[r] += __mul24(sc, p[r]);
-                    __builtin_amdgcn_sched_barrier(0);              // keep one MFMA result live (register pressure)
-                }
-                // mins: msum[m][n] = sum_j m_j[n] * bsum_j[m],  bsum = 64*hi + lo; K = 8 of 32 used (lanes kg == 0, first 8 bytes)
-                i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0}, bm = {0, 0, 0, 0};
-                if (kg == 0) {
-                    const uint2 h2 = *reinterpret_cast<const uint2 *>(S.bh + (tq * 32 + n) * 8);
-                    const uint2 l2 = *reinterpret_cast<const uint2 *>(S.bl + (tq * 32 + n) * 8);
-                    ah.x = (int)h2.x; ah.y = (int)h2.y; al.x = (int)l2.x; al.y = (int)l2.y;
-                    bm.x = (int)R.mn_lo; bm.y = (int)R.mn_hi;
-                }
-                i32x16 zero;
-#pragma unroll
-                for (int r = 0; r < 16; r++) zero[r] = 0;
-                const i32x16 mh = mfma_i8(ah, bm, zero), mlo = mfma_i8(al, bm, zero);
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    const float yd = S.yd[tq * 32 + m];
-                    const int msum = 64 * mh[r] + mlo[r];
-                    facc[tt][r] += (R.d * yd) * (float)isum[r] - (R.dmin * yd) * (float)msum;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
     // store: lane = weight row n, regs = tokens; 32 consecutive rows per token -> 128-B coalesced
     if (row_ok) {
 #pragma unroll
-        for (int tt = 0; tt < 2; tt++)
+        for (int t = 0; t < MT; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const int gt = tok0 + (2 * th + tt) * 32 + m;
+                const int gt = tok0 + (tw * MT + t) * 32 + m;
                 if (gt < T) {
                     const size_t o = (size_t)gt * ld_out + row0 + n;
-                    out[o] = resid ? resid[o] + facc[tt][r] : facc[tt][r];
+                    out[o] = resid ? resid[o] + facc[t][r] : facc[t][r];
                 }
             }
     }
 }
 
-// block sums of 32 codes split into int8 planes: bsum = 64*hi + lo, hi in [-64, 63], lo in [0, 63]
-__global__ void mmq_prep_kernel(const int16_t *bsums, int K, int T, int8_t *bh, int8_t *bl) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over T * K/32
-    const size_t n = (size_t)T * (K >> 5);
+// ------------------------------------------------------------------------------------------------------------------
+// Pre-expanded weights ("planes"): the two int8 planes of every K-step are computed ONCE at model load and laid out
+// exactly as the MFMA B operands are consumed, so the prefill kernel does no per-weight VALU work at all:
+//   block(rt, sb) = 32 rows x one super-block:  [K-step J 0..7][plane 0 = hi, 1 = lo][lane 0..63][16 B]  (16 KB)
+//                                               [row n 0..31][16 B meta: d | dmin << 16 (f16 bits), mins 0-3, mins 4-7, 0]
+// 2 bytes per weight + 1/16 B meta (Q4_K: 3.7x the GGUF bytes).  Q6_K planes carry the SIGNED code (q - 32), so that
+// type needs no block-sum term at all.
+constexpr int PL_BLOCK = 8 * 2 * 1024 + 32 * 16;
+
+template <int TYPE>
+__global__ __launch_bounds__(256) void mmq_expand_kernel(const uint8_t *W, size_t row_bytes, int n_rows, int nb, int n_rt, uint8_t *planes) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);     // (row tile, super-block)
+    if (idx >= n_rt * nb) return;
+    const int rt = idx / nb, sb = idx - rt * nb;
+    const int n = lane & 31, kg = lane >> 5;
+    int row = rt * 32 + n;
+    if (row >= n_rows) row = n_rows - 1;
+    RowSB<TYPE> R;
+    R.load(W + (size_t)row * row_bytes, nb, sb, kg);
+    uint8_t *blk = planes + (size_t)idx * PL_BLOCK;
+    uint32_t sc_lo = 0, sc_hi = 0, mn_lo = 0, mn_hi = 0;
+    if constexpr (TYPE != T_Q6_K) R.scales(sc_lo, sc_hi, mn_lo, mn_hi);
+#define EXP(J)                                                                                                 \
+    {                                                                                                          \
+        i32x4 bh, bl;                                                                                          \
+        if constexpr (TYPE == T_Q6_K) R.template bop_signed<J>(R.scale_pk(8 * (J >> 2) + 2 * (J & 3) + kg), bh, bl); \
+        else R.template bop<J>(((J < 4 ? sc_lo : sc_hi) >> (8 * (J & 3))) & 0xff, bh, bl);                     \
+        *reinterpret_cast<i32x4 *>(blk + (J * 2) * 1024 + lane * 16) = bh;                                     \
+        *reinterpret_cast<i32x4 *>(blk + (J * 2 + 1) * 1024 + lane * 16) = bl;                                 \
+    }
+    EXP(0) EXP(1) EXP(2) EXP(3) EXP(4) EXP(5) EXP(6) EXP(7)
+#undef EXP
+    if (kg == 0) {
+        u32x4 m = {0, 0, 0, 0};
+        if constexpr (TYPE == T_Q6_K) m.x = R.d16;
+        else { m.x = R.h.x; m.y = mn_lo; m.z = mn_hi; }
+        *reinterpret_cast<u32x4 *>(blk + 16384 + n * 16) = m;
+    }
+}
+
+// MINS: Q4_K / Q5_K (block-sum term, shift 5); otherwise Q6_K (shift 6, nothing else)
+template <bool MINS, int MT>
+__global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
+                                                              const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
+                                                              float *out, int ld_out, const float *resid) {
+    using G = Geo<MT>;
+    constexpr int SH = MINS ? 5 : 6;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int8_t *s_aq = reinterpret_cast<int8_t *>(smem);
+    int8_t *s_bh = s_aq + G::LDS_A, *s_bl = s_bh + G::LDS_P;
+    float *s_yd = reinterpret_cast<float *>(s_bl + G::LDS_P);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = K >> 8;
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int tok_tile = loc % n_tok_tiles;
+    const int row_tile = (loc / n_tok_tiles) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    const int rw = wave % G::RW, tw = wave / G::RW;
+    const int rt32 = row_tile * G::RW + rw;                    // 32-row tile of this wave
+    const int n_rt32 = (n_rows + 31) >> 5;
+    const int row0 = rt32 * 32;
+    const int tok0 = tok_tile * G::TOK_TILE;
+    const int n = lane & 31, kg = lane >> 5;
+    const bool tile_ok = rt32 < n_rt32;
+    const uint8_t *blk0 = planes + (size_t)(tile_ok ? rt32 : n_rt32 - 1) * nb * PL_BLOCK;
+    const unsigned b_off = (unsigned)lane * 16u;
+
+    unsigned st_g[G::NST], st_l[G::NST];
+#pragma unroll
+    for (int i = 0; i < G::NST; i++) {
+        const int p = tid + NTHREADS * i;
+        int tk = p >> 4;
+        if (tk >= G::TOK_TILE) tk = G::TOK_TILE - 1;
+        int gt = tok0 + tk;
+        if (gt >= T) gt = T - 1;
+        st_g[i] = (unsigned)gt * (unsigned)K + (unsigned)(p & 15) * 16u;
+        st_l[i] = (unsigned)tk * A_STRIDE + (unsigned)(p & 15) * 16u;
+    }
+    int ptok = tok0 + (tid < G::TOK_TILE ? tid : 0);
+    if (ptok >= T) ptok = T - 1;
+    const unsigned pl_g = (unsigned)ptok * (unsigned)nb;
+
+    float facc[MT][16];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) facc[t][r] = 0.0f;
+
+    // ---- prologue: B operands and meta of super-block 0 into registers, activation tile 0 into LDS
+    i32x4 Bh[4], Bl[4];                                         // ring of 4 K-steps
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        Bh[j] = *reinterpret_cast<const i32x4 *>(blk0 + (j * 2) * 1024 + b_off);
+        Bl[j] = *reinterpret_cast<const i32x4 *>(blk0 + (j * 2 + 1) * 1024 + b_off);
+    }
+    u32x4 meta = ldg16(blk0 + 16384 + n * 16);
+    {
+        u32x4 tmp[G::NST];
+#pragma unroll
+        for (int i = 0; i < G::NST; i++) tmp[i] = ldg16(aq + st_g[i]);
+#pragma unroll
+        for (int i = 0; i < G::NST; i++) if (tid + NTHREADS * i < G::TOK_TILE * 16) *reinterpret_cast<u32x4 *>(s_aq + st_l[i]) = tmp[i];
+        if (tid < G::TOK_TILE) {
+            s_yd[tid] = ad[pl_g];
+            if (MINS) {
+                *reinterpret_cast<u32x4 *>(s_bh + tid * 16) = ldg16(abh + (size_t)pl_g * 16);
+                *reinterpret_cast<u32x4 *>(s_bl + tid * 16) = ldg16(abl + (size_t)pl_g * 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int sb = 0; sb < nb; sb++) {
+        const bool more = sb + 1 < nb;
+        const int sbn = more ? sb + 1 : sb;
+        const uint8_t *blkn = blk0 + (size_t)sbn * PL_BLOCK;
+        // next activation tile: request now, park in registers across the MFMA work
+        u32x4 nxt[G::NST];
+#pragma unroll
+        for (int i = 0; i < G::NST; i++) nxt[i] = ldg16(aq + st_g[i] + (unsigned)sbn * 256u);
+        float nyd = 0.0f;
+        u32x4 nbh = {0, 0, 0, 0}, nbl = {0, 0, 0, 0};
+        if (tid < G::TOK_TILE) {
+            nyd = ad[pl_g + (unsigned)sbn];
+            if (MINS) {
+                nbh = ldg16(abh + ((size_t)pl_g + (unsigned)sbn) * 16);
+                nbl = ldg16(abl + ((size_t)pl_g + (unsigned)sbn) * 16);
+            }
+        }
+        const u32x4 mcur = meta;
+        meta = ldg16(blkn + 16384 + n * 16);
+
+        i32x16 H[MT], L[MT];
+        const int8_t *abase = s_aq + (tw * MT * 32 + n) * A_STRIDE + 16 * kg;
+        const uint8_t *blkc = blk0 + (size_t)sb * PL_BLOCK;
+        // K-step J: MFMAs on ring slot J & 3, then the slot is refilled with the operand four K-steps ahead (same
+        // super-block for J < 4, the next one otherwise): every B register waits half an iteration before its use
+#define KSTEP(J)                                                                                              \
+        {                                                                                                     \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * J);          \
+                if (J == 0) {                                                                                 \
+                    i32x16 z;                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                  \
+                    H[t] = mfma_i8(a, Bh[J & 3], z); L[t] = mfma_i8(a, Bl[J & 3], z);                         \
+                } else { H[t] = mfma_i8(a, Bh[J & 3], H[t]); L[t] = mfma_i8(a, Bl[J & 3], L[t]); }            \
+            }                                                                                                 \
+            const uint8_t *src = (J < 4 ? blkc : blkn) + (((J + 4) & 7) * 2) * 1024 + b_off;                  \
+            Bh[J & 3] = *reinterpret_cast<const i32x4 *>(src);                                                \
+            Bl[J & 3] = *reinterpret_cast<const i32x4 *>(src + 1024);                                         \
+        }
+        KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
+#undef KSTEP
+        const float dd = h2f((uint16_t)(mcur.x & 0xffff));
+        float dm = 0.0f;
+        i32x4 bm = {0, 0, 0, 0};
+        if (MINS) {
+            dm = h2f((uint16_t)(mcur.x >> 16));
+            if (kg == 0) {
+                bm.x = (int)perm(0, mcur.y, 0x01010000u); bm.y = (int)perm(0, mcur.y, 0x03030202u);
+                bm.z = (int)perm(0, mcur.z, 0x01010000u); bm.w = (int)perm(0, mcur.z, 0x03030202u);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int tl = (tw * MT + t) * 32;
+            i32x16 ms;                                // block-sum term: 64 * (bh . m) + (bl . m) in ONE accumulator
+            if (MINS) {
+                i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0};
+                if (kg == 0) {
+                    ah = *reinterpret_cast<const i32x4 *>(s_bh + (tl + n) * 16);
+                    al = *reinterpret_cast<const i32x4 *>(s_bl + (tl + n) * 16);
+                }
+                i32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0;
+                ms = mfma_i8(ah, bm, z);
+#pragma unroll
+                for (int r = 0; r < 16; r++) ms[r] <<= 6;
+                ms = mfma_i8(al, bm, ms);
+            }
+#pragma unroll
+            for (int rq = 0; rq < 4; rq++) {
+                const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + tl + 8 * rq + 4 * kg);
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++) {
+                    const int r = rq * 4 + ri;
+                    const float yd = yd4[ri];
+                    const int isum = (H[t][r] << SH) + L[t][r];
+                    if (MINS) {
+                        facc[t][r] += (dd * yd) * (float)isum - (dm * yd) * (float)ms[r];
+                    } else {
+                        facc[t][r] += (dd * yd) * (float)isum;
+                    }
+                }
+            }
+        }
+        __syncthreads();                             // every wave is done reading this tile
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < G::NST; i++) if (tid + NTHREADS * i < G::TOK_TILE * 16) *reinterpret_cast<u32x4 *>(s_aq + st_l[i]) = nxt[i];
+            if (tid < G::TOK_TILE) {
+                s_yd[tid] = nyd;
+                if (MINS) {
+                    *reinterpret_cast<u32x4 *>(s_bh + tid * 16) = nbh;
+                    *reinterpret_cast<u32x4 *>(s_bl + tid * 16) = nbl;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tile_ok) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int gt = tok0 + (tw * MT + t) * 32 + m;
+                if (gt < T && row0 + n < n_rows) {
+                    const size_t o = (size_t)gt * ld_out + row0 + n;
+                    out[o] = resid ? resid[o] + facc[t][r] : facc[t][r];
+                }
+            }
+    }
+}
+
+// per-16 block sums of Q8_K split into int8 planes: bsum = 64*hi + lo, hi in [-32, 31], lo in [0, 63]
+__global__ void mmq_prep_kernel(const int16_t *bsums, size_t n, int8_t *bh, int8_t *bl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over T * K/16
     if (i >= n) return;
-    const int s = (int)bsums[2 * i] + (int)bsums[2 * i + 1];
+    const int s = (int)bsums[i];
     const int hi = s >> 6;                    // arithmetic shift: floor(s / 64)
     bh[i] = (int8_t)hi;
     bl[i] = (int8_t)(s - 64 * hi);
 }
 
+template <int TYPE, int MT>
+hipError_t launch_one(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
+                      float *out, int ld_out, const float *resid, hipStream_t st) {
+    using G = Geo<MT>;
+    const int nrt = (n_rows + G::ROW_TILE - 1) / G::ROW_TILE, ntt = (T + G::TOK_TILE - 1) / G::TOK_TILE;
+    const int groups = (nrt + 7) / 8;                                   // row tiles in groups of 8 (one per XCD)
+    const dim3 grid((unsigned)(groups * ntt * 8));
+    hipLaunchKernelGGL((mmq_kernel<TYPE, MT>), grid, dim3(NTHREADS), (size_t)G::LDS_BYTES, st, W, row_bytes, n_rows, K, T, nrt, ntt,
+                       q.qs, q.d, bh, bl, out, ld_out, resid);
+    return hipGetLastError();
+}
+
+int g_mmq_mt = 0;   // 0 = by T; tools may force 1 / 2 / 4
+
+template <int TYPE>
+hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
+                       float *out, int ld_out, const float *resid, hipStream_t st) {
+    static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
+    int mt = T <= 32 ? 1 : 2;
+    if (env_mt == 1 || env_mt == 2 || env_mt == 4) mt = env_mt;
+    if (g_mmq_mt == 1 || g_mmq_mt == 2 || g_mmq_mt == 4) mt = g_mmq_mt;
+    switch (mt) {
+        case 1: return launch_one<TYPE, 1>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
+        case 2: return launch_one<TYPE, 2>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
+        default: return launch_one<TYPE, 4>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
+    }
+}
+
 }  // namespace
 
-bool mmq_applicable(int type, int K, int T) {
-    return (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K) && (K % 256) == 0 && T >= 32;
+void mmq_set_tiles(int mt) { g_mmq_mt = mt; }
+
+size_t mmq_planes_bytes(int type, int64_t n_rows, int K) {
+    if ((type != T_Q4_K && type != T_Q5_K && type != T_Q6_K) || (K % 256) != 0) return 0;
+    return (size_t)((n_rows + 31) / 32) * (size_t)(K >> 8) * PL_BLOCK;
 }
-size_t mmq_prep_bytes(int K, int T) { return (size_t)T * (K >> 5); }
+
+hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *planes, hipStream_t st) {
+    const int nb = K >> 8, n_rt = (n_rows + 31) / 32;
+    const dim3 grid((unsigned)((n_rt * nb + 3) / 4));
+    switch (type) {
+        case T_Q4_K: hipLaunchKernelGGL(mmq_expand_kernel<T_Q4_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
+        case T_Q5_K: hipLaunchKernelGGL(mmq_expand_kernel<T_Q5_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
+        case T_Q6_K: hipLaunchKernelGGL(mmq_expand_kernel<T_Q6_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
+                             float *out, int ld_out, const float *resid, hipStream_t st) {
+    static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
+    int mt = T <= 32 ? 1 : 2;
+    if (env_mt == 1 || env_mt == 2) mt = env_mt;
+    if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
+    const bool mins = type != T_Q6_K;
+#define PLN(MINSV, MTV)                                                                                                   \
+    {                                                                                                                     \
+        using G = Geo<MTV>;                                                                                               \
+        const int nrt = (n_rows + G::ROW_TILE - 1) / G::ROW_TILE, ntt = (T + G::TOK_TILE - 1) / G::TOK_TILE;              \
+        const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));                                                           \
+        hipLaunchKernelGGL((mmq_planes_kernel<MINSV, MTV>), grid, dim3(NTHREADS), (size_t)G::LDS_BYTES, st, planes, n_rows, K, T, nrt, ntt, \
+                           q.qs, q.d, bh, bl, out, ld_out, resid);                                                        \
+    }
+    if (mins) { if (mt == 1) PLN(true, 1) else PLN(true, 2) }
+    else { if (mt == 1) PLN(false, 1) else PLN(false, 2) }
+#undef PLN
+    return hipGetLastError();
+}
+
+bool mmq_applicable(int type, int K, int T) {
+    return (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K) && (K % 256) == 0 && T >= 32 && (size_t)T * (size_t)K < (1ull << 32);
+}
+size_t mmq_prep_bytes(int K, int T) { return (size_t)T * (K >> 4); }
 
 hipError_t launch_mmq_prep(const ActQuant &q, int K, int T, int8_t *bh, int8_t *bl, hipStream_t st) {
-    const size_t n = (size_t)T * (K >> 5);
-    hipLaunchKernelGGL(mmq_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q.bsums, K, T, bh, bl);
+    const size_t n = (size_t)T * (K >> 4);
+    hipLaunchKernelGGL(mmq_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q.bsums, n, bh, bl);
     return hipGetLastError();
 }
 
 // out[t * ld_out + r] = (resid ? resid[...] : 0) + dot(W[r], act[t]);  bh/bl from launch_mmq_prep
 hipError_t launch_mmq(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
                       const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st) {
-    const dim3 grid((n_rows + ROW_TILE - 1) / ROW_TILE, (T + TOK_TILE - 1) / TOK_TILE);
-    const size_t lds = (size_t)TOK_TILE * A_STRIDE + TOK_TILE * 16 + TOK_TILE * 4;
     switch (type) {
-        case T_Q4_K: hipLaunchKernelGGL(mmq_kernel<T_Q4_K>, grid, dim3(512), lds, st, W, row_bytes, n_rows, K, T, q.qs, q.d, bh, bl, out, ld_out, resid); break;
-        case T_Q5_K: hipLaunchKernelGGL(mmq_kernel<T_Q5_K>, grid, dim3(512), lds, st, W, row_bytes, n_rows, K, T, q.qs, q.d, bh, bl, out, ld_out, resid); break;
-        case T_Q6_K: hipLaunchKernelGGL(mmq_kernel<T_Q6_K>, grid, dim3(512), lds, st, W, row_bytes, n_rows, K, T, q.qs, q.d, bh, bl, out, ld_out, resid); break;
+        case T_Q4_K: return launch_type<T_Q4_K>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
+        case T_Q5_K: return launch_type<T_Q5_K>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
+        case T_Q6_K: return launch_type<T_Q6_K>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace mi355

@@ -40,7 +40,7 @@ static bool type_supported(int t) {
     return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K;
 }
 
-Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status) {
+Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes) {
     status = 0;
     std::unique_ptr<Model> m(new Model());
     m->file.reset(new GGUFFile());
@@ -168,6 +168,40 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     if (!m->output.valid()) m->output = m->tok_embd;   // tied embeddings
     m->device_bytes = total;
     m->host_bytes = 0;
+
+    // prompt-processing copy of the per-layer projection weights: both int8 MFMA operand planes of every K-step,
+    // expanded once here (2 B per weight) so that the prefill kernel spends nothing per weight (mmq.hip).  288 GB of HBM
+    // is what makes this the default; it is skipped (the prefill kernel then expands on the fly) when memory is short.
+    if (const char *e = getenv("MI355_PREFILL_PLANES")) prefill_planes = atoi(e);
+    if (prefill_planes != 0) {
+        std::vector<DevTensor *> want;
+        for (auto &L : m->layers)
+            for (DevTensor *d : {&L.wq, &L.wk, &L.wv, &L.wo, &L.gate, &L.up, &L.down})
+                if (d->valid() && d->n_expert == 1 && mmq_planes_bytes(d->type, d->N, (int)d->K)) want.push_back(d);
+        size_t need = 0;
+        for (DevTensor *d : want) need += (mmq_planes_bytes(d->type, d->N, (int)d->K) + 255) & ~(size_t)255;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t reserve = (size_t)24 << 30;             // KV cache, activations, other contexts
+        const bool fits = need > 0 && free_b > need + reserve;
+        if (need > 0 && !fits && prefill_planes == 1) { err = "not enough device memory for the prefill planes (" + std::to_string(need >> 20) + " MiB)"; status = -104; return nullptr; }
+        if (fits) {
+            uint8_t *parena = nullptr;
+            if (hipMalloc(&parena, need) != hipSuccess) { err = "hipMalloc of the prefill planes failed"; status = -104; return nullptr; }
+            m->arenas.push_back(parena);
+            size_t off = 0;
+            for (DevTensor *d : want) {
+                d->planes = parena + off;
+                d->planes_bytes = mmq_planes_bytes(d->type, d->N, (int)d->K);
+                off += (d->planes_bytes + 255) & ~(size_t)255;
+                const hipError_t e = launch_mmq_expand(d->type, d->data, d->row_bytes, (int)d->N, (int)d->K, d->planes, nullptr);
+                if (e != hipSuccess) { err = std::string("plane expansion of ") + d->name + " failed: " + hipGetErrorString(e); status = -105; return nullptr; }
+            }
+            if (hipDeviceSynchronize() != hipSuccess) { err = "plane expansion failed"; status = -105; return nullptr; }
+            m->planes_bytes = need;
+            m->device_bytes += need;
+        }
+    }
 
     // algorithmic bytes per decoded token: each tensor once, one embedding row, used experts only
     uint64_t bpt = 0;
@@ -299,8 +333,8 @@ bool Context::init(std::string &err) {
     alloc_actq(aq_e_, E, T, true, true, allocs_, device_bytes, ok);
     alloc_actq(aq_o_, E, T, true, true, allocs_, device_bytes, ok);
     alloc_actq(aq_ff_, FF, T, true, true, allocs_, device_bytes, ok);
-    mmq_bh_ = (int8_t *)dalloc(T * (std::max(E, FF) / 32));
-    mmq_bl_ = (int8_t *)dalloc(T * (std::max(E, FF) / 32));
+    mmq_bh_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), (int)T));
+    mmq_bl_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), (int)T));
     if (!ok || !x_ || !ffn_u_) { err = "activation buffer allocation failed"; return false; }
 
     size_t ws = 0;
@@ -470,7 +504,8 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
         if (mmq_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // prompt processing: MFMA path
-            HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+            if (w.type != T_Q6_K || !w.planes) HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+            if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
             return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
@@ -487,8 +522,10 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     for (int i = 0; i < n; i++) all_mmq &= mmq_applicable(ws[i]->type, K, T);
     if (all_mmq && pending_fuse_.mode == 0) {
         HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
-        for (int i = 0; i < n; i++)
-            HIP_TRY(launch_mmq(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
+        for (int i = 0; i < n; i++) {
+            if (ws[i]->planes) HIP_TRY(launch_mmq_planes(ws[i]->type, ws[i]->planes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
+            else HIP_TRY(launch_mmq(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
+        }
         return hipSuccess;
     }
     if (all_q && n <= 3) {

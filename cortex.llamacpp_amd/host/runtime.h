@@ -28,6 +28,8 @@ struct DevTensor {
     size_t row_bytes = 0;   // device row stride
     size_t bytes = 0;       // device bytes
     size_t ggml_bytes = 0;  // on-disk bytes
+    uint8_t *planes = nullptr;   // pre-expanded MFMA operand planes for prompt processing (mmq.hip), optional
+    size_t planes_bytes = 0;
     bool valid() const { return data != nullptr; }
 };
 
@@ -53,11 +55,12 @@ struct Model {
     std::vector<uint8_t *> arenas;      // hipMalloc'd blocks
     DevTensor tok_embd, out_norm, output, rope_freqs;
     std::vector<LayerWeights> layers;
-    uint64_t device_bytes = 0, host_bytes = 0, file_tensor_bytes = 0, bytes_per_token = 0;
+    uint64_t device_bytes = 0, host_bytes = 0, file_tensor_bytes = 0, bytes_per_token = 0, planes_bytes = 0;
     ~Model();
 };
 
-Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status);
+// prefill_planes: 0 = never, 1 = always (fails when memory is short), -1 = when device memory allows (default)
+Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes = -1);
 
 struct KVCell {
     int32_t pos = -1;

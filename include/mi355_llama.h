@@ -68,6 +68,9 @@ typedef struct mi355_model_params {
     /* row-split tensor parallelism over RCCL (new keys proposed in SURVEY.md §2b) */
     int32_t tp_rank;        /* 0 when tp_size <= 1 */
     int32_t tp_size;        /* 1 = whole model on this GPU */
+    /* prompt-processing copy of the projection weights as pre-expanded int8 MFMA operand planes (2 B / weight):
+     * -1 = keep it when device memory allows (default), 0 = never (expand on the fly), 1 = required */
+    int32_t prefill_planes;
 } mi355_model_params;
 
 MI355_API mi355_model_params mi355_model_default_params(void);
@@ -87,6 +90,7 @@ MI355_API uint64_t mi355_model_cpu_buffer(const mi355_model *m);    /* llama_get
 MI355_API uint64_t mi355_model_other_buffer(const mi355_model *m);  /* llama_get_other_buffer -> `vram` */
 /* algorithmic weight bytes one decoded token reads; for roofline reporting */
 MI355_API uint64_t mi355_model_bytes_per_token(const mi355_model *m);
+MI355_API uint64_t mi355_model_planes_bytes(const mi355_model *m);  /* device bytes of the prefill planes (0 = none) */
 MI355_API const char *mi355_model_desc(const mi355_model *m);
 /* GGUF metadata lookup: returns 1 and fills buf if `key` exists and is a string/scalar */
 MI355_API int mi355_model_meta_str(const mi355_model *m, const char *key, char *buf, size_t buf_size);
@@ -207,6 +211,11 @@ MI355_API void mi355_engine_handle_chat_completion(mi355_engine *e, const char *
 MI355_API void mi355_engine_handle_embedding(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
 MI355_API int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature);
 MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id);
+
+/* Test / tool switches of the per-op entry points: "mmq_planes" (1: mi355_op_mul_mat with T >= 32 expands the weight
+ * into MFMA planes first, as a loaded model does; 0: expands on the fly inside the kernel), "mmq_tiles" (0 | 1 | 2 | 4
+ * token tiles per wave).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
+MI355_API int mi355_debug_set_option(const char *name, int32_t value);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* Streams `bytes` through a read-only reduction kernel `iters` times; returns achieved GB/s (HIP events). */

@@ -63,6 +63,28 @@ def test_mul_mat_int_partials_exact_and_value(be, t, K, N, T):
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
+@pytest.mark.parametrize("planes", [0, 1])
+@pytest.mark.parametrize("tiles", [1, 2])
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
+@pytest.mark.parametrize("K,N,T", [(2048, 130, 40), (4096, 300, 129), (5632, 37, 33), (4096, 70, 512), (14336, 40, 96)])
+def test_mul_mat_mfma_prefill_paths(be, t, K, N, T, planes, tiles):
+    """Prompt-processing contraction on the matrix cores, both forms (weights expanded into int8 operand planes ahead of
+    time / on the fly) and both wave tilings; ragged row and token tails.  The integer sums are exact by construction
+    (scale folded into the weight, two int8 planes), so only the f32 order over super-blocks differs from the oracle."""
+    rng = np.random.default_rng(K + N + T + t)
+    W = rand_weights(rng, t, N * K)
+    x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
+    be.set_option("mmq_planes", planes)
+    be.set_option("mmq_tiles", tiles)
+    try:
+        y = be.mul_mat(t, W, N, K, x)
+    finally:
+        be.set_option("mmq_planes", 1)
+        be.set_option("mmq_tiles", 0)
+    ref = oq.mul_mat(t, W, N, K, x)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
 def test_mul_mat_f32_f16_weights(be):
     rng = np.random.default_rng(5)
     N, K, T = 8, 512, 3
