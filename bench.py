@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 / fp8 matrix-core peak of MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
@@ -157,6 +158,23 @@ def main() -> int:
     achieved = sweep_bytes / (sweep_us * 1e-6) / 1e9
     hbm_read = pkg.Backend().hbm_read_gbps(2 << 30, 5)
 
+    # HBM bytes the same sweep moved, from the PMC pass committed under profiles/ (FETCH_SIZE, corrected x2 per the gfx950
+    # note of the microarchitecture guide); null when the profile is absent or is for another workload
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_decode_traffic.json")
+    if os.path.exists(tpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
+        try:
+            with open(tpath) as f:
+                traffic = int(json.load(f)["matvec_hbm_read_bytes_per_token"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
+
+    # prompt processing against the matrix-core peak: 2 * (projection weights) * tokens, int8 MFMA dense peak
+    E, FF, L_, GD = cfg.n_embd, cfg.n_ff, cfg.n_layer, cfg.n_head_kv * cfg.head_dim
+    p_layer = E * E * 2 + 2 * E * GD + 3 * E * FF
+    prefill_ops = 2.0 * p_layer * L_ * args.prompt + 4.0 * (args.prompt / 2.0) * E * L_ * args.prompt
+    prefill_tops = prefill_ops / t_prefill / 1e12
+
     kv_pos_mid = args.prompt + args.warmup + args.steps // 2
     b_per = {"f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.cache_type]
     kv_bytes = 2 * cfg.n_layer * cfg.n_head_kv * cfg.head_dim * kv_pos_mid * b_per
@@ -194,11 +212,21 @@ def main() -> int:
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "bytes_per_sweep": int(sweep_bytes),
             "launches_per_sweep": n_launch,
             "avg_launch_us": round(sweep_us / n_launch, 3),
             "measured_stream_read_GBps": round(hbm_read, 1),
+        },
+        "prefill_roofline": {
+            "bound": "mfma",
+            "kernel": "mmq_planes_kernel (int8 v_mfma_i32_32x32x32_i8, weights pre-expanded into two exact int8 planes)",
+            "achieved": round(prefill_tops, 1),
+            "peak": MFMA_I8_PEAK_TOPS,
+            "unit": "TOP/s",
+            "frac": round(prefill_tops / MFMA_I8_PEAK_TOPS, 4),
+            "note": "algorithmic ops (2 x weights x tokens + attention); the kernel issues 2x the MACs (hi / lo planes)",
+            "planes_bytes": int(model.planes_bytes),
         },
         "load_s": round(t_load, 2),
         "synth_s": round(t_gen, 2),

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void mmq_expand_kernel(const uint8_t *W, size_
 template <bool MINS, int MT>
 __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
                                                               const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
-                                                              float *out, int ld_out, const float *resid) {
+                                                              float *out, int ld_out, const float *resid, int exp) {
     using G = Geo<MT>;
     constexpr int SH = MINS ? 5 : 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -528,15 +528,23 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
                     H[t] = mfma_i8(a, Bh[J & 3], z); L[t] = mfma_i8(a, Bl[J & 3], z);                         \
                 } else { H[t] = mfma_i8(a, Bh[J & 3], H[t]); L[t] = mfma_i8(a, Bl[J & 3], L[t]); }            \
             }                                                                                                 \
+            if (!(exp & 1)) {                                                                                 \
             const uint8_t *src = (J < 4 ? blkc : blkn) + (((J + 4) & 7) * 2) * 1024 + b_off;                  \
             Bh[J & 3] = *reinterpret_cast<const i32x4 *>(src);                                                \
             Bl[J & 3] = *reinterpret_cast<const i32x4 *>(src + 1024);                                         \
+            }                                                                                                 \
         }
         KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
 #undef KSTEP
         const float dd = h2f((uint16_t)(mcur.x & 0xffff));
         float dm = 0.0f;
         i32x4 bm = {0, 0, 0, 0};
+        if (exp & 4) {
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) facc[t][r] += (float)(H[t][r] + L[t][r]);
+        } else {
         if (MINS) {
             dm = h2f((uint16_t)(mcur.x >> 16));
             if (kg == 0) {
@@ -578,6 +586,8 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
                 }
             }
         }
+        }
+        if (exp & 2) continue;
         __syncthreads();                             // every wave is done reading this tile
         if (more) {
 #pragma unroll
@@ -679,8 +689,9 @@ hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K,
         const int nrt = (n_rows + G::ROW_TILE - 1) / G::ROW_TILE, ntt = (T + G::TOK_TILE - 1) / G::TOK_TILE;              \
         const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));                                                           \
         hipLaunchKernelGGL((mmq_planes_kernel<MINSV, MTV>), grid, dim3(NTHREADS), (size_t)G::LDS_BYTES, st, planes, n_rows, K, T, nrt, ntt, \
-                           q.qs, q.d, bh, bl, out, ld_out, resid);                                                        \
+                           q.qs, q.d, bh, bl, out, ld_out, resid, env_exp);                                               \
     }
+    static const int env_exp = getenv("MI355_MMQ_EXP") ? atoi(getenv("MI355_MMQ_EXP")) : 0;
     if (mins) { if (mt == 1) PLN(true, 1) else PLN(true, 2) }
     else { if (mt == 1) PLN(false, 1) else PLN(false, 2) }
 #undef PLN

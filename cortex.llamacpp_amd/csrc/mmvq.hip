@@ -662,7 +662,8 @@ static void launch_nt(const MMVQArgs &a, int blocks, int bs, size_t lds, hipStre
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     static const bool fast_init = (mmvq_fast_set_threads(getenv("MI355_MMVQ_NT") ? atoi(getenv("MI355_MMVQ_NT")) : 0), true);
     (void)fast_init;
-    if (mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
+    static const bool fast_on = !(getenv("MI355_MMVQ_FAST") && getenv("MI355_MMVQ_FAST")[0] == '0');   // diagnosis switch
+    if (fast_on && mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
     if ((a.T == 16 || a.T == 8) && a.fuse_mode == 0) {
         bool moe = false;
         for (int s = 0; s < a.n_seg; s++) moe |= a.seg[s].expert_sel != nullptr;

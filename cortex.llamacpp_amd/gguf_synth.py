@@ -161,6 +161,9 @@ CONFIGS = {
     "tiny-d128": LlamaConfig("tiny-d128", 1024, 2, 8, 2, 2048, 512, 500000.0, 1e-5, 1024),      # head_dim 128, GQA 4:1
     "tiny-d128-mha": LlamaConfig("tiny-d128-mha", 512, 2, 4, 4, 1024, 512, 10000.0, 1e-5, 1024),  # head_dim 128, MHA
     "tiny-moe": LlamaConfig("tiny-moe", 256, 2, 4, 2, 512, 512, 1e6, 1e-5, 512, 8, 2),
+    # hidden sizes that are multiples of 2048: the shapes the persistent single-token mat-vec (fused RMSNorm / quantise
+    # prologues) and the MFMA prefill planes are built for
+    "tiny-e2048": LlamaConfig("tiny-e2048", 2048, 2, 16, 4, 4096, 512, 500000.0, 1e-5, 1024),
 }
 
 FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17}

@@ -353,6 +353,9 @@ bool Context::init(std::string &err) {
     if (hipHostMalloc((void **)&h_argmax_, T * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     embeddings_enabled = cp.embeddings;
     kv_clear();
+    // the zero-fills above ran on the null stream, which the context's non-blocking stream does not wait for: drain them
+    // before any kernel can touch these buffers (a late fill would wipe live KV rows; seen under rocprofv3 --pmc)
+    if (hipDeviceSynchronize() != hipSuccess) { err = "device synchronise failed"; return false; }
     return true;
 }
 
@@ -700,7 +703,8 @@ hipError_t Context::run_output(int n_out, int out_base) {
     prof_mark("lm_head");
     for (int r0 = 0; r0 < n_out; r0 += (int)cp.n_ubatch) {
         const int nr = std::min((int)cp.n_ubatch, n_out - r0);
-        HIP_TRY(launch_argmax_rows(lg + (size_t)r0 * V, V, nr, d_argmax_ + out_base + r0, argmax_scratch_, stream_));
+        // the winner goes straight into pinned host memory (visible once the stream has drained): no copy node
+        HIP_TRY(launch_argmax_rows(lg + (size_t)r0 * V, V, nr, h_argmax_ + out_base + r0, argmax_scratch_, stream_));
     }
     prof_mark("argmax");
     return hipSuccess;
@@ -742,6 +746,10 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         if (flags[i]) h_out[n_out++] = i;
     }
     if (hipMemcpyAsync(d_stage_, h_stage_, stage_bytes_, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "token upload failed"; return -1; }
+    // rocprofv3 --pmc does not keep copy-engine transfers ordered with the kernels it serialises (observed: kernels reading
+    // the previous step's token / position block); MI355_PROFILER_SAFE=1 drains the stream around the transfers
+    static const bool profiler_safe = getenv("MI355_PROFILER_SAFE") && getenv("MI355_PROFILER_SAFE")[0] == '1';
+    if (profiler_safe) (void)hipStreamSynchronize(stream_);
     if (!stage_event_) (void)hipEventCreateWithFlags(&stage_event_, hipEventDisableTiming);
     if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
@@ -759,7 +767,6 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
             if (e == hipSuccess) {
                 hipError_t e2 = run_layers(1, bucket);
                 if (e2 == hipSuccess) e2 = run_output(1, 0);
-                if (e2 == hipSuccess) e2 = hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, stream_);
                 if (e2 == hipSuccess && cp.logits_to_host) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
                 e = hipStreamEndCapture(stream_, &g);
                 if (e2 != hipSuccess) e = e2;
@@ -774,7 +781,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         prof_begin();
         e = run_layers(n, n_kv_);
         if (e == hipSuccess) e = run_output(n_out, out_base);
-        if (e == hipSuccess && n_out > 0) e = hipMemcpyAsync(h_argmax_ + out_base, d_argmax_ + out_base, (size_t)n_out * 4, hipMemcpyDeviceToHost, stream_);
+        if (profiler_safe) (void)hipStreamSynchronize(stream_);
         if (e == hipSuccess && n_out > 0 && cp.logits_to_host)
             e = hipMemcpyAsync(h_logits_ + (size_t)out_base * V, d_logits_ + (size_t)out_base * V, (size_t)n_out * V * 4, hipMemcpyDeviceToHost, stream_);
         prof_end();
@@ -827,6 +834,7 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
             if (hipHostMalloc((void **)&h_argmax_, rows * 4, hipHostMallocDefault) != hipSuccess) return -1;
         }
         logits_cap_rows_ = rows;
+        (void)hipDeviceSynchronize();                  // null-stream zero-fills of the new buffers (see init)
         for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
         graphs_.clear();
         graph_exec_ = nullptr;
