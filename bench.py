@@ -30,6 +30,47 @@ MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 / fp8 matrix-core peak of MI355X (M
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
+def aggregate(n_gpus: int, steps: int, dt_max: float) -> dict:
+    """Whole-job numbers from the slowest rank's wall time: every rank decoded `steps` tokens of its own sequence."""
+    return {"value": round(n_gpus * steps / dt_max, 2), "ms_per_step": round(dt_max / steps * 1e3, 4)}
+
+
+def simulate(args) -> int:
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    step_s = 0.002 * (1 + rank)                      # rank r is (r + 1) x slower: the MAX over ranks must win
+    for _ in range(args.warmup):
+        time.sleep(step_s)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(step_s)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        out = {"metric": "decode tok/s (simulated step)", "unit": "tok/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "simulated",
+               "config": {"workload": "sleep-based stand-in for the decode step", "parallelism": f"{world} replicas, no collective"},
+               "roofline": None, "cpu_baseline": None}
+        out.update(aggregate(args.gpus, args.steps, dt))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,7 +85,12 @@ def main() -> int:
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--model-dir", default=os.environ.get("MI355_BENCH_DIR", "/tmp"))
     ap.add_argument("--keep-model", action="store_true")
+    ap.add_argument("--simulate", action="store_true",
+                    help="no GPU: the same rank bookkeeping (rendezvous over gloo, barriers, MAX over ranks, rank-0 JSON) around a "
+                         "sleep standing in for the decode step; used by the two-rank CPU test")
     args = ap.parse_args()
+    if args.simulate:
+        return simulate(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,12 +224,12 @@ def main() -> int:
     kv_pos_mid = args.prompt + args.warmup + args.steps // 2
     b_per = {"f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.cache_type]
     kv_bytes = 2 * cfg.n_layer * cfg.n_head_kv * cfg.head_dim * kv_pos_mid * b_per
-    tok_s = n_gpus * args.steps / dt
+    tok_s = aggregate(n_gpus, args.steps, dt)["value"]
     decode_frac = (model.bytes_per_token + kv_bytes) * (args.steps / dt) / (HBM_PEAK_GBPS * 1e9)
 
     out = {
         "metric": "decode tok/s, Llama-3-8B Q4_K_M GGUF (prefill tok/s in `prefill_tok_s`)",
-        "value": round(tok_s, 2),
+        "value": tok_s,
         "unit": "tok/s",
         "n_gpus": n_gpus,
         "steps": args.steps,

@@ -366,16 +366,22 @@ __global__ __launch_bounds__(NTHREADS) void mmq_kernel(const uint8_t *W, size_t 
     // store: lane = weight row n, regs = tokens; 32 consecutive rows per token -> 128-B coalesced
     if (row_ok) {
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int t = 0; t < MT; t++) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                int gt = tok0 + (tw * MT + t) * 32 + m;
+                if (gt >= T) gt = T - 1;
+                rv[r] = resid ? resid[(size_t)gt * ld_out + row0 + n] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
                 const int gt = tok0 + (tw * MT + t) * 32 + m;
-                if (gt < T) {
-                    const size_t o = (size_t)gt * ld_out + row0 + n;
-                    out[o] = resid ? resid[o] + facc[t][r] : facc[t][r];
-                }
+                if (gt < T) out[(size_t)gt * ld_out + row0 + n] = rv[r] + facc[t][r];
             }
+        }
     }
 }
 
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256) void mmq_expand_kernel(const uint8_t *W, size_
 template <bool MINS, int MT>
 __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
                                                               const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
-                                                              float *out, int ld_out, const float *resid, int exp) {
+                                                              float *out, int ld_out, const float *resid) {
     using G = Geo<MT>;
     constexpr int SH = MINS ? 5 : 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -518,33 +524,32 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
         const uint8_t *blkc = blk0 + (size_t)sb * PL_BLOCK;
         // K-step J: MFMAs on ring slot J & 3, then the slot is refilled with the operand four K-steps ahead (same
         // super-block for J < 4, the next one otherwise): every B register waits half an iteration before its use
-#define KSTEP(J)                                                                                              \
+        // A fragments are read one K-step ahead of the MFMAs that use them (two register sets)
+        i32x4 a0[MT], a1[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) a0[t] = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE);
+#define KSTEP(J, ACUR, ANXT)                                                                                  \
         {                                                                                                     \
+            if (J < 7) {                                                                                      \
+                _Pragma("unroll") for (int t = 0; t < MT; t++)                                                \
+                    ANXT[t] = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * (J + 1));     \
+            }                                                                                                 \
             _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
-                const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * J);          \
                 if (J == 0) {                                                                                 \
                     i32x16 z;                                                                                 \
                     _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                  \
-                    H[t] = mfma_i8(a, Bh[J & 3], z); L[t] = mfma_i8(a, Bl[J & 3], z);                         \
-                } else { H[t] = mfma_i8(a, Bh[J & 3], H[t]); L[t] = mfma_i8(a, Bl[J & 3], L[t]); }            \
+                    H[t] = mfma_i8(ACUR[t], Bh[J & 3], z); L[t] = mfma_i8(ACUR[t], Bl[J & 3], z);             \
+                } else { H[t] = mfma_i8(ACUR[t], Bh[J & 3], H[t]); L[t] = mfma_i8(ACUR[t], Bl[J & 3], L[t]); } \
             }                                                                                                 \
-            if (!(exp & 1)) {                                                                                 \
             const uint8_t *src = (J < 4 ? blkc : blkn) + (((J + 4) & 7) * 2) * 1024 + b_off;                  \
             Bh[J & 3] = *reinterpret_cast<const i32x4 *>(src);                                                \
             Bl[J & 3] = *reinterpret_cast<const i32x4 *>(src + 1024);                                         \
-            }                                                                                                 \
         }
-        KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
+        KSTEP(0, a0, a1) KSTEP(1, a1, a0) KSTEP(2, a0, a1) KSTEP(3, a1, a0) KSTEP(4, a0, a1) KSTEP(5, a1, a0) KSTEP(6, a0, a1) KSTEP(7, a1, a0)
 #undef KSTEP
         const float dd = h2f((uint16_t)(mcur.x & 0xffff));
         float dm = 0.0f;
         i32x4 bm = {0, 0, 0, 0};
-        if (exp & 4) {
-#pragma unroll
-            for (int t = 0; t < MT; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) facc[t][r] += (float)(H[t][r] + L[t][r]);
-        } else {
         if (MINS) {
             dm = h2f((uint16_t)(mcur.x >> 16));
             if (kg == 0) {
@@ -586,8 +591,6 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
                 }
             }
         }
-        }
-        if (exp & 2) continue;
         __syncthreads();                             // every wave is done reading this tile
         if (more) {
 #pragma unroll
@@ -602,18 +605,26 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
         }
         __syncthreads();
     }
-    if (tile_ok) {
+    // store: lane = weight row n, regs = tokens; 32 consecutive rows per token -> 128-B coalesced.  Residual values are
+    // all requested before the first add (a load + wait per element serialised the epilogue).
+    if (tile_ok && row0 + n < n_rows) {
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int t = 0; t < MT; t++) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                int gt = tok0 + (tw * MT + t) * 32 + m;
+                if (gt >= T) gt = T - 1;
+                rv[r] = resid ? resid[(size_t)gt * ld_out + row0 + n] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
                 const int gt = tok0 + (tw * MT + t) * 32 + m;
-                if (gt < T && row0 + n < n_rows) {
-                    const size_t o = (size_t)gt * ld_out + row0 + n;
-                    out[o] = resid ? resid[o] + facc[t][r] : facc[t][r];
-                }
+                if (gt < T) out[(size_t)gt * ld_out + row0 + n] = rv[r] + facc[t][r];
             }
+        }
     }
 }
 
@@ -644,14 +655,15 @@ int g_mmq_mt = 0;   // 0 = by T; tools may force 1 / 2 / 4
 template <int TYPE>
 hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                        float *out, int ld_out, const float *resid, hipStream_t st) {
+    // one token tile per wave: the expansion is VALU-bound and larger tiles spill (measured 34 ms vs 40 ms per 512-token
+    // prompt of the 8B model); MI355_MMQ_MT / mmq_set_tiles(2) select the 128 x 128 workgroup tile
     static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
-    int mt = T <= 32 ? 1 : 2;
-    if (env_mt == 1 || env_mt == 2 || env_mt == 4) mt = env_mt;
-    if (g_mmq_mt == 1 || g_mmq_mt == 2 || g_mmq_mt == 4) mt = g_mmq_mt;
+    int mt = 1;
+    if (env_mt == 1 || env_mt == 2) mt = env_mt;
+    if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
     switch (mt) {
-        case 1: return launch_one<TYPE, 1>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
         case 2: return launch_one<TYPE, 2>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
-        default: return launch_one<TYPE, 4>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
+        default: return launch_one<TYPE, 1>(W, row_bytes, n_rows, K, T, q, bh, bl, out, ld_out, resid, st);
     }
 }
 
@@ -679,7 +691,11 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                              float *out, int ld_out, const float *resid, hipStream_t st) {
     static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
-    int mt = T <= 32 ? 1 : 2;
+    // 128 x 128 workgroup tiles (two token tiles per wave) when that still yields ~2 workgroups per CU, else 256 x 32
+    // tiles, which quadruple the workgroup count (measured on the 8B shapes: gate/up 297 vs 383 us, N = 4096 tensors
+    // 54-144 vs 75-204 us per layer)
+    const long wg2 = (long)((n_rows + 127) / 128) * ((T + 127) / 128);
+    int mt = (T <= 32 || wg2 < 3L * num_cu() / 2) ? 1 : 2;
     if (env_mt == 1 || env_mt == 2) mt = env_mt;
     if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
     const bool mins = type != T_Q6_K;
@@ -689,9 +705,8 @@ hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K,
         const int nrt = (n_rows + G::ROW_TILE - 1) / G::ROW_TILE, ntt = (T + G::TOK_TILE - 1) / G::TOK_TILE;              \
         const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));                                                           \
         hipLaunchKernelGGL((mmq_planes_kernel<MINSV, MTV>), grid, dim3(NTHREADS), (size_t)G::LDS_BYTES, st, planes, n_rows, K, T, nrt, ntt, \
-                           q.qs, q.d, bh, bl, out, ld_out, resid, env_exp);                                               \
+                           q.qs, q.d, bh, bl, out, ld_out, resid);                                                        \
     }
-    static const int env_exp = getenv("MI355_MMQ_EXP") ? atoi(getenv("MI355_MMQ_EXP")) : 0;
     if (mins) { if (mt == 1) PLN(true, 1) else PLN(true, 2) }
     else { if (mt == 1) PLN(false, 1) else PLN(false, 2) }
 #undef PLN
