@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void flash_attn_split_kernel(const AttnArgs a)
 //     mat-vec (saves a launch on the decode path).
 __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits,
                                                                  ActQuant q, int want_q8k, int want_q80) {
-    __shared__ float wgt[4 * 64];
+    extern __shared__ float wgt[];                 // [hpb][splits]
     __shared__ __attribute__((aligned(16))) float merged[256];
     const int t = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int E = H * D, nblk = E >> 8;
@@ -431,20 +431,22 @@ __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *pa
                 const float m = p[(size_t)sidx * (D + 2) + D];
                 l = p[(size_t)sidx * (D + 2) + D + 1];
                 w = (m == -INFINITY) ? 0.0f : expf(m - M);
+                wgt[wave * splits + sidx] = w;
             }
             den += wave_sum(w * l);
-            if (sidx < splits && s0 == 0) wgt[wave * 64 + lane] = w;   // splits <= 64 on this path (host-checked)
         }
         const float inv = 1.0f / den;
-        if (lane < splits) wgt[wave * 64 + lane] *= inv;
+        for (int sidx = lane; sidx < splits; sidx += 64) wgt[wave * splits + sidx] *= inv;
     }
     __syncthreads();
     {
         const int e = tid, hl = e / D, d = e - hl * D;
         const float *p = part + ((size_t)t * H + h0 + hl) * splits * (D + 2) + d;
         float acc = 0.0f;
-#pragma unroll 8
-        for (int s = 0; s < splits; s++) acc += wgt[hl * 64 + s] * p[(size_t)s * (D + 2)];
+        for (int s = 0; s < splits; s++) {
+            const float w = wgt[hl * splits + s];
+            if (w != 0.0f) acc += w * p[(size_t)s * (D + 2)];        // chunks with no visible cell publish only (m, l)
+        }
         merged[e] = acc;
         out[(size_t)t * E + b * 256 + e] = acc;
     }
@@ -571,6 +573,18 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
     const int32_t tpos = a.tok_pos[t];
     const int tseq = a.tok_seq[t];
+    if (!FUSED && a.T > 1) {
+        // batched steps (one token per sequence): most chunks hold other sequences' cells only.  Decide that before
+        // touching K / V: such a chunk publishes (m, l) = (-inf, 0) and leaves; the merge skips it.
+        const int mine = (tid < C && cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
+        if (!__syncthreads_or(mine)) {
+            if (tid < R) {
+                float *dst = a.part + (((size_t)t * H + (size_t)g * R + tid) * a.splits + sp) * (D + 2);
+                dst[D] = -INFINITY; dst[D + 1] = 0.0f;
+            }
+            return;
+        }
+    }
     // q pairs: R*64 pairs, pair pp -> (head r = pp / 64, i = pp % 64); NORM pairing (2i, 2i+1)
     constexpr int NPAIR = R * 64, PPT = (NPAIR + 255) / 256;
     float2 qv[PPT], csv[PPT];
@@ -786,16 +800,15 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
 
     // ---- FUSED: ticket; the last workgroup of this kv head merges
     const int splits = a.splits;
-    __threadfence();                                   // release: this thread's partials are visible device-wide
-    __syncthreads();
+    __syncthreads();                                   // every wave's partial stores are issued and counted (vmcnt 0 before the barrier)
     if (tid == 0) {
+        // ONE release per workgroup (the barrier ordered the other waves' stores before it), then the ticket
         const unsigned old = __hip_atomic_fetch_add(fz.counters + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (old == (unsigned)splits - 1u) ? 1 : 0;
         if (last_flag) __hip_atomic_store(fz.counters + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     __syncthreads();
     if (!last_flag) return;
-    __threadfence();                                   // acquire side
     float *wgt = S;                                    // [R][64] split weights (S is free now: R * C floats)
     float *merged = accs;                              // [R * D]
     for (int r = wave; r < R; r += 4) {                // same arithmetic as flash_attn_combine_kernel
@@ -851,10 +864,10 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
 
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
-    return a.D == 128 && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 8 && a.n_kv_max <= 64 * 64 &&
+    return a.D == 128 && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 64 && a.n_kv_max <= 64 * 2048 &&
            (a.type_k == T_F16 || a.type_k == T_Q8_0) && (a.type_v == T_F16 || a.type_v == T_Q8_0);
 }
-int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }   // <= 64 (applicability check)
+int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }
 
 // q is the UN-rotated query; a.splits must be flash_attn_decode_splits(a.n_kv_max)
 hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st) {
@@ -881,7 +894,7 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     const int nblk = (a.H * a.D) >> 8;
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
-    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
                        qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
     return hipGetLastError();
 }
@@ -916,7 +929,7 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || counters) return e;
     const int nblk = (a.H * a.D) >> 8;
-    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, 1), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, 1), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
                        fz.q, fz.want_q8k, fz.want_q80);
     return hipGetLastError();
 }
@@ -960,7 +973,7 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
     const int nblk = (a.H * a.D) >> 8;
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
-    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), 0, st, a.part, a.out, a.H, a.D, a.splits,
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
                        qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
     return hipGetLastError();
 }

@@ -31,7 +31,7 @@ struct mi355_context {
 };
 
 static thread_local std::string t_err;
-static int g_op_mmq_planes = 1;
+static int g_op_mmq_planes = 1, g_op_mmq_ksplit = 1;
 static bool g_backend_ok = false;
 
 static void fail(const std::string &s) { t_err = s; }
@@ -274,6 +274,14 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
     if (quant) {
         e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, type != T_Q8_0, type == T_Q8_0, nullptr);
         if (e != hipSuccess) return hip_fail(e, "quantize");
+        if (g_op_mmq_ksplit && mmq_ksplit_applicable(type, (int)K, (int)T)) {
+            DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
+            if (!bh.p || !bl.p) return MI355_ERR_OOM;
+            e = launch_mmq_prep(ab.q, (int)K, (int)T, bh.as<int8_t>(), bl.as<int8_t>(), nullptr);
+            if (e == hipSuccess) e = launch_mmq_ksplit(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_fail(e, "mmq_ksplit");
+        } else
         if (mmq_applicable(type, (int)K, (int)T)) {
             DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
             if (!bh.p || !bl.p) return MI355_ERR_OOM;
@@ -457,6 +465,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!name) return MI355_ERR_ARG;
     if (!strcmp(name, "mmq_planes")) { g_op_mmq_planes = value != 0; return MI355_OK; }
     if (!strcmp(name, "mmq_tiles")) { mmq_set_tiles(value); return MI355_OK; }
+    if (!strcmp(name, "mmq_ksplit")) { g_op_mmq_ksplit = value != 0; return MI355_OK; }
     fail(std::string("unknown option ") + name);
     return MI355_ERR_ARG;
 }

@@ -66,6 +66,10 @@ size_t mmq_planes_bytes(int type, int64_t n_rows, int K);   // 0 if the type has
 hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *planes, hipStream_t st);
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                              float *out, int ld_out, const float *resid, hipStream_t st);
+// small batches (continuous-batching decode steps, 8 <= T <= 64): K split over the waves of a workgroup, GGUF-form weights
+bool mmq_ksplit_applicable(int type, int K, int T);
+hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
+                             const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st);
 size_t mmq_prep_bytes(int K, int T);                       // bytes of each of the two block-sum planes
 hipError_t launch_mmq_prep(const ActQuant &q, int K, int T, int8_t *bh, int8_t *bl, hipStream_t st);
 hipError_t launch_mmq(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,

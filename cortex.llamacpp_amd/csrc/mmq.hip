@@ -386,6 +386,169 @@ __global__ __launch_bounds__(NTHREADS) void mmq_kernel(const uint8_t *W, size_t 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Small token counts (continuous-batching decode steps, 8 <= T <= 64): the contraction is HBM-bound again, so the
+// weights are read in their GGUF form (0.56 B / weight, expanded in registers — at 32 tokens that VALU work runs at about
+// the HBM rate) and the parallelism comes from K instead of tokens: workgroup = 32 weight rows x (32 * MT tokens), its 8
+// waves take the super-blocks round-robin, each wave stages its OWN activation tile (no workgroup barrier in the loop),
+// and the eight partial f32 tiles are summed through LDS in fixed wave order (deterministic).
+template <int TYPE, int MT>
+__global__ __launch_bounds__(NTHREADS) void mmq_ksplit_kernel(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T,
+                                                              const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
+                                                              float *out, int ld_out, const float *resid) {
+    constexpr int TOK = 32 * MT;
+    constexpr int W_A = TOK * A_STRIDE, W_P = TOK * 16;
+    constexpr int W_BYTES = W_A + 2 * W_P + TOK * 4;            // per-wave LDS region
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int8_t *s_aq = reinterpret_cast<int8_t *>(smem + wave * W_BYTES);
+    int8_t *s_bh = s_aq + W_A, *s_bl = s_bh + W_P;
+    float *s_yd = reinterpret_cast<float *>(s_bl + W_P);
+    const int nb = K >> 8;
+    const int row0 = blockIdx.x * 32, tok0 = blockIdx.y * TOK;
+    const int n = lane & 31, kg = lane >> 5;
+    int my_row = row0 + n;
+    const bool row_ok = my_row < n_rows;
+    if (!row_ok) my_row = n_rows - 1;
+    const uint8_t *rowp = W + (size_t)my_row * row_bytes;
+
+    // staging roles of this wave: piece p = lane + 64 i -> token p / 16, 16-byte column p % 16
+    constexpr int NST = TOK * 16 / 64;
+    int ptok = tok0 + (lane < TOK ? lane : 0);
+    if (ptok >= T) ptok = T - 1;
+    const unsigned pl_g = (unsigned)ptok * (unsigned)nb;
+
+    float facc[MT][16];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) facc[t][r] = 0.0f;
+
+    for (int sb = wave; sb < nb; sb += 8) {
+        RowSB<TYPE> R;
+        R.load(rowp, nb, sb, kg);
+        {   // this wave's activation tile of super-block sb
+            u32x4 tmp[NST];
+#pragma unroll
+            for (int i = 0; i < NST; i++) {
+                const int p = lane + 64 * i;
+                int gt = tok0 + (p >> 4);
+                if (gt >= T) gt = T - 1;
+                tmp[i] = ldg16(aq + (size_t)gt * K + (size_t)sb * 256 + (p & 15) * 16);
+            }
+            float yd = 0.0f;
+            u32x4 vbh = {0, 0, 0, 0}, vbl = {0, 0, 0, 0};
+            if (lane < TOK) {
+                yd = ad[pl_g + (unsigned)sb];
+                if (TYPE != T_Q6_K) {
+                    vbh = ldg16(abh + ((size_t)pl_g + (unsigned)sb) * 16);
+                    vbl = ldg16(abl + ((size_t)pl_g + (unsigned)sb) * 16);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                    // the previous tile's reads are done (in-order LDS per wave)
+#pragma unroll
+            for (int i = 0; i < NST; i++) {
+                const int p = lane + 64 * i;
+                *reinterpret_cast<u32x4 *>(s_aq + (p >> 4) * A_STRIDE + (p & 15) * 16) = tmp[i];
+            }
+            if (lane < TOK) {
+                s_yd[lane] = yd;
+                if (TYPE != T_Q6_K) {
+                    *reinterpret_cast<u32x4 *>(s_bh + lane * 16) = vbh;
+                    *reinterpret_cast<u32x4 *>(s_bl + lane * 16) = vbl;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        i32x16 H[MT], L[MT];
+        const int8_t *abase = s_aq + n * A_STRIDE + 16 * kg;
+        uint32_t sc_lo = 0, sc_hi = 0, mn_lo = 0, mn_hi = 0;
+        if constexpr (TYPE != T_Q6_K) R.scales(sc_lo, sc_hi, mn_lo, mn_hi);
+#define KSTEP(J)                                                                                              \
+        {                                                                                                     \
+            i32x4 bh, bl;                                                                                     \
+            if constexpr (TYPE == T_Q6_K) R.template bop_signed<J>(R.scale_pk(8 * (J >> 2) + 2 * (J & 3) + kg), bh, bl); \
+            else R.template bop<J>(((J < 4 ? sc_lo : sc_hi) >> (8 * (J & 3))) & 0xff, bh, bl);                \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * J);          \
+                if (J == 0) {                                                                                 \
+                    i32x16 z;                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                  \
+                    H[t] = mfma_i8(a, bh, z); L[t] = mfma_i8(a, bl, z);                                       \
+                } else { H[t] = mfma_i8(a, bh, H[t]); L[t] = mfma_i8(a, bl, L[t]); }                          \
+            }                                                                                                 \
+        }
+        KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
+#undef KSTEP
+        const float dd = R.d();
+        float dm = 0.0f;
+        i32x4 bm = {0, 0, 0, 0};
+        if constexpr (TYPE != T_Q6_K) {
+            dm = R.dmin();
+            if (kg == 0) {
+                bm.x = (int)perm(0, mn_lo, 0x01010000u); bm.y = (int)perm(0, mn_lo, 0x03030202u);
+                bm.z = (int)perm(0, mn_hi, 0x01010000u); bm.w = (int)perm(0, mn_hi, 0x03030202u);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            i32x16 ms;
+            if constexpr (TYPE != T_Q6_K) {
+                i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0};
+                if (kg == 0) {
+                    ah = *reinterpret_cast<const i32x4 *>(s_bh + (t * 32 + n) * 16);
+                    al = *reinterpret_cast<const i32x4 *>(s_bl + (t * 32 + n) * 16);
+                }
+                i32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0;
+                ms = mfma_i8(ah, bm, z);
+#pragma unroll
+                for (int r = 0; r < 16; r++) ms[r] <<= 6;
+                ms = mfma_i8(al, bm, ms);
+            }
+#pragma unroll
+            for (int rq = 0; rq < 4; rq++) {
+                const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + t * 32 + 8 * rq + 4 * kg);
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++) {
+                    const int r = rq * 4 + ri;
+                    const float yd = yd4[ri];
+                    if constexpr (TYPE == T_Q6_K) {
+                        const int isum = 64 * H[t][r] + L[t][r];
+                        facc[t][r] += (dd * yd) * (float)isum;
+                    } else {
+                        const int isum = 32 * H[t][r] + L[t][r];
+                        facc[t][r] += (dd * yd) * (float)isum - (dm * yd) * (float)ms[r];
+                    }
+                }
+            }
+        }
+    }
+    // ---- sum the eight waves' partial tiles in wave order (deterministic), then store
+    __syncthreads();                                   // all activation tiles consumed: the LDS is reused for the partials
+    float *part = reinterpret_cast<float *>(smem);     // [wave][MT * 16][64]
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) part[(wave * MT * 16 + t * 16 + r) * 64 + lane] = facc[t][r];
+    __syncthreads();
+    for (int e = tid; e < MT * 16 * 64; e += NTHREADS) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) sum += part[w * MT * 16 * 64 + e];
+        const int ln = e & 63, tr = e >> 6;            // tr = t * 16 + r
+        const int t = tr >> 4, r = tr & 15;
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int gt = tok0 + t * 32 + m, row = row0 + (ln & 31);
+        if (gt < T && row < n_rows) {
+            const size_t o = (size_t)gt * ld_out + row;
+            out[o] = resid ? resid[o] + sum : sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Pre-expanded weights ("planes"): the two int8 planes of every K-step are computed ONCE at model load and laid out
 // exactly as the MFMA B operands are consumed, so the prefill kernel does no per-weight VALU work at all:
 //   block(rt, sb) = 32 rows x one super-block:  [K-step J 0..7][plane 0 = hi, 1 = lo][lane 0..63][16 B]  (16 KB)
@@ -670,6 +833,33 @@ hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, in
 }  // namespace
 
 void mmq_set_tiles(int mt) { g_mmq_mt = mt; }
+
+// continuous-batching decode steps: 8 <= T <= 64 tokens
+bool mmq_ksplit_applicable(int type, int K, int T) {
+    return (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K) && (K % 256) == 0 && T >= 8 && T <= 64;
+}
+hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
+                             const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st) {
+    const int mt = T <= 32 ? 1 : 2;
+    const dim3 grid((unsigned)((n_rows + 31) / 32), (unsigned)((T + 32 * mt - 1) / (32 * mt)));
+#define KS(TY, MTV)                                                                                                  \
+    {                                                                                                                \
+        constexpr int TOKV = 32 * MTV;                                                                               \
+        size_t lds = (size_t)8 * (TOKV * A_STRIDE + 2 * TOKV * 16 + TOKV * 4);                                        \
+        const size_t red = (size_t)8 * MTV * 16 * 64 * 4;                                                            \
+        if (red > lds) lds = red;                                                                                    \
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_ksplit_kernel<TY, MTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mmq_ksplit_kernel<TY, MTV>), grid, dim3(NTHREADS), lds, st, W, row_bytes, n_rows, K, T, q.qs, q.d, bh, bl, out, ld_out, resid); \
+    }
+    switch (type) {
+        case T_Q4_K: if (mt == 1) KS(T_Q4_K, 1) else KS(T_Q4_K, 2) break;
+        case T_Q5_K: if (mt == 1) KS(T_Q5_K, 1) else KS(T_Q5_K, 2) break;
+        case T_Q6_K: if (mt == 1) KS(T_Q6_K, 1) else KS(T_Q6_K, 2) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef KS
+    return hipGetLastError();
+}
 
 size_t mmq_planes_bytes(int type, int64_t n_rows, int K) {
     if ((type != T_Q4_K && type != T_Q5_K && type != T_Q6_K) || (K % 256) != 0) return 0;

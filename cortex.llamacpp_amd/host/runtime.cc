@@ -342,7 +342,7 @@ bool Context::init(std::string &err) {
         const int sp = flash_attn_pick_splits(t, (int)G, (int)NC);
         ws = std::max(ws, flash_attn_workspace_floats(t, hp.n_head, (int)D, sp));
     }
-    ws = std::max(ws, flash_attn_workspace_floats(std::min<int>((int)T, 8), hp.n_head, (int)D, flash_attn_decode_splits((int)NC)));
+    ws = std::max(ws, flash_attn_workspace_floats(std::min<int>((int)T, 64), hp.n_head, (int)D, flash_attn_decode_splits((int)NC)));
     att_part_ = (float *)dalloc(ws * 4);
     att_counters_ = (unsigned *)dalloc(256 * sizeof(unsigned));
     if (!att_part_ || !att_counters_) { err = "attention workspace allocation failed"; return false; }
@@ -506,6 +506,10 @@ static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, c
 hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
+        if (mmq_ksplit_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // batched decode steps: MFMA, K split
+            if (w.type != T_Q6_K) HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+            return launch_mmq_ksplit(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+        }
         if (mmq_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // prompt processing: MFMA path
             if (w.type != T_Q6_K || !w.planes) HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
             if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
@@ -521,8 +525,14 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     bool all_q = true;
     for (int i = 0; i < n; i++) all_q &= is_quant(ws[i]->type);
     const int K = (int)ws[0]->K;
-    bool all_mmq = true;
-    for (int i = 0; i < n; i++) all_mmq &= mmq_applicable(ws[i]->type, K, T);
+    bool all_mmq = true, all_ks = true;
+    for (int i = 0; i < n; i++) { all_mmq &= mmq_applicable(ws[i]->type, K, T); all_ks &= mmq_ksplit_applicable(ws[i]->type, K, T); }
+    if (all_ks && pending_fuse_.mode == 0) {
+        HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+        for (int i = 0; i < n; i++)
+            HIP_TRY(launch_mmq_ksplit(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
+        return hipSuccess;
+    }
     if (all_mmq && pending_fuse_.mode == 0) {
         HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
         for (int i = 0; i < n; i++) {
@@ -589,7 +599,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
         if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
-            static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 1;
+            static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
             if (attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra)) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch
                 HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));
@@ -655,7 +665,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
                 prof_mark("norm_quant");
             }
-            const bool ffn_mmq = mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T);
+            const bool ffn_mmq = (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
+                                 (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T));
             if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_, fz));

@@ -213,8 +213,9 @@ MI355_API int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature
 MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id);
 
 /* Test / tool switches of the per-op entry points: "mmq_planes" (1: mi355_op_mul_mat with T >= 32 expands the weight
- * into MFMA planes first, as a loaded model does; 0: expands on the fly inside the kernel), "mmq_tiles" (0 | 1 | 2 | 4
- * token tiles per wave).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
+ * into MFMA planes first, as a loaded model does; 0: expands on the fly inside the kernel), "mmq_tiles" (0 | 1 | 2
+ * token tiles per wave), "mmq_ksplit" (1: 8 <= T <= 64 uses the K-split small-batch kernel, as the runtime does; 0: the
+ * kernels the other T ranges use).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
 MI355_API int mi355_debug_set_option(const char *name, int32_t value);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */

@@ -76,11 +76,27 @@ def test_mul_mat_mfma_prefill_paths(be, t, K, N, T, planes, tiles):
     x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
     be.set_option("mmq_planes", planes)
     be.set_option("mmq_tiles", tiles)
+    be.set_option("mmq_ksplit", 0)               # T in 33..64 would otherwise take the small-batch kernel (tested below)
     try:
         y = be.mul_mat(t, W, N, K, x)
     finally:
         be.set_option("mmq_planes", 1)
         be.set_option("mmq_tiles", 0)
+        be.set_option("mmq_ksplit", 1)
+    ref = oq.mul_mat(t, W, N, K, x)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
+@pytest.mark.parametrize("K,N,T", [(4096, 100, 8), (4096, 64, 32), (14336, 40, 17), (5632, 37, 33), (2048, 130, 64), (256, 5, 9),
+                                   (4096, 33, 48)])
+def test_mul_mat_small_batch_ksplit(be, t, K, N, T):
+    """Continuous-batching decode steps (8..64 tokens): MFMA contraction with K split over the waves of a workgroup;
+    ragged rows / tokens, K smaller than the 8-way split."""
+    rng = np.random.default_rng(K + N + T + t)
+    W = rand_weights(rng, t, N * K)
+    x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
+    y = be.mul_mat(t, W, N, K, x)
     ref = oq.mul_mat(t, W, N, K, x)
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
