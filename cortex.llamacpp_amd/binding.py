@@ -75,6 +75,7 @@ SYMBOLS = {
     "mi355_get_logits_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_get_argmax_ith": (_i32, [_vp, _i32]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
+    "mi355_get_embeddings_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_synchronize": (None, [_vp]),
     "mi355_kv_cache_clear": (None, [_vp]),
     "mi355_kv_cache_seq_rm": (_i32, [_vp, _i32, _i32, _i32]),
@@ -342,6 +343,15 @@ class Context:
         """Block until the logits row is host-visible (no numpy copy)."""
         if not self.lib.mi355_get_logits_ith(self.h, i):
             raise MI355Error("no logits for that batch row")
+
+    def set_embeddings(self, on: bool = True) -> None:
+        self.lib.mi355_set_embeddings(self.h, int(on))
+
+    def embeddings(self, i: int = -1) -> np.ndarray:
+        p = self.lib.mi355_get_embeddings_ith(self.h, i)
+        if not p:
+            raise MI355Error("no embeddings for that row")
+        return np.ctypeslib.as_array(p, shape=(self.model.n_embd,)).copy()
 
     def argmax(self, i: int = -1) -> int:
         return int(self.lib.mi355_get_argmax_ith(self.h, i))

@@ -185,6 +185,7 @@ int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
 float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0; }
+float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
 
 void mi355_kv_cache_clear(mi355_context *ctx) { ctx->c->kv_clear(); }

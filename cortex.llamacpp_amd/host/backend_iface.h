@@ -31,6 +31,9 @@ class IBackend {
     virtual int decode(const BatchView &b) = 0;
     // logits row of batch index i of the last decode (llama_get_logits_ith)
     virtual const float *logits_ith(int i) = 0;
+    // llama_set_embeddings / llama_get_embeddings_ith (llama_server_context.cc:299, 1042-1044)
+    virtual void set_embeddings(bool on) = 0;
+    virtual const float *embeddings_ith(int i) = 0;
     virtual void kv_clear() = 0;
     virtual bool kv_seq_rm(int seq, int p0, int p1) = 0;
     virtual void kv_seq_add(int seq, int p0, int p1, int delta) = 0;

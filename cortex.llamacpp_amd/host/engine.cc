@@ -247,8 +247,85 @@ void LlamaEngine::StopInferencing(const std::string &model_id) {   // :502-508
     force_stop_.insert(model_id);
 }
 
-void LlamaEngine::HandleEmbedding(const Json &, Callback cb) {
-    cb(make_status(false, true, false, k400BadRequest), message("Embeddings are not available in this build"));
+// base64 of the raw little-endian f32 bytes (encoding_format = "base64"; llama_utils::base64Encode / FloatVectorToBytes)
+static std::string base64_floats(const std::vector<float> &v) {
+    static const char tbl[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(v.data());
+    const size_t n = v.size() * sizeof(float);
+    std::string out;
+    out.reserve((n + 2) / 3 * 4);
+    for (size_t i = 0; i < n; i += 3) {
+        const unsigned b0 = p[i], b1 = i + 1 < n ? p[i + 1] : 0, b2 = i + 2 < n ? p[i + 2] : 0;
+        out += tbl[b0 >> 2];
+        out += tbl[((b0 & 3) << 4) | (b1 >> 4)];
+        out += i + 1 < n ? tbl[((b1 & 15) << 2) | (b2 >> 6)] : '=';
+        out += i + 2 < n ? tbl[b2 & 63] : '=';
+    }
+    return out;
+}
+
+static Json embedding_payload(const Json &embedding, int index, bool is_base64) {   // CreateEmbeddingPayload :92-114
+    Json item = Json::object();
+    item["object"] = "embedding";
+    item["index"] = index;
+    if (is_base64) {
+        std::vector<float> v;
+        for (const Json &x : embedding.items()) v.push_back((float)x.as_double());
+        item["embedding"] = base64_floats(v);
+    } else {
+        item["embedding"] = embedding;
+    }
+    return item;
+}
+
+static bool all_int32(const Json &a) {   // AreAllElementsInt32
+    if (!a.is_array() || a.size() == 0) return false;
+    for (const Json &x : a.items()) if (!x.is_int()) return false;
+    return true;
+}
+
+void LlamaEngine::HandleEmbedding(const Json &body, Callback cb) {   // :353-361, HandleEmbeddingImpl :1115-1223
+    const std::string model_id = GetModelId(body);
+    if (!CheckModelLoaded(cb, model_id)) return;
+    std::shared_ptr<ServerInfo> si;
+    { std::lock_guard<std::mutex> lk(map_mutex_); si = server_map_[model_id]; }
+    ++no_of_requests_;
+    si->q->run([si, cb, body, model_id]() mutable {
+        LlamaServerContext &llama = *si->ctx;
+        Json data = Json::array();
+        const bool is_base64 = body.value<std::string>("encoding_format", "float") == "base64";
+        int prompt_tokens = 0;
+        auto request = [&](const Json &elem) -> int {             // one prompt: a string, or an array of token ids
+            Json d = Json::object();
+            d["n_predict"] = 0;
+            if (elem.is_string()) d["prompt"] = elem.as_string();
+            else { d["prompt"] = "Mock prompt"; d["prompt_tokens"] = elem; }
+            return llama.RequestCompletion(d, false, true, -1);
+        };
+        auto collect = [&](int task_id, int index) {
+            TaskResult r = llama.NextResult(task_id);
+            if (r.error || !r.result_json["embedding"].is_array()) { data.push_back(embedding_payload(Json::array(), index, is_base64)); return; }
+            prompt_tokens += (int)r.result_json["tokens_evaluated"].as_int();
+            data.push_back(embedding_payload(r.result_json["embedding"], index, is_base64));
+        };
+        const Json &input = body["input"];
+        if (input.is_string() || all_int32(input)) {
+            collect(request(input), 0);
+        } else if (input.is_array()) {
+            std::vector<int> ids;
+            for (const Json &elem : input.items())
+                if (elem.is_string() || all_int32(elem)) ids.push_back(request(elem));
+            for (size_t i = 0; i < ids.size(); i++) collect(ids[i], (int)i);
+        }
+        Json root = Json::object(), usage = Json::object();
+        root["data"] = data;
+        root["model"] = model_id;
+        root["object"] = "list";
+        usage["prompt_tokens"] = prompt_tokens;
+        usage["total_tokens"] = prompt_tokens;
+        root["usage"] = usage;
+        cb(make_status(true, false, false, k200OK), std::move(root));
+    });
 }
 
 void LlamaEngine::HandleChatCompletion(const Json &body, Callback cb) {   // :341-351

@@ -232,6 +232,7 @@ Context::~Context() {
     if (h_stage_) (void)hipHostFree(h_stage_);
     if (h_logits_) (void)hipHostFree(h_logits_);
     if (h_argmax_) (void)hipHostFree(h_argmax_);
+    if (h_embd_) (void)hipHostFree(h_embd_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -350,6 +351,8 @@ bool Context::init(std::string &err) {
     d_argmax_ = (int32_t *)dalloc(T * 4);
     argmax_scratch_ = (float *)dalloc(T * 128 * 4);
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
+    d_embd_ = (float *)dalloc(T * E * 4);
+    if (hipHostMalloc((void **)&h_embd_, T * E * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     if (hipHostMalloc((void **)&h_argmax_, T * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     embeddings_enabled = cp.embeddings;
     kv_clear();
@@ -700,6 +703,12 @@ hipError_t Context::run_output(int n_out, int out_base) {
     const HParams &hp = model->hp;
     const int E = hp.n_embd, V = hp.n_vocab;
     HIP_TRY(launch_gather_rows_f32(x_, d_outrow_, n_out, E, xo_, stream_));
+    if (embeddings_enabled) {
+        // embeddings mode (llama_set_embeddings): output = result_norm rows, no lm-head (pooling NONE on this architecture)
+        HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, d_embd_ + (size_t)out_base * E, nullptr, false, false, stream_));
+        prof_mark("embd");
+        return hipSuccess;
+    }
     const bool oq = is_quant(model->output.type);
     if (oq && can_fuse(E, n_out)) {
         pending_fuse_.mode = 1; pending_fuse_.x = xo_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps;
@@ -765,7 +774,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
     const int V = model->hp.n_vocab;
-    const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_;
+    const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
     hipError_t e = hipSuccess;
     if (graph_ok) {
         // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
@@ -793,7 +802,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         e = run_layers(n, n_kv_);
         if (e == hipSuccess) e = run_output(n_out, out_base);
         if (profiler_safe) (void)hipStreamSynchronize(stream_);
-        if (e == hipSuccess && n_out > 0 && cp.logits_to_host)
+        if (e == hipSuccess && n_out > 0 && cp.logits_to_host && !embeddings_enabled)
             e = hipMemcpyAsync(h_logits_ + (size_t)out_base * V, d_logits_ + (size_t)out_base * V, (size_t)n_out * V * 4, hipMemcpyDeviceToHost, stream_);
         prof_end();
     }
@@ -852,6 +861,9 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
     }
     n_out_last_ = n_out;
     logits_fetched_ = false;
+    embd_fetched_ = false;
+    last_was_embd_ = embeddings_enabled;
+    if (embeddings_enabled && (size_t)n_out > cp.n_ubatch) { last_error = "embeddings: more flagged rows than n_ubatch"; return -1; }
     argmax_fetched_ = false;
 
     const std::vector<KVCell> saved = cells_;
@@ -872,6 +884,7 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
 void Context::synchronize() { (void)hipStreamSynchronize(stream_); }
 
 float *Context::logits_ith(int i) {
+    if (last_was_embd_) return nullptr;            // embeddings mode computes no logits
     if (i < 0) i += (int)out_row_of_batch_.size();
     if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return nullptr;
     if (!logits_fetched_) {
@@ -881,6 +894,19 @@ float *Context::logits_ith(int i) {
         logits_fetched_ = true;
     }
     return h_logits_ + (size_t)out_row_of_batch_[(size_t)i] * model->hp.n_vocab;
+}
+
+float *Context::embeddings_ith(int i) {
+    if (!last_was_embd_) return nullptr;
+    if (i < 0) i += (int)out_row_of_batch_.size();
+    if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return nullptr;
+    const int E = model->hp.n_embd;
+    if (!embd_fetched_) {
+        if (hipMemcpyAsync(h_embd_, d_embd_, (size_t)n_out_last_ * E * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return nullptr;
+        if (hipStreamSynchronize(stream_) != hipSuccess) return nullptr;
+        embd_fetched_ = true;
+    }
+    return h_embd_ + (size_t)out_row_of_batch_[(size_t)i] * E;
 }
 
 int32_t Context::argmax_ith(int i) {

@@ -93,6 +93,9 @@ class Context {
     int decode(int n_tokens, const int32_t *tokens, const int32_t *pos, const int32_t *n_seq_id, int32_t *const *seq_id,
                const int8_t *logits_flags);
     float *logits_ith(int i);
+    // llama_get_embeddings_ith: the final-norm hidden state of batch row i (n_embd floats, host memory); rows are
+    // produced for the flagged tokens of the last decode while embeddings_enabled is set (then no logits are computed)
+    float *embeddings_ith(int i);
     int32_t argmax_ith(int i);
     void synchronize();
 
@@ -157,6 +160,8 @@ class Context {
     ActQuant aq_e_, aq_ff_, aq_o_;
     int8_t *mmq_bh_ = nullptr, *mmq_bl_ = nullptr;   // (hi, lo) planes of the 32-code block sums for the MFMA path
     float *att_part_ = nullptr;
+    float *d_embd_ = nullptr, *h_embd_ = nullptr;   // [n_ubatch][n_embd], embeddings mode
+    bool embd_fetched_ = false, last_was_embd_ = false;
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;

@@ -90,9 +90,9 @@ void LlamaServerContext::DoBackgroundTasks() {  // :1239-1246
 
 void LlamaServerContext::KvCacheClear() { be_->kv_clear(); clean_kv_cache = false; }
 
-int LlamaServerContext::RequestCompletion(Json data, bool, bool, int) {   // :295-323
+int LlamaServerContext::RequestCompletion(Json data, bool, bool embedding, int) {   // :295-323
     std::unique_lock<std::mutex> lock(mutex_tasks_);
-    Task t{id_gen_++, -1, false, std::move(data)};
+    Task t{id_gen_++, -1, false, std::move(data), embedding};
     const int id = t.id;
     queue_tasks_.push_back(std::move(t));
     condition_tasks_.notify_one();
@@ -222,6 +222,31 @@ bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &
     return true;
 }
 
+void LlamaServerContext::SendEmbedding(LlamaClientSlot &slot, int batch_index) {   // :1026-1070
+    TaskResult res;
+    res.id = slot.task_id; res.error = false; res.stop = true;
+    const int n_embd = be_->n_embd();
+    std::vector<float> embd_res((size_t)n_embd, 0.0f);
+    const float *embd = be_->embeddings_ith(batch_index);
+    if (embd) {                                          // common_embd_normalize(embd, out, n, 2): Euclidean norm in double
+        double sum = 0.0;
+        for (int i = 0; i < n_embd; i++) sum += (double)embd[i] * (double)embd[i];
+        sum = std::sqrt(sum);
+        const float norm = sum > 0.0 ? (float)(1.0 / sum) : 0.0f;
+        for (int i = 0; i < n_embd; i++) embd_res[(size_t)i] = embd[i] * norm;
+    }
+    Json arr = Json::array();
+    for (float v : embd_res) arr.push_back((double)v);
+    res.result_json = Json::object();
+    res.result_json["tokens_evaluated"] = slot.num_prompt_tokens;
+    res.result_json["embedding"] = arr;
+    {
+        std::lock_guard<std::mutex> lock(mutex_results_);
+        queue_results_.push_back(std::move(res));
+    }
+    condition_results_.notify_all();
+}
+
 void LlamaServerContext::ProcessTasks() {   // :1152-1237
     std::unique_lock<std::mutex> lock(mutex_tasks_);
     std::deque<Task> deferred;
@@ -238,6 +263,7 @@ void LlamaServerContext::ProcessTasks() {   // :1152-1237
         if (!slot) { deferred.push_back(std::move(task)); continue; }     // no free slot: retry on the next tick
         slot->Reset();
         slot->task_id = task.id;
+        slot->embedding = task.embedding_mode;       // :1194
         if (!LaunchSlotWithData(slot, task.data)) {
             SendError(*slot, "internal_error");
         }
@@ -454,6 +480,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
         if (slot.params.cache_prompt) slot.cache_tokens.push_back(slot.sampled);
     }
     int32_t n_batch = be_->n_batch();
+    bool embd_tick = false, tick_mode_set = n_tokens > 0;      // a tick that already carries generated tokens is a generation tick
     // prompt ingestion (:1355-1621)
     if (params.cont_batching || n_tokens == 0) {
         for (auto &slot : slots) {
@@ -464,6 +491,10 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                 continue;
             }
             if (!(slot.state == SlotState::kIdle && slot.command == SlotCommand::kLoadPrompt)) continue;
+            // an embedding prompt never shares a tick with generation (see the note at the decode call): it waits while
+            // any slot generates, and a generation prompt waits for a tick that already took an embedding prompt
+            if (!tick_mode_set) { embd_tick = slot.embedding && n_tokens == 0; tick_mode_set = true; }
+            if (slot.embedding != embd_tick) continue;
             auto &prompt_tokens = slot.prompt_tokens;
             if (!slot.prompt_ready) {   // first visit of this prompt: tokenise, truncate, find the cached prefix
                 slot.t_start_process_prompt = time_us();
@@ -483,6 +514,12 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                     prompt_tokens = nt;
                     slot.num_prompt_tokens = (int32_t)prompt_tokens.size();
                 }
+                if (slot.embedding && slot.num_prompt_tokens > be_->n_ubatch()) {     // this prompt is too large to process (:1431-1447)
+                    slot.state = SlotState::kProcessing; slot.command = SlotCommand::kNone;
+                    slot.Release();
+                    SendError(slot, "input is too large to process. increase the physical batch size");
+                    continue;
+                }
                 slot.smpl->reset();
                 if (!slot.params.cache_prompt) {
                     slot.n_past = 0;
@@ -494,6 +531,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                 slot.num_prompt_tokens_processed = 0;
                 slot.prompt_ready = true;
             }
+            if (slot.embedding && n_tokens + slot.num_prompt_tokens > n_batch) continue;   // does not fit this tick (:1519-1524)
             // keep only the common part of the cache (:1536-1558)
             if (!be_->kv_seq_rm(slot.id, slot.n_past, -1)) {
                 be_->kv_seq_rm(slot.id, -1, -1);
@@ -517,6 +555,9 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
     }
     if (n_tokens == 0) { all_slots_are_idle = true; return true; }
 
+    // llama_set_embeddings is a context-wide switch that the reference flips per request (:299); here a tick is either an
+    // embedding tick or a generation tick (decided at prompt ingestion below), so the switch follows the batch
+    be_->set_embeddings(embd_tick);
     for (int32_t i = 0; i < n_tokens; i += n_batch) {   // :1628-1707
         const int32_t nt = std::min(n_batch, n_tokens - i);
         BatchView bv{nt, b_token_.data() + i, b_pos_.data() + i, b_seq_.data() + i, b_logits_.data() + i};
@@ -537,6 +578,12 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
         }
         for (auto &slot : slots) {
             if (slot.i_batch < i || slot.i_batch >= i + nt) continue;
+            if (slot.embedding) {                        // prompt evaluated for embedding (:1670-1676)
+                SendEmbedding(slot, slot.i_batch - i);
+                slot.Release();
+                slot.i_batch = -1;
+                continue;
+            }
             CompletionTokenOutput result;
             const float *logits = be_->logits_ith(slot.i_batch - i);
             if (!logits) { slot.Release(); SendError(slot, "no logits"); slot.i_batch = -1; continue; }

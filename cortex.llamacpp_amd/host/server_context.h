@@ -2,7 +2,7 @@
 // LlamaServerContext (src/llama_server_context.{h,cc}): task / result queues, LRU slot assignment, the continuous-batching
 // UpdateSlots loop (:1248-1710), context shift (:1274-1306), prompt-prefix reuse (:1489-1558), stop strings and partial
 // UTF-8 hold-back (ProcessToken :716-813), timings (llama_client_slot.cc:55-94).  Same names, same JSON keys.
-// Not mirrored: LLaVA image ingest, infill, system-prompt broadcast, embeddings.
+// Embedding requests (SendEmbedding :1026-1070) included.  Not mirrored: LLaVA image ingest, infill, system-prompt broadcast.
 #pragma once
 
 #include <atomic>
@@ -65,6 +65,7 @@ struct LlamaClientSlot {
     bool prompt_ready = false;      // prompt tokenised / truncated / matched against the cache (first visit done)
     bool has_next_token = true, truncated = false, stopped_eos = false, stopped_word = false, stopped_limit = false;
     bool oaicompat = false;
+    bool embedding = false;         // task.embedding_mode (:1194): the prompt is evaluated for its embedding, nothing is sampled
     std::string oaicompat_model, stopping_word;
     SamplingParams sparams;
     std::unique_ptr<Sampler> smpl;
@@ -112,7 +113,8 @@ class LlamaServerContext {
     int n_ctx = 0;
 
   private:
-    struct Task { int id; int target_id; bool cancel; Json data; };
+    struct Task { int id; int target_id; bool cancel; Json data; bool embedding_mode = false; };
+    void SendEmbedding(LlamaClientSlot &slot, int batch_index);
     LlamaClientSlot *GetSlot(int id);
     bool LaunchSlotWithData(LlamaClientSlot *&slot, const Json &data);
     void ProcessTasks();

@@ -145,6 +145,10 @@ MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);
 MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
+/* llama_get_embeddings_ith (ctx.cc:1042-1044): final-norm hidden state (n_embd floats, host memory) of batch row i of the
+ * last mi355_decode issued while embeddings were enabled; NULL otherwise.  Pooling is NONE on this architecture, so
+ * llama_get_embeddings_seq has no counterpart (the reference falls back to _ith, ctx.cc:1043-1045). */
+MI355_API float  *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i);
 MI355_API void    mi355_synchronize(mi355_context *ctx);
 
 /* KV cache bookkeeping (ctx.cc:287; 661,1547; 1288,1540,1542; 1290) */

@@ -3,6 +3,7 @@
 #include <cassert>
 #include <cstdio>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <thread>
 #include <map>
@@ -84,6 +85,17 @@ struct FakeBackend : IBackend {
             }
         }
         return 0;
+    }
+    bool embd_on = false;
+    std::vector<float> embd_row;
+    void set_embeddings(bool on) override { embd_on = on; embd_flags.push_back(on); }
+    std::vector<bool> embd_flags;
+    const float *embeddings_ith(int i) override {
+        if (!embd_on || i < 0 || i >= (int)last_flag_index.size() || last_flag_index[(size_t)i] < 0) return nullptr;
+        embd_row.assign((size_t)n_embd(), 0.0f);
+        const auto &tk = calls_tokens.back();
+        for (int k = 0; k < n_embd(); k++) embd_row[(size_t)k] = (float)((tk[(size_t)i] + 3 * k) % 7) - 3.0f;   // depends on the row's token
+        return embd_row.data();
     }
     const float *logits_ith(int i) override { return (i >= 0 && i < (int)last_flag_index.size() && last_flag_index[(size_t)i] >= 0) ? last_logits[(size_t)last_flag_index[(size_t)i]].data() : nullptr; }
     void kv_clear() override { kv.clear(); kv_ops.push_back("clear"); }
@@ -390,6 +402,49 @@ static int tokenize_cli(const char *gguf, const char *cases) {
     return 0;
 }
 
+static void test_embeddings() {
+    LlamaEngine eng([](const Json &, BackendInfo &, std::string &) -> std::unique_ptr<IBackend> { return std::unique_ptr<IBackend>(new FakeBackend()); });
+    Json load = Json::object();
+    load["llama_model_path"] = "/models/emb.gguf"; load["n_parallel"] = 2;
+    int code = 0;
+    eng.LoadModel(load, [&](Json &&st, Json &&) { code = (int)st["status_code"].as_int(); });
+    CHECK(code == 200);
+    std::mutex mu; std::condition_variable cv; bool done = false; Json body, status;
+    auto wait_cb = [&](Json &&st, Json &&b) { std::lock_guard<std::mutex> lk(mu); status = st; body = b; done = true; cv.notify_all(); };
+    auto run = [&](const Json &req) { done = false; eng.HandleEmbedding(req, wait_cb); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); };
+    Json req = Json::object();
+    req["model"] = "emb"; req["input"] = "hello world";
+    run(req);
+    CHECK(status["status_code"].as_int() == 200 && body["object"].as_string() == "list" && body["model"].as_string() == "emb");
+    CHECK(body["data"].size() == 1 && body["data"].at(0)["object"].as_string() == "embedding" && body["data"].at(0)["index"].as_int() == 0);
+    const Json &e = body["data"].at(0)["embedding"];
+    CHECK(e.size() == 8);
+    double n2 = 0;
+    for (const Json &x : e.items()) n2 += x.as_double() * x.as_double();
+    CHECK(std::fabs(n2 - 1.0) < 1e-5);                          // L2-normalised (common_embd_normalize)
+    CHECK(body["usage"]["prompt_tokens"].as_int() == 3 && body["usage"]["total_tokens"].as_int() == 3);
+    // array of strings + token arrays, base64 encoding
+    Json arr = Json::array();
+    arr.push_back("hello"); arr.push_back("world hello");
+    Json toks = Json::array(); toks.push_back(5); toks.push_back(270); toks.push_back(271);
+    arr.push_back(toks);
+    req["input"] = arr; req["encoding_format"] = "base64";
+    run(req);
+    CHECK(body["data"].size() == 3 && body["data"].at(2)["index"].as_int() == 2);
+    CHECK(body["data"].at(0)["embedding"].is_string() && body["data"].at(0)["embedding"].as_string().size() == 44);   // 8 floats = 32 B -> 44 chars
+    CHECK(body["usage"]["prompt_tokens"].as_int() == 2 + 3 + 3);
+    // a chat completion afterwards still samples (the embeddings switch follows the tick)
+    Json chat = Json::object();
+    chat["model"] = "emb"; chat["max_tokens"] = 4; chat["temperature"] = 0.0;
+    Json msgs = Json::array(), m1 = Json::object();
+    m1["role"] = "user"; m1["content"] = "hello";
+    msgs.push_back(m1); chat["messages"] = msgs;
+    done = false;
+    eng.HandleChatCompletion(chat, wait_cb);
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+    CHECK(status["status_code"].as_int() == 200 && body["object"].as_string() == "chat.completion");
+}
+
 int main(int argc, char **argv) {
     if (argc == 4 && std::string(argv[1]) == "--tokenize") return tokenize_cli(argv[2], argv[3]);
     test_json();
@@ -399,6 +454,7 @@ int main(int argc, char **argv) {
     test_prompt_cache_and_shift();
     test_kv_full_error();
     test_engine();
+    test_embeddings();
     if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
     printf("all host-logic checks passed\n");
     return 0;

@@ -141,8 +141,16 @@ def test_errors_and_unload(pkg, tiny_vocab_model):
     assert st["status_code"] == 409
     res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "hi"}], max_tokens=4, **GREEDY)
     assert res[-1][0]["status_code"] == 200
-    st, body = e.embedding(model="tiny-d128", input="hi")
-    assert st["has_error"]
+    st, body = e.embedding(model="tiny-d128", input=["hi", "hello world", [5, 300, 301]])
+    assert st["status_code"] == 200 and body["object"] == "list" and len(body["data"]) == 3
+    for i, d in enumerate(body["data"]):
+        v = np.asarray(d["embedding"], np.float64)
+        assert d["index"] == i and v.shape == (1024,) and abs(float((v * v).sum()) - 1.0) < 1e-4
+    assert body["usage"]["prompt_tokens"] == body["usage"]["total_tokens"] > 6
+    st, b64 = e.embedding(model="tiny-d128", input="hi", encoding_format="base64")
+    import base64
+    raw = np.frombuffer(base64.b64decode(b64["data"][0]["embedding"]), dtype="<f4")
+    assert np.allclose(raw, np.asarray(body["data"][0]["embedding"], np.float32), atol=1e-6)
     st, body = e.unload_model(model="tiny-d128")
     assert st["status_code"] == 200
     res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "hi"}], max_tokens=4)

@@ -208,3 +208,32 @@ def test_load_errors(be, pkg, tmp_path):
         pkg.Model(str(bad))
     with pytest.raises(pkg.MI355Error):
         pkg.Model(str(tmp_path / "missing.gguf"))
+
+
+def test_embeddings_match_oracle_hidden_state(be, pkg, tmp_models):
+    """llama_set_embeddings + llama_get_embeddings_ith: the final-norm hidden state of the flagged row (pooling NONE on
+    this architecture), against the oracle's last-layer residual stream normalised in numpy with the file's own
+    output_norm weights."""
+    cfg, ftype, seed = "tiny-d128", "q4_k_m", 11
+    path = make(pkg, tmp_models, cfg, ftype, seed)
+    m, c, om, oc = open_pair(pkg, path, 128, "q8_0")
+    gs = pkg.gguf_synth
+    names = [t[0] for t in gs.model_tensors(gs.CONFIGS[cfg], ftype)]
+    idx = names.index("output_norm.weight")
+    w = np.random.default_rng([seed, idx]).uniform(0.9, 1.1, size=m.n_embd).astype(np.float32)
+    prompt = np.random.default_rng(9).integers(0, m.n_vocab, 13)
+    c.set_embeddings(True)
+    assert c.decode(prompt, np.arange(13)) == 0
+    got = c.embeddings(-1)
+    oc.decode(prompt, np.arange(13))
+    x = oc.layer_out(m.n_layer - 1, 13).reshape(13, -1)[-1].astype(np.float32)
+    want = oq.rms_norm(x, gs.CONFIGS[cfg].eps) * w
+    assert np.abs(got - want).max() <= FLIP_TOL * max(1.0, float(np.abs(want).max()))
+    with pytest.raises(pkg.MI355Error):
+        c.logits()                                   # embeddings mode computes no logits
+    c.set_embeddings(False)
+    assert c.decode([3], [13]) == 0
+    assert c.logits().shape == (m.n_vocab,)
+    with pytest.raises(pkg.MI355Error):
+        c.embeddings()
+    c.close(); m.close(); oc.close(); om.close()
