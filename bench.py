@@ -85,6 +85,7 @@ def main() -> int:
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--model-dir", default=os.environ.get("MI355_BENCH_DIR", "/tmp"))
     ap.add_argument("--keep-model", action="store_true")
+    ap.add_argument("--no-long-context", action="store_true", help="skip the context-filled-to-3968 measurement")
     ap.add_argument("--simulate", action="store_true",
                     help="no GPU: the same rank bookkeeping (rendezvous over gloo, barriers, MAX over ranks, rank-0 JSON) around a "
                          "sleep standing in for the decode step; used by the two-rank CPU test")
@@ -198,6 +199,34 @@ def main() -> int:
     ctx.synchronize()
     dt_greedy = time.perf_counter() - t0
 
+    # ---- the long-context point of the same config: context filled to 3968 of 4096, then greedy decode
+    long_ctx = None
+    if args.ctx >= 4096 and not args.no_long_context:
+        fill = args.ctx - 128
+        lp = rng.integers(0, model.n_vocab, fill)
+        ctx.kv_clear()
+        t0 = time.perf_counter()
+        for i0 in range(0, fill, 2048):
+            chunk = lp[i0:i0 + 2048]
+            assert ctx.decode(chunk, np.arange(i0, i0 + chunk.size)) == 0
+        tok_l = ctx.argmax()
+        t_fill = time.perf_counter() - t0
+        pos_l = fill
+        for _ in range(8):
+            ctx.decode([tok_l], [pos_l]); tok_l = ctx.argmax(); pos_l += 1
+        ctx.synchronize()
+        n_l = min(64, args.ctx - pos_l)
+        t0 = time.perf_counter()
+        for _ in range(n_l):
+            ctx.decode([tok_l], [pos_l]); tok_l = ctx.argmax(); pos_l += 1
+        ctx.synchronize()
+        dt_l = time.perf_counter() - t0
+        b_per_l = {"f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.cache_type]
+        kv_l = 2 * cfg.n_layer * cfg.n_head_kv * cfg.head_dim * (pos_l - n_l // 2) * b_per_l
+        long_ctx = {"prompt": fill, "prefill_tok_s": round(fill / t_fill, 1), "decode_tok_s_device_greedy": round(n_l / dt_l, 2),
+                    "decode_pos": [pos_l - n_l, pos_l], "kv_bytes_per_token": int(kv_l),
+                    "decode_hbm_fraction_of_8TBps": round((model.bytes_per_token + kv_l) * (n_l / dt_l) / (HBM_PEAK_GBPS * 1e9), 4)}
+
     # ---- roofline of the dominant kernel (quantised mat-vec), HIP events on the kernel's own stream
     sweep_us, sweep_bytes = ctx.weight_sweep_us(iters=5)
     n_launch = cfg.n_layer * 4 + 1                        # qkv, attn_output, gate+up, down per layer + lm-head
@@ -274,6 +303,7 @@ def main() -> int:
             "note": "algorithmic ops (2 x weights x tokens + attention); the kernel issues 2x the MACs (hi / lo planes)",
             "planes_bytes": int(model.planes_bytes),
         },
+        "long_context": long_ctx,
         "load_s": round(t_load, 2),
         "synth_s": round(t_gen, 2),
     }

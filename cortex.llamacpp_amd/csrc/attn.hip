@@ -8,6 +8,8 @@
 // Cache layout in HBM is head-major per layer: plane[g][cell][...] so that one kv-head's cells are a
 // contiguous stream; quantised caches keep int8/int4 codes and f16 block scales in separate planes
 // (same values as ggml block_q8_0 / block_q4_0, regrouped for 16-byte aligned coalesced loads).
+#include <cstdlib>
+
 #include "kernels.h"
 #include "quant_dev.h"
 
@@ -800,7 +802,10 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
 
     // ---- FUSED: ticket; the last workgroup of this kv head merges
     const int splits = a.splits;
-    __syncthreads();                                   // every wave's partial stores are issued and counted (vmcnt 0 before the barrier)
+    // every wave's partial stores must have reached L2 before thread 0 releases them device-wide: __syncthreads() fences
+    // LDS only (hipcc emitted no vmcnt wait before the barrier here), so each wave drains its own stores first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release fence compiles to nothing on this target)
+    __syncthreads();
     if (tid == 0) {
         // ONE release per workgroup (the barrier ordered the other waves' stores before it), then the ticket
         const unsigned old = __hip_atomic_fetch_add(fz.counters + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -962,6 +967,8 @@ static hipError_t launch_fa(const AttnArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
+    static const bool mfma_prefill = !(getenv("MI355_ATTN_PREFILL_MFMA") && getenv("MI355_ATTN_PREFILL_MFMA")[0] == '0');
+    if (mfma_prefill && flash_attn_prefill_applicable(a)) return launch_flash_attn_prefill(a, st);   // prompt processing: matrix cores
     const int R = a.H / a.G;
     hipError_t e = hipErrorInvalidValue;
     if ((size_t)a.splits * ATT_MAX_CHUNK < (size_t)a.n_kv_max) return hipErrorInvalidValue;

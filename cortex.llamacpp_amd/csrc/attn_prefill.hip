@@ -1,0 +1,339 @@
+// attn_prefill.hip — prompt-processing attention on the matrix cores (ggml_flash_attn_ext for T >= 32 query rows;
+// SURVEY.md §8a row a11), head_dim 128, q8_0 K and V cache.
+//
+// Same arithmetic as the CPU path it stands in for (flash_attn_ext with a q8_0 K cache: q is quantised to Q8_0 per
+// 32-block and K.q is vec_dot_q8_0_q8_0 = sum_b float(int dot) * (d_q * d_k); V rows are dequantised and accumulated in
+// f32 with the online-softmax weights), laid out for MFMA:
+//   * workgroup = (kv head g, tile of 32 query tokens), 4..8 waves = the R query heads of the group; a wave owns
+//     32 queries x one head.  K / V chunks of 32 cells are staged in LDS once per workgroup and shared by the R heads.
+//   * S^T = K . Q^T with v_mfma_i32_32x32x32_i8: A = K codes of one 32-block (rows = keys, from LDS), B = the wave's Q
+//     codes of that block (columns = queries, resident in registers for the whole kernel); the int32 tile is scaled
+//     by d_q (per lane = per query) x d_k (per register = per key) and summed over the 4 blocks in f32, as the CPU does.
+//     With queries in the N dimension a lane holds ONE query (and 16 of the 32 keys): the softmax state (m, l) and the
+//     rescale of O are per-lane scalars, the row max / sum need only the partner lane (lane ^ 32).
+//   * O^T += V'^T . P^T with v_mfma_f32_32x32x16_f16: V' = code * d_v is exact in 18 bits, so it is split EXACTLY into two
+//     f16 planes (hi + lo) when the chunk is staged; P is split into f16 hi + lo per wave (22 bits); three products
+//     (Ph.Vh, Pl.Vh, Ph.Vl) accumulate in f32 — f32-grade accuracy on the f16 matrix pipe.  The MFMA K index is bound
+//     to the key order the score tile leaves in registers, and the V^T planes are written to LDS in that order.
+//   * visibility is the KV-cell test of the cache (pos >= 0, pos <= query pos, sequence bit), so ragged batches, several
+//     sequences and fragmented caches take the same path; a prologue pass over the cell table marks the chunks that hold
+//     a cell visible to some query of the tile, the main loop walks only those, with the next one's K / V in flight
+//     (registers) while the current one is on the matrix cores.
+#include "kernels.h"
+#include "quant_dev.h"
+
+namespace mi355 {
+
+namespace {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int D = 128, NB = 4, CK = 32, QT = 32;      // head dim, 32-blocks per row, keys per chunk, queries per tile
+constexpr int K_STRIDE = 144;                         // 128 codes + 16 B pad: ds_read_b128 conflict-free
+constexpr int MAX_CHUNKS = 8192;                      // 262144 cells
+
+// LDS layout of one chunk
+struct Chunk {
+    int8_t *k;          // [CK][K_STRIDE]
+    float *dk;          // [NB][CK]      f32 block scales of K
+    _Float16 *vh, *vl;  // [4 db][2 j][2 kg][32 m][8 slots]   V'^T planes in MFMA A-operand order
+    int *cpos;          // [CK]
+    unsigned long long *cseq;   // [CK]
+};
+
+// key index (0..31) of MFMA K-slot (j, kg, i): the order the score tile leaves its 16 keys per lane in registers
+__device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 8 * (i >> 2) + 4 * kg + (i & 3); }
+
+template <int R>
+__global__ __launch_bounds__(64 * R) void flash_attn_prefill_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Chunk S;
+    S.k = reinterpret_cast<int8_t *>(smem);
+    S.dk = reinterpret_cast<float *>(smem + CK * K_STRIDE);
+    S.vh = reinterpret_cast<_Float16 *>(smem + CK * K_STRIDE + NB * CK * 4);
+    S.vl = S.vh + 4 * 2 * 2 * 32 * 8;
+    S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
+    S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
+    __shared__ unsigned s_vis[MAX_CHUNKS / 32];                // bit c: some cell of chunk c is visible to some query of the tile
+    __shared__ int s_tile_maxpos;
+    __shared__ unsigned long long s_tile_seqs;
+
+    constexpr int NT = 64 * R;
+    const int g = blockIdx.x, tile = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, kg = lane >> 5;
+    const int H = a.H, n_ctx = a.n_ctx;
+    const int h = g * R + wave;                                // this wave's query head
+    int qt = tile * QT + n;                                    // this lane's query token
+    const bool q_ok = qt < a.T;
+    if (!q_ok) qt = a.T - 1;
+    const int tpos = a.tok_pos[qt];
+    const int tseq = a.tok_seq[qt];
+    const int n_kv = *a.n_kv_dev;
+    const int n_chunks = (n_kv + CK - 1) / CK;
+    const size_t head_row0 = (size_t)g * n_ctx;
+
+    // ---- tile-wide visibility bounds
+    if (tid == 0) { s_tile_maxpos = -1; s_tile_seqs = 0ull; }
+    for (int i = tid; i < MAX_CHUNKS / 32; i += NT) s_vis[i] = 0u;
+    __syncthreads();
+    if (wave == 0 && kg == 0) {
+        atomicMax(&s_tile_maxpos, tpos);
+        atomicOr(&s_tile_seqs, 1ull << tseq);
+    }
+
+    // ---- Q of this lane's query: quantise to Q8_0 per 32-block (lane holds dims 32 b + 16 kg .. + 15 of block b)
+    i32x4 qc[NB];
+    float dq[NB];
+    {
+        const float *qrow = a.q + ((size_t)qt * H + h) * D;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            f32x4 x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = *reinterpret_cast<const f32x4 *>(qrow + 32 * b + 16 * kg + 4 * i);
+            float am = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) am = fmaxf(am, fmaxf(fmaxf(fabsf(x[i].x), fabsf(x[i].y)), fmaxf(fabsf(x[i].z), fabsf(x[i].w))));
+            am = fmaxf(am, __shfl_xor(am, 32, 64));            // the other half of the block lives in lane ^ 32
+            const float d = am / 127.0f;
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            int w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int c0 = (int)roundf(x[i].x * id), c1 = (int)roundf(x[i].y * id), c2 = (int)roundf(x[i].z * id), c3 = (int)roundf(x[i].w * id);
+                w[i] = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16) | ((c3 & 0xff) << 24);
+            }
+            qc[b].x = w[0]; qc[b].y = w[1]; qc[b].z = w[2]; qc[b].w = w[3];
+            dq[b] = h2f(f2h(d));
+        }
+    }
+
+    // ---- staging roles: piece p = tid (+ NT) -> key p / 8, 16-byte column p % 8 of the 128-byte K / V rows
+    constexpr int NP = (CK * 8 + NT - 1) / NT;
+    u32x4 kq[NP], vq[NP];
+    constexpr int NKD = (CK * NB + NT - 1) / NT;
+    float kdn[NKD], vdn[NP];
+    int cpn = -1;
+    unsigned long long csn = 0ull;
+    auto load_data = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int p = tid + NT * i;
+            int key = p >> 3;
+            if (key >= CK) key = CK - 1;
+            int cell = c * CK + key;
+            if (cell >= n_ctx) cell = n_ctx - 1;
+            const size_t rowi = head_row0 + cell;
+            kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p & 7) * 16);
+            vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D + (p & 7) * 16);
+            vdn[i] = h2f(a.kv.vd[rowi * NB + ((p & 7) >> 1)]);
+        }
+#pragma unroll
+        for (int i = 0; i < NKD; i++) {
+            int q = tid + NT * i;
+            if (q >= CK * NB) q = CK * NB - 1;
+            int cell = c * CK + (q & 31);
+            if (cell >= n_ctx) cell = n_ctx - 1;
+            kdn[i] = h2f(a.kv.kd[(head_row0 + cell) * NB + (q >> 5)]);
+        }
+        cpn = -1; csn = 0ull;
+        const int mcell = c * CK + tid;
+        if (tid < CK && mcell < n_kv) { cpn = a.cell_pos[mcell]; csn = a.cell_seq[mcell]; }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int p = tid + NT * i;
+            if (p >= CK * 8) continue;
+            const int key = p >> 3, col = p & 7;               // dims 16 col .. 16 col + 15
+            *reinterpret_cast<u32x4 *>(S.k + key * K_STRIDE + col * 16) = kq[i];
+            // V' = code * d_v, split exactly into f16 hi + lo, written transposed in MFMA K-slot order
+            const int j = key >> 4, r8 = key & 15;              // key = 16 j + 8 (i >> 2) + 4 kgs + (i & 3)
+            const int kgs = (r8 >> 2) & 1, slot = ((r8 >> 3) << 2) | (r8 & 3);
+            const uint32_t wv[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int dim = col * 16 + e;
+                const float v = (float)(int8_t)((wv[e >> 2] >> (8 * (e & 3))) & 0xff) * vdn[i];
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot;
+                S.vh[o] = hi; S.vl[o] = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NKD; i++) {
+            const int q = tid + NT * i;
+            if (q < CK * NB) S.dk[(q >> 5) * CK + (q & 31)] = kdn[i];
+        }
+        if (tid < CK) { S.cpos[tid] = cpn; S.cseq[tid] = csn; }
+    };
+    auto next_visible = [&](int from) -> int {                   // first marked chunk >= from, or n_chunks
+        int c = from;
+        while (c < n_chunks) {
+            const unsigned w = s_vis[c >> 5] >> (c & 31);
+            if (w) return c + __builtin_ctz(w);
+            c = (c | 31) + 1;
+        }
+        return n_chunks;
+    };
+
+    // ---- online-softmax state of this lane's query and the O^T accumulators (d = 32 db + row of the tile)
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 O[4];
+#pragma unroll
+    for (int db = 0; db < 4; db++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) O[db][r] = 0.0f;
+
+    __syncthreads();                                            // tile bounds complete
+    // ---- which chunks matter: one pass over the cell table (a wave's 64 cells = two chunks per ballot)
+    for (int cell0 = 0; cell0 < n_chunks * CK; cell0 += NT) {
+        const int cell = cell0 + tid;
+        int mine = 0;
+        if (cell < n_kv) {
+            const int cp = a.cell_pos[cell];
+            const unsigned long long cs = a.cell_seq[cell];
+            mine = (cp >= 0 && cp <= s_tile_maxpos && (cs & s_tile_seqs) != 0ull) ? 1 : 0;
+        }
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) {
+            const int c0 = (cell0 + wave * 64) / CK;
+            if (c0 < MAX_CHUNKS) {
+                unsigned bits = ((unsigned)(bal & 0xffffffffull) != 0u ? 1u : 0u) | ((unsigned)(bal >> 32) != 0u ? 2u : 0u);
+                if (bits) atomicOr(&s_vis[c0 >> 5], bits << (c0 & 31));
+            }
+        }
+    }
+    __syncthreads();
+
+    int c = next_visible(0);
+    if (c < n_chunks) { load_data(c); store_chunk(); }
+    __syncthreads();
+    while (c < n_chunks) {
+        const int cn = next_visible(c + 1);
+        if (cn < n_chunks) load_data(cn);                       // in flight while this chunk is on the matrix cores
+        {
+            // ---- scores S^T[key][query] of this chunk
+            float sc[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = 0.0f;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const i32x4 ak = *reinterpret_cast<const i32x4 *>(S.k + n * K_STRIDE + 32 * b + 16 * kg);
+                i32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0;
+                const i32x16 I = __builtin_amdgcn_mfma_i32_32x32x32_i8(ak, qc[b], z, 0, 0, 0);
+#pragma unroll
+                for (int rq = 0; rq < 4; rq++) {
+                    const f32x4 dk4 = *reinterpret_cast<const f32x4 *>(S.dk + b * CK + 8 * rq + 4 * kg);   // keys 8 rq + 4 kg + (0..3)
+#pragma unroll
+                    for (int ri = 0; ri < 4; ri++) sc[rq * 4 + ri] += (float)I[rq * 4 + ri] * (dq[b] * dk4[ri]);
+                }
+            }
+            // ---- mask + online softmax (this lane: one query, 16 keys; partner lane ^ 32: the other 16)
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int cp = S.cpos[key];
+                const unsigned long long cs = S.cseq[key];
+                const bool vis = q_ok && cp >= 0 && cp <= tpos && ((cs >> tseq) & 1ull);
+                sc[r] = vis ? sc[r] * a.scale : -INFINITY;
+                mloc = fmaxf(mloc, sc[r]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            float p[16], lsum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                p[r] = (sc[r] == -INFINITY) ? 0.0f : expf(sc[r] - m_new);
+                lsum += p[r];
+            }
+            lsum += __shfl_xor(lsum, 32, 64);
+            const float alpha = (m_run == -INFINITY) ? 0.0f : expf(m_run - m_new);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) O[db][r] *= alpha;
+            // ---- P^T operands: f16 hi / lo, two MFMAs' worth (regs 0..7 and 8..15)
+            f16x8 ph[2], pl[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float v = p[8 * j + i];
+                    const _Float16 hi = (_Float16)v;
+                    ph[j][i] = hi;
+                    pl[j][i] = (_Float16)(v - (float)hi);
+                }
+            // ---- O^T[d][query] += V'^T . P^T
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int o = (((db * 2 + j) * 2 + kg) * 32 + n) * 8;
+                    const f16x8 avh = *reinterpret_cast<const f16x8 *>(S.vh + o);
+                    const f16x8 avl = *reinterpret_cast<const f16x8 *>(S.vl + o);
+                    O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, ph[j], O[db], 0, 0, 0);
+                    O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, pl[j], O[db], 0, 0, 0);
+                    O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, ph[j], O[db], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                        // chunk c consumed
+        if (cn < n_chunks) store_chunk();
+        __syncthreads();
+        c = cn;
+    }
+
+    // ---- out[t][h][d] = O / l ; lane (query n, kg) holds d = 32 db + 8 rq + 4 kg + (0..3)
+    if (q_ok) {
+        const float inv = 1.0f / l_run;
+        float *orow = a.out + ((size_t)qt * H + h) * D;
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+#pragma unroll
+            for (int rq = 0; rq < 4; rq++) {
+                f32x4 v;
+                v.x = O[db][rq * 4 + 0] * inv; v.y = O[db][rq * 4 + 1] * inv; v.z = O[db][rq * 4 + 2] * inv; v.w = O[db][rq * 4 + 3] * inv;
+                *reinterpret_cast<f32x4 *>(orow + 32 * db + 8 * rq + 4 * kg) = v;
+            }
+    }
+}
+
+}  // namespace
+
+bool flash_attn_prefill_applicable(const AttnArgs &a) {
+    const int R = a.G > 0 ? a.H / a.G : 0;
+    return a.D == 128 && a.T >= 32 && a.type_k == T_Q8_0 && a.type_v == T_Q8_0 && (R == 1 || R == 2 || R == 4 || R == 8) &&
+           a.n_kv_max <= MAX_CHUNKS * CK;
+}
+
+hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
+    const int R = a.H / a.G;
+    const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT));
+    const size_t lds = (size_t)CK * K_STRIDE + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
+    switch (R) {
+        case 1: hipLaunchKernelGGL(flash_attn_prefill_kernel<1>, grid, dim3(64), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(flash_attn_prefill_kernel<2>, grid, dim3(128), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(flash_attn_prefill_kernel<4>, grid, dim3(256), lds, st, a); break;
+        case 8: hipLaunchKernelGGL(flash_attn_prefill_kernel<8>, grid, dim3(512), lds, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.out_q) e = launch_quantize(a.out, a.H * a.D, a.T, *a.out_q, a.out_q8k, a.out_q80, st);
+    return e;
+}
+
+}  // namespace mi355

@@ -146,6 +146,9 @@ struct AttnArgs {
     bool out_q8k, out_q80;
 };
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
+// prompt processing on the matrix cores (attn_prefill.hip): D = 128, q8_0 K / V, T >= 32; q already rotated
+bool flash_attn_prefill_applicable(const AttnArgs &a);
+hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st);
 // decode-step variants (attn.hip): single round trip per workgroup; q passed UN-rotated (rope fused), NORM rope, D = 128
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra);
 int flash_attn_decode_splits(int n_kv_max);
