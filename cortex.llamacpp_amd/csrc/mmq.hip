@@ -597,9 +597,15 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
     using G = Geo<MT>;
     constexpr int SH = MINS ? 5 : 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int8_t *s_aq = reinterpret_cast<int8_t *>(smem);
-    int8_t *s_bh = s_aq + G::LDS_A, *s_bl = s_bh + G::LDS_P;
-    float *s_yd = reinterpret_cast<float *>(s_bl + G::LDS_P);
+    // two activation tiles: super-block sb is read from buffer sb & 1 while sb + 1 is written into the other one, so one
+    // barrier per super-block suffices and the LDS writes overlap the other waves' MFMA work
+    uint8_t *buf0 = smem, *buf1 = smem + G::LDS_BYTES;
+    auto p_aq = [&](int b) { return reinterpret_cast<int8_t *>(b ? buf1 : buf0); };
+    auto p_bh = [&](int b) { return p_aq(b) + G::LDS_A; };
+    auto p_bl = [&](int b) { return p_aq(b) + G::LDS_A + G::LDS_P; };
+    auto p_yd = [&](int b) { return reinterpret_cast<float *>(p_aq(b) + G::LDS_A + 2 * G::LDS_P); };
+    int8_t *s_aq = p_aq(0), *s_bh = p_bh(0), *s_bl = p_bl(0);
+    float *s_yd = p_yd(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = K >> 8;
@@ -663,6 +669,7 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
     __syncthreads();
 
     for (int sb = 0; sb < nb; sb++) {
+        s_aq = p_aq(sb & 1); s_bh = p_bh(sb & 1); s_bl = p_bl(sb & 1); s_yd = p_yd(sb & 1);
         const bool more = sb + 1 < nb;
         const int sbn = more ? sb + 1 : sb;
         const uint8_t *blkn = blk0 + (size_t)sbn * PL_BLOCK;
@@ -746,27 +753,32 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
                     const int r = rq * 4 + ri;
                     const float yd = yd4[ri];
                     const int isum = (H[t][r] << SH) + L[t][r];
+                    // yd * (d * isum - dmin * msum) with explicit fmas: 6 VALU ops per output instead of 10 (this fold was the
+                    // kernel's VALU bottleneck: PMC showed 9.5 VALU instructions per MFMA); one rounding fewer than the CPU's
+                    // expression, far inside the 2e-5 parity bound
                     if (MINS) {
-                        facc[t][r] += (dd * yd) * (float)isum - (dm * yd) * (float)ms[r];
+                        const float t0 = fmaf(dd, (float)isum, -(dm * (float)ms[r]));
+                        facc[t][r] = fmaf(yd, t0, facc[t][r]);
                     } else {
-                        facc[t][r] += (dd * yd) * (float)isum;
+                        facc[t][r] = fmaf(yd * dd, (float)isum, facc[t][r]);
                     }
                 }
             }
         }
-        __syncthreads();                             // every wave is done reading this tile
-        if (more) {
+        if (more) {                                  // next tile into the other buffer (nobody reads it during this iteration)
+            int8_t *w_aq = p_aq((sb + 1) & 1), *w_bh = p_bh((sb + 1) & 1), *w_bl = p_bl((sb + 1) & 1);
+            float *w_yd = p_yd((sb + 1) & 1);
 #pragma unroll
-            for (int i = 0; i < G::NST; i++) if (tid + NTHREADS * i < G::TOK_TILE * 16) *reinterpret_cast<u32x4 *>(s_aq + st_l[i]) = nxt[i];
+            for (int i = 0; i < G::NST; i++) if (tid + NTHREADS * i < G::TOK_TILE * 16) *reinterpret_cast<u32x4 *>(w_aq + st_l[i]) = nxt[i];
             if (tid < G::TOK_TILE) {
-                s_yd[tid] = nyd;
+                w_yd[tid] = nyd;
                 if (MINS) {
-                    *reinterpret_cast<u32x4 *>(s_bh + tid * 16) = nbh;
-                    *reinterpret_cast<u32x4 *>(s_bl + tid * 16) = nbl;
+                    *reinterpret_cast<u32x4 *>(w_bh + tid * 16) = nbh;
+                    *reinterpret_cast<u32x4 *>(w_bl + tid * 16) = nbl;
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                             // tile sb + 1 complete; every wave is done reading tile sb
     }
     // store: lane = weight row n, regs = tokens; 32 consecutive rows per token -> 128-B coalesced.  Residual values are
     // all requested before the first add (a load + wait per element serialised the epilogue).
@@ -894,7 +906,9 @@ hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K,
         using G = Geo<MTV>;                                                                                               \
         const int nrt = (n_rows + G::ROW_TILE - 1) / G::ROW_TILE, ntt = (T + G::TOK_TILE - 1) / G::TOK_TILE;              \
         const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));                                                           \
-        hipLaunchKernelGGL((mmq_planes_kernel<MINSV, MTV>), grid, dim3(NTHREADS), (size_t)G::LDS_BYTES, st, planes, n_rows, K, T, nrt, ntt, \
+        const size_t lds2 = 2 * (size_t)G::LDS_BYTES;                                                                     \
+        if (lds2 > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes_kernel<MINSV, MTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        hipLaunchKernelGGL((mmq_planes_kernel<MINSV, MTV>), grid, dim3(NTHREADS), lds2, st, planes, n_rows, K, T, nrt, ntt, \
                            q.qs, q.d, bh, bl, out, ld_out, resid);                                                        \
     }
     if (mins) { if (mt == 1) PLN(true, 1) else PLN(true, 2) }
