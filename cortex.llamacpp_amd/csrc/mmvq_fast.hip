@@ -203,18 +203,21 @@ __device__ __forceinline__ void stage_issue(const MMVQArgs &a, u32x4_t (&rq)[Sta
     const int tid = threadIdx.x;
     if (FUSE == 0) {
         const u32x4_t *src = reinterpret_cast<const u32x4_t *>(a.aq);
+        const int n16 = (a.K >> 8) * 16;                       // K may end inside the last pass (K % 256 == 0 only)
 #pragma unroll
-        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; rq[j] = src[i < S::N16 ? i : S::N16 - 1]; }
+        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; rq[j] = src[i < n16 ? i : n16 - 1]; }
         const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(a.abs);
+        const int nbt = a.K >> 8;
 #pragma unroll
-        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; rb[j] = bsrc[i < KB * 64 ? i : KB * 64 - 1]; }
-        rdv = a.ad[tid < KB * 8 ? tid : KB * 8 - 1];
+        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; rb[j] = bsrc[i < nbt * 8 ? i : nbt * 8 - 1]; }
+        rdv = a.ad[tid < nbt ? tid : nbt - 1];
     } else {
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int j = 0; j < S::NJW; j++) {
             const int b = wave + S::NW * j;
-            const int bc = b < KB * 8 ? b : KB * 8 - 1;            // clamped: always a valid address, result unused when b is out of range
+            const int nbt = a.K >> 8;
+            const int bc = b < nbt ? b : nbt - 1;                  // clamped: always a valid address, result unused when b is out of range
             rxv[j] = *reinterpret_cast<const f32x4_t *>(a.nx + bc * 256 + lane * 4);
             if (FUSE == 1) rwv[j] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
         }
@@ -225,17 +228,18 @@ template <int KB, int NT, int FUSE>
 __device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&rq)[StageDims<KB, NT>::NQ], const uint32_t (&rb)[StageDims<KB, NT>::NB32], float rdv,
                                              const f32x4_t (&rxv)[StageDims<KB, NT>::NJW], const f32x4_t (&rwv)[StageDims<KB, NT>::NJW], uint8_t *smem) {
     using S = StageDims<KB, NT>;
-    constexpr int K = KB * 2048;
+    constexpr int K = KB * 2048;                               // LDS layout is sized for whole passes
+    const int nbt = a.K >> 8;                                  // super-blocks that exist
     const int tid = threadIdx.x;
     int8_t *qs = reinterpret_cast<int8_t *>(smem);
     float *d = reinterpret_cast<float *>(smem + K);
     int16_t *bs = reinterpret_cast<int16_t *>(smem + K + (((K >> 8) * 4 + 15) & ~15));
     if (FUSE == 0) {
 #pragma unroll
-        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; if (i < S::N16) reinterpret_cast<u32x4_t *>(qs)[i] = rq[j]; }
+        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; if (i < nbt * 16) reinterpret_cast<u32x4_t *>(qs)[i] = rq[j]; }
 #pragma unroll
-        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; if (i < KB * 64) reinterpret_cast<uint32_t *>(bs)[i] = rb[j]; }
-        if (tid < KB * 8) d[tid] = rdv;
+        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; if (i < nbt * 8) reinterpret_cast<uint32_t *>(bs)[i] = rb[j]; }
+        if (tid < nbt) d[tid] = rdv;
     } else {
         double *red = reinterpret_cast<double *>(smem + a.red_off);
         const int lane = tid & 63, wave = tid >> 6;
@@ -247,7 +251,7 @@ __device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&
                 const f32x4_t v = rxv[j];
                 double t = 0.0;
                 t += (double)(v.x * v.x); t += (double)(v.y * v.y); t += (double)(v.z * v.z); t += (double)(v.w * v.w);
-                if (wave + S::NW * j < KB * 8) sum += t;
+                if (wave + S::NW * j < nbt) sum += t;
             }
             sum = wave_sum(sum);
             if (lane == 0) red[wave] = sum;
@@ -255,13 +259,13 @@ __device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < S::NW; w++) tot += red[w];
-            const float mean = (float)(tot / (double)K);
+            const float mean = (float)(tot / (double)a.K);
             scale = 1.0f / sqrtf(mean + a.neps);
         }
 #pragma unroll
         for (int j = 0; j < S::NJW; j++) {
             const int b = wave + S::NW * j;
-            if (b >= KB * 8) continue;                             // wave-uniform
+            if (b >= nbt) continue;                                // wave-uniform
             const int e0 = b * 256 + lane * 4;
             f32x4_t v = rxv[j];
             if (FUSE == 1) {
@@ -281,6 +285,20 @@ __device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&
     return A;
 }
 
+// slice of super-block sb, or a zero-scale slice past the end of the row (partial last pass): its dot contributes 0
+template <int TYPE>
+__device__ __forceinline__ ActSlice global_slice_t(const MMVQArgs &a, int sb, int nb, const LaneRole &L) {
+    ActSlice s = global_slice<TYPE>(a, sb < nb ? sb : nb - 1, L);
+    if (sb >= nb) s.yd = 0.0f;
+    return s;
+}
+template <int TYPE>
+__device__ __forceinline__ ActSlice read_slice_t(const ActL &A, int sb, int nb, const LaneRole &L) {
+    ActSlice s = read_slice<TYPE>(A, sb < nb ? sb : nb - 1, L);
+    if (sb >= nb) s.yd = 0.0f;
+    return s;
+}
+
 // One segment, persistent waves.  A unit is (row pair, PPU passes): PPU = 2 for an even number of passes, 1 otherwise,
 // so that every unit has the same shape and its loads need no condition.  NSETS units (8 Raw blocks in all) are always
 // in flight ahead of the one being decoded.
@@ -295,7 +313,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     using R = Raw<TYPE>;
     constexpr bool ACT_REGS = KB <= 2;
     constexpr bool DIRECT = ACT_REGS && FUSE == 0;
-    constexpr int nb = KB * 8;
+    const int nb = a.K >> 8;                            // super-blocks per row (the last pass may be partial: K % 256 == 0)
     constexpr int PPU = (KB % 2 == 0) ? 2 : 1;          // passes per unit
     constexpr int NCH = KB / PPU;                       // units per row pair
     constexpr int NSETS = 4 / PPU;                      // register sets in the ring (2 rows x PPU passes each)
@@ -314,8 +332,8 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     ActSlice S0, S1;                                    // K <= 4096: this lane's slices of pass 0 / pass 1, kept in registers
     STAGE_REGS_DECL(KB, NT);
     if (DIRECT) {
-        S0 = global_slice<TYPE>(a, L.sbl, L);
-        if (KB > 1) S1 = global_slice<TYPE>(a, 8 + L.sbl, L);
+        S0 = global_slice_t<TYPE>(a, L.sbl, nb, L);
+        if (KB > 1) S1 = global_slice_t<TYPE>(a, 8 + L.sbl, nb, L);
     } else {
         stage_issue<KB, NT, FUSE>(a, STAGE_REGS_ARGS);
     }
@@ -335,8 +353,10 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
         if (!real) { ra = W0; rbp = W0; sb0 = L.sbl; }              // nothing to fetch: everybody's dummy is row 0, pass 0
 #pragma unroll
         for (int p = 0; p < PPU; p++) {
-            w[2 * p].load(ra, nb, sb0 + 8 * p, L);
-            w[2 * p + 1].load(rbp, nb, sb0 + 8 * p, L);
+            int sb = sb0 + 8 * p;
+            if (sb >= nb) sb = nb - 1;                  // tail of a partial last pass: any valid block, its slice scale is zero
+            w[2 * p].load(ra, nb, sb, L);
+            w[2 * p + 1].load(rbp, nb, sb, L);
         }
     };
 #pragma unroll
@@ -347,8 +367,8 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     if (!DIRECT) {
         AL = stage_finish<KB, NT, FUSE>(a, STAGE_REGS_ARGS, smem);
         if (ACT_REGS) {
-            S0 = read_slice<TYPE>(AL, L.sbl, L);
-            if (KB > 1) S1 = read_slice<TYPE>(AL, 8 + L.sbl, L);
+            S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
+            if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
         }
     }
 
@@ -357,7 +377,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
         const int pi = u / NCH, ch = u - pi * NCH;
 #pragma unroll
         for (int p = 0; p < PPU; p++) {
-            const ActSlice sl = ACT_REGS ? (ch * PPU + p == 0 ? S0 : S1) : read_slice<TYPE>(AL, (ch * PPU + p) * 8 + L.sbl, L);
+            const ActSlice sl = ACT_REGS ? (ch * PPU + p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, (ch * PPU + p) * 8 + L.sbl, nb, L);
             acc0 += w[2 * p].dot(sl, L);
             acc1 += w[2 * p + 1].dot(sl, L);
         }
@@ -427,9 +447,9 @@ __global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
 }  // namespace
 
 bool mmvq_fast_applicable(const MMVQArgs &a) {
-    if (a.T != 1 || (a.K % 2048) != 0) return false;
-    const int kb = a.K >> 11;
-    if (kb != 1 && kb != 2 && kb != 4 && kb != 7 && kb != 14) return false;
+    if (a.T != 1 || (a.K % 256) != 0 || a.K <= 0) return false;
+    const int kb = (a.K + 2047) >> 11;                         // passes of 8 super-blocks; the last one may be partial
+    if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7 && kb != 14) return false;
     const int n = a.epi == EPI_SWIGLU ? 2 : a.n_seg;
     for (int s = 0; s < n; s++)
         if (a.seg[s].type != T_Q4_K && a.seg[s].type != T_Q5_K && a.seg[s].type != T_Q6_K) return false;
@@ -444,7 +464,7 @@ void mmvq_fast_set_threads(int nt) { g_fast_nt = (nt == 512 || nt == 768) ? nt :
 hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
     if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
     const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
-    const int kb = a.K >> 11;
+    const int kb = (a.K + 2047) >> 11;
     // persistent grid, one workgroup per CU: 12 waves (768 threads) when the registers allow it (K <= 4096), else 8;
     // between the two, pick the one whose unit count per wave divides most evenly (e.g. 14336 pairs over 256 x 8
     // waves = exactly 7 each), fewer resident waves costing a little latency hiding
@@ -478,7 +498,7 @@ hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
     for (int s = n_work_seg; s < 3; s++) a.seg_block0[s + 1] = a.seg_block0[n_work_seg];
     const int blocks = a.seg_block0[n_work_seg];
     if (a.epi == EPI_SWIGLU) a.n_seg = 1;
-    const size_t K = (size_t)a.K;
+    const size_t K = (size_t)kb * 2048;                        // whole passes
     size_t lds = K + (((K >> 8) * 4 + 15) & ~(size_t)15) + (((K >> 4) * 2 + 15) & ~(size_t)15);
     lds = (lds + 15) & ~(size_t)15;
     a.red_off = (int)lds;
@@ -488,7 +508,9 @@ hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
     switch (kb) {
         case 1: if (nt == 768) FAST_F(1, 768); else FAST_F(1, 512); break;
         case 2: if (nt == 768) FAST_F(2, 768); else FAST_F(2, 512); break;
+        case 3: FAST_F(3, 512); break;
         case 4: FAST_F(4, 512); break;
+        case 6: if (a.fuse_mode == 2) FAST(6, 512, 2); else FAST(6, 512, 0); break;
         case 7: if (a.fuse_mode == 2) FAST(7, 512, 2); else FAST(7, 512, 0); break;
         case 14: if (a.fuse_mode == 2) FAST(14, 512, 2); else FAST(14, 512, 0); break;
         default: return hipErrorInvalidValue;

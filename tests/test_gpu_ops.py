@@ -45,6 +45,8 @@ def test_activation_quant_bit_exact(be, act):
 @pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K, Q8_0])
 @pytest.mark.parametrize("K,N,T", [(256, 3, 1), (2048, 37, 1), (4096, 64, 2), (5632, 10, 3), (11008, 5, 5), (14336, 8, 1),
                                    (4096, 33, 21), (14336, 6, 9), (5632, 7, 16), (8192, 4, 8),
+                                   # single token, K ending inside a pass of 2048 (persistent kernel's partial last pass)
+                                   (5632, 70, 1), (11008, 33, 1), (5120, 20, 1), (13824, 9, 1), (768, 11, 1), (28672, 3, 1),
                                    (2048, 130, 40), (4096, 64, 129), (5632, 37, 33)])   # T >= 32: MFMA path for K-quants
 def test_mul_mat_int_partials_exact_and_value(be, t, K, N, T):
     rng = np.random.default_rng(K + N + t)
