@@ -410,15 +410,17 @@ __global__ __launch_bounds__(256) void flash_attn_split_kernel(const AttnArgs a)
 //  3. wave 0 re-reads the 256 merged values from LDS (4 per lane) and, when asked, quantises them for the attn_output
 //     mat-vec (saves a launch on the decode path).
 __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits,
-                                                                 ActQuant q, int want_q8k, int want_q80) {
+                                                                 ActQuant q, int want_q8k, int want_q80, const int32_t *tok_nsplits) {
     extern __shared__ float wgt[];                 // [hpb][splits]
     __shared__ __attribute__((aligned(16))) float merged[256];
     const int t = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int E = H * D, nblk = E >> 8;
+    const int stride_s = splits;                   // workspace stride; a token of a batched step may use fewer slots
+    if (tok_nsplits) splits = tok_nsplits[t];
     const int hpb = 256 / D;                       // heads per block (D = 64 -> 4, D = 128 -> 2)
     const int h0 = b * hpb;
     if (wave < hpb) {
-        const float *p = part + ((size_t)t * H + h0 + wave) * splits * (D + 2);
+        const float *p = part + ((size_t)t * H + h0 + wave) * stride_s * (D + 2);
         float M = -INFINITY;
         for (int s0 = 0; s0 < splits; s0 += 64) {
             const int sidx = s0 + lane;
@@ -433,20 +435,20 @@ __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *pa
                 const float m = p[(size_t)sidx * (D + 2) + D];
                 l = p[(size_t)sidx * (D + 2) + D + 1];
                 w = (m == -INFINITY) ? 0.0f : expf(m - M);
-                wgt[wave * splits + sidx] = w;
+                wgt[wave * stride_s + sidx] = w;
             }
             den += wave_sum(w * l);
         }
         const float inv = 1.0f / den;
-        for (int sidx = lane; sidx < splits; sidx += 64) wgt[wave * splits + sidx] *= inv;
+        for (int sidx = lane; sidx < splits; sidx += 64) wgt[wave * stride_s + sidx] *= inv;
     }
     __syncthreads();
     {
         const int e = tid, hl = e / D, d = e - hl * D;
-        const float *p = part + ((size_t)t * H + h0 + hl) * splits * (D + 2) + d;
+        const float *p = part + ((size_t)t * H + h0 + hl) * stride_s * (D + 2) + d;
         float acc = 0.0f;
         for (int s = 0; s < splits; s++) {
-            const float w = wgt[hl * splits + s];
+            const float w = wgt[hl * stride_s + s];
             if (w != 0.0f) acc += w * p[(size_t)s * (D + 2)];        // chunks with no visible cell publish only (m, l)
         }
         merged[e] = acc;
@@ -566,7 +568,12 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     const int g = blockIdx.x, sp = blockIdx.y, t = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_ctx = a.n_ctx, H = a.H;
-    const int c_lo = sp * C;
+    int chunk = sp;
+    if (!FUSED && a.tok_chunks) {                              // batched steps: walk this token's chunk list only
+        if (sp >= a.tok_nchunks[t]) return;
+        chunk = a.tok_chunks[(size_t)t * a.chunk_stride + sp];
+    }
+    const int c_lo = chunk * C;
     const size_t head_row0 = (size_t)g * n_ctx;
 
     // ---- issue every global load of the workgroup
@@ -900,7 +907,7 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
-                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), a.tok_nchunks);
     return hipGetLastError();
 }
 
@@ -935,7 +942,7 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     if (e != hipSuccess || counters) return e;
     const int nblk = (a.H * a.D) >> 8;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, 1), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
-                       fz.q, fz.want_q8k, fz.want_q80);
+                       fz.q, fz.want_q8k, fz.want_q80, (const int32_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -981,7 +988,7 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
-                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80));
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), a.tok_nchunks);
     return hipGetLastError();
 }
 

@@ -142,6 +142,11 @@ struct AttnArgs {
     float scale;
     float *part;               // workspace [T][H][splits][D+2]
     int splits;
+    // batched single-token steps: per token, the 64-cell chunks that can hold a visible cell (host-built from the cell
+    // table); nullptr = every chunk of the scanned range.  tok_chunks[t * chunk_stride + i], i < tok_nchunks[t] <= splits
+    const int32_t *tok_chunks = nullptr;
+    const int32_t *tok_nchunks = nullptr;
+    int chunk_stride = 0;
     const ActQuant *out_q;     // nullable: also quantise the merged rows (for attn_output)
     bool out_q8k, out_q80;
 };

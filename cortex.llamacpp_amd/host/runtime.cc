@@ -233,6 +233,7 @@ Context::~Context() {
     if (h_logits_) (void)hipHostFree(h_logits_);
     if (h_argmax_) (void)hipHostFree(h_argmax_);
     if (h_embd_) (void)hipHostFree(h_embd_);
+    if (h_chunks_) (void)hipHostFree(h_chunks_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -351,6 +352,9 @@ bool Context::init(std::string &err) {
     d_argmax_ = (int32_t *)dalloc(T * 4);
     argmax_scratch_ = (float *)dalloc(T * 128 * 4);
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
+    chunk_stride_ = (int)((NC + 63) / 64);
+    d_chunks_ = (int32_t *)dalloc((size_t)64 * (chunk_stride_ + 1) * 4);
+    if (hipHostMalloc((void **)&h_chunks_, (size_t)64 * (chunk_stride_ + 1) * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     d_embd_ = (float *)dalloc(T * E * 4);
     if (hipHostMalloc((void **)&h_embd_, T * E * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     if (hipHostMalloc((void **)&h_argmax_, T * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
@@ -602,6 +606,10 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
         if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
+            if (T >= 2 && chunk_lmax_ > 0) {                   // batched step: per-token chunk lists (decode_ubatch)
+                aa.tok_chunks = d_chunks_; aa.tok_nchunks = d_chunks_ + (size_t)64 * chunk_stride_; aa.chunk_stride = chunk_stride_;
+                aa.splits = chunk_lmax_;
+            }
             static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
             if (attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra)) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch
@@ -766,6 +774,26 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         if (flags[i]) h_out[n_out++] = i;
     }
     if (hipMemcpyAsync(d_stage_, h_stage_, stage_bytes_, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "token upload failed"; return -1; }
+    // continuous-batching steps (a few tokens, usually one per sequence): each token scans only the 64-cell chunks that
+    // hold cells of its own sequence instead of the whole cache
+    chunk_lmax_ = 0;
+    if (n >= 2 && n <= 64) {
+        const int nch = (n_kv_ + 63) / 64;
+        std::vector<uint64_t> seq_of_chunk((size_t)nch, 0ull);
+        for (int i = 0; i < n_kv_ && i < (int)cells_.size(); i++)
+            if (cells_[(size_t)i].pos >= 0) seq_of_chunk[(size_t)(i >> 6)] |= cells_[(size_t)i].seqs;
+        int32_t *cnt = h_chunks_ + (size_t)64 * chunk_stride_;
+        for (int t = 0; t < n; t++) {
+            int32_t *lst = h_chunks_ + (size_t)t * chunk_stride_;
+            int c = 0;
+            const uint64_t bit = 1ull << (seq[t] & 63);
+            for (int ch = 0; ch < nch; ch++) if (seq_of_chunk[(size_t)ch] & bit) lst[c++] = ch;
+            cnt[t] = c;
+            chunk_lmax_ = std::max(chunk_lmax_, c);
+        }
+        if (chunk_lmax_ < 1) chunk_lmax_ = 1;
+        if (hipMemcpyAsync(d_chunks_, h_chunks_, (size_t)64 * (chunk_stride_ + 1) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "chunk list upload failed"; return -1; }
+    }
     // rocprofv3 --pmc does not keep copy-engine transfers ordered with the kernels it serialises (observed: kernels reading
     // the previous step's token / position block); MI355_PROFILER_SAFE=1 drains the stream around the transfers
     static const bool profiler_safe = getenv("MI355_PROFILER_SAFE") && getenv("MI355_PROFILER_SAFE")[0] == '1';

@@ -162,6 +162,9 @@ class Context {
     float *att_part_ = nullptr;
     float *d_embd_ = nullptr, *h_embd_ = nullptr;   // [n_ubatch][n_embd], embeddings mode
     bool embd_fetched_ = false, last_was_embd_ = false;
+    // batched single-token steps: per-token lists of the 64-cell chunks that hold cells of the token's sequence
+    int32_t *h_chunks_ = nullptr, *d_chunks_ = nullptr;     // [64][chunk_stride_] lists, then [64] counts
+    int chunk_stride_ = 0, chunk_lmax_ = 0;                 // lmax = longest list of the current batch (0 = lists not in use)
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;
