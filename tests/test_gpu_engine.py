@@ -156,3 +156,23 @@ def test_errors_and_unload(pkg, tiny_vocab_model):
     res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "hi"}], max_tokens=4)
     assert res[-1][0]["status_code"] == 409
     e.close()
+
+
+def test_context_shift_and_prompt_cache_on_device(pkg, tiny_vocab_model):
+    """A slot context of 96 cells and 200 generated tokens: the loop must shift the context (kv_seq_rm + kv_seq_add with
+    K re-rotation on the device) several times and keep producing tokens; then a second request sharing the prompt
+    prefix reuses the cache (cache_prompt) and, being greedy, starts with the same text."""
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=96, n_parallel=1, ngl=100, user_prompt="u:", ai_prompt="a:",
+                            caching_enabled=True)
+    assert st["status_code"] == 200
+    msgs = [{"role": "user", "content": "abc def ghi"}]
+    r1 = e.chat_completion(model="tiny-d128", messages=msgs, max_tokens=200, ignore_eos=True, **GREEDY)[-1]
+    assert r1[0]["status_code"] == 200
+    u = r1[1]["usage"]
+    assert u["completion_tokens"] == 200                       # went well past the 96-cell context
+    r2 = e.chat_completion(model="tiny-d128", messages=msgs, max_tokens=12, ignore_eos=True, **GREEDY)[-1]
+    assert r2[0]["status_code"] == 200
+    a, b = _norm(r1[1]["choices"][0]["message"]["content"]), _norm(r2[1]["choices"][0]["message"]["content"])
+    assert len(b) > 0 and a[:max(1, len(b) // 2)] == b[:max(1, len(b) // 2)]
+    e.close()
