@@ -50,7 +50,7 @@ struct Chunk {
 __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 8 * (i >> 2) + 4 * kg + (i & 3); }
 
 template <int R>
-__global__ __launch_bounds__(64 * R) void flash_attn_prefill_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Chunk S;
     S.k = reinterpret_cast<int8_t *>(smem);
