@@ -31,6 +31,9 @@ class IBackend {
     virtual int decode(const BatchView &b) = 0;
     // logits row of batch index i of the last decode (llama_get_logits_ith)
     virtual const float *logits_ith(int i) = 0;
+    // index of the largest logit of batch row i, computed on the device (first maximum wins), or -1 when the backend has
+    // no such front end: lets a purely greedy request skip the host pass over the vocabulary
+    virtual int argmax_ith(int i) { (void)i; return -1; }
     // llama_set_embeddings / llama_get_embeddings_ith (llama_server_context.cc:299, 1042-1044)
     virtual void set_embeddings(bool on) = 0;
     virtual const float *embeddings_ith(int i) = 0;

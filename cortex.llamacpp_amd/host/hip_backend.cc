@@ -34,6 +34,7 @@ class HipBackend : public IBackend {
         return ctx_->decode(b.n_tokens, b.token, b.pos, n_seq_id_.data(), seq_ptr_.data(), b.logits);
     }
     const float *logits_ith(int i) override { return ctx_->logits_ith(i); }
+    int argmax_ith(int i) override { return ctx_->argmax_ith(i); }
     void set_embeddings(bool on) override { ctx_->embeddings_enabled = on; }
     const float *embeddings_ith(int i) override { return ctx_->embeddings_ith(i); }
     void kv_clear() override { ctx_->kv_clear(); }

@@ -38,6 +38,10 @@ class Sampler {
     void reset();
     void accept(int32_t token);
     int32_t sample(const float *logits, int n_vocab);
+    // true when sample() would return the plain argmax of the raw logits (greedy, nothing modifies them, no probabilities
+    // asked for): the caller may then take the device-side argmax instead of reading the row
+    bool is_plain_greedy() const;
+    void set_greedy_result(int32_t tok) { cand_.assign(1, TokenProb{tok, 1.0f}); }
     // candidates of the last sample(), sorted by probability (descending), probabilities after the chain
     const std::vector<TokenProb> &candidates() const { return cand_; }
     const SamplingParams &params() const { return p_; }

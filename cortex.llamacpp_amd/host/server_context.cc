@@ -585,9 +585,16 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                 continue;
             }
             CompletionTokenOutput result;
-            const float *logits = be_->logits_ith(slot.i_batch - i);
-            if (!logits) { slot.Release(); SendError(slot, "no logits"); slot.i_batch = -1; continue; }
-            const int32_t id = slot.smpl->sample(logits, be_->n_vocab());
+            int32_t id = -1;
+            if (slot.smpl->is_plain_greedy()) {             // device-side greedy front end: no pass over the vocabulary on the host
+                id = be_->argmax_ith(slot.i_batch - i);
+                if (id >= 0) slot.smpl->set_greedy_result(id);
+            }
+            if (id < 0) {
+                const float *logits = be_->logits_ith(slot.i_batch - i);
+                if (!logits) { slot.Release(); SendError(slot, "no logits"); slot.i_batch = -1; continue; }
+                id = slot.smpl->sample(logits, be_->n_vocab());
+            }
             slot.smpl->accept(id);
             if (slot.n_decoded == 1) {
                 slot.t_start_genereration = time_us();

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <thread>
 #include <map>
+#include <random>
 #include <set>
 #include <string>
 
@@ -172,6 +173,45 @@ static void test_sampler() {
 
 // The reference counts n_decoded when a sampled token is fed back (llama_server_context.cc:1335), so the budget check
 // (:787) fires on the (n_predict+1)-th sampled token: n_predict = n yields n + 1 pieces of text and tokens_predicted = n.
+static void test_sampler_topk_matches_full_sort() {
+    // the one-pass heap selection with sparse overrides against a full sort of the modified row, with ties and
+    // overrides that move tokens both ways across the cut
+    std::mt19937 rng(7);
+    const int V = 5000;
+    for (int trial = 0; trial < 20; trial++) {
+        std::vector<float> lg((size_t)V);
+        for (auto &x : lg) x = (float)((int)(rng() % 2001) - 1000) / 64.0f;      // coarse grid: many exact ties
+        SamplingParams p;
+        p.temp = 1.0f; p.top_k = 1 + (int)(rng() % 60); p.top_p = 1.0f; p.min_p = 0.0f; p.seed = 5;
+        p.penalty_repeat = 1.3f; p.penalty_freq = 0.1f; p.penalty_present = 0.2f; p.penalty_last_n = 16;
+        for (int b = 0; b < 5; b++) p.logit_bias.push_back({(int)(rng() % V), (float)((int)(rng() % 41) - 20)});
+        Sampler s(p);
+        std::vector<int> prev;
+        for (int i = 0; i < 20; i++) { const int t = (int)(rng() % V); s.accept(t); prev.push_back(t); }
+        if (prev.size() > 16) prev.erase(prev.begin(), prev.end() - 16);
+        std::vector<float> mod = lg;
+        for (const auto &lb : p.logit_bias) mod[(size_t)lb.first] += lb.second;
+        std::map<int, int> cnt;
+        for (int t : prev) cnt[t]++;
+        for (const auto &kv : cnt) {
+            float &l = mod[(size_t)kv.first];
+            if (l <= 0) l *= p.penalty_repeat; else l /= p.penalty_repeat;
+            l -= (float)kv.second * p.penalty_freq + p.penalty_present;
+        }
+        std::vector<int> order((size_t)V);
+        for (int i = 0; i < V; i++) order[(size_t)i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return mod[(size_t)a] > mod[(size_t)b] || (mod[(size_t)a] == mod[(size_t)b] && a < b); });
+        s.sample(lg.data(), V);
+        const auto &c = s.candidates();
+        CHECK((int)c.size() == p.top_k);
+        for (size_t i = 0; i < c.size(); i++) CHECK(c[i].tok == order[i]);
+        SamplingParams g = p; g.temp = 0.0f;
+        Sampler sg(g);
+        for (int t : prev) sg.accept(t);
+        CHECK(sg.sample(lg.data(), V) == order[0]);
+    }
+}
+
 static std::string expected_text(const FakeBackend &be, const std::vector<int32_t> &prompt, int n_predict) {
     const int n = n_predict + 1;
     std::string s;
@@ -450,6 +490,7 @@ int main(int argc, char **argv) {
     test_json();
     test_vocab();
     test_sampler();
+    test_sampler_topk_matches_full_sort();
     test_slot_loop();
     test_prompt_cache_and_shift();
     test_kv_full_error();
