@@ -5,8 +5,68 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <functional>
 
 namespace mi355 {
+
+// Minimal fork-join pool: run(n, f) calls f(0..n-1) on the workers plus the caller and returns when all are done.
+struct LlamaServerContext::SamplePool {
+    explicit SamplePool(int n_threads) {
+        for (int i = 0; i < n_threads; i++) workers.emplace_back([this] { loop(); });
+    }
+    ~SamplePool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void run(int n, const std::function<void(int)> &f) {
+        if (n <= 1 || workers.empty()) { for (int i = 0; i < n; i++) f(i); return; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = &f; total = n; next = 0; done = 0; gen++;
+        }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return done == total; });
+        fn = nullptr;
+    }
+    void work() {
+        for (;;) {
+            int i;
+            const std::function<void(int)> *f;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!fn || next >= total) return;
+                i = next++; f = fn;
+            }
+            (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (++done == total) cv_done.notify_all();
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    int total = 0, next = 0, done = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+};
 
 int64_t time_us() {
     using namespace std::chrono;
@@ -576,6 +636,8 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
             i -= n_batch;
             continue;
         }
+        // phase 1: token ids of every generating slot of this chunk (host sampling in parallel, device argmax for plain greedy)
+        std::vector<LlamaClientSlot *> gen;
         for (auto &slot : slots) {
             if (slot.i_batch < i || slot.i_batch >= i + nt) continue;
             if (slot.embedding) {                        // prompt evaluated for embedding (:1670-1676)
@@ -584,17 +646,30 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                 slot.i_batch = -1;
                 continue;
             }
-            CompletionTokenOutput result;
-            int32_t id = -1;
+            gen.push_back(&slot);
+        }
+        std::vector<int32_t> ids(gen.size(), -1);
+        std::vector<const float *> rows(gen.size(), nullptr);
+        for (size_t gi = 0; gi < gen.size(); gi++) {
+            LlamaClientSlot &slot = *gen[gi];
             if (slot.smpl->is_plain_greedy()) {             // device-side greedy front end: no pass over the vocabulary on the host
-                id = be_->argmax_ith(slot.i_batch - i);
-                if (id >= 0) slot.smpl->set_greedy_result(id);
+                ids[gi] = be_->argmax_ith(slot.i_batch - i);
+                if (ids[gi] >= 0) { slot.smpl->set_greedy_result(ids[gi]); continue; }
             }
-            if (id < 0) {
-                const float *logits = be_->logits_ith(slot.i_batch - i);
-                if (!logits) { slot.Release(); SendError(slot, "no logits"); slot.i_batch = -1; continue; }
-                id = slot.smpl->sample(logits, be_->n_vocab());
-            }
+            rows[gi] = be_->logits_ith(slot.i_batch - i);
+        }
+        const int n_vocab = be_->n_vocab();
+        const std::function<void(int)> sample_one = [&](int gi) {
+            if (ids[(size_t)gi] < 0 && rows[(size_t)gi]) ids[(size_t)gi] = gen[(size_t)gi]->smpl->sample(rows[(size_t)gi], n_vocab);
+        };
+        if (!sample_pool_) sample_pool_.reset(new SamplePool((int)std::min<unsigned>(7u, std::max(1u, std::thread::hardware_concurrency()) - 1u)));
+        sample_pool_->run((int)gen.size(), sample_one);
+        // phase 2: in slot order, exactly as the reference's loop (:1665-1704)
+        for (size_t gi = 0; gi < gen.size(); gi++) {
+            LlamaClientSlot &slot = *gen[gi];
+            const int32_t id = ids[gi];
+            if (id < 0) { slot.Release(); SendError(slot, "no logits"); slot.i_batch = -1; continue; }
+            CompletionTokenOutput result;
             slot.smpl->accept(id);
             if (slot.n_decoded == 1) {
                 slot.t_start_genereration = time_us();

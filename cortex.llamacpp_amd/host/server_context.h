@@ -115,6 +115,10 @@ class LlamaServerContext {
   private:
     struct Task { int id; int target_id; bool cancel; Json data; bool embedding_mode = false; };
     void SendEmbedding(LlamaClientSlot &slot, int batch_index);
+    // sampling of the slots of one decoded batch, spread over a few host threads (the chains are independent per slot;
+    // at a 128 K vocabulary one chain costs ~0.1 ms, and the reference's loop runs them back to back)
+    struct SamplePool;
+    std::unique_ptr<SamplePool> sample_pool_;
     LlamaClientSlot *GetSlot(int id);
     bool LaunchSlotWithData(LlamaClientSlot *&slot, const Json &data);
     void ProcessTasks();
