@@ -67,7 +67,14 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                              float *out, int ld_out, const float *resid, hipStream_t st);
 // small batches (continuous-batching decode steps, 8 <= T <= 64): K split over the waves of a workgroup, GGUF-form weights
+struct MMQSeg {
+    const uint8_t *W; size_t row_bytes; int n_rows, type;
+    float *out; int ld_out; const float *resid;
+    int tile0;                 // first workgroup of this segment (set by the launcher)
+};
 bool mmq_ksplit_applicable(int type, int K, int T);
+hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
+                                   bool swiglu, hipStream_t st);
 hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
                              const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st);
 size_t mmq_prep_bytes(int K, int T);                       // bytes of each of the two block-sum planes

@@ -391,38 +391,112 @@ __global__ __launch_bounds__(NTHREADS) void mmq_kernel(const uint8_t *W, size_t 
 // the HBM rate) and the parallelism comes from K instead of tokens: workgroup = 32 weight rows x (32 * MT tokens), its 8
 // waves take the super-blocks round-robin, each wave stages its OWN activation tile (no workgroup barrier in the loop),
 // and the eight partial f32 tiles are summed through LDS in fixed wave order (deterministic).
+// One launch covers up to three tensors that share the activation (Q / K / V), or the gate / up pair with the SwiGLU
+// applied in the epilogue (both rows of a pair are contracted against the same staged tile).
+struct KSplitArgs {
+    MMQSeg seg[3];
+    int n_seg, K, T, swiglu;
+    const int8_t *aq; const float *ad; const int8_t *abh, *abl;
+};
+
+// one super-block of one 32-row tile against the wave's staged activation tile: facc += fold(H, L, block sums)
 template <int TYPE, int MT>
-__global__ __launch_bounds__(NTHREADS) void mmq_ksplit_kernel(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T,
-                                                              const int8_t *aq, const float *ad, const int8_t *abh, const int8_t *abl,
-                                                              float *out, int ld_out, const float *resid) {
+__device__ __forceinline__ void ksplit_superblock(const RowSB<TYPE> &R, const int8_t *s_aq, const int8_t *s_bh, const int8_t *s_bl, const float *s_yd,
+                                                  int n, int kg, float (&facc)[MT][16]) {
+    i32x16 H[MT], L[MT];
+    const int8_t *abase = s_aq + n * A_STRIDE + 16 * kg;
+    uint32_t sc_lo = 0, sc_hi = 0, mn_lo = 0, mn_hi = 0;
+    if constexpr (TYPE != T_Q6_K) R.scales(sc_lo, sc_hi, mn_lo, mn_hi);
+#define KSTEP(J)                                                                                              \
+    {                                                                                                         \
+        i32x4 bh, bl;                                                                                         \
+        if constexpr (TYPE == T_Q6_K) R.template bop_signed<J>(R.scale_pk(8 * (J >> 2) + 2 * (J & 3) + kg), bh, bl); \
+        else R.template bop<J>(((J < 4 ? sc_lo : sc_hi) >> (8 * (J & 3))) & 0xff, bh, bl);                    \
+        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                      \
+            const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * J);              \
+            if (J == 0) {                                                                                     \
+                i32x16 z;                                                                                     \
+                _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                      \
+                H[t] = mfma_i8(a, bh, z); L[t] = mfma_i8(a, bl, z);                                           \
+            } else { H[t] = mfma_i8(a, bh, H[t]); L[t] = mfma_i8(a, bl, L[t]); }                              \
+        }                                                                                                     \
+    }
+    KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
+#undef KSTEP
+    const float dd = R.d();
+    float dm = 0.0f;
+    i32x4 bm = {0, 0, 0, 0};
+    if constexpr (TYPE != T_Q6_K) {
+        dm = R.dmin();
+        if (kg == 0) {
+            bm.x = (int)perm(0, mn_lo, 0x01010000u); bm.y = (int)perm(0, mn_lo, 0x03030202u);
+            bm.z = (int)perm(0, mn_hi, 0x01010000u); bm.w = (int)perm(0, mn_hi, 0x03030202u);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        i32x16 ms;
+        if constexpr (TYPE != T_Q6_K) {
+            i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0};
+            if (kg == 0) {
+                ah = *reinterpret_cast<const i32x4 *>(s_bh + (t * 32 + n) * 16);
+                al = *reinterpret_cast<const i32x4 *>(s_bl + (t * 32 + n) * 16);
+            }
+            i32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[r] = 0;
+            ms = mfma_i8(ah, bm, z);
+#pragma unroll
+            for (int r = 0; r < 16; r++) ms[r] <<= 6;
+            ms = mfma_i8(al, bm, ms);
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+            const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + t * 32 + 8 * rq + 4 * kg);
+#pragma unroll
+            for (int ri = 0; ri < 4; ri++) {
+                const int r = rq * 4 + ri;
+                const float yd = yd4[ri];
+                if constexpr (TYPE == T_Q6_K) {
+                    const int isum = 64 * H[t][r] + L[t][r];
+                    facc[t][r] += (dd * yd) * (float)isum;
+                } else {
+                    const int isum = 32 * H[t][r] + L[t][r];
+                    facc[t][r] += (dd * yd) * (float)isum - (dm * yd) * (float)ms[r];
+                }
+            }
+        }
+    }
+}
+
+template <int TYPE, int MT, bool SWIGLU>
+__device__ __forceinline__ void ksplit_body(const KSplitArgs &a, const MMQSeg &sg, int row_tile, uint8_t *smem) {
     constexpr int TOK = 32 * MT;
     constexpr int W_A = TOK * A_STRIDE, W_P = TOK * 16;
     constexpr int W_BYTES = W_A + 2 * W_P + TOK * 4;            // per-wave LDS region
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int8_t *s_aq = reinterpret_cast<int8_t *>(smem + wave * W_BYTES);
     int8_t *s_bh = s_aq + W_A, *s_bl = s_bh + W_P;
     float *s_yd = reinterpret_cast<float *>(s_bl + W_P);
-    const int nb = K >> 8;
-    const int row0 = blockIdx.x * 32, tok0 = blockIdx.y * TOK;
+    const int K = a.K, T = a.T, nb = K >> 8;
+    const int row0 = row_tile * 32, tok0 = blockIdx.y * TOK;
     const int n = lane & 31, kg = lane >> 5;
     int my_row = row0 + n;
-    const bool row_ok = my_row < n_rows;
-    if (!row_ok) my_row = n_rows - 1;
-    const uint8_t *rowp = W + (size_t)my_row * row_bytes;
+    if (my_row >= sg.n_rows) my_row = sg.n_rows - 1;
+    const uint8_t *rowp = sg.W + (size_t)my_row * sg.row_bytes;
+    const uint8_t *rowp2 = SWIGLU ? a.seg[1].W + (size_t)my_row * a.seg[1].row_bytes : nullptr;
 
-    // staging roles of this wave: piece p = lane + 64 i -> token p / 16, 16-byte column p % 16
     constexpr int NST = TOK * 16 / 64;
     int ptok = tok0 + (lane < TOK ? lane : 0);
     if (ptok >= T) ptok = T - 1;
     const unsigned pl_g = (unsigned)ptok * (unsigned)nb;
 
-    float facc[MT][16];
+    float facc[MT][16], facc2[MT][16];
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) facc[t][r] = 0.0f;
+        for (int r = 0; r < 16; r++) { facc[t][r] = 0.0f; if (SWIGLU) facc2[t][r] = 0.0f; }
 
     for (int sb = wave; sb < nb; sb += 8) {
         RowSB<TYPE> R;
@@ -434,15 +508,15 @@ __global__ __launch_bounds__(NTHREADS) void mmq_ksplit_kernel(const uint8_t *W, 
                 const int p = lane + 64 * i;
                 int gt = tok0 + (p >> 4);
                 if (gt >= T) gt = T - 1;
-                tmp[i] = ldg16(aq + (size_t)gt * K + (size_t)sb * 256 + (p & 15) * 16);
+                tmp[i] = ldg16(a.aq + (size_t)gt * K + (size_t)sb * 256 + (p & 15) * 16);
             }
             float yd = 0.0f;
             u32x4 vbh = {0, 0, 0, 0}, vbl = {0, 0, 0, 0};
             if (lane < TOK) {
-                yd = ad[pl_g + (unsigned)sb];
+                yd = a.ad[pl_g + (unsigned)sb];
                 if (TYPE != T_Q6_K) {
-                    vbh = ldg16(abh + ((size_t)pl_g + (unsigned)sb) * 16);
-                    vbl = ldg16(abl + ((size_t)pl_g + (unsigned)sb) * 16);
+                    vbh = ldg16(a.abh + ((size_t)pl_g + (unsigned)sb) * 16);
+                    vbl = ldg16(a.abl + ((size_t)pl_g + (unsigned)sb) * 16);
                 }
             }
             __builtin_amdgcn_wave_barrier();                    // the previous tile's reads are done (in-order LDS per wave)
@@ -460,91 +534,57 @@ __global__ __launch_bounds__(NTHREADS) void mmq_ksplit_kernel(const uint8_t *W, 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        i32x16 H[MT], L[MT];
-        const int8_t *abase = s_aq + n * A_STRIDE + 16 * kg;
-        uint32_t sc_lo = 0, sc_hi = 0, mn_lo = 0, mn_hi = 0;
-        if constexpr (TYPE != T_Q6_K) R.scales(sc_lo, sc_hi, mn_lo, mn_hi);
-#define KSTEP(J)                                                                                              \
-        {                                                                                                     \
-            i32x4 bh, bl;                                                                                     \
-            if constexpr (TYPE == T_Q6_K) R.template bop_signed<J>(R.scale_pk(8 * (J >> 2) + 2 * (J & 3) + kg), bh, bl); \
-            else R.template bop<J>(((J < 4 ? sc_lo : sc_hi) >> (8 * (J & 3))) & 0xff, bh, bl);                \
-            _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
-                const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + t * 32 * A_STRIDE + 32 * J);          \
-                if (J == 0) {                                                                                 \
-                    i32x16 z;                                                                                 \
-                    _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                  \
-                    H[t] = mfma_i8(a, bh, z); L[t] = mfma_i8(a, bl, z);                                       \
-                } else { H[t] = mfma_i8(a, bh, H[t]); L[t] = mfma_i8(a, bl, L[t]); }                          \
-            }                                                                                                 \
-        }
-        KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3) KSTEP(4) KSTEP(5) KSTEP(6) KSTEP(7)
-#undef KSTEP
-        const float dd = R.d();
-        float dm = 0.0f;
-        i32x4 bm = {0, 0, 0, 0};
-        if constexpr (TYPE != T_Q6_K) {
-            dm = R.dmin();
-            if (kg == 0) {
-                bm.x = (int)perm(0, mn_lo, 0x01010000u); bm.y = (int)perm(0, mn_lo, 0x03030202u);
-                bm.z = (int)perm(0, mn_hi, 0x01010000u); bm.w = (int)perm(0, mn_hi, 0x03030202u);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            i32x16 ms;
-            if constexpr (TYPE != T_Q6_K) {
-                i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0};
-                if (kg == 0) {
-                    ah = *reinterpret_cast<const i32x4 *>(s_bh + (t * 32 + n) * 16);
-                    al = *reinterpret_cast<const i32x4 *>(s_bl + (t * 32 + n) * 16);
-                }
-                i32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; r++) z[r] = 0;
-                ms = mfma_i8(ah, bm, z);
-#pragma unroll
-                for (int r = 0; r < 16; r++) ms[r] <<= 6;
-                ms = mfma_i8(al, bm, ms);
-            }
-#pragma unroll
-            for (int rq = 0; rq < 4; rq++) {
-                const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + t * 32 + 8 * rq + 4 * kg);
-#pragma unroll
-                for (int ri = 0; ri < 4; ri++) {
-                    const int r = rq * 4 + ri;
-                    const float yd = yd4[ri];
-                    if constexpr (TYPE == T_Q6_K) {
-                        const int isum = 64 * H[t][r] + L[t][r];
-                        facc[t][r] += (dd * yd) * (float)isum;
-                    } else {
-                        const int isum = 32 * H[t][r] + L[t][r];
-                        facc[t][r] += (dd * yd) * (float)isum - (dm * yd) * (float)ms[r];
-                    }
-                }
-            }
+        ksplit_superblock<TYPE, MT>(R, s_aq, s_bh, s_bl, s_yd, n, kg, facc);
+        if constexpr (SWIGLU) {                                 // the up row of the pair against the same tile
+            RowSB<TYPE> R2;
+            R2.load(rowp2, nb, sb, kg);
+            ksplit_superblock<TYPE, MT>(R2, s_aq, s_bh, s_bl, s_yd, n, kg, facc2);
         }
     }
     // ---- sum the eight waves' partial tiles in wave order (deterministic), then store
+    constexpr int NP = SWIGLU ? 2 : 1;
     __syncthreads();                                   // all activation tiles consumed: the LDS is reused for the partials
-    float *part = reinterpret_cast<float *>(smem);     // [wave][MT * 16][64]
+    float *part = reinterpret_cast<float *>(smem);     // [wave][NP][MT * 16][64]
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) part[(wave * MT * 16 + t * 16 + r) * 64 + lane] = facc[t][r];
+        for (int r = 0; r < 16; r++) {
+            part[((wave * NP + 0) * MT * 16 + t * 16 + r) * 64 + lane] = facc[t][r];
+            if (SWIGLU) part[((wave * NP + 1) * MT * 16 + t * 16 + r) * 64 + lane] = facc2[t][r];
+        }
     __syncthreads();
     for (int e = tid; e < MT * 16 * 64; e += NTHREADS) {
-        float sum = 0.0f;
+        float sum = 0.0f, sum2 = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; w++) sum += part[w * MT * 16 * 64 + e];
+        for (int w = 0; w < 8; w++) {
+            sum += part[(w * NP + 0) * MT * 16 * 64 + e];
+            if (SWIGLU) sum2 += part[(w * NP + 1) * MT * 16 * 64 + e];
+        }
         const int ln = e & 63, tr = e >> 6;            // tr = t * 16 + r
         const int t = tr >> 4, r = tr & 15;
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
         const int gt = tok0 + t * 32 + m, row = row0 + (ln & 31);
-        if (gt < T && row < n_rows) {
-            const size_t o = (size_t)gt * ld_out + row;
-            out[o] = resid ? resid[o] + sum : sum;
+        if (gt < T && row < sg.n_rows) {
+            const size_t o = (size_t)gt * sg.ld_out + row;
+            if (SWIGLU) sg.out[o] = (sum / (1.0f + expf(-sum))) * sum2;
+            else sg.out[o] = sg.resid ? sg.resid[o] + sum : sum;
         }
+    }
+}
+
+template <int MT, bool SWIGLU>
+__global__ __launch_bounds__(NTHREADS) void mmq_ksplit_kernel(const KSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int s = 0;
+    if (a.n_seg > 1 && (int)blockIdx.x >= a.seg[1].tile0) s = 1;
+    if (a.n_seg > 2 && (int)blockIdx.x >= a.seg[2].tile0) s = 2;
+    if (SWIGLU) s = 0;
+    const int row_tile = (int)blockIdx.x - a.seg[s].tile0;
+    switch (a.seg[s].type) {
+        case T_Q4_K: ksplit_body<T_Q4_K, MT, SWIGLU>(a, a.seg[s], row_tile, smem); break;
+        case T_Q5_K: ksplit_body<T_Q5_K, MT, SWIGLU>(a, a.seg[s], row_tile, smem); break;
+        case T_Q6_K: ksplit_body<T_Q6_K, MT, SWIGLU>(a, a.seg[s], row_tile, smem); break;
+        default: break;
     }
 }
 
@@ -850,27 +890,43 @@ void mmq_set_tiles(int mt) { g_mmq_mt = mt; }
 bool mmq_ksplit_applicable(int type, int K, int T) {
     return (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K) && (K % 256) == 0 && T >= 8 && T <= 64;
 }
-hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
-                             const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st) {
+
+// segs: up to 3 tensors sharing the activation; swiglu: segs = {gate, up} of one type and shape, out = silu(gate.x) * (up.x) into segs[0].out
+hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
+                                   bool swiglu, hipStream_t st) {
+    if (n_seg < 1 || n_seg > 3) return hipErrorInvalidValue;
+    if (swiglu && (n_seg != 2 || segs[0].type != segs[1].type || segs[0].n_rows != segs[1].n_rows)) return hipErrorInvalidValue;
+    KSplitArgs a{};
+    a.n_seg = n_seg; a.K = K; a.T = T; a.swiglu = swiglu ? 1 : 0;
+    a.aq = q.qs; a.ad = q.d; a.abh = bh; a.abl = bl;
+    int tiles = 0;
+    for (int i = 0; i < n_seg; i++) {
+        a.seg[i] = segs[i];
+        a.seg[i].tile0 = tiles;
+        if (!swiglu || i == 0) tiles += (segs[i].n_rows + 31) / 32;
+    }
     const int mt = T <= 32 ? 1 : 2;
-    const dim3 grid((unsigned)((n_rows + 31) / 32), (unsigned)((T + 32 * mt - 1) / (32 * mt)));
-#define KS(TY, MTV)                                                                                                  \
+    const dim3 grid((unsigned)tiles, (unsigned)((T + 32 * mt - 1) / (32 * mt)));
+#define KS(MTV, SW)                                                                                                  \
     {                                                                                                                \
         constexpr int TOKV = 32 * MTV;                                                                               \
         size_t lds = (size_t)8 * (TOKV * A_STRIDE + 2 * TOKV * 16 + TOKV * 4);                                        \
-        const size_t red = (size_t)8 * MTV * 16 * 64 * 4;                                                            \
+        const size_t red = (size_t)8 * (SW ? 2 : 1) * MTV * 16 * 64 * 4;                                             \
         if (red > lds) lds = red;                                                                                    \
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_ksplit_kernel<TY, MTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mmq_ksplit_kernel<TY, MTV>), grid, dim3(NTHREADS), lds, st, W, row_bytes, n_rows, K, T, q.qs, q.d, bh, bl, out, ld_out, resid); \
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_ksplit_kernel<MTV, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mmq_ksplit_kernel<MTV, SW>), grid, dim3(NTHREADS), lds, st, a);                          \
     }
-    switch (type) {
-        case T_Q4_K: if (mt == 1) KS(T_Q4_K, 1) else KS(T_Q4_K, 2) break;
-        case T_Q5_K: if (mt == 1) KS(T_Q5_K, 1) else KS(T_Q5_K, 2) break;
-        case T_Q6_K: if (mt == 1) KS(T_Q6_K, 1) else KS(T_Q6_K, 2) break;
-        default: return hipErrorInvalidValue;
-    }
+    if (swiglu) { if (mt == 1) KS(1, true) else KS(2, true) }
+    else { if (mt == 1) KS(1, false) else KS(2, false) }
 #undef KS
     return hipGetLastError();
+}
+
+hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,
+                             const int8_t *bh, const int8_t *bl, float *out, int ld_out, const float *resid, hipStream_t st) {
+    MMQSeg sg{};
+    sg.W = W; sg.row_bytes = row_bytes; sg.n_rows = n_rows; sg.type = type; sg.out = out; sg.ld_out = ld_out; sg.resid = resid;
+    return launch_mmq_ksplit_multi(&sg, 1, K, T, q, bh, bl, false, st);
 }
 
 size_t mmq_planes_bytes(int type, int64_t n_rows, int K) {

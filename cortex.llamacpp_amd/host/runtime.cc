@@ -534,11 +534,11 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     const int K = (int)ws[0]->K;
     bool all_mmq = true, all_ks = true;
     for (int i = 0; i < n; i++) { all_mmq &= mmq_applicable(ws[i]->type, K, T); all_ks &= mmq_ksplit_applicable(ws[i]->type, K, T); }
-    if (all_ks && pending_fuse_.mode == 0) {
+    if (all_ks && pending_fuse_.mode == 0 && n <= 3) {         // batched decode step: Q, K, V in one launch
         HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
-        for (int i = 0; i < n; i++)
-            HIP_TRY(launch_mmq_ksplit(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
-        return hipSuccess;
+        MMQSeg sg[3];
+        for (int i = 0; i < n; i++) sg[i] = MMQSeg{ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, ws[i]->type, outs[i], (int)ws[i]->N, nullptr, 0};
+        return launch_mmq_ksplit_multi(sg, n, K, T, aq, mmq_bh_, mmq_bl_, false, stream_);
     }
     if (all_mmq && pending_fuse_.mode == 0) {
         HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
@@ -678,9 +678,17 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             }
             const bool ffn_mmq = (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
                                  (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T));
+            const bool ffn_ks = mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T) && !fuse_ffn;
             if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_, fz));
+            } else if (ffn_ks) {                               // batched decode step: gate and up in one launch
+                if (L.gate.type != T_Q6_K || L.up.type != T_Q6_K) HIP_TRY(launch_mmq_prep(aq_e_, E, T, mmq_bh_, mmq_bl_, stream_));
+                MMQSeg sg[2] = {{L.gate.data, L.gate.row_bytes, (int)L.gate.N, L.gate.type, ffn_, FF, nullptr, 0},
+                                {L.up.data, L.up.row_bytes, (int)L.up.N, L.up.type, ffn_u_, FF, nullptr, 0}};
+                const bool pair = T <= 32 && L.gate.type == L.up.type && L.gate.N == L.up.N;     // SwiGLU in the epilogue
+                HIP_TRY(launch_mmq_ksplit_multi(sg, 2, E, T, aq_e_, mmq_bh_, mmq_bl_, pair, stream_));
+                if (!pair) HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
             } else {
                 HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
@@ -690,7 +698,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             static const bool fuse_down_env = !(getenv("MI355_FUSE_DOWN") && getenv("MI355_FUSE_DOWN")[0] == '0');
             // quantise inside the down-projection's prologue (once per CU, overlapped with its first weight loads)
             const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K) &&
-                                   (FF % 2048) == 0 && (FF / 2048 == 1 || FF / 2048 == 2 || FF / 2048 == 4 || FF / 2048 == 7 || FF / 2048 == 14);
+                                   (FF % 256) == 0 && [](int kb) { return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 14; }((FF + 2047) / 2048);
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
             } else if (is_quant(L.down.type)) {
