@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 
 namespace mi355 {
@@ -136,6 +138,10 @@ void LlamaServerContext::Initialize() {    // :244-282
 }
 
 void LlamaServerContext::ReleaseResources() {   // :366-380
+    if (getenv("MI355_LOOP_TIMING") && n_ticks_ > 0)
+        fprintf(stderr, "[loop] %ld decode calls, %.1f tokens each: decode+logits %.3f ms, sampling %.3f ms, post-processing %.3f ms per call\n",
+                n_ticks_, (double)n_tick_tokens_ / (double)n_ticks_, t_decode_us_ / 1e3 / (double)n_ticks_, t_sample_us_ / 1e3 / (double)n_ticks_,
+                t_post_us_ / 1e3 / (double)n_ticks_);
     if (model_loaded_external.exchange(false)) {
         condition_tasks_.notify_all();
         if (bgr_thread_.joinable()) bgr_thread_.join();
@@ -621,6 +627,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
     for (int32_t i = 0; i < n_tokens; i += n_batch) {   // :1628-1707
         const int32_t nt = std::min(n_batch, n_tokens - i);
         BatchView bv{nt, b_token_.data() + i, b_pos_.data() + i, b_seq_.data() + i, b_logits_.data() + i};
+        const int64_t t_d0 = time_us();
         const int ret = be_->decode(bv);
         if (ret != 0) {
             if (n_batch == 1 || ret < 0) {
@@ -637,6 +644,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
             continue;
         }
         // phase 1: token ids of every generating slot of this chunk (host sampling in parallel, device argmax for plain greedy)
+        const int64_t t_s0 = time_us();
         std::vector<LlamaClientSlot *> gen;
         for (auto &slot : slots) {
             if (slot.i_batch < i || slot.i_batch >= i + nt) continue;
@@ -664,6 +672,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
         };
         if (!sample_pool_) sample_pool_.reset(new SamplePool((int)std::min<unsigned>(7u, std::max(1u, std::thread::hardware_concurrency()) - 1u)));
         sample_pool_->run((int)gen.size(), sample_one);
+        const int64_t t_p0 = time_us();
         // phase 2: in slot order, exactly as the reference's loop (:1665-1704)
         for (size_t gi = 0; gi < gen.size(); gi++) {
             LlamaClientSlot &slot = *gen[gi];
@@ -684,6 +693,9 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
             }
             slot.i_batch = -1;
         }
+        const int64_t t_e = time_us();
+        t_decode_us_ += (double)(t_s0 - t_d0); t_sample_us_ += (double)(t_p0 - t_s0); t_post_us_ += (double)(t_e - t_p0);
+        n_ticks_++; n_tick_tokens_ += nt;
     }
     return true;
 }

@@ -117,6 +117,9 @@ class LlamaServerContext {
     void SendEmbedding(LlamaClientSlot &slot, int batch_index);
     // sampling of the slots of one decoded batch, spread over a few host threads (the chains are independent per slot;
     // at a 128 K vocabulary one chain costs ~0.1 ms, and the reference's loop runs them back to back)
+    // MI355_LOOP_TIMING=1: where a scheduler tick spends its time (printed when the context is released)
+    double t_decode_us_ = 0, t_sample_us_ = 0, t_post_us_ = 0, t_tick_us_ = 0;
+    long n_ticks_ = 0, n_tick_tokens_ = 0;
     struct SamplePool;
     std::unique_ptr<SamplePool> sample_pool_;
     LlamaClientSlot *GetSlot(int id);
