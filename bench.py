@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+N_UBATCH = int(os.environ.get("MI355_BENCH_UBATCH", "2048"))   # the reference default: n_ubatch = n_batch = 2048 (llama_engine.cc:617-620)
 MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 / fp8 matrix-core peak of MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
@@ -125,7 +126,7 @@ def main() -> int:
     t0 = time.time()
     model = pkg.Model(path, main_gpu=local_rank if world > 1 else 0)
     t_load = time.time() - t0
-    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=512, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
+    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
 
     rng = np.random.default_rng(1234 + rank)
     prompt = rng.integers(0, model.n_vocab, args.prompt)
@@ -184,7 +185,7 @@ def main() -> int:
 
     # ---- device-greedy variant: logits stay on the device, only the argmax crosses
     ctx.close()
-    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=512, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True,
+    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True,
                       logits_to_host=False)
     _, tok = prefill()
     pos = args.prompt
