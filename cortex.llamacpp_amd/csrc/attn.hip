@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_ctx = a.n_ctx, H = a.H;
     int chunk = sp;
-    if (!FUSED && a.tok_chunks) {                              // batched steps: walk this token's chunk list only
+    if (a.tok_chunks) {                                        // walk this token's chunk list only (sequences own cache regions)
         if (sp >= a.tok_nchunks[t]) return;
         chunk = a.tok_chunks[(size_t)t * a.chunk_stride + sp];
     }
@@ -808,7 +808,8 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     if (fz.counters == nullptr) return;               // store-fused only: the merge runs as its own launch
 
     // ---- FUSED: ticket; the last workgroup of this kv head merges
-    const int splits = a.splits;
+    const int stride_s = a.splits;                             // workspace stride; with a chunk list fewer slots are in use
+    const int splits = a.tok_nchunks ? a.tok_nchunks[0] : a.splits;
     // every wave's partial stores must have reached L2 before thread 0 releases them device-wide: __syncthreads() fences
     // LDS only (hipcc emitted no vmcnt wait before the barrier here), so each wave drains its own stores first
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release fence compiles to nothing on this target)
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     float *wgt = S;                                    // [R][64] split weights (S is free now: R * C floats)
     float *merged = accs;                              // [R * D]
     for (int r = wave; r < R; r += 4) {                // same arithmetic as flash_attn_combine_kernel
-        const float *p = a.part + ((size_t)g * R + r) * splits * (D + 2);
+        const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2);
         float m = -INFINITY, l = 0.0f;
         if (lane < splits) {
             m = __hip_atomic_load(p + (size_t)lane * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a
     const int E = H * D;
     for (int e = tid; e < R * D; e += 256) {
         const int r = e / D, d = e - r * D;
-        const float *p = a.part + ((size_t)g * R + r) * splits * (D + 2) + d;
+        const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2) + d;
         float acc = 0.0f;
 #pragma unroll 8
         for (int s2 = 0; s2 < splits; s2++)

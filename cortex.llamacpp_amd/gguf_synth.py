@@ -164,6 +164,9 @@ CONFIGS = {
     # hidden sizes that are multiples of 2048: the shapes the persistent single-token mat-vec (fused RMSNorm / quantise
     # prologues) and the MFMA prefill planes are built for
     "tiny-e2048": LlamaConfig("tiny-e2048", 2048, 2, 16, 4, 4096, 512, 500000.0, 1e-5, 1024),
+    # 8 KV heads of 128 (one 1024-wide K / V row, GQA 2:1): the shape the single-launch decode attention (rope + cache
+    # store + split attention + merge) and the chunk-list batched steps are built for — Llama-3-8B's own KV geometry
+    "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
 }
 
 FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17}

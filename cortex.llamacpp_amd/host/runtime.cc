@@ -372,6 +372,7 @@ void Context::kv_clear() {
     head_ = 0;
     has_shift_ = false;
     meta_dirty_ = true;
+    region_next_.clear();
 }
 bool Context::kv_seq_rm(int seq, int p0, int p1) {
     if (p0 < 0) p0 = 0;
@@ -386,6 +387,7 @@ bool Context::kv_seq_rm(int seq, int p0, int p1) {
         if (!c.seqs) { c.pos = -1; c.delta = 0; if (i < new_head) new_head = i; }
     }
     if (new_head < (int)cells_.size() && new_head < head_) head_ = new_head;
+    if (new_head < (int)cells_.size()) region_next_.clear();   // cells came free: the next allocation starts at its region's lowest free cell
     meta_dirty_ = true;
     return true;
 }
@@ -406,7 +408,7 @@ void Context::kv_seq_add(int seq, int p0, int p1, int delta) {
         has_shift_ = true;
         c.pos += delta;
         c.delta += delta;
-        if (c.pos < 0) { c.pos = -1; c.seqs = 0; c.delta = 0; }
+        if (c.pos < 0) { c.pos = -1; c.seqs = 0; c.delta = 0; region_next_.clear(); }
     }
     meta_dirty_ = true;
 }
@@ -428,6 +430,47 @@ int Context::find_slot(int n) {
         if (ok) return head;
         if (tested >= NC) return -1;
     }
+}
+
+bool Context::alloc_cells(int n, const uint64_t *seqmask, std::vector<int> &out) {
+    out.assign((size_t)n, -1);
+    const int NC = (int)cells_.size();
+    const int NS = (int)cp.n_seq_max;
+    if (NS <= 1) {                                              // one sequence: a contiguous run, as before
+        const int slot = find_slot(n);
+        if (slot < 0) return false;
+        for (int i = 0; i < n; i++) out[(size_t)i] = slot + i;
+        head_ = slot + n;
+        if (head_ >= NC) head_ = 0;
+        return true;
+    }
+    // every sequence owns a region of the cache, a whole number of 64-cell attention chunks where the cache allows it: a
+    // sequence then sees the same chunk partition whichever region it lives in (results do not depend on the slot), and
+    // the hint below always points at the region's lowest free cell, so allocation is a pure function of the cell table
+    int R = std::max(1, NC / NS);
+    if (R >= 64) R &= ~63;
+    if ((int)region_next_.size() != NS) { region_next_.assign((size_t)NS, 0); for (int s = 0; s < NS; s++) region_next_[(size_t)s] = s * R; }
+    std::vector<char> taken((size_t)NC, 0);                    // cells handed out within this call
+    auto is_free = [&](int c) { return cells_[(size_t)c].pos < 0 && !taken[(size_t)c]; };
+    for (int i = 0; i < n; i++) {
+        int s = seqmask[i] ? __builtin_ctzll(seqmask[i]) : 0;
+        if (s >= NS) s = NS - 1;
+        const int lo = s * R, hi = (s == NS - 1) ? NC : lo + R;
+        int c = -1;
+        int start = region_next_[(size_t)s];
+        if (start < lo || start >= hi) start = lo;
+        for (int k = 0; k < hi - lo; k++) {                    // own region first, from where the last cell went
+            int cand = start + k;
+            if (cand >= hi) cand -= hi - lo;
+            if (is_free(cand)) { c = cand; break; }
+        }
+        if (c < 0) for (int cand = 0; cand < NC; cand++) if (is_free(cand)) { c = cand; break; }   // region full: anywhere
+        if (c < 0) return false;
+        taken[(size_t)c] = 1;
+        out[(size_t)i] = c;
+        if (c >= lo && c < hi) region_next_[(size_t)s] = c + 1;
+    }
+    return true;
 }
 
 void Context::apply_k_shift() {
@@ -606,9 +649,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
         if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
-            if (T >= 2 && chunk_lmax_ > 0) {                   // batched step: per-token chunk lists (decode_ubatch)
+            if (chunk_lmax_ > 0) {                             // per-token chunk lists (decode_ubatch): batched steps, or regions in use
                 aa.tok_chunks = d_chunks_; aa.tok_nchunks = d_chunks_ + (size_t)64 * chunk_stride_; aa.chunk_stride = chunk_stride_;
-                aa.splits = chunk_lmax_;
+                aa.splits = std::max(chunk_cap_, chunk_lmax_);
             }
             static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
             if (attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra)) {
@@ -748,14 +791,12 @@ hipError_t Context::run_output(int n_out, int out_base) {
 
 int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
                            const int8_t *flags, int out_base) {
-    const int slot = find_slot(n);
-    if (slot < 0) return 1;
+    std::vector<int> tcell;
+    if (!alloc_cells(n, seqmask, tcell)) return 1;
     for (int i = 0; i < n; i++) {
-        KVCell &c = cells_[(size_t)(slot + i)];
+        KVCell &c = cells_[(size_t)tcell[(size_t)i]];
         c.pos = pos[i]; c.seqs = seqmask[i]; c.delta = 0;
     }
-    head_ = slot + n;
-    if (head_ >= (int)cells_.size()) head_ = 0;
     int hi = 0;
     for (int i = (int)cells_.size() - 1; i >= 0; i--) if (cells_[(size_t)i].pos >= 0) { hi = i + 1; break; }
     n_kv_ = std::min((int)cp.n_ctx, (hi + 31) & ~31);
@@ -778,14 +819,22 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     h_nkv[0] = n_kv_;
     int n_out = 0;
     for (int i = 0; i < n; i++) {
-        h_tok[i] = tokens[i]; h_pos[i] = pos[i]; h_seq[i] = seq[i]; h_cell[i] = slot + i; h_mask[i] = seqmask[i];
+        h_tok[i] = tokens[i]; h_pos[i] = pos[i]; h_seq[i] = seq[i]; h_cell[i] = tcell[(size_t)i]; h_mask[i] = seqmask[i];
         if (flags[i]) h_out[n_out++] = i;
     }
     if (hipMemcpyAsync(d_stage_, h_stage_, stage_bytes_, hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "token upload failed"; return -1; }
     // continuous-batching steps (a few tokens, usually one per sequence): each token scans only the 64-cell chunks that
     // hold cells of its own sequence instead of the whole cache
     chunk_lmax_ = 0;
-    if (n >= 2 && n <= 64) {
+    bool lists_usable = false;                                 // only the split-per-chunk attention kernels walk the lists
+    {
+        const HParams &hp = model->hp;
+        RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, nullptr, hp.rope_neox};
+        AttnArgs aa{};
+        aa.T = n; aa.H = hp.n_head; aa.G = hp.n_head_kv; aa.D = hp.head_dim; aa.n_kv_max = n_kv_; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
+        lists_usable = n <= 64 && flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(aa.G, aa.D, cp.type_k, cp.type_v, ra);
+    }
+    if ((n >= 2 || cp.n_seq_max > 1) && lists_usable) {
         const int nch = (n_kv_ + 63) / 64;
         std::vector<uint64_t> seq_of_chunk((size_t)nch, 0ull);
         for (int i = 0; i < n_kv_ && i < (int)cells_.size(); i++)
@@ -814,14 +863,19 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     hipError_t e = hipSuccess;
     if (graph_ok) {
         // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
-        const int bucket = std::min((int)cp.n_ctx, (n_kv_ + 255) & ~255);
+        int bucket = std::min((int)cp.n_ctx, (n_kv_ + 255) & ~255);
+        chunk_cap_ = 0;
+        if (chunk_lmax_ > 0) {                                 // chunk lists: the grid is sized by the list length, in steps of 4
+            chunk_cap_ = std::min(chunk_stride_, (chunk_lmax_ + 3) & ~3);
+            bucket = -chunk_cap_;                              // separate key space from the cell-count buckets
+        }
         auto git = graphs_.find(bucket);
         graph_exec_ = git == graphs_.end() ? nullptr : git->second;
         if (!graph_exec_) {
             hipGraph_t g = nullptr;
             e = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                hipError_t e2 = run_layers(1, bucket);
+                hipError_t e2 = run_layers(1, bucket > 0 ? bucket : std::min((int)cp.n_ctx, chunk_cap_ * 64));
                 if (e2 == hipSuccess) e2 = run_output(1, 0);
                 if (e2 == hipSuccess && cp.logits_to_host) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
                 e = hipStreamEndCapture(stream_, &g);
@@ -835,6 +889,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         e = hipGraphLaunch(graph_exec_, stream_);
     } else {
         prof_begin();
+        chunk_cap_ = chunk_lmax_;
         e = run_layers(n, n_kv_);
         if (e == hipSuccess) e = run_output(n_out, out_base);
         if (profiler_safe) (void)hipStreamSynchronize(stream_);
@@ -909,7 +964,7 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
         const int n = std::min((int)cp.n_ubatch, n_tokens - i0);
         const int rc = decode_ubatch(n, tokens + i0, pos + i0, seq.data() + i0, mask.data() + i0, flags.data() + i0, out_base);
         if (rc != 0) {
-            cells_ = saved; head_ = saved_head; meta_dirty_ = true;
+            cells_ = saved; head_ = saved_head; meta_dirty_ = true; region_next_.clear();
             return rc;
         }
         for (int i = 0; i < n; i++) out_base += flags[(size_t)(i0 + i)] ? 1 : 0;

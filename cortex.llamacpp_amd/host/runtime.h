@@ -122,6 +122,10 @@ class Context {
     int decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
                       const int8_t *flags, int out_base);
     int find_slot(int n);
+    // one cell per token; with n_seq_max > 1 every sequence allocates from its own region of the cache
+    // (n_ctx / n_seq_max cells, the reference's per-slot context), so a sequence's cells stay together
+    bool alloc_cells(int n, const uint64_t *seqmask, std::vector<int> &out);
+    std::vector<int> region_next_;     // per sequence: where its next cell is looked for first
     void apply_k_shift();
     hipError_t run_layers(int T, int n_kv_cap);
     hipError_t run_output(int n_out, int out_base);
@@ -164,7 +168,7 @@ class Context {
     bool embd_fetched_ = false, last_was_embd_ = false;
     // batched single-token steps: per-token lists of the 64-cell chunks that hold cells of the token's sequence
     int32_t *h_chunks_ = nullptr, *d_chunks_ = nullptr;     // [64][chunk_stride_] lists, then [64] counts
-    int chunk_stride_ = 0, chunk_lmax_ = 0;                 // lmax = longest list of the current batch (0 = lists not in use)
+    int chunk_stride_ = 0, chunk_lmax_ = 0, chunk_cap_ = 0;   // cap = grid size used for the lists (>= lmax; rounded up for graph reuse)                 // lmax = longest list of the current batch (0 = lists not in use)
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;

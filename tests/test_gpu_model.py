@@ -56,7 +56,9 @@ def rel_err(a, b):
                                           # steps; 40-token prompts go through the MFMA prefill contraction (planes form)
                                           ("tiny-e2048", "q4_k_m", "q8_0"), ("tiny-e2048", "q5_k_m", "q8_0"),
                                           ("tiny-e2048:40", "q4_k_m", "q8_0"), ("tiny-d128:40", "q4_k_m", "q8_0"),
-                                          ("tiny-gqa4:40", "q5_k_m", "f16")])
+                                          ("tiny-gqa4:40", "q5_k_m", "f16"),
+                                          # 8 x 128 KV heads: single-launch decode attention (rope + store + merge fused)
+                                          ("tiny-g8", "q4_k_m", "q8_0"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-g8:70", "q4_k_m", "q8_0")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)
@@ -117,7 +119,37 @@ def test_f16_cache_vs_stock_fp16_accumulation(be, pkg, tmp_models):
     c.close(); m.close(); oc.close(); om.close()
 
 
-@pytest.mark.parametrize("cfg", ["tiny-gqa4", "tiny-d128"])
+@pytest.mark.parametrize("cfg", ["tiny-d128", "tiny-g8"])
+@pytest.mark.parametrize("graphs", [True, False])
+def test_logits_do_not_depend_on_the_sequence_region(be, pkg, tmp_models, cfg, graphs):
+    """With n_seq_max > 1 every sequence owns a 64-aligned region of the cache and the single-token steps walk per-token
+    chunk lists: a sequence must produce bit-identical logits whichever region it lives in, and the same as a
+    one-sequence context (same chunk partition, same merge order).  70 steps cross a chunk boundary."""
+    path = make(pkg, tmp_models, cfg, "q4_k_m")
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(3).integers(0, m.n_vocab, 30)
+
+    def run(n_seq_max, seq):
+        c = pkg.Context(m, n_ctx=1024, n_seq_max=n_seq_max, type_k=8, type_v=8, use_graphs=graphs)
+        assert c.decode(prompt, np.arange(30), seq=seq) == 0
+        rows = [c.logits().copy()]
+        for s in range(70):
+            assert c.decode([int(rows[-1].argmax())], [30 + s], seq=seq) == 0
+            rows.append(c.logits().copy())
+        c.close()
+        return np.stack(rows)
+
+    base = run(1, 0)
+    for seq in (0, 1, 3):
+        got = run(4, seq)
+        if cfg == "tiny-g8":
+            assert np.array_equal(got, base), (seq, int(np.argmax(np.abs(got - base).max(axis=1) > 0)))
+        else:   # 2 x 128 KV heads take the general split-by-length kernel: the split count follows the highest occupied cell
+            assert rel_err(got, base) <= FLIP_TOL, (seq, rel_err(got, base))
+    m.close()
+
+
+@pytest.mark.parametrize("cfg", ["tiny-gqa4", "tiny-d128", "tiny-g8"])
 def test_graph_and_eager_agree_bitwise(be, pkg, tmp_models, cfg):
     path = make(pkg, tmp_models, cfg, "q4_k_m")
     m = pkg.Model(path)
