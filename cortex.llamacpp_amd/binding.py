@@ -74,6 +74,7 @@ SYMBOLS = {
     "mi355_decode": (_i32, [_vp, Batch]),
     "mi355_get_logits_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_get_argmax_ith": (_i32, [_vp, _i32]),
+    "mi355_debug_mega_steps": (C.c_int64, [_vp]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
     "mi355_get_embeddings_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_synchronize": (None, [_vp]),
@@ -355,6 +356,10 @@ class Context:
 
     def argmax(self, i: int = -1) -> int:
         return int(self.lib.mi355_get_argmax_ith(self.h, i))
+
+    def mega_steps(self) -> int:
+        """Single-token steps that ran as one whole-step launch (diagnosis)."""
+        return int(self.lib.mi355_debug_mega_steps(self.h))
 
     def synchronize(self):
         self.lib.mi355_synchronize(self.h)

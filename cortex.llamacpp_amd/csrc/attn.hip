@@ -186,16 +186,17 @@ hipError_t launch_k_shift(KVLayerView kv, int type_k, int G, int D, int n_ctx, c
 }
 
 __global__ void kv_meta_set_kernel(int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell, const int32_t *tok_pos,
-                                   const uint64_t *tok_seqmask, int T) {
+                                   const uint64_t *tok_seqmask, int T, unsigned *zero_word) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_word && t < 9) zero_word[t == 0 ? 0 : 32 * t] = 0u;   // barrier counters of the whole-step kernel that follows (decode_mega.hip)
     if (t < T) {
         cell_pos[tok_cell[t]] = tok_pos[t];
         cell_seq[tok_cell[t]] = tok_seqmask[t];
     }
 }
 hipError_t launch_kv_meta_set(int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell, const int32_t *tok_pos,
-                              const uint64_t *tok_seqmask, int T, hipStream_t st) {
-    hipLaunchKernelGGL(kv_meta_set_kernel, dim3((T + 255) / 256), dim3(256), 0, st, cell_pos, cell_seq, tok_cell, tok_pos, tok_seqmask, T);
+                              const uint64_t *tok_seqmask, int T, hipStream_t st, unsigned *zero_word) {
+    hipLaunchKernelGGL(kv_meta_set_kernel, dim3((T + 255) / 256), dim3(256), 0, st, cell_pos, cell_seq, tok_cell, tok_pos, tok_seqmask, T, zero_word);
     return hipGetLastError();
 }
 
@@ -531,349 +532,9 @@ hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, in
     return hipGetLastError();
 }
 
-// Decode attention: workgroup = (kv head g, chunk of 64 cells, token t).  The query heads of the group are read
-// un-rotated, rotated with the cos/sin table and converted to the K cache's dot type here (so no separate pass over q),
-// and K / V / scales / cell table of the chunk are all requested before the first wait.
-//
-// FUSED (single-token step, R*D a multiple of 256) folds the two neighbouring launches into this one:
-//  * KV store: the workgroup whose chunk holds the token's cell rotates K, converts K/V to the cache type, writes the
-//    cache row and patches its own registers / LDS scales with the same codes (no other workgroup reads that cell);
-//  * merge: every workgroup publishes its chunk partial, then takes a ticket on a per-kv-head counter; the LAST arriver
-//    merges the splits of its R heads exactly as flash_attn_combine_kernel does, writes the f32 rows and the quantised
-//    activation of the attn_output mat-vec, and re-arms the counter.  Nobody waits: no spin, no co-residency needed.
-struct DecodeFuse {
-    const float *knew, *vnew;      // [G*D] un-rotated K and V of the token
-    const int32_t *tok_cell;       // [1]
-    unsigned *counters;            // [G], zero between launches
-    ActQuant q;
-    int want_q8k, want_q80;
-};
-
-template <int R, int TK, int TV, bool FUSED>
-__global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz) {
-    constexpr int D = 128, C = 64, NB = 4;
-    constexpr int KP = TK == T_F16 ? 4 : 2;                 // 16-byte K pieces per thread
-    constexpr int LPC = TK == T_F16 ? 16 : 8;               // lanes per cell in the score pass
-    __shared__ __attribute__((aligned(16))) float qf[R * D];         // rotated q (f16-rounded for an f16 cache)
-    __shared__ __attribute__((aligned(16))) int8_t qc[R * D];        // q8_0 codes of q
-    __shared__ float qd[R * NB];
-    __shared__ float S[R * C];
-    __shared__ float ml[R * 2];
-    __shared__ int vis[C];
-    __shared__ uint32_t ksc[C * NB / 2], vsc[C * NB / 2];           // f16 block scales of the chunk
-    __shared__ __attribute__((aligned(16))) float accs[8 * R * D];
-    __shared__ __attribute__((aligned(16))) uint8_t newk[D * 2], newv[D * 2];   // the token's own cache row (codes or f16)
-    __shared__ uint32_t newkd[2], newvd[2];                                      // its f16 block scales, two per word
-    __shared__ int last_flag;
-    const int g = blockIdx.x, sp = blockIdx.y, t = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_ctx = a.n_ctx, H = a.H;
-    int chunk = sp;
-    if (a.tok_chunks) {                                        // walk this token's chunk list only (sequences own cache regions)
-        if (sp >= a.tok_nchunks[t]) return;
-        chunk = a.tok_chunks[(size_t)t * a.chunk_stride + sp];
-    }
-    const int c_lo = chunk * C;
-    const size_t head_row0 = (size_t)g * n_ctx;
-
-    // ---- issue every global load of the workgroup
-    int cpos = -1;
-    unsigned long long cseq = 0;
-    if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
-    const int32_t tpos = a.tok_pos[t];
-    const int tseq = a.tok_seq[t];
-    if (!FUSED && a.T > 1) {
-        // batched steps (one token per sequence): most chunks hold other sequences' cells only.  Decide that before
-        // touching K / V: such a chunk publishes (m, l) = (-inf, 0) and leaves; the merge skips it.
-        const int mine = (tid < C && cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
-        if (!__syncthreads_or(mine)) {
-            if (tid < R) {
-                float *dst = a.part + (((size_t)t * H + (size_t)g * R + tid) * a.splits + sp) * (D + 2);
-                dst[D] = -INFINITY; dst[D + 1] = 0.0f;
-            }
-            return;
-        }
-    }
-    // q pairs: R*64 pairs, pair pp -> (head r = pp / 64, i = pp % 64); NORM pairing (2i, 2i+1)
-    constexpr int NPAIR = R * 64, PPT = (NPAIR + 255) / 256;
-    float2 qv[PPT], csv[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; j++) {
-        const int pp = tid + 256 * j;
-        if (pp < NPAIR) {
-            const int r = pp >> 6, i = pp & 63;
-            qv[j] = *reinterpret_cast<const float2 *>(a.q + ((size_t)t * H + (size_t)g * R + r) * D + 2 * i);
-            csv[j] = (2 * i < n_rot) ? *reinterpret_cast<const float2 *>(cs_table + (size_t)t * n_rot + 2 * i) : make_float2(1.0f, 0.0f);
-        }
-    }
-    uint4 kreg[KP];
-#pragma unroll
-    for (int j = 0; j < KP; j++) {
-        const int p = tid + 256 * j;
-        int cell = c_lo + p / LPC;
-        if (cell >= n_ctx) cell = n_ctx - 1;
-        const size_t rowi = head_row0 + cell;
-        if (TK == T_F16) kreg[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
-        else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * D + (p % LPC) * 16);
-    }
-    const int dq = tid & 31, cg = tid >> 5;
-    uint2 vreg[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int cell = c_lo + cg + 8 * i;
-        if (cell >= n_ctx) cell = n_ctx - 1;
-        const size_t rowi = head_row0 + cell;
-        if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
-        else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
-    }
-    uint32_t ks2 = 0, vs2 = 0;
-    if (tid < C * NB / 2) {
-        int cell = c_lo + tid / 2;
-        if (cell >= n_ctx) cell = n_ctx - 1;
-        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid & 1) * 2);
-        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid & 1) * 2);
-    }
-
-    // ---- FUSED: this token's K/V row (wave 0: lanes 0..31 rotate + convert K, lanes 32..63 convert V; 4 elements each)
-    int own_cl = -1;                                   // chunk-local index of the token's cell, if this chunk holds it
-    if (FUSED) {
-        const int cellnew = fz.tok_cell[0];
-        if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
-        if (own_cl >= 0 && wave == 0) {
-            const bool isk = lane < 32;
-            const int dd = (lane & 31) * 4;
-            float4 x4 = *reinterpret_cast<const float4 *>((isk ? fz.knew : fz.vnew) + (size_t)g * D + dd);
-            if (isk && dd < n_rot) {
-                const float4 cs = *reinterpret_cast<const float4 *>(cs_table + dd);   // c0 s0 c1 s1
-                const float x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
-                x4.x = x0 * cs.x - x1 * cs.y; x4.y = x0 * cs.y + x1 * cs.x;
-                x4.z = x2 * cs.z - x3 * cs.w; x4.w = x2 * cs.w + x3 * cs.z;
-            }
-            const float xa[4] = {x4.x, x4.y, x4.z, x4.w};
-            const size_t rowi = head_row0 + cellnew;
-            const int TT = isk ? TK : TV;              // (TK, TV are compile-time; the select folds per branch below)
-            uint32_t packed = 0; float dsc = 0.0f;
-            if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
-            if (TT == T_F16) {
-                uint2 o; o.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); o.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
-                *reinterpret_cast<uint2 *>((isk ? newk : newv) + dd * 2) = o;
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(isk ? a.kv.k : a.kv.v) + rowi * D + dd) = o;
-            } else {
-                *reinterpret_cast<uint32_t *>((isk ? newk : newv) + dd) = packed;
-                *reinterpret_cast<uint32_t *>((isk ? a.kv.k : a.kv.v) + rowi * D + dd) = packed;
-                if ((lane & 7) == 0) {
-                    const uint16_t hd = f2h(dsc);
-                    (isk ? a.kv.kd : a.kv.vd)[rowi * NB + (dd >> 5)] = hd;
-                    reinterpret_cast<uint16_t *>(isk ? newkd : newvd)[dd >> 5] = hd;
-                }
-            }
-        }
-    }
-
-    // ---- q: rotate, convert
-    if (tid < C) vis[tid] = (cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
-    if (tid < C * NB / 2) { ksc[tid] = ks2; vsc[tid] = vs2; }
-#pragma unroll
-    for (int j = 0; j < PPT; j++) {
-        const int pp = tid + 256 * j;
-        if (pp < NPAIR) {
-            const float x0 = qv[j].x, x1 = qv[j].y, c = csv[j].x, s = csv[j].y;
-            float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;
-            if (TK == T_F16) { y0 = h2f(f2h(y0)); y1 = h2f(f2h(y1)); }
-            *reinterpret_cast<float2 *>(qf + 2 * pp) = make_float2(y0, y1);
-        }
-    }
-    __syncthreads();
-    if (FUSED && own_cl >= 0) {   // workgroup-uniform: use the row just produced instead of what the cache held before
-        if (tid < 2) {
-            if (TK != T_F16) ksc[own_cl * 2 + tid] = newkd[tid];
-            if (TV != T_F16) vsc[own_cl * 2 + tid] = newvd[tid];
-        }
-#pragma unroll
-        for (int j = 0; j < KP; j++) {
-            const int p = tid + 256 * j;
-            if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const uint4 *>(newk + (p % LPC) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (cg + 8 * i == own_cl) {
-                if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(newv + dq * 8);
-                else { vreg[i].x = *reinterpret_cast<const uint32_t *>(newv + dq * 4); vreg[i].y = 0; }
-            }
-        }
-    }
-    if (TK != T_F16) {   // q8_0 of the rotated q: 4 values per thread, 8-lane groups
-        for (int e0 = tid * 4; e0 < R * D; e0 += 1024) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(qf + e0);
-            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-            uint32_t packed; float d;
-            wave_quant_q80(vv, packed, d);
-            *reinterpret_cast<uint32_t *>(qc + e0) = packed;
-            if ((lane & 7) == 0) qd[e0 >> 5] = h2f(f2h(d));
-        }
-        __syncthreads();
-    }
-
-    // ---- scores
-#pragma unroll
-    for (int j = 0; j < KP; j++) {
-        const int p = tid + 256 * j;
-        const int cl = p / LPC, piece = p % LPC;
-        float sc[R];
-        if (TK == T_F16) {
-            const uint32_t kw[4] = {kreg[j].x, kreg[j].y, kreg[j].z, kreg[j].w};
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const float *qq = qf + r * D + piece * 8;
-                float s = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    s += h2f((uint16_t)(kw[i] & 0xffff)) * qq[2 * i];
-                    s += h2f((uint16_t)(kw[i] >> 16)) * qq[2 * i + 1];
-                }
-                s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s); s += dpp_f<DPP_MIRROR>(s);
-                sc[r] = s;
-            }
-        } else {
-            const uint32_t kpair = ksc[cl * 2 + (piece >> 2)];
-            const float dk = h2f((uint16_t)(((piece >> 1) & 1) ? (kpair >> 16) : (kpair & 0xffff)));
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint4 qq = *reinterpret_cast<const uint4 *>(qc + r * D + piece * 16);
-                int s = 0;
-                s = dot4(kreg[j].x, qq.x, s); s = dot4(kreg[j].y, qq.y, s); s = dot4(kreg[j].z, qq.z, s); s = dot4(kreg[j].w, qq.w, s);
-                s += dpp_i<DPP_QP_1032>(s);                    // both halves of the 32-block (integer)
-                float f = (piece & 1) ? 0.0f : (float)s * (dk * qd[r * NB + (piece >> 1)]);
-                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f); f += dpp_f<DPP_HALF_MIRROR>(f);   // 8 lanes
-                sc[r] = f;
-            }
-        }
-        if (piece == 0) {
-            const bool v = vis[cl] != 0;
-#pragma unroll
-            for (int r = 0; r < R; r++) S[r * C + cl] = v ? sc[r] * a.scale : -INFINITY;
-        }
-    }
-    __syncthreads();
-
-    // ---- softmax of the chunk: wave w -> heads w, w+4, ...; lane = cell
-    for (int r = wave; r < R; r += 4) {
-        const float s = S[r * C + lane];
-        const float m = wave_max(s);
-        const float p = (s == -INFINITY) ? 0.0f : expf(s - m);
-        const float l = wave_sum(p);
-        S[r * C + lane] = p;
-        if (lane == 0) { ml[2 * r] = m; ml[2 * r + 1] = l; }
-    }
-    __syncthreads();
-
-    // ---- P.V
-    float acc[R][4];
-#pragma unroll
-    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int cl = cg + 8 * i;
-        float v4[4];
-        if (TV == T_F16) {
-            v4[0] = h2f((uint16_t)(vreg[i].x & 0xffff)); v4[1] = h2f((uint16_t)(vreg[i].x >> 16));
-            v4[2] = h2f((uint16_t)(vreg[i].y & 0xffff)); v4[3] = h2f((uint16_t)(vreg[i].y >> 16));
-        } else {
-            const uint32_t vpair = vsc[cl * 2 + (dq >> 4)];
-            const float dv = h2f((uint16_t)(((dq >> 3) & 1) ? (vpair >> 16) : (vpair & 0xffff)));
-            const uint32_t w = vreg[i].x;
-            v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
-            v4[2] = (float)(int8_t)((w >> 16) & 0xff) * dv; v4[3] = (float)(int8_t)(w >> 24) * dv;
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const float p = S[r * C + cl];
-            acc[r][0] += v4[0] * p; acc[r][1] += v4[1] * p; acc[r][2] += v4[2] * p; acc[r][3] += v4[3] * p;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++)
-        *reinterpret_cast<float4 *>(accs + ((size_t)cg * R + r) * D + dq * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-    __syncthreads();
-    for (int e = tid; e < R * D; e += 256) {
-        const int r = e / D, d = e - r * D;
-        float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) s += accs[((size_t)j * R + r) * D + d];
-        float *dst = a.part + (((size_t)t * H + (size_t)g * R + r) * a.splits + sp) * (D + 2);
-        dst[d] = s;
-        if (d == 0) { dst[D] = ml[2 * r]; dst[D + 1] = ml[2 * r + 1]; }
-    }
-    if (!FUSED) return;
-    if (fz.counters == nullptr) return;               // store-fused only: the merge runs as its own launch
-
-    // ---- FUSED: ticket; the last workgroup of this kv head merges
-    const int stride_s = a.splits;                             // workspace stride; with a chunk list fewer slots are in use
-    const int splits = a.tok_nchunks ? a.tok_nchunks[0] : a.splits;
-    // every wave's partial stores must have reached L2 before thread 0 releases them device-wide: __syncthreads() fences
-    // LDS only (hipcc emitted no vmcnt wait before the barrier here), so each wave drains its own stores first
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release fence compiles to nothing on this target)
-    __syncthreads();
-    if (tid == 0) {
-        // ONE release per workgroup (the barrier ordered the other waves' stores before it), then the ticket
-        const unsigned old = __hip_atomic_fetch_add(fz.counters + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (old == (unsigned)splits - 1u) ? 1 : 0;
-        if (last_flag) __hip_atomic_store(fz.counters + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    float *wgt = S;                                    // [R][64] split weights (S is free now: R * C floats)
-    float *merged = accs;                              // [R * D]
-    for (int r = wave; r < R; r += 4) {                // same arithmetic as flash_attn_combine_kernel
-        const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2);
-        float m = -INFINITY, l = 0.0f;
-        if (lane < splits) {
-            m = __hip_atomic_load(p + (size_t)lane * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            l = __hip_atomic_load(p + (size_t)lane * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const float M = wave_max(m);
-        const float w = (lane < splits && m != -INFINITY) ? expf(m - M) : 0.0f;
-        const float den = wave_sum(w * l);
-        const float inv = 1.0f / den;
-        wgt[r * 64 + lane] = w * inv;
-    }
-    __syncthreads();
-    const int E = H * D;
-    for (int e = tid; e < R * D; e += 256) {
-        const int r = e / D, d = e - r * D;
-        const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2) + d;
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int s2 = 0; s2 < splits; s2++)
-            acc += wgt[r * 64 + s2] * __hip_atomic_load(p + (size_t)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        merged[e] = acc;
-        a.out[(size_t)g * R * D + e] = acc;
-    }
-    __syncthreads();
-    constexpr int NBLK = (R * D) >> 8;                 // 256-blocks this kv head owns in the H*D row
-    if (wave < NBLK && (fz.want_q8k || fz.want_q80)) {
-        for (int b = wave; b < NBLK; b += 4) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(merged + b * 256 + lane * 4);
-            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-            const int gb = ((g * R * D) >> 8) + b;     // global block index
-            const int e0 = gb * 256 + lane * 4;
-            if (fz.want_q8k) {
-                uint32_t packed; int bs; float dq8;
-                wave_quant_q8k(vv, lane, packed, bs, dq8);
-                *reinterpret_cast<uint32_t *>(fz.q.qs + e0) = packed;
-                if ((lane & 3) == 0) fz.q.bsums[gb * 16 + (lane >> 2)] = (int16_t)bs;
-                if (lane == 0) fz.q.d[gb] = dq8;
-            }
-            if (fz.want_q80) {
-                uint32_t packed; float dd;
-                wave_quant_q80(vv, packed, dd);
-                *reinterpret_cast<uint32_t *>(fz.q.qs0 + e0) = packed;
-                if ((lane & 7) == 0) fz.q.d0[gb * 8 + (lane >> 3)] = f2h(dd);
-            }
-        }
-    }
-    (void)E;
-}
+}  // namespace mi355
+#include "attn_decode_dev.h"   // DecodeFuse, flash_attn_decode_item / flash_attn_decode_kernel
+namespace mi355 {
 
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
@@ -925,7 +586,11 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters;
     if (a.out_q) fz.q = *a.out_q;
     fz.want_q8k = (int)(a.out_q && a.out_q8k); fz.want_q80 = (int)(a.out_q && a.out_q80);
-#define FAD(RR, TK, TV) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz)
+    // MI355_ATTN_COH=1: publish the chunk partials with write-through stores and a relaxed ticket instead of an agent-scope
+    // release / acquire per workgroup (whole-L2 write-back + invalidate)
+    static const bool coh = getenv("MI355_ATTN_COH") && getenv("MI355_ATTN_COH")[0] == '1';
+#define FAD(RR, TK, TV) do { if (coh && counters) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); \
+                             else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); } while (0)
 #define FAD_T(RR)                                                              \
     if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \

@@ -184,6 +184,7 @@ int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
 }
 float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
+int64_t mi355_debug_mega_steps(const mi355_context *ctx) { return ctx->c->mega_steps; }
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0; }
 float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
@@ -467,6 +468,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "mmq_planes")) { g_op_mmq_planes = value != 0; return MI355_OK; }
     if (!strcmp(name, "mmq_tiles")) { mmq_set_tiles(value); return MI355_OK; }
     if (!strcmp(name, "mmq_ksplit")) { g_op_mmq_ksplit = value != 0; return MI355_OK; }
+    if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
     fail(std::string("unknown option ") + name);
     return MI355_ERR_ARG;
 }

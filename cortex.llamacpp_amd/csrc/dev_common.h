@@ -42,6 +42,52 @@ __host__ __device__ inline size_t dev_row_bytes(int t, int64_t K) {
 // ---- wave-level reductions ---------------------------------------------------------------
 // DPP butterflies inside each 16-lane row (VALU speed, no LDS crossbar), then the four row totals are read
 // with v_readlane and combined in a fixed order; the result is wave-uniform (valid in every lane).
+// ---- device-coherent accesses (agent scope, no cache-wide fence) for data exchanged between workgroups of ONE running
+// kernel (decode_mega.hip).  MI355X has one L2 per XCD: a plain store may sit in the writer's L2 and a plain load may hit
+// a stale line in the reader's.  An agent-scope release / acquire pair fixes that with buffer_wbl2 / buffer_inv over the
+// whole L2, which costs ~25 us when 512 workgroups do it at once (tools/bench_gridbar.hip).  Marking just the exchanged
+// accesses sc1 (write-through to / read from the coherence point) costs nothing extra: they are a few KB per phase.
+// COH = false compiles to the plain access.  `base` must be wave-uniform; byte offsets below 2 GB.
+typedef unsigned int coh_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int coh_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
+}
+template <bool COH> __device__ __forceinline__ coh_u32x4 cld16(const void *base, int byte_off) {
+    if (COH) return __builtin_amdgcn_raw_buffer_load_b128(coh_rsrc(base), byte_off, 0, 16);
+    return *reinterpret_cast<const coh_u32x4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <bool COH> __device__ __forceinline__ coh_u32x2 cld8(const void *base, int byte_off) {
+    if (COH) return __builtin_amdgcn_raw_buffer_load_b64(coh_rsrc(base), byte_off, 0, 16);
+    return *reinterpret_cast<const coh_u32x2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <bool COH> __device__ __forceinline__ unsigned cld4(const void *base, int byte_off) {
+    if (COH) return __builtin_amdgcn_raw_buffer_load_b32(coh_rsrc(base), byte_off, 0, 16);
+    return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <bool COH> __device__ __forceinline__ int cld2s(const void *base, int byte_off) {          // int16 -> int
+    if (COH) return (int)(short)__builtin_amdgcn_raw_buffer_load_b16(coh_rsrc(base), byte_off, 0, 16);
+    return (int)*reinterpret_cast<const short *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <bool COH> __device__ __forceinline__ float cldf(const float *p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void cstf(float *p, float v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void cst4(void *p, unsigned v) {
+    if (COH) __hip_atomic_store(reinterpret_cast<unsigned *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *reinterpret_cast<unsigned *>(p) = v;
+}
+template <bool COH> __device__ __forceinline__ void cst2(void *p, unsigned short v) {
+    if (COH) __hip_atomic_store(reinterpret_cast<unsigned short *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *reinterpret_cast<unsigned short *>(p) = v;
+}
+
+// threadIdx.x through an opaque move: what is derived from it cannot be hoisted out of an enclosing loop or merged
+// with another phase's copy.  decode_mega.hip runs several kernels' bodies inside one layer loop; with the plain builtin
+// the compiler computed every phase's lane constants once at the top and kept them in scratch.
+__device__ __forceinline__ int tid_now() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
 constexpr int DPP_QP_1032 = 0xB1;    // quad_perm [1,0,3,2]

@@ -55,6 +55,10 @@ void mmvq_fast_set_threads(int nt);
 bool mmvq_fast_applicable(const MMVQArgs &a);
 hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st);
 hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_t st);
+// workgroup ranges per segment, LDS bytes and the reduction-scratch offset for a grid of `blocks` workgroups of `waves`
+// waves each (what launch_mmvq_fast works out for its own launch); returns the LDS bytes, 0 if the shape has no fast form
+size_t mmvq_fast_plan(MMVQArgs &a, int blocks, int waves);
+
 void set_num_cu(int n);
 int num_cu();
 
@@ -169,6 +173,28 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
 bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra);
 hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew,
                                           const int32_t *tok_cell, unsigned *counters, hipStream_t st);
+
+// ---------------------------------------------------------------- whole decode step in one launch (decode_mega.hip)
+// Every mat-vec of every layer and the decode attention run as PHASES of one persistent kernel, separated by device-wide
+// barriers; the first weight blocks of a phase are requested before its barrier.  Dense Llama layers, K-quant weights,
+// one token.  The descriptors live in device memory (built once per context); what changes per step is in the launch.
+struct MegaLayer {
+    MMVQArgs qkv, wo, gate_up, down;   // planned with mmvq_fast_plan(.., mega_blocks(), 4)
+    KVLayerView kv;
+};
+constexpr int MEGA_SYNC_WORDS = 32 * 9;
+int mega_blocks();                                           // grid size: 2 workgroups of 256 threads per CU
+bool decode_mega_applicable(int kb_e, int kb_ff, int R, int type_k, int type_v);
+// a: the single-token AttnArgs of launch_flash_attn_decode_fused (kv is taken from the layer descriptors);
+// sync: MEGA_SYNC_WORDS words; [0] and [32 * (1 + g)], g < 8 = barrier counters (0 at launch: launch_kv_meta_set zeroes them),
+// sync[1] = sticky time-out flag (stays 0 on a healthy run; copied to the
+// pinned host word host_flag when the kernel ends)
+hipError_t launch_decode_mega(const MegaLayer *layers_dev, int n_layer, int kb_e, int kb_ff, const AttnArgs &a, const float *cs_table,
+                              int n_rot, const float *knew, const float *vnew, const int32_t *tok_cell, unsigned *counters,
+                              unsigned *sync, int *host_flag, unsigned long long *probe, size_t lds_mmvq, hipStream_t st);
+constexpr int MEGA_PROBES_PER_LAYER = 10;  // probe (nullable): 1 + 10 * n_layer wall-clock stamps of workgroup 0: per phase (qkv, attention, wo, gate_up,
+                                           // down) the end of its wait for the previous phase and its own arrival
+
 bool kv_store_fast_applicable(int G, int D, int type_k, int type_v, const RopeArgs &ra);
 hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, int D, const float *cs_table, RopeArgs ra,
                                 const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);
@@ -180,6 +206,6 @@ hipError_t launch_k_shift(KVLayerView kv, int type_k, int G, int D, int n_ctx, c
 
 // cell metadata update inside the decode graph: cell_pos[cell] = pos, cell_seq[cell] = mask
 hipError_t launch_kv_meta_set(int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell, const int32_t *tok_pos,
-                              const uint64_t *tok_seqmask, int T, hipStream_t st);
+                              const uint64_t *tok_seqmask, int T, hipStream_t st, unsigned *zero_word = nullptr);
 
 }  // namespace mi355

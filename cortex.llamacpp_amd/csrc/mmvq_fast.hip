@@ -10,419 +10,11 @@
 //     activation slice of a pass is read once and applied to both rows of the pair;
 //   * for K <= 4096 the lane's activation slices (2 passes) live in registers for the whole kernel, so the inner loop
 //     touches neither LDS nor L2 for activations.
-#include "kernels.h"
-#include "quant_dev.h"
+#include "mmvq_fast_dev.h"
 
 namespace mi355 {
 
 namespace {
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t ldw(const void *p) {   // weight stream: non-temporal
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
-}
-__device__ __forceinline__ u32x4_t lds16(const void *p) { return *reinterpret_cast<const u32x4_t *>(p); }
-__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
-
-// activation slice one lane needs for one pass (8 super-blocks per wave, lane -> (sb, 16-code piece))
-struct ActSlice {
-    u32x4_t lo, hi;      // 16 + 16 int8 codes
-    float yd;          // Q8_K block scale
-    int bs_lo, bs_hi;  // sums of the two 16-code groups
-};
-
-struct LaneRole {      // constants of this lane, computed once
-    int sbl;           // super-block within the pass (0..7)
-    int v, c, h;       // piece (0..7), chunk (0..3), half (0..1)
-    int sh;            // bit shift selecting this chunk's 16-bit scale pair
-    bool hi_scales;    // c >= 2: 6-bit scales split across bytes
-    int n, w;          // Q6_K: half (0..1) and 16-code column (0..3)
-};
-
-template <int TYPE> struct Raw;
-
-// ---------------------------------------------------------------- Q4_K
-template <> struct Raw<T_Q4_K> {
-    u32x4_t hdr, q;
-    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
-        const uint8_t *b = row + (size_t)sb * 144;
-        hdr = ldw(b);
-        q = ldw(b + 16 + L.v * 16);
-    }
-    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ hdr.y ^ hdr.z ^ hdr.w ^ q.x ^ q.y ^ q.z ^ q.w); }
-    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
-        const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
-        const uint32_t a16 = (hdr.y >> L.sh) & 0xffff, b16 = (hdr.z >> L.sh) & 0xffff, c16 = (hdr.w >> L.sh) & 0xffff;
-        const uint32_t sc = L.hi_scales ? ((c16 & 0x0f0f) | ((a16 >> 2) & 0x3030)) : (a16 & 0x3f3f);
-        const uint32_t mn = L.hi_scales ? (((c16 >> 4) & 0x0f0f) | ((b16 >> 2) & 0x3030)) : (b16 & 0x3f3f);
-        int dl = 0, dh = 0;
-        dl = dot4(q.x & 0x0f0f0f0f, A.lo.x, dl); dh = dot4((q.x >> 4) & 0x0f0f0f0f, A.hi.x, dh);
-        dl = dot4(q.y & 0x0f0f0f0f, A.lo.y, dl); dh = dot4((q.y >> 4) & 0x0f0f0f0f, A.hi.y, dh);
-        dl = dot4(q.z & 0x0f0f0f0f, A.lo.z, dl); dh = dot4((q.z >> 4) & 0x0f0f0f0f, A.hi.z, dh);
-        dl = dot4(q.w & 0x0f0f0f0f, A.lo.w, dl); dh = dot4((q.w >> 4) & 0x0f0f0f0f, A.hi.w, dh);
-        const int isum = mul24((int)(sc & 0xff), dl) + mul24((int)(sc >> 8), dh);
-        const int msum = mul24((int)(mn & 0xff), A.bs_lo) + mul24((int)(mn >> 8), A.bs_hi);
-        return (d * A.yd) * (float)isum - (dmin * A.yd) * (float)msum;
-    }
-};
-
-// ---------------------------------------------------------------- Q5_K
-template <> struct Raw<T_Q5_K> {
-    u32x4_t hdr, qh, q;
-    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ qh.x ^ q.x ^ q.y ^ q.z ^ q.w); }
-    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
-        const uint8_t *b = row + (size_t)sb * 176;
-        hdr = ldw(b);
-        qh = ldw(b + 16 + L.h * 16);
-        q = ldw(b + 48 + L.v * 16);
-    }
-    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
-        const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
-        const uint32_t a16 = (hdr.y >> L.sh) & 0xffff, b16 = (hdr.z >> L.sh) & 0xffff, c16 = (hdr.w >> L.sh) & 0xffff;
-        const uint32_t sc = L.hi_scales ? ((c16 & 0x0f0f) | ((a16 >> 2) & 0x3030)) : (a16 & 0x3f3f);
-        const uint32_t mn = L.hi_scales ? (((c16 >> 4) & 0x0f0f) | ((b16 >> 2) & 0x3030)) : (b16 & 0x3f3f);
-        const int s0 = 2 * L.c, s1 = s0 + 1;
-        int dl = 0, dh = 0;
-#define Q5L(w, hw) (((w) & 0x0f0f0f0f) | ((((hw) >> s0) & 0x01010101u) << 4))
-#define Q5H(w, hw) ((((w) >> 4) & 0x0f0f0f0f) | ((((hw) >> s1) & 0x01010101u) << 4))
-        dl = dot4(Q5L(q.x, qh.x), A.lo.x, dl); dh = dot4(Q5H(q.x, qh.x), A.hi.x, dh);
-        dl = dot4(Q5L(q.y, qh.y), A.lo.y, dl); dh = dot4(Q5H(q.y, qh.y), A.hi.y, dh);
-        dl = dot4(Q5L(q.z, qh.z), A.lo.z, dl); dh = dot4(Q5H(q.z, qh.z), A.hi.z, dh);
-        dl = dot4(Q5L(q.w, qh.w), A.lo.w, dl); dh = dot4(Q5H(q.w, qh.w), A.hi.w, dh);
-#undef Q5L
-#undef Q5H
-        const int isum = mul24((int)(sc & 0xff), dl) + mul24((int)(sc >> 8), dh);
-        const int msum = mul24((int)(mn & 0xff), A.bs_lo) + mul24((int)(mn >> 8), A.bs_hi);
-        return (d * A.yd) * (float)isum - (dmin * A.yd) * (float)msum;
-    }
-};
-
-// ---------------------------------------------------------------- Q6_K (device row planes: ql | qh | scales | d)
-template <> struct Raw<T_Q6_K> {
-    u32x4_t ql, qh;
-    int sc_lo, sc_hi;
-    uint32_t dh16;
-    __device__ __forceinline__ float probe() const { return (float)(ql.x ^ ql.y ^ ql.z ^ ql.w ^ qh.x ^ qh.y ^ qh.z ^ qh.w ^ (uint32_t)sc_lo ^ (uint32_t)sc_hi ^ dh16); }
-    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
-        ql = ldw(row + (size_t)sb * 128 + L.v * 16);
-        qh = ldw(row + (size_t)nb * 128 + (size_t)sb * 64 + L.n * 32 + (L.w & 1) * 16);
-        const int8_t *sc = reinterpret_cast<const int8_t *>(row + (size_t)nb * 192 + (size_t)sb * 16 + 8 * L.n + L.w);
-        sc_lo = sc[0];
-        sc_hi = sc[4];
-        dh16 = *reinterpret_cast<const uint16_t *>(row + (size_t)nb * 208 + (size_t)sb * 2);
-    }
-    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
-        const float d = h2f((uint16_t)dh16);
-        const int s0 = 2 * (L.w >> 1), s1 = s0 + 4;
-        int dl = 0, dh = 0;
-#define Q6L(l, hh) (((l) & 0x0f0f0f0f) | ((((hh) >> s0) & 0x03030303u) << 4))
-#define Q6H(l, hh) ((((l) >> 4) & 0x0f0f0f0f) | ((((hh) >> s1) & 0x03030303u) << 4))
-        dl = dot4(Q6L(ql.x, qh.x), A.lo.x, dl); dh = dot4(Q6H(ql.x, qh.x), A.hi.x, dh);
-        dl = dot4(Q6L(ql.y, qh.y), A.lo.y, dl); dh = dot4(Q6H(ql.y, qh.y), A.hi.y, dh);
-        dl = dot4(Q6L(ql.z, qh.z), A.lo.z, dl); dh = dot4(Q6H(ql.z, qh.z), A.hi.z, dh);
-        dl = dot4(Q6L(ql.w, qh.w), A.lo.w, dl); dh = dot4(Q6H(ql.w, qh.w), A.hi.w, dh);
-#undef Q6L
-#undef Q6H
-        const int isum = mul24(sc_lo, dl - 32 * A.bs_lo) + mul24(sc_hi, dh - 32 * A.bs_hi);
-        return (d * A.yd) * (float)isum;
-    }
-};
-
-template <int TYPE> __device__ __forceinline__ LaneRole make_role(int lane) {
-    LaneRole L;
-    L.sbl = lane >> 3; L.v = lane & 7; L.c = L.v >> 1; L.h = L.v & 1;
-    L.sh = (L.c & 1) * 16; L.hi_scales = L.c >= 2;
-    L.n = L.v >> 2; L.w = L.v & 3;
-    return L;
-}
-
-// LDS view of the staged Q8_K activation of the token
-struct ActL { const int8_t *qs; const float *d; const int16_t *bs; };
-
-template <int TYPE>
-__device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const LaneRole &L) {
-    ActSlice s;
-    if (TYPE == T_Q6_K) {
-        const int8_t *a = A.qs + sb * 256 + 128 * L.n + 16 * L.w;
-        s.lo = lds16(a); s.hi = lds16(a + 64);
-        const int16_t *b = A.bs + sb * 16 + 8 * L.n + L.w;
-        s.bs_lo = b[0]; s.bs_hi = b[4];
-    } else {
-        const int8_t *a = A.qs + sb * 256 + 64 * L.c + 16 * L.h;
-        s.lo = lds16(a); s.hi = lds16(a + 32);
-        const int16_t *b = A.bs + sb * 16 + 4 * L.c + L.h;
-        s.bs_lo = b[0]; s.bs_hi = b[2];
-    }
-    s.yd = A.d[sb];
-    return s;
-}
-
-// ---- activation of the token.  Three ways in, chosen per launch (all wave-uniform):
-//   direct : fuse_mode 0 and K <= 4096 -> each lane loads its own two slices straight from the Q8_K planes in global
-//            memory (L2/L1 hits) into registers: no LDS, no barrier;
-//   copy   : fuse_mode 0, longer K      -> the planes are copied to LDS once per workgroup;
-//   fused  : fuse_mode 1 / 2            -> RMSNorm * w and / or the Q8_K quantisation happen here, result in LDS.
-// Global loads are always ISSUED before the first weight loads and CONSUMED after them: memory returns in order, so
-// waiting for activations that were requested after the weights would also wait for the weights (the first version did
-// exactly that, and its conditional register array went through scratch: 2-6 us per launch, tools/bench_mmvq.hip).
-template <int TYPE>
-__device__ __forceinline__ ActSlice global_slice(const MMVQArgs &a, int sb, const LaneRole &L) {
-    ActSlice s;
-    if (TYPE == T_Q6_K) {
-        const int8_t *q = a.aq + sb * 256 + 128 * L.n + 16 * L.w;
-        s.lo = *reinterpret_cast<const u32x4_t *>(q); s.hi = *reinterpret_cast<const u32x4_t *>(q + 64);
-        const int16_t *b = a.abs + sb * 16 + 8 * L.n + L.w;
-        s.bs_lo = b[0]; s.bs_hi = b[4];
-    } else {
-        const int8_t *q = a.aq + sb * 256 + 64 * L.c + 16 * L.h;
-        s.lo = *reinterpret_cast<const u32x4_t *>(q); s.hi = *reinterpret_cast<const u32x4_t *>(q + 32);
-        const int16_t *b = a.abs + sb * 16 + 4 * L.c + L.h;
-        s.bs_lo = b[0]; s.bs_hi = b[2];
-    }
-    s.yd = a.ad[sb];
-    return s;
-}
-
-template <int KB, int NT> struct StageDims {
-    static constexpr int NW = NT / 64;
-    static constexpr int N16 = KB * 128, NQ = (N16 + NT - 1) / NT;      // u32x4_t words of the code plane, per thread
-    static constexpr int NB32 = (KB * 64 + NT - 1) / NT;                // bsums as 32-bit words, per thread
-    static constexpr int NJW = (KB * 8 + NW - 1) / NW;                  // fused: 256-blocks per wave (wave w owns blocks w, w + NW, ..)
-};
-// the staged values travel in plain local arrays of NATIVE vector types (statically indexed after unrolling, so they stay
-// in registers; arrays of HIP's u32x4_t class under a conditional were placed in scratch by hipcc)
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-#define STAGE_REGS_DECL(KB, NT) u32x4_t sq_[StageDims<KB, NT>::NQ]; uint32_t sb_[StageDims<KB, NT>::NB32]; float sdv_ = 0.0f; \
-                                f32x4_t sxv_[StageDims<KB, NT>::NJW], swv_[StageDims<KB, NT>::NJW]
-#define STAGE_REGS_ARGS sq_, sb_, sdv_, sxv_, swv_
-
-template <int KB, int NT, int FUSE>
-__device__ __forceinline__ void stage_issue(const MMVQArgs &a, u32x4_t (&rq)[StageDims<KB, NT>::NQ], uint32_t (&rb)[StageDims<KB, NT>::NB32], float &rdv,
-                                            f32x4_t (&rxv)[StageDims<KB, NT>::NJW], f32x4_t (&rwv)[StageDims<KB, NT>::NJW]) {
-    using S = StageDims<KB, NT>;
-    const int tid = threadIdx.x;
-    if (FUSE == 0) {
-        const u32x4_t *src = reinterpret_cast<const u32x4_t *>(a.aq);
-        const int n16 = (a.K >> 8) * 16;                       // K may end inside the last pass (K % 256 == 0 only)
-#pragma unroll
-        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; rq[j] = src[i < n16 ? i : n16 - 1]; }
-        const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(a.abs);
-        const int nbt = a.K >> 8;
-#pragma unroll
-        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; rb[j] = bsrc[i < nbt * 8 ? i : nbt * 8 - 1]; }
-        rdv = a.ad[tid < nbt ? tid : nbt - 1];
-    } else {
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int j = 0; j < S::NJW; j++) {
-            const int b = wave + S::NW * j;
-            const int nbt = a.K >> 8;
-            const int bc = b < nbt ? b : nbt - 1;                  // clamped: always a valid address, result unused when b is out of range
-            rxv[j] = *reinterpret_cast<const f32x4_t *>(a.nx + bc * 256 + lane * 4);
-            if (FUSE == 1) rwv[j] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
-        }
-    }
-}
-
-template <int KB, int NT, int FUSE>
-__device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&rq)[StageDims<KB, NT>::NQ], const uint32_t (&rb)[StageDims<KB, NT>::NB32], float rdv,
-                                             const f32x4_t (&rxv)[StageDims<KB, NT>::NJW], const f32x4_t (&rwv)[StageDims<KB, NT>::NJW], uint8_t *smem) {
-    using S = StageDims<KB, NT>;
-    constexpr int K = KB * 2048;                               // LDS layout is sized for whole passes
-    const int nbt = a.K >> 8;                                  // super-blocks that exist
-    const int tid = threadIdx.x;
-    int8_t *qs = reinterpret_cast<int8_t *>(smem);
-    float *d = reinterpret_cast<float *>(smem + K);
-    int16_t *bs = reinterpret_cast<int16_t *>(smem + K + (((K >> 8) * 4 + 15) & ~15));
-    if (FUSE == 0) {
-#pragma unroll
-        for (int j = 0; j < S::NQ; j++) { const int i = j * NT + tid; if (i < nbt * 16) reinterpret_cast<u32x4_t *>(qs)[i] = rq[j]; }
-#pragma unroll
-        for (int j = 0; j < S::NB32; j++) { const int i = j * NT + tid; if (i < nbt * 8) reinterpret_cast<uint32_t *>(bs)[i] = rb[j]; }
-        if (tid < nbt) d[tid] = rdv;
-    } else {
-        double *red = reinterpret_cast<double *>(smem + a.red_off);
-        const int lane = tid & 63, wave = tid >> 6;
-        float scale = 1.0f;
-        if (FUSE == 1) {
-            double sum = 0.0;
-#pragma unroll
-            for (int j = 0; j < S::NJW; j++) {
-                const f32x4_t v = rxv[j];
-                double t = 0.0;
-                t += (double)(v.x * v.x); t += (double)(v.y * v.y); t += (double)(v.z * v.z); t += (double)(v.w * v.w);
-                if (wave + S::NW * j < nbt) sum += t;
-            }
-            sum = wave_sum(sum);
-            if (lane == 0) red[wave] = sum;
-            __syncthreads();
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < S::NW; w++) tot += red[w];
-            const float mean = (float)(tot / (double)a.K);
-            scale = 1.0f / sqrtf(mean + a.neps);
-        }
-#pragma unroll
-        for (int j = 0; j < S::NJW; j++) {
-            const int b = wave + S::NW * j;
-            if (b >= nbt) continue;                                // wave-uniform
-            const int e0 = b * 256 + lane * 4;
-            f32x4_t v = rxv[j];
-            if (FUSE == 1) {
-                const f32x4_t ww = rwv[j];
-                v.x = (v.x * scale) * ww.x; v.y = (v.y * scale) * ww.y; v.z = (v.z * scale) * ww.z; v.w = (v.w * scale) * ww.w;
-            }
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-            uint32_t packed; int bsum; float dq;
-            wave_quant_q8k(vv, lane, packed, bsum, dq);
-            *reinterpret_cast<uint32_t *>(qs + e0) = packed;
-            if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum;
-            if (lane == 0) d[b] = dq;
-        }
-    }
-    __syncthreads();
-    ActL A{qs, d, bs};
-    return A;
-}
-
-// slice of super-block sb, or a zero-scale slice past the end of the row (partial last pass): its dot contributes 0
-template <int TYPE>
-__device__ __forceinline__ ActSlice global_slice_t(const MMVQArgs &a, int sb, int nb, const LaneRole &L) {
-    ActSlice s = global_slice<TYPE>(a, sb < nb ? sb : nb - 1, L);
-    if (sb >= nb) s.yd = 0.0f;
-    return s;
-}
-template <int TYPE>
-__device__ __forceinline__ ActSlice read_slice_t(const ActL &A, int sb, int nb, const LaneRole &L) {
-    ActSlice s = read_slice<TYPE>(A, sb < nb ? sb : nb - 1, L);
-    if (sb >= nb) s.yd = 0.0f;
-    return s;
-}
-
-// One segment, persistent waves.  A unit is (row pair, PPU passes): PPU = 2 for an even number of passes, 1 otherwise,
-// so that every unit has the same shape and its loads need no condition.  NSETS units (8 Raw blocks in all) are always
-// in flight ahead of the one being decoded.
-//
-// Control flow matters for the memory pipeline: hipcc derives each s_waitcnt vmcnt(N) from the loads issued since, and
-// where a load sits under a condition it must assume the path WITHOUT it (N = 0: wait for everything, including what
-// was just requested).  So everything from the first activation load to the end of the steady-state loop is straight-
-// line: the staging mode is a template parameter, the first NSETS units are loaded unconditionally (waves with fewer
-// units read one shared dummy block that stays in L2), and only the drain after the loop loads under conditions.
-template <int TYPE, int KB, int NT, int FUSE>
-__device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int gw, int nw) {
-    using R = Raw<TYPE>;
-    constexpr bool ACT_REGS = KB <= 2;
-    constexpr bool DIRECT = ACT_REGS && FUSE == 0;
-    const int nb = a.K >> 8;                            // super-blocks per row (the last pass may be partial: K % 256 == 0)
-    constexpr int PPU = (KB % 2 == 0) ? 2 : 1;          // passes per unit
-    constexpr int NCH = KB / PPU;                       // units per row pair
-    constexpr int NSETS = 4 / PPU;                      // register sets in the ring (2 rows x PPU passes each)
-    const int lane = threadIdx.x & 63;
-    const LaneRole L = make_role<TYPE>(lane);
-    const bool swiglu = a.epi == EPI_SWIGLU;
-    const uint8_t *W0 = sg.W + (sg.expert_sel ? (size_t)sg.expert_sel[0] * sg.expert_stride : 0);
-    const MMVQSeg &ug = a.seg[1];
-    const uint8_t *W1 = swiglu ? ug.W + (ug.expert_sel ? (size_t)ug.expert_sel[0] * ug.expert_stride : 0) : W0;
-    const size_t rb0 = sg.row_bytes, rb1 = swiglu ? ug.row_bytes : sg.row_bytes;
-    const int npairs = swiglu ? sg.n_rows : (sg.n_rows + 1) >> 1;
-    const int my_pairs = gw < npairs ? (npairs - gw + nw - 1) / nw : 0;
-    const int n_units = my_pairs * NCH;                 // unit u: pair = gw + (u / NCH) * nw, chunk = u % NCH
-
-    // ---- 1. activation loads first
-    ActSlice S0, S1;                                    // K <= 4096: this lane's slices of pass 0 / pass 1, kept in registers
-    STAGE_REGS_DECL(KB, NT);
-    if (DIRECT) {
-        S0 = global_slice_t<TYPE>(a, L.sbl, nb, L);
-        if (KB > 1) S1 = global_slice_t<TYPE>(a, 8 + L.sbl, nb, L);
-    } else {
-        stage_issue<KB, NT, FUSE>(a, STAGE_REGS_ARGS);
-    }
-
-    // ---- 2. weights
-    R W[NSETS][2 * PPU];                                // statically indexed after unrolling
-    auto load_unit = [&](int u, R (&w)[2 * PPU], bool real) {
-        const int pi = u / NCH, ch = u - pi * NCH;
-        const int pair = gw + pi * nw;
-        const uint8_t *ra, *rbp;
-        if (swiglu) { ra = W0 + (size_t)pair * rb0; rbp = W1 + (size_t)pair * rb1; }
-        else {
-            ra = W0 + (size_t)(2 * pair) * rb0;
-            rbp = (2 * pair + 1 < sg.n_rows) ? ra + rb0 : ra;       // odd tail: row b re-reads row a, result discarded
-        }
-        int sb0 = ch * PPU * 8 + L.sbl;
-        if (!real) { ra = W0; rbp = W0; sb0 = L.sbl; }              // nothing to fetch: everybody's dummy is row 0, pass 0
-#pragma unroll
-        for (int p = 0; p < PPU; p++) {
-            int sb = sb0 + 8 * p;
-            if (sb >= nb) sb = nb - 1;                  // tail of a partial last pass: any valid block, its slice scale is zero
-            w[2 * p].load(ra, nb, sb, L);
-            w[2 * p + 1].load(rbp, nb, sb, L);
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < NSETS; s++) load_unit(s, W[s], s < n_units);
-
-    // ---- 3. activations into place (workgroup barrier inside the LDS paths: reached by every wave)
-    ActL AL{nullptr, nullptr, nullptr};
-    if (!DIRECT) {
-        AL = stage_finish<KB, NT, FUSE>(a, STAGE_REGS_ARGS, smem);
-        if (ACT_REGS) {
-            S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
-            if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
-        }
-    }
-
-    float acc0 = 0.0f, acc1 = 0.0f;
-    auto compute_unit = [&](int u, const R (&w)[2 * PPU]) {
-        const int pi = u / NCH, ch = u - pi * NCH;
-#pragma unroll
-        for (int p = 0; p < PPU; p++) {
-            const ActSlice sl = ACT_REGS ? (ch * PPU + p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, (ch * PPU + p) * 8 + L.sbl, nb, L);
-            acc0 += w[2 * p].dot(sl, L);
-            acc1 += w[2 * p + 1].dot(sl, L);
-        }
-        if (ch == NCH - 1) {                            // pair finished
-            const float v0 = wave_sum(acc0), v1 = wave_sum(acc1);
-            acc0 = 0.0f; acc1 = 0.0f;
-            if (lane == 0) {
-                const int pair = gw + pi * nw;
-                if (swiglu) {
-                    sg.out[pair] = (v0 / (1.0f + expf(-v0))) * v1;
-                } else {
-                    const int row0 = 2 * pair;
-                    const bool has1 = row0 + 1 < sg.n_rows;
-                    if (a.epi == EPI_ADD) {
-                        sg.out[row0] = sg.resid[row0] + v0;
-                        if (has1) sg.out[row0 + 1] = sg.resid[row0 + 1] + v1;
-                    } else {
-                        sg.out[row0] = v0;
-                        if (has1) sg.out[row0 + 1] = v1;
-                    }
-                }
-            }
-        }
-    };
-    int u = 0;
-#pragma unroll 1
-    for (; u + 2 * NSETS <= n_units; u += NSETS) {       // steady state: every refill exists
-#pragma unroll
-        for (int s = 0; s < NSETS; s++) {
-            compute_unit(u + s, W[s]);
-            load_unit(u + NSETS + s, W[s], true);
-        }
-    }
-    // drain: units u .. n_units-1 (fewer than 2 * NSETS); sets 0 .. NSETS-1 hold u .. u+NSETS-1
-#pragma unroll
-    for (int s = 0; s < NSETS; s++) {
-        if (u + s < n_units) {
-            compute_unit(u + s, W[s]);
-            if (u + NSETS + s < n_units) load_unit(u + NSETS + s, W[s], true);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NSETS; s++)
-        if (u + NSETS + s < n_units) compute_unit(u + NSETS + s, W[s]);
-}
 
 // NT threads per workgroup, ONE workgroup per CU (the activation is staged / normalised / quantised once per CU)
 template <int KB, int NT, int FUSE>
@@ -461,21 +53,10 @@ bool mmvq_fast_applicable(const MMVQArgs &a) {
 static int g_fast_nt = 0;     // 0 = pick per launch; tools/bench_mmvq.hip forces 512 / 768 to compare
 void mmvq_fast_set_threads(int nt) { g_fast_nt = (nt == 512 || nt == 768) ? nt : 0; }
 
-hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
-    if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
+size_t mmvq_fast_plan(MMVQArgs &a, int max_blocks, int nwv) {
+    if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return 0;
     const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
     const int kb = (a.K + 2047) >> 11;
-    // persistent grid, one workgroup per CU: 12 waves (768 threads) when the registers allow it (K <= 4096), else 8;
-    // between the two, pick the one whose unit count per wave divides most evenly (e.g. 14336 pairs over 256 x 8
-    // waves = exactly 7 each), fewer resident waves costing a little latency hiding
-    int total_pairs_all = 0;
-    for (int s = 0; s < n_work_seg; s++) total_pairs_all += a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
-    // 8 waves per CU measured better than 12 on the whole decode step (tools/profile_decode.py: 2.05 vs 2.13 ms / token);
-    // MI355_MMVQ_NT=768 selects the 12-wave form for K <= 4096
-    int nt = 512;
-    if (kb <= 2 && g_fast_nt == 768) nt = 768;
-    const int nwv = nt / 64;
-    const int max_blocks = num_cu();
     size_t bytes[3] = {0, 0, 0}, total = 0;
     int want[3] = {0, 0, 0}, sum_want = 0;
     for (int s = 0; s < n_work_seg; s++) {
@@ -495,14 +76,32 @@ hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
         }
         a.seg_block0[s + 1] = a.seg_block0[s] + nb;
     }
+    if (a.seg_block0[n_work_seg] > max_blocks) {               // rounding pushed the total over: trim the largest range
+        int big = 0;
+        for (int s = 1; s < n_work_seg; s++) if (a.seg_block0[s + 1] - a.seg_block0[s] > a.seg_block0[big + 1] - a.seg_block0[big]) big = s;
+        const int over = a.seg_block0[n_work_seg] - max_blocks;
+        for (int s = big; s < n_work_seg; s++) a.seg_block0[s + 1] -= over;
+    }
     for (int s = n_work_seg; s < 3; s++) a.seg_block0[s + 1] = a.seg_block0[n_work_seg];
-    const int blocks = a.seg_block0[n_work_seg];
     if (a.epi == EPI_SWIGLU) a.n_seg = 1;
     const size_t K = (size_t)kb * 2048;                        // whole passes
     size_t lds = K + (((K >> 8) * 4 + 15) & ~(size_t)15) + (((K >> 4) * 2 + 15) & ~(size_t)15);
     lds = (lds + 15) & ~(size_t)15;
     a.red_off = (int)lds;
     lds += 128;
+    return lds;
+}
+
+hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
+    if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
+    const int kb = (a.K + 2047) >> 11;
+    // persistent grid, one workgroup per CU.  8 waves per CU measured better than 12 on the whole decode step
+    // (tools/profile_decode.py: 2.05 vs 2.13 ms / token); MI355_MMVQ_NT=768 selects the 12-wave form for K <= 4096
+    int nt = 512;
+    if (kb <= 2 && g_fast_nt == 768) nt = 768;
+    const size_t lds = mmvq_fast_plan(a, num_cu(), nt / 64);
+    if (!lds) return hipErrorInvalidValue;
+    const int blocks = a.seg_block0[3];
 #define FAST(KBV, NTV, FZ) hipLaunchKernelGGL((mmvq_fast_kernel<KBV, NTV, FZ>), dim3(blocks), dim3(NTV), lds, st, a)
 #define FAST_F(KBV, NTV) do { if (a.fuse_mode == 0) FAST(KBV, NTV, 0); else if (a.fuse_mode == 1) FAST(KBV, NTV, 1); else FAST(KBV, NTV, 2); } while (0)
     switch (kb) {

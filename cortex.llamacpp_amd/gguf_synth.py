@@ -166,6 +166,8 @@ CONFIGS = {
     "tiny-e2048": LlamaConfig("tiny-e2048", 2048, 2, 16, 4, 4096, 512, 500000.0, 1e-5, 1024),
     # 8 KV heads of 128 (one 1024-wide K / V row, GQA 2:1): the shape the single-launch decode attention (rope + cache
     # store + split attention + merge) and the chunk-list batched steps are built for — Llama-3-8B's own KV geometry
+    # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads), two layers: the whole-step kernel's shape
+    "tiny-8b-2l": LlamaConfig("tiny-8b-2l", 4096, 2, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
     "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
 }
 

@@ -225,6 +225,21 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
 Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
 Context::~Context() {
+    if (d_mega_probe_) {                                       // diagnosis: where the last whole-step launch spent its time
+        const int nl = model->hp.n_layer, np = 1 + MEGA_PROBES_PER_LAYER * nl;
+        std::vector<unsigned long long> t((size_t)np);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(t.data(), d_mega_probe_, (size_t)np * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            const char *names[MEGA_PROBES_PER_LAYER] = {"wait", "qkv", "wait", "attention", "wait", "wo", "wait", "gate_up", "wait", "down"};
+            double sum[MEGA_PROBES_PER_LAYER] = {0};
+            for (int il = 0; il < nl; il++)
+                for (int k = 0; k < MEGA_PROBES_PER_LAYER; k++)
+                    sum[k] += (double)(t[(size_t)(1 + il * MEGA_PROBES_PER_LAYER + k)] - t[(size_t)(il * MEGA_PROBES_PER_LAYER + k)]) * 0.01;
+            fprintf(stderr, "mega probe (workgroup 0, us per layer):");
+            for (int k = 0; k < MEGA_PROBES_PER_LAYER; k++) fprintf(stderr, " %s %.2f", names[k], sum[k] / nl);
+            fprintf(stderr, " | total %.1f us\n", (double)(t[(size_t)np - 1] - t[0]) * 0.01);
+        }
+    }
     for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
     if (stage_event_) (void)hipEventDestroy(stage_event_);
     for (auto &pe : prof_events_) (void)hipEventDestroy(pe.second);
@@ -234,6 +249,7 @@ Context::~Context() {
     if (h_argmax_) (void)hipHostFree(h_argmax_);
     if (h_embd_) (void)hipHostFree(h_embd_);
     if (h_chunks_) (void)hipHostFree(h_chunks_);
+    if (h_mega_flag_) (void)hipHostFree(h_mega_flag_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -603,6 +619,92 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------ whole-step kernel
+// Off by default: measured on MI355X (tools/bench_gridbar.hip) a device-wide barrier costs ~4 us where a
+// launch boundary inside a graph costs ~2.7 us, so the whole-step kernel is ~10 % slower than one launch per operation.
+// MI355_MEGA=1 or mi355_debug_set_option("decode_mega", 1) turns it on for contexts created afterwards.
+static int g_decode_mega = -1;           // -1: take the environment
+void set_decode_mega(bool on) { g_decode_mega = on ? 1 : 0; }
+
+// Builds the per-layer phase descriptors of decode_mega.hip: the same MMVQArgs the per-launch path passes to
+// launch_mmvq_fast for Q/K/V, attn_output, gate/up and down of a single token, planned for the mega grid.
+bool Context::mega_prepare() {
+    if (mega_state_ != 0) return mega_state_ > 0;
+    mega_state_ = -1;
+    static const bool mega_env_on = getenv("MI355_MEGA") && getenv("MI355_MEGA")[0] == '1';
+    const bool mega_env = g_decode_mega < 0 ? mega_env_on : g_decode_mega > 0;
+    const HParams &hp = model->hp;
+    const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
+    if (!mega_env || hp.n_expert > 0 || G <= 0 || H % G != 0 || H * D != E) return false;
+    const int kb_e = (E + 2047) >> 11, kb_ff = (FF + 2047) >> 11;
+    if ((E % 2048) != 0 || (FF % 256) != 0 || !decode_mega_applicable(kb_e, kb_ff, H / G, cp.type_k, cp.type_v)) return false;
+    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, nullptr, hp.rope_neox};
+    if (ra.neox || (ra.n_rot % 4) != 0 || D != 128 || !kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) return false;
+    auto kq = [](int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; };
+    std::vector<MegaLayer> ml((size_t)hp.n_layer);
+    const int blocks = mega_blocks();
+    size_t lds = 0;
+    for (int il = 0; il < hp.n_layer; il++) {
+        const LayerWeights &L = model->layers[(size_t)il];
+        if (!kq(L.wq.type) || !kq(L.wk.type) || !kq(L.wv.type) || !kq(L.wo.type) || !kq(L.gate.type) || !kq(L.up.type) || !kq(L.down.type)) return false;
+        if (L.gate.type != L.up.type || L.gate.N != L.up.N || L.bq.valid() || L.bk.valid() || L.bv.valid()) return false;
+        if ((int)L.wq.K != E || (int)L.wo.K != E || (int)L.gate.K != E || (int)L.down.K != FF) return false;
+        MegaLayer &m = ml[(size_t)il];
+        auto base = [&](MMVQArgs &a, int n_seg, int K, int epi, int fuse, const float *nx, const float *nw, const ActQuant &aq) {
+            a = MMVQArgs{};
+            a.n_seg = n_seg; a.K = K; a.T = 1; a.epi = epi;
+            a.fuse_mode = fuse; a.nx = nx; a.nw = nw; a.neps = hp.eps;
+            chunk_act(a, aq, K, 0);
+        };
+        base(m.qkv, 3, E, EPI_STORE, 1, x_, (const float *)L.attn_norm.data, aq_e_);
+        m.qkv.seg[0] = make_seg(L.wq, q_, (int)L.wq.N, nullptr, nullptr);
+        m.qkv.seg[1] = make_seg(L.wk, k_, (int)L.wk.N, nullptr, nullptr);
+        m.qkv.seg[2] = make_seg(L.wv, v_, (int)L.wv.N, nullptr, nullptr);
+        base(m.wo, 1, E, EPI_ADD, 0, nullptr, nullptr, aq_o_);
+        m.wo.seg[0] = make_seg(L.wo, x_, E, x_, nullptr);
+        base(m.gate_up, 2, E, EPI_SWIGLU, 1, x_, (const float *)L.ffn_norm.data, aq_e_);
+        m.gate_up.seg[0] = make_seg(L.gate, ffn_, FF, nullptr, nullptr);
+        m.gate_up.seg[1] = make_seg(L.up, ffn_u_, FF, nullptr, nullptr);
+        base(m.down, 1, FF, EPI_ADD, 2, ffn_, nullptr, aq_ff_);
+        m.down.seg[0] = make_seg(L.down, x_, E, x_, nullptr);
+        for (MMVQArgs *a : {&m.qkv, &m.wo, &m.gate_up, &m.down}) {
+            if (!mmvq_fast_applicable(*a)) return false;
+            const size_t l = mmvq_fast_plan(*a, blocks, 4);
+            if (!l) return false;
+            lds = std::max(lds, l);
+        }
+        m.kv = kv_[(size_t)il];
+    }
+    d_mega_layers_ = (MegaLayer *)dalloc(ml.size() * sizeof(MegaLayer));
+    // the barrier words are polled through the scalar cache path: they must never be cached in an XCD's L2
+    if (hipExtMallocWithFlags((void **)&d_mega_sync_, MEGA_SYNC_WORDS * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) { d_mega_sync_ = nullptr; return false; }
+    allocs_.push_back(d_mega_sync_);
+    if (!d_mega_layers_ || !d_mega_sync_) return false;
+    if (!h_mega_flag_ && hipHostMalloc((void **)&h_mega_flag_, sizeof(int), hipHostMallocDefault) != hipSuccess) return false;
+    *h_mega_flag_ = 0;
+    if (hipMemcpy(d_mega_layers_, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemset(d_mega_sync_, 0, MEGA_SYNC_WORDS * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+    if (getenv("MI355_MEGA_PROBE") && getenv("MI355_MEGA_PROBE")[0] == '1')
+        d_mega_probe_ = (unsigned long long *)dalloc((size_t)(1 + MEGA_PROBES_PER_LAYER * hp.n_layer) * 8);
+    mega_lds_ = lds;
+    mega_state_ = 1;
+    return true;
+}
+
+bool Context::mega_check() {
+    if (mega_state_ <= 0 || !h_mega_flag_ || *h_mega_flag_ == 0) return true;
+    // a device-wide barrier gave up: the step's results are not valid.  Fall back to one launch per operation from here on.
+    *h_mega_flag_ = 0;
+    (void)hipMemset(d_mega_sync_, 0, MEGA_SYNC_WORDS * sizeof(unsigned));
+    (void)hipDeviceSynchronize();
+    mega_state_ = -1;
+    for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
+    graphs_.clear();
+    graph_exec_ = nullptr;
+    last_error = "whole-step kernel: device-wide barrier timed out (workgroups not co-resident?); results of the step discarded";
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------ the forward pass
 hipError_t Context::run_layers(int T, int n_kv_cap) {
     const HParams &hp = model->hp;
@@ -612,10 +714,31 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
     const int n_kv_max = std::max(n_kv_cap, 1);   // upper bound of occupied cells the kernels are sized for
     att_splits_ = flash_attn_pick_splits(T, G, n_kv_max);
 
-    HIP_TRY(launch_kv_meta_set(d_cell_pos_, d_cell_seq_, d_cell_, d_pos_, d_seqmask_, T, stream_));
+    // single-token step on a dense K-quant model: all layers in one launch (decode_mega.hip)
+    bool mega = T == 1 && !profile_ && !debug_taps_ && mega_prepare();
+    AttnArgs ma{};
+    if (mega) {
+        ma.q = q_; ma.out = att_; ma.type_k = cp.type_k; ma.type_v = cp.type_v;
+        ma.T = 1; ma.H = H; ma.G = G; ma.D = D; ma.n_ctx = (int)cp.n_ctx;
+        ma.cell_pos = d_cell_pos_; ma.cell_seq = d_cell_seq_; ma.tok_pos = d_pos_; ma.tok_seq = d_seq_;
+        ma.n_kv_dev = d_nkv_; ma.n_kv_max = n_kv_max; ma.scale = kq_scale; ma.part = att_part_;
+        const DevTensor &wo0 = model->layers[0].wo;
+        ma.out_q = &aq_o_; ma.out_q8k = wo0.type != T_Q8_0; ma.out_q80 = false;
+        ma.splits = flash_attn_decode_splits(n_kv_max);
+        if (chunk_lmax_ > 0) {
+            ma.tok_chunks = d_chunks_; ma.tok_nchunks = d_chunks_ + (size_t)64 * chunk_stride_; ma.chunk_stride = chunk_stride_;
+            ma.splits = std::max(chunk_cap_, chunk_lmax_);
+        }
+        mega = flash_attn_decode_fused_applicable(ma, ra);      // (more than 64 chunks: the per-launch path merges them)
+    }
+    HIP_TRY(launch_kv_meta_set(d_cell_pos_, d_cell_seq_, d_cell_, d_pos_, d_seqmask_, T, stream_, mega ? d_mega_sync_ : nullptr));
     HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
     HIP_TRY(launch_rope_table(d_pos_, T, ra, rope_cs_, stream_));
     prof_mark("embed");
+    last_layers_mega_ = mega;
+    if (mega)
+        return launch_decode_mega(d_mega_layers_, hp.n_layer, (E + 2047) >> 11, (FF + 2047) >> 11, ma, rope_cs_, ra.n_rot, k_, v_, d_cell_,
+                                  att_counters_, d_mega_sync_, h_mega_flag_, d_mega_probe_, mega_lds_, stream_);
 
     for (int il = 0; il < hp.n_layer; il++) {
         const LayerWeights &L = model->layers[(size_t)il];
@@ -859,6 +982,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
     const int V = model->hp.n_vocab;
+    if (n == 1) (void)mega_prepare();      // allocates and uploads on first use: must not happen inside a stream capture
     const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
     hipError_t e = hipSuccess;
     if (graph_ok) {
@@ -885,6 +1009,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
             if (g) (void)hipGraphDestroy(g);
             if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
             graphs_[bucket] = graph_exec_;
+            graph_is_mega_[graph_exec_] = last_layers_mega_;
         }
         e = hipGraphLaunch(graph_exec_, stream_);
     } else {
@@ -898,6 +1023,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         prof_end();
     }
     if (e != hipSuccess) { last_error = std::string("decode failed: ") + hipGetErrorString(e) + " / " + last_error_string(); return -1; }
+    if (n == 1 && (graph_ok ? graph_is_mega_[graph_exec_] : last_layers_mega_)) mega_steps++;
     dbg_tokens_ = n;
     return 0;
 }
@@ -981,7 +1107,7 @@ float *Context::logits_ith(int i) {
     if (!logits_fetched_) {
         if (!cp.logits_to_host &&
             hipMemcpyAsync(h_logits_, d_logits_, (size_t)n_out_last_ * model->hp.n_vocab * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return nullptr;
-        if (hipStreamSynchronize(stream_) != hipSuccess) return nullptr;
+        if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check()) return nullptr;
         logits_fetched_ = true;
     }
     return h_logits_ + (size_t)out_row_of_batch_[(size_t)i] * model->hp.n_vocab;
@@ -1004,7 +1130,7 @@ int32_t Context::argmax_ith(int i) {
     if (i < 0) i += (int)out_row_of_batch_.size();
     if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return -1;
     if (!argmax_fetched_) {
-        if (hipStreamSynchronize(stream_) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check()) return -1;
         argmax_fetched_ = true;
     }
     return h_argmax_[out_row_of_batch_[(size_t)i]];

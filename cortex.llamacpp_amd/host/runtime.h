@@ -83,8 +83,11 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
     float eps = 0.0f;
 };
 
+void set_decode_mega(bool on);   // tests: compare the whole-step kernel with the per-launch path (read when a context first decodes one token)
+
 class Context {
   public:
+    int64_t mega_steps = 0;            // single-token steps issued as one whole-step launch (graph replays included)
     Context(Model *m, const ContextParams &p);
     ~Context();
     bool init(std::string &err);
@@ -169,6 +172,17 @@ class Context {
     // batched single-token steps: per-token lists of the 64-cell chunks that hold cells of the token's sequence
     int32_t *h_chunks_ = nullptr, *d_chunks_ = nullptr;     // [64][chunk_stride_] lists, then [64] counts
     int chunk_stride_ = 0, chunk_lmax_ = 0, chunk_cap_ = 0;   // cap = grid size used for the lists (>= lmax; rounded up for graph reuse)                 // lmax = longest list of the current batch (0 = lists not in use)
+    // whole-step kernel (decode_mega.hip): per-layer descriptors in device memory, barrier words, pinned time-out flag
+    MegaLayer *d_mega_layers_ = nullptr;
+    unsigned *d_mega_sync_ = nullptr;
+    int *h_mega_flag_ = nullptr;
+    unsigned long long *d_mega_probe_ = nullptr;   // MI355_MEGA_PROBE=1: phase time stamps of the last step (printed by the destructor)
+    size_t mega_lds_ = 0;
+    bool last_layers_mega_ = false;      // what the last run_layers call issued
+    std::map<hipGraphExec_t, bool> graph_is_mega_;
+    int mega_state_ = 0;                 // 0 = not looked at yet, 1 = descriptors built, -1 = this model / context takes the per-launch path
+    bool mega_prepare();
+    bool mega_check();                   // after a stream sync: false (and last_error set) if a barrier of the last step timed out
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;

@@ -143,6 +143,8 @@ MI355_API int32_t mi355_decode(mi355_context *ctx, mi355_batch batch);
 MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);
 /* device-side greedy front end: argmax token of row i without copying the row */
 MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
+/* diagnosis: single-token steps this context ran as ONE launch (decode_mega.hip; see mi355_debug_set_option "decode_mega") */
+MI355_API int64_t mi355_debug_mega_steps(const mi355_context *ctx);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
 /* llama_get_embeddings_ith (ctx.cc:1042-1044): final-norm hidden state (n_embd floats, host memory) of batch row i of the
@@ -219,7 +221,9 @@ MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_
 /* Test / tool switches of the per-op entry points: "mmq_planes" (1: mi355_op_mul_mat with T >= 32 expands the weight
  * into MFMA planes first, as a loaded model does; 0: expands on the fly inside the kernel), "mmq_tiles" (0 | 1 | 2
  * token tiles per wave), "mmq_ksplit" (1: 8 <= T <= 64 uses the K-split small-batch kernel, as the runtime does; 0: the
- * kernels the other T ranges use).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
+ * kernels the other T ranges use); and of contexts created afterwards: "decode_mega" (1: single-token steps of a dense
+ * K-quant model with Llama-3-8B's layer geometry run every layer in one launch; 0, the default: one launch per operation
+ * — both produce the same bits; the single launch measured slower).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
 MI355_API int mi355_debug_set_option(const char *name, int32_t value);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */

@@ -58,7 +58,9 @@ def rel_err(a, b):
                                           ("tiny-e2048:40", "q4_k_m", "q8_0"), ("tiny-d128:40", "q4_k_m", "q8_0"),
                                           ("tiny-gqa4:40", "q5_k_m", "f16"),
                                           # 8 x 128 KV heads: single-launch decode attention (rope + store + merge fused)
-                                          ("tiny-g8", "q4_k_m", "q8_0"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-g8:70", "q4_k_m", "q8_0")])
+                                          ("tiny-g8", "q4_k_m", "q8_0"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-g8:70", "q4_k_m", "q8_0"),
+                                          # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads)
+                                          ("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l:70", "q5_k_m", "f16")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)
@@ -146,6 +148,38 @@ def test_logits_do_not_depend_on_the_sequence_region(be, pkg, tmp_models, cfg, g
             assert np.array_equal(got, base), (seq, int(np.argmax(np.abs(got - base).max(axis=1) > 0)))
         else:   # 2 x 128 KV heads take the general split-by-length kernel: the split count follows the highest occupied cell
             assert rel_err(got, base) <= FLIP_TOL, (seq, rel_err(got, base))
+    m.close()
+
+
+@pytest.mark.parametrize("kv", ["q8_0", "f16"])
+@pytest.mark.parametrize("graphs", [True, False])
+def test_mega_step_matches_per_launch_bitwise(be, pkg, tmp_models, kv, graphs):
+    """The whole-step kernel (all layers of a single-token step in one launch, device-wide barriers between the phases)
+    runs the same arithmetic as the per-launch path: logits must agree bit for bit, step after step, with one sequence
+    and with sequence regions / chunk lists in use.  100 steps cross a 64-cell chunk boundary."""
+    path = make(pkg, tmp_models, "tiny-8b-2l", "q4_k_m")
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(9).integers(0, m.n_vocab, 40)
+
+    def run(mega, n_seq_max, seq):
+        be.set_option("decode_mega", 1 if mega else 0)
+        try:
+            c = pkg.Context(m, n_ctx=512, n_seq_max=n_seq_max, type_k=KV[kv], type_v=KV[kv], use_graphs=graphs)
+            assert c.decode(prompt, np.arange(40), seq=seq) == 0
+            rows = [c.logits().copy()]
+            for s in range(100):
+                assert c.decode([int(rows[-1].argmax())], [40 + s], seq=seq) == 0
+                rows.append(c.logits().copy())
+            assert c.mega_steps() == (100 if mega else 0)      # the path under test really ran
+            c.close()
+        finally:
+            be.set_option("decode_mega", 0)
+        return np.stack(rows)
+
+    for n_seq_max, seq in ((1, 0), (4, 2)):
+        a, b = run(True, n_seq_max, seq), run(False, n_seq_max, seq)
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (n_seq_max, int(np.argmax(np.abs(a - b).max(axis=1) > 0)))
     m.close()
 
 

@@ -23,3 +23,4 @@ for _ in range(n):
     assert ctx.decode([tok], [pos]) == 0
     tok = ctx.argmax(); pos += 1
 ctx.synchronize()
+ctx.close(); model.close()
