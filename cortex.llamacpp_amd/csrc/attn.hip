@@ -8,7 +8,10 @@
 // Cache layout in HBM is head-major per layer: plane[g][cell][...] so that one kv-head's cells are a
 // contiguous stream; quantised caches keep int8/int4 codes and f16 block scales in separate planes
 // (same values as ggml block_q8_0 / block_q4_0, regrouped for 16-byte aligned coalesced loads).
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "kernels.h"
 #include "quant_dev.h"
@@ -578,17 +581,55 @@ bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
     return a.T == 1 && flash_attn_decode_applicable(a, ra) && (R == 2 || R == 4 || R == 8) && (ra.n_rot % 4) == 0 && a.splits <= 64;
 }
+// diagnosis: MI355_ATTN_PROBE=1 makes the fused decode attention stamp its phases (DecodeFuse::probe); the stamps of the
+// LAST launch are summarised on stderr by attn_probe_report() (called when a context is destroyed)
+static unsigned long long *g_attn_probe = nullptr;
+static int g_attn_probe_G = 0, g_attn_probe_splits = 0;
+static unsigned long long *attn_probe_buffer() {
+    static const bool on = getenv("MI355_ATTN_PROBE") && getenv("MI355_ATTN_PROBE")[0] == '1';
+    if (on && !g_attn_probe && hipMalloc((void **)&g_attn_probe, (4096 + 64) * 8) == hipSuccess) (void)hipMemset(g_attn_probe, 0, (4096 + 64) * 8);
+    return g_attn_probe;
+}
+void attn_probe_report() {
+    if (!g_attn_probe || g_attn_probe_G <= 0) return;
+    std::vector<unsigned long long> t(4096 + 64);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(t.data(), g_attn_probe, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    const int n = std::min(2048, g_attn_probe_G * g_attn_probe_splits);
+    unsigned long long t0 = ~0ull, s_hi = 0, e_hi = 0;
+    double dur = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+        if (!t[2 * i] || !t[2 * i + 1]) continue;
+        t0 = std::min(t0, t[2 * i]); s_hi = std::max(s_hi, t[2 * i]); e_hi = std::max(e_hi, t[2 * i + 1]);
+        dur += (double)(t[2 * i + 1] - t[2 * i]) * 0.01; cnt++;
+    }
+    if (!cnt) return;
+    fprintf(stderr, "attn probe: %d workgroups, starts spread %.2f us, mean item %.2f us, last partial stored at %.2f us\n", cnt,
+            (double)(s_hi - t0) * 0.01, dur / cnt, (double)(e_hi - t0) * 0.01);
+    for (int g = 0; g < g_attn_probe_G && g < 8; g++) {
+        const unsigned long long *m = &t[4096 + 8 * g];
+        if (!m[0]) continue;
+        fprintf(stderr, "  head %d merge: ticket at %.2f us, weights +%.2f, sums +%.2f, stores +%.2f -> done at %.2f us\n", g, (double)(m[0] - t0) * 0.01,
+                (double)(m[1] - m[0]) * 0.01, (double)(m[2] - m[1]) * 0.01, (double)(m[3] - m[2]) * 0.01, (double)(m[3] - t0) * 0.01);
+    }
+}
+
 hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew,
                                           const int32_t *tok_cell, unsigned *counters, hipStream_t st) {
     const int R = a.H / a.G;
     const dim3 grid(a.G, a.splits, 1);
+    g_attn_probe_G = a.G; g_attn_probe_splits = a.splits;
     DecodeFuse fz{};
     fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters;
     if (a.out_q) fz.q = *a.out_q;
     fz.want_q8k = (int)(a.out_q && a.out_q8k); fz.want_q80 = (int)(a.out_q && a.out_q80);
-    // MI355_ATTN_COH=1: publish the chunk partials with write-through stores and a relaxed ticket instead of an agent-scope
-    // release / acquire per workgroup (whole-L2 write-back + invalidate)
-    static const bool coh = getenv("MI355_ATTN_COH") && getenv("MI355_ATTN_COH")[0] == '1';
+    fz.probe = attn_probe_buffer();
+    // The chunk partials are published with write-through stores and a relaxed ticket instead of an agent-scope release /
+    // acquire per workgroup: that pair is a write-back + invalidate of the whole L2, and hundreds of workgroups issuing it at
+    // once serialise (tools/bench_gridbar.hip: 25 us for 512).  Measured on the 8B step: 424 -> 448 tok/s at 4000 cells.
+    // MI355_ATTN_COH=0 restores the fenced form.
+    static const bool coh = !(getenv("MI355_ATTN_COH") && getenv("MI355_ATTN_COH")[0] == '0');
 #define FAD(RR, TK, TV) do { if (coh && counters) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); \
                              else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); } while (0)
 #define FAD_T(RR)                                                              \

@@ -22,6 +22,10 @@ struct DecodeFuse {
     unsigned *counters;            // [G], zero between launches
     ActQuant q;
     int want_q8k, want_q80;
+    // diagnosis (MI355_ATTN_PROBE=1): 100 MHz wall-clock stamps.  [2 * wg], [2 * wg + 1] = start / partials-stored of every
+    // workgroup (wg = sp * G + g); [4096 + 8 * g + k] = the merging workgroup of kv head g: ticket taken, weights done,
+    // partials summed, outputs stored
+    unsigned long long *probe;
 };
 
 // body of one (kv head g, chunk slot sp, token t) work item; 256 threads, every exit is workgroup-uniform
@@ -46,6 +50,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     __shared__ int last_flag;
     const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
     const int n_ctx = a.n_ctx, H = a.H;
+    if (FUSED && fz.probe && tid == 0) fz.probe[2 * (sp * a.G + g)] = wall_clock64();
     int chunk = sp;
     if (a.tok_chunks) {                                        // walk this token's chunk list only (sequences own cache regions)
         if (sp >= a.tok_nchunks[t]) return;
@@ -291,6 +296,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     }
     if (!FUSED) return;
     if (fz.counters == nullptr) return;               // store-fused only: the merge runs as its own launch
+    if (fz.probe && tid == 0) fz.probe[2 * (sp * a.G + g) + 1] = wall_clock64();
 
     // ---- FUSED: ticket; the last workgroup of this kv head merges
     const int stride_s = a.splits;                             // workspace stride; with a chunk list fewer slots are in use
@@ -308,8 +314,33 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     }
     __syncthreads();
     if (!last_flag) return;
+    if (fz.probe && tid == 0) fz.probe[4096 + 8 * g] = wall_clock64();
     float *wgt = S;                                    // [R][64] split weights (S is free now: R * C floats)
     float *merged = accs;                              // [R * D]
+    // The merge is a chain of memory round trips (~1.5 us each: the partials come from other XCDs).  Every output still
+    // sums its splits in order (the combine kernel's arithmetic), but the partials of the first 32 splits of all of this
+    // thread's outputs are requested BEFORE the (m, l) pairs, so the weight computation runs under them: ticket, one trip
+    // for (m, l) + 32 splits, one more per further 32 splits (it was ticket + (m, l) + one trip per 8 splits and output).
+    constexpr int NE = (R * D + 255) / 256, UB = 32;
+    float macc[NE], x[NE][UB];
+    const float *pp[NE];
+    int wr[NE];
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        const int e = tid + 256 * j < R * D ? tid + 256 * j : 0, r = e / D, d = e - r * D;
+        pp[j] = a.part + ((size_t)g * R + r) * stride_s * (D + 2) + d;
+        wr[j] = r * 64;
+        macc[j] = 0.0f;
+    }
+    auto request = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int s2 = s0 + u < splits ? s0 + u : splits - 1;              // clamped: straight-line loads
+#pragma unroll
+            for (int j = 0; j < NE; j++) x[j][u] = __hip_atomic_load(pp[j] + (size_t)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    request(0);
     for (int r = wave; r < R; r += 4) {                // same arithmetic as flash_attn_combine_kernel
         const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2);
         float m = -INFINITY, l = 0.0f;
@@ -324,17 +355,26 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         wgt[r * 64 + lane] = w * inv;
     }
     __syncthreads();
+    if (fz.probe && tid == 0) fz.probe[4096 + 8 * g + 1] = wall_clock64();
     const int E = H * D;
-    for (int e = tid; e < R * D; e += 256) {
-        const int r = e / D, d = e - r * D;
-        const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2) + d;
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int s2 = 0; s2 < splits; s2++)
-            acc += wgt[r * 64 + s2] * __hip_atomic_load(p + (size_t)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        merged[e] = acc;
-        a.out[(size_t)g * R * D + e] = acc;
+    for (int s0 = 0;;) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            if (s0 + u < splits) {                                             // workgroup-uniform
+#pragma unroll
+                for (int j = 0; j < NE; j++) macc[j] += wgt[wr[j] + s0 + u] * x[j][u];
+            }
+        }
+        s0 += UB;
+        if (s0 >= splits) break;
+        request(s0);
     }
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        const int e = tid + 256 * j;
+        if (e < R * D) { merged[e] = macc[j]; a.out[(size_t)g * R * D + e] = macc[j]; }
+    }
+    if (fz.probe && tid == 0) fz.probe[4096 + 8 * g + 2] = wall_clock64();
     __syncthreads();
     constexpr int NBLK = (R * D) >> 8;                 // 256-blocks this kv head owns in the H*D row
     if (wave < NBLK && (fz.want_q8k || fz.want_q80)) {
@@ -359,6 +399,10 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         }
     }
     (void)E;
+    if (fz.probe) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) fz.probe[4096 + 8 * g + 3] = wall_clock64();
+    }
 }
 
 template <int R, int TK, int TV, bool FUSED, bool COH = false>

@@ -173,6 +173,7 @@ hipError_t launch_decode_mega(const MegaLayer *layers_dev, int n_layer, int kb_e
     fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters;
     if (a.out_q) fz.q = *a.out_q;
     fz.want_q8k = (int)(a.out_q && a.out_q8k); fz.want_q80 = (int)(a.out_q && a.out_q80);
+    fz.probe = nullptr;
     // exactly two workgroups per CU: with more than a third of the CU's 160 KB of LDS each, a third cannot be placed, and
     // 2 x 256 CUs = the whole grid is resident.  (The attention item's static LDS comes on top of the dynamic part.)
     size_t lds = lds_mmvq < 36 * 1024 ? 36 * 1024 : lds_mmvq;

@@ -171,6 +171,7 @@ int flash_attn_decode_splits(int n_kv_max);
 hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st);
 // one launch per layer for a single-token step: KV store + attention + split merge + quantise (a.splits set by the caller)
 bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra);
+void attn_probe_report();   // MI355_ATTN_PROBE=1: phase timing of the last fused decode attention launch, on stderr
 hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew,
                                           const int32_t *tok_cell, unsigned *counters, hipStream_t st);
 

@@ -225,6 +225,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
 Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
 Context::~Context() {
+    attn_probe_report();
     if (d_mega_probe_) {                                       // diagnosis: where the last whole-step launch spent its time
         const int nl = model->hp.n_layer, np = 1 + MEGA_PROBES_PER_LAYER * nl;
         std::vector<unsigned long long> t((size_t)np);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Minimal decode loop for profilers: prompt 512 then N single-token steps on the bench model (no timing, no output)."""
+"""Minimal decode loop for profilers: prompt (default 512 tokens) then N single-token steps on the bench model.
+usage: decode_loop.py [steps] [prompt_tokens]"""
 import os
 import sys
 
@@ -11,14 +12,16 @@ import __graft_entry__ as ge  # noqa: E402
 pkg = ge.load_pkg()
 gs = pkg.gguf_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+n_prompt = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 path = "/tmp/mi355-bench-llama-3-8b-q4_k_m.gguf"
 if not os.path.exists(path):
     gs.write_synthetic_llama(path, gs.CONFIGS["llama-3-8b"], "q4_k_m", seed=0xC0FFEE, with_vocab=False)
 model = pkg.Model(path)
-ctx = pkg.Context(model, n_ctx=4096, n_batch=2048, n_ubatch=512, type_k=8, type_v=8, logits_to_host=False)
-prompt = np.random.default_rng(1234).integers(0, model.n_vocab, 512)
-assert ctx.decode(prompt, np.arange(512)) == 0
-tok, pos = ctx.argmax(), 512
+ctx = pkg.Context(model, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=8, type_v=8, logits_to_host=False)
+prompt = np.random.default_rng(1234).integers(0, model.n_vocab, n_prompt)
+for i0 in range(0, n_prompt, 2048):
+    assert ctx.decode(prompt[i0:i0 + 2048], np.arange(i0, min(n_prompt, i0 + 2048))) == 0
+tok, pos = ctx.argmax(), n_prompt
 for _ in range(n):
     assert ctx.decode([tok], [pos]) == 0
     tok = ctx.argmax(); pos += 1
