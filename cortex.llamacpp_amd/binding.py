@@ -112,7 +112,15 @@ SYMBOLS = {
     "mi355_engine_handle_embedding": (None, [_vp, _cp, ENGINE_CB, _vp]),
     "mi355_engine_is_supported": (_i32, [_vp, _cp]),
     "mi355_engine_stop_inferencing": (None, [_vp, _cp]),
+    "mi355_tp_unique_id": (C.c_int, [_vp, _sz]),
+    "mi355_tp_init": (C.c_int, [_i32, _i32, _i32, _vp, _sz]),
+    "mi355_tp_shutdown": (None, []),
+    "mi355_tp_rank": (_i32, []),
+    "mi355_tp_size": (_i32, []),
+    "mi355_tp_set_host_exchange": (C.c_int, [_vp, _vp, _i32, _i32]),
 }
+TP_HOST_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int32)
+TP_ID_BYTES = 128
 
 _lib = None
 
@@ -240,13 +248,77 @@ class Backend:
         return float(self.lib.mi355_bench_hbm_read(nbytes, iters))
 
 
+def gloo_exchange(group=None):
+    """The host exchange of mi355_tp_set_host_exchange over a torch.distributed (gloo) group: op 0 sums the buffer in
+    place over the ranks, op 1 gathers `n` floats per rank (the caller's part already at buf + rank * n)."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(_user, buf, n, op):
+        try:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            total = n if op == 0 else n * world
+            t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(total,)))
+            if op == 0:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                parts = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, t[rank * n:(rank + 1) * n].clone(), group=group)
+                for r in range(world):
+                    t[r * n:(r + 1) * n] = parts[r]
+            return 0
+        except Exception:   # noqa: BLE001 - a Python exception must not unwind through the C caller
+            import traceback
+            traceback.print_exc()
+            return 1
+    return fn
+
+
+_tp_keepalive = []
+
+
+def tp_init(rank: int, size: int, device: int = 0, transport: str = "rccl", group=None):
+    """Forms the process's row-split group (include/mi355_llama.h, mi355_tp_*).  transport "rccl": rank 0 makes the RCCL
+    id, torch.distributed (any backend) carries it to the others, every rank calls mi355_tp_init on its device.
+    transport "host": the exchange goes through gloo_exchange(group) (ranks sharing one GPU; validation only)."""
+    lib = load_library()
+    if transport == "host":
+        cb = TP_HOST_EXCHANGE(gloo_exchange(group))
+        _tp_keepalive.append(cb)
+        if lib.mi355_tp_set_host_exchange(C.cast(cb, C.c_void_p), None, rank, size) != 0:
+            raise MI355Error(f"mi355_tp_set_host_exchange failed: {_err(lib)}")
+        return
+    buf = (C.c_uint8 * TP_ID_BYTES)()
+    if size > 1:
+        import torch
+        import torch.distributed as dist
+        if rank == 0 and lib.mi355_tp_unique_id(buf, TP_ID_BYTES) != TP_ID_BYTES:
+            raise MI355Error(f"mi355_tp_unique_id failed: {_err(lib)}")
+        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+        t = t.to(dev)
+        dist.broadcast(t, src=0, group=group)
+        buf = (C.c_uint8 * TP_ID_BYTES)(*t.cpu().tolist())
+    elif lib.mi355_tp_unique_id(buf, TP_ID_BYTES) != TP_ID_BYTES:
+        raise MI355Error(f"mi355_tp_unique_id failed: {_err(lib)}")
+    if lib.mi355_tp_init(device, rank, size, buf, TP_ID_BYTES) != 0:
+        raise MI355Error(f"mi355_tp_init failed: {_err(lib)}")
+
+
+def tp_shutdown():
+    load_library().mi355_tp_shutdown()
+    _tp_keepalive.clear()
+
+
 class Model:
-    def __init__(self, path: str, n_gpu_layers: int = 300, main_gpu: int = 0, prefill_planes: int = -1):
+    def __init__(self, path: str, n_gpu_layers: int = 300, main_gpu: int = 0, prefill_planes: int = -1, tp_rank: int = 0, tp_size: int = 1):
         self.lib = load_library()
         mp = self.lib.mi355_model_default_params()
         mp.n_gpu_layers = n_gpu_layers
         mp.main_gpu = main_gpu
         mp.prefill_planes = prefill_planes
+        mp.tp_rank, mp.tp_size = tp_rank, tp_size
         self.h = self.lib.mi355_model_load_from_file(path.encode(), mp)
         if not self.h:
             raise MI355Error(f"mi355_model_load_from_file({path}) failed: {_err(self.lib)}")

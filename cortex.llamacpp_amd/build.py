@@ -14,10 +14,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [
     "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmq.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/attn.hip", "csrc/attn_prefill.hip", "csrc/decode_mega.hip",
-    "host/gguf.cc", "host/runtime.cc", "host/vocab.cc", "host/sampling.cc", "host/server_context.cc", "host/engine.cc",
+    "host/gguf.cc", "host/runtime.cc", "host/tp_comm.cc", "host/vocab.cc", "host/sampling.cc", "host/server_context.cc", "host/engine.cc",
     "host/hip_backend.cc", "csrc/c_api.cc",
 ]
-HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "csrc/mmvq_fast_dev.h", "csrc/attn_decode_dev.h", "host/gguf.h", "host/runtime.h", "host/json.h", "host/vocab.h",
+HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "csrc/mmvq_fast_dev.h", "csrc/attn_decode_dev.h", "host/gguf.h", "host/runtime.h", "host/tp_comm.h", "host/json.h", "host/vocab.h",
         "host/sampling.h", "host/backend_iface.h", "host/server_context.h", "host/engine.h", "host/hip_backend.h",
         "../include/mi355_llama.h"]
 LIB = os.path.join(HERE, "lib", "libmi355_llama.so")
@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(warn)
     objs = [os.path.join(objdir, s.replace("/", "_") + ".o") for s in SRC]
     if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-pthread", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-pthread", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

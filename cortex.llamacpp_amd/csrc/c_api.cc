@@ -11,6 +11,7 @@
 #include "../host/engine.h"
 #include "../host/hip_backend.h"
 #include "../host/runtime.h"
+#include "../host/tp_comm.h"
 #include "../host/vocab.h"
 
 namespace mi355 {
@@ -85,10 +86,13 @@ mi355_model *mi355_model_load_from_file(const char *path, mi355_model_params par
     if (!path) { fail("null path"); return nullptr; }
     if (!g_backend_ok && mi355_backend_init() != MI355_OK) return nullptr;
     if (params.n_gpu_layers <= 0) { fail("ngl=0 requested: this backend is device-only (no CPU path)"); return nullptr; }
-    if (params.tp_size > 1) { fail("tp_size > 1 is not available in this build"); return nullptr; }
+    if (params.tp_size > 1 && (tp_size() != params.tp_size || tp_rank() != params.tp_rank)) {
+        fail("tp_size > 1 needs the process's row-split group first (mi355_tp_init with the same rank / size)");
+        return nullptr;
+    }
     std::string err;
     int status = 0;
-    Model *m = model_load(path, params.main_gpu, err, status, params.prefill_planes);
+    Model *m = model_load(path, params.main_gpu, err, status, params.prefill_planes, params.tp_rank, params.tp_size);
     if (!m) { fail(err); return nullptr; }
     mi355_model *h = new mi355_model;
     h->m = m;
@@ -474,6 +478,30 @@ int mi355_debug_set_option(const char *name, int32_t value) {
 }
 
 // simple read-bandwidth probe: sum-reduce `bytes` of device memory
+// ---------------------------------------------------------------- row split group
+int mi355_tp_unique_id(void *id_out, size_t cap) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    std::string err;
+    const int n = tp_unique_id(id_out, cap, err);
+    if (n < 0) { fail(err); return MI355_ERR_ARG; }
+    return n;
+}
+int mi355_tp_init(int32_t device, int32_t rank, int32_t size, const void *id, size_t id_len) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return MI355_ERR_ARG; }
+    std::string err;
+    if (tp_init(rank, size, id, id_len, err) != 0) { fail(err); return MI355_ERR_ARG; }
+    return MI355_OK;
+}
+void mi355_tp_shutdown(void) { tp_shutdown(); }
+int32_t mi355_tp_rank(void) { return tp_rank(); }
+int32_t mi355_tp_size(void) { return tp_size(); }
+int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t rank, int32_t size) {
+    if (fn && (size < 1 || rank < 0 || rank >= size)) { fail("bad rank / size"); return MI355_ERR_ARG; }
+    tp_set_host_exchange(reinterpret_cast<tp_host_exchange_fn>(fn), user, rank, size);
+    return MI355_OK;
+}
+
 double mi355_bench_hbm_read(size_t bytes, int iters) {
     if (!need_device()) return -1.0;
     return hbm_read_probe(bytes, iters);

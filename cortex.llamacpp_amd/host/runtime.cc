@@ -2,6 +2,7 @@
 // (op order of upstream llm_build_llama / build_attn / build_ffn / build_moe_ffn).
 // Reference caller: LlamaServerContext::UpdateSlots -> llama_decode (src/llama_server_context.cc:1628-1635).
 #include "runtime.h"
+#include "tp_comm.h"
 
 #include <algorithm>
 #include <cmath>
@@ -40,7 +41,7 @@ static bool type_supported(int t) {
     return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K;
 }
 
-Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes) {
+Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes, int tp_rank, int tp_size) {
     status = 0;
     std::unique_ptr<Model> m(new Model());
     m->file.reset(new GGUFFile());
@@ -70,16 +71,34 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     if (scaling == "linear") hp.rope_scale = 1.0f / (float)f.get_f(a + "rope.scaling.factor", 1.0);
     if (hp.head_dim != 64 && hp.head_dim != 128) { err = "unsupported head_dim " + std::to_string(hp.head_dim); status = -102; return nullptr; }
     if (hp.n_embd % 256) { err = "n_embd must be a multiple of 256"; status = -102; return nullptr; }
+    // ---- row split: this rank's share of the heads and of the feed-forward width
+    const int P = tp_size > 1 ? tp_size : 1, R = tp_size > 1 ? tp_rank : 0;
+    hp.n_head_full = hp.n_head; hp.n_head_kv_full = hp.n_head_kv; hp.n_ff_full = hp.n_ff;
+    hp.tp_rank = R; hp.tp_size = P;
+    // the exchange steps run whenever the process has a group of that size — also a group of ONE rank, which is how the
+    // RCCL calls (and their capture into graphs) are exercised on a single GPU
+    hp.tp_exchange = tp_active() && mi355::tp_size() == P && mi355::tp_rank() == R;
+    if (P > 1 && !hp.tp_exchange) { err = "tp_size > 1 needs the process's row-split group first (mi355_tp_init with the same rank / size)"; status = -102; return nullptr; }
+    if (P > 1) {
+        if (R < 0 || R >= P) { err = "tp_rank out of range"; status = -102; return nullptr; }
+        if (hp.n_expert > 0) { err = "row split of mixture-of-experts files is not supported"; status = -102; return nullptr; }
+        if (hp.n_head % P || hp.n_head_kv % P) { err = "tp_size must divide the head counts (" + std::to_string(hp.n_head) + " / " + std::to_string(hp.n_head_kv) + ")"; status = -102; return nullptr; }
+        if (((hp.n_head / P) * hp.head_dim) % 256) { err = "a rank's attention width must be a multiple of 256"; status = -102; return nullptr; }
+        hp.n_head /= P; hp.n_head_kv /= P;
+    }
 
     if (hipSetDevice(main_gpu) != hipSuccess) { err = "hipSetDevice failed"; status = -100; return nullptr; }
     m->device = main_gpu;
 
     // plan the arena
-    struct Plan { const GGUFTensorInfo *ti; DevTensor *dst; size_t off; };
+    // where a tensor's bytes come from: the whole tensor, or this rank's rows (a contiguous range), or this rank's
+    // columns (the same block range of every row: a strided copy)
+    enum { SPLIT_NONE = 0, SPLIT_ROWS = 1, SPLIT_COLS = 2 };
+    struct Plan { const GGUFTensorInfo *ti; DevTensor *dst; size_t off; size_t src_off, src_pitch, src_width; int64_t src_rows; size_t src_bytes; };
     std::vector<Plan> plan;
     size_t total = 0, max_stage = 0;
     bool fail = false;
-    auto want = [&](const std::string &name, DevTensor &dst, bool required) {
+    auto want = [&](const std::string &name, DevTensor &dst, bool required, int split = SPLIT_NONE) {
         const GGUFTensorInfo *ti = f.tensor(name);
         if (!ti) {
             if (required) { err = "missing tensor " + name; fail = true; }
@@ -96,30 +115,51 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         dst.N = ti->ne[1];
         dst.n_expert = ti->ne[2];
         if (ggml_block_elems(dst.type) > 1 && dst.K % ggml_block_elems(dst.type)) { err = "tensor " + name + ": row length not a block multiple"; fail = true; return; }
+        const size_t full_row = ggml_row_bytes(dst.type, dst.K);
+        Plan pl{ti, &dst, total, 0, full_row, full_row, ti->n_dims == 1 ? 1 : dst.N * dst.n_expert, (size_t)ti->bytes};
+        if (P > 1 && split != SPLIT_NONE) {
+            const int64_t blk = std::max<int64_t>(ggml_block_elems(dst.type), 1);
+            if (ti->n_dims == 1 || split == SPLIT_COLS) {          // a bias vector is cut like the rows it is added to
+                const int64_t unit = split == SPLIT_COLS && blk > 1 ? std::max<int64_t>(blk, 256) : blk;
+                if (dst.K % P || (dst.K / P) % unit) { err = "tensor " + name + ": row length " + std::to_string(dst.K) + " cannot be cut " + std::to_string(P) + " ways on block boundaries"; fail = true; return; }
+                dst.K /= P;
+                pl.src_width = ggml_row_bytes(dst.type, dst.K);
+                pl.src_off = (size_t)R * pl.src_width;
+            } else {
+                if (dst.N % P) { err = "tensor " + name + ": " + std::to_string(dst.N) + " rows cannot be cut " + std::to_string(P) + " ways"; fail = true; return; }
+                dst.N /= P;
+                pl.src_rows = dst.N;
+                pl.src_off = (size_t)R * (size_t)dst.N * full_row;
+            }
+            pl.src_bytes = pl.src_width * (size_t)pl.src_rows;
+        }
         dst.row_bytes = ti->n_dims == 1 ? ggml_row_bytes(dst.type, dst.K) : dev_row_bytes(dst.type, dst.K);
         const int64_t rows = ti->n_dims == 1 ? 1 : dst.N * dst.n_expert;
         dst.bytes = dst.row_bytes * (size_t)rows;
-        dst.ggml_bytes = ti->bytes;
-        plan.push_back({ti, &dst, total});
+        dst.ggml_bytes = pl.src_bytes;
+        plan.push_back(pl);
         total += (dst.bytes + 255) & ~(size_t)255;
-        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, ti->bytes);
+        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, pl.src_bytes);
     };
     want("token_embd.weight", m->tok_embd, true);
     want("output_norm.weight", m->out_norm, true);
-    want("output.weight", m->output, false);
+    {   // the output projection is cut by vocabulary rows when they divide evenly (logits are gathered), else every rank keeps it whole
+        const GGUFTensorInfo *ot = f.tensor("output.weight");
+        want("output.weight", m->output, false, ot && ot->ne[1] % P == 0 ? SPLIT_ROWS : SPLIT_NONE);
+    }
     want("rope_freqs.weight", m->rope_freqs, false);
     m->layers.resize((size_t)hp.n_layer);
     for (int il = 0; il < hp.n_layer && !fail; il++) {
         LayerWeights &L = m->layers[(size_t)il];
         const std::string p = "blk." + std::to_string(il) + ".";
         want(p + "attn_norm.weight", L.attn_norm, true);
-        want(p + "attn_q.weight", L.wq, true);
-        want(p + "attn_k.weight", L.wk, true);
-        want(p + "attn_v.weight", L.wv, true);
-        want(p + "attn_output.weight", L.wo, true);
-        want(p + "attn_q.bias", L.bq, false);
-        want(p + "attn_k.bias", L.bk, false);
-        want(p + "attn_v.bias", L.bv, false);
+        want(p + "attn_q.weight", L.wq, true, SPLIT_ROWS);
+        want(p + "attn_k.weight", L.wk, true, SPLIT_ROWS);
+        want(p + "attn_v.weight", L.wv, true, SPLIT_ROWS);
+        want(p + "attn_output.weight", L.wo, true, SPLIT_COLS);
+        want(p + "attn_q.bias", L.bq, false, SPLIT_ROWS);
+        want(p + "attn_k.bias", L.bk, false, SPLIT_ROWS);
+        want(p + "attn_v.bias", L.bv, false, SPLIT_ROWS);
         want(p + "ffn_norm.weight", L.ffn_norm, true);
         if (hp.n_expert > 0) {
             want(p + "ffn_gate_inp.weight", L.gate_inp, true);
@@ -127,14 +167,16 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
             want(p + "ffn_up_exps.weight", L.up_exps, true);
             want(p + "ffn_down_exps.weight", L.down_exps, true);
         } else {
-            want(p + "ffn_gate.weight", L.gate, true);
-            want(p + "ffn_up.weight", L.up, true);
-            want(p + "ffn_down.weight", L.down, true);
+            want(p + "ffn_gate.weight", L.gate, true, SPLIT_ROWS);
+            want(p + "ffn_up.weight", L.up, true, SPLIT_ROWS);
+            want(p + "ffn_down.weight", L.down, true, SPLIT_COLS);
         }
     }
     if (fail) { status = -102; return nullptr; }
     hp.n_vocab = (int)m->tok_embd.N;
-    if (!hp.n_ff) hp.n_ff = (int)(hp.n_expert ? m->layers[0].gate_exps.N : m->layers[0].gate.N);
+    hp.n_ff = (int)(hp.n_expert ? m->layers[0].gate_exps.N : m->layers[0].gate.N);     // this rank's width under a row split
+    if (!hp.n_ff_full) hp.n_ff_full = hp.n_ff * P;
+    hp.n_vocab_local = !m->output.name.empty() ? (int)m->output.N : hp.n_vocab;      // (planned, not uploaded yet)
 
     uint8_t *arena = nullptr, *stage = nullptr;
     if (hipMalloc(&arena, total) != hipSuccess) { err = "hipMalloc of " + std::to_string(total) + " weight bytes failed"; status = -104; return nullptr; }
@@ -147,12 +189,11 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         d.data = arena + pl.off;
         const bool direct = !(d.type == T_Q6_K || d.type == T_Q8_0) && (pl.ti->n_dims == 1 || d.row_bytes == ggml_row_bytes(d.type, d.K));
         hipError_t e;
-        if (direct) {
-            e = hipMemcpyAsync(d.data, pl.ti->data, pl.ti->bytes, hipMemcpyHostToDevice, st);
-        } else {
-            e = hipMemcpyAsync(stage, pl.ti->data, pl.ti->bytes, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = launch_repack_rows(d.type, stage, d.data, d.K, d.N * d.n_expert, st);
-        }
+        const uint8_t *src = (const uint8_t *)pl.ti->data + pl.src_off;
+        uint8_t *to = direct ? d.data : stage;
+        if (pl.src_width == pl.src_pitch) e = hipMemcpyAsync(to, src, pl.src_bytes, hipMemcpyHostToDevice, st);
+        else e = hipMemcpy2DAsync(to, pl.src_width, src, pl.src_pitch, pl.src_width, (size_t)pl.src_rows, hipMemcpyHostToDevice, st);
+        if (!direct && e == hipSuccess) e = launch_repack_rows(d.type, stage, d.data, d.K, d.N * d.n_expert, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             err = std::string("upload of ") + d.name + " failed: " + hipGetErrorString(e);
@@ -161,7 +202,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
             (void)hipStreamDestroy(st);
             return nullptr;
         }
-        m->file_tensor_bytes += pl.ti->bytes;
+        m->file_tensor_bytes += pl.src_bytes;
     }
     if (stage) (void)hipFree(stage);
     (void)hipStreamDestroy(st);
@@ -207,7 +248,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     uint64_t bpt = 0;
     for (const Plan &pl : plan) {
         const DevTensor &d = *pl.dst;
-        uint64_t b = pl.ti->bytes;
+        uint64_t b = pl.src_bytes;
         if (&d == &m->tok_embd) b = ggml_row_bytes(d.type, d.K);
         else if (d.n_expert > 1 && hp.n_expert_used > 0) b = b / (uint64_t)d.n_expert * (uint64_t)hp.n_expert_used;
         bpt += b;
@@ -342,6 +383,11 @@ bool Context::init(std::string &err) {
     ffn_ = (float *)dalloc(T * FF * 4);
     ffn_u_ = (float *)dalloc(T * FF * 4);
     xo_ = (float *)dalloc(T * E * 4);
+    if (hp.tp_exchange) {
+        if (!tp_active() || tp_size() != hp.tp_size || tp_rank() != hp.tp_rank) { err = "model was loaded as rank " + std::to_string(hp.tp_rank) + " of " + std::to_string(hp.tp_size) + " but the process has no matching row-split group (mi355_tp_init)"; return false; }
+        tp_part_ = (float *)dalloc(T * E * 4);
+        if (tp_uses_host()) cp.use_graphs = false;     // the host transport drains the stream inside the step
+    }
     if (hp.n_expert > 0) {
         router_ = (float *)dalloc(T * hp.n_expert * 4);
         moe_ids_ = (int32_t *)dalloc(T * hp.n_expert_used * 4);
@@ -741,6 +787,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         return launch_decode_mega(d_mega_layers_, hp.n_layer, (E + 2047) >> 11, (FF + 2047) >> 11, ma, rope_cs_, ra.n_rot, k_, v_, d_cell_,
                                   att_counters_, d_mega_sync_, h_mega_flag_, d_mega_probe_, mega_lds_, stream_);
 
+    const bool tp = hp.tp_exchange;
     for (int il = 0; il < hp.n_layer; il++) {
         const LayerWeights &L = model->layers[(size_t)il];
         // --- attention block
@@ -759,7 +806,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
         pending_fuse_ = Fuse();
         for (int t = 0; t < T; t++) {   // biases are rare on this architecture (one tiny launch per token when present)
-            if (L.bq.valid()) HIP_TRY(launch_add(q_ + (size_t)t * E, (const float *)L.bq.data, q_ + (size_t)t * E, (int64_t)E, stream_));
+            if (L.bq.valid()) HIP_TRY(launch_add(q_ + (size_t)t * H * D, (const float *)L.bq.data, q_ + (size_t)t * H * D, (int64_t)H * D, stream_));
             if (L.bk.valid()) HIP_TRY(launch_add(k_ + (size_t)t * G * D, (const float *)L.bk.data, k_ + (size_t)t * G * D, (int64_t)G * D, stream_));
             if (L.bv.valid()) HIP_TRY(launch_add(v_ + (size_t)t * G * D, (const float *)L.bv.data, v_ + (size_t)t * G * D, (int64_t)G * D, stream_));
         }
@@ -794,7 +841,12 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_flash_attn(aa, stream_));
         }
         prof_mark("attn");
-        HIP_TRY(linear(L.wo, aq_o_, att_, E, T, x_, E, x_, EPI_ADD));
+        if (tp) {   // this rank's partial sum (rank 0 carries the residual), then the exchange: x = sum over ranks
+            HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, T, tp_part_, E, hp.tp_rank == 0 ? x_ : nullptr, hp.tp_rank == 0 ? EPI_ADD : EPI_STORE));
+            HIP_TRY(tp_reduce_into_x(T));
+        } else {
+            HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, T, x_, E, x_, EPI_ADD));
+        }
         prof_mark("attn_out");
 
         // --- feed-forward block
@@ -872,13 +924,23 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
                 prof_mark("quant");
             }
-            HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, T, x_, E, x_, EPI_ADD));
+            if (tp) {
+                HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, T, tp_part_, E, hp.tp_rank == 0 ? x_ : nullptr, hp.tp_rank == 0 ? EPI_ADD : EPI_STORE));
+                pending_fuse_ = Fuse();
+                HIP_TRY(tp_reduce_into_x(T));
+            } else {
+                HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, T, x_, E, x_, EPI_ADD));
+            }
             pending_fuse_ = Fuse();
             prof_mark("ffn_down");
         }
         if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
     }
     return hipSuccess;
+}
+
+hipError_t Context::tp_reduce_into_x(int T) {
+    return tp_all_reduce_sum(tp_part_, x_, (size_t)T * model->hp.n_embd, stream_);
 }
 
 hipError_t Context::run_output(int n_out, int out_base) {
@@ -901,7 +963,28 @@ hipError_t Context::run_output(int n_out, int out_base) {
         prof_mark("norm_quant");
     }
     float *lg = d_logits_ + (size_t)out_base * V;
-    HIP_TRY(linear(model->output, aq_e_, xn_, E, n_out, lg, V, nullptr, EPI_STORE));
+    const int VL = hp.n_vocab_local, P = hp.tp_size;
+    if (hp.tp_exchange && VL * P == V) {
+        // vocabulary rows are cut across the ranks: each computes its slice of every flagged row, the slices are gathered
+        // rank-major and copied into place (for a single row the gathered buffer already is the logits row)
+        if (n_out > 1 && (size_t)n_out > tp_logits_rows_) {      // (never inside a capture: graphs carry single-row steps only)
+            HIP_TRY(hipStreamSynchronize(stream_));
+            tp_logits_ = (float *)dalloc((size_t)n_out * V * 4);
+            if (!tp_logits_) return hipErrorOutOfMemory;
+            tp_logits_rows_ = (size_t)n_out;
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        float *gathered = n_out == 1 ? lg : tp_logits_;
+        float *part = gathered + (size_t)hp.tp_rank * n_out * VL;
+        HIP_TRY(linear(model->output, aq_e_, xn_, E, n_out, part, VL, nullptr, EPI_STORE));
+        pending_fuse_ = Fuse();
+        HIP_TRY(tp_all_gather(part, gathered, (size_t)n_out * VL, stream_));
+        for (int r = 0; r < P && n_out > 1; r++)
+            HIP_TRY(hipMemcpy2DAsync(lg + (size_t)r * VL, (size_t)V * 4, tp_logits_ + (size_t)r * n_out * VL, (size_t)VL * 4, (size_t)VL * 4, (size_t)n_out,
+                                     hipMemcpyDeviceToDevice, stream_));
+    } else {
+        HIP_TRY(linear(model->output, aq_e_, xn_, E, n_out, lg, V, nullptr, EPI_STORE));
+    }
     pending_fuse_ = Fuse();
     prof_mark("lm_head");
     for (int r0 = 0; r0 < n_out; r0 += (int)cp.n_ubatch) {
@@ -1160,7 +1243,7 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
             const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
             float *outs[3] = {q_, k_, v_};
             HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
-            HIP_TRY(linear(L.wo, aq_o_, att_, E, 1, xo_, E, nullptr, EPI_STORE));
+            HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, nullptr, EPI_STORE));
             if (is_quant(L.gate.type) && L.gate.type == L.up.type) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 HIP_TRY(mmvq_tokens(segs, 2, E, 1, EPI_SWIGLU, aq_e_, stream_));
@@ -1168,7 +1251,7 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
             HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, nullptr, EPI_STORE));
             if (count) bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + L.wo.ggml_bytes + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
         }
-        HIP_TRY(linear(model->output, aq_e_, xn_, E, 1, d_logits_, hp.n_vocab, nullptr, EPI_STORE));
+        HIP_TRY(linear(model->output, aq_e_, xn_, E, 1, d_logits_, (int)model->output.N, nullptr, EPI_STORE));
         if (count) bytes += model->output.ggml_bytes;
         return hipSuccess;
     };

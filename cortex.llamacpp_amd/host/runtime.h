@@ -45,6 +45,13 @@ struct HParams {
     int n_expert = 0, n_expert_used = 0, head_dim = 0, n_ctx_train = 0;
     float eps = 1e-5f, rope_base = 10000.0f, rope_scale = 1.0f;
     int rope_neox = 0;
+    // row split: n_head, n_head_kv and n_ff above are THIS RANK's share; the file's values are kept here.
+    // A shard is the same graph with fewer heads and a narrower feed-forward, attn_output and ffn_down contracting over
+    // the local slice only: their partial sums are the one thing exchanged (tp_comm.h).
+    int tp_rank = 0, tp_size = 1;
+    bool tp_exchange = false;    // the process has a matching group: partial sums and logits slices go through it
+    int n_head_full = 0, n_head_kv_full = 0, n_ff_full = 0;
+    int n_vocab_local = 0;       // rows of the output projection held here (n_vocab when it is not split)
 };
 
 struct Model {
@@ -60,7 +67,9 @@ struct Model {
 };
 
 // prefill_planes: 0 = never, 1 = always (fails when memory is short), -1 = when device memory allows (default)
-Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes = -1);
+// tp_size > 1: load rank tp_rank's slice of every projection (rows of attn_q/k/v, ffn_gate/up and output; the matching
+// super-block columns of attn_output and ffn_down), cut on head and 256-element boundaries
+Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes = -1, int tp_rank = 0, int tp_size = 1);
 
 struct KVCell {
     int32_t pos = -1;
@@ -162,6 +171,9 @@ class Context {
     // activations
     float *x_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *ffn_ = nullptr, *ffn_u_ = nullptr;
     float *xo_ = nullptr, *router_ = nullptr, *moe_out_ = nullptr;
+    float *tp_part_ = nullptr, *tp_logits_ = nullptr;   // row split: this rank's partial sums / logits slices before the exchange
+    size_t tp_logits_rows_ = 0;
+    hipError_t tp_reduce_into_x(int T);                 // x_ = sum over ranks of tp_part_
     int32_t *moe_ids_ = nullptr;
     float *moe_w_ = nullptr;
     ActQuant aq_e_, aq_ff_, aq_o_;

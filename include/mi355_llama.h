@@ -65,7 +65,7 @@ typedef struct mi355_model_params {
     int32_t main_gpu;       /* HIP device ordinal */
     int32_t use_mmap;       /* `use_mmap` (llama_engine.cc:649) */
     int32_t use_mlock;      /* `mlock` (llama_engine.cc:569-571); accepted, ignored */
-    /* row-split tensor parallelism over RCCL (new keys proposed in SURVEY.md §2b) */
+    /* row split over RCCL (see mi355_tp_init below; new keys proposed in SURVEY.md §2b) */
     int32_t tp_rank;        /* 0 when tp_size <= 1 */
     int32_t tp_size;        /* 1 = whole model on this GPU */
     /* prompt-processing copy of the projection weights as pre-expanded int8 MFMA operand planes (2 B / weight):
@@ -225,6 +225,26 @@ MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_
  * K-quant model with Llama-3-8B's layer geometry run every layer in one launch; 0, the default: one launch per operation
  * — both produce the same bits; the single launch measured slower).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
 MI355_API int mi355_debug_set_option(const char *name, int32_t value);
+
+/* ------------------------------------------------------------------ row split across GPUs (one process per GPU)
+ * Not in the reference: cortex.llamacpp never sets llama.cpp's split_mode / tensor_split (llama_engine.cc:553-658
+ * writes no such field), so every visible GPU gets whole layers.  Here a model loaded with tp_size > 1 holds rank tp_rank's
+ * rows of attn_q/k/v, ffn_gate/up and output and the matching columns of attn_output / ffn_down; the partial sums of those
+ * two are summed across the ranks (RCCL all-reduce over xGMI on the context's stream, inside its graphs), the logits slices
+ * are gathered.  Every rank must issue the same mi355_decode calls.  Order: mi355_tp_unique_id on rank 0 -> hand the 128
+ * bytes to the other ranks (any side channel) -> mi355_tp_init on every rank (after selecting its device with
+ * main_gpu / HIP_VISIBLE_DEVICES) -> mi355_model_load_from_file with the same tp_rank / tp_size. */
+#define MI355_TP_ID_BYTES 128
+MI355_API int mi355_tp_unique_id(void *id_out, size_t cap);                         /* returns bytes written or < 0 */
+MI355_API int mi355_tp_init(int32_t device, int32_t rank, int32_t size, const void *id, size_t id_len);
+MI355_API void mi355_tp_shutdown(void);
+MI355_API int32_t mi355_tp_rank(void);
+MI355_API int32_t mi355_tp_size(void);
+/* Validation transport for boxes where the ranks share one GPU (RCCL refuses that): the exchange goes through this
+ * host callback instead (op 0: sum `n` floats in place over the ranks; op 1: all-gather, `n` floats per rank, the caller's
+ * part already at buf + rank * n).  Graphs are off while it is set.  fn == NULL removes it. */
+typedef int (*mi355_tp_host_exchange)(void *user, float *buf, size_t n, int32_t op);
+MI355_API int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t rank, int32_t size);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* Streams `bytes` through a read-only reduction kernel `iters` times; returns achieved GB/s (HIP events). */
