@@ -10,6 +10,10 @@ row made host-visible, i.e. one pass of the hot path; the prompt is prefilled (a
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a full replica and decodes its own
 sequence; no data-path collective (weak scaling, "replicas").  value = N*K tokens / max-over-ranks time.
+The same launch then measures the ROW SPLIT of the same model over the N GPUs (one sequence, every rank
+holds 1/N of each projection, two RCCL all-reduces per layer inside the decode graph) and reports it next to the
+replicas number as `row_split` (single-stream tok/s: what one request sees; strong scaling).  That section is fenced
+by a watchdog so that a communication problem cannot take the headline line with it.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -34,6 +38,59 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MIC
 def aggregate(n_gpus: int, steps: int, dt_max: float) -> dict:
     """Whole-job numbers from the slowest rank's wall time: every rank decoded `steps` tokens of its own sequence."""
     return {"value": round(n_gpus * steps / dt_max, 2), "ms_per_step": round(dt_max / steps * 1e3, 4)}
+
+
+def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch) -> dict:
+    """Row split of the bench model over the ranks of this launch: the same prompt on every rank (they execute one
+    sequence together), prefill, warm-up, K timed single-token steps bracketed by barriers, MAX over ranks."""
+    pkg.binding.tp_init(rank, world, device=local_rank, transport="rccl")
+    model = pkg.Model(path, main_gpu=local_rank, tp_rank=rank, tp_size=world)
+    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
+    prompt = np.random.default_rng(1234).integers(0, model.n_vocab, args.prompt)
+
+    def prefill():
+        ctx.kv_clear()
+        t = time.perf_counter()
+        for i0 in range(0, args.prompt, 2048):
+            chunk = prompt[i0:i0 + 2048]
+            assert ctx.decode(chunk, np.arange(i0, i0 + chunk.size)) == 0
+        tok = ctx.argmax()                                 # first sampled token: end of the reference's prompt time
+        return time.perf_counter() - t, tok
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    prefill()
+    sync_all()
+    t_prefill, tok = prefill()
+    pos = args.prompt
+    for _ in range(args.warmup):
+        assert ctx.decode([tok], [pos]) == 0
+        ctx.logits_ready(); tok = ctx.argmax(); pos += 1
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert ctx.decode([tok], [pos]) == 0
+        ctx.logits_ready(); tok = ctx.argmax(); pos += 1
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    sync_all()
+    tt = torch.tensor([dt, t_prefill], dtype=torch.float64, device=f"cuda:{local_rank}")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, t_prefill = float(tt[0].item()), float(tt[1].item())
+    toks = torch.tensor([tok], dtype=torch.int64, device=f"cuda:{local_rank}")
+    lo, hi = toks.clone(), toks.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    res = {"parallelism": f"row split over {world} GPUs (RCCL all-reduce of attn_output / ffn_down partial sums, logits gathered)",
+           "scaling": "strong", "decode_tok_s": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "prefill_tok_s": round(args.prompt / t_prefill, 1), "weight_bytes_per_token_per_gpu": int(model.bytes_per_token),
+           "ranks_agree_on_last_token": bool(int(lo.item()) == int(hi.item()))}
+    ctx.close(); model.close()
+    pkg.binding.tp_shutdown()
+    return res
 
 
 def simulate(args) -> int:
@@ -87,6 +144,8 @@ def main() -> int:
     ap.add_argument("--model-dir", default=os.environ.get("MI355_BENCH_DIR", "/tmp"))
     ap.add_argument("--keep-model", action="store_true")
     ap.add_argument("--no-long-context", action="store_true", help="skip the context-filled-to-3968 measurement")
+    ap.add_argument("--no-row-split", action="store_true", help="N > 1: skip the row-split measurement after the replicas one")
+    ap.add_argument("--row-split-timeout", type=float, default=240.0, help="seconds the row-split section may take before it is abandoned")
     ap.add_argument("--simulate", action="store_true",
                     help="no GPU: the same rank bookkeeping (rendezvous over gloo, barriers, MAX over ranks, rank-0 JSON) around a "
                          "sleep standing in for the decode step; used by the two-rank CPU test")
@@ -100,7 +159,8 @@ def main() -> int:
     n_gpus = args.gpus
     dist = None
     torch = None
-    if world > 1:
+    # MI355_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, row-split section) with one rank
+    if world > 1 or os.environ.get("MI355_BENCH_FORCE_DIST") == "1":
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -176,11 +236,40 @@ def main() -> int:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    if rank != 0:
-        ctx.close(); model.close()
+    def finish_rank(out):
+        """Everything after the replicas measurement that involves all ranks: the row-split section (fenced), then the line."""
+        if dist is not None and not args.no_row_split:
+            import threading
+
+            def give_up():                                 # a rank stuck in a collective cannot be recovered in-process
+                if rank == 0 and out is not None:
+                    out["row_split"] = {"error": f"abandoned after {args.row_split_timeout:.0f} s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            wd = threading.Timer(args.row_split_timeout, give_up)
+            wd.daemon = True
+            wd.start()
+            try:
+                rs = row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch)
+            except Exception as e:  # noqa: BLE001 - reported in the line; the other ranks run into the watchdog
+                rs = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if rank == 0 and out is not None:
+                out["row_split"] = rs
+                print(json.dumps(out), flush=True)
+            if "error" in rs:                              # peers may be stuck: do not enter another collective
+                os._exit(0)
+            wd.cancel()
+        elif rank == 0 and out is not None:
+            print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+
+    if rank != 0:
+        ctx.close(); model.close()
+        if dist is not None:
+            dist.barrier()                                 # rank 0 finishes its single-GPU extras first
+        finish_rank(None)
         return 0
 
     # ---- device-greedy variant (SURVEY §8f.1): logits stay on the device, only the argmax crosses
@@ -336,15 +425,14 @@ def main() -> int:
         out["cpu_baseline"] = None
 
     ctx.close(); model.close()
+    if dist is not None:
+        dist.barrier()                                     # releases the other ranks into the row-split section
+    finish_rank(out)
     if not args.keep_model and world == 1 and os.environ.get("MI355_BENCH_KEEP") is None:
         try:
             os.remove(path)
         except OSError:
             pass
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 
