@@ -116,6 +116,17 @@ hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int
 hipError_t launch_moe_combine(float *x, const float *eo, const float *w, int T, int E, int k, size_t eo_stride, hipStream_t st);
 hipError_t launch_gather_rows_f32(const float *src, const int32_t *rows, int n_rows, int n, float *dst, hipStream_t st);
 
+// ---- ggml_mul_mat_id for more than a few tokens (build_moe_ffn): the (token, rank) pairs are grouped
+// by the expert they selected, every expert then sees ONE contiguous batch of activation rows (its weights are read once
+// per batch instead of once per token), and the expert outputs are combined back per token in rank order.
+// Counting sort of the T*k selections by expert, stable in (token, rank) order: counts[e], offs[e] (exclusive prefix,
+// offs[n_expert] = T*k), slot_of[t*k + j] = grouped row of the pair, tok_of[row] = its token.  meta = counts | offs.
+hipError_t launch_moe_group(const int32_t *ids, int T, int k, int n_expert, int32_t *meta, int32_t *slot_of, int32_t *tok_of, hipStream_t st);
+// grouped[r] = src[tok_of[r]] for the quantised activation planes that exist in both (K codes per row)
+hipError_t launch_moe_gather_act(const ActQuant &src, const int32_t *tok_of, int n_rows, int K, const ActQuant &dst, hipStream_t st);
+// x[t][d] += sum_j y[slot_of[t*k + j]][d] * w[t][j]   (same order of operations as launch_moe_combine)
+hipError_t launch_moe_scatter_combine(float *x, const float *y, const float *w, const int32_t *slot_of, int T, int E, int k, hipStream_t st);
+
 // ---------------------------------------------------------------- attention side (attn.hip)
 struct KVLayerView {
     // head-major cache planes of one layer: cell c of kv-head g

@@ -232,6 +232,89 @@ hipError_t launch_moe_combine(float *x, const float *eo, const float *w, int T, 
     hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, eo, w, T, E, k, eo_stride);
     return hipGetLastError();
 }
+// ---------------------------------------------------------------- grouping by expert (ggml_mul_mat_id with a batch of tokens)
+// One workgroup of 4 waves.  The selections are staged in LDS; wave w owns experts w, w + 4, ...: it walks the selections
+// 64 at a time in (token, rank) order, a ballot marks the ones that chose its expert and a prefix count of the ballot
+// gives each its row: stable, deterministic, no atomics.  (Runs once per layer of a prompt batch: a few microseconds.)
+__global__ __launch_bounds__(256) void moe_group_kernel(const int32_t *ids, int n_sel, int k, int n_expert, int32_t *meta, int32_t *slot_of, int32_t *tok_of) {
+    extern __shared__ int32_t sid[];               // [n_sel]
+    __shared__ int cnt[64], off[65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n_sel; i += 256) sid[i] = ids[i];
+    __syncthreads();
+    for (int e = wave; e < n_expert; e += 4) {
+        int c = 0;
+        for (int b = 0; b < n_sel; b += 64) {
+            const bool hit = b + lane < n_sel && sid[b + lane] == e;
+            c += __popcll(__ballot(hit));
+        }
+        if (lane == 0) cnt[e] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int j = 0; j < n_expert; j++) { off[j] = run; run += cnt[j]; }
+        off[n_expert] = run;
+    }
+    __syncthreads();
+    if (tid < n_expert) { meta[tid] = cnt[tid]; meta[n_expert + tid] = off[tid]; }
+    if (tid == 0) meta[2 * n_expert] = off[n_expert];
+    for (int e = wave; e < n_expert; e += 4) {
+        int r = off[e];
+        for (int b = 0; b < n_sel; b += 64) {
+            const bool hit = b + lane < n_sel && sid[b + lane] == e;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int row = r + __popcll(m & ((1ull << lane) - 1ull));
+                slot_of[b + lane] = row;
+                tok_of[row] = (b + lane) / k;
+            }
+            r += __popcll(m);
+        }
+    }
+}
+hipError_t launch_moe_group(const int32_t *ids, int T, int k, int n_expert, int32_t *meta, int32_t *slot_of, int32_t *tok_of, hipStream_t st) {
+    if (n_expert > 64 || T * k <= 0 || (size_t)T * k * 4 > 60 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), (size_t)T * k * 4, st, ids, T * k, k, n_expert, meta, slot_of, tok_of);
+    return hipGetLastError();
+}
+// one workgroup per grouped row: 16-byte copies of the code plane(s), then the small per-block planes
+__global__ __launch_bounds__(256) void moe_gather_act_kernel(ActQuant src, const int32_t *tok_of, int K, ActQuant dst) {
+    const int r = blockIdx.x, t = tok_of[r], tid = threadIdx.x;
+    if (src.qs && dst.qs) {
+        const uint4 *s = reinterpret_cast<const uint4 *>(src.qs + (size_t)t * K);
+        uint4 *d = reinterpret_cast<uint4 *>(dst.qs + (size_t)r * K);
+        for (int i = tid; i < (K >> 4); i += 256) d[i] = s[i];
+        for (int i = tid; i < (K >> 8); i += 256) dst.d[(size_t)r * (K >> 8) + i] = src.d[(size_t)t * (K >> 8) + i];
+        for (int i = tid; i < (K >> 4); i += 256) dst.bsums[(size_t)r * (K >> 4) + i] = src.bsums[(size_t)t * (K >> 4) + i];
+    }
+    if (src.qs0 && dst.qs0) {
+        const uint4 *s = reinterpret_cast<const uint4 *>(src.qs0 + (size_t)t * K);
+        uint4 *d = reinterpret_cast<uint4 *>(dst.qs0 + (size_t)r * K);
+        for (int i = tid; i < (K >> 4); i += 256) d[i] = s[i];
+        for (int i = tid; i < (K >> 5); i += 256) dst.d0[(size_t)r * (K >> 5) + i] = src.d0[(size_t)t * (K >> 5) + i];
+    }
+}
+hipError_t launch_moe_gather_act(const ActQuant &src, const int32_t *tok_of, int n_rows, int K, const ActQuant &dst, hipStream_t st) {
+    if (n_rows <= 0) return hipSuccess;
+    if (K % 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_gather_act_kernel, dim3(n_rows), dim3(256), 0, st, src, tok_of, K, dst);
+    return hipGetLastError();
+}
+__global__ void moe_scatter_combine_kernel(float *x, const float *y, const float *w, const int32_t *slot_of, int T, int E, int k) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * E) return;
+    const int t = (int)(i / E), d = (int)(i - (int64_t)t * E);
+    float o = y[(size_t)slot_of[(size_t)t * k] * E + d] * w[(size_t)t * k];
+    for (int j = 1; j < k; j++) o = o + y[(size_t)slot_of[(size_t)t * k + j] * E + d] * w[(size_t)t * k + j];
+    x[i] = x[i] + o;
+}
+hipError_t launch_moe_scatter_combine(float *x, const float *y, const float *w, const int32_t *slot_of, int T, int E, int k, hipStream_t st) {
+    const int64_t n = (int64_t)T * E;
+    hipLaunchKernelGGL(moe_scatter_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, w, slot_of, T, E, k);
+    return hipGetLastError();
+}
+
 __global__ void gather_rows_kernel(const float *src, const int32_t *rows, int n, float *dst) {
     const int r = blockIdx.y;
     const float *s = src + (size_t)rows[r] * n;

@@ -292,6 +292,7 @@ Context::~Context() {
     if (h_embd_) (void)hipHostFree(h_embd_);
     if (h_chunks_) (void)hipHostFree(h_chunks_);
     if (h_mega_flag_) (void)hipHostFree(h_mega_flag_);
+    if (h_moe_meta_) (void)hipHostFree(h_moe_meta_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -393,6 +394,20 @@ bool Context::init(std::string &err) {
         moe_ids_ = (int32_t *)dalloc(T * hp.n_expert_used * 4);
         moe_w_ = (float *)dalloc(T * hp.n_expert_used * 4);
         moe_out_ = (float *)dalloc((size_t)hp.n_expert_used * T * E * 4);
+        if (T >= 8) {                                              // grouped-by-expert batches of a prompt (run_layers)
+            const size_t GR = (size_t)hp.n_expert_used * T;
+            bool okg = true;
+            alloc_actq(aq_eg_, E, GR, true, true, allocs_, device_bytes, okg);
+            alloc_actq(aq_ffg_, FF, GR, true, true, allocs_, device_bytes, okg);
+            ffn_g_ = (float *)dalloc(GR * FF * 4);
+            ffn_ug_ = (float *)dalloc(GR * FF * 4);
+            y_g_ = (float *)dalloc(GR * E * 4);
+            moe_meta_ = (int32_t *)dalloc((size_t)(2 * hp.n_expert + 1) * 4);
+            moe_slot_ = (int32_t *)dalloc(GR * 4);
+            moe_tok_ = (int32_t *)dalloc(GR * 4);
+            if (!okg || !ffn_g_ || !ffn_ug_ || !y_g_ || !moe_tok_ ||
+                hipHostMalloc((void **)&h_moe_meta_, (size_t)(2 * hp.n_expert + 1) * 4, hipHostMallocDefault) != hipSuccess) { err = "MoE batch buffers allocation failed"; return false; }
+        }
     }
     bool ok = true;
     alloc_actq(aq_e_, E, T, true, true, allocs_, device_bytes, ok);
@@ -670,6 +685,10 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
 // Off by default: measured on MI355X (tools/bench_gridbar.hip) a device-wide barrier costs ~4 us where a
 // launch boundary inside a graph costs ~2.7 us, so the whole-step kernel is ~10 % slower than one launch per operation.
 // MI355_MEGA=1 or mi355_debug_set_option("decode_mega", 1) turns it on for contexts created afterwards.
+// Batches of at least this many tokens run a mixture-of-experts feed-forward grouped by expert (ggml_mul_mat_id as one
+// batched contraction per expert); fewer tokens loop over (token, expert) with the mat-vec.  Tests move it to compare both.
+static int g_moe_group_min = getenv("MI355_MOE_GROUP_MIN") ? atoi(getenv("MI355_MOE_GROUP_MIN")) : 8;
+void set_moe_group_min(int t) { g_moe_group_min = t < 1 ? 1 : t; }
 static int g_decode_mega = -1;           // -1: take the environment
 void set_decode_mega(bool on) { g_decode_mega = on ? 1 : 0; }
 
@@ -858,6 +877,47 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_moe_route(router_, T, hp.n_expert, hp.n_expert_used, moe_ids_, moe_w_, stream_));
             prof_mark("moe_route");
             const int KU = hp.n_expert_used;
+            const bool exps_q = is_quant(L.gate_exps.type) && is_quant(L.up_exps.type) && is_quant(L.down_exps.type);
+            const int group_min = g_moe_group_min;
+            if (exps_q && T >= group_min && aq_eg_.qs) {
+                // ggml_mul_mat_id on a batch: group the (token, rank) pairs by expert, one contiguous activation batch per
+                // expert (its weights are read once per batch, through the same batched kernels as the dense projections)
+                const int NE = hp.n_expert, GR = T * KU;
+                HIP_TRY(launch_moe_group(moe_ids_, T, KU, NE, moe_meta_, moe_slot_, moe_tok_, stream_));
+                HIP_TRY(hipMemcpyAsync(h_moe_meta_, moe_meta_, (size_t)(2 * NE + 1) * 4, hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(launch_moe_gather_act(aq_e_, moe_tok_, GR, E, aq_eg_, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));            // the batch sizes size the launches (prompt batches only: never inside a graph)
+                auto view = [](const DevTensor &w, int e) {
+                    DevTensor v = w;
+                    v.data = w.data + (size_t)e * w.row_bytes * (size_t)w.N;
+                    v.n_expert = 1;
+                    v.planes = w.planes ? w.planes + (size_t)e * (w.planes_bytes / (size_t)w.n_expert) : nullptr;
+                    return v;
+                };
+                auto rows = [](const ActQuant &q, int r0, int K) {
+                    ActQuant v;
+                    if (q.qs) { v.qs = q.qs + (size_t)r0 * K; v.d = q.d + (size_t)r0 * (K / 256); v.bsums = q.bsums + (size_t)r0 * (K / 16); }
+                    if (q.qs0) { v.qs0 = q.qs0 + (size_t)r0 * K; v.d0 = q.d0 + (size_t)r0 * (K / 32); }
+                    return v;
+                };
+                for (int e = 0; e < NE; e++) {
+                    const int n_e = h_moe_meta_[e], r0 = h_moe_meta_[NE + e];
+                    if (n_e <= 0) continue;
+                    HIP_TRY(linear(view(L.gate_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_g_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
+                    HIP_TRY(linear(view(L.up_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_ug_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
+                }
+                HIP_TRY(launch_swiglu(ffn_g_, ffn_ug_, ffn_g_, (int64_t)GR * FF, stream_));
+                HIP_TRY(launch_quantize(ffn_g_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                for (int e = 0; e < NE; e++) {
+                    const int n_e = h_moe_meta_[e], r0 = h_moe_meta_[NE + e];
+                    if (n_e <= 0) continue;
+                    HIP_TRY(linear(view(L.down_exps, e), rows(aq_ffg_, r0, FF), nullptr, FF, n_e, y_g_ + (size_t)r0 * E, E, nullptr, EPI_STORE));
+                }
+                HIP_TRY(launch_moe_scatter_combine(x_, y_g_, moe_w_, moe_slot_, T, E, KU, stream_));
+                prof_mark("moe_ffn");
+                if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
+                continue;
+            }
             for (int t = 0; t < T; t++) {
                 for (int j = 0; j < KU; j++) {
                     const int32_t *esel = moe_ids_ + (size_t)t * KU + j;

@@ -92,6 +92,7 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
     float eps = 0.0f;
 };
 
+void set_moe_group_min(int tokens);   // tests: batch size from which a mixture-of-experts feed-forward is grouped by expert
 void set_decode_mega(bool on);   // tests: compare the whole-step kernel with the per-launch path (read when a context first decodes one token)
 
 class Context {
@@ -176,6 +177,10 @@ class Context {
     hipError_t tp_reduce_into_x(int T);                 // x_ = sum over ranks of tp_part_
     int32_t *moe_ids_ = nullptr;
     float *moe_w_ = nullptr;
+    // prompt batches of a mixture-of-experts model: (token, rank) pairs grouped by expert (run_layers)
+    ActQuant aq_eg_, aq_ffg_;
+    float *ffn_g_ = nullptr, *ffn_ug_ = nullptr, *y_g_ = nullptr;
+    int32_t *moe_meta_ = nullptr, *moe_slot_ = nullptr, *moe_tok_ = nullptr, *h_moe_meta_ = nullptr;
     ActQuant aq_e_, aq_ff_, aq_o_;
     int8_t *mmq_bh_ = nullptr, *mmq_bl_ = nullptr;   // (hi, lo) planes of the 32-code block sums for the MFMA path
     float *att_part_ = nullptr;

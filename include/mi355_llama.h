@@ -223,7 +223,9 @@ MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_
  * token tiles per wave), "mmq_ksplit" (1: 8 <= T <= 64 uses the K-split small-batch kernel, as the runtime does; 0: the
  * kernels the other T ranges use); and of contexts created afterwards: "decode_mega" (1: single-token steps of a dense
  * K-quant model with Llama-3-8B's layer geometry run every layer in one launch; 0, the default: one launch per operation
- * — both produce the same bits; the single launch measured slower).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
+ * — both produce the same bits; the single launch measured slower); "moe_group_min" (batches of at least
+ * this many tokens run a mixture-of-experts feed-forward grouped by expert, default 8; smaller ones loop over (token,
+ * expert) with the mat-vec).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
 MI355_API int mi355_debug_set_option(const char *name, int32_t value);
 
 /* ------------------------------------------------------------------ row split across GPUs (one process per GPU)

@@ -303,3 +303,39 @@ def test_embeddings_match_oracle_hidden_state(be, pkg, tmp_models):
     with pytest.raises(pkg.MI355Error):
         c.embeddings()
     c.close(); m.close(); oc.close(); om.close()
+
+
+@pytest.mark.parametrize("ftype,kv,n_prompt", [("q4_k_m", "q8_0", 300), ("q5_k_m", "q8_0", 96), ("q8_0", "q8_0", 40)])
+def test_moe_prompt_batches_grouped_by_expert(be, pkg, tmp_models, ftype, kv, n_prompt):
+    """ggml_mul_mat_id on a prompt batch (build_moe_ffn): the (token, rank) pairs are grouped by expert and every expert
+    runs ONE batched contraction over its tokens (300 tokens / 8 experts top-2: ~75 rows per expert -> the MFMA kernels;
+    96 -> the K-split small-batch kernel; Q8_0 experts -> the tiled mat-vec).  Checked against the CPU oracle per layer
+    and on the logits, and against the per-(token, expert) mat-vec loop the single-token steps use (same integer sums)."""
+    path = make(pkg, tmp_models, "tiny-moe", ftype)
+    rng = np.random.default_rng(9)
+    prompt = rng.integers(0, 512, n_prompt)
+    om = oq.OracleModel(path)
+    oc = oq.OracleContext(om, 512, KV[kv], KV[kv], True, 4)
+    ref = oc.decode(prompt, np.arange(n_prompt))[0]
+    ref_layers = [oc.layer_out(il, n_prompt) for il in range(2)]
+    outs = {}
+    for mode, gmin in (("grouped", 8), ("loop", 1 << 20)):
+        be.set_option("moe_group_min", gmin)
+        m = pkg.Model(path)
+        c = pkg.Context(m, n_ctx=512, type_k=KV[kv], type_v=KV[kv], n_ubatch=512)
+        c.enable_taps(True)
+        c.decode(prompt, np.arange(n_prompt))
+        outs[mode] = (c.logits(), [c.layer_out(il, n_prompt) for il in range(m.n_layer)])
+        c.close(); m.close()
+    be.set_option("moe_group_min", 8)
+    for mode, (lg, layers) in outs.items():
+        errs = [rel_err(a, b) for a, b in zip(layers, ref_layers)] + [rel_err(lg, ref)]
+        assert max(errs) <= FLIP_TOL, (mode, errs)
+        # most tokens are flip-free after the first layer: they agree with the oracle to f32 round-off
+        a0, b0 = layers[0].reshape(n_prompt, -1), ref_layers[0].reshape(n_prompt, -1)
+        tok_err0 = np.abs(a0 - b0).max(axis=1) / max(1.0, float(np.abs(b0).max()))
+        assert float(np.median(tok_err0)) <= TIGHT_TOL, (mode, tok_err0)
+    g0, l0 = outs["grouped"][1][0].reshape(n_prompt, -1), outs["loop"][1][0].reshape(n_prompt, -1)
+    tok = np.abs(g0 - l0).max(axis=1) / max(1.0, float(np.abs(l0).max()))
+    assert float(np.median(tok)) <= TIGHT_TOL and rel_err(outs["grouped"][0], outs["loop"][0]) <= FLIP_TOL, tok
+    oc.close(); om.close()
