@@ -168,13 +168,28 @@ __global__ __launch_bounds__(256) void mmv_float_kernel(int type, const uint8_t 
     if (gw >= n_rows * T) return;
     const int r = gw % n_rows, t = gw / n_rows;
     const float *xr = x + (size_t)t * K;
+    // sixteen loads in flight per lane, then the products are added in the same order as a plain k-loop would add them
+    // (a dependent load per iteration made the 8 x 4096 router of a mixture-of-experts layer take 18 us)
     double s = 0.0;
+    constexpr int UN = 16;
     if (type == T_F32) {
         const float *w = reinterpret_cast<const float *>(W) + (size_t)r * K;
-        for (int k = lane; k < K; k += 64) s += (double)(w[k] * xr[k]);
+        for (int k0 = lane; k0 < K; k0 += 64 * UN) {
+            float wv[UN], xv[UN];
+#pragma unroll
+            for (int j = 0; j < UN; j++) { const int k = k0 + 64 * j, kc = k < K ? k : lane; wv[j] = w[kc]; xv[j] = xr[kc]; }
+#pragma unroll
+            for (int j = 0; j < UN; j++) if (k0 + 64 * j < K) s += (double)(wv[j] * xv[j]);
+        }
     } else {
         const uint16_t *w = reinterpret_cast<const uint16_t *>(W) + (size_t)r * K;
-        for (int k = lane; k < K; k += 64) s += (double)(h2f(w[k]) * h2f(f2h(xr[k])));   // activations cast to f16 like the CPU path
+        for (int k0 = lane; k0 < K; k0 += 64 * UN) {
+            uint16_t wv[UN]; float xv[UN];
+#pragma unroll
+            for (int j = 0; j < UN; j++) { const int k = k0 + 64 * j, kc = k < K ? k : lane; wv[j] = w[kc]; xv[j] = xr[kc]; }
+#pragma unroll
+            for (int j = 0; j < UN; j++) if (k0 + 64 * j < K) s += (double)(h2f(wv[j]) * h2f(f2h(xv[j])));   // activations cast to f16 like the CPU path
+        }
     }
     s = wave_sum(s);
     if (lane == 0) {

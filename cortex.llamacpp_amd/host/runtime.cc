@@ -217,10 +217,12 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     if (prefill_planes != 0) {
         std::vector<DevTensor *> want;
         for (auto &L : m->layers)
-            for (DevTensor *d : {&L.wq, &L.wk, &L.wv, &L.wo, &L.gate, &L.up, &L.down})
-                if (d->valid() && d->n_expert == 1 && mmq_planes_bytes(d->type, d->N, (int)d->K)) want.push_back(d);
+            for (DevTensor *d : {&L.wq, &L.wk, &L.wv, &L.wo, &L.gate, &L.up, &L.down, &L.gate_exps, &L.up_exps, &L.down_exps})
+                if (d->valid() && mmq_planes_bytes(d->type, d->N, (int)d->K)) want.push_back(d);
+        // (an *_exps tensor holds one plane set per expert, back to back: a prompt batch runs one contraction per expert)
+        auto planes_of = [](const DevTensor *d) { return (mmq_planes_bytes(d->type, d->N, (int)d->K) + 255) & ~(size_t)255; };
         size_t need = 0;
-        for (DevTensor *d : want) need += (mmq_planes_bytes(d->type, d->N, (int)d->K) + 255) & ~(size_t)255;
+        for (DevTensor *d : want) need += planes_of(d) * (size_t)d->n_expert;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const size_t reserve = (size_t)24 << 30;             // KV cache, activations, other contexts
@@ -233,10 +235,13 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
             size_t off = 0;
             for (DevTensor *d : want) {
                 d->planes = parena + off;
-                d->planes_bytes = mmq_planes_bytes(d->type, d->N, (int)d->K);
-                off += (d->planes_bytes + 255) & ~(size_t)255;
-                const hipError_t e = launch_mmq_expand(d->type, d->data, d->row_bytes, (int)d->N, (int)d->K, d->planes, nullptr);
-                if (e != hipSuccess) { err = std::string("plane expansion of ") + d->name + " failed: " + hipGetErrorString(e); status = -105; return nullptr; }
+                d->planes_bytes = planes_of(d) * (size_t)d->n_expert;
+                off += d->planes_bytes;
+                for (int64_t x = 0; x < d->n_expert; x++) {
+                    const hipError_t e = launch_mmq_expand(d->type, d->data + (size_t)x * d->row_bytes * (size_t)d->N, d->row_bytes, (int)d->N, (int)d->K,
+                                                           d->planes + (size_t)x * planes_of(d), nullptr);
+                    if (e != hipSuccess) { err = std::string("plane expansion of ") + d->name + " failed: " + hipGetErrorString(e); status = -105; return nullptr; }
+                }
             }
             if (hipDeviceSynchronize() != hipSuccess) { err = "plane expansion failed"; status = -105; return nullptr; }
             m->planes_bytes = need;
@@ -669,11 +674,14 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
         }
         return hipSuccess;
     }
-    if (all_q && n <= 3) {
+    bool any_mmq = false;
+    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T);
+    if (all_q && n <= 3 && !(any_mmq && pending_fuse_.mode == 0)) {
         MMVQSeg segs[3];
         for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
         return mmvq_tokens(segs, n, K, T, EPI_STORE, aq, stream_, pending_fuse_);
     }
+    // a prompt batch with mixed types (8-expert files keep attn_k / attn_v in Q8_0): every tensor takes its own best path
     for (int i = 0; i < n; i++) {
         hipError_t e = linear(*ws[i], aq, x_f32, K, T, outs[i], (int)ws[i]->N, nullptr, EPI_STORE);
         if (e != hipSuccess) return e;
@@ -933,9 +941,15 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                         HIP_TRY(launch_mmvq(a, stream_));
                         HIP_TRY(launch_swiglu(ffn_ + (size_t)t * FF, ffn_u_ + (size_t)t * FF, ffn_ + (size_t)t * FF, FF, stream_));
                     }
-                    HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                    // quantise inside the down projection's prologue where the persistent mat-vec takes this shape (as the
+                    // dense feed-forward does), else as its own launch
+                    const int kbf = (FF + 2047) / 2048;
+                    const bool fuse_q = (L.down_exps.type == T_Q4_K || L.down_exps.type == T_Q5_K || L.down_exps.type == T_Q6_K) && (FF % 256) == 0 &&
+                                        (kbf == 1 || kbf == 2 || kbf == 3 || kbf == 4 || kbf == 6 || kbf == 7 || kbf == 14);
+                    if (!fuse_q) HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
                     MMVQArgs d{};
                     d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE;
+                    if (fuse_q) { d.fuse_mode = 2; d.nx = ffn_ + (size_t)t * FF; }
                     d.seg[0] = make_seg(L.down_exps, moe_out_ + ((size_t)j * T + t) * E, E, nullptr, esel);
                     chunk_act(d, aq_ff_, FF, 0);
                     HIP_TRY(launch_mmvq(d, stream_));

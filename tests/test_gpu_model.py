@@ -329,12 +329,16 @@ def test_moe_prompt_batches_grouped_by_expert(be, pkg, tmp_models, ftype, kv, n_
         c.close(); m.close()
     be.set_option("moe_group_min", 8)
     for mode, (lg, layers) in outs.items():
-        errs = [rel_err(a, b) for a, b in zip(layers, ref_layers)] + [rel_err(lg, ref)]
-        assert max(errs) <= FLIP_TOL, (mode, errs)
-        # most tokens are flip-free after the first layer: they agree with the oracle to f32 round-off
-        a0, b0 = layers[0].reshape(n_prompt, -1), ref_layers[0].reshape(n_prompt, -1)
-        tok_err0 = np.abs(a0 - b0).max(axis=1) / max(1.0, float(np.abs(b0).max()))
-        assert float(np.median(tok_err0)) <= TIGHT_TOL, (mode, tok_err0)
+        # per token: besides the int8 rounding flips of the dense models, a token whose router probabilities are a near tie
+        # may pick another expert pair than the CPU did (its output then moves by more than FLIP_TOL): a few of 300 tokens
+        # may, the rest must hold the usual bound, and most must agree with the oracle to f32 round-off after layer 0
+        for il, (a, b) in enumerate(zip(layers, ref_layers)):
+            a2, b2 = a.reshape(n_prompt, -1), b.reshape(n_prompt, -1)
+            tok_err = np.abs(a2 - b2).max(axis=1) / max(1.0, float(np.abs(b2).max()))
+            assert float((tok_err > FLIP_TOL).mean()) <= 0.02, (mode, il, np.sort(tok_err)[-8:])
+            if il == 0:
+                assert float(np.median(tok_err)) <= TIGHT_TOL, (mode, tok_err)
+        assert rel_err(lg, ref) <= FLIP_TOL, (mode, rel_err(lg, ref))
     g0, l0 = outs["grouped"][1][0].reshape(n_prompt, -1), outs["loop"][1][0].reshape(n_prompt, -1)
     tok = np.abs(g0 - l0).max(axis=1) / max(1.0, float(np.abs(l0).max()))
     assert float(np.median(tok)) <= TIGHT_TOL and rel_err(outs["grouped"][0], outs["loop"][0]) <= FLIP_TOL, tok
