@@ -280,6 +280,11 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
     if (quant) {
         e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, type != T_Q8_0, type == T_Q8_0, nullptr);
         if (e != hipSuccess) return hip_fail(e, "quantize");
+        if (mmq_q80_applicable(type, (int)K, (int)T)) {
+            e = launch_mmq_q80(wdev.as<uint8_t>(), drow, (int)N, (int)K, (int)T, ab.q, dy.as<float>(), (int)N, nullptr, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_fail(e, "mmq_q80");
+        } else
         if (g_op_mmq_ksplit && mmq_ksplit_applicable(type, (int)K, (int)T)) {
             DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
             if (!bh.p || !bl.p) return MI355_ERR_OOM;

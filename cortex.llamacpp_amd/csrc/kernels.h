@@ -76,6 +76,10 @@ struct MMQSeg {
     float *out; int ld_out; const float *resid;
     int tile0;                 // first workgroup of this segment (set by the launcher)
 };
+// prompt batches against Q8_0 weights (mmq_q80.hip): int8 MFMA per 32-block, f32 fold in block order (bit-exact with the CPU)
+bool mmq_q80_applicable(int type, int K, int T);
+hipError_t launch_mmq_q80(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, float *out, int ld_out,
+                          const float *resid, hipStream_t st);
 bool mmq_ksplit_applicable(int type, int K, int T);
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st);

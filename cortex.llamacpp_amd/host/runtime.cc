@@ -639,6 +639,8 @@ static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, c
 hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
+        if (mmq_q80_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU && aq.qs0)   // prompt processing, Q8_0 weights
+            return launch_mmq_q80(w.data, w.row_bytes, (int)w.N, K, T, aq, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         if (mmq_ksplit_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // batched decode steps: MFMA, K split
             if (w.type != T_Q6_K) HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
             return launch_mmq_ksplit(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
@@ -675,7 +677,7 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
         return hipSuccess;
     }
     bool any_mmq = false;
-    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T);
+    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T) || mmq_q80_applicable(ws[i]->type, K, T);
     if (all_q && n <= 3 && !(any_mmq && pending_fuse_.mode == 0)) {
         MMVQSeg segs[3];
         for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
@@ -969,7 +971,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
                 prof_mark("norm_quant");
             }
-            const bool ffn_mmq = (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
+            const bool ffn_mmq = (mmq_q80_applicable(L.gate.type, E, T) && mmq_q80_applicable(L.up.type, E, T)) ||
+                                 (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
                                  (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T));
             const bool ffn_ks = mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T) && !fuse_ffn;
             if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {

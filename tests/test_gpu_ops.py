@@ -103,6 +103,19 @@ def test_mul_mat_small_batch_ksplit(be, t, K, N, T):
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
+@pytest.mark.parametrize("K,N,T", [(2048, 130, 40), (4096, 300, 129), (5632, 37, 33), (1024, 256, 512), (14336, 40, 96), (256, 5, 32)])
+def test_mul_mat_q8_0_prefill_mfma_bit_exact(be, K, N, T):
+    """Prompt batches against Q8_0 weights (mmq_q80.hip): one int8 MFMA per 32-block, one f32 multiply-add per block in block
+    order — the arithmetic of ggml_vec_dot_q8_0_q8_0, so the result equals the CPU restatement bit for bit; ragged rows and
+    tokens, K beyond 48 KB of scale staging."""
+    rng = np.random.default_rng(K + N + T)
+    W = rand_weights(rng, Q8_0, N * K)
+    x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
+    y = be.mul_mat(Q8_0, W, N, K, x)
+    ref = oq.mul_mat(Q8_0, W, N, K, x)
+    assert np.array_equal(y, ref), float(np.abs(y - ref).max())
+
+
 def test_mul_mat_f32_f16_weights(be):
     rng = np.random.default_rng(5)
     N, K, T = 8, 512, 3
