@@ -692,7 +692,7 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
 }
 
 // ------------------------------------------------------------------------------------------ whole-step kernel
-// Off by default: measured on MI355X (DESIGN.md 4.6, tools/bench_gridbar.hip) a device-wide barrier costs ~4 us where a
+// Off by default: measured on MI355X (DESIGN.md 4.4, tools/bench_gridbar.hip) a device-wide barrier costs ~4 us where a
 // launch boundary inside a graph costs ~2.7 us, so the whole-step kernel is ~10 % slower than one launch per operation.
 // MI355_MEGA=1 or mi355_debug_set_option("decode_mega", 1) turns it on for contexts created afterwards.
 // Batches of at least this many tokens run a mixture-of-experts feed-forward grouped by expert (ggml_mul_mat_id as one
