@@ -347,7 +347,8 @@ def main() -> int:
     decode_frac = (model.bytes_per_token + kv_bytes) * (args.steps / dt) / (HBM_PEAK_GBPS * 1e9)
 
     out = {
-        "metric": "decode tok/s, Llama-3-8B Q4_K_M GGUF (prefill tok/s in `prefill_tok_s`)",
+        "metric": "decode tok/s, Llama-3-8B Q4_K_M GGUF (prefill tok/s in `prefill_tok_s`)" if (args.config, args.ftype) == ("llama-3-8b", "q4_k_m")
+                  else f"decode tok/s, {cfg.name} {args.ftype.upper()} GGUF (prefill tok/s in `prefill_tok_s`)",
         "value": tok_s,
         "unit": "tok/s",
         "n_gpus": n_gpus,
