@@ -47,6 +47,10 @@ struct MMVQArgs {
     // fused prologue (T == 1, K <= 8192, K % 1024 == 0): 0 = planes above; 1 = rms_norm(nx)*nw then quantise; 2 = quantise nx
     int fuse_mode;
     const float *nx; const float *nw; float neps;
+    // single-token mixture-of-experts step, fast path only: n_sel > 1 runs the n_sel selected experts of ONE token in one
+    // launch — the workgroups are divided evenly among them; expert j reads expert_sel[j], writes out + j * sel_out_stride
+    // and (fuse_mode 2) quantises nx + j * sel_nx_stride (all strides in floats).  0 / 1 = one expert (expert_sel[0]).
+    int n_sel, sel_out_stride, sel_nx_stride;
 };
 
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);
@@ -116,6 +120,9 @@ hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const
 
 // MoE router: softmax over n_expert logits per token, top-k (first index wins ties), weights renormalised
 hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, hipStream_t st);
+// the two above in one launch (f32 / f16 gate_inp), same arithmetic; logits_out may be null
+hipError_t launch_moe_router(int type, const uint8_t *W, int n_expert, int K, const float *x, int T, int k, float *logits_out, int32_t *ids, float *w,
+                             hipStream_t st);
 // x[t][d] += sum_j eo[j][t][d] * w[t][j]   (experts added in rank order, then the residual)
 hipError_t launch_moe_combine(float *x, const float *eo, const float *w, int T, int E, int k, size_t eo_stride, hipStream_t st);
 hipError_t launch_gather_rows_f32(const float *src, const int32_t *rows, int n_rows, int n, float *dst, hipStream_t st);

@@ -234,6 +234,67 @@ hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int
     hipLaunchKernelGGL(moe_route_kernel, dim3((T + 63) / 64), dim3(64), 0, st, logits, T, n_expert, k, ids, w);
     return hipGetLastError();
 }
+// Router of a mixture-of-experts layer in ONE launch: logits = gate_inp . x (the arithmetic of mmv_float_kernel: lane l adds
+// the products k = l, l + 64, ... in a double, waves reduced the same way), then the selection of moe_route_kernel, per
+// token.  Workgroup = token; wave w computes experts w, w + 4, ...; thread 0 selects.  Same bits as the two launches.
+__global__ __launch_bounds__(256) void moe_router_kernel(int type, const uint8_t *W, int n_expert, int K, const float *x, int k, float *logits_out,
+                                                         int32_t *ids, float *w) {
+    __shared__ float lg[64];
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *xr = x + (size_t)t * K;
+    constexpr int UN = 16;
+    for (int e = wave; e < n_expert; e += 4) {
+        double s = 0.0;
+        if (type == T_F32) {
+            const float *wr = reinterpret_cast<const float *>(W) + (size_t)e * K;
+            for (int k0 = lane; k0 < K; k0 += 64 * UN) {
+                float wv[UN], xv[UN];
+#pragma unroll
+                for (int j = 0; j < UN; j++) { const int kk = k0 + 64 * j, kc = kk < K ? kk : lane; wv[j] = wr[kc]; xv[j] = xr[kc]; }
+#pragma unroll
+                for (int j = 0; j < UN; j++) if (k0 + 64 * j < K) s += (double)(wv[j] * xv[j]);
+            }
+        } else {
+            const uint16_t *wr = reinterpret_cast<const uint16_t *>(W) + (size_t)e * K;
+            for (int k0 = lane; k0 < K; k0 += 64 * UN) {
+                uint16_t wv[UN]; float xv[UN];
+#pragma unroll
+                for (int j = 0; j < UN; j++) { const int kk = k0 + 64 * j, kc = kk < K ? kk : lane; wv[j] = wr[kc]; xv[j] = xr[kc]; }
+#pragma unroll
+                for (int j = 0; j < UN; j++) if (k0 + 64 * j < K) s += (double)(h2f(wv[j]) * h2f(f2h(xv[j])));
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) { lg[e] = (float)s; if (logits_out) logits_out[(size_t)t * n_expert + e] = (float)s; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float p[64];
+    float mx = -INFINITY;
+    for (int e = 0; e < n_expert; e++) mx = fmaxf(mx, lg[e]);
+    double sum = 0.0;
+    for (int e = 0; e < n_expert; e++) { p[e] = expf(lg[e] - mx); sum += (double)p[e]; }
+    const float inv = (float)(1.0 / sum);
+    for (int e = 0; e < n_expert; e++) p[e] *= inv;
+    unsigned long long used = 0;
+    float wsum = 0.0f;
+    for (int j = 0; j < k; j++) {
+        int best = -1;
+        for (int e = 0; e < n_expert; e++)
+            if (!((used >> e) & 1ull) && (best < 0 || p[e] > p[best])) best = e;
+        used |= 1ull << best;
+        ids[(size_t)t * k + j] = best;
+        w[(size_t)t * k + j] = p[best];
+        wsum += p[best];
+    }
+    for (int j = 0; j < k; j++) w[(size_t)t * k + j] /= wsum;
+}
+hipError_t launch_moe_router(int type, const uint8_t *W, int n_expert, int K, const float *x, int T, int k, float *logits_out, int32_t *ids, float *w,
+                             hipStream_t st) {
+    if (n_expert > 64 || (type != T_F32 && type != T_F16) || T <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_router_kernel, dim3(T), dim3(256), 0, st, type, W, n_expert, K, x, k, logits_out, ids, w);
+    return hipGetLastError();
+}
 __global__ void moe_combine_kernel(float *x, const float *eo, const float *w, int T, int E, int k, size_t eo_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)T * E) return;

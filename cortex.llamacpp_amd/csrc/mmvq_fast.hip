@@ -24,14 +24,22 @@ __global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
     int s = 0;
     if (a.n_seg > 1 && (int)blockIdx.x >= a.seg_block0[1]) s = 1;
     if (a.n_seg > 2 && (int)blockIdx.x >= a.seg_block0[2]) s = 2;
-    const int nblk = a.seg_block0[s + 1] - a.seg_block0[s];
+    int nblk = a.seg_block0[s + 1] - a.seg_block0[s];
+    int bl = (int)blockIdx.x - a.seg_block0[s];
+    int sel_j = 0;
+    if (a.n_sel > 1) {                       // the selected experts of one token share the launch: an even share of workgroups each
+        const int per = nblk / a.n_sel;
+        sel_j = bl / per < a.n_sel ? bl / per : a.n_sel - 1;
+        bl -= sel_j * per;
+        nblk = sel_j == a.n_sel - 1 ? nblk - sel_j * per : per;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gw = ((int)blockIdx.x - a.seg_block0[s]) * NW + wave;
+    const int gw = bl * NW + wave;
     const int nw = nblk * NW;
     switch (a.seg[s].type) {
-        case T_Q4_K: run_fast<T_Q4_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw); break;
-        case T_Q5_K: run_fast<T_Q5_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw); break;
-        case T_Q6_K: run_fast<T_Q6_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw); break;
+        case T_Q4_K: run_fast<T_Q4_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
+        case T_Q5_K: run_fast<T_Q5_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
+        case T_Q6_K: run_fast<T_Q6_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
         default: break;
     }
 }
@@ -47,6 +55,7 @@ bool mmvq_fast_applicable(const MMVQArgs &a) {
         if (a.seg[s].type != T_Q4_K && a.seg[s].type != T_Q5_K && a.seg[s].type != T_Q6_K) return false;
     if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;
     if (a.fuse_mode == 1 && a.K > 8192) return false;          // RMSNorm + quantise: the hidden size; quantise-only (2): any listed K
+    if (a.n_sel > 1 && (a.n_sel > 8 || (a.epi == EPI_SWIGLU ? 1 : a.n_seg) != 1 || a.epi == EPI_ADD)) return false;   // experts of one token: one tensor (or one gate/up pair)
     return true;
 }
 
@@ -63,7 +72,7 @@ size_t mmvq_fast_plan(MMVQArgs &a, int max_blocks, int nwv) {
         bytes[s] = (size_t)a.seg[s].n_rows * a.seg[s].row_bytes;
         total += bytes[s];
         const int pairs = a.epi == EPI_SWIGLU ? a.seg[s].n_rows : (a.seg[s].n_rows + 1) / 2;
-        want[s] = (pairs + nwv - 1) / nwv;
+        want[s] = (pairs + nwv - 1) / nwv * (a.n_sel > 1 ? a.n_sel : 1);
         sum_want += want[s];
     }
     a.seg_block0[0] = 0;

@@ -190,7 +190,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int KB, int NT, int FUSE, bool COH = false>
 __device__ __forceinline__ void stage_issue(const MMVQArgs &a, u32x4_t (&rq)[StageDims<KB, NT>::NQ], uint32_t (&rb)[StageDims<KB, NT>::NB32], float &rdv,
-                                            f32x4_t (&rxv)[StageDims<KB, NT>::NJW], f32x4_t (&rwv)[StageDims<KB, NT>::NJW]) {
+                                            f32x4_t (&rxv)[StageDims<KB, NT>::NJW], f32x4_t (&rwv)[StageDims<KB, NT>::NJW], int nx_off = 0) {
     using S = StageDims<KB, NT>;
     const int tid = tid_now();
     if (FUSE == 0) {
@@ -211,7 +211,7 @@ __device__ __forceinline__ void stage_issue(const MMVQArgs &a, u32x4_t (&rq)[Sta
             const int nbt = a.K >> 8;
             const int bc = b < nbt ? b : nbt - 1;                  // clamped: always a valid address, result unused when b is out of range
             {
-                const coh_u32x4 r = cld16<COH>(a.nx, (bc * 256 + lane * 4) * 4);
+                const coh_u32x4 r = cld16<COH>(a.nx, (nx_off + bc * 256 + lane * 4) * 4);
                 rxv[j].x = __uint_as_float(r.x); rxv[j].y = __uint_as_float(r.y); rxv[j].z = __uint_as_float(r.z); rxv[j].w = __uint_as_float(r.w);
             }
             if (FUSE == 1) rwv[j] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
@@ -309,7 +309,7 @@ __device__ __forceinline__ ActSlice read_slice_t(const ActL &A, int sb, int nb, 
 // then sync() waits for the other workgroups (the requests are in flight meanwhile), then the activation is fetched.
 struct NoSync { __device__ __forceinline__ void operator()() const {} };
 template <int TYPE, int KB, int NT, int FUSE, bool PRE = false, class Sync = NoSync>
-__device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int gw, int nw, Sync sync = Sync()) {
+__device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int gw, int nw, Sync sync = Sync(), int sel_j = 0) {
     using R = Raw<TYPE>;
     constexpr bool ACT_REGS = KB <= 2;
     constexpr bool DIRECT = ACT_REGS && FUSE == 0;
@@ -321,9 +321,12 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     const int lane = tid_now() & 63;
     const LaneRole L = make_role<TYPE>(lane);
     const bool swiglu = a.epi == EPI_SWIGLU;
-    const uint8_t *W0 = sg.W + (sg.expert_sel ? (size_t)sg.expert_sel[0] * sg.expert_stride : 0);
+    // sel_j: which of the token's selected experts this workgroup serves (mixture-of-experts step, MMVQArgs::n_sel)
+    const uint8_t *W0 = sg.W + (sg.expert_sel ? (size_t)sg.expert_sel[sel_j] * sg.expert_stride : 0);
     const MMVQSeg &ug = a.seg[1];
-    const uint8_t *W1 = swiglu ? ug.W + (ug.expert_sel ? (size_t)ug.expert_sel[0] * ug.expert_stride : 0) : W0;
+    const uint8_t *W1 = swiglu ? ug.W + (ug.expert_sel ? (size_t)ug.expert_sel[sel_j] * ug.expert_stride : 0) : W0;
+    float *const outp = sg.out + (size_t)sel_j * (size_t)a.sel_out_stride;
+    const int nx_off = sel_j * a.sel_nx_stride;
     const size_t rb0 = sg.row_bytes, rb1 = swiglu ? ug.row_bytes : sg.row_bytes;
     const int npairs = swiglu ? sg.n_rows : (sg.n_rows + 1) >> 1;
     const int my_pairs = gw < npairs ? (npairs - gw + nw - 1) / nw : 0;
@@ -337,7 +340,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
             S0 = global_slice_t<TYPE, COH>(a, L.sbl, nb, L);
             if (KB > 1) S1 = global_slice_t<TYPE, COH>(a, 8 + L.sbl, nb, L);
         } else {
-            stage_issue<KB, NT, FUSE, COH>(a, STAGE_REGS_ARGS);
+            stage_issue<KB, NT, FUSE, COH>(a, STAGE_REGS_ARGS, nx_off);
         }
     };
     if (!PRE) issue_act();
@@ -392,16 +395,16 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
             if (lane == 0) {
                 const int pair = gw + pi * nw;
                 if (swiglu) {
-                    cstf<COH>(sg.out + pair, (v0 / (1.0f + expf(-v0))) * v1);
+                    cstf<COH>(outp + pair, (v0 / (1.0f + expf(-v0))) * v1);
                 } else {
                     const int row0 = 2 * pair;
                     const bool has1 = row0 + 1 < sg.n_rows;
                     if (a.epi == EPI_ADD) {
-                        cstf<COH>(sg.out + row0, cldf<COH>(sg.resid + row0) + v0);
-                        if (has1) cstf<COH>(sg.out + row0 + 1, cldf<COH>(sg.resid + row0 + 1) + v1);
+                        cstf<COH>(outp + row0, cldf<COH>(sg.resid + row0) + v0);
+                        if (has1) cstf<COH>(outp + row0 + 1, cldf<COH>(sg.resid + row0 + 1) + v1);
                     } else {
-                        cstf<COH>(sg.out + row0, v0);
-                        if (has1) cstf<COH>(sg.out + row0 + 1, v1);
+                        cstf<COH>(outp + row0, v0);
+                        if (has1) cstf<COH>(outp + row0 + 1, v1);
                     }
                 }
             }

@@ -883,8 +883,12 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, xn_, &aq_e_,
                                          L.gate_exps.type != T_Q8_0 || L.up_exps.type != T_Q8_0, L.gate_exps.type == T_Q8_0 || L.up_exps.type == T_Q8_0, stream_));
             prof_mark("norm_quant");
-            HIP_TRY(launch_mmv_float(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, router_, hp.n_expert, nullptr, stream_));
-            HIP_TRY(launch_moe_route(router_, T, hp.n_expert, hp.n_expert_used, moe_ids_, moe_w_, stream_));
+            if (L.gate_inp.type == T_F32 || L.gate_inp.type == T_F16) {
+                HIP_TRY(launch_moe_router(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, hp.n_expert_used, router_, moe_ids_, moe_w_, stream_));
+            } else {
+                HIP_TRY(launch_mmv_float(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, router_, hp.n_expert, nullptr, stream_));
+                HIP_TRY(launch_moe_route(router_, T, hp.n_expert, hp.n_expert_used, moe_ids_, moe_w_, stream_));
+            }
             prof_mark("moe_route");
             const int KU = hp.n_expert_used;
             const bool exps_q = is_quant(L.gate_exps.type) && is_quant(L.up_exps.type) && is_quant(L.down_exps.type);
@@ -928,7 +932,27 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
                 continue;
             }
-            for (int t = 0; t < T; t++) {
+            // single-token step: the token's selected experts share one launch per projection (the workgroups are divided
+            // among them; each reads its own expert index on the device): gate/up with SwiGLU, then down with the Q8_K
+            // quantisation of its own expert's activation in the prologue
+            bool experts_done = false;
+            if (T == 1 && KU >= 2 && KU <= 8 && (int)cp.n_ubatch >= KU && L.gate_exps.type == L.up_exps.type) {
+                MMVQArgs a{};
+                a.n_seg = 2; a.K = E; a.T = 1; a.epi = EPI_SWIGLU; a.n_sel = KU; a.sel_out_stride = FF;
+                a.seg[0] = make_seg(L.gate_exps, ffn_, FF, nullptr, moe_ids_);
+                a.seg[1] = make_seg(L.up_exps, ffn_u_, FF, nullptr, moe_ids_);
+                chunk_act(a, aq_e_, E, 0);
+                MMVQArgs d{};
+                d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE; d.fuse_mode = 2; d.nx = ffn_; d.n_sel = KU; d.sel_nx_stride = FF; d.sel_out_stride = E;
+                d.seg[0] = make_seg(L.down_exps, moe_out_, E, nullptr, moe_ids_);
+                chunk_act(d, aq_ff_, FF, 0);
+                if (mmvq_fast_applicable(a) && mmvq_fast_applicable(d)) {
+                    HIP_TRY(launch_mmvq_fast(a, stream_));
+                    HIP_TRY(launch_mmvq_fast(d, stream_));
+                    experts_done = true;
+                }
+            }
+            for (int t = 0; t < T && !experts_done; t++) {
                 for (int j = 0; j < KU; j++) {
                     const int32_t *esel = moe_ids_ + (size_t)t * KU + j;
                     MMVQArgs a{};
