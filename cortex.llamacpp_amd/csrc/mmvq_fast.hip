@@ -40,6 +40,9 @@ __global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
         case T_Q4_K: run_fast<T_Q4_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
         case T_Q5_K: run_fast<T_Q5_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
         case T_Q6_K: run_fast<T_Q6_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
+        case T_Q8_0:                                           // pre-quantised Q8_0 planes only in the register form (K <= 4096)
+            if constexpr (FUSE != 0 || KB <= 2) run_fast<T_Q8_0, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j);
+            break;
         default: break;
     }
 }
@@ -51,8 +54,16 @@ bool mmvq_fast_applicable(const MMVQArgs &a) {
     const int kb = (a.K + 2047) >> 11;                         // passes of 8 super-blocks; the last one may be partial
     if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7 && kb != 14) return false;
     const int n = a.epi == EPI_SWIGLU ? 2 : a.n_seg;
-    for (int s = 0; s < n; s++)
-        if (a.seg[s].type != T_Q4_K && a.seg[s].type != T_Q5_K && a.seg[s].type != T_Q6_K) return false;
+    for (int s = 0; s < n; s++) {
+        const int t = a.seg[s].type;
+        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q8_0) return false;
+        // segments may mix K-quants and Q8_0 (8-expert files keep attn_k / attn_v in Q8_0): every workgroup stages the
+        // activation in the format of ITS segment; pre-quantised planes must exist in that format
+        if (a.fuse_mode == 0) {
+            if (t == T_Q8_0 && (kb > 2 || !a.aq0 || !a.ad0)) return false;
+            if (t != T_Q8_0 && (!a.aq || !a.ad || !a.abs)) return false;
+        }
+    }
     if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;
     if (a.fuse_mode == 1 && a.K > 8192) return false;          // RMSNorm + quantise: the hidden size; quantise-only (2): any listed K
     if (a.n_sel > 1 && (a.n_sel > 8 || (a.epi == EPI_SWIGLU ? 1 : a.n_seg) != 1 || a.epi == EPI_ADD)) return false;   // experts of one token: one tensor (or one gate/up pair)

@@ -120,6 +120,27 @@ template <> struct Raw<T_Q6_K> {
     }
 };
 
+// ---------------------------------------------------------------- Q8_0 (device row planes: codes K | f16 scales K/32)
+// lane v of a super-block owns 32-block v: its 32 codes (two 16-byte pieces) and the block scale; the activation is
+// Q8_0 too (ActSlice: lo / hi = the block's 32 codes, yd = its f16 scale), dot = (float)isum * (d_w * d_a) per block
+template <> struct Raw<T_Q8_0> {
+    u32x4_t q0, q1;
+    uint32_t dh16;
+    __device__ __forceinline__ float probe() const { return (float)(q0.x ^ q0.y ^ q0.z ^ q0.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w ^ dh16); }
+    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
+        const uint8_t *b = row + (size_t)sb * 256 + L.v * 32;
+        q0 = ldw(b);
+        q1 = ldw(b + 16);
+        dh16 = *reinterpret_cast<const uint16_t *>(row + (size_t)nb * 256 + ((size_t)sb * 8 + L.v) * 2);
+    }
+    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
+        int s = 0;
+        s = dot4(q0.x, A.lo.x, s); s = dot4(q0.y, A.lo.y, s); s = dot4(q0.z, A.lo.z, s); s = dot4(q0.w, A.lo.w, s);
+        s = dot4(q1.x, A.hi.x, s); s = dot4(q1.y, A.hi.y, s); s = dot4(q1.z, A.hi.z, s); s = dot4(q1.w, A.hi.w, s);
+        return (float)s * (h2f((uint16_t)dh16) * A.yd);
+    }
+};
+
 template <int TYPE> __device__ __forceinline__ LaneRole make_role(int lane) {
     LaneRole L;
     L.sbl = lane >> 3; L.v = lane & 7; L.c = L.v >> 1; L.h = L.v & 1;
@@ -134,6 +155,13 @@ struct ActL { const int8_t *qs; const float *d; const int16_t *bs; };
 template <int TYPE>
 __device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const LaneRole &L) {
     ActSlice s;
+    if (TYPE == T_Q8_0) {                                  // (the block-sum region of the LDS layout holds the f32 block scales)
+        const int8_t *a = A.qs + sb * 256 + 32 * L.v;
+        s.lo = lds16(a); s.hi = lds16(a + 16);
+        s.bs_lo = 0; s.bs_hi = 0;
+        s.yd = reinterpret_cast<const float *>(A.bs)[sb * 8 + L.v];
+        return s;
+    }
     if (TYPE == T_Q6_K) {
         const int8_t *a = A.qs + sb * 256 + 128 * L.n + 16 * L.w;
         s.lo = lds16(a); s.hi = lds16(a + 64);
@@ -160,6 +188,13 @@ __device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const Lane
 template <int TYPE, bool COH = false>
 __device__ __forceinline__ ActSlice global_slice(const MMVQArgs &a, int sb, const LaneRole &L) {
     ActSlice s;
+    if (TYPE == T_Q8_0) {
+        const int qo = sb * 256 + 32 * L.v;
+        s.lo = cld16<COH>(a.aq0, qo); s.hi = cld16<COH>(a.aq0, qo + 16);
+        s.bs_lo = 0; s.bs_hi = 0;
+        s.yd = h2f((uint16_t)(cld2s<COH>(a.ad0, (sb * 8 + L.v) * 2) & 0xffff));
+        return s;
+    }
     if (TYPE == T_Q6_K) {
         const int qo = sb * 256 + 128 * L.n + 16 * L.w;
         s.lo = cld16<COH>(a.aq, qo); s.hi = cld16<COH>(a.aq, qo + 64);
@@ -219,7 +254,7 @@ __device__ __forceinline__ void stage_issue(const MMVQArgs &a, u32x4_t (&rq)[Sta
     }
 }
 
-template <int KB, int NT, int FUSE>
+template <int KB, int NT, int FUSE, bool Q80 = false>
 __device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&rq)[StageDims<KB, NT>::NQ], const uint32_t (&rb)[StageDims<KB, NT>::NB32], float rdv,
                                              const f32x4_t (&rxv)[StageDims<KB, NT>::NJW], const f32x4_t (&rwv)[StageDims<KB, NT>::NJW], uint8_t *smem) {
     using S = StageDims<KB, NT>;
@@ -268,6 +303,13 @@ __device__ __forceinline__ ActL stage_finish(const MMVQArgs &a, const u32x4_t (&
                 v.x = (v.x * scale) * ww.x; v.y = (v.y * scale) * ww.y; v.z = (v.z * scale) * ww.z; v.w = (v.w * scale) * ww.w;
             }
             const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (Q80) {                                             // quantize_row_q8_0: the scale is stored as f16
+                uint32_t packed; float dd;
+                wave_quant_q80(vv, packed, dd);
+                *reinterpret_cast<uint32_t *>(qs + e0) = packed;
+                if ((lane & 7) == 0) reinterpret_cast<float *>(bs)[b * 8 + (lane >> 3)] = h2f(f2h(dd));
+                continue;
+            }
             uint32_t packed; int bsum; float dq;
             wave_quant_q8k(vv, lane, packed, bsum, dq);
             *reinterpret_cast<uint32_t *>(qs + e0) = packed;
@@ -373,7 +415,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     // ---- 3. activations into place (workgroup barrier inside the LDS paths: reached by every wave)
     ActL AL{nullptr, nullptr, nullptr};
     if (!DIRECT) {
-        AL = stage_finish<KB, NT, FUSE>(a, STAGE_REGS_ARGS, smem);
+        AL = stage_finish<KB, NT, FUSE, TYPE == T_Q8_0>(a, STAGE_REGS_ARGS, smem);
         if (ACT_REGS) {
             S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
             if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
