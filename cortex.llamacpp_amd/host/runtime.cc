@@ -393,6 +393,7 @@ bool Context::init(std::string &err) {
         if (!tp_active() || tp_size() != hp.tp_size || tp_rank() != hp.tp_rank) { err = "model was loaded as rank " + std::to_string(hp.tp_rank) + " of " + std::to_string(hp.tp_size) + " but the process has no matching row-split group (mi355_tp_init)"; return false; }
         tp_part_ = (float *)dalloc(T * E * 4);
         if (tp_uses_host()) cp.use_graphs = false;     // the host transport drains the stream inside the step
+        if (const char *tg = getenv("MI355_TP_GRAPHS")) { if (tg[0] == '0') cp.use_graphs = false; }
     }
     if (hp.n_expert > 0) {
         router_ = (float *)dalloc(T * hp.n_expert * 4);
@@ -1168,7 +1169,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
 
     const int V = model->hp.n_vocab;
     if (n == 1) (void)mega_prepare();      // allocates and uploads on first use: must not happen inside a stream capture
-    const bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
+    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
     hipError_t e = hipSuccess;
     if (graph_ok) {
         // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
@@ -1192,12 +1193,23 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
             }
             if (e == hipSuccess) e = hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0);
             if (g) (void)hipGraphDestroy(g);
-            if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
-            graphs_[bucket] = graph_exec_;
-            graph_is_mega_[graph_exec_] = last_layers_mega_;
+            if (e != hipSuccess && model->hp.tp_exchange) {
+                // a collective that cannot be captured on this RCCL / driver pair: every rank fails the same way, so all
+                // of them continue with eager launches from here on (nothing was executed during the failed capture)
+                (void)hipGetLastError();
+                cp.use_graphs = false;
+                graph_ok = false;
+                graph_exec_ = nullptr;
+                e = hipSuccess;
+            } else {
+                if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
+                graphs_[bucket] = graph_exec_;
+                graph_is_mega_[graph_exec_] = last_layers_mega_;
+            }
         }
-        e = hipGraphLaunch(graph_exec_, stream_);
-    } else {
+        if (graph_ok) e = hipGraphLaunch(graph_exec_, stream_);
+    }
+    if (!graph_ok) {
         prof_begin();
         chunk_cap_ = chunk_lmax_;
         e = run_layers(n, n_kv_);
