@@ -579,7 +579,8 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
 // Single-token step in ONE launch: K rope + KV store + attention + split merge + quantise (see DecodeFuse).
 bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
-    return a.T == 1 && flash_attn_decode_applicable(a, ra) && (R == 2 || R == 4 || R == 8) && (ra.n_rot % 4) == 0 && a.splits <= 64;
+    // (R = 1: two kv heads share a merge ticket, see attn_decode_dev.h)
+    return a.T == 1 && flash_attn_decode_applicable(a, ra) && (R == 2 || R == 4 || R == 8 || (R == 1 && a.G % 2 == 0)) && (ra.n_rot % 4) == 0 && a.splits <= 64;
 }
 // diagnosis: MI355_ATTN_PROBE=1 makes the fused decode attention stamp its phases (DecodeFuse::probe); the stamps of the
 // LAST launch are summarised on stderr by attn_probe_report() (called when a context is destroyed)
@@ -638,6 +639,7 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
     else FAD(RR, T_F16, T_Q8_0);
     switch (R) {
+        case 1: FAD_T(1) break;
         case 2: FAD_T(2) break;
         case 4: FAD_T(4) break;
         case 8: FAD_T(8) break;

@@ -298,7 +298,13 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     if (fz.counters == nullptr) return;               // store-fused only: the merge runs as its own launch
     if (fz.probe && tid == 0) fz.probe[2 * (sp * a.G + g) + 1] = wall_clock64();
 
-    // ---- FUSED: ticket; the last workgroup of this kv head merges
+    // ---- FUSED: ticket; the last workgroup of this kv head merges.  The merge also quantises whole 256-element blocks of
+    // the attention output, so with one 128-wide query head per kv head (R = 1, multi-head attention) TWO neighbouring kv
+    // heads share a ticket and the last arriver of the pair merges both: GP kv heads per ticket, RM = GP * R heads merged.
+    constexpr int GP = (R * D) % 256 == 0 ? 1 : 256 / (R * D);
+    constexpr int RM = R * GP;
+    const int gq = g / GP;                                     // ticket group
+    const int hb = gq * RM;                                    // its first query head
     const int stride_s = a.splits;                             // workspace stride; with a chunk list fewer slots are in use
     const int splits = a.tok_nchunks ? a.tok_nchunks[0] : a.splits;
     // every wave's partial stores must have reached L2 before thread 0 releases them device-wide: __syncthreads() fences
@@ -307,28 +313,28 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     __syncthreads();
     if (tid == 0) {
         // ONE release per workgroup (the barrier ordered the other waves' stores before it), then the ticket
-        const unsigned old = COH ? __hip_atomic_fetch_add(fz.counters + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : __hip_atomic_fetch_add(fz.counters + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (old == (unsigned)splits - 1u) ? 1 : 0;
-        if (last_flag) __hip_atomic_store(fz.counters + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        const unsigned old = COH ? __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (old == (unsigned)(splits * GP) - 1u) ? 1 : 0;
+        if (last_flag) __hip_atomic_store(fz.counters + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     __syncthreads();
     if (!last_flag) return;
     if (fz.probe && tid == 0) fz.probe[4096 + 8 * g] = wall_clock64();
-    float *wgt = S;                                    // [R][64] split weights (S is free now: R * C floats)
-    float *merged = accs;                              // [R * D]
+    float *merged = accs;                              // [RM * D]
+    float *wgt = GP > 1 ? accs + RM * D : S;           // [RM][64] split weights (S is free now, but holds R * C floats only)
     // The merge is a chain of memory round trips (~1.5 us each: the partials come from other XCDs).  Every output still
     // sums its splits in order (the combine kernel's arithmetic), but the partials of the first 32 splits of all of this
     // thread's outputs are requested BEFORE the (m, l) pairs, so the weight computation runs under them: ticket, one trip
     // for (m, l) + 32 splits, one more per further 32 splits (it was ticket + (m, l) + one trip per 8 splits and output).
-    constexpr int NE = (R * D + 255) / 256, UB = 32;
+    constexpr int NE = (RM * D + 255) / 256, UB = 32;
     float macc[NE], x[NE][UB];
     const float *pp[NE];
     int wr[NE];
 #pragma unroll
     for (int j = 0; j < NE; j++) {
-        const int e = tid + 256 * j < R * D ? tid + 256 * j : 0, r = e / D, d = e - r * D;
-        pp[j] = a.part + ((size_t)g * R + r) * stride_s * (D + 2) + d;
+        const int e = tid + 256 * j < RM * D ? tid + 256 * j : 0, r = e / D, d = e - r * D;
+        pp[j] = a.part + ((size_t)hb + r) * stride_s * (D + 2) + d;
         wr[j] = r * 64;
         macc[j] = 0.0f;
     }
@@ -341,8 +347,8 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         }
     };
     request(0);
-    for (int r = wave; r < R; r += 4) {                // same arithmetic as flash_attn_combine_kernel
-        const float *p = a.part + ((size_t)g * R + r) * stride_s * (D + 2);
+    for (int r = wave; r < RM; r += 4) {               // same arithmetic as flash_attn_combine_kernel
+        const float *p = a.part + ((size_t)hb + r) * stride_s * (D + 2);
         float m = -INFINITY, l = 0.0f;
         if (lane < splits) {
             m = __hip_atomic_load(p + (size_t)lane * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -372,16 +378,16 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
 #pragma unroll
     for (int j = 0; j < NE; j++) {
         const int e = tid + 256 * j;
-        if (e < R * D) { merged[e] = macc[j]; a.out[(size_t)g * R * D + e] = macc[j]; }
+        if (e < RM * D) { merged[e] = macc[j]; a.out[(size_t)hb * D + e] = macc[j]; }
     }
     if (fz.probe && tid == 0) fz.probe[4096 + 8 * g + 2] = wall_clock64();
     __syncthreads();
-    constexpr int NBLK = (R * D) >> 8;                 // 256-blocks this kv head owns in the H*D row
+    constexpr int NBLK = (RM * D) >> 8;                // 256-blocks this ticket group owns in the H*D row
     if (wave < NBLK && (fz.want_q8k || fz.want_q80)) {
         for (int b = wave; b < NBLK; b += 4) {
             const float4 v4 = *reinterpret_cast<const float4 *>(merged + b * 256 + lane * 4);
             const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-            const int gb = ((g * R * D) >> 8) + b;     // global block index
+            const int gb = ((hb * D) >> 8) + b;        // global block index
             const int e0 = gb * 256 + lane * 4;
             if (fz.want_q8k) {
                 uint32_t packed; int bs; float dq8;
