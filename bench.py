@@ -319,7 +319,8 @@ def main() -> int:
 
     # ---- roofline of the dominant kernel (quantised mat-vec), HIP events on the kernel's own stream
     sweep_us, sweep_bytes = ctx.weight_sweep_us(iters=5)
-    n_launch = cfg.n_layer * 4 + 1                        # qkv, attn_output, gate+up, down per layer + lm-head
+    n_launch = cfg.n_layer * 4 + 1                        # qkv, attn_output, gate+up, down per layer (all selected experts of a
+                                                          # mixture-of-experts layer share the two launches) + lm-head
     achieved = sweep_bytes / (sweep_us * 1e-6) / 1e9
     hbm_read = pkg.Backend().hbm_read_gbps(2 << 30, 5)
 

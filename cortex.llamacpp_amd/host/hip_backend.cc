@@ -67,7 +67,8 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     if (body.value<int>("ngl", 300) <= 0) { err = "ngl=0 requested: this engine is device-only (no CPU path)"; return nullptr; }
 
     int status = 0;
-    std::unique_ptr<Model> model(model_load(path, body.value<int>("main_gpu", 0), err, status, body.value<int>("prefill_planes", -1)));
+    std::unique_ptr<Model> model(model_load(path, body.value<int>("main_gpu", 0), err, status, body.value<int>("prefill_planes", -1),
+                                            body.value<int>("tp_rank", 0), body.value<int>("tp_size", 1)));   // row split: the process's group is formed first (mi355_tp_init)
     if (!model) return nullptr;
 
     Vocab vocab;

@@ -1352,7 +1352,34 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
     auto sweep = [&](bool count) -> hipError_t {
         for (int il = 0; il < hp.n_layer; il++) {
             const LayerWeights &L = model->layers[(size_t)il];
-            if (hp.n_expert > 0) continue;
+            if (hp.n_expert > 0) {
+                // mixture of experts: the attention projections and the token's n_expert_used experts (indices 0..k-1 stand in
+                // for a selection; every expert has the same shape and bytes)
+                const int KU = hp.n_expert_used;
+                if (!moe_ids_ || KU < 1 || KU > 8 || (int)cp.n_ubatch < KU || L.gate_exps.type != L.up_exps.type) continue;
+                if (count) { std::vector<int32_t> ids((size_t)KU); for (int j = 0; j < KU; j++) ids[(size_t)j] = j; HIP_TRY(hipMemcpy(moe_ids_, ids.data(), ids.size() * 4, hipMemcpyHostToDevice)); }
+                const DevTensor *wsm[3] = {&L.wq, &L.wk, &L.wv};
+                float *outm[3] = {q_, k_, v_};
+                pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
+                HIP_TRY(linear_multi(wsm, outm, 3, aq_e_, xn_, 1));
+                pending_fuse_ = Fuse();
+                HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, nullptr, EPI_STORE));
+                MMVQArgs a{};
+                a.n_seg = 2; a.K = E; a.T = 1; a.epi = EPI_SWIGLU; a.n_sel = KU; a.sel_out_stride = FF;
+                a.seg[0] = make_seg(L.gate_exps, ffn_, FF, nullptr, moe_ids_);
+                a.seg[1] = make_seg(L.up_exps, ffn_u_, FF, nullptr, moe_ids_);
+                chunk_act(a, aq_e_, E, 0);
+                MMVQArgs d{};
+                d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE; d.fuse_mode = 2; d.nx = ffn_; d.n_sel = KU; d.sel_nx_stride = FF; d.sel_out_stride = E;
+                d.seg[0] = make_seg(L.down_exps, moe_out_, E, nullptr, moe_ids_);
+                chunk_act(d, aq_ff_, FF, 0);
+                if (!mmvq_fast_applicable(a) || !mmvq_fast_applicable(d)) continue;
+                HIP_TRY(launch_mmvq_fast(a, stream_));
+                HIP_TRY(launch_mmvq_fast(d, stream_));
+                if (count) bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + L.wo.ggml_bytes +
+                                    (L.gate_exps.ggml_bytes + L.up_exps.ggml_bytes + L.down_exps.ggml_bytes) / (uint64_t)L.gate_exps.n_expert * (uint64_t)KU;
+                continue;
+            }
             const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
             float *outs[3] = {q_, k_, v_};
             HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
