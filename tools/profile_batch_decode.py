@@ -19,7 +19,7 @@ if not os.path.exists(path):
     gs.write_synthetic_llama(path, gs.CONFIGS["llama-3-8b"], "q4_k_m", seed=0xC0FFEE, with_vocab=False)
 model = pkg.Model(path)
 n_ctx = B * (P + 96)
-ctx = pkg.Context(model, n_ctx=n_ctx, n_batch=2048, n_ubatch=512, n_seq_max=B, type_k=8, type_v=8, logits_to_host=False, use_graphs=False)
+ctx = pkg.Context(model, n_ctx=n_ctx, n_batch=2048, n_ubatch=512, n_seq_max=B, type_k=8, type_v=8, logits_to_host=False, use_graphs=os.environ.get("GRAPHS", "1") == "1")
 rng = np.random.default_rng(1)
 for s in range(B):
     prompt = rng.integers(0, model.n_vocab, P)
