@@ -1,5 +1,5 @@
 // attn_prefill.hip — prompt-processing attention on the matrix cores (ggml_flash_attn_ext for T >= 32 query rows;
-// SURVEY.md §8a row a11), head_dim 128, q8_0 K and V cache.
+// SURVEY.md §8a row a11), head_dim 128, q8_0 K and V cache — and, at the end of this comment, the f16 cache.
 //
 // Same arithmetic as the CPU path it stands in for (flash_attn_ext with a q8_0 K cache: q is quantised to Q8_0 per
 // 32-block and K.q is vec_dot_q8_0_q8_0 = sum_b float(int dot) * (d_q * d_k); V rows are dequantised and accumulated in
@@ -19,6 +19,10 @@
 //     sequences and fragmented caches take the same path; a prologue pass over the cell table marks the chunks that hold
 //     a cell visible to some query of the tile, the main loop walks only those, with the next one's K / V in flight
 //     (registers) while the current one is on the matrix cores.
+// F16 = true (f16 K and V cache, the reference's default cache type): the CPU path converts q to f16 and takes
+// vec_dot_f16 against the K row, so S^T = K . Q^T is eight v_mfma_f32_32x32x16_f16 per chunk (K rows as halfs in LDS, Q as
+// halfs in registers, f32 accumulation, no block scales); V rows are already f16, so the hi plane IS V and the lo plane
+// (and its product) disappear: O^T += V^T . (Ph + Pl)^T.  Everything else — visibility, online softmax, staging order — is shared.
 #include "kernels.h"
 #include "quant_dev.h"
 
@@ -35,6 +39,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int D = 128, NB = 4, CK = 32, QT = 32;      // head dim, 32-blocks per row, keys per chunk, queries per tile
 constexpr int K_STRIDE = 144;                         // 128 codes + 16 B pad: ds_read_b128 conflict-free
+constexpr int KF_STRIDE = 272;                        // f16 cache: 128 halfs + 16 B pad
 constexpr int MAX_CHUNKS = 8192;                      // 262144 cells
 
 // LDS layout of one chunk
@@ -49,13 +54,15 @@ struct Chunk {
 // key index (0..31) of MFMA K-slot (j, kg, i): the order the score tile leaves its 16 keys per lane in registers
 __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 8 * (i >> 2) + 4 * kg + (i & 3); }
 
-template <int R>
+template <int R, bool F16>
 __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int KS = F16 ? KF_STRIDE : K_STRIDE;    // bytes per staged K row
+    constexpr int PPK = F16 ? 16 : 8;                 // 16-byte pieces per K / V row
     Chunk S;
     S.k = reinterpret_cast<int8_t *>(smem);
-    S.dk = reinterpret_cast<float *>(smem + CK * K_STRIDE);
-    S.vh = reinterpret_cast<_Float16 *>(smem + CK * K_STRIDE + NB * CK * 4);
+    S.dk = reinterpret_cast<float *>(smem + CK * KS);
+    S.vh = reinterpret_cast<_Float16 *>(smem + CK * KS + NB * CK * 4);
     S.vl = S.vh + 4 * 2 * 2 * 32 * 8;
     S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
     S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
@@ -88,10 +95,22 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         atomicOr(&s_tile_seqs, 1ull << tseq);
     }
 
-    // ---- Q of this lane's query: quantise to Q8_0 per 32-block (lane holds dims 32 b + 16 kg .. + 15 of block b)
+    // ---- Q of this lane's query: quantise to Q8_0 per 32-block (lane holds dims 32 b + 16 kg .. + 15 of block b);
+    //      f16 cache: round to f16, lane holds dims 16 j + 8 kg .. + 7 of K-step j
     i32x4 qc[NB];
     float dq[NB];
-    {
+    f16x8 qh[F16 ? 8 : 1];
+    if constexpr (F16) {
+        const float *qrow = a.q + ((size_t)qt * H + h) * D;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(qrow + 16 * j + 8 * kg), x1 = *reinterpret_cast<const f32x4 *>(qrow + 16 * j + 8 * kg + 4);
+            qh[j][0] = (_Float16)x0.x; qh[j][1] = (_Float16)x0.y; qh[j][2] = (_Float16)x0.z; qh[j][3] = (_Float16)x0.w;
+            qh[j][4] = (_Float16)x1.x; qh[j][5] = (_Float16)x1.y; qh[j][6] = (_Float16)x1.z; qh[j][7] = (_Float16)x1.w;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) { qc[b] = i32x4{0, 0, 0, 0}; dq[b] = 0.0f; }
+    } else {
         const float *qrow = a.q + ((size_t)qt * H + h) * D;
 #pragma unroll
         for (int b = 0; b < NB; b++) {
@@ -115,8 +134,8 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         }
     }
 
-    // ---- staging roles: piece p = tid (+ NT) -> key p / 8, 16-byte column p % 8 of the 128-byte K / V rows
-    constexpr int NP = (CK * 8 + NT - 1) / NT;
+    // ---- staging roles: piece p = tid (+ NT) -> key p / PPK, 16-byte column p % PPK of the 128- (q8_0) or 256-byte (f16) K / V rows
+    constexpr int NP = (CK * PPK + NT - 1) / NT;
     u32x4 kq[NP], vq[NP];
     constexpr int NKD = (CK * NB + NT - 1) / NT;
     float kdn[NKD], vdn[NP];
@@ -126,17 +145,23 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int p = tid + NT * i;
-            int key = p >> 3;
+            int key = p / PPK;
             if (key >= CK) key = CK - 1;
             int cell = c * CK + key;
             if (cell >= n_ctx) cell = n_ctx - 1;
             const size_t rowi = head_row0 + cell;
-            kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p & 7) * 16);
-            vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D + (p & 7) * 16);
-            vdn[i] = h2f(a.kv.vd[rowi * NB + ((p & 7) >> 1)]);
+            if constexpr (F16) {
+                kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D * 2 + (p % PPK) * 16);
+                vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D * 2 + (p % PPK) * 16);
+                vdn[i] = 0.0f;
+            } else {
+                kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p & 7) * 16);
+                vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D + (p & 7) * 16);
+                vdn[i] = h2f(a.kv.vd[rowi * NB + ((p & 7) >> 1)]);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NKD; i++) {
+        for (int i = 0; i < (F16 ? 0 : NKD); i++) {
             int q = tid + NT * i;
             if (q >= CK * NB) q = CK * NB - 1;
             int cell = c * CK + (q & 31);
@@ -151,13 +176,23 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int p = tid + NT * i;
-            if (p >= CK * 8) continue;
-            const int key = p >> 3, col = p & 7;               // dims 16 col .. 16 col + 15
-            *reinterpret_cast<u32x4 *>(S.k + key * K_STRIDE + col * 16) = kq[i];
+            if (p >= CK * PPK) continue;
+            const int key = p / PPK, col = p % PPK;            // q8_0: dims 16 col .. + 15; f16: dims 8 col .. + 7
+            *reinterpret_cast<u32x4 *>(S.k + key * KS + col * 16) = kq[i];
             // V' = code * d_v, split exactly into f16 hi + lo, written transposed in MFMA K-slot order
             const int j = key >> 4, r8 = key & 15;              // key = 16 j + 8 (i >> 2) + 4 kgs + (i & 3)
             const int kgs = (r8 >> 2) & 1, slot = ((r8 >> 3) << 2) | (r8 & 3);
             const uint32_t wv[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
+            if constexpr (F16) {                               // V is f16 already: the hi plane is V itself, there is no lo plane
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int dim = col * 8 + e;
+                    const uint16_t hb = (uint16_t)((wv[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                    const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot;
+                    reinterpret_cast<uint16_t *>(S.vh)[o] = hb;
+                }
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int dim = col * 16 + e;
@@ -169,7 +204,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
             }
         }
 #pragma unroll
-        for (int i = 0; i < NKD; i++) {
+        for (int i = 0; i < (F16 ? 0 : NKD); i++) {
             const int q = tid + NT * i;
             if (q < CK * NB) S.dk[(q >> 5) * CK + (q & 31)] = kdn[i];
         }
@@ -225,8 +260,20 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
             float sc[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) sc[r] = 0.0f;
+            if constexpr (F16) {
+                f32x16 sa;
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
+                for (int r = 0; r < 16; r++) sa[r] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const f16x8 ak = *reinterpret_cast<const f16x8 *>(S.k + n * KS + (16 * j + 8 * kg) * 2);
+                    sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, qh[j], sa, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) sc[r] = sa[r];
+            }
+#pragma unroll
+            for (int b = 0; b < (F16 ? 0 : NB); b++) {
                 const i32x4 ak = *reinterpret_cast<const i32x4 *>(S.k + n * K_STRIDE + 32 * b + 16 * kg);
                 i32x16 z;
 #pragma unroll
@@ -287,7 +334,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                     const f16x8 avl = *reinterpret_cast<const f16x8 *>(S.vl + o);
                     O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, ph[j], O[db], 0, 0, 0);
                     O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, pl[j], O[db], 0, 0, 0);
-                    O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, ph[j], O[db], 0, 0, 0);
+                    if constexpr (!F16) O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, ph[j], O[db], 0, 0, 0);
                 }
         }
         __syncthreads();                                        // chunk c consumed
@@ -315,21 +362,25 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
 
 bool flash_attn_prefill_applicable(const AttnArgs &a) {
     const int R = a.G > 0 ? a.H / a.G : 0;
-    return a.D == 128 && a.T >= 32 && a.type_k == T_Q8_0 && a.type_v == T_Q8_0 && (R == 1 || R == 2 || R == 4 || R == 8) &&
+    return a.D == 128 && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16)) && (R == 1 || R == 2 || R == 4 || R == 8) &&
            a.n_kv_max <= MAX_CHUNKS * CK;
 }
 
 hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
     const int R = a.H / a.G;
     const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT));
-    const size_t lds = (size_t)CK * K_STRIDE + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
+    const bool f16 = a.type_k == T_F16;
+    const size_t lds = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
+#define FAP(RR) do { if (f16) hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true>), grid, dim3(64 * RR), lds, st, a); \
+                     else hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false>), grid, dim3(64 * RR), lds, st, a); } while (0)
     switch (R) {
-        case 1: hipLaunchKernelGGL(flash_attn_prefill_kernel<1>, grid, dim3(64), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(flash_attn_prefill_kernel<2>, grid, dim3(128), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(flash_attn_prefill_kernel<4>, grid, dim3(256), lds, st, a); break;
-        case 8: hipLaunchKernelGGL(flash_attn_prefill_kernel<8>, grid, dim3(512), lds, st, a); break;
+        case 1: FAP(1); break;
+        case 2: FAP(2); break;
+        case 4: FAP(4); break;
+        case 8: FAP(8); break;
         default: return hipErrorInvalidValue;
     }
+#undef FAP
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.out_q) e = launch_quantize(a.out, a.H * a.D, a.T, *a.out_q, a.out_q8k, a.out_q80, st);

@@ -60,7 +60,9 @@ def rel_err(a, b):
                                           # 8 x 128 KV heads: single-launch decode attention (rope + store + merge fused)
                                           ("tiny-g8", "q4_k_m", "q8_0"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-g8:70", "q4_k_m", "q8_0"),
                                           # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads)
-                                          ("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l:70", "q5_k_m", "f16")])
+                                          ("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l:70", "q5_k_m", "f16"),
+                                          # f16 cache, 40-token prompts: the matrix-core prompt attention with f16 K / V (GQA 4:1 and MHA)
+                                          ("tiny-d128:40", "q4_k_m", "f16"), ("tiny-d128-mha:40", "q5_k_m", "f16")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)

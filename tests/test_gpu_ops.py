@@ -207,16 +207,20 @@ def test_flash_attn(be, tk, tv, tol, H, G, D, n_cells):
         assert np.abs(out[i] - ref).max() <= tol, (i, np.abs(out[i] - ref).max())
 
 
+@pytest.mark.parametrize("tkv,tol", [(Q8_0, 2e-5), (F16, 2e-5)])
 @pytest.mark.parametrize("H,G,n_cells,T", [(8, 2, 70, 40), (32, 8, 300, 33), (4, 4, 129, 64), (16, 2, 1000, 37)])
-def test_flash_attn_prefill_matrix_cores(be, H, G, n_cells, T):
-    """Prompt-processing attention on the MFMA path (T >= 32 query rows, head_dim 128, q8_0 K / V): ragged query tile,
-    ragged last key chunk, holes in the cache, queries that see one cell only, R = 1 / 4 / 8 heads per kv head."""
+def test_flash_attn_prefill_matrix_cores(be, H, G, n_cells, T, tkv, tol):
+    """Prompt-processing attention on the MFMA path (T >= 32 query rows, head_dim 128, q8_0 or f16 K / V): ragged query
+    tile, ragged last key chunk, holes in the cache, queries that see one cell only, R = 1 / 4 / 8 heads per kv head.
+    f16: the CPU path accumulates V in fp16 and is itself only good to ~1e-2 over hundreds of cells, so the tight comparison
+    is against the restatement with that accumulation in f32 (oq.set_fa_v_acc_f32) — the HIP kernel agrees with it to 1e-6 —
+    and the stock fp16 mode is checked at its own noise level."""
     D = 128
     rng = np.random.default_rng(H * 1000 + n_cells + T)
     kf = rng.standard_normal((n_cells, G * D)).astype(np.float32)
     vf = (rng.standard_normal((n_cells, G * D)) * rng.uniform(0.2, 3.0, (n_cells, 1))).astype(np.float32)
-    kc = np.stack([oq.quantize(Q8_0, r) for r in kf])
-    vc = np.stack([oq.quantize(Q8_0, r) for r in vf])
+    kc = np.stack([oq.quantize(tkv, r) for r in kf])
+    vc = np.stack([oq.quantize(tkv, r) for r in vf])
     cell_pos = np.arange(n_cells, dtype=np.int32)
     cell_pos[rng.random(n_cells) < 0.1] = -1            # holes
     cell_pos[0] = 0
@@ -225,8 +229,17 @@ def test_flash_attn_prefill_matrix_cores(be, H, G, n_cells, T):
     q_pos[-1] = n_cells - 1
     q = rng.standard_normal((T, H, D)).astype(np.float32)
     scale = 1 / np.sqrt(D)
-    out = be.flash_attn(q, H, G, D, Q8_0, kc, Q8_0, vc, cell_pos, q_pos, scale)
-    for i in range(0, T, 3):
-        cells = np.nonzero((cell_pos >= 0) & (cell_pos <= q_pos[i]))[0].astype(np.int32)
-        ref = oq.flash_attn(q[i], H, G, D, Q8_0, kc, Q8_0, vc, cells, scale)
-        assert np.abs(out[i] - ref).max() <= 2e-5, (i, np.abs(out[i] - ref).max())
+    out = be.flash_attn(q, H, G, D, tkv, kc, tkv, vc, cell_pos, q_pos, scale)
+    oq.set_fa_v_acc_f32(1 if tkv == F16 else 0)
+    try:
+        for i in range(0, T, 3):
+            cells = np.nonzero((cell_pos >= 0) & (cell_pos <= q_pos[i]))[0].astype(np.int32)
+            ref = oq.flash_attn(q[i], H, G, D, tkv, kc, tkv, vc, cells, scale)
+            assert np.abs(out[i] - ref).max() <= tol * max(1.0, float(np.abs(ref).max())), (i, np.abs(out[i] - ref).max())
+    finally:
+        oq.set_fa_v_acc_f32(0)
+    if tkv == F16:
+        for i in range(0, T, 7):
+            cells = np.nonzero((cell_pos >= 0) & (cell_pos <= q_pos[i]))[0].astype(np.int32)
+            ref = oq.flash_attn(q[i], H, G, D, tkv, kc, tkv, vc, cells, scale)
+            assert np.abs(out[i] - ref).max() <= 2e-2 * max(1.0, float(np.abs(ref).max())), (i, np.abs(out[i] - ref).max())
