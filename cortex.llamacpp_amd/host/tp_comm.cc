@@ -29,6 +29,7 @@ struct Group {
     void *host_user = nullptr;
     float *pinned = nullptr;          // host transport staging
     size_t pinned_floats = 0;
+    bool null_group = false;          // tp_set_null_group
 };
 
 RcclApi g_api;
@@ -108,6 +109,12 @@ void tp_set_host_exchange(tp_host_exchange_fn fn, void *user, int rank, int size
     else if (!g_grp.comm) { g_grp.rank = 0; g_grp.size = 1; }
 }
 
+void tp_set_null_group(int rank, int size) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_grp.comm || g_grp.host_fn) return;
+    g_grp.null_group = size >= 1; g_grp.rank = rank; g_grp.size = size >= 1 ? size : 1;
+}
+
 void tp_shutdown() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_grp.comm && g_api.CommDestroy) (void)g_api.CommDestroy(g_grp.comm);
@@ -115,9 +122,9 @@ void tp_shutdown() {
     g_grp = Group();
 }
 
-bool tp_active() { return g_grp.comm != nullptr || g_grp.host_fn != nullptr; }
+bool tp_active() { return g_grp.comm != nullptr || g_grp.host_fn != nullptr || g_grp.null_group; }
 int tp_rank() { return g_grp.rank; }
-int tp_size() { return (g_grp.comm || g_grp.host_fn) ? g_grp.size : 1; }
+int tp_size() { return (g_grp.comm || g_grp.host_fn || g_grp.null_group) ? g_grp.size : 1; }
 bool tp_uses_host() { return g_grp.host_fn != nullptr; }
 
 hipError_t tp_all_reduce_sum(const float *send, float *recv, size_t n, hipStream_t st) {

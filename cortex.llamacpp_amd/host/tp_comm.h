@@ -23,6 +23,9 @@ typedef int (*tp_host_exchange_fn)(void *user, float *buf, size_t n, int op);
 int tp_unique_id(void *out, size_t cap, std::string &err);                       // 128 bytes (ncclGetUniqueId), made by rank 0
 int tp_init(int rank, int size, const void *id, size_t id_len, std::string &err); // ncclCommInitRank on the current device
 void tp_set_host_exchange(tp_host_exchange_fn fn, void *user, int rank, int size);
+// Measurement aid: a group of `size` ranks of which only this one exists — every exchange degenerates to a device copy of
+// this rank's own part (results are NOT the model's; timings are this rank's compute without communication).
+void tp_set_null_group(int rank, int size);
 void tp_shutdown();
 int tp_rank();
 bool tp_active();         // a group exists (possibly of one rank)

@@ -225,7 +225,10 @@ MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_
  * K-quant model with Llama-3-8B's layer geometry run every layer in one launch; 0, the default: one launch per operation
  * — both produce the same bits; the single launch measured slower); "moe_group_min" (batches of at least
  * this many tokens run a mixture-of-experts feed-forward grouped by expert, default 8; smaller ones loop over (token,
- * expert) with the mat-vec).  Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
+ * expert) with the mat-vec); "tp_null_group" (measurement aid: the process becomes rank 0 of a row-split group of `value`
+ * ranks whose other members do not exist — every exchange is a device copy of this rank's own part, so a model loaded with
+ * tp_rank 0 / tp_size value times ONE rank's compute without communication; its outputs are not the model's).
+ * Returns MI355_OK or MI355_ERR_ARG for an unknown name. */
 MI355_API int mi355_debug_set_option(const char *name, int32_t value);
 
 /* ------------------------------------------------------------------ row split across GPUs (one process per GPU)
