@@ -84,6 +84,10 @@ struct MMQSeg {
 bool mmq_q80_applicable(int type, int K, int T);
 hipError_t launch_mmq_q80(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, float *out, int ld_out,
                           const float *resid, hipStream_t st);
+// up to three tensors of one plane format (Q4_K / Q5_K together, or Q6_K) whose plane sets are contiguous in memory, as one
+// launch over the concatenated rows; seg_rows[i] rows go to outs[i] (leading dimension lds_out[i])
+hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
+                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st);
 bool mmq_ksplit_applicable(int type, int K, int T);
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st);

@@ -671,7 +671,19 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     }
     if (all_mmq && pending_fuse_.mode == 0) {
         HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
-        for (int i = 0; i < n; i++) {
+        // Q | K | V (or Q | K) as one launch over the concatenated rows where their plane sets are adjacent in the arena and
+        // of one plane format (Q4_K and Q5_K share it; the Q6_K attn_v of the "more bits" layers runs on its own)
+        auto mins = [](int t) { return t != T_Q6_K; };
+        int nf = 1;
+        while (nf < n && nf < 3 && ws[nf]->planes && ws[nf - 1]->planes && ws[nf]->planes == ws[nf - 1]->planes + ws[nf - 1]->planes_bytes &&
+               mins(ws[nf]->type) == mins(ws[0]->type) && (ws[nf - 1]->N % 32) == 0 && ws[nf]->n_expert == 1) nf++;
+        if (nf >= 2) {
+            int rows[3], ldo[3];
+            float *o[3];
+            for (int i = 0; i < nf; i++) { rows[i] = (int)ws[i]->N; ldo[i] = (int)ws[i]->N; o[i] = outs[i]; }
+            HIP_TRY(launch_mmq_planes_multi(ws[0]->type, ws[0]->planes, rows, o, ldo, nf, K, T, aq, mmq_bh_, mmq_bl_, nullptr, stream_));
+        } else nf = 0;
+        for (int i = nf; i < n; i++) {
             if (ws[i]->planes) HIP_TRY(launch_mmq_planes(ws[i]->type, ws[i]->planes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
             else HIP_TRY(launch_mmq(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
         }
