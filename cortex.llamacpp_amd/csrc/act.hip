@@ -76,6 +76,40 @@ hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool
     return hipGetLastError();
 }
 
+// SwiGLU and the quantisation of its result for the down projection in one pass (prompt batches): y = silu(g) * u is
+// quantised block by block as norm_quant_kernel does and never written as f32 — the arithmetic of swiglu_kernel followed by
+// the quantiser, so the blocks are bit-identical to the two launches it replaces.
+__global__ __launch_bounds__(256) void swiglu_quant_kernel(const float *__restrict__ g, const float *__restrict__ u, int n, ActQuant q,
+                                                           int want_q8k, int want_q80) {
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = n >> 8;
+    for (int b = blockIdx.y * 4 + wave; b < nblk; b += 4 * gridDim.y) {
+        const int e0 = b * 256 + lane * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(g + (size_t)row * n + e0), c = *reinterpret_cast<const float4 *>(u + (size_t)row * n + e0);
+        const float vv[4] = {(a.x / (1.0f + expf(-a.x))) * c.x, (a.y / (1.0f + expf(-a.y))) * c.y, (a.z / (1.0f + expf(-a.z))) * c.z,
+                             (a.w / (1.0f + expf(-a.w))) * c.w};
+        if (want_q8k) {
+            uint32_t packed; int bs; float dq;
+            wave_quant_q8k(vv, lane, packed, bs, dq);
+            *reinterpret_cast<uint32_t *>(q.qs + (size_t)row * n + e0) = packed;
+            if ((lane & 3) == 0) q.bsums[(size_t)row * (n >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+            if (lane == 0) q.d[(size_t)row * nblk + b] = dq;
+        }
+        if (want_q80) {
+            uint32_t packed; float d;
+            wave_quant_q80(vv, packed, d);
+            *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)row * n + e0) = packed;
+            if ((lane & 7) == 0) q.d0[(size_t)row * (n >> 5) + b * 8 + (lane >> 3)] = f2h(d);
+        }
+    }
+}
+hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st) {
+    if ((n % 256) != 0 || T <= 0) return hipErrorInvalidValue;
+    const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
+    hipLaunchKernelGGL(swiglu_quant_kernel, dim3(T, splits), dim3(256), 0, st, g, u, n, q, (int)want_q8k, (int)want_q80);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- elementwise
 __global__ void swiglu_kernel(const float *g, const float *u, float *y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

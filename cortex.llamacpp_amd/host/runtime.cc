@@ -933,8 +933,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     HIP_TRY(linear(view(L.gate_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_g_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
                     HIP_TRY(linear(view(L.up_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_ug_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
                 }
-                HIP_TRY(launch_swiglu(ffn_g_, ffn_ug_, ffn_g_, (int64_t)GR * FF, stream_));
-                HIP_TRY(launch_quantize(ffn_g_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                HIP_TRY(launch_swiglu_quant(ffn_g_, ffn_ug_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
                 for (int e = 0; e < NE; e++) {
                     const int n_e = h_moe_meta_[e], r0 = h_moe_meta_[NE + e];
                     if (n_e <= 0) continue;
@@ -1008,6 +1007,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
                 prof_mark("norm_quant");
             }
+            bool swiglu_quantised = false;
             const bool ffn_mmq = (mmq_q80_applicable(L.gate.type, E, T) && mmq_q80_applicable(L.up.type, E, T)) ||
                                  (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
                                  (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T));
@@ -1025,7 +1025,13 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             } else {
                 HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
-                HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
+                // prompt batch: SwiGLU and the quantisation for the down projection in one pass (no f32 round trip of T x FF)
+                if (T > 1 && is_quant(L.down.type) && (FF % 256) == 0) {
+                    HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
+                    swiglu_quantised = true;
+                } else {
+                    HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
+                }
             }
             prof_mark("ffn_gate_up");
             static const bool fuse_down_env = !(getenv("MI355_FUSE_DOWN") && getenv("MI355_FUSE_DOWN")[0] == '0');
@@ -1034,7 +1040,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                                    (FF % 256) == 0 && [](int kb) { return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 14; }((FF + 2047) / 2048);
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
-            } else if (is_quant(L.down.type)) {
+            } else if (is_quant(L.down.type) && !swiglu_quantised) {
                 HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
                 prof_mark("quant");
             }
