@@ -14,7 +14,7 @@ namespace mi355 {
 // One workgroup per row.  do_norm: y = (x * rsqrt(mean(x^2)+eps)) * w, else y = x.
 __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                          int n, float eps, int do_norm, float *__restrict__ yf,
-                                                         ActQuant q, int want_q8k, int want_q80) {
+                                                         ActQuant q, int want_q8k, int want_q80, int8_t *__restrict__ bh, int8_t *__restrict__ bl) {
     __shared__ double red[4];
     // grid = (rows, splits): each workgroup re-derives the row scale (cheap, L2-resident) and quantises its share of blocks
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict
             uint32_t packed; int bs; float dq;
             wave_quant_q8k(vv, lane, packed, bs, dq);
             *reinterpret_cast<uint32_t *>(q.qs + (size_t)row * n + e0) = packed;
-            if ((lane & 3) == 0) q.bsums[(size_t)row * (n >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+            if ((lane & 3) == 0) {
+                const size_t bi = (size_t)row * (n >> 4) + b * 16 + (lane >> 2);
+                q.bsums[bi] = (int16_t)bs;
+                if (bh) { const int hi = bs >> 6; bh[bi] = (int8_t)hi; bl[bi] = (int8_t)(bs - 64 * hi); }   // mmq_prep_kernel's split, for the MFMA kernels
+            }
             if (lane == 0) q.d[(size_t)row * nblk + b] = dq;
         }
         if (want_q80) {
@@ -60,19 +64,19 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict
 }
 
 hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, float eps, float *y_f32,
-                                const ActQuant *q, bool want_q8k, bool want_q80, hipStream_t st) {
+                                const ActQuant *q, bool want_q8k, bool want_q80, hipStream_t st, int8_t *bh, int8_t *bl) {
     ActQuant qq;
     if (q) qq = *q;
     const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
     hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, w, n, eps, 1, y_f32, qq,
-                       (int)(q && want_q8k), (int)(q && want_q80));
+                       (int)(q && want_q8k), (int)(q && want_q80), (q && want_q8k) ? bh : nullptr, bl);
     return hipGetLastError();
 }
 
-hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st) {
+hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st, int8_t *bh, int8_t *bl) {
     const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
     hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, (const float *)nullptr, n, 0.0f, 0,
-                       (float *)nullptr, q, (int)want_q8k, (int)want_q80);
+                       (float *)nullptr, q, (int)want_q8k, (int)want_q80, want_q8k ? bh : nullptr, bl);
     return hipGetLastError();
 }
 
@@ -80,7 +84,7 @@ hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool
 // quantised block by block as norm_quant_kernel does and never written as f32 — the arithmetic of swiglu_kernel followed by
 // the quantiser, so the blocks are bit-identical to the two launches it replaces.
 __global__ __launch_bounds__(256) void swiglu_quant_kernel(const float *__restrict__ g, const float *__restrict__ u, int n, ActQuant q,
-                                                           int want_q8k, int want_q80) {
+                                                           int want_q8k, int want_q80, int8_t *__restrict__ bh, int8_t *__restrict__ bl) {
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = n >> 8;
     for (int b = blockIdx.y * 4 + wave; b < nblk; b += 4 * gridDim.y) {
@@ -92,7 +96,11 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const float *__restri
             uint32_t packed; int bs; float dq;
             wave_quant_q8k(vv, lane, packed, bs, dq);
             *reinterpret_cast<uint32_t *>(q.qs + (size_t)row * n + e0) = packed;
-            if ((lane & 3) == 0) q.bsums[(size_t)row * (n >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+            if ((lane & 3) == 0) {
+                const size_t bi = (size_t)row * (n >> 4) + b * 16 + (lane >> 2);
+                q.bsums[bi] = (int16_t)bs;
+                if (bh) { const int hi = bs >> 6; bh[bi] = (int8_t)hi; bl[bi] = (int8_t)(bs - 64 * hi); }
+            }
             if (lane == 0) q.d[(size_t)row * nblk + b] = dq;
         }
         if (want_q80) {
@@ -103,10 +111,11 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const float *__restri
         }
     }
 }
-hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st) {
+hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
+                               int8_t *bh, int8_t *bl) {
     if ((n % 256) != 0 || T <= 0) return hipErrorInvalidValue;
     const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
-    hipLaunchKernelGGL(swiglu_quant_kernel, dim3(T, splits), dim3(256), 0, st, g, u, n, q, (int)want_q8k, (int)want_q80);
+    hipLaunchKernelGGL(swiglu_quant_kernel, dim3(T, splits), dim3(256), 0, st, g, u, n, q, (int)want_q8k, (int)want_q80, want_q8k ? bh : nullptr, bl);
     return hipGetLastError();
 }
 

@@ -100,14 +100,18 @@ hipError_t launch_mmq(int type, const uint8_t *W, size_t row_bytes, int n_rows, 
 
 // ---------------------------------------------------------------- activation-side kernels (act.hip)
 // y = rms_norm(x) * w  for T rows of n; optionally f32 out and/or q8_K / q8_0 planes
+// bh / bl (optional, with q8_K): also write the block sums split into the int8 planes the MFMA kernels contract
+// (bsum = 64 * bh + bl, what launch_mmq_prep computes as its own launch), [T][n / 16] each
 hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, float eps,
                                 float *y_f32 /*nullable*/, const ActQuant *q /*nullable*/, bool want_q8k, bool want_q80,
-                                hipStream_t st);
+                                hipStream_t st, int8_t *bh = nullptr, int8_t *bl = nullptr);
 // quantise f32 rows
-hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st);
+hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
+                           int8_t *bh = nullptr, int8_t *bl = nullptr);
 hipError_t launch_swiglu(const float *g, const float *u, float *y, int64_t n, hipStream_t st);
 // silu(g) * u quantised for the next mat-mul without an f32 round trip (n % 256 == 0); same blocks as launch_swiglu + launch_quantize
-hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st);
+hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
+                               int8_t *bh = nullptr, int8_t *bl = nullptr);
 hipError_t launch_add(const float *a, const float *b, float *y, int64_t n, hipStream_t st);
 hipError_t launch_soft_max(const float *x, const float *mask, float *y, int n, int rows, float scale, hipStream_t st);
 // pack device planes back into ggml blocks (parity tests)

@@ -637,17 +637,24 @@ static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, c
     return hipSuccess;
 }
 
+hipError_t Context::ensure_prep(const ActQuant &aq, int K, int T) {
+    if (prep_owner_ == aq.qs && prep_K_ == K && prep_T_ == T && aq.qs) return hipSuccess;
+    HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+    prep_written(aq, K, T);
+    return hipSuccess;
+}
+
 hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
         if (mmq_q80_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU && aq.qs0)   // prompt processing, Q8_0 weights
             return launch_mmq_q80(w.data, w.row_bytes, (int)w.N, K, T, aq, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         if (mmq_ksplit_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // batched decode steps: MFMA, K split
-            if (w.type != T_Q6_K) HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+            if (w.type != T_Q6_K) HIP_TRY(ensure_prep(aq, K, T));
             return launch_mmq_ksplit(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
         if (mmq_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // prompt processing: MFMA path
-            if (w.type != T_Q6_K || !w.planes) HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+            if (w.type != T_Q6_K || !w.planes) HIP_TRY(ensure_prep(aq, K, T));
             if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
             return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
@@ -664,13 +671,13 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
     bool all_mmq = true, all_ks = true;
     for (int i = 0; i < n; i++) { all_mmq &= mmq_applicable(ws[i]->type, K, T); all_ks &= mmq_ksplit_applicable(ws[i]->type, K, T); }
     if (all_ks && pending_fuse_.mode == 0 && n <= 3) {         // batched decode step: Q, K, V in one launch
-        HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+        HIP_TRY(ensure_prep(aq, K, T));
         MMQSeg sg[3];
         for (int i = 0; i < n; i++) sg[i] = MMQSeg{ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, ws[i]->type, outs[i], (int)ws[i]->N, nullptr, 0};
         return launch_mmq_ksplit_multi(sg, n, K, T, aq, mmq_bh_, mmq_bl_, false, stream_);
     }
     if (all_mmq && pending_fuse_.mode == 0) {
-        HIP_TRY(launch_mmq_prep(aq, K, T, mmq_bh_, mmq_bl_, stream_));
+        HIP_TRY(ensure_prep(aq, K, T));
         // Q | K | V (or Q | K) as one launch over the concatenated rows where their plane sets are adjacent in the arena and
         // of one plane format (Q4_K and Q5_K share it; the Q6_K attn_v of the "more bits" layers runs on its own)
         auto mins = [](int t) { return t != T_Q6_K; };
@@ -840,7 +847,11 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         if (fuse_attn) {
             pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
         } else {
-            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_));
+            const bool pl = need_k && T >= 8;                  // the batched kernels will want the block-sum planes
+            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_,
+                                         pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+            prep_owner_ = nullptr;
+            if (pl) prep_written(aq_e_, E, T);
             prof_mark("norm_quant");
         }
         const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
@@ -883,6 +894,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_flash_attn(aa, stream_));
         }
         prof_mark("attn");
+        if (prep_owner_ == aq_o_.qs) prep_owner_ = nullptr;   // the attention just re-quantised its output
         if (tp) {   // this rank's partial sum (rank 0 carries the residual), then the exchange: x = sum over ranks
             HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, T, tp_part_, E, hp.tp_rank == 0 ? x_ : nullptr, hp.tp_rank == 0 ? EPI_ADD : EPI_STORE));
             HIP_TRY(tp_reduce_into_x(T));
@@ -895,6 +907,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         if (hp.n_expert > 0) {
             HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, xn_, &aq_e_,
                                          L.gate_exps.type != T_Q8_0 || L.up_exps.type != T_Q8_0, L.gate_exps.type == T_Q8_0 || L.up_exps.type == T_Q8_0, stream_));
+            prep_owner_ = nullptr;
             prof_mark("norm_quant");
             if (L.gate_inp.type == T_F32 || L.gate_inp.type == T_F16) {
                 HIP_TRY(launch_moe_router(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, hp.n_expert_used, router_, moe_ids_, moe_w_, stream_));
@@ -913,6 +926,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_moe_group(moe_ids_, T, KU, NE, moe_meta_, moe_slot_, moe_tok_, stream_));
                 HIP_TRY(hipMemcpyAsync(h_moe_meta_, moe_meta_, (size_t)(2 * NE + 1) * 4, hipMemcpyDeviceToHost, stream_));
                 HIP_TRY(launch_moe_gather_act(aq_e_, moe_tok_, GR, E, aq_eg_, stream_));
+                prep_owner_ = nullptr;                             // the grouped rows were just rewritten
                 HIP_TRY(hipStreamSynchronize(stream_));            // the batch sizes size the launches (prompt batches only: never inside a graph)
                 auto view = [](const DevTensor &w, int e) {
                     DevTensor v = w;
@@ -934,6 +948,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     HIP_TRY(linear(view(L.up_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_ug_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
                 }
                 HIP_TRY(launch_swiglu_quant(ffn_g_, ffn_ug_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                prep_owner_ = nullptr;
                 for (int e = 0; e < NE; e++) {
                     const int n_e = h_moe_meta_[e], r0 = h_moe_meta_[NE + e];
                     if (n_e <= 0) continue;
@@ -984,7 +999,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     const int kbf = (FF + 2047) / 2048;
                     const bool fuse_q = (L.down_exps.type == T_Q4_K || L.down_exps.type == T_Q5_K || L.down_exps.type == T_Q6_K) && (FF % 256) == 0 &&
                                         (kbf == 1 || kbf == 2 || kbf == 3 || kbf == 4 || kbf == 6 || kbf == 7 || kbf == 14);
-                    if (!fuse_q) HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                    if (!fuse_q) { HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_)); prep_owner_ = nullptr; }
                     MMVQArgs d{};
                     d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE;
                     if (fuse_q) { d.fuse_mode = 2; d.nx = ffn_ + (size_t)t * FF; }
@@ -1004,7 +1019,11 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (fuse_ffn) {
                 fz.mode = 1; fz.x = x_; fz.w = (const float *)L.ffn_norm.data; fz.eps = hp.eps;
             } else {
-                HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_));
+                const bool pl = fk && T >= 8;
+                HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_,
+                                             pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+                prep_owner_ = nullptr;
+                if (pl) prep_written(aq_e_, E, T);
                 prof_mark("norm_quant");
             }
             bool swiglu_quantised = false;
@@ -1016,7 +1035,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_, fz));
             } else if (ffn_ks) {                               // batched decode step: gate and up in one launch
-                if (L.gate.type != T_Q6_K || L.up.type != T_Q6_K) HIP_TRY(launch_mmq_prep(aq_e_, E, T, mmq_bh_, mmq_bl_, stream_));
+                if (L.gate.type != T_Q6_K || L.up.type != T_Q6_K) HIP_TRY(ensure_prep(aq_e_, E, T));
                 MMQSeg sg[2] = {{L.gate.data, L.gate.row_bytes, (int)L.gate.N, L.gate.type, ffn_, FF, nullptr, 0},
                                 {L.up.data, L.up.row_bytes, (int)L.up.N, L.up.type, ffn_u_, FF, nullptr, 0}};
                 const bool pair = T <= 32 && L.gate.type == L.up.type && L.gate.N == L.up.N;     // SwiGLU in the epilogue
@@ -1027,7 +1046,11 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
                 // prompt batch: SwiGLU and the quantisation for the down projection in one pass (no f32 round trip of T x FF)
                 if (T > 1 && is_quant(L.down.type) && (FF % 256) == 0) {
-                    HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
+                    const bool pl = L.down.type != T_Q8_0 && T >= 8;
+                    HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_,
+                                                pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+                    prep_owner_ = nullptr;
+                    if (pl) prep_written(aq_ff_, FF, T);
                     swiglu_quantised = true;
                 } else {
                     HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
@@ -1042,6 +1065,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
             } else if (is_quant(L.down.type) && !swiglu_quantised) {
                 HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
+                prep_owner_ = nullptr;
                 prof_mark("quant");
             }
             if (tp) {
@@ -1078,6 +1102,7 @@ hipError_t Context::run_output(int n_out, int out_base) {
     if (oq && can_fuse(E, n_out)) {
         pending_fuse_.mode = 1; pending_fuse_.x = xo_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps;
     } else {
+        prep_owner_ = nullptr;
         HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
                                      oq && model->output.type != T_Q8_0, model->output.type == T_Q8_0, stream_));
         prof_mark("norm_quant");

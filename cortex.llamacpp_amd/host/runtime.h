@@ -183,6 +183,12 @@ class Context {
     int32_t *moe_meta_ = nullptr, *moe_slot_ = nullptr, *moe_tok_ = nullptr, *h_moe_meta_ = nullptr;
     ActQuant aq_e_, aq_ff_, aq_o_;
     int8_t *mmq_bh_ = nullptr, *mmq_bl_ = nullptr;   // (hi, lo) planes of the 32-code block sums for the MFMA path
+    // whose block sums mmq_bh_ / mmq_bl_ currently hold (code plane pointer, K, rows): the quantisers of a prompt batch write
+    // the planes themselves, launch_mmq_prep runs only when they are not there (ensure_prep)
+    const void *prep_owner_ = nullptr;
+    int prep_K_ = 0, prep_T_ = 0;
+    hipError_t ensure_prep(const ActQuant &aq, int K, int T);
+    void prep_written(const ActQuant &aq, int K, int T) { prep_owner_ = aq.qs; prep_K_ = K; prep_T_ = T; }
     float *att_part_ = nullptr;
     float *d_embd_ = nullptr, *h_embd_ = nullptr;   // [n_ubatch][n_embd], embeddings mode
     bool embd_fetched_ = false, last_was_embd_ = false;
