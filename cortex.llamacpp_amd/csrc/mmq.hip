@@ -696,9 +696,12 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
         for (int r = 0; r < 16; r++) facc[t][r] = 0.0f;
 
     // ---- prologue: B operands and meta of super-block 0 into registers, activation tile 0 into LDS
-    i32x4 Bh[4], Bl[4];                                         // ring of 4 K-steps
+    // ring of K-steps: 4 (half a super-block ahead) where two token tiles per wave leave no registers for more; 8 (a whole
+    // super-block ahead) with one tile per wave, whose 2 MFMAs per K-step otherwise cover only 256 cycles of the planes' latency
+    constexpr int RING = MT == 1 ? 8 : 4;
+    i32x4 Bh[RING], Bl[RING];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < RING; j++) {
         Bh[j] = *reinterpret_cast<const i32x4 *>(blk0 + (j * 2) * 1024 + b_off);
         Bl[j] = *reinterpret_cast<const i32x4 *>(blk0 + (j * 2 + 1) * 1024 + b_off);
     }
@@ -759,12 +762,13 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
                 if (J == 0) {                                                                                 \
                     i32x16 z;                                                                                 \
                     _Pragma("unroll") for (int r = 0; r < 16; r++) z[r] = 0;                                  \
-                    H[t] = mfma_i8(ACUR[t], Bh[J & 3], z); L[t] = mfma_i8(ACUR[t], Bl[J & 3], z);             \
-                } else { H[t] = mfma_i8(ACUR[t], Bh[J & 3], H[t]); L[t] = mfma_i8(ACUR[t], Bl[J & 3], L[t]); } \
+                    H[t] = mfma_i8(ACUR[t], Bh[J & (RING - 1)], z); L[t] = mfma_i8(ACUR[t], Bl[J & (RING - 1)], z); \
+                } else { H[t] = mfma_i8(ACUR[t], Bh[J & (RING - 1)], H[t]); L[t] = mfma_i8(ACUR[t], Bl[J & (RING - 1)], L[t]); } \
             }                                                                                                 \
-            const uint8_t *src = (J < 4 ? blkc : blkn) + (((J + 4) & 7) * 2) * 1024 + b_off;                  \
-            Bh[J & 3] = *reinterpret_cast<const i32x4 *>(src);                                                \
-            Bl[J & 3] = *reinterpret_cast<const i32x4 *>(src + 1024);                                         \
+            const uint8_t *src = RING == 8 ? blkn + (J * 2) * 1024 + b_off                                    \
+                                           : (J < 4 ? blkc : blkn) + (((J + 4) & 7) * 2) * 1024 + b_off;       \
+            Bh[J & (RING - 1)] = *reinterpret_cast<const i32x4 *>(src);                                       \
+            Bl[J & (RING - 1)] = *reinterpret_cast<const i32x4 *>(src + 1024);                                \
         }
         KSTEP(0, a0, a1) KSTEP(1, a1, a0) KSTEP(2, a0, a1) KSTEP(3, a1, a0) KSTEP(4, a0, a1) KSTEP(5, a1, a0) KSTEP(6, a0, a1) KSTEP(7, a1, a0)
 #undef KSTEP
