@@ -847,7 +847,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         if (fuse_attn) {
             pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
         } else {
-            const bool pl = need_k && T >= 8;                  // the batched kernels will want the block-sum planes
+            const bool pl = need_k && T >= 3;                  // the batched kernels will want the block-sum planes
             HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_,
                                          pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
             prep_owner_ = nullptr;
@@ -1019,7 +1019,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (fuse_ffn) {
                 fz.mode = 1; fz.x = x_; fz.w = (const float *)L.ffn_norm.data; fz.eps = hp.eps;
             } else {
-                const bool pl = fk && T >= 8;
+                const bool pl = fk && T >= 3;
                 HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, (!gq || !uq) ? xn_ : nullptr, &aq_e_, fk, f0, stream_,
                                              pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
                 prep_owner_ = nullptr;
@@ -1046,7 +1046,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
                 // prompt batch: SwiGLU and the quantisation for the down projection in one pass (no f32 round trip of T x FF)
                 if (T > 1 && is_quant(L.down.type) && (FF % 256) == 0) {
-                    const bool pl = L.down.type != T_Q8_0 && T >= 8;
+                    const bool pl = L.down.type != T_Q8_0 && T >= 3;
                     HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_,
                                                 pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
                     prep_owner_ = nullptr;
