@@ -1040,7 +1040,18 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                                 {L.up.data, L.up.row_bytes, (int)L.up.N, L.up.type, ffn_u_, FF, nullptr, 0}};
                 const bool pair = T <= 32 && L.gate.type == L.up.type && L.gate.N == L.up.N;     // SwiGLU in the epilogue
                 HIP_TRY(launch_mmq_ksplit_multi(sg, 2, E, T, aq_e_, mmq_bh_, mmq_bl_, pair, stream_));
-                if (!pair) HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
+                if (!pair) {
+                    if (is_quant(L.down.type) && (FF % 256) == 0) {
+                        const bool pl = L.down.type != T_Q8_0;
+                        HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_,
+                                                    pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+                        prep_owner_ = nullptr;
+                        if (pl) prep_written(aq_ff_, FF, T);
+                        swiglu_quantised = true;
+                    } else {
+                        HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
+                    }
+                }
             } else {
                 HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
