@@ -62,6 +62,9 @@ hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_
 // workgroup ranges per segment, LDS bytes and the reduction-scratch offset for a grid of `blocks` workgroups of `waves`
 // waves each (what launch_mmvq_fast works out for its own launch); returns the LDS bytes, 0 if the shape has no fast form
 size_t mmvq_fast_plan(MMVQArgs &a, int blocks, int waves);
+// single-token weight-stream form (mmvq_stream.hip): HBM -> LDS DMA rings, bit-identical to the fast path
+bool mmvq_stream_applicable(const MMVQArgs &a);
+hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st);
 
 void set_num_cu(int n);
 int num_cu();
