@@ -663,6 +663,9 @@ hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     static const bool fast_init = (mmvq_fast_set_threads(getenv("MI355_MMVQ_NT") ? atoi(getenv("MI355_MMVQ_NT")) : 0), true);
     (void)fast_init;
     static const bool fast_on = !(getenv("MI355_MMVQ_FAST") && getenv("MI355_MMVQ_FAST")[0] == '0');   // diagnosis switch
+    // single-token steps: the weight-stream kernel (LDS-DMA loader / consumer waves) where it has a form, else the register ring
+    static const bool stream_on = !(getenv("MI355_MMVQ_STREAM") && getenv("MI355_MMVQ_STREAM")[0] == '0');
+    if (fast_on && stream_on && mmvq_stream_applicable(a)) return launch_mmvq_stream(a, st);
     if (fast_on && mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
     if ((a.T == 16 || a.T == 8) && a.fuse_mode == 0) {
         bool moe = false;

@@ -1,22 +1,24 @@
-// mmvq_stream.hip — single-token quantised mat-vec as a weight STREAM: every wave copies its contiguous share of the
-// weight rows HBM -> LDS with the DMA form of the global load (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per
-// instruction, no register round trip), into a private 16 KiB ring, and decodes rows out of the ring while the next
-// groups are in flight.  Same arithmetic, lane roles and summation order as mmvq_fast.hip (ggml_vec_dot_q{4,5,6}_K_q8_K /
-// q8_0_q8_0): the two kernels are bit-identical (tools/exp_stream.hip, tests/test_gpu_ops.py).
+// mmvq_stream.hip — single-token quantised mat-vec as a weight STREAM.  One workgroup of 8 waves per CU owns a contiguous
+// run of weight rows.  Wave 0 is the LOADER: it copies that run HBM -> LDS with the DMA form of the global load
+// (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per instruction, no register round trip) into a 128 KiB ring, 4 KiB
+// slots, up to 12 slots in flight, and publishes a slot once it has landed.  Waves 1..7 are CONSUMERS: they quantise the
+// activation (RMSNorm * w -> Q8_K, the fused prologues) while the ring fills, then decode row pairs out of the ring as
+// the slots are published, round-robin in stream order, and report their progress so that the loader can reuse the space.
+// Same arithmetic, lane roles and summation order as mmvq_fast.hip (ggml_vec_dot_q{4,5,6}_K_q8_K / q8_0_q8_0, SURVEY.md
+// §8a a8): the two kernels are bit-identical (tools/exp_stream.hip, tests/test_gpu_ops.py).
 //
-// Why (measured): a decode step is ~160 dependent launches of 9-66 MB; each paid 3-5 us on top of its
-// bytes because the first weight request of a wave waited for the activation prologue, the register ring held at most
-// 9 KB per wave, and the drain of one unit gated the request of the next.  Here
-//   * every byte of a wave's first 16 KiB is requested in the first few hundred cycles of the kernel, before the
-//     activation exists (128 KiB per CU in flight: all of attn_output / Q/K/V, half of gate/up);
-//   * the DMA is issued from inline asm, so hipcc's waitcnt pass does not see it: with the builtin form it puts
-//     s_waitcnt vmcnt(0) before every ds_read that follows (it cannot prove the LDS ranges differ), which serialises
-//     request and decode — the 4.1 TB/s "LDS-DMA ring" of round 1 (tools/bench_stream.hip) was that, not the hardware;
-//     the ring is drained with counted waits (vmcnt(4 k): groups complete in order);
-//   * the f32 inputs of the fused prologues (RMSNorm / Q8_K quantise) are requested first, by asm loads into registers,
-//     and waited for with the same counter, so the prologue costs no extra round trip;
-//   * a row never leaves its wave: no barrier after the prologue, results are collected one per lane and stored with
-//     one coalesced store per wave (+ residual, prefetched by DMA; or SwiGLU of a gate/up pair).
+// Why (measured on MI355X, tools/exp_stream.hip):
+//   * a DMA-only kernel reads these tensors at the chip's streaming rate (33 MB in 6.4 us in a graph chain = 6.4 TB/s behind
+//     a 1.2 us boundary) — wave-private, workgroup-window or chip-wide interleaved alike; a register-load kernel of the same
+//     shape needs 7.5 us.  hipcc serialises the BUILTIN form: it cannot prove that a later ds_read misses the DMA's LDS
+//     range and puts s_waitcnt vmcnt(0) in front of every one (the 4.1 TB/s "LDS-DMA ring" of round 1 was that).  Issued
+//     from inline asm the DMA is invisible to that pass; completion is tracked by hand (vmcnt counts, in-order return);
+//   * a wave that issues its own DMA (v1 of this file: a 16 KiB ring per wave) is BLOCKED in the issue for microseconds:
+//     the vector-memory queue of a CU is shallow and drains at the HBM rate, so the 16 requests of a ring take 3-5 us to
+//     be accepted, then the wave does its prologue (2-3 us, ring full, HBM idle), then decodes (VALU-bound: 0.66 us per
+//     row pair) before it may request again.  Request, prologue and decode in series per wave: no faster than the
+//     register ring (42 vs 42 us per layer).  With the roles split the loader is the only wave that ever blocks on the
+//     memory queue, which is exactly the flow control wanted; nobody else issues vector memory in the loop.
 // Weight stream policy: non-temporal (each byte is read once per token).
 #include "mmvq_fast_dev.h"
 
@@ -24,16 +26,23 @@ namespace mi355 {
 
 namespace {
 
-constexpr int ST_NT = 512, ST_NW = ST_NT / 64;
-constexpr int ST_RING = 16384;                  // per wave, power of two (ring offsets wrap with a mask)
-constexpr int ST_GC = 4;                        // DMA instructions (1 KiB each) per group
-constexpr int ST_GB = ST_GC * 1024;             // the unit of issue and of the counted wait
-constexpr int ST_RG = ST_RING / ST_GB;          // groups the ring holds
-constexpr unsigned ST_MASK = ST_RING - 1;
-constexpr int ST_MAX_STEP = ST_RING - ST_GB;    // bytes one decode step may span (row or row pair): always issuable
+#ifndef MI355_STREAM_NL
+#define MI355_STREAM_NL 2
+#endif
+constexpr int ST_NL = MI355_STREAM_NL;          // loader waves (the first waves of the workgroup): 2 or 4
+constexpr int ST_NC = 8;                        // consumer waves: the wave count the prologue of mmvq_fast is cut for
+constexpr int ST_NW = ST_NL + ST_NC, ST_NT = ST_NW * 64;
+constexpr int ST_RING = 131072;                 // bytes, power of two (ring offsets wrap with a mask)
+constexpr int ST_SI = 4;                        // DMA instructions (1 KiB each) per slot
+constexpr int ST_SLOT = ST_SI * 1024;           // unit of publication
+constexpr int ST_D = ST_NL == 2 ? 15 : 8;       // slots in flight per loader (at most 60 of the 63 countable vector-memory operations of a wave)
+constexpr unsigned ST_MASK = ST_RING - 1;      // one stream in the whole ring
+constexpr unsigned ST_MASK2 = ST_RING / 2 - 1;  // SwiGLU: gate rows in the lower half, up rows in the upper half
+constexpr int ST_MAX_STEP = 16384;              // bytes one decode step may span (a row, a row pair or a gate/up pair)
+constexpr int ST_PAIR_MAX = 12288;              // rows are decoded two at a time up to this many bytes per pair
 
-// ---- the DMA forms.  M0 = LDS byte address of the 64-lane destination (lane l lands at M0 + 16 l / 4 l); saved and
-// restored inside the statement (hipcc does not preserve M0 around asm and does not expect it changed).
+// ---- the DMA.  M0 = LDS byte address of the 64-lane destination (lane l lands at M0 + 16 l); saved and restored inside
+// the statement (hipcc does not preserve M0 around asm and does not expect it changed).
 template <bool NTL> __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
     unsigned keep;
     if (NTL) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
@@ -41,31 +50,28 @@ template <bool NTL> __device__ __forceinline__ void dma16(const void *gsrc, unsi
     else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                       : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void dma4(const void *gsrc, unsigned lds_dst) {
+// one whole slot: lane l copies 16 B from g, g + 1 KiB, g + 2 KiB, g + 3 KiB; the instruction offset applies to the global
+// AND to the LDS address (piece i lands at M0 + i KiB + 16 l)
+__device__ __forceinline__ void dma_slot(const void *g, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
-// at most n of this wave's vector-memory operations still outstanding (n wave-uniform, 0..20; they complete in order)
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-#define C(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-        C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18) C(19) C(20)
-#undef C
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-}
+template <int N> __device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(N) : "memory"); }
 #ifdef MI355_STREAM_PROBE
-// tools/exp_stream.hip: per wave, six 100 MHz wall-clock stamps (entry, first groups issued, activation ready, first row
-// landed, last row decoded, outputs stored)
+// tools/exp_stream.hip: per wave, 100 MHz wall-clock stamps and accumulated waits
 __device__ unsigned long long *g_stream_probe = nullptr;
-#define ST_SLOT(i) g_stream_probe[(((size_t)(a.nck >> 2) * 256 + blockIdx.x) * ST_NW + wave) * 8 + (i)]
-#define ST_STAMP(i) do { if (g_stream_probe && lane == 0) ST_SLOT(i) = wall_clock64(); } while (0)
-// accumulated phase times of the decode loop: slots 3 (waiting for data), 6 (decoding), 7 (refilling)
-#define ST_ACC_DECL unsigned long long st_t0 = 0, st_acc_w = 0, st_acc_d = 0, st_acc_r = 0
+#define ST_SLOTP(i) g_stream_probe[(((size_t)(a.nck >> 2) * 256 + blockIdx.x) * ST_NW + wave) * 8 + (i)]
+#define ST_STAMP(i) do { if (g_stream_probe && lane == 0) ST_SLOTP(i) = wall_clock64(); } while (0)
+#define ST_ACC_DECL unsigned long long st_t0 = 0, st_acc_w = 0, st_acc_d = 0
 #define ST_T0() do { st_t0 = wall_clock64(); } while (0)
 #define ST_ACC(x) do { const unsigned long long t_ = wall_clock64(); x += t_ - st_t0; st_t0 = t_; } while (0)
-#define ST_ACC_OUT() do { if (g_stream_probe && lane == 0) { ST_SLOT(3) = st_acc_w; ST_SLOT(6) = st_acc_d; ST_SLOT(7) = st_acc_r; } } while (0)
+#define ST_ACC_OUT() do { if (g_stream_probe && lane == 0) { ST_SLOTP(3) = st_acc_w; ST_SLOTP(6) = st_acc_d; } } while (0)
 #else
 #define ST_STAMP(i) do { } while (0)
 #define ST_ACC_DECL do { } while (0)
@@ -75,23 +81,25 @@ __device__ unsigned long long *g_stream_probe = nullptr;
 #endif
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // low half of a flat LDS address = LDS byte offset
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// words shared by the waves of the workgroup (LDS is coherent inside a CU; every access is a real ds instruction)
+__device__ __forceinline__ int ld_sync(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_sync(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// ---- decoders reading a row out of the ring (row_off = ring offset of the row's first byte; everything is 16-B granular,
-// so a piece never straddles the wrap).  Same fields as Raw<TYPE>::load of mmvq_fast_dev.h.
-#define RO(x) (ring + (((x)) & ST_MASK))
-template <int TYPE> __device__ __forceinline__ void ring_load(Raw<TYPE> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L);
-template <> __device__ __forceinline__ void ring_load<T_Q4_K>(Raw<T_Q4_K> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
+// ---- decoders reading a row out of the ring (row_off = stream offset of the row's first byte; everything is 16-B
+// granular, so a piece never straddles the wrap).  Same fields as Raw<TYPE>::load of mmvq_fast_dev.h.
+#define RO(x) (ring + (((x)) & MASK))
+template <unsigned MASK> __device__ __forceinline__ void ring_load(Raw<T_Q4_K> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
     const unsigned b = row_off + (unsigned)sb * 144u;
     r.hdr = lds16(RO(b));
     r.q = lds16(RO(b + 16u + (unsigned)L.v * 16u));
 }
-template <> __device__ __forceinline__ void ring_load<T_Q5_K>(Raw<T_Q5_K> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
+template <unsigned MASK> __device__ __forceinline__ void ring_load(Raw<T_Q5_K> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
     const unsigned b = row_off + (unsigned)sb * 176u;
     r.hdr = lds16(RO(b));
     r.qh = lds16(RO(b + 16u + (unsigned)L.h * 16u));
     r.q = lds16(RO(b + 48u + (unsigned)L.v * 16u));
 }
-template <> __device__ __forceinline__ void ring_load<T_Q6_K>(Raw<T_Q6_K> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
+template <unsigned MASK> __device__ __forceinline__ void ring_load(Raw<T_Q6_K> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
     r.ql = lds16(RO(row_off + (unsigned)sb * 128u + (unsigned)L.v * 16u));
     r.qh = lds16(RO(row_off + (unsigned)nb * 128u + (unsigned)sb * 64u + (unsigned)L.n * 32u + (unsigned)(L.w & 1) * 16u));
     const unsigned so = row_off + (unsigned)nb * 192u + (unsigned)sb * 16u + 8u * (unsigned)L.n + (unsigned)L.w;
@@ -99,7 +107,7 @@ template <> __device__ __forceinline__ void ring_load<T_Q6_K>(Raw<T_Q6_K> &r, co
     r.sc_hi = *reinterpret_cast<const int8_t *>(RO(so + 4u));
     r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + (unsigned)nb * 208u + (unsigned)sb * 2u));
 }
-template <> __device__ __forceinline__ void ring_load<T_Q8_0>(Raw<T_Q8_0> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
+template <unsigned MASK> __device__ __forceinline__ void ring_load(Raw<T_Q8_0> &r, const uint8_t *ring, unsigned row_off, int nb, int sb, const LaneRole &L) {
     const unsigned b = row_off + (unsigned)sb * 256u + (unsigned)L.v * 32u;
     r.q0 = lds16(RO(b));
     r.q1 = lds16(RO(b + 16u));
@@ -107,9 +115,9 @@ template <> __device__ __forceinline__ void ring_load<T_Q8_0>(Raw<T_Q8_0> &r, co
 }
 #undef RO
 
-// ---- LDS layout (bytes from smem): activation | reduction scratch | residual prefetch | rings
+// ---- LDS layout (bytes from smem): activation | reduction scratch | sync words | ring
 struct StLayout {
-    int qs, d, bs, red, resid, ring, total;
+    int qs, d, bs, red, sync, ring, total;
 };
 __host__ __device__ inline StLayout st_layout(int kb) {
     const int Kp = kb * 2048;
@@ -118,79 +126,94 @@ __host__ __device__ inline StLayout st_layout(int kb) {
     l.d = Kp;                                   // one DMA piece (1 KiB) of room: nb * 4 B of scales
     l.bs = Kp + 1024;                           // Kp / 8 B of block sums (Q8_0: f32 block scales, Kp / 8 B too), in whole DMA pieces
     l.red = l.bs + ((Kp / 8 + 1023) & ~1023);
-    l.resid = l.red + 128;
-    l.ring = l.resid + ST_NW * 256;
-    l.total = l.ring + ST_NW * ST_RING;
+    l.sync = l.red + 128;
+    l.ring = l.sync + 128;
+    l.total = l.ring + ST_RING;
     return l;
 }
+// sync words (ints at smem + lay.sync): [q] slots published by loader q, [4] / [5] arrivals at the two prologue
+// rendezvous, [6] consumers whose own global requests (prologue inputs, residual) are in the memory queue: the loaders
+// start after that, [8 + c] consumer c: the first of its steps it has NOT finished
+enum { SY_LANDED = 0, SY_PRO1 = 4, SY_PRO2 = 5, SY_GO = 6, SY_DONE = 8 };
 
-// ---- fused prologue inputs: asm loads (hipcc must not count them: its own wait would drain the weight DMA behind them)
-template <int KB, int FUSE>
-__device__ __forceinline__ void pre_issue(const MMVQArgs &a, f32x4_t (&rxv)[StageDims<KB, ST_NT>::NJW], f32x4_t (&rwv)[StageDims<KB, ST_NT>::NJW]) {
-    using S = StageDims<KB, ST_NT>;
-    const int tid = tid_now();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int nbt = a.K >> 8;
-#pragma unroll
-    for (int j = 0; j < S::NJW; j++) {
-        const int b = wave + S::NW * j;
-        const int bc = b < nbt ? b : nbt - 1;   // clamped: always a valid address, result unused when b is out of range
-        const float *px = a.nx + bc * 256 + lane * 4;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rxv[j]) : "v"(px) : "memory");
-        if (FUSE == 1) {
-            const float *pw = a.nw + bc * 256 + lane * 4;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rwv[j]) : "v"(pw) : "memory");
-        }
-    }
-}
-template <int N> __device__ __forceinline__ void pin_regs(f32x4_t (&r)[N]) {
-#pragma unroll
-    for (int j = 0; j < N; j++) asm volatile("" : "+v"(r[j]));
+// every wait on another wave of the workgroup is bounded: the waves of a workgroup are always co-resident, so a healthy
+// wait ends within microseconds; if a protocol bug ever broke that, the launch still ends (with wrong numbers, which the
+// parity tests catch) instead of hanging the device.  ~0.2 s of polls.
+constexpr int ST_SPIN_LIMIT = 1 << 21;
+#define ST_SPIN_WHILE(cond, sleep_arg) do { int spins_ = 0; while ((cond) && ++spins_ < ST_SPIN_LIMIT) __builtin_amdgcn_s_sleep(sleep_arg); } while (0)
+__device__ __forceinline__ void consumers_rendezvous(int *word, int lane) {
+    if (lane == 0) (void)__hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ST_SPIN_WHILE(ld_sync(word) < ST_NC, 1);
 }
 
-// RMSNorm * w and / or the Q8_K (Q8_0) quantisation of the token, result in LDS: stage_finish of mmvq_fast_dev.h on this
-// kernel's layout (wave w owns 256-blocks w, w + 8, ..; sum of squares in double, fixed order)
+// What the device code needs of MMVQArgs, read ONCE at the top of the kernel in straight-line code: the kernel argument
+// segment is cold at every launch (~0.7 us per miss, tools/exp_stream.hip timeline) and hipcc loads a field where it is
+// first used, so `a.seg[s]` behind the segment choice and a.nx behind the role choice were two more serial misses.
+struct StArgs {
+    int K, epi, nck;
+    float neps;
+    const int8_t *aq; const float *ad; const int16_t *abs;
+    const float *nx, *nw;
+    const uint8_t *W1;            // SwiGLU: the up tensor
+};
+struct StSeg {
+    const uint8_t *W; float *out; const float *resid;
+    int type, n_rows;
+    unsigned row_bytes;
+};
+
+// RMSNorm * w and / or the Q8_K (Q8_0) quantisation of the token by the 8 consumer waves, result in LDS: stage_finish of
+// mmvq_fast_dev.h (consumer c owns 256-blocks c, c + 8, ..; sum of squares in double, fixed order), with the workgroup
+// barrier replaced by a rendezvous of the consumers (the loaders never join: they sit in the memory queue).
 template <int KB, int FUSE, bool Q80>
-__device__ __forceinline__ void pre_finish(const MMVQArgs &a, const f32x4_t (&rxv)[StageDims<KB, ST_NT>::NJW], const f32x4_t (&rwv)[StageDims<KB, ST_NT>::NJW],
-                                           uint8_t *smem, const StLayout &lay) {
-    using S = StageDims<KB, ST_NT>;
+__device__ __forceinline__ void consumer_prologue(const StArgs &a, uint8_t *smem, const StLayout &lay, int c, int lane) {
+    constexpr int NJW = (KB * 8 + ST_NC - 1) / ST_NC;
     const int nbt = a.K >> 8;
-    const int tid = tid_now();
     int8_t *qs = reinterpret_cast<int8_t *>(smem + lay.qs);
     float *d = reinterpret_cast<float *>(smem + lay.d);
     int16_t *bs = reinterpret_cast<int16_t *>(smem + lay.bs);
     double *red = reinterpret_cast<double *>(smem + lay.red);
-    const int lane = tid & 63, wave = tid >> 6;
+    int *sy = reinterpret_cast<int *>(smem + lay.sync);
+    f32x4_t rxv[NJW], rwv[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; j++) {
+        const int b = c + ST_NC * j;
+        const int bc = b < nbt ? b : nbt - 1;                  // clamped: always a valid address, result unused when b is out of range
+        rxv[j] = *reinterpret_cast<const f32x4_t *>(a.nx + bc * 256 + lane * 4);
+        if (FUSE == 1) rwv[j] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
+    }
+    asm volatile("" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     float scale = 1.0f;
     if (FUSE == 1) {
         double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < S::NJW; j++) {
-            const f32x4_t v = rxv[j];
+        for (int j = 0; j < NJW; j++) {
+            const f32x4_t x = rxv[j];
             double t = 0.0;
-            t += (double)(v.x * v.x); t += (double)(v.y * v.y); t += (double)(v.z * v.z); t += (double)(v.w * v.w);
-            if (wave + S::NW * j < nbt) sum += t;
+            t += (double)(x.x * x.x); t += (double)(x.y * x.y); t += (double)(x.z * x.z); t += (double)(x.w * x.w);
+            if (c + ST_NC * j < nbt) sum += t;
         }
         sum = wave_sum(sum);
-        if (lane == 0) red[wave] = sum;
-        __syncthreads();
+        if (lane == 0) red[c] = sum;
+        consumers_rendezvous(sy + SY_PRO1, lane);
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < S::NW; w++) tot += red[w];
+        for (int w = 0; w < ST_NC; w++) tot += red[w];
         const float mean = (float)(tot / (double)a.K);
         scale = 1.0f / sqrtf(mean + a.neps);
     }
 #pragma unroll
-    for (int j = 0; j < S::NJW; j++) {
-        const int b = wave + S::NW * j;
+    for (int j = 0; j < NJW; j++) {
+        const int b = c + ST_NC * j;
         if (b >= nbt) continue;                                // wave-uniform
         const int e0 = b * 256 + lane * 4;
-        f32x4_t v = rxv[j];
+        f32x4_t x = rxv[j];
         if (FUSE == 1) {
             const f32x4_t ww = rwv[j];
-            v.x = (v.x * scale) * ww.x; v.y = (v.y * scale) * ww.y; v.z = (v.z * scale) * ww.z; v.w = (v.w * scale) * ww.w;
+            x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
         }
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const float vv[4] = {x.x, x.y, x.z, x.w};
         if (Q80) {
             uint32_t packed; float dd;
             wave_quant_q80(vv, packed, dd);
@@ -204,43 +227,30 @@ __device__ __forceinline__ void pre_finish(const MMVQArgs &a, const f32x4_t (&rx
         if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum;
         if (lane == 0) d[b] = dq;
     }
-    __syncthreads();
+    consumers_rendezvous(sy + SY_PRO2, lane);
 }
 
-// One wave: n_out outputs; output j is row  row0 + (j / UO) * ustride + j % UO  of the segment, UO = 2 for row pairs, 1
-// otherwise (SWIGLU: output j = gate row j and up row j, adjacent in the stream).  Returns after its outputs are stored.
-template <int TYPE, int KB, int FUSE, bool SWIGLU, bool PAIR>
-__device__ __forceinline__ void run_stream(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, const StLayout &lay, int row0, int ustride, int n_out) {
-    constexpr int UO = (PAIR && !SWIGLU) ? 2 : 1;
-    auto phys = [&](int j) { return row0 + (UO == 2 ? (j >> 1) * ustride + (j & 1) : j * ustride); };
-    using R = Raw<TYPE>;
-    constexpr bool ACT_REGS = KB <= 2;
-    constexpr int STEP = (SWIGLU || PAIR) ? 2 : 1;                // logical rows decoded together
+// ---- a loader wave (q < ST_NL).  The workgroup's rows [b0, b0 + n) are one contiguous run of `total` bytes per tensor.
+//   one tensor : the run is cut into 4 KiB slots, slot k lives at ring offset k * 4096 mod 128 KiB, loader q copies the
+//                slots k = q mod ST_NL;
+//   SwiGLU     : even loaders copy the gate run into the lower half of the ring, odd loaders the up run into the upper
+//                half (slot k of either at k * 4096 mod 64 KiB; loader q takes k = q / 2 mod ST_NL / 2).
+// FUSE 0: loader 0 first copies the quantised activation planes of the token.
+template <int FUSE, bool SWIGLU>
+__device__ __forceinline__ void run_loader(const StArgs &a, const StSeg &sg, uint8_t *smem, const StLayout &lay, int b0, unsigned total, unsigned step_bytes, int q) {
     const int lane = tid_now() & 63;
-    const int wave = uni(tid_now() >> 6);
-    const LaneRole L = make_role<TYPE>(lane);
-    const int nb = a.K >> 8;
+    const int wave = q; (void)wave;
+    int *sy = reinterpret_cast<int *>(smem + lay.sync);
     const unsigned rb = (unsigned)sg.row_bytes;
-    const uint8_t *W0 = sg.W, *W1 = SWIGLU ? a.seg[1].W : sg.W;
-    const int n_lr = SWIGLU ? 2 * n_out : n_out;                  // logical rows of the stream
-    const unsigned share = (unsigned)n_lr * rb;
-    const int NG = uni((int)((share + ST_GB - 1) / ST_GB));
-    uint8_t *ring = smem + lay.ring + wave * ST_RING;
-    const unsigned ring_lds = lds_addr(ring);
-    ST_STAMP(0);
-
-    // ---- 0. prologue requests that must land before the weights: f32 inputs of the fused modes (registers), the
-    //         residual of this wave's rows and (FUSE 0) this wave's pieces of the quantised activation planes (DMA)
-    f32x4_t rxv[StageDims<KB, ST_NT>::NJW], rwv[StageDims<KB, ST_NT>::NJW];
-    if (FUSE != 0) pre_issue<KB, FUSE>(a, rxv, rwv);
-    if (!SWIGLU && a.epi == EPI_ADD) {
-        const int j = lane < n_out ? lane : (n_out > 0 ? n_out - 1 : 0);
-        if (n_out > 0) dma4(sg.resid + phys(j), lds_addr(smem + lay.resid + wave * 256));
-    }
-    if (FUSE == 0) {
-        // pieces of 1 KiB: qs [K], then d [nb * 4], then bs [K / 8] (Q8_0 segments: not supported in this mode)
+    constexpr int NLT = SWIGLU ? ST_NL / 2 : ST_NL;              // loaders per run
+    const int t = SWIGLU ? (q & 1) : 0, u = SWIGLU ? (q >> 1) : q;
+    const uint8_t *W = (t == 1 ? a.W1 : sg.W) + (size_t)b0 * rb;
+    const unsigned ring_lds = lds_addr(smem + lay.ring) + (t == 1 ? ST_RING / 2 : 0);
+    if (FUSE == 0 && q == 0) {
+        // pieces of 1 KiB: qs [K], then d [nb * 4], then bs [K / 8]
+        const int nb = a.K >> 8;
         const int nq = a.K >> 10, nbs = ((a.K >> 3) + 1023) >> 10;
-        for (int c = wave; c < nq + 1 + nbs; c += ST_NW) {
+        for (int c = 0; c < nq + 1 + nbs; c++) {
             const uint8_t *src; int size; unsigned dst;
             if (c < nq) { src = reinterpret_cast<const uint8_t *>(a.aq) + c * 1024; size = 1024; dst = lay.qs + c * 1024; }
             else if (c == nq) { src = reinterpret_cast<const uint8_t *>(a.ad); size = nb * 4; dst = lay.d; }
@@ -249,44 +259,98 @@ __device__ __forceinline__ void run_stream(const MMVQArgs &a, const MMVQSeg &sg,
             dma16<false>(src + o, lds_addr(smem + dst));
         }
     }
-
-    // ---- 1. the weight stream.  Per lane: (lr, within) = logical row and byte inside it of this lane's 16 B of the NEXT
-    //         piece; pieces are issued strictly in order, so the cursor only moves forward.
-    int lr = 0;
-    unsigned within = (unsigned)lane * 16u;
-    while (within >= rb) { within -= rb; lr++; }
-    unsigned piece_off = (unsigned)lane * 16u;                    // logical byte offset of this lane in the next piece
-    const int last_lr = n_lr - 1;
-    auto issue_group = [&](int g) {
-        const unsigned dst = ring_lds + (unsigned)(g & (ST_RG - 1)) * ST_GB;
+    // the consumers' own requests go first: a load queued behind this wave's 60 KiB waits for all of it
+    ST_SPIN_WHILE(ld_sync(sy + SY_GO) < ST_NC, 0);
+    ST_STAMP(2);
+    const int NS_all = uni((int)((total + ST_SLOT - 1) / ST_SLOT));                 // slots of the run
+    const int NS = NS_all > u ? (NS_all - u + NLT - 1) / NLT : 0;                    // slots of this loader
+    const unsigned last = total - 16u;
+    const unsigned ring_bytes = SWIGLU ? ST_RING / 2 : ST_RING;
+    const uint8_t *pl = W + (size_t)u * ST_SLOT + (size_t)lane * 16;                 // this lane's 16 B of the next slot
+    auto issue_slot = [&](int j) {
+        const unsigned k = (unsigned)NLT * (unsigned)j + (unsigned)u;               // slot of the run
+        const unsigned dst = ring_lds + ((k * ST_SLOT) & (ring_bytes - 1));
+        if ((k + 1u) * ST_SLOT <= total) dma_slot(pl, dst);
+        else {
+            const unsigned off0 = k * ST_SLOT + (unsigned)lane * 16u;
 #pragma unroll
-        for (int k = 0; k < ST_GC; k++) {
-            const bool valid = piece_off < share;                 // past the share: every such lane re-reads the share's last 16 B
-            const int lr_u = valid ? lr : last_lr;
-            const unsigned wi_u = valid ? within : rb - 16u;
-            const int row = phys(SWIGLU ? (lr_u >> 1) : lr_u);
-            const uint8_t *base = (SWIGLU && (lr_u & 1)) ? W1 : W0;
-            dma16<true>(base + (size_t)row * rb + wi_u, dst + k * 1024);
-            piece_off += 1024u;
-            within += 1024u;
-            while (within >= rb) { within -= rb; lr++; }
+            for (int i = 0; i < ST_SI; i++) {
+                const unsigned off = off0 + i * 1024u;            // past the end: every such lane re-reads the run's last 16 B
+                dma16<true>(W + (off < total ? off : last), dst + i * 1024);
+            }
         }
+        pl += (size_t)NLT * ST_SLOT;
     };
-    int issued = 0;
-    if (n_lr > 0)
-        for (; issued < NG && issued < ST_RG; issued++) issue_group(issued);
-    ST_STAMP(1);
-
-    // ---- 2. activation into LDS / registers.  Everything requested in step 0 precedes the `issued` groups in this wave's queue.
-    if (FUSE != 0) {
-        wait_vm(issued * ST_GC);
-        pin_regs(rxv);
-        if (FUSE == 1) pin_regs(rwv);
-        pre_finish<KB, FUSE, TYPE == T_Q8_0>(a, rxv, rwv, smem, lay);
-    } else {
-        wait_vm(issued * ST_GC);
-        __syncthreads();
+    int issued = 0, published = 0, blocked_polls = 0;
+    unsigned free_until = ring_bytes;                             // bytes of the run that may be in the ring: consumed frontier + ring size
+    const unsigned consumed_per_step = SWIGLU ? rb : step_bytes;  // bytes of THIS run a decode step retires
+    while (issued < NS) {
+        const unsigned k = (unsigned)NLT * (unsigned)issued + (unsigned)u;
+        if ((k + 1u) * ST_SLOT > free_until) {
+            // the ring is full of unconsumed rows: nothing to issue, so everything in flight may as well be waited for
+            if (published < issued) { wait_vm_c<0>(); published = issued; st_sync(sy + SY_LANDED + q, published); }
+            int f = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < ST_NC; c++) { const int x = uni(ld_sync(sy + SY_DONE + c)); f = x < f ? x : f; }
+            const unsigned long long fb = (unsigned long long)(unsigned)f * (unsigned long long)consumed_per_step;
+            free_until = fb > 0xffffffffull - ring_bytes ? 0xffffffffu : (unsigned)fb + ring_bytes;
+            if ((k + 1u) * ST_SLOT > free_until) {
+                if (++blocked_polls > ST_SPIN_LIMIT) break;       // (never on a healthy run)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            continue;
+        }
+        issue_slot(issued);
+        issued++;
+        if (issued - published > ST_D) { wait_vm_c<ST_D * ST_SI>(); published = issued - ST_D; st_sync(sy + SY_LANDED + q, published); }
     }
+    ST_STAMP(1);
+    // drain in order
+#define DR(r) if (issued - published > r) { wait_vm_c<(r) * ST_SI>(); published = issued - r; st_sync(sy + SY_LANDED + q, published); }
+    if constexpr (ST_D > 8) { DR(14) DR(13) DR(12) DR(11) DR(10) DR(9) DR(8) }
+    DR(7) DR(6) DR(5) DR(4) DR(3) DR(2) DR(1) DR(0)
+#undef DR
+    ST_STAMP(5);
+}
+
+// ---- a consumer wave.  Step s of the workgroup = a row pair (UO = 2 outputs), one row (big K) or gate row s + up row s
+// (one output); consumer c decodes steps c, c + 8, ..
+template <int TYPE, int KB, int FUSE, bool SWIGLU, bool PAIR>
+__device__ __forceinline__ void run_consumer(const StArgs &a, const StSeg &sg, uint8_t *smem, const StLayout &lay, int b0, int n_rows_wg, int c) {
+    using R = Raw<TYPE>;
+    constexpr bool ACT_REGS = KB <= 2;
+    constexpr int STEP = (SWIGLU || PAIR) ? 2 : 1;                // rows decoded together
+    constexpr int UO = (PAIR && !SWIGLU) ? 2 : 1;                 // outputs per step
+    constexpr unsigned MASK = SWIGLU ? ST_MASK2 : ST_MASK;
+    const int lane = tid_now() & 63;
+    const int wave = c + ST_NL; (void)wave;
+    const LaneRole L = make_role<TYPE>(lane);
+    const int nb = a.K >> 8;
+    const unsigned rb = (unsigned)sg.row_bytes;
+    int *sy = reinterpret_cast<int *>(smem + lay.sync);
+    const uint8_t *ring = smem + lay.ring;
+    const uint8_t *ring1 = SWIGLU ? ring + ST_RING / 2 : ring;    // where the second row of a step is read from
+    const int n_steps = (n_rows_wg + UO - 1) / UO;
+    auto phys = [&](int j) { return b0 + (UO == 2 ? ((j >> 1) * ST_NC + c) * 2 + (j & 1) : j * ST_NC + c); };
+    // outputs of this consumer
+    int n_out = 0;
+    if (c < n_steps) {
+        const int my_steps = (n_steps - c + ST_NC - 1) / ST_NC;
+        const int last_step = c + (my_steps - 1) * ST_NC;
+        const int rows_last = n_rows_wg - last_step * UO < UO ? n_rows_wg - last_step * UO : UO;
+        n_out = (my_steps - 1) * UO + rows_last;
+    }
+    float rsd = 0.0f;                                             // residual of output `lane` (first 64 outputs), requested now
+    if (!SWIGLU && a.epi == EPI_ADD && lane < n_out) rsd = sg.resid[phys(lane)];
+
+    // ---- activation into LDS (fused modes: by the consumers themselves; planes: DMA'd by loader 0 ahead of its slot 0)
+    if (FUSE != 0) consumer_prologue<KB, FUSE, TYPE == T_Q8_0>(a, smem, lay, c, lane);
+    else {
+        asm volatile("" ::: "memory");
+        if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ST_SPIN_WHILE(ld_sync(sy + SY_LANDED) < 1, 1);
+    }
+    ST_STAMP(2);
     ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
     ActSlice S0, S1;
     if (ACT_REGS) {
@@ -294,8 +358,6 @@ __device__ __forceinline__ void run_stream(const MMVQArgs &a, const MMVQSeg &sg,
         if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
     }
 
-    ST_STAMP(2);
-    // ---- 3. decode rows out of the ring
     float res = 0.0f;                                             // lane i: output i of this wave (64 per flush)
     int n_done = 0, flushed = 0;
     auto flush = [&](int upto) {                                  // outputs [flushed, upto) are in lanes 0 ..
@@ -303,22 +365,33 @@ __device__ __forceinline__ void run_stream(const MMVQArgs &a, const MMVQSeg &sg,
         if (lane < cnt) {
             const int row = phys(flushed + lane);
             float v = res;
-            if (!SWIGLU && a.epi == EPI_ADD) {
-                const float rsd = flushed == 0 ? reinterpret_cast<const float *>(smem + lay.resid + wave * 256)[lane] : sg.resid[row];
-                v = rsd + v;
-            }
+            if (!SWIGLU && a.epi == EPI_ADD) v = (flushed == 0 ? rsd : sg.resid[row]) + v;
             sg.out[row] = v;
         }
         flushed = upto;
     };
     ST_ACC_DECL;
     ST_T0();
-    for (int i = 0; i < n_lr; i += STEP) {
-        const bool two = STEP == 2 && i + 1 < n_lr;
-        const unsigned off0 = (unsigned)i * rb;
-        const unsigned end = off0 + (two ? 2u : 1u) * rb;
-        const int g_need = (int)((end - 1u) / ST_GB);
-        wait_vm((issued - 1 - g_need) * ST_GC);
+    for (int s = c; s < n_steps; s += ST_NC) {
+        const bool two = STEP == 2 && (SWIGLU || s * 2 + 1 < n_rows_wg);
+        // ring offsets of the step's rows and the slots that must have landed
+        const unsigned off0 = SWIGLU ? (unsigned)s * rb : (unsigned)s * (unsigned)STEP * rb;
+        const unsigned off1 = SWIGLU ? off0 : (two ? off0 + rb : off0);
+        const unsigned end = SWIGLU ? off0 + rb : off0 + (two ? 2u : 1u) * rb;
+        const int n = (int)((end + ST_SLOT - 1) / ST_SLOT);       // slots [0, n) of the run(s)
+        {
+            constexpr int NLT = SWIGLU ? ST_NL / 2 : ST_NL;
+            auto missing = [&]() {
+                bool m = false;
+#pragma unroll
+                for (int q = 0; q < ST_NL; q++) {
+                    const int u = SWIGLU ? (q >> 1) : q;
+                    m = m || ld_sync(sy + SY_LANDED + q) < (n > u ? (n - u + NLT - 1) / NLT : 0);
+                }
+                return m;
+            };
+            ST_SPIN_WHILE(missing(), 1);
+        }
         ST_ACC(st_acc_w);
         float acc0 = 0.0f, acc1 = 0.0f;
         // K <= 4096: both passes in flight at once; longer rows: two passes at a time (fully unrolled, the compiler hoists
@@ -329,18 +402,16 @@ __device__ __forceinline__ void run_stream(const MMVQArgs &a, const MMVQSeg &sg,
             int sb = p * 8 + L.sbl;
             if (sb >= nb) sb = nb - 1;                            // tail of a partial last pass: any valid block, its slice scale is zero
             R w0, w1;
-            ring_load<TYPE>(w0, ring, off0, nb, sb, L);
-            if (STEP == 2) ring_load<TYPE>(w1, ring, two ? off0 + rb : off0, nb, sb, L);
+            ring_load<MASK>(w0, ring, off0, nb, sb, L);
+            if (STEP == 2) ring_load<MASK>(w1, ring1, off1, nb, sb, L);
             acc0 += w0.dot(sl, L);
             if (STEP == 2) acc1 += w1.dot(sl, L);
         }
         const float v0 = wave_sum(acc0);
         const float v1 = STEP == 2 ? wave_sum(acc1) : 0.0f;
-        asm volatile("" ::: "memory");                            // the ring reads above stay above the refill below
+        asm volatile("" ::: "memory");                            // the ring reads above stay above the release below
+        if (lane == 0) st_sync(sy + SY_DONE + c, s + ST_NC);
         ST_ACC(st_acc_d);
-        // refill: group `issued` lands on the slot of group issued - RG, free once every byte of it is consumed
-        while (issued < NG && (unsigned)(issued - ST_RG + 1) * ST_GB <= end) { issue_group(issued); issued++; }
-        ST_ACC(st_acc_r);
         if (SWIGLU) {
             const float y = (v0 / (1.0f + expf(-v0))) * v1;
             if (lane == (n_done & 63)) res = y;
@@ -366,54 +437,77 @@ __device__ __forceinline__ void run_stream(const MMVQArgs &a, const MMVQSeg &sg,
 }
 
 template <int KB, int FUSE>
-__global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs a) {
+__global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef MI355_STREAM_PROBE
+    const unsigned long long t_top = wall_clock64();
+#endif
     const StLayout lay = st_layout(KB);
+    // every kernel argument the launch can need, unconditionally (one batch of scalar loads)
+    const int n_seg = ka.n_seg, sb0 = ka.seg_block0[0], sb1 = ka.seg_block0[1], sb2 = ka.seg_block0[2], sb3 = ka.seg_block0[3];
+    const StArgs a{ka.K, ka.epi, ka.nck, ka.neps, ka.aq, ka.ad, ka.abs, ka.nx, ka.nw, ka.seg[1].W};
+    const StSeg g0{ka.seg[0].W, ka.seg[0].out, ka.seg[0].resid, ka.seg[0].type, ka.seg[0].n_rows, (unsigned)ka.seg[0].row_bytes};
+    const StSeg g1{ka.seg[1].W, ka.seg[1].out, ka.seg[1].resid, ka.seg[1].type, ka.seg[1].n_rows, (unsigned)ka.seg[1].row_bytes};
+    const StSeg g2{ka.seg[2].W, ka.seg[2].out, ka.seg[2].resid, ka.seg[2].type, ka.seg[2].n_rows, (unsigned)ka.seg[2].row_bytes};
+    // (pinned: without a use here hipcc sinks each load to its first use again)
+#define PIN(x) asm volatile("" :: "s"(x))
+    PIN(n_seg); PIN(sb0); PIN(sb1); PIN(sb2); PIN(sb3);
+    PIN(a.K); PIN(a.epi); PIN(a.nck); PIN(a.neps); PIN(a.aq); PIN(a.ad); PIN(a.abs); PIN(a.nx); PIN(a.nw); PIN(a.W1);
+    PIN(g0.W); PIN(g0.out); PIN(g0.resid); PIN(g0.type); PIN(g0.n_rows); PIN(g0.row_bytes);
+    PIN(g1.W); PIN(g1.out); PIN(g1.resid); PIN(g1.type); PIN(g1.n_rows); PIN(g1.row_bytes);
+    PIN(g2.W); PIN(g2.out); PIN(g2.resid); PIN(g2.type); PIN(g2.n_rows); PIN(g2.row_bytes);
+#undef PIN
     int s = 0;
-    if (a.n_seg > 1 && (int)blockIdx.x >= a.seg_block0[1]) s = 1;
-    if (a.n_seg > 2 && (int)blockIdx.x >= a.seg_block0[2]) s = 2;
-    const int nblk = a.seg_block0[s + 1] - a.seg_block0[s];
-    const int bl = (int)blockIdx.x - a.seg_block0[s];
-    const MMVQSeg &sg = a.seg[s];
+    if (n_seg > 1 && (int)blockIdx.x >= sb1) s = 1;
+    if (n_seg > 2 && (int)blockIdx.x >= sb2) s = 2;
+    const int lo = s == 0 ? sb0 : s == 1 ? sb1 : sb2, hi = s == 0 ? sb1 : s == 1 ? sb2 : sb3;
+    const int nblk = hi - lo;
+    const int bl = (int)blockIdx.x - lo;
+    StSeg sg;
+    sg.W = s == 0 ? g0.W : s == 1 ? g1.W : g2.W;
+    sg.out = s == 0 ? g0.out : s == 1 ? g1.out : g2.out;
+    sg.resid = s == 0 ? g0.resid : s == 1 ? g1.resid : g2.resid;
+    sg.type = s == 0 ? g0.type : s == 1 ? g1.type : g2.type;
+    sg.n_rows = s == 0 ? g0.n_rows : s == 1 ? g1.n_rows : g2.n_rows;
+    sg.row_bytes = s == 0 ? g0.row_bytes : s == 1 ? g1.row_bytes : g2.row_bytes;
     const int wave = uni(tid_now() >> 6);
-    // contiguous rows per workgroup, then per wave
+    // sync words: published slots 0, rendezvous 0, every consumer at its first step
+    if (threadIdx.x < 32) reinterpret_cast<int *>(smem + lay.sync)[threadIdx.x] = threadIdx.x >= SY_DONE ? (int)threadIdx.x - SY_DONE : 0;
+    __syncthreads();
+    // contiguous rows per workgroup
     const int rpb = (sg.n_rows + nblk - 1) / nblk;
     int b0 = bl * rpb, b1 = b0 + rpb;
     if (b0 > sg.n_rows) b0 = sg.n_rows;
     if (b1 > sg.n_rows) b1 = sg.n_rows;
+    const int n_rows_wg = b1 - b0;
+    if (n_rows_wg <= 0) return;
     const bool swiglu = a.epi == EPI_SWIGLU;
-    const bool pair = 2 * sg.row_bytes <= (size_t)ST_MAX_STEP;
-    // which rows a wave takes (a.nck, experiments): 0 = a contiguous run of its workgroup's rows; 1 = every 8th unit of its
-    // workgroup's rows (the workgroup reads one moving window); 2 = every (8 * workgroups)th unit of the segment
-    const int uo = (pair && !swiglu) ? 2 : 1;
-    int r0, ustride, n_out;
+    const bool pair = 2 * sg.row_bytes <= (size_t)ST_PAIR_MAX;
+    const unsigned total = (unsigned)n_rows_wg * (unsigned)sg.row_bytes;      // per tensor
+#ifdef MI355_STREAM_PROBE
     {
-        int lo, hi, first, stride;                                 // units [first, first + stride, ..) of rows [lo, hi)
-        if ((a.nck & 3) == 2) { lo = 0; hi = sg.n_rows; first = bl * ST_NW + wave; stride = nblk * ST_NW; }
-        else if ((a.nck & 3) == 1) { lo = b0; hi = b1; first = wave; stride = ST_NW; }
-        else {
-            const int upb = (b1 - b0 + uo - 1) / uo, upw = (upb + ST_NW - 1) / ST_NW;
-            lo = b0 + wave * upw * uo; hi = lo + upw * uo;
-            if (lo > b1) lo = b1;
-            if (hi > b1) hi = b1;
-            first = 0; stride = 1;
-        }
-        r0 = lo + first * uo; ustride = stride * uo;
-        const int avail = hi - r0;                                 // rows from the first unit to the end of the range
-        if (avail <= 0) n_out = 0;
-        else {
-            const int nu = (avail + ustride - 1) / ustride;        // units that start inside the range
-            const int last = avail - (nu - 1) * ustride;           // rows of the last one
-            n_out = (nu - 1) * uo + (last < uo ? last : uo);
+        unsigned dep = uni((int)total); asm volatile("" : "+s"(dep));
+        const unsigned long long t_args = wall_clock64() + (dep & 0);
+        if (g_stream_probe && (threadIdx.x & 63) == 0) {
+            unsigned long long *pp = &g_stream_probe[(((size_t)(a.nck >> 2) * 256 + blockIdx.x) * ST_NW + wave) * 8];
+            pp[0] = t_top; pp[7] = t_args;
         }
     }
+#endif
+    if (wave < ST_NL) {
+        const unsigned step_bytes = (unsigned)sg.row_bytes * ((swiglu || pair) ? 2u : 1u);
+        if (swiglu) { if constexpr (FUSE == 1) run_loader<FUSE, true>(a, sg, smem, lay, b0, total, step_bytes, wave); }
+        else run_loader<FUSE, false>(a, sg, smem, lay, b0, total, step_bytes, wave);
+        return;
+    }
+    const int c = wave - ST_NL;
     // forms that exist: SwiGLU pairs only with the fused RMSNorm prologue (gate/up), row pairs up to K = 8192, single rows
     // from K = 6144 (mmvq_stream_applicable agrees)
 #define RUN(TY)                                                                                               \
     do {                                                                                                      \
-        if (swiglu) { if constexpr (FUSE == 1) run_stream<TY, KB, FUSE, true, true>(a, sg, smem, lay, r0, ustride, n_out); } \
-        else if (pair) { if constexpr (KB <= 4) run_stream<TY, KB, FUSE, false, true>(a, sg, smem, lay, r0, ustride, n_out); } \
-        else { if constexpr (KB >= 3) run_stream<TY, KB, FUSE, false, false>(a, sg, smem, lay, r0, ustride, n_out); } \
+        if (swiglu) { if constexpr (FUSE == 1) run_consumer<TY, KB, FUSE, true, true>(a, sg, smem, lay, b0, n_rows_wg, c); } \
+        else if (pair) { if constexpr (KB <= 4) run_consumer<TY, KB, FUSE, false, true>(a, sg, smem, lay, b0, n_rows_wg, c); } \
+        else { if constexpr (KB >= 3) run_consumer<TY, KB, FUSE, false, false>(a, sg, smem, lay, b0, n_rows_wg, c); } \
     } while (0)
     switch (sg.type) {
         case T_Q4_K: RUN(T_Q4_K); break;
@@ -448,9 +542,9 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
         if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q8_0) return false;
         if (g.expert_sel) return false;
         if ((g.row_bytes % 16) != 0 || g.row_bytes < 1024) return false;
-        if ((swiglu ? 2 : 1) * g.row_bytes > (size_t)ST_MAX_STEP) return false;
-        if (kb <= 2 && 2 * g.row_bytes > (size_t)ST_MAX_STEP) return false;      // K <= 4096 only has the row-pair form
-        if (kb >= 6 && 2 * g.row_bytes <= (size_t)ST_MAX_STEP) return false;     // K >= 10240 only the single-row form
+        if (g.row_bytes > (size_t)ST_MAX_STEP) return false;
+        if (kb <= 2 && 2 * g.row_bytes > (size_t)ST_PAIR_MAX) return false;      // K <= 4096 only has the row-pair form
+        if (kb >= 6 && 2 * g.row_bytes <= (size_t)ST_PAIR_MAX) return false;     // K >= 10240 only the single-row form
         if ((reinterpret_cast<uintptr_t>(g.W) & 15) != 0) return false;
         if (a.fuse_mode == 0 && (t == T_Q8_0 || !a.aq || !a.ad || !a.abs)) return false;
     }

@@ -15,6 +15,9 @@ using namespace mi355;
 namespace mi355 { void mmvq_stream_set_probe(unsigned long long *p); }
 #endif
 #include <algorithm>
+#ifndef MI355_STREAM_NL
+#define MI355_STREAM_NL 2
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -159,16 +162,15 @@ int main(int argc, char **argv) {
         CK(hipStreamSynchronize(st));
         std::vector<uint32_t> ha(tot), hb(tot);
         CK(hipMemcpy(ha.data(), op.out_a, tot * 4, hipMemcpyDeviceToHost));
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 1; mode++) {
             CK(hipMemset(op.out_b, 0xee, tot * 4));
-            b.nck = mode;
             CK(launch_mmvq_stream(b, st));
             CK(hipStreamSynchronize(st));
             CK(hipMemcpy(hb.data(), op.out_b, tot * 4, hipMemcpyDeviceToHost));
             size_t bad = 0, first = 0;
             for (size_t i = 0; i < tot; i++) if (ha[i] != hb[i]) { if (!bad) first = i; bad++; }
             float fa, fb; memcpy(&fa, &ha[first], 4); memcpy(&fb, &hb[first], 4);
-            printf("%s mapping %d: %zu outputs, %zu differ%s", op.name.c_str(), mode, tot, bad, bad ? "" : "  (bit-identical)\n");
+            printf("%s: %zu outputs, %zu differ%s", op.name.c_str(), tot, bad, bad ? "" : "  (bit-identical)\n");
             if (bad) printf("  first at %zu: fast %g stream %g\n", first, fa, fb);
             bad_total += bad != 0;
         }
@@ -219,16 +221,6 @@ int main(int argc, char **argv) {
                    b0 / std::min({t[0], t[1], t[2], t[3], t[4]}) * 1e-3);
         }
     }
-    // row-to-wave mapping of the stream kernel
-    printf("\n%-42s %10s %10s %10s\n", "stream kernel by row mapping, us per launch", "contig", "cu-window", "chip");
-    for (auto &op : ops) {
-        const int nsets = (int)op.W[0].size();
-        if (nsets < NL) continue;
-        double t[3];
-        for (int mode = 0; mode < 3; mode++)
-            t[mode] = time_graph([&] { for (int r = 0; r < 4; r++) for (int l = 0; l < nsets; l++) { MMVQArgs a = make_args(op, l, op.out_b); a.nck = mode; CK(launch_mmvq_stream(a, st)); } }, 4 * nsets);
-        printf("%-42s %10.2f %10.2f %10.2f\n", op.name.c_str(), t[0], t[1], t[2]);
-    }
     // the layer chain: qkv -> o -> gate/up -> down (q4k), 8 layers x 4
     {
         Op &qkv = ops[0], &o = ops[2], &gu = ops[3], &dn = ops[4];
@@ -245,7 +237,8 @@ int main(int argc, char **argv) {
     {   // timeline of the stream kernels of one layer in the middle of a 3-layer chain (100 MHz wall clock)
         Op &qkv = ops[0], &o = ops[2], &gu = ops[3], &dn = ops[4];
         const int NK = 12;
-        unsigned long long *probe; const size_t pn = (size_t)NK * 256 * 8 * 8;
+        unsigned long long *probe; const int WPW = MI355_STREAM_NL + 8, WPK = 256 * WPW;   // waves per kernel (loaders + 8 consumers per workgroup)
+        const size_t pn = (size_t)NK * WPK * 8;
         CK(hipMalloc(&probe, pn * 8)); CK(hipMemset(probe, 0, pn * 8));
         mmvq_stream_set_probe(probe);
         Op *chain[4] = {&qkv, &o, &gu, &dn};
@@ -258,20 +251,28 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(h.data(), probe, pn * 8, hipMemcpyDeviceToHost));
         mmvq_stream_set_probe(nullptr);
         unsigned long long base = ~0ull;
-        for (int w = 0; w < 2048; w++) { const unsigned long long t = h[((size_t)4 * 2048 + w) * 8]; if (t && t < base) base = t; }
+        for (int w = 0; w < WPK; w++) { const unsigned long long t = h[((size_t)4 * WPK + w) * 8]; if (t && t < base) base = t; }
         printf("\nstream kernel timeline, layer 2 of 3 (eager launches), us since the first wave of its qkv entered; min / median / max over waves\n");
-        printf("%-8s %-20s %-20s %-20s %-20s %-20s | %-18s %-18s %-18s\n", "kernel", "entry", "first groups issued", "activation ready", "last row decoded", "outputs stored",
-               "sum wait-for-data", "sum decode", "sum refill");
+        printf("%-8s %-18s %-18s %-18s %-18s %-18s | %-18s %-18s %-18s %-18s %-18s | %-16s %-16s\n", "kernel", "loader: top", "args loaded", "go", "all issued", "all landed",
+               "consumers: top", "args loaded", "activation ready", "last decoded", "outputs stored", "sum wait-slot", "sum decode");
         for (int k = 4; k < 9; k++) {
             printf("%-8s", k == 4 ? "qkv" : k == 5 ? "o" : k == 6 ? "gate/up" : k == 7 ? "down" : "qkv(3)");
-            for (int sidx : {0, 1, 2, 4, 5, 3, 6, 7}) {
+            for (int col = 0; col < 12; col++) {
+                const bool loader = col < 5;
+                static const int lmap[5] = {0, 7, 2, 1, 5}, cmap[7] = {0, 7, 2, 4, 5, 3, 6};
+                const int sidx = loader ? lmap[col] : cmap[col - 5];
+                const bool rel = col >= 10;
                 std::vector<double> v;
-                const bool rel = sidx == 3 || sidx == 6 || sidx == 7;
-                for (int w = 0; w < 2048; w++) { const unsigned long long t = h[((size_t)k * 2048 + w) * 8 + sidx]; if (t || rel) v.push_back(rel ? (double)t * 0.01 : (double)(long long)(t - base) * 0.01); }
-                if (v.empty()) { printf(" %-20s", "-"); continue; }
+                for (int w = 0; w < WPK; w++) {
+                    if (loader != ((w % WPW) < MI355_STREAM_NL)) continue;
+                    const unsigned long long t = h[((size_t)k * WPK + w) * 8 + sidx];
+                    if (t || rel) v.push_back(rel ? (double)t * 0.01 : (double)(long long)(t - base) * 0.01);
+                }
+                if (col == 5 || col == 10) printf(" |");
+                if (v.empty()) { printf(" %-18s", "-"); continue; }
                 std::sort(v.begin(), v.end());
                 char buf[64]; snprintf(buf, sizeof buf, "%.2f/%.2f/%.2f", v.front(), v[v.size() / 2], v.back());
-                printf(sidx == 3 ? " | %-18s" : rel ? " %-18s" : " %-20s", buf);
+                printf(rel ? " %-16s" : " %-18s", buf);
             }
             printf("\n");
         }
