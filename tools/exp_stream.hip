@@ -118,6 +118,7 @@ static MMVQArgs make_args(const Op &op, int set, float *out) {
 
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); set_num_cu(prop.multiProcessorCount);
     printf("device: %s, %d CUs\n", prop.name, prop.multiProcessorCount);
     g_aq = (int8_t *)dev_rand_bytes(FF, 1, 0xff);
@@ -237,7 +238,7 @@ int main(int argc, char **argv) {
     {   // timeline of the stream kernels of one layer in the middle of a 3-layer chain (100 MHz wall clock)
         Op &qkv = ops[0], &o = ops[2], &gu = ops[3], &dn = ops[4];
         const int NK = 12;
-        unsigned long long *probe; const int WPW = MI355_STREAM_NL + 8, WPK = 256 * WPW;   // waves per kernel (loaders + 8 consumers per workgroup)
+        unsigned long long *probe; const int WPW = 2 + 8, WPK = 256 * WPW;   // waves per kernel (loaders + 8 consumers per workgroup)
         const size_t pn = (size_t)NK * WPK * 8;
         CK(hipMalloc(&probe, pn * 8)); CK(hipMemset(probe, 0, pn * 8));
         mmvq_stream_set_probe(probe);
@@ -264,7 +265,7 @@ int main(int argc, char **argv) {
                 const bool rel = col >= 10;
                 std::vector<double> v;
                 for (int w = 0; w < WPK; w++) {
-                    if (loader != ((w % WPW) < MI355_STREAM_NL)) continue;
+                    if (loader != ((w % WPW) < 2)) continue;
                     const unsigned long long t = h[((size_t)k * WPK + w) * 8 + sidx];
                     if (t || rel) v.push_back(rel ? (double)t * 0.01 : (double)(long long)(t - base) * 0.01);
                 }
