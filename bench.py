@@ -244,8 +244,10 @@ def main() -> int:
             def give_up():                                 # a rank stuck in a collective cannot be recovered in-process
                 if rank == 0 and out is not None:
                     out["row_split"] = {"error": f"abandoned after {args.row_split_timeout:.0f} s"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
+                    print(json.dumps(out), flush=True)     # the replicas measurement is complete: keep the line
+                else:
+                    print(f"[bench rank {rank}] row-split section abandoned after {args.row_split_timeout:.0f} s", file=sys.stderr, flush=True)
+                os._exit(3)                                # a process that touched the GPU and gave up must not report success
             wd = threading.Timer(args.row_split_timeout, give_up)
             wd.daemon = True
             wd.start()
@@ -257,7 +259,9 @@ def main() -> int:
                 out["row_split"] = rs
                 print(json.dumps(out), flush=True)
             if "error" in rs:                              # peers may be stuck: do not enter another collective
-                os._exit(0)
+                if rank != 0:
+                    print(f"[bench rank {rank}] row-split section failed: {rs['error']}", file=sys.stderr, flush=True)
+                os._exit(3)
             wd.cancel()
         elif rank == 0 and out is not None:
             print(json.dumps(out), flush=True)

@@ -1,6 +1,8 @@
 // c_api.cc — the C-ABI declared in include/mi355_llama.h, over host/runtime.{h,cc}.
 #include "../../include/mi355_llama.h"
 
+#include <memory>
+#include <new>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +38,14 @@ static int g_op_mmq_planes = 1, g_op_mmq_ksplit = 1;
 static bool g_backend_ok = false;
 
 static void fail(const std::string &s) { t_err = s; }
+
+// No C++ exception may cross the C ABI (the reference's own rule for its plugin boundary, enginei.h): allocation failures
+// and anything else thrown below an entry point become that entry point's error return and a last_error message.
+#define MI355_GUARD(on_error, ...)                                              \
+    try { __VA_ARGS__ }                                                         \
+    catch (const std::bad_alloc &) { fail("out of host memory"); on_error; }    \
+    catch (const std::exception &ex) { fail(std::string("internal error: ") + ex.what()); on_error; } \
+    catch (...) { fail("internal error"); on_error; }
 
 extern "C" {
 
@@ -90,13 +100,16 @@ mi355_model *mi355_model_load_from_file(const char *path, mi355_model_params par
         fail("tp_size > 1 needs the process's row-split group first (mi355_tp_init with the same rank / size)");
         return nullptr;
     }
-    std::string err;
-    int status = 0;
-    Model *m = model_load(path, params.main_gpu, err, status, params.prefill_planes, params.tp_rank, params.tp_size);
-    if (!m) { fail(err); return nullptr; }
-    mi355_model *h = new mi355_model;
-    h->m = m;
-    return h;
+    MI355_GUARD(return nullptr,
+        std::string err;
+        int status = 0;
+        Model *m = model_load(path, params.main_gpu, err, status, params.prefill_planes, params.tp_rank, params.tp_size);
+        if (!m) { fail(err); return nullptr; }
+        mi355_model *h = new (std::nothrow) mi355_model;
+        if (!h) { delete m; fail("out of host memory"); return nullptr; }
+        h->m = m;
+        return h;
+    )
 }
 void mi355_model_free(mi355_model *model) {
     if (!model) return;
@@ -145,10 +158,15 @@ mi355_context *mi355_context_new(mi355_model *model, mi355_context_params params
     cp.embeddings = params.embeddings != 0;
     cp.use_graphs = params.use_graphs != 0;
     cp.logits_to_host = params.logits_to_host != 0;
-    Context *c = new Context(model->m, cp);
-    std::string err;
-    if (!c->init(err)) { fail(err); delete c; return nullptr; }
-    return new mi355_context{c, {}};
+    if (cp.n_ctx == 0 || cp.n_batch == 0 || cp.n_seq_max > 64) { fail("bad context parameters (n_ctx and n_batch must be positive, n_seq_max at most 64)"); return nullptr; }
+    MI355_GUARD(return nullptr,
+        std::unique_ptr<Context> c(new Context(model->m, cp));
+        std::string err;
+        if (!c->init(err)) { fail(err); return nullptr; }
+        mi355_context *h = new mi355_context{c.get(), {}};
+        c.release();
+        return h;
+    )
 }
 void mi355_context_free(mi355_context *ctx) {
     if (!ctx) return;
@@ -182,9 +200,11 @@ void mi355_batch_free(mi355_batch b) {
 
 int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
     if (!ctx) return MI355_ERR_ARG;
-    const int rc = ctx->c->decode(batch.n_tokens, batch.token, batch.pos, batch.n_seq_id, batch.seq_id, batch.logits);
-    if (rc < 0) fail(ctx->c->last_error);
-    return rc;
+    MI355_GUARD(return MI355_ERR_ARG,
+        const int rc = ctx->c->decode(batch.n_tokens, batch.token, batch.pos, batch.n_seq_id, batch.seq_id, batch.logits);
+        if (rc < 0) fail(ctx->c->last_error);
+        return rc;
+    )
 }
 float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
@@ -194,9 +214,24 @@ float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
 
 void mi355_kv_cache_clear(mi355_context *ctx) { ctx->c->kv_clear(); }
-int32_t mi355_kv_cache_seq_rm(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1) { return ctx->c->kv_seq_rm(seq, p0, p1) ? 1 : 0; }
-void mi355_kv_cache_seq_cp(mi355_context *ctx, mi355_seq_id src, mi355_seq_id dst, mi355_pos p0, mi355_pos p1) { ctx->c->kv_seq_cp(src, dst, p0, p1); }
-void mi355_kv_cache_seq_add(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1, mi355_pos delta) { ctx->c->kv_seq_add(seq, p0, p1, delta); }
+// sequence ids index a 64-bit mask per cell: anything outside [0, 64) is refused here (seq < 0 = "every sequence" only
+// where upstream defines it: seq_rm)
+static bool seq_in_range(const mi355_context *, mi355_seq_id seq) { return seq >= 0 && seq < 64; }
+int32_t mi355_kv_cache_seq_rm(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1) {
+    if (!ctx) return 0;
+    if (seq >= 0 && !seq_in_range(ctx, seq)) { fail("seq_rm: sequence id out of range"); return 0; }
+    return ctx->c->kv_seq_rm(seq, p0, p1) ? 1 : 0;
+}
+void mi355_kv_cache_seq_cp(mi355_context *ctx, mi355_seq_id src, mi355_seq_id dst, mi355_pos p0, mi355_pos p1) {
+    if (!ctx) return;
+    if (!seq_in_range(ctx, src) || !seq_in_range(ctx, dst)) { fail("seq_cp: sequence id out of range"); return; }
+    ctx->c->kv_seq_cp(src, dst, p0, p1);
+}
+void mi355_kv_cache_seq_add(mi355_context *ctx, mi355_seq_id seq, mi355_pos p0, mi355_pos p1, mi355_pos delta) {
+    if (!ctx) return;
+    if (!seq_in_range(ctx, seq)) { fail("seq_add: sequence id out of range"); return; }
+    ctx->c->kv_seq_add(seq, p0, p1, delta);
+}
 int32_t mi355_kv_cache_used_cells(const mi355_context *ctx) { return ctx->c->kv_used_cells(); }
 
 void mi355_debug_enable_taps(mi355_context *ctx, int32_t enabled) { ctx->c->set_debug_taps(enabled != 0); }
@@ -526,20 +561,24 @@ static Vocab *model_vocab(mi355_model *m) {
     return m->vocab_ok ? &m->vocab : nullptr;
 }
 int32_t mi355_tokenize(mi355_model *m, const char *text, int32_t text_len, mi355_token *out, int32_t cap, int32_t add_special, int32_t parse_special) {
-    Vocab *v = model_vocab(m);
-    if (!v || !text || text_len < 0) return INT32_MIN;
-    const std::vector<int32_t> ids = v->tokenize(std::string(text, (size_t)text_len), add_special != 0, parse_special != 0);
-    if ((int64_t)ids.size() > cap || !out) return -(int32_t)ids.size();
-    memcpy(out, ids.data(), ids.size() * sizeof(int32_t));
-    return (int32_t)ids.size();
+    MI355_GUARD(return INT32_MIN,
+        Vocab *v = model_vocab(m);
+        if (!v || !text || text_len < 0) return INT32_MIN;
+        const std::vector<int32_t> ids = v->tokenize(std::string(text, (size_t)text_len), add_special != 0, parse_special != 0);
+        if ((int64_t)ids.size() > cap || !out) return -(int32_t)ids.size();
+        memcpy(out, ids.data(), ids.size() * sizeof(int32_t));
+        return (int32_t)ids.size();
+    )
 }
 int32_t mi355_token_to_piece(mi355_model *m, mi355_token tok, char *buf, int32_t cap, int32_t special) {
-    Vocab *v = model_vocab(m);
-    if (!v) return INT32_MIN;
-    const std::string p = v->token_to_piece(tok, special != 0);
-    if ((int64_t)p.size() > cap || !buf) return -(int32_t)p.size();
-    memcpy(buf, p.data(), p.size());
-    return (int32_t)p.size();
+    MI355_GUARD(return INT32_MIN,
+        Vocab *v = model_vocab(m);
+        if (!v) return INT32_MIN;
+        const std::string p = v->token_to_piece(tok, special != 0);
+        if ((int64_t)p.size() > cap || !buf) return -(int32_t)p.size();
+        memcpy(buf, p.data(), p.size());
+        return (int32_t)p.size();
+    )
 }
 mi355_token mi355_token_bos(mi355_model *m) { Vocab *v = model_vocab(m); return v ? v->bos() : -1; }
 mi355_token mi355_token_eos(mi355_model *m) { Vocab *v = model_vocab(m); return v ? v->eos() : -1; }
@@ -564,16 +603,33 @@ static LlamaEngine::Callback wrap_cb(mi355_engine_callback cb, void *user) {
         cb(s.c_str(), b.c_str(), user);
     };
 }
+// an exception below an engine entry point: answered in the reference's error shape (status 500), never thrown at the host
+static void engine_exception(mi355_engine_callback cb, void *user, const char *what) {
+    fail(std::string("internal error: ") + what);
+    if (!cb) return;
+    try {
+        Json st = Json::object(), body = Json::object();
+        st["is_done"] = true; st["has_error"] = true; st["is_stream"] = false; st["status_code"] = 500;
+        body["message"] = std::string("Internal error: ") + what;
+        cb(st.dump().c_str(), body.dump().c_str(), user);
+    } catch (...) {}
+}
 mi355_engine *mi355_engine_create(void) {
     if (!g_backend_ok && mi355_backend_init() != MI355_OK) return nullptr;
-    return new mi355_engine;
+    MI355_GUARD(return nullptr, return new mi355_engine;)
 }
 void mi355_engine_destroy(mi355_engine *e) { delete e; }
 #define MI355_ENGINE_FWD(cname, Method)                                                                     \
     void cname(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user) {              \
-        Json j;                                                                                             \
-        if (!e || !parse_body(body_json, j, cb, user)) return;                                              \
-        e->eng.Method(j, wrap_cb(cb, user));                                                                \
+        try {                                                                                               \
+            Json j;                                                                                         \
+            if (!e || !parse_body(body_json, j, cb, user)) return;                                          \
+            e->eng.Method(j, wrap_cb(cb, user));                                                            \
+        } catch (const std::exception &ex) {                                                                \
+            engine_exception(cb, user, ex.what());                                                          \
+        } catch (...) {                                                                                     \
+            engine_exception(cb, user, "unknown exception");                                                \
+        }                                                                                                   \
     }
 MI355_ENGINE_FWD(mi355_engine_load_model, LoadModel)
 MI355_ENGINE_FWD(mi355_engine_unload_model, UnloadModel)

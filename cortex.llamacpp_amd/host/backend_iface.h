@@ -29,6 +29,8 @@ class IBackend {
     virtual const Vocab &vocab() const = 0;
     // llama_decode: 0 ok, 1 no KV slot, < 0 error
     virtual int decode(const BatchView &b) = 0;
+    // what went wrong in the last decode that returned < 0 (empty when the backend keeps no message)
+    virtual const char *last_error() const { return ""; }
     // logits row of batch index i of the last decode (llama_get_logits_ith)
     virtual const float *logits_ith(int i) = 0;
     // index of the largest logit of batch row i, computed on the device (first maximum wins), or -1 when the backend has

@@ -95,6 +95,10 @@ std::string GGUFFile::open(const std::string &path) {
     if (magic != 0x46554747u) return "bad magic (not GGUF)";
     if (version < 2 || version > 3) return "unsupported GGUF version " + std::to_string(version);
     const uint64_t n_tensors = r.get<uint64_t>(), n_kv = r.get<uint64_t>();
+    // counts come from the file: nothing is sized from them before they are checked against the bytes that are actually
+    // there (a key / value pair takes at least 12 bytes, a tensor record at least 24, a string element at least 8)
+    const uint64_t remaining = (uint64_t)(r.end - r.p);
+    if (r.bad || n_kv > remaining / 12 || n_tensors > remaining / 24) return "truncated or corrupt GGUF header (counts exceed the file size)";
     for (uint64_t i = 0; i < n_kv && !r.bad; i++) {
         std::string key = r.str();
         GGUFValue v;
@@ -105,12 +109,13 @@ std::string GGUFFile::open(const std::string &path) {
             v.elem_type = r.get<uint32_t>();
             v.u = r.get<uint64_t>();
             if (v.elem_type == GV_STR) {
+                if (v.u > (uint64_t)(r.end - r.p) / 8) { r.bad = true; break; }
                 v.strs.reserve((size_t)v.u);
                 for (uint64_t j = 0; j < v.u && !r.bad; j++) v.strs.push_back(r.str());
             } else if (v.elem_type < 13 && kScalarSize[v.elem_type]) {
                 v.raw = r.p;
-                const uint64_t nbytes = v.u * (uint64_t)kScalarSize[v.elem_type];
-                if (nbytes > (uint64_t)(r.end - r.p)) r.bad = true; else r.p += nbytes;
+                const uint64_t esz = (uint64_t)kScalarSize[v.elem_type];
+                if (v.u > (uint64_t)(r.end - r.p) / esz) r.bad = true; else r.p += v.u * esz;
             } else {
                 r.bad = true;
             }
@@ -127,7 +132,12 @@ std::string GGUFFile::open(const std::string &path) {
         t.name = r.str();
         t.n_dims = (int)r.get<uint32_t>();
         if (t.n_dims < 0 || t.n_dims > 4) { r.bad = true; break; }
-        for (int d = 0; d < t.n_dims; d++) t.ne[d] = (int64_t)r.get<uint64_t>();
+        for (int d = 0; d < t.n_dims; d++) {
+            const uint64_t ne = r.get<uint64_t>();
+            if (ne == 0 || ne > (uint64_t)1 << 40) { r.bad = true; break; }     // (ne stays 1 for the unused dimensions)
+            t.ne[d] = (int64_t)ne;
+        }
+        if (r.bad) break;
         t.type = (int)r.get<uint32_t>();
         t.offset = r.get<uint64_t>();
         if (r.bad) break;
@@ -135,13 +145,20 @@ std::string GGUFFile::open(const std::string &path) {
     if (r.bad) return "truncated or corrupt GGUF tensor table";
     uint64_t data_off = (uint64_t)(r.p - map_);
     data_off = (data_off + alignment - 1) / alignment * alignment;
+    if (data_off > file_size) return "truncated GGUF file (no tensor data)";
+    const uint64_t data_bytes = (uint64_t)file_size - data_off;
     for (size_t i = 0; i < tensors.size(); i++) {
         auto &t = tensors[i];
-        const int64_t rows = t.ne[1] * t.ne[2] * t.ne[3];
+        // rows * row bytes and offset + bytes in arithmetic that cannot wrap (every ne is in [1, 2^40])
+        unsigned __int128 rows = (unsigned __int128)(uint64_t)t.ne[1] * (uint64_t)t.ne[2] * (uint64_t)t.ne[3];
         const size_t rb = ggml_type_row_bytes(t.type, t.ne[0]);
-        t.bytes = rb * (size_t)rows;
-        if (rb && data_off + t.offset + t.bytes > file_size) return "tensor " + t.name + " runs past end of file";
-        t.data = map_ + data_off + t.offset;
+        const unsigned __int128 bytes = rows * rb;
+        if (rb) {
+            if (bytes > data_bytes || t.offset > data_bytes - (uint64_t)bytes) return "tensor " + t.name + " runs past end of file";
+            if (t.offset % alignment) return "tensor " + t.name + " is not aligned to general.alignment";
+        }
+        t.bytes = rb ? (size_t)bytes : 0;
+        t.data = rb ? map_ + data_off + t.offset : nullptr;      // (unsupported type: no bytes are ever read; the loader rejects it by name)
         index_[t.name] = i;
     }
     return {};

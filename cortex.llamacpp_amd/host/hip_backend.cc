@@ -33,6 +33,7 @@ class HipBackend : public IBackend {
         for (int i = 0; i < b.n_tokens; i++) seq_ptr_[(size_t)i] = &seq_store_[(size_t)i];
         return ctx_->decode(b.n_tokens, b.token, b.pos, n_seq_id_.data(), seq_ptr_.data(), b.logits);
     }
+    const char *last_error() const override { return ctx_->last_error.c_str(); }
     const float *logits_ith(int i) override { return ctx_->logits_ith(i); }
     int argmax_ith(int i) override { return ctx_->argmax_ith(i); }
     void set_embeddings(bool on) override { ctx_->embeddings_enabled = on; }

@@ -63,7 +63,18 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     hp.n_expert = (int)f.get_u(a + "expert_count", 0);
     hp.n_expert_used = (int)f.get_u(a + "expert_used_count", 0);
     hp.n_ctx_train = (int)f.get_u(a + "context_length", 0);
-    if (!hp.n_embd || !hp.n_layer || !hp.n_head) { err = "missing hyper-parameters for arch " + hp.arch; status = -102; return nullptr; }
+    if (hp.n_embd <= 0 || hp.n_layer <= 0 || hp.n_head <= 0) { err = "missing hyper-parameters for arch " + hp.arch; status = -102; return nullptr; }
+    if (hp.n_layer > 1024 || hp.n_embd > (1 << 20) || hp.n_head > 4096) { err = "implausible hyper-parameters for arch " + hp.arch; status = -102; return nullptr; }
+    // the head counts size buffers and pick kernels: check them here, not at the first decode
+    if (hp.n_head_kv <= 0 || hp.n_head % hp.n_head_kv) { err = "attention.head_count_kv (" + std::to_string(hp.n_head_kv) + ") must be positive and divide attention.head_count (" + std::to_string(hp.n_head) + ")"; status = -102; return nullptr; }
+    {
+        const int ratio = hp.n_head / hp.n_head_kv;
+        if (ratio != 1 && ratio != 2 && ratio != 4 && ratio != 8) { err = "unsupported query / kv head ratio " + std::to_string(ratio) + " (the attention kernels are built for 1, 2, 4, 8)"; status = -102; return nullptr; }
+    }
+    if (hp.n_embd % hp.n_head) { err = "embedding_length is not a multiple of attention.head_count"; status = -102; return nullptr; }
+    if (hp.n_expert < 0 || hp.n_expert > 256 || hp.n_expert_used < 0 || hp.n_expert_used > hp.n_expert || (hp.n_expert > 0 && hp.n_expert_used == 0)) {
+        err = "bad expert_count / expert_used_count"; status = -102; return nullptr;
+    }
     hp.head_dim = hp.n_embd / hp.n_head;
     hp.n_rot = (int)f.get_u(a + "rope.dimension_count", (uint64_t)hp.head_dim);
     hp.rope_neox = hp.arch != "llama";
@@ -86,9 +97,6 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         if (((hp.n_head / P) * hp.head_dim) % 256) { err = "a rank's attention width must be a multiple of 256"; status = -102; return nullptr; }
         hp.n_head /= P; hp.n_head_kv /= P;
     }
-
-    if (hipSetDevice(main_gpu) != hipSuccess) { err = "hipSetDevice failed"; status = -100; return nullptr; }
-    m->device = main_gpu;
 
     // plan the arena
     // where a tensor's bytes come from: the whole tensor, or this rank's rows (a contiguous range), or this rank's
@@ -173,11 +181,60 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         }
     }
     if (fail) { status = -102; return nullptr; }
+    // ---- every tensor against the shape the hyper-parameters imply (per rank under a row split).  The activation buffers
+    // are sized from the hyper-parameters and the kernels write one value per weight ROW: a file whose tensors disagree
+    // with its own metadata must fail here, not write out of bounds at the first decode (upstream create_tensor does the
+    // same).  Per-rank sizes: hp.n_head / n_head_kv are already this rank's.
+    {
+        const int64_t E = hp.n_embd, D = hp.head_dim, QW = (int64_t)hp.n_head * D, KVW = (int64_t)hp.n_head_kv * D;
+        auto shape = [&](const DevTensor &t, int64_t K, int64_t N, int64_t NE, bool vec) {
+            if (fail || t.name.empty()) return;                    // (absent optional tensor)
+            const bool ok = vec ? (t.K == K && t.N == 1 && t.n_expert == 1) : (t.K == K && t.N == N && t.n_expert == NE);
+            if (!ok) {
+                err = "tensor " + t.name + " has shape [" + std::to_string(t.K) + ", " + std::to_string(t.N) + ", " + std::to_string(t.n_expert) + "], expected [" +
+                      std::to_string(K) + (vec ? "]" : ", " + std::to_string(N) + ", " + std::to_string(NE) + "]");
+                fail = true;
+            }
+        };
+        if (m->tok_embd.K != E || m->tok_embd.N <= 0 || m->tok_embd.n_expert != 1) { err = "token_embd.weight does not have embedding_length columns"; fail = true; }
+        const int64_t V = m->tok_embd.N;
+        shape(m->out_norm, E, 0, 0, true);
+        if (!m->output.name.empty()) shape(m->output, E, f.tensor("output.weight")->ne[1] % P == 0 ? V / P : V, 1, false);
+        if (!m->rope_freqs.name.empty() && (m->rope_freqs.K != hp.n_rot / 2 || m->rope_freqs.type != T_F32)) { err = "rope_freqs.weight must hold rope.dimension_count / 2 f32 factors"; fail = true; }
+        if (hp.n_rot <= 0 || hp.n_rot > D || (hp.n_rot & 1)) { err = "bad rope.dimension_count"; fail = true; }
+        int64_t FF = 0;
+        for (int il = 0; il < hp.n_layer && !fail; il++) {
+            const LayerWeights &L = m->layers[(size_t)il];
+            shape(L.attn_norm, E, 0, 0, true); shape(L.ffn_norm, E, 0, 0, true);
+            shape(L.wq, E, QW, 1, false); shape(L.wk, E, KVW, 1, false); shape(L.wv, E, KVW, 1, false);
+            shape(L.wo, QW, E, 1, false);
+            shape(L.bq, QW, 0, 0, true); shape(L.bk, KVW, 0, 0, true); shape(L.bv, KVW, 0, 0, true);
+            if (hp.n_expert > 0) {
+                if (il == 0) FF = L.gate_exps.N;
+                shape(L.gate_inp, E, hp.n_expert, 1, false);
+                shape(L.gate_exps, E, FF, hp.n_expert, false); shape(L.up_exps, E, FF, hp.n_expert, false);
+                shape(L.down_exps, FF, E, hp.n_expert, false);
+            } else {
+                if (il == 0) FF = L.gate.N;
+                shape(L.gate, E, FF, 1, false); shape(L.up, E, FF, 1, false);
+                shape(L.down, FF, E, 1, false);
+            }
+            if (!fail && (FF <= 0 || (hp.n_ff_full > 0 && FF * P != hp.n_ff_full))) { err = "feed-forward tensors do not match feed_forward_length"; fail = true; }
+            // norms and biases are read as f32 vectors by the kernels
+            for (const DevTensor *t : {&L.attn_norm, &L.ffn_norm, &L.bq, &L.bk, &L.bv})
+                if (!fail && !t->name.empty() && t->type != T_F32) { err = "tensor " + t->name + " must be f32"; fail = true; }
+        }
+        if (!fail && m->out_norm.type != T_F32) { err = "output_norm.weight must be f32"; fail = true; }
+        if (fail) { status = -102; return nullptr; }
+    }
     hp.n_vocab = (int)m->tok_embd.N;
     hp.n_ff = (int)(hp.n_expert ? m->layers[0].gate_exps.N : m->layers[0].gate.N);     // this rank's width under a row split
     if (!hp.n_ff_full) hp.n_ff_full = hp.n_ff * P;
     hp.n_vocab_local = !m->output.name.empty() ? (int)m->output.N : hp.n_vocab;      // (planned, not uploaded yet)
 
+    // (the file has been validated without touching the device: a malformed file fails the same way with and without a GPU)
+    if (hipSetDevice(main_gpu) != hipSuccess) { err = "hipSetDevice failed"; status = -100; return nullptr; }
+    m->device = main_gpu;
     uint8_t *arena = nullptr, *stage = nullptr;
     if (hipMalloc(&arena, total) != hipSuccess) { err = "hipMalloc of " + std::to_string(total) + " weight bytes failed"; status = -104; return nullptr; }
     m->arenas.push_back(arena);
@@ -459,6 +516,7 @@ void Context::kv_clear() {
     region_next_.clear();
 }
 bool Context::kv_seq_rm(int seq, int p0, int p1) {
+    if (seq >= 64) return false;                                   // (the cell masks are 64 bits wide)
     if (p0 < 0) p0 = 0;
     if (p1 < 0) p1 = 0x7fffffff;
     int new_head = (int)cells_.size();
@@ -476,7 +534,7 @@ bool Context::kv_seq_rm(int seq, int p0, int p1) {
     return true;
 }
 void Context::kv_seq_cp(int src, int dst, int p0, int p1) {
-    if (src == dst) return;
+    if (src == dst || src < 0 || dst < 0 || src >= 64 || dst >= 64) return;
     if (p0 < 0) p0 = 0;
     if (p1 < 0) p1 = 0x7fffffff;
     for (auto &c : cells_)
@@ -484,6 +542,7 @@ void Context::kv_seq_cp(int src, int dst, int p0, int p1) {
     meta_dirty_ = true;
 }
 void Context::kv_seq_add(int seq, int p0, int p1, int delta) {
+    if (seq < 0 || seq >= 64) return;
     if (p0 < 0) p0 = 0;
     if (p1 < 0) p1 = 0x7fffffff;
     if (p0 == p1 || delta == 0) return;
@@ -1293,12 +1352,14 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
     int n_out = 0;
     out_row_of_batch_.assign((size_t)n_tokens, -1);
     for (int i = 0; i < n_tokens; i++) {
-        if (tokens[i] < 0 || tokens[i] >= hp.n_vocab) { last_error = "token id out of range"; return -1; }
+        if (tokens[i] < 0 || tokens[i] >= hp.n_vocab) { last_error = "token id " + std::to_string(tokens[i]) + " out of range [0, " + std::to_string(hp.n_vocab) + ")"; return -1; }
+        // a negative position would mark the cell it is written to as free although its KV row was stored
+        if (pos && pos[i] < 0) { last_error = "negative position " + std::to_string(pos[i]) + " for token " + std::to_string(i); return -1; }
         uint64_t mk = 0;
         const int ns = n_seq_id ? n_seq_id[i] : 1;
         for (int j = 0; j < ns; j++) {
             const int s = seq_id ? seq_id[i][j] : 0;
-            if (s < 0 || s >= 64) { last_error = "seq id out of range"; return -1; }
+            if (s < 0 || s >= 64) { last_error = "seq id " + std::to_string(s) + " out of range [0, 64)"; return -1; }   // (the cell masks are 64 bits wide)
             mk |= 1ull << s;
         }
         seq[(size_t)i] = seq_id ? seq_id[i][0] : 0;

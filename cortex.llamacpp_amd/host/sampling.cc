@@ -14,17 +14,19 @@ void Sampler::reset() {
     uint32_t seed = p_.seed;
     if (seed == 0xFFFFFFFFu) seed = std::random_device{}();
     rng_.seed(seed);
+    mu_ = 2.0f * p_.mirostat_tau;
 }
 
 void Sampler::accept(int32_t token) {
     prev_.push_back(token);
-    const size_t keep = (size_t)std::max(p_.penalty_last_n, 0);
+    // -1 = the whole context (upstream: penalty_last_n < 0 -> n_ctx), 0 = no window at all
+    const size_t keep = p_.penalty_last_n < 0 ? (size_t)std::max(p_.penalty_n_ctx, 64) : (size_t)p_.penalty_last_n;
     if (keep == 0) prev_.clear();
     else if (prev_.size() > keep) prev_.erase(prev_.begin(), prev_.begin() + (long)(prev_.size() - keep));
 }
 
 bool Sampler::is_plain_greedy() const {
-    if (p_.temp > 0.0f || p_.n_probs > 0 || !p_.logit_bias.empty()) return false;
+    if (p_.temp > 0.0f || p_.n_probs > 0 || !p_.logit_bias.empty()) return false;   // (temp <= 0 is greedy in the mirostat chains too: temperature comes first there)
     const bool penalties = p_.penalty_repeat != 1.0f || p_.penalty_freq != 0.0f || p_.penalty_present != 0.0f;
     return !penalties || prev_.empty();
 }
@@ -124,6 +126,45 @@ int32_t Sampler::sample(const float *logits, int n_vocab) {
         else cand_.push_back({best, 1.0f});
         return best;
     }
+    std::uniform_real_distribution<double> u01(0.0, 1.0);
+    auto draw = [&](const std::vector<TokenProb> &cc) -> size_t {
+        const double r = u01(rng_);
+        double cum = 0.0;
+        for (size_t i = 0; i < cc.size(); i++) { cum += cc[i].p; if (r < cum) return i; }
+        return cc.size() - 1;
+    };
+    if (p_.mirostat == 1 || p_.mirostat == 2) {
+        // temperature over the whole vocabulary, then the mirostat truncation (no top_k / top_p / min_p in this chain)
+        std::vector<TokenProb> c;
+        top_k_pass((size_t)n_vocab, c);
+        if (p_.temp != 1.0f) for (auto &e : c) e.p /= p_.temp;
+        softmax_sorted(c);
+        if (p_.mirostat == 1) {
+            // Zipf exponent from the top m = 100 probabilities, then the k that gives a surprise of mu
+            const size_t m = 100;
+            double sum_ti_bi = 0.0, sum_ti_sq = 0.0;
+            for (size_t i = 0; i + 1 < std::min(m, c.size()); i++) {
+                const double t_i = log((double)(i + 2) / (double)(i + 1)), b_i = log((double)c[i].p / (double)std::max(c[i + 1].p, 1e-37f));
+                sum_ti_bi += t_i * b_i; sum_ti_sq += t_i * t_i;
+            }
+            const double s_hat = sum_ti_sq > 0 ? sum_ti_bi / sum_ti_sq : 1.0;
+            const double eps_hat = s_hat - 1.0;
+            double kf = pow((eps_hat * pow(2.0, (double)mu_)) / (1.0 - pow((double)n_vocab, -eps_hat)), 1.0 / s_hat);
+            if (!(kf >= 1.0)) kf = 1.0;                            // (also catches NaN)
+            const size_t kk = (size_t)std::min<double>(kf, (double)c.size());
+            c.resize(std::max<size_t>(kk, 1));
+        } else {
+            size_t keep = c.size();
+            for (size_t i = 0; i < c.size(); i++) if (-log2((double)std::max(c[i].p, 1e-37f)) > (double)mu_) { keep = i; break; }
+            c.resize(std::max<size_t>(keep, 1));
+        }
+        { double s2 = 0; for (auto &e : c) s2 += e.p; for (auto &e : c) e.p = (float)(e.p / s2); }
+        const size_t idx = draw(c);
+        const float observed = -log2f(std::max(c[idx].p, 1e-37f));
+        mu_ -= p_.mirostat_eta * (observed - p_.mirostat_tau);
+        cand_ = c;
+        return c[idx].tok;
+    }
     // top_k (also establishes descending order)
     size_t k = p_.top_k <= 0 ? (size_t)n_vocab : std::min<size_t>((size_t)p_.top_k, (size_t)n_vocab);
     k = std::max(k, min_keep);
@@ -163,18 +204,26 @@ int32_t Sampler::sample(const float *logits, int n_vocab) {
         c.resize(std::max<size_t>(last, 1));
         double s = 0; for (auto &e : c) s += e.p; for (auto &e : c) e.p = (float)(e.p / s);
     }
-    // temperature on the surviving candidates: p_i ^ (1/T), renormalised (equivalent to scaling logits)
-    if (p_.temp != 1.0f) {
+    // temperature on the surviving candidates: p_i ^ (1/T), renormalised (equivalent to scaling logits).  With
+    // dynatemp_range > 0 the temperature follows the normalised entropy of the candidates:
+    // T = T_min + (T_max - T_min) * (H / ln n) ^ exponent, T_min = max(0, temp - range), T_max = temp + range
+    float temp = p_.temp;
+    if (p_.dynatemp_range > 0.0f && c.size() > 1) {
+        const double t_min = std::max(0.0, (double)p_.temp - (double)p_.dynatemp_range), t_max = (double)p_.temp + (double)p_.dynatemp_range;
+        double ent = 0.0;
+        for (const auto &e : c) if (e.p > 0) ent -= (double)e.p * log((double)e.p);
+        const double norm = ent / log((double)c.size());
+        temp = (float)(t_min + (t_max - t_min) * pow(std::max(norm, 0.0), (double)p_.dynatemp_exponent));
+    }
+    if (temp != 1.0f && temp > 0.0f) {
         double s = 0;
-        for (auto &e : c) { e.p = (float)pow((double)e.p, 1.0 / (double)p_.temp); s += e.p; }
+        for (auto &e : c) { e.p = (float)pow((double)e.p, 1.0 / (double)temp); s += e.p; }
         for (auto &e : c) e.p = (float)(e.p / s);
+    } else if (temp <= 0.0f) {                                   // entropy drove the temperature to zero: the most likely candidate
+        c.resize(1); c[0].p = 1.0f;
     }
     cand_ = c;
-    std::uniform_real_distribution<double> u(0.0, 1.0);
-    const double r = u(rng_);
-    double cum = 0.0;
-    for (const auto &e : c) { cum += e.p; if (r < cum) return e.tok; }
-    return c.back().tok;
+    return c[draw(c)].tok;
 }
 
 }  // namespace mi355

@@ -1,8 +1,10 @@
 // sampling.h — host sampler chain the slot loop applies to one logits row.  Stands in for common_sampler_{init,reset,
 // accept,sample,get_candidates} (reference call sites src/llama_server_context.cc:626-628,886,1487,1495,1553,1680-1690);
 // chain order per SURVEY.md §A.6: logit_bias -> penalties(last_n, repeat, freq, presence) -> top_k -> typical_p -> top_p
-// -> min_p -> temperature (<= 0 => greedy) -> seeded draw.  Not carried over: grammar, DRY, XTC, mirostat, dynatemp
-// (accepted in the parameter struct, ignored; documented in DESIGN.md).
+// -> min_p -> temperature (entropy-driven when dynatemp_range > 0; <= 0 => greedy) -> seeded draw.  mirostat 1 / 2 replace
+// everything after the penalties by temperature -> the mirostat truncation -> draw, as common_sampler_init chains them
+// (upstream common/sampling.cpp, llama-sampling.cpp: llama_sampler_temp_ext / _mirostat / _mirostat_v2).  Not carried
+// over: grammar, DRY, XTC.
 #pragma once
 
 #include <cstdint>
@@ -22,7 +24,8 @@ struct SamplingParams {            // defaults of chat_completion_request.h:60-9
     float typ_p = 1.0f;
     float temp = 0.8f;
     float dynatemp_range = 0.0f, dynatemp_exponent = 1.0f;
-    int32_t penalty_last_n = 64;
+    int32_t penalty_last_n = 64;   // 0 = penalties off, -1 = the whole context (penalty_n_ctx tokens)
+    int32_t penalty_n_ctx = 0;     // what -1 stands for: the slot's context size
     float penalty_repeat = 1.0f, penalty_freq = 0.0f, penalty_present = 0.0f;
     int32_t mirostat = 0;
     float mirostat_tau = 5.0f, mirostat_eta = 0.1f;
@@ -51,6 +54,7 @@ class Sampler {
     std::vector<int32_t> prev_;     // ring of accepted tokens (penalty window)
     std::vector<TokenProb> cand_;
     std::mt19937 rng_;
+    float mu_ = 0.0f;               // mirostat: running surprise target (starts at 2 tau)
 };
 
 }  // namespace mi355

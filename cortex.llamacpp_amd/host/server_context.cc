@@ -238,6 +238,7 @@ bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &
     sp.typ_p = data.value<float>("typical_p", ds.typ_p);
     sp.temp = data.value<float>("temperature", ds.temp);
     sp.penalty_last_n = data.value<int>("repeat_last_n", ds.penalty_last_n);
+    sp.penalty_n_ctx = slot->n_ctx;                            // what repeat_last_n = -1 means (upstream: the context size)
     sp.penalty_repeat = data.value<float>("repeat_penalty", ds.penalty_repeat);
     sp.penalty_freq = data.value<float>("frequency_penalty", ds.penalty_freq);
     sp.penalty_present = data.value<float>("presence_penalty", ds.penalty_present);
@@ -258,6 +259,13 @@ bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &
         for (const Json &t : pt->items()) slot->prompt_tokens.push_back((int32_t)t.as_int());
     slot->num_prompt_tokens = (int32_t)slot->prompt_tokens.size();
     slot->prompt = data.contains("prompt") ? data["prompt"] : Json("");
+    {   // token ids straight from the request: one bad id must fail THIS request, not the decode of every slot in the tick
+        const int n_vocab = be_->n_vocab();
+        auto bad_id = [&](int64_t t) { return t < 0 || t >= n_vocab; };
+        for (int32_t t : slot->prompt_tokens) if (bad_id(t)) return false;
+        if (slot->prompt.is_array())
+            for (const Json &p : slot->prompt.items()) if (!p.is_string() && (!p.is_int() || bad_id(p.as_int()))) return false;
+    }
 
     sp.logit_bias.clear();
     const Vocab &vocab = be_->vocab();
@@ -331,7 +339,8 @@ void LlamaServerContext::ProcessTasks() {   // :1152-1237
         slot->task_id = task.id;
         slot->embedding = task.embedding_mode;       // :1194
         if (!LaunchSlotWithData(slot, task.data)) {
-            SendError(*slot, "internal_error");
+            slot->Release();
+            SendError(*slot, "Invalid request: token id out of range for this model's vocabulary");
         }
     }
     for (auto &t : deferred) queue_tasks_.push_back(std::move(t));
@@ -631,11 +640,17 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
         const int ret = be_->decode(bv);
         if (ret != 0) {
             if (n_batch == 1 || ret < 0) {
+                // ret > 0 down to a batch of one: no KV cell left (the reference's message); ret < 0: a backend failure,
+                // reported as what it is.  Slots whose prompt is only partly ingested are part of the failed batch too.
+                const char *why = be_->last_error();
+                const std::string msg = ret < 0 ? std::string("Decode failed: ") + (why && *why ? why : "backend error")
+                                                : std::string("Input prompt is too big compared to KV size. Please try increasing KV size.");
                 for (auto &slot : slots) {
-                    if (!slot.IsProcessing()) continue;
+                    const bool ingesting = slot.state == SlotState::kIdle && slot.command == SlotCommand::kLoadPrompt && slot.n_past > 0;
+                    if (!slot.IsProcessing() && !ingesting) continue;
                     slot.state = SlotState::kProcessing; slot.command = SlotCommand::kNone;
                     slot.Release();
-                    SendError(slot, "Input prompt is too big compared to KV size. Please try increasing KV size.");
+                    SendError(slot, msg);
                 }
                 break;
             }

@@ -9,6 +9,8 @@
 #include <map>
 #include <random>
 #include <set>
+#include <unistd.h>
+#include <cstdlib>
 #include <string>
 
 #include "../../cortex.llamacpp_amd/host/engine.h"
@@ -67,7 +69,10 @@ struct FakeBackend : IBackend {
         const int nn = voc.n_tokens() - first_normal;
         return first_normal + (int)(((unsigned)tok * 31u + (unsigned)pos * 7u + 11u) % (unsigned)nn);
     }
+    int hard_fail = 0;                 // decode returns -1 with this message (a backend failure, not a full cache)
+    const char *last_error() const override { return hard_fail ? "device lost (test)" : ""; }
     int decode(const BatchView &b) override {
+        if (hard_fail) return -1;
         if (fail_decode_over >= 0 && b.n_tokens > fail_decode_over) return 1;
         if (decode_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(decode_sleep_us));
         calls_tokens.emplace_back(b.token, b.token + b.n_tokens);
@@ -169,6 +174,75 @@ static void test_sampler() {
     std::set<int> seen;
     for (int i = 0; i < 200; i++) seen.insert(tp.sample(lg.data(), 100));
     CHECK(seen.size() <= 2 && seen.count(17));              // nucleus of 0.5 keeps the two dominant tokens at most
+}
+
+// mirostat 1 / 2, dynamic temperature and the -1 penalty window (upstream common/sampling.cpp chains)
+static void test_sampler_mirostat_dynatemp() {
+    const int V = 2000;
+    std::vector<float> lg((size_t)V);
+    for (int i = 0; i < V; i++) lg[(size_t)i] = -0.01f * (float)((i * 37) % V);          // a long smooth tail
+    lg[5] = 3.0f; lg[9] = 2.5f;
+    for (int mode = 1; mode <= 2; mode++) {
+        SamplingParams p;
+        p.mirostat = mode; p.mirostat_tau = 3.0f; p.mirostat_eta = 0.2f; p.temp = 1.0f; p.seed = 11;
+        p.top_k = 1;                                           // ignored by the mirostat chains: with it the draw would always be 5
+        Sampler a(p), b(p);
+        std::set<int> seen;
+        double surprise = 0.0;
+        const int N = 400;
+        for (int i = 0; i < N; i++) {
+            const int x = a.sample(lg.data(), V), y = b.sample(lg.data(), V);
+            CHECK(x == y);                                    // seeded: reproducible
+            CHECK(x >= 0 && x < V);
+            seen.insert(x);
+            const auto &c = a.candidates();
+            CHECK(!c.empty());
+            double ps = 0; for (const auto &e : c) ps += e.p;
+            CHECK(fabs(ps - 1.0) < 1e-3);
+            for (const auto &e : c) if (e.tok == x) surprise += -log2((double)e.p) / N;
+            a.accept(x); b.accept(y);
+        }
+        CHECK(seen.size() > 3);                                // not collapsed to top_k = 1
+        (void)surprise;
+    }
+    {   // the truncation follows mu: a tiny target surprise keeps only the head of the distribution
+        SamplingParams p; p.mirostat = 2; p.mirostat_tau = 0.05f; p.mirostat_eta = 0.0f; p.temp = 1.0f; p.seed = 3;
+        Sampler s(p);                                          // mu = 2 tau = 0.1 bit: only tokens with p > 0.93 pass, else the single best
+        for (int i = 0; i < 50; i++) CHECK(s.sample(lg.data(), V) == 5);
+    }
+    {   // dynamic temperature: range 0 is the plain chain (same draws); a flat pair of candidates gets T_max, a peaked one less
+        std::vector<float> l2(50, -20.0f); l2[1] = 2.0f; l2[2] = 2.0f; l2[3] = 1.9f;
+        SamplingParams p; p.temp = 0.7f; p.top_k = 3; p.top_p = 1.0f; p.min_p = 0.0f; p.seed = 5;
+        Sampler plain(p);
+        p.dynatemp_range = 0.0f;
+        Sampler zero(p);
+        for (int i = 0; i < 30; i++) CHECK(plain.sample(l2.data(), 50) == zero.sample(l2.data(), 50));
+        p.dynatemp_range = 0.6f; p.dynatemp_exponent = 1.0f;
+        Sampler dyn(p);
+        (void)dyn.sample(l2.data(), 50);
+        const auto c_dyn = dyn.candidates();
+        (void)plain.sample(l2.data(), 50);
+        const auto c_pl = plain.candidates();
+        CHECK(c_dyn.size() == 3 && c_pl.size() == 3);
+        // near-uniform candidates: entropy ~ max -> temperature ~ temp + range = 1.3 > 0.7: flatter than the plain chain
+        CHECK(c_dyn[2].p > c_pl[2].p);
+        p.temp = 0.3f; p.dynatemp_range = 0.3f;                // T_min = 0: a one-sided distribution drives it towards greedy
+        std::vector<float> l3(50, -30.0f); l3[7] = 10.0f; l3[8] = 0.0f;
+        Sampler d2(p);
+        for (int i = 0; i < 20; i++) CHECK(d2.sample(l3.data(), 50) == 7);
+    }
+    {   // repeat_last_n = -1: the window is the context, not "off"
+        std::vector<float> l4(100, 0.0f); l4[17] = 5.0f; l4[42] = 4.9f;
+        SamplingParams p; p.temp = 0.0f; p.penalty_repeat = 2.0f; p.penalty_last_n = -1; p.penalty_n_ctx = 256;
+        Sampler s(p);
+        s.accept(17);
+        for (int i = 0; i < 100; i++) s.accept(60 + (i % 30));  // 17 is 100 tokens back: outside a 64 window, inside the context
+        CHECK(s.sample(l4.data(), 100) == 42);
+        p.penalty_last_n = 0;                                  // 0 = no penalties at all
+        Sampler off(p);
+        off.accept(17);
+        CHECK(off.sample(l4.data(), 100) == 17);
+    }
 }
 
 // The reference counts n_decoded when a sampled token is fed back (llama_server_context.cc:1335), so the budget check
@@ -345,6 +419,110 @@ static void test_kv_full_error() {
     ctx.ReleaseResources();
 }
 
+// a request carrying a token id outside the vocabulary fails alone; a backend failure is reported as such
+static void test_bad_token_ids_and_backend_errors() {
+    FakeBackend be;
+    ServerParams sp;
+    sp.n_parallel = 2;
+    LlamaServerContext ctx(&be, sp);
+    ctx.Initialize();
+    Json good = Json::object();
+    good["prompt"] = "hello world"; good["n_predict"] = 3;
+    Json bad = Json::object();
+    Json toks = Json::array();
+    toks.push_back(Json((int64_t)5)); toks.push_back(Json((int64_t)(be.n_vocab() + 7)));
+    bad["prompt_tokens"] = toks; bad["n_predict"] = 3;
+    const int id_bad = ctx.RequestCompletion(bad, false, false, -1);
+    const int id_good = ctx.RequestCompletion(good, false, false, -1);
+    TaskResult rb = ctx.NextResult(id_bad);
+    CHECK(rb.error && rb.result_json["content"].as_string().find("token id") != std::string::npos);
+    TaskResult rg = ctx.NextResult(id_good);
+    CHECK(!rg.error);                                          // the neighbour was not dragged down
+    Json bad2 = Json::object();
+    Json mixed = Json::array();
+    mixed.push_back(Json("hi")); mixed.push_back(Json((int64_t)-4));
+    bad2["prompt"] = mixed; bad2["n_predict"] = 2;
+    TaskResult rb2 = ctx.NextResult(ctx.RequestCompletion(bad2, false, false, -1));
+    CHECK(rb2.error);
+    be.hard_fail = 1;
+    TaskResult rf = ctx.NextResult(ctx.RequestCompletion(good, false, false, -1));
+    CHECK(rf.error && rf.result_json["content"].as_string().find("device lost") != std::string::npos);
+    CHECK(rf.result_json["content"].as_string().find("too big") == std::string::npos);
+    be.hard_fail = 0;
+    TaskResult ok = ctx.NextResult(ctx.RequestCompletion(good, false, false, -1));
+    CHECK(!ok.error);                                          // the slots came back
+    ctx.ReleaseResources();
+}
+
+// a GGUF whose counts, sizes or offsets lie about the file must be refused without sizing anything from them
+static void test_gguf_hardening() {
+    auto put = [](std::string &b, const void *p, size_t n) { b.append(reinterpret_cast<const char *>(p), n); };
+    auto u32 = [&](std::string &b, uint32_t v) { put(b, &v, 4); };
+    auto u64 = [&](std::string &b, uint64_t v) { put(b, &v, 8); };
+    auto str = [&](std::string &b, const std::string &t) { u64(b, t.size()); b += t; };
+    auto header = [&](uint64_t n_tensors, uint64_t n_kv) { std::string b; u32(b, 0x46554747u); u32(b, 3); u64(b, n_tensors); u64(b, n_kv); return b; };
+    auto open_err = [&](const std::string &bytes) {
+        char path[] = "/tmp/mi355_gguf_XXXXXX";
+        const int fd = mkstemp(path);
+        CHECK(fd >= 0);
+        CHECK(write(fd, bytes.data(), bytes.size()) == (ssize_t)bytes.size());
+        close(fd);
+        GGUFFile f;
+        const std::string err = f.open(path);
+        unlink(path);
+        return err;
+    };
+    auto tensor = [&](std::string &b, const std::string &name, std::initializer_list<uint64_t> ne, uint32_t type, uint64_t off) {
+        str(b, name); u32(b, (uint32_t)ne.size()); for (uint64_t d : ne) u64(b, d); u32(b, type); u64(b, off);
+    };
+    {   // a well-formed one-tensor file loads
+        std::string b = header(1, 1);
+        str(b, "general.architecture"); u32(b, 8); str(b, "llama");
+        tensor(b, "t", {32, 2}, 0, 0);
+        while (b.size() % 32) b.push_back('\0');
+        b.append(32 * 2 * 4, '\1');
+        CHECK(open_err(b).empty());
+    }
+    CHECK(!open_err(header(1ull << 60, 0)).empty());             // tensor count far beyond the file: no resize()
+    CHECK(!open_err(header(0, 1ull << 60)).empty());             // key count likewise
+    {   // string array whose count exceeds the remaining bytes: no reserve()
+        std::string b = header(0, 1);
+        str(b, "tokenizer.ggml.tokens"); u32(b, 9); u32(b, 8); u64(b, 1ull << 58);
+        CHECK(!open_err(b).empty());
+    }
+    {   // scalar array whose count * size wraps 64 bits
+        std::string b = header(0, 1);
+        str(b, "x"); u32(b, 9); u32(b, 10); u64(b, (1ull << 61) + 1);
+        CHECK(!open_err(b).empty());
+    }
+    {   // a "negative" dimension (2^63 + ..) and a zero dimension
+        std::string b = header(1, 0);
+        tensor(b, "t", {0x8000000000000010ull, 2}, 0, 0);
+        CHECK(!open_err(b).empty());
+        std::string c = header(1, 0);
+        tensor(c, "t", {32, 0}, 0, 0);
+        CHECK(!open_err(c).empty());
+    }
+    {   // rows * row bytes overflows size_t; offset + bytes wraps
+        std::string b = header(1, 0);
+        tensor(b, "t", {1ull << 40, 1ull << 40, 1ull << 40}, 0, 0);
+        while (b.size() % 32) b.push_back('\0');
+        CHECK(!open_err(b).empty());
+        std::string c = header(1, 0);
+        tensor(c, "t", {32, 2}, 0, 0xffffffffffffffe0ull);
+        while (c.size() % 32) c.push_back('\0');
+        c.append(256, '\1');
+        CHECK(!open_err(c).empty());
+    }
+    {   // tensor data past the end of the file
+        std::string b = header(1, 0);
+        tensor(b, "t", {32, 64}, 0, 0);
+        while (b.size() % 32) b.push_back('\0');
+        b.append(100, '\1');
+        CHECK(!open_err(b).empty());
+    }
+}
+
 static void test_engine() {
     LlamaEngine eng([](const Json &body, BackendInfo &info, std::string &err) -> std::unique_ptr<IBackend> {
         if (body["llama_model_path"].as_string() == "/bad") { err = "no such file"; return nullptr; }
@@ -491,9 +669,12 @@ int main(int argc, char **argv) {
     test_vocab();
     test_sampler();
     test_sampler_topk_matches_full_sort();
+    test_sampler_mirostat_dynatemp();
     test_slot_loop();
     test_prompt_cache_and_shift();
     test_kv_full_error();
+    test_bad_token_ids_and_backend_errors();
+    test_gguf_hardening();
     test_engine();
     test_embeddings();
     if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }

@@ -278,6 +278,60 @@ def test_load_errors(be, pkg, tmp_path):
         pkg.Model(str(tmp_path / "missing.gguf"))
 
 
+def _patch_u32(path, key, value):
+    """Overwrite a u32 metadata value of a GGUF in place (key\0-less string, then type u32 = 4, then the value)."""
+    import struct
+    blob = bytearray(open(path, "rb").read())
+    k = key.encode()
+    at = blob.find(struct.pack("<Q", len(k)) + k + struct.pack("<I", 4))
+    assert at >= 0, key
+    off = at + 8 + len(k) + 4
+    blob[off:off + 4] = struct.pack("<I", value)
+    open(path, "wb").write(bytes(blob))
+
+
+@pytest.mark.parametrize("key,value,needle", [
+    ("llama.attention.head_count_kv", 0, "head_count_kv"),        # would divide by zero in the group size
+    ("llama.attention.head_count_kv", 3, "head_count_kv"),        # does not divide head_count
+    ("llama.attention.head_count", 2, "shape"),                   # head_dim 128 is fine, but attn_q has twice the rows it implies
+    ("llama.embedding_length", 512, "token_embd"),                # tensors are 256 wide
+    ("llama.feed_forward_length", 768, "feed_forward_length"),
+    ("llama.expert_used_count", 9, "expert"),                     # more experts used than the file has (tiny-moe: 8)
+])
+def test_load_rejects_tensors_that_contradict_the_metadata(be, pkg, tmp_path, key, value, needle):
+    """buffers are sized from the hyper-parameters, the kernels write one value per tensor row: a file whose
+    tensors disagree with its own metadata must fail at load (upstream create_tensor checks every shape), not write out
+    of bounds at the first decode."""
+    path = str(tmp_path / "m.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, "tiny-moe" if "expert" in key else "tiny", "q4_k_m", seed=3)
+    m = pkg.Model(path); m.close()                                 # the untouched file loads
+    _patch_u32(path, key, value)
+    with pytest.raises(pkg.MI355Error) as ei:
+        pkg.Model(path)
+    assert needle in str(ei.value), str(ei.value)
+
+
+def test_kv_entry_points_refuse_out_of_range_sequence_ids(be, pkg, tmp_models):
+    """sequence ids index a 64-bit mask (1 << seq); positions below zero would free the cell just written."""
+    path = make(pkg, tmp_models, "tiny", "q4_k_m")
+    m = pkg.Model(path)
+    c = pkg.Context(m, n_ctx=64, n_seq_max=2)
+    lib = pkg.load_library()
+    c.decode([1, 2, 3], [0, 1, 2])
+    used = c.kv_used()
+    lib.mi355_kv_cache_seq_cp(c.h, 0, 64, -1, -1)                  # UB before: 1ull << 64
+    lib.mi355_kv_cache_seq_cp(c.h, -3, 1, -1, -1)
+    lib.mi355_kv_cache_seq_add(c.h, 200, 0, -1, 1)
+    assert lib.mi355_kv_cache_seq_rm(c.h, 99, -1, -1) == 0
+    assert c.kv_used() == used
+    with pytest.raises(pkg.MI355Error):
+        c.decode([4], [-1])                                        # negative position
+    with pytest.raises(pkg.MI355Error):
+        c.decode([4], [3], seq=[64])                               # beyond the 64-bit cell mask
+    c.decode([4], [3])
+    c.close(); m.close()
+
+
 def test_embeddings_match_oracle_hidden_state(be, pkg, tmp_models):
     """llama_set_embeddings + llama_get_embeddings_ith: the final-norm hidden state of the flagged row (pooling NONE on
     this architecture), against the oracle's last-layer residual stream normalised in numpy with the file's own
