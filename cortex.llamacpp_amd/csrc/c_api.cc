@@ -513,6 +513,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "mmq_tiles")) { mmq_set_tiles(value); return MI355_OK; }
     if (!strcmp(name, "mmq_ksplit")) { g_op_mmq_ksplit = value != 0; return MI355_OK; }
     if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
+    if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
     if (!strcmp(name, "tp_null_group")) { tp_set_null_group(0, value); return MI355_OK; }
     fail(std::string("unknown option ") + name);

@@ -63,6 +63,7 @@ hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_
 // waves each (what launch_mmvq_fast works out for its own launch); returns the LDS bytes, 0 if the shape has no fast form
 size_t mmvq_fast_plan(MMVQArgs &a, int blocks, int waves);
 // single-token weight-stream form (mmvq_stream.hip): HBM -> LDS DMA rings, bit-identical to the fast path
+void mmvq_set_stream(bool on);                            // tests: route single-token mat-vecs to mmvq_fast instead
 bool mmvq_stream_applicable(const MMVQArgs &a);
 hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st);
 

@@ -657,6 +657,11 @@ static void launch_nt(const MMVQArgs &a, int blocks, int bs, size_t lds, hipStre
     else hipLaunchKernelGGL((mmvq_kernel<NT, 256>), dim3(blocks), dim3(256), lds, st, a);
 }
 
+// MI355_MMVQ_STREAM=0 / mi355_debug_set_option("mmvq_stream", 0): single-token mat-vecs take the register-ring kernel
+// (mmvq_fast.hip) instead of the weight-stream kernel; the two are bit-identical (tests/test_gpu_model.py)
+static bool g_stream_on = !(getenv("MI355_MMVQ_STREAM") && getenv("MI355_MMVQ_STREAM")[0] == '0');
+void mmvq_set_stream(bool on) { g_stream_on = on; }
+
 // host launcher: a.T tokens (1, 2 or 4 per launch; larger T is chunked by the caller).
 // EPI_SWIGLU: seg[0] = ffn_gate, seg[1] = ffn_up (same type), out = silu(gate) * up into seg[0].out.
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
@@ -664,8 +669,7 @@ hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     (void)fast_init;
     static const bool fast_on = !(getenv("MI355_MMVQ_FAST") && getenv("MI355_MMVQ_FAST")[0] == '0');   // diagnosis switch
     // single-token steps: the weight-stream kernel (LDS-DMA loader / consumer waves) where it has a form, else the register ring
-    static const bool stream_on = !(getenv("MI355_MMVQ_STREAM") && getenv("MI355_MMVQ_STREAM")[0] == '0');
-    if (fast_on && stream_on && mmvq_stream_applicable(a)) return launch_mmvq_stream(a, st);
+    if (fast_on && g_stream_on && mmvq_stream_applicable(a)) return launch_mmvq_stream(a, st);
     if (fast_on && mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
     if ((a.T == 16 || a.T == 8) && a.fuse_mode == 0) {
         bool moe = false;

@@ -185,6 +185,37 @@ def test_mega_step_matches_per_launch_bitwise(be, pkg, tmp_models, kv, graphs):
     m.close()
 
 
+@pytest.mark.parametrize("cfg,ftype,kv", [("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l", "q5_k_m", "f16"), ("tiny-e2048", "q4_k_m", "q8_0"),
+                                          ("tiny-d128", "q4_k_m", "q8_0"), ("tiny-g8", "q8_0", "q8_0")])
+def test_weight_stream_matvec_matches_register_ring_bitwise(be, pkg, tmp_models, cfg, ftype, kv):
+    """The single-token mat-vecs run as an LDS-DMA weight stream (mmvq_stream.hip: loader waves + consumer waves per CU);
+    the register-ring kernel (mmvq_fast.hip) stays as the form for shapes the stream has none for.  Same arithmetic, same
+    lane roles, same summation order: logits must agree bit for bit, step after step (Llama-3-8B's layer geometry with
+    Q4_K / Q6_K and Q5_K tensors, K = 2048 and 1024 models, a Q8_0 model where only the fused-prologue launches stream)."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(5).integers(0, m.n_vocab, 24)
+
+    def run(stream):
+        be.set_option("mmvq_stream", 1 if stream else 0)
+        try:
+            c = pkg.Context(m, n_ctx=256, type_k=KV[kv], type_v=KV[kv])
+            assert c.decode(prompt, np.arange(24)) == 0
+            rows = [c.logits().copy()]
+            for s in range(40):
+                assert c.decode([int(rows[-1].argmax())], [24 + s]) == 0
+                rows.append(c.logits().copy())
+            c.close()
+        finally:
+            be.set_option("mmvq_stream", 1)
+        return np.stack(rows)
+
+    a, b = run(True), run(False)
+    assert np.isfinite(a).all()
+    assert np.array_equal(a, b), int(np.argmax(np.abs(a - b).max(axis=1) > 0))
+    m.close()
+
+
 @pytest.mark.parametrize("cfg", ["tiny-gqa4", "tiny-d128", "tiny-g8"])
 def test_graph_and_eager_agree_bitwise(be, pkg, tmp_models, cfg):
     path = make(pkg, tmp_models, cfg, "q4_k_m")
