@@ -331,7 +331,7 @@ def main() -> int:
     # HBM bytes the same sweep moved, from the PMC pass committed under profiles/ (FETCH_SIZE, corrected x2 per the gfx950
     # note of the microarchitecture guide); null when the profile is absent or is for another workload
     traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_decode_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_decode_traffic.json")
     if os.path.exists(tpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
             with open(tpath) as f:
@@ -378,7 +378,7 @@ def main() -> int:
         "decode_hbm_fraction_of_8TBps": round(decode_frac, 4),
         "roofline": {
             "bound": "hbm",
-            "kernel": "mmvq_fast_kernel (single-token quantised mat-vec, every weight tensor of one token)",
+            "kernel": "mmvq_stream_kernel (single-token quantised mat-vec as an LDS-DMA weight stream, every weight tensor of one token)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -1495,18 +1495,28 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
                                     (L.gate_exps.ggml_bytes + L.up_exps.ggml_bytes + L.down_exps.ggml_bytes) / (uint64_t)L.gate_exps.n_expert * (uint64_t)KU;
                 continue;
             }
+            // the launches of a single-token step as run_layers issues them (same fused prologues, same epilogues)
             const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
             float *outs[3] = {q_, k_, v_};
+            const bool qkv_q = is_quant(L.wq.type) && is_quant(L.wk.type) && is_quant(L.wv.type);
+            if (qkv_q && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps; }
             HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
-            HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, nullptr, EPI_STORE));
+            pending_fuse_ = Fuse();
+            HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, xo_, EPI_ADD));
             if (is_quant(L.gate.type) && L.gate.type == L.up.type) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
-                HIP_TRY(mmvq_tokens(segs, 2, E, 1, EPI_SWIGLU, aq_e_, stream_));
+                Fuse fz;
+                if (can_fuse(E, 1)) { fz.mode = 1; fz.x = x_; fz.w = (const float *)L.ffn_norm.data; fz.eps = hp.eps; }
+                HIP_TRY(mmvq_tokens(segs, 2, E, 1, EPI_SWIGLU, aq_e_, stream_, fz));
             }
-            HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, nullptr, EPI_STORE));
+            if (is_quant(L.down.type) && (FF % 256) == 0) { pending_fuse_.mode = 2; pending_fuse_.x = ffn_; }
+            HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, xo_, EPI_ADD));
+            pending_fuse_ = Fuse();
             if (count) bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + L.wo.ggml_bytes + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
         }
+        if (is_quant(model->output.type) && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps; }
         HIP_TRY(linear(model->output, aq_e_, xn_, E, 1, d_logits_, (int)model->output.N, nullptr, EPI_STORE));
+        pending_fuse_ = Fuse();
         if (count) bytes += model->output.ggml_bytes;
         return hipSuccess;
     };
@@ -1515,13 +1525,27 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipStreamSynchronize(stream_);
+    // replayed from a hipGraph, as the decode step is (eager launches are host-bound at these kernel lengths)
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    bool graphed = cp.use_graphs && hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (graphed) {
+        const hipError_t es = sweep(false);
+        const hipError_t ec = hipStreamEndCapture(stream_, &g);
+        graphed = es == hipSuccess && ec == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+        if (graphed) { (void)hipGraphLaunch(ge, stream_); (void)hipStreamSynchronize(stream_); }
+    }
     (void)hipEventRecord(e0, stream_);
-    for (int i = 0; i < iters; i++) if (sweep(false) != hipSuccess) return -1.0;
+    for (int i = 0; i < iters; i++) {
+        if (graphed) { if (hipGraphLaunch(ge, stream_) != hipSuccess) return -1.0; }
+        else if (sweep(false) != hipSuccess) return -1.0;
+    }
     (void)hipEventRecord(e1, stream_);
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
     if (bytes_out) *bytes_out = bytes;
     return (double)ms * 1000.0 / iters;
 }
