@@ -106,6 +106,35 @@ hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *
     return hipGetLastError();
 }
 
+// the two tiny launches that open every micro-batch as one: the cos/sin table (above) and the cell metadata of the
+// batch's tokens (launch_kv_meta_set below); ~5 us of a 1.7 ms single-token step each
+__global__ void step_setup_kernel(const int32_t *tok_pos, int T, RopeArgs ra, float theta_scale, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq,
+                                  const int32_t *tok_cell, const uint64_t *tok_seqmask, unsigned *zero_word) {
+    if (blockIdx.x == 0) {
+        if (zero_word && threadIdx.x < 9) zero_word[threadIdx.x == 0 ? 0 : 32 * threadIdx.x] = 0u;   // barrier counters of the whole-step kernel (decode_mega.hip)
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            cell_pos[tok_cell[t]] = tok_pos[t];
+            cell_seq[tok_cell[t]] = tok_seqmask[t];
+        }
+    }
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = ra.n_rot >> 1;
+    if (idx >= T * half) return;
+    const int t = idx / half, i = idx - t * half;
+    float c, s;
+    rope_angle(i, tok_pos[t], theta_scale, ra.freq_scale, ra.freq_factors, c, s);
+    cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
+    cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
+}
+hipError_t launch_step_setup(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
+                             const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st) {
+    const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
+    const int n = T * (ra.n_rot >> 1);
+    hipLaunchKernelGGL(step_setup_kernel, dim3(n > 0 ? (n + 63) / 64 : 1), dim3(64), 0, st, tok_pos, T, ra, theta_scale, cs_out, cell_pos, cell_seq, tok_cell,
+                       tok_seqmask, zero_word);
+    return hipGetLastError();
+}
+
 // One workgroup per token: rope(q) in place; rope(k) -> cache; v -> cache.  cs_table (nullable): precomputed [T][n_rot].
 __global__ __launch_bounds__(256) void rope_kv_store_kernel(float *q, const float *k, const float *v, int n_head, int G, int D,
                                                             const int32_t *tok_pos, const int32_t *tok_cell, RopeArgs ra,

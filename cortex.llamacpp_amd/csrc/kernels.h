@@ -172,6 +172,9 @@ hipError_t launch_rope_kv_store(float *q, const float *k, const float *v, int T,
                                 KVLayerView kv, int type_k, int type_v, int n_ctx, const float *cs_table, hipStream_t st);
 // cos/sin of every token of the micro-batch: cs_out[T][n_rot] (pairs c,s), reused by all layers
 hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, hipStream_t st);
+// launch_rope_table + launch_kv_meta_set (below) in one launch
+hipError_t launch_step_setup(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
+                             const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st);
 hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t *tok_pos, RopeArgs ra, hipStream_t st);
 
 struct AttnArgs {

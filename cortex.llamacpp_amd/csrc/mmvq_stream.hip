@@ -48,9 +48,10 @@ constexpr int ST_SI = 4;                        // DMA instructions (1 KiB each)
 constexpr int ST_SLOT = ST_SI * 1024;           // unit of publication; global slot g lives at ring offset g * 4 KiB mod ring,
 constexpr int ST_RING_SLOTS = ST_RING / ST_SLOT;   // loader q copies the slots g = q mod 2
 #ifndef MI355_STREAM_DEPTH
-#define MI355_STREAM_DEPTH 15
+#define MI355_STREAM_DEPTH 12
 #endif
-constexpr int ST_D = MI355_STREAM_DEPTH;        // slots in flight per loader (at most 15: 60 of the 63 countable vector-memory operations of a wave)
+constexpr int ST_D = MI355_STREAM_DEPTH;        // slots in flight per loader (4 .. 15 measured alike); together with the activation-plane
+                                                // pieces never more than 60 of the 63 vector-memory operations a wave's counter can count
 constexpr int ST_MAX_STEP = 16384;              // bytes one decode step may span (a row, a row pair or one row of a gate/up pair)
 constexpr int ST_PAIR_MAX = 12288;              // rows are decoded two at a time up to this many bytes per pair
 
@@ -332,7 +333,8 @@ __device__ __forceinline__ void loader_op(LoaderState &st, const StOp &a, uint8_
     for (int i = 0; i < n_mine;) {
         loader_publish(st, sy, q);
         const unsigned g = g0 + 2u * (unsigned)i + (unsigned)q;                  // global slot
-        bool wait = st.issued - st.published >= ST_D;                            // in flight: at most ST_D slots
+        const int depth = ST_D * ST_SI + st.pre <= 60 ? ST_D : (60 - st.pre) / ST_SI;   // (the counter read by vm_outstanding() saturates at 63)
+        bool wait = st.issued - st.published >= depth;                           // in flight: at most `depth` slots
         if (!wait && g + 1u > st.free_until) {                                   // ring space: the slowest consumer's front + the ring
             int f = 0x7fffffff;
 #pragma unroll

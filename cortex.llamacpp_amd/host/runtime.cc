@@ -862,6 +862,7 @@ bool Context::mega_check() {
 
 // ------------------------------------------------------------------------------------------ the forward pass
 hipError_t Context::run_layers(int T, int n_kv_cap) {
+    cur_T_ = T;
     const HParams &hp = model->hp;
     const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
     RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, model->rope_freqs.valid() ? (const float *)model->rope_freqs.data : nullptr, hp.rope_neox};
@@ -886,9 +887,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         }
         mega = flash_attn_decode_fused_applicable(ma, ra);      // (more than 64 chunks: the per-launch path merges them)
     }
-    HIP_TRY(launch_kv_meta_set(d_cell_pos_, d_cell_seq_, d_cell_, d_pos_, d_seqmask_, T, stream_, mega ? d_mega_sync_ : nullptr));
+    HIP_TRY(launch_step_setup(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr, stream_));
     HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
-    HIP_TRY(launch_rope_table(d_pos_, T, ra, rope_cs_, stream_));
     prof_mark("embed");
     last_layers_mega_ = mega;
     if (mega)
@@ -1161,19 +1161,21 @@ hipError_t Context::run_output(int n_out, int out_base) {
     if (n_out <= 0) return hipSuccess;
     const HParams &hp = model->hp;
     const int E = hp.n_embd, V = hp.n_vocab;
-    HIP_TRY(launch_gather_rows_f32(x_, d_outrow_, n_out, E, xo_, stream_));
+    // (a single-token step has one row and it is the flagged one: no gather launch)
+    float *const xo = cur_T_ == 1 && n_out == 1 ? x_ : xo_;
+    if (xo != x_) HIP_TRY(launch_gather_rows_f32(x_, d_outrow_, n_out, E, xo_, stream_));
     if (embeddings_enabled) {
         // embeddings mode (llama_set_embeddings): output = result_norm rows, no lm-head (pooling NONE on this architecture)
-        HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, d_embd_ + (size_t)out_base * E, nullptr, false, false, stream_));
+        HIP_TRY(launch_rmsnorm_quant(xo, (const float *)model->out_norm.data, E, n_out, hp.eps, d_embd_ + (size_t)out_base * E, nullptr, false, false, stream_));
         prof_mark("embd");
         return hipSuccess;
     }
     const bool oq = is_quant(model->output.type);
     if (oq && can_fuse(E, n_out)) {
-        pending_fuse_.mode = 1; pending_fuse_.x = xo_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps;
+        pending_fuse_.mode = 1; pending_fuse_.x = xo; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps;
     } else {
         prep_owner_ = nullptr;
-        HIP_TRY(launch_rmsnorm_quant(xo_, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
+        HIP_TRY(launch_rmsnorm_quant(xo, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
                                      oq && model->output.type != T_Q8_0, model->output.type == T_Q8_0, stream_));
         prof_mark("norm_quant");
     }

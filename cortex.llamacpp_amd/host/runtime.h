@@ -151,6 +151,7 @@ class Context {
     void *dalloc(size_t bytes);
 
     hipStream_t stream_ = nullptr;
+    int cur_T_ = 0;                    // tokens of the micro-batch run_layers last ran (run_output: a single row needs no gather)
     std::vector<void *> allocs_;
     std::vector<KVCell> cells_;
     int head_ = 0;
