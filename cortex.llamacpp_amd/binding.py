@@ -15,7 +15,8 @@ class MI355Error(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "lib", "libmi355_llama.so")
+    # MI355_LLAMA_LIB: an alternative build of the same library (tools/ experiments)
+    return os.environ.get("MI355_LLAMA_LIB") or os.path.join(HERE, "lib", "libmi355_llama.so")
 
 
 class ModelParams(C.Structure):

@@ -27,6 +27,7 @@
 // staged in LDS once per workgroup (row stride 272 B: ds_read_b128 conflict-free), the next tile's global loads are
 // issued before the MFMA work of the current one, and the raw weights of the next super-block likewise.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -863,6 +864,343 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
     }
 }
 
+// ---- the same contraction with BOTH operands through LDS (prompts of a few hundred tokens and more on the wide tensors).
+// mmq_planes_kernel reads its B operand (the weight planes) per lane from L2: 2 KiB per K-step per wave for MT x 2 MFMAs, so
+// at MT = 2 the eight waves of a CU ask the vector L1 for 64 B / clk at full matrix-core rate - the L1's whole bandwidth - and
+// the matrix cores idle most of the time (16 % busy on gate/up of the 8B model).  Here a workgroup covers 128 rows x 256 tokens:
+// a wave owns 32 rows x 128 tokens (four token tiles: 8 MFMAs per pair of B registers), and each plane byte is fetched ONCE per
+// workgroup - by the LDS-DMA (global_load_lds_dwordx4, no register round trip), half a super-block (4 K-steps) per stage into one
+// of two 64 KiB buffers, the other one being read by the MFMAs:
+//   B  32 KiB = [row tile 0..3][K-step 0..3][plane hi, lo][lane][16 B]   - the layout mmq_expand_kernel writes, copied verbatim
+//   A  32 KiB = [token 0..255][8 pieces of 16 B]; piece p of token t sits in slot p ^ ((t >> 1) & 7) (the swizzle is applied on
+//               the SOURCE side of the DMA, whose LDS side is always lane-linear), so the 16 lanes of a ds_read_b128 phase hit 16
+//               different 16-B bank groups
+// Per stage and CU: 64 KiB over the L1 (32 B / clk at full rate), 192 KiB out of LDS (96 B / clk of 128), 256 MFMAs.
+// Per-super-block activation scales and block-sum planes are staged by ordinary loads one super-block ahead (two parities).
+// The integer sums, the fold and the f32 order over super-blocks are those of mmq_planes_kernel: results are bit-identical.
+__device__ __forceinline__ unsigned lds_addr32(const void *p) { return (unsigned)(uintptr_t)p; }
+// lane l: 16 B from gbase + voff (voff per lane) to LDS dst + 16 l
+__device__ __forceinline__ void dma16_s(const void *gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+// lane l: 4 x 16 B from g, g + 1 KiB, g + 2 KiB, g + 3 KiB (g per lane) to dst + {0, 1, 2, 3} KiB + 16 l: the instruction
+// offset applies to the global and to the LDS address alike
+__device__ __forceinline__ void dma_4k(const void *g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
+// lane l: 16 B from g + OFF (g per lane) to LDS dst + OFF + 16 l
+template <int OFF> __device__ __forceinline__ void dma16_o(const void *g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%c3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst), "i"(OFF) : "memory");
+}
+
+constexpr int P2_ROWS = 128, P2_TOK = 256, P2_MT = 4;
+constexpr int P2_BUF = 65536, P2_A = 32768;                         // per buffer: B planes | A codes
+constexpr int P2_YD = 0, P2_BS = 1024, P2_META = 1024 + 8192;
+constexpr int P2_SBARR = P2_META + 2048;                            // per parity: yd[256] | bsums[256][16] (int16, then f16) | meta[4][32][16]
+constexpr int P2_LDS = 2 * P2_BUF + 2 * P2_SBARR;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// lane l: 4 B from gbase + voff to LDS dst + 4 l
+__device__ __forceinline__ void dma4_s(const void *gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+
+#ifdef MI355_P2_PROBE
+// tools/exp_p2.hip: per wave of workgroup 0, shader cycles spent per stage kind {first, second half} in {compute issue, DMA wait, barrier}
+__device__ unsigned long long *g_p2_probe = nullptr;
+#define P2_STAMP() __builtin_readcyclecounter()
+#endif
+#ifndef MI355_P2_EXP
+#define MI355_P2_EXP 0       // tools: 1 = no fold, 2 = no DMA, 3 = no MFMA (timing experiments; results are garbage)
+#endif
+// Schedule.  A stage is half a super-block (4 K-steps); stage s is computed from buffer s & 1 while the DMA fills the other one;
+// one workgroup barrier per stage.  A SIMD holds two waves of the workgroup, one of each token half, and the f32 fold of a
+// super-block (VALU work, 40 % of the MFMA time) would leave the matrix cores idle if both did it at the same point.  So the
+// token halves fold at DIFFERENT points: waves 0-3 right after the super-block's last MFMAs (end of its second stage), waves 4-7
+// at the start of the next super-block's first stage - each half's fold runs beside the other half's MFMAs.
+// The block-sum ("mins") term is one v_mfma_f32_32x32x16_f16 per tile: the 16 block sums (|.| <= 2032) and the 6-bit mins are
+// exact in f16 and their 16 products sum to < 2^24, so the f32 result IS the integer msum - no shift, no conversion.
+template <bool MINS>
+__global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
+                                                               const int8_t *aq, const float *ad, const int16_t *absum,
+                                                               const PlanesOut po, const float *resid) {
+    constexpr int SH = MINS ? 5 : 6;
+    constexpr int MT = P2_MT;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = K >> 8;
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int tok_tile = loc % n_tok_tiles;
+    const int row_tile = (loc / n_tok_tiles) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    const int rw = wave & 3, tw = wave >> 2;
+    const int n_rt32 = (n_rows + 31) >> 5;
+    const int rt32 = row_tile * 4 + rw;
+    const bool tile_ok = rt32 < n_rt32;
+    const int row0 = rt32 * 32;
+    const int tok0 = tok_tile * P2_TOK;
+    const int n = lane & 31, kg = lane >> 5;
+
+    // ---- this wave's share of the DMA.  Per stage: 4 KiB of B (row tile wave / 2, K-steps 2 (wave & 1) .. + 1, both planes) and
+    // 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x 32 B),
+    // activation scales (waves 0-3, 64 tokens each) and the row tiles' d / dmin / mins words (waves 4, 5: two row tiles each).
+    int drt = row_tile * 4 + (wave >> 1);
+    if (drt >= n_rt32) drt = n_rt32 - 1;
+    const uint8_t *dma_b = planes + (size_t)drt * nb * PL_BLOCK + (wave & 1) * 4096 + lane * 16;
+    unsigned a_off[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int tk = 8 * (4 * wave + k) + (lane >> 3);
+        int gt = tok0 + tk;
+        if (gt >= T) gt = T - 1;
+        const int piece = (lane & 7) ^ ((tk >> 1) & 7);
+        a_off[k] = (unsigned)gt * (unsigned)K + (unsigned)piece * 16u;
+    }
+    unsigned sb_off;                                            // yd (waves 0-3) or meta (waves 4, 5) source offset
+    {
+        int ptok = tok0 + 64 * (wave & 3) + lane;
+        if (ptok >= T) ptok = T - 1;
+        int mrt = row_tile * 4 + 2 * (wave & 1) + kg;
+        if (mrt >= n_rt32) mrt = n_rt32 - 1;
+        sb_off = wave < 4 ? (unsigned)ptok * (unsigned)nb * 4u
+                          : (unsigned)(mrt - row_tile * 4) * (unsigned)nb * (unsigned)PL_BLOCK + (unsigned)n * 16u;
+    }
+    unsigned bs_off;
+    {
+        int btok = tok0 + 32 * wave + (lane >> 1);
+        if (btok >= T) btok = T - 1;
+        bs_off = (unsigned)btok * (unsigned)nb * 32u + (unsigned)(lane & 1) * 16u;
+    }
+    const uint8_t *meta_base = planes + (size_t)row_tile * 4 * nb * PL_BLOCK + 16384;
+    const unsigned lds0 = lds_addr32(smem);
+    auto issue = [&](int s) {                                   // stage s = (super-block s >> 1, half s & 1) into buffer s & 1
+        if (MI355_P2_EXP == 2) return;
+        const unsigned buf = lds0 + (unsigned)(s & 1) * P2_BUF;
+        dma_4k(dma_b + (size_t)(s >> 1) * PL_BLOCK + (s & 1) * 8192, buf + (unsigned)wave * 4096u);
+        const int8_t *ga = aq + (size_t)s * 128;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dma16_s(ga, a_off[k], buf + P2_A + (unsigned)(4 * wave + k) * 1024u);
+    };
+    auto issue_sb = [&](int sb) {                               // per-super-block words into parity sb & 1
+        if (MI355_P2_EXP == 2) return;
+        const unsigned par = lds0 + 2 * P2_BUF + (unsigned)(sb & 1) * P2_SBARR;
+        if (MINS) dma16_s(absum + (size_t)sb * 16, bs_off, par + P2_BS + (unsigned)wave * 1024u);
+        if (wave < 4) dma4_s(ad + sb, sb_off, par + P2_YD + (unsigned)wave * 256u);
+        else if (wave < 6) dma16_s(meta_base + (size_t)sb * PL_BLOCK, sb_off, par + P2_META + (unsigned)(wave - 4) * 1024u);
+    };
+    auto convert_bs = [&](int sb) {                             // int16 block sums -> f16, in place (16 B per thread)
+        if (!MINS) return;
+        uint8_t *q = smem + 2 * P2_BUF + (sb & 1) * P2_SBARR + P2_BS + tid * 16;
+        const i16x8 v = *reinterpret_cast<const i16x8 *>(q);
+        f16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] = (_Float16)v[e];
+        *reinterpret_cast<f16x8 *>(q) = f;
+    };
+
+    float facc[MT][16];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) facc[t][r] = 0.0f;
+
+    // swizzled byte offset of this lane's A fragment for K-step j of a stage (same for every token tile: tiles start at multiples of 32)
+    const unsigned a_lane = (unsigned)(tw * 128 + n) * 128u;
+    const unsigned a_key = (unsigned)((n >> 1) & 7);
+    i32x16 H[MT], L[MT];
+
+    // fold of the super-block whose words sit in parity par, token tile by token tile
+    auto fold_all = [&](int par) {
+        if (MI355_P2_EXP == 1) return;
+        const uint8_t *pp = smem + 2 * P2_BUF + par * P2_SBARR;
+        const float *s_yd = reinterpret_cast<const float *>(pp + P2_YD);
+        const u32x4 mcur = *reinterpret_cast<const u32x4 *>(pp + P2_META + rw * 512 + n * 16);
+        const float dd = h2f((uint16_t)(mcur.x & 0xffff));
+        float ndm = 0.0f;
+        f16x8 bm8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (MINS) {
+            ndm = -h2f((uint16_t)(mcur.x >> 16));
+            const unsigned w = kg ? mcur.z : mcur.y;            // mins 4 kg .. 4 kg + 3, each for two consecutive block sums
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const _Float16 v = (_Float16)(float)((w >> (8 * e)) & 0xffu);
+                bm8[2 * e] = v; bm8[2 * e + 1] = v;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int tl = (tw * MT + t) * 32;
+            f32x16 ms;
+            if (MINS) {
+                const f16x8 ab = *reinterpret_cast<const f16x8 *>(pp + P2_BS + (tl + n) * 32 + kg * 16);
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0.0f;
+                ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab, bm8, z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rq = 0; rq < 4; rq++) {
+                const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + tl + 8 * rq + 4 * kg);
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++) {
+                    const int r = rq * 4 + ri;
+                    const float yd = yd4[ri];
+                    const int isum = (H[t][r] << SH) + L[t][r];
+                    if (MINS) {
+                        // dd * isum - dmin * msum:  (-dmin) * msum is -(dmin * msum) bit for bit
+                        const float t0 = fmaf(dd, (float)isum, ndm * ms[r]);
+                        facc[t][r] = fmaf(yd, t0, facc[t][r]);
+                    } else {
+                        facc[t][r] = fmaf(yd * dd, (float)isum, facc[t][r]);
+                    }
+                }
+            }
+#ifndef MI355_P2_NOFB
+            __builtin_amdgcn_sched_barrier(0);                   // one tile's block-sum accumulator at a time (four at once spill)
+#endif
+        }
+    };
+#ifdef MI355_P2_PROBE
+    unsigned long long pr_acc[2][3] = {{0, 0, 0}, {0, 0, 0}}, pr_t0 = P2_STAMP();
+    int pr_kind = 0;
+#endif
+    auto stage_end = [&]() {
+#ifdef MI355_P2_PROBE
+        const unsigned long long t1 = P2_STAMP();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = P2_STAMP();
+        __syncthreads();
+        const unsigned long long t3 = P2_STAMP();
+        pr_acc[pr_kind][0] += t1 - pr_t0; pr_acc[pr_kind][1] += t2 - t1; pr_acc[pr_kind][2] += t3 - t2;
+        pr_t0 = t3;
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next stage has landed (this wave's share; the barrier covers the rest)
+        __syncthreads();
+#endif
+    };
+    // the 4 K-steps of buffer h, K-step-major, as 8 groups of {two token tiles x two planes}; the operands of group g + 1 (and,
+    // every other group, the planes of the next K-step) are requested before the MFMAs of group g are issued: a lone wave
+    // otherwise waits out the LDS latency once per group with its matrix-core slot empty
+    auto mma_stage = [&](int h, bool first) {
+        const uint8_t *bs = smem + h * P2_BUF + rw * 8192 + lane * 16;
+        const uint8_t *as = smem + h * P2_BUF + P2_A + a_lane;
+        auto ld_a = [&](int t, int j) {
+            const unsigned slot = ((unsigned)(2 * j + kg) ^ a_key) * 16u;
+            return *reinterpret_cast<const i32x4 *>(as + t * 32 * 128 + slot);
+        };
+        i32x4 bh = *reinterpret_cast<const i32x4 *>(bs), bl = *reinterpret_cast<const i32x4 *>(bs + 1024);
+        i32x4 a0 = ld_a(0, 0), a1 = ld_a(1, 0);
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int j = g >> 1, t0 = (g & 1) * 2;
+            i32x4 n0 = a0, n1 = a1, nbh = bh, nbl = bl;
+            if (g < 7) {
+                n0 = ld_a((t0 + 2) & 3, (g + 1) >> 1); n1 = ld_a((t0 + 3) & 3, (g + 1) >> 1);
+                if (g & 1) { nbh = *reinterpret_cast<const i32x4 *>(bs + (j + 1) * 2048); nbl = *reinterpret_cast<const i32x4 *>(bs + (j + 1) * 2048 + 1024); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int t = t0 + u;
+                const i32x4 a = u ? a1 : a0;
+                if (MI355_P2_EXP == 3) {
+                    if (first && j == 0) { for (int r = 0; r < 16; r++) { H[t][r] = 0; L[t][r] = 0; } }
+                    H[t][j] += a.x + bh.y; L[t][j] += a.z + bl.w;
+                } else if (first && j == 0) {
+                    i32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[r] = 0;
+                    H[t] = mfma_i8(a, bh, z); L[t] = mfma_i8(a, bl, z);
+                } else { H[t] = mfma_i8(a, bh, H[t]); L[t] = mfma_i8(a, bl, L[t]); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0; a1 = n1; bh = nbh; bl = nbl;
+        }
+    };
+
+    issue(0);
+    issue_sb(0);
+    stage_end();
+    for (int sb = 0; sb < nb; sb++) {
+        // ---- first half (buffer 0).  The block sums of sb (landed with the barrier just passed) become f16 here, one barrier
+        // ahead of their first use; waves 4-7 fold super-block sb - 1 before they overwrite its accumulators.
+#ifdef MI355_P2_PROBE
+        pr_kind = 0;
+#endif
+        issue(2 * sb + 1);
+        convert_bs(sb);
+        if (tw == 1 && sb > 0) fold_all((sb - 1) & 1);
+        mma_stage(0, true);
+        stage_end();
+        // ---- second half (buffer 1).  The words of super-block sb + 1 go to the other parity, which waves 4-7 finished
+        // reading in the stage just ended; waves 0-3 fold sb at the end of this one.
+#ifdef MI355_P2_PROBE
+        pr_kind = 1;
+#endif
+        if (sb + 1 < nb) { issue(2 * sb + 2); issue_sb(sb + 1); }
+        mma_stage(1, false);
+        if (tw == 0 || sb + 1 == nb) fold_all(sb & 1);
+        stage_end();
+    }
+    if (MI355_P2_EXP == 1) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) facc[t][r] = (float)(H[t][r] + L[t][r]);
+    }
+
+#ifdef MI355_P2_PROBE
+    if (g_p2_probe && blockIdx.x == 0 && lane == 0) {
+        const unsigned long long t4 = P2_STAMP();
+        unsigned long long *o = g_p2_probe + wave * 8;
+        for (int k = 0; k < 2; k++) for (int c = 0; c < 3; c++) o[k * 3 + c] = pr_acc[k][c];
+        o[6] = t4 - pr_t0;                                      // last fold
+    }
+#endif
+    if (tile_ok && row0 + n < n_rows) {
+        int sg = 0;
+        if (po.n_seg > 1 && row0 >= po.row_end[0]) sg = 1;
+        if (po.n_seg > 2 && row0 >= po.row_end[1]) sg = 2;
+        float *out = po.out[sg] - (sg ? po.row_end[sg - 1] : 0);
+        const int ld_out = po.ld[sg];
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                int gt = tok0 + (tw * MT + t) * 32 + m;
+                if (gt >= T) gt = T - 1;
+                rv[r] = resid ? resid[(size_t)gt * ld_out + row0 + n] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int gt = tok0 + (tw * MT + t) * 32 + m;
+                if (gt < T) out[(size_t)gt * ld_out + row0 + n] = rv[r] + facc[t][r];
+            }
+        }
+    }
+}
+
 // per-16 block sums of Q8_K split into int8 planes: bsum = 64*hi + lo, hi in [-32, 31], lo in [0, 63]
 __global__ void mmq_prep_kernel(const int16_t *bsums, size_t n, int8_t *bh, int8_t *bl) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over T * K/16
@@ -905,6 +1243,9 @@ hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, in
 }  // namespace
 
 void mmq_set_tiles(int mt) { g_mmq_mt = mt; }
+#ifdef MI355_P2_PROBE
+void mmq_p2_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p2_probe), &p, sizeof(p)); }
+#endif
 
 // continuous-batching decode steps and prompts up to a few hundred tokens: 3 <= T <= g_ksplit_max.  This kernel reads the GGUF
 // bytes (0.56 B / weight) and expands them in registers, the planes kernel reads 2 B / weight it need not expand: measured on the
@@ -1000,6 +1341,22 @@ hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *s
     if (env_mt == 1 || env_mt == 2) mt = env_mt;
     if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
     const bool mins = type != T_Q6_K;
+    // both operands through LDS (128 rows x 256 tokens per workgroup) once that grid still covers most of the chip
+    static const int env_p2 = getenv("MI355_MMQ_PLANES2") ? atoi(getenv("MI355_MMQ_PLANES2")) : 1;
+    const long wg4 = (long)((n_rows + P2_ROWS - 1) / P2_ROWS) * ((T + P2_TOK - 1) / P2_TOK);
+    const bool p2 = g_mmq_mt == 4 || (g_mmq_mt == 0 && env_mt == 0 && env_p2 != 0 && T > 128 && wg4 * 4 >= 3L * num_cu());
+    if (p2) {
+        const int nrt = (n_rows + P2_ROWS - 1) / P2_ROWS, ntt = (T + P2_TOK - 1) / P2_TOK;
+        const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));
+        if (mins) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+            hipLaunchKernelGGL((mmq_planes2_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+            hipLaunchKernelGGL((mmq_planes2_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid);
+        }
+        return hipGetLastError();
+    }
 #define PLN(MINSV, MTV)                                                                                                   \
     {                                                                                                                     \
         using G = Geo<MTV>;                                                                                               \

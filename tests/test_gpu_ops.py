@@ -90,6 +90,30 @@ def test_mul_mat_mfma_prefill_paths(be, t, K, N, T, planes, tiles):
 
 
 @pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
+@pytest.mark.parametrize("K,N,T", [(2048, 130, 40), (4096, 300, 129), (1024, 128, 256), (4096, 70, 512), (14336, 40, 300), (256, 257, 513)])
+def test_mul_mat_prefill_both_operands_through_lds(be, t, K, N, T):
+    """The 128-row x 256-token workgroup tile whose weight planes AND activation codes reach LDS by DMA (mmq_planes2_kernel):
+    same integer sums, same fold and same f32 order over super-blocks as the per-lane planes kernel, so the two agree bit
+    for bit; ragged row tiles, ragged token tiles and a single super-block included."""
+    rng = np.random.default_rng(7 * K + N + T + t)
+    W = rand_weights(rng, t, N * K)
+    x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
+    be.set_option("mmq_planes", 1)
+    be.set_option("mmq_ksplit", 0)
+    try:
+        be.set_option("mmq_tiles", 4)
+        y = be.mul_mat(t, W, N, K, x)
+        be.set_option("mmq_tiles", 2)
+        y2 = be.mul_mat(t, W, N, K, x)
+    finally:
+        be.set_option("mmq_tiles", 0)
+        be.set_option("mmq_ksplit", 1)
+    ref = oq.mul_mat(t, W, N, K, x)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+    assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
 @pytest.mark.parametrize("K,N,T", [(4096, 100, 8), (4096, 64, 32), (14336, 40, 17), (5632, 37, 33), (2048, 130, 64), (256, 5, 9),
                                    (4096, 33, 48), (4096, 70, 5), (14336, 33, 6), (4096, 64, 3), (2048, 40, 4), (4096, 70, 129), (2048, 40, 300), (14336, 33, 97)])
 def test_mul_mat_small_batch_ksplit(be, t, K, N, T):
