@@ -336,7 +336,11 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
                 DevBuf pl(mmq_planes_bytes(type, N, (int)K));
                 if (!pl.p) return MI355_ERR_OOM;
                 if (e == hipSuccess) e = launch_mmq_expand(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, pl.as<uint8_t>(), nullptr);
-                if (e == hipSuccess) e = launch_mmq_planes(type, pl.as<uint8_t>(), (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr);
+                DevBuf wsb((size_t)4 * T * N * sizeof(float));      // K-split partial sums (tensors with few rows)
+                if (!wsb.p) return MI355_ERR_OOM;
+                MMQWorkspace wsp; wsp.p = wsb.as<float>(); wsp.bytes = (size_t)4 * T * N * sizeof(float);
+                if (e == hipSuccess) e = launch_mmq_planes(type, pl.as<uint8_t>(), (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr, wsp);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             } else
             if (e == hipSuccess) e = launch_mmq(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr);
@@ -511,6 +515,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!name) return MI355_ERR_ARG;
     if (!strcmp(name, "mmq_planes")) { g_op_mmq_planes = value != 0; return MI355_OK; }
     if (!strcmp(name, "mmq_tiles")) { mmq_set_tiles(value); return MI355_OK; }
+    if (!strcmp(name, "mmq_split")) { mmq_set_split(value); return MI355_OK; }
     if (!strcmp(name, "mmq_ksplit")) { g_op_mmq_ksplit = value != 0; return MI355_OK; }
     if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }

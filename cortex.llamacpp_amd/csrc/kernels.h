@@ -76,8 +76,11 @@ void mmq_set_tiles(int mt);                                // tools: force 1 / 2
 // pre-expanded MFMA operand planes of a weight tensor (2 B / weight, built once at load; mmq.hip)
 size_t mmq_planes_bytes(int type, int64_t n_rows, int K);   // 0 if the type has no planes form
 hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *planes, hipStream_t st);
+// workspace for the K-split form of the planes kernel (tensors with few rows): n_split * T * n_rows floats; none = no split
+struct MMQWorkspace { float *p = nullptr; size_t bytes = 0; };
+void mmq_set_split(int n);                                 // tools: force the K split (0 = by shape)
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
-                             float *out, int ld_out, const float *resid, hipStream_t st);
+                             float *out, int ld_out, const float *resid, hipStream_t st, MMQWorkspace wsp = MMQWorkspace());
 // small batches (continuous-batching decode steps, 8 <= T <= 64): K split over the waves of a workgroup, GGUF-form weights
 struct MMQSeg {
     const uint8_t *W; size_t row_bytes; int n_rows, type;
@@ -91,7 +94,8 @@ hipError_t launch_mmq_q80(const uint8_t *W, size_t row_bytes, int n_rows, int K,
 // up to three tensors of one plane format (Q4_K / Q5_K together, or Q6_K) whose plane sets are contiguous in memory, as one
 // launch over the concatenated rows; seg_rows[i] rows go to outs[i] (leading dimension lds_out[i])
 hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
-                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st);
+                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st,
+                                   MMQWorkspace wsp = MMQWorkspace());
 bool mmq_ksplit_applicable(int type, int K, int T);
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st);

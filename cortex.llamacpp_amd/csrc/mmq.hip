@@ -940,17 +940,19 @@ __device__ unsigned long long *g_p2_probe = nullptr;
 template <bool MINS>
 __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
                                                                const int8_t *aq, const float *ad, const int16_t *absum,
-                                                               const PlanesOut po, const float *resid) {
+                                                               const PlanesOut po, const float *resid, float *ws, int n_split) {
     constexpr int SH = MINS ? 5 : 6;
     constexpr int MT = P2_MT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = K >> 8;
+    const int nb_all = K >> 8;                                 // super-blocks per row (strides); this workgroup's share is [sb_lo, sb_lo + nb)
     const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
     const int tok_tile = loc % n_tok_tiles;
-    const int row_tile = (loc / n_tok_tiles) * 8 + xcd;
+    const int zz = (loc / n_tok_tiles) % n_split;              // K split: partial sums go to ws[zz], mmq_splitk_reduce_kernel adds them up
+    const int row_tile = (loc / (n_tok_tiles * n_split)) * 8 + xcd;
     if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    const int sb_lo = (int)((long)nb_all * zz / n_split), nb = (int)((long)nb_all * (zz + 1) / n_split) - sb_lo;
     const int rw = wave & 3, tw = wave >> 2;
     const int n_rt32 = (n_rows + 31) >> 5;
     const int rt32 = row_tile * 4 + rw;
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
     // activation scales (waves 0-3, 64 tokens each) and the row tiles' d / dmin / mins words (waves 4, 5: two row tiles each).
     int drt = row_tile * 4 + (wave >> 1);
     if (drt >= n_rt32) drt = n_rt32 - 1;
-    const uint8_t *dma_b = planes + (size_t)drt * nb * PL_BLOCK + (wave & 1) * 4096 + lane * 16;
+    const uint8_t *dma_b = planes + ((size_t)drt * nb_all + sb_lo) * PL_BLOCK + (wave & 1) * 4096 + lane * 16;
     unsigned a_off[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
         int gt = tok0 + tk;
         if (gt >= T) gt = T - 1;
         const int piece = (lane & 7) ^ ((tk >> 1) & 7);
-        a_off[k] = (unsigned)gt * (unsigned)K + (unsigned)piece * 16u;
+        a_off[k] = (unsigned)gt * (unsigned)K + (unsigned)sb_lo * 256u + (unsigned)piece * 16u;
     }
     unsigned sb_off;                                            // yd (waves 0-3) or meta (waves 4, 5) source offset
     {
@@ -980,16 +982,16 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
         if (ptok >= T) ptok = T - 1;
         int mrt = row_tile * 4 + 2 * (wave & 1) + kg;
         if (mrt >= n_rt32) mrt = n_rt32 - 1;
-        sb_off = wave < 4 ? (unsigned)ptok * (unsigned)nb * 4u
-                          : (unsigned)(mrt - row_tile * 4) * (unsigned)nb * (unsigned)PL_BLOCK + (unsigned)n * 16u;
+        sb_off = wave < 4 ? ((unsigned)ptok * (unsigned)nb_all + (unsigned)sb_lo) * 4u
+                          : (unsigned)(mrt - row_tile * 4) * (unsigned)nb_all * (unsigned)PL_BLOCK + (unsigned)n * 16u;
     }
     unsigned bs_off;
     {
         int btok = tok0 + 32 * wave + (lane >> 1);
         if (btok >= T) btok = T - 1;
-        bs_off = (unsigned)btok * (unsigned)nb * 32u + (unsigned)(lane & 1) * 16u;
+        bs_off = ((unsigned)btok * (unsigned)nb_all + (unsigned)sb_lo) * 32u + (unsigned)(lane & 1) * 16u;
     }
-    const uint8_t *meta_base = planes + (size_t)row_tile * 4 * nb * PL_BLOCK + 16384;
+    const uint8_t *meta_base = planes + ((size_t)row_tile * 4 * nb_all + sb_lo) * PL_BLOCK + 16384;
     const unsigned lds0 = lds_addr32(smem);
     auto issue = [&](int s) {                                   // stage s = (super-block s >> 1, half s & 1) into buffer s & 1
         if (MI355_P2_EXP == 2) return;
@@ -1175,6 +1177,19 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
         o[6] = t4 - pr_t0;                                      // last fold
     }
 #endif
+    if (n_split > 1) {                                          // partial sums of this K range: ws[zz][token][row], no residual
+        if (tile_ok && row0 + n < n_rows) {
+            float *o = ws + (size_t)zz * T * n_rows;
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int gt = tok0 + (tw * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (gt < T) o[(size_t)gt * n_rows + row0 + n] = facc[t][r];
+                }
+        }
+        return;
+    }
     if (tile_ok && row0 + n < n_rows) {
         int sg = 0;
         if (po.n_seg > 1 && row0 >= po.row_end[0]) sg = 1;
@@ -1201,6 +1216,28 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
     }
 }
 
+// out[t][row] = (resid) + ws[0][t][row] + ws[1][t][row] + ... in split order (fixed, so results do not depend on timing)
+__global__ __launch_bounds__(256) void mmq_splitk_reduce_kernel(const float *ws, int n_split, int T, int n_rows, const PlanesOut po, const float *resid) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x, per_tok = (size_t)n_rows >> 2;      // n_rows % 4 == 0 (launcher)
+    if (i4 >= per_tok * T) return;
+    const int t = (int)(i4 / per_tok), row = (int)(i4 % per_tok) * 4;
+    const size_t plane = (size_t)T * n_rows, at = (size_t)t * n_rows + row;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(ws + at);
+    for (int z = 1; z < n_split; z++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ws + z * plane + at);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    int sg = 0;
+    if (po.n_seg > 1 && row >= po.row_end[0]) sg = 1;
+    if (po.n_seg > 2 && row >= po.row_end[1]) sg = 2;
+    float *o = po.out[sg] + (size_t)t * po.ld[sg] + (row - (sg ? po.row_end[sg - 1] : 0));
+    if (resid) {
+        const float *rp = resid + (size_t)t * po.ld[0] + row;
+        acc.x = rp[0] + acc.x; acc.y = rp[1] + acc.y; acc.z = rp[2] + acc.z; acc.w = rp[3] + acc.w;
+    }
+    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+}
+
 // per-16 block sums of Q8_K split into int8 planes: bsum = 64*hi + lo, hi in [-32, 31], lo in [0, 63]
 __global__ void mmq_prep_kernel(const int16_t *bsums, size_t n, int8_t *bh, int8_t *bl) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over T * K/16
@@ -1224,6 +1261,7 @@ hipError_t launch_one(const uint8_t *W, size_t row_bytes, int n_rows, int K, int
 }
 
 int g_mmq_mt = 0;   // 0 = by T; tools may force 1 / 2 / 4
+int g_mmq_split = 0;   // tools: force the K split of the 128 x 256 kernel (0 = by shape, 1 = none)
 
 template <int TYPE>
 hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
@@ -1243,6 +1281,7 @@ hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, in
 }  // namespace
 
 void mmq_set_tiles(int mt) { g_mmq_mt = mt; }
+void mmq_set_split(int n) { g_mmq_split = n; }
 #ifdef MI355_P2_PROBE
 void mmq_p2_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p2_probe), &p, sizeof(p)); }
 #endif
@@ -1312,16 +1351,13 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
     return hipGetLastError();
 }
 
-hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
-                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st);
-
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
-                             float *out, int ld_out, const float *resid, hipStream_t st) {
-    return launch_mmq_planes_multi(type, planes, &n_rows, &out, &ld_out, 1, K, T, q, bh, bl, resid, st);
+                             float *out, int ld_out, const float *resid, hipStream_t st, MMQWorkspace wsp) {
+    return launch_mmq_planes_multi(type, planes, &n_rows, &out, &ld_out, 1, K, T, q, bh, bl, resid, st, wsp);
 }
 
 hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
-                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st) {
+                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st, MMQWorkspace wsp) {
     if (n_seg < 1 || n_seg > 3 || (n_seg > 1 && resid)) return hipErrorInvalidValue;
     PlanesOut po{};
     po.n_seg = n_seg;
@@ -1341,19 +1377,36 @@ hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *s
     if (env_mt == 1 || env_mt == 2) mt = env_mt;
     if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
     const bool mins = type != T_Q6_K;
-    // both operands through LDS (128 rows x 256 tokens per workgroup) once that grid still covers most of the chip
+    // both operands through LDS (128 rows x 256 tokens per workgroup) once that grid covers most of the chip; tensors with
+    // too few rows for that split K over 2..4 workgroups (partial sums in the caller's workspace, added up in split order)
     static const int env_p2 = getenv("MI355_MMQ_PLANES2") ? atoi(getenv("MI355_MMQ_PLANES2")) : 1;
+    static const int env_sk = getenv("MI355_MMQ_SPLITK") ? atoi(getenv("MI355_MMQ_SPLITK")) : -1;   // 0 off, 2..4 forced
+    const int nb = K >> 8;
     const long wg4 = (long)((n_rows + P2_ROWS - 1) / P2_ROWS) * ((T + P2_TOK - 1) / P2_TOK);
-    const bool p2 = g_mmq_mt == 4 || (g_mmq_mt == 0 && env_mt == 0 && env_p2 != 0 && T > 128 && wg4 * 4 >= 3L * num_cu());
+    int n_split = 1;
+    if (g_mmq_split > 1 || env_sk > 1) n_split = g_mmq_split > 1 ? g_mmq_split : env_sk;
+    else if (wg4 * 4 < 3L * num_cu() && env_sk != 0 && g_mmq_split != 1) {
+        n_split = (int)((num_cu() + wg4 - 1) / wg4);
+        if (n_split > 4) n_split = 4;
+        if (n_split > nb / 8) n_split = nb / 8;                 // at least eight super-blocks per workgroup: a 4096-wide K split four ways
+                                                                // (40.9 us with its reduction) loses to the 256 x 32 tiles (37.9), a 14336-wide one wins (89.7 vs 120.9)
+    }
+    if (n_split > nb) n_split = nb;
+    if (n_split < 1 || (n_rows % 4) != 0 || !wsp.p || (size_t)n_split * T * n_rows * sizeof(float) > wsp.bytes) n_split = 1;
+    const bool p2 = g_mmq_mt == 4 || (g_mmq_mt == 0 && env_mt == 0 && env_p2 != 0 && T > 128 && wg4 * n_split * 4 >= 3L * num_cu());
     if (p2) {
         const int nrt = (n_rows + P2_ROWS - 1) / P2_ROWS, ntt = (T + P2_TOK - 1) / P2_TOK;
-        const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));
+        const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * n_split * 8));
         if (mins) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
-            hipLaunchKernelGGL((mmq_planes2_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid);
+            hipLaunchKernelGGL((mmq_planes2_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid, wsp.p, n_split);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
-            hipLaunchKernelGGL((mmq_planes2_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid);
+            hipLaunchKernelGGL((mmq_planes2_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid, wsp.p, n_split);
+        }
+        if (n_split > 1) {
+            const size_t n4 = (size_t)T * (n_rows >> 2);
+            hipLaunchKernelGGL(mmq_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, wsp.p, n_split, T, n_rows, po, resid);
         }
         return hipGetLastError();
     }

@@ -478,6 +478,11 @@ bool Context::init(std::string &err) {
     alloc_actq(aq_ff_, FF, T, true, true, allocs_, device_bytes, ok);
     mmq_bh_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), (int)T));
     mmq_bl_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), (int)T));
+    // partial sums of the K-split prompt contraction: only tensors with few rows split (Q | K | V, attention output, FFN down),
+    // up to four ways; tensors that do not fit fall back to an unsplit kernel
+    mmq_ws_.bytes = (size_t)4 * T * std::max<size_t>(E, (size_t)(hp.n_head + 2 * hp.n_head_kv) * D) * sizeof(float);
+    mmq_ws_.p = T >= 128 ? (float *)dalloc(mmq_ws_.bytes) : nullptr;
+    if (!mmq_ws_.p) mmq_ws_.bytes = 0;
     if (!ok || !x_ || !ffn_u_) { err = "activation buffer allocation failed"; return false; }
 
     size_t ws = 0;
@@ -714,7 +719,7 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
         }
         if (mmq_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // prompt processing: MFMA path
             if (w.type != T_Q6_K || !w.planes) HIP_TRY(ensure_prep(aq, K, T));
-            if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+            if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_, mmq_ws_);
             return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
@@ -747,10 +752,10 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
             int rows[3], ldo[3];
             float *o[3];
             for (int i = 0; i < nf; i++) { rows[i] = (int)ws[i]->N; ldo[i] = (int)ws[i]->N; o[i] = outs[i]; }
-            HIP_TRY(launch_mmq_planes_multi(ws[0]->type, ws[0]->planes, rows, o, ldo, nf, K, T, aq, mmq_bh_, mmq_bl_, nullptr, stream_));
+            HIP_TRY(launch_mmq_planes_multi(ws[0]->type, ws[0]->planes, rows, o, ldo, nf, K, T, aq, mmq_bh_, mmq_bl_, nullptr, stream_, mmq_ws_));
         } else nf = 0;
         for (int i = nf; i < n; i++) {
-            if (ws[i]->planes) HIP_TRY(launch_mmq_planes(ws[i]->type, ws[i]->planes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
+            if (ws[i]->planes) HIP_TRY(launch_mmq_planes(ws[i]->type, ws[i]->planes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_, mmq_ws_));
             else HIP_TRY(launch_mmq(ws[i]->type, ws[i]->data, ws[i]->row_bytes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_));
         }
         return hipSuccess;

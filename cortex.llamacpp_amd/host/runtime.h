@@ -184,6 +184,7 @@ class Context {
     int32_t *moe_meta_ = nullptr, *moe_slot_ = nullptr, *moe_tok_ = nullptr, *h_moe_meta_ = nullptr;
     ActQuant aq_e_, aq_ff_, aq_o_;
     int8_t *mmq_bh_ = nullptr, *mmq_bl_ = nullptr;   // (hi, lo) planes of the 32-code block sums for the MFMA path
+    MMQWorkspace mmq_ws_;                            // partial sums of the K-split prompt contraction
     // whose block sums mmq_bh_ / mmq_bl_ currently hold (code plane pointer, K, rows): the quantisers of a prompt batch write
     // the planes themselves, launch_mmq_prep runs only when they are not there (ensure_prep)
     const void *prep_owner_ = nullptr;

@@ -102,15 +102,45 @@ def test_mul_mat_prefill_both_operands_through_lds(be, t, K, N, T):
     be.set_option("mmq_ksplit", 0)
     try:
         be.set_option("mmq_tiles", 4)
+        be.set_option("mmq_split", 1)                          # no K split (tested below): same f32 order as the other kernel
         y = be.mul_mat(t, W, N, K, x)
         be.set_option("mmq_tiles", 2)
         y2 = be.mul_mat(t, W, N, K, x)
     finally:
         be.set_option("mmq_tiles", 0)
+        be.set_option("mmq_split", 0)
         be.set_option("mmq_ksplit", 1)
     ref = oq.mul_mat(t, W, N, K, x)
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q6_K])
+@pytest.mark.parametrize("K,N,T,split", [(4096, 300, 129, 2), (2048, 128, 256, 3), (14336, 40, 300, 4), (1024, 260, 513, 4), (256, 36, 140, 4)])
+def test_mul_mat_prefill_split_k(be, t, K, N, T, split):
+    """Tensors with few rows: the 128 x 256 kernel splits K over `split` workgroups, partial sums go through a workspace and are
+    added in split order by mmq_splitk_reduce_kernel.  Only the f32 order over super-blocks changes; a split wider than the
+    number of super-blocks is clamped."""
+    rng = np.random.default_rng(11 * K + N + T + t)
+    W = rand_weights(rng, t, N * K)
+    x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
+    be.set_option("mmq_planes", 1)
+    be.set_option("mmq_ksplit", 0)
+    try:
+        be.set_option("mmq_tiles", 4)
+        be.set_option("mmq_split", split)
+        y = be.mul_mat(t, W, N, K, x)
+        be.set_option("mmq_split", 1)
+        y1 = be.mul_mat(t, W, N, K, x)
+    finally:
+        be.set_option("mmq_tiles", 0)
+        be.set_option("mmq_split", 0)
+        be.set_option("mmq_ksplit", 1)
+    ref = oq.mul_mat(t, W, N, K, x)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+    assert np.abs(y - y1).max() <= 2e-6 * np.abs(ref).max() + 1e-6
+    if K > 256:
+        assert not np.array_equal(y, y1)                       # the split really ran (a different f32 order)
 
 
 @pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])

@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <cmath>
+#include <algorithm>
 #include "kernels.h"
 namespace mi355 {
 void set_error(const char *, ...) {}
@@ -13,6 +15,7 @@ static int g_ncu = 256;
 void set_num_cu(int n) { g_ncu = n; }
 int num_cu() { return g_ncu; }
 void mmq_set_tiles(int mt);
+void mmq_set_split(int n);
 #ifdef MI355_P2_PROBE
 void mmq_p2_set_probe(unsigned long long *p);
 #endif
@@ -59,21 +62,31 @@ int main(int argc, char **argv) {
     float *o_old, *o_new; CK(hipMalloc(&o_old, (size_t)T * N * 4)); CK(hipMalloc(&o_new, (size_t)T * N * 4));
     CK(hipMemset(o_old, 0, (size_t)T * N * 4)); CK(hipMemset(o_new, 0xff, (size_t)T * N * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto run = [&](int tiles, float *out) {
-        mmq_set_tiles(tiles);
-        CK(launch_mmq_planes(type, planes, N, K, T, q, bh, bl, out, N, nullptr, nullptr));
+    MMQWorkspace wsp; wsp.bytes = (size_t)4 * T * N * 4; CK(hipMalloc(&wsp.p, wsp.bytes));
+    auto run = [&](int tiles, float *out, int split = 0) {
+        mmq_set_tiles(tiles); mmq_set_split(split);
+        CK(launch_mmq_planes(type, planes, N, K, T, q, bh, bl, out, N, nullptr, nullptr, wsp));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; i++) CK(launch_mmq_planes(type, planes, N, K, T, q, bh, bl, out, N, nullptr, nullptr));
+        for (int i = 0; i < reps; i++) CK(launch_mmq_planes(type, planes, N, K, T, q, bh, bl, out, N, nullptr, nullptr, wsp));
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         return ms * 1e3f / reps;
     };
-    const float us1 = run(1, o_old), us2 = run(2, o_old);
+    const float us1 = run(1, o_old, 1), us2 = run(2, o_old, 1);
 #ifdef MI355_P2_PROBE
     unsigned long long *probe; CK(hipMalloc(&probe, 64 * 8)); CK(hipMemset(probe, 0, 64 * 8)); mmq_p2_set_probe(probe);
 #endif
-    const float us4 = run(4, o_new);
+    const float us4 = run(4, o_new, 1);
+    float *o_sk; CK(hipMalloc(&o_sk, (size_t)T * N * 4));
+    float us_sk[5] = {0, 0, 0, 0, 0};
+    for (int sp = 2; sp <= 4; sp++) us_sk[sp] = run(4, o_sk, sp);
+    {
+        std::vector<float> a((size_t)T * N), b((size_t)T * N);
+        CK(hipMemcpy(a.data(), o_new, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o_sk, b.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0; for (size_t i = 0; i < a.size(); i++) { md = std::max(md, (double)fabsf(a[i] - b[i])); mx = std::max(mx, (double)fabsf(a[i])); }
+        printf("  split K (+ reduce): x2 %.1f us  x3 %.1f us  x4 %.1f us   max |diff| vs unsplit %.3g of max |y| %.3g\n", us_sk[2], us_sk[3], us_sk[4], md, mx);
+    }
     std::vector<float> a((size_t)T * N), b((size_t)T * N);
     CK(hipMemcpy(a.data(), o_old, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o_new, b.size() * 4, hipMemcpyDeviceToHost));
     size_t bad = 0; for (size_t i = 0; i < a.size(); i++) if (memcmp(&a[i], &b[i], 4)) bad++;
