@@ -686,6 +686,16 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
 
 size_t flash_attn_workspace_floats(int T, int H, int D, int splits) { return (size_t)T * H * splits * (D + 2); }
 
+hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t st) {
+    if (a.D != 64 && a.D != 128) return hipErrorInvalidValue;
+    const int nblk = (a.H * a.D) >> 8;
+    ActQuant qq;
+    if (a.out_q) qq = *a.out_q;
+    hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * splits * 4, st, a.part, a.out, a.H, a.D, splits,
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), (const int32_t *)nullptr);
+    return hipGetLastError();
+}
+
 int flash_attn_pick_splits(int T, int G, int n_kv_max) {
     int min_splits = (n_kv_max + ATT_MAX_CHUNK - 1) / ATT_MAX_CHUNK;
     if (min_splits < 1) min_splits = 1;

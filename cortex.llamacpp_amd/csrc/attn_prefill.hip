@@ -23,6 +23,7 @@
 // vec_dot_f16 against the K row, so S^T = K . Q^T is eight v_mfma_f32_32x32x16_f16 per chunk (K rows as halfs in LDS, Q as
 // halfs in registers, f32 accumulation, no block scales); V rows are already f16, so the hi plane IS V and the lo plane
 // (and its product) disappear: O^T += V^T . (Ph + Pl)^T.  Everything else — visibility, online softmax, staging order — is shared.
+#include <cstdlib>
 #include "kernels.h"
 #include "quant_dev.h"
 
@@ -69,9 +70,11 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     __shared__ unsigned s_vis[MAX_CHUNKS / 32];                // bit c: some cell of chunk c is visible to some query of the tile
     __shared__ int s_tile_maxpos;
     __shared__ unsigned long long s_tile_seqs;
+    __shared__ int s_nvis;                                      // marked chunks of this tile
 
     constexpr int NT = 64 * R;
     const int g = blockIdx.x, tile = blockIdx.y;
+    const int zsp = blockIdx.z, nsp = gridDim.z;               // key split: this workgroup walks its share of the tile's marked chunks
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, kg = lane >> 5;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     const size_t head_row0 = (size_t)g * n_ctx;
 
     // ---- tile-wide visibility bounds
-    if (tid == 0) { s_tile_maxpos = -1; s_tile_seqs = 0ull; }
+    if (tid == 0) { s_tile_maxpos = -1; s_tile_seqs = 0ull; s_nvis = 0; }
     for (int i = tid; i < MAX_CHUNKS / 32; i += NT) s_vis[i] = 0u;
     __syncthreads();
     if (wave == 0 && kg == 0) {
@@ -248,12 +251,31 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         }
     }
     __syncthreads();
-
-    int c = next_visible(0);
+    // ---- key split (causal prompts leave tile i with i + 1 chunks: without it the last tile's workgroup runs 16x as long as the
+    // first one's and half the chip idles): the marked chunks of the tile are dealt out in equal contiguous runs to the nsp
+    // workgroups of the tile; each leaves an unnormalised (O, m, l) record per query and head, flash_attn_combine_kernel merges them
+    int c = next_visible(0), left = n_chunks;                    // left: marked chunks still to walk (unsplit: all of them)
+    if (nsp > 1) {
+        if (wave == 0) {
+            int cnt = 0;
+            for (int i = lane; i < (n_chunks + 31) / 32; i += 64) cnt += __builtin_popcount(s_vis[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0) s_nvis = cnt;
+        }
+        __syncthreads();
+        const int nvis = s_nvis, per = (nvis + nsp - 1) / nsp;
+        const int first = zsp * per;
+        left = nvis - first < per ? nvis - first : per;
+        if (left < 0) left = 0;
+        for (int i = 0; i < first && c < n_chunks; i++) c = next_visible(c + 1);
+        if (left == 0) c = n_chunks;
+    }
     if (c < n_chunks) { load_data(c); store_chunk(); }
     __syncthreads();
     while (c < n_chunks) {
-        const int cn = next_visible(c + 1);
+        int cn = next_visible(c + 1);
+        if (--left <= 0) cn = n_chunks;
         if (cn < n_chunks) load_data(cn);                       // in flight while this chunk is on the matrix cores
         {
             // ---- scores S^T[key][query] of this chunk
@@ -343,6 +365,20 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         c = cn;
     }
 
+    if (nsp > 1) {                                              // partial record [D O][m][l] of (query, head, split)
+        if (q_ok) {
+            float *dst = a.part + (((size_t)qt * H + h) * nsp + zsp) * (D + 2);
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+#pragma unroll
+                for (int rq = 0; rq < 4; rq++) {
+                    float *o = dst + 32 * db + 8 * rq + 4 * kg;  // records are 8-byte aligned only ((D + 2) floats)
+                    o[0] = O[db][rq * 4 + 0]; o[1] = O[db][rq * 4 + 1]; o[2] = O[db][rq * 4 + 2]; o[3] = O[db][rq * 4 + 3];
+                }
+            if (kg == 0) { dst[D] = m_run; dst[D + 1] = l_run; }
+        }
+        return;
+    }
     // ---- out[t][h][d] = O / l ; lane (query n, kg) holds d = 32 db + 8 rq + 4 kg + (0..3)
     if (q_ok) {
         const float inv = 1.0f / l_run;
@@ -366,9 +402,20 @@ bool flash_attn_prefill_applicable(const AttnArgs &a) {
            a.n_kv_max <= MAX_CHUNKS * CK;
 }
 
+// key splits of a prompt batch: ~4 chunks of 32 cells per workgroup at the longest tile, at most 8, and a workspace of at most 512 MiB
+int flash_attn_prefill_splits(int T, int H, int D, int n_kv_max) {
+    static const int env = getenv("MI355_ATTN_PREFILL_SPLITS") ? atoi(getenv("MI355_ATTN_PREFILL_SPLITS")) : 0;
+    int s = ((n_kv_max + CK - 1) / CK + 3) / 4;
+    if (s > 8) s = 8;
+    if (env > 0) s = env;
+    while (s > 1 && (size_t)T * H * s * (D + 2) * sizeof(float) > ((size_t)512 << 20)) s >>= 1;
+    return s < 1 ? 1 : s;
+}
+
 hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
     const int R = a.H / a.G;
-    const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT));
+    const int nsp = (a.pf_splits > 1 && a.part) ? a.pf_splits : 1;
+    const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT), (unsigned)nsp);
     const bool f16 = a.type_k == T_F16;
     const size_t lds = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
 #define FAP(RR) do { if (f16) hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true>), grid, dim3(64 * RR), lds, st, a); \
@@ -383,6 +430,7 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
 #undef FAP
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (nsp > 1) return launch_flash_attn_combine(a, nsp, st);      // merges the splits and quantises the rows when asked
     if (a.out_q) e = launch_quantize(a.out, a.H * a.D, a.T, *a.out_q, a.out_q8k, a.out_q80, st);
     return e;
 }

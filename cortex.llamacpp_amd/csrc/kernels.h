@@ -196,6 +196,7 @@ struct AttnArgs {
     float scale;
     float *part;               // workspace [T][H][splits][D+2]
     int splits;
+    int pf_splits = 0;         // prompt kernel (attn_prefill.hip): key splits per query tile, workspace [T][H][pf_splits][D+2]; 0 / 1 = none
     // batched single-token steps: per token, the 64-cell chunks that can hold a visible cell (host-built from the cell
     // table); nullptr = every chunk of the scanned range.  tok_chunks[t * chunk_stride + i], i < tok_nchunks[t] <= splits
     const int32_t *tok_chunks = nullptr;
@@ -207,7 +208,10 @@ struct AttnArgs {
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
 // prompt processing on the matrix cores (attn_prefill.hip): D = 128, q8_0 K / V, T >= 32; q already rotated
 bool flash_attn_prefill_applicable(const AttnArgs &a);
+int flash_attn_prefill_splits(int T, int H, int D, int n_kv_max);
 hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st);
+// merge of [T][H][splits][D+2] partial records into a.out (+ quantised rows when a.out_q): attn.hip
+hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t st);
 // decode-step variants (attn.hip): single round trip per workgroup; q passed UN-rotated (rope fused), NORM rope, D = 128
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra);
 int flash_attn_decode_splits(int n_kv_max);
