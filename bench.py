@@ -391,7 +391,7 @@ def main() -> int:
         },
         "prefill_roofline": {
             "bound": "mfma",
-            "kernel": "mmq_planes_kernel (int8 v_mfma_i32_32x32x32_i8, weights pre-expanded into two exact int8 planes)",
+            "kernel": "mmq_planes2_kernel / mmq_planes_kernel (int8 v_mfma_i32_32x32x32_i8, weights pre-expanded into two exact int8 planes)",
             "achieved": round(prefill_tops, 1),
             "peak": MFMA_I8_PEAK_TOPS,
             "unit": "TOP/s",
