@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
 
     // ---- online-softmax state of this lane's query and the O^T accumulators (d = 32 db + row of the tile)
     float m_run = -INFINITY, l_run = 0.0f;
+    const float scale_l2 = a.scale * 1.4426950408889634f;       // softmax scale * log2(e)
     f32x16 O[4];
 #pragma unroll
     for (int db = 0; db < 4; db++)
@@ -309,6 +310,8 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                 }
             }
             // ---- mask + online softmax (this lane: one query, 16 keys; partner lane ^ 32: the other 16)
+            // (scores and the running maximum are kept in log2 units: exp(s - m) is one v_exp_f32 of (s - m) * log2(e), which is
+            // folded into the softmax scale; exp2(-inf) = 0 does the masking; the record a split leaves converts m back)
             float mloc = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -316,25 +319,28 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                 const int cp = S.cpos[key];
                 const unsigned long long cs = S.cseq[key];
                 const bool vis = q_ok && cp >= 0 && cp <= tpos && ((cs >> tseq) & 1ull);
-                sc[r] = vis ? sc[r] * a.scale : -INFINITY;
+                sc[r] = vis ? sc[r] * scale_l2 : -INFINITY;
                 mloc = fmaxf(mloc, sc[r]);
             }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);
+            const float m_ref = m_new == -INFINITY ? 0.0f : m_new;           // (nothing visible yet: exp2(-inf - 0) = 0, no NaN)
             float p[16], lsum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                p[r] = (sc[r] == -INFINITY) ? 0.0f : expf(sc[r] - m_new);
+                p[r] = __builtin_amdgcn_exp2f(sc[r] - m_ref);
                 lsum += p[r];
             }
             lsum += __shfl_xor(lsum, 32, 64);
-            const float alpha = (m_run == -INFINITY) ? 0.0f : expf(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);        // m_run = -inf: 0
             l_run = l_run * alpha + lsum;
             m_run = m_new;
+            if (!__all(alpha == 1.0f)) {                                      // (the maximum moves in the first chunks, rarely later)
 #pragma unroll
-            for (int db = 0; db < 4; db++)
+                for (int db = 0; db < 4; db++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) O[db][r] *= alpha;
+                    for (int r = 0; r < 16; r++) O[db][r] *= alpha;
+            }
             // ---- P^T operands: f16 hi / lo, two MFMAs' worth (regs 0..7 and 8..15)
             f16x8 ph[2], pl[2];
 #pragma unroll
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                     float *o = dst + 32 * db + 8 * rq + 4 * kg;  // records are 8-byte aligned only ((D + 2) floats)
                     o[0] = O[db][rq * 4 + 0]; o[1] = O[db][rq * 4 + 1]; o[2] = O[db][rq * 4 + 2]; o[3] = O[db][rq * 4 + 3];
                 }
-            if (kg == 0) { dst[D] = m_run; dst[D + 1] = l_run; }
+            if (kg == 0) { dst[D] = m_run * 0.6931471805599453f; dst[D + 1] = l_run; }   // (the merge works in natural-log units)
         }
         return;
     }
