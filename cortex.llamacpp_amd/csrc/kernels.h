@@ -79,6 +79,7 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
 // workspace for the K-split form of the planes kernel (tensors with few rows): n_split * T * n_rows floats; none = no split
 struct MMQWorkspace { float *p = nullptr; size_t bytes = 0; };
 void mmq_set_split(int n);                                 // tools: force the K split (0 = by shape)
+void mmq_set_lds_form(int on);                             // tools: 0 = never the 128 x 256 LDS kernel, 1 = by shape, -1 = environment / default
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                              float *out, int ld_out, const float *resid, hipStream_t st, MMQWorkspace wsp = MMQWorkspace());
 // small batches (continuous-batching decode steps, 8 <= T <= 64): K split over the waves of a workgroup, GGUF-form weights
@@ -95,7 +96,10 @@ hipError_t launch_mmq_q80(const uint8_t *W, size_t row_bytes, int n_rows, int K,
 // launch over the concatenated rows; seg_rows[i] rows go to outs[i] (leading dimension lds_out[i])
 hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
                                    const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st,
-                                   MMQWorkspace wsp = MMQWorkspace());
+                                   MMQWorkspace wsp = MMQWorkspace(), const int *seg_types = nullptr);
+// seg_types (per segment; nullptr = all `type`): Q4_K / Q5_K segments beside Q6_K ones in ONE launch where this says so (segments end on
+// 128-row tiles and the launch takes the 128 x 256 kernel)
+bool mmq_planes_mixed_ok(const int *seg_rows, int n_seg, int K, int T, MMQWorkspace wsp);
 bool mmq_ksplit_applicable(int type, int K, int T);
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st);

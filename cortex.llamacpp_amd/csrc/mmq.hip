@@ -639,6 +639,7 @@ struct PlanesOut {
     int ld[3];
     int row_end[3];
     int n_seg;
+    unsigned mins_mask;     // bit s: segment s is Q4_K / Q5_K (block-sum term, shift 5); mmq_planes2_kernel<2> only
 };
 
 // MINS: Q4_K / Q5_K (block-sum term, shift 5); otherwise Q6_K (shift 6, nothing else)
@@ -937,11 +938,12 @@ __device__ unsigned long long *g_p2_probe = nullptr;
 // at the start of the next super-block's first stage - each half's fold runs beside the other half's MFMAs.
 // The block-sum ("mins") term is one v_mfma_f32_32x32x16_f16 per tile: the 16 block sums (|.| <= 2032) and the 6-bit mins are
 // exact in f16 and their 16 products sum to < 2^24, so the f32 result IS the integer msum - no shift, no conversion.
-template <bool MINS>
+// MODE 0: Q6_K planes (signed codes, no block-sum term); 1: Q4_K / Q5_K; 2: per segment (po.mins_mask; segment boundaries at multiples of 128
+// rows, so a workgroup's row tile is of one kind) - Q | K | V of the layers whose attn_v is Q6_K, in one launch
+template <int MODE>
 __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
                                                                const int8_t *aq, const float *ad, const int16_t *absum,
                                                                const PlanesOut po, const float *resid, float *ws, int n_split) {
-    constexpr int SH = MINS ? 5 : 6;
     constexpr int MT = P2_MT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -960,6 +962,14 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
     const int row0 = rt32 * 32;
     const int tok0 = tok_tile * P2_TOK;
     const int n = lane & 31, kg = lane >> 5;
+    bool MINS = MODE == 1;                                      // (workgroup-uniform)
+    if (MODE == 2) {
+        int sg0 = 0;
+        if (po.n_seg > 1 && row_tile * P2_ROWS >= po.row_end[0]) sg0 = 1;
+        if (po.n_seg > 2 && row_tile * P2_ROWS >= po.row_end[1]) sg0 = 2;
+        MINS = (po.mins_mask >> sg0) & 1u;
+    }
+    const int SH = MINS ? 5 : 6;
 
     // ---- this wave's share of the DMA.  Per stage: 4 KiB of B (row tile wave / 2, K-steps 2 (wave & 1) .. + 1, both planes) and
     // 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x 32 B),
@@ -1262,6 +1272,7 @@ hipError_t launch_one(const uint8_t *W, size_t row_bytes, int n_rows, int K, int
 
 int g_mmq_mt = 0;   // 0 = by T; tools may force 1 / 2 / 4
 int g_mmq_split = 0;   // tools: force the K split of the 128 x 256 kernel (0 = by shape, 1 = none)
+int g_mmq_p2 = -1;     // tools: 0 = never the 128 x 256 kernel, 1 = by shape, -1 = MI355_MMQ_PLANES2 / default
 
 template <int TYPE>
 hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
@@ -1282,6 +1293,7 @@ hipError_t launch_type(const uint8_t *W, size_t row_bytes, int n_rows, int K, in
 
 void mmq_set_tiles(int mt) { g_mmq_mt = mt; }
 void mmq_set_split(int n) { g_mmq_split = n; }
+void mmq_set_lds_form(int on) { g_mmq_p2 = on; }
 #ifdef MI355_P2_PROBE
 void mmq_p2_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p2_probe), &p, sizeof(p)); }
 #endif
@@ -1353,33 +1365,14 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
 
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                              float *out, int ld_out, const float *resid, hipStream_t st, MMQWorkspace wsp) {
-    return launch_mmq_planes_multi(type, planes, &n_rows, &out, &ld_out, 1, K, T, q, bh, bl, resid, st, wsp);
+    return launch_mmq_planes_multi(type, planes, &n_rows, &out, &ld_out, 1, K, T, q, bh, bl, resid, st, wsp, nullptr);
 }
 
-hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
-                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st, MMQWorkspace wsp) {
-    if (n_seg < 1 || n_seg > 3 || (n_seg > 1 && resid)) return hipErrorInvalidValue;
-    PlanesOut po{};
-    po.n_seg = n_seg;
-    int n_rows = 0;
-    for (int i = 0; i < n_seg; i++) {
-        if (i + 1 < n_seg && (seg_rows[i] % 32) != 0) return hipErrorInvalidValue;
-        n_rows += seg_rows[i];
-        po.out[i] = outs[i]; po.ld[i] = lds_out[i]; po.row_end[i] = n_rows;
-    }
+// the K split the 128 x 256 kernel would run a tensor (or concatenation) of n_rows rows with, and whether it takes the launch at all
+static int planes2_split(int n_rows, int K, int T, const MMQWorkspace &wsp, bool *takes) {
     static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
-    // 128 x 128 workgroup tiles (two token tiles per wave) when that still yields ~2 workgroups per CU, else 256 x 32
-    // tiles, which quadruple the workgroup count (measured on the 8B shapes: gate/up 297 vs 383 us, N = 4096 tensors
-    // 54-144 vs 75-204 us per layer)
-    const long wg2 = (long)((n_rows + 127) / 128) * ((T + 127) / 128);
-    int mt = (T <= 32 || wg2 < 3L * num_cu() / 2) ? 1 : 2;
-    if (n_seg > 1 && T > 32 && wg2 * 4 >= 3L * num_cu()) mt = 2;       // concatenated Q | K | V: 192 workgroups of 128 x 128 beat 384 of 256 x 32 (59 vs 71 us)
-    if (env_mt == 1 || env_mt == 2) mt = env_mt;
-    if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
-    const bool mins = type != T_Q6_K;
-    // both operands through LDS (128 rows x 256 tokens per workgroup) once that grid covers most of the chip; tensors with
-    // too few rows for that split K over 2..4 workgroups (partial sums in the caller's workspace, added up in split order)
-    static const int env_p2 = getenv("MI355_MMQ_PLANES2") ? atoi(getenv("MI355_MMQ_PLANES2")) : 1;
+    static const int env_p2_0 = getenv("MI355_MMQ_PLANES2") ? atoi(getenv("MI355_MMQ_PLANES2")) : 1;
+    const int env_p2 = g_mmq_p2 >= 0 ? g_mmq_p2 : env_p2_0;
     static const int env_sk = getenv("MI355_MMQ_SPLITK") ? atoi(getenv("MI355_MMQ_SPLITK")) : -1;   // 0 off, 2..4 forced
     const int nb = K >> 8;
     const long wg4 = (long)((n_rows + P2_ROWS - 1) / P2_ROWS) * ((T + P2_TOK - 1) / P2_TOK);
@@ -1393,11 +1386,59 @@ hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *s
     }
     if (n_split > nb) n_split = nb;
     if (n_split < 1 || (n_rows % 4) != 0 || !wsp.p || (size_t)n_split * T * n_rows * sizeof(float) > wsp.bytes) n_split = 1;
-    const bool p2 = g_mmq_mt == 4 || (g_mmq_mt == 0 && env_mt == 0 && env_p2 != 0 && T > 128 && wg4 * n_split * 4 >= 3L * num_cu());
+    *takes = g_mmq_mt == 4 || (g_mmq_mt == 0 && env_mt == 0 && env_p2 != 0 && T > 128 && wg4 * n_split * 4 >= 3L * num_cu());
+    return n_split;
+}
+
+// Q4_K / Q5_K segments beside Q6_K ones in one launch: only the 128 x 256 kernel has that form, and segments must end on its row tiles
+bool mmq_planes_mixed_ok(const int *seg_rows, int n_seg, int K, int T, MMQWorkspace wsp) {
+    static const bool env_on = !(getenv("MI355_MMQ_MIXED") && getenv("MI355_MMQ_MIXED")[0] == '0');
+    if (!env_on) return false;
+    int n_rows = 0;
+    for (int i = 0; i < n_seg; i++) { if (i + 1 < n_seg && (seg_rows[i] % P2_ROWS) != 0) return false; n_rows += seg_rows[i]; }
+    bool takes = false;
+    (void)planes2_split(n_rows, K, T, wsp, &takes);
+    return takes && n_seg >= 1 && n_seg <= 3;
+}
+
+hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,
+                                   const ActQuant &q, const int8_t *bh, const int8_t *bl, const float *resid, hipStream_t st, MMQWorkspace wsp,
+                                   const int *seg_types) {
+    if (n_seg < 1 || n_seg > 3 || (n_seg > 1 && resid)) return hipErrorInvalidValue;
+    PlanesOut po{};
+    po.n_seg = n_seg;
+    int n_rows = 0;
+    bool mixed = false;
+    for (int i = 0; i < n_seg; i++) {
+        if (i + 1 < n_seg && (seg_rows[i] % 32) != 0) return hipErrorInvalidValue;
+        n_rows += seg_rows[i];
+        po.out[i] = outs[i]; po.ld[i] = lds_out[i]; po.row_end[i] = n_rows;
+        const int ti = seg_types ? seg_types[i] : type;
+        if (ti != T_Q6_K) po.mins_mask |= 1u << i;
+        mixed = mixed || (ti != T_Q6_K) != (type != T_Q6_K);
+    }
+    if (mixed && !mmq_planes_mixed_ok(seg_rows, n_seg, K, T, wsp)) return hipErrorInvalidValue;
+    static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
+    // 128 x 128 workgroup tiles (two token tiles per wave) when that still yields ~2 workgroups per CU, else 256 x 32
+    // tiles, which quadruple the workgroup count (measured on the 8B shapes: gate/up 297 vs 383 us, N = 4096 tensors
+    // 54-144 vs 75-204 us per layer)
+    const long wg2 = (long)((n_rows + 127) / 128) * ((T + 127) / 128);
+    int mt = (T <= 32 || wg2 < 3L * num_cu() / 2) ? 1 : 2;
+    if (n_seg > 1 && T > 32 && wg2 * 4 >= 3L * num_cu()) mt = 2;       // concatenated Q | K | V: 192 workgroups of 128 x 128 beat 384 of 256 x 32 (59 vs 71 us)
+    if (env_mt == 1 || env_mt == 2) mt = env_mt;
+    if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
+    const bool mins = type != T_Q6_K;
+    // both operands through LDS (128 rows x 256 tokens per workgroup) once that grid covers most of the chip; tensors with
+    // too few rows for that split K over 2..4 workgroups (partial sums in the caller's workspace, added up in split order)
+    bool p2 = false;
+    const int n_split = planes2_split(n_rows, K, T, wsp, &p2);
     if (p2) {
         const int nrt = (n_rows + P2_ROWS - 1) / P2_ROWS, ntt = (T + P2_TOK - 1) / P2_TOK;
         const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * n_split * 8));
-        if (mins) {
+        if (mixed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+            hipLaunchKernelGGL((mmq_planes2_kernel<2>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid, wsp.p, n_split);
+        } else if (mins) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
             hipLaunchKernelGGL((mmq_planes2_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po, resid, wsp.p, n_split);
         } else {

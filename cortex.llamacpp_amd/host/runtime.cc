@@ -747,14 +747,23 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
         // Q | K | V (or Q | K) as one launch over the concatenated rows where their plane sets are adjacent in the arena and
         // of one plane format (Q4_K and Q5_K share it; the Q6_K attn_v of the "more bits" layers runs on its own)
         auto mins = [](int t) { return t != T_Q6_K; };
+        auto adjacent = [&](int i) { return ws[i]->planes && ws[i - 1]->planes && ws[i]->planes == ws[i - 1]->planes + ws[i - 1]->planes_bytes &&
+                                            (ws[i - 1]->N % 32) == 0 && ws[i]->n_expert == 1; };
         int nf = 1;
-        while (nf < n && nf < 3 && ws[nf]->planes && ws[nf - 1]->planes && ws[nf]->planes == ws[nf - 1]->planes + ws[nf - 1]->planes_bytes &&
-               mins(ws[nf]->type) == mins(ws[0]->type) && (ws[nf - 1]->N % 32) == 0 && ws[nf]->n_expert == 1) nf++;
+        while (nf < n && nf < 3 && adjacent(nf) && mins(ws[nf]->type) == mins(ws[0]->type)) nf++;
+        // the "more bits" layers (Q6_K attn_v beside Q4_K / Q5_K attn_q, attn_k): still one launch where the 128 x 256 kernel takes it
+        int nm = nf;
+        while (nm < n && nm < 3 && adjacent(nm)) nm++;
+        if (nm > nf) {
+            int rows[3];
+            for (int i = 0; i < nm; i++) rows[i] = (int)ws[i]->N;
+            if (mmq_planes_mixed_ok(rows, nm, K, T, mmq_ws_)) nf = nm;
+        }
         if (nf >= 2) {
-            int rows[3], ldo[3];
+            int rows[3], ldo[3], types[3];
             float *o[3];
-            for (int i = 0; i < nf; i++) { rows[i] = (int)ws[i]->N; ldo[i] = (int)ws[i]->N; o[i] = outs[i]; }
-            HIP_TRY(launch_mmq_planes_multi(ws[0]->type, ws[0]->planes, rows, o, ldo, nf, K, T, aq, mmq_bh_, mmq_bl_, nullptr, stream_, mmq_ws_));
+            for (int i = 0; i < nf; i++) { rows[i] = (int)ws[i]->N; ldo[i] = (int)ws[i]->N; o[i] = outs[i]; types[i] = ws[i]->type; }
+            HIP_TRY(launch_mmq_planes_multi(ws[0]->type, ws[0]->planes, rows, o, ldo, nf, K, T, aq, mmq_bh_, mmq_bl_, nullptr, stream_, mmq_ws_, types));
         } else nf = 0;
         for (int i = nf; i < n; i++) {
             if (ws[i]->planes) HIP_TRY(launch_mmq_planes(ws[i]->type, ws[i]->planes, (int)ws[i]->N, K, T, aq, mmq_bh_, mmq_bl_, outs[i], (int)ws[i]->N, nullptr, stream_, mmq_ws_));

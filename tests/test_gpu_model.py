@@ -216,6 +216,39 @@ def test_weight_stream_matvec_matches_register_ring_bitwise(be, pkg, tmp_models,
     m.close()
 
 
+@pytest.mark.parametrize("ftype", ["q4_k_m", "q5_k_m"])
+def test_prompt_lds_kernel_matches_per_lane_kernels(be, pkg, tmp_models, ftype):
+    """A 400-token prompt (longer than the K-split kernel takes) on Llama-3-8B's layer geometry (2 layers; the second one carries the Q6_K attn_v / ffn_down of the
+    *_K_M mixes): with the 128 x 256 LDS kernel in play gate | up run on it, FFN down splits K, and Q | K | V of the mixed-type
+    layer go out as ONE launch whose row tiles are Q4_K / Q5_K or Q6_K by segment.  Same integer sums as the per-lane planes
+    kernels; only the f32 order over super-blocks differs where K is split."""
+    path = make(pkg, tmp_models, "tiny-8b-2l", ftype)
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(8).integers(0, m.n_vocab, 400)
+
+    def run(lds, split):
+        be.set_option("mmq_lds_form", 1 if lds else 0)
+        be.set_option("mmq_split", split)
+        try:
+            c = pkg.Context(m, n_ctx=512, type_k=8, type_v=8)
+            assert c.decode(prompt, np.arange(400)) == 0
+            out = c.logits().copy()
+            c.close()
+        finally:
+            be.set_option("mmq_lds_form", -1)
+            be.set_option("mmq_split", 0)
+        return out
+
+    old, lds, lds_split = run(False, 0), run(True, 1), run(True, 0)
+    assert np.isfinite(lds).all()
+    assert np.array_equal(lds, old)                            # unsplit: same sums in the same order, mixed-type launch included
+    # split K: the f32 order over super-blocks changes; this random-weight model amplifies such last-bit changes through the
+    # re-quantisation of the activations (a different attention split count moves its logits by as much)
+    assert not np.array_equal(lds_split, old)
+    assert np.abs(lds_split - old).max() <= 3e-2 * max(1.0, float(np.abs(old).max()))
+    m.close()
+
+
 @pytest.mark.parametrize("cfg", ["tiny-gqa4", "tiny-d128", "tiny-g8"])
 def test_graph_and_eager_agree_bitwise(be, pkg, tmp_models, cfg):
     path = make(pkg, tmp_models, cfg, "q4_k_m")
