@@ -503,7 +503,7 @@ int mi355_op_flash_attn(const float *q, int64_t T, int32_t H, int32_t G, int32_t
     a.cell_pos = dcp.as<int32_t>(); a.cell_seq = dcs.as<uint64_t>(); a.tok_pos = dtp.as<int32_t>(); a.tok_seq = dts.as<int32_t>();
     a.n_kv_dev = dn.as<int32_t>(); a.n_kv_max = n_cells; a.scale = scale;
     a.splits = flash_attn_pick_splits((int)T, G, n_cells);
-    a.pf_splits = flash_attn_prefill_splits((int)T, H, D, n_cells);
+    a.pf_splits = flash_attn_prefill_splits((int)T, H, G, D, n_cells);
     DevBuf part(flash_attn_workspace_floats((int)T, H, D, std::max(a.splits, a.pf_splits)) * 4);
     a.part = part.as<float>();
     hipError_t e = launch_flash_attn(a, nullptr);

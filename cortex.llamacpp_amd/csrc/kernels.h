@@ -212,7 +212,7 @@ struct AttnArgs {
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
 // prompt processing on the matrix cores (attn_prefill.hip): D = 128, q8_0 K / V, T >= 32; q already rotated
 bool flash_attn_prefill_applicable(const AttnArgs &a);
-int flash_attn_prefill_splits(int T, int H, int D, int n_kv_max);
+int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max);
 hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st);
 // merge of [T][H][splits][D+2] partial records into a.out (+ quantised rows when a.out_q): attn.hip
 hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t st);

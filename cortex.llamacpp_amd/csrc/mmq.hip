@@ -938,22 +938,16 @@ __device__ unsigned long long *g_p2_probe = nullptr;
 // at the start of the next super-block's first stage - each half's fold runs beside the other half's MFMAs.
 // The block-sum ("mins") term is one v_mfma_f32_32x32x16_f16 per tile: the 16 block sums (|.| <= 2032) and the 6-bit mins are
 // exact in f16 and their 16 products sum to < 2^24, so the f32 result IS the integer msum - no shift, no conversion.
-// MODE 0: Q6_K planes (signed codes, no block-sum term); 1: Q4_K / Q5_K; 2: per segment (po.mins_mask; segment boundaries at multiples of 128
-// rows, so a workgroup's row tile is of one kind) - Q | K | V of the layers whose attn_v is Q6_K, in one launch
-template <int MODE>
-__global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
-                                                               const int8_t *aq, const float *ad, const int16_t *absum,
-                                                               const PlanesOut po, const float *resid, float *ws, int n_split) {
+template <bool MINS>
+__device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
+                                             const int8_t *aq, const float *ad, const int16_t *absum,
+                                             const PlanesOut &po, const float *resid, float *ws, int n_split, int row_tile, int tok_tile, int zz) {
     constexpr int MT = P2_MT;
+    constexpr int SH = MINS ? 5 : 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb_all = K >> 8;                                 // super-blocks per row (strides); this workgroup's share is [sb_lo, sb_lo + nb)
-    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-    const int tok_tile = loc % n_tok_tiles;
-    const int zz = (loc / n_tok_tiles) % n_split;              // K split: partial sums go to ws[zz], mmq_splitk_reduce_kernel adds them up
-    const int row_tile = (loc / (n_tok_tiles * n_split)) * 8 + xcd;
-    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
     const int sb_lo = (int)((long)nb_all * zz / n_split), nb = (int)((long)nb_all * (zz + 1) / n_split) - sb_lo;
     const int rw = wave & 3, tw = wave >> 2;
     const int n_rt32 = (n_rows + 31) >> 5;
@@ -962,14 +956,6 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
     const int row0 = rt32 * 32;
     const int tok0 = tok_tile * P2_TOK;
     const int n = lane & 31, kg = lane >> 5;
-    bool MINS = MODE == 1;                                      // (workgroup-uniform)
-    if (MODE == 2) {
-        int sg0 = 0;
-        if (po.n_seg > 1 && row_tile * P2_ROWS >= po.row_end[0]) sg0 = 1;
-        if (po.n_seg > 2 && row_tile * P2_ROWS >= po.row_end[1]) sg0 = 2;
-        MINS = (po.mins_mask >> sg0) & 1u;
-    }
-    const int SH = MINS ? 5 : 6;
 
     // ---- this wave's share of the DMA.  Per stage: 4 KiB of B (row tile wave / 2, K-steps 2 (wave & 1) .. + 1, both planes) and
     // 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x 32 B),
@@ -1224,6 +1210,29 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
             }
         }
     }
+}
+
+// MODE 0: Q6_K planes (signed codes, no block-sum term); 1: Q4_K / Q5_K; 2: per segment (po.mins_mask; segment boundaries at multiples of
+// 128 rows, so a workgroup's row tile is of one kind) - Q | K | V of the layers whose attn_v is Q6_K, in one launch.  MODE 2 carries both
+// bodies behind one workgroup-uniform branch (a run-time flag inside ONE body costs 92 bytes of scratch per lane and 2.3x the time).
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
+                                                               const int8_t *aq, const float *ad, const int16_t *absum,
+                                                               const PlanesOut po, const float *resid, float *ws, int n_split) {
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int tok_tile = loc % n_tok_tiles;
+    const int zz = (loc / n_tok_tiles) % n_split;              // K split: partial sums go to ws[zz], mmq_splitk_reduce_kernel adds them up
+    const int row_tile = (loc / (n_tok_tiles * n_split)) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    bool mins = MODE == 1;
+    if (MODE == 2) {
+        int sg0 = 0;
+        if (po.n_seg > 1 && row_tile * P2_ROWS >= po.row_end[0]) sg0 = 1;
+        if (po.n_seg > 2 && row_tile * P2_ROWS >= po.row_end[1]) sg0 = 2;
+        mins = (po.mins_mask >> sg0) & 1u;
+    }
+    if (MODE == 1 || (MODE == 2 && mins)) planes2_body<true>(planes, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, resid, ws, n_split, row_tile, tok_tile, zz);
+    else planes2_body<false>(planes, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, resid, ws, n_split, row_tile, tok_tile, zz);
 }
 
 // out[t][row] = (resid) + ws[0][t][row] + ws[1][t][row] + ... in split order (fixed, so results do not depend on timing)

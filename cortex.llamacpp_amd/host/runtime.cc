@@ -491,7 +491,8 @@ bool Context::init(std::string &err) {
         ws = std::max(ws, flash_attn_workspace_floats(t, hp.n_head, (int)D, sp));
     }
     ws = std::max(ws, flash_attn_workspace_floats(std::min<int>((int)T, 64), hp.n_head, (int)D, flash_attn_decode_splits((int)NC)));
-    if (T >= 32) ws = std::max(ws, flash_attn_workspace_floats((int)T, hp.n_head, (int)D, flash_attn_prefill_splits((int)T, hp.n_head, (int)D, (int)NC)));   // key splits of a prompt batch
+    for (int t = 32; t <= (int)T; t += 32)                       // key splits of a prompt batch (fewer tokens take more splits)
+        ws = std::max(ws, flash_attn_workspace_floats(t, hp.n_head, (int)D, flash_attn_prefill_splits(t, hp.n_head, (int)G, (int)D, (int)NC)));
     att_part_ = (float *)dalloc(ws * 4);
     att_part_floats_ = ws;
     att_counters_ = (unsigned *)dalloc(256 * sizeof(unsigned));
@@ -966,7 +967,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
             prof_mark("rope_kv");
             aa.splits = att_splits_;
-            aa.pf_splits = flash_attn_prefill_splits(T, H, D, n_kv_max);
+            aa.pf_splits = flash_attn_prefill_splits(T, H, G, D, n_kv_max);
             while (aa.pf_splits > 1 && flash_attn_workspace_floats(T, H, D, aa.pf_splits) > att_part_floats_) aa.pf_splits >>= 1;
             HIP_TRY(launch_flash_attn(aa, stream_));
         }

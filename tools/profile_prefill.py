@@ -10,7 +10,7 @@ path = "/tmp/mi355-bench-llama-3-8b-q4_k_m.gguf"
 if not os.path.exists(path):
     pkg.gguf_synth.write_synthetic_llama(path, "llama-3-8b", "q4_k_m", seed=0xC0FFEE, with_vocab=False)
 m = pkg.Model(path)
-c = pkg.Context(m, n_ctx=4096, type_k=8, type_v=8, use_graphs=False)
+c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=int(os.environ.get("UBATCH", "2048")), type_k=8, type_v=8, use_graphs=False)
 rng = np.random.default_rng(0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 p = rng.integers(0, m.n_vocab, T)
