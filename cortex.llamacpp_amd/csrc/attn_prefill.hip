@@ -55,8 +55,19 @@ struct Chunk {
 // key index (0..31) of MFMA K-slot (j, kg, i): the order the score tile leaves its 16 keys per lane in registers
 __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 8 * (i >> 2) + 4 * kg + (i & 3); }
 
+#ifdef MI355_FA_PROBE
+// tools/build_fa_probe.sh: shader-clock split of one workgroup (printed by the last tile's first split): prologue | per chunk: scores,
+// softmax, P.V, barrier, store, barrier
+#define FA_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); fa_acc[i] += t_ - fa_t; fa_t = t_; } while (0)
+#else
+#define FA_T(i) do { } while (0)
+#endif
 template <int R, bool F16>
 __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_kernel(const AttnArgs a) {
+#ifdef MI355_FA_PROBE
+    unsigned long long fa_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fa_t = __builtin_readcyclecounter();
+    int fa_chunks = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KS = F16 ? KF_STRIDE : K_STRIDE;    // bytes per staged K row
     constexpr int PPK = F16 ? 16 : 8;                 // 16-byte pieces per K / V row
@@ -68,8 +79,9 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
     S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
     __shared__ unsigned s_vis[MAX_CHUNKS / 32];                // bit c: some cell of chunk c is visible to some query of the tile
-    __shared__ int s_tile_maxpos;
+    __shared__ int s_tile_maxpos, s_tile_minpos;
     __shared__ unsigned long long s_tile_seqs;
+    __shared__ int s_chunk_open[2];                             // [parity]: every cell of the staged chunk is visible to every query of the tile
     __shared__ int s_nvis;                                      // marked chunks of this tile
 
     constexpr int NT = 64 * R;
@@ -90,11 +102,12 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     const size_t head_row0 = (size_t)g * n_ctx;
 
     // ---- tile-wide visibility bounds
-    if (tid == 0) { s_tile_maxpos = -1; s_tile_seqs = 0ull; s_nvis = 0; }
+    if (tid == 0) { s_tile_maxpos = -1; s_tile_minpos = 0x7fffffff; s_tile_seqs = 0ull; s_nvis = 0; }
     for (int i = tid; i < MAX_CHUNKS / 32; i += NT) s_vis[i] = 0u;
     __syncthreads();
     if (wave == 0 && kg == 0) {
         atomicMax(&s_tile_maxpos, tpos);
+        atomicMin(&s_tile_minpos, tpos);
         atomicOr(&s_tile_seqs, 1ull << tseq);
     }
 
@@ -141,7 +154,13 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     constexpr int NP = (CK * PPK + NT - 1) / NT;
     u32x4 kq[NP], vq[NP];
     constexpr int NKD = (CK * NB + NT - 1) / NT;
-    float kdn[NKD], vdn[NP];
+    float kdn[NKD];
+    // q8_0 V: unit u = tid (+ NT) -> four consecutive keys 4 (u >> 5) .. + 3 x four dims 4 (u & 31) .. + 3: the four keys are four adjacent
+    // K-slots of the transposed planes, so a dim's hi (lo) halves of the unit go out as ONE 8-byte LDS store (the key-per-thread
+    // mapping wrote 32 two-byte stores per thread: the staging was 3.0 of a chunk's 8.3 kilocycles)
+    constexpr int NV = F16 ? 1 : (256 + NT - 1) / NT;
+    uint32_t v4[NV][4];
+    float vd4[NV][4];
     int cpn = -1;
     unsigned long long csn = 0ull;
     auto load_data = [&](int c) {
@@ -156,11 +175,24 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
             if constexpr (F16) {
                 kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D * 2 + (p % PPK) * 16);
                 vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D * 2 + (p % PPK) * 16);
-                vdn[i] = 0.0f;
             } else {
                 kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p & 7) * 16);
-                vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D + (p & 7) * 16);
-                vdn[i] = h2f(a.kv.vd[rowi * NB + ((p & 7) >> 1)]);
+            }
+        }
+        if constexpr (!F16) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                int u = tid + NT * i;
+                if (u >= 256) u = 255;
+                const int kgp = u >> 5, dg = u & 31;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    int cell = c * CK + 4 * kgp + kk;
+                    if (cell >= n_ctx) cell = n_ctx - 1;
+                    const size_t rowi = head_row0 + cell;
+                    v4[i][kk] = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + 4 * dg);
+                    vd4[i][kk] = h2f(a.kv.vd[rowi * NB + (dg >> 3)]);
+                }
             }
         }
 #pragma unroll
@@ -175,6 +207,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         const int mcell = c * CK + tid;
         if (tid < CK && mcell < n_kv) { cpn = a.cell_pos[mcell]; csn = a.cell_seq[mcell]; }
     };
+    int stage_par = 0, read_par = 0;                             // parity of s_chunk_open written by the next store / read by the current chunk
     auto store_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -182,11 +215,10 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
             if (p >= CK * PPK) continue;
             const int key = p / PPK, col = p % PPK;            // q8_0: dims 16 col .. + 15; f16: dims 8 col .. + 7
             *reinterpret_cast<u32x4 *>(S.k + key * KS + col * 16) = kq[i];
-            // V' = code * d_v, split exactly into f16 hi + lo, written transposed in MFMA K-slot order
-            const int j = key >> 4, r8 = key & 15;              // key = 16 j + 8 (i >> 2) + 4 kgs + (i & 3)
-            const int kgs = (r8 >> 2) & 1, slot = ((r8 >> 3) << 2) | (r8 & 3);
-            const uint32_t wv[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
-            if constexpr (F16) {                               // V is f16 already: the hi plane is V itself, there is no lo plane
+            if constexpr (F16) {                               // V is f16 already: the hi plane is V itself, there is no lo plane; written
+                const int j = key >> 4, r8 = key & 15;          // transposed in MFMA K-slot order: key = 16 j + 8 (i >> 2) + 4 kgs + (i & 3)
+                const int kgs = (r8 >> 2) & 1, slot = ((r8 >> 3) << 2) | (r8 & 3);
+                const uint32_t wv[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int dim = col * 8 + e;
@@ -194,16 +226,32 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                     const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot;
                     reinterpret_cast<uint16_t *>(S.vh)[o] = hb;
                 }
-                continue;
             }
+        }
+        if constexpr (!F16) {
+            // V' = code * d_v, split exactly into f16 hi + lo, transposed into MFMA K-slot order: keys 4 kgp .. + 3 are slots slot0 .. + 3 of
+            // (j = key >> 4, kgs = (key >> 2) & 1)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int dim = col * 16 + e;
-                const float v = (float)(int8_t)((wv[e >> 2] >> (8 * (e & 3))) & 0xff) * vdn[i];
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot;
-                S.vh[o] = hi; S.vl[o] = lo;
+            for (int i = 0; i < NV; i++) {
+                const int u = tid + NT * i;
+                if (u >= 256) continue;
+                const int kgp = u >> 5, dg = u & 31;
+                const int j = kgp >> 2, kgs = kgp & 1, slot0 = ((kgp >> 1) & 1) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int dim = 4 * dg + e;
+                    _Float16 hi[4], lo[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const float v = (float)(int8_t)((v4[i][kk] >> (8 * e)) & 0xff) * vd4[i][kk];
+                        hi[kk] = (_Float16)v;
+                        lo[kk] = (_Float16)(v - (float)hi[kk]);
+                    }
+                    const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot0;
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<f16x4 *>(S.vh + o) = f16x4{hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<f16x4 *>(S.vl + o) = f16x4{lo[0], lo[1], lo[2], lo[3]};
+                }
             }
         }
 #pragma unroll
@@ -212,6 +260,14 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
             if (q < CK * NB) S.dk[(q >> 5) * CK + (q & 31)] = kdn[i];
         }
         if (tid < CK) { S.cpos[tid] = cpn; S.cseq[tid] = csn; }
+        // a chunk below the diagonal of a causal prompt is visible to the whole tile: no per-score cell test then (16 x two LDS reads, a
+        // 64-bit shift and three compares per lane and chunk).  Lanes 0..31 of wave 0 hold the chunk's cells.
+        if (wave == 0) {
+            const bool open = kg == 1 || (cpn >= 0 && cpn <= s_tile_minpos && (csn & s_tile_seqs) == s_tile_seqs);
+            const bool all_open = __all(open);
+            if (lane == 0) s_chunk_open[stage_par] = all_open ? 1 : 0;
+        }
+        stage_par ^= 1;
     };
     auto next_visible = [&](int from) -> int {                   // first marked chunk >= from, or n_chunks
         int c = from;
@@ -274,7 +330,11 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     }
     if (c < n_chunks) { load_data(c); store_chunk(); }
     __syncthreads();
+    FA_T(0);
     while (c < n_chunks) {
+#ifdef MI355_FA_PROBE
+        fa_chunks++;
+#endif
         int cn = next_visible(c + 1);
         if (--left <= 0) cn = n_chunks;
         if (cn < n_chunks) load_data(cn);                       // in flight while this chunk is on the matrix cores
@@ -310,18 +370,25 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                 }
             }
             // ---- mask + online softmax (this lane: one query, 16 keys; partner lane ^ 32: the other 16)
+            FA_T(1);
             // (scores and the running maximum are kept in log2 units: exp(s - m) is one v_exp_f32 of (s - m) * log2(e), which is
             // folded into the softmax scale; exp2(-inf) = 0 does the masking; the record a split leaves converts m back)
             float mloc = -INFINITY;
+            if (s_chunk_open[read_par]) {                                     // (workgroup-uniform)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int key = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const int cp = S.cpos[key];
-                const unsigned long long cs = S.cseq[key];
-                const bool vis = q_ok && cp >= 0 && cp <= tpos && ((cs >> tseq) & 1ull);
-                sc[r] = vis ? sc[r] * scale_l2 : -INFINITY;
-                mloc = fmaxf(mloc, sc[r]);
+                for (int r = 0; r < 16; r++) { sc[r] *= scale_l2; mloc = fmaxf(mloc, sc[r]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    const int cp = S.cpos[key];
+                    const unsigned long long cs = S.cseq[key];
+                    const bool vis = q_ok && cp >= 0 && cp <= tpos && ((cs >> tseq) & 1ull);
+                    sc[r] = vis ? sc[r] * scale_l2 : -INFINITY;
+                    mloc = fmaxf(mloc, sc[r]);
+                }
             }
+            read_par ^= 1;
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);
             const float m_ref = m_new == -INFINITY ? 0.0f : m_new;           // (nothing visible yet: exp2(-inf - 0) = 0, no NaN)
@@ -352,6 +419,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                     ph[j][i] = hi;
                     pl[j][i] = (_Float16)(v - (float)hi);
                 }
+            FA_T(2);
             // ---- O^T[d][query] += V'^T . P^T
 #pragma unroll
             for (int db = 0; db < 4; db++)
@@ -365,11 +433,20 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
                     if constexpr (!F16) O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, ph[j], O[db], 0, 0, 0);
                 }
         }
+        FA_T(3);
         __syncthreads();                                        // chunk c consumed
+        FA_T(4);
         if (cn < n_chunks) store_chunk();
+        FA_T(5);
         __syncthreads();
+        FA_T(6);
         c = cn;
     }
+#ifdef MI355_FA_PROBE
+    if (tid == 0 && g == 0 && tile == (int)gridDim.y - 1 && zsp == 0)
+        printf("fa probe: %d chunks; cycles: prologue %llu | scores %llu softmax %llu PV %llu barrier %llu store %llu barrier %llu\n", fa_chunks,
+               fa_acc[0], fa_acc[1], fa_acc[2], fa_acc[3], fa_acc[4], fa_acc[5], fa_acc[6]);
+#endif
 
     if (nsp > 1) {                                              // partial record [D O][m][l] of (query, head, split)
         if (q_ok) {
