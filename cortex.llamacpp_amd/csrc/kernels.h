@@ -100,6 +100,10 @@ hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *s
 // seg_types (per segment; nullptr = all `type`): Q4_K / Q5_K segments beside Q6_K ones in ONE launch where this says so (segments end on
 // 128-row tiles and the launch takes the 128 x 256 kernel)
 bool mmq_planes_mixed_ok(const int *seg_rows, int n_seg, int K, int T, MMQWorkspace wsp);
+// ffn_gate and ffn_up (one plane type, n_rows rows each) in one launch with SwiGLU in the epilogue: out[t][row] = silu(gate . x) * (up . x)
+bool mmq_planes_swiglu_ok(int type_gate, int type_up, int n_rows, int K, int T);
+hipError_t launch_mmq_planes_swiglu(int type, const uint8_t *planes_gate, const uint8_t *planes_up, int n_rows, int K, int T, const ActQuant &q,
+                                    float *out, int ld_out, hipStream_t st);
 bool mmq_ksplit_applicable(int type, int K, int T);
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st);

@@ -938,8 +938,11 @@ __device__ unsigned long long *g_p2_probe = nullptr;
 // at the start of the next super-block's first stage - each half's fold runs beside the other half's MFMAs.
 // The block-sum ("mins") term is one v_mfma_f32_32x32x16_f16 per tile: the 16 block sums (|.| <= 2032) and the 6-bit mins are
 // exact in f16 and their 16 products sum to < 2^24, so the f32 result IS the integer msum - no shift, no conversion.
-template <bool MINS>
-__device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
+// SWIGLU: `planes` = ffn_gate, `planes_up` = ffn_up (n_rows rows each, same type): a workgroup takes 64 rows of BOTH (row-waves 0, 1 the
+// gate rows, 2, 3 the same rows of up), the up waves hand their tile over through LDS at the end and the gate waves store
+// silu(gate . x) * (up . x) - one [T][n_rows] f32 result instead of two, and no separate SwiGLU pass over them
+template <bool MINS, bool SWIGLU>
+__device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_t *planes_up, int n_rows, int K, int T, int n_row_tiles, int n_tok_tiles,
                                              const int8_t *aq, const float *ad, const int16_t *absum,
                                              const PlanesOut &po, const float *resid, float *ws, int n_split, int row_tile, int tok_tile, int zz) {
     constexpr int MT = P2_MT;
@@ -951,7 +954,10 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, 
     const int sb_lo = (int)((long)nb_all * zz / n_split), nb = (int)((long)nb_all * (zz + 1) / n_split) - sb_lo;
     const int rw = wave & 3, tw = wave >> 2;
     const int n_rt32 = (n_rows + 31) >> 5;
-    const int rt32 = row_tile * 4 + rw;
+    // 32-row tile of row-wave index p (compute: p = rw; plane DMA: p = wave >> 1; row-word DMA: p = 2 (wave & 1) + kg) and its tensor
+    auto tile_of = [&](int p) { return SWIGLU ? row_tile * 2 + (p & 1) : row_tile * 4 + p; };
+    auto base_of = [&](int p) { return SWIGLU && (p >> 1) ? planes_up : planes; };
+    const int rt32 = tile_of(rw);
     const bool tile_ok = rt32 < n_rt32;
     const int row0 = rt32 * 32;
     const int tok0 = tok_tile * P2_TOK;
@@ -960,9 +966,9 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, 
     // ---- this wave's share of the DMA.  Per stage: 4 KiB of B (row tile wave / 2, K-steps 2 (wave & 1) .. + 1, both planes) and
     // 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x 32 B),
     // activation scales (waves 0-3, 64 tokens each) and the row tiles' d / dmin / mins words (waves 4, 5: two row tiles each).
-    int drt = row_tile * 4 + (wave >> 1);
+    int drt = tile_of(wave >> 1);
     if (drt >= n_rt32) drt = n_rt32 - 1;
-    const uint8_t *dma_b = planes + ((size_t)drt * nb_all + sb_lo) * PL_BLOCK + (wave & 1) * 4096 + lane * 16;
+    const uint8_t *dma_b = base_of(wave >> 1) + ((size_t)drt * nb_all + sb_lo) * PL_BLOCK + (wave & 1) * 4096 + lane * 16;
     unsigned a_off[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -976,10 +982,12 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, 
     {
         int ptok = tok0 + 64 * (wave & 3) + lane;
         if (ptok >= T) ptok = T - 1;
-        int mrt = row_tile * 4 + 2 * (wave & 1) + kg;
+        int mt0 = tile_of(2 * (wave & 1));                       // first tile of this wave's pair (SwiGLU: the pair is one tensor's)
+        if (mt0 >= n_rt32) mt0 = n_rt32 - 1;
+        int mrt = tile_of(2 * (wave & 1) + kg);
         if (mrt >= n_rt32) mrt = n_rt32 - 1;
         sb_off = wave < 4 ? ((unsigned)ptok * (unsigned)nb_all + (unsigned)sb_lo) * 4u
-                          : (unsigned)(mrt - row_tile * 4) * (unsigned)nb_all * (unsigned)PL_BLOCK + (unsigned)n * 16u;
+                          : (unsigned)(mrt - mt0) * (unsigned)nb_all * (unsigned)PL_BLOCK + (unsigned)n * 16u;
     }
     unsigned bs_off;
     {
@@ -987,7 +995,9 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, 
         if (btok >= T) btok = T - 1;
         bs_off = ((unsigned)btok * (unsigned)nb_all + (unsigned)sb_lo) * 32u + (unsigned)(lane & 1) * 16u;
     }
-    const uint8_t *meta_base = planes + ((size_t)row_tile * 4 * nb_all + sb_lo) * PL_BLOCK + 16384;
+    int mb0 = tile_of(2 * (wave & 1));
+    if (mb0 >= n_rt32) mb0 = n_rt32 - 1;
+    const uint8_t *meta_base = base_of(2 * (wave & 1)) + ((size_t)mb0 * nb_all + sb_lo) * PL_BLOCK + 16384;
     const unsigned lds0 = lds_addr32(smem);
     auto issue = [&](int s) {                                   // stage s = (super-block s >> 1, half s & 1) into buffer s & 1
         if (MI355_P2_EXP == 2) return;
@@ -1173,6 +1183,29 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, int n_rows, 
         o[6] = t4 - pr_t0;                                      // last fold
     }
 #endif
+    if (SWIGLU) {                                               // the up tile crosses to the gate wave of the same rows and tokens
+        float *exch = reinterpret_cast<float *>(smem) + (size_t)((rw & 1) * 2 + tw) * (MT * 16 * 64) + lane;   // (both buffers are idle now)
+        if (rw >= 2) {
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) exch[(t * 16 + r) * 64] = facc[t][r];
+        }
+        __syncthreads();
+        if (rw < 2 && tile_ok && row0 + n < n_rows) {
+            float *out = po.out[0];
+            const int ld_out = po.ld[0];
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int gt = tok0 + (tw * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    const float gv = facc[t][r], uv = exch[(t * 16 + r) * 64];
+                    if (gt < T) out[(size_t)gt * ld_out + row0 + n] = (gv / (1.0f + expf(-gv))) * uv;
+                }
+        }
+        return;
+    }
     if (n_split > 1) {                                          // partial sums of this K range: ws[zz][token][row], no residual
         if (tile_ok && row0 + n < n_rows) {
             float *o = ws + (size_t)zz * T * n_rows;
@@ -1231,8 +1264,20 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_kernel(const uint8_t *pl
         if (po.n_seg > 2 && row_tile * P2_ROWS >= po.row_end[1]) sg0 = 2;
         mins = (po.mins_mask >> sg0) & 1u;
     }
-    if (MODE == 1 || (MODE == 2 && mins)) planes2_body<true>(planes, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, resid, ws, n_split, row_tile, tok_tile, zz);
-    else planes2_body<false>(planes, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, resid, ws, n_split, row_tile, tok_tile, zz);
+    if (MODE == 1 || (MODE == 2 && mins)) planes2_body<true, false>(planes, nullptr, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, resid, ws, n_split, row_tile, tok_tile, zz);
+    else planes2_body<false, false>(planes, nullptr, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, resid, ws, n_split, row_tile, tok_tile, zz);
+}
+
+// ffn_gate and ffn_up with SwiGLU in the epilogue: n_rows rows of each, 64 per workgroup, out[t][row] = silu(gate) * up
+template <bool MINS>
+__global__ __launch_bounds__(NTHREADS) void mmq_planes2_swiglu_kernel(const uint8_t *planes_gate, const uint8_t *planes_up, int n_rows, int K, int T,
+                                                                      int n_row_tiles, int n_tok_tiles, const int8_t *aq, const float *ad,
+                                                                      const int16_t *absum, const PlanesOut po) {
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int tok_tile = loc % n_tok_tiles;
+    const int row_tile = (loc / n_tok_tiles) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    planes2_body<MINS, true>(planes_gate, planes_up, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, nullptr, nullptr, 1, row_tile, tok_tile, 0);
 }
 
 // out[t][row] = (resid) + ws[0][t][row] + ws[1][t][row] + ... in split order (fixed, so results do not depend on timing)
@@ -1408,6 +1453,32 @@ bool mmq_planes_mixed_ok(const int *seg_rows, int n_seg, int K, int T, MMQWorksp
     bool takes = false;
     (void)planes2_split(n_rows, K, T, wsp, &takes);
     return takes && n_seg >= 1 && n_seg <= 3;
+}
+
+// ffn_gate | ffn_up of one plane type with SwiGLU in the epilogue: 64 rows of each per workgroup
+bool mmq_planes_swiglu_ok(int type_gate, int type_up, int n_rows, int K, int T) {
+    static const bool env_on = !(getenv("MI355_MMQ_SWIGLU") && getenv("MI355_MMQ_SWIGLU")[0] == '0');
+    if (!env_on || type_gate != type_up || mmq_planes_bytes(type_gate, n_rows, K) == 0 || (n_rows % 32) != 0) return false;
+    bool takes = false;
+    (void)planes2_split(2 * n_rows, K, T, MMQWorkspace(), &takes);
+    return takes && g_mmq_mt != 4;
+}
+
+hipError_t launch_mmq_planes_swiglu(int type, const uint8_t *planes_gate, const uint8_t *planes_up, int n_rows, int K, int T, const ActQuant &q,
+                                    float *out, int ld_out, hipStream_t st) {
+    if (!mmq_planes_swiglu_ok(type, type, n_rows, K, T)) return hipErrorInvalidValue;
+    PlanesOut po{};
+    po.n_seg = 1; po.out[0] = out; po.ld[0] = ld_out; po.row_end[0] = n_rows;
+    const int nrt = (n_rows + 63) / 64, ntt = (T + P2_TOK - 1) / P2_TOK;
+    const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));
+    if (type != T_Q6_K) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_swiglu_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        hipLaunchKernelGGL((mmq_planes2_swiglu_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes_gate, planes_up, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_swiglu_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        hipLaunchKernelGGL((mmq_planes2_swiglu_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes_gate, planes_up, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *seg_rows, float *const *outs, const int *lds_out, int n_seg, int K, int T,

@@ -1130,6 +1130,18 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                         HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
                     }
                 }
+            } else if (T > 1 && !fuse_ffn && L.gate.planes && L.up.planes && L.gate.N == L.up.N && mmq_applicable(L.gate.type, E, T) &&
+                       mmq_planes_swiglu_ok(L.gate.type, L.up.type, (int)L.gate.N, E, T)) {
+                // prompt batch on the LDS kernel: gate and up in one launch, 64 rows of each per workgroup, SwiGLU in the epilogue (one
+                // f32 result of T x FF instead of two); the quantiser for the down projection then reads half as much
+                HIP_TRY(launch_mmq_planes_swiglu(L.gate.type, L.gate.planes, L.up.planes, (int)L.gate.N, E, T, aq_e_, ffn_, FF, stream_));
+                if (is_quant(L.down.type) && (FF % 256) == 0) {
+                    const bool pl = L.down.type != T_Q8_0 && T >= 3;
+                    HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_, pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+                    prep_owner_ = nullptr;
+                    if (pl) prep_written(aq_ff_, FF, T);
+                    swiglu_quantised = true;
+                }
             } else {
                 HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
