@@ -78,6 +78,9 @@ int main(int argc, char **argv) {
     unsigned long long *probe; CK(hipMalloc(&probe, 64 * 8)); CK(hipMemset(probe, 0, 64 * 8)); mmq_p2_set_probe(probe);
 #endif
     const float us4 = run(4, o_new, 1);
+#ifdef MI355_P2_PROBE
+    unsigned long long hpz[64]; CK(hipMemcpy(hpz, probe, sizeof(hpz), hipMemcpyDeviceToHost));   // (of the unsplit launch)
+#endif
     float *o_sk; CK(hipMalloc(&o_sk, (size_t)T * N * 4));
     float us_sk[5] = {0, 0, 0, 0, 0};
     for (int sp = 2; sp <= 4; sp++) us_sk[sp] = run(4, o_sk, sp);
@@ -94,7 +97,6 @@ int main(int argc, char **argv) {
     printf("N %d K %d T %d type %d: 256x32 %.1f us (%.0f TOP/s)  128x128 %.1f us (%.0f)  lds 128x256 %.1f us (%.0f)  mismatches %zu / %zu  sample %g\n",
            N, K, T, type, us1, top / us1, us2, top / us2, us4, top / us4, bad, a.size(), (double)b[12345 % b.size()]);
 #ifdef MI355_P2_PROBE
-    unsigned long long hpz[64]; CK(hipMemcpy(hpz, probe, sizeof(hpz), hipMemcpyDeviceToHost));
     { unsigned long long *tk, htk = 0; CK(hipMalloc(&tk, 8)); hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, 0, tk); CK(hipMemcpy(&htk, tk, 8, hipMemcpyDeviceToHost));
       printf("  s_memtime: %.1f ticks per us\n", htk / 100.0); }
     printf("  workgroup 0, cycles per wave over %d super-blocks:   first half: compute / dma wait / barrier   second half: compute / dma wait / barrier   last fold\n", nb);
