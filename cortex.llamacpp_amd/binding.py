@@ -88,6 +88,7 @@ SYMBOLS = {
     "mi355_debug_layer_out": (_i32, [_vp, _i32, _vp, _sz]),
     "mi355_op_quantize_act": (C.c_int, [_i32, _vp, _i64, _i64, _vp]),
     "mi355_op_mul_mat": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "mi355_op_ffn_gate_up": (C.c_int, [_i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "mi355_op_rms_norm_mul": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
     "mi355_op_rope": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _i32]),
     "mi355_op_get_rows": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _vp]),
@@ -192,6 +193,14 @@ class Backend:
             msum = np.zeros((T, N, nblk), np.int32)
         self._chk(self.lib.mi355_op_mul_mat(t, _ptr(W), N, K, _ptr(x), T, _ptr(y), _ptr(isum), _ptr(msum)), "op_mul_mat")
         return (y, isum, msum) if want_ints else y
+
+    def ffn_gate_up(self, t: int, Wg: np.ndarray, Wu: np.ndarray, N: int, K: int, x: np.ndarray) -> np.ndarray:
+        Wg = np.ascontiguousarray(Wg.view(np.uint8).reshape(-1))
+        Wu = np.ascontiguousarray(Wu.view(np.uint8).reshape(-1))
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, K)
+        y = np.zeros((x.shape[0], N), np.float32)
+        self._chk(self.lib.mi355_op_ffn_gate_up(t, _ptr(Wg), _ptr(Wu), N, K, _ptr(x), x.shape[0], _ptr(y)), "op_ffn_gate_up")
+        return y
 
     def rms_norm_mul(self, x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32)

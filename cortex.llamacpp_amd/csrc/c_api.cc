@@ -302,6 +302,29 @@ int mi355_op_quantize_act(int32_t act_type, const float *x, int64_t n, int64_t r
     return dout.down(out_blocks, ob) ? MI355_OK : MI355_ERR_HIP;
 }
 
+int mi355_op_ffn_gate_up(int32_t type, const void *Wg, const void *Wu, int64_t N, int64_t K, const float *x, int64_t T, float *y) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    const size_t grow = ggml_row_bytes(type, K), drow = dev_row_bytes(type, K);
+    const size_t pb = mmq_planes_bytes(type, N, (int)K);
+    if (!grow || K % 256 || !pb || N % 32) { fail("bad type / K / N"); return MI355_ERR_ARG; }
+    if (!mmq_planes_swiglu_ok(type, type, (int)N, (int)K, (int)T)) { fail("shape does not take the SwiGLU launch (set mmq_tiles = 4 to force it)"); return MI355_ERR_ARG; }
+    DevBuf wsrc(grow * N), wdev(drow * N), pg(pb), pu(pb), dx((size_t)K * T * 4), dy((size_t)N * T * 4);
+    ActBufs ab((size_t)K, (size_t)T);
+    if (!wsrc.p || !wdev.p || !pg.p || !pu.p || !dx.up(x, (size_t)K * T * 4) || !dy.p || !ab.ok()) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        if (!wsrc.up(i ? Wu : Wg, grow * N)) { fail("device copy failed"); return MI355_ERR_OOM; }
+        e = launch_repack_rows(type, wsrc.as<uint8_t>(), wdev.as<uint8_t>(), K, N, nullptr);
+        if (e == hipSuccess) e = launch_mmq_expand(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, (i ? pu : pg).as<uint8_t>(), nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, true, false, nullptr);
+    if (e == hipSuccess) e = launch_mmq_planes_swiglu(type, pg.as<uint8_t>(), pu.as<uint8_t>(), (int)N, (int)K, (int)T, ab.q, dy.as<float>(), (int)N, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "ffn_gate_up");
+    return dy.down(y, (size_t)N * T * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
 int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const float *x, int64_t T, float *y, int32_t *isum, int32_t *msum) {
     if (!need_device()) return MI355_ERR_NO_DEVICE;
     const size_t grow = ggml_row_bytes(type, K), drow = dev_row_bytes(type, K);

@@ -1461,7 +1461,7 @@ bool mmq_planes_swiglu_ok(int type_gate, int type_up, int n_rows, int K, int T) 
     if (!env_on || type_gate != type_up || mmq_planes_bytes(type_gate, n_rows, K) == 0 || (n_rows % 32) != 0) return false;
     bool takes = false;
     (void)planes2_split(2 * n_rows, K, T, MMQWorkspace(), &takes);
-    return takes && g_mmq_mt != 4;
+    return takes;
 }
 
 hipError_t launch_mmq_planes_swiglu(int type, const uint8_t *planes_gate, const uint8_t *planes_up, int n_rows, int K, int T, const ActQuant &q,

@@ -175,6 +175,10 @@ MI355_API int mi355_op_quantize_act(int32_t act_type, const float *x, int64_t n_
  * per (token, row, block) integer partial sums for bit-exact checks. */
 MI355_API int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const float *x, int64_t T,
                                float *y, int32_t *isum, int32_t *msum);
+/* ffn_gate and ffn_up (one K-quant type, N rows each, N % 32 == 0) against the same T activation rows with SwiGLU in the
+ * epilogue, as the prompt path launches them (mmq_planes2_swiglu_kernel): y[t][n] = silu(Wg[n] . x[t]) * (Wu[n] . x[t]).
+ * Shapes too small for that launch are refused unless the debug option "mmq_tiles" = 4 forces the kernel. */
+MI355_API int mi355_op_ffn_gate_up(int32_t type, const void *Wg, const void *Wu, int64_t N, int64_t K, const float *x, int64_t T, float *y);
 MI355_API int mi355_op_rms_norm_mul(const float *x, const float *w, int64_t n, int64_t T, float eps, float *y);
 MI355_API int mi355_op_rope(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, const int32_t *pos, int64_t T,
                             float freq_base, float freq_scale, const float *freq_factors, int32_t neox);

@@ -115,6 +115,26 @@ def test_mul_mat_prefill_both_operands_through_lds(be, t, K, N, T):
     assert np.array_equal(y, y2)
 
 
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
+@pytest.mark.parametrize("K,N,T", [(1024, 64, 40), (4096, 96, 300), (2048, 224, 513), (256, 32, 257)])
+def test_ffn_gate_up_swiglu_launch(be, t, K, N, T):
+    """ffn_gate and ffn_up in one launch of the LDS kernel, 64 rows of each per workgroup, the up tile handed to the gate waves through
+    LDS and SwiGLU in the epilogue: against silu(gate . x) * (up . x) of the oracle's mat-muls; ragged token tiles, a last workgroup
+    with 32 rows of each tensor, a single super-block."""
+    rng = np.random.default_rng(3 * K + N + T + t)
+    Wg, Wu = rand_weights(rng, t, N * K), rand_weights(rng, t, N * K)
+    x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 2.0, (T, 1))).astype(np.float32)
+    be.set_option("mmq_tiles", 4)
+    try:
+        y = be.ffn_gate_up(t, Wg, Wu, N, K, x)
+    finally:
+        be.set_option("mmq_tiles", 0)
+    g, u = oq.mul_mat(t, Wg, N, K, x), oq.mul_mat(t, Wu, N, K, x)
+    with np.errstate(over="ignore"):                           # exp(-g) may overflow to inf: g / inf = 0, as on the device
+        ref = (g / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32) * u
+    assert np.abs(y - ref).max() <= 4e-5 * np.abs(ref).max() + 1e-6
+
+
 @pytest.mark.parametrize("t", [Q4_K, Q6_K])
 @pytest.mark.parametrize("K,N,T,split", [(4096, 300, 129, 2), (2048, 128, 256, 3), (14336, 40, 300, 4), (1024, 260, 513, 4), (256, 36, 140, 4)])
 def test_mul_mat_prefill_split_k(be, t, K, N, T, split):
