@@ -103,6 +103,12 @@ template <> struct RowSB<T_Q4_K> {
         sc_hi = (h.w & 0x0f0f0f0f) | ((h.y >> 2) & 0x30303030);
         mn_hi = ((h.w >> 4) & 0x0f0f0f0f) | ((h.z >> 2) & 0x30303030);
     }
+    // the raw codes of group J (one per byte): the B operand of the group-scale form (scale applied to the MFMA result)
+    template <int J> __device__ __forceinline__ i32x4 codes() const {
+        const u32x4 v = (J >> 1) == 0 ? q0 : (J >> 1) == 1 ? q1 : (J >> 1) == 2 ? q2 : q3;
+        constexpr int sh = (J & 1) * 4;
+        return i32x4{(int)((v.x >> sh) & 0x0f0f0f0f), (int)((v.y >> sh) & 0x0f0f0f0f), (int)((v.z >> sh) & 0x0f0f0f0f), (int)((v.w >> sh) & 0x0f0f0f0f)};
+    }
     template <int J> __device__ __forceinline__ void bop(uint32_t sc, i32x4 &bh, i32x4 &bl) const {
         const u32x4 v = (J >> 1) == 0 ? q0 : (J >> 1) == 1 ? q1 : (J >> 1) == 2 ? q2 : q3;
         constexpr int sh = (J & 1) * 4;
@@ -129,6 +135,13 @@ template <> struct RowSB<T_Q5_K> {
         sc_lo = h.y & 0x3f3f3f3f; mn_lo = h.z & 0x3f3f3f3f;
         sc_hi = (h.w & 0x0f0f0f0f) | ((h.y >> 2) & 0x30303030);
         mn_hi = ((h.w >> 4) & 0x0f0f0f0f) | ((h.z >> 2) & 0x30303030);
+    }
+    template <int J> __device__ __forceinline__ i32x4 codes() const {
+        const u32x4 v = (J >> 1) == 0 ? q0 : (J >> 1) == 1 ? q1 : (J >> 1) == 2 ? q2 : q3;
+        constexpr int sh = (J & 1) * 4;
+#define Q5C(vv, hh) (int)((((vv) >> sh) & 0x0f0f0f0f) | ((((hh) >> J) & 0x01010101u) << 4))
+        return i32x4{Q5C(v.x, qh.x), Q5C(v.y, qh.y), Q5C(v.z, qh.z), Q5C(v.w, qh.w)};
+#undef Q5C
     }
     template <int J> __device__ __forceinline__ void bop(uint32_t sc, i32x4 &bh, i32x4 &bl) const {
         const u32x4 v = (J >> 1) == 0 ? q0 : (J >> 1) == 1 ? q1 : (J >> 1) == 2 ? q2 : q3;
@@ -470,6 +483,59 @@ __device__ __forceinline__ void ksplit_superblock(const RowSB<TYPE> &R, const in
     }
 }
 
+// The same super-block for one token tile (T <= 32) in the GROUP-SCALE form: a K-step of the MFMA is exactly one 32-weight group of Q4_K /
+// Q5_K, so the raw 4- / 5-bit codes go in as the B operand (two VALU instructions per 8 weights instead of ~10 for the two scaled planes),
+// ONE MFMA per K-step yields sum_k q_k a_k of the group, and the 6-bit group scale is applied to the 16 results per lane with one
+// v_mad_i32_i24 each.  With a single token tile the expansion per weight dominated the planes form (4 VALU cycles per MFMA cycle); this
+// form trades the second MFMA chain for 16 multiply-adds.  The integer isum is the same number, so everything downstream is unchanged.
+template <int TYPE>
+__device__ __forceinline__ void ksplit_superblock_gs(const RowSB<TYPE> &R, const int8_t *s_aq, const int8_t *s_bh, const int8_t *s_bl, const float *s_yd,
+                                                     int n, int kg, float (&facc)[1][16]) {
+    const int8_t *abase = s_aq + n * A_STRIDE + 16 * kg;
+    uint32_t sc_lo = 0, sc_hi = 0, mn_lo = 0, mn_hi = 0;
+    R.scales(sc_lo, sc_hi, mn_lo, mn_hi);
+    int isum[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) isum[r] = 0;
+    i32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0;
+#define GSTEP(J)                                                                                              \
+    {                                                                                                         \
+        const i32x16 I = mfma_i8(*reinterpret_cast<const i32x4 *>(abase + 32 * J), R.template codes<J>(), z); \
+        const int sc = (int)(((J < 4 ? sc_lo : sc_hi) >> (8 * (J & 3))) & 0xff);                              \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) { isum[r] = __mul24(I[r], sc) + isum[r]; asm volatile("" : "+v"(isum[r])); } \
+        __builtin_amdgcn_sched_barrier(0);   /* (LLVM reassociates the eight-term integer sums otherwise: all eight MFMA results live, 217 registers) */ \
+    }
+    GSTEP(0) GSTEP(1) GSTEP(2) GSTEP(3) GSTEP(4) GSTEP(5) GSTEP(6) GSTEP(7)
+#undef GSTEP
+    const float dd = R.d(), dm = R.dmin();
+    i32x4 bm = {0, 0, 0, 0};
+    if (kg == 0) {
+        bm.x = (int)perm(0, mn_lo, 0x01010000u); bm.y = (int)perm(0, mn_lo, 0x03030202u);
+        bm.z = (int)perm(0, mn_hi, 0x01010000u); bm.w = (int)perm(0, mn_hi, 0x03030202u);
+    }
+    i32x4 ah = {0, 0, 0, 0}, al = {0, 0, 0, 0};
+    if (kg == 0) {
+        ah = *reinterpret_cast<const i32x4 *>(s_bh + n * 16);
+        al = *reinterpret_cast<const i32x4 *>(s_bl + n * 16);
+    }
+    i32x16 ms = mfma_i8(ah, bm, z);
+#pragma unroll
+    for (int r = 0; r < 16; r++) ms[r] <<= 6;
+    ms = mfma_i8(al, bm, ms);
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+        const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + 8 * rq + 4 * kg);
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++) {
+            const int r = rq * 4 + ri;
+            const float yd = yd4[ri];
+            facc[0][r] += (dd * yd) * (float)isum[r] - (dm * yd) * (float)ms[r];
+        }
+    }
+}
+
 template <int TYPE, int MT, bool SWIGLU>
 __device__ __forceinline__ void ksplit_body(const KSplitArgs &a, const MMQSeg &sg, int row_tile, uint8_t *smem) {
     constexpr int TOK = 32 * MT;
@@ -535,11 +601,18 @@ __device__ __forceinline__ void ksplit_body(const KSplitArgs &a, const MMQSeg &s
             }
             __builtin_amdgcn_wave_barrier();
         }
-        ksplit_superblock<TYPE, MT>(R, s_aq, s_bh, s_bl, s_yd, n, kg, facc);
+#ifndef MI355_KSPLIT_TWO_PLANES                                  // (tools: the two-plane form for one token tile too, for comparison)
+        constexpr bool GS_FORM = MT == 1 && TYPE != T_Q6_K;   // (Q6_K: 16-weight groups, a K-step spans two)
+#else
+        constexpr bool GS_FORM = false;
+#endif
+        if constexpr (GS_FORM) ksplit_superblock_gs<TYPE>(R, s_aq, s_bh, s_bl, s_yd, n, kg, facc);
+        else ksplit_superblock<TYPE, MT>(R, s_aq, s_bh, s_bl, s_yd, n, kg, facc);
         if constexpr (SWIGLU) {                                 // the up row of the pair against the same tile
             RowSB<TYPE> R2;
             R2.load(rowp2, nb, sb, kg);
-            ksplit_superblock<TYPE, MT>(R2, s_aq, s_bh, s_bl, s_yd, n, kg, facc2);
+            if constexpr (GS_FORM) ksplit_superblock_gs<TYPE>(R2, s_aq, s_bh, s_bl, s_yd, n, kg, facc2);
+            else ksplit_superblock<TYPE, MT>(R2, s_aq, s_bh, s_bl, s_yd, n, kg, facc2);
         }
     }
     // ---- sum the eight waves' partial tiles in wave order (deterministic), then store
