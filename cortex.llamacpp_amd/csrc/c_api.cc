@@ -359,9 +359,11 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
                 DevBuf pl(mmq_planes_bytes(type, N, (int)K));
                 if (!pl.p) return MI355_ERR_OOM;
                 if (e == hipSuccess) e = launch_mmq_expand(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, pl.as<uint8_t>(), nullptr);
-                DevBuf wsb((size_t)4 * T * N * sizeof(float));      // K-split partial sums (tensors with few rows)
+                // K-split partial sums: only tensors with few rows split (a large N x T never does, and gets no workspace)
+                const size_t ws_bytes = (size_t)4 * T * N * sizeof(float) <= ((size_t)256 << 20) ? (size_t)4 * T * N * sizeof(float) : 0;
+                DevBuf wsb(ws_bytes ? ws_bytes : 16);
                 if (!wsb.p) return MI355_ERR_OOM;
-                MMQWorkspace wsp; wsp.p = wsb.as<float>(); wsp.bytes = (size_t)4 * T * N * sizeof(float);
+                MMQWorkspace wsp; wsp.p = ws_bytes ? wsb.as<float>() : nullptr; wsp.bytes = ws_bytes;
                 if (e == hipSuccess) e = launch_mmq_planes(type, pl.as<uint8_t>(), (int)N, (int)K, (int)T, ab.q, bh.as<int8_t>(), bl.as<int8_t>(), dy.as<float>(), (int)N, nullptr, nullptr, wsp);
                 if (e == hipSuccess) e = hipDeviceSynchronize();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
