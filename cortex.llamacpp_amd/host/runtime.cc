@@ -967,7 +967,10 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
             prof_mark("rope_kv");
             aa.splits = att_splits_;
-            aa.pf_splits = flash_attn_prefill_splits(T, H, G, D, n_kv_max);
+            // (splits balance the causal tiles of ONE long sequence: sized by what a query of this batch can see - its position + 1 -
+            // not by the cache's high-water mark: 32 sequences of 50-token prompts in a 32000-cell cache need none, and every
+            // extra workgroup would scan the whole cell table)
+            aa.pf_splits = flash_attn_prefill_splits(T, H, G, D, std::min(n_kv_max, cur_max_pos_ + 1));
             while (aa.pf_splits > 1 && flash_attn_workspace_floats(T, H, D, aa.pf_splits) > att_part_floats_) aa.pf_splits >>= 1;
             HIP_TRY(launch_flash_attn(aa, stream_));
         }
@@ -1246,6 +1249,8 @@ hipError_t Context::run_output(int n_out, int out_base) {
 
 int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
                            const int8_t *flags, int out_base) {
+    cur_max_pos_ = 0;
+    for (int i = 0; i < n; i++) cur_max_pos_ = std::max(cur_max_pos_, (int)pos[i]);
     std::vector<int> tcell;
     if (!alloc_cells(n, seqmask, tcell)) return 1;
     for (int i = 0; i < n; i++) {

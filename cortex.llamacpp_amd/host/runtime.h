@@ -193,6 +193,7 @@ class Context {
     void prep_written(const ActQuant &aq, int K, int T) { prep_owner_ = aq.qs; prep_K_ = K; prep_T_ = T; }
     float *att_part_ = nullptr;
     size_t att_part_floats_ = 0;
+    int cur_max_pos_ = 0;                            // largest position of the micro-batch being decoded
     float *d_embd_ = nullptr, *h_embd_ = nullptr;   // [n_ubatch][n_embd], embeddings mode
     bool embd_fetched_ = false, last_was_embd_ = false;
     // batched single-token steps: per-token lists of the 64-cell chunks that hold cells of the token's sequence
