@@ -488,14 +488,15 @@ bool flash_attn_prefill_applicable(const AttnArgs &a) {
 // Key splits of a prompt batch.  Two things pull: the causal tiles are 1 .. n_chunks long, so a few splits balance the workgroups
 // (512 tokens: 128 (kv head, tile) pairs on 512 workgroup slots, the last 16x as long as the first - 4 splits took 3.1 -> 2.0 ms);
 // but every split leaves a (D + 2)-float record per query and head that the merge reads back (2048 tokens x 8 splits: 272 MB, a
-// 110 us merge per layer beside a 327 us kernel).  So: as many splits as fill ~512 workgroups, at least 2 once a tile is 8 chunks
-// long, never more than a quarter of the chunks, at most 8, and a workspace of at most 512 MiB.
+// 110 us merge per layer beside a 327 us kernel).  So: as many splits as fill ~512 workgroups (measured, 8B model: 512 tokens 4 splits
+// 1.76 ms of attention per prompt against 1.80 with 2 and 2.07 with 6; 2048 tokens NO split 7.1 ms against 8.8 with 2 - the 512
+// (kv head, tile) pairs fill the chip by themselves and the merge costs more than the imbalance), never more than a quarter of the
+// chunks, at most 8, and a workspace of at most 512 MiB.
 int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max) {
     static const int env = getenv("MI355_ATTN_PREFILL_SPLITS") ? atoi(getenv("MI355_ATTN_PREFILL_SPLITS")) : 0;
     const int n_chunks = (n_kv_max + CK - 1) / CK, tiles = (T + QT - 1) / QT;
     const int pairs = (G > 0 ? G : 1) * tiles;
     int s = (512 + pairs - 1) / pairs;
-    if (n_chunks >= 8 && s < 2) s = 2;
     if (s > n_chunks / 4) s = n_chunks / 4;
     if (s > 8) s = 8;
     if (env > 0) s = env;
