@@ -1428,7 +1428,9 @@ void mmq_p2_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 // continuous-batching decode steps and prompts up to a few hundred tokens: 3 <= T <= g_ksplit_max.  This kernel reads the GGUF
 // bytes (0.56 B / weight) and expands them in registers, the planes kernel reads 2 B / weight it need not expand: measured on the
 // 8B model the whole prompt takes 8.3 vs 13.7 ms at 128 tokens, 13.6 vs 16.7 at 256, 19.4 vs 21.0 at 384 and 22.7 vs 21.1 at 448
-static int g_ksplit_max = getenv("MI355_KSPLIT_MAX") ? atoi(getenv("MI355_KSPLIT_MAX")) : 384;
+// (round 2: the LDS-form planes kernel moved the crossover down - whole prompt, K-split against planes: 13.8 vs 14.1 ms at 256 tokens,
+// 17.2 vs 15.2 at 320, 19.1 vs 15.5 at 384)
+static int g_ksplit_max = getenv("MI355_KSPLIT_MAX") ? atoi(getenv("MI355_KSPLIT_MAX")) : 256;
 bool mmq_ksplit_applicable(int type, int K, int T) {
     // from 3 tokens: the mat-vec takes 4 + 2 + 1 tokens per pass over the weights, so 3 sequences cost 4.5 ms and 6 cost 6.4 ms a step against
     // 3.7 ms through this kernel; for 2 the mat-vec pass is cheaper (3.2 ms)
