@@ -249,6 +249,33 @@ def test_prompt_lds_kernel_matches_per_lane_kernels(be, pkg, tmp_models, ftype):
     m.close()
 
 
+def test_prompt_path_is_deterministic_across_micro_batches(be, pkg, tmp_models):
+    """A 700-token prompt in micro-batches of 512 (the second one attends to the first one's cells): the default path - K split
+    with its fixed-order reduction, attention key splits merged in split order - gives the same bits twice, and the unsplit LDS
+    form equals the per-lane kernels bit for bit there too.  (tools/stress_prefill.py runs the same check over random lengths.)"""
+    path = make(pkg, tmp_models, "tiny-8b-2l", "q4_k_m")
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(10).integers(0, m.n_vocab, 700)
+
+    def run(lds, split):
+        be.set_option("mmq_lds_form", lds)
+        be.set_option("mmq_split", split)
+        try:
+            c = pkg.Context(m, n_ctx=1024, n_batch=2048, n_ubatch=512, type_k=8, type_v=8)
+            assert c.decode(prompt, np.arange(700)) == 0
+            out = c.logits().copy()
+            c.close()
+        finally:
+            be.set_option("mmq_lds_form", -1)
+            be.set_option("mmq_split", 0)
+        return out
+
+    a, b = run(-1, 0), run(-1, 0)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.array_equal(run(1, 1), run(0, 0))
+    m.close()
+
+
 @pytest.mark.parametrize("cfg", ["tiny-gqa4", "tiny-d128", "tiny-g8"])
 def test_graph_and_eager_agree_bitwise(be, pkg, tmp_models, cfg):
     path = make(pkg, tmp_models, cfg, "q4_k_m")
