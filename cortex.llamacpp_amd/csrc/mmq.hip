@@ -1035,6 +1035,9 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
     const int row0 = rt32 * 32;
     const int tok0 = tok_tile * P2_TOK;
     const int n = lane & 31, kg = lane >> 5;
+    // a token half (128 tokens) past the end of the batch - 320 tokens leave the second workgroup tile 64 of 256 - keeps the DMA and
+    // barrier protocol and skips its MFMAs and folds: the other half then has the matrix cores to itself
+    const bool idle_half = tok0 + tw * 128 >= T;                // (wave-uniform)
 
     // ---- this wave's share of the DMA.  Per stage: 4 KiB of B (row tile wave / 2, K-steps 2 (wave & 1) .. + 1, both planes) and
     // 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x 32 B),
@@ -1220,6 +1223,15 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
     issue(0);
     issue_sb(0);
     stage_end();
+    if (idle_half) {
+        for (int sb = 0; sb < nb; sb++) {
+            issue(2 * sb + 1);
+            convert_bs(sb);
+            stage_end();
+            if (sb + 1 < nb) { issue(2 * sb + 2); issue_sb(sb + 1); }
+            stage_end();
+        }
+    } else
     for (int sb = 0; sb < nb; sb++) {
         // ---- first half (buffer 0).  The block sums of sb (landed with the barrier just passed) become f16 here, one barrier
         // ahead of their first use; waves 4-7 fold super-block sb - 1 before they overwrite its accumulators.
