@@ -1039,57 +1039,60 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
     // barrier protocol and skips its MFMAs and folds: the other half then has the matrix cores to itself
     const bool idle_half = tok0 + tw * 128 >= T;                // (wave-uniform)
 
-    // ---- this wave's share of the DMA.  Per stage: 4 KiB of B (row tile wave / 2, K-steps 2 (wave & 1) .. + 1, both planes) and
-    // 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x 32 B),
-    // activation scales (waves 0-3, 64 tokens each) and the row tiles' d / dmin / mins words (waves 4, 5: two row tiles each).
-    int drt = tile_of(wave >> 1);
-    if (drt >= n_rt32) drt = n_rt32 - 1;
-    const uint8_t *dma_b = base_of(wave >> 1) + ((size_t)drt * nb_all + sb_lo) * PL_BLOCK + (wave & 1) * 4096 + lane * 16;
-    unsigned a_off[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int tk = 8 * (4 * wave + k) + (lane >> 3);
-        int gt = tok0 + tk;
-        if (gt >= T) gt = T - 1;
-        const int piece = (lane & 7) ^ ((tk >> 1) & 7);
-        a_off[k] = (unsigned)gt * (unsigned)K + (unsigned)sb_lo * 256u + (unsigned)piece * 16u;
-    }
-    unsigned sb_off;                                            // yd (waves 0-3) or meta (waves 4, 5) source offset
-    {
-        int ptok = tok0 + 64 * (wave & 3) + lane;
-        if (ptok >= T) ptok = T - 1;
-        int mt0 = tile_of(2 * (wave & 1));                       // first tile of this wave's pair (SwiGLU: the pair is one tensor's)
-        if (mt0 >= n_rt32) mt0 = n_rt32 - 1;
-        int mrt = tile_of(2 * (wave & 1) + kg);
-        if (mrt >= n_rt32) mrt = n_rt32 - 1;
-        sb_off = wave < 4 ? ((unsigned)ptok * (unsigned)nb_all + (unsigned)sb_lo) * 4u
-                          : (unsigned)(mrt - mt0) * (unsigned)nb_all * (unsigned)PL_BLOCK + (unsigned)n * 16u;
-    }
-    unsigned bs_off;
-    {
-        int btok = tok0 + 32 * wave + (lane >> 1);
-        if (btok >= T) btok = T - 1;
-        bs_off = ((unsigned)btok * (unsigned)nb_all + (unsigned)sb_lo) * 32u + (unsigned)(lane & 1) * 16u;
-    }
-    int mb0 = tile_of(2 * (wave & 1));
-    if (mb0 >= n_rt32) mb0 = n_rt32 - 1;
-    const uint8_t *meta_base = base_of(2 * (wave & 1)) + ((size_t)mb0 * nb_all + sb_lo) * PL_BLOCK + 16384;
+    // ---- the DMA, in shares of a "virtual wave" vw = 0..7.  Per stage: 4 KiB of B (row tile vw / 2, K-steps 2 (vw & 1) .. + 1, both
+    // planes) and 4 KiB of A (32 tokens x 128 B, eight tokens per instruction).  Per super-block: 1 KiB of block sums (32 tokens x
+    // 32 B), activation scales (vw 0-3, 64 tokens each) and the row tiles' d / dmin / mins words (vw 4, 5: two row tiles each).
+    // Addresses are formed when a share is issued (a dozen VALU instructions) instead of living in eight registers, and WHO issues
+    // follows the schedule below: an LDS-DMA instruction costs its wave ~100 cycles of issue in a busy phase, so a stage's 64 + 14
+    // instructions go to the token half that is NOT folding in that stage (it waits at the barrier for the folding half anyway), or to
+    // the half that has no tokens at all.
     const unsigned lds0 = lds_addr32(smem);
-    auto issue = [&](int s) {                                   // stage s = (super-block s >> 1, half s & 1) into buffer s & 1
+    auto issue_v = [&](int s, int vw) {                         // stage s = (super-block s >> 1, half s & 1) into buffer s & 1
         if (MI355_P2_EXP == 2) return;
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));                          // (formed here, every time: hoisted out of the loop the offsets would cost 20 registers)
         const unsigned buf = lds0 + (unsigned)(s & 1) * P2_BUF;
-        dma_4k(dma_b + (size_t)(s >> 1) * PL_BLOCK + (s & 1) * 8192, buf + (unsigned)wave * 4096u);
+        int drt = tile_of(vw >> 1);
+        if (drt >= n_rt32) drt = n_rt32 - 1;
+        const uint8_t *gb = base_of(vw >> 1) + ((size_t)drt * nb_all + sb_lo + (s >> 1)) * PL_BLOCK + (vw & 1) * 4096 + (s & 1) * 8192;
+        dma_4k(gb + lane * 16, buf + (unsigned)vw * 4096u);
         const int8_t *ga = aq + (size_t)s * 128;
 #pragma unroll
-        for (int k = 0; k < 4; k++) dma16_s(ga, a_off[k], buf + P2_A + (unsigned)(4 * wave + k) * 1024u);
+        for (int k = 0; k < 4; k++) {
+            const int tk = 8 * (4 * vw + k) + (lane >> 3);
+            int gt = tok0 + tk;
+            if (gt >= T) gt = T - 1;
+            const int piece = (lane & 7) ^ ((tk >> 1) & 7);
+            dma16_s(ga, (unsigned)gt * (unsigned)K + (unsigned)sb_lo * 256u + (unsigned)piece * 16u, buf + P2_A + (unsigned)(4 * vw + k) * 1024u);
+        }
     };
-    auto issue_sb = [&](int sb) {                               // per-super-block words into parity sb & 1
+    auto issue_sb_v = [&](int sb, int vw) {                     // per-super-block words into parity sb & 1
         if (MI355_P2_EXP == 2) return;
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int n = lane & 31, kg = lane >> 5;
         const unsigned par = lds0 + 2 * P2_BUF + (unsigned)(sb & 1) * P2_SBARR;
-        if (MINS) dma16_s(absum + (size_t)sb * 16, bs_off, par + P2_BS + (unsigned)wave * 1024u);
-        if (wave < 4) dma4_s(ad + sb, sb_off, par + P2_YD + (unsigned)wave * 256u);
-        else if (wave < 6) dma16_s(meta_base + (size_t)sb * PL_BLOCK, sb_off, par + P2_META + (unsigned)(wave - 4) * 1024u);
+        if (MINS) {
+            int btok = tok0 + 32 * vw + (lane >> 1);
+            if (btok >= T) btok = T - 1;
+            dma16_s(absum + (size_t)sb * 16, ((unsigned)btok * (unsigned)nb_all + (unsigned)sb_lo) * 32u + (unsigned)(lane & 1) * 16u, par + P2_BS + (unsigned)vw * 1024u);
+        }
+        if (vw < 4) {
+            int ptok = tok0 + 64 * vw + lane;
+            if (ptok >= T) ptok = T - 1;
+            dma4_s(ad + sb, ((unsigned)ptok * (unsigned)nb_all + (unsigned)sb_lo) * 4u, par + P2_YD + (unsigned)vw * 256u);
+        } else if (vw < 6) {
+            const int p0 = 2 * (vw & 1);                         // first tile of this share's pair (SwiGLU: the pair is one tensor's)
+            int mb0 = tile_of(p0), mrt = tile_of(p0 + kg);
+            if (mb0 >= n_rt32) mb0 = n_rt32 - 1;
+            if (mrt >= n_rt32) mrt = n_rt32 - 1;
+            const uint8_t *mb = base_of(p0) + ((size_t)mb0 * nb_all + sb_lo + sb) * PL_BLOCK + 16384;
+            dma16_s(mb, (unsigned)(mrt - mb0) * (unsigned)nb_all * (unsigned)PL_BLOCK + (unsigned)n * 16u, par + P2_META + (unsigned)(vw - 4) * 1024u);
+        }
     };
+    // the issuing half of a stage takes two shares per wave
+    auto issue = [&](int s, int issuer_tw) { if (tw == issuer_tw) { issue_v(s, rw); issue_v(s, rw + 4); } };
+    auto issue_sb = [&](int sb, int issuer_tw) { if (tw == issuer_tw) { issue_sb_v(sb, rw); issue_sb_v(sb, rw + 4); } };
     auto convert_bs = [&](int sb) {                             // int16 block sums -> f16, in place (16 B per thread)
         if (!MINS) return;
         uint8_t *q = smem + 2 * P2_BUF + (sb & 1) * P2_SBARR + P2_BS + tid * 16;
@@ -1220,15 +1223,18 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
         }
     };
 
-    issue(0);
-    issue_sb(0);
+    issue_v(0, wave);
+    issue_sb_v(0, wave);
     stage_end();
+    // first-half stages: waves 4-7 fold there, so waves 0-3 issue - unless waves 4-7 have no tokens and nothing else to do;
+    // second-half stages: waves 0-3 fold, waves 4-7 issue
+    const int issuer0 = (tok0 + 128 >= T) ? 1 : 0, issuer1 = 1;
     if (idle_half) {
         for (int sb = 0; sb < nb; sb++) {
-            issue(2 * sb + 1);
+            issue(2 * sb + 1, issuer0);
             convert_bs(sb);
             stage_end();
-            if (sb + 1 < nb) { issue(2 * sb + 2); issue_sb(sb + 1); }
+            if (sb + 1 < nb) { issue(2 * sb + 2, issuer1); issue_sb(sb + 1, issuer1); }
             stage_end();
         }
     } else
@@ -1238,7 +1244,7 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
 #ifdef MI355_P2_PROBE
         pr_kind = 0;
 #endif
-        issue(2 * sb + 1);
+        issue(2 * sb + 1, issuer0);
         convert_bs(sb);
         if (tw == 1 && sb > 0) fold_all((sb - 1) & 1);
         mma_stage(0, true);
@@ -1248,7 +1254,7 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
 #ifdef MI355_P2_PROBE
         pr_kind = 1;
 #endif
-        if (sb + 1 < nb) { issue(2 * sb + 2); issue_sb(sb + 1); }
+        if (sb + 1 < nb) { issue(2 * sb + 2, issuer1); issue_sb(sb + 1, issuer1); }
         mma_stage(1, false);
         if (tw == 0 || sb + 1 == nb) fold_all(sb & 1);
         stage_end();
