@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void flash_attn_split_kernel(const AttnArgs a)
 //  3. wave 0 re-reads the 256 merged values from LDS (4 per lane) and, when asked, quantises them for the attn_output
 //     mat-vec (saves a launch on the decode path).
 __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *part, float *out, int H, int D, int splits,
-                                                                 ActQuant q, int want_q8k, int want_q80, const int32_t *tok_nsplits) {
+                                                                 ActQuant q, int want_q8k, int want_q80, const int32_t *tok_nsplits, int8_t *bh, int8_t *bl) {
     extern __shared__ float wgt[];                 // [hpb][splits]
     __shared__ __attribute__((aligned(16))) float merged[256];
     const int t = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -496,7 +496,11 @@ __global__ __launch_bounds__(256) void flash_attn_combine_kernel(const float *pa
             uint32_t packed; int bs; float dq;
             wave_quant_q8k(vv, lane, packed, bs, dq);
             *reinterpret_cast<uint32_t *>(q.qs + (size_t)t * E + e0) = packed;
-            if ((lane & 3) == 0) q.bsums[(size_t)t * (E >> 4) + b * 16 + (lane >> 2)] = (int16_t)bs;
+            if ((lane & 3) == 0) {
+                const size_t bi = (size_t)t * (E >> 4) + b * 16 + (lane >> 2);
+                q.bsums[bi] = (int16_t)bs;
+                if (bh) { const int hi = bs >> 6; bh[bi] = (int8_t)hi; bl[bi] = (int8_t)(bs - 64 * hi); }   // mmq_prep_kernel's split, for the MFMA kernels
+            }
             if (lane == 0) q.d[(size_t)t * nblk + b] = dq;
         }
         if (want_q80) {
@@ -601,7 +605,7 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
-                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), a.tok_nchunks);
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), a.tok_nchunks, a.out_q ? a.out_bh : nullptr, a.out_q ? a.out_bl : nullptr);
     return hipGetLastError();
 }
 
@@ -680,7 +684,7 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     if (e != hipSuccess || counters) return e;
     const int nblk = (a.H * a.D) >> 8;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, 1), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
-                       fz.q, fz.want_q8k, fz.want_q80, (const int32_t *)nullptr);
+                       fz.q, fz.want_q8k, fz.want_q80, (const int32_t *)nullptr, (int8_t *)nullptr, (int8_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -692,7 +696,7 @@ hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t 
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * splits * 4, st, a.part, a.out, a.H, a.D, splits,
-                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), (const int32_t *)nullptr);
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), (const int32_t *)nullptr, a.out_q ? a.out_bh : nullptr, a.out_q ? a.out_bl : nullptr);
     return hipGetLastError();
 }
 
@@ -736,7 +740,7 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * a.splits * 4, st, a.part, a.out, a.H, a.D, a.splits,
-                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), a.tok_nchunks);
+                       qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), a.tok_nchunks, a.out_q ? a.out_bh : nullptr, a.out_q ? a.out_bl : nullptr);
     return hipGetLastError();
 }
 

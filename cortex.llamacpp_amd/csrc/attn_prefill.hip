@@ -523,7 +523,7 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (nsp > 1) return launch_flash_attn_combine(a, nsp, st);      // merges the splits and quantises the rows when asked
-    if (a.out_q) e = launch_quantize(a.out, a.H * a.D, a.T, *a.out_q, a.out_q8k, a.out_q80, st);
+    if (a.out_q) e = launch_quantize(a.out, a.H * a.D, a.T, *a.out_q, a.out_q8k, a.out_q80, st, a.out_bh, a.out_bl);
     return e;
 }
 

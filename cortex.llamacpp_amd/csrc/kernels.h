@@ -212,6 +212,7 @@ struct AttnArgs {
     int chunk_stride = 0;
     const ActQuant *out_q;     // nullable: also quantise the merged rows (for attn_output)
     bool out_q8k, out_q80;
+    int8_t *out_bh = nullptr, *out_bl = nullptr;   // nullable (with out_q, Q8_K): the block sums also as the int8 planes the MFMA kernels take (launch_mmq_prep's)
 };
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
 // prompt processing on the matrix cores (attn_prefill.hip): D = 128, q8_0 K / V, T >= 32; q already rotated

@@ -947,6 +947,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_;
         const bool o_q = is_quant(L.wo.type);
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
+        const bool o_pl = o_q && aa.out_q8k && T >= 3;         // the batched kernels will want the block-sum planes: the merge writes them too
+        if (o_pl) { aa.out_bh = mmq_bh_; aa.out_bl = mmq_bl_; }
         if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
             if (chunk_lmax_ > 0) {                             // per-token chunk lists (decode_ubatch): batched steps, or regions in use
@@ -975,7 +977,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_flash_attn(aa, stream_));
         }
         prof_mark("attn");
-        if (prep_owner_ == aq_o_.qs) prep_owner_ = nullptr;   // the attention just re-quantised its output
+        if (o_pl) prep_written(aq_o_, (int)L.wo.K, T);          // the attention just re-quantised its output, planes included
+        else if (prep_owner_ == aq_o_.qs) prep_owner_ = nullptr;
         if (tp) {   // this rank's partial sum (rank 0 carries the residual), then the exchange: x = sum over ranks
             HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, T, tp_part_, E, hp.tp_rank == 0 ? x_ : nullptr, hp.tp_rank == 0 ? EPI_ADD : EPI_STORE));
             HIP_TRY(tp_reduce_into_x(T));
