@@ -23,6 +23,7 @@
 // vec_dot_f16 against the K row, so S^T = K . Q^T is eight v_mfma_f32_32x32x16_f16 per chunk (K rows as halfs in LDS, Q as
 // halfs in registers, f32 accumulation, no block scales); V rows are already f16, so the hi plane IS V and the lo plane
 // (and its product) disappear: O^T += V^T . (Ph + Pl)^T.  Everything else — visibility, online softmax, staging order — is shared.
+#include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
 #include "quant_dev.h"
@@ -62,8 +63,12 @@ __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 
 #else
 #define FA_T(i) do { } while (0)
 #endif
-template <int R, bool F16>
-__global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_kernel(const AttnArgs a) {
+// KH = key halves inside the workgroup (R <= 4: two): waves [0, R) walk the even chunks of the workgroup's run, waves [R, 2R) the odd ones,
+// each half staging its own chunk buffer with its own 64 R threads; at the end the second half hands its (O, m, l) over through LDS and
+// the first one merges them as two softmax partials.  A causal tile's chunk walk - the longest workgroups of a prompt - takes half
+// the iterations, and with the long tiles dispatched first the short ones fill the slots they leave: no records, no second launch.
+template <int R, bool F16, int KH>
+__global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(const AttnArgs a) {
 #ifdef MI355_FA_PROBE
     unsigned long long fa_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fa_t = __builtin_readcyclecounter();
     int fa_chunks = 0;
@@ -71,24 +76,32 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KS = F16 ? KF_STRIDE : K_STRIDE;    // bytes per staged K row
     constexpr int PPK = F16 ? 16 : 8;                 // 16-byte pieces per K / V row
+    constexpr int CHUNK_LDS = CK * KS + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;   // one staged chunk (launcher: one per half)
+    static_assert(CHUNK_LDS % 16 == 0, "chunk buffers stay 16-byte aligned");
+    constexpr int NT = 64 * R;                        // threads of one half: the staging roles below are per half
+    const int tid_all = threadIdx.x, lane = tid_all & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
+    const int half = wave_all / R, wave = wave_all - half * R;     // wave: the head of the kv group this wave owns
+    const int tid = tid_all - half * NT;
     Chunk S;
-    S.k = reinterpret_cast<int8_t *>(smem);
-    S.dk = reinterpret_cast<float *>(smem + CK * KS);
-    S.vh = reinterpret_cast<_Float16 *>(smem + CK * KS + NB * CK * 4);
-    S.vl = S.vh + 4 * 2 * 2 * 32 * 8;
-    S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
-    S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
+    {
+        uint8_t *base = smem + half * CHUNK_LDS;
+        S.k = reinterpret_cast<int8_t *>(base);
+        S.dk = reinterpret_cast<float *>(base + CK * KS);
+        S.vh = reinterpret_cast<_Float16 *>(base + CK * KS + NB * CK * 4);
+        S.vl = S.vh + 4 * 2 * 2 * 32 * 8;
+        S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
+        S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
+    }
     __shared__ unsigned s_vis[MAX_CHUNKS / 32];                // bit c: some cell of chunk c is visible to some query of the tile
     __shared__ int s_tile_maxpos, s_tile_minpos;
     __shared__ unsigned long long s_tile_seqs;
-    __shared__ int s_chunk_open[2];                             // [parity]: every cell of the staged chunk is visible to every query of the tile
+    __shared__ int s_chunk_open_all[KH][2];                     // [half][parity]: every cell of the staged chunk is visible to every query of the tile
+    int *s_chunk_open = s_chunk_open_all[half];
     __shared__ int s_nvis;                                      // marked chunks of this tile
 
-    constexpr int NT = 64 * R;
-    const int g = blockIdx.x, tile = blockIdx.y;
+    const int g = blockIdx.x, tile = (int)gridDim.y - 1 - (int)blockIdx.y;     // (the last tiles of a causal prompt walk the most chunks: first out)
     const int zsp = blockIdx.z, nsp = gridDim.z;               // key split: this workgroup walks its share of the tile's marked chunks
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, kg = lane >> 5;
     const int H = a.H, n_ctx = a.n_ctx;
     const int h = g * R + wave;                                // this wave's query head
@@ -102,10 +115,10 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     const size_t head_row0 = (size_t)g * n_ctx;
 
     // ---- tile-wide visibility bounds
-    if (tid == 0) { s_tile_maxpos = -1; s_tile_minpos = 0x7fffffff; s_tile_seqs = 0ull; s_nvis = 0; }
-    for (int i = tid; i < MAX_CHUNKS / 32; i += NT) s_vis[i] = 0u;
+    if (tid_all == 0) { s_tile_maxpos = -1; s_tile_minpos = 0x7fffffff; s_tile_seqs = 0ull; s_nvis = 0; }
+    for (int i = tid_all; i < MAX_CHUNKS / 32; i += NT * KH) s_vis[i] = 0u;
     __syncthreads();
-    if (wave == 0 && kg == 0) {
+    if (wave_all == 0 && kg == 0) {
         atomicMax(&s_tile_maxpos, tpos);
         atomicMin(&s_tile_minpos, tpos);
         atomicOr(&s_tile_seqs, 1ull << tseq);
@@ -290,8 +303,8 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
 
     __syncthreads();                                            // tile bounds complete
     // ---- which chunks matter: one pass over the cell table (a wave's 64 cells = two chunks per ballot)
-    for (int cell0 = 0; cell0 < n_chunks * CK; cell0 += NT) {
-        const int cell = cell0 + tid;
+    for (int cell0 = 0; cell0 < n_chunks * CK; cell0 += NT * KH) {
+        const int cell = cell0 + tid_all;
         int mine = 0;
         if (cell < n_kv) {
             const int cp = a.cell_pos[cell];
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         }
         const unsigned long long bal = __ballot(mine);
         if (lane == 0) {
-            const int c0 = (cell0 + wave * 64) / CK;
+            const int c0 = (cell0 + wave_all * 64) / CK;
             if (c0 < MAX_CHUNKS) {
                 unsigned bits = ((unsigned)(bal & 0xffffffffull) != 0u ? 1u : 0u) | ((unsigned)(bal >> 32) != 0u ? 2u : 0u);
                 if (bits) atomicOr(&s_vis[c0 >> 5], bits << (c0 & 31));
@@ -311,9 +324,9 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
     // ---- key split (causal prompts leave tile i with i + 1 chunks: without it the last tile's workgroup runs 16x as long as the
     // first one's and half the chip idles): the marked chunks of the tile are dealt out in equal contiguous runs to the nsp
     // workgroups of the tile; each leaves an unnormalised (O, m, l) record per query and head, flash_attn_combine_kernel merges them
-    int c = next_visible(0), left = n_chunks;                    // left: marked chunks still to walk (unsplit: all of them)
-    if (nsp > 1) {
-        if (wave == 0) {
+    int c = next_visible(0), left;                               // left: marked chunks of this workgroup's run
+    {
+        if (wave_all == 0) {
             int cnt = 0;
             for (int i = lane; i < (n_chunks + 31) / 32; i += 64) cnt += __builtin_popcount(s_vis[i]);
 #pragma unroll
@@ -325,20 +338,24 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         const int first = zsp * per;
         left = nvis - first < per ? nvis - first : per;
         if (left < 0) left = 0;
-        for (int i = 0; i < first && c < n_chunks; i++) c = next_visible(c + 1);
-        if (left == 0) c = n_chunks;
+        for (int i = 0; i < first + half && c < n_chunks; i++) c = next_visible(c + 1);     // (the second half starts one chunk in)
     }
-    if (c < n_chunks) { load_data(c); store_chunk(); }
+    const int mine = (left + KH - 1 - half) / KH;               // chunks this half walks: every KH-th of the run
+    const int n_it = (left + KH - 1) / KH;                      // iterations of the workgroup (the barriers are everybody's)
+    if (mine > 0) { load_data(c); store_chunk(); }
     __syncthreads();
     FA_T(0);
-    while (c < n_chunks) {
+    for (int it = 0; it < n_it; it++) {
 #ifdef MI355_FA_PROBE
         fa_chunks++;
 #endif
-        int cn = next_visible(c + 1);
-        if (--left <= 0) cn = n_chunks;
-        if (cn < n_chunks) load_data(cn);                       // in flight while this chunk is on the matrix cores
-        {
+        int cn = n_chunks;
+        if (it + 1 < mine) {
+            cn = next_visible(c + 1);
+            if (KH == 2) cn = next_visible(cn + 1);
+            load_data(cn);                                      // in flight while this chunk is on the matrix cores
+        }
+        if (it < mine) {
             // ---- scores S^T[key][query] of this chunk
             float sc[16];
 #pragma unroll
@@ -442,6 +459,30 @@ __global__ __launch_bounds__(64 * R, R <= 4 ? 2 : 1) void flash_attn_prefill_ker
         FA_T(6);
         c = cn;
     }
+    if constexpr (KH == 2) {
+        // ---- the second half's partial (O, m, l) -> LDS (the chunk buffers are done with) -> merged into the first half's: two softmax
+        // partials over disjoint keys, O = O_a 2^(m_a - m) + O_b 2^(m_b - m)
+        float *mrg = reinterpret_cast<float *>(smem) + (size_t)wave * 66 * 64;       // [66][64 lanes] per head: 64 O registers, m, l
+        if (half == 1) {
+#pragma unroll
+            for (int db = 0; db < 4; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) mrg[(db * 16 + r) * 64 + lane] = O[db][r];
+            mrg[64 * 64 + lane] = m_run; mrg[65 * 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (half == 1) return;
+        const float m_b = mrg[64 * 64 + lane], l_b = mrg[65 * 64 + lane];
+        const float m_new = fmaxf(m_run, m_b);
+        const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
+        const float wa = __builtin_amdgcn_exp2f(m_run - m_ref), wb = __builtin_amdgcn_exp2f(m_b - m_ref);
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) O[db][r] = O[db][r] * wa + mrg[(db * 16 + r) * 64 + lane] * wb;
+        l_run = l_run * wa + l_b * wb;
+        m_run = m_new;
+    }
 #ifdef MI355_FA_PROBE
     if (tid == 0 && g == 0 && tile == (int)gridDim.y - 1 && zsp == 0)
         printf("fa probe: %d chunks; cycles: prologue %llu | scores %llu softmax %llu PV %llu barrier %llu store %llu barrier %llu\n", fa_chunks,
@@ -492,12 +533,19 @@ bool flash_attn_prefill_applicable(const AttnArgs &a) {
 // 1.76 ms of attention per prompt against 1.80 with 2 and 2.07 with 6; 2048 tokens NO split 7.1 ms against 8.8 with 2 - the 512
 // (kv head, tile) pairs fill the chip by themselves and the merge costs more than the imbalance), never more than a quarter of the
 // chunks, at most 8, and a workspace of at most 512 MiB.
+static int fa_key_halves(int R) {                               // key halves per workgroup: eight waves at most
+    static const int env = getenv("MI355_FA_KH") ? atoi(getenv("MI355_FA_KH")) : 0;
+    return (R <= 4 && env != 1) ? 2 : 1;
+}
+
 int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max) {
     static const int env = getenv("MI355_ATTN_PREFILL_SPLITS") ? atoi(getenv("MI355_ATTN_PREFILL_SPLITS")) : 0;
+    const int R = G > 0 ? H / G : 1, kh = fa_key_halves(R);
     const int n_chunks = (n_kv_max + CK - 1) / CK, tiles = (T + QT - 1) / QT;
     const int pairs = (G > 0 ? G : 1) * tiles;
-    int s = (512 + pairs - 1) / pairs;
-    if (s > n_chunks / 4) s = n_chunks / 4;
+    const int slots = 2048 / (R * kh > 0 ? R * kh : 1);          // workgroups the chip holds at two waves per SIMD
+    int s = (slots + pairs - 1) / pairs;
+    if (s > n_chunks / (4 * kh)) s = n_chunks / (4 * kh);        // (~4 chunks per half and workgroup at least)
     if (s > 8) s = 8;
     if (env > 0) s = env;
     while (s > 1 && (size_t)T * H * s * (D + 2) * sizeof(float) > ((size_t)512 << 20)) s >>= 1;
@@ -505,18 +553,22 @@ int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max) {
 }
 
 hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
-    const int R = a.H / a.G;
+    const int R = a.H / a.G, kh = fa_key_halves(R);
     const int nsp = (a.pf_splits > 1 && a.part) ? a.pf_splits : 1;
     const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT), (unsigned)nsp);
     const bool f16 = a.type_k == T_F16;
-    const size_t lds = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
-#define FAP(RR) do { if (f16) hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true>), grid, dim3(64 * RR), lds, st, a); \
-                     else hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false>), grid, dim3(64 * RR), lds, st, a); } while (0)
+    const size_t chunk = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
+    const size_t lds = kh == 2 ? std::max(2 * chunk, (size_t)R * 66 * 64 * 4) : chunk;      // two chunk buffers, later the hand-over of the second half
+#define FAP(RR, KK) do { \
+        if (f16) { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, true, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                   hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true, KK>), grid, dim3(64 * RR * KK), lds, st, a); } \
+        else { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK>), grid, dim3(64 * RR * KK), lds, st, a); } } while (0)
     switch (R) {
-        case 1: FAP(1); break;
-        case 2: FAP(2); break;
-        case 4: FAP(4); break;
-        case 8: FAP(8); break;
+        case 1: if (kh == 2) FAP(1, 2); else FAP(1, 1); break;
+        case 2: if (kh == 2) FAP(2, 2); else FAP(2, 1); break;
+        case 4: if (kh == 2) FAP(4, 2); else FAP(4, 1); break;
+        case 8: FAP(8, 1); break;
         default: return hipErrorInvalidValue;
     }
 #undef FAP
