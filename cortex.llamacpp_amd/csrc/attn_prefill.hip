@@ -83,16 +83,17 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
     const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
     const int half = wave_all / R, wave = wave_all - half * R;     // wave: the head of the kv group this wave owns
     const int tid = tid_all - half * NT;
-    Chunk S;
-    {
-        uint8_t *base = smem + half * CHUNK_LDS;
+    auto chunk_at = [&](int par) {                    // buffer par of this half
+        Chunk S;
+        uint8_t *base = smem + (half * 2 + par) * CHUNK_LDS;
         S.k = reinterpret_cast<int8_t *>(base);
         S.dk = reinterpret_cast<float *>(base + CK * KS);
         S.vh = reinterpret_cast<_Float16 *>(base + CK * KS + NB * CK * 4);
         S.vl = S.vh + 4 * 2 * 2 * 32 * 8;
         S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
         S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
-    }
+        return S;
+    };
     __shared__ unsigned s_vis[MAX_CHUNKS / 32];                // bit c: some cell of chunk c is visible to some query of the tile
     __shared__ int s_tile_maxpos, s_tile_minpos;
     __shared__ unsigned long long s_tile_seqs;
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
         const int mcell = c * CK + tid;
         if (tid < CK && mcell < n_kv) { cpn = a.cell_pos[mcell]; csn = a.cell_seq[mcell]; }
     };
-    int stage_par = 0, read_par = 0;                             // parity of s_chunk_open written by the next store / read by the current chunk
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int par) {                            // the registers load_data filled -> buffer par of this half
+        const Chunk S = chunk_at(par);
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int p = tid + NT * i;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
                 for (int e = 0; e < 8; e++) {
                     const int dim = col * 8 + e;
                     const uint16_t hb = (uint16_t)((wv[e >> 1] >> (16 * (e & 1))) & 0xffff);
-                    const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot;
+                    const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + ((dim & 31) ^ (dim >> 5))) * 8 + slot;
                     reinterpret_cast<uint16_t *>(S.vh)[o] = hb;
                 }
             }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
                         hi[kk] = (_Float16)v;
                         lo[kk] = (_Float16)(v - (float)hi[kk]);
                     }
-                    const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + (dim & 31)) * 8 + slot0;
+                    const int o = ((((dim >> 5) * 2 + j) * 2 + kgs) * 32 + ((dim & 31) ^ (dim >> 5))) * 8 + slot0;   // (column ^ dim block: the 32 lanes of a store spread over the banks)
                     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                     *reinterpret_cast<f16x4 *>(S.vh + o) = f16x4{hi[0], hi[1], hi[2], hi[3]};
                     *reinterpret_cast<f16x4 *>(S.vl + o) = f16x4{lo[0], lo[1], lo[2], lo[3]};
@@ -278,9 +279,8 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
         if (wave == 0) {
             const bool open = kg == 1 || (cpn >= 0 && cpn <= s_tile_minpos && (csn & s_tile_seqs) == s_tile_seqs);
             const bool all_open = __all(open);
-            if (lane == 0) s_chunk_open[stage_par] = all_open ? 1 : 0;
+            if (lane == 0) s_chunk_open[par] = all_open ? 1 : 0;
         }
-        stage_par ^= 1;
     };
     auto next_visible = [&](int from) -> int {                   // first marked chunk >= from, or n_chunks
         int c = from;
@@ -342,20 +342,26 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
     }
     const int mine = (left + KH - 1 - half) / KH;               // chunks this half walks: every KH-th of the run
     const int n_it = (left + KH - 1) / KH;                      // iterations of the workgroup (the barriers are everybody's)
-    if (mine > 0) { load_data(c); store_chunk(); }
+    // two buffers per half: chunk c is on the matrix cores from one while chunk c + 1 (requested an iteration ago) is converted into the
+    // other and chunk c + 2's requests go out: ONE barrier per chunk (eight waves meet at it; the second one cost 0.5 kilocycles a chunk)
+    auto next_mine = [&](int cur) -> int { int x = next_visible(cur + 1); if (KH == 2) x = next_visible(x + 1); return x; };
+    int cn = n_chunks, par = 0;
+    if (mine > 0) { load_data(c); store_chunk(0); }
+    if (mine > 1) { cn = next_mine(c); load_data(cn); }
     __syncthreads();
     FA_T(0);
     for (int it = 0; it < n_it; it++) {
 #ifdef MI355_FA_PROBE
         fa_chunks++;
 #endif
-        int cn = n_chunks;
+        int cnn = n_chunks;
         if (it + 1 < mine) {
-            cn = next_visible(c + 1);
-            if (KH == 2) cn = next_visible(cn + 1);
-            load_data(cn);                                      // in flight while this chunk is on the matrix cores
+            store_chunk(par ^ 1);
+            if (it + 2 < mine) { cnn = next_mine(cn); load_data(cnn); }     // in flight while this chunk and the next conversion run
         }
+        FA_T(5);
         if (it < mine) {
+            const Chunk S = chunk_at(par);
             // ---- scores S^T[key][query] of this chunk
             float sc[16];
 #pragma unroll
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
             // (scores and the running maximum are kept in log2 units: exp(s - m) is one v_exp_f32 of (s - m) * log2(e), which is
             // folded into the softmax scale; exp2(-inf) = 0 does the masking; the record a split leaves converts m back)
             float mloc = -INFINITY;
-            if (s_chunk_open[read_par]) {                                     // (workgroup-uniform)
+            if (s_chunk_open[par]) {                                          // (uniform over the half)
 #pragma unroll
                 for (int r = 0; r < 16; r++) { sc[r] *= scale_l2; mloc = fmaxf(mloc, sc[r]); }
             } else {
@@ -405,7 +411,6 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
                     mloc = fmaxf(mloc, sc[r]);
                 }
             }
-            read_par ^= 1;
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);
             const float m_ref = m_new == -INFINITY ? 0.0f : m_new;           // (nothing visible yet: exp2(-inf - 0) = 0, no NaN)
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
             for (int db = 0; db < 4; db++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    const int o = (((db * 2 + j) * 2 + kg) * 32 + n) * 8;
+                    const int o = (((db * 2 + j) * 2 + kg) * 32 + (n ^ db)) * 8;
                     const f16x8 avh = *reinterpret_cast<const f16x8 *>(S.vh + o);
                     const f16x8 avl = *reinterpret_cast<const f16x8 *>(S.vl + o);
                     O[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, ph[j], O[db], 0, 0, 0);
@@ -451,13 +456,9 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
                 }
         }
         FA_T(3);
-        __syncthreads();                                        // chunk c consumed
+        __syncthreads();                                        // chunk c consumed, chunk cn staged
         FA_T(4);
-        if (cn < n_chunks) store_chunk();
-        FA_T(5);
-        __syncthreads();
-        FA_T(6);
-        c = cn;
+        c = cn; cn = cnn; par ^= 1;
     }
     if constexpr (KH == 2) {
         // ---- the second half's partial (O, m, l) -> LDS (the chunk buffers are done with) -> merged into the first half's: two softmax
@@ -485,8 +486,8 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
     }
 #ifdef MI355_FA_PROBE
     if (tid == 0 && g == 0 && tile == (int)gridDim.y - 1 && zsp == 0)
-        printf("fa probe: %d chunks; cycles: prologue %llu | scores %llu softmax %llu PV %llu barrier %llu store %llu barrier %llu\n", fa_chunks,
-               fa_acc[0], fa_acc[1], fa_acc[2], fa_acc[3], fa_acc[4], fa_acc[5], fa_acc[6]);
+        printf("fa probe: %d chunks; cycles: prologue %llu | store + requests %llu scores %llu softmax %llu PV %llu barrier %llu\n", fa_chunks,
+               fa_acc[0], fa_acc[5], fa_acc[1], fa_acc[2], fa_acc[3], fa_acc[4]);
 #endif
 
     if (nsp > 1) {                                              // partial record [D O][m][l] of (query, head, split)
@@ -558,7 +559,7 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
     const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT), (unsigned)nsp);
     const bool f16 = a.type_k == T_F16;
     const size_t chunk = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
-    const size_t lds = kh == 2 ? std::max(2 * chunk, (size_t)R * 66 * 64 * 4) : chunk;      // two chunk buffers, later the hand-over of the second half
+    const size_t lds = kh == 2 ? std::max(4 * chunk, (size_t)R * 66 * 64 * 4) : 2 * chunk;      // two chunk buffers per half, later the hand-over of the second half
 #define FAP(RR, KK) do { \
         if (f16) { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, true, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                    hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true, KK>), grid, dim3(64 * RR * KK), lds, st, a); } \
