@@ -67,8 +67,10 @@ __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 
 // each half staging its own chunk buffer with its own 64 R threads; at the end the second half hands its (O, m, l) over through LDS and
 // the first one merges them as two softmax partials.  A causal tile's chunk walk - the longest workgroups of a prompt - takes half
 // the iterations, and with the long tiles dispatched first the short ones fill the slots they leave: no records, no second launch.
-template <int R, bool F16, int KH>
-__global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(const AttnArgs a) {
+// QS = query sub-tiles of 32 per workgroup (R = 1: four, R = 2: two, else one - four waves per half in every case): the sub-tiles share
+// every staged chunk, which a single-head workgroup of multi-head attention otherwise stages for one wave's use.
+template <int R, bool F16, int KH, int QS>
+__global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel(const AttnArgs a) {
 #ifdef MI355_FA_PROBE
     unsigned long long fa_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fa_t = __builtin_readcyclecounter();
     int fa_chunks = 0;
@@ -78,10 +80,11 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
     constexpr int PPK = F16 ? 16 : 8;                 // 16-byte pieces per K / V row
     constexpr int CHUNK_LDS = CK * KS + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;   // one staged chunk (launcher: one per half)
     static_assert(CHUNK_LDS % 16 == 0, "chunk buffers stay 16-byte aligned");
-    constexpr int NT = 64 * R;                        // threads of one half: the staging roles below are per half
+    constexpr int NT = 64 * R * QS;                   // threads of one half: the staging roles below are per half
     const int tid_all = threadIdx.x, lane = tid_all & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
-    const int half = wave_all / R, wave = wave_all - half * R;     // wave: the head of the kv group this wave owns
+    const int half = wave_all / (R * QS), wave = wave_all - half * (R * QS);   // wave: index inside the half = (query sub-tile, head of the kv group)
+    const int sub = wave / R, hw = wave - sub * R;
     const int tid = tid_all - half * NT;
     auto chunk_at = [&](int par) {                    // buffer par of this half
         Chunk S;
@@ -100,13 +103,16 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
     __shared__ int s_chunk_open_all[KH][2];                     // [half][parity]: every cell of the staged chunk is visible to every query of the tile
     int *s_chunk_open = s_chunk_open_all[half];
     __shared__ int s_nvis;                                      // marked chunks of this tile
+    __shared__ int s_sub_maxpos[QS];                            // highest query position of each sub-tile
+    __shared__ int s_chunk_minpos_all[KH][2];                   // [half][parity]: lowest position held by a staged chunk that is not open (a sub-tile wholly before it skips it)
+    int *s_chunk_minpos = s_chunk_minpos_all[half];
 
     const int g = blockIdx.x, tile = (int)gridDim.y - 1 - (int)blockIdx.y;     // (the last tiles of a causal prompt walk the most chunks: first out)
     const int zsp = blockIdx.z, nsp = gridDim.z;               // key split: this workgroup walks its share of the tile's marked chunks
     const int n = lane & 31, kg = lane >> 5;
     const int H = a.H, n_ctx = a.n_ctx;
-    const int h = g * R + wave;                                // this wave's query head
-    int qt = tile * QT + n;                                    // this lane's query token
+    const int h = g * R + hw;                                  // this wave's query head
+    int qt = (tile * QS + sub) * QT + n;                       // this lane's query token
     const bool q_ok = qt < a.T;
     if (!q_ok) qt = a.T - 1;
     const int tpos = a.tok_pos[qt];
@@ -117,10 +123,12 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
 
     // ---- tile-wide visibility bounds
     if (tid_all == 0) { s_tile_maxpos = -1; s_tile_minpos = 0x7fffffff; s_tile_seqs = 0ull; s_nvis = 0; }
+    if (tid_all < QS) s_sub_maxpos[tid_all] = -1;
     for (int i = tid_all; i < MAX_CHUNKS / 32; i += NT * KH) s_vis[i] = 0u;
     __syncthreads();
-    if (wave_all == 0 && kg == 0) {
+    if (half == 0 && hw == 0 && kg == 0) {
         atomicMax(&s_tile_maxpos, tpos);
+        atomicMax(&s_sub_maxpos[sub], tpos);
         atomicMin(&s_tile_minpos, tpos);
         atomicOr(&s_tile_seqs, 1ull << tseq);
     }
@@ -279,7 +287,13 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
         if (wave == 0) {
             const bool open = kg == 1 || (cpn >= 0 && cpn <= s_tile_minpos && (csn & s_tile_seqs) == s_tile_seqs);
             const bool all_open = __all(open);
-            if (lane == 0) s_chunk_open[par] = all_open ? 1 : 0;
+            int mp = -1;
+            if (QS > 1 && !all_open) {                        // (a tile of several sub-tiles: its diagonal spans several chunks)
+                mp = (kg == 0 && cpn >= 0) ? cpn : 0x7fffffff;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) mp = min(mp, __shfl_xor(mp, o, 64));
+            }
+            if (lane == 0) { s_chunk_open[par] = all_open ? 1 : 0; if (QS > 1) s_chunk_minpos[par] = mp; }
         }
     };
     auto next_visible = [&](int from) -> int {                   // first marked chunk >= from, or n_chunks
@@ -346,6 +360,8 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
     // other and chunk c + 2's requests go out: ONE barrier per chunk (eight waves meet at it; the second one cost 0.5 kilocycles a chunk)
     auto next_mine = [&](int cur) -> int { int x = next_visible(cur + 1); if (KH == 2) x = next_visible(x + 1); return x; };
     int cn = n_chunks, par = 0;
+    const int sub_maxpos = s_sub_maxpos[sub];
+    const bool sub_live = (tile * QS + sub) * QT < a.T;         // (a ragged last tile may leave a sub-tile without queries)
     if (mine > 0) { load_data(c); store_chunk(0); }
     if (mine > 1) { cn = next_mine(c); load_data(cn); }
     __syncthreads();
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64 * R * KH, 2) void flash_attn_prefill_kernel(cons
             if (it + 2 < mine) { cnn = next_mine(cn); load_data(cnn); }     // in flight while this chunk and the next conversion run
         }
         FA_T(5);
-        if (it < mine) {
+        if (it < mine && (QS == 1 || (sub_live && (s_chunk_open[par] || s_chunk_minpos[par] <= sub_maxpos)))) {   // (wave-uniform)
             const Chunk S = chunk_at(par);
             // ---- scores S^T[key][query] of this chunk
             float sc[16];
@@ -538,13 +554,17 @@ static int fa_key_halves(int R) {                               // key halves pe
     static const int env = getenv("MI355_FA_KH") ? atoi(getenv("MI355_FA_KH")) : 0;
     return (R <= 4 && env != 1) ? 2 : 1;
 }
+static int fa_sub_tiles(int R) {                                // query sub-tiles per workgroup: four waves per half
+    static const int env = getenv("MI355_FA_QS") ? atoi(getenv("MI355_FA_QS")) : 0;
+    return env == 1 ? 1 : R == 1 ? 4 : R == 2 ? 2 : 1;
+}
 
 int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max) {
     static const int env = getenv("MI355_ATTN_PREFILL_SPLITS") ? atoi(getenv("MI355_ATTN_PREFILL_SPLITS")) : 0;
-    const int R = G > 0 ? H / G : 1, kh = fa_key_halves(R);
-    const int n_chunks = (n_kv_max + CK - 1) / CK, tiles = (T + QT - 1) / QT;
+    const int R = G > 0 ? H / G : 1, kh = fa_key_halves(R), qs = fa_sub_tiles(R);
+    const int n_chunks = (n_kv_max + CK - 1) / CK, tiles = (T + QT * qs - 1) / (QT * qs);
     const int pairs = (G > 0 ? G : 1) * tiles;
-    const int slots = 2048 / (R * kh > 0 ? R * kh : 1);          // workgroups the chip holds at two waves per SIMD
+    const int slots = 2048 / (R * kh * qs > 0 ? R * kh * qs : 1);  // workgroups the chip holds at two waves per SIMD
     int s = (slots + pairs - 1) / pairs;
     if (s > n_chunks / (4 * kh)) s = n_chunks / (4 * kh);        // (~4 chunks per half and workgroup at least)
     if (s > 8) s = 8;
@@ -554,22 +574,22 @@ int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max) {
 }
 
 hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
-    const int R = a.H / a.G, kh = fa_key_halves(R);
+    const int R = a.H / a.G, kh = fa_key_halves(R), qs = fa_sub_tiles(R);
     const int nsp = (a.pf_splits > 1 && a.part) ? a.pf_splits : 1;
-    const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT - 1) / QT), (unsigned)nsp);
+    const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT * qs - 1) / (QT * qs)), (unsigned)nsp);
     const bool f16 = a.type_k == T_F16;
     const size_t chunk = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
-    const size_t lds = kh == 2 ? std::max(4 * chunk, (size_t)R * 66 * 64 * 4) : 2 * chunk;      // two chunk buffers per half, later the hand-over of the second half
-#define FAP(RR, KK) do { \
-        if (f16) { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, true, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                   hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true, KK>), grid, dim3(64 * RR * KK), lds, st, a); } \
-        else { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-               hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK>), grid, dim3(64 * RR * KK), lds, st, a); } } while (0)
+    const size_t lds = kh == 2 ? std::max(4 * chunk, (size_t)R * qs * 66 * 64 * 4) : 2 * chunk;   // two chunk buffers per half, later the hand-over of the second half
+#define FAP(RR, KK, QQ) do { \
+        if (f16) { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, true, KK, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                   hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true, KK, QQ>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } \
+        else { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK, QQ>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } } while (0)
     switch (R) {
-        case 1: if (kh == 2) FAP(1, 2); else FAP(1, 1); break;
-        case 2: if (kh == 2) FAP(2, 2); else FAP(2, 1); break;
-        case 4: if (kh == 2) FAP(4, 2); else FAP(4, 1); break;
-        case 8: FAP(8, 1); break;
+        case 1: if (kh == 2 && qs == 4) FAP(1, 2, 4); else if (kh == 2) FAP(1, 2, 1); else if (qs == 4) FAP(1, 1, 4); else FAP(1, 1, 1); break;
+        case 2: if (kh == 2 && qs == 2) FAP(2, 2, 2); else if (kh == 2) FAP(2, 2, 1); else if (qs == 2) FAP(2, 1, 2); else FAP(2, 1, 1); break;
+        case 4: if (kh == 2) FAP(4, 2, 1); else FAP(4, 1, 1); break;
+        case 8: FAP(8, 1, 1); break;
         default: return hipErrorInvalidValue;
     }
 #undef FAP

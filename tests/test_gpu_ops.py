@@ -282,11 +282,12 @@ def test_flash_attn(be, tk, tv, tol, H, G, D, n_cells):
 
 
 @pytest.mark.parametrize("tkv,tol", [(Q8_0, 2e-5), (F16, 2e-5)])
-@pytest.mark.parametrize("H,G,n_cells,T", [(8, 2, 70, 40), (32, 8, 300, 33), (4, 4, 129, 64), (16, 2, 1000, 37), (32, 8, 700, 200), (8, 2, 520, 97), (2, 2, 333, 130)])
+@pytest.mark.parametrize("H,G,n_cells,T", [(8, 2, 70, 40), (32, 8, 300, 33), (4, 4, 129, 64), (16, 2, 1000, 37), (32, 8, 700, 200), (8, 2, 520, 97), (2, 2, 333, 130), (8, 4, 500, 150), (4, 4, 900, 300)])
 def test_flash_attn_prefill_matrix_cores(be, H, G, n_cells, T, tkv, tol):
     """Prompt-processing attention on the MFMA path (T >= 32 query rows, head_dim 128, q8_0 or f16 K / V): ragged query
     tile, ragged last key chunk, holes in the cache, queries that see one cell only, R = 1 / 4 / 8 heads per kv head; several
-    64-query tiles whose two sub-tiles see different chunk ranges, a last tile with one sub-tile only, key splits.
+    tiles whose key halves and query sub-tiles (R = 1: four, R = 2: two per workgroup) see different chunk ranges, a last tile with one
+    sub-tile only, key splits across workgroups.
     f16: the CPU path accumulates V in fp16 and is itself only good to ~1e-2 over hundreds of cells, so the tight comparison
     is against the restatement with that accumulation in f32 (oq.set_fa_v_acc_f32) — the HIP kernel agrees with it to 1e-6 —
     and the stock fp16 mode is checked at its own noise level."""

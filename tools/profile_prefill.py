@@ -6,11 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 pkg = ge.load_pkg(); pkg.Backend()
-path = "/tmp/mi355-bench-llama-3-8b-q4_k_m.gguf"
+cfg, ftype, kv = os.environ.get("CONFIG", "llama-3-8b"), os.environ.get("FTYPE", "q4_k_m"), int(os.environ.get("KV", "8"))   # KV: 8 = q8_0, 1 = f16
+path = f"/tmp/mi355-bench-{cfg}-{ftype}.gguf"
 if not os.path.exists(path):
-    pkg.gguf_synth.write_synthetic_llama(path, "llama-3-8b", "q4_k_m", seed=0xC0FFEE, with_vocab=False)
+    pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=0xC0FFEE, with_vocab=False)
 m = pkg.Model(path)
-c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=int(os.environ.get("UBATCH", "2048")), type_k=8, type_v=8, use_graphs=False)
+c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=int(os.environ.get("UBATCH", "2048")), type_k=kv, type_v=kv, use_graphs=False)
 rng = np.random.default_rng(0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 p = rng.integers(0, m.n_vocab, T)
