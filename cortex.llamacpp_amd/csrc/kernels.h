@@ -105,6 +105,8 @@ bool mmq_planes_swiglu_ok(int type_gate, int type_up, int n_rows, int K, int T);
 hipError_t launch_mmq_planes_swiglu(int type, const uint8_t *planes_gate, const uint8_t *planes_up, int n_rows, int K, int T, const ActQuant &q,
                                     float *out, int ld_out, hipStream_t st);
 bool mmq_ksplit_applicable(int type, int K, int T);
+// ... and preferred over the planes kernels for a tensor of n_rows rows (has_planes: its pre-expanded planes exist)
+bool mmq_ksplit_preferred(int type, int n_rows, int K, int T, bool has_planes, bool pair = false);
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st);
 hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q,

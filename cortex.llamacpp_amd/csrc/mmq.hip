@@ -1455,6 +1455,22 @@ bool mmq_ksplit_applicable(int type, int K, int T) {
     return (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K) && (K % 256) == 0 && T >= 3 && T <= g_ksplit_max;
 }
 
+// Which kernel takes a 3..256-token launch is a matter of shape (tools/exp_planes_shapes.py, Q5_K, us per launch):
+//     N x K          T = 48     64     96    128    160    192    256
+//   14336 x 4096   K-split 29     30     56     58     83     86    103      planes 256x32: 34 34 35 37 67 68 70   128x128: 55 56 56 57 60 60 61
+//    4096 x 14336  K-split 38     39     41     43     77     80     83      planes 256x32: 99 .. 102              128x128: 166 .. 172
+// a tensor of >= 8192 rows has enough 256-row tiles for the planes kernels to fill the chip from 65 tokens on (56 x 3 workgroups) and
+// they read pre-expanded operands; a tensor of 4096 rows does not, and the K-split kernel's waves share its long K instead.
+// (pair: gate | up of a dense layer go out as ONE K-split launch of 2 n_rows rows, which holds its own against two planes launches up to
+// 128 tokens - whole 8B prompt 8.8 vs 9.0 ms at 100 tokens, 9.0 vs 9.2 at 128; past that the LDS-form SwiGLU launch takes the pair:
+// 13.6 -> 10.6 ms at 200 tokens, 14.1 -> 11.1 at 256.)
+bool mmq_ksplit_preferred(int type, int n_rows, int K, int T, bool has_planes, bool pair) {
+    static const int env = getenv("MI355_KSPLIT_SHAPE") ? atoi(getenv("MI355_KSPLIT_SHAPE")) : 1;
+    if (!mmq_ksplit_applicable(type, K, T)) return false;
+    if (env && has_planes && T > (pair ? 128 : 64) && n_rows >= 8192 && mmq_applicable(type, K, T)) return false;
+    return true;
+}
+
 // segs: up to 3 tensors sharing the activation; swiglu: segs = {gate, up} of one type and shape, out = silu(gate.x) * (up.x) into segs[0].out
 hipError_t launch_mmq_ksplit_multi(const MMQSeg *segs, int n_seg, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                                    bool swiglu, hipStream_t st) {

@@ -476,8 +476,9 @@ bool Context::init(std::string &err) {
     alloc_actq(aq_e_, E, T, true, true, allocs_, device_bytes, ok);
     alloc_actq(aq_o_, E, T, true, true, allocs_, device_bytes, ok);
     alloc_actq(aq_ff_, FF, T, true, true, allocs_, device_bytes, ok);
-    mmq_bh_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), (int)T));
-    mmq_bl_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), (int)T));
+    const int prep_rows = (int)T * (hp.n_expert > 0 ? std::max(1, (int)hp.n_expert_used) : 1);   // (expert batches: every (token, rank) pair is a row)
+    mmq_bh_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), prep_rows));
+    mmq_bl_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), prep_rows));
     // partial sums of the K-split prompt contraction: only tensors with few rows split (Q | K | V, attention output, FFN down),
     // up to four ways; tensors that do not fit fall back to an unsplit kernel
     mmq_ws_.bytes = (size_t)4 * T * std::max<size_t>(E, (size_t)(hp.n_head + 2 * hp.n_head_kv) * D) * sizeof(float);
@@ -716,14 +717,16 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
     if (is_quant(w.type)) {
         if (mmq_q80_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU && aq.qs0)   // prompt processing, Q8_0 weights
             return launch_mmq_q80(w.data, w.row_bytes, (int)w.N, K, T, aq, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
-        if (mmq_ksplit_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // batched decode steps: MFMA, K split
-            if (w.type != T_Q6_K) HIP_TRY(ensure_prep(aq, K, T));
-            return launch_mmq_ksplit(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+        // (bh_over_ / bl_over_: the caller prepared the block-sum planes of a larger batch that aq's rows are a slice of - the expert loop)
+        const int8_t *bh = bh_over_ ? bh_over_ : mmq_bh_, *bl = bh_over_ ? bl_over_ : mmq_bl_;
+        if (mmq_ksplit_preferred(w.type, (int)w.N, K, T, w.planes != nullptr) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // batched decode steps, short prompts, expert batches: MFMA, K split
+            if (w.type != T_Q6_K && !bh_over_) HIP_TRY(ensure_prep(aq, K, T));
+            return launch_mmq_ksplit(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
         if (mmq_applicable(w.type, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU) {   // prompt processing: MFMA path
-            if (w.type != T_Q6_K || !w.planes) HIP_TRY(ensure_prep(aq, K, T));
-            if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_, mmq_ws_);
-            return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, mmq_bh_, mmq_bl_, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+            if ((w.type != T_Q6_K || !w.planes) && !bh_over_) HIP_TRY(ensure_prep(aq, K, T));
+            if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_, mmq_ws_);
+            return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
         return mmvq_tokens(&s, 1, K, T, epi, aq, stream_, pending_fuse_);
@@ -1025,19 +1028,31 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     if (q.qs0) { v.qs0 = q.qs0 + (size_t)r0 * K; v.d0 = q.d0 + (size_t)r0 * (K / 32); }
                     return v;
                 };
-                for (int e = 0; e < NE; e++) {
+                // the block-sum planes of ALL grouped rows in one launch (they were one launch per expert and projection: 16 a layer);
+                // an expert's batch takes its slice of them
+                const bool pl_gu = L.gate_exps.type != T_Q8_0 || L.up_exps.type != T_Q8_0, pl_d = L.down_exps.type != T_Q8_0;
+                if (pl_gu) HIP_TRY(launch_mmq_prep(aq_eg_, E, GR, mmq_bh_, mmq_bl_, stream_));
+                hipError_t e_exp = hipSuccess;
+                for (int e = 0; e < NE && e_exp == hipSuccess; e++) {
                     const int n_e = h_moe_meta_[e], r0 = h_moe_meta_[NE + e];
                     if (n_e <= 0) continue;
-                    HIP_TRY(linear(view(L.gate_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_g_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
-                    HIP_TRY(linear(view(L.up_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_ug_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE));
+                    if (pl_gu) { bh_over_ = mmq_bh_ + (size_t)r0 * (E >> 4); bl_over_ = mmq_bl_ + (size_t)r0 * (E >> 4); }
+                    e_exp = linear(view(L.gate_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_g_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE);
+                    if (e_exp == hipSuccess) e_exp = linear(view(L.up_exps, e), rows(aq_eg_, r0, E), nullptr, E, n_e, ffn_ug_ + (size_t)r0 * FF, FF, nullptr, EPI_STORE);
                 }
-                HIP_TRY(launch_swiglu_quant(ffn_g_, ffn_ug_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_));
+                bh_over_ = bl_over_ = nullptr;
+                HIP_TRY(e_exp);
+                HIP_TRY(launch_swiglu_quant(ffn_g_, ffn_ug_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_,
+                                            pl_d ? mmq_bh_ : nullptr, pl_d ? mmq_bl_ : nullptr));
                 prep_owner_ = nullptr;
-                for (int e = 0; e < NE; e++) {
+                for (int e = 0; e < NE && e_exp == hipSuccess; e++) {
                     const int n_e = h_moe_meta_[e], r0 = h_moe_meta_[NE + e];
                     if (n_e <= 0) continue;
-                    HIP_TRY(linear(view(L.down_exps, e), rows(aq_ffg_, r0, FF), nullptr, FF, n_e, y_g_ + (size_t)r0 * E, E, nullptr, EPI_STORE));
+                    if (pl_d) { bh_over_ = mmq_bh_ + (size_t)r0 * (FF >> 4); bl_over_ = mmq_bl_ + (size_t)r0 * (FF >> 4); }
+                    e_exp = linear(view(L.down_exps, e), rows(aq_ffg_, r0, FF), nullptr, FF, n_e, y_g_ + (size_t)r0 * E, E, nullptr, EPI_STORE);
                 }
+                bh_over_ = bl_over_ = nullptr;
+                HIP_TRY(e_exp);
                 HIP_TRY(launch_moe_scatter_combine(x_, y_g_, moe_w_, moe_slot_, T, E, KU, stream_));
                 prof_mark("moe_ffn");
                 if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
@@ -1114,7 +1129,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             const bool ffn_mmq = (mmq_q80_applicable(L.gate.type, E, T) && mmq_q80_applicable(L.up.type, E, T)) ||
                                  (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
                                  (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T));
-            const bool ffn_ks = mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T) && !fuse_ffn;
+            const bool ffn_ks = mmq_ksplit_preferred(L.gate.type, (int)L.gate.N, E, T, L.gate.planes != nullptr, true) &&
+                                mmq_ksplit_preferred(L.up.type, (int)L.up.N, E, T, L.up.planes != nullptr, true) && !fuse_ffn;
             if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 HIP_TRY(mmvq_tokens(segs, 2, E, T, EPI_SWIGLU, aq_e_, stream_, fz));

@@ -191,6 +191,7 @@ class Context {
     int prep_K_ = 0, prep_T_ = 0;
     hipError_t ensure_prep(const ActQuant &aq, int K, int T);
     void prep_written(const ActQuant &aq, int K, int T) { prep_owner_ = aq.qs; prep_K_ = K; prep_T_ = T; }
+    const int8_t *bh_over_ = nullptr, *bl_over_ = nullptr;   // linear(): block-sum planes prepared by the caller for a slice of a larger batch
     float *att_part_ = nullptr;
     size_t att_part_floats_ = 0;
     int cur_max_pos_ = 0;                            // largest position of the micro-batch being decoded
