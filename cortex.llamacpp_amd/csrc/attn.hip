@@ -580,11 +580,17 @@ bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
 int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }
 
 // q is the UN-rotated query; a.splits must be flash_attn_decode_splits(a.n_kv_max)
-hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st) {
+// knew / vnew / tok_cell (all or none): the K rope + KV store of the step's tokens happens inside this launch (every token of the batch
+// belongs to a different sequence, so no token reads another one's new cell) instead of in launch_kv_store_fast before it
+hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st, const float *knew, const float *vnew,
+                                    const int32_t *tok_cell) {
     const int R = a.H / a.G;
     const dim3 grid(a.G, a.splits, a.T);
-    const DecodeFuse nofz{};
-#define FAD(RR, TK, TV) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, false>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz)
+    DecodeFuse nofz{};
+    const bool store = knew && vnew && tok_cell;
+    if (store) { nofz.knew = knew; nofz.vnew = vnew; nofz.tok_cell = tok_cell; }
+#define FAD(RR, TK, TV) do { if (store) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); \
+                             else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, false>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); } while (0)
 #define FAD_T(RR)                                                              \
     if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \

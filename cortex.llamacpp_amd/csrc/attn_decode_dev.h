@@ -12,7 +12,10 @@ namespace mi355 {
 //
 // FUSED (single-token step, R*D a multiple of 256) folds the two neighbouring launches into this one:
 //  * KV store: the workgroup whose chunk holds the token's cell rotates K, converts K/V to the cache type, writes the
-//    cache row and patches its own registers / LDS scales with the same codes (no other workgroup reads that cell);
+//    cache row and patches its own registers / LDS scales with the same codes (no other workgroup reads that cell).
+//    A batched step whose tokens all belong to different sequences takes this part too (T > 1, no tickets): another
+//    token's workgroup may read the row while it is written, but that cell is not visible to it - its score is replaced
+//    by -inf and its V (old or new bytes, finite either way) is weighted by zero;
 //  * merge: every workgroup publishes its chunk partial, then takes a ticket on a per-kv-head counter; the LAST arriver
 //    merges the splits of its R heads exactly as flash_attn_combine_kernel does, writes the f32 rows and the quantised
 //    activation of the attn_output mat-vec, and re-arms the counter.  Nobody waits: no spin, no co-residency needed.
@@ -65,7 +68,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
     const int32_t tpos = a.tok_pos[t];
     const int tseq = a.tok_seq[t];
-    if (!FUSED && a.T > 1) {
+    if (a.T > 1) {   // (FUSED with T > 1 is the store-fused form of a batched step: no tickets, the merge is its own launch)
         // batched steps (one token per sequence): most chunks hold other sequences' cells only.  Decide that before
         // touching K / V: such a chunk publishes (m, l) = (-inf, 0) and leaves; the merge skips it.
         const int mine = (tid < C && cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
@@ -123,18 +126,18 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     // ---- FUSED: this token's K/V row (wave 0: lanes 0..31 rotate + convert K, lanes 32..63 convert V; 4 elements each)
     int own_cl = -1;                                   // chunk-local index of the token's cell, if this chunk holds it
     if (FUSED) {
-        const int cellnew = fz.tok_cell[0];
+        const int cellnew = fz.tok_cell[t];                      // (t = 0 in a single-token step)
         if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
         if (own_cl >= 0 && wave == 0) {
             const bool isk = lane < 32;
             const int dd = (lane & 31) * 4;
             float4 x4;
             {
-                const coh_u32x4 xx = cld16<COH>(isk ? fz.knew : fz.vnew, (g * D + dd) * 4);
+                const coh_u32x4 xx = cld16<COH>(isk ? fz.knew : fz.vnew, ((t * a.G + g) * D + dd) * 4);
                 x4 = make_float4(__uint_as_float(xx.x), __uint_as_float(xx.y), __uint_as_float(xx.z), __uint_as_float(xx.w));
             }
             if (isk && dd < n_rot) {
-                const float4 cs = *reinterpret_cast<const float4 *>(cs_table + dd);   // c0 s0 c1 s1
+                const float4 cs = *reinterpret_cast<const float4 *>(cs_table + (size_t)t * n_rot + dd);   // c0 s0 c1 s1
                 const float x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
                 x4.x = x0 * cs.x - x1 * cs.y; x4.y = x0 * cs.y + x1 * cs.x;
                 x4.z = x2 * cs.z - x3 * cs.w; x4.w = x2 * cs.w + x3 * cs.z;

@@ -226,7 +226,8 @@ hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t 
 // decode-step variants (attn.hip): single round trip per workgroup; q passed UN-rotated (rope fused), NORM rope, D = 128
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra);
 int flash_attn_decode_splits(int n_kv_max);
-hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st);
+hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, RopeArgs ra, hipStream_t st, const float *knew = nullptr,
+                                    const float *vnew = nullptr, const int32_t *tok_cell = nullptr);   // knew..: KV store inside (tokens of different sequences)
 // one launch per layer for a single-token step: KV store + attention + split merge + quantise (a.splits set by the caller)
 bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra);
 void attn_probe_report();   // MI355_ATTN_PROBE=1: phase timing of the last fused decode attention launch, on stderr

@@ -799,6 +799,12 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
 static int g_moe_group_min = getenv("MI355_MOE_GROUP_MIN") ? atoi(getenv("MI355_MOE_GROUP_MIN")) : 8;
 void set_moe_group_min(int t) { g_moe_group_min = t < 1 ? 1 : t; }
 static int g_decode_mega = -1;           // -1: take the environment
+static bool g_store_fuse = true;
+void set_attn_store_fuse(bool on) { g_store_fuse = on; }
+static bool store_fuse_enabled() {
+    static const bool env_off = getenv("MI355_ATTN_STORE_FUSE") && getenv("MI355_ATTN_STORE_FUSE")[0] == '0';
+    return g_store_fuse && !env_off;
+}
 void set_decode_mega(bool on) { g_decode_mega = on ? 1 : 0; }
 
 // Builds the per-layer phase descriptors of decode_mega.hip: the same MMVQArgs the per-launch path passes to
@@ -962,6 +968,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra)) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch
                 HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));
+            } else if (batch_distinct_ && store_fuse_enabled()) {
+                // batched step, every token of a different sequence: K rope + KV store inside the attention launch (no token reads another's new cell)
+                HIP_TRY(launch_flash_attn_decode(aa, rope_cs_, ra, stream_, k_, v_, d_cell_));
             } else {
                 // small-batch step: K rope + KV store in one small kernel; q is rotated inside the attention kernel
                 HIP_TRY(launch_kv_store_fast(k_, v_, T, G, D, rope_cs_, ra, d_cell_, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
@@ -1305,6 +1314,15 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     // continuous-batching steps (a few tokens, usually one per sequence): each token scans only the 64-cell chunks that
     // hold cells of its own sequence instead of the whole cache
     chunk_lmax_ = 0;
+    batch_distinct_ = n >= 2 && n <= 64;                       // every token in exactly one sequence, no two in the same one (a continuous-batching step)
+    {
+        uint64_t seen = 0;
+        for (int i = 0; i < n && batch_distinct_; i++) {
+            const uint64_t mk = seqmask[i];
+            if (mk == 0 || (mk & (mk - 1)) != 0 || (seen & mk) != 0) batch_distinct_ = false;
+            seen |= mk;
+        }
+    }
     bool lists_usable = false;                                 // only the split-per-chunk attention kernels walk the lists
     {
         const HParams &hp = model->hp;

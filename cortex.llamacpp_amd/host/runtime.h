@@ -93,6 +93,7 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
 };
 
 void set_moe_group_min(int tokens);   // tests: batch size from which a mixture-of-experts feed-forward is grouped by expert
+void set_attn_store_fuse(bool on);   // tests: 0 = batched steps store K / V in their own launch before the attention
 void set_decode_mega(bool on);   // tests: compare the whole-step kernel with the per-launch path (read when a context first decodes one token)
 
 class Context {
@@ -191,6 +192,7 @@ class Context {
     int prep_K_ = 0, prep_T_ = 0;
     hipError_t ensure_prep(const ActQuant &aq, int K, int T);
     void prep_written(const ActQuant &aq, int K, int T) { prep_owner_ = aq.qs; prep_K_ = K; prep_T_ = T; }
+    bool batch_distinct_ = false;                    // the micro-batch is one token each of different sequences (decode_ubatch)
     const int8_t *bh_over_ = nullptr, *bl_over_ = nullptr;   // linear(): block-sum planes prepared by the caller for a slice of a larger batch
     float *att_part_ = nullptr;
     size_t att_part_floats_ = 0;

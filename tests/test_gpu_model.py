@@ -153,6 +153,47 @@ def test_logits_do_not_depend_on_the_sequence_region(be, pkg, tmp_models, cfg, g
     m.close()
 
 
+@pytest.mark.parametrize("kv", [8, 1])
+def test_batched_step_stores_kv_inside_the_attention_launch(be, pkg, tmp_models, kv):
+    """A continuous-batching step (one token each of different sequences) rotates and stores its K / V rows inside the attention
+    launch - the workgroup whose chunk holds a token's new cell writes it - instead of in a launch of its own before it.  Five
+    sequences with prompts of different lengths, 70 batched steps (the cells cross chunk boundaries), q8_0 and f16 cache: the
+    same bits as with the separate store; a step with two tokens of ONE sequence keeps the separate store (the second token
+    reads the first one's cell) and agrees with two single-token steps' cache content."""
+    path = make(pkg, tmp_models, "tiny-g8", "q4_k_m")
+    m = pkg.Model(path)
+    rng = np.random.default_rng(21)
+    lens = [30, 5, 64, 17, 41]
+    prompts = [rng.integers(0, m.n_vocab, n) for n in lens]
+
+    def run(fuse):
+        be.set_option("attn_store_fuse", fuse)
+        try:
+            c = pkg.Context(m, n_ctx=2048, n_seq_max=8, type_k=kv, type_v=kv)
+            for sq, p in enumerate(prompts):
+                assert c.decode(p, np.arange(len(p)), seq=[sq] * len(p)) == 0
+            toks = [int(p[-1]) for p in prompts]
+            rows = []
+            for step in range(70):
+                assert c.decode(toks, [n + step for n in lens], seq=list(range(5)), logits=[1] * 5) == 0
+                lg = np.stack([c.logits(i).copy() for i in range(5)])
+                rows.append(lg)
+                toks = [int(r.argmax()) for r in lg]
+            # two tokens of one sequence in one step (not a distinct-sequence batch)
+            assert c.decode([toks[0], toks[1]], [lens[0] + 70, lens[0] + 71], seq=[0, 0], logits=[1, 1]) == 0
+            rows.append(np.stack([c.logits(0).copy(), c.logits(1).copy()]))
+            c.close()
+        finally:
+            be.set_option("attn_store_fuse", 1)
+        return rows
+
+    a, b = run(1), run(0)
+    for x, y in zip(a, b):
+        assert np.isfinite(x).all()
+        assert np.array_equal(x, y)
+    m.close()
+
+
 @pytest.mark.parametrize("kv", ["q8_0", "f16"])
 @pytest.mark.parametrize("graphs", [True, False])
 def test_mega_step_matches_per_launch_bitwise(be, pkg, tmp_models, kv, graphs):
