@@ -554,6 +554,79 @@ __global__ __launch_bounds__(256) void kv_store_fast_kernel(const float *k, cons
     }
 }
 
+// Prompt batches: the same K / V part (grid row y >= q_parts) plus the rotation of q in place (rows y < q_parts, 1024 elements of the
+// token's H * D each), four consecutive elements = two rope pairs per thread.  Same arithmetic as rope_kv_store_kernel (one workgroup per
+// token, one element per thread and pass, byte stores into a q8_0 cache: 14 us per layer at 512 tokens against 6).
+template <int TK, int TV>
+__global__ __launch_bounds__(256) void rope_q_kv_store_fast_kernel(float *q, int HD, int q_parts, const float *k, const float *v, int GD, int D,
+                                                                   const float *cs_table, int n_rot, const int32_t *tok_cell, KVLayerView kv, int n_ctx) {
+    const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    if (part < q_parts) {
+        const int e0 = part * 1024 + tid * 4;
+        const int dd = e0 % D;
+        if (dd < n_rot) {
+            float4 *qp = reinterpret_cast<float4 *>(q + (size_t)t * HD + e0);
+            float4 x = *qp;
+            const float4 cs = *reinterpret_cast<const float4 *>(cs_table + (size_t)t * n_rot + dd);   // c0 s0 c1 s1
+            const float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+            x.x = x0 * cs.x - x1 * cs.y; x.y = x0 * cs.y + x1 * cs.x;
+            x.z = x2 * cs.z - x3 * cs.w; x.w = x2 * cs.w + x3 * cs.z;
+            *qp = x;
+        }
+        return;
+    }
+    const int cell = tok_cell[t];
+    {
+        const int e0 = (part - q_parts) * 1024 + tid * 4;
+        float4 kk = *reinterpret_cast<const float4 *>(k + (size_t)t * GD + e0);
+        const float4 vv4 = *reinterpret_cast<const float4 *>(v + (size_t)t * GD + e0);
+        const int g = e0 / D, dd = e0 - g * D;
+        if (dd < n_rot) {
+            const float4 cs = *reinterpret_cast<const float4 *>(cs_table + (size_t)t * n_rot + dd);   // c0 s0 c1 s1
+            const float x0 = kk.x, x1 = kk.y, x2 = kk.z, x3 = kk.w;
+            kk.x = x0 * cs.x - x1 * cs.y; kk.y = x0 * cs.y + x1 * cs.x;
+            kk.z = x2 * cs.z - x3 * cs.w; kk.w = x2 * cs.w + x3 * cs.z;
+        }
+        const size_t rowi = (size_t)g * n_ctx + cell;
+        const float ka[4] = {kk.x, kk.y, kk.z, kk.w}, va[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+        if (TK == T_F16) {
+            uint2 o; o.x = (uint32_t)f2h(ka[0]) | ((uint32_t)f2h(ka[1]) << 16); o.y = (uint32_t)f2h(ka[2]) | ((uint32_t)f2h(ka[3]) << 16);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(kv.k) + rowi * D + dd) = o;
+        } else {
+            uint32_t packed; float d;
+            wave_quant_q80(ka, packed, d);
+            *reinterpret_cast<uint32_t *>(kv.k + rowi * D + dd) = packed;
+            if ((lane & 7) == 0) kv.kd[rowi * (D >> 5) + (dd >> 5)] = f2h(d);
+        }
+        if (TV == T_F16) {
+            uint2 o; o.x = (uint32_t)f2h(va[0]) | ((uint32_t)f2h(va[1]) << 16); o.y = (uint32_t)f2h(va[2]) | ((uint32_t)f2h(va[3]) << 16);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(kv.v) + rowi * D + dd) = o;
+        } else {
+            uint32_t packed; float d;
+            wave_quant_q80(va, packed, d);
+            *reinterpret_cast<uint32_t *>(kv.v + rowi * D + dd) = packed;
+            if ((lane & 7) == 0) kv.vd[rowi * (D >> 5) + (dd >> 5)] = f2h(d);
+        }
+    }
+}
+
+bool rope_q_kv_store_fast_applicable(int H, int G, int D, int type_k, int type_v, const RopeArgs &ra) {
+    return kv_store_fast_applicable(G, D, type_k, type_v, ra) && (H * D) % 1024 == 0 && D % 4 == 0;
+}
+hipError_t launch_rope_q_kv_store_fast(float *q, const float *k, const float *v, int T, int H, int G, int D, const float *cs_table, RopeArgs ra,
+                                       const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st) {
+    if (!cs_table || !rope_q_kv_store_fast_applicable(H, G, D, type_k, type_v, ra)) return hipErrorInvalidValue;
+    const int q_parts = H * D / 1024, kv_parts = G * D / 1024;
+    const dim3 grid((unsigned)T, (unsigned)(q_parts + kv_parts));
+#define RKS(TK, TV) hipLaunchKernelGGL((rope_q_kv_store_fast_kernel<TK, TV>), grid, dim3(256), 0, st, q, H * D, q_parts, k, v, G * D, D, cs_table, ra.n_rot, tok_cell, kv, n_ctx)
+    if (type_k == T_F16 && type_v == T_F16) RKS(T_F16, T_F16);
+    else if (type_k == T_Q8_0 && type_v == T_Q8_0) RKS(T_Q8_0, T_Q8_0);
+    else if (type_k == T_Q8_0 && type_v == T_F16) RKS(T_Q8_0, T_F16);
+    else RKS(T_F16, T_Q8_0);
+#undef RKS
+    return hipGetLastError();
+}
+
 bool kv_store_fast_applicable(int G, int D, int type_k, int type_v, const RopeArgs &ra) {
     return !ra.neox && (G * D) % 1024 == 0 && D % 32 == 0 && (ra.n_rot % 4) == 0 && (type_k == T_F16 || type_k == T_Q8_0) && (type_v == T_F16 || type_v == T_Q8_0);
 }

@@ -545,6 +545,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "mmq_lds_form")) { mmq_set_lds_form(value); return MI355_OK; }
     if (!strcmp(name, "mmq_ksplit")) { g_op_mmq_ksplit = value != 0; return MI355_OK; }
     if (!strcmp(name, "attn_store_fuse")) { set_attn_store_fuse(value != 0); return MI355_OK; }
+    if (!strcmp(name, "rope_fast")) { set_rope_fast(value != 0); return MI355_OK; }
     if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }

@@ -255,6 +255,10 @@ hipError_t launch_decode_mega(const MegaLayer *layers_dev, int n_layer, int kb_e
 constexpr int MEGA_PROBES_PER_LAYER = 10;  // probe (nullable): 1 + 10 * n_layer wall-clock stamps of workgroup 0: per phase (qkv, attention, wo, gate_up,
                                            // down) the end of its wait for the previous phase and its own arrival
 
+// prompt batches: rope(q) in place + rope(k) -> cache + v -> cache, vectorised (cs_table required); same results as launch_rope_kv_store
+bool rope_q_kv_store_fast_applicable(int H, int G, int D, int type_k, int type_v, const RopeArgs &ra);
+hipError_t launch_rope_q_kv_store_fast(float *q, const float *k, const float *v, int T, int H, int G, int D, const float *cs_table, RopeArgs ra,
+                                       const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);
 bool kv_store_fast_applicable(int G, int D, int type_k, int type_v, const RopeArgs &ra);
 hipError_t launch_kv_store_fast(const float *k, const float *v, int T, int G, int D, const float *cs_table, RopeArgs ra,
                                 const int32_t *tok_cell, KVLayerView kv, int type_k, int type_v, int n_ctx, hipStream_t st);

@@ -805,6 +805,8 @@ static bool store_fuse_enabled() {
     static const bool env_off = getenv("MI355_ATTN_STORE_FUSE") && getenv("MI355_ATTN_STORE_FUSE")[0] == '0';
     return g_store_fuse && !env_off;
 }
+static bool g_rope_fast = true;
+void set_rope_fast(bool on) { g_rope_fast = on; }
 void set_decode_mega(bool on) { g_decode_mega = on ? 1 : 0; }
 
 // Builds the per-layer phase descriptors of decode_mega.hip: the same MMVQArgs the per-launch path passes to
@@ -978,7 +980,11 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_flash_attn_decode(aa, rope_cs_, ra, stream_));
             }
         } else {
-            HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
+            static const bool rope_fast = !(getenv("MI355_ROPE_FAST") && getenv("MI355_ROPE_FAST")[0] == '0');
+            if (rope_fast && g_rope_fast && rope_cs_ && rope_q_kv_store_fast_applicable(H, G, D, cp.type_k, cp.type_v, ra))
+                HIP_TRY(launch_rope_q_kv_store_fast(q_, k_, v_, T, H, G, D, rope_cs_, ra, d_cell_, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, stream_));
+            else
+                HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
             prof_mark("rope_kv");
             aa.splits = att_splits_;
             // (splits balance the causal tiles of ONE long sequence: sized by what a query of this batch can see - its position + 1 -

@@ -94,6 +94,7 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
 
 void set_moe_group_min(int tokens);   // tests: batch size from which a mixture-of-experts feed-forward is grouped by expert
 void set_attn_store_fuse(bool on);   // tests: 0 = batched steps store K / V in their own launch before the attention
+void set_rope_fast(bool on);         // tests: 0 = prompt batches rotate q / store K, V with the one-workgroup-per-token kernel
 void set_decode_mega(bool on);   // tests: compare the whole-step kernel with the per-launch path (read when a context first decodes one token)
 
 class Context {

@@ -153,6 +153,35 @@ def test_logits_do_not_depend_on_the_sequence_region(be, pkg, tmp_models, cfg, g
     m.close()
 
 
+@pytest.mark.parametrize("cfg,kv", [("tiny-g8", 8), ("tiny-g8", 1), ("tiny-8b-2l", 8)])
+def test_prompt_rope_and_kv_store_vectorised(be, pkg, tmp_models, cfg, kv):
+    """Prompt batches rotate q in place and rotate / quantise / store K and V four elements per thread (a grid row per 1024
+    elements of a token) instead of one workgroup per token with byte stores: the same bits in q and in the cache - logits of the
+    prompt and of ten decode steps over that cache are identical."""
+    path = make(pkg, tmp_models, cfg, "q4_k_m")
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(23).integers(0, m.n_vocab, 150)
+
+    def run(fast):
+        be.set_option("rope_fast", fast)
+        try:
+            c = pkg.Context(m, n_ctx=512, type_k=kv, type_v=kv)
+            assert c.decode(prompt, np.arange(150)) == 0
+            rows = [c.logits().copy()]
+            for s_ in range(10):
+                assert c.decode([int(rows[-1].argmax())], [150 + s_]) == 0
+                rows.append(c.logits().copy())
+            c.close()
+        finally:
+            be.set_option("rope_fast", 1)
+        return np.stack(rows)
+
+    a, b = run(1), run(0)
+    assert np.isfinite(a).all()
+    assert np.array_equal(a, b)
+    m.close()
+
+
 @pytest.mark.parametrize("kv", [8, 1])
 def test_batched_step_stores_kv_inside_the_attention_launch(be, pkg, tmp_models, kv):
     """A continuous-batching step (one token each of different sequences) rotates and stores its K / V rows inside the attention
