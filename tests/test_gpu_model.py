@@ -110,6 +110,37 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
         oq.set_fa_v_acc_f32(0)
 
 
+@pytest.mark.parametrize("cfg,ftype,kv,n_prompt,ubatch", [("tiny-d128", "q4_k_m", "q8_0", 300, 512), ("tiny-d128-mha", "q5_k_m", "f16", 300, 512),
+                                                          ("tiny-g8", "q4_k_m", "q8_0", 330, 512), ("tiny-d128", "q4_k_m", "q8_0", 300, 128),
+                                                          ("tiny-d128-mha", "q4_k_m", "q8_0", 200, 64)])
+def test_long_prompt_logits_match_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt, ubatch):
+    """Prompts of a few hundred tokens against the CPU restatement: the matrix-core prompt attention with several query tiles,
+    its two key halves per workgroup, the query sub-tiles of one- and two-head kv groups (R = 1: four, R = 2: two), key splits across
+    workgroups, and micro-batches that attend to the cells of earlier ones; the last-layer output of every token and the logits."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
+    try:
+        m, c, om, oc = open_pair(pkg, path, 512, kv, n_ubatch=ubatch)
+        prompt = np.random.default_rng(31).integers(0, m.n_vocab, n_prompt)
+        c.enable_taps(True)
+        assert c.decode(prompt, np.arange(n_prompt)) == 0
+        ref = oc.decode(prompt, np.arange(n_prompt))[0]
+        if ubatch >= n_prompt:                                # (the taps hold one micro-batch)
+            # first layer, per token: a rounding flip of one K / V code reaches the tokens after it through the attention, so the
+            # bulk of the tokens - not every one - agrees to f32 round-off; the last layer within the flip tolerance
+            for il, tight in ((0, kv != "f16"), (m.n_layer - 1, False)):
+                a0 = c.layer_out(il, n_prompt).reshape(n_prompt, -1)
+                b0 = oc.layer_out(il, n_prompt).reshape(n_prompt, -1)
+                tok_err = np.abs(a0 - b0).max(axis=1) / max(1.0, float(np.abs(b0).max()))
+                assert float(tok_err.max()) <= FLIP_TOL, (il, int(tok_err.argmax()), float(tok_err.max()))
+                if tight:
+                    assert float(np.median(tok_err)) <= TIGHT_TOL, (il, float(np.median(tok_err)), tok_err[:40])
+        assert rel_err(c.logits(), ref) <= FLIP_TOL
+        c.close(); m.close(); oc.close(); om.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
+
+
 def test_f16_cache_vs_stock_fp16_accumulation(be, pkg, tmp_models):
     """Against the unmodified CPU restatement (V accumulated in fp16) the f16-cache path agrees to the noise level of
     that fp16 accumulation (measured CPU-vs-CPU: ~1e-2)."""
