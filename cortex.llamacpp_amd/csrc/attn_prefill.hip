@@ -53,6 +53,18 @@ struct Chunk {
     unsigned long long *cseq;   // [CK]
 };
 
+// max / sum of a value with its copy in lane ^ 32 (the two lanes of a query): v_permlane32_swap hands each half of the wave the other
+// half's registers in one VALU instruction - no LDS round trip (ds_bpermute) on the softmax's dependent chain.  Both lanes get the same bits
+// as x op x[lane ^ 32] (the operations commute).
+__device__ __forceinline__ float xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // key index (0..31) of MFMA K-slot (j, kg, i): the order the score tile leaves its 16 keys per lane in registers
 __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 8 * (i >> 2) + 4 * kg + (i & 3); }
 
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
             float am = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; i++) am = fmaxf(am, fmaxf(fmaxf(fabsf(x[i].x), fabsf(x[i].y)), fmaxf(fabsf(x[i].z), fabsf(x[i].w))));
-            am = fmaxf(am, __shfl_xor(am, 32, 64));            // the other half of the block lives in lane ^ 32
+            am = xhalf_max(am);                                // the other half of the block lives in lane ^ 32
             const float d = am / 127.0f;
             const float id = d != 0.0f ? 1.0f / d : 0.0f;
             int w[4];
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
                     mloc = fmaxf(mloc, sc[r]);
                 }
             }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            mloc = xhalf_max(mloc);
             const float m_new = fmaxf(m_run, mloc);
             const float m_ref = m_new == -INFINITY ? 0.0f : m_new;           // (nothing visible yet: exp2(-inf - 0) = 0, no NaN)
             float p[16], lsum = 0.0f;
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
                 p[r] = __builtin_amdgcn_exp2f(sc[r] - m_ref);
                 lsum += p[r];
             }
-            lsum += __shfl_xor(lsum, 32, 64);
+            lsum = xhalf_sum(lsum);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);        // m_run = -inf: 0
             l_run = l_run * alpha + lsum;
             m_run = m_new;
