@@ -112,7 +112,10 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
 
 @pytest.mark.parametrize("cfg,ftype,kv,n_prompt,ubatch", [("tiny-d128", "q4_k_m", "q8_0", 300, 512), ("tiny-d128-mha", "q5_k_m", "f16", 300, 512),
                                                           ("tiny-g8", "q4_k_m", "q8_0", 330, 512), ("tiny-d128", "q4_k_m", "q8_0", 300, 128),
-                                                          ("tiny-d128-mha", "q4_k_m", "q8_0", 200, 64)])
+                                                          ("tiny-d128-mha", "q4_k_m", "q8_0", 200, 64),
+                                                          # Llama-3-8B's layer shapes at 130 tokens: gate | up (>= 8192 rows) on the LDS-form SwiGLU launch,
+                                                          # Q | K | V, attn_output and ffn_down on the K-split kernel (kernel choice by shape)
+                                                          ("tiny-8b-2l", "q4_k_m", "q8_0", 130, 512)])
 def test_long_prompt_logits_match_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt, ubatch):
     """Prompts of a few hundred tokens against the CPU restatement: the matrix-core prompt attention with several query tiles,
     its two key halves per workgroup, the query sub-tiles of one- and two-head kv groups (R = 1: four, R = 2: two), key splits across
