@@ -65,6 +65,7 @@ size_t mmvq_fast_plan(MMVQArgs &a, int blocks, int waves);
 // single-token weight-stream form (mmvq_stream.hip): HBM -> LDS DMA rings, bit-identical to the fast path
 void mmvq_set_stream(bool on);                            // tests: route single-token mat-vecs to mmvq_fast instead
 bool mmvq_stream_applicable(const MMVQArgs &a);
+void mmvq_stream_set_anyorder_for_timing(bool on);   // tools/exp_stream.hip only: barrier-less dispatch, results undefined
 hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st);
 
 void set_num_cu(int n);

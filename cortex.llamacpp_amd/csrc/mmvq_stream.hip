@@ -34,6 +34,7 @@
 // streams with in-kernel waits (HIP promises no dispatch order between graph branches: the graph form deadlocks).
 // Weight stream policy: non-temporal (each byte is read once per token).
 #include "mmvq_fast_dev.h"
+#include <hip/hip_ext.h>
 
 namespace mi355 {
 
@@ -42,7 +43,10 @@ namespace {
 constexpr int ST_NL = 2;                        // loader waves (the first waves of the workgroup)
 constexpr int ST_NC = 8;                        // consumer waves: the wave count the prologue of mmvq_fast is cut for
 constexpr int ST_NW = ST_NL + ST_NC, ST_NT = ST_NW * 64;
-constexpr int ST_RING = 131072;                 // bytes, a power of two (ring offsets wrap with a mask)
+#ifndef MI355_ST_RING
+#define MI355_ST_RING 131072                    // (tools/exp_stream.hip builds a 64 KiB variant: two workgroups per CU)
+#endif
+constexpr int ST_RING = MI355_ST_RING;          // bytes, a power of two (ring offsets wrap with a mask)
 constexpr unsigned ST_MASK = ST_RING - 1;
 constexpr int ST_SI = 4;                        // DMA instructions (1 KiB each) per slot
 constexpr int ST_SLOT = ST_SI * 1024;           // unit of publication; global slot g lives at ring offset g * 4 KiB mod ring,
@@ -623,6 +627,12 @@ static void stream_plan(MMVQArgs &a, int max_blocks) {
     if (swiglu) a.n_seg = 1;
 }
 
+// tools/exp_stream.hip ONLY: dispatch without the barrier behind the previous launch of the stream.  Nothing makes a launch wait for the
+// results of its predecessor then - the harness uses it to price what overlapping a launch's ramp with its predecessor's tail could gain
+// at most (the numbers it computes that way are garbage).
+static bool g_stream_anyorder = false;
+void mmvq_stream_set_anyorder_for_timing(bool on) { g_stream_anyorder = on; }
+
 hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     if (!mmvq_stream_applicable(a)) return hipErrorInvalidValue;
     const int kb = (a.K + 2047) >> 11;
@@ -637,7 +647,8 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
             if (e != hipSuccess) return e;                                                                               \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                       \
+        if (g_stream_anyorder) hipExtLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a); \
+        else hipLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                  \
     } while (0)
 #define STREAM_F(KBV) do { if (a.fuse_mode == 0) STREAM(KBV, 0); else if (a.fuse_mode == 1) STREAM(KBV, 1); else STREAM(KBV, 2); } while (0)
     switch (kb) {

@@ -19,6 +19,10 @@ namespace mi355 { void mmvq_stream_set_probe(unsigned long long *p); }
 #define MI355_STREAM_NL 2
 #endif
 
+#ifndef MI355_ST_RING
+#define MI355_ST_RING 131072
+#endif
+#define MI355_ST_RING_KIB (MI355_ST_RING / 1024)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 static uint8_t *dev_rand_bytes(size_t n, unsigned seed, int mask) {
@@ -233,6 +237,29 @@ int main(int argc, char **argv) {
             CK(launch_mmvq_stream(make_args(qkv, l, qkv.out_b), st)); CK(launch_mmvq_stream(make_args(o, l, o.out_b), st));
             CK(launch_mmvq_stream(make_args(gu, l, gu.out_b), st)); CK(launch_mmvq_stream(make_args(dn, l, dn.out_b), st)); } }, 4 * NL);
         printf("%-42s %10.2f %10.2f   %8.0f %8.0f   (%.1f MB per layer, no attention)\n", "layer chain: qkv, o, gate/up, down", ta, tb, layer_bytes / ta * 1e-3, layer_bytes / tb * 1e-3, layer_bytes / 1e6);
+    }
+    // the same chain launched eagerly, with and without the barrier between launches (hipExtAnyOrderLaunch; a stream capture drops the flag).
+    // Barrier-less, NOTHING orders a launch behind its predecessor's results: the time is an upper bound of what hiding a launch's ramp under
+    // its predecessor's tail could gain (with the 64 KiB-ring build, exp_stream_r64, two workgroups fit a CU, so a successor can enter early)
+    {
+        Op &qkv = ops[0], &o = ops[2], &gu = ops[3], &dn = ops[4];
+        auto time_eager = [&](bool anyorder) {
+            mmvq_stream_set_anyorder_for_timing(anyorder);
+            auto body = [&] { for (int r = 0; r < 4; r++) for (int l = 0; l < NL; l++) {
+                CK(launch_mmvq_stream(make_args(qkv, l, qkv.out_b), st)); CK(launch_mmvq_stream(make_args(o, l, o.out_b), st));
+                CK(launch_mmvq_stream(make_args(gu, l, gu.out_b), st)); CK(launch_mmvq_stream(make_args(dn, l, dn.out_b), st)); } };
+            for (int i = 0; i < 3; i++) body();
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; i++) body();
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            mmvq_stream_set_anyorder_for_timing(false);
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            return (double)ms * 1e3 / iters / (4 * NL);
+        };
+        const double t_bar = time_eager(false), t_any = time_eager(true);
+        printf("%-42s %10.2f %10.2f   (us per layer of four launches, ring %d KiB; barrier-less: unordered, an upper bound)\n", "eager chain: with barrier / barrier-less", t_bar, t_any,
+               MI355_ST_RING_KIB);
     }
 #ifdef MI355_STREAM_PROBE
     {   // timeline of the stream kernels of one layer in the middle of a 3-layer chain (100 MHz wall clock)
