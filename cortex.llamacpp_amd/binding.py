@@ -76,6 +76,7 @@ SYMBOLS = {
     "mi355_get_logits_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_get_argmax_ith": (_i32, [_vp, _i32]),
     "mi355_debug_mega_steps": (C.c_int64, [_vp]),
+    "mi355_debug_engine_steps": (C.c_int64, [_vp]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
     "mi355_get_embeddings_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_synchronize": (None, [_vp]),
@@ -94,6 +95,7 @@ SYMBOLS = {
     "mi355_op_get_rows": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _vp]),
     "mi355_op_swiglu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mi355_op_soft_max": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
+    "mi355_op_moe_route": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mi355_op_flash_attn": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp]),
     "mi355_bench_hbm_read": (C.c_double, [_sz, C.c_int]),
     "mi355_profile_last_decode": (_i32, [_vp, C.POINTER(_cp), C.POINTER(_f32), _i32]),
@@ -114,6 +116,11 @@ SYMBOLS = {
     "mi355_engine_handle_embedding": (None, [_vp, _cp, ENGINE_CB, _vp]),
     "mi355_engine_is_supported": (_i32, [_vp, _cp]),
     "mi355_engine_stop_inferencing": (None, [_vp, _cp]),
+    "mi355_engine_load": (None, [_vp, _cp, _cp, _i32, _cp, _i32, _i32]),
+    "mi355_engine_unload": (None, [_vp]),
+    "mi355_engine_set_file_logger": (None, [_vp, _i32, _cp]),
+    "mi355_engine_set_log_level": (None, [_vp, _i32]),
+    "mi355_engine_set_log_callback": (None, [_vp, _vp, _vp]),
     "mi355_tp_unique_id": (C.c_int, [_vp, _sz]),
     "mi355_tp_init": (C.c_int, [_i32, _i32, _i32, _vp, _sz]),
     "mi355_tp_shutdown": (None, []),
@@ -240,6 +247,13 @@ class Backend:
         y = np.zeros_like(x)
         self._chk(self.lib.mi355_op_soft_max(_ptr(x), _ptr(m), n, rows, scale, _ptr(y)), "op_soft_max")
         return y
+
+    def moe_route(self, logits: np.ndarray, k: int):
+        x = np.ascontiguousarray(logits, np.float32)
+        T, ne = x.shape
+        ids = np.zeros((T, k), np.int32); w = np.zeros((T, k), np.float32)
+        self._chk(self.lib.mi355_op_moe_route(_ptr(x), T, ne, k, _ptr(ids), _ptr(w)), "op_moe_route")
+        return ids, w
 
     def flash_attn(self, q: np.ndarray, n_head: int, n_head_kv: int, hd: int, type_k: int, k_rows: np.ndarray, type_v: int,
                    v_rows: np.ndarray, cell_pos, q_pos, scale: float) -> np.ndarray:
@@ -442,6 +456,10 @@ class Context:
     def mega_steps(self) -> int:
         """Single-token steps that ran as one whole-step launch (diagnosis)."""
         return int(self.lib.mi355_debug_mega_steps(self.h))
+
+    def engine_steps(self) -> int:
+        """Single-token steps that ran through the layer engine (one persistent launch per layer; diagnosis)."""
+        return int(self.lib.mi355_debug_engine_steps(self.h))
 
     def synchronize(self):
         self.lib.mi355_synchronize(self.h)

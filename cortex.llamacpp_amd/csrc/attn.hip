@@ -109,9 +109,10 @@ hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *
 // the two tiny launches that open every micro-batch as one: the cos/sin table (above) and the cell metadata of the
 // batch's tokens (launch_kv_meta_set below); ~5 us of a 1.7 ms single-token step each
 __global__ void step_setup_kernel(const int32_t *tok_pos, int T, RopeArgs ra, float theta_scale, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq,
-                                  const int32_t *tok_cell, const uint64_t *tok_seqmask, unsigned *zero_word) {
+                                  const int32_t *tok_cell, const uint64_t *tok_seqmask, unsigned *zero_word, unsigned *epoch_word) {
     if (blockIdx.x == 0) {
         if (zero_word && threadIdx.x < 9) zero_word[threadIdx.x == 0 ? 0 : 32 * threadIdx.x] = 0u;   // barrier counters of the whole-step kernel (decode_mega.hip)
+        if (epoch_word && threadIdx.x == 0) epoch_word[0] = epoch_word[0] + 1u;                       // step serial (decode_engine.hip)
         for (int t = threadIdx.x; t < T; t += blockDim.x) {
             cell_pos[tok_cell[t]] = tok_pos[t];
             cell_seq[tok_cell[t]] = tok_seqmask[t];
@@ -127,11 +128,11 @@ __global__ void step_setup_kernel(const int32_t *tok_pos, int T, RopeArgs ra, fl
     cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
 }
 hipError_t launch_step_setup(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
-                             const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st) {
+                             const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st, unsigned *epoch_word) {
     const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
     const int n = T * (ra.n_rot >> 1);
     hipLaunchKernelGGL(step_setup_kernel, dim3(n > 0 ? (n + 63) / 64 : 1), dim3(64), 0, st, tok_pos, T, ra, theta_scale, cs_out, cell_pos, cell_seq, tok_cell,
-                       tok_seqmask, zero_word);
+                       tok_seqmask, zero_word, epoch_word);
     return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@
 
 #include "../host/engine.h"
 #include "../host/hip_backend.h"
+#include "../host/log.h"
 #include "../host/runtime.h"
 #include "../host/tp_comm.h"
 #include "../host/vocab.h"
@@ -209,6 +210,7 @@ int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
 float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
 int64_t mi355_debug_mega_steps(const mi355_context *ctx) { return ctx->c->mega_steps; }
+int64_t mi355_debug_engine_steps(const mi355_context *ctx) { return ctx->c->engine_steps; }
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0; }
 float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
@@ -470,6 +472,17 @@ int mi355_op_soft_max(const float *x, const float *mask, int64_t n, int64_t rows
     return dy.down(y, nb) ? MI355_OK : MI355_ERR_HIP;
 }
 
+int mi355_op_moe_route(const float *logits, int64_t T, int32_t n_expert, int32_t k, int32_t *ids, float *w) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    if (T <= 0 || n_expert <= 0 || n_expert > 64 || k <= 0 || k > n_expert) { fail("moe_route: bad shape"); return MI355_ERR_ARG; }
+    DevBuf dl((size_t)T * n_expert * 4), di((size_t)T * k * 4), dw((size_t)T * k * 4);
+    if (!dl.up(logits, (size_t)T * n_expert * 4) || !di.p || !dw.p) return MI355_ERR_OOM;
+    hipError_t e = launch_moe_route(dl.as<float>(), (int)T, n_expert, k, di.as<int32_t>(), dw.as<float>(), nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "moe_route");
+    return di.down(ids, (size_t)T * k * 4) && dw.down(w, (size_t)T * k * 4) ? MI355_OK : MI355_ERR_HIP;
+}
+
 int mi355_op_flash_attn(const float *q, int64_t T, int32_t H, int32_t G, int32_t D, int32_t type_k, const void *k, int32_t type_v,
                         const void *v, int32_t n_cells, const int32_t *cell_pos, const int32_t *q_pos, float scale, float *out) {
     if (!need_device()) return MI355_ERR_NO_DEVICE;
@@ -547,6 +560,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "attn_store_fuse")) { set_attn_store_fuse(value != 0); return MI355_OK; }
     if (!strcmp(name, "rope_fast")) { set_rope_fast(value != 0); return MI355_OK; }
     if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
+    if (!strcmp(name, "decode_engine")) { set_decode_engine(value); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
     if (!strcmp(name, "tp_null_group")) { tp_set_null_group(0, value); return MI355_OK; }
@@ -675,5 +689,22 @@ MI355_ENGINE_FWD(mi355_engine_handle_embedding, HandleEmbedding)
 #undef MI355_ENGINE_FWD
 int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature) { return e && feature && e->eng.IsSupported(feature) ? 1 : 0; }
 void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id) { if (e && model_id) e->eng.StopInferencing(model_id); }
+void mi355_engine_load(mi355_engine *e, const char *engine_path, const char *deps_path, int32_t is_custom_engine_path, const char *log_path, int32_t max_log_lines,
+                       int32_t log_level) {
+    if (!e) return;
+    MI355_GUARD(return, {
+        LlamaEngine::EngineLoadOption o;
+        o.engine_path = engine_path ? engine_path : ""; o.deps_path = deps_path ? deps_path : ""; o.is_custom_engine_path = is_custom_engine_path != 0;
+        o.log_path = log_path ? log_path : ""; o.max_log_lines = max_log_lines; o.log_level = log_level;
+        e->eng.Load(o);
+        return;
+    })
+}
+void mi355_engine_unload(mi355_engine *e) { if (e) { MI355_GUARD(return, { e->eng.Unload(); return; }) } }
+void mi355_engine_set_file_logger(mi355_engine *e, int32_t max_log_lines, const char *log_path) {
+    if (e) { MI355_GUARD(return, { e->eng.SetFileLogger(max_log_lines, log_path ? log_path : ""); return; }) }
+}
+void mi355_engine_set_log_level(mi355_engine *e, int32_t log_level) { if (e) e->eng.SetLogLevel(log_level); }
+void mi355_engine_set_log_callback(mi355_engine *e, mi355_log_callback cb, void *user) { (void)e; log_set_callback(cb, user); }
 
 }  // extern "C"

@@ -68,6 +68,26 @@ bool mmvq_stream_applicable(const MMVQArgs &a);
 void mmvq_stream_set_anyorder_for_timing(bool on);   // tools/exp_stream.hip only: barrier-less dispatch, results undefined
 hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st);
 
+// workgroup ranges per segment for a grid of `blocks` workgroups, in proportion to the segments' bytes (what launch_mmvq_stream works out for its own launch)
+void mmvq_stream_plan(MMVQArgs &a, int blocks);
+// the sticky error word of the weight-stream kernels (pinned host memory, or nullptr): a bounded wait that gives up ORs a code into it
+void mmvq_stream_set_error_word(unsigned *w);
+
+// ---------------------------------------------------------------- one decoder layer's mat-vecs in one persistent launch (decode_engine.hip)
+// attn_output -> gate | up -> down -> the next layer's Q | K | V, hand-overs through tagged granules; descriptors in device memory, each planned with
+// mmvq_stream_plan(.., num_cu()).  has_qkv = 0: the launch ends behind ffn_down (last layer).
+struct EngineLayer {
+    MMVQArgs wo, gu, dn, qkv;
+    int has_qkv;
+};
+bool decode_engine_applicable(const EngineLayer &l, int E, int FF);   // on UNPLANNED descriptors (as launch_mmvq_stream would get them)
+void decode_engine_plan(EngineLayer &l);                                // mmvq_stream_plan of the four mat-vecs for num_cu() workgroups
+size_t decode_engine_granule_words(int E, int FF);          // 8-byte words of hand-over space a context needs
+void decode_engine_set_error_word(unsigned *w);
+// epoch_dev: device word holding the step serial (changes every step: step_setup); probe: nullable, num_cu() * 10 * 32 stamps
+hipError_t launch_decode_engine(const EngineLayer *layer_dev, int E, int FF, unsigned long long *granules, const unsigned *epoch_dev, int layer_index,
+                                unsigned long long *probe, hipStream_t st);
+
 void set_num_cu(int n);
 int num_cu();
 
@@ -188,8 +208,9 @@ hipError_t launch_rope_kv_store(float *q, const float *k, const float *v, int T,
 // cos/sin of every token of the micro-batch: cs_out[T][n_rot] (pairs c,s), reused by all layers
 hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, hipStream_t st);
 // launch_rope_table + launch_kv_meta_set (below) in one launch
+// epoch_word (nullable): device word incremented once per call - the step serial the hand-over tags of decode_engine.hip are built from
 hipError_t launch_step_setup(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
-                             const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st);
+                             const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st, unsigned *epoch_word = nullptr);
 hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t *tok_pos, RopeArgs ra, hipStream_t st);
 
 struct AttnArgs {

@@ -33,499 +33,11 @@
 // HBM, so each hand-over costs 6-8 us where a kernel boundary costs 1.5.  Also dropped: launches chained across two
 // streams with in-kernel waits (HIP promises no dispatch order between graph branches: the graph form deadlocks).
 // Weight stream policy: non-temporal (each byte is read once per token).
-#include "mmvq_fast_dev.h"
-#include <hip/hip_ext.h>
+#include "mmvq_stream_dev.h"
 
 namespace mi355 {
 
 namespace {
-
-constexpr int ST_NL = 2;                        // loader waves (the first waves of the workgroup)
-constexpr int ST_NC = 8;                        // consumer waves: the wave count the prologue of mmvq_fast is cut for
-constexpr int ST_NW = ST_NL + ST_NC, ST_NT = ST_NW * 64;
-#ifndef MI355_ST_RING
-#define MI355_ST_RING 131072                    // (tools/exp_stream.hip builds a 64 KiB variant: two workgroups per CU)
-#endif
-constexpr int ST_RING = MI355_ST_RING;          // bytes, a power of two (ring offsets wrap with a mask)
-constexpr unsigned ST_MASK = ST_RING - 1;
-constexpr int ST_SI = 4;                        // DMA instructions (1 KiB each) per slot
-constexpr int ST_SLOT = ST_SI * 1024;           // unit of publication; global slot g lives at ring offset g * 4 KiB mod ring,
-constexpr int ST_RING_SLOTS = ST_RING / ST_SLOT;   // loader q copies the slots g = q mod 2
-#ifndef MI355_STREAM_DEPTH
-#define MI355_STREAM_DEPTH 12
-#endif
-constexpr int ST_D = MI355_STREAM_DEPTH;        // slots in flight per loader (4 .. 15 measured alike); together with the activation-plane
-                                                // pieces never more than 60 of the 63 vector-memory operations a wave's counter can count
-constexpr int ST_MAX_STEP = 16384;              // bytes one decode step may span (a row, a row pair or one row of a gate/up pair)
-constexpr int ST_PAIR_MAX = 12288;              // rows are decoded two at a time up to this many bytes per pair
-
-// ---- the DMA.  M0 = LDS byte address of the 64-lane destination (lane l lands at M0 + 16 l); saved and restored inside
-// the statement (hipcc does not preserve M0 around asm and does not expect it changed).
-template <bool NTL> __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    if (NTL) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                          : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// one whole slot: lane l copies 16 B from g, g + 1 KiB, g + 2 KiB, g + 3 KiB; the instruction offset applies to the global
-// AND to the LDS address (piece i lands at M0 + i KiB + 16 l)
-__device__ __forceinline__ void dma_slot(const void *g, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off nt\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:2048 nt\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:3072 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(N) : "memory"); }
-#ifdef MI355_STREAM_PROBE
-// tools/exp_stream.hip: per wave, 100 MHz wall-clock stamps and accumulated waits (single-op launches)
-__device__ unsigned long long *g_stream_probe = nullptr;
-#define ST_SLOTP(i) g_stream_probe[(((size_t)(a.nck >> 2) * 256 + blockIdx.x) * ST_NW + wave) * 8 + (i)]
-#define ST_STAMP(i) do { if (g_stream_probe && lane == 0) ST_SLOTP(i) = wall_clock64(); } while (0)
-#define ST_ACC_DECL unsigned long long st_t0 = 0, st_acc_w = 0, st_acc_d = 0
-#define ST_T0() do { st_t0 = wall_clock64(); } while (0)
-#define ST_ACC(x) do { const unsigned long long t_ = wall_clock64(); x += t_ - st_t0; st_t0 = t_; } while (0)
-#define ST_ACC_OUT() do { if (g_stream_probe && lane == 0) { ST_SLOTP(3) = st_acc_w; ST_SLOTP(6) = st_acc_d; } } while (0)
-#else
-#define ST_STAMP(i) do { } while (0)
-#define ST_ACC_DECL do { } while (0)
-#define ST_T0() do { } while (0)
-#define ST_ACC(x) do { } while (0)
-#define ST_ACC_OUT() do { } while (0)
-#endif
-__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // low half of a flat LDS address = LDS byte offset
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// words shared by the waves of the workgroup (LDS is coherent inside a CU; every access is a real ds instruction)
-__device__ __forceinline__ int ld_sync(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void st_sync(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// ---- decoders reading a row out of the ring.  `base` = ring byte offset of the mat-vec's first slot; `x` = byte offset in
-// the workgroup's run of the tensor.  One tensor: run byte x is ring byte base + x.  IL (gate/up): gate slot j and up slot
-// j alternate in the ring (loader 0 streams the gate run, loader 1 the up run), so run byte x of tensor t is ring byte
-// base + 4096 * (2 * (x / 4096) + t) + x % 4096; t is folded into base.  Everything is 16-B granular: a piece never
-// straddles a slot or the wrap.  Same fields as Raw<TYPE>::load of mmvq_fast_dev.h.
-template <bool IL> __device__ __forceinline__ const uint8_t *ring_at(const uint8_t *ring, unsigned base, unsigned x) {
-    const unsigned o = IL ? base + ((x >> 12) << 13) + (x & 4095u) : base + x;
-    return ring + (o & ST_MASK);
-}
-#define RO(x) ring_at<IL>(ring, base, (x))
-template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q4_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
-    const unsigned b = row_off + (unsigned)sb * 144u;
-    r.hdr = lds16(RO(b));
-    r.q = lds16(RO(b + 16u + (unsigned)L.v * 16u));
-}
-template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q5_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
-    const unsigned b = row_off + (unsigned)sb * 176u;
-    r.hdr = lds16(RO(b));
-    r.qh = lds16(RO(b + 16u + (unsigned)L.h * 16u));
-    r.q = lds16(RO(b + 48u + (unsigned)L.v * 16u));
-}
-template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q6_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
-    r.ql = lds16(RO(row_off + (unsigned)sb * 128u + (unsigned)L.v * 16u));
-    r.qh = lds16(RO(row_off + (unsigned)nb * 128u + (unsigned)sb * 64u + (unsigned)L.n * 32u + (unsigned)(L.w & 1) * 16u));
-    const unsigned so = row_off + (unsigned)nb * 192u + (unsigned)sb * 16u + 8u * (unsigned)L.n + (unsigned)L.w;
-    r.sc_lo = *reinterpret_cast<const int8_t *>(RO(so));
-    r.sc_hi = *reinterpret_cast<const int8_t *>(RO(so + 4u));
-    r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + (unsigned)nb * 208u + (unsigned)sb * 2u));
-}
-template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q8_0> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
-    const unsigned b = row_off + (unsigned)sb * 256u + (unsigned)L.v * 32u;
-    r.q0 = lds16(RO(b));
-    r.q1 = lds16(RO(b + 16u));
-    r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + (unsigned)nb * 256u + ((unsigned)sb * 8u + (unsigned)L.v) * 2u));
-}
-#undef RO
-
-// ---- LDS layout (bytes from smem): sync words | reduction scratch | ring | activation of the current mat-vec
-constexpr int ST_OFF_SYNC = 0, ST_OFF_RED = 128, ST_OFF_RING = 256, ST_OFF_ACT = ST_OFF_RING + ST_RING;
-struct StLayout { int qs, d, bs, total; };
-__host__ __device__ inline StLayout st_layout(int kb) {
-    const int Kp = kb * 2048;
-    StLayout l;
-    l.qs = ST_OFF_ACT;
-    l.d = l.qs + Kp;                            // one DMA piece (1 KiB) of room: nb * 4 B of scales
-    l.bs = l.d + 1024;                          // Kp / 8 B of block sums (Q8_0: f32 block scales, Kp / 8 B too), in whole DMA pieces
-    l.total = l.bs + ((Kp / 8 + 1023) & ~1023);
-    return l;
-}
-// sync words (ints at smem): [q] slots published by loader q; [2] consumers whose own global requests are in the memory
-// queue (the loaders start after that); [8] / [12] arrivals at the two prologue rendezvous; [24 + c] consumer c: the first
-// slot it still needs
-enum { SY_LANDED = 0, SY_GO = 2, SY_PRO1 = 8, SY_PRO2 = 12, SY_FRONT = 24 };
-
-// every wait on another wave is bounded: the waves of a workgroup are always co-resident, so a healthy wait ends within microseconds; if a protocol bug ever
-// broke that, the launch still ends (with wrong numbers, which the parity tests catch) instead of hanging the device.
-#ifndef MI355_STREAM_SPIN_LIMIT
-#define MI355_STREAM_SPIN_LIMIT (1 << 21)
-#endif
-constexpr int ST_SPIN_LIMIT = MI355_STREAM_SPIN_LIMIT;
-#define ST_SPIN_WHILE(cond, sleep_arg) do { int spins_ = 0; while ((cond) && ++spins_ < ST_SPIN_LIMIT) __builtin_amdgcn_s_sleep(sleep_arg); } while (0)
-__device__ __forceinline__ void consumers_rendezvous(int *word, int lane) {
-    if (lane == 0) (void)__hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    ST_SPIN_WHILE(ld_sync(word) < ST_NC, 1);
-}
-
-// What the device code needs of one MMVQArgs, read in ONE batch of scalar loads: the kernel argument segment is cold at
-// every launch (~0.7 us per miss, tools/exp_stream.hip timeline) and hipcc loads a field where it is first used, so
-// `a.seg[s]` behind the segment choice and a.nx behind the role choice were two more serial misses.
-struct StOp {
-    int K, epi, nck, type, n_rows, b0, n_rows_wg;
-    float neps;
-    const int8_t *aq; const float *ad; const int16_t *abs;
-    const float *nx, *nw;
-    const uint8_t *W, *W1;        // this workgroup's segment; SwiGLU: W1 = the up tensor
-    float *out; const float *resid;
-    unsigned row_bytes, total;    // total = bytes of the workgroup's run of rows, per tensor
-    bool swiglu, pair;
-    int ns_raw, ns_pad;           // ring slots of the workgroup's share (gate / up slots alternate), and padded to an even count
-};
-__device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
-    const int n_seg = ka.n_seg, sb0 = ka.seg_block0[0], sb1 = ka.seg_block0[1], sb2 = ka.seg_block0[2], sb3 = ka.seg_block0[3];
-    const int K = ka.K, epi = ka.epi, nck = ka.nck;
-    const float neps = ka.neps;
-    const int8_t *aq = ka.aq; const float *ad = ka.ad; const int16_t *abs = ka.abs; const float *nx = ka.nx, *nw = ka.nw;
-    const uint8_t *w0 = ka.seg[0].W, *w1 = ka.seg[1].W, *w2 = ka.seg[2].W;
-    float *o0 = ka.seg[0].out, *o1 = ka.seg[1].out, *o2 = ka.seg[2].out;
-    const float *r0 = ka.seg[0].resid, *r1 = ka.seg[1].resid, *r2 = ka.seg[2].resid;
-    const int t0 = ka.seg[0].type, t1 = ka.seg[1].type, t2 = ka.seg[2].type;
-    const int n0 = ka.seg[0].n_rows, n1 = ka.seg[1].n_rows, n2 = ka.seg[2].n_rows;
-    const unsigned rb0 = (unsigned)ka.seg[0].row_bytes, rb1 = (unsigned)ka.seg[1].row_bytes, rb2 = (unsigned)ka.seg[2].row_bytes;
-    // (pinned: without a use here hipcc sinks each load to its first use again)
-#define PIN(x) asm volatile("" :: "s"(x))
-    PIN(n_seg); PIN(sb0); PIN(sb1); PIN(sb2); PIN(sb3); PIN(K); PIN(epi); PIN(nck); PIN(neps);
-    PIN(aq); PIN(ad); PIN(abs); PIN(nx); PIN(nw);
-    PIN(w0); PIN(w1); PIN(w2); PIN(o0); PIN(o1); PIN(o2); PIN(r0); PIN(r1); PIN(r2);
-    PIN(t0); PIN(t1); PIN(t2); PIN(n0); PIN(n1); PIN(n2); PIN(rb0); PIN(rb1); PIN(rb2);
-#undef PIN
-    int s = 0;
-    if (n_seg > 1 && (int)blockIdx.x >= sb1) s = 1;
-    if (n_seg > 2 && (int)blockIdx.x >= sb2) s = 2;
-    const int lo = s == 0 ? sb0 : s == 1 ? sb1 : sb2, hi = s == 0 ? sb1 : s == 1 ? sb2 : sb3;
-    const int nblk = hi - lo, bl = (int)blockIdx.x - lo;
-    o.K = K; o.epi = epi; o.nck = nck; o.neps = neps; o.aq = aq; o.ad = ad; o.abs = abs; o.nx = nx; o.nw = nw;
-    o.W = s == 0 ? w0 : s == 1 ? w1 : w2; o.W1 = w1;
-    o.out = s == 0 ? o0 : s == 1 ? o1 : o2;
-    o.resid = s == 0 ? r0 : s == 1 ? r1 : r2;
-    o.type = s == 0 ? t0 : s == 1 ? t1 : t2;
-    o.n_rows = s == 0 ? n0 : s == 1 ? n1 : n2;
-    o.row_bytes = s == 0 ? rb0 : s == 1 ? rb1 : rb2;
-    // contiguous rows per workgroup (workgroups past the last row of the segment have none)
-    int b0 = 0, b1 = 0;
-    if (nblk > 0 && bl >= 0 && (int)blockIdx.x < sb3) {
-        const int rpb = (o.n_rows + nblk - 1) / nblk;
-        b0 = bl * rpb; b1 = b0 + rpb;
-        if (b0 > o.n_rows) b0 = o.n_rows;
-        if (b1 > o.n_rows) b1 = o.n_rows;
-    }
-    o.b0 = b0; o.n_rows_wg = b1 - b0;
-    o.swiglu = epi == EPI_SWIGLU;
-    o.pair = 2 * o.row_bytes <= (unsigned)ST_PAIR_MAX;
-    o.total = (unsigned)o.n_rows_wg * o.row_bytes;
-    const int per_tensor = (int)((o.total + ST_SLOT - 1) / ST_SLOT);
-    o.ns_raw = o.swiglu ? 2 * per_tensor : per_tensor;
-    o.ns_pad = (o.ns_raw + 1) & ~1;
-}
-
-// RMSNorm * w and / or the Q8_K (Q8_0) quantisation of the token by the 8 consumer waves, result in LDS: stage_finish of
-// mmvq_fast_dev.h (consumer c owns 256-blocks c, c + 8, ..; sum of squares in double, fixed order), with the workgroup
-// barrier replaced by a rendezvous of the consumers (the loaders never join: they sit in the memory queue).
-template <int KB, int FUSE, bool Q80>
-__device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, const StLayout &lay, int c, int lane) {
-    constexpr int NJW = (KB * 8 + ST_NC - 1) / ST_NC;
-    const int nbt = a.K >> 8;
-    int8_t *qs = reinterpret_cast<int8_t *>(smem + lay.qs);
-    float *d = reinterpret_cast<float *>(smem + lay.d);
-    int16_t *bs = reinterpret_cast<int16_t *>(smem + lay.bs);
-    double *red = reinterpret_cast<double *>(smem + ST_OFF_RED);
-    int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
-    f32x4_t rxv[NJW], rwv[NJW];
-#pragma unroll
-    for (int i = 0; i < NJW; i++) {
-        const int b = c + ST_NC * i;
-        const int bc = b < nbt ? b : nbt - 1;                  // clamped: always a valid address, result unused when b is out of range
-        rxv[i] = *reinterpret_cast<const f32x4_t *>(a.nx + bc * 256 + lane * 4);
-        if (FUSE == 1) rwv[i] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
-    }
-    asm volatile("" ::: "memory");
-    if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    float scale = 1.0f;
-    if (FUSE == 1) {
-        double sum = 0.0;
-#pragma unroll
-        for (int i = 0; i < NJW; i++) {
-            const f32x4_t x = rxv[i];
-            double t = 0.0;
-            t += (double)(x.x * x.x); t += (double)(x.y * x.y); t += (double)(x.z * x.z); t += (double)(x.w * x.w);
-            if (c + ST_NC * i < nbt) sum += t;
-        }
-        sum = wave_sum(sum);
-        if (lane == 0) red[c] = sum;
-        consumers_rendezvous(sy + SY_PRO1, lane);
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < ST_NC; w++) tot += red[w];
-        const float mean = (float)(tot / (double)a.K);
-        scale = 1.0f / sqrtf(mean + a.neps);
-    }
-#pragma unroll
-    for (int i = 0; i < NJW; i++) {
-        const int b = c + ST_NC * i;
-        if (b >= nbt) continue;                                // wave-uniform
-        const int e0 = b * 256 + lane * 4;
-        f32x4_t x = rxv[i];
-        if (FUSE == 1) {
-            const f32x4_t ww = rwv[i];
-            x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
-        }
-        const float vv[4] = {x.x, x.y, x.z, x.w};
-        if (Q80) {
-            uint32_t packed; float dd;
-            wave_quant_q80(vv, packed, dd);
-            *reinterpret_cast<uint32_t *>(qs + e0) = packed;
-            if ((lane & 7) == 0) reinterpret_cast<float *>(bs)[b * 8 + (lane >> 3)] = h2f(f2h(dd));
-            continue;
-        }
-        uint32_t packed; int bsum; float dq;
-        wave_quant_q8k(vv, lane, packed, bsum, dq);
-        *reinterpret_cast<uint32_t *>(qs + e0) = packed;
-        if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum;
-        if (lane == 0) d[b] = dq;
-    }
-    consumers_rendezvous(sy + SY_PRO2, lane);
-}
-
-// ---- a loader wave (q = 0, 1).  The workgroup's rows of a mat-vec are one contiguous run of `total` bytes per tensor, cut
-// into 4 KiB slots; the mat-vec's slots follow the previous mat-vec's in the ring (g0 = its first global slot, even).
-//   one tensor : local slot k = run bytes [4096 k, ..); loader q copies the slots k = q mod 2;
-//   SwiGLU     : local slot 2 i = gate slot i, 2 i + 1 = up slot i: loader 0 streams the gate run, loader 1 the up run.
-// Every slot is four DMA instructions (the tail re-reads the run's last 16 B, the padding slot of an odd count likewise),
-// so "at most 60 outstanding" always means "everything but my last 15 slots has landed".
-// Nothing here blocks: what has landed is read off the wave's own vector-memory counter (the one s_waitcnt vmcnt waits on,
-// HW_REG_IB_STS) after every step, so a slot is published as soon as it is in LDS — with counted waits a slot was only
-// published once 15 more had been issued (5 us at the streaming rate), and a loader blocked on ring space had to drain
-// everything (vmcnt(0)) before it could publish anything, one slot per round trip.
-struct LoaderState {
-    int issued, published;        // slots of THIS loader, over the whole launch (its i-th slot is global slot 2 i + q)
-    int pre;                      // DMA instructions issued before the first slot (activation planes)
-    unsigned free_until;          // global slots below this index may be in the ring
-    int idle_polls;
-};
-__device__ __forceinline__ int vm_outstanding() {
-    unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_IB_STS)" : "=s"(x) :: "memory");
-    return (int)((x & 0xfu) | ((x >> 18) & 0x30u));              // VM_CNT = {bits 23:22, bits 3:0}
-}
-__device__ __forceinline__ void loader_publish(LoaderState &st, int *sy, int q) {
-    const int done = st.pre + ST_SI * st.issued - vm_outstanding();   // DMA instructions complete (they complete in order)
-    const int landed = done <= st.pre ? 0 : (done - st.pre) / ST_SI;
-    if (landed > st.published) { st.published = landed; st_sync(sy + SY_LANDED + q, landed); }
-}
-__device__ __forceinline__ void loader_op(LoaderState &st, const StOp &a, uint8_t *smem, int q, unsigned g0, int lane) {
-    int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
-    if (a.ns_pad == 0) return;
-    const unsigned ring_lds = lds_addr(smem + ST_OFF_RING);
-    const uint8_t *W = (a.swiglu && q == 1 ? a.W1 : a.W) + (size_t)a.b0 * a.row_bytes;
-    const unsigned total = a.total, last = total - 16u;
-    const unsigned run_stride = a.swiglu ? ST_SLOT : 2u * ST_SLOT;              // run bytes between two slots of this loader
-    unsigned run_off = a.swiglu ? 0u : (unsigned)q * ST_SLOT;                    // run offset of this loader's next slot
-    const uint8_t *pl = W + run_off + (size_t)lane * 16;                         // this lane's 16 B of it
-    const int n_mine = a.ns_pad / 2;                                             // slots of this loader in the mat-vec
-    for (int i = 0; i < n_mine;) {
-        loader_publish(st, sy, q);
-        const unsigned g = g0 + 2u * (unsigned)i + (unsigned)q;                  // global slot
-        const int depth = ST_D * ST_SI + st.pre <= 60 ? ST_D : (60 - st.pre) / ST_SI;   // (the counter read by vm_outstanding() saturates at 63)
-        bool wait = st.issued - st.published >= depth;                           // in flight: at most `depth` slots
-        if (!wait && g + 1u > st.free_until) {                                   // ring space: the slowest consumer's front + the ring
-            int f = 0x7fffffff;
-#pragma unroll
-            for (int c = 0; c < ST_NC; c++) { const int x = uni(ld_sync(sy + SY_FRONT + c)); f = x < f ? x : f; }
-            st.free_until = (unsigned)f + ST_RING_SLOTS;
-            wait = g + 1u > st.free_until;
-        }
-        if (wait) {
-            if (++st.idle_polls > ST_SPIN_LIMIT) return;                         // (never on a healthy run)
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        const unsigned dst = ring_lds + ((g * ST_SLOT) & ST_MASK);
-        if (run_off + ST_SLOT <= total) dma_slot(pl, dst);
-        else {
-#pragma unroll
-            for (int p = 0; p < ST_SI; p++) {
-                const unsigned off = run_off + (unsigned)lane * 16u + p * 1024u;  // past the end: every such lane re-reads the run's last 16 B
-                dma16<true>(W + (off < total ? off : last), dst + p * 1024);
-            }
-        }
-        pl += run_stride; run_off += run_stride;
-        i++;
-        st.issued++;
-    }
-}
-__device__ __forceinline__ void loader_drain(LoaderState &st, uint8_t *smem, int q) {
-    int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
-    int polls = 0;
-    while (st.published < st.issued && ++polls < ST_SPIN_LIMIT) { loader_publish(st, sy, q); __builtin_amdgcn_s_sleep(1); }
-}
-// the quantised activation planes of the token (pre-quantised by the attention's merge): pieces of 1 KiB by DMA, ahead of
-// the first weight slot of the launch: qs [K], then d [nb * 4], then bs [K / 8]
-__device__ __forceinline__ int loader_planes(const StOp &a, uint8_t *smem, const StLayout &lay, int lane) {   // returns the DMA instructions issued
-    const int nb = a.K >> 8;
-    const int nq = a.K >> 10, nbs = ((a.K >> 3) + 1023) >> 10;
-    for (int c = 0; c < nq + 1 + nbs; c++) {
-        const uint8_t *src; int size; unsigned dst;
-        if (c < nq) { src = reinterpret_cast<const uint8_t *>(a.aq) + c * 1024; size = 1024; dst = lay.qs + c * 1024; }
-        else if (c == nq) { src = reinterpret_cast<const uint8_t *>(a.ad); size = nb * 4; dst = lay.d; }
-        else { const int i = c - nq - 1; src = reinterpret_cast<const uint8_t *>(a.abs) + i * 1024; size = (a.K >> 3) - i * 1024; if (size > 1024) size = 1024; dst = lay.bs + i * 1024; }
-        const int o = lane * 16 < size ? lane * 16 : size - 16;
-        dma16<false>(src + o, lds_addr(smem + dst));
-    }
-    return nq + 1 + nbs;
-}
-
-// ---- a consumer wave, one mat-vec.  Step s = a row pair (UO = 2 outputs), one row (big K) or gate row s + up row s (one
-// output); consumer c decodes steps c, c + 8, ..  g0 = the first ring slot of the mat-vec (0: one mat-vec per launch).
-template <int TYPE, int KB, int FUSE, bool SWIGLU, bool PAIR>
-__device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c, unsigned g0) {
-    using R = Raw<TYPE>;
-    constexpr bool ACT_REGS = KB <= 2;
-    constexpr int STEP = (SWIGLU || PAIR) ? 2 : 1;                // rows decoded together
-    constexpr int UO = (PAIR && !SWIGLU) ? 2 : 1;                 // outputs per step
-    const StLayout lay = st_layout(KB);
-    const int lane = tid_now() & 63;
-    const int wave = c + ST_NL; (void)wave;
-    const LaneRole L = make_role<TYPE>(lane);
-    const int nb = a.K >> 8;
-    const unsigned rb = a.row_bytes;
-    int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
-    const uint8_t *ring = smem + ST_OFF_RING;
-    const unsigned base0 = (g0 * ST_SLOT) & ST_MASK, base1 = SWIGLU ? (base0 + ST_SLOT) & ST_MASK : base0;
-    const int n_rows_wg = a.n_rows_wg, b0 = a.b0;
-    const int n_steps = (n_rows_wg + UO - 1) / UO;
-    auto phys = [&](int i) { return b0 + (UO == 2 ? ((i >> 1) * ST_NC + c) * 2 + (i & 1) : i * ST_NC + c); };
-    // the first global slot step s needs (what this consumer frees the ring up to)
-    auto front_of = [&](int s) { return (int)(g0 + (SWIGLU ? 2u * (((unsigned)s * rb) >> 12) : ((unsigned)s * (unsigned)STEP * rb) >> 12)); };
-    if (lane == 0) st_sync(sy + SY_FRONT + c, c < n_steps ? front_of(c) : (int)(g0 + (unsigned)a.ns_pad));
-    // outputs of this consumer
-    int n_out = 0;
-    if (c < n_steps) {
-        const int my_steps = (n_steps - c + ST_NC - 1) / ST_NC;
-        const int last_step = c + (my_steps - 1) * ST_NC;
-        const int rows_last = n_rows_wg - last_step * UO < UO ? n_rows_wg - last_step * UO : UO;
-        n_out = (my_steps - 1) * UO + rows_last;
-    }
-    float rsd = 0.0f;                                             // residual of output `lane` (first 64 outputs), requested now
-    if (!SWIGLU && a.epi == EPI_ADD && lane < n_out) rsd = a.resid[phys(lane)];
-
-    // ---- activation into LDS (fused modes: by the consumers themselves; planes: DMA'd by loader 0 ahead of its first slot)
-    if (FUSE != 0) consumer_prologue<KB, FUSE, TYPE == T_Q8_0>(a, smem, lay, c, lane);
-    else {
-        asm volatile("" ::: "memory");
-        if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ST_SPIN_WHILE(ld_sync(sy + SY_LANDED) < 1, 1);
-    }
-    ST_STAMP(2);
-    ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
-    ActSlice S0, S1;
-    if (ACT_REGS) {
-        S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
-        if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
-    }
-
-    float res = 0.0f;                                             // lane i: output i of this wave (64 per flush)
-    int n_done = 0, flushed = 0;
-    auto flush = [&](int upto) {                                  // outputs [flushed, upto) are in lanes 0 ..
-        const int cnt = upto - flushed;
-        if (lane < cnt) {
-            const int row = phys(flushed + lane);
-            float v = res;
-            if (!SWIGLU && a.epi == EPI_ADD) v = (flushed == 0 ? rsd : a.resid[row]) + v;
-            a.out[row] = v;
-        }
-        flushed = upto;
-    };
-    ST_ACC_DECL;
-    ST_T0();
-    for (int s = c; s < n_steps; s += ST_NC) {
-        const bool two = STEP == 2 && (SWIGLU || s * 2 + 1 < n_rows_wg);
-        // run offsets of the step's rows and the slots that must have landed
-        const unsigned off0 = SWIGLU ? (unsigned)s * rb : (unsigned)s * (unsigned)STEP * rb;
-        const unsigned off1 = SWIGLU ? off0 : (two ? off0 + rb : off0);
-        const unsigned end = SWIGLU ? off0 + rb : off0 + (two ? 2u : 1u) * rb;
-        const unsigned n = (end + ST_SLOT - 1) / ST_SLOT;         // slots [0, n) of the run
-        const unsigned gn = g0 + (SWIGLU ? 2u * n : n);           // global slots below gn
-        const int need0 = (int)((gn + 1u) >> 1), need1 = (int)(gn >> 1);
-        ST_SPIN_WHILE(ld_sync(sy + SY_LANDED) < need0 || ld_sync(sy + SY_LANDED + 1) < need1, 1);
-        ST_ACC(st_acc_w);
-        float acc0 = 0.0f, acc1 = 0.0f;
-        // K <= 4096: both passes in flight at once; longer rows: two passes at a time (fully unrolled, the compiler hoists
-        // every pass's ring reads to the top: 246+ registers at 7 passes)
-#pragma unroll KB <= 2 ? KB : 2
-        for (int p = 0; p < KB; p++) {
-            const ActSlice sl = ACT_REGS ? (p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, p * 8 + L.sbl, nb, L);
-            int sb = p * 8 + L.sbl;
-            if (sb >= nb) sb = nb - 1;                            // tail of a partial last pass: any valid block, its slice scale is zero
-            R w0, w1;
-            ring_load<SWIGLU>(w0, ring, base0, off0, nb, sb, L);
-            if (STEP == 2) ring_load<SWIGLU>(w1, ring, base1, off1, nb, sb, L);
-            acc0 += w0.dot(sl, L);
-            if (STEP == 2) acc1 += w1.dot(sl, L);
-        }
-        const float v0 = wave_sum(acc0);
-        const float v1 = STEP == 2 ? wave_sum(acc1) : 0.0f;
-        asm volatile("" ::: "memory");                            // the ring reads above stay above the release below
-        if (lane == 0) st_sync(sy + SY_FRONT + c, s + ST_NC < n_steps ? front_of(s + ST_NC) : (int)(g0 + (unsigned)a.ns_pad));
-        ST_ACC(st_acc_d);
-        if (SWIGLU) {
-            const float y = (v0 / (1.0f + expf(-v0))) * v1;
-            if (lane == (n_done & 63)) res = y;
-            n_done++;
-        } else {
-            if (lane == (n_done & 63)) res = v0;
-            n_done++;
-            if (two) {
-                if ((n_done & 63) == 0) flush(n_done);
-                if (lane == (n_done & 63)) res = v1;
-                n_done++;
-            }
-        }
-        if ((n_done & 63) == 0) flush(n_done);
-    }
-    ST_STAMP(4);
-    ST_ACC_OUT();
-    if (flushed < n_done) flush(n_done);
-#ifdef MI355_STREAM_PROBE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ST_STAMP(5);
-#endif
-}
-// forms that exist: SwiGLU pairs only with the fused RMSNorm prologue (gate/up), row pairs up to K = 8192, single rows
-// from K = 6144 (mmvq_stream_applicable agrees)
-template <int KB, int FUSE>
-__device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, int c, unsigned g0) {
-#define RUN(TY)                                                                                               \
-    do {                                                                                                      \
-        if (a.swiglu) { if constexpr (FUSE == 1) consumer_op<TY, KB, FUSE, true, true>(a, smem, c, g0); } \
-        else if (a.pair) { if constexpr (KB <= 4) consumer_op<TY, KB, FUSE, false, true>(a, smem, c, g0); } \
-        else { if constexpr (KB >= 3) consumer_op<TY, KB, FUSE, false, false>(a, smem, c, g0); } \
-    } while (0)
-    switch (a.type) {
-        case T_Q4_K: RUN(T_Q4_K); break;
-        case T_Q5_K: RUN(T_Q5_K); break;
-        case T_Q6_K: RUN(T_Q6_K); break;
-        case T_Q8_0: if constexpr (FUSE != 0) RUN(T_Q8_0); break;
-        default: break;
-    }
-#undef RUN
-}
-
-__device__ __forceinline__ void sync_init(uint8_t *smem) {
-    if (threadIdx.x < 32) reinterpret_cast<int *>(smem + ST_OFF_SYNC)[threadIdx.x] = 0;
-    __syncthreads();
-}
 
 // ---- one mat-vec per launch
 template <int KB, int FUSE>
@@ -563,7 +75,7 @@ __global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
         ST_STAMP(5);
         return;
     }
-    consumer_dispatch<KB, FUSE>(a, smem, wave - ST_NL, 0u);
+    consumer_dispatch<KB, FUSE>(a, smem, wave - ST_NL, 0u, st_layout(KB));
 }
 
 }  // namespace
@@ -607,8 +119,10 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
     return true;
 }
 
+void mmvq_stream_set_error_word(unsigned *w) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_err_word), &w, sizeof(w)); }
+
 // workgroups per segment in proportion to its bytes (every workgroup streams about the same number of bytes)
-static void stream_plan(MMVQArgs &a, int max_blocks) {
+void mmvq_stream_plan(MMVQArgs &a, int max_blocks) {
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int n = swiglu ? 1 : a.n_seg;
     double bytes[3] = {0, 0, 0}, total = 0;
@@ -636,17 +150,14 @@ void mmvq_stream_set_anyorder_for_timing(bool on) { g_stream_anyorder = on; }
 hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     if (!mmvq_stream_applicable(a)) return hipErrorInvalidValue;
     const int kb = (a.K + 2047) >> 11;
-    stream_plan(a, num_cu());
+    mmvq_stream_plan(a, num_cu());
     const int blocks = a.seg_block0[3];
     const size_t lds = (size_t)st_layout(kb).total;
 #define STREAM(KBV, FZ)                                                                                                  \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mmvq_stream_kernel<KBV, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                                               \
-            attr_set = true;                                                                                             \
-        }                                                                                                                \
+        /* (per launch: the attribute is per device, and a process may hold contexts on several) */                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mmvq_stream_kernel<KBV, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                   \
         if (g_stream_anyorder) hipExtLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a); \
         else hipLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                  \
     } while (0)

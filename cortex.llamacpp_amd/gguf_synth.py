@@ -169,6 +169,8 @@ CONFIGS = {
     # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads), two layers: the whole-step kernel's shape
     "tiny-8b-2l": LlamaConfig("tiny-8b-2l", 4096, 2, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
     "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
+    # three layers of Llama-3-8B's geometry: two launches of the layer engine (decode_engine.hip) that hand Q | K | V on + the last one
+    "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 
 FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17}

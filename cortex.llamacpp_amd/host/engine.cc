@@ -1,5 +1,6 @@
 // engine.cc — see engine.h.  Citations are into /root/reference/src/llama_engine.cc unless noted.
 #include "engine.h"
+#include "log.h"
 
 #include <algorithm>
 #include <chrono>
@@ -109,6 +110,20 @@ LlamaEngine::~LlamaEngine() {
     server_map_.clear();
 }
 
+void LlamaEngine::Load(const EngineLoadOption &opts) {   // llama_engine.cc:289-299
+    log_line(LOG_DEBUG, "Loading engine..");
+    log_line(LOG_DEBUG, "Is custom engine path: %d", opts.is_custom_engine_path ? 1 : 0);
+    log_line(LOG_DEBUG, "Engine path: %s", opts.engine_path.c_str());
+    SetFileLogger(opts.max_log_lines, opts.log_path);
+    SetLogLevel(opts.log_level);
+    log_line(LOG_INFO, "Engine loaded successfully");
+}
+void LlamaEngine::Unload() { log_line(LOG_INFO, "Engine unloaded successfully"); }   // :301-303
+void LlamaEngine::SetLogLevel(int log_level) { log_set_level(log_level); }          // :502-504
+void LlamaEngine::SetFileLogger(int max_log_lines, const std::string &log_path) {   // :510-548
+    if (!log_set_file(log_path, max_log_lines)) log_line(LOG_WARN, "cannot open log file %s", log_path.c_str());
+}
+
 bool LlamaEngine::IsSupported(const std::string &f) const {   // enginei.h:54-62
     return f == "HandleChatCompletion" || f == "HandleEmbedding" || f == "LoadModel" || f == "UnloadModel" || f == "GetModelStatus" ||
            f == "GetModels" || f == "SetFileLogger" || f == "SetLogLevel" || f == "StopInferencing";
@@ -132,21 +147,28 @@ std::string LlamaEngine::GetModelId(const Json &body) {   // llama_utils.h:153-1
 
 void LlamaEngine::LoadModel(const Json &body, Callback cb) {   // :363-423
     const std::string model_id = GetModelId(body);
-    if (model_id.empty()) { cb(make_status(false, true, false, k400BadRequest), message("No model id found in request body")); return; }
+    if (model_id.empty()) {
+        log_line(LOG_INFO, "Model id is empty in request");
+        cb(make_status(false, true, false, k400BadRequest), message("No model id found in request body"));
+        return;
+    }
     {
         std::lock_guard<std::mutex> lk(map_mutex_);
         auto it = server_map_.find(model_id);
         if (it != server_map_.end() && it->second->ctx && it->second->ctx->model_loaded_external) {
+            log_line(LOG_INFO, "Model already loaded");
             cb(make_status(true, false, false, k409Conflict), message("Model already loaded"));
             return;
         }
     }
     std::string err;
     if (!LoadModelImpl(body, err)) {
+        log_line(LOG_ERROR, "Failed to load model: %s", err.c_str());
         Json m = message("Failed to load model");
         if (!err.empty()) m["error"] = err;
         cb(make_status(false, true, false, k500InternalServerError), std::move(m));
     } else {
+        log_line(LOG_INFO, "Model loaded successfully: %s", model_id.c_str());
         cb(make_status(true, false, false, k200OK), message("Model loaded successfully"));
     }
 }
@@ -202,6 +224,7 @@ void LlamaEngine::UnloadModel(const Json &body, Callback cb) {   // :425-445
     si->ctx->ReleaseResources();
     si->q.reset();
     cb(make_status(true, false, false, k200OK), message("Model unloaded successfully"));
+    log_line(LOG_INFO, "Model unloaded successfully");
 }
 
 void LlamaEngine::GetModelStatus(const Json &body, Callback cb) {   // :447-466
@@ -209,7 +232,13 @@ void LlamaEngine::GetModelStatus(const Json &body, Callback cb) {   // :447-466
     if (!CheckModelLoaded(cb, model_id)) return;
     Json j = Json::object();
     j["model_loaded"] = true;
+    {
+        std::lock_guard<std::mutex> lk(map_mutex_);
+        auto it = server_map_.find(model_id);
+        j["model_data"] = it != server_map_.end() && it->second->ctx ? it->second->ctx->GetModelProps().dump() : std::string("{}");   // :457
+    }
     cb(make_status(true, false, false, k200OK), std::move(j));
+    log_line(LOG_INFO, "Model status responded");
 }
 
 void LlamaEngine::GetModels(const Json &, Callback cb) {   // :468-500

@@ -54,6 +54,13 @@ class LlamaEngine {
     void GetModels(const Json &body, Callback cb);
     bool IsSupported(const std::string &f) const;
     void StopInferencing(const std::string &model_id);
+    // enginei.h:14-35: EngineLoadOption {engine_path, deps_path, is_custom_engine_path, log_path, max_log_lines, log_level} / Load / Unload, and
+    // SetFileLogger / SetLogLevel (:69-71), as LlamaEngine implements them (llama_engine.cc:289-303, 502-548): Load = SetFileLogger + SetLogLevel
+    struct EngineLoadOption { std::string engine_path, deps_path, log_path; bool is_custom_engine_path = false; int max_log_lines = 0; int log_level = 2; };
+    void Load(const EngineLoadOption &opts);
+    void Unload();
+    void SetFileLogger(int max_log_lines, const std::string &log_path);
+    void SetLogLevel(int log_level);                       // trantor::Logger::LogLevel numbers (kTrace 0 .. kFatal 5)
 
     static std::string GetModelId(const Json &body);   // llama_utils.h:153-177
 

@@ -12,6 +12,8 @@
 
 namespace mi355 {
 
+static unsigned *stream_error_word();   // pinned, one per process: raised by a weight-stream / engine kernel whose bounded wait gave up
+
 static thread_local std::string g_err;
 void set_error(const char *fmt, ...) {
     char buf[1024];
@@ -329,6 +331,47 @@ Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
 Context::~Context() {
     attn_probe_report();
+    if (d_engine_probe_) {                                     // diagnosis: time line of the probed layer's last engine launch
+        const int ncu = num_cu(), NW = 10, NS = 32;
+        std::vector<unsigned long long> t((size_t)ncu * NW * NS);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(t.data(), d_engine_probe_, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (const char *pf = getenv("MI355_ENGINE_PROBE_FILE")) {          // raw stamps [workgroup][wave][32] for tools/engine_probe.py
+                if (FILE *f = fopen(pf, "wb")) { fwrite(t.data(), 8, t.size(), f); fclose(f); }
+            }
+            unsigned long long base = ~0ull;
+            for (int w = 0; w < ncu * NW; w++) { const unsigned long long v = t[(size_t)w * NS]; if (v && v < base) base = v; }
+            // kind 0: wall-clock stamp relative to the first wave; 1: a duration (10 ns ticks); 2: a count
+            auto stat = [&](bool loader, int idx, const char *name, int kind = 0) {
+                std::vector<double> v;
+                for (int w = 0; w < ncu * NW; w++) {
+                    if (loader != ((w % NW) < 2)) continue;
+                    const unsigned long long x = t[(size_t)w * NS + idx];
+                    if (kind == 0) { if (x) v.push_back((double)(long long)(x - base) * 0.01); }
+                    else v.push_back(kind == 1 ? (double)x * 0.01 : (double)x);
+                }
+                if (v.empty()) return;
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "  %-52s n=%4zu  min %8.2f  med %8.2f  max %8.2f %s\n", name, v.size(), v.front(), v[v.size() / 2], v.back(), kind == 2 ? "" : "us");
+            };
+            fprintf(stderr, "engine probe, layer %d (us since the first wave entered):\n", engine_probe_layer_);
+            stat(true, 0, "loader: enter"); stat(true, 1, "loader: go (consumers' requests queued)"); stat(true, 2, "loader: attn_output issued");
+            stat(true, 3, "loader: gate|up issued"); stat(true, 4, "loader: down issued"); stat(true, 5, "loader: qkv issued"); stat(true, 6, "loader: all landed");
+            stat(true, 12, "loader: attn_output polls waiting for landings", 2); stat(true, 13, "loader: attn_output polls waiting for ring space", 2);
+            stat(true, 14, "loader: gate|up polls waiting for landings", 2); stat(true, 15, "loader: gate|up polls waiting for ring space", 2);
+            stat(true, 16, "loader: down polls waiting for landings", 2); stat(true, 17, "loader: down polls waiting for ring space", 2);
+            stat(true, 18, "loader: qkv polls waiting for landings", 2); stat(true, 19, "loader: qkv polls waiting for ring space", 2);
+            stat(false, 0, "consumer: enter"); stat(false, 20, "consumer: attn_output activation ready"); stat(false, 21, "consumer: attn_output waiting for slots", 1);
+            stat(false, 22, "consumer: attn_output decoding", 1); stat(false, 1, "consumer: attn_output decoded");
+            stat(false, 2, "consumer: x' gather starts"); stat(false, 3, "consumer: x' in LDS");
+            stat(false, 23, "consumer: gate|up activation ready"); stat(false, 24, "consumer: gate|up waiting for slots", 1); stat(false, 25, "consumer: gate|up decoding", 1);
+            stat(false, 4, "consumer: gate|up decoded"); stat(false, 5, "last arriver: swiglu hand-over starts"); stat(false, 6, "last arriver: own blocks quantised + published");
+            stat(false, 7, "consumer: codes in LDS"); stat(false, 26, "consumer: down activation ready"); stat(false, 27, "consumer: down waiting for slots", 1);
+            stat(false, 28, "consumer: down decoding", 1); stat(false, 8, "consumer: down decoded"); stat(false, 9, "consumer: x'' gather starts");
+            stat(false, 10, "consumer: x'' in LDS"); stat(false, 29, "consumer: qkv activation ready"); stat(false, 30, "consumer: qkv waiting for slots", 1);
+            stat(false, 31, "consumer: qkv decoding", 1); stat(false, 11, "consumer: qkv decoded");
+        }
+    }
     if (d_mega_probe_) {                                       // diagnosis: where the last whole-step launch spent its time
         const int nl = model->hp.n_layer, np = 1 + MEGA_PROBES_PER_LAYER * nl;
         std::vector<unsigned long long> t((size_t)np);
@@ -401,6 +444,7 @@ bool Context::init(std::string &err) {
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, model->device) == hipSuccess) set_num_cu(prop.multiProcessorCount);
+    if (unsigned *ew = stream_error_word()) { mmvq_stream_set_error_word(ew); decode_engine_set_error_word(ew); }   // (per device: the pointer lives in device globals)
 
     const size_t T = cp.n_ubatch, E = hp.n_embd, FF = hp.n_ff, G = hp.n_head_kv, D = hp.head_dim, NC = cp.n_ctx;
     cells_.assign(NC, KVCell());
@@ -888,6 +932,98 @@ bool Context::mega_check() {
     return false;
 }
 
+// ------------------------------------------------------------------------------------------ layer engine
+// On by default for the shapes decode_engine.hip has forms for; MI355_ENGINE=0 or mi355_debug_set_option("decode_engine", 0) keeps one launch per mat-vec.
+static int g_decode_engine = -1;         // -1: take the environment
+void set_decode_engine(int on) { g_decode_engine = on < 0 ? -1 : on ? 1 : 0; }
+
+// the sticky error word of the weight-stream / engine kernels: one pinned word per process, raised by a bounded wait that gave up
+static unsigned *stream_error_word() {
+    static unsigned *w = [] { unsigned *p = nullptr; if (hipHostMalloc((void **)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr; if (p) *p = 0u; return p; }();
+    return w;
+}
+
+bool Context::stream_check() {
+    unsigned *w = stream_error_word();
+    if (!w || *w == 0u) return true;
+    const unsigned code = *w;
+    *w = 0u;
+    // a wait inside a weight-stream / engine kernel gave up (debugger, time-slicing, a workgroup that was not resident): the step's results are not valid.
+    // Take one launch per mat-vec from here on (the engine is the only kernel that waits for OTHER workgroups) and say so.
+    engine_state_ = -1;
+    for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
+    graphs_.clear();
+    graph_exec_ = nullptr;
+    char buf[160];
+    snprintf(buf, sizeof buf, "weight-stream kernel: a bounded wait gave up (code 0x%x); results of the step discarded", code);
+    last_error = buf;
+    return false;
+}
+
+// Builds the per-layer descriptors of decode_engine.hip: the same MMVQArgs the per-launch path passes to launch_mmvq_stream for attn_output, gate | up,
+// down and the next layer's Q | K | V of a single token, planned for one workgroup per CU.
+bool Context::engine_prepare() {
+    if (engine_state_ != 0) return engine_state_ > 0;
+    engine_state_ = -1;
+    static const bool env_off = getenv("MI355_ENGINE") && getenv("MI355_ENGINE")[0] == '0';
+    const bool on = g_decode_engine < 0 ? !env_off : g_decode_engine > 0;
+    const HParams &hp = model->hp;
+    const int E = hp.n_embd, FF = hp.n_ff;
+    if (!on || hp.n_expert > 0 || hp.tp_exchange || cp.n_ubatch < 1) return false;
+    std::vector<EngineLayer> el((size_t)hp.n_layer);
+    for (int il = 0; il < hp.n_layer; il++) {
+        const LayerWeights &L = model->layers[(size_t)il];
+        if (L.bq.valid() || L.bk.valid() || L.bv.valid()) return false;
+        if (!is_quant(L.wo.type) || L.wo.type == T_Q8_0) return false;
+        EngineLayer &m = el[(size_t)il];
+        auto base = [&](MMVQArgs &a, int n_seg, int K, int epi, int fuse, const float *nx, const float *nw, const ActQuant &aq) {
+            a = MMVQArgs{};
+            a.n_seg = n_seg; a.K = K; a.T = 1; a.epi = epi;
+            a.fuse_mode = fuse; a.nx = nx; a.nw = nw; a.neps = hp.eps;
+            chunk_act(a, aq, K, 0);
+        };
+        base(m.wo, 1, E, EPI_ADD, 0, nullptr, nullptr, aq_o_);
+        m.wo.seg[0] = make_seg(L.wo, x_, E, x_, nullptr);
+        base(m.gu, 2, E, EPI_SWIGLU, 1, x_, (const float *)L.ffn_norm.data, aq_e_);
+        m.gu.seg[0] = make_seg(L.gate, ffn_, FF, nullptr, nullptr);
+        m.gu.seg[1] = make_seg(L.up, ffn_u_, FF, nullptr, nullptr);
+        base(m.dn, 1, FF, EPI_ADD, 2, ffn_, nullptr, aq_ff_);
+        m.dn.seg[0] = make_seg(L.down, x_, E, x_, nullptr);
+        m.has_qkv = il + 1 < hp.n_layer ? 1 : 0;
+        m.qkv = MMVQArgs{};
+        if (m.has_qkv) {
+            const LayerWeights &N = model->layers[(size_t)il + 1];
+            base(m.qkv, 3, E, EPI_STORE, 1, x_, (const float *)N.attn_norm.data, aq_e_);
+            m.qkv.seg[0] = make_seg(N.wq, q_, (int)N.wq.N, nullptr, nullptr);
+            m.qkv.seg[1] = make_seg(N.wk, k_, (int)N.wk.N, nullptr, nullptr);
+            m.qkv.seg[2] = make_seg(N.wv, v_, (int)N.wv.N, nullptr, nullptr);
+        }
+        if ((int)L.wo.K != E || (int)L.gate.K != E || (int)L.down.K != FF || (int)L.gate.N != FF || (int)L.up.N != FF) return false;
+        if (!decode_engine_applicable(m, E, FF)) return false;
+        decode_engine_plan(m);
+    }
+    unsigned *ew = stream_error_word();
+    if (!ew) return false;
+    mmvq_stream_set_error_word(ew);
+    decode_engine_set_error_word(ew);
+    d_engine_layers_ = (EngineLayer *)dalloc(el.size() * sizeof(EngineLayer));
+    const size_t gw = decode_engine_granule_words(E, FF);
+    d_engine_gran_ = (unsigned long long *)dalloc(gw * 8);
+    d_engine_epoch_ = (unsigned *)dalloc(64);
+    if (!d_engine_layers_ || !d_engine_gran_ || !d_engine_epoch_) return false;
+    if (hipMemcpy(d_engine_layers_, el.data(), el.size() * sizeof(EngineLayer), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemset(d_engine_gran_, 0, gw * 8) != hipSuccess || hipMemset(d_engine_epoch_, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+    if (const char *pl = getenv("MI355_ENGINE_PROBE")) {
+        engine_probe_layer_ = atoi(pl);
+        const size_t np = (size_t)num_cu() * 10 * 32;
+        d_engine_probe_ = (unsigned long long *)dalloc(np * 8);
+        if (d_engine_probe_) (void)hipMemset(d_engine_probe_, 0, np * 8);
+        (void)hipDeviceSynchronize();
+    }
+    engine_state_ = 1;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------ the forward pass
 hipError_t Context::run_layers(int T, int n_kv_cap) {
     cur_T_ = T;
@@ -915,7 +1051,11 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         }
         mega = flash_attn_decode_fused_applicable(ma, ra);      // (more than 64 chunks: the per-launch path merges them)
     }
-    HIP_TRY(launch_step_setup(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr, stream_));
+    // ... or one persistent launch per layer for the mat-vecs between two attention calls (decode_engine.hip)
+    const bool engine = T == 1 && !mega && !profile_ && !debug_taps_ && engine_prepare();
+    last_layers_engine_ = engine;
+    HIP_TRY(launch_step_setup(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr, stream_,
+                              engine ? d_engine_epoch_ : nullptr));
     HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
     prof_mark("embed");
     last_layers_mega_ = mega;
@@ -931,7 +1071,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         const bool need_k = is_quant(L.wq.type) && L.wq.type != T_Q8_0 || is_quant(L.wk.type) && L.wk.type != T_Q8_0 || is_quant(L.wv.type) && L.wv.type != T_Q8_0;
         const bool need_0 = L.wq.type == T_Q8_0 || L.wk.type == T_Q8_0 || L.wv.type == T_Q8_0;
         const bool fuse_attn = !any_f && can_fuse(E, T);
-        if (fuse_attn) {
+        if (engine && il > 0) {
+            // Q | K | V of this layer were computed at the end of the previous layer's engine launch
+        } else if (fuse_attn) {
             pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
         } else {
             const bool pl = need_k && T >= 3;                  // the batched kernels will want the block-sum planes
@@ -943,7 +1085,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         }
         const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
         float *outs[3] = {q_, k_, v_};
-        HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
+        if (!(engine && il > 0)) HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
         pending_fuse_ = Fuse();
         for (int t = 0; t < T; t++) {   // biases are rare on this architecture (one tiny launch per token when present)
             if (L.bq.valid()) HIP_TRY(launch_add(q_ + (size_t)t * H * D, (const float *)L.bq.data, q_ + (size_t)t * H * D, (int64_t)H * D, stream_));
@@ -997,6 +1139,10 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         prof_mark("attn");
         if (o_pl) prep_written(aq_o_, (int)L.wo.K, T);          // the attention just re-quantised its output, planes included
         else if (prep_owner_ == aq_o_.qs) prep_owner_ = nullptr;
+        if (engine) {   // attn_output, gate | up, down and the next layer's Q | K | V in one launch
+            HIP_TRY(launch_decode_engine(d_engine_layers_ + il, E, FF, d_engine_gran_, d_engine_epoch_, il, il == engine_probe_layer_ ? d_engine_probe_ : nullptr, stream_));
+            continue;
+        }
         if (tp) {   // this rank's partial sum (rank 0 carries the residual), then the exchange: x = sum over ranks
             HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, T, tp_part_, E, hp.tp_rank == 0 ? x_ : nullptr, hp.tp_rank == 0 ? EPI_ADD : EPI_STORE));
             HIP_TRY(tp_reduce_into_x(T));
@@ -1362,7 +1508,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
     const int V = model->hp.n_vocab;
-    if (n == 1) (void)mega_prepare();      // allocates and uploads on first use: must not happen inside a stream capture
+    if (n == 1) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
     bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
     hipError_t e = hipSuccess;
     if (graph_ok) {
@@ -1399,6 +1545,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
                 if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
                 graphs_[bucket] = graph_exec_;
                 graph_is_mega_[graph_exec_] = last_layers_mega_;
+                graph_is_engine_[graph_exec_] = last_layers_engine_;
             }
         }
         if (graph_ok) e = hipGraphLaunch(graph_exec_, stream_);
@@ -1415,6 +1562,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     }
     if (e != hipSuccess) { last_error = std::string("decode failed: ") + hipGetErrorString(e) + " / " + last_error_string(); return -1; }
     if (n == 1 && (graph_ok ? graph_is_mega_[graph_exec_] : last_layers_mega_)) mega_steps++;
+    if (n == 1 && (graph_ok ? graph_is_engine_[graph_exec_] : last_layers_engine_)) engine_steps++;
     dbg_tokens_ = n;
     return 0;
 }
@@ -1500,7 +1648,7 @@ float *Context::logits_ith(int i) {
     if (!logits_fetched_) {
         if (!cp.logits_to_host &&
             hipMemcpyAsync(h_logits_, d_logits_, (size_t)n_out_last_ * model->hp.n_vocab * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return nullptr;
-        if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check()) return nullptr;
+        if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check() || !stream_check()) return nullptr;
         logits_fetched_ = true;
     }
     return h_logits_ + (size_t)out_row_of_batch_[(size_t)i] * model->hp.n_vocab;
@@ -1523,7 +1671,7 @@ int32_t Context::argmax_ith(int i) {
     if (i < 0) i += (int)out_row_of_batch_.size();
     if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return -1;
     if (!argmax_fetched_) {
-        if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check()) return -1;
+        if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check() || !stream_check()) return -1;
         argmax_fetched_ = true;
     }
     return h_argmax_[out_row_of_batch_[(size_t)i]];

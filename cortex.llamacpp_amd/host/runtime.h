@@ -95,10 +95,12 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
 void set_moe_group_min(int tokens);   // tests: batch size from which a mixture-of-experts feed-forward is grouped by expert
 void set_attn_store_fuse(bool on);   // tests: 0 = batched steps store K / V in their own launch before the attention
 void set_rope_fast(bool on);         // tests: 0 = prompt batches rotate q / store K, V with the one-workgroup-per-token kernel
+void set_decode_engine(int on);  // 1 / 0: the layer engine (decode_engine.hip) for single-token steps of contexts created afterwards; -1: environment / default (on)
 void set_decode_mega(bool on);   // tests: compare the whole-step kernel with the per-launch path (read when a context first decodes one token)
 
 class Context {
   public:
+    int64_t engine_steps = 0;          // single-token steps issued through the layer engine (graph replays included)
     int64_t mega_steps = 0;            // single-token steps issued as one whole-step launch (graph replays included)
     Context(Model *m, const ContextParams &p);
     ~Context();
@@ -210,10 +212,20 @@ class Context {
     unsigned long long *d_mega_probe_ = nullptr;   // MI355_MEGA_PROBE=1: phase time stamps of the last step (printed by the destructor)
     size_t mega_lds_ = 0;
     bool last_layers_mega_ = false;      // what the last run_layers call issued
-    std::map<hipGraphExec_t, bool> graph_is_mega_;
+    std::map<hipGraphExec_t, bool> graph_is_mega_, graph_is_engine_;
+    bool last_layers_engine_ = false;
     int mega_state_ = 0;                 // 0 = not looked at yet, 1 = descriptors built, -1 = this model / context takes the per-launch path
     bool mega_prepare();
     bool mega_check();                   // after a stream sync: false (and last_error set) if a barrier of the last step timed out
+    // layer engine (decode_engine.hip): attn_output -> gate | up -> down -> next Q | K | V of a single-token step in one persistent launch per layer
+    EngineLayer *d_engine_layers_ = nullptr;
+    unsigned long long *d_engine_gran_ = nullptr;      // hand-over granules
+    unsigned *d_engine_epoch_ = nullptr;               // step serial (incremented by step_setup)
+    unsigned long long *d_engine_probe_ = nullptr;     // MI355_ENGINE_PROBE=<layer>: wall-clock stamps of that layer's launch (printed by the destructor)
+    int engine_probe_layer_ = -1;
+    int engine_state_ = 0;                             // 0 = not looked at yet, 1 = ready, -1 = this model / context takes one launch per mat-vec
+    bool engine_prepare();
+    bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     Fuse pending_fuse_;

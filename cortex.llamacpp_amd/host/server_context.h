@@ -131,6 +131,9 @@ class LlamaServerContext {
     void SendFinalResponse(LlamaClientSlot &slot);
     void SendError(LlamaClientSlot &slot, const std::string &err);
     Json GetFormatedGeneration(const LlamaClientSlot &slot) const;
+  public:
+    Json GetModelProps() const { return slots.empty() ? Json::object() : GetFormatedGeneration(slots[0]); }   // llama_server_context.cc:291-293
+  private:
     Json ProbsToJson(const std::vector<CompletionTokenOutput> &probs) const;
     void DoBackgroundTasks();
 

@@ -145,6 +145,9 @@ MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);
 MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
 /* diagnosis: single-token steps this context ran as ONE launch (decode_mega.hip; see mi355_debug_set_option "decode_mega") */
 MI355_API int64_t mi355_debug_mega_steps(const mi355_context *ctx);
+/* diagnosis: single-token steps this context ran through the layer engine (decode_engine.hip: one persistent launch per layer for the mat-vecs between two
+   attention calls; mi355_debug_set_option "decode_engine" 0 keeps one launch per mat-vec) */
+MI355_API int64_t mi355_debug_engine_steps(const mi355_context *ctx);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
 /* llama_get_embeddings_ith (ctx.cc:1042-1044): final-norm hidden state (n_embd floats, host memory) of batch row i of the
@@ -186,6 +189,9 @@ MI355_API int mi355_op_get_rows(int32_t type, const void *table, int64_t row_ele
                                 const int32_t *ids, int64_t n_ids, float *dst);
 MI355_API int mi355_op_swiglu(const float *gate, const float *up, int64_t n, float *y);
 MI355_API int mi355_op_soft_max(const float *x, const float *mask, int64_t n, int64_t rows, float scale, float *y);
+/* build_moe_ffn's expert selection: softmax over n_expert router logits per token, the k largest (first index wins ties), weights
+   renormalised; ids [T][k], w [T][k] */
+MI355_API int mi355_op_moe_route(const float *logits, int64_t T, int32_t n_expert, int32_t k, int32_t *ids, float *w);
 /* flash_attn_ext for T query tokens: K/V given as ggml-layout rows [n_cells][n_head_kv*head_dim] of type_k/type_v;
  * visibility: cell c is visible to token t iff cell_pos[c] >= 0 && cell_pos[c] <= q_pos[t]. */
 MI355_API int mi355_op_flash_attn(const float *q, int64_t T, int32_t n_head, int32_t n_head_kv, int32_t head_dim,
@@ -211,7 +217,7 @@ MI355_API int32_t mi355_token_is_eog(mi355_model *m, mi355_token tok);
  * streaming completions call it once per chunk (body = {"data": "data: {...}\n\n"}) from a worker thread. */
 typedef struct mi355_engine mi355_engine;
 typedef void (*mi355_engine_callback)(const char *status_json, const char *body_json, void *user);
-MI355_API mi355_engine *mi355_engine_create(void);                 /* get_engine()  (src/llama_engine.cc:1366) */
+MI355_API mi355_engine *mi355_engine_create(void);                 /* get_engine()  (src/llama_engine.cc:1300-1304) */
 MI355_API void mi355_engine_destroy(mi355_engine *e);
 MI355_API void mi355_engine_load_model(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
 MI355_API void mi355_engine_unload_model(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
@@ -221,6 +227,20 @@ MI355_API void mi355_engine_handle_chat_completion(mi355_engine *e, const char *
 MI355_API void mi355_engine_handle_embedding(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
 MI355_API int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature);
 MI355_API void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id);
+/* EngineI::Load(EngineLoadOption) / Unload(EngineUnloadOption) (base/cortex-common/enginei.h:14-35; LlamaEngine: src/llama_engine.cc:289-303): Load =
+   SetFileLogger(max_log_lines, log_path) + SetLogLevel(log_level).  Paths as UTF-8 strings (std::filesystem::path::string()), log_level = the value of
+   trantor::Logger::LogLevel (kTrace 0, kDebug 1, kInfo 2, kWarn 3, kError 4, kFatal 5). */
+MI355_API void mi355_engine_load(mi355_engine *e, const char *engine_path, const char *deps_path, int32_t is_custom_engine_path, const char *log_path,
+                                 int32_t max_log_lines, int32_t log_level);
+MI355_API void mi355_engine_unload(mi355_engine *e);
+/* EngineI::SetFileLogger / SetLogLevel (enginei.h:69-71; src/llama_engine.cc:502-548): log lines go to log_path, kept to its last max_log_lines lines
+   ("" = back to stderr); messages below log_level are dropped */
+MI355_API void mi355_engine_set_file_logger(mi355_engine *e, int32_t max_log_lines, const char *log_path);
+MI355_API void mi355_engine_set_log_level(mi355_engine *e, int32_t log_level);
+/* the bridge the other way: every log line also goes to cb (level = trantor's numbers), so an adapter can re-emit it through the host's own LOG_* macros
+   (the reference routes llama.cpp's log through trantor the same way: llama_log_set, src/llama_engine.cc:313-330).  Process-wide, like trantor::Logger. */
+typedef void (*mi355_log_callback)(int level, const char *line, void *user);
+MI355_API void mi355_engine_set_log_callback(mi355_engine *e, mi355_log_callback cb, void *user);
 
 /* Test / tool switches of the per-op entry points: "mmq_planes" (1: mi355_op_mul_mat with T >= 32 expands the weight
  * into MFMA planes first, as a loaded model does; 0: expands on the fly inside the kernel), "mmq_tiles" (0 | 1 | 2

@@ -371,19 +371,8 @@ static void ffn_moe(const oq_ctx *c, const oq_layer *L, const float *h, int64_t 
     for (int64_t t = 0; t < T; t++) {
         const float *x = h + t * D;
         linear(c, L->gate_inp, x, 1, logits);
-        oq_soft_max(logits, NULL, probs, E, 1.0f);
         int ids[16]; float wts[16];
-        uint64_t used = 0;
-        for (int k = 0; k < KU; k++) { /* descending order, first index wins ties */
-            int best = -1;
-            for (int e = 0; e < E; e++)
-                if (!(used & (1ull << e)) && (best < 0 || probs[e] > probs[best])) best = e;
-            used |= 1ull << best;
-            ids[k] = best; wts[k] = probs[best];
-        }
-        float wsum = 0.0f;
-        for (int k = 0; k < KU; k++) wsum += wts[k];
-        for (int k = 0; k < KU; k++) wts[k] /= wsum;
+        oq_moe_route(logits, E, KU, probs, ids, wts);
         float *o = out + t * D;
         for (int k = 0; k < KU; k++) {
             const int e = ids[k];

@@ -70,6 +70,23 @@ static void rope_table(float *cs, int n_rot, int32_t pos, float freq_base, float
     }
 }
 
+/* build_moe_ffn's selection (upstream: src/llama-graph.cpp): softmax over the router logits, the k largest probabilities in descending order with the
+ * first index winning ties (ggml_top_k = argsort), weights renormalised to sum 1.  probs: scratch of n_expert floats. */
+void oq_moe_route(const float *logits, int n_expert, int k, float *probs, int32_t *ids, float *w) {
+    oq_soft_max(logits, NULL, probs, n_expert, 1.0f);
+    uint64_t used = 0;
+    for (int j = 0; j < k; j++) {
+        int best = -1;
+        for (int e = 0; e < n_expert; e++)
+            if (!(used & (1ull << e)) && (best < 0 || probs[e] > probs[best])) best = e;
+        used |= 1ull << best;
+        ids[j] = best; w[j] = probs[best];
+    }
+    float wsum = 0.0f;
+    for (int j = 0; j < k; j++) wsum += w[j];
+    for (int j = 0; j < k; j++) w[j] /= wsum;
+}
+
 void oq_rope_norm(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
                   float freq_base, float freq_scale, const float *ff) {
     float cs[1024];

@@ -83,6 +83,7 @@ void oq_mul_f32(const float *a, const float *b, float *y, int64_t n);
 void oq_add_f32(const float *a, const float *b, float *y, int64_t n);
 void oq_silu_f32(const float *x, float *y, int64_t n);
 void oq_soft_max(const float *x, const float *mask /*nullable*/, float *y, int64_t n, float scale);
+void oq_moe_route(const float *logits, int n_expert, int k, float *probs /* scratch [n_expert] */, int32_t *ids, float *w);
 /* rope, NORM pairing (x[2i],x[2i+1]); x is [n_head][head_dim] for one token */
 void oq_rope_norm(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
                   float freq_base, float freq_scale, const float *freq_factors /*nullable*/);

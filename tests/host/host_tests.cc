@@ -663,8 +663,60 @@ static void test_embeddings() {
     CHECK(status["status_code"].as_int() == 200 && body["object"].as_string() == "chat.completion");
 }
 
+// `host_tests --api-shapes`: runs the engine façade over the fake backend through the request kinds of the reference's surface and prints every status /
+// body pair as JSON — tests/test_golden_ops.py compares them with tests/golden/api_shapes_v1.json (transcribed from src/llama_engine.cc)
+static int api_shapes_cli() {
+    LlamaEngine eng([](const Json &body, BackendInfo &info, std::string &err) -> std::unique_ptr<IBackend> {
+        if (body["llama_model_path"].as_string() == "/bad") { err = "no such file"; return nullptr; }
+        info.vram = 123; info.model_size = 456;
+        return std::unique_ptr<IBackend>(new FakeBackend());
+    });
+    Json out = Json::object();
+    auto rec = [&](const char *name) { return [&out, name](Json &&st, Json &&b) { Json e = Json::object(); e["status"] = st; e["body"] = b; out[name] = e; }; };
+    Json load = Json::object();
+    load["llama_model_path"] = "/models/tiny-test.gguf"; load["ctx_len"] = 256; load["n_parallel"] = 2;
+    eng.LoadModel(Json::object(), rec("load_model_no_id"));
+    eng.LoadModel(load, rec("load_model_ok"));
+    eng.LoadModel(load, rec("load_model_again"));
+    Json bad = Json::object(); bad["llama_model_path"] = "/bad";
+    eng.LoadModel(bad, rec("load_model_failed"));
+    Json id = Json::object(); id["model"] = "tiny-test";
+    eng.GetModelStatus(id, rec("get_model_status_ok"));
+    eng.GetModels(Json::object(), rec("get_models"));
+    Json req = Json::object();
+    req["model"] = "tiny-test"; req["max_tokens"] = 5; req["temperature"] = 0.0;
+    Json msgs = Json::array(), m1 = Json::object();
+    m1["role"] = "user"; m1["content"] = "hello world";
+    msgs.push_back(m1);
+    req["messages"] = msgs;
+    std::mutex mu; std::condition_variable cv; bool done = false;
+    eng.HandleChatCompletion(req, [&](Json &&st, Json &&b) {
+        std::lock_guard<std::mutex> lk(mu);
+        Json e = Json::object(); e["status"] = st; e["body"] = b; out["chat_completion"] = e; done = true; cv.notify_all();
+    });
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+    for (int usage = 0; usage < 2; usage++) {
+        req["stream"] = true;
+        Json so = Json::object(); so["include_usage"] = usage != 0; req["stream_options"] = so;
+        Json frames = Json::array();
+        done = false;
+        eng.HandleChatCompletion(req, [&](Json &&st, Json &&b) {
+            std::lock_guard<std::mutex> lk(mu);
+            Json e = Json::object(); e["status"] = st; e["body"] = b; frames.push_back(e);
+            if (st["is_done"].as_bool() || st["has_error"].as_bool()) { done = true; cv.notify_all(); }
+        });
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+        out[usage ? "stream_with_usage" : "stream"] = frames;
+    }
+    eng.UnloadModel(id, rec("unload_model_ok"));
+    eng.GetModelStatus(id, rec("model_not_loaded"));
+    printf("%s\n", out.dump().c_str());
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc == 4 && std::string(argv[1]) == "--tokenize") return tokenize_cli(argv[2], argv[3]);
+    if (argc == 2 && std::string(argv[1]) == "--api-shapes") return api_shapes_cli();
     test_json();
     test_vocab();
     test_sampler();

@@ -49,6 +49,7 @@ def lib():
         L.oq_rms_norm.argtypes = [vp, vp, i64, f32]
         L.oq_silu_f32.argtypes = [vp, vp, i64]
         L.oq_soft_max.argtypes = [vp, vp, vp, i64, f32]
+        L.oq_moe_route.argtypes = [vp, i32, i32, vp, vp, vp]
         L.oq_rope_norm.argtypes = [vp, i32, i32, i32, C.c_int32, f32, f32, vp]
         L.oq_rope_neox.argtypes = [vp, i32, i32, i32, C.c_int32, f32, f32, vp]
         L.oq_get_rows.argtypes = [i32, vp, i64, vp, i64, vp]
@@ -148,6 +149,14 @@ def soft_max(x: np.ndarray, mask, scale: float) -> np.ndarray:
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.float32)
     lib().oq_soft_max(_p(x), None if m is None else _p(m), _p(y), x.size, scale)
     return y
+
+
+def moe_route(logits: np.ndarray, k: int):
+    """Top-k expert selection of one token: (ids [k] int32, weights [k] f32)."""
+    x = np.ascontiguousarray(logits, dtype=np.float32)
+    probs = np.empty_like(x); ids = np.zeros(k, np.int32); w = np.zeros(k, np.float32)
+    lib().oq_moe_route(_p(x), x.size, k, _p(probs), _p(ids), _p(w))
+    return ids, w
 
 
 def rope(x: np.ndarray, n_head: int, head_dim: int, pos: int, base: float, neox: bool = False,

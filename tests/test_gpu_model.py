@@ -289,6 +289,41 @@ def test_mega_step_matches_per_launch_bitwise(be, pkg, tmp_models, kv, graphs):
     m.close()
 
 
+@pytest.mark.parametrize("cfg,ftype,kv,graphs", [("tiny-8b-3l", "q4_k_m", "q8_0", True), ("tiny-8b-3l", "q4_k_m", "q8_0", False), ("tiny-8b-2l", "q5_k_m", "f16", True),
+                                                 ("tiny-8b-3l", "q5_k_m", "q8_0", True)])
+def test_layer_engine_matches_per_launch_bitwise(be, pkg, tmp_models, cfg, ftype, kv, graphs):
+    """The layer engine (decode_engine.hip: attn_output -> gate | up -> down -> next Q | K | V of a single-token step in ONE persistent launch per layer,
+    results handed between the CUs as tagged 8-byte granules, the ffn_down activation quantised by the CUs that own its 256-blocks) runs the arithmetic
+    of the per-launch kernels: logits must agree bit for bit, step after step - Llama-3-8B's layer geometry (the one the engine has a form for: an ffn_down
+    whose K is a multiple of 1024), Q4_K / Q5_K / Q6_K tensors, two and three layers, from a graph and eagerly, across a 64-cell chunk boundary, and again after the cache was cleared (hand-over tags keep counting)."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(5).integers(0, m.n_vocab, 40)
+
+    def run(engine):
+        be.set_option("decode_engine", 1 if engine else 0)
+        try:
+            c = pkg.Context(m, n_ctx=256, type_k=KV[kv], type_v=KV[kv], use_graphs=graphs)
+            rows = []
+            for rep in range(2):
+                assert c.decode(prompt, np.arange(40)) == 0
+                rows.append(c.logits().copy())
+                for s in range(40):
+                    assert c.decode([int(rows[-1].argmax())], [40 + s]) == 0
+                    rows.append(c.logits().copy())
+                c.kv_clear()
+            assert c.engine_steps() == (80 if engine else 0)      # the path under test really ran
+            c.close()
+        finally:
+            be.set_option("decode_engine", -1)
+        return np.stack(rows)
+
+    a, b = run(True), run(False)
+    assert np.isfinite(a).all()
+    assert np.array_equal(a, b), int(np.argmax(np.abs(a - b).max(axis=1) > 0))
+    m.close()
+
+
 @pytest.mark.parametrize("cfg,ftype,kv", [("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l", "q5_k_m", "f16"), ("tiny-e2048", "q4_k_m", "q8_0"),
                                           ("tiny-d128", "q4_k_m", "q8_0"), ("tiny-g8", "q8_0", "q8_0")])
 def test_weight_stream_matvec_matches_register_ring_bitwise(be, pkg, tmp_models, cfg, ftype, kv):
