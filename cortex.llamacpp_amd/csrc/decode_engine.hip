@@ -49,13 +49,14 @@ template <int KBE, int KBF> struct EnLayout {
 };
 
 struct EngineArgsDev {
-    const EngineLayer *layer;
+    const EngineLayer *layer;       // device memory; copied into LDS once per launch (by value in the kernel argument segment hipcc reads all 160 words
+                                    // at the top of the kernel and keeps them in spilled SGPRs: 250 spills, a slower step)
     unsigned long long *gx, *gs, *gc, *gd, *gx2;
     const unsigned *epoch;
     int layer_index;
     unsigned long long *probe;      // nullable: per wave EN_PROBE_STAMPS wall-clock stamps
 };
-constexpr int EN_PROBE_STAMPS = 32;
+constexpr int EN_PROBE_STAMPS = 48;
 #define EN_STAMP(i) do { if (ea.probe && lane == 0) ea.probe[((size_t)blockIdx.x * ST_NW + wave) * EN_PROBE_STAMPS + (i)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ bool en_abort(const int *sy) { return ld_sync(sy + SY_ABORT) != 0; }
@@ -137,7 +138,8 @@ __device__ __forceinline__ void en_norm_issue(EnNorm<KB> &nw, const StOp &a, int
     }
 }
 template <int KB>
-__device__ __forceinline__ void en_norm_finish(const EnNorm<KB> &nw, const StOp &a, const float *xf, uint8_t *smem, const StLayout &lay, int c, int lane, int round) {
+__device__ __forceinline__ void en_norm_finish(const EnNorm<KB> &nw, const StOp &a, const float *xf, uint8_t *smem, const StLayout &lay, int c, int lane, int round,
+                                               unsigned long long *pr = nullptr) {   // pr: diagnosis, 4 wall-clock stamps
     constexpr int NJW = EnNorm<KB>::NJW;
     const int nbt = a.K >> 8;
     int8_t *qs = reinterpret_cast<int8_t *>(smem + lay.qs);
@@ -162,27 +164,39 @@ __device__ __forceinline__ void en_norm_finish(const EnNorm<KB> &nw, const StOp 
     }
     sum = wave_sum(sum);
     if (lane == 0) red[c] = sum;
+    if (pr && lane == 0) pr[0] = wall_clock64();
     consumers_rendezvous(sy + SY_PRO1, lane, round);
+    if (pr && lane == 0) pr[1] = wall_clock64();
     double tot = 0.0;
 #pragma unroll
     for (int w = 0; w < ST_NC; w++) tot += red[w];
-    const float mean = (float)(tot / (double)a.K);
+    // tot / K: a power-of-two K (every model's embedding width so far) divides exactly by a multiplication - the same bits as the division
+    const double dk = (double)a.K;
+    const float mean = (a.K & (a.K - 1)) == 0 ? (float)(tot * (1.0 / dk)) : (float)(tot / dk);
     const float scale = 1.0f / sqrtf(mean + a.neps);
+    // the wave's blocks side by side in ONE straight line (a clamped block where the last one does not exist, only its stores are skipped): each
+    // block's quantisation is a chain of wave-level steps (max -> first lane holding it -> its value -> 1 / scale -> codes -> sums) that waits on
+    // itself; two of them interleave
+    if (pr && lane == 0) pr[2] = wall_clock64();
+    uint32_t packed[NJW]; int bsum[NJW]; float dq[NJW];
 #pragma unroll
     for (int i = 0; i < NJW; i++) {
-        const int b = c + ST_NC * i;
-        if (b >= nbt) continue;                                // wave-uniform
-        const int e0 = b * 256 + lane * 4;
         f32x4_t x = rxv[i];
         const f32x4_t ww = nw.w[i];
         x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
         const float vv[4] = {x.x, x.y, x.z, x.w};
-        uint32_t packed; int bsum; float dq;
-        wave_quant_q8k(vv, lane, packed, bsum, dq);
-        *reinterpret_cast<uint32_t *>(qs + e0) = packed;
-        if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum;
-        if (lane == 0) d[b] = dq;
+        wave_quant_q8k(vv, lane, packed[i], bsum[i], dq[i]);
     }
+#pragma unroll
+    for (int i = 0; i < NJW; i++) {
+        const int b = c + ST_NC * i;
+        if (b < nbt) {
+            *reinterpret_cast<uint32_t *>(qs + b * 256 + lane * 4) = packed[i];
+            if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum[i];
+            if (lane == 0) d[b] = dq[i];
+        }
+    }
+    if (pr && lane == 0) pr[3] = wall_clock64();
     consumers_rendezvous(sy + SY_PRO2, lane, round);
 }
 
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
     using LY = EnLayout<KBE, KBF>;
     const int wave = uni(tid_now() >> 6);
     const int lane = tid_now() & 63;
-    // the layer's descriptors: one copy into LDS by the whole workgroup (a description read from global memory when its mat-vec starts costs ~1 us
+    // the layer's descriptors: one copy into LDS by the whole workgroup (a description read from global memory when its mat-vec starts would cost ~1 us
     // of dependent loads on the critical path of every hand-over)
     {
         const unsigned *src = reinterpret_cast<const unsigned *>(ea.layer);
@@ -238,6 +252,8 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
         return;
     }
     const int c = wave - ST_NL;
+    int step_base = 0;                                         // the step tickets run over the launch: every mat-vec uses its steps + one per consumer (the "none left" answers)
+    auto steps_of = [](const StOp &o) { return (o.n_rows_wg + ((o.pair && !o.swiglu) ? 1 : 0)) / ((o.pair && !o.swiglu) ? 2 : 1) + ST_NC; };
     float *xf = reinterpret_cast<float *>(smem + LY::A);
     float *rs = reinterpret_cast<float *>(smem + LY::RS);
     int lo, hi;
@@ -245,17 +261,18 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
     // ---------------- 1. attn_output: planes by DMA, residual from global memory, x' as granules
     op_setup<true>(L->wo, a);
     {
-        EngIO io; io.gran = ea.gx; io.tag = tag0 + 1u; io.probe = pw ? pw + 20 : nullptr;
+        EngIO io; io.gran = ea.gx; io.tag = tag0 + 1u; io.probe = pw ? pw + 20 : nullptr; io.step_base = step_base;
         consumer_dispatch<KBE, 0, 2>(a, smem, c, g0, LY::lay_e(), io);
     }
-    g0 += (unsigned)a.ns_pad;
+    g0 += (unsigned)a.ns_pad; step_base += steps_of(a);
     EN_STAMP(1);
     StOp an, ad;
     op_setup<true>(L->gu, an);
-    op_setup<true>(L->dn, ad);
     EnNorm<KBE> nrm;
     en_norm_issue<KBE>(nrm, an, c, lane);                       // ffn_norm's weights: requested before the hand-over is waited for
+    EN_STAMP(32);
     if (en_arrive(sy, lane, 1)) en_gather_go(sy, lane, 1);
+    op_setup<true>(L->dn, ad);
     en_gather_wait(sy, 1);
     EN_STAMP(2);
     en_slice(an.K, c, lo, hi);
@@ -267,15 +284,15 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
 
     // ---------------- 2. ffn_gate | ffn_up: RMSNorm * w + Q8_K from the gathered x', SwiGLU, results as f32 granules
     a = an;
-    en_norm_finish<KBE>(nrm, a, xf, smem, LY::lay_e(), c, lane, 1);
+    en_norm_finish<KBE>(nrm, a, xf, smem, LY::lay_e(), c, lane, 1, pw ? pw + 34 : nullptr);
     {
-        EngIO io; io.gran = ea.gs; io.tag = tag0 + 2u; io.probe = pw ? pw + 23 : nullptr;
+        EngIO io; io.gran = ea.gs; io.tag = tag0 + 2u; io.probe = pw ? pw + 23 : nullptr; io.step_base = step_base;
         consumer_dispatch<KBE, 3, 1>(a, smem, c, g0, LY::lay_e(), io);
     }
-    g0 += (unsigned)a.ns_pad;
+    g0 += (unsigned)a.ns_pad; step_base += steps_of(a);
     EN_STAMP(4);
-    if (has_qkv) { op_setup<true>(L->qkv, an); en_norm_issue<KBE>(nrm, an, c, lane); }   // the next attn_norm's weights: one hand-over early, they have time
     const int FF = ad.K, nb = FF >> 8;
+    EN_STAMP(33);
     if (en_arrive(sy, lane, 2)) {
         if (lane == 0) st_sync(sy + SY_THIN, 1);
         EN_STAMP(5);
@@ -306,6 +323,7 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
         EN_STAMP(6);
         en_gather_go(sy, lane, 2);
     }
+    if (has_qkv) { op_setup<true>(L->qkv, an); en_norm_issue<KBE>(nrm, an, c, lane); }   // the next attn_norm's weights: requested a hand-over and a mat-vec early
     en_gather_wait(sy, 2);
     {
         unsigned *qs = reinterpret_cast<unsigned *>(smem + LY::A);
@@ -327,10 +345,10 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
     // ---------------- 3. ffn_down: the gathered Q8_K planes, residual from LDS, x'' as granules and as plain stores (the next launch's residual)
     a = ad;
     {
-        EngIO io; io.gran = ea.gx2; io.tag = tag0 + 4u; io.plain = a.out; io.rs = rs; io.probe = pw ? pw + 26 : nullptr;
+        EngIO io; io.gran = ea.gx2; io.tag = tag0 + 4u; io.plain = a.out; io.rs = rs; io.probe = pw ? pw + 26 : nullptr; io.step_base = step_base;
         consumer_dispatch<KBF, 3, 1>(a, smem, c, g0, LY::lay_f(), io);
     }
-    g0 += (unsigned)a.ns_pad;
+    g0 += (unsigned)a.ns_pad; step_base += steps_of(a);
     EN_STAMP(8);
     if (!has_qkv) return;
     if (en_arrive(sy, lane, 3)) en_gather_go(sy, lane, 3);
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(ST_NT) void decode_engine_kernel(const EngineArgsDe
     a = an;
     en_norm_finish<KBE>(nrm, a, xf, smem, LY::lay_e(), c, lane, 2);
     {
-        EngIO io; io.probe = pw ? pw + 29 : nullptr;
+        EngIO io; io.probe = pw ? pw + 29 : nullptr; io.step_base = step_base;
         consumer_dispatch<KBE, 3, 1>(a, smem, c, g0, LY::lay_e(), io);
     }
     EN_STAMP(11);

@@ -84,7 +84,7 @@ bool decode_engine_applicable(const EngineLayer &l, int E, int FF);   // on UNPL
 void decode_engine_plan(EngineLayer &l);                                // mmvq_stream_plan of the four mat-vecs for num_cu() workgroups
 size_t decode_engine_granule_words(int E, int FF);          // 8-byte words of hand-over space a context needs
 void decode_engine_set_error_word(unsigned *w);
-// epoch_dev: device word holding the step serial (changes every step: step_setup); probe: nullable, num_cu() * 10 * 32 stamps
+// epoch_dev: device word holding the step serial (changes every step: step_setup); probe: nullable, num_cu() * 10 * 48 stamps
 hipError_t launch_decode_engine(const EngineLayer *layer_dev, int E, int FF, unsigned long long *granules, const unsigned *epoch_dev, int layer_index,
                                 unsigned long long *probe, hipStream_t st);
 

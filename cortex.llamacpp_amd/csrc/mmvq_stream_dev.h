@@ -128,7 +128,7 @@ __host__ __device__ inline StLayout st_layout(int kb) {
 // sync words (ints at smem): [q] slots published by loader q; [2] consumers whose own global requests are in the memory
 // queue (the loaders start after that); [8] / [12] arrivals at the two prologue rendezvous; [24 + c] consumer c: the first
 // slot it still needs
-enum { SY_LANDED = 0, SY_GO = 2, SY_THIN = 3, SY_PRO1 = 8, SY_PRO2 = 12, SY_DONE = 16, SY_READY = 17, SY_ABORT = 18, SY_GATHER = 19, SY_GDONE = 20, SY_FRONT = 24 };
+enum { SY_LANDED = 0, SY_GO = 2, SY_THIN = 3, SY_PRO1 = 8, SY_PRO2 = 12, SY_DONE = 16, SY_READY = 17, SY_ABORT = 18, SY_GATHER = 19, SY_GDONE = 20, SY_STEP = 21, SY_FRONT = 24 };
 // (decode_engine.hip: [SY_THIN] != 0: a wave of this CU is gathering a hand-over, the loaders keep ST_THIN_D slots in flight; [SY_DONE] consumers that have
 // finished their steps, counted over the launch; [SY_READY] hand-overs gathered into LDS so far; the rendezvous words count over the launch too)
 
@@ -182,9 +182,35 @@ template <bool MEM, class T> __device__ __forceinline__ T st_uni(T v) {
         return __builtin_bit_cast(T, b);
     }
 }
+// MEM (the description sits in LDS, decode_engine.hip): every lane reads two words of it in ONE pair of LDS reads and the fields are picked out of those
+// two registers with v_readlane - a field-by-field read (ds_read -> wait -> v_readfirstlane, forty times) cost 0.8 us per mat-vec on the critical path of
+// every hand-over
+struct StDescRegs { unsigned r0, r1; };
+static_assert(sizeof(MMVQArgs) <= 512, "MMVQArgs no longer fits two words per lane");
+__device__ __forceinline__ StDescRegs st_desc_load(const MMVQArgs &ka) {
+    const unsigned *p = reinterpret_cast<const unsigned *>(&ka);
+    const int lane = tid_now() & 63;
+    constexpr int NW = (int)(sizeof(MMVQArgs) / 4);
+    StDescRegs r;
+    r.r0 = p[lane < NW ? lane : NW - 1];
+    r.r1 = p[64 + lane < NW ? 64 + lane : NW - 1];
+    return r;
+}
+template <class T> __device__ __forceinline__ T st_desc_get(const StDescRegs &r, size_t byte_off) {
+    const int d = (int)(byte_off >> 2);
+    auto word = [&](int i) { return (unsigned)__builtin_amdgcn_readlane((int)(i < 64 ? r.r0 : r.r1), i & 63); };
+    if constexpr (sizeof(T) == 4) { const unsigned w = word(d); return __builtin_bit_cast(T, w); }
+    else {
+        static_assert(sizeof(T) == 8, "st_desc_get");
+        const unsigned long long w = (unsigned long long)word(d) | ((unsigned long long)word(d + 1) << 32);
+        return __builtin_bit_cast(T, w);
+    }
+}
 template <bool MEM = false>
 __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
-#define U(x) st_uni<MEM>(x)
+    StDescRegs dr{0u, 0u};
+    if constexpr (MEM) dr = st_desc_load(ka);
+#define U(x) (MEM ? st_desc_get<decltype(st_uni<false>(x))>(dr, (size_t)(reinterpret_cast<const char *>(&(x)) - reinterpret_cast<const char *>(&ka))) : (x))
     const int n_seg = U(ka.n_seg), sb0 = U(ka.seg_block0[0]), sb1 = U(ka.seg_block0[1]), sb2 = U(ka.seg_block0[2]), sb3 = U(ka.seg_block0[3]);
     const int K = U(ka.K), epi = U(ka.epi), nck = U(ka.nck);
     const float neps = U(ka.neps);
@@ -194,7 +220,7 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     const float *r0 = U(ka.seg[0].resid), *r1 = U(ka.seg[1].resid), *r2 = U(ka.seg[2].resid);
     const int t0 = U(ka.seg[0].type), t1 = U(ka.seg[1].type), t2 = U(ka.seg[2].type);
     const int n0 = U(ka.seg[0].n_rows), n1 = U(ka.seg[1].n_rows), n2 = U(ka.seg[2].n_rows);
-    const unsigned rb0 = U((unsigned)ka.seg[0].row_bytes), rb1 = U((unsigned)ka.seg[1].row_bytes), rb2 = U((unsigned)ka.seg[2].row_bytes);
+    const unsigned rb0 = (unsigned)U(ka.seg[0].row_bytes), rb1 = (unsigned)U(ka.seg[1].row_bytes), rb2 = (unsigned)U(ka.seg[2].row_bytes);
 #undef U
     // (pinned: without a use here hipcc sinks each load to its first use again)
 #define PIN(x) asm volatile("" :: "s"(x))
@@ -245,6 +271,7 @@ struct EngIO {
     float *plain = nullptr;               // with gran: the results also as plain stores (read by a LATER launch)
     const float *rs = nullptr;            // LDS: residual of this workgroup's rows, rs[row - b0] (nullptr: a.resid in global memory)
     unsigned long long *probe = nullptr;  // diagnosis: [0] activation ready (wall clock), [1] time spent waiting for ring slots, [2] time spent decoding
+    int step_base = 0;                    // value of the step ticket counter [SY_STEP] at which this mat-vec's step 0 sits (the counter runs over the launch)
 };
 __device__ __forceinline__ void st_store_granule(unsigned long long *g, unsigned tag, unsigned value) {
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -423,7 +450,10 @@ __device__ __forceinline__ int loader_planes(const StOp &a, uint8_t *smem, const
 }
 
 // ---- a consumer wave, one mat-vec.  Step s = a row pair (UO = 2 outputs), one row (big K) or gate row s + up row s (one
-// output); consumer c decodes steps c, c + 8, ..  g0 = the first ring slot of the mat-vec (0: one mat-vec per launch).
+// output).  Steps are handed out FIRST COME, in stream order, through a ticket counter in LDS: the eight consumers of a workgroup do not run at one
+// speed - two of them share each SIMD and the older wave wins the issue slots (measured: the same seven gate|up steps take 5.0 us on consumer 0 and 8.1
+// us on consumer 7, tools/engine_probe.py), so with the static deal (consumer c: steps c, c + 8, ..) the mat-vec ended when the slowest wave did, 3 us
+// after the fastest had gone idle.  Which wave decodes a row does not change a bit of its result.  g0 = the first ring slot of the mat-vec (0: one mat-vec per launch).
 // ENG (decode_engine.hip): 0 = one mat-vec per launch; 1 = the activation arrives through LDS as io says (FUSE 1: f32 vector -> RMSNorm -> Q8_K by the
 // consumers; FUSE 2: f32 vector -> Q8_K; FUSE 3: the Q8_K planes are already in LDS at `lay`), 2 = FUSE 0 as in a launch of its own (planes by DMA); with
 // ENG != 0 the results go where io says.  The arithmetic is the same in every form.
@@ -443,20 +473,14 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     const unsigned base0 = (g0 * ST_SLOT) & ST_MASK, base1 = SWIGLU ? (base0 + ST_SLOT) & ST_MASK : base0;
     const int n_rows_wg = a.n_rows_wg, b0 = a.b0;
     const int n_steps = (n_rows_wg + UO - 1) / UO;
-    auto phys = [&](int i) { return b0 + (UO == 2 ? ((i >> 1) * ST_NC + c) * 2 + (i & 1) : i * ST_NC + c); };
     // the first global slot step s needs (what this consumer frees the ring up to)
     auto front_of = [&](int s) { return (int)(g0 + (SWIGLU ? 2u * (((unsigned)s * rb) >> 12) : ((unsigned)s * (unsigned)STEP * rb) >> 12)); };
-    if (lane == 0) st_sync(sy + SY_FRONT + c, c < n_steps ? front_of(c) : (int)(g0 + (unsigned)a.ns_pad));
-    // outputs of this consumer
-    int n_out = 0;
-    if (c < n_steps) {
-        const int my_steps = (n_steps - c + ST_NC - 1) / ST_NC;
-        const int last_step = c + (my_steps - 1) * ST_NC;
-        const int rows_last = n_rows_wg - last_step * UO < UO ? n_rows_wg - last_step * UO : UO;
-        n_out = (my_steps - 1) * UO + rows_last;
-    }
-    float rsd = 0.0f;                                             // residual of output `lane` (first 64 outputs), requested now
-    if (!SWIGLU && a.epi == EPI_ADD && lane < n_out && !(ENG != 0 && io.rs)) rsd = a.resid[phys(lane)];
+    if (lane == 0) st_sync(sy + SY_FRONT + c, (int)g0);           // any step may become this wave's: the mat-vec's first slot stays until it holds a ticket
+    // residual of the workgroup's rows, requested now: lane i holds row b0 + i (the rows a wave will decode are not known yet); more than 64 rows
+    // per workgroup: read when the results are stored
+    const bool rsd_regs = !SWIGLU && a.epi == EPI_ADD && !(ENG != 0 && io.rs) && n_rows_wg <= 64;
+    float rsd = 0.0f;
+    if (rsd_regs && lane < n_rows_wg) rsd = a.resid[b0 + lane];
 
     // ---- activation into LDS (fused modes: by the consumers themselves; planes: DMA'd by loader 0 ahead of its first slot)
     if (FUSE == 1 || FUSE == 2) consumer_prologue<KB, FUSE, TYPE == T_Q8_0, ENG == 1>(a, smem, lay, c, lane, io);
@@ -478,14 +502,17 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
         if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
     }
 
-    float res = 0.0f;                                             // lane i: output i of this wave (64 per flush)
+    float res = 0.0f;                                             // lane i: output i of this wave (64 per flush) ...
+    int rrow = b0;                                                // ... and the row it belongs to
     int n_done = 0, flushed = 0;
     auto flush = [&](int upto) {                                  // outputs [flushed, upto) are in lanes 0 ..
         const int cnt = upto - flushed;
+        const int row = rrow;
+        float rv = 0.0f;
+        if (rsd_regs) rv = __int_as_float(__builtin_amdgcn_ds_bpermute((row - b0) << 2, __float_as_int(rsd)));   // (every lane takes part)
         if (lane < cnt) {
-            const int row = phys(flushed + lane);
             float v = res;
-            if (!SWIGLU && a.epi == EPI_ADD) v = (ENG != 0 && io.rs ? io.rs[row - b0] : flushed == 0 ? rsd : a.resid[row]) + v;
+            if (!SWIGLU && a.epi == EPI_ADD) v = (ENG != 0 && io.rs ? io.rs[row - b0] : rsd_regs ? rv : a.resid[row]) + v;
             if (ENG != 0 && io.gran) {
                 st_store_granule(io.gran + row, io.tag, __float_as_uint(v));
                 if (io.plain) io.plain[row] = v;
@@ -495,7 +522,13 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     };
     ST_ACC_DECL;
     ST_T0();
-    for (int s = c; s < n_steps; s += ST_NC) {
+    auto claim = [&]() {                                          // the next step of the mat-vec nobody has taken (>= n_steps: none left)
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(sy + SY_STEP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return uni(t) - io.step_base;
+    };
+    for (int s = claim(); s < n_steps; s = claim()) {
+        if (lane == 0) st_sync(sy + SY_FRONT + c, front_of(s));
         const bool two = STEP == 2 && (SWIGLU || s * 2 + 1 < n_rows_wg);
         // run offsets of the step's rows and the slots that must have landed
         const unsigned off0 = SWIGLU ? (unsigned)s * rb : (unsigned)s * (unsigned)STEP * rb;
@@ -523,25 +556,27 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
         }
         const float v0 = wave_sum(acc0);
         const float v1 = STEP == 2 ? wave_sum(acc1) : 0.0f;
-        asm volatile("" ::: "memory");                            // the ring reads above stay above the release below
-        if (lane == 0) st_sync(sy + SY_FRONT + c, s + ST_NC < n_steps ? front_of(s + ST_NC) : (int)(g0 + (unsigned)a.ns_pad));
+        asm volatile("" ::: "memory");                            // the ring reads above stay above the next ticket (whose front releases the slots)
         ST_ACC(st_acc_d);
         if (eprobe) { const unsigned long long t_ = wall_clock64(); ep_d += t_ - ep_t0; ep_t0 = t_; }
+        const int row0 = b0 + s * UO;
         if (SWIGLU) {
             const float y = (v0 / (1.0f + expf(-v0))) * v1;
-            if (lane == (n_done & 63)) res = y;
+            if (lane == (n_done & 63)) { res = y; rrow = row0; }
             n_done++;
         } else {
-            if (lane == (n_done & 63)) res = v0;
+            if (lane == (n_done & 63)) { res = v0; rrow = row0; }
             n_done++;
             if (two) {
                 if ((n_done & 63) == 0) flush(n_done);
-                if (lane == (n_done & 63)) res = v1;
+                if (lane == (n_done & 63)) { res = v1; rrow = row0 + 1; }
                 n_done++;
             }
         }
         if ((n_done & 63) == 0) flush(n_done);
     }
+    asm volatile("" ::: "memory");
+    if (lane == 0) st_sync(sy + SY_FRONT + c, (int)(g0 + (unsigned)a.ns_pad));   // no step left for this wave: nothing of this mat-vec is held back by it
     ST_STAMP(4);
     ST_ACC_OUT();
     if (eprobe && lane == 0) { io.probe[1] = ep_w; io.probe[2] = ep_d; }

@@ -332,7 +332,7 @@ Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 Context::~Context() {
     attn_probe_report();
     if (d_engine_probe_) {                                     // diagnosis: time line of the probed layer's last engine launch
-        const int ncu = num_cu(), NW = 10, NS = 32;
+        const int ncu = num_cu(), NW = 10, NS = 48;
         std::vector<unsigned long long> t((size_t)ncu * NW * NS);
         (void)hipDeviceSynchronize();
         if (hipMemcpy(t.data(), d_engine_probe_, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -363,7 +363,10 @@ Context::~Context() {
             stat(true, 18, "loader: qkv polls waiting for landings", 2); stat(true, 19, "loader: qkv polls waiting for ring space", 2);
             stat(false, 0, "consumer: enter"); stat(false, 20, "consumer: attn_output activation ready"); stat(false, 21, "consumer: attn_output waiting for slots", 1);
             stat(false, 22, "consumer: attn_output decoding", 1); stat(false, 1, "consumer: attn_output decoded");
+            stat(false, 32, "consumer: next described, norm weights requested");
             stat(false, 2, "consumer: x' gather starts"); stat(false, 3, "consumer: x' in LDS");
+            stat(false, 34, "consumer: sum of squares done"); stat(false, 35, "consumer: rendezvous 1 passed"); stat(false, 36, "consumer: scale known");
+            stat(false, 37, "consumer: blocks quantised");
             stat(false, 23, "consumer: gate|up activation ready"); stat(false, 24, "consumer: gate|up waiting for slots", 1); stat(false, 25, "consumer: gate|up decoding", 1);
             stat(false, 4, "consumer: gate|up decoded"); stat(false, 5, "last arriver: swiglu hand-over starts"); stat(false, 6, "last arriver: own blocks quantised + published");
             stat(false, 7, "consumer: codes in LDS"); stat(false, 26, "consumer: down activation ready"); stat(false, 27, "consumer: down waiting for slots", 1);
@@ -933,7 +936,9 @@ bool Context::mega_check() {
 }
 
 // ------------------------------------------------------------------------------------------ layer engine
-// On by default for the shapes decode_engine.hip has forms for; MI355_ENGINE=0 or mi355_debug_set_option("decode_engine", 0) keeps one launch per mat-vec.
+// Opt-in (MI355_ENGINE=1 or mi355_debug_set_option("decode_engine", 1)): measured on MI355X the layer launch takes 42 us against 38.7 us for the four
+// launches it replaces (545 vs 570 tok/s on Llama-3-8B Q4_K_M; DESIGN.md 4.8 has the per-phase time line and what bounds it), so one launch per mat-vec
+// stays the default; the bitwise test turns the engine on explicitly.
 static int g_decode_engine = -1;         // -1: take the environment
 void set_decode_engine(int on) { g_decode_engine = on < 0 ? -1 : on ? 1 : 0; }
 
@@ -965,8 +970,8 @@ bool Context::stream_check() {
 bool Context::engine_prepare() {
     if (engine_state_ != 0) return engine_state_ > 0;
     engine_state_ = -1;
-    static const bool env_off = getenv("MI355_ENGINE") && getenv("MI355_ENGINE")[0] == '0';
-    const bool on = g_decode_engine < 0 ? !env_off : g_decode_engine > 0;
+    static const bool env_on = getenv("MI355_ENGINE") && getenv("MI355_ENGINE")[0] == '1';
+    const bool on = g_decode_engine < 0 ? env_on : g_decode_engine > 0;
     const HParams &hp = model->hp;
     const int E = hp.n_embd, FF = hp.n_ff;
     if (!on || hp.n_expert > 0 || hp.tp_exchange || cp.n_ubatch < 1) return false;
@@ -1015,7 +1020,7 @@ bool Context::engine_prepare() {
     if (hipMemset(d_engine_gran_, 0, gw * 8) != hipSuccess || hipMemset(d_engine_epoch_, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
     if (const char *pl = getenv("MI355_ENGINE_PROBE")) {
         engine_probe_layer_ = atoi(pl);
-        const size_t np = (size_t)num_cu() * 10 * 32;
+        const size_t np = (size_t)num_cu() * 10 * 48;
         d_engine_probe_ = (unsigned long long *)dalloc(np * 8);
         if (d_engine_probe_) (void)hipMemset(d_engine_probe_, 0, np * 8);
         (void)hipDeviceSynchronize();

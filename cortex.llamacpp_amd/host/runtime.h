@@ -95,7 +95,7 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
 void set_moe_group_min(int tokens);   // tests: batch size from which a mixture-of-experts feed-forward is grouped by expert
 void set_attn_store_fuse(bool on);   // tests: 0 = batched steps store K / V in their own launch before the attention
 void set_rope_fast(bool on);         // tests: 0 = prompt batches rotate q / store K, V with the one-workgroup-per-token kernel
-void set_decode_engine(int on);  // 1 / 0: the layer engine (decode_engine.hip) for single-token steps of contexts created afterwards; -1: environment / default (on)
+void set_decode_engine(int on);  // 1 / 0: the layer engine (decode_engine.hip) for single-token steps of contexts created afterwards; -1: environment MI355_ENGINE / default (off)
 void set_decode_mega(bool on);   // tests: compare the whole-step kernel with the per-launch path (read when a context first decodes one token)
 
 class Context {

@@ -146,7 +146,7 @@ MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
 /* diagnosis: single-token steps this context ran as ONE launch (decode_mega.hip; see mi355_debug_set_option "decode_mega") */
 MI355_API int64_t mi355_debug_mega_steps(const mi355_context *ctx);
 /* diagnosis: single-token steps this context ran through the layer engine (decode_engine.hip: one persistent launch per layer for the mat-vecs between two
-   attention calls; mi355_debug_set_option "decode_engine" 0 keeps one launch per mat-vec) */
+   attention calls; opt-in: mi355_debug_set_option "decode_engine" 1 or MI355_ENGINE=1) */
 MI355_API int64_t mi355_debug_engine_steps(const mi355_context *ctx);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);

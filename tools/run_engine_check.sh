@@ -4,9 +4,9 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "layer_engine or weight_stream or mega_step" 2>&1 | tail -15 > gpurun_out/engine_tests.txt
 cat gpurun_out/engine_tests.txt
-timeout 600 python bench.py > gpurun_out/bench_engine.json 2> gpurun_out/bench_engine.err
+MI355_ENGINE=1 timeout 600 python bench.py > gpurun_out/bench_engine.json 2> gpurun_out/bench_engine.err
 MI355_ENGINE=0 timeout 600 python bench.py > gpurun_out/bench_noengine.json 2> gpurun_out/bench_noengine.err
-MI355_ENGINE_PROBE=5 MI355_ENGINE_PROBE_FILE=gpurun_out/engine_probe.bin timeout 600 python bench.py --steps 8 --warmup 4 > gpurun_out/bench_probe.json 2> gpurun_out/engine_probe.txt
+MI355_ENGINE=1 MI355_ENGINE_PROBE=5 MI355_ENGINE_PROBE_FILE=gpurun_out/engine_probe.bin timeout 600 python bench.py --steps 8 --warmup 4 > gpurun_out/bench_probe.json 2> gpurun_out/engine_probe.txt
 python - <<'PY'
 import json
 for n in ("engine", "noengine"):
