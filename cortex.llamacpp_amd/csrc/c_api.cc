@@ -336,7 +336,7 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
     if (!wsrc.up(W, grow * N) || !wdev.p || !dx.up(x, (size_t)K * T * 4) || !dy.p || !ab.ok()) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }
     hipError_t e = launch_repack_rows(type, wsrc.as<uint8_t>(), wdev.as<uint8_t>(), K, N, nullptr);
     if (e != hipSuccess) return hip_fail(e, "repack");
-    const bool quant = type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q8_0;
+    const bool quant = type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q8_0 || type == T_Q2_K || type == T_Q3_K;
     if (quant) {
         e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, type != T_Q8_0, type == T_Q8_0, nullptr);
         if (e != hipSuccess) return hip_fail(e, "quantize");

@@ -25,9 +25,37 @@ __global__ void repack_q80_kernel(const uint8_t *src, uint8_t *dst, int nblk, in
     d[(size_t)b * 32 + j] = s[2 + j];
     if (j < 2) d[(size_t)K + (size_t)b * 2 + j] = s[j];
 }
+// Q2_K block: scales 16 | qs 64 | d 2 | dmin 2 -> planes qs | scales | (d, dmin);  Q3_K block: hmask 32 | qs 64 | scales 12 | d 2 -> hmask | qs | scales | d
+__global__ void repack_q2k_kernel(const uint8_t *src, uint8_t *dst, int nb, size_t dst_row) {
+    const int row = blockIdx.y, sb = blockIdx.x, i = threadIdx.x;   // 128 threads, 84 used
+    if (i >= 84) return;
+    const uint8_t v = src[((size_t)row * nb + sb) * 84 + i];
+    uint8_t *d = dst + (size_t)row * dst_row;
+    if (i < 16) d[(size_t)nb * 64 + (size_t)sb * 16 + i] = v;
+    else if (i < 80) d[(size_t)sb * 64 + (i - 16)] = v;
+    else d[(size_t)nb * 80 + (size_t)sb * 4 + (i - 80)] = v;
+}
+__global__ void repack_q3k_kernel(const uint8_t *src, uint8_t *dst, int nb, size_t dst_row) {
+    const int row = blockIdx.y, sb = blockIdx.x, i = threadIdx.x;   // 128 threads, 110 used
+    if (i >= 110) return;
+    const uint8_t v = src[((size_t)row * nb + sb) * 110 + i];
+    uint8_t *d = dst + (size_t)row * dst_row;
+    if (i < 32) d[(size_t)sb * 32 + i] = v;
+    else if (i < 96) d[(size_t)nb * 32 + (size_t)sb * 64 + (i - 32)] = v;
+    else if (i < 108) d[(size_t)nb * 96 + (size_t)sb * 12 + (i - 96)] = v;
+    else d[(size_t)nb * 108 + (size_t)sb * 2 + (i - 108)] = v;
+}
 hipError_t launch_repack_rows(int type, const uint8_t *src, uint8_t *dst, int64_t K, int64_t n_rows, hipStream_t st) {
     const size_t drow = dev_row_bytes(type, K);
-    if (type == T_Q6_K) {
+    if (type == T_Q2_K || type == T_Q3_K) {
+        for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+            const int nr = (int)((n_rows - r0) < 65535 ? (n_rows - r0) : 65535);
+            if (type == T_Q2_K) hipLaunchKernelGGL(repack_q2k_kernel, dim3((unsigned)(K >> 8), nr), dim3(128), 0, st,
+                                                   src + (size_t)r0 * ggml_row_bytes(type, K), dst + (size_t)r0 * drow, (int)(K >> 8), drow);
+            else hipLaunchKernelGGL(repack_q3k_kernel, dim3((unsigned)(K >> 8), nr), dim3(128), 0, st,
+                                    src + (size_t)r0 * ggml_row_bytes(type, K), dst + (size_t)r0 * drow, (int)(K >> 8), drow);
+        }
+    } else if (type == T_Q6_K) {
         for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
             const int nr = (int)((n_rows - r0) < 65535 ? (n_rows - r0) : 65535);
             hipLaunchKernelGGL(repack_q6k_kernel, dim3((unsigned)(K >> 8), nr), dim3(256), 0, st,
@@ -78,6 +106,22 @@ __device__ float dequant_elem(int type, const uint8_t *row, int K, int e) {
             int q = (j & 1) ? (qs[32 * c + l] >> 4) : (qs[32 * c + l] & 0x0f);
             if (type == T_Q5_K && ((b[16 + l] >> j) & 1)) q += 16;
             return __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(dm, (float)mn));
+        }
+        case T_Q2_K: {   // element (n, j, l) of block sb: bits 2 j .. 2 j + 1 of qs[32 n + l]; sub-block is = 8 n + 2 j + l / 16
+            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, j = (r >> 5) & 3, l = r & 31, is = 8 * n + 2 * j + (l >> 4);
+            const uint8_t q = row[(size_t)sb * 64 + 32 * n + l], sc = row[(size_t)nb * 64 + (size_t)sb * 16 + is];
+            const uint16_t *dm = reinterpret_cast<const uint16_t *>(row + (size_t)nb * 80 + (size_t)sb * 4);
+            const float dl = __fmul_rn(h2f(dm[0]), (float)(sc & 0xf)), ml = __fmul_rn(h2f(dm[1]), (float)(sc >> 4));
+            return __fsub_rn(__fmul_rn(dl, (float)((q >> (2 * j)) & 3)), ml);
+        }
+        case T_Q3_K: {
+            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, j = (r >> 5) & 3, l = r & 31, is = 8 * n + 2 * j + (l >> 4);
+            const uint8_t q = row[(size_t)nb * 32 + (size_t)sb * 64 + 32 * n + l], hm = row[(size_t)sb * 32 + l];
+            const uint8_t *s12 = row + (size_t)nb * 96 + (size_t)sb * 12;
+            const int low = is < 8 ? (s12[is] & 0xf) : (s12[is - 8] >> 4), high = (s12[8 + (is & 3)] >> (2 * (is >> 2))) & 3;
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + (size_t)nb * 108 + (size_t)sb * 2));
+            const int code = (int)((q >> (2 * j)) & 3) - (((hm >> (4 * n + j)) & 1) ? 0 : 4);
+            return __fmul_rn(__fmul_rn(d, (float)((low | (high << 4)) - 32)), (float)code);
         }
         case T_Q6_K: {
             const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, rr = r & 127, k = rr >> 5, l = rr & 31;

@@ -238,6 +238,124 @@ template <> struct Item<T_Q6_K> {
     }
 };
 
+// ---- Q2_K : device row planes [qs nb*64][scales nb*16][d, dmin nb*4].  Lane v of a super-block: half n = v / 4, bytes l0 = 8 (v % 4) .. + 7 of that
+// half's 32 code bytes; their four 2-bit fields are elements 128 n + 32 j + l0 .. + 7 (j = 0..3), which sit in sub-block is = 8 n + 2 j + (v % 4) / 2.
+// ggml_vec_dot_q2_K_q8_K: isum = sum_is (scales[is] & 15) * sum16(q2 * q8), summs = sum_is (scales[is] >> 4) * bsums[is] ----------------
+__device__ __forceinline__ uint2 ld8w(const void *p) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t *>(p));
+    return make_uint2(v.x, v.y);
+}
+template <> struct Item<T_Q2_K> {
+    uint4 hdr;                        // the 16 scale / min bytes of the super-block
+    static constexpr int EPP = 2048;
+    uint2 q;
+    uint32_t dm;
+    float d, dmin;
+    int sb;
+    bool valid;
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
+        const int nb = K >> 8;
+        sb = pass * 8 + (lane >> 3);
+        valid = sb < nb;
+        if (valid) {
+            const int v = lane & 7;
+            q = ld8w(row + (size_t)sb * 64 + 32 * (v >> 2) + 8 * (v & 3));
+            hdr = ld16w(row + (size_t)nb * 64 + (size_t)sb * 16);
+            dm = *reinterpret_cast<const uint32_t *>(row + (size_t)nb * 80 + (size_t)sb * 4);
+        }
+    }
+    __device__ __forceinline__ void prep(int lane) {
+        if (!valid) return;
+        d = h2f((uint16_t)(dm & 0xffff));
+        dmin = h2f((uint16_t)(dm >> 16));
+    }
+    __device__ __forceinline__ void ints(const ActLds &A, int t, int lane, int &isum, int &msum) const {
+        const int v = lane & 7, n = v >> 2, kq = v & 3, h = kq >> 1;
+        const int8_t *a = A.qs + (size_t)t * A.K + sb * 256 + 128 * n + 8 * kq;
+        const int16_t *bs = A.bs + (size_t)t * (A.K >> 4) + sb * 16 + 8 * n + h;
+        const uint32_t w01 = n ? hdr.z : hdr.x, w23 = n ? hdr.w : hdr.y;      // scale bytes 8 n .. 8 n + 3 / 8 n + 4 .. 8 n + 7
+        int is_ = 0, ms_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint2 aa = *reinterpret_cast<const uint2 *>(a + 32 * j);
+            int s = dot4((q.x >> (2 * j)) & 0x03030303u, aa.x, 0);
+            s = dot4((q.y >> (2 * j)) & 0x03030303u, aa.y, s);
+            const uint32_t scb = ((j < 2 ? w01 : w23) >> (8 * ((2 * j + h) & 3))) & 0xffu;
+            is_ += __mul24((int)(scb & 0xf), s);
+            if ((v & 1) == 0) ms_ += __mul24((int)(scb >> 4), (int)bs[2 * j]);   // the two lanes of a sub-block: the even one carries its minimum
+        }
+        isum = is_; msum = ms_;
+    }
+    __device__ __forceinline__ float dot(const ActLds &A, int t, int lane) const {
+        if (!valid) return 0.0f;
+        int isum, msum;
+        ints(A, t, lane, isum, msum);
+        const float yd = A.d[(size_t)t * (A.K >> 8) + sb];
+        return (yd * d) * (float)isum - (yd * dmin) * (float)msum;
+    }
+};
+
+// ---- Q3_K : device row planes [hmask nb*32][qs nb*64][scales nb*12][d nb*2].  Same lane -> element map as Q2_K; the third bit of element (n, j, l) is
+// bit 4 n + j of hmask[l] and the value is code - 4 where it is CLEAR; sub-block scale = 6-bit scale - 32 (ggml_vec_dot_q3_K_q8_K) ----------
+template <> struct Item<T_Q3_K> {
+    uint4 hdr;                        // x, y, z: the 12 packed scale bytes; w: d (f16)
+    static constexpr int EPP = 2048;
+    uint2 q, hm;
+    int sc[4];                        // (scale - 32) of this lane's four sub-blocks
+    float d;
+    int sb;
+    bool valid;
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
+        const int nb = K >> 8;
+        sb = pass * 8 + (lane >> 3);
+        valid = sb < nb;
+        if (valid) {
+            const int v = lane & 7;
+            hm = ld8w(row + (size_t)sb * 32 + 8 * (v & 3));
+            q = ld8w(row + (size_t)nb * 32 + (size_t)sb * 64 + 32 * (v >> 2) + 8 * (v & 3));
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(row + (size_t)nb * 96 + (size_t)sb * 12);
+            hdr.x = s[0]; hdr.y = s[1]; hdr.z = s[2];
+            hdr.w = *reinterpret_cast<const uint16_t *>(row + (size_t)nb * 108 + (size_t)sb * 2);
+        }
+    }
+    __device__ __forceinline__ void prep(int lane) {
+        if (!valid) return;
+        d = h2f((uint16_t)hdr.w);
+        // the kmask shuffle of the CPU code: 16 six-bit scales as 16 bytes
+        const uint32_t k1 = 0x03030303u, k2 = 0x0f0f0f0fu, tmp = hdr.z;
+        const uint32_t a0 = (hdr.x & k2) | (((tmp >> 0) & k1) << 4), a1 = (hdr.y & k2) | (((tmp >> 2) & k1) << 4);
+        const uint32_t a2 = ((hdr.x >> 4) & k2) | (((tmp >> 4) & k1) << 4), a3 = ((hdr.y >> 4) & k2) | (((tmp >> 6) & k1) << 4);
+        const int v = lane & 7, n = v >> 2, h = (v & 3) >> 1;
+        const uint32_t w01 = n ? a2 : a0, w23 = n ? a3 : a1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sc[j] = (int)(((j < 2 ? w01 : w23) >> (8 * ((2 * j + h) & 3))) & 0xffu) - 32;
+    }
+    __device__ __forceinline__ void ints(const ActLds &A, int t, int lane, int &isum, int &msum) const {
+        const int v = lane & 7, n = v >> 2, kq = v & 3;
+        const int8_t *a = A.qs + (size_t)t * A.K + sb * 256 + 128 * n + 8 * kq;
+        int is_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint2 aa = *reinterpret_cast<const uint2 *>(a + 32 * j);
+            int s = dot4((q.x >> (2 * j)) & 0x03030303u, aa.x, 0);
+            s = dot4((q.y >> (2 * j)) & 0x03030303u, aa.y, s);
+            // - 4 for every element whose high bit is clear: 4 * sum of the activations under the complemented mask
+            int m = dot4(((hm.x >> (4 * n + j)) & 0x01010101u) ^ 0x01010101u, aa.x, 0);
+            m = dot4(((hm.y >> (4 * n + j)) & 0x01010101u) ^ 0x01010101u, aa.y, m);
+            is_ += __mul24(sc[j], s - 4 * m);
+        }
+        isum = is_; msum = 0;
+    }
+    __device__ __forceinline__ float dot(const ActLds &A, int t, int lane) const {
+        if (!valid) return 0.0f;
+        int isum, msum;
+        ints(A, t, lane, isum, msum);
+        const float yd = A.d[(size_t)t * (A.K >> 8) + sb];
+        return (d * yd) * (float)isum;
+    }
+};
+
 // ---- Q8_0 : device row planes [qs K][d K/32 f16] -------------------------------------------------
 template <> struct Item<T_Q8_0> {
     uint4 hdr;
@@ -490,6 +608,8 @@ __global__ __launch_bounds__(BS) void mmvq_kernel(const MMVQArgs a) {
         case T_Q4_K: run_segment<T_Q4_K, NT, BS>(a, a.seg[s], smem, bis); break;
         case T_Q5_K: run_segment<T_Q5_K, NT, BS>(a, a.seg[s], smem, bis); break;
         case T_Q6_K: run_segment<T_Q6_K, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q2_K: run_segment<T_Q2_K, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q3_K: run_segment<T_Q3_K, NT, BS>(a, a.seg[s], smem, bis); break;
         case T_Q8_0: run_segment<T_Q8_0, NT, BS>(a, a.seg[s], smem, bis); break;
         default: break;
     }
@@ -616,6 +736,8 @@ __global__ __launch_bounds__(256, 2) void mmvq_tiled_kernel(const MMVQArgs a) {
         case T_Q4_K: run_tiled<T_Q4_K, NT>(a, a.seg[s], smem, bis); break;
         case T_Q5_K: run_tiled<T_Q5_K, NT>(a, a.seg[s], smem, bis); break;
         case T_Q6_K: run_tiled<T_Q6_K, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q2_K: run_tiled<T_Q2_K, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q3_K: run_tiled<T_Q3_K, NT>(a, a.seg[s], smem, bis); break;
         case T_Q8_0: run_tiled<T_Q8_0, NT>(a, a.seg[s], smem, bis); break;
         default: break;
     }
@@ -771,6 +893,8 @@ hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_
         case T_Q4_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q4_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         case T_Q5_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q5_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         case T_Q6_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q6_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
+        case T_Q2_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q2_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
+        case T_Q3_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q3_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         case T_Q8_0: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q8_0>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         default: return hipErrorInvalidValue;
     }

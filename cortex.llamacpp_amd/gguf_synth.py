@@ -17,23 +17,27 @@ import numpy as np
 
 # ggml type ids
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 0, 1, 2, 8, 12, 13, 14
-TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K"}
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210}
+Q2_K, Q3_K = 10, 11
+TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q2_K: "q2_K", Q3_K: "q3_K"}
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q2_K: 256, Q3_K: 256}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q2_K: 84, Q3_K: 110}
 
 DT_Q4_0 = np.dtype([("d", "<f2"), ("qs", "u1", 16)])
 DT_Q8_0 = np.dtype([("d", "<f2"), ("qs", "i1", 32)])
 DT_Q4_K = np.dtype([("d", "<f2"), ("dmin", "<f2"), ("scales", "u1", 12), ("qs", "u1", 128)])
 DT_Q5_K = np.dtype([("d", "<f2"), ("dmin", "<f2"), ("scales", "u1", 12), ("qh", "u1", 32), ("qs", "u1", 128)])
 DT_Q6_K = np.dtype([("ql", "u1", 128), ("qh", "u1", 64), ("scales", "i1", 16), ("d", "<f2")])
-BLOCK_DTYPE = {Q4_0: DT_Q4_0, Q8_0: DT_Q8_0, Q4_K: DT_Q4_K, Q5_K: DT_Q5_K, Q6_K: DT_Q6_K}
+DT_Q2_K = np.dtype([("scales", "u1", 16), ("qs", "u1", 64), ("d", "<f2"), ("dmin", "<f2")])
+DT_Q3_K = np.dtype([("hmask", "u1", 32), ("qs", "u1", 64), ("scales", "u1", 12), ("d", "<f2")])
+BLOCK_DTYPE = {Q4_0: DT_Q4_0, Q8_0: DT_Q8_0, Q4_K: DT_Q4_K, Q5_K: DT_Q5_K, Q6_K: DT_Q6_K, Q2_K: DT_Q2_K, Q3_K: DT_Q3_K}
 for _t, _dt in BLOCK_DTYPE.items():
     assert _dt.itemsize == BLOCK_BYTES[_t], (_t, _dt.itemsize)
 
 # std of (dequantised weight / d) for uniformly random block payloads (derived in DESIGN.md)
-_UNIT_STD = {Q4_0: 4.6, Q8_0: 73.9, Q4_K: 258.0, Q5_K: 527.0, Q6_K: 1367.0}
+# (Q2_K: w / d = sc * q - r * m with sc, m uniform 0..15, q uniform 0..3, r = 1.5: variance 144.7 + 2.25 * 21.25; Q3_K: (sc - 32) * q, sc 0..63, q -4..3)
+_UNIT_STD = {Q4_0: 4.6, Q8_0: 73.9, Q4_K: 258.0, Q5_K: 527.0, Q6_K: 1367.0, Q2_K: 13.9, Q3_K: 43.3}
 # dmin/d ratio that centres the weights of a random block on zero
-_DMIN_RATIO = {Q4_K: 7.5, Q5_K: 15.5}
+_DMIN_RATIO = {Q4_K: 7.5, Q5_K: 15.5, Q2_K: 1.5}
 
 
 def row_bytes(t: int, n: int) -> int:
@@ -173,7 +177,7 @@ CONFIGS = {
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 
-FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17}
+FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17, "q2_k": 10, "q3_k_m": 12}
 
 
 def use_more_bits(i: int, n: int) -> bool:
@@ -186,6 +190,22 @@ def tensor_type(cfg: LlamaConfig, ftype: str, kind: str, il: int) -> int:
         return F16
     if ftype == "q8_0":
         return Q8_0
+    if ftype in ("q2_k", "q3_k_m"):
+        # llama-quantize's rules for LLAMA_FTYPE_MOSTLY_Q2_K / Q3_K_M on the llama architecture (the reference's e2e smoke model is a TinyLlama Q2_K
+        # file, /root/reference/Makefile:5): output Q6_K; Q2_K: attn_v Q4_K with a query / kv head ratio >= 4 (else Q3_K), ffn_down and attn_output
+        # Q3_K; Q3_K_M: attn_v Q5_K in the first two layers then Q4_K, ffn_down Q5_K in the first n_layer / 16 layers then Q4_K, attn_output Q4_K
+        q2 = ftype == "q2_k"
+        if kind == "output":
+            return Q6_K
+        if kind == "attn_v":
+            if q2:
+                return Q4_K if cfg.n_head // cfg.n_head_kv >= 4 else Q3_K
+            return Q5_K if il < 2 else Q4_K
+        if kind == "ffn_down":
+            return Q3_K if q2 else (Q5_K if il < cfg.n_layer // 16 else Q4_K)
+        if kind == "attn_output":
+            return Q3_K if q2 else Q4_K
+        return Q2_K if q2 else Q3_K
     base = {"q4_k_m": Q4_K, "q5_k_m": Q5_K}[ftype]
     if kind == "output":
         return Q6_K

@@ -54,7 +54,14 @@ size_t ggml_type_row_bytes(int type, int64_t n) {
         case 0: be = 1; bb = 4; break;      // f32
         case 1: be = 1; bb = 2; break;      // f16
         case 2: be = 32; bb = 18; break;    // q4_0
+        case 3: be = 32; bb = 20; break;    // q4_1   (sizes of the types this backend has no kernels for are known too: such a file is
+        case 6: be = 32; bb = 22; break;    // q5_0    refused by name at load, not by a size mismatch)
+        case 7: be = 32; bb = 24; break;    // q5_1
         case 8: be = 32; bb = 34; break;    // q8_0
+        case 10: be = 256; bb = 84; break;  // q2_K
+        case 11: be = 256; bb = 110; break; // q3_K
+        case 20: be = 32; bb = 18; break;   // iq4_nl
+        case 30: be = 1; bb = 2; break;     // bf16
         case 12: be = 256; bb = 144; break; // q4_K
         case 13: be = 256; bb = 176; break; // q5_K
         case 14: be = 256; bb = 210; break; // q6_K

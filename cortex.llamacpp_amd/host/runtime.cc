@@ -40,7 +40,7 @@ Model::~Model() {
 }
 
 static bool type_supported(int t) {
-    return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K;
+    return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q2_K || t == T_Q3_K;
 }
 
 Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes, int tp_rank, int tp_size) {
@@ -149,7 +149,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         dst.ggml_bytes = pl.src_bytes;
         plan.push_back(pl);
         total += (dst.bytes + 255) & ~(size_t)255;
-        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, pl.src_bytes);
+        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.type == T_Q2_K || dst.type == T_Q3_K || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, pl.src_bytes);
     };
     want("token_embd.weight", m->tok_embd, true);
     want("output_norm.weight", m->out_norm, true);
@@ -246,7 +246,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     for (const Plan &pl : plan) {
         DevTensor &d = *pl.dst;
         d.data = arena + pl.off;
-        const bool direct = !(d.type == T_Q6_K || d.type == T_Q8_0) && (pl.ti->n_dims == 1 || d.row_bytes == ggml_row_bytes(d.type, d.K));
+        const bool direct = !(d.type == T_Q6_K || d.type == T_Q8_0 || d.type == T_Q2_K || d.type == T_Q3_K) && (pl.ti->n_dims == 1 || d.row_bytes == ggml_row_bytes(d.type, d.K));
         hipError_t e;
         const uint8_t *src = (const uint8_t *)pl.ti->data + pl.src_off;
         uint8_t *to = direct ? d.data : stage;
@@ -713,7 +713,7 @@ void Context::prof_end() {
 }
 
 // ------------------------------------------------------------------------------------------ linear layers
-static bool is_quant(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
+static bool is_quant(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0 || t == T_Q2_K || t == T_Q3_K; }
 
 static MMVQSeg make_seg(const DevTensor &w, float *out, int ld_out, const float *resid, const int32_t *esel) {
     MMVQSeg s{};
@@ -1348,7 +1348,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             prof_mark("ffn_gate_up");
             static const bool fuse_down_env = !(getenv("MI355_FUSE_DOWN") && getenv("MI355_FUSE_DOWN")[0] == '0');
             // quantise inside the down-projection's prologue (once per CU, overlapped with its first weight loads)
-            const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || L.down.type == T_Q8_0) &&
+            const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || L.down.type == T_Q8_0 ||
+                                                               L.down.type == T_Q2_K || L.down.type == T_Q3_K) &&
                                    (FF % 256) == 0 && [](int kb) { return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 14; }((FF + 2047) / 2048);
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue

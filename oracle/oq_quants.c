@@ -79,13 +79,16 @@ typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; } blk_q4
 typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } blk_q5_K; /* 176 B */
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } blk_q6_K;  /* 210 B */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } blk_q8_K;                      /* 292 B */
+typedef struct { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; } blk_q5_0;                        /* 22 B / 32 */
+typedef struct { uint8_t scales[16]; uint8_t qs[64]; uint16_t d, dmin; } blk_q2_K;             /* 84 B */
+typedef struct { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; } blk_q3_K; /* 110 B */
 #pragma pack(pop)
 
 int oq_block_elems(int type) {
     switch (type) {
         case OQ_TYPE_F32: case OQ_TYPE_F16: return 1;
-        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: return 32;
-        case OQ_TYPE_Q4_K: case OQ_TYPE_Q5_K: case OQ_TYPE_Q6_K: case OQ_TYPE_Q8_K: return 256;
+        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: case OQ_TYPE_Q5_0: return 32;
+        case OQ_TYPE_Q4_K: case OQ_TYPE_Q5_K: case OQ_TYPE_Q6_K: case OQ_TYPE_Q8_K: case OQ_TYPE_Q2_K: case OQ_TYPE_Q3_K: return 256;
     }
     return 0;
 }
@@ -99,6 +102,9 @@ size_t oq_block_bytes(int type) {
         case OQ_TYPE_Q5_K: return sizeof(blk_q5_K);
         case OQ_TYPE_Q6_K: return sizeof(blk_q6_K);
         case OQ_TYPE_Q8_K: return sizeof(blk_q8_K);
+        case OQ_TYPE_Q5_0: return sizeof(blk_q5_0);
+        case OQ_TYPE_Q2_K: return sizeof(blk_q2_K);
+        case OQ_TYPE_Q3_K: return sizeof(blk_q3_K);
     }
     return 0;
 }
@@ -189,6 +195,75 @@ static void deq_q6_K(const blk_q6_K *b, float *y, int64_t nb) {
         }
     }
 }
+/* upstream: dequantize_row_q5_0 - 16 low nibbles then 16 high nibbles, bit j / j + 16 of qh is the fifth bit, offset 16 */
+static void deq_q5_0(const blk_q5_0 *b, float *y, int64_t nb) {
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = oq_fp16_to_fp32(b[i].d);
+        uint32_t qh; memcpy(&qh, b[i].qh, 4);
+        for (int j = 0; j < 16; j++) {
+            const uint8_t xh0 = (uint8_t)(((qh >> j) << 4) & 0x10), xh1 = (uint8_t)((qh >> (j + 12)) & 0x10);
+            y[i * 32 + j]      = (float)((int)((b[i].qs[j] & 0x0f) | xh0) - 16) * d;
+            y[i * 32 + j + 16] = (float)((int)((b[i].qs[j] >> 4) | xh1) - 16) * d;
+        }
+    }
+}
+/* upstream: dequantize_row_q2_K - 16 sub-blocks of 16; scales[is]: low nibble scale, high nibble min; 2-bit codes, four per byte: byte l of a 32-byte
+ * half holds elements l, l + 32, l + 64, l + 96 of that half */
+static void deq_q2_K(const blk_q2_K *b, float *y, int64_t nb) {
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = oq_fp16_to_fp32(b[i].d), mn = oq_fp16_to_fp32(b[i].dmin);
+        const uint8_t *q = b[i].qs;
+        int is = 0;
+        for (int n = 0; n < 256; n += 128) {
+            int shift = 0;
+            for (int j = 0; j < 4; j++) {
+                uint8_t sc = b[i].scales[is++];
+                float dl = d * (float)(sc & 0xf), ml = mn * (float)(sc >> 4);
+                for (int l = 0; l < 16; l++) *y++ = dl * (float)((int8_t)((q[l] >> shift) & 3)) - ml;
+                sc = b[i].scales[is++];
+                dl = d * (float)(sc & 0xf); ml = mn * (float)(sc >> 4);
+                for (int l = 0; l < 16; l++) *y++ = dl * (float)((int8_t)((q[l + 16] >> shift) & 3)) - ml;
+                shift += 2;
+            }
+            q += 32;
+        }
+    }
+}
+/* the sixteen 6-bit scales of a q3_K super-block (upstream: the kmask1 / kmask2 shuffle of dequantize_row_q3_K / ggml_vec_dot_q3_K_q8_K) */
+static void q3_scales(const uint8_t *s12, int8_t *sc16) {
+    uint32_t aux[4];
+    memcpy(aux, s12, 12);
+    const uint32_t kmask1 = 0x03030303u, kmask2 = 0x0f0f0f0fu, tmp = aux[2];
+    aux[2] = ((aux[0] >> 4) & kmask2) | (((tmp >> 4) & kmask1) << 4);
+    aux[3] = ((aux[1] >> 4) & kmask2) | (((tmp >> 6) & kmask1) << 4);
+    aux[0] = (aux[0] & kmask2) | (((tmp >> 0) & kmask1) << 4);
+    aux[1] = (aux[1] & kmask2) | (((tmp >> 2) & kmask1) << 4);
+    memcpy(sc16, aux, 16);
+}
+/* signed 3-bit weights of a q3_K super-block: low two bits from qs, minus 4 where the hmask bit is CLEAR */
+static void unpack_q3_K(const blk_q3_K *b, int8_t *w) {
+    const uint8_t *q = b->qs, *hm = b->hmask;
+    uint8_t m = 1;
+    for (int n = 0; n < 256; n += 128) {
+        for (int j = 0; j < 4; j++) {
+            for (int l = 0; l < 32; l++) w[l] = (int8_t)((int8_t)((q[l] >> (2 * j)) & 3) - ((hm[l] & m) ? 0 : 4));
+            w += 32; m <<= 1;
+        }
+        q += 32;
+    }
+}
+static void deq_q3_K(const blk_q3_K *b, float *y, int64_t nb) {
+    int8_t w[256], sc[16];
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = oq_fp16_to_fp32(b[i].d);
+        unpack_q3_K(&b[i], w);
+        q3_scales(b[i].scales, sc);
+        for (int g = 0; g < 16; g++) {
+            const float dl = d * (float)(sc[g] - 32);
+            for (int l = 0; l < 16; l++) y[i * 256 + g * 16 + l] = dl * (float)w[g * 16 + l];
+        }
+    }
+}
 static void deq_q8_K(const blk_q8_K *b, float *y, int64_t nb) {
     for (int64_t i = 0; i < nb; i++)
         for (int j = 0; j < 256; j++) y[i * 256 + j] = b[i].d * b[i].qs[j];
@@ -204,6 +279,9 @@ void oq_dequantize_row(int type, const void *src, float *dst, int64_t n) {
         case OQ_TYPE_Q5_K: deq_q5_K((const blk_q5_K *)src, dst, n / 256); break;
         case OQ_TYPE_Q6_K: deq_q6_K((const blk_q6_K *)src, dst, n / 256); break;
         case OQ_TYPE_Q8_K: deq_q8_K((const blk_q8_K *)src, dst, n / 256); break;
+        case OQ_TYPE_Q5_0: deq_q5_0((const blk_q5_0 *)src, dst, n / 32); break;
+        case OQ_TYPE_Q2_K: deq_q2_K((const blk_q2_K *)src, dst, n / 256); break;
+        case OQ_TYPE_Q3_K: deq_q3_K((const blk_q3_K *)src, dst, n / 256); break;
         default: abort();
     }
 }
@@ -293,8 +371,8 @@ int oq_vec_dot_type(int type) {
     switch (type) {
         case OQ_TYPE_F32: return OQ_TYPE_F32;
         case OQ_TYPE_F16: return OQ_TYPE_F16;
-        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: return OQ_TYPE_Q8_0;
-        case OQ_TYPE_Q4_K: case OQ_TYPE_Q5_K: case OQ_TYPE_Q6_K: return OQ_TYPE_Q8_K;
+        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: case OQ_TYPE_Q5_0: return OQ_TYPE_Q8_0;
+        case OQ_TYPE_Q4_K: case OQ_TYPE_Q5_K: case OQ_TYPE_Q6_K: case OQ_TYPE_Q2_K: case OQ_TYPE_Q3_K: return OQ_TYPE_Q8_K;
     }
     return -1;
 }
@@ -444,6 +522,81 @@ static float dot_q4_0(int64_t n, const blk_q4_0 *x, const blk_q8_0 *y) {
     }
     return s;
 }
+/* upstream scalar ggml_vec_dot_q5_0_q8_0: one integer sum per block, sumf += (d_x * d_y) * sumi */
+static int32_t q5_0_block(const blk_q5_0 *x, const blk_q8_0 *y) {
+    uint32_t qh; memcpy(&qh, x->qh, 4);
+    int32_t si = 0;
+    for (int j = 0; j < 16; j++) {
+        const uint8_t xh0 = (uint8_t)(((qh & (1u << (j + 0))) >> (j + 0)) << 4), xh1 = (uint8_t)((qh & (1u << (j + 16))) >> (j + 12));
+        const int32_t x0 = (int8_t)(((x->qs[j] & 0x0f) | xh0) - 16), x1 = (int8_t)(((x->qs[j] >> 4) | xh1) - 16);
+        si += x0 * y->qs[j] + x1 * y->qs[j + 16];
+    }
+    return si;
+}
+static float dot_q5_0(int64_t n, const blk_q5_0 *x, const blk_q8_0 *y) {
+    float s = 0.0f;
+    for (int64_t i = 0; i < n / 32; i++)
+        s += (oq_fp16_to_fp32(x[i].d) * oq_fp16_to_fp32(y[i].d)) * (float)q5_0_block(&x[i], &y[i]);
+    return s;
+}
+/* upstream scalar ggml_vec_dot_q2_K_q8_K: per super-block isum = sum over the 16 sub-blocks of (scale nibble) * sum16(q2 * q8), summs = sum of
+ * (min nibble) * bsums; ONE float accumulator: sumf += dall * isum - dmin * summs */
+static void q2_block(const blk_q2_K *x, const blk_q8_K *y, int32_t *isum, int32_t *summs) {
+    int32_t ms = 0;
+    for (int j = 0; j < 16; j++) ms += (int32_t)y->bsums[j] * (x->scales[j] >> 4);
+    const uint8_t *q2 = x->qs; const int8_t *q8 = y->qs;
+    int32_t is_ = 0; int is = 0;
+    for (int k = 0; k < 2; k++) {
+        int shift = 0;
+        for (int j = 0; j < 4; j++) {
+            int32_t d = x->scales[is++] & 0xf, l16 = 0;
+            for (int l = 0; l < 16; l++) l16 += q8[l] * ((q2[l] >> shift) & 3);
+            is_ += d * l16;
+            d = x->scales[is++] & 0xf; l16 = 0;
+            for (int l = 16; l < 32; l++) l16 += q8[l] * ((q2[l] >> shift) & 3);
+            is_ += d * l16;
+            shift += 2; q8 += 32;
+        }
+        q2 += 32;
+    }
+    *isum = is_; *summs = ms;
+}
+static float dot_q2_K(int64_t n, const blk_q2_K *x, const blk_q8_K *y) {
+    float s = 0.0f;
+    for (int64_t i = 0; i < n / 256; i++) {
+        int32_t isum, ms;
+        q2_block(&x[i], &y[i], &isum, &ms);
+        const float dall = y[i].d * oq_fp16_to_fp32(x[i].d), dmin = y[i].d * oq_fp16_to_fp32(x[i].dmin);
+        s += dall * (float)isum - dmin * (float)ms;
+    }
+    return s;
+}
+/* upstream scalar ggml_vec_dot_q3_K_q8_K: eight integer lanes per super-block (lane = element index mod 8), each product scaled by (scale - 32) of its
+ * 16-element sub-block, then sums[l] += d * aux32[l]; the eight float lanes are added at the end */
+static void q3_block(const int8_t *w, const int8_t *sc16, const blk_q8_K *y, int32_t lanes[8]) {
+    memset(lanes, 0, 8 * sizeof(int32_t));
+    for (int j = 0; j < 16; j++)
+        for (int i = 0; i < 16; i++)
+            lanes[i & 7] += (int32_t)(sc16[j] - 32) * (int32_t)(int16_t)((int32_t)y->qs[j * 16 + i] * w[j * 16 + i]);
+}
+static float dot_q3_K(int64_t n, const blk_q3_K *x, const blk_q8_K *y) {
+    acc8 a; memset(&a, 0, sizeof a);
+    int8_t w[256], sc[16]; int32_t lanes[8];
+    for (int64_t i = 0; i < n / 256; i++) {
+        unpack_q3_K(&x[i], w);
+        q3_scales(x[i].scales, sc);
+        q3_block(w, sc, &y[i], lanes);
+        const float d = oq_fp16_to_fp32(x[i].d) * y[i].d;
+        if (g_assoc_variant == 1) {
+            int32_t tot = 0;
+            for (int l = 0; l < 8; l++) tot += lanes[l];
+            a.tail += d * (float)tot;
+            continue;
+        }
+        for (int l = 0; l < 8; l++) a.lane[l] += d * (float)lanes[l];
+    }
+    return acc8_finish(&a);
+}
 static float dot_f16(int64_t n, const uint16_t *x, const uint16_t *y) {
     double s = 0.0; /* upstream scalar: ggml_float accumulator */
     for (int64_t i = 0; i < n; i++) s += (double)(oq_fp16_to_fp32(x[i]) * oq_fp16_to_fp32(y[i]));
@@ -464,6 +617,9 @@ float oq_vec_dot(int type, int64_t n, const void *w, const void *a) {
         case OQ_TYPE_Q4_K: return dot_q4_K(n, (const blk_q4_K *)w, (const blk_q8_K *)a);
         case OQ_TYPE_Q5_K: return dot_q5_K(n, (const blk_q5_K *)w, (const blk_q8_K *)a);
         case OQ_TYPE_Q6_K: return dot_q6_K(n, (const blk_q6_K *)w, (const blk_q8_K *)a);
+        case OQ_TYPE_Q5_0: return dot_q5_0(n, (const blk_q5_0 *)w, (const blk_q8_0 *)a);
+        case OQ_TYPE_Q2_K: return dot_q2_K(n, (const blk_q2_K *)w, (const blk_q8_K *)a);
+        case OQ_TYPE_Q3_K: return dot_q3_K(n, (const blk_q3_K *)w, (const blk_q8_K *)a);
     }
     abort();
 }
@@ -477,6 +633,27 @@ void oq_vec_dot_int_partials(int type, int64_t n, const void *wrow, const void *
             int32_t si = 0;
             for (int j = 0; j < 32; j++) si += (int32_t)x[i].qs[j] * y[i].qs[j];
             isum[i] = si; msum[i] = 0;
+        }
+        return;
+    }
+    if (type == OQ_TYPE_Q5_0) {
+        const blk_q5_0 *x = (const blk_q5_0 *)wrow; const blk_q8_0 *y = (const blk_q8_0 *)act;
+        for (int64_t i = 0; i < n / 32; i++) { isum[i] = q5_0_block(&x[i], &y[i]); msum[i] = 0; }
+        return;
+    }
+    if (type == OQ_TYPE_Q2_K) {
+        const blk_q2_K *x = (const blk_q2_K *)wrow; const blk_q8_K *y2 = (const blk_q8_K *)act;
+        for (int64_t i = 0; i < n / 256; i++) q2_block(&x[i], &y2[i], &isum[i], &msum[i]);
+        return;
+    }
+    if (type == OQ_TYPE_Q3_K) {
+        const blk_q3_K *x = (const blk_q3_K *)wrow; const blk_q8_K *y3 = (const blk_q8_K *)act;
+        int8_t sc[16];
+        for (int64_t i = 0; i < n / 256; i++) {
+            unpack_q3_K(&x[i], w); q3_scales(x[i].scales, sc); q3_block(w, sc, &y3[i], lanes);
+            int32_t t = 0;
+            for (int l = 0; l < 8; l++) t += lanes[l];
+            isum[i] = t; msum[i] = 0;
         }
         return;
     }

@@ -32,7 +32,10 @@ enum {
     OQ_TYPE_F32  = 0,
     OQ_TYPE_F16  = 1,
     OQ_TYPE_Q4_0 = 2,
+    OQ_TYPE_Q5_0 = 6,
     OQ_TYPE_Q8_0 = 8,
+    OQ_TYPE_Q2_K = 10,
+    OQ_TYPE_Q3_K = 11,
     OQ_TYPE_Q4_K = 12,
     OQ_TYPE_Q5_K = 13,
     OQ_TYPE_Q6_K = 14,

@@ -6,6 +6,7 @@ from __future__ import annotations
 import numpy as np
 
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
+Q5_0, Q2_K, Q3_K = 6, 10, 11
 
 DT = {
     Q4_0: np.dtype([("d", "<f2"), ("qs", "u1", 16)]),
@@ -14,7 +15,22 @@ DT = {
     Q5_K: np.dtype([("d", "<f2"), ("dmin", "<f2"), ("scales", "u1", 12), ("qh", "u1", 32), ("qs", "u1", 128)]),
     Q6_K: np.dtype([("ql", "u1", 128), ("qh", "u1", 64), ("scales", "i1", 16), ("d", "<f2")]),
     Q8_K: np.dtype([("d", "<f4"), ("qs", "i1", 256), ("bsums", "<i2", 16)]),
+    Q5_0: np.dtype([("d", "<f2"), ("qh", "<u4"), ("qs", "u1", 16)]),
+    Q2_K: np.dtype([("scales", "u1", 16), ("qs", "u1", 64), ("d", "<f2"), ("dmin", "<f2")]),
+    Q3_K: np.dtype([("hmask", "u1", 32), ("qs", "u1", 64), ("scales", "u1", 12), ("d", "<f2")]),
 }
+
+
+def q3_scales(scales12: np.ndarray) -> np.ndarray:
+    """[nb,12] packed bytes -> [nb,16] 6-bit scales (0..63; the format subtracts 32).  Scale j: low 4 bits = nibble j of the first 8 bytes (bytes 0-7 low
+    nibbles are scales 0-7, high nibbles scales 8-15), high 2 bits = bit pair (j // 4) of byte 8 + j % 4."""
+    s = scales12.astype(np.int32)
+    out = np.empty(s.shape[:-1] + (16,), np.int32)
+    for j in range(16):
+        low = (s[..., j] & 15) if j < 8 else (s[..., j - 8] >> 4)
+        high = (s[..., 8 + j % 4] >> (2 * (j // 4))) & 3
+        out[..., j] = low | (high << 4)
+    return out
 
 
 def k_scales(scales12: np.ndarray):
@@ -46,6 +62,23 @@ def unpack_ints(t: int, raw: np.ndarray) -> np.ndarray:
             lo = lo + (((h >> (2 * c)) & 1) << 4)
             hi = hi + (((h >> (2 * c + 1)) & 1) << 4)
         return np.stack([lo, hi], axis=2).reshape(-1, 256)
+    if t == Q5_0:
+        q = b["qs"].astype(np.int32)
+        h = b["qh"].astype(np.int64)[:, None]
+        j = np.arange(16)[None, :]
+        lo = (q & 15) | (((h >> j) & 1) << 4)
+        hi = (q >> 4) | (((h >> (j + 16)) & 1) << 4)
+        return (np.concatenate([lo, hi], axis=1) - 16).astype(np.int32)
+    if t in (Q2_K, Q3_K):
+        # byte l of 32-byte half n holds elements 128 n + 32 j + l at bits 2 j .. 2 j + 1
+        q = b["qs"].astype(np.int32).reshape(-1, 2, 1, 32)
+        jj = np.arange(4)[None, None, :, None]
+        w = (q >> (2 * jj)) & 3                                  # [nb, 2, 4, 32]
+        if t == Q3_K:
+            hm = b["hmask"].astype(np.int32)[:, None, None, :]   # [nb,1,1,32]; bit 4 n + j belongs to element (n, j, l)
+            bit = 4 * np.arange(2)[None, :, None, None] + jj
+            w = w - np.where((hm >> bit) & 1, 0, 4)
+        return w.reshape(-1, 256)
     if t == Q6_K:
         ql = b["ql"].astype(np.int32).reshape(-1, 2, 64)
         qh = b["qh"].astype(np.int32).reshape(-1, 2, 32)
@@ -67,8 +100,18 @@ def dequantize(t: int, raw: np.ndarray) -> np.ndarray:
         return (b["d"][:, None] * b["qs"].astype(np.float32)).reshape(-1)
     q = unpack_ints(t, raw).astype(np.float32)
     d = b["d"].astype(np.float32)
-    if t in (Q8_0, Q4_0):
+    if t in (Q8_0, Q4_0, Q5_0):
         return (q * d[:, None]).reshape(-1)
+    if t == Q2_K:
+        sc = b["scales"].astype(np.int32)
+        dm = b["dmin"].astype(np.float32)
+        dl = d[:, None] * (sc & 15).astype(np.float32)           # one (scale, min) nibble pair per 16 elements
+        ml = dm[:, None] * (sc >> 4).astype(np.float32)
+        y = dl[:, :, None] * q.reshape(-1, 16, 16) - ml[:, :, None]
+        return y.astype(np.float32).reshape(-1)
+    if t == Q3_K:
+        dl = d[:, None] * (q3_scales(b["scales"]) - 32).astype(np.float32)
+        return (dl[:, :, None] * q.reshape(-1, 16, 16)).astype(np.float32).reshape(-1)
     if t in (Q4_K, Q5_K):
         sc, mn = k_scales(b["scales"])
         dm = b["dmin"].astype(np.float32)
@@ -122,7 +165,7 @@ def quantize_q8_K(x: np.ndarray) -> np.ndarray:
 def int_partials(t: int, w_raw: np.ndarray, a_raw: np.ndarray):
     """(isum[nb], msum[nb]) of one weight row against a q8_K / q8_0 activation row (exact ints)."""
     w = unpack_ints(t, w_raw).astype(np.int64)
-    if t == Q8_0:
+    if t in (Q8_0, Q5_0):
         a = a_raw.view(np.uint8).reshape(-1).view(DT[Q8_0])["qs"].astype(np.int64)
         return (w * a).sum(axis=1).astype(np.int32), np.zeros(w.shape[0], np.int32)
     ab = a_raw.view(np.uint8).reshape(-1).view(DT[Q8_K])
@@ -138,5 +181,15 @@ def int_partials(t: int, w_raw: np.ndarray, a_raw: np.ndarray):
     if t == Q6_K:
         sub = (w * a).reshape(-1, 16, 16).sum(axis=2)
         isum = (sub * wb["scales"].astype(np.int64)).sum(axis=1)
+        return isum.astype(np.int32), np.zeros(w.shape[0], np.int32)
+    if t == Q2_K:
+        sc = wb["scales"].astype(np.int64)
+        sub = (w * a).reshape(-1, 16, 16).sum(axis=2)
+        isum = (sub * (sc & 15)).sum(axis=1)
+        msum = (ab["bsums"].astype(np.int64) * (sc >> 4)).sum(axis=1)
+        return isum.astype(np.int32), msum.astype(np.int32)
+    if t == Q3_K:
+        sub = (w * a).reshape(-1, 16, 16).sum(axis=2)
+        isum = (sub * (q3_scales(wb["scales"]).astype(np.int64) - 32)).sum(axis=1)
         return isum.astype(np.int32), np.zeros(w.shape[0], np.int32)
     raise ValueError(t)

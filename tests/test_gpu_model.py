@@ -62,7 +62,10 @@ def rel_err(a, b):
                                           # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads)
                                           ("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l:70", "q5_k_m", "f16"),
                                           # f16 cache, 40-token prompts: the matrix-core prompt attention with f16 K / V (GQA 4:1 and MHA)
-                                          ("tiny-d128:40", "q4_k_m", "f16"), ("tiny-d128-mha:40", "q5_k_m", "f16")])
+                                          ("tiny-d128:40", "q4_k_m", "f16"), ("tiny-d128-mha:40", "q5_k_m", "f16"),
+                                          # Q2_K / Q3_K_M files (Q2_K + Q3_K + Q4_K / Q5_K + Q6_K tensors side by side): the type mix of the reference's smoke model
+                                          ("tiny-gqa4", "q2_k", "q8_0"), ("tiny-gqa4", "q3_k_m", "f16"), ("tiny-e2048", "q2_k", "q8_0"), ("tiny-d128:40", "q3_k_m", "q8_0"),
+                                          ("tiny-d128-mha", "q2_k", "f16")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)

@@ -10,7 +10,7 @@ import pytest
 
 import np_twin as tw
 import oracle_py as oq
-from oracle_py import F16, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K
+from oracle_py import F16, Q2_K, Q3_K, Q4_0, Q4_K, Q5_0, Q5_K, Q6_K, Q8_0, Q8_K
 
 
 def pack_k_scales(sc, mn):
@@ -151,15 +151,78 @@ def test_q6_K_offset_edges():
     assert y[5 + 96] == 0.5 * sc[6] * ((7 | (3 << 4)) - 32)
 
 
+def test_q5_0_closed_form():
+    """d = 0.5; element j: low nibble of qs[j] + 16 * bit j of qh, element j + 16: high nibble + 16 * bit j + 16; minus 16."""
+    b = np.zeros(1, tw.DT[Q5_0])
+    b["d"] = np.float16(0.5)
+    qs = np.zeros(16, np.uint8)
+    qs[3] = 0xA7                     # element 3: nibble 7, element 19: nibble 10
+    b["qs"] = qs
+    b["qh"] = np.uint32((1 << 3) | (1 << 31))     # fifth bit set for element 3 and element 31 (= bit 15 + 16)
+    y = oq.dequantize(Q5_0, b.view(np.uint8), 32)
+    assert y[3] == 0.5 * ((7 | 16) - 16) and y[19] == 0.5 * (10 - 16)
+    assert y[31] == 0.5 * ((0 | 16) - 16) and y[0] == 0.5 * (0 - 16)
+
+
+def test_q2_K_closed_form():
+    """Sub-block is = 8 n + 2 j + (l >= 16): value = d * (scales[is] & 15) * code - dmin * (scales[is] >> 4); code = bits 2 j .. 2 j + 1 of qs[32 n + l]."""
+    b = np.zeros(1, tw.DT[Q2_K])
+    b["d"] = np.float16(0.25); b["dmin"] = np.float16(0.5)
+    sc = np.arange(16, dtype=np.uint8) | ((15 - np.arange(16, dtype=np.uint8)) << 4)      # scale = is, min = 15 - is
+    b["scales"] = sc
+    qs = np.zeros(64, np.uint8)
+    qs[5] = 0b11_10_01_00            # n = 0, l = 5: codes 0, 1, 2, 3 for j = 0..3 (elements 5, 37, 69, 101)
+    qs[32 + 20] = 0b01_00_11_10      # n = 1, l = 20: codes 2, 3, 0, 1 (elements 128 + 20, + 52, + 84, + 116)
+    b["qs"] = qs
+    y = oq.dequantize(Q2_K, b.view(np.uint8), 256)
+    for j, code in enumerate([0, 1, 2, 3]):
+        is_ = 2 * j                  # n = 0, l = 5 < 16
+        assert y[32 * j + 5] == np.float32(0.25 * is_) * code - np.float32(0.5 * (15 - is_)), j
+    for j, code in enumerate([2, 3, 0, 1]):
+        is_ = 8 + 2 * j + 1          # n = 1, l = 20 >= 16
+        assert y[128 + 32 * j + 20] == np.float32(0.25 * is_) * code - np.float32(0.5 * (15 - is_)), j
+    assert y[0] == -np.float32(0.5 * 15)          # code 0, sub-block 0: just the minimum
+
+
+def test_q3_K_closed_form():
+    """value = d * (scale[is] - 32) * (code - (hmask bit ? 0 : 4)); scale is: low nibble from bytes 0..7 (is < 8: low, is >= 8: high nibble of byte is - 8),
+    high two bits from byte 8 + is % 4 at bit pair is // 4; hmask bit of element (n, j, l) is bit 4 n + j of hmask[l]."""
+    b = np.zeros(1, tw.DT[Q3_K])
+    b["d"] = np.float16(0.5)
+    want = np.array([0, 1, 31, 32, 33, 47, 48, 63, 5, 17, 29, 36, 44, 52, 60, 62])      # the 16 six-bit scales
+    s = np.zeros(12, np.uint8)
+    for j in range(16):
+        if j < 8:
+            s[j] |= want[j] & 15
+        else:
+            s[j - 8] |= (want[j] & 15) << 4
+        s[8 + j % 4] |= (want[j] >> 4) << (2 * (j // 4))
+    b["scales"] = s
+    assert tw.q3_scales(s[None, :])[0].tolist() == want.tolist()
+    qs = np.zeros(64, np.uint8); hm = np.zeros(32, np.uint8)
+    qs[7] = 0b10_01_11_00            # n = 0, l = 7: codes 0, 3, 1, 2 (elements 7, 39, 71, 103)
+    hm[7] = 0b0000_0101              # high bit present for j = 0 and j = 2 of half 0
+    qs[32 + 18] = 0b00_11_00_01      # n = 1, l = 18: codes 1, 0, 3, 0
+    hm[18] = 0b1010_0000             # high bit present for j = 1 and j = 3 of half 1 (bits 5, 7)
+    b["qs"] = qs; b["hmask"] = hm
+    y = oq.dequantize(Q3_K, b.view(np.uint8), 256)
+    for j, (code, hb) in enumerate([(0, 1), (3, 0), (1, 1), (2, 0)]):
+        assert y[32 * j + 7] == np.float32(0.5 * (want[2 * j] - 32)) * (code - (0 if hb else 4)), j
+    for j, (code, hb) in enumerate([(1, 0), (0, 1), (3, 0), (0, 1)]):
+        assert y[128 + 32 * j + 18] == np.float32(0.5 * (want[8 + 2 * j + 1] - 32)) * (code - (0 if hb else 4)), j
+    assert y[0] == np.float32(0.5 * (want[0] - 32)) * -4        # code 0, no high bit: -4
+
+
 # ------------------------------------------------------------------ twin agreement on random blocks
-@pytest.mark.parametrize("t,be,bb", [(Q4_0, 32, 18), (Q8_0, 32, 34), (Q4_K, 256, 144), (Q5_K, 256, 176), (Q6_K, 256, 210)])
+@pytest.mark.parametrize("t,be,bb", [(Q4_0, 32, 18), (Q8_0, 32, 34), (Q4_K, 256, 144), (Q5_K, 256, 176), (Q6_K, 256, 210), (Q5_0, 32, 22), (Q2_K, 256, 84),
+                                     (Q3_K, 256, 110)])
 def test_dequant_matches_twin_bit_exact(t, be, bb):
     rng = np.random.default_rng(100 + t)
     nb = 64
     raw = rng.integers(0, 256, nb * bb, dtype=np.uint8)
     blk = raw.view(tw.DT[t])
     blk["d"] = rng.uniform(-2, 2, nb).astype("<f2")
-    if t in (Q4_K, Q5_K):
+    if t in (Q4_K, Q5_K, Q2_K):
         blk["dmin"] = rng.uniform(-2, 2, nb).astype("<f2")
     a = oq.dequantize(t, raw, nb * be)
     b = tw.dequantize(t, raw)
@@ -211,15 +274,15 @@ def test_activation_quant_matches_twin():
 
 
 # ------------------------------------------------------------------ dot products
-@pytest.mark.parametrize("t,bb", [(Q8_0, 34), (Q4_K, 144), (Q5_K, 176), (Q6_K, 210)])
+@pytest.mark.parametrize("t,bb", [(Q8_0, 34), (Q4_K, 144), (Q5_K, 176), (Q6_K, 210), (Q5_0, 22), (Q2_K, 84), (Q3_K, 110)])
 def test_vec_dot_int_partials_and_value(t, bb):
     rng = np.random.default_rng(200 + t)
     K = 2048
-    be = 32 if t == Q8_0 else 256
+    be = 32 if t in (Q8_0, Q5_0) else 256
     raw = rng.integers(0, 256, K // be * bb, dtype=np.uint8)
     blk = raw.view(tw.DT[t])
     blk["d"] = rng.uniform(0.5, 1.5, K // be).astype("<f2") * np.float16(1e-2)
-    if t in (Q4_K, Q5_K):
+    if t in (Q4_K, Q5_K, Q2_K):
         blk["dmin"] = rng.uniform(0.5, 1.5, K // be).astype("<f2") * np.float16(1e-2)
     x = rng.standard_normal(K).astype(np.float32)
     at = oq.vec_dot_type(t)
