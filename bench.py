@@ -35,6 +35,19 @@ MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 / fp8 matrix-core peak of MI355X (M
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
+KERNEL_SOURCES = ("mmvq_stream.hip", "mmvq_stream_dev.h", "mmvq_fast.hip", "mmvq_fast_dev.h", "mmvq.hip", "quant_dev.h", "dev_common.h")
+
+
+def kernel_sources_sha256(root: str) -> str:
+    """Identity of the decode mat-vec kernel sources (what a committed PMC traffic figure is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in KERNEL_SOURCES:
+        with open(os.path.join(root, "cortex.llamacpp_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def aggregate(n_gpus: int, steps: int, dt_max: float) -> dict:
     """Whole-job numbers from the slowest rank's wall time: every rank decoded `steps` tokens of its own sequence."""
     return {"value": round(n_gpus * steps / dt_max, 2), "ms_per_step": round(dt_max / steps * 1e3, 4)}
@@ -140,7 +153,7 @@ def main() -> int:
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--cache-type", default="q8_0", choices=["f16", "q8_0", "q4_0"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--model-dir", default=os.environ.get("MI355_BENCH_DIR", "/tmp"))
     ap.add_argument("--keep-model", action="store_true")
     ap.add_argument("--no-long-context", action="store_true", help="skip the context-filled-to-3968 measurement")
@@ -276,6 +289,27 @@ def main() -> int:
         finish_rank(None)
         return 0
 
+    # ---- the long-context point of the same config under the SAME contract as the headline (logits row host-visible after every step): context
+    # filled to 3968 of 4096, then greedy decode
+    long_host = None
+    if args.ctx >= 4096 and not args.no_long_context:
+        fill = args.ctx - 128
+        lp0 = np.random.default_rng(4321).integers(0, model.n_vocab, fill)
+        ctx.kv_clear()
+        for i0 in range(0, fill, 2048):
+            chunk = lp0[i0:i0 + 2048]
+            assert ctx.decode(chunk, np.arange(i0, i0 + chunk.size)) == 0
+        tok_l, pos_l = ctx.argmax(), fill
+        for _ in range(8):
+            tok_l = step(tok_l, pos_l); pos_l += 1
+        ctx.synchronize()
+        n_l = min(64, args.ctx - pos_l)
+        t0 = time.perf_counter()
+        for _ in range(n_l):
+            tok_l = step(tok_l, pos_l); pos_l += 1
+        ctx.synchronize()
+        long_host = n_l / (time.perf_counter() - t0)
+
     # ---- device-greedy variant: logits stay on the device, only the argmax crosses
     ctx.close()
     ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True,
@@ -317,9 +351,10 @@ def main() -> int:
         dt_l = time.perf_counter() - t0
         b_per_l = {"f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.cache_type]
         kv_l = 2 * cfg.n_layer * cfg.n_head_kv * cfg.head_dim * (pos_l - n_l // 2) * b_per_l
-        long_ctx = {"prompt": fill, "prefill_tok_s": round(fill / t_fill, 1), "decode_tok_s_device_greedy": round(n_l / dt_l, 2),
+        long_ctx = {"prompt": fill, "prefill_tok_s": round(fill / t_fill, 1), "decode_tok_s": round(long_host, 2) if long_host else None,
+                    "decode_tok_s_device_greedy": round(n_l / dt_l, 2),
                     "decode_pos": [pos_l - n_l, pos_l], "kv_bytes_per_token": int(kv_l),
-                    "decode_hbm_fraction_of_8TBps": round((model.bytes_per_token + kv_l) * (n_l / dt_l) / (HBM_PEAK_GBPS * 1e9), 4)}
+                    "decode_hbm_fraction_of_8TBps": round((model.bytes_per_token + kv_l) * (long_host or n_l / dt_l) / (HBM_PEAK_GBPS * 1e9), 4)}
 
     # ---- roofline of the dominant kernel (quantised mat-vec), HIP events on the kernel's own stream
     sweep_us, sweep_bytes = ctx.weight_sweep_us(iters=5)
@@ -330,12 +365,19 @@ def main() -> int:
 
     # HBM bytes the same sweep moved, from the PMC pass committed under profiles/ (FETCH_SIZE, corrected x2 per the gfx950
     # note of the microarchitecture guide); null when the profile is absent or is for another workload
-    traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_decode_traffic.json")
+    traffic, traffic_note = None, "no PMC profile for this workload"
+    root = os.path.dirname(os.path.abspath(__file__))
+    tpath = os.path.join(root, "profiles", "r3_pmc_decode_traffic.json")
     if os.path.exists(tpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
             with open(tpath) as f:
-                traffic = int(json.load(f)["matvec_hbm_read_bytes_per_token"])
+                tj = json.load(f)
+            # the profile names the kernel sources it was taken from (sha256 over the mat-vec kernel files): a kernel change since then makes the
+            # figure stale, and it is withheld rather than repeated
+            if tj.get("kernel_sources_sha256") == kernel_sources_sha256(root):
+                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), "profiles/r3_pmc_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
+            else:
+                traffic_note = "profiles/r3_pmc_decode_traffic.json was taken from other kernel sources than this tree's: withheld"
         except (OSError, ValueError, KeyError):
             traffic = None
 
@@ -384,6 +426,10 @@ def main() -> int:
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_note,
+            "method": "the step's own fused single-token launches of every weight tensor (129 for this model), replayed from a hipGraph, HIP events on the "
+                      "context's stream; achieved = algorithmic weight bytes / sweep time, so launch boundaries count as kernel time (rounds 2-3; round 1 "
+                      "swept unfused eager launches: its 0.441 is not comparable)",
             "bytes_per_sweep": int(sweep_bytes),
             "launches_per_sweep": n_launch,
             "avg_launch_us": round(sweep_us / n_launch, 3),

@@ -593,6 +593,21 @@ int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t ra
     return MI355_OK;
 }
 
+int mi355_tp_p2p_local_handle(void *out, size_t cap, size_t max_floats) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    std::string err;
+    const int n = tp_p2p_local_handle(out, cap, max_floats, err);
+    if (n < 0) { fail(err); return MI355_ERR_ARG; }
+    return n;
+}
+int mi355_tp_p2p_enable(const void *handles, size_t len) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    std::string err;
+    if (tp_p2p_enable(handles, len, err) != 0) { fail(err); return MI355_ERR_HIP; }
+    return MI355_OK;
+}
+int64_t mi355_tp_p2p_exchanges(void) { return tp_p2p_exchanges(); }
+
 double mi355_bench_hbm_read(size_t bytes, int iters) {
     if (!need_device()) return -1.0;
     return hbm_read_probe(bytes, iters);

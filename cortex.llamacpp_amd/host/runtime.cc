@@ -447,7 +447,7 @@ bool Context::init(std::string &err) {
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, model->device) == hipSuccess) set_num_cu(prop.multiProcessorCount);
-    if (unsigned *ew = stream_error_word()) { mmvq_stream_set_error_word(ew); decode_engine_set_error_word(ew); }   // (per device: the pointer lives in device globals)
+    if (unsigned *ew = stream_error_word()) { mmvq_stream_set_error_word(ew); decode_engine_set_error_word(ew); tp_p2p_set_error_word(ew); }   // (per device: the pointer lives in device globals)
 
     const size_t T = cp.n_ubatch, E = hp.n_embd, FF = hp.n_ff, G = hp.n_head_kv, D = hp.head_dim, NC = cp.n_ctx;
     cells_.assign(NC, KVCell());
@@ -528,7 +528,11 @@ bool Context::init(std::string &err) {
     mmq_bl_ = (int8_t *)dalloc(mmq_prep_bytes((int)std::max(E, FF), prep_rows));
     // partial sums of the K-split prompt contraction: only tensors with few rows split (Q | K | V, attention output, FFN down),
     // up to four ways; tensors that do not fit fall back to an unsplit kernel
-    mmq_ws_.bytes = (size_t)4 * T * std::max<size_t>(E, (size_t)(hp.n_head + 2 * hp.n_head_kv) * D) * sizeof(float);
+    // A launch only splits while its 128 x 256 tiles number fewer than 3/4 of the CUs, and then into ceil(CUs / tiles) <= 4 parts (mmq.hip planes2_split):
+    // n_split * tiles < CUs + tiles < 7/4 CUs, i.e. never more than 7/4 * CUs tiles' worth of partial sums whatever the model (58.7 MB on 256 CUs;
+    // sized by the widest tensor instead it was 335 MB per context for Llama-3-70B at n_ubatch 2048)
+    mmq_ws_.bytes = std::min((size_t)4 * T * std::max<size_t>(E, (size_t)(hp.n_head + 2 * hp.n_head_kv) * D) * sizeof(float),
+                             (size_t)(num_cu() * 7 / 4) * 128 * 256 * sizeof(float));
     mmq_ws_.p = T >= 128 ? (float *)dalloc(mmq_ws_.bytes) : nullptr;
     if (!mmq_ws_.p) mmq_ws_.bytes = 0;
     if (!ok || !x_ || !ffn_u_) { err = "activation buffer allocation failed"; return false; }

@@ -262,9 +262,14 @@ bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &
     {   // token ids straight from the request: one bad id must fail THIS request, not the decode of every slot in the tick
         const int n_vocab = be_->n_vocab();
         auto bad_id = [&](int64_t t) { return t < 0 || t >= n_vocab; };
-        for (int32_t t : slot->prompt_tokens) if (bad_id(t)) return false;
+        auto refuse = [&](const std::string &why) { launch_error_ = why; return false; };
+        for (int32_t t : slot->prompt_tokens) if (bad_id(t)) return refuse("token id " + std::to_string(t) + " out of range for this model's vocabulary");
         if (slot->prompt.is_array())
-            for (const Json &p : slot->prompt.items()) if (!p.is_string() && (!p.is_int() || bad_id(p.as_int()))) return false;
+            for (const Json &p : slot->prompt.items()) {
+                if (p.is_string()) continue;
+                if (!p.is_int()) return refuse("prompt array elements must be strings or token ids");
+                if (bad_id(p.as_int())) return refuse("token id " + std::to_string(p.as_int()) + " out of range for this model's vocabulary");
+            }
     }
 
     sp.logit_bias.clear();
@@ -340,7 +345,8 @@ void LlamaServerContext::ProcessTasks() {   // :1152-1237
         slot->embedding = task.embedding_mode;       // :1194
         if (!LaunchSlotWithData(slot, task.data)) {
             slot->Release();
-            SendError(*slot, "Invalid request: token id out of range for this model's vocabulary");
+            SendError(*slot, "Invalid request: " + (launch_error_.empty() ? std::string("the slot could not take it") : launch_error_));
+            launch_error_.clear();
         }
     }
     for (auto &t : deferred) queue_tasks_.push_back(std::move(t));

@@ -124,6 +124,7 @@ class LlamaServerContext {
     std::unique_ptr<SamplePool> sample_pool_;
     LlamaClientSlot *GetSlot(int id);
     bool LaunchSlotWithData(LlamaClientSlot *&slot, const Json &data);
+    std::string launch_error_;         // why the last LaunchSlotWithData refused its request (sent to the client with the error)
     void ProcessTasks();
     bool ProcessToken(CompletionTokenOutput &result, LlamaClientSlot &slot);
     size_t FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot);

@@ -32,6 +32,21 @@ bool tp_active();         // a group exists (possibly of one rank)
 int tp_size();            // 1 = no group, or a group of one
 bool tp_uses_host();      // host transport: no stream capture
 
+// ---- one-shot peer-to-peer all-reduce for the decode-sized messages (SURVEY.md §8e "fast path"): 2 L exchanges of 16 - 32 KB per token are
+// latency-bound, and a collective library call costs 10 - 20 us each.  Every rank owns one buffer (IPC-exported device memory) of 2 sets x P slots;
+// an exchange = each rank writes its partial into slot `rank` of EVERY rank's buffer (xGMI peer stores), raises a per-slice flag there, waits for
+// the P flags of its own buffer and adds the P slots in rank order (the same order on every rank: all ranks hold the same bits).  One kernel per
+// exchange, capturable into the decode graphs; the two sets alternate, so a rank that runs one exchange ahead never overwrites what a peer still
+// reads.  Messages above `max_floats` (prompt batches) keep the base transport (RCCL / host).
+// Bootstrap: tp_p2p_local_handle on every rank -> all-gather the 64-byte handles over any side channel (the one that carried the RCCL id) ->
+// tp_p2p_enable with all of them, after tp_init / tp_set_host_exchange.
+constexpr int TP_P2P_HANDLE_BYTES = 64;
+int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, std::string &err);   // returns TP_P2P_HANDLE_BYTES or < 0
+int tp_p2p_enable(const void *handles, size_t len, std::string &err);                  // len = size * TP_P2P_HANDLE_BYTES, rank-major
+bool tp_p2p_active();
+void tp_p2p_set_error_word(unsigned *host_word);     // pinned host word ORed with 32 when a bounded wait of the exchange kernel gives up
+int64_t tp_p2p_exchanges();                          // diagnosis: all-reduces that took the peer-to-peer kernel
+
 // recv[i] = sum over ranks of send[i]; send may equal recv
 hipError_t tp_all_reduce_sum(const float *send, float *recv, size_t n, hipStream_t st);
 // recv[r * n + i] = rank r's send[i]

@@ -272,6 +272,14 @@ MI355_API int32_t mi355_tp_size(void);
 /* Validation transport for boxes where the ranks share one GPU (RCCL refuses that): the exchange goes through this
  * host callback instead (op 0: sum `n` floats in place over the ranks; op 1: all-gather, `n` floats per rank, the caller's
  * part already at buf + rank * n).  Graphs are off while it is set.  fn == NULL removes it. */
+/* One-shot peer-to-peer all-reduce for the decode-sized exchanges (host/tp_comm.h): after mi355_tp_init (or _set_host_exchange) every
+ * rank calls mi355_tp_p2p_local_handle (64 bytes out; max_floats = the largest message it should take, e.g. n_embd * 8), the handles are gathered
+ * rank-major over the side channel that carried the RCCL id, and every rank calls mi355_tp_p2p_enable with all of them.  All-reduces of up to max_floats
+ * floats then run as one peer-to-peer kernel (IPC-mapped buffers, xGMI peer stores, rank-order sum); larger ones keep the base transport. */
+#define MI355_TP_P2P_HANDLE_BYTES 64
+MI355_API int mi355_tp_p2p_local_handle(void *out, size_t cap, size_t max_floats);   /* returns bytes written or < 0 */
+MI355_API int mi355_tp_p2p_enable(const void *handles, size_t len);
+MI355_API int64_t mi355_tp_p2p_exchanges(void);                                      /* diagnosis: all-reduces that took the peer-to-peer kernel */
 typedef int (*mi355_tp_host_exchange)(void *user, float *buf, size_t n, int32_t op);
 MI355_API int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t rank, int32_t size);
 

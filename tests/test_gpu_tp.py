@@ -59,7 +59,7 @@ def run_ranks(world, plan_path, out_path, timeout=600):
     return np.load(out_path)
 
 
-def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n_tail=3, seed=21):
+def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n_tail=3, seed=21, p2p_floats=0):
     path = str(tmp_models / f"tp-{cfg}-{ftype}.gguf")
     if not os.path.exists(path):
         pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
@@ -81,9 +81,9 @@ def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n
     ref.extend(oc.decode(tail, np.arange(pos, pos + n_tail), want_logits=np.ones(n_tail, np.int8)))
     oq.set_fa_v_acc_f32(0)
     oc.close(); om.close()
-    plan_path = str(tmp_models / f"tp-plan-{cfg}-{ftype}-{kv}-{n_prompt}-{transport}.npz")
+    plan_path = str(tmp_models / f"tp-plan-{cfg}-{ftype}-{kv}-{n_prompt}-{transport}-{p2p_floats}.npz")
     np.savez(plan_path, path=path, kv=KV[kv], transport=transport, n_ctx=256, n_ubatch=64, prompt=prompt,
-             steps=np.asarray(steps, np.int32), tail=tail)
+             steps=np.asarray(steps, np.int32), tail=tail, p2p_floats=p2p_floats)
     return path, plan_path, np.stack(ref)
 
 
@@ -143,6 +143,32 @@ def test_ranks_sharing_one_gpu_match_oracle_and_unsplit(pkg, tmp_models, cfg, ft
         top = np.sort(b)[-2:]
         if top[1] - top[0] > 2 * FLIP_TOL * max(1.0, np.abs(b).max()):
             assert int(a.argmax()) == int(b.argmax())
+
+
+@pytest.mark.parametrize("cfg,ftype,kv,world", [("tiny-e2048", "q4_k_m", "q8_0", 2), ("tiny-8b-2l", "q4_k_m", "q8_0", 2), ("tiny-e2048", "q4_k_m", "q8_0", 4)])
+def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg, ftype, kv, world):
+    """The one-shot peer-to-peer all-reduce (host/tp_comm.cc: every rank writes its partial into slot `rank` of every rank's IPC-mapped buffer, flags,
+    rank-order sum) takes the decode-sized exchanges; the prompt batch and the logits gather keep the host transport.  IPC mapping works between
+    processes that share the one GPU of this box (the xGMI path itself needs a multi-GPU node).  Two ranks: p0 + p1 is the same sum in either
+    transport, so every logits row is bit-identical to the pure host-exchange run; four ranks: the rank-order sum differs from gloo's by re-association
+    only - oracle bound, and the same bits on a second run."""
+    pkg.Backend()
+    E = pkg.gguf_synth.CONFIGS[cfg].n_embd
+    path, plan_host, ref = make_plan(pkg, tmp_models, cfg, ftype, kv, 8, "host")
+    _, plan_p2p, _ = make_plan(pkg, tmp_models, cfg, ftype, kv, 8, "host", p2p_floats=4 * E)
+    host = run_ranks(world, plan_host, str(tmp_models / f"tp-out-host-{cfg}-{world}.npz"))
+    p2p = run_ranks(world, plan_p2p, str(tmp_models / f"tp-out-p2p-{cfg}-{world}.npz"))
+    n_layer = pkg.gguf_synth.CONFIGS[cfg].n_layer
+    assert int(host["p2p_exchanges"]) == 0
+    assert int(p2p["p2p_exchanges"]) >= 2 * n_layer * 6            # the six single-token steps (and the three-token tail: 3 E <= 4 E)
+    errs = [rel_err(a, b) for a, b in zip(p2p["logits"], ref)]
+    assert max(errs) <= FLIP_TOL, errs
+    if world == 2:
+        assert np.array_equal(p2p["logits"], host["logits"])
+    else:
+        again = run_ranks(world, plan_p2p, str(tmp_models / f"tp-out-p2p2-{cfg}-{world}.npz"))
+        assert np.array_equal(p2p["logits"], again["logits"])
+        assert max(rel_err(a, b) for a, b in zip(p2p["logits"], host["logits"])) <= FLIP_TOL
 
 
 def test_rccl_group_of_one_captured_in_graphs_is_bit_identical(pkg, tmp_models):

@@ -26,7 +26,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg.Backend()
-    pkg.binding.tp_init(rank, world, device=0, transport=transport)
+    p2p = int(plan["p2p_floats"]) if "p2p_floats" in plan.files else 0
+    pkg.binding.tp_init(rank, world, device=0, transport=transport, p2p_floats=p2p)
     model = pkg.Model(str(plan["path"]), tp_rank=rank, tp_size=world)
     ctx = pkg.Context(model, n_ctx=int(plan["n_ctx"]), type_k=int(plan["kv"]), type_v=int(plan["kv"]), n_ubatch=int(plan["n_ubatch"]))
     rows = []
@@ -51,7 +52,7 @@ def main():
         np.savez(sys.argv[2] + f".rank{rank}.npz", logits=np.stack(rows))
     if rank == 0:
         np.savez(sys.argv[2], logits=np.stack(rows), taps=taps, n_head=model.n_head, n_head_kv=model.n_head_kv,
-                 bytes_per_token=model.bytes_per_token)
+                 bytes_per_token=model.bytes_per_token, p2p_exchanges=pkg.binding.tp_p2p_exchanges())
     ctx.close(); model.close()
     pkg.binding.tp_shutdown()
     if world > 1:
