@@ -76,6 +76,7 @@ SYMBOLS = {
     "mi355_decode": (_i32, [_vp, Batch]),
     "mi355_get_logits_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_get_argmax_ith": (_i32, [_vp, _i32]),
+    "mi355_get_topk_ith": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp]),
     "mi355_debug_mega_steps": (C.c_int64, [_vp]),
     "mi355_debug_engine_steps": (C.c_int64, [_vp]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
@@ -488,6 +489,15 @@ class Context:
     def mega_steps(self) -> int:
         """Single-token steps that ran as one whole-step launch (diagnosis)."""
         return int(self.lib.mi355_debug_mega_steps(self.h))
+
+    def topk(self, k: int, i: int = -1, adj_tok=(), adj_bias=(), adj_count=(), repeat: float = 1.0, freq: float = 0.0, present: float = 0.0):
+        """Device-side sampling front end: (tokens [k] int32, logits [k] f32) of row i after the adjustments, best first."""
+        at = np.ascontiguousarray(adj_tok, np.int32); ab = np.ascontiguousarray(adj_bias, np.float32); ac = np.ascontiguousarray(adj_count, np.int32)
+        toks = np.zeros(k, np.int32); lg = np.zeros(k, np.float32)
+        r = self.lib.mi355_get_topk_ith(self.h, i, k, at.size, _ptr(at), _ptr(ab), _ptr(ac), repeat, freq, present, _ptr(toks), _ptr(lg))
+        if r != k:
+            raise MI355Error(f"mi355_get_topk_ith failed: {_err(self.lib)}")
+        return toks, lg
 
     def engine_steps(self) -> int:
         """Single-token steps that ran through the layer engine (one persistent launch per layer; diagnosis)."""

@@ -127,6 +127,45 @@ __global__ void step_setup_kernel(const int32_t *tok_pos, int T, RopeArgs ra, fl
     cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
     cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
 }
+// ... and the embedding rows of the batch's tokens (ggml_get_rows of token_embd, dequantised: get_rows_kernel of misc.hip) in the same launch: grid
+// (row parts, tokens) of 256 threads; the first T * n_rot / 2 threads of the grid also fill the cos / sin table, block (0, 0) the cell metadata
+__global__ __launch_bounds__(256) void step_setup_embed_kernel(const int32_t *tok_pos, int T, RopeArgs ra, float theta_scale, float *cs_out, int32_t *cell_pos,
+                                                               uint64_t *cell_seq, const int32_t *tok_cell, const uint64_t *tok_seqmask, unsigned *zero_word,
+                                                               unsigned *epoch_word, int type, const uint8_t *table, int K, size_t row_bytes,
+                                                               const int32_t *ids, float *dst) {
+    const int lin = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (zero_word && threadIdx.x < 9) zero_word[threadIdx.x == 0 ? 0 : 32 * threadIdx.x] = 0u;
+        if (epoch_word && threadIdx.x == 0) epoch_word[0] = epoch_word[0] + 1u;
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            cell_pos[tok_cell[t]] = tok_pos[t];
+            cell_seq[tok_cell[t]] = tok_seqmask[t];
+        }
+    }
+    const int half = ra.n_rot >> 1;
+    if (lin < T * half) {
+        const int t = lin / half, i = lin - t * half;
+        float c, s;
+        rope_angle(i, tok_pos[t], theta_scale, ra.freq_scale, ra.freq_factors, c, s);
+        cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
+        cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
+    }
+    const int i = blockIdx.y;
+    const uint8_t *row = table + (size_t)ids[i] * row_bytes;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < K; e += gridDim.x * blockDim.x)
+        dst[(size_t)i * K + e] = dequant_elem(type, row, K, e);
+}
+hipError_t launch_step_setup_embed(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
+                                   const uint64_t *tok_seqmask, unsigned *zero_word, unsigned *epoch_word, int type, const uint8_t *table, int64_t K,
+                                   const int32_t *ids, float *dst, hipStream_t st) {
+    const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);
+    int bx = (int)((K + 255) / 256);
+    if (bx > 64) bx = 64;
+    while ((long)bx * T * 256 < (long)T * (ra.n_rot >> 1)) bx++;          // (enough threads for the table: n_rot / 2 <= 256 * bx per token)
+    hipLaunchKernelGGL(step_setup_embed_kernel, dim3(bx, T), dim3(256), 0, st, tok_pos, T, ra, theta_scale, cs_out, cell_pos, cell_seq, tok_cell, tok_seqmask,
+                       zero_word, epoch_word, type, table, (int)K, dev_row_bytes(type, K), ids, dst);
+    return hipGetLastError();
+}
 hipError_t launch_step_setup(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
                              const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st, unsigned *epoch_word) {
     const float theta_scale = powf(ra.freq_base, -2.0f / (float)ra.n_rot);

@@ -209,6 +209,16 @@ int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
 }
 float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
+int32_t mi355_get_topk_ith(mi355_context *ctx, int32_t i, int32_t k, int32_t n_adj, const int32_t *adj_tok, const float *adj_bias, const int32_t *adj_count,
+                           float penalty_repeat, float penalty_freq, float penalty_present, int32_t *toks_out, float *logits_out) {
+    if (!ctx || !toks_out || !logits_out || n_adj < 0 || n_adj > TOPK_MAX_ADJ || (n_adj > 0 && (!adj_tok || !adj_bias || !adj_count))) { fail("bad arguments"); return -1; }
+    TopkAdj a{};
+    a.n = n_adj; a.repeat = penalty_repeat; a.freq = penalty_freq; a.present = penalty_present;
+    for (int j = 0; j < n_adj; j++) { a.tok[j] = adj_tok[j]; a.bias[j] = adj_bias[j]; a.cnt[j] = adj_count[j]; }
+    const int r = ctx->c->topk_ith(i, k, a, toks_out, logits_out);
+    if (r < 0) fail(ctx->c->last_error.empty() ? "top-k failed" : ctx->c->last_error);
+    return r;
+}
 int64_t mi355_debug_mega_steps(const mi355_context *ctx) { return ctx->c->mega_steps; }
 int64_t mi355_debug_engine_steps(const mi355_context *ctx) { return ctx->c->engine_steps; }
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0; }
@@ -561,6 +571,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "rope_fast")) { set_rope_fast(value != 0); return MI355_OK; }
     if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
     if (!strcmp(name, "decode_engine")) { set_decode_engine(value); return MI355_OK; }
+    if (!strcmp(name, "tp_p2p")) { tp_p2p_use(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
     if (!strcmp(name, "tp_null_group")) { tp_set_null_group(0, value); return MI355_OK; }

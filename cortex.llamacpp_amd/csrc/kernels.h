@@ -162,7 +162,23 @@ hipError_t launch_pack_q80_blocks(const ActQuant &q, int n, int T, uint8_t *bloc
 hipError_t launch_repack_rows(int type, const uint8_t *src_ggml, uint8_t *dst_dev, int64_t K, int64_t n_rows, hipStream_t st);
 // dst[i][:] = dequant(table row ids[i]) from device-layout rows
 hipError_t launch_get_rows(int type, const uint8_t *table_dev, int64_t K, const int32_t *ids, int n_ids, float *dst, hipStream_t st);
-hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch /* rows*128 words */, hipStream_t st);
+hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch /* rows*129 words, zero */, hipStream_t st);
+// ---- device-side sampling front end (reference call site common_sampler_sample, src/llama_server_context.cc:1679-1698): the k best
+// candidates of a logits row after logit_bias and the repetition / frequency / presence penalties, so that k (token, logit) pairs cross to the host
+// instead of the 513 KB row.  Order = the host sampler's (host/sampling.cc `better`): higher logit first, lower token id on ties.  Exact: the same f32
+// operations on the adjusted tokens (l + bias; l <= 0 ? l * repeat : l / repeat; l -= count * freq + present), keys compared as integers.
+constexpr int TOPK_MAX_K = 128, TOPK_MAX_ADJ = 192;
+struct TopkAdj {                        // by value into the first kernel
+    int n;                              // adjusted tokens
+    float repeat, freq, present;
+    int tok[TOPK_MAX_ADJ];
+    float bias[TOPK_MAX_ADJ];           // 0 = none
+    int cnt[TOPK_MAX_ADJ];              // occurrences in the penalty window (0 = not penalised)
+};
+size_t topk_scratch_bytes(int n);       // workspace for a row of n logits
+// keys_out (device or pinned host memory, k 64-bit words): key = (order-preserving image of the f32 logit) << 32 | (0xffffffff - token), best first
+hipError_t launch_topk_row(const float *x, int n, int k, const TopkAdj &adj, void *scratch, unsigned long long *keys_out, hipStream_t st);
+
 // f32 / f16 weight mat-vec (router, unquantised models): y[t][r] = dot(W[r], x[t])
 hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,
                             const float *resid, hipStream_t st);
@@ -211,6 +227,10 @@ hipError_t launch_rope_table(const int32_t *tok_pos, int T, RopeArgs ra, float *
 // epoch_word (nullable): device word incremented once per call - the step serial the hand-over tags of decode_engine.hip are built from
 hipError_t launch_step_setup(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
                              const uint64_t *tok_seqmask, unsigned *zero_word, hipStream_t st, unsigned *epoch_word = nullptr);
+// launch_step_setup + launch_get_rows (the batch's embedding rows, dst[T][K]) in one launch
+hipError_t launch_step_setup_embed(const int32_t *tok_pos, int T, RopeArgs ra, float *cs_out, int32_t *cell_pos, uint64_t *cell_seq, const int32_t *tok_cell,
+                                   const uint64_t *tok_seqmask, unsigned *zero_word, unsigned *epoch_word, int type, const uint8_t *table_dev, int64_t K,
+                                   const int32_t *ids, float *dst, hipStream_t st);
 hipError_t launch_rope_inplace(float *x, int T, int n_head, int D, const int32_t *tok_pos, RopeArgs ra, hipStream_t st);
 
 struct AttnArgs {

@@ -2,6 +2,7 @@
 // f32/f16 mat-vec (MoE router, unquantised tensors), row argmax (device-side greedy front end).
 // SURVEY.md §8a rows a16 (get_rows), a18 (router), §8f.1 (device argmax).
 #include "kernels.h"
+#include "quant_dev.h"
 
 namespace mi355 {
 
@@ -81,62 +82,7 @@ hipError_t launch_repack_rows(int type, const uint8_t *src, uint8_t *dst, int64_
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------- dequantise one element of a device row
-__device__ __forceinline__ void k4_scale_min(int j, const uint8_t *p, int &sc, int &mn) {
-    if (j < 4) { sc = p[j] & 63; mn = p[j + 4] & 63; }
-    else { sc = (p[j + 4] & 0x0f) | ((p[j - 4] >> 6) << 4); mn = (p[j + 4] >> 4) | ((p[j] >> 6) << 4); }
-}
-
-__device__ float dequant_elem(int type, const uint8_t *row, int K, int e) {
-    switch (type) {
-        case T_F32: return reinterpret_cast<const float *>(row)[e];
-        case T_F16: return h2f(reinterpret_cast<const uint16_t *>(row)[e]);
-        case T_Q8_0: {
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + K + (e >> 5) * 2));
-            return __fmul_rn((float)(int8_t)row[e], d);
-        }
-        case T_Q4_K: case T_Q5_K: {
-            const int bsz = type == T_Q4_K ? 144 : 176;
-            const uint8_t *b = row + (size_t)(e >> 8) * bsz;
-            const int r = e & 255, j = r >> 5, l = r & 31, c = j >> 1;
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(b)), dm = h2f(*reinterpret_cast<const uint16_t *>(b + 2));
-            int sc, mn;
-            k4_scale_min(j, b + 4, sc, mn);
-            const uint8_t *qs = b + (type == T_Q4_K ? 16 : 48);
-            int q = (j & 1) ? (qs[32 * c + l] >> 4) : (qs[32 * c + l] & 0x0f);
-            if (type == T_Q5_K && ((b[16 + l] >> j) & 1)) q += 16;
-            return __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(dm, (float)mn));
-        }
-        case T_Q2_K: {   // element (n, j, l) of block sb: bits 2 j .. 2 j + 1 of qs[32 n + l]; sub-block is = 8 n + 2 j + l / 16
-            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, j = (r >> 5) & 3, l = r & 31, is = 8 * n + 2 * j + (l >> 4);
-            const uint8_t q = row[(size_t)sb * 64 + 32 * n + l], sc = row[(size_t)nb * 64 + (size_t)sb * 16 + is];
-            const uint16_t *dm = reinterpret_cast<const uint16_t *>(row + (size_t)nb * 80 + (size_t)sb * 4);
-            const float dl = __fmul_rn(h2f(dm[0]), (float)(sc & 0xf)), ml = __fmul_rn(h2f(dm[1]), (float)(sc >> 4));
-            return __fsub_rn(__fmul_rn(dl, (float)((q >> (2 * j)) & 3)), ml);
-        }
-        case T_Q3_K: {
-            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, j = (r >> 5) & 3, l = r & 31, is = 8 * n + 2 * j + (l >> 4);
-            const uint8_t q = row[(size_t)nb * 32 + (size_t)sb * 64 + 32 * n + l], hm = row[(size_t)sb * 32 + l];
-            const uint8_t *s12 = row + (size_t)nb * 96 + (size_t)sb * 12;
-            const int low = is < 8 ? (s12[is] & 0xf) : (s12[is - 8] >> 4), high = (s12[8 + (is & 3)] >> (2 * (is >> 2))) & 3;
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + (size_t)nb * 108 + (size_t)sb * 2));
-            const int code = (int)((q >> (2 * j)) & 3) - (((hm >> (4 * n + j)) & 1) ? 0 : 4);
-            return __fmul_rn(__fmul_rn(d, (float)((low | (high << 4)) - 32)), (float)code);
-        }
-        case T_Q6_K: {
-            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, rr = r & 127, k = rr >> 5, l = rr & 31;
-            const uint8_t *ql = row + (size_t)sb * 128 + n * 64, *qh = row + (size_t)nb * 128 + (size_t)sb * 64 + n * 32;
-            const int8_t *sc = reinterpret_cast<const int8_t *>(row + (size_t)nb * 192 + (size_t)sb * 16 + n * 8);
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + (size_t)nb * 208 + (size_t)sb * 2));
-            const int lo = (k & 1) ? ql[l + 32] : ql[l];
-            const int nib = (k & 2) ? (lo >> 4) : (lo & 0x0f);
-            const int q = (nib | (((qh[l] >> (2 * k)) & 3) << 4)) - 32;
-            return __fmul_rn(__fmul_rn(d, (float)sc[2 * k + (l >> 4)]), (float)q);
-        }
-    }
-    return 0.0f;
-}
-
+// (dequant_elem: one element of a device row - quant_dev.h, shared with the step set-up kernel of attn.hip)
 __global__ void get_rows_kernel(int type, const uint8_t *table, int K, size_t row_bytes, const int32_t *ids, float *dst) {
     const int i = blockIdx.y;
     const uint8_t *row = table + (size_t)ids[i] * row_bytes;
@@ -167,9 +113,12 @@ __device__ __forceinline__ void argmax_block_reduce(float &best, int &idx, float
         for (int w = 1; w < 4; w++)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
 }
-__global__ __launch_bounds__(256) void argmax_part_kernel(const float *x, int n, float *pv, int *pi) {
+// One launch: every workgroup reduces its part, takes a ticket on the row's counter, and the LAST arriver reduces the 64 parts (device-coherent loads
+// of what the others wrote, no cache-wide fence) and writes the winner - the second launch this replaced cost ~4.5 us of every decoded token.
+__global__ __launch_bounds__(256) void argmax_part_kernel(const float *x, int n, float *pv, int *pi, unsigned *cnt, int32_t *out) {
     __shared__ float bv[4];
     __shared__ int bi[4];
+    __shared__ int last_sh;
     const int row = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const float *xr = x + (size_t)row * n;
     const int chunk = (n + ARGMAX_PARTS - 1) / ARGMAX_PARTS;
@@ -181,26 +130,111 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const float *x, int n,
         if (v > best || (v == best && i < idx)) { best = v; idx = i; }
     }
     argmax_block_reduce(best, idx, bv, bi);
-    if (tid == 0) { pv[row * ARGMAX_PARTS + part] = best; pi[row * ARGMAX_PARTS + part] = idx; }
-}
-__global__ void argmax_final_kernel(const float *pv, const int *pi, int32_t *out) {
-    const int row = blockIdx.x, lane = threadIdx.x;   // 64 threads
-    float best = pv[row * ARGMAX_PARTS + lane];
-    int idx = pi[row * ARGMAX_PARTS + lane];
+    if (tid == 0) {
+        __hip_atomic_store(pv + row * ARGMAX_PARTS + part, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pi + row * ARGMAX_PARTS + part, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the two write-through stores have left before the ticket does
+        const unsigned t = __hip_atomic_fetch_add(cnt + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = t == ARGMAX_PARTS - 1 ? 1 : 0;
+        if (last_sh) __hip_atomic_store(cnt + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+    }
+    __syncthreads();
+    if (!last_sh || tid >= 64) return;
+    float b2 = __hip_atomic_load(pv + row * ARGMAX_PARTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int i2 = __hip_atomic_load(pi + row * ARGMAX_PARTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        const float ov = __shfl_xor(b2, o, 64);
+        const int oi = __shfl_xor(i2, o, 64);
+        if (ov > b2 || (ov == b2 && oi < i2)) { b2 = ov; i2 = oi; }
     }
-    if (lane == 0) out[row] = idx;
+    if (tid == 0) out[row] = i2;
 }
-// scratch: rows * 64 floats + rows * 64 ints
+// scratch: rows * 64 floats + rows * 64 ints + rows ticket words (zero between launches)
 hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch, hipStream_t st) {
     float *pv = scratch;
     int *pi = reinterpret_cast<int *>(scratch + (size_t)rows * ARGMAX_PARTS);
-    hipLaunchKernelGGL(argmax_part_kernel, dim3(ARGMAX_PARTS, rows), dim3(256), 0, st, x, n, pv, pi);
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, pv, pi, out);
+    unsigned *cnt = reinterpret_cast<unsigned *>(scratch + (size_t)rows * ARGMAX_PARTS * 2);
+    hipLaunchKernelGGL(argmax_part_kernel, dim3(ARGMAX_PARTS, rows), dim3(256), 0, st, x, n, pv, pi, cnt, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- top-k of a logits row (device-side sampling front end, kernels.h)
+// Level 0: a workgroup takes 512 logits, applies the adjustments that fall into its range, sorts the 512 keys in LDS (bitonic, descending) and keeps
+// its KK = next power of two >= k best.  Levels 1..: a workgroup merges 1024 / KK such lists the same way, until one list is left; the last level
+// writes straight into the caller's (pinned) buffer.  Keys are unique (the token id is part of them), so the order is total and the result exact.
+typedef unsigned long long topk_key;
+__device__ __forceinline__ topk_key topk_make_key(float v, int tok) {
+    unsigned u = __float_as_uint(v);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;                  // order-preserving image of the float
+    return ((topk_key)u << 32) | (topk_key)(0xffffffffu - (unsigned)tok);
+}
+template <int N, int NT>
+__device__ __forceinline__ void topk_sort_desc(topk_key *s, int tid) {
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < N; i += NT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const topk_key a = s[i], b = s[ixj];
+                    const bool desc = (i & k) == 0;             // this run ends up descending
+                    if (desc ? a < b : a > b) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+__global__ __launch_bounds__(256) void topk_part_kernel(const float *x, int n, int kk, const TopkAdj adj, topk_key *part) {
+    __shared__ topk_key s[512];
+    const int tid = threadIdx.x, base = blockIdx.x * 512;
+    for (int e = tid; e < 512; e += 256) {
+        const int i = base + e;
+        topk_key key = 0;                                        // below every real key
+        if (i < n) {
+            float l = x[i];
+            for (int a = 0; a < adj.n; a++) {
+                if (adj.tok[a] != i) continue;
+                l = l + adj.bias[a];
+                if (adj.cnt[a] > 0) {
+                    if (l <= 0.0f) l *= adj.repeat; else l /= adj.repeat;
+                    l -= (float)adj.cnt[a] * adj.freq + adj.present;
+                }
+            }
+            key = topk_make_key(l, i);
+        }
+        s[e] = key;
+    }
+    __syncthreads();
+    topk_sort_desc<512, 256>(s, tid);
+    for (int e = tid; e < kk; e += 256) part[(size_t)blockIdx.x * kk + e] = s[e];
+}
+__global__ __launch_bounds__(256) void topk_merge_kernel(const topk_key *in, int n_lists, int kk, topk_key *out, int out_count) {
+    __shared__ topk_key s[1024];
+    const int tid = threadIdx.x, per = 1024 / kk, l0 = blockIdx.x * per;
+    for (int e = tid; e < 1024; e += 256) {
+        const int l = l0 + e / kk;
+        s[e] = l < n_lists ? in[(size_t)l * kk + (e % kk)] : 0;
+    }
+    __syncthreads();
+    topk_sort_desc<1024, 256>(s, tid);
+    for (int e = tid; e < out_count; e += 256) out[(size_t)blockIdx.x * out_count + e] = s[e];
+}
+static int topk_kk(int k) { int kk = 16; while (kk < k) kk <<= 1; return kk; }
+size_t topk_scratch_bytes(int n) { return (size_t)((n + 511) / 512) * TOPK_MAX_K * sizeof(topk_key) * 2; }
+hipError_t launch_topk_row(const float *x, int n, int k, const TopkAdj &adj, void *scratch, unsigned long long *keys_out, hipStream_t st) {
+    if (k < 1 || k > TOPK_MAX_K || n < 1 || adj.n < 0 || adj.n > TOPK_MAX_ADJ) return hipErrorInvalidValue;
+    const int kk = topk_kk(k);
+    int lists = (n + 511) / 512;
+    topk_key *a = reinterpret_cast<topk_key *>(scratch), *b = a + (size_t)lists * TOPK_MAX_K;
+    hipLaunchKernelGGL(topk_part_kernel, dim3(lists), dim3(256), 0, st, x, n, kk, adj, a);
+    for (;;) {
+        const int per = 1024 / kk, blocks = (lists + per - 1) / per;
+        const bool last = blocks == 1;
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(blocks), dim3(256), 0, st, a, lists, kk, last ? keys_out : b, last ? k : kk);
+        if (last) break;
+        lists = blocks;
+        topk_key *t = a; a = b; b = t;
+    }
     return hipGetLastError();
 }
 

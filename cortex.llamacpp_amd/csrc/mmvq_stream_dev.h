@@ -322,32 +322,52 @@ __device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, 
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < ST_NC; w++) tot += red[w];
-        const float mean = (float)(tot / (double)a.K);
+        // tot / K: a power-of-two K divides exactly by a multiplication - the same bits as the division, without the f64 divide on this serial path
+        const double dk = (double)a.K;
+        const float mean = (a.K & (a.K - 1)) == 0 ? (float)(tot * (1.0 / dk)) : (float)(tot / dk);
         scale = 1.0f / sqrtf(mean + a.neps);
     }
+    if (Q80) {
 #pragma unroll
-    for (int i = 0; i < NJW; i++) {
-        const int b = c + ST_NC * i;
-        if (b >= nbt) continue;                                // wave-uniform
-        const int e0 = b * 256 + lane * 4;
-        f32x4_t x = rxv[i];
-        if (FUSE == 1) {
-            const f32x4_t ww = rwv[i];
-            x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
-        }
-        const float vv[4] = {x.x, x.y, x.z, x.w};
-        if (Q80) {
+        for (int i = 0; i < NJW; i++) {
+            const int b = c + ST_NC * i;
+            if (b >= nbt) continue;                            // wave-uniform
+            const int e0 = b * 256 + lane * 4;
+            f32x4_t x = rxv[i];
+            if (FUSE == 1) {
+                const f32x4_t ww = rwv[i];
+                x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
+            }
+            const float vv[4] = {x.x, x.y, x.z, x.w};
             uint32_t packed; float dd;
             wave_quant_q80(vv, packed, dd);
             *reinterpret_cast<uint32_t *>(qs + e0) = packed;
             if ((lane & 7) == 0) reinterpret_cast<float *>(bs)[b * 8 + (lane >> 3)] = h2f(f2h(dd));
-            continue;
         }
-        uint32_t packed; int bsum; float dq;
-        wave_quant_q8k(vv, lane, packed, bsum, dq);
-        *reinterpret_cast<uint32_t *>(qs + e0) = packed;
-        if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum;
-        if (lane == 0) d[b] = dq;
+    } else {
+        // the wave's blocks side by side in ONE straight line (a clamped block where the last one does not exist; only its stores are skipped): a
+        // block's quantisation is a chain of wave-level steps (max -> first lane holding it -> its value -> 1 / scale -> codes -> sums) that waits on
+        // itself, so two or more of them interleave (decode_engine.hip's probe: 0.84 us for two blocks, most of it latency)
+        uint32_t packed[NJW]; int bsum[NJW]; float dq[NJW];
+#pragma unroll
+        for (int i = 0; i < NJW; i++) {
+            f32x4_t x = rxv[i];
+            if (FUSE == 1) {
+                const f32x4_t ww = rwv[i];
+                x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
+            }
+            const float vv[4] = {x.x, x.y, x.z, x.w};
+            wave_quant_q8k(vv, lane, packed[i], bsum[i], dq[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NJW; i++) {
+            const int b = c + ST_NC * i;
+            if (b < nbt) {
+                *reinterpret_cast<uint32_t *>(qs + b * 256 + lane * 4) = packed[i];
+                if ((lane & 3) == 0) bs[b * 16 + (lane >> 2)] = (int16_t)bsum[i];
+                if (lane == 0) d[b] = dq[i];
+            }
+        }
     }
     consumers_rendezvous(sy + SY_PRO2, lane, io.round);
 }

@@ -52,4 +52,61 @@ __device__ __forceinline__ void wave_quant_q80(const float (&vv)[4], uint32_t &p
     packed = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) | ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
 }
 
+// ---------------------------------------------------------------- dequantise one element of a device row
+__device__ __forceinline__ void k4_scale_min(int j, const uint8_t *p, int &sc, int &mn) {
+    if (j < 4) { sc = p[j] & 63; mn = p[j + 4] & 63; }
+    else { sc = (p[j + 4] & 0x0f) | ((p[j - 4] >> 6) << 4); mn = (p[j + 4] >> 4) | ((p[j] >> 6) << 4); }
+}
+
+__device__ __forceinline__ float dequant_elem(int type, const uint8_t *row, int K, int e) {
+    switch (type) {
+        case T_F32: return reinterpret_cast<const float *>(row)[e];
+        case T_F16: return h2f(reinterpret_cast<const uint16_t *>(row)[e]);
+        case T_Q8_0: {
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + K + (e >> 5) * 2));
+            return __fmul_rn((float)(int8_t)row[e], d);
+        }
+        case T_Q4_K: case T_Q5_K: {
+            const int bsz = type == T_Q4_K ? 144 : 176;
+            const uint8_t *b = row + (size_t)(e >> 8) * bsz;
+            const int r = e & 255, j = r >> 5, l = r & 31, c = j >> 1;
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(b)), dm = h2f(*reinterpret_cast<const uint16_t *>(b + 2));
+            int sc, mn;
+            k4_scale_min(j, b + 4, sc, mn);
+            const uint8_t *qs = b + (type == T_Q4_K ? 16 : 48);
+            int q = (j & 1) ? (qs[32 * c + l] >> 4) : (qs[32 * c + l] & 0x0f);
+            if (type == T_Q5_K && ((b[16 + l] >> j) & 1)) q += 16;
+            return __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(dm, (float)mn));
+        }
+        case T_Q2_K: {   // element (n, j, l) of block sb: bits 2 j .. 2 j + 1 of qs[32 n + l]; sub-block is = 8 n + 2 j + l / 16
+            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, j = (r >> 5) & 3, l = r & 31, is = 8 * n + 2 * j + (l >> 4);
+            const uint8_t q = row[(size_t)sb * 64 + 32 * n + l], sc = row[(size_t)nb * 64 + (size_t)sb * 16 + is];
+            const uint16_t *dm = reinterpret_cast<const uint16_t *>(row + (size_t)nb * 80 + (size_t)sb * 4);
+            const float dl = __fmul_rn(h2f(dm[0]), (float)(sc & 0xf)), ml = __fmul_rn(h2f(dm[1]), (float)(sc >> 4));
+            return __fsub_rn(__fmul_rn(dl, (float)((q >> (2 * j)) & 3)), ml);
+        }
+        case T_Q3_K: {
+            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, j = (r >> 5) & 3, l = r & 31, is = 8 * n + 2 * j + (l >> 4);
+            const uint8_t q = row[(size_t)nb * 32 + (size_t)sb * 64 + 32 * n + l], hm = row[(size_t)sb * 32 + l];
+            const uint8_t *s12 = row + (size_t)nb * 96 + (size_t)sb * 12;
+            const int low = is < 8 ? (s12[is] & 0xf) : (s12[is - 8] >> 4), high = (s12[8 + (is & 3)] >> (2 * (is >> 2))) & 3;
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + (size_t)nb * 108 + (size_t)sb * 2));
+            const int code = (int)((q >> (2 * j)) & 3) - (((hm >> (4 * n + j)) & 1) ? 0 : 4);
+            return __fmul_rn(__fmul_rn(d, (float)((low | (high << 4)) - 32)), (float)code);
+        }
+        case T_Q6_K: {
+            const int nb = K >> 8, sb = e >> 8, r = e & 255, n = r >> 7, rr = r & 127, k = rr >> 5, l = rr & 31;
+            const uint8_t *ql = row + (size_t)sb * 128 + n * 64, *qh = row + (size_t)nb * 128 + (size_t)sb * 64 + n * 32;
+            const int8_t *sc = reinterpret_cast<const int8_t *>(row + (size_t)nb * 192 + (size_t)sb * 16 + n * 8);
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + (size_t)nb * 208 + (size_t)sb * 2));
+            const int lo = (k & 1) ? ql[l + 32] : ql[l];
+            const int nib = (k & 2) ? (lo >> 4) : (lo & 0x0f);
+            const int q = (nib | (((qh[l] >> (2 * k)) & 3) << 4)) - 32;
+            return __fmul_rn(__fmul_rn(d, (float)sc[2 * k + (l >> 4)]), (float)q);
+        }
+    }
+    return 0.0f;
+}
+
+
 }  // namespace mi355

@@ -36,6 +36,15 @@ class IBackend {
     // index of the largest logit of batch row i, computed on the device (first maximum wins), or -1 when the backend has
     // no such front end: lets a purely greedy request skip the host pass over the vocabulary
     virtual int argmax_ith(int i) { (void)i; return -1; }
+    // device-side head of the sampler chain (Sampler::plan_front / finish): the k best (token, adjusted logit) candidates of batch row i, best first;
+    // returns k, or -1 when the backend has no such front end (the caller then samples from the whole row)
+    virtual int topk_ith(int i, int k, const std::vector<int32_t> &adj_tok, const std::vector<float> &adj_bias, const std::vector<int32_t> &adj_cnt,
+                         float repeat, float freq, float present, int32_t *toks, float *logits) {
+        (void)i; (void)k; (void)adj_tok; (void)adj_bias; (void)adj_cnt; (void)repeat; (void)freq; (void)present; (void)toks; (void)logits;
+        return -1;
+    }
+    virtual int topk_max_k() const { return 0; }      // 0: no device front end
+    virtual int topk_max_adj() const { return 0; }
     // llama_set_embeddings / llama_get_embeddings_ith (llama_server_context.cc:299, 1042-1044)
     virtual void set_embeddings(bool on) = 0;
     virtual const float *embeddings_ith(int i) = 0;

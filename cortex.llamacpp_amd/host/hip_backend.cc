@@ -16,7 +16,8 @@ namespace {
 
 class HipBackend : public IBackend {
   public:
-    HipBackend(std::unique_ptr<Model> m, std::unique_ptr<Context> c, Vocab v) : model_(std::move(m)), ctx_(std::move(c)), vocab_(std::move(v)) {}
+    HipBackend(std::unique_ptr<Model> m, std::unique_ptr<Context> c, Vocab v, bool device_sampling)
+        : model_(std::move(m)), ctx_(std::move(c)), vocab_(std::move(v)), device_sampling_(device_sampling) {}
     ~HipBackend() override { ctx_.reset(); model_.reset(); }
 
     int n_ctx() const override { return (int)ctx_->cp.n_ctx; }
@@ -36,6 +37,16 @@ class HipBackend : public IBackend {
     const char *last_error() const override { return ctx_->last_error.c_str(); }
     const float *logits_ith(int i) override { return ctx_->logits_ith(i); }
     int argmax_ith(int i) override { return ctx_->argmax_ith(i); }
+    int topk_ith(int i, int k, const std::vector<int32_t> &adj_tok, const std::vector<float> &adj_bias, const std::vector<int32_t> &adj_cnt, float repeat, float freq,
+                 float present, int32_t *toks, float *logits) override {
+        if (adj_tok.size() > (size_t)TOPK_MAX_ADJ) return -1;
+        TopkAdj a{};
+        a.n = (int)adj_tok.size(); a.repeat = repeat; a.freq = freq; a.present = present;
+        for (int j = 0; j < a.n; j++) { a.tok[j] = adj_tok[(size_t)j]; a.bias[j] = adj_bias[(size_t)j]; a.cnt[j] = adj_cnt[(size_t)j]; }
+        return ctx_->topk_ith(i, k, a, toks, logits);
+    }
+    int topk_max_k() const override { return device_sampling_ ? TOPK_MAX_K : 0; }
+    int topk_max_adj() const override { return TOPK_MAX_ADJ; }
     void set_embeddings(bool on) override { ctx_->embeddings_enabled = on; }
     const float *embeddings_ith(int i) override { return ctx_->embeddings_ith(i); }
     void kv_clear() override { ctx_->kv_clear(); }
@@ -47,6 +58,7 @@ class HipBackend : public IBackend {
     std::unique_ptr<Model> model_;
     std::unique_ptr<Context> ctx_;
     Vocab vocab_;
+    bool device_sampling_ = true;
     std::vector<int32_t> n_seq_id_, seq_store_;
     std::vector<int32_t *> seq_ptr_;
 };
@@ -89,14 +101,16 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     cp.flash_attn = body.value<bool>("flash_attn", true) || cp.type_k != T_F16;
     cp.embeddings = false;
     cp.use_graphs = body.value<bool>("use_graphs", true);
-    cp.logits_to_host = true;   // the sampler reads whole logits rows on the host, as common_sampler_sample does
+    // a flagged row is not copied to the host with every step: plain greedy takes the device arg-max, the usual chains take the device top-k
+    // (Sampler::plan_front), and a chain that needs the whole row (mirostat, top_k off, long penalty windows) fetches it on demand
+    cp.logits_to_host = body.value<bool>("logits_to_host", false);
     std::unique_ptr<Context> ctx(new Context(model.get(), cp));
     if (!ctx->init(err)) return nullptr;
 
     info.vram = model->device_bytes + ctx->device_bytes;
     info.ram = model->host_bytes;
     info.model_size = model->file_tensor_bytes;
-    return std::unique_ptr<IBackend>(new HipBackend(std::move(model), std::move(ctx), std::move(vocab)));
+    return std::unique_ptr<IBackend>(new HipBackend(std::move(model), std::move(ctx), std::move(vocab), body.value<bool>("device_sampling", true)));
 }
 
 }  // namespace mi355

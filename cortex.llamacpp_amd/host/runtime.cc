@@ -400,6 +400,7 @@ Context::~Context() {
     if (h_embd_) (void)hipHostFree(h_embd_);
     if (h_chunks_) (void)hipHostFree(h_chunks_);
     if (h_mega_flag_) (void)hipHostFree(h_mega_flag_);
+    if (h_topk_) (void)hipHostFree(h_topk_);
     if (h_moe_meta_) (void)hipHostFree(h_moe_meta_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -551,7 +552,7 @@ bool Context::init(std::string &err) {
     if (!att_part_ || !att_counters_) { err = "attention workspace allocation failed"; return false; }
     if (hipMemset(att_counters_, 0, 256 * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
-    argmax_scratch_ = (float *)dalloc(T * 128 * 4);
+    argmax_scratch_ = (float *)dalloc(T * 129 * 4);     // per row: 64 part values, 64 part indices, one ticket word (zero-filled: dalloc)
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
     chunk_stride_ = (int)((NC + 63) / 64);
     d_chunks_ = (int32_t *)dalloc((size_t)64 * (chunk_stride_ + 1) * 4);
@@ -1063,9 +1064,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
     // ... or one persistent launch per layer for the mat-vecs between two attention calls (decode_engine.hip)
     const bool engine = T == 1 && !mega && !profile_ && !debug_taps_ && engine_prepare();
     last_layers_engine_ = engine;
-    HIP_TRY(launch_step_setup(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr, stream_,
-                              engine ? d_engine_epoch_ : nullptr));
-    HIP_TRY(launch_get_rows(model->tok_embd.type, model->tok_embd.data, E, d_tok_, T, x_, stream_));
+    // cos / sin table, cell metadata and the tokens' embedding rows: one launch
+    HIP_TRY(launch_step_setup_embed(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr,
+                                    engine ? d_engine_epoch_ : nullptr, model->tok_embd.type, model->tok_embd.data, E, d_tok_, x_, stream_));
     prof_mark("embed");
     last_layers_mega_ = mega;
     if (mega)
@@ -1685,6 +1686,34 @@ int32_t Context::argmax_ith(int i) {
         argmax_fetched_ = true;
     }
     return h_argmax_[out_row_of_batch_[(size_t)i]];
+}
+
+int Context::topk_ith(int i, int k, const TopkAdj &adj, int32_t *toks, float *logits) {
+    if (last_was_embd_) return -1;
+    if (i < 0) i += (int)out_row_of_batch_.size();
+    if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return -1;
+    const int V = model->hp.n_vocab;
+    if (k < 1 || k > TOPK_MAX_K || k > V) return -1;
+    if (hipSetDevice(model->device) != hipSuccess) return -1;
+    if (!topk_scratch_) {
+        (void)hipStreamSynchronize(stream_);
+        topk_scratch_ = dalloc(topk_scratch_bytes(V));
+        if (!topk_scratch_ || hipHostMalloc((void **)&h_topk_, TOPK_MAX_K * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { last_error = "top-k workspace allocation failed"; return -1; }
+        (void)hipDeviceSynchronize();                      // null-stream zero-fill of the new buffer (see init)
+    }
+    const float *row = d_logits_ + (size_t)out_row_of_batch_[(size_t)i] * V;
+    if (launch_topk_row(row, V, k, adj, topk_scratch_, h_topk_, stream_) != hipSuccess) { last_error = "top-k launch failed"; return -1; }
+    if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check() || !stream_check()) return -1;
+    for (int j = 0; j < k; j++) {
+        const unsigned long long key = h_topk_[j];
+        unsigned u = (unsigned)(key >> 32);
+        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;        // inverse of the order-preserving image
+        float f;
+        memcpy(&f, &u, 4);
+        toks[j] = (int32_t)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+        logits[j] = f;
+    }
+    return k;
 }
 
 int Context::debug_layer_out(int il, float *dst, size_t cap) {

@@ -114,6 +114,9 @@ class Context {
     // produced for the flagged tokens of the last decode while embeddings_enabled is set (then no logits are computed)
     float *embeddings_ith(int i);
     int32_t argmax_ith(int i);
+    // device-side sampling front end: the k best (token, logit) candidates of batch row i after the adjustments (kernels.h launch_topk_row), best
+    // first; returns the count written (k) or < 0
+    int topk_ith(int i, int k, const TopkAdj &adj, int32_t *toks, float *logits);
     void synchronize();
 
     void kv_clear();
@@ -228,6 +231,8 @@ class Context {
     bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
+    void *topk_scratch_ = nullptr;                     // launch_topk_row workspace (allocated on first use)
+    unsigned long long *h_topk_ = nullptr;             // pinned: the winning keys
     Fuse pending_fuse_;
     int att_splits_ = 1;
     float *dbg_ = nullptr;

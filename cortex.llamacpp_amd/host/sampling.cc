@@ -115,16 +115,10 @@ int32_t Sampler::sample(const float *logits, int n_vocab) {
         if (out.size() < k) std::make_heap(out.begin(), out.end(), better);
         std::sort(out.begin(), out.end(), better);
     };
-    const size_t min_keep = (size_t)std::max(p_.min_keep, 1);
     if (p_.temp <= 0.0f) {   // greedy: first maximum wins
-        const size_t np = (size_t)std::max(p_.n_probs, 0);
         std::vector<TokenProb> c;
-        top_k_pass(std::max<size_t>(np, 1), c);
-        const int best = c[0].tok;
-        cand_.clear();
-        if (np > 0) { softmax_sorted(c); cand_ = c; }
-        else cand_.push_back({best, 1.0f});
-        return best;
+        top_k_pass(front_k(n_vocab), c);
+        return finish(c);
     }
     std::uniform_real_distribution<double> u01(0.0, 1.0);
     auto draw = [&](const std::vector<TokenProb> &cc) -> size_t {
@@ -166,11 +160,64 @@ int32_t Sampler::sample(const float *logits, int n_vocab) {
         return c[idx].tok;
     }
     // top_k (also establishes descending order)
+    std::vector<TokenProb> c;
+    top_k_pass(front_k(n_vocab), c);
+    return finish(c);
+}
+
+// how many candidates the head of the chain (logit_bias -> penalties -> top_k) hands to the rest: the greedy chains keep max(n_probs, 1)
+size_t Sampler::front_k(int n_vocab) const {
+    if (p_.temp <= 0.0f) return std::max<size_t>((size_t)std::max(p_.n_probs, 0), 1);
+    const size_t min_keep = (size_t)std::max(p_.min_keep, 1);
     size_t k = p_.top_k <= 0 ? (size_t)n_vocab : std::min<size_t>((size_t)p_.top_k, (size_t)n_vocab);
     k = std::max(k, min_keep);
-    k = std::min(k, (size_t)n_vocab);
-    std::vector<TokenProb> c;
-    top_k_pass(k, c);
+    return std::min(k, (size_t)n_vocab);
+}
+
+// The head of the chain can run on the device (mi355_get_topk_ith: the same f32 operations on the adjusted tokens, the same order): this says whether
+// this sampler's state allows it and what to send - at most max_k candidates, at most max_adj adjusted tokens, no mirostat (it truncates the whole
+// vocabulary), one bias per token (two biases on one token are added one after the other on the host: not the same float as their sum).
+bool Sampler::plan_front(int n_vocab, int max_k, int max_adj, FrontPlan &pl) const {
+    if (p_.mirostat == 1 || p_.mirostat == 2) return false;
+    const size_t k = front_k(n_vocab);
+    if (k > (size_t)max_k) return false;
+    pl.k = (int)k;
+    pl.tok.clear(); pl.bias.clear(); pl.cnt.clear();
+    auto slot = [&](int32_t t) -> int {
+        for (size_t i = 0; i < pl.tok.size(); i++) if (pl.tok[i] == t) return (int)i;
+        pl.tok.push_back(t); pl.bias.push_back(0.0f); pl.cnt.push_back(0);
+        return (int)pl.tok.size() - 1;
+    };
+    std::vector<int32_t> biased;
+    for (const auto &lb : p_.logit_bias) {
+        if (lb.first < 0 || lb.first >= n_vocab) continue;
+        if (std::find(biased.begin(), biased.end(), lb.first) != biased.end()) return false;
+        biased.push_back(lb.first);
+        pl.bias[(size_t)slot(lb.first)] = lb.second;
+    }
+    if (!prev_.empty() && (p_.penalty_repeat != 1.0f || p_.penalty_freq != 0.0f || p_.penalty_present != 0.0f))
+        for (int32_t t : prev_) if (t >= 0 && t < n_vocab) pl.cnt[(size_t)slot(t)]++;
+    return pl.tok.size() <= (size_t)max_adj;
+}
+
+// the rest of the chain on the candidates the head produced ((token, adjusted logit), best first)
+int32_t Sampler::finish(std::vector<TokenProb> &c) {
+    const size_t min_keep = (size_t)std::max(p_.min_keep, 1);
+    if (c.empty()) { cand_.clear(); return -1; }
+    if (p_.temp <= 0.0f) {
+        const int best = c[0].tok;
+        cand_.clear();
+        if (p_.n_probs > 0) { softmax_sorted(c); cand_ = c; }
+        else cand_.push_back({best, 1.0f});
+        return best;
+    }
+    std::uniform_real_distribution<double> u01(0.0, 1.0);
+    auto draw = [&](const std::vector<TokenProb> &cc) -> size_t {
+        const double r = u01(rng_);
+        double cum = 0.0;
+        for (size_t i = 0; i < cc.size(); i++) { cum += cc[i].p; if (r < cum) return i; }
+        return cc.size() - 1;
+    };
     softmax_sorted(c);
     // typical_p
     if (p_.typ_p < 1.0f && c.size() > 1) {

@@ -41,6 +41,12 @@ class Sampler {
     void reset();
     void accept(int32_t token);
     int32_t sample(const float *logits, int n_vocab);
+    // sample() = head (logit_bias -> penalties -> top_k over the whole row) + finish().  The head can run on the device instead (SURVEY.md §8f.1,
+    // mi355_get_topk_ith): plan_front says whether this sampler's state allows it (false: take sample()) and what to send; finish() then runs the rest
+    // of the chain on the (token, adjusted logit) candidates, best first - the same token and the same candidates() as sample() on the whole row
+    struct FrontPlan { int k = 0; std::vector<int32_t> tok; std::vector<float> bias; std::vector<int32_t> cnt; };
+    bool plan_front(int n_vocab, int max_k, int max_adj, FrontPlan &pl) const;
+    int32_t finish(std::vector<TokenProb> &c);
     // true when sample() would return the plain argmax of the raw logits (greedy, nothing modifies them, no probabilities
     // asked for): the caller may then take the device-side argmax instead of reading the row
     bool is_plain_greedy() const;
@@ -50,6 +56,7 @@ class Sampler {
     const SamplingParams &params() const { return p_; }
 
   private:
+    size_t front_k(int n_vocab) const;
     SamplingParams p_;
     std::vector<int32_t> prev_;     // ring of accepted tokens (penalty window)
     std::vector<TokenProb> cand_;

@@ -679,11 +679,25 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
         }
         std::vector<int32_t> ids(gen.size(), -1);
         std::vector<const float *> rows(gen.size(), nullptr);
+        const int n_vocab_now = be_->n_vocab();
         for (size_t gi = 0; gi < gen.size(); gi++) {
             LlamaClientSlot &slot = *gen[gi];
             if (slot.smpl->is_plain_greedy()) {             // device-side greedy front end: no pass over the vocabulary on the host
                 ids[gi] = be_->argmax_ith(slot.i_batch - i);
                 if (ids[gi] >= 0) { slot.smpl->set_greedy_result(ids[gi]); continue; }
+            }
+            // device-side head of the chain (logit_bias -> penalties -> top_k): k candidates cross instead of the row
+            Sampler::FrontPlan fp;
+            if (be_->topk_max_k() > 0 && slot.smpl->plan_front(n_vocab_now, be_->topk_max_k(), be_->topk_max_adj(), fp)) {
+                std::vector<int32_t> tk((size_t)fp.k);
+                std::vector<float> lg((size_t)fp.k);
+                const SamplingParams &sp = slot.smpl->params();
+                if (be_->topk_ith(slot.i_batch - i, fp.k, fp.tok, fp.bias, fp.cnt, sp.penalty_repeat, sp.penalty_freq, sp.penalty_present, tk.data(), lg.data()) == fp.k) {
+                    std::vector<TokenProb> c((size_t)fp.k);
+                    for (int j = 0; j < fp.k; j++) c[(size_t)j] = TokenProb{tk[(size_t)j], lg[(size_t)j]};
+                    ids[gi] = slot.smpl->finish(c);
+                    if (ids[gi] >= 0) continue;
+                }
             }
             rows[gi] = be_->logits_ith(slot.i_batch - i);
         }

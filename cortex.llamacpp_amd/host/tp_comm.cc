@@ -221,6 +221,7 @@ int tp_p2p_enable(const void *handles, size_t len, std::string &err) {
     return 0;
 }
 bool tp_p2p_active() { return g_p2p.on; }
+void tp_p2p_use(bool on) { g_p2p.on = on && g_p2p.peer[g_grp.rank] != nullptr; }
 void tp_p2p_set_error_word(unsigned *w) { g_p2p.err = w; g_p2p.dev.err = w; }
 int64_t tp_p2p_exchanges() { return g_p2p.exchanges; }
 

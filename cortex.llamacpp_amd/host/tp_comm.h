@@ -44,6 +44,7 @@ constexpr int TP_P2P_HANDLE_BYTES = 64;
 int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, std::string &err);   // returns TP_P2P_HANDLE_BYTES or < 0
 int tp_p2p_enable(const void *handles, size_t len, std::string &err);                  // len = size * TP_P2P_HANDLE_BYTES, rank-major
 bool tp_p2p_active();
+void tp_p2p_use(bool on);                            // measurement: route the small all-reduces back to the base transport (contexts created afterwards)
 void tp_p2p_set_error_word(unsigned *host_word);     // pinned host word ORed with 32 when a bounded wait of the exchange kernel gives up
 int64_t tp_p2p_exchanges();                          // diagnosis: all-reduces that took the peer-to-peer kernel
 

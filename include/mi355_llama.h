@@ -143,6 +143,13 @@ MI355_API int32_t mi355_decode(mi355_context *ctx, mi355_batch batch);
 MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);
 /* device-side greedy front end: argmax token of row i without copying the row */
 MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
+/* device-side sampling front end beyond greedy (stands in for the head of common_sampler_sample's chain, reference call site
+   src/llama_server_context.cc:1679-1698): the k <= 128 best candidates of row i after logit_bias and the repetition / frequency / presence penalties,
+   best first (higher logit; lower token id on ties) - k (token, logit) pairs cross to the host instead of the whole row.  adj_tok / adj_bias / adj_count:
+   n_adj <= 192 adjusted tokens (bias 0 = none, count = occurrences in the penalty window, 0 = not penalised).  Returns k or < 0. */
+MI355_API int32_t mi355_get_topk_ith(mi355_context *ctx, int32_t i, int32_t k, int32_t n_adj, const int32_t *adj_tok, const float *adj_bias,
+                                     const int32_t *adj_count, float penalty_repeat, float penalty_freq, float penalty_present,
+                                     int32_t *toks_out, float *logits_out);
 /* diagnosis: single-token steps this context ran as ONE launch (decode_mega.hip; see mi355_debug_set_option "decode_mega") */
 MI355_API int64_t mi355_debug_mega_steps(const mi355_context *ctx);
 /* diagnosis: single-token steps this context ran through the layer engine (decode_engine.hip: one persistent launch per layer for the mat-vecs between two

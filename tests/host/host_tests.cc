@@ -294,6 +294,68 @@ static std::string expected_text(const FakeBackend &be, const std::vector<int32_
     return s;
 }
 
+// The head of the chain (logit_bias -> penalties -> top_k) computed apart - what mi355_get_topk_ith does on the device, restated here with the same f32
+// operations - followed by Sampler::finish must give the token and the candidates of Sampler::sample on the whole row: same parameters, same seed, same
+// history; ties in the logits included.
+static void test_sampler_front_plan_matches_full_chain() {
+    const int V = 3000;
+    std::mt19937 rng(99);
+    std::normal_distribution<float> nd(0.0f, 3.0f);
+    auto better = [](const TokenProb &a, const TokenProb &b) { return a.p > b.p || (a.p == b.p && a.tok < b.tok); };
+    int planned = 0;
+    for (int trial = 0; trial < 60; trial++) {
+        SamplingParams sp;
+        sp.seed = 1234u + (uint32_t)trial;
+        sp.top_k = trial % 7 == 0 ? 1 : 5 + trial % 60;
+        sp.top_p = trial % 3 ? 0.9f : 1.0f; sp.min_p = trial % 4 ? 0.05f : 0.0f; sp.typ_p = trial % 5 == 0 ? 0.8f : 1.0f;
+        sp.temp = trial % 6 == 0 ? 0.0f : 0.7f + 0.01f * (float)trial;
+        sp.n_probs = trial % 4 == 0 ? 5 : 0;
+        if (trial % 2) { sp.penalty_repeat = 1.15f; sp.penalty_freq = 0.1f; sp.penalty_present = 0.2f; sp.penalty_last_n = 32; }
+        if (trial % 3 == 0) { sp.logit_bias.push_back({7, 2.5f}); sp.logit_bias.push_back({11, -INFINITY}); sp.logit_bias.push_back({V + 5, 1.0f}); }
+        std::vector<float> lg((size_t)V);
+        for (auto &x : lg) x = nd(rng);
+        lg[100] = lg[200] = lg[50] = 9.5f;                       // a three-way tie near the top: the lowest id ranks first
+        Sampler a(sp), b(sp);
+        for (int h = 0; h < 40; h++) { const int32_t t = (int32_t)(rng() % 300); a.accept(t); b.accept(t); }
+        const int32_t id_full = a.sample(lg.data(), V);
+        Sampler::FrontPlan fp;
+        CHECK(b.plan_front(V, 128, 192, fp));
+        planned++;
+        // the device's part: adjustments on the listed tokens, then the k best of the row
+        std::vector<float> adj = lg;
+        for (size_t j = 0; j < fp.tok.size(); j++) {
+            float l = adj[(size_t)fp.tok[j]] + fp.bias[j];
+            if (fp.cnt[j] > 0) {
+                if (l <= 0.0f) l *= sp.penalty_repeat; else l /= sp.penalty_repeat;
+                l -= (float)fp.cnt[j] * sp.penalty_freq + sp.penalty_present;
+            }
+            adj[(size_t)fp.tok[j]] = l;
+        }
+        std::vector<TokenProb> all((size_t)V);
+        for (int v = 0; v < V; v++) all[(size_t)v] = TokenProb{v, adj[(size_t)v]};
+        std::partial_sort(all.begin(), all.begin() + fp.k, all.end(), better);
+        std::vector<TokenProb> c(all.begin(), all.begin() + fp.k);
+        const int32_t id_front = b.finish(c);
+        CHECK(id_front == id_full);
+        CHECK(a.candidates().size() == b.candidates().size());
+        for (size_t j = 0; j < a.candidates().size() && j < b.candidates().size(); j++)
+            CHECK(a.candidates()[j].tok == b.candidates()[j].tok && a.candidates()[j].p == b.candidates()[j].p);
+    }
+    CHECK(planned == 60);
+    // what keeps the whole row on the host: mirostat, top_k off, two biases on one token, a penalty window with more distinct tokens than the device takes
+    SamplingParams m; m.mirostat = 2;
+    Sampler::FrontPlan fp;
+    CHECK(!Sampler(m).plan_front(V, 128, 192, fp));
+    SamplingParams nk; nk.top_k = 0;
+    CHECK(!Sampler(nk).plan_front(V, 128, 192, fp));
+    SamplingParams two; two.logit_bias.push_back({3, 1.0f}); two.logit_bias.push_back({3, 2.0f});
+    CHECK(!Sampler(two).plan_front(V, 128, 192, fp));
+    SamplingParams win; win.penalty_repeat = 1.1f; win.penalty_last_n = 400;
+    Sampler w(win);
+    for (int h = 0; h < 400; h++) w.accept(h);
+    CHECK(!w.plan_front(V, 128, 192, fp));
+}
+
 static void test_slot_loop() {
     FakeBackend be;
     ServerParams sp;
@@ -722,6 +784,7 @@ int main(int argc, char **argv) {
     test_sampler();
     test_sampler_topk_matches_full_sort();
     test_sampler_mirostat_dynatemp();
+    test_sampler_front_plan_matches_full_chain();
     test_slot_loop();
     test_prompt_cache_and_shift();
     test_kv_full_error();

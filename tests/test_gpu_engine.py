@@ -176,3 +176,32 @@ def test_context_shift_and_prompt_cache_on_device(pkg, tiny_vocab_model):
     a, b = _norm(r1[1]["choices"][0]["message"]["content"]), _norm(r2[1]["choices"][0]["message"]["content"])
     assert len(b) > 0 and a[:max(1, len(b) // 2)] == b[:max(1, len(b) // 2)]
     e.close()
+
+
+def test_device_sampling_front_end_gives_the_host_chain_text(pkg, tiny_vocab_model):
+    """The device-side head of the sampler chain (logit_bias -> penalties -> top_k on the device, k candidates to the host: mi355_get_topk_ith) against the
+    whole chain over the whole row on the host (load option device_sampling=false): same seeded text, request by request, for chains the front end
+    takes (top_k within its limit, penalties, logit_bias) and for chains it leaves to the host (top_k off, mirostat)."""
+    reqs = [
+        dict(max_tokens=24, temperature=0.9, top_k=20, top_p=0.9, seed=7),
+        dict(max_tokens=24, temperature=1.3, top_k=40, top_p=0.95, min_p=0.02, seed=8, repeat_penalty=1.2, frequency_penalty=0.1, presence_penalty=0.2),
+        dict(max_tokens=24, temperature=0.7, top_k=100, seed=9, logit_bias=[[5, 4.0], [9, -100.0], [17, False]], repeat_penalty=1.1),
+        dict(max_tokens=16, temperature=0.0, repeat_penalty=1.3, top_k=40),          # greedy with penalties: not the plain arg-max path
+        dict(max_tokens=16, temperature=0.8, top_k=0, seed=10),                      # top_k off: the whole row
+        dict(max_tokens=16, temperature=0.8, mirostat=2, seed=11),
+        dict(max_tokens=16, temperature=0.8, top_k=30, seed=12, n_probs=3),
+    ]
+    texts = {}
+    for dev in (True, False):
+        e = pkg.Engine()
+        st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=512, n_parallel=1, ngl=100, user_prompt="u:", ai_prompt="a:",
+                                system_prompt="s:", device_sampling=dev)
+        assert st["status_code"] == 200, (st, body)
+        out = []
+        for r in reqs:
+            res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "tell me a story"}], **r)[-1][1]
+            out.append(res["choices"][0]["message"]["content"])
+        texts[dev] = out
+        e.close()
+    assert texts[True] == texts[False]
+    assert len(set(texts[True])) > 1

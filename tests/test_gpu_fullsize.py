@@ -78,6 +78,7 @@ def test_fullsize_determinism_graph_equals_eager_and_causality(pkg, big):
     prompt = rng.integers(0, m.n_vocab, 512)
 
     def run(use_graphs):
+        rng2 = np.random.default_rng(11)
         c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=8, type_v=8, use_graphs=use_graphs)
         c.decode(prompt, np.arange(512))
         rows = [c.logits()]
@@ -87,6 +88,16 @@ def test_fullsize_determinism_graph_equals_eager_and_causality(pkg, big):
             c.decode([tok], [512 + s])
             rows.append(c.logits())
             assert int(rows[-1].argmax()) == c.argmax()
+            if use_graphs and s % 8 == 0:
+                # device top-k over the full 128256-entry row (251 partitions, merge tree): ids and float bits of the host's ordering
+                for k, n_adj in ((1, 0), (40, 64), (128, 192)):
+                    at = rng2.choice(m.n_vocab, n_adj, replace=False).astype(np.int32)
+                    ab = (rng2.standard_normal(n_adj) * 4).astype(np.float32)
+                    want = rows[-1].copy()
+                    want[at] = want[at] + ab
+                    order = np.lexsort((np.arange(m.n_vocab), -want.astype(np.float64)))[:k]
+                    gt, gl = c.topk(k, adj_tok=at, adj_bias=ab, adj_count=np.zeros(n_adj, np.int32))
+                    assert gt.tolist() == order.tolist() and gl.view(np.uint32).tolist() == want[order].view(np.uint32).tolist(), (s, k)
             tok = c.argmax()
             toks.append(tok)
         c.close()

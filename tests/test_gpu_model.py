@@ -632,3 +632,42 @@ def test_moe_prompt_batches_grouped_by_expert(be, pkg, tmp_models, ftype, kv, n_
     tok = np.abs(g0 - l0).max(axis=1) / max(1.0, float(np.abs(l0).max()))
     assert float(np.median(tok)) <= TIGHT_TOL and rel_err(outs["grouped"][0], outs["loop"][0]) <= FLIP_TOL, tok
     oc.close(); om.close()
+
+
+@pytest.mark.parametrize("cfg", ["tiny-gqa4", "tiny-e2048"])
+def test_device_topk_front_end_matches_host_order(be, pkg, tmp_models, cfg):
+    """Device-side head of the sampler chain (mi355_get_topk_ith): the k best (token, logit) pairs of a row after logit_bias and the
+    repetition / frequency / presence penalties, in the host sampler's order (higher logit first, lower id on ties) - ids and float bits exactly those
+    of the same f32 operations done on the host copy of the row; k = 1 .. 128, with and without adjustments, a -inf bias, single-token steps and a
+    flagged prompt row."""
+    path = make(pkg, tmp_models, cfg, "q4_k_m")
+    m = pkg.Model(path)
+    c = pkg.Context(m, n_ctx=128, type_k=KV["q8_0"], type_v=KV["q8_0"])
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(0, m.n_vocab, 20)
+    assert c.decode(prompt, np.arange(20)) == 0
+    pos = 20
+    for trial in range(6):
+        row = c.logits().copy()
+        for k in (1, 7, 40, 128):
+            n_adj = [0, 5, 64, 190][trial % 4]
+            tok = rng.choice(m.n_vocab, n_adj, replace=False).astype(np.int32)
+            bias = np.where(rng.random(n_adj) < 0.5, rng.standard_normal(n_adj) * 3, 0).astype(np.float32)
+            if n_adj:
+                bias[0] = -np.inf
+            cnt = np.where(rng.random(n_adj) < 0.6, rng.integers(1, 5, n_adj), 0).astype(np.int32)
+            rp, fr, pr = np.float32(1.1), np.float32(0.05), np.float32(0.3)
+            want = row.copy()
+            for t, b, n in zip(tok, bias, cnt):
+                l = np.float32(want[t] + b)
+                if n > 0:
+                    l = np.float32(l * rp) if l <= 0 else np.float32(l / rp)
+                    l = np.float32(l - np.float32(np.float32(np.float32(n) * fr) + pr))
+                want[t] = l
+            order = np.lexsort((np.arange(m.n_vocab), -want.astype(np.float64)))[:k]      # logit descending, id ascending on ties
+            got_t, got_l = c.topk(k, adj_tok=tok, adj_bias=bias, adj_count=cnt, repeat=float(rp), freq=float(fr), present=float(pr))
+            assert got_t.tolist() == order.tolist(), (trial, k)
+            assert got_l.view(np.uint32).tolist() == want[order].view(np.uint32).tolist(), (trial, k)
+        assert c.decode([int(row.argmax())], [pos]) == 0
+        pos += 1
+    c.close(); m.close()
