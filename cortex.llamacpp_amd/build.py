@@ -21,6 +21,7 @@ HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "csrc/mmvq_fa
         "host/sampling.h", "host/log.h", "host/backend_iface.h", "host/server_context.h", "host/engine.h", "host/hip_backend.h",
         "../include/mi355_llama.h"]
 LIB = os.path.join(HERE, "lib", "libmi355_llama.so")
+SERVER = os.path.join(HERE, "bin", "mi355_server")          # the HTTP host: plain C++, dlopen()s LIB at run time (server/mi355_server.cc)
 # -ffp-contract=off: the CPU restatement this backend is checked against does not fuse mul+add
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
@@ -66,7 +67,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+    build_server(force)
     return LIB
+
+
+def build_server(force: bool = False) -> str:
+    src = os.path.join(HERE, "server", "mi355_server.cc")
+    deps = [src, os.path.join(HERE, "host", "json.h")]
+    if force or not os.path.exists(SERVER) or os.path.getmtime(SERVER) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(SERVER), exist_ok=True)
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-pthread", src, "-o", SERVER, "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"server build failed:\n{r.stderr}")
+    return SERVER
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 //   llama_model_path | model_path, ngl (300), ctx_len (2048), n_batch (2048), n_ubatch (= n_batch), n_parallel (1),
 //   cache_type f16|q8_0|q4_0 (invalid -> f16), flash_attn (true; forced on by a quantised cache), embedding.
 #include "hip_backend.h"
+#include "log.h"
 
 #include <sys/stat.h>
 
@@ -77,12 +78,18 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     if (path.empty()) { err = "Missing model path in request"; return nullptr; }
     struct stat st;
     if (stat(path.c_str(), &st) != 0) { err = "Could not find model in path " + path; return nullptr; }
-    if (body.value<int>("ngl", 300) <= 0) { err = "ngl=0 requested: this engine is device-only (no CPU path)"; return nullptr; }
+    // ngl (src/llama_engine.cc:609-611) is the reference's count of layers placed on the GPU; here every layer lives in HBM whatever it says
+    // (there is no host compute path to leave layers on): 0 - the reference's CPU configuration - and partial counts are accepted and run
+    // fully on the device; results do not depend on placement.  The load logs what was asked for.
+    const int ngl_asked = body.value<int>("ngl", 300);
 
     int status = 0;
     std::unique_ptr<Model> model(model_load(path, body.value<int>("main_gpu", 0), err, status, body.value<int>("prefill_planes", -1),
                                             body.value<int>("tp_rank", 0), body.value<int>("tp_size", 1)));   // row split: the process's group is formed first (mi355_tp_init)
     if (!model) return nullptr;
+    if (ngl_asked <= (int)model->hp.n_layer)
+        log_line(LOG_WARN, "ngl=%d asked for (%s): all %d layers and the output head are resident on the MI355X - this engine has no host compute path",
+                 ngl_asked, ngl_asked <= 0 ? "CPU only" : "partial offload", (int)model->hp.n_layer);
 
     Vocab vocab;
     std::string verr;

@@ -6,7 +6,7 @@
 
 namespace mi355 {
 
-// BackendFactory for LlamaEngine; device-only (no CPU fallback): a load with ngl <= 0 is refused.
+// BackendFactory for LlamaEngine; device-only (no CPU fallback): ngl is accepted as a placement hint and every layer is placed in HBM.
 std::unique_ptr<IBackend> make_hip_backend(const Json &load_body, BackendInfo &info, std::string &err);
 
 }  // namespace mi355

@@ -133,9 +133,12 @@ def test_errors_and_unload(pkg, tiny_vocab_model):
     e = pkg.Engine()
     st, body = e.load_model(llama_model_path="/nonexistent/model.gguf")
     assert st["status_code"] == 500 and st["has_error"]
-    st, body = e.load_model(llama_model_path=tiny_vocab_model, ngl=0)
-    assert st["has_error"] and st["status_code"] == 500
-    st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=256, cache_type="q8_0")
+    # ngl = 0 (BASELINE config 1: the reference's CPU configuration) and partial counts load: every layer is placed on the device regardless
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ngl=0, ctx_len=256, model="cpu-config")
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    ref = e.chat_completion(model="cpu-config", messages=[{"role": "user", "content": "hi"}], max_tokens=8, **GREEDY)[-1][1]["choices"][0]["message"]["content"]
+    assert e.unload_model(model="cpu-config")[0]["status_code"] == 200
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=256, cache_type="q8_0", ngl=1)
     assert st["status_code"] == 200
     st, body = e.load_model(llama_model_path=tiny_vocab_model)
     assert st["status_code"] == 409

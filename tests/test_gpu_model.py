@@ -106,7 +106,10 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
             assert int(g.argmax()) == c.argmax()
         assert max(step_err) <= FLIP_TOL, step_err
         if kv != "f16" and ftype != "f16":   # f16 weights / f16 K rows add an f16 rounding per element: never flip-free
-            assert min(errs + step_err) <= TIGHT_TOL or float(np.median(tok_err0)) <= TIGHT_TOL, (errs, step_err, tok_err0)
+            # before the first rounding flip HIP == CPU to f32 round-off: (i) the typical token of the first layer (median over the prompt's tokens) and
+            # (ii) at least three quarters of its tokens individually (measured: 0.81 - 1.0; medians 6e-8 - 2e-7) - both, not either
+            assert float(np.median(tok_err0)) <= TIGHT_TOL, (errs, step_err, tok_err0)
+            assert int((tok_err0 <= TIGHT_TOL).sum()) * 4 >= 3 * n_prompt, (errs, step_err, tok_err0)
         assert mism <= (2 if kv == "f16" else 1), mism   # every mismatch was checked above to be a near tie of the CPU logits
         c.close(); m.close(); oc.close(); om.close()
     finally:
@@ -118,7 +121,10 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
                                                           ("tiny-d128-mha", "q4_k_m", "q8_0", 200, 64),
                                                           # Llama-3-8B's layer shapes at 130 tokens: gate | up (>= 8192 rows) on the LDS-form SwiGLU launch,
                                                           # Q | K | V, attn_output and ffn_down on the K-split kernel (kernel choice by shape)
-                                                          ("tiny-8b-2l", "q4_k_m", "q8_0", 130, 512)])
+                                                          ("tiny-8b-2l", "q4_k_m", "q8_0", 130, 512),
+                                                          # and at 512 tokens, the headline prompt: every contraction on the LDS-form kernels (both operands
+                                                          # through LDS, SwiGLU launch, split K for ffn_down), the prompt attention with 16 query tiles
+                                                          ("tiny-8b-2l", "q4_k_m", "q8_0", 512, 512)])
 def test_long_prompt_logits_match_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt, ubatch):
     """Prompts of a few hundred tokens against the CPU restatement: the matrix-core prompt attention with several query tiles,
     its two key halves per workgroup, the query sub-tiles of one- and two-head kv groups (R = 1: four, R = 2: two), key splits across

@@ -16,7 +16,7 @@ namespace mi355 { void mmvq_stream_set_probe(unsigned long long *p); }
 #endif
 #include <algorithm>
 #ifndef MI355_STREAM_NL
-#define MI355_STREAM_NL 2
+#define MI355_STREAM_NL 8
 #endif
 
 #ifndef MI355_ST_RING
@@ -102,7 +102,7 @@ struct Op {
     size_t bytes;
 };
 
-static const int E = 4096, FF = 14336, NL = 8;
+static const int E = 4096, FF = 14336, NL = MI355_STREAM_NL;   // 8 sets = 1 GB: nothing stays in the Infinity Cache; 1 set: everything does
 static int8_t *g_aq; static float *g_ad; static int16_t *g_abs; static float *g_x, *g_nw, *g_ffn, *g_resid;
 
 static MMVQArgs make_args(const Op &op, int set, float *out) {
