@@ -1,5 +1,6 @@
 // engine.cc — see engine.h.  Citations are into /root/reference/src/llama_engine.cc unless noted.
 #include "engine.h"
+#include "grammar.h"
 #include "log.h"
 
 #include <algorithm>
@@ -178,6 +179,15 @@ bool LlamaEngine::LoadModelImpl(const Json &body, std::string &err) {   // :547-
     auto si = std::make_shared<ServerInfo>();
     const std::string path = body["llama_model_path"].is_string() ? body["llama_model_path"].as_string() : body["model_path"].str_or("");
     if (path.empty()) { err = "Missing model path in request"; return false; }
+    if (body["grammar_file"].is_string()) {                                   // :573-585
+        FILE *gf = fopen(body["grammar_file"].as_string().c_str(), "rb");
+        if (!gf) { err = "Grammar file not found"; log_line(LOG_ERROR, "Grammar file not found"); return false; }
+        char buf[4096];
+        for (size_t n; (n = fread(buf, 1, sizeof buf, gf)) > 0;) si->grammar_file_content.append(buf, n);
+        fclose(gf);
+        std::string gerr;
+        if (!si->grammar_file_content.empty() && !Grammar::parse(si->grammar_file_content, gerr)) { err = "grammar_file: " + gerr; return false; }
+    }
     si->backend = factory_(body, si->info, err);
     if (!si->backend) return false;
     ServerParams sp;
@@ -400,6 +410,25 @@ void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734
     data["ignore_eos"] = body.value<bool>("ignore_eos", false);
     data["n_probs"] = n_probs;
     data["min_keep"] = body.value<int>("min_keep", 0);
+    data["grammar"] = body.value<std::string>("grammar", "");               // :793
+    if (const Json &rf = body["response_format"]; rf.is_object() && (rf["type"].str_or("") == "json_object" || rf["type"].str_or("") == "json_schema")) {   // :794-801
+        std::string gbnf, gerr;
+        if (!json_schema_to_gbnf(rf["json_schema"]["schema"], gbnf, gerr)) {
+            cb(make_status(false, true, false, k400BadRequest), message("response_format: " + gerr));
+            return;
+        }
+        data["grammar"] = gbnf;
+    }
+    if (!si->grammar_file_content.empty()) data["grammar"] = si->grammar_file_content;   // :812-814
+    if (const std::string &gtext = data["grammar"].as_string(); !gtext.empty()) {
+        // a grammar that does not parse is answered here, with the parser's message (from inside the slot loop a non-streaming request would only
+        // learn "Internal error during inference", :1094-1096)
+        std::string gerr;
+        if (!Grammar::parse(gtext, gerr)) {
+            cb(make_status(false, true, false, k400BadRequest), message("grammar: " + gerr));
+            return;
+        }
+    }
     if (body["logit_bias"].is_array()) data["logit_bias"] = body["logit_bias"];
     else if (body["logit_bias"].is_object()) {    // {"token": bias} -> [[token, bias]] (chat_completion_request.h:140-160)
         Json arr = Json::array();

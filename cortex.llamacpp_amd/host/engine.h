@@ -77,6 +77,7 @@ class LlamaEngine {
         int64_t start_time = 0;
         BackendInfo info;
         int ngl = 0;
+        std::string grammar_file_content;   // load option grammar_file: its text constrains every completion of this model (:573-585, 812-814)
     };
     bool LoadModelImpl(const Json &body, std::string &err);
     bool CheckModelLoaded(const Callback &cb, const std::string &model_id);

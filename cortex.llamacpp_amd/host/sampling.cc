@@ -15,9 +15,43 @@ void Sampler::reset() {
     if (seed == 0xFFFFFFFFu) seed = std::random_device{}();
     rng_.seed(seed);
     mu_ = 2.0f * p_.mirostat_tau;
+    if (gm_) gm_->reset();
 }
 
-void Sampler::accept(int32_t token) {
+void Sampler::set_grammar(std::shared_ptr<const Grammar> g, const std::vector<std::string> *pieces, const std::vector<uint8_t> *eog) {
+    gm_.reset(g ? new GrammarMatcher(std::move(g)) : nullptr);
+    pieces_ = pieces; eog_ = eog;
+}
+
+bool Sampler::grammar_admits(int32_t token) const {
+    if (!gm_) return true;
+    if (token < 0 || (size_t)token >= pieces_->size()) return false;
+    if ((*eog_)[(size_t)token]) return gm_->can_end();
+    return gm_->admits((*pieces_)[(size_t)token]);
+}
+
+int32_t Sampler::resample_with_grammar(const float *logits, int n_vocab) {
+    std::vector<float> masked(logits, logits + n_vocab);
+    int32_t n_ok = 0, first_eog = -1;
+    for (int t = 0; t < n_vocab; t++) {
+        if (first_eog < 0 && (size_t)t < eog_->size() && (*eog_)[(size_t)t]) first_eog = t;
+        if (grammar_admits(t)) n_ok++; else masked[(size_t)t] = -INFINITY;
+    }
+    if (n_ok == 0) {            // nothing in this vocabulary can continue the sentence: end the generation rather than leave the grammar
+        cand_.assign(1, TokenProb{first_eog, 1.0f});
+        return first_eog;
+    }
+    return sample_chain(masked.data(), n_vocab);
+}
+
+int32_t Sampler::sample(const float *logits, int n_vocab) {
+    const int32_t t = sample_chain(logits, n_vocab);
+    if (!gm_ || grammar_admits(t)) return t;
+    return resample_with_grammar(logits, n_vocab);
+}
+
+void Sampler::accept(int32_t token, bool advance_grammar) {
+    if (gm_ && advance_grammar && token >= 0 && (size_t)token < pieces_->size() && !(*eog_)[(size_t)token]) gm_->accept((*pieces_)[(size_t)token]);
     prev_.push_back(token);
     // -1 = the whole context (upstream: penalty_last_n < 0 -> n_ctx), 0 = no window at all
     const size_t keep = p_.penalty_last_n < 0 ? (size_t)std::max(p_.penalty_n_ctx, 64) : (size_t)p_.penalty_last_n;
@@ -26,6 +60,7 @@ void Sampler::accept(int32_t token) {
 }
 
 bool Sampler::is_plain_greedy() const {
+    if (gm_) return false;
     if (p_.temp > 0.0f || p_.n_probs > 0 || !p_.logit_bias.empty()) return false;   // (temp <= 0 is greedy in the mirostat chains too: temperature comes first there)
     const bool penalties = p_.penalty_repeat != 1.0f || p_.penalty_freq != 0.0f || p_.penalty_present != 0.0f;
     return !penalties || prev_.empty();
@@ -43,7 +78,7 @@ static void softmax_sorted(std::vector<TokenProb> &c) {   // c sorted by logit d
 // tokens, so they are kept as a small sorted override list and every pass over the row merges it on the fly; the top-k
 // selection is one pass with a k-element heap.  (The first version copied the row into (token, logit) pairs and
 // partial-sorted them: 230-530 us per token, a quarter of a decode step.)
-int32_t Sampler::sample(const float *logits, int n_vocab) {
+int32_t Sampler::sample_chain(const float *logits, int n_vocab) {
     // ---- sparse overrides: token -> modified logit, ascending token order
     std::vector<std::pair<int32_t, float>> ov;
     auto ov_find = [&](int32_t t) -> float * {

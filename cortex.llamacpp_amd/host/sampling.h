@@ -3,14 +3,19 @@
 // chain order per SURVEY.md §A.6: logit_bias -> penalties(last_n, repeat, freq, presence) -> top_k -> typical_p -> top_p
 // -> min_p -> temperature (entropy-driven when dynatemp_range > 0; <= 0 => greedy) -> seeded draw.  mirostat 1 / 2 replace
 // everything after the penalties by temperature -> the mirostat truncation -> draw, as common_sampler_init chains them
-// (upstream common/sampling.cpp, llama-sampling.cpp: llama_sampler_temp_ext / _mirostat / _mirostat_v2).  Not carried
-// over: grammar, DRY, XTC.
+// (upstream common/sampling.cpp, llama-sampling.cpp: llama_sampler_temp_ext / _mirostat / _mirostat_v2).  A grammar (grammar.h) constrains the
+// draw the way common_sampler_sample does with grammar_first = false: the chain runs unconstrained, the drawn token is checked against the grammar,
+// and only if it is refused the row is masked to the admissible tokens and the chain runs again.  Not carried over: DRY, XTC.
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <random>
+#include <string>
 #include <utility>
 #include <vector>
+
+#include "grammar.h"
 
 namespace mi355 {
 
@@ -39,8 +44,15 @@ class Sampler {
   public:
     explicit Sampler(const SamplingParams &p = SamplingParams());
     void reset();
-    void accept(int32_t token);
+    void accept(int32_t token, bool advance_grammar = true);     // (prompt tokens are accepted without the grammar: src/llama_server_context.cc:1493-1495)
     int32_t sample(const float *logits, int n_vocab);
+    // grammar-constrained sampling: `pieces[token]` = the bytes of the token's text ("" for tokens without text), eog[token] != 0 for the end tokens;
+    // both belong to the caller and outlive the sampler
+    void set_grammar(std::shared_ptr<const Grammar> g, const std::vector<std::string> *pieces, const std::vector<uint8_t> *eog);
+    bool has_grammar() const { return gm_ != nullptr; }
+    bool grammar_admits(int32_t token) const;
+    // the token finish() / the device arg-max produced was refused by the grammar: mask the whole row and run the chain again
+    int32_t resample_with_grammar(const float *logits, int n_vocab);
     // sample() = head (logit_bias -> penalties -> top_k over the whole row) + finish().  The head can run on the device instead (SURVEY.md §8f.1,
     // mi355_get_topk_ith): plan_front says whether this sampler's state allows it (false: take sample()) and what to send; finish() then runs the rest
     // of the chain on the (token, adjusted logit) candidates, best first - the same token and the same candidates() as sample() on the whole row
@@ -57,7 +69,11 @@ class Sampler {
 
   private:
     size_t front_k(int n_vocab) const;
+    int32_t sample_chain(const float *logits, int n_vocab);
     SamplingParams p_;
+    std::unique_ptr<GrammarMatcher> gm_;
+    const std::vector<std::string> *pieces_ = nullptr;
+    const std::vector<uint8_t> *eog_ = nullptr;
     std::vector<int32_t> prev_;     // ring of accepted tokens (penalty window)
     std::vector<TokenProb> cand_;
     std::mt19937 rng_;

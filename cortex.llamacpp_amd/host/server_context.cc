@@ -1,6 +1,7 @@
 // server_context.cc — see server_context.h.  Behavioural mirror of the reference loop; citations are into
 // /root/reference/src/llama_server_context.cc unless noted.
 #include "server_context.h"
+#include "grammar.h"
 
 #include <algorithm>
 #include <chrono>
@@ -296,6 +297,22 @@ bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &
         for (const Json &w : stop->items()) if (w.is_string() && !w.as_string().empty()) slot->params.antiprompt.push_back(w.as_string());
 
     slot->smpl.reset(new Sampler(sp));
+    // `grammar` (src/llama_server_context.cc:473): GBNF text; a text that does not parse fails this request with the parser's message
+    if (const std::string gtext = data.value<std::string>("grammar", ""); !gtext.empty()) {
+        std::string gerr;
+        std::shared_ptr<const Grammar> g = Grammar::parse(gtext, gerr);
+        if (!g) { launch_error_ = "grammar: " + gerr; return false; }
+        if (grammar_pieces_.empty()) {
+            const int n_vocab = be_->n_vocab();
+            grammar_pieces_.resize((size_t)n_vocab);
+            grammar_eog_.assign((size_t)n_vocab, 0);
+            for (int t = 0; t < n_vocab; t++) {
+                if (vocab.is_eog(t)) grammar_eog_[(size_t)t] = 1;
+                else if (!vocab.is_control(t)) grammar_pieces_[(size_t)t] = vocab.token_to_piece(t, false);
+            }
+        }
+        slot->smpl->set_grammar(std::move(g), &grammar_pieces_, &grammar_eog_);
+    }
     slot->command = SlotCommand::kLoadPrompt;
     all_slots_are_idle = false;
     return true;
@@ -605,7 +622,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                 if (!slot.params.cache_prompt) {
                     slot.n_past = 0;
                 } else {
-                    for (int32_t t : prompt_tokens) slot.smpl->accept(t);
+                    for (int32_t t : prompt_tokens) slot.smpl->accept(t, false);
                     slot.n_past = (int32_t)common_part(slot.cache_tokens, prompt_tokens);
                 }
                 if (slot.n_past == slot.num_prompt_tokens && slot.n_past > 0) slot.n_past--;   // evaluate at least one token
@@ -696,7 +713,12 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                     std::vector<TokenProb> c((size_t)fp.k);
                     for (int j = 0; j < fp.k; j++) c[(size_t)j] = TokenProb{tk[(size_t)j], lg[(size_t)j]};
                     ids[gi] = slot.smpl->finish(c);
-                    if (ids[gi] >= 0) continue;
+                    if (ids[gi] >= 0 && slot.smpl->grammar_admits(ids[gi])) continue;
+                    if (ids[gi] >= 0) {                     // refused by the request's grammar: the whole row, masked to what the grammar admits
+                        const float *row = be_->logits_ith(slot.i_batch - i);
+                        ids[gi] = row ? slot.smpl->resample_with_grammar(row, n_vocab_now) : -1;
+                        if (ids[gi] >= 0) continue;
+                    }
                 }
             }
             rows[gi] = be_->logits_ith(slot.i_batch - i);

@@ -125,6 +125,9 @@ class LlamaServerContext {
     LlamaClientSlot *GetSlot(int id);
     bool LaunchSlotWithData(LlamaClientSlot *&slot, const Json &data);
     std::string launch_error_;         // why the last LaunchSlotWithData refused its request (sent to the client with the error)
+    // grammar-constrained requests: every token's text once per model (what a candidate is checked with), and which tokens end the generation
+    std::vector<std::string> grammar_pieces_;
+    std::vector<uint8_t> grammar_eog_;
     void ProcessTasks();
     bool ProcessToken(CompletionTokenOutput &result, LlamaClientSlot &slot);
     size_t FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot);

@@ -17,6 +17,7 @@
 #include "../../cortex.llamacpp_amd/host/gguf.h"
 #include "../../cortex.llamacpp_amd/host/json.h"
 #include "../../cortex.llamacpp_amd/host/sampling.h"
+#include "../../cortex.llamacpp_amd/host/grammar.h"
 #include "../../cortex.llamacpp_amd/host/server_context.h"
 #include "../../cortex.llamacpp_amd/host/vocab.h"
 
@@ -356,6 +357,199 @@ static void test_sampler_front_plan_matches_full_chain() {
     CHECK(!w.plan_front(V, 128, 192, fp));
 }
 
+// ---------------------------------------------------------------- grammars (host/grammar.h)
+static bool g_accepts(const std::shared_ptr<const Grammar> &g, const std::string &text, bool *could_end = nullptr) {
+    GrammarMatcher m(g);
+    for (const char c : text) if (!m.accept(std::string(1, c))) return false;      // byte by byte: multi-byte characters cross calls
+    if (could_end) *could_end = m.can_end();
+    return true;
+}
+static bool g_sentence(const std::shared_ptr<const Grammar> &g, const std::string &text) { bool e = false; return g_accepts(g, text, &e) && e; }
+
+static void test_grammar_parse_and_match() {
+    std::string err;
+    auto arith = Grammar::parse(
+        "# sums and products\n"
+        "root ::= expr\n"
+        "expr ::= term ([-+*/] term)*\n"
+        "term ::= num | \"(\" expr \")\"\n"
+        "num  ::= [0-9]+\n", err);
+    CHECK(arith && err.empty());
+    CHECK(g_sentence(arith, "1+(23*4)") && g_sentence(arith, "7") && g_sentence(arith, "((1))"));
+    bool e = true;
+    CHECK(g_accepts(arith, "1+", &e) && !e);                      // a prefix, not a sentence
+    CHECK(g_accepts(arith, "(1", &e) && !e);
+    CHECK(!g_accepts(arith, "1+)") && !g_accepts(arith, ")") && !g_accepts(arith, "1 + 2"));
+    { GrammarMatcher m(arith); CHECK(m.admits("12") && m.admits("(") && !m.admits("+") && !m.admits("") && !m.can_end()); CHECK(m.accept("12+3") && m.can_end() && m.admits("*(") && !m.admits(")")); }
+    // repetition forms, bounded and not, on literals, classes and groups
+    auto rep = Grammar::parse("root ::= \"ab\"{2,3} [x-z]? (\"-\" [0-9]{2}){0,2} \"!\"+\n", err);
+    CHECK(rep);
+    CHECK(g_sentence(rep, "abab!") && g_sentence(rep, "abababz-12-34!!!") && g_sentence(rep, "ababx!"));
+    CHECK(!g_sentence(rep, "ab!") && !g_accepts(rep, "abababab") && !g_accepts(rep, "abab-1!") && !g_accepts(rep, "abab-12-34-56") && !g_sentence(rep, "abab"));
+    // any character, negated classes, escapes, characters outside ASCII (in literals, in classes, split across pieces)
+    auto uni = Grammar::parse("root ::= \"caf\\u00e9\" . [^a-z\\n] [\\x41-\\x43] \"\xE2\x86\x92\" [\xCE\xB1-\xCF\x89]+\n", err);
+    CHECK(uni);
+    CHECK(g_sentence(uni, "caf\xC3\xA9\xF0\x9F\x99\x82" "7B\xE2\x86\x92\xCE\xB2\xCE\xB3"));
+    CHECK(!g_accepts(uni, "cafe") && !g_accepts(uni, "caf\xC3\xA9xq") && !g_accepts(uni, "caf\xC3\xA9x7D"));
+    {
+        GrammarMatcher m(uni);
+        CHECK(m.accept("caf") && m.admits("\xC3") && !m.admits("\xC4") && m.admits("\xC3\xA9") && !m.admits("\xC3\xA8"));
+        CHECK(m.accept("\xC3") && !m.can_end() && m.admits("\xA9") && !m.admits("x") && m.accept("\xA9"));
+        CHECK(m.admits("\xF0\x9F") && m.accept("\xF0\x9F") && m.accept("\x99\x82") && m.accept("7B") && m.admits("\xE2") && !m.admits("\xE3"));
+        GrammarMatcher bad(uni);
+        CHECK(bad.accept("caf") && !bad.accept("\xC3(") && bad.dead());          // a continuation byte was due
+        // overlong forms of an admissible character are not that character: "f" as C1 A6 / E0 81 A6 / F0 80 81 A6
+        GrammarMatcher ov(uni);
+        CHECK(ov.accept("ca") && ov.admits("f") && !ov.admits("\xC1") && !ov.admits("\xC1\xA6") && !ov.admits("\xE0\x81") && !ov.admits("\xF0\x80\x81\xA6") && !ov.admits("\xF0\x80"));
+    }
+    // the usual layout of a JSON grammar: groups over several lines, alternatives starting a line inside them, comments
+    auto js = Grammar::parse(
+        "root   ::= object\n"
+        "value  ::= object | array | string | number | (\"true\" | \"false\" | \"null\") ws\n"
+        "object ::=\n"
+        "  \"{\" ws (\n"
+        "            string \":\" ws value\n"
+        "    (\",\" ws string \":\" ws value)*\n"
+        "  )? \"}\" ws\n"
+        "array  ::=\n"
+        "  \"[\" ws (\n"
+        "            value\n"
+        "    (\",\" ws value)*\n"
+        "  )? \"]\" ws\n"
+        "string ::=\n"
+        "  \"\\\"\" (\n"
+        "    [^\"\\\\\\x7F\\x00-\\x1F] |\n"
+        "    \"\\\\\" ([\"\\\\bfnrt] | \"u\" [0-9a-fA-F]{4}) # escapes\n"
+        "  )* \"\\\"\" ws\n"
+        "number ::= (\"-\"? ([0-9] | [1-9] [0-9]{0,15})) (\".\" [0-9]+)? ([eE] [-+]? [0-9] [1-9]{0,15})? ws\n"
+        "# Optional space: by convention, applied in this grammar after literal chars when allowed\n"
+        "ws ::= | \" \" | \"\\n\" [ \\t]{0,20}\n", err);
+    CHECK(js);
+    if (!js) printf("  %s\n", err.c_str());
+    CHECK(g_sentence(js, "{\"a\": [1, 2.5e3, \"x\\n\\u00e9\", true, null], \"b\": {\"c\": -3}}") && g_sentence(js, "{}"));
+    CHECK(!g_accepts(js, "[1]") && !g_accepts(js, "{\"a\" 1}") && !g_accepts(js, "{'a': 1}") && !g_sentence(js, "{\"a\": 1"));
+    // what cannot be a grammar
+    CHECK(!Grammar::parse("root ::= root \"a\" | \"a\"\n", err) && err.find("left recursion") != std::string::npos);
+    CHECK(!Grammar::parse("root ::= a\na ::= b \"x\"\nb ::= | a\n", err) && err.find("left recursion") != std::string::npos);   // through an empty alternative
+    CHECK(!Grammar::parse("root ::= thing\n", err) && err.find("undefined rule thing") != std::string::npos);
+    CHECK(!Grammar::parse("start ::= \"a\"\n", err) && err.find("root") != std::string::npos);
+    CHECK(!Grammar::parse("root ::= \"abc\n", err) && !Grammar::parse("root ::= [a-\n", err) && !Grammar::parse("root ::= (\"a\"\n", err));
+    CHECK(!Grammar::parse("root ::= *\n", err) && !Grammar::parse("root ::= \"a\"{3,2}\n", err) && !Grammar::parse("root = \"a\"\n", err) && !Grammar::parse("", err));
+    CHECK(!Grammar::parse("root ::= \"a\"\nroot ::= \"b\"\n", err) && err.find("twice") != std::string::npos);
+    CHECK(Grammar::parse("root ::= \"a\"", err));                                                                               // no final newline
+}
+
+static void test_json_schema_grammar() {
+    auto conv = [&](const std::string &schema_text, std::string *gbnf_out = nullptr) -> std::shared_ptr<const Grammar> {
+        Json schema;
+        if (!schema_text.empty() && !Json::parse(schema_text, schema)) { printf("  bad test schema\n"); return nullptr; }
+        std::string gbnf, err;
+        if (!json_schema_to_gbnf(schema, gbnf, err)) { printf("  schema: %s\n", err.c_str()); return nullptr; }
+        if (gbnf_out) *gbnf_out = gbnf;
+        auto g = Grammar::parse(gbnf, err);
+        if (!g) printf("  gbnf: %s\n%s\n", err.c_str(), gbnf.c_str());
+        return g;
+    };
+    // json_object mode: no schema -> any JSON object, compact or spaced
+    auto any = conv("");
+    CHECK(any);
+    CHECK(g_sentence(any, "{\"a\":[1,2,{\"b\":null}],\"c\":\"x\\\"y\",\"d\":-1.5e-3}") && g_sentence(any, "{ \"k\" : [ true , false ] }\n") == false);   // (nothing after the closing brace)
+    CHECK(g_sentence(any, "{ \"k\" : [ true , false ] }") && g_sentence(any, "{}") && !g_accepts(any, "[1]") && !g_accepts(any, "\"s\"") && !g_sentence(any, "{\"a\":1"));
+    CHECK(!g_accepts(any, "{\"a\":01}") && !g_accepts(any, "{\"a\":\"\t\"}") && !g_accepts(any, "{a:1}"));
+    // an object with required and optional members, a bounded array, numbers
+    auto person = conv("{\"type\":\"object\",\"properties\":{\"name\":{\"type\":\"string\"},\"age\":{\"type\":\"integer\"},\"tags\":{\"type\":\"array\",\"items\":{\"type\":\"string\"},\"maxItems\":2},"
+                       "\"score\":{\"type\":\"number\"}},\"required\":[\"name\",\"age\"]}");
+    CHECK(person);
+    CHECK(g_sentence(person, "{\"name\":\"x\",\"age\":3}") && g_sentence(person, "{ \"name\": \"Ann\", \"age\": 41, \"tags\": [\"a\", \"b\"], \"score\": 2.5 }"));
+    CHECK(g_sentence(person, "{\"name\":\"x\",\"age\":3,\"score\":1}") && g_sentence(person, "{\"name\":\"x\",\"age\":3,\"tags\":[]}"));
+    CHECK(!g_sentence(person, "{\"name\":\"x\"}") && !g_accepts(person, "{\"age\":3,") && !g_accepts(person, "{\"name\":\"x\",\"age\":3.5") &&
+          !g_accepts(person, "{\"name\":\"x\",\"age\":3,\"tags\":[\"a\",\"b\",") && !g_accepts(person, "{\"name\":\"x\",\"age\":3,\"other\"") &&
+          !g_accepts(person, "{\"name\":\"x\",\"age\":3,\"score\":1,\"tags\""));                  // optional members keep the schema's order
+    // nothing required: any subset, in order, commas only between members; additionalProperties: false with no members -> {}
+    auto opt = conv("{\"type\":\"object\",\"properties\":{\"a\":{\"type\":\"boolean\"},\"b\":{\"type\":\"null\"},\"c\":{\"const\":\"k\"}}}");
+    CHECK(opt);
+    for (const char *ok : {"{}", "{\"a\":true}", "{\"b\":null}", "{\"c\":\"k\"}", "{\"a\":false,\"c\":\"k\"}", "{\"a\":true,\"b\":null,\"c\":\"k\"}", "{ \"b\": null , \"c\": \"k\" }"}) CHECK(g_sentence(opt, ok));
+    for (const char *no : {"{,", "{\"a\":true,}", "{\"b\":null,\"a\"", "{\"c\":\"x\"", "{\"a\":1"}) CHECK(!g_sentence(opt, no) && !(g_accepts(opt, no) && std::string(no).back() != ','));
+    auto closed = conv("{\"type\":\"object\",\"additionalProperties\":false}");
+    CHECK(closed && g_sentence(closed, "{ }") && !g_accepts(closed, "{\"a\""));
+    auto typed = conv("{\"type\":\"object\",\"additionalProperties\":{\"type\":\"integer\"}}");
+    CHECK(typed && g_sentence(typed, "{\"a\":1,\"b\":-2}") && !g_accepts(typed, "{\"a\":\"x\"") );
+    // enum / const / anyOf / type lists / string lengths / tuples
+    auto en = conv("{\"enum\":[\"red\",\"green\",3,null,{\"a\":1}]}");
+    CHECK(en && g_sentence(en, "\"red\"") && g_sentence(en, "3") && g_sentence(en, "null") && g_sentence(en, "{\"a\":1}") && !g_accepts(en, "\"blue\"") && !g_accepts(en, "4"));
+    auto alt = conv("{\"anyOf\":[{\"type\":\"integer\"},{\"type\":\"string\",\"minLength\":2,\"maxLength\":3},{\"type\":[\"boolean\",\"null\"]}]}");
+    CHECK(alt && g_sentence(alt, "-12") && g_sentence(alt, "\"ab\"") && g_sentence(alt, "\"abc\"") && g_sentence(alt, "true") && g_sentence(alt, "null"));
+    CHECK(!g_sentence(alt, "\"a\"") && !g_accepts(alt, "\"abcd") && !g_accepts(alt, "1.5") && !g_accepts(alt, "["));
+    auto tup = conv("{\"type\":\"array\",\"prefixItems\":[{\"type\":\"integer\"},{\"type\":\"string\"}]}");
+    CHECK(tup && g_sentence(tup, "[1, \"a\"]") && !g_sentence(tup, "[1]") && !g_accepts(tup, "[\"a\""));
+    auto arr = conv("{\"type\":\"array\",\"items\":{\"type\":\"integer\"},\"minItems\":2,\"maxItems\":3}");
+    CHECK(arr && g_sentence(arr, "[1,2]") && g_sentence(arr, "[1, 2, 3]") && !g_sentence(arr, "[1]") && !g_accepts(arr, "[1,2,3,") && !g_sentence(arr, "[]"));
+    // $ref, also recursive; allOf
+    auto tree = conv("{\"$ref\":\"#/$defs/node\",\"$defs\":{\"node\":{\"type\":\"object\",\"properties\":{\"v\":{\"type\":\"integer\"},\"kids\":{\"type\":\"array\",\"items\":{\"$ref\":\"#/$defs/node\"}}},"
+                     "\"required\":[\"v\"]}}}");
+    CHECK(tree && g_sentence(tree, "{\"v\":1,\"kids\":[{\"v\":2},{\"v\":3,\"kids\":[]}]}") && !g_accepts(tree, "{\"v\":1,\"kids\":[{\"kids\""));
+    auto all = conv("{\"allOf\":[{\"properties\":{\"a\":{\"type\":\"integer\"}},\"required\":[\"a\"]},{\"properties\":{\"b\":{\"type\":\"string\"}}}]}");
+    CHECK(all && g_sentence(all, "{\"a\":1,\"b\":\"x\"}") && g_sentence(all, "{\"a\":1}") && !g_sentence(all, "{\"b\":\"x\"}"));
+    // what it refuses
+    Json bad; std::string gbnf, err;
+    CHECK(Json::parse("{\"$ref\":\"#/$defs/missing\"}", bad) && !json_schema_to_gbnf(bad, gbnf, err) && err.find("$ref") != std::string::npos);
+    CHECK(Json::parse("{\"type\":\"frob\"}", bad) && !json_schema_to_gbnf(bad, gbnf, err));
+    CHECK(Json::parse("{\"enum\":[]}", bad) && !json_schema_to_gbnf(bad, gbnf, err));
+}
+
+static void test_sampler_with_grammar() {
+    // a vocabulary of pieces; the logits prefer tokens the grammar refuses
+    const std::vector<std::string> pieces = {"", "yes", "no", "y", "es", " ", "!", "maybe", "\xC3", "\xA9", "n"};
+    std::vector<uint8_t> eog(pieces.size(), 0);
+    eog[0] = 1;                                                    // token 0 ends the generation
+    std::string err;
+    auto g = Grammar::parse("root ::= (\"yes\" | \"no\" | \"n\\u00e9\") \"!\"\n", err);
+    CHECK(g);
+    SamplingParams p;
+    p.temp = 0.0f; p.penalty_repeat = 1.0f;
+    Sampler s(p);
+    s.set_grammar(g, &pieces, &eog);
+    CHECK(!s.is_plain_greedy() && s.has_grammar());
+    std::vector<float> lg = {9.0f, 1.0f, 0.5f, 2.0f, 3.0f, 5.0f, 6.0f, 8.0f, 0.1f, 0.2f, 0.3f};
+    CHECK(!s.grammar_admits(0) && !s.grammar_admits(7) && s.grammar_admits(1) && s.grammar_admits(3) && !s.grammar_admits(4) && s.grammar_admits(10));
+    int t = s.sample(lg.data(), (int)lg.size());
+    CHECK(t == 3);                                                 // "y": the best of {yes, no, y, n}; "maybe", the end token, "!" and " " are refused
+    s.accept(t);
+    t = s.sample(lg.data(), (int)lg.size());
+    CHECK(t == 4);                                                 // only "es" continues "y"
+    s.accept(t);
+    CHECK(!s.grammar_admits(0) && s.grammar_admits(6));
+    t = s.sample(lg.data(), (int)lg.size());
+    CHECK(t == 6);
+    s.accept(t);
+    CHECK(s.grammar_admits(0) && !s.grammar_admits(6) && !s.grammar_admits(1));
+    t = s.sample(lg.data(), (int)lg.size());
+    CHECK(t == 0);                                                 // the sentence is complete: nothing but the end token
+    // a character split over two tokens; tokens accepted as PROMPT do not move the grammar; reset() starts the sentence again
+    s.reset();
+    s.accept(7, false);
+    CHECK(s.grammar_admits(10));
+    s.accept(10);
+    CHECK(s.grammar_admits(8) && !s.grammar_admits(9) && !s.grammar_admits(6) && !s.grammar_admits(0));
+    s.accept(8);
+    CHECK(s.grammar_admits(9) && !s.grammar_admits(8) && !s.grammar_admits(6));
+    s.accept(9);
+    CHECK(s.grammar_admits(6) && !s.grammar_admits(0));
+    s.reset();
+    CHECK(s.grammar_admits(1) && !s.grammar_admits(6));
+    // the device front end hands over k candidates: a refused draw is re-drawn from the whole row
+    std::vector<TokenProb> c = {{0, 9.0f}, {7, 8.0f}, {6, 6.0f}};
+    t = s.finish(c);
+    CHECK(t == 0 && !s.grammar_admits(t) && s.resample_with_grammar(lg.data(), (int)lg.size()) == 3);
+    // a vocabulary that cannot continue the sentence ends the generation
+    const std::vector<std::string> poor = {"", "x", "z"};
+    std::vector<uint8_t> poor_eog = {1, 0, 0};
+    Sampler s2(p);
+    s2.set_grammar(g, &poor, &poor_eog);
+    std::vector<float> lg2 = {0.0f, 1.0f, 2.0f};
+    CHECK(s2.sample(lg2.data(), 3) == 0);
+}
+
 static void test_slot_loop() {
     FakeBackend be;
     ServerParams sp;
@@ -682,6 +876,102 @@ static int tokenize_cli(const char *gguf, const char *cases) {
     return 0;
 }
 
+static std::string strip_eos(std::string t) { if (t.size() >= 4 && t.compare(t.size() - 4, 4, "</s>") == 0) t.resize(t.size() - 4); return t; }
+
+static void test_engine_grammar_requests() {
+    LlamaEngine eng([](const Json &, BackendInfo &, std::string &) -> std::unique_ptr<IBackend> { return std::unique_ptr<IBackend>(new FakeBackend()); });
+    Json load = Json::object();
+    load["llama_model_path"] = "/models/g.gguf"; load["ctx_len"] = 256; load["n_parallel"] = 1;
+    int code = 0;
+    eng.LoadModel(load, [&](Json &&st, Json &&) { code = (int)st["status_code"].as_int(); });
+    CHECK(code == 200);
+    auto complete = [&](Json req, Json &status) {
+        std::mutex mu; std::condition_variable cv; bool done = false; Json body;
+        Json msgs = Json::array(), m1 = Json::object();
+        m1["role"] = "user"; m1["content"] = "hello";
+        msgs.push_back(m1);
+        req["model"] = "g"; req["messages"] = msgs;
+        eng.HandleChatCompletion(req, [&](Json &&st, Json &&b) { std::lock_guard<std::mutex> lk(mu); status = st; body = b; done = true; cv.notify_all(); });
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        return body;
+    };
+    // the backend's logits prefer pseudo-random tokens; the grammar leaves one sentence, spelt with whatever pieces the vocabulary has, then only the end
+    for (double temp : {0.0, 0.9}) {
+        Json req = Json::object(), st;
+        req["max_tokens"] = 40; req["temperature"] = temp; req["seed"] = 5; req["grammar"] = "root ::= \"hello\" \" world\" [!.]\n";
+        Json body = complete(req, st);
+        CHECK(st["status_code"].as_int() == 200);
+        // (the end token's text is part of the content, as in the reference: common_token_to_piece(ctx, tok) with special = true, src/llama_server_context.cc:720)
+        const std::string text = strip_eos(body["choices"].at(0)["message"]["content"].as_string());
+        CHECK(text == "hello world!" || text == "hello world.");
+        CHECK(body["choices"].at(0)["finish_reason"].as_string() == "stop");
+    }
+    {   // response_format json_object: the text is a prefix of a JSON object (the token budget ends it), and a schema shapes it
+        Json req = Json::object(), st, rf = Json::object();
+        rf["type"] = "json_object";
+        req["max_tokens"] = 24; req["temperature"] = 0.7; req["seed"] = 11; req["response_format"] = rf;
+        const std::string text = strip_eos(complete(req, st)["choices"].at(0)["message"]["content"].as_string());
+        CHECK(st["status_code"].as_int() == 200 && !text.empty() && text[0] == '{');
+        std::string gbnf, err;
+        CHECK(json_schema_to_gbnf(Json(), gbnf, err));
+        GrammarMatcher m(Grammar::parse(gbnf, err));
+        CHECK(m.accept(text));
+        Json schema;
+        CHECK(Json::parse("{\"type\":\"object\",\"properties\":{\"ok\":{\"type\":\"boolean\"}},\"required\":[\"ok\"]}", schema));
+        Json js = Json::object();
+        js["schema"] = schema;
+        rf["type"] = "json_schema"; rf["json_schema"] = js;
+        req["response_format"] = rf; req["max_tokens"] = 60;
+        Json body = complete(req, st);
+        Json parsed;
+        CHECK(st["status_code"].as_int() == 200 && Json::parse(strip_eos(body["choices"].at(0)["message"]["content"].as_string()), parsed) && parsed["ok"].is_bool());
+        CHECK(body["choices"].at(0)["finish_reason"].as_string() == "stop");
+        Json bad_schema;
+        CHECK(Json::parse("{\"type\":\"frob\"}", bad_schema));
+        js["schema"] = bad_schema; rf["json_schema"] = js; req["response_format"] = rf;
+        Json eb = complete(req, st);
+        CHECK(st["status_code"].as_int() == 400 && st["has_error"].as_bool() && eb["message"].as_string().find("response_format") != std::string::npos);
+    }
+    {   // a grammar that does not parse fails its request with the parser's message; the model keeps serving
+        Json req = Json::object(), st;
+        req["max_tokens"] = 4; req["grammar"] = "root ::= missing-rule\n";
+        Json eb = complete(req, st);
+        CHECK(st["has_error"].as_bool() && st["status_code"].as_int() == 400 && eb["message"].as_string().find("undefined rule missing-rule") != std::string::npos);
+        Json ok = Json::object();
+        ok["max_tokens"] = 3; ok["temperature"] = 0.0;
+        complete(ok, st);
+        CHECK(st["status_code"].as_int() == 200);
+    }
+    // grammar_file at load: its text constrains every completion of that model; a missing file fails the load
+    char path[] = "/tmp/mi355_grammar_XXXXXX";
+    const int fd = mkstemp(path);
+    const char *gtext = "root ::= \"st\" \"o\"+ \"p\"\n";
+    CHECK(fd >= 0 && write(fd, gtext, strlen(gtext)) == (ssize_t)strlen(gtext));
+    close(fd);
+    Json load2 = Json::object();
+    load2["llama_model_path"] = "/models/h.gguf"; load2["ctx_len"] = 256; load2["grammar_file"] = path; load2["model"] = "h";
+    eng.LoadModel(load2, [&](Json &&st, Json &&) { code = (int)st["status_code"].as_int(); });
+    CHECK(code == 200);
+    {
+        std::mutex mu; std::condition_variable cv; bool done = false; Json body, st;
+        Json req = Json::object(), msgs = Json::array(), m1 = Json::object();
+        m1["role"] = "user"; m1["content"] = "hello";
+        msgs.push_back(m1);
+        req["model"] = "h"; req["messages"] = msgs; req["max_tokens"] = 30; req["temperature"] = 1.0; req["seed"] = 3; req["grammar"] = "root ::= \"ignored\"\n";
+        eng.HandleChatCompletion(req, [&](Json &&s2, Json &&b) { std::lock_guard<std::mutex> lk(mu); st = s2; body = b; done = true; cv.notify_all(); });
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        const std::string text = strip_eos(body["choices"].at(0)["message"]["content"].as_string());
+        CHECK(text.size() >= 4 && text.compare(0, 3, "sto") == 0 && text.find_first_not_of('o', 2) == text.size() - 1 && text.back() == 'p');
+    }
+    unlink(path);
+    Json load3 = Json::object();
+    load3["llama_model_path"] = "/models/i.gguf"; load3["grammar_file"] = "/nonexistent/grammar.gbnf";
+    eng.LoadModel(load3, [&](Json &&st, Json &&) { code = (int)st["status_code"].as_int(); });
+    CHECK(code == 500);
+}
+
 static void test_embeddings() {
     LlamaEngine eng([](const Json &, BackendInfo &, std::string &) -> std::unique_ptr<IBackend> { return std::unique_ptr<IBackend>(new FakeBackend()); });
     Json load = Json::object();
@@ -785,12 +1075,16 @@ int main(int argc, char **argv) {
     test_sampler_topk_matches_full_sort();
     test_sampler_mirostat_dynatemp();
     test_sampler_front_plan_matches_full_chain();
+    test_grammar_parse_and_match();
+    test_json_schema_grammar();
+    test_sampler_with_grammar();
     test_slot_loop();
     test_prompt_cache_and_shift();
     test_kv_full_error();
     test_bad_token_ids_and_backend_errors();
     test_gguf_hardening();
     test_engine();
+    test_engine_grammar_requests();
     test_embeddings();
     if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
     printf("all host-logic checks passed\n");

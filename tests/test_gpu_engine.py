@@ -208,3 +208,53 @@ def test_device_sampling_front_end_gives_the_host_chain_text(pkg, tiny_vocab_mod
         e.close()
     assert texts[True] == texts[False]
     assert len(set(texts[True])) > 1
+
+
+def test_grammar_and_response_format_constrain_the_text(pkg, tiny_vocab_model, tmp_path):
+    """`grammar` (GBNF), `response_format` {json_object | json_schema} and the load option `grammar_file` (src/llama_engine.cc:573-585, 793-814): a
+    random-weight model writes what the grammar leaves it - with the device sampling front end (k candidates, a refused draw re-drawn from the masked
+    row) and with the whole chain on the host, seed for seed the same text."""
+    texts = {}
+    for dev in (True, False):
+        e = pkg.Engine()
+        st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=512, n_parallel=1, ngl=100, user_prompt="u:", ai_prompt="a:", system_prompt="s:",
+                                device_sampling=dev)
+        assert st["status_code"] == 200, (st, body)
+        out = []
+
+        def ask(**kw):
+            res = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "go"}], **kw)
+            return res[-1][0], res[-1][1]
+        st, b = ask(max_tokens=64, temperature=0.8, seed=3, grammar='root ::= ("yes" | "no") " " [a-z]{3,5} "."\n')
+        text = b["choices"][0]["message"]["content"].replace("</s>", "")
+        import re
+        assert st["status_code"] == 200 and re.fullmatch(r"(yes|no) [a-z]{3,5}\.", text), text
+        assert b["choices"][0]["finish_reason"] == "stop"
+        out.append(text)
+        st, b = ask(max_tokens=0 + 200, temperature=0.0, response_format={"type": "json_schema", "json_schema": {"schema": {
+            "type": "object", "properties": {"n": {"type": "integer"}, "tag": {"enum": ["a", "b"]}, "ok": {"type": "boolean"}}, "required": ["n", "tag"]}}})
+        text = b["choices"][0]["message"]["content"].replace("</s>", "")
+        doc = json.loads(text)
+        assert st["status_code"] == 200 and isinstance(doc["n"], int) and doc["tag"] in ("a", "b") and set(doc) <= {"n", "tag", "ok"}, text
+        out.append(text)
+        st, b = ask(max_tokens=48, temperature=0.9, seed=4, response_format={"type": "json_object"})
+        text = b["choices"][0]["message"]["content"].replace("</s>", "")
+        assert st["status_code"] == 200 and text.lstrip().startswith("{"), text
+        out.append(text)
+        st, b = ask(max_tokens=8, grammar="root ::= nothing\n")
+        assert st["status_code"] == 400 and "undefined rule nothing" in b["message"]
+        texts[dev] = out
+        e.close()
+    assert texts[True] == texts[False]
+    # grammar_file: the model's grammar for every completion
+    gf = tmp_path / "only.gbnf"
+    gf.write_text('root ::= "<" [0-9]+ ">"\n')
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, ctx_len=256, grammar_file=str(gf))
+    assert st["status_code"] == 200
+    b = e.chat_completion(model="tiny-d128", messages=[{"role": "user", "content": "go"}], max_tokens=40, temperature=0.7, seed=9)[-1][1]
+    import re
+    assert re.match(r"<[0-9]+>?", b["choices"][0]["message"]["content"]), b
+    st, body = e.load_model(llama_model_path=tiny_vocab_model, model="other", grammar_file=str(tmp_path / "missing.gbnf"))
+    assert st["status_code"] == 500
+    e.close()

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "cortex.llamacpp_amd", "host")
 SRCS = [os.path.join(ROOT, "tests", "host", "host_tests.cc")] + [
-    os.path.join(HOST, f) for f in ("vocab.cc", "sampling.cc", "server_context.cc", "engine.cc", "gguf.cc", "log.cc")]
+    os.path.join(HOST, f) for f in ("vocab.cc", "sampling.cc", "grammar.cc", "json_schema.cc", "server_context.cc", "engine.cc", "gguf.cc", "log.cc")]
 
 
 @pytest.fixture(scope="module")
