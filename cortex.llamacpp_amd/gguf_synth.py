@@ -177,7 +177,7 @@ CONFIGS = {
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 
-FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17, "q2_k": 10, "q3_k_m": 12}
+FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17, "q2_k": 10, "q3_k_s": 11, "q3_k_m": 12, "q3_k_l": 13, "q4_k_s": 14, "q5_k_s": 16, "q6_k": 18}
 
 
 def use_more_bits(i: int, n: int) -> bool:
@@ -206,6 +206,21 @@ def tensor_type(cfg: LlamaConfig, ftype: str, kind: str, il: int) -> int:
         if kind == "attn_output":
             return Q3_K if q2 else Q4_K
         return Q2_K if q2 else Q3_K
+    if ftype in ("q3_k_s", "q3_k_l", "q4_k_s", "q5_k_s", "q6_k"):
+        # the other mixes the reference publishes (.github/workflows/convert-model-all-quant.yml:106-152), by llama-quantize's rules for the llama
+        # architecture: output Q6_K everywhere; Q3_K_S: everything else Q3_K; Q3_K_L: attn_v, ffn_down, attn_output Q5_K, the rest Q3_K; Q4_K_S: Q4_K
+        # with attn_v Q5_K in the first four layers and ffn_down Q5_K in the first n_layer / 8; Q5_K_S: Q5_K; Q6_K: Q6_K
+        if kind == "output" or ftype == "q6_k":
+            return Q6_K
+        if ftype == "q3_k_s":
+            return Q3_K
+        if ftype == "q3_k_l":
+            return Q5_K if kind in ("attn_v", "ffn_down", "attn_output") else Q3_K
+        if ftype == "q4_k_s":
+            if (kind == "attn_v" and il < 4) or (kind == "ffn_down" and il < max(1, cfg.n_layer // 8)):
+                return Q5_K
+            return Q4_K
+        return Q5_K
     base = {"q4_k_m": Q4_K, "q5_k_m": Q5_K}[ftype]
     if kind == "output":
         return Q6_K
