@@ -168,16 +168,18 @@ hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, flo
 // instead of the 513 KB row.  Order = the host sampler's (host/sampling.cc `better`): higher logit first, lower token id on ties.  Exact: the same f32
 // operations on the adjusted tokens (l + bias; l <= 0 ? l * repeat : l / repeat; l -= count * freq + present), keys compared as integers.
 constexpr int TOPK_MAX_K = 128, TOPK_MAX_ADJ = 192;
-struct TopkAdj {                        // by value into the first kernel
+struct TopkAdj {                        // one per row, in device memory
     int n;                              // adjusted tokens
     float repeat, freq, present;
     int tok[TOPK_MAX_ADJ];
     float bias[TOPK_MAX_ADJ];           // 0 = none
     int cnt[TOPK_MAX_ADJ];              // occurrences in the penalty window (0 = not penalised)
 };
-size_t topk_scratch_bytes(int n);       // workspace for a row of n logits
-// keys_out (device or pinned host memory, k 64-bit words): key = (order-preserving image of the f32 logit) << 32 | (0xffffffff - token), best first
-hipError_t launch_topk_row(const float *x, int n, int k, const TopkAdj &adj, void *scratch, unsigned long long *keys_out, hipStream_t st);
+size_t topk_scratch_bytes(int n);       // workspace PER ROW of n logits
+// n_rows rows of `base` ([.][n] f32; row r of the launch = base row rows_dev[r], adjustments adjs_dev[r]) in one set of launches: the k best of each
+// into keys_out[r * TOPK_MAX_K + 0..k) (device or pinned host memory), key = (order-preserving image of the f32 logit) << 32 | (0xffffffff - token)
+hipError_t launch_topk_rows(const float *base, int n, int n_rows, const int *rows_dev, int k, const TopkAdj *adjs_dev, void *scratch, unsigned long long *keys_out,
+                            hipStream_t st);
 
 // f32 / f16 weight mat-vec (router, unquantised models): y[t][r] = dot(W[r], x[t])
 hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,

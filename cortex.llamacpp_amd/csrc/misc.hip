@@ -184,20 +184,29 @@ __device__ __forceinline__ void topk_sort_desc(topk_key *s, int tid) {
             __syncthreads();
         }
 }
-__global__ __launch_bounds__(256) void topk_part_kernel(const float *x, int n, int kk, const TopkAdj adj, topk_key *part) {
+// grid = (lists of 512 logits, rows).  Row r of the launch is logits row rows[r] of `base` with adjustments adj[r]; its lists go to part[r][...]
+__global__ __launch_bounds__(256) void topk_part_kernel(const float *base, int n, const int *rows, int kk, const TopkAdj *adjs, topk_key *part, size_t part_stride) {
     __shared__ topk_key s[512];
-    const int tid = threadIdx.x, base = blockIdx.x * 512;
+    __shared__ int a_tok[TOPK_MAX_ADJ], a_cnt[TOPK_MAX_ADJ];
+    __shared__ float a_bias[TOPK_MAX_ADJ];
+    const int tid = threadIdx.x, first = blockIdx.x * 512, r = blockIdx.y;
+    const TopkAdj &adj = adjs[r];
+    const int na = adj.n;
+    for (int a = tid; a < na; a += 256) { a_tok[a] = adj.tok[a]; a_bias[a] = adj.bias[a]; a_cnt[a] = adj.cnt[a]; }
+    const float repeat = adj.repeat, freq = adj.freq, present = adj.present;
+    const float *x = base + (size_t)rows[r] * n;
+    __syncthreads();
     for (int e = tid; e < 512; e += 256) {
-        const int i = base + e;
+        const int i = first + e;
         topk_key key = 0;                                        // below every real key
         if (i < n) {
             float l = x[i];
-            for (int a = 0; a < adj.n; a++) {
-                if (adj.tok[a] != i) continue;
-                l = l + adj.bias[a];
-                if (adj.cnt[a] > 0) {
-                    if (l <= 0.0f) l *= adj.repeat; else l /= adj.repeat;
-                    l -= (float)adj.cnt[a] * adj.freq + adj.present;
+            for (int a = 0; a < na; a++) {
+                if (a_tok[a] != i) continue;
+                l = l + a_bias[a];
+                if (a_cnt[a] > 0) {
+                    if (l <= 0.0f) l *= repeat; else l /= repeat;
+                    l -= (float)a_cnt[a] * freq + present;
                 }
             }
             key = topk_make_key(l, i);
@@ -206,31 +215,36 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const float *x, int n, i
     }
     __syncthreads();
     topk_sort_desc<512, 256>(s, tid);
-    for (int e = tid; e < kk; e += 256) part[(size_t)blockIdx.x * kk + e] = s[e];
+    topk_key *o = part + (size_t)r * part_stride + (size_t)blockIdx.x * kk;
+    for (int e = tid; e < kk; e += 256) o[e] = s[e];
 }
-__global__ __launch_bounds__(256) void topk_merge_kernel(const topk_key *in, int n_lists, int kk, topk_key *out, int out_count) {
+__global__ __launch_bounds__(256) void topk_merge_kernel(const topk_key *in, size_t in_stride, int n_lists, int kk, topk_key *out, size_t out_stride, int out_count) {
     __shared__ topk_key s[1024];
     const int tid = threadIdx.x, per = 1024 / kk, l0 = blockIdx.x * per;
+    const topk_key *src = in + (size_t)blockIdx.y * in_stride;
     for (int e = tid; e < 1024; e += 256) {
         const int l = l0 + e / kk;
-        s[e] = l < n_lists ? in[(size_t)l * kk + (e % kk)] : 0;
+        s[e] = l < n_lists ? src[(size_t)l * kk + (e % kk)] : 0;
     }
     __syncthreads();
     topk_sort_desc<1024, 256>(s, tid);
-    for (int e = tid; e < out_count; e += 256) out[(size_t)blockIdx.x * out_count + e] = s[e];
+    topk_key *o = out + (size_t)blockIdx.y * out_stride + (size_t)blockIdx.x * out_count;
+    for (int e = tid; e < out_count; e += 256) o[e] = s[e];
 }
 static int topk_kk(int k) { int kk = 16; while (kk < k) kk <<= 1; return kk; }
 size_t topk_scratch_bytes(int n) { return (size_t)((n + 511) / 512) * TOPK_MAX_K * sizeof(topk_key) * 2; }
-hipError_t launch_topk_row(const float *x, int n, int k, const TopkAdj &adj, void *scratch, unsigned long long *keys_out, hipStream_t st) {
-    if (k < 1 || k > TOPK_MAX_K || n < 1 || adj.n < 0 || adj.n > TOPK_MAX_ADJ) return hipErrorInvalidValue;
+hipError_t launch_topk_rows(const float *base, int n, int n_rows, const int *rows_dev, int k, const TopkAdj *adjs_dev, void *scratch, unsigned long long *keys_out,
+                            hipStream_t st) {
+    if (k < 1 || k > TOPK_MAX_K || n < 1 || n_rows < 1) return hipErrorInvalidValue;
     const int kk = topk_kk(k);
     int lists = (n + 511) / 512;
-    topk_key *a = reinterpret_cast<topk_key *>(scratch), *b = a + (size_t)lists * TOPK_MAX_K;
-    hipLaunchKernelGGL(topk_part_kernel, dim3(lists), dim3(256), 0, st, x, n, kk, adj, a);
+    const size_t stride = topk_scratch_bytes(n) / sizeof(topk_key) / 2;      // keys per row and buffer
+    topk_key *a = reinterpret_cast<topk_key *>(scratch), *b = a + stride * (size_t)n_rows;
+    hipLaunchKernelGGL(topk_part_kernel, dim3(lists, n_rows), dim3(256), 0, st, base, n, rows_dev, kk, adjs_dev, a, stride);
     for (;;) {
         const int per = 1024 / kk, blocks = (lists + per - 1) / per;
         const bool last = blocks == 1;
-        hipLaunchKernelGGL(topk_merge_kernel, dim3(blocks), dim3(256), 0, st, a, lists, kk, last ? keys_out : b, last ? k : kk);
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(blocks, n_rows), dim3(256), 0, st, a, stride, lists, kk, last ? keys_out : b, last ? (size_t)TOPK_MAX_K : stride, last ? k : kk);
         if (last) break;
         lists = blocks;
         topk_key *t = a; a = b; b = t;

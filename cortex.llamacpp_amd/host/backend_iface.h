@@ -43,6 +43,22 @@ class IBackend {
         (void)i; (void)k; (void)adj_tok; (void)adj_bias; (void)adj_cnt; (void)repeat; (void)freq; (void)present; (void)toks; (void)logits;
         return -1;
     }
+    // the same for every sampling slot of a scheduler tick at once (one set of launches, one synchronisation); default: row by row
+    struct TopkRequest {
+        int i = 0, k = 0;
+        std::vector<int32_t> tok, cnt;
+        std::vector<float> bias;
+        float repeat = 1.0f, freq = 0.0f, present = 0.0f;
+        std::vector<int32_t> out_tok;
+        std::vector<float> out_logit;
+        bool ok = false;
+    };
+    virtual void topk_batch(std::vector<TopkRequest> &reqs) {
+        for (auto &r : reqs) {
+            r.out_tok.assign((size_t)r.k, 0); r.out_logit.assign((size_t)r.k, 0.0f);
+            r.ok = topk_ith(r.i, r.k, r.tok, r.bias, r.cnt, r.repeat, r.freq, r.present, r.out_tok.data(), r.out_logit.data()) == r.k;
+        }
+    }
     virtual int topk_max_k() const { return 0; }      // 0: no device front end
     virtual int topk_max_adj() const { return 0; }
     // llama_set_embeddings / llama_get_embeddings_ith (llama_server_context.cc:299, 1042-1044)

@@ -46,6 +46,29 @@ class HipBackend : public IBackend {
         for (int j = 0; j < a.n; j++) { a.tok[j] = adj_tok[(size_t)j]; a.bias[j] = adj_bias[(size_t)j]; a.cnt[j] = adj_cnt[(size_t)j]; }
         return ctx_->topk_ith(i, k, a, toks, logits);
     }
+    void topk_batch(std::vector<TopkRequest> &reqs) override {
+        const int n = (int)reqs.size();
+        if (n == 0) return;
+        adjs_.resize((size_t)n); is_.resize((size_t)n); ks_.resize((size_t)n);
+        out_t_.resize((size_t)n * TOPK_MAX_K); out_l_.resize((size_t)n * TOPK_MAX_K);
+        bool fits = true;
+        for (int r = 0; r < n; r++) {
+            const TopkRequest &q = reqs[(size_t)r];
+            TopkAdj &a = adjs_[(size_t)r];
+            if (q.tok.size() > (size_t)TOPK_MAX_ADJ || q.k < 1 || q.k > TOPK_MAX_K) { fits = false; break; }
+            a.n = (int)q.tok.size(); a.repeat = q.repeat; a.freq = q.freq; a.present = q.present;
+            for (int j = 0; j < a.n; j++) { a.tok[j] = q.tok[(size_t)j]; a.bias[j] = q.bias[(size_t)j]; a.cnt[j] = q.cnt[(size_t)j]; }
+            is_[(size_t)r] = q.i; ks_[(size_t)r] = q.k;
+        }
+        const bool ok = fits && ctx_->topk_rows(n, is_.data(), ks_.data(), adjs_.data(), out_t_.data(), out_l_.data()) == n;
+        for (int r = 0; r < n; r++) {
+            TopkRequest &q = reqs[(size_t)r];
+            q.ok = ok;
+            if (!ok) continue;
+            q.out_tok.assign(out_t_.begin() + (long)r * TOPK_MAX_K, out_t_.begin() + (long)r * TOPK_MAX_K + q.k);
+            q.out_logit.assign(out_l_.begin() + (long)r * TOPK_MAX_K, out_l_.begin() + (long)r * TOPK_MAX_K + q.k);
+        }
+    }
     int topk_max_k() const override { return device_sampling_ ? TOPK_MAX_K : 0; }
     int topk_max_adj() const override { return TOPK_MAX_ADJ; }
     void set_embeddings(bool on) override { ctx_->embeddings_enabled = on; }
@@ -61,6 +84,10 @@ class HipBackend : public IBackend {
     Vocab vocab_;
     bool device_sampling_ = true;
     std::vector<int32_t> n_seq_id_, seq_store_;
+    std::vector<TopkAdj> adjs_;
+    std::vector<int> is_, ks_;
+    std::vector<int32_t> out_t_;
+    std::vector<float> out_l_;
     std::vector<int32_t *> seq_ptr_;
 };
 

@@ -401,6 +401,9 @@ Context::~Context() {
     if (h_chunks_) (void)hipHostFree(h_chunks_);
     if (h_mega_flag_) (void)hipHostFree(h_mega_flag_);
     if (h_topk_) (void)hipHostFree(h_topk_);
+    if (h_topk_adj_) (void)hipHostFree(h_topk_adj_);
+    if (d_topk_adj_) (void)hipFree(d_topk_adj_);
+    if (topk_scratch_) { (void)hipFree(topk_scratch_); topk_scratch_ = nullptr; }
     if (h_moe_meta_) (void)hipHostFree(h_moe_meta_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -1689,31 +1692,74 @@ int32_t Context::argmax_ith(int i) {
     return h_argmax_[out_row_of_batch_[(size_t)i]];
 }
 
-int Context::topk_ith(int i, int k, const TopkAdj &adj, int32_t *toks, float *logits) {
-    if (last_was_embd_) return -1;
-    if (i < 0) i += (int)out_row_of_batch_.size();
-    if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return -1;
+// n rows of the last batch in ONE set of launches and ONE synchronisation (a scheduler tick asks for all its sampling slots together: row by row, each
+// with its own launch + sync, 32 slots cost more than copying 32 rows to the host did).  toks / logits: [n][TOPK_MAX_K]; ks[r] of each row are valid.
+int Context::topk_rows(int n, const int *is, const int *ks, const TopkAdj *adjs, int32_t *toks, float *logits) {
+    if (last_was_embd_ || n < 1) return -1;
     const int V = model->hp.n_vocab;
-    if (k < 1 || k > TOPK_MAX_K || k > V) return -1;
+    int kmax = 0;
+    std::vector<int> rows((size_t)n);
+    for (int r = 0; r < n; r++) {
+        int i = is[r];
+        if (i < 0) i += (int)out_row_of_batch_.size();
+        if (i < 0 || i >= (int)out_row_of_batch_.size() || out_row_of_batch_[(size_t)i] < 0) return -1;
+        if (ks[r] < 1 || ks[r] > TOPK_MAX_K || ks[r] > V || adjs[r].n < 0 || adjs[r].n > TOPK_MAX_ADJ) return -1;
+        rows[(size_t)r] = out_row_of_batch_[(size_t)i];
+        kmax = std::max(kmax, ks[r]);
+    }
     if (hipSetDevice(model->device) != hipSuccess) return -1;
-    if (!topk_scratch_) {
+    if (n > topk_rows_cap_) {
         (void)hipStreamSynchronize(stream_);
-        topk_scratch_ = dalloc(topk_scratch_bytes(V));
-        if (!topk_scratch_ || hipHostMalloc((void **)&h_topk_, TOPK_MAX_K * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { last_error = "top-k workspace allocation failed"; return -1; }
-        (void)hipDeviceSynchronize();                      // null-stream zero-fill of the new buffer (see init)
+        if (topk_scratch_) (void)hipFree(topk_scratch_);
+        if (d_topk_adj_) (void)hipFree(d_topk_adj_);
+        if (h_topk_) (void)hipHostFree(h_topk_);
+    if (h_topk_adj_) (void)hipHostFree(h_topk_adj_);
+    if (d_topk_adj_) (void)hipFree(d_topk_adj_);
+    if (topk_scratch_) { (void)hipFree(topk_scratch_); topk_scratch_ = nullptr; }
+        if (h_topk_adj_) (void)hipHostFree(h_topk_adj_);
+        topk_scratch_ = nullptr; d_topk_adj_ = nullptr; h_topk_ = nullptr; h_topk_adj_ = nullptr; topk_rows_cap_ = 0;
+        const int cap = std::max(n, std::min(64, (int)cp.n_seq_max));
+        const size_t adj_bytes = (size_t)cap * sizeof(TopkAdj) + (size_t)cap * sizeof(int);
+        if (hipMalloc(&topk_scratch_, topk_scratch_bytes(V) * (size_t)cap) != hipSuccess || hipMalloc((void **)&d_topk_adj_, adj_bytes) != hipSuccess ||
+            hipHostMalloc((void **)&h_topk_, (size_t)cap * TOPK_MAX_K * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&h_topk_adj_, adj_bytes, hipHostMallocDefault) != hipSuccess) { last_error = "top-k workspace allocation failed"; return -1; }
+        topk_rows_cap_ = cap;
     }
-    const float *row = d_logits_ + (size_t)out_row_of_batch_[(size_t)i] * V;
-    if (launch_topk_row(row, V, k, adj, topk_scratch_, h_topk_, stream_) != hipSuccess) { last_error = "top-k launch failed"; return -1; }
+    // adjustments and row numbers: one staged copy
+    TopkAdj *ha = reinterpret_cast<TopkAdj *>(h_topk_adj_);
+    int *hr = reinterpret_cast<int *>(h_topk_adj_ + (size_t)topk_rows_cap_ * sizeof(TopkAdj));
+    for (int r = 0; r < n; r++) {
+        TopkAdj &d = ha[r];
+        const TopkAdj &a = adjs[r];
+        d.n = a.n; d.repeat = a.repeat; d.freq = a.freq; d.present = a.present;
+        memcpy(d.tok, a.tok, (size_t)a.n * sizeof(int)); memcpy(d.bias, a.bias, (size_t)a.n * sizeof(float)); memcpy(d.cnt, a.cnt, (size_t)a.n * sizeof(int));
+        hr[r] = rows[(size_t)r];
+    }
+    const size_t rows_off = (size_t)topk_rows_cap_ * sizeof(TopkAdj);
+    if (hipMemcpyAsync(d_topk_adj_, h_topk_adj_, (size_t)n * sizeof(TopkAdj), hipMemcpyHostToDevice, stream_) != hipSuccess ||
+        hipMemcpyAsync(d_topk_adj_ + rows_off, h_topk_adj_ + rows_off, (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream_) != hipSuccess) { last_error = "top-k staging failed"; return -1; }
+    if (launch_topk_rows(d_logits_, V, n, reinterpret_cast<const int *>(d_topk_adj_ + rows_off), kmax, reinterpret_cast<const TopkAdj *>(d_topk_adj_), topk_scratch_, h_topk_,
+                         stream_) != hipSuccess) { last_error = "top-k launch failed"; return -1; }
     if (hipStreamSynchronize(stream_) != hipSuccess || !mega_check() || !stream_check()) return -1;
-    for (int j = 0; j < k; j++) {
-        const unsigned long long key = h_topk_[j];
-        unsigned u = (unsigned)(key >> 32);
-        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;        // inverse of the order-preserving image
-        float f;
-        memcpy(&f, &u, 4);
-        toks[j] = (int32_t)(0xffffffffu - (unsigned)(key & 0xffffffffull));
-        logits[j] = f;
-    }
+    for (int r = 0; r < n; r++)
+        for (int j = 0; j < ks[r]; j++) {
+            const unsigned long long key = h_topk_[(size_t)r * TOPK_MAX_K + (size_t)j];
+            unsigned u = (unsigned)(key >> 32);
+            u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;        // inverse of the order-preserving image
+            float f;
+            memcpy(&f, &u, 4);
+            toks[(size_t)r * TOPK_MAX_K + (size_t)j] = (int32_t)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+            logits[(size_t)r * TOPK_MAX_K + (size_t)j] = f;
+        }
+    return n;
+}
+
+int Context::topk_ith(int i, int k, const TopkAdj &adj, int32_t *toks, float *logits) {
+    int32_t t[TOPK_MAX_K];
+    float l[TOPK_MAX_K];
+    if (topk_rows(1, &i, &k, &adj, t, l) != 1) return -1;
+    memcpy(toks, t, (size_t)k * sizeof(int32_t));
+    memcpy(logits, l, (size_t)k * sizeof(float));
     return k;
 }
 

@@ -114,9 +114,10 @@ class Context {
     // produced for the flagged tokens of the last decode while embeddings_enabled is set (then no logits are computed)
     float *embeddings_ith(int i);
     int32_t argmax_ith(int i);
-    // device-side sampling front end: the k best (token, logit) candidates of batch row i after the adjustments (kernels.h launch_topk_row), best
+    // device-side sampling front end: the k best (token, logit) candidates of batch row i after the adjustments (kernels.h launch_topk_rows), best
     // first; returns the count written (k) or < 0
     int topk_ith(int i, int k, const TopkAdj &adj, int32_t *toks, float *logits);
+    int topk_rows(int n, const int *is, const int *ks, const TopkAdj *adjs, int32_t *toks, float *logits);   // n rows at once; outputs [n][TOPK_MAX_K]
     void synchronize();
 
     void kv_clear();
@@ -231,7 +232,9 @@ class Context {
     bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
-    void *topk_scratch_ = nullptr;                     // launch_topk_row workspace (allocated on first use)
+    void *topk_scratch_ = nullptr;                     // launch_topk_rows workspace (own allocation, sized for topk_rows_cap_ rows on first use)
+    uint8_t *d_topk_adj_ = nullptr, *h_topk_adj_ = nullptr;   // [cap] TopkAdj + [cap] row numbers: device copy and its pinned staging
+    int topk_rows_cap_ = 0;
     unsigned long long *h_topk_ = nullptr;             // pinned: the winning keys
     Fuse pending_fuse_;
     int att_splits_ = 1;

@@ -697,32 +697,42 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
         std::vector<int32_t> ids(gen.size(), -1);
         std::vector<const float *> rows(gen.size(), nullptr);
         const int n_vocab_now = be_->n_vocab();
+        // device-side head of the chain (logit_bias -> penalties -> top_k): k candidates per slot cross instead of the row, all the
+        // tick's sampling slots in one request to the backend
+        std::vector<IBackend::TopkRequest> front;
+        std::vector<size_t> front_slot;
         for (size_t gi = 0; gi < gen.size(); gi++) {
             LlamaClientSlot &slot = *gen[gi];
             if (slot.smpl->is_plain_greedy()) {             // device-side greedy front end: no pass over the vocabulary on the host
                 ids[gi] = be_->argmax_ith(slot.i_batch - i);
                 if (ids[gi] >= 0) { slot.smpl->set_greedy_result(ids[gi]); continue; }
             }
-            // device-side head of the chain (logit_bias -> penalties -> top_k): k candidates cross instead of the row
             Sampler::FrontPlan fp;
             if (be_->topk_max_k() > 0 && slot.smpl->plan_front(n_vocab_now, be_->topk_max_k(), be_->topk_max_adj(), fp)) {
-                std::vector<int32_t> tk((size_t)fp.k);
-                std::vector<float> lg((size_t)fp.k);
+                IBackend::TopkRequest rq;
                 const SamplingParams &sp = slot.smpl->params();
-                if (be_->topk_ith(slot.i_batch - i, fp.k, fp.tok, fp.bias, fp.cnt, sp.penalty_repeat, sp.penalty_freq, sp.penalty_present, tk.data(), lg.data()) == fp.k) {
-                    std::vector<TokenProb> c((size_t)fp.k);
-                    for (int j = 0; j < fp.k; j++) c[(size_t)j] = TokenProb{tk[(size_t)j], lg[(size_t)j]};
-                    ids[gi] = slot.smpl->finish(c);
-                    if (ids[gi] >= 0 && slot.smpl->grammar_admits(ids[gi])) continue;
-                    if (ids[gi] >= 0) {                     // refused by the request's grammar: the whole row, masked to what the grammar admits
-                        const float *row = be_->logits_ith(slot.i_batch - i);
-                        ids[gi] = row ? slot.smpl->resample_with_grammar(row, n_vocab_now) : -1;
-                        if (ids[gi] >= 0) continue;
-                    }
-                }
+                rq.i = slot.i_batch - i; rq.k = fp.k; rq.tok = std::move(fp.tok); rq.bias = std::move(fp.bias); rq.cnt = std::move(fp.cnt);
+                rq.repeat = sp.penalty_repeat; rq.freq = sp.penalty_freq; rq.present = sp.penalty_present;
+                front.push_back(std::move(rq));
+                front_slot.push_back(gi);
             }
-            rows[gi] = be_->logits_ith(slot.i_batch - i);
         }
+        if (!front.empty()) be_->topk_batch(front);
+        for (size_t fi = 0; fi < front.size(); fi++) {
+            const size_t gi = front_slot[fi];
+            LlamaClientSlot &slot = *gen[gi];
+            const IBackend::TopkRequest &rq = front[fi];
+            if (!rq.ok) continue;
+            std::vector<TokenProb> c((size_t)rq.k);
+            for (int j = 0; j < rq.k; j++) c[(size_t)j] = TokenProb{rq.out_tok[(size_t)j], rq.out_logit[(size_t)j]};
+            ids[gi] = slot.smpl->finish(c);
+            if (ids[gi] >= 0 && !slot.smpl->grammar_admits(ids[gi])) {   // refused by the request's grammar: the whole row, masked to what the grammar admits
+                const float *row = be_->logits_ith(slot.i_batch - i);
+                ids[gi] = row ? slot.smpl->resample_with_grammar(row, n_vocab_now) : -1;
+            }
+        }
+        for (size_t gi = 0; gi < gen.size(); gi++)
+            if (ids[gi] < 0) rows[gi] = be_->logits_ith(gen[gi]->i_batch - i);
         const int n_vocab = be_->n_vocab();
         const std::function<void(int)> sample_one = [&](int gi) {
             if (ids[(size_t)gi] < 0 && rows[(size_t)gi]) ids[(size_t)gi] = gen[(size_t)gi]->smpl->sample(rows[(size_t)gi], n_vocab);

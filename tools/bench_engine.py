@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ctx-per-seq", type=int, default=1000)
     ap.add_argument("--config", default="llama-3-8b")
     ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--device-sampling", type=int, default=1, help="0: the whole sampler chain on the host over the whole logits row (load option device_sampling)")
     args = ap.parse_args()
     pkg = ge.load_pkg()
     gs = pkg.gguf_synth
@@ -31,7 +32,7 @@ def main():
     eng = pkg.Engine()
     t0 = time.time()
     st, body = eng.load_model(llama_model_path=path, ctx_len=args.ctx_per_seq * args.n_parallel, n_parallel=args.n_parallel, ngl=300,
-                              model_alias="bench", user_prompt="user: ", ai_prompt="assistant: ")
+                              model_alias="bench", user_prompt="user: ", ai_prompt="assistant: ", device_sampling=bool(args.device_sampling))
     assert st["status_code"] == 200, (st, body)
     print(f"load: {time.time() - t0:.1f} s", flush=True)
     extra = dict(temperature=0.0, repeat_penalty=1.0) if args.greedy else {}
@@ -54,7 +55,7 @@ def main():
     [t.start() for t in th]
     [t.join() for t in th]
     dt = time.time() - t0
-    print(f"users={args.users} rounds={args.rounds} n_parallel={args.n_parallel} max_tokens={args.max_tokens} greedy={args.greedy}: "
+    print(f"users={args.users} rounds={args.rounds} n_parallel={args.n_parallel} max_tokens={args.max_tokens} greedy={args.greedy} device_sampling={args.device_sampling}: "
           f"{done_tokens[0]} completion tokens (+{prompt_tokens[0]} prompt) in {dt:.2f} s = {done_tokens[0] / dt:.0f} tok/s aggregate")
     eng.close()
 
