@@ -1538,11 +1538,14 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         graph_exec_ = git == graphs_.end() ? nullptr : git->second;
         if (!graph_exec_) {
             hipGraph_t g = nullptr;
+            std::string inner;                                  // which launch refused, when one did (HIP_TRY's message)
             e = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
+                last_error.clear();
                 hipError_t e2 = run_layers(1, bucket > 0 ? bucket : std::min((int)cp.n_ctx, chunk_cap_ * 64));
                 if (e2 == hipSuccess) e2 = run_output(1, 0);
                 if (e2 == hipSuccess && cp.logits_to_host) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
+                if (e2 != hipSuccess) inner = last_error;
                 e = hipStreamEndCapture(stream_, &g);
                 if (e2 != hipSuccess) e = e2;
             }
@@ -1557,7 +1560,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
                 graph_exec_ = nullptr;
                 e = hipSuccess;
             } else {
-                if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e); return -1; }
+                if (e != hipSuccess) { last_error = std::string("graph capture failed: ") + hipGetErrorString(e) + (inner.empty() ? "" : " / " + inner); return -1; }
                 graphs_[bucket] = graph_exec_;
                 graph_is_mega_[graph_exec_] = last_layers_mega_;
                 graph_is_engine_[graph_exec_] = last_layers_engine_;

@@ -15,7 +15,10 @@
  * published ggml algorithm (block formats of ggml-common.h, scalar
  * ggml_vec_dot_* of ggml-cpu-quants.c, ops of ggml-cpu) from its specification
  *  and is pinned only by the closed-form known-answer
- * tests in tests/test_oracle_kat.py and an independent numpy twin.
+ * tests in tests/test_oracle_kat.py and an independent numpy twin; its answers
+ * of round 3 are frozen as fixtures under tests/golden/ (ops_v1.npz, e2e_v1.npz,
+ * written by tests/golden/make_golden_ops.py) so that a later drift of this
+ * file is visible (tests/test_golden_ops.py).
  */
 #ifndef ORACLE_H
 #define ORACLE_H
