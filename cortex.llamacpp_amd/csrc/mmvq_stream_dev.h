@@ -542,7 +542,12 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     };
     ST_ACC_DECL;
     ST_T0();
+#ifndef MI355_ST_TICKETS
+#define MI355_ST_TICKETS 0       // 1: the one-mat-vec-per-launch form takes its steps first-come too (the engine always does)
+#endif
+    int s_static = c;
     auto claim = [&]() {                                          // the next step of the mat-vec nobody has taken (>= n_steps: none left)
+        if (ENG == 0 && !MI355_ST_TICKETS) { const int t = s_static; s_static += ST_NC; return t; }   // a launch: consumer c takes steps c, c + 8, ...
         int t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(sy + SY_STEP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return uni(t) - io.step_base;
