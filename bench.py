@@ -53,15 +53,24 @@ def aggregate(n_gpus: int, steps: int, dt_max: float) -> dict:
     return {"value": round(n_gpus * steps / dt_max, 2), "ms_per_step": round(dt_max / steps * 1e3, 4)}
 
 
-def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch) -> dict:
+def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch, partial=None) -> dict:
     """Row split of the bench model over the ranks of this launch: the same prompt on every rank (they execute one
-    sequence together), prefill, warm-up, K timed single-token steps bracketed by barriers, MAX over ranks."""
+    sequence together), prefill, warm-up, K timed single-token steps bracketed by barriers, MAX over ranks.
+    Timed twice: every exchange through RCCL first (the result is stashed in `partial`, so the watchdog can still report it), then with the one-shot
+    peer-to-peer all-reduce kernel for the decode-sized exchanges unless --no-p2p; the better one is `decode_tok_s`."""
+    partial = {} if partial is None else partial
     pkg.binding.tp_init(rank, world, device=local_rank, transport="rccl")
     model = pkg.Model(path, main_gpu=local_rank, tp_rank=rank, tp_size=world)
-    ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
     prompt = np.random.default_rng(1234).integers(0, model.n_vocab, args.prompt)
+    holder = {}
+
+    def new_context():
+        if "ctx" in holder:
+            holder["ctx"].close()
+        holder["ctx"] = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
 
     def prefill():
+        ctx = holder["ctx"]
         ctx.kv_clear()
         t = time.perf_counter()
         for i0 in range(0, args.prompt, 2048):
@@ -71,16 +80,14 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch)
         return time.perf_counter() - t, tok
 
     def sync_all():
-        ctx.synchronize()
+        holder["ctx"].synchronize()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    prefill()
-    sync_all()
-
     def timed():
         """prefill, warm-up, K timed single-token steps; (seconds, prefill seconds, last token) with the MAX over ranks"""
+        ctx = holder["ctx"]
         t_pf, tok = prefill()
         pos = args.prompt
         for _ in range(args.warmup):
@@ -98,31 +105,54 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt[0].item()), float(tt[1].item()), tok
 
-    dt, t_prefill, tok = timed()
-    p2p_used = pkg.binding.tp_p2p_exchanges()
-    # the same steps with every exchange through RCCL (the peer-to-peer kernel switched off; a new context captures new graphs)
-    dt_rccl = tok_rccl = None
-    if p2p_used > 0:
-        pkg.Backend().set_option("tp_p2p", 0)
-        ctx.close()
-        ctx = pkg.Context(model, n_ctx=args.ctx, n_batch=2048, n_ubatch=N_UBATCH, type_k=KV, type_v=KV, flash_attn=True, use_graphs=True)
-        prefill()
-        sync_all()
-        dt_rccl, _, tok_rccl = timed()
-    toks = torch.tensor([tok], dtype=torch.int64, device=f"cuda:{local_rank}")
-    lo, hi = toks.clone(), toks.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    best = min(dt, dt_rccl) if dt_rccl else dt
-    res = {"parallelism": f"row split over {world} GPUs (attn_output / ffn_down partial sums all-reduced twice per layer: one-shot peer-to-peer kernel over "
-                          f"IPC-mapped buffers for the decode steps, RCCL for prompt batches; logits gathered)",
-           "scaling": "strong", "ranks": int(pkg.binding.load_library().mi355_tp_size()), "decode_tok_s": round(args.steps / best, 2),
-           "ms_per_step": round(best / args.steps * 1e3, 4),
-           "decode_tok_s_p2p": round(args.steps / dt, 2) if p2p_used > 0 else None, "p2p_exchanges": int(p2p_used),
-           "decode_tok_s_rccl": round(args.steps / (dt_rccl if dt_rccl else dt), 2),
-           "p2p_and_rccl_agree_on_last_token": (bool(tok == tok_rccl) if dt_rccl else None),
+    def agree(tok):
+        toks = torch.tensor([tok], dtype=torch.int64, device=f"cuda:{local_rank}")
+        lo, hi = toks.clone(), toks.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(int(lo.item()) == int(hi.item()))
+
+    # ---- every exchange through RCCL
+    new_context()
+    prefill()
+    sync_all()
+    dt_rccl, t_prefill, tok_rccl = timed()
+    res = {"parallelism": f"row split over {world} GPUs (attn_output / ffn_down partial sums all-reduced twice per layer through RCCL; logits gathered)",
+           "scaling": "strong", "ranks": int(pkg.binding.load_library().mi355_tp_size()), "decode_tok_s": round(args.steps / dt_rccl, 2),
+           "ms_per_step": round(dt_rccl / args.steps * 1e3, 4), "decode_tok_s_p2p": None, "p2p_exchanges": 0,
+           "decode_tok_s_rccl": round(args.steps / dt_rccl, 2), "p2p_and_rccl_agree_on_last_token": None,
            "prefill_tok_s": round(args.prompt / t_prefill, 1), "weight_bytes_per_token_per_gpu": int(model.bytes_per_token),
-           "ranks_agree_on_last_token": bool(int(lo.item()) == int(hi.item()))}
-    ctx.close(); model.close()
+           "ranks_agree_on_last_token": agree(tok_rccl)}
+    partial.update(res)
+    # ---- the decode-sized exchanges through the one-shot peer-to-peer kernel (IPC-mapped buffers).  Enabling is collective; every rank must succeed
+    if world > 1 and not args.no_p2p:
+        ok, why = 1, ""
+        try:
+            pkg.binding.tp_p2p_enable(rank, world, local_rank, 16384)
+        except Exception as e:  # noqa: BLE001 - reported in the record
+            ok, why = 0, f"{type(e).__name__}: {e}"[:200]
+        flag = torch.tensor([ok], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            partial["p2p_error"] = "the peer-to-peer phase did not finish"      # what the watchdog reports if this phase hangs
+            new_context()                                  # new graphs: the exchange is part of them
+            prefill()
+            sync_all()
+            dt_p2p, _, tok_p2p = timed()
+            used = int(pkg.binding.tp_p2p_exchanges())
+            res["decode_tok_s_p2p"] = round(args.steps / dt_p2p, 2)
+            res["p2p_exchanges"] = used
+            res["p2p_and_rccl_agree_on_last_token"] = bool(tok_p2p == tok_rccl)
+            res["ranks_agree_on_last_token"] = res["ranks_agree_on_last_token"] and agree(tok_p2p)
+            if used > 0 and dt_p2p < dt_rccl:
+                res["decode_tok_s"], res["ms_per_step"] = round(args.steps / dt_p2p, 2), round(dt_p2p / args.steps * 1e3, 4)
+                res["parallelism"] = (f"row split over {world} GPUs (attn_output / ffn_down partial sums all-reduced twice per layer: one-shot peer-to-peer kernel "
+                                      f"over IPC-mapped buffers for the decode steps, RCCL for prompt batches; logits gathered)")
+            partial.pop("p2p_error", None)
+        else:
+            pkg.Backend().set_option("tp_p2p", 0)
+            res["p2p_error"] = why or "another rank could not map its peers' buffers"
+        partial.update(res)
+    holder["ctx"].close(); model.close()
     pkg.binding.tp_shutdown()
     return res
 
@@ -276,9 +306,23 @@ def main() -> int:
         if dist is not None and not args.no_row_split:
             import threading
 
+            rs_partial = {}                                # what the section has measured so far (the RCCL timing comes first)
+
+            def split_headline(o, rs):
+                if args.config == "llama-3-70b" and "error" not in rs:
+                    # BASELINE config 5 is defined as the row split of ONE sequence over the GPUs: that is the headline of this config
+                    # (the replicas figure stays in the line as `replicas_value`)
+                    o["replicas_value"], o["replicas_ms_per_step"] = o["value"], o["ms_per_step"]
+                    o["value"], o["ms_per_step"], o["scaling"] = rs["decode_tok_s"], rs["ms_per_step"], "strong"
+                    o["config"]["parallelism"] = rs["parallelism"]
+
             def give_up():                                 # a rank stuck in a collective cannot be recovered in-process
                 if rank == 0 and out is not None:
-                    out["row_split"] = {"error": f"abandoned after {args.row_split_timeout:.0f} s"}
+                    if "decode_tok_s" in rs_partial:
+                        out["row_split"] = dict(rs_partial, p2p_error=f"abandoned after {args.row_split_timeout:.0f} s")
+                        split_headline(out, out["row_split"])
+                    else:
+                        out["row_split"] = {"error": f"abandoned after {args.row_split_timeout:.0f} s"}
                     print(json.dumps(out), flush=True)     # the replicas measurement is complete: keep the line
                 else:
                     print(f"[bench rank {rank}] row-split section abandoned after {args.row_split_timeout:.0f} s", file=sys.stderr, flush=True)
@@ -287,17 +331,12 @@ def main() -> int:
             wd.daemon = True
             wd.start()
             try:
-                rs = row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch)
+                rs = row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch, rs_partial)
             except Exception as e:  # noqa: BLE001 - reported in the line; the other ranks run into the watchdog
                 rs = {"error": f"{type(e).__name__}: {e}"[:300]}
             if rank == 0 and out is not None:
                 out["row_split"] = rs
-                if args.config == "llama-3-70b" and "error" not in rs:
-                    # BASELINE config 5 is defined as the row split of ONE sequence over the GPUs: that is the headline of this config
-                    # (the replicas figure stays in the line as `replicas_value`)
-                    out["replicas_value"], out["replicas_ms_per_step"] = out["value"], out["ms_per_step"]
-                    out["value"], out["ms_per_step"], out["scaling"] = rs["decode_tok_s"], rs["ms_per_step"], "strong"
-                    out["config"]["parallelism"] = rs["parallelism"]
+                split_headline(out, rs)
                 print(json.dumps(out), flush=True)
             if "error" in rs:                              # peers may be stuck: do not enter another collective
                 if rank != 0:
