@@ -9,6 +9,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
 Q2_K, Q3_K = 10, 11
+Q5_0, IQ4_NL = 6, 20
 
 
 class MI355Error(RuntimeError):
@@ -200,7 +201,7 @@ class Backend:
         y = np.zeros((T, N), np.float32)
         isum = msum = None
         if want_ints:
-            nblk = K // 32 if t == Q8_0 else K // 256
+            nblk = K // 32 if t in (Q8_0, Q4_0, Q5_0, IQ4_NL) else K // 256
             isum = np.zeros((T, N, nblk), np.int32)
             msum = np.zeros((T, N, nblk), np.int32)
         self._chk(self.lib.mi355_op_mul_mat(t, _ptr(W), N, K, _ptr(x), T, _ptr(y), _ptr(isum), _ptr(msum)), "op_mul_mat")

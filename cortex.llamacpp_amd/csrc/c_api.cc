@@ -346,9 +346,9 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
     if (!wsrc.up(W, grow * N) || !wdev.p || !dx.up(x, (size_t)K * T * 4) || !dy.p || !ab.ok()) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }
     hipError_t e = launch_repack_rows(type, wsrc.as<uint8_t>(), wdev.as<uint8_t>(), K, N, nullptr);
     if (e != hipSuccess) return hip_fail(e, "repack");
-    const bool quant = type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q8_0 || type == T_Q2_K || type == T_Q3_K;
+    const bool quant = type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q8_0 || type == T_Q2_K || type == T_Q3_K || type == T_Q4_0 || type == T_Q5_0 || type == T_IQ4_NL;
     if (quant) {
-        e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, type != T_Q8_0, type == T_Q8_0, nullptr);
+        e = launch_quantize(dx.as<float>(), (int)K, (int)T, ab.q, !act_is_q80(type), act_is_q80(type), nullptr);
         if (e != hipSuccess) return hip_fail(e, "quantize");
         if (mmq_q80_applicable(type, (int)K, (int)T)) {
             e = launch_mmq_q80(wdev.as<uint8_t>(), drow, (int)N, (int)K, (int)T, ab.q, dy.as<float>(), (int)N, nullptr, nullptr);
@@ -398,7 +398,7 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
             t0 += nt;
         }
         if (isum && msum) {
-            const int64_t nblk = type == T_Q8_0 ? K / 32 : K / 256;
+            const int64_t nblk = act_is_q80(type) ? K / 32 : K / 256;
             DevBuf di((size_t)N * nblk * 4), dm((size_t)N * nblk * 4);
             for (int64_t t = 0; t < T; t++) {
                 MMVQArgs a{};

@@ -12,20 +12,23 @@ constexpr int QK_K = 256;
 
 // ggml type ids (GGUF on-disk values)
 enum : int {
-    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15,
+    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q5_0 = 6, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20,
 };
 
 // ---- ggml on-disk block sizes ------------------------------------------------------------
 __host__ __device__ constexpr int ggml_block_elems(int t) {
-    return (t == T_F32 || t == T_F16) ? 1 : (t == T_Q4_0 || t == T_Q8_0) ? 32 : 256;
+    return (t == T_F32 || t == T_F16) ? 1 : (t == T_Q4_0 || t == T_Q5_0 || t == T_Q8_0 || t == T_IQ4_NL) ? 32 : 256;
 }
 __host__ __device__ constexpr int ggml_block_bytes(int t) {
     return t == T_F32 ? 4 : t == T_F16 ? 2 : t == T_Q4_0 ? 18 : t == T_Q8_0 ? 34 : t == T_Q4_K ? 144 :
-           t == T_Q5_K ? 176 : t == T_Q6_K ? 210 : t == T_Q8_K ? 292 : t == T_Q2_K ? 84 : t == T_Q3_K ? 110 : 0;
+           t == T_Q5_K ? 176 : t == T_Q6_K ? 210 : t == T_Q8_K ? 292 : t == T_Q2_K ? 84 : t == T_Q3_K ? 110 : t == T_Q5_0 ? 22 : t == T_IQ4_NL ? 18 : 0;
 }
 __host__ __device__ inline size_t ggml_row_bytes(int t, int64_t n) {
     return (size_t)(n / ggml_block_elems(t)) * (size_t)ggml_block_bytes(t);
 }
+
+// the CPU backend's activation format for a weight type: Q8_0 blocks for the 32-element formats, Q8_K for the K-quants
+__host__ __device__ constexpr bool act_is_q80(int t) { return t == T_Q8_0 || t == T_Q4_0 || t == T_Q5_0 || t == T_IQ4_NL; }
 
 // ---- device-resident weight row layouts --------------------------------------------------
 // Q4_K / Q5_K rows stay in ggml order (144 / 176 B super-blocks are 16-B aligned: header | [qh] | qs).
@@ -35,6 +38,8 @@ __host__ __device__ inline size_t ggml_row_bytes(int t, int64_t n) {
 //   Q8_0 row: [qs: K][d: K/32*2] padded to 16
 //   Q2_K row (84 B blocks: scales 16 | qs 64 | d | dmin):      [qs: nb*64][scales: nb*16][d, dmin: nb*4] padded to 16
 //   Q3_K row (110 B blocks: hmask 32 | qs 64 | scales 12 | d): [hmask: nb*32][qs: nb*64][scales: nb*12][d: nb*2] padded to 16
+//   Q4_0 / IQ4_NL row (18 B blocks: d | qs 16):              [qs: K/2][d: K/32*2] padded to 16
+//   Q5_0 row (22 B blocks: d | qh 4 | qs 16):                 [qs: K/2][qh: K/32*4][d: K/32*2] padded to 16
 // F16 / F32 rows are unchanged.
 __host__ __device__ inline size_t dev_row_bytes(int t, int64_t K) {
     size_t b = ggml_row_bytes(t, K);

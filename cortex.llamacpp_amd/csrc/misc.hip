@@ -46,8 +46,33 @@ __global__ void repack_q3k_kernel(const uint8_t *src, uint8_t *dst, int nb, size
     else if (i < 108) d[(size_t)nb * 96 + (size_t)sb * 12 + (i - 96)] = v;
     else d[(size_t)nb * 108 + (size_t)sb * 2 + (i - 108)] = v;
 }
+// 32-element blocks with a 16-byte nibble field: Q4_0 / IQ4_NL (d | qs) and Q5_0 (d | qh | qs) -> planes qs | [qh] | d
+__global__ void repack_nib32_kernel(const uint8_t *src, uint8_t *dst, int nblk, int K, size_t dst_row, int bsz) {
+    const int row = blockIdx.y;
+    const int b = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+    if (b >= nblk || j >= bsz) return;
+    const uint8_t v = src[((size_t)row * nblk + b) * bsz + j];
+    uint8_t *d = dst + (size_t)row * dst_row;
+    const size_t half = (size_t)K >> 1;
+    if (bsz == 18) {
+        if (j < 2) d[half + (size_t)b * 2 + j] = v; else d[(size_t)b * 16 + (j - 2)] = v;
+    } else {
+        if (j < 2) d[half + (size_t)nblk * 4 + (size_t)b * 2 + j] = v;
+        else if (j < 6) d[half + (size_t)b * 4 + (j - 2)] = v;
+        else d[(size_t)b * 16 + (j - 6)] = v;
+    }
+}
 hipError_t launch_repack_rows(int type, const uint8_t *src, uint8_t *dst, int64_t K, int64_t n_rows, hipStream_t st) {
     const size_t drow = dev_row_bytes(type, K);
+    if (type == T_Q4_0 || type == T_Q5_0 || type == T_IQ4_NL) {
+        const int nblk = (int)(K >> 5);
+        for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+            const int nr = (int)((n_rows - r0) < 65535 ? (n_rows - r0) : 65535);
+            hipLaunchKernelGGL(repack_nib32_kernel, dim3((nblk + 7) / 8, nr), dim3(256), 0, st,
+                               src + (size_t)r0 * ggml_row_bytes(type, K), dst + (size_t)r0 * drow, nblk, (int)K, drow, ggml_block_bytes(type));
+        }
+        return hipGetLastError();
+    }
     if (type == T_Q2_K || type == T_Q3_K) {
         for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
             const int nr = (int)((n_rows - r0) < 65535 ? (n_rows - r0) : 65535);

@@ -357,6 +357,80 @@ template <> struct Item<T_Q3_K> {
 };
 
 // ---- Q8_0 : device row planes [qs K][d K/32 f16] -------------------------------------------------
+// 32-element formats with a nibble field (Q4_0, Q5_0, IQ4_NL; activation Q8_0): two lanes per block as for Q8_0, lane half h = (e >> 4) & 1 takes
+// nibble h of the block's 16 code bytes (element j in the low nibbles, j + 16 in the high ones).  Integer sums exact:
+//   Q4_0:   sum (nib - 8) a      = dot(nib, a) - 8 sum a
+//   Q5_0:   sum (nib | b << 4 - 16) a = dot(nib + 16 b, a) - 16 sum a
+//   IQ4_NL: sum level[nib] a     (levels looked up with v_perm from the 16-byte code book)
+template <int TYPE> struct ItemNib32 {
+    uint4 hdr;
+    static constexpr int EPP = 1024;
+    uint4 q;          // the block's 16 code bytes
+    uint32_t qh;
+    float d;
+    int e;
+    bool valid;
+    __device__ __forceinline__ void load(const uint8_t *row, int K, int pass, int lane) {
+        e = pass * 1024 + lane * 16;
+        valid = e < K;
+        if (valid) {
+            const int b = e >> 5;
+            const size_t half = (size_t)K >> 1;
+            q = ld16w(row + (size_t)b * 16);
+            if (TYPE == T_Q5_0) {
+                qh = *reinterpret_cast<const uint32_t *>(row + half + (size_t)b * 4);
+                hdr.x = *reinterpret_cast<const uint16_t *>(row + half + (size_t)(K >> 5) * 4 + (size_t)b * 2);
+            } else {
+                hdr.x = *reinterpret_cast<const uint16_t *>(row + half + (size_t)b * 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void prep(int lane) {
+        if (valid) d = h2f((uint16_t)hdr.x);
+    }
+    static __device__ __forceinline__ uint32_t levels(uint32_t idx) {      // four IQ4_NL levels from four nibble indices (one per byte)
+        const uint32_t lo = __builtin_amdgcn_perm(0xf6eaddcfu, 0xbfad9881u, idx & 0x07070707u);
+        const uint32_t hi = __builtin_amdgcn_perm(0x71594535u, 0x26190d01u, idx & 0x07070707u);
+        const uint32_t m = ((idx >> 3) & 0x01010101u) * 0xffu;
+        return (hi & m) | (lo & ~m);
+    }
+    __device__ __forceinline__ void ints(const ActLds &A, int t, int lane, int &isum, int &msum) const {
+        int s = 0;
+        if (valid) {
+            const int h = (e >> 4) & 1;
+            const uint4 a = ld16(A.qs0 + (size_t)t * A.K + e);
+            const uint32_t qq[4] = {q.x, q.y, q.z, q.w}, aa[4] = {a.x, a.y, a.z, a.w};
+            int asum = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t v = (qq[w] >> (4 * h)) & 0x0f0f0f0fu;
+                if (TYPE == T_IQ4_NL) { s = dot4(levels(v), aa[w], s); continue; }
+                if (TYPE == T_Q5_0) {
+                    const uint32_t bits = (qh >> (16 * h + 4 * w)) & 0xfu;              // fifth bits of these four elements
+                    v |= ((bits * 0x00204081u) & 0x01010101u) << 4;
+                }
+                s = dot4(v, aa[w], s);                                                   // codes are 0 .. 31: the same as unsigned bytes
+                asum = dot4(0x01010101u, aa[w], asum);
+            }
+            if (TYPE == T_Q4_0) s -= 8 * asum;
+            if (TYPE == T_Q5_0) s -= 16 * asum;
+        }
+        isum = s + __shfl_xor(s, 1, 64);   // both halves of the 32-element block
+        msum = 0;
+    }
+    __device__ __forceinline__ float dot(const ActLds &A, int t, int lane) const {
+        int isum, msum;
+        ints(A, t, lane, isum, msum);     // shuffle executed by all lanes
+        if (!valid || (lane & 1)) return 0.0f;
+        const float da = h2f(A.d0[(size_t)t * (A.K >> 5) + (e >> 5)]);
+        if (TYPE == T_Q4_0) return ((float)isum * d) * da;          // ggml_vec_dot_q4_0_q8_0: sumi * d_x * d_y, left to right
+        return (d * da) * (float)isum;                              // q5_0 / iq4_nl: (d_x * d_y) * sumi
+    }
+};
+template <> struct Item<T_Q4_0> : ItemNib32<T_Q4_0> {};
+template <> struct Item<T_Q5_0> : ItemNib32<T_Q5_0> {};
+template <> struct Item<T_IQ4_NL> : ItemNib32<T_IQ4_NL> {};
+
 template <> struct Item<T_Q8_0> {
     uint4 hdr;
     static constexpr int EPP = 1024;
@@ -611,6 +685,9 @@ __global__ __launch_bounds__(BS) void mmvq_kernel(const MMVQArgs a) {
         case T_Q2_K: run_segment<T_Q2_K, NT, BS>(a, a.seg[s], smem, bis); break;
         case T_Q3_K: run_segment<T_Q3_K, NT, BS>(a, a.seg[s], smem, bis); break;
         case T_Q8_0: run_segment<T_Q8_0, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q4_0: run_segment<T_Q4_0, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_Q5_0: run_segment<T_Q5_0, NT, BS>(a, a.seg[s], smem, bis); break;
+        case T_IQ4_NL: run_segment<T_IQ4_NL, NT, BS>(a, a.seg[s], smem, bis); break;
         default: break;
     }
 }
@@ -662,7 +739,7 @@ __device__ __forceinline__ void run_tiled(const MMVQArgs &a, const MMVQSeg &sg, 
             if (have && ps + 1 < npass) { i2.load(ra, K, ps + 1, lane); if (hasb) i3.load(rbp, K, ps + 1, lane); else i3.valid = false; }
             else { i2.valid = false; i3.valid = false; }
             if (pp == 0) {                                 // stage this chunk's activations (all waves), loads already in flight
-                if (TYPE == T_Q8_0) {
+                if (act_is_q80(TYPE)) {
                     for (int i = tid; i < NT * (kc >> 4); i += 256) {
                         const int t = i / (kc >> 4), j = i - t * (kc >> 4);
                         reinterpret_cast<uint4 *>(qs + (size_t)t * kc)[j] = reinterpret_cast<const uint4 *>(a.aq0 + (size_t)t * K + k0)[j];
@@ -739,6 +816,9 @@ __global__ __launch_bounds__(256, 2) void mmvq_tiled_kernel(const MMVQArgs a) {
         case T_Q2_K: run_tiled<T_Q2_K, NT>(a, a.seg[s], smem, bis); break;
         case T_Q3_K: run_tiled<T_Q3_K, NT>(a, a.seg[s], smem, bis); break;
         case T_Q8_0: run_tiled<T_Q8_0, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q4_0: run_tiled<T_Q4_0, NT>(a, a.seg[s], smem, bis); break;
+        case T_Q5_0: run_tiled<T_Q5_0, NT>(a, a.seg[s], smem, bis); break;
+        case T_IQ4_NL: run_tiled<T_IQ4_NL, NT>(a, a.seg[s], smem, bis); break;
         default: break;
     }
 }
@@ -801,14 +881,14 @@ hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     }
     a.need_q8k = 0; a.need_q80 = 0;
     for (int s = 0; s < a.n_seg; s++) {
-        if (a.seg[s].type == T_Q8_0) a.need_q80 = 1; else a.need_q8k = 1;
+        if (act_is_q80(a.seg[s].type)) a.need_q80 = 1; else a.need_q8k = 1;
     }
     if (a.epi == EPI_SWIGLU && (a.n_seg != 2 || a.seg[0].type != a.seg[1].type)) return hipErrorInvalidValue;
     const int n_work_seg = a.epi == EPI_SWIGLU ? 1 : a.n_seg;
     // chunks of 2 passes per row; the pass size is the same for every K-quant (2048), 1024 for Q8_0
     int nchunk = 1;
     for (int s = 0; s < n_work_seg; s++) {
-        const int epp = a.seg[s].type == T_Q8_0 ? 1024 : 2048;
+        const int epp = act_is_q80(a.seg[s].type) ? 1024 : 2048;
         const int npass = (a.K + epp - 1) / epp;
         nchunk = ((npass + 1) >> 1) > nchunk ? ((npass + 1) >> 1) : nchunk;
     }
@@ -860,7 +940,7 @@ __global__ __launch_bounds__(256) void mmvq_ints_kernel(const MMVQArgs a, int32_
     const int nw = gridDim.x * (blockDim.x >> 6);
     const int K = a.K;
     const MMVQSeg &sg = a.seg[0];
-    const int nblk = TYPE == T_Q8_0 ? (K >> 5) : (K >> 8);
+    const int nblk = act_is_q80(TYPE) ? (K >> 5) : (K >> 8);
     const int npass = (K + It::EPP - 1) / It::EPP;
     for (int r = gw; r < sg.n_rows; r += nw) {
         const uint8_t *row = sg.W + (size_t)r * sg.row_bytes;
@@ -869,7 +949,7 @@ __global__ __launch_bounds__(256) void mmvq_ints_kernel(const MMVQArgs a, int32_
             it.load(row, K, p, lane);
             it.prep(lane);
             int is = 0, ms = 0;
-            if constexpr (TYPE == T_Q8_0) {
+            if constexpr (act_is_q80(TYPE)) {
                 it.ints(A, 0, lane, is, ms);
                 if (it.valid && !(lane & 1)) { isum_out[(size_t)r * nblk + (it.e >> 5)] = is; msum_out[(size_t)r * nblk + (it.e >> 5)] = 0; }
             } else {
@@ -885,8 +965,8 @@ __global__ __launch_bounds__(256) void mmvq_ints_kernel(const MMVQArgs a, int32_
 }
 
 hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_t st) {
-    a.need_q8k = a.seg[0].type != T_Q8_0;
-    a.need_q80 = a.seg[0].type == T_Q8_0;
+    a.need_q8k = !act_is_q80(a.seg[0].type);
+    a.need_q80 = act_is_q80(a.seg[0].type);
     const size_t lds = mmvq_lds_bytes(a, 1);
     const int blocks = 64;
     switch (a.seg[0].type) {
@@ -896,6 +976,9 @@ hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_
         case T_Q2_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q2_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         case T_Q3_K: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q3_K>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         case T_Q8_0: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q8_0>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
+        case T_Q4_0: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q4_0>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
+        case T_Q5_0: hipLaunchKernelGGL(mmvq_ints_kernel<T_Q5_0>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
+        case T_IQ4_NL: hipLaunchKernelGGL(mmvq_ints_kernel<T_IQ4_NL>, dim3(blocks), dim3(256), lds, st, a, isum, msum); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

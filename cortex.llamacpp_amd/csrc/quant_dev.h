@@ -58,6 +58,13 @@ __device__ __forceinline__ void k4_scale_min(int j, const uint8_t *p, int &sc, i
     else { sc = (p[j + 4] & 0x0f) | ((p[j - 4] >> 6) << 4); mn = (p[j + 4] >> 4) | ((p[j] >> 6) << 4); }
 }
 
+// IQ4_NL's code book (ggml-common.h kvalues_iq4nl): sixteen int8 levels, denser around zero
+__device__ __forceinline__ int iq4nl_value(int nib) {
+    // packed little-endian: levels 0-3, 4-7, 8-11, 12-15
+    const uint32_t w = nib < 8 ? (nib < 4 ? 0xbfad9881u : 0xf6eaddcfu) : (nib < 12 ? 0x26190d01u : 0x71594535u);
+    return (int)(int8_t)((w >> (8 * (nib & 3))) & 0xffu);
+}
+
 __device__ __forceinline__ float dequant_elem(int type, const uint8_t *row, int K, int e) {
     switch (type) {
         case T_F32: return reinterpret_cast<const float *>(row)[e];
@@ -65,6 +72,19 @@ __device__ __forceinline__ float dequant_elem(int type, const uint8_t *row, int 
         case T_Q8_0: {
             const float d = h2f(*reinterpret_cast<const uint16_t *>(row + K + (e >> 5) * 2));
             return __fmul_rn((float)(int8_t)row[e], d);
+        }
+        case T_Q4_0: case T_IQ4_NL: case T_Q5_0: {   // element r of block b: nibble r / 16 of qs[16 b + r % 16]; Q5_0: bit r of qh is the fifth bit
+            const int b = e >> 5, r = e & 31, nblk = K >> 5;
+            const int nib = (row[(size_t)b * 16 + (r & 15)] >> (4 * (r >> 4))) & 0x0f;
+            const size_t half = (size_t)K >> 1;
+            if (type == T_Q5_0) {
+                const uint32_t qh = *reinterpret_cast<const uint32_t *>(row + half + (size_t)b * 4);
+                const float d = h2f(*reinterpret_cast<const uint16_t *>(row + half + (size_t)nblk * 4 + (size_t)b * 2));
+                return __fmul_rn((float)((nib | (int)(((qh >> r) & 1u) << 4)) - 16), d);
+            }
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + half + (size_t)b * 2));
+            if (type == T_Q4_0) return __fmul_rn((float)(nib - 8), d);
+            return __fmul_rn(d, (float)iq4nl_value(nib));
         }
         case T_Q4_K: case T_Q5_K: {
             const int bsz = type == T_Q4_K ? 144 : 176;

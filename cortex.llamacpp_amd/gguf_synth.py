@@ -18,9 +18,10 @@ import numpy as np
 # ggml type ids
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 0, 1, 2, 8, 12, 13, 14
 Q2_K, Q3_K = 10, 11
-TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q2_K: "q2_K", Q3_K: "q3_K"}
-BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q2_K: 256, Q3_K: 256}
-BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q2_K: 84, Q3_K: 110}
+Q5_0, IQ4_NL = 6, 20
+TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q2_K: "q2_K", Q3_K: "q3_K", Q5_0: "q5_0", IQ4_NL: "iq4_nl"}
+BLOCK_ELEMS = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q2_K: 256, Q3_K: 256, Q5_0: 32, IQ4_NL: 32}
+BLOCK_BYTES = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q2_K: 84, Q3_K: 110, Q5_0: 22, IQ4_NL: 18}
 
 DT_Q4_0 = np.dtype([("d", "<f2"), ("qs", "u1", 16)])
 DT_Q8_0 = np.dtype([("d", "<f2"), ("qs", "i1", 32)])
@@ -29,13 +30,14 @@ DT_Q5_K = np.dtype([("d", "<f2"), ("dmin", "<f2"), ("scales", "u1", 12), ("qh", 
 DT_Q6_K = np.dtype([("ql", "u1", 128), ("qh", "u1", 64), ("scales", "i1", 16), ("d", "<f2")])
 DT_Q2_K = np.dtype([("scales", "u1", 16), ("qs", "u1", 64), ("d", "<f2"), ("dmin", "<f2")])
 DT_Q3_K = np.dtype([("hmask", "u1", 32), ("qs", "u1", 64), ("scales", "u1", 12), ("d", "<f2")])
-BLOCK_DTYPE = {Q4_0: DT_Q4_0, Q8_0: DT_Q8_0, Q4_K: DT_Q4_K, Q5_K: DT_Q5_K, Q6_K: DT_Q6_K, Q2_K: DT_Q2_K, Q3_K: DT_Q3_K}
+DT_Q5_0 = np.dtype([("d", "<f2"), ("qh", "u1", 4), ("qs", "u1", 16)])
+BLOCK_DTYPE = {Q4_0: DT_Q4_0, Q8_0: DT_Q8_0, Q4_K: DT_Q4_K, Q5_K: DT_Q5_K, Q6_K: DT_Q6_K, Q2_K: DT_Q2_K, Q3_K: DT_Q3_K, Q5_0: DT_Q5_0, IQ4_NL: DT_Q4_0}
 for _t, _dt in BLOCK_DTYPE.items():
     assert _dt.itemsize == BLOCK_BYTES[_t], (_t, _dt.itemsize)
 
 # std of (dequantised weight / d) for uniformly random block payloads (derived in DESIGN.md)
 # (Q2_K: w / d = sc * q - r * m with sc, m uniform 0..15, q uniform 0..3, r = 1.5: variance 144.7 + 2.25 * 21.25; Q3_K: (sc - 32) * q, sc 0..63, q -4..3)
-_UNIT_STD = {Q4_0: 4.6, Q8_0: 73.9, Q4_K: 258.0, Q5_K: 527.0, Q6_K: 1367.0, Q2_K: 13.9, Q3_K: 43.3}
+_UNIT_STD = {Q4_0: 4.6, Q8_0: 73.9, Q4_K: 258.0, Q5_K: 527.0, Q6_K: 1367.0, Q2_K: 13.9, Q3_K: 43.3, Q5_0: 9.23, IQ4_NL: 67.2}   # (Q5_0: codes 0..31 minus 16; IQ4_NL: the sixteen code-book levels)
 # dmin/d ratio that centres the weights of a random block on zero
 _DMIN_RATIO = {Q4_K: 7.5, Q5_K: 15.5, Q2_K: 1.5}
 
@@ -177,7 +179,7 @@ CONFIGS = {
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 
-FTYPE_ID = {"f16": 1, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17, "q2_k": 10, "q3_k_s": 11, "q3_k_m": 12, "q3_k_l": 13, "q4_k_s": 14, "q5_k_s": 16, "q6_k": 18}
+FTYPE_ID = {"f16": 1, "q4_0": 2, "q5_0": 8, "iq4_nl": 25, "q8_0": 7, "q4_k_m": 15, "q5_k_m": 17, "q2_k": 10, "q3_k_s": 11, "q3_k_m": 12, "q3_k_l": 13, "q4_k_s": 14, "q5_k_s": 16, "q6_k": 18}
 
 
 def use_more_bits(i: int, n: int) -> bool:
@@ -206,6 +208,14 @@ def tensor_type(cfg: LlamaConfig, ftype: str, kind: str, il: int) -> int:
         if kind == "attn_output":
             return Q3_K if q2 else Q4_K
         return Q2_K if q2 else Q3_K
+    if ftype in ("q4_0", "q5_0", "iq4_nl"):
+        # the 32-element formats (llama-quantize's legacy types and the fallbacks it takes for rows that are not a multiple of 256): output Q6_K;
+        # IQ4_NL promotes attn_v (grouped-query models) and the first eighth of ffn_down to Q5_K, as upstream does for IQ4_NL / IQ4_XS
+        if kind == "output":
+            return Q6_K
+        if ftype == "iq4_nl" and ((kind == "attn_v" and cfg.n_head // cfg.n_head_kv >= 4) or (kind == "ffn_down" and il < max(1, cfg.n_layer // 8))):
+            return Q5_K
+        return {"q4_0": Q4_0, "q5_0": Q5_0, "iq4_nl": IQ4_NL}[ftype]
     if ftype in ("q3_k_s", "q3_k_l", "q4_k_s", "q5_k_s", "q6_k"):
         # the other mixes the reference publishes (.github/workflows/convert-model-all-quant.yml:106-152), by llama-quantize's rules for the llama
         # architecture: output Q6_K everywhere; Q3_K_S: everything else Q3_K; Q3_K_L: attn_v, ffn_down, attn_output Q5_K, the rest Q3_K; Q4_K_S: Q4_K

@@ -40,7 +40,7 @@ Model::~Model() {
 }
 
 static bool type_supported(int t) {
-    return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q2_K || t == T_Q3_K;
+    return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q2_K || t == T_Q3_K || t == T_Q4_0 || t == T_Q5_0 || t == T_IQ4_NL;
 }
 
 Model *model_load(const std::string &path, int main_gpu, std::string &err, int &status, int prefill_planes, int tp_rank, int tp_size) {
@@ -149,7 +149,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         dst.ggml_bytes = pl.src_bytes;
         plan.push_back(pl);
         total += (dst.bytes + 255) & ~(size_t)255;
-        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.type == T_Q2_K || dst.type == T_Q3_K || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, pl.src_bytes);
+        if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.type == T_Q2_K || dst.type == T_Q3_K || dst.type == T_Q4_0 || dst.type == T_Q5_0 || dst.type == T_IQ4_NL || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, pl.src_bytes);
     };
     want("token_embd.weight", m->tok_embd, true);
     want("output_norm.weight", m->out_norm, true);
@@ -246,7 +246,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     for (const Plan &pl : plan) {
         DevTensor &d = *pl.dst;
         d.data = arena + pl.off;
-        const bool direct = !(d.type == T_Q6_K || d.type == T_Q8_0 || d.type == T_Q2_K || d.type == T_Q3_K) && (pl.ti->n_dims == 1 || d.row_bytes == ggml_row_bytes(d.type, d.K));
+        const bool direct = !(d.type == T_Q6_K || d.type == T_Q8_0 || d.type == T_Q2_K || d.type == T_Q3_K || d.type == T_Q4_0 || d.type == T_Q5_0 || d.type == T_IQ4_NL) && (pl.ti->n_dims == 1 || d.row_bytes == ggml_row_bytes(d.type, d.K));
         hipError_t e;
         const uint8_t *src = (const uint8_t *)pl.ti->data + pl.src_off;
         uint8_t *to = direct ? d.data : stage;
@@ -721,7 +721,7 @@ void Context::prof_end() {
 }
 
 // ------------------------------------------------------------------------------------------ linear layers
-static bool is_quant(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0 || t == T_Q2_K || t == T_Q3_K; }
+static bool is_quant(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0 || t == T_Q2_K || t == T_Q3_K || t == T_Q4_0 || t == T_Q5_0 || t == T_IQ4_NL; }
 
 static MMVQSeg make_seg(const DevTensor &w, float *out, int ld_out, const float *resid, const int32_t *esel) {
     MMVQSeg s{};
@@ -987,7 +987,7 @@ bool Context::engine_prepare() {
     for (int il = 0; il < hp.n_layer; il++) {
         const LayerWeights &L = model->layers[(size_t)il];
         if (L.bq.valid() || L.bk.valid() || L.bv.valid()) return false;
-        if (!is_quant(L.wo.type) || L.wo.type == T_Q8_0) return false;
+        if (!is_quant(L.wo.type) || act_is_q80(L.wo.type)) return false;
         EngineLayer &m = el[(size_t)il];
         auto base = [&](MMVQArgs &a, int n_seg, int K, int epi, int fuse, const float *nx, const float *nw, const ActQuant &aq) {
             a = MMVQArgs{};
@@ -1056,7 +1056,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         ma.cell_pos = d_cell_pos_; ma.cell_seq = d_cell_seq_; ma.tok_pos = d_pos_; ma.tok_seq = d_seq_;
         ma.n_kv_dev = d_nkv_; ma.n_kv_max = n_kv_max; ma.scale = kq_scale; ma.part = att_part_;
         const DevTensor &wo0 = model->layers[0].wo;
-        ma.out_q = &aq_o_; ma.out_q8k = wo0.type != T_Q8_0; ma.out_q80 = false;
+        ma.out_q = &aq_o_; ma.out_q8k = !act_is_q80(wo0.type); ma.out_q80 = false;
         ma.splits = flash_attn_decode_splits(n_kv_max);
         if (chunk_lmax_ > 0) {
             ma.tok_chunks = d_chunks_; ma.tok_nchunks = d_chunks_ + (size_t)64 * chunk_stride_; ma.chunk_stride = chunk_stride_;
@@ -1081,8 +1081,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         const LayerWeights &L = model->layers[(size_t)il];
         // --- attention block
         const bool any_f = !is_quant(L.wq.type) || !is_quant(L.wk.type) || !is_quant(L.wv.type);
-        const bool need_k = is_quant(L.wq.type) && L.wq.type != T_Q8_0 || is_quant(L.wk.type) && L.wk.type != T_Q8_0 || is_quant(L.wv.type) && L.wv.type != T_Q8_0;
-        const bool need_0 = L.wq.type == T_Q8_0 || L.wk.type == T_Q8_0 || L.wv.type == T_Q8_0;
+        const bool need_k = is_quant(L.wq.type) && !act_is_q80(L.wq.type) || is_quant(L.wk.type) && !act_is_q80(L.wk.type) || is_quant(L.wv.type) && !act_is_q80(L.wv.type);
+        const bool need_0 = act_is_q80(L.wq.type) || act_is_q80(L.wk.type) || act_is_q80(L.wv.type);
         const bool fuse_attn = !any_f && can_fuse(E, T);
         if (engine && il > 0) {
             // Q | K | V of this layer were computed at the end of the previous layer's engine launch
@@ -1112,7 +1112,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         aa.cell_pos = d_cell_pos_; aa.cell_seq = d_cell_seq_; aa.tok_pos = d_pos_; aa.tok_seq = d_seq_;
         aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_;
         const bool o_q = is_quant(L.wo.type);
-        aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = L.wo.type != T_Q8_0; aa.out_q80 = L.wo.type == T_Q8_0;   // merged + quantised in one pass
+        aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = !act_is_q80(L.wo.type); aa.out_q80 = act_is_q80(L.wo.type);   // merged + quantised in one pass
         const bool o_pl = o_q && aa.out_q8k && T >= 3;         // the batched kernels will want the block-sum planes: the merge writes them too
         if (o_pl) { aa.out_bh = mmq_bh_; aa.out_bl = mmq_bl_; }
         if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
@@ -1167,7 +1167,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         // --- feed-forward block
         if (hp.n_expert > 0) {
             HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.ffn_norm.data, E, T, hp.eps, xn_, &aq_e_,
-                                         L.gate_exps.type != T_Q8_0 || L.up_exps.type != T_Q8_0, L.gate_exps.type == T_Q8_0 || L.up_exps.type == T_Q8_0, stream_));
+                                         !act_is_q80(L.gate_exps.type) || !act_is_q80(L.up_exps.type), act_is_q80(L.gate_exps.type) || act_is_q80(L.up_exps.type), stream_));
             prep_owner_ = nullptr;
             prof_mark("norm_quant");
             if (L.gate_inp.type == T_F32 || L.gate_inp.type == T_F16) {
@@ -1204,7 +1204,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 };
                 // the block-sum planes of ALL grouped rows in one launch (they were one launch per expert and projection: 16 a layer);
                 // an expert's batch takes its slice of them
-                const bool pl_gu = L.gate_exps.type != T_Q8_0 || L.up_exps.type != T_Q8_0, pl_d = L.down_exps.type != T_Q8_0;
+                const bool pl_gu = !act_is_q80(L.gate_exps.type) || !act_is_q80(L.up_exps.type), pl_d = !act_is_q80(L.down_exps.type);
                 if (pl_gu) HIP_TRY(launch_mmq_prep(aq_eg_, E, GR, mmq_bh_, mmq_bl_, stream_));
                 hipError_t e_exp = hipSuccess;
                 for (int e = 0; e < NE && e_exp == hipSuccess; e++) {
@@ -1216,7 +1216,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 }
                 bh_over_ = bl_over_ = nullptr;
                 HIP_TRY(e_exp);
-                HIP_TRY(launch_swiglu_quant(ffn_g_, ffn_ug_, FF, GR, aq_ffg_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_,
+                HIP_TRY(launch_swiglu_quant(ffn_g_, ffn_ug_, FF, GR, aq_ffg_, !act_is_q80(L.down_exps.type), act_is_q80(L.down_exps.type), stream_,
                                             pl_d ? mmq_bh_ : nullptr, pl_d ? mmq_bl_ : nullptr));
                 prep_owner_ = nullptr;
                 for (int e = 0; e < NE && e_exp == hipSuccess; e++) {
@@ -1272,7 +1272,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     const int kbf = (FF + 2047) / 2048;
                     const bool fuse_q = (L.down_exps.type == T_Q4_K || L.down_exps.type == T_Q5_K || L.down_exps.type == T_Q6_K) && (FF % 256) == 0 &&
                                         (kbf == 1 || kbf == 2 || kbf == 3 || kbf == 4 || kbf == 6 || kbf == 7 || kbf == 14);
-                    if (!fuse_q) { HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, L.down_exps.type != T_Q8_0, L.down_exps.type == T_Q8_0, stream_)); prep_owner_ = nullptr; }
+                    if (!fuse_q) { HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, !act_is_q80(L.down_exps.type), act_is_q80(L.down_exps.type), stream_)); prep_owner_ = nullptr; }
                     MMVQArgs d{};
                     d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE;
                     if (fuse_q) { d.fuse_mode = 2; d.nx = ffn_ + (size_t)t * FF; }
@@ -1285,8 +1285,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             prof_mark("moe_ffn");
         } else {
             const bool gq = is_quant(L.gate.type), uq = is_quant(L.up.type);
-            const bool fk = (gq && L.gate.type != T_Q8_0) || (uq && L.up.type != T_Q8_0);
-            const bool f0 = L.gate.type == T_Q8_0 || L.up.type == T_Q8_0;
+            const bool fk = (gq && !act_is_q80(L.gate.type)) || (uq && !act_is_q80(L.up.type));
+            const bool f0 = act_is_q80(L.gate.type) || act_is_q80(L.up.type);
             const bool fuse_ffn = gq && uq && L.gate.type == L.up.type && can_fuse(E, T);
             Fuse fz;
             if (fuse_ffn) {
@@ -1316,8 +1316,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(launch_mmq_ksplit_multi(sg, 2, E, T, aq_e_, mmq_bh_, mmq_bl_, pair, stream_));
                 if (!pair) {
                     if (is_quant(L.down.type) && (FF % 256) == 0) {
-                        const bool pl = L.down.type != T_Q8_0;
-                        HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_,
+                        const bool pl = !act_is_q80(L.down.type);
+                        HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, !act_is_q80(L.down.type), act_is_q80(L.down.type), stream_,
                                                     pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
                         prep_owner_ = nullptr;
                         if (pl) prep_written(aq_ff_, FF, T);
@@ -1332,8 +1332,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 // f32 result of T x FF instead of two); the quantiser for the down projection then reads half as much
                 HIP_TRY(launch_mmq_planes_swiglu(L.gate.type, L.gate.planes, L.up.planes, (int)L.gate.N, E, T, aq_e_, ffn_, FF, stream_));
                 if (is_quant(L.down.type) && (FF % 256) == 0) {
-                    const bool pl = L.down.type != T_Q8_0 && T >= 3;
-                    HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_, pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+                    const bool pl = !act_is_q80(L.down.type) && T >= 3;
+                    HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, !act_is_q80(L.down.type), act_is_q80(L.down.type), stream_, pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
                     prep_owner_ = nullptr;
                     if (pl) prep_written(aq_ff_, FF, T);
                     swiglu_quantised = true;
@@ -1343,8 +1343,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
                 // prompt batch: SwiGLU and the quantisation for the down projection in one pass (no f32 round trip of T x FF)
                 if (T > 1 && is_quant(L.down.type) && (FF % 256) == 0) {
-                    const bool pl = L.down.type != T_Q8_0 && T >= 3;
-                    HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_,
+                    const bool pl = !act_is_q80(L.down.type) && T >= 3;
+                    HIP_TRY(launch_swiglu_quant(ffn_, ffn_u_, FF, T, aq_ff_, !act_is_q80(L.down.type), act_is_q80(L.down.type), stream_,
                                                 pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
                     prep_owner_ = nullptr;
                     if (pl) prep_written(aq_ff_, FF, T);
@@ -1363,7 +1363,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
             } else if (is_quant(L.down.type) && !swiglu_quantised) {
-                HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, L.down.type != T_Q8_0, L.down.type == T_Q8_0, stream_));
+                HIP_TRY(launch_quantize(ffn_, FF, T, aq_ff_, !act_is_q80(L.down.type), act_is_q80(L.down.type), stream_));
                 prep_owner_ = nullptr;
                 prof_mark("quant");
             }
@@ -1405,7 +1405,7 @@ hipError_t Context::run_output(int n_out, int out_base) {
     } else {
         prep_owner_ = nullptr;
         HIP_TRY(launch_rmsnorm_quant(xo, (const float *)model->out_norm.data, E, n_out, hp.eps, oq ? nullptr : xn_, &aq_e_,
-                                     oq && model->output.type != T_Q8_0, model->output.type == T_Q8_0, stream_));
+                                     oq && !act_is_q80(model->output.type), act_is_q80(model->output.type), stream_));
         prof_mark("norm_quant");
     }
     float *lg = d_logits_ + (size_t)out_base * V;

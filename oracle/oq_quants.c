@@ -87,7 +87,7 @@ typedef struct { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t
 int oq_block_elems(int type) {
     switch (type) {
         case OQ_TYPE_F32: case OQ_TYPE_F16: return 1;
-        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: case OQ_TYPE_Q5_0: return 32;
+        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: case OQ_TYPE_Q5_0: case OQ_TYPE_IQ4_NL: return 32;
         case OQ_TYPE_Q4_K: case OQ_TYPE_Q5_K: case OQ_TYPE_Q6_K: case OQ_TYPE_Q8_K: case OQ_TYPE_Q2_K: case OQ_TYPE_Q3_K: return 256;
     }
     return 0;
@@ -96,7 +96,7 @@ size_t oq_block_bytes(int type) {
     switch (type) {
         case OQ_TYPE_F32: return 4;
         case OQ_TYPE_F16: return 2;
-        case OQ_TYPE_Q4_0: return sizeof(blk_q4_0);
+        case OQ_TYPE_Q4_0: case OQ_TYPE_IQ4_NL: return sizeof(blk_q4_0);   /* IQ4_NL: the same 18 bytes, the nibbles index a code book */
         case OQ_TYPE_Q8_0: return sizeof(blk_q8_0);
         case OQ_TYPE_Q4_K: return sizeof(blk_q4_K);
         case OQ_TYPE_Q5_K: return sizeof(blk_q5_K);
@@ -195,6 +195,17 @@ static void deq_q6_K(const blk_q6_K *b, float *y, int64_t nb) {
         }
     }
 }
+/* upstream: kvalues_iq4nl (ggml-common.h) and dequantize_row_iq4_nl: y = d * level[nibble]; low nibbles are elements 0..15, high ones 16..31 */
+static const int8_t iq4nl_levels[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+static void deq_iq4_nl(const blk_q4_0 *b, float *y, int64_t nb) {
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = oq_fp16_to_fp32(b[i].d);
+        for (int j = 0; j < 16; j++) {
+            y[i * 32 + j]      = d * (float)iq4nl_levels[b[i].qs[j] & 0x0f];
+            y[i * 32 + j + 16] = d * (float)iq4nl_levels[b[i].qs[j] >> 4];
+        }
+    }
+}
 /* upstream: dequantize_row_q5_0 - 16 low nibbles then 16 high nibbles, bit j / j + 16 of qh is the fifth bit, offset 16 */
 static void deq_q5_0(const blk_q5_0 *b, float *y, int64_t nb) {
     for (int64_t i = 0; i < nb; i++) {
@@ -280,6 +291,7 @@ void oq_dequantize_row(int type, const void *src, float *dst, int64_t n) {
         case OQ_TYPE_Q6_K: deq_q6_K((const blk_q6_K *)src, dst, n / 256); break;
         case OQ_TYPE_Q8_K: deq_q8_K((const blk_q8_K *)src, dst, n / 256); break;
         case OQ_TYPE_Q5_0: deq_q5_0((const blk_q5_0 *)src, dst, n / 32); break;
+        case OQ_TYPE_IQ4_NL: deq_iq4_nl((const blk_q4_0 *)src, dst, n / 32); break;
         case OQ_TYPE_Q2_K: deq_q2_K((const blk_q2_K *)src, dst, n / 256); break;
         case OQ_TYPE_Q3_K: deq_q3_K((const blk_q3_K *)src, dst, n / 256); break;
         default: abort();
@@ -371,7 +383,7 @@ int oq_vec_dot_type(int type) {
     switch (type) {
         case OQ_TYPE_F32: return OQ_TYPE_F32;
         case OQ_TYPE_F16: return OQ_TYPE_F16;
-        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: case OQ_TYPE_Q5_0: return OQ_TYPE_Q8_0;
+        case OQ_TYPE_Q4_0: case OQ_TYPE_Q8_0: case OQ_TYPE_Q5_0: case OQ_TYPE_IQ4_NL: return OQ_TYPE_Q8_0;
         case OQ_TYPE_Q4_K: case OQ_TYPE_Q5_K: case OQ_TYPE_Q6_K: case OQ_TYPE_Q2_K: case OQ_TYPE_Q3_K: return OQ_TYPE_Q8_K;
     }
     return -1;
@@ -522,6 +534,31 @@ static float dot_q4_0(int64_t n, const blk_q4_0 *x, const blk_q8_0 *y) {
     }
     return s;
 }
+static int32_t q4_0_block(const blk_q4_0 *x, const blk_q8_0 *y) {
+    int32_t si = 0;
+    for (int j = 0; j < 16; j++) {
+        si += ((int)(x->qs[j] & 0x0f) - 8) * y->qs[j];
+        si += ((int)(x->qs[j] >> 4) - 8) * y->qs[j + 16];
+    }
+    return si;
+}
+/* upstream scalar ggml_vec_dot_iq4_nl_q8_0: d = d_y * d_x; sumi1 over the low nibbles, sumi2 over the high ones; sumf += d * (sumi1 + sumi2) */
+static int32_t iq4_nl_block(const blk_q4_0 *x, const blk_q8_0 *y) {
+    int32_t s1 = 0, s2 = 0;
+    for (int j = 0; j < 16; j++) {
+        s1 += y->qs[j] * iq4nl_levels[x->qs[j] & 0x0f];
+        s2 += y->qs[j + 16] * iq4nl_levels[x->qs[j] >> 4];
+    }
+    return s1 + s2;
+}
+static float dot_iq4_nl(int64_t n, const blk_q4_0 *x, const blk_q8_0 *y) {
+    float s = 0.0f;
+    for (int64_t i = 0; i < n / 32; i++) {
+        const float d = oq_fp16_to_fp32(y[i].d) * oq_fp16_to_fp32(x[i].d);
+        s += d * (float)iq4_nl_block(&x[i], &y[i]);
+    }
+    return s;
+}
 /* upstream scalar ggml_vec_dot_q5_0_q8_0: one integer sum per block, sumf += (d_x * d_y) * sumi */
 static int32_t q5_0_block(const blk_q5_0 *x, const blk_q8_0 *y) {
     uint32_t qh; memcpy(&qh, x->qh, 4);
@@ -618,6 +655,7 @@ float oq_vec_dot(int type, int64_t n, const void *w, const void *a) {
         case OQ_TYPE_Q5_K: return dot_q5_K(n, (const blk_q5_K *)w, (const blk_q8_K *)a);
         case OQ_TYPE_Q6_K: return dot_q6_K(n, (const blk_q6_K *)w, (const blk_q8_K *)a);
         case OQ_TYPE_Q5_0: return dot_q5_0(n, (const blk_q5_0 *)w, (const blk_q8_0 *)a);
+        case OQ_TYPE_IQ4_NL: return dot_iq4_nl(n, (const blk_q4_0 *)w, (const blk_q8_0 *)a);
         case OQ_TYPE_Q2_K: return dot_q2_K(n, (const blk_q2_K *)w, (const blk_q8_K *)a);
         case OQ_TYPE_Q3_K: return dot_q3_K(n, (const blk_q3_K *)w, (const blk_q8_K *)a);
     }
@@ -634,6 +672,11 @@ void oq_vec_dot_int_partials(int type, int64_t n, const void *wrow, const void *
             for (int j = 0; j < 32; j++) si += (int32_t)x[i].qs[j] * y[i].qs[j];
             isum[i] = si; msum[i] = 0;
         }
+        return;
+    }
+    if (type == OQ_TYPE_Q4_0 || type == OQ_TYPE_IQ4_NL) {
+        const blk_q4_0 *x = (const blk_q4_0 *)wrow; const blk_q8_0 *y = (const blk_q8_0 *)act;
+        for (int64_t i = 0; i < n / 32; i++) { isum[i] = type == OQ_TYPE_Q4_0 ? q4_0_block(&x[i], &y[i]) : iq4_nl_block(&x[i], &y[i]); msum[i] = 0; }
         return;
     }
     if (type == OQ_TYPE_Q5_0) {

@@ -43,6 +43,7 @@ enum {
     OQ_TYPE_Q5_K = 13,
     OQ_TYPE_Q6_K = 14,
     OQ_TYPE_Q8_K = 15,
+    OQ_TYPE_IQ4_NL = 20,
 };
 
 #define OQ_QK_K 256

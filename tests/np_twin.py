@@ -6,7 +6,8 @@ from __future__ import annotations
 import numpy as np
 
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
-Q5_0, Q2_K, Q3_K = 6, 10, 11
+Q5_0, Q2_K, Q3_K, IQ4_NL = 6, 10, 11, 20
+IQ4NL_LEVELS = np.array([-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113], np.int32)   # the format's code book
 
 DT = {
     Q4_0: np.dtype([("d", "<f2"), ("qs", "u1", 16)]),
@@ -16,6 +17,7 @@ DT = {
     Q6_K: np.dtype([("ql", "u1", 128), ("qh", "u1", 64), ("scales", "i1", 16), ("d", "<f2")]),
     Q8_K: np.dtype([("d", "<f4"), ("qs", "i1", 256), ("bsums", "<i2", 16)]),
     Q5_0: np.dtype([("d", "<f2"), ("qh", "<u4"), ("qs", "u1", 16)]),
+    IQ4_NL: np.dtype([("d", "<f2"), ("qs", "u1", 16)]),
     Q2_K: np.dtype([("scales", "u1", 16), ("qs", "u1", 64), ("d", "<f2"), ("dmin", "<f2")]),
     Q3_K: np.dtype([("hmask", "u1", 32), ("qs", "u1", 64), ("scales", "u1", 12), ("d", "<f2")]),
 }
@@ -62,6 +64,9 @@ def unpack_ints(t: int, raw: np.ndarray) -> np.ndarray:
             lo = lo + (((h >> (2 * c)) & 1) << 4)
             hi = hi + (((h >> (2 * c + 1)) & 1) << 4)
         return np.stack([lo, hi], axis=2).reshape(-1, 256)
+    if t == IQ4_NL:
+        q = b["qs"].astype(np.int32)
+        return np.concatenate([IQ4NL_LEVELS[q & 15], IQ4NL_LEVELS[q >> 4]], axis=1)
     if t == Q5_0:
         q = b["qs"].astype(np.int32)
         h = b["qh"].astype(np.int64)[:, None]
@@ -100,7 +105,7 @@ def dequantize(t: int, raw: np.ndarray) -> np.ndarray:
         return (b["d"][:, None] * b["qs"].astype(np.float32)).reshape(-1)
     q = unpack_ints(t, raw).astype(np.float32)
     d = b["d"].astype(np.float32)
-    if t in (Q8_0, Q4_0, Q5_0):
+    if t in (Q8_0, Q4_0, Q5_0, IQ4_NL):
         return (q * d[:, None]).reshape(-1)
     if t == Q2_K:
         sc = b["scales"].astype(np.int32)
@@ -165,7 +170,7 @@ def quantize_q8_K(x: np.ndarray) -> np.ndarray:
 def int_partials(t: int, w_raw: np.ndarray, a_raw: np.ndarray):
     """(isum[nb], msum[nb]) of one weight row against a q8_K / q8_0 activation row (exact ints)."""
     w = unpack_ints(t, w_raw).astype(np.int64)
-    if t in (Q8_0, Q5_0):
+    if t in (Q8_0, Q5_0, Q4_0, IQ4_NL):
         a = a_raw.view(np.uint8).reshape(-1).view(DT[Q8_0])["qs"].astype(np.int64)
         return (w * a).sum(axis=1).astype(np.int32), np.zeros(w.shape[0], np.int32)
     ab = a_raw.view(np.uint8).reshape(-1).view(DT[Q8_K])

@@ -12,7 +12,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
-Q5_0, Q2_K, Q3_K = 6, 10, 11
+Q5_0, Q2_K, Q3_K, IQ4_NL = 6, 10, 11, 20
 
 
 def build_oracle(force: bool = False) -> str:
@@ -111,7 +111,7 @@ def vec_dot(t: int, w_row: np.ndarray, act_q: np.ndarray, n: int) -> float:
 
 
 def vec_dot_int_partials(t: int, w_row: np.ndarray, act_q: np.ndarray, n: int):
-    nb = n // (32 if t in (Q8_0, Q5_0, Q4_0) else 256)
+    nb = n // (32 if t in (Q8_0, Q5_0, Q4_0, IQ4_NL) else 256)
     isum = np.zeros(nb, dtype=np.int32)
     msum = np.zeros(nb, dtype=np.int32)
     w_row = np.ascontiguousarray(w_row.view(np.uint8))

@@ -6,11 +6,11 @@ import pytest
 
 import np_twin as tw
 import oracle_py as oq
-from oracle_py import F16, F32, Q2_K, Q3_K, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K
+from oracle_py import F16, F32, IQ4_NL, Q2_K, Q3_K, Q4_0, Q4_K, Q5_0, Q5_K, Q6_K, Q8_0, Q8_K
 
 pytestmark = pytest.mark.gpu
 
-BB = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q2_K: 84, Q3_K: 110}
+BB = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q2_K: 84, Q3_K: 110, Q5_0: 22, IQ4_NL: 18}
 
 
 @pytest.fixture(scope="module")
@@ -19,7 +19,7 @@ def be(pkg):
 
 
 def rand_weights(rng, t, n_elems, dscale=1e-2):
-    be_ = 32 if t in (Q8_0, Q4_0) else 256
+    be_ = 32 if t in (Q8_0, Q4_0, Q5_0, IQ4_NL) else 256
     raw = rng.integers(0, 256, n_elems // be_ * BB[t], dtype=np.uint8)
     blk = raw.view(tw.DT[t])
     blk["d"] = (rng.uniform(0.5, 1.5, blk.size) * dscale).astype("<f2")
@@ -83,6 +83,27 @@ def test_mul_mat_q2_k_q3_k_int_partials_exact_and_value(be, t, K, N, T):
         for r in range(0, N, max(1, N // 7)):
             wi, wm = oq.vec_dot_int_partials(t, W[r * rb:(r + 1) * rb], act, K)
             assert (isum[tt, r] == wi).all() and (msum[tt, r] == wm).all(), (tt, r)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
+@pytest.mark.parametrize("t", [Q4_0, Q5_0, IQ4_NL])
+@pytest.mark.parametrize("K,N,T", [(256, 3, 1), (2048, 37, 1), (4096, 64, 2), (5632, 10, 3), (2048, 33, 21), (5632, 7, 16), (4096, 20, 8), (11008, 9, 1), (768, 11, 1),
+                                   (2048, 50, 40)])
+def test_mul_mat_32_element_formats_int_partials_exact_and_value(be, t, K, N, T):
+    """Q4_0 / Q5_0 / IQ4_NL tensors (llama-quantize's legacy types and the fallbacks it takes for rows that are not a multiple of 256):
+    integer sums per (token, row, 32-block) bit-exact against ggml_vec_dot_q4_0_q8_0 / _q5_0_q8_0 / _iq4_nl_q8_0 as restated in oracle/ (activation:
+    Q8_0 blocks), f32 result within the re-association bound; single tokens, 2..21 tokens (tiled mat-vec) and a 40-token batch."""
+    rng = np.random.default_rng(K + N + t)
+    W = rand_weights(rng, t, N * K)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    y, isum, msum = be.mul_mat(t, W, N, K, x, want_ints=True)
+    ref = oq.mul_mat(t, W, N, K, x)
+    rb = oq.row_bytes(t, K)
+    for tt in range(T):
+        act = oq.quantize(Q8_0, x[tt])
+        for r in range(0, N, max(1, N // 7)):
+            wi, wm = oq.vec_dot_int_partials(t, W[r * rb:(r + 1) * rb], act, K)
+            assert (isum[tt, r] == wi).all() and (msum[tt, r] == 0).all(), (tt, r)
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
@@ -249,7 +270,7 @@ def test_rope(be, neox, base):
     assert (y[0] == x[0]).all()
 
 
-@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K, Q8_0, F16, F32, Q2_K, Q3_K])
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K, Q8_0, F16, F32, Q2_K, Q3_K, Q4_0, Q5_0, IQ4_NL])
 def test_get_rows_bit_exact(be, t):
     rng = np.random.default_rng(4 + t)
     K, R = 1024, 40

@@ -10,7 +10,7 @@ import pytest
 
 import np_twin as tw
 import oracle_py as oq
-from oracle_py import F16, Q2_K, Q3_K, Q4_0, Q4_K, Q5_0, Q5_K, Q6_K, Q8_0, Q8_K
+from oracle_py import F16, IQ4_NL, Q2_K, Q3_K, Q4_0, Q4_K, Q5_0, Q5_K, Q6_K, Q8_0, Q8_K
 
 
 def pack_k_scales(sc, mn):
@@ -164,6 +164,37 @@ def test_q5_0_closed_form():
     assert y[31] == 0.5 * ((0 | 16) - 16) and y[0] == 0.5 * (0 - 16)
 
 
+def test_iq4_nl_closed_form():
+    """y = d * level[nibble] with the format's sixteen-level code book (ggml-common.h kvalues_iq4nl); low nibbles are elements 0..15, high ones 16..31.
+    The dot against Q8_0: (d_x * d_y) * sum level * q8, one integer sum per block."""
+    levels = [-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113]
+    b = np.zeros(1, tw.DT[IQ4_NL])
+    b["d"] = np.float16(0.25)
+    b["qs"] = (np.arange(16, dtype=np.uint8) | ((15 - np.arange(16, dtype=np.uint8)) << 4))[None, :]     # element j: level j, element j + 16: level 15 - j
+    y = oq.dequantize(IQ4_NL, b.view(np.uint8), 32)
+    assert y[:16].tolist() == [0.25 * v for v in levels] and y[16:].tolist() == [0.25 * v for v in levels[::-1]]
+    a = np.zeros(1, tw.DT[Q8_0])
+    a["d"] = np.float16(2.0)
+    a["qs"] = np.arange(32, dtype=np.int8)[None, :] - 16
+    isum, msum = oq.vec_dot_int_partials(IQ4_NL, b.view(np.uint8), a.view(np.uint8), 32)
+    want = sum(levels[j] * (j - 16) for j in range(16)) + sum(levels[15 - j] * j for j in range(16))
+    assert isum.tolist() == [want] and msum.tolist() == [0]
+    assert oq.vec_dot(IQ4_NL, b.view(np.uint8), a.view(np.uint8), 32) == 0.5 * want
+
+
+def test_q4_0_dot_closed_form():
+    """(nibble - 8) * q8 summed per block, then sumi * d_x * d_y left to right (ggml_vec_dot_q4_0_q8_0)."""
+    b = np.zeros(1, tw.DT[Q4_0])
+    b["d"] = np.float16(0.5)
+    b["qs"] = np.full((1, 16), 0x3C, np.uint8)                   # elements 0..15: 12 - 8 = 4, elements 16..31: 3 - 8 = -5
+    a = np.zeros(1, tw.DT[Q8_0])
+    a["d"] = np.float16(0.125)
+    a["qs"] = np.concatenate([np.full(16, 3, np.int8), np.full(16, -2, np.int8)])[None, :]
+    isum, msum = oq.vec_dot_int_partials(Q4_0, b.view(np.uint8), a.view(np.uint8), 32)
+    assert isum.tolist() == [16 * 4 * 3 + 16 * -5 * -2]
+    assert oq.vec_dot(Q4_0, b.view(np.uint8), a.view(np.uint8), 32) == (16 * 12 + 16 * 10) * 0.5 * 0.125
+
+
 def test_q2_K_closed_form():
     """Sub-block is = 8 n + 2 j + (l >= 16): value = d * (scales[is] & 15) * code - dmin * (scales[is] >> 4); code = bits 2 j .. 2 j + 1 of qs[32 n + l]."""
     b = np.zeros(1, tw.DT[Q2_K])
@@ -215,7 +246,7 @@ def test_q3_K_closed_form():
 
 # ------------------------------------------------------------------ twin agreement on random blocks
 @pytest.mark.parametrize("t,be,bb", [(Q4_0, 32, 18), (Q8_0, 32, 34), (Q4_K, 256, 144), (Q5_K, 256, 176), (Q6_K, 256, 210), (Q5_0, 32, 22), (Q2_K, 256, 84),
-                                     (Q3_K, 256, 110)])
+                                     (Q3_K, 256, 110), (IQ4_NL, 32, 18)])
 def test_dequant_matches_twin_bit_exact(t, be, bb):
     rng = np.random.default_rng(100 + t)
     nb = 64
@@ -274,11 +305,11 @@ def test_activation_quant_matches_twin():
 
 
 # ------------------------------------------------------------------ dot products
-@pytest.mark.parametrize("t,bb", [(Q8_0, 34), (Q4_K, 144), (Q5_K, 176), (Q6_K, 210), (Q5_0, 22), (Q2_K, 84), (Q3_K, 110)])
+@pytest.mark.parametrize("t,bb", [(Q8_0, 34), (Q4_K, 144), (Q5_K, 176), (Q6_K, 210), (Q5_0, 22), (Q2_K, 84), (Q3_K, 110), (Q4_0, 18), (IQ4_NL, 18)])
 def test_vec_dot_int_partials_and_value(t, bb):
     rng = np.random.default_rng(200 + t)
     K = 2048
-    be = 32 if t in (Q8_0, Q5_0) else 256
+    be = 32 if t in (Q8_0, Q5_0, Q4_0, IQ4_NL) else 256
     raw = rng.integers(0, 256, K // be * bb, dtype=np.uint8)
     blk = raw.view(tw.DT[t])
     blk["d"] = rng.uniform(0.5, 1.5, K // be).astype("<f2") * np.float16(1e-2)
