@@ -170,6 +170,8 @@ CONFIGS = {
     # hidden sizes that are multiples of 2048: the shapes the persistent single-token mat-vec (fused RMSNorm / quantise
     # prologues) and the MFMA prefill planes are built for
     "tiny-e2048": LlamaConfig("tiny-e2048", 2048, 2, 16, 4, 4096, 512, 500000.0, 1e-5, 1024),
+    # TinyLlama-1.1B's layer geometry (the reference's smoke model, Makefile:5): head_dim 64, 8 query heads per kv head, FF = 5632 = 5.5 x 1024
+    "tiny-tl-2l": LlamaConfig("tiny-tl-2l", 2048, 2, 32, 4, 5632, 512, 10000.0, 1e-5, 1024),
     # 8 KV heads of 128 (one 1024-wide K / V row, GQA 2:1): the shape the single-launch decode attention (rope + cache
     # store + split attention + merge) and the chunk-list batched steps are built for — Llama-3-8B's own KV geometry
     # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads), two layers: the whole-step kernel's shape

@@ -150,11 +150,11 @@ def test_fullsize_row_split_two_ranks(pkg, big, tmp_models):
 # the oracle's own re-association noise at that size; and the size-independent properties on a 512-token prompt (same bits twice, hipGraph replay == eager
 # launches, device arg-max == arg-max of the host-visible row).  The MFMA operand planes of the two largest files (90 / 137 GB) are not built here
 # (prefill_planes = 0: the prompt goes through the expand-in-registers MFMA kernels) to keep the run short.
-OTHER = [("tinyllama-1.1b", "q8_0", "f16", -1), ("llama-2-7b", "q5_k_m", "f16", -1), ("mixtral-8x7b", "q5_k_m", "q8_0", 0), ("llama-3-70b", "q4_k_m", "q8_0", 0)]
+OTHER = [("tinyllama-1.1b", "q8_0", "f16", -1), ("tinyllama-1.1b", "q2_k", "f16", -1), ("llama-2-7b", "q5_k_m", "f16", -1), ("mixtral-8x7b", "q5_k_m", "q8_0", 0), ("llama-3-70b", "q4_k_m", "q8_0", 0)]
 KVT = {"f16": 1, "q8_0": 8}
 
 
-@pytest.fixture(scope="module", params=OTHER, ids=[c[0] for c in OTHER])
+@pytest.fixture(scope="module", params=OTHER, ids=[c[0] + ("-" + c[1] if c[1] == "q2_k" else "") for c in OTHER])
 def other(request, pkg, tmp_path_factory):
     cfg, ftype, kv, planes = request.param
     d = tmp_path_factory.mktemp("full-" + cfg)

@@ -71,7 +71,10 @@ def rel_err(a, b):
                                           ("tiny-gqa4", "q6_k", "q8_0"), ("tiny-g8", "q3_k_l", "q8_0"), ("tiny-8b-2l", "q6_k", "q8_0"), ("tiny-8b-2l", "q3_k_s", "q8_0"),
                                           # 32-element weight formats: Q4_0, Q5_0, IQ4_NL files (Q8_0 activations; IQ4_NL with its Q5_K promotions)
                                           ("tiny-gqa4", "q4_0", "q8_0"), ("tiny-d128", "q5_0", "q8_0"), ("tiny-gqa4", "iq4_nl", "f16"), ("tiny-d128:40", "iq4_nl", "q8_0"),
-                                          ("tiny-e2048", "q4_0", "q8_0"), ("tiny-8b-2l", "q5_0", "q8_0")])
+                                          ("tiny-e2048", "q4_0", "q8_0"), ("tiny-8b-2l", "q5_0", "q8_0"),
+                                          # TinyLlama-1.1B's layer geometry in the type mix of the reference's smoke model (a Q2_K file, Makefile:5) and neighbours
+                                          ("tiny-tl-2l", "q2_k", "f16"), ("tiny-tl-2l", "q2_k", "q8_0"), ("tiny-tl-2l", "q3_k_m", "q8_0"), ("tiny-tl-2l", "q4_k_m", "f16"),
+                                          ("tiny-tl-2l", "q8_0", "f16"), ("tiny-tl-2l:40", "q5_0", "q8_0")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)
