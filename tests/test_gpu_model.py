@@ -1,6 +1,8 @@
 """GPU parity end to end through the C-ABI: synthetic GGUF -> mi355_model_load_from_file -> mi355_decode,
 against the CPU oracle on the same file and tokens: per-layer residual stream, logits, greedy token ids, and
 the KV-cache sequence operations the reference's slot loop uses."""
+import os
+
 import numpy as np
 import pytest
 
@@ -692,3 +694,43 @@ def test_device_topk_front_end_matches_host_order(be, pkg, tmp_models, cfg):
         assert c.decode([int(row.argmax())], [pos]) == 0
         pos += 1
     c.close(); m.close()
+
+
+# Layer geometries of llama-architecture checkpoints in the wild (hidden size, heads, kv heads, feed-forward width) x the file types this backend loads: every
+# combination must LOAD, run a prompt and three captured single-token steps, and land on the CPU restatement's logits.  (The kernels a tensor takes depend on
+# its shape and type together - a feed-forward width that is not a multiple of 1024 under a Q3_K ffn_down once refused its first decode step.)
+SHAPES = {
+    "d64-mha": (1024, 16, 16, 2816),          # head_dim 64, one query head per kv head
+    "tinyllama": (2048, 32, 4, 5632),
+    "llama-3.2-1b": (2048, 32, 8, 8192),
+    "llama-2-7b": (4096, 32, 32, 11008),
+    "llama-3-8b": (4096, 32, 8, 14336),
+    "llama-2-13b": (5120, 40, 40, 13824),
+    "llama-30b": (6656, 52, 52, 17920),
+    "codellama-34b": (8192, 64, 8, 22016),
+    "llama-3-70b": (8192, 64, 8, 28672),
+}
+
+
+@pytest.mark.parametrize("ftype", ["q4_k_m", "q2_k", "q3_k_s", "q6_k", "q8_0", "q4_0", "iq4_nl"])
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_real_layer_geometries_by_file_type(be, pkg, tmp_path, shape, ftype):
+    E, H, G, FF = SHAPES[shape]
+    cfg = pkg.gguf_synth.LlamaConfig(f"sweep-{shape}", E, 1, H, G, FF, 512, 10000.0, 1e-5, 512, big_model=(shape == "llama-3-70b"))
+    path = str(tmp_path / "m.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=3)
+    m, c, om, oc = open_pair(pkg, path, 64, "q8_0")
+    prompt = np.random.default_rng(9).integers(0, m.n_vocab, 9)
+    assert c.decode(prompt, np.arange(9)) == 0
+    ref = oc.decode(prompt, np.arange(9))[0]
+    errs = [rel_err(c.logits(), ref)]
+    tok = int(ref.argmax())
+    for s in range(3):
+        assert c.decode([tok], [9 + s]) == 0
+        r = oc.decode([tok], [9 + s])[0]
+        errs.append(rel_err(c.logits(), r))
+        assert int(c.logits().argmax()) == c.argmax()
+        tok = int(r.argmax())
+    assert max(errs) <= FLIP_TOL, (shape, ftype, errs)
+    c.close(); m.close(); oc.close(); om.close()
+    os.remove(path)
