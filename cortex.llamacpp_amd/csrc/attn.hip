@@ -853,6 +853,9 @@ hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
 #define FA_CASE(DD, RR) if (a.D == DD && R == RR) e = launch_fa<DD, RR>(a, st);
     FA_CASE(128, 1) FA_CASE(128, 2) FA_CASE(128, 4) FA_CASE(128, 8)
     FA_CASE(64, 1) FA_CASE(64, 2) FA_CASE(64, 4) FA_CASE(64, 8)
+    // query / kv head ratios the tuned kernels are not cut for (Llama-3.2-3B: 3, Yi-34B: 7, ...): this general kernel is the only path
+    FA_CASE(128, 3) FA_CASE(128, 5) FA_CASE(128, 6) FA_CASE(128, 7)
+    FA_CASE(64, 3) FA_CASE(64, 5) FA_CASE(64, 6) FA_CASE(64, 7)
 #undef FA_CASE
     if (e != hipSuccess) return e;
     const int nblk = (a.H * a.D) >> 8;

@@ -71,7 +71,8 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     if (hp.n_head_kv <= 0 || hp.n_head % hp.n_head_kv) { err = "attention.head_count_kv (" + std::to_string(hp.n_head_kv) + ") must be positive and divide attention.head_count (" + std::to_string(hp.n_head) + ")"; status = -102; return nullptr; }
     {
         const int ratio = hp.n_head / hp.n_head_kv;
-        if (ratio != 1 && ratio != 2 && ratio != 4 && ratio != 8) { err = "unsupported query / kv head ratio " + std::to_string(ratio) + " (the attention kernels are built for 1, 2, 4, 8)"; status = -102; return nullptr; }
+        // (1, 2, 4, 8 have the tuned single-launch decode attention and the matrix-core prompt attention; 3, 5, 6, 7 take the general split kernel)
+        if (ratio < 1 || ratio > 8) { err = "unsupported query / kv head ratio " + std::to_string(ratio) + " (the attention kernels are built for 1 .. 8)"; status = -102; return nullptr; }
     }
     if (hp.n_embd % hp.n_head) { err = "embedding_length is not a multiple of attention.head_count"; status = -102; return nullptr; }
     if (hp.n_expert < 0 || hp.n_expert > 256 || hp.n_expert_used < 0 || hp.n_expert_used > hp.n_expert || (hp.n_expert > 0 && hp.n_expert_used == 0)) {

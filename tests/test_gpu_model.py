@@ -703,6 +703,8 @@ SHAPES = {
     "d64-mha": (1024, 16, 16, 2816),          # head_dim 64, one query head per kv head
     "tinyllama": (2048, 32, 4, 5632),
     "llama-3.2-1b": (2048, 32, 8, 8192),
+    "llama-3.2-3b": (3072, 24, 8, 8192),       # three query heads per kv head: the general attention kernel
+    "yi-34b": (7168, 56, 8, 20480),            # seven
     "llama-2-7b": (4096, 32, 32, 11008),
     "llama-3-8b": (4096, 32, 8, 14336),
     "llama-2-13b": (5120, 40, 40, 13824),
