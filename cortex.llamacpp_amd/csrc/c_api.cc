@@ -363,7 +363,7 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
             if (e == hipSuccess) e = hipDeviceSynchronize();
             if (e != hipSuccess) return hip_fail(e, "mmq_ksplit");
         } else
-        if (mmq_applicable(type, (int)K, (int)T)) {
+        if (mmq_applicable(type, (int)K, (int)T) || ((type == T_Q2_K || type == T_Q3_K) && T >= 32 && g_op_mmq_planes)) {   // (Q2_K / Q3_K: planes only)
             DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
             if (!bh.p || !bl.p) return MI355_ERR_OOM;
             e = launch_mmq_prep(ab.q, (int)K, (int)T, bh.as<int8_t>(), bl.as<int8_t>(), nullptr);

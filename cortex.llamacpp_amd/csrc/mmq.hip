@@ -703,6 +703,83 @@ __global__ __launch_bounds__(256) void mmq_expand_kernel(const uint8_t *W, size_
     }
 }
 
+// Q2_K and Q3_K into the same plane format (their prompts then run on the kernels below; there is no expand-on-the-fly form for them):
+//   Q2_K: p = scale * code <= 15 * 3, planes as Q4_K's (hi = p >> 5, lo = p & 31); sub-block 2 J + kg (16 weights) is exactly a lane's share of K-step J;
+//         its sixteen 4-bit mins go into the meta words as nibbles (y: sub-blocks 0-7, z: 8-15) and w = 1 tells the fold to read them that way
+//         (one min per block sum instead of one per two);
+//   Q3_K: p = (scale - 32) * code with code in [-4, 3]: signed, 16-weight groups, no mins - planes as Q6_K's (hi = p >> 6 floored, lo = p & 63).
+// device rows (dev_common.h): Q2_K [qs nb*64][scales nb*16][d, dmin nb*4];  Q3_K [hmask nb*32][qs nb*64][scales nb*12][d nb*2]
+template <int TYPE>
+__global__ __launch_bounds__(256) void mmq_expand_small_kernel(const uint8_t *W, size_t row_bytes, int n_rows, int nb, int n_rt, uint8_t *planes) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);     // (row tile, super-block)
+    if (idx >= n_rt * nb) return;
+    const int rt = idx / nb, sb = idx - rt * nb;
+    const int n = lane & 31, kg = lane >> 5;
+    int row = rt * 32 + n;
+    if (row >= n_rows) row = n_rows - 1;
+    const uint8_t *r = W + (size_t)row * row_bytes;
+    uint8_t *blk = planes + (size_t)idx * PL_BLOCK;
+    const size_t qs_off = TYPE == T_Q2_K ? 0 : (size_t)nb * 32;
+    // this lane's code bytes: l = 16 kg .. 16 kg + 15 of both 32-byte halves
+    const u32x4 q0 = ldg16(r + qs_off + (size_t)sb * 64 + 16 * kg), q1 = ldg16(r + qs_off + (size_t)sb * 64 + 32 + 16 * kg);
+    u32x4 hm = {0, 0, 0, 0};
+    int sc[16];
+    uint32_t mn_lo = 0, mn_hi = 0;
+    if (TYPE == T_Q2_K) {
+        const uint8_t *scp = r + (size_t)nb * 64 + (size_t)sb * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int b = scp[i];
+            sc[i] = b & 15;
+            if (i < 8) mn_lo |= (uint32_t)(b >> 4) << (4 * i); else mn_hi |= (uint32_t)(b >> 4) << (4 * (i - 8));
+        }
+    } else {
+        hm = ldg16(r + (size_t)sb * 32 + 16 * kg);
+        const uint8_t *scp = r + (size_t)nb * 96 + (size_t)sb * 12;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {   // 6-bit scale i: low 4 bits = nibble i of bytes 0-7 (low nibbles 0-7, high nibbles 8-15), high 2 bits = bit pair i / 4 of byte 8 + i % 4
+            const int low = i < 8 ? (scp[i] & 15) : (scp[i - 8] >> 4);
+            sc[i] = (low | (((scp[8 + (i & 3)] >> (2 * (i >> 2))) & 3) << 4)) - 32;
+        }
+    }
+#pragma unroll
+    for (int J = 0; J < 8; J++) {
+        const u32x4 qv = (J >> 2) ? q1 : q0;
+        const int sh = 2 * (J & 3);
+        const int s = sc[2 * J + kg];
+        const uint32_t cw[4] = {(qv.x >> sh) & 0x03030303u, (qv.y >> sh) & 0x03030303u, (qv.z >> sh) & 0x03030303u, (qv.w >> sh) & 0x03030303u};
+        const uint32_t hw[4] = {hm.x, hm.y, hm.z, hm.w};
+        uint32_t hv[4], lv[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t hx = 0, lx = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int code = (int)((cw[w] >> (8 * b)) & 3u);
+                int p;
+                if (TYPE == T_Q2_K) { p = s * code; hx |= (uint32_t)((p >> 5) & 0xff) << (8 * b); lx |= (uint32_t)(p & 31) << (8 * b); }
+                else {
+                    if (!((hw[w] >> (8 * b + J)) & 1u)) code -= 4;          // bit J = 4 (J >> 2) + (J & 3) of the element's hmask byte
+                    p = s * code;
+                    hx |= (uint32_t)((p >> 6) & 0xff) << (8 * b); lx |= (uint32_t)(p & 63) << (8 * b);
+                }
+            }
+            hv[w] = hx; lv[w] = lx;
+        }
+        *reinterpret_cast<u32x4 *>(blk + (J * 2) * 1024 + lane * 16) = u32x4{hv[0], hv[1], hv[2], hv[3]};
+        *reinterpret_cast<u32x4 *>(blk + (J * 2 + 1) * 1024 + lane * 16) = u32x4{lv[0], lv[1], lv[2], lv[3]};
+    }
+    if (kg == 0) {
+        u32x4 m = {0, 0, 0, 0};
+        if (TYPE == T_Q2_K) { m.x = *reinterpret_cast<const uint32_t *>(r + (size_t)nb * 80 + (size_t)sb * 4); m.y = mn_lo; m.z = mn_hi; m.w = 1u; }
+        else m.x = *reinterpret_cast<const uint16_t *>(r + (size_t)nb * 108 + (size_t)sb * 2);
+        *reinterpret_cast<u32x4 *>(blk + 16384 + n * 16) = m;
+    }
+}
+// which fold a plane set takes: the block-sum ("mins") form with shift 5, or the signed form with shift 6
+__host__ __device__ constexpr bool planes_have_mins(int type) { return type == T_Q4_K || type == T_Q5_K || type == T_Q2_K; }
+
 // Several tensors that share the activation and whose plane sets lie back to back in memory (attn_q | attn_k | attn_v) run as
 // ONE launch over the concatenated rows: rows [row_end[s-1], row_end[s]) go to out[s] with leading dimension ld[s] (segment
 // boundaries are multiples of 32, so a wave's 32-row tile belongs to one segment).  A 1024-row tensor alone fills a quarter of
@@ -853,8 +930,14 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes_kernel(const uint8_t *pla
         if (MINS) {
             dm = h2f((uint16_t)(mcur.x >> 16));
             if (kg == 0) {
-                bm.x = (int)perm(0, mcur.y, 0x01010000u); bm.y = (int)perm(0, mcur.y, 0x03030202u);
-                bm.z = (int)perm(0, mcur.z, 0x01010000u); bm.w = (int)perm(0, mcur.z, 0x03030202u);
+                if (mcur.w) {           // sixteen 4-bit mins, one per block sum (Q2_K planes): nibbles -> bytes in block-sum order
+                    const uint32_t ey = mcur.y & 0x0f0f0f0fu, oy = (mcur.y >> 4) & 0x0f0f0f0fu, ez = mcur.z & 0x0f0f0f0fu, oz = (mcur.z >> 4) & 0x0f0f0f0fu;
+                    bm.x = (int)perm(oy, ey, 0x05010400u); bm.y = (int)perm(oy, ey, 0x07030602u);
+                    bm.z = (int)perm(oz, ez, 0x05010400u); bm.w = (int)perm(oz, ez, 0x07030602u);
+                } else {
+                    bm.x = (int)perm(0, mcur.y, 0x01010000u); bm.y = (int)perm(0, mcur.y, 0x03030202u);
+                    bm.z = (int)perm(0, mcur.z, 0x01010000u); bm.w = (int)perm(0, mcur.z, 0x03030202u);
+                }
             }
         }
 #pragma unroll
@@ -1126,10 +1209,15 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
         if (MINS) {
             ndm = -h2f((uint16_t)(mcur.x >> 16));
             const unsigned w = kg ? mcur.z : mcur.y;            // mins 4 kg .. 4 kg + 3, each for two consecutive block sums
+            if (mcur.w) {                                       // Q2_K planes: eight 4-bit mins 8 kg .. 8 kg + 7, one per block sum
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const _Float16 v = (_Float16)(float)((w >> (8 * e)) & 0xffu);
-                bm8[2 * e] = v; bm8[2 * e + 1] = v;
+                for (int e = 0; e < 8; e++) bm8[e] = (_Float16)(float)((w >> (4 * e)) & 0xfu);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const _Float16 v = (_Float16)(float)((w >> (8 * e)) & 0xffu);
+                    bm8[2 * e] = v; bm8[2 * e + 1] = v;
+                }
             }
         }
 #pragma unroll
@@ -1510,7 +1598,7 @@ hipError_t launch_mmq_ksplit(int type, const uint8_t *W, size_t row_bytes, int n
 }
 
 size_t mmq_planes_bytes(int type, int64_t n_rows, int K) {
-    if ((type != T_Q4_K && type != T_Q5_K && type != T_Q6_K) || (K % 256) != 0) return 0;
+    if ((type != T_Q4_K && type != T_Q5_K && type != T_Q6_K && type != T_Q2_K && type != T_Q3_K) || (K % 256) != 0) return 0;
     return (size_t)((n_rows + 31) / 32) * (size_t)(K >> 8) * PL_BLOCK;
 }
 
@@ -1521,6 +1609,8 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
         case T_Q4_K: hipLaunchKernelGGL(mmq_expand_kernel<T_Q4_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
         case T_Q5_K: hipLaunchKernelGGL(mmq_expand_kernel<T_Q5_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
         case T_Q6_K: hipLaunchKernelGGL(mmq_expand_kernel<T_Q6_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
+        case T_Q2_K: hipLaunchKernelGGL(mmq_expand_small_kernel<T_Q2_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
+        case T_Q3_K: hipLaunchKernelGGL(mmq_expand_small_kernel<T_Q3_K>, grid, dim3(256), 0, st, W, row_bytes, n_rows, nb, n_rt, planes); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1580,7 +1670,7 @@ hipError_t launch_mmq_planes_swiglu(int type, const uint8_t *planes_gate, const 
     po.n_seg = 1; po.out[0] = out; po.ld[0] = ld_out; po.row_end[0] = n_rows;
     const int nrt = (n_rows + 63) / 64, ntt = (T + P2_TOK - 1) / P2_TOK;
     const dim3 grid((unsigned)(((nrt + 7) / 8) * ntt * 8));
-    if (type != T_Q6_K) {
+    if (planes_have_mins(type)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_swiglu_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
         hipLaunchKernelGGL((mmq_planes2_swiglu_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes_gate, planes_up, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po);
     } else {
@@ -1603,8 +1693,8 @@ hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *s
         n_rows += seg_rows[i];
         po.out[i] = outs[i]; po.ld[i] = lds_out[i]; po.row_end[i] = n_rows;
         const int ti = seg_types ? seg_types[i] : type;
-        if (ti != T_Q6_K) po.mins_mask |= 1u << i;
-        mixed = mixed || (ti != T_Q6_K) != (type != T_Q6_K);
+        if (planes_have_mins(ti)) po.mins_mask |= 1u << i;
+        mixed = mixed || planes_have_mins(ti) != planes_have_mins(type);
     }
     if (mixed && !mmq_planes_mixed_ok(seg_rows, n_seg, K, T, wsp)) return hipErrorInvalidValue;
     static const int env_mt = getenv("MI355_MMQ_MT") ? atoi(getenv("MI355_MMQ_MT")) : 0;
@@ -1616,7 +1706,7 @@ hipError_t launch_mmq_planes_multi(int type, const uint8_t *planes, const int *s
     if (n_seg > 1 && T > 32 && wg2 * 4 >= 3L * num_cu()) mt = 2;       // concatenated Q | K | V: 192 workgroups of 128 x 128 beat 384 of 256 x 32 (59 vs 71 us)
     if (env_mt == 1 || env_mt == 2) mt = env_mt;
     if (g_mmq_mt == 1 || g_mmq_mt == 2) mt = g_mmq_mt;
-    const bool mins = type != T_Q6_K;
+    const bool mins = planes_have_mins(type);
     // both operands through LDS (128 rows x 256 tokens per workgroup) once that grid covers most of the chip; tensors with
     // too few rows for that split K over 2..4 workgroups (partial sums in the caller's workspace, added up in split order)
     bool p2 = false;

@@ -768,6 +768,9 @@ hipError_t Context::ensure_prep(const ActQuant &aq, int K, int T) {
     return hipSuccess;
 }
 
+// Q2_K / Q3_K tensors reach the matrix cores only through their plane sets (no expand-on-the-fly kernel): prompt batches of 32 tokens and more
+static bool planes_small(const DevTensor &w, int K, int T) { return (w.type == T_Q2_K || w.type == T_Q3_K) && w.planes && T >= 32 && (K % 256) == 0; }
+
 hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                            const float *resid, int epi) {
     if (is_quant(w.type)) {
@@ -783,6 +786,11 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
             if ((w.type != T_Q6_K || !w.planes) && !bh_over_) HIP_TRY(ensure_prep(aq, K, T));
             if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_, mmq_ws_);
             return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
+        }
+        if (planes_small(w, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU && aq.qs) {
+            // prompt processing of Q2_K / Q3_K tensors: their plane sets (expanded at load in the Q4_K / Q6_K plane formats, mmq.hip) on the same kernels
+            if (w.type == T_Q2_K && !bh_over_) HIP_TRY(ensure_prep(aq, K, T));
+            return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_, mmq_ws_);
         }
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
         return mmvq_tokens(&s, 1, K, T, epi, aq, stream_, pending_fuse_);
@@ -832,7 +840,7 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
         return hipSuccess;
     }
     bool any_mmq = false;
-    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T) || mmq_q80_applicable(ws[i]->type, K, T);
+    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T) || mmq_q80_applicable(ws[i]->type, K, T) || planes_small(*ws[i], K, T);
     if (all_q && n <= 3 && !(any_mmq && pending_fuse_.mode == 0)) {
         MMVQSeg segs[3];
         for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
@@ -1303,7 +1311,8 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             bool swiglu_quantised = false;
             const bool ffn_mmq = (mmq_q80_applicable(L.gate.type, E, T) && mmq_q80_applicable(L.up.type, E, T)) ||
                                  (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
-                                 (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T));
+                                 (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T)) ||
+                                 (planes_small(L.gate, E, T) && planes_small(L.up, E, T));
             const bool ffn_ks = mmq_ksplit_preferred(L.gate.type, (int)L.gate.N, E, T, L.gate.planes != nullptr, true) &&
                                 mmq_ksplit_preferred(L.up.type, (int)L.up.N, E, T, L.up.planes != nullptr, true) && !fuse_ffn;
             if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {
@@ -1327,7 +1336,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                         HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
                     }
                 }
-            } else if (T > 1 && !fuse_ffn && L.gate.planes && L.up.planes && L.gate.N == L.up.N && mmq_applicable(L.gate.type, E, T) &&
+            } else if (T > 1 && !fuse_ffn && L.gate.planes && L.up.planes && L.gate.N == L.up.N && (mmq_applicable(L.gate.type, E, T) || planes_small(L.gate, E, T)) &&
                        mmq_planes_swiglu_ok(L.gate.type, L.up.type, (int)L.gate.N, E, T)) {
                 // prompt batch on the LDS kernel: gate and up in one launch, 64 rows of each per workgroup, SwiGLU in the epilogue (one
                 // f32 result of T x FF instead of two); the quantiser for the down projection then reads half as much

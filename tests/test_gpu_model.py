@@ -141,7 +141,11 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
                                                           ("tiny-8b-2l", "q4_k_m", "q8_0", 130, 512),
                                                           # and at 512 tokens, the headline prompt: every contraction on the LDS-form kernels (both operands
                                                           # through LDS, SwiGLU launch, split K for ffn_down), the prompt attention with 16 query tiles
-                                                          ("tiny-8b-2l", "q4_k_m", "q8_0", 512, 512)])
+                                                          ("tiny-8b-2l", "q4_k_m", "q8_0", 512, 512),
+                                                          # Q2_K / Q3_K files: prompts on the matrix cores through their plane sets (TinyLlama's geometry: the reference's
+                                                          # smoke model, and the 8B layer shapes)
+                                                          ("tiny-tl-2l", "q2_k", "f16", 200, 512), ("tiny-tl-2l", "q3_k_m", "q8_0", 130, 512), ("tiny-8b-2l", "q2_k", "q8_0", 96, 512),
+                                                          ("tiny-8b-2l", "q3_k_s", "q8_0", 160, 512)])
 def test_long_prompt_logits_match_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt, ubatch):
     """Prompts of a few hundred tokens against the CPU restatement: the matrix-core prompt attention with several query tiles,
     its two key halves per workgroup, the query sub-tiles of one- and two-head kv groups (R = 1: four, R = 2: two), key splits across
@@ -162,7 +166,13 @@ def test_long_prompt_logits_match_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_
                 b0 = oc.layer_out(il, n_prompt).reshape(n_prompt, -1)
                 tok_err = np.abs(a0 - b0).max(axis=1) / max(1.0, float(np.abs(b0).max()))
                 assert float(tok_err.max()) <= FLIP_TOL, (il, int(tok_err.argmax()), float(tok_err.max()))
-                if tight:
+                if tight and ftype.startswith(("q2_k", "q3_k")):
+                    # a Q2_K / Q3_K embedding table holds few distinct values per row, so the normalised inputs sit on or near rounding ties far more often than
+                    # a 4-bit table's do and a 1-ulp difference in the RMSNorm scale flips more codes (measured: ~half the tokens of a 96-token prompt carry a
+                    # flip at E = 4096, and a flipped K / V code reaches every later token through the attention: 24 % exact at 300 tokens): the tokens are
+                    # either exact to f32 round-off or flips away - at least a fifth must be exact
+                    assert int((tok_err <= TIGHT_TOL).sum()) * 5 >= n_prompt, (il, float(np.median(tok_err)), tok_err[:40])
+                elif tight:
                     assert float(np.median(tok_err)) <= TIGHT_TOL, (il, float(np.median(tok_err)), tok_err[:40])
         assert rel_err(c.logits(), ref) <= FLIP_TOL
         c.close(); m.close(); oc.close(); om.close()

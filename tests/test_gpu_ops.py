@@ -131,12 +131,13 @@ def test_mul_mat_mfma_prefill_paths(be, t, K, N, T, planes, tiles):
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
-@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K, Q2_K, Q3_K])
 @pytest.mark.parametrize("K,N,T", [(2048, 130, 40), (4096, 300, 129), (1024, 128, 256), (4096, 70, 512), (14336, 40, 300), (256, 257, 513)])
 def test_mul_mat_prefill_both_operands_through_lds(be, t, K, N, T):
     """The 128-row x 256-token workgroup tile whose weight planes AND activation codes reach LDS by DMA (mmq_planes2_kernel):
     same integer sums, same fold and same f32 order over super-blocks as the per-lane planes kernel, so the two agree bit
-    for bit; ragged row tiles, ragged token tiles and a single super-block included."""
+    for bit; ragged row tiles, ragged token tiles and a single super-block included.  Q2_K / Q3_K tensors ride on the same kernels through
+    plane sets in the Q4_K / Q6_K formats (Q2_K: sixteen 4-bit mins per super-block, one per block sum)."""
     rng = np.random.default_rng(7 * K + N + T + t)
     W = rand_weights(rng, t, N * K)
     x = (rng.standard_normal((T, K)) * rng.uniform(0.1, 4.0, (T, 1))).astype(np.float32)
