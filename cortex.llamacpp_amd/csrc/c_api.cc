@@ -355,6 +355,14 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
             if (e == hipSuccess) e = hipDeviceSynchronize();
             if (e != hipSuccess) return hip_fail(e, "mmq_q80");
         } else
+        if (mmq_q80_copy_bytes(type, N, (int)K) && mmq_q80_applicable(T_Q8_0, (int)K, (int)T) && g_op_mmq_planes) {   // Q4_0 / Q5_0 / IQ4_NL prompt batches: exact Q8_0-layout copy
+            DevBuf cp(mmq_q80_copy_bytes(type, N, (int)K));
+            if (!cp.p) return MI355_ERR_OOM;
+            e = launch_expand_q80_copy(type, wdev.as<uint8_t>(), drow, (int)N, (int)K, cp.as<uint8_t>(), nullptr);
+            if (e == hipSuccess) e = launch_mmq_q80(cp.as<uint8_t>(), dev_row_bytes(T_Q8_0, K), (int)N, (int)K, (int)T, ab.q, dy.as<float>(), (int)N, nullptr, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_fail(e, "mmq_q80 (copy)");
+        } else
         if (g_op_mmq_ksplit && mmq_ksplit_applicable(type, (int)K, (int)T)) {
             DevBuf bh(mmq_prep_bytes((int)K, (int)T)), bl(mmq_prep_bytes((int)K, (int)T));
             if (!bh.p || !bl.p) return MI355_ERR_OOM;

@@ -96,6 +96,9 @@ bool mmq_applicable(int type, int K, int T);
 void mmq_set_tiles(int mt);                                // tools: force 1 / 2 / 4 token tiles per wave (0 = by T)
 // pre-expanded MFMA operand planes of a weight tensor (2 B / weight, built once at load; mmq.hip)
 size_t mmq_planes_bytes(int type, int64_t n_rows, int K);   // 0 if the type has no planes form
+// Q4_0 / Q5_0 / IQ4_NL: an exact Q8_0-layout copy of the tensor for prompt batches (mmq_q80.hip); 0 for other types
+size_t mmq_q80_copy_bytes(int type, int64_t n_rows, int K);
+hipError_t launch_expand_q80_copy(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *dst, hipStream_t st);
 hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *planes, hipStream_t st);
 // workspace for the K-split form of the planes kernel (tensors with few rows): n_split * T * n_rows floats; none = no split
 struct MMQWorkspace { float *p = nullptr; size_t bytes = 0; };

@@ -97,6 +97,46 @@ __global__ __launch_bounds__(256) void mmq_q80_kernel(const uint8_t *__restrict_
 
 }  // namespace
 
+// Q4_0 / Q5_0 / IQ4_NL rows as Q8_0 device rows ([codes K][scales K/32]): code = nibble - 8, (nibble | fifth bit) - 16, level[nibble] - all int8 -
+// with the block's own f16 scale.  The copy is EXACT (same integers, same scales), so the kernel above computes the same block sums as the format's
+// own vec_dot; it is made once at load for prompt batches (1.06 B per weight beside the file's 0.56 - 0.69).
+__global__ __launch_bounds__(256) void expand_nib32_q80_kernel(int type, const uint8_t *__restrict__ W, size_t row_bytes, int n_rows, int K, uint8_t *__restrict__ dst,
+                                                               size_t dst_row) {
+    const int row = blockIdx.y;
+    const int nblk = K >> 5;
+    const size_t half = (size_t)K >> 1;
+    const uint8_t *r = W + (size_t)row * row_bytes;
+    uint8_t *o = dst + (size_t)row * dst_row;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < K; e += gridDim.x * 256) {
+        const int b = e >> 5, j = e & 31;
+        const int nib = (r[(size_t)b * 16 + (j & 15)] >> (4 * (j >> 4))) & 0x0f;
+        int code;
+        if (type == T_Q4_0) code = nib - 8;
+        else if (type == T_Q5_0) {
+            const uint32_t qh = *reinterpret_cast<const uint32_t *>(r + half + (size_t)b * 4);
+            code = (nib | (int)(((qh >> j) & 1u) << 4)) - 16;
+        } else code = iq4nl_value(nib);
+        o[e] = (uint8_t)(int8_t)code;
+        if (j == 0) {
+            const uint16_t d = *reinterpret_cast<const uint16_t *>(r + half + (type == T_Q5_0 ? (size_t)nblk * 4 : 0) + (size_t)b * 2);
+            *reinterpret_cast<uint16_t *>(o + (size_t)K + (size_t)b * 2) = d;
+        }
+    }
+}
+size_t mmq_q80_copy_bytes(int type, int64_t n_rows, int K) {
+    if ((type != T_Q4_0 && type != T_Q5_0 && type != T_IQ4_NL) || (K % 32) != 0 || K > 16384) return 0;
+    return (size_t)n_rows * dev_row_bytes(T_Q8_0, K);
+}
+hipError_t launch_expand_q80_copy(int type, const uint8_t *W, size_t row_bytes, int n_rows, int K, uint8_t *dst, hipStream_t st) {
+    if (!mmq_q80_copy_bytes(type, n_rows, K)) return hipErrorInvalidValue;
+    for (int r0 = 0; r0 < n_rows; r0 += 65535) {
+        const int nr = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
+        hipLaunchKernelGGL(expand_nib32_q80_kernel, dim3((unsigned)((K + 255) / 256 < 8 ? (K + 255) / 256 : 8), nr), dim3(256), 0, st, type, W + (size_t)r0 * row_bytes, row_bytes, nr, K,
+                           dst + (size_t)r0 * dev_row_bytes(T_Q8_0, K), dev_row_bytes(T_Q8_0, K));
+    }
+    return hipGetLastError();
+}
+
 bool mmq_q80_applicable(int type, int K, int T) { return type == T_Q8_0 && T >= 32 && K >= 32 && (K % 32) == 0 && K <= 16384; }
 
 hipError_t launch_mmq_q80(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, float *out, int ld_out,

@@ -278,9 +278,13 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         std::vector<DevTensor *> want;
         for (auto &L : m->layers)
             for (DevTensor *d : {&L.wq, &L.wk, &L.wv, &L.wo, &L.gate, &L.up, &L.down, &L.gate_exps, &L.up_exps, &L.down_exps})
-                if (d->valid() && mmq_planes_bytes(d->type, d->N, (int)d->K)) want.push_back(d);
+                if (d->valid() && (mmq_planes_bytes(d->type, d->N, (int)d->K) || mmq_q80_copy_bytes(d->type, d->N, (int)d->K))) want.push_back(d);
         // (an *_exps tensor holds one plane set per expert, back to back: a prompt batch runs one contraction per expert)
-        auto planes_of = [](const DevTensor *d) { return (mmq_planes_bytes(d->type, d->N, (int)d->K) + 255) & ~(size_t)255; };
+        // (K-quants: the two int8 MFMA planes; Q4_0 / Q5_0 / IQ4_NL: an exact Q8_0-layout copy for the Q8_0 prompt kernel)
+        auto planes_of = [](const DevTensor *d) {
+            const size_t b = mmq_planes_bytes(d->type, d->N, (int)d->K);
+            return ((b ? b : mmq_q80_copy_bytes(d->type, d->N, (int)d->K)) + 255) & ~(size_t)255;
+        };
         size_t need = 0;
         for (DevTensor *d : want) need += planes_of(d) * (size_t)d->n_expert;
         size_t free_b = 0, total_b = 0;
@@ -298,8 +302,10 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
                 d->planes_bytes = planes_of(d) * (size_t)d->n_expert;
                 off += d->planes_bytes;
                 for (int64_t x = 0; x < d->n_expert; x++) {
-                    const hipError_t e = launch_mmq_expand(d->type, d->data + (size_t)x * d->row_bytes * (size_t)d->N, d->row_bytes, (int)d->N, (int)d->K,
-                                                           d->planes + (size_t)x * planes_of(d), nullptr);
+                    const uint8_t *src = d->data + (size_t)x * d->row_bytes * (size_t)d->N;
+                    uint8_t *dst = d->planes + (size_t)x * planes_of(d);
+                    const hipError_t e = mmq_planes_bytes(d->type, d->N, (int)d->K) ? launch_mmq_expand(d->type, src, d->row_bytes, (int)d->N, (int)d->K, dst, nullptr)
+                                                                                   : launch_expand_q80_copy(d->type, src, d->row_bytes, (int)d->N, (int)d->K, dst, nullptr);
                     if (e != hipSuccess) { err = std::string("plane expansion of ") + d->name + " failed: " + hipGetErrorString(e); status = -105; return nullptr; }
                 }
             }
@@ -769,6 +775,9 @@ hipError_t Context::ensure_prep(const ActQuant &aq, int K, int T) {
 }
 
 // Q2_K / Q3_K tensors reach the matrix cores only through their plane sets (no expand-on-the-fly kernel): prompt batches of 32 tokens and more
+static bool q80_copy(const DevTensor &w, int K, int T) {
+    return (w.type == T_Q4_0 || w.type == T_Q5_0 || w.type == T_IQ4_NL) && w.planes && w.n_expert == 1 && mmq_q80_applicable(T_Q8_0, K, T);
+}
 static bool planes_small(const DevTensor &w, int K, int T) { return (w.type == T_Q2_K || w.type == T_Q3_K) && w.planes && T >= 32 && (K % 256) == 0; }
 
 hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
@@ -787,6 +796,8 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
             if (w.planes) return launch_mmq_planes(w.type, w.planes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_, mmq_ws_);
             return launch_mmq(w.type, w.data, w.row_bytes, (int)w.N, K, T, aq, bh, bl, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         }
+        if (q80_copy(w, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU && aq.qs0)      // prompt processing of Q4_0 / Q5_0 / IQ4_NL tensors: their exact Q8_0-layout copy
+            return launch_mmq_q80(w.planes, dev_row_bytes(T_Q8_0, K), (int)w.N, K, T, aq, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
         if (planes_small(w, K, T) && pending_fuse_.mode == 0 && epi != EPI_SWIGLU && aq.qs) {
             // prompt processing of Q2_K / Q3_K tensors: their plane sets (expanded at load in the Q4_K / Q6_K plane formats, mmq.hip) on the same kernels
             if (w.type == T_Q2_K && !bh_over_) HIP_TRY(ensure_prep(aq, K, T));
@@ -840,7 +851,7 @@ hipError_t Context::linear_multi(const DevTensor *const *ws, float *const *outs,
         return hipSuccess;
     }
     bool any_mmq = false;
-    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T) || mmq_q80_applicable(ws[i]->type, K, T) || planes_small(*ws[i], K, T);
+    for (int i = 0; i < n; i++) any_mmq |= mmq_applicable(ws[i]->type, K, T) || mmq_q80_applicable(ws[i]->type, K, T) || planes_small(*ws[i], K, T) || q80_copy(*ws[i], K, T);
     if (all_q && n <= 3 && !(any_mmq && pending_fuse_.mode == 0)) {
         MMVQSeg segs[3];
         for (int i = 0; i < n; i++) segs[i] = make_seg(*ws[i], outs[i], (int)ws[i]->N, nullptr, nullptr);
@@ -1312,7 +1323,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             const bool ffn_mmq = (mmq_q80_applicable(L.gate.type, E, T) && mmq_q80_applicable(L.up.type, E, T)) ||
                                  (mmq_applicable(L.gate.type, E, T) && mmq_applicable(L.up.type, E, T)) ||
                                  (mmq_ksplit_applicable(L.gate.type, E, T) && mmq_ksplit_applicable(L.up.type, E, T)) ||
-                                 (planes_small(L.gate, E, T) && planes_small(L.up, E, T));
+                                 (planes_small(L.gate, E, T) && planes_small(L.up, E, T)) || (q80_copy(L.gate, E, T) && q80_copy(L.up, E, T));
             const bool ffn_ks = mmq_ksplit_preferred(L.gate.type, (int)L.gate.N, E, T, L.gate.planes != nullptr, true) &&
                                 mmq_ksplit_preferred(L.up.type, (int)L.up.N, E, T, L.up.planes != nullptr, true) && !fuse_ffn;
             if (gq && uq && L.gate.type == L.up.type && !ffn_mmq) {

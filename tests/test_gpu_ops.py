@@ -88,11 +88,12 @@ def test_mul_mat_q2_k_q3_k_int_partials_exact_and_value(be, t, K, N, T):
 
 @pytest.mark.parametrize("t", [Q4_0, Q5_0, IQ4_NL])
 @pytest.mark.parametrize("K,N,T", [(256, 3, 1), (2048, 37, 1), (4096, 64, 2), (5632, 10, 3), (2048, 33, 21), (5632, 7, 16), (4096, 20, 8), (11008, 9, 1), (768, 11, 1),
-                                   (2048, 50, 40)])
+                                   (2048, 50, 40), (4096, 300, 129), (14336, 70, 512), (5632, 129, 33)])
 def test_mul_mat_32_element_formats_int_partials_exact_and_value(be, t, K, N, T):
     """Q4_0 / Q5_0 / IQ4_NL tensors (llama-quantize's legacy types and the fallbacks it takes for rows that are not a multiple of 256):
     integer sums per (token, row, 32-block) bit-exact against ggml_vec_dot_q4_0_q8_0 / _q5_0_q8_0 / _iq4_nl_q8_0 as restated in oracle/ (activation:
-    Q8_0 blocks), f32 result within the re-association bound; single tokens, 2..21 tokens (tiled mat-vec) and a 40-token batch."""
+    Q8_0 blocks), f32 result within the re-association bound; single tokens, 2..21 tokens (tiled mat-vec) and batches of 32 tokens and more (the Q8_0
+    matrix-core kernel on an exact Q8_0-layout copy of the tensor)."""
     rng = np.random.default_rng(K + N + t)
     W = rand_weights(rng, t, N * K)
     x = rng.standard_normal((T, K)).astype(np.float32)
