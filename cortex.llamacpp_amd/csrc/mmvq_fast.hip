@@ -43,6 +43,15 @@ __global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
         case T_Q8_0:                                           // pre-quantised Q8_0 planes only in the register form (K <= 4096)
             if constexpr (FUSE != 0 || KB <= 2) run_fast<T_Q8_0, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j);
             break;
+        case T_Q4_0:                                           // the other Q8_0-activation formats: same staging, same limits
+            if constexpr (FUSE != 0 || KB <= 2) run_fast<T_Q4_0, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j);
+            break;
+        case T_Q5_0:
+            if constexpr (FUSE != 0 || KB <= 2) run_fast<T_Q5_0, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j);
+            break;
+        case T_IQ4_NL:
+            if constexpr (FUSE != 0 || KB <= 2) run_fast<T_IQ4_NL, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j);
+            break;
         default: break;
     }
 }
@@ -56,12 +65,12 @@ bool mmvq_fast_applicable(const MMVQArgs &a) {
     const int n = a.epi == EPI_SWIGLU ? 2 : a.n_seg;
     for (int s = 0; s < n; s++) {
         const int t = a.seg[s].type;
-        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q8_0) return false;
+        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && !act_is_q80(t)) return false;
         // segments may mix K-quants and Q8_0 (8-expert files keep attn_k / attn_v in Q8_0): every workgroup stages the
         // activation in the format of ITS segment; pre-quantised planes must exist in that format
         if (a.fuse_mode == 0) {
-            if (t == T_Q8_0 && (kb > 2 || !a.aq0 || !a.ad0)) return false;
-            if (t != T_Q8_0 && (!a.aq || !a.ad || !a.abs)) return false;
+            if (act_is_q80(t) && (kb > 2 || !a.aq0 || !a.ad0)) return false;
+            if (!act_is_q80(t) && (!a.aq || !a.ad || !a.abs)) return false;
         }
     }
     if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;

@@ -141,6 +141,54 @@ template <> struct Raw<T_Q8_0> {
     }
 };
 
+// ---------------------------------------------------------------- Q4_0 / Q5_0 / IQ4_NL (device rows: nibbles K/2 | [qh K/32*4] | f16 scales K/32*2)
+// lane v of a super-block owns 32-block v as for Q8_0: its 16 nibble bytes (elements j in the low nibbles, j + 16 in the high ones: the two halves of
+// the activation slice), the fifth bits (Q5_0) and the block scale; dot products as the formats' scalar vec_dot (oracle/oq_quants.c)
+template <int TYPE> struct RawNib32 {
+    u32x4_t q;
+    uint32_t qh, dh16;
+    __device__ __forceinline__ float probe() const { return (float)(q.x ^ q.y ^ q.z ^ q.w ^ dh16); }
+    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
+        const size_t blk = (size_t)sb * 8 + L.v, half = (size_t)nb * 128, nblk = (size_t)nb * 8;
+        q = ldw(row + blk * 16);
+        if (TYPE == T_Q5_0) {
+            qh = *reinterpret_cast<const uint32_t *>(row + half + blk * 4);
+            dh16 = *reinterpret_cast<const uint16_t *>(row + half + nblk * 4 + blk * 2);
+        } else {
+            qh = 0;
+            dh16 = *reinterpret_cast<const uint16_t *>(row + half + blk * 2);
+        }
+    }
+    static __device__ __forceinline__ uint32_t levels(uint32_t idx) {
+        const uint32_t lo = __builtin_amdgcn_perm(0xf6eaddcfu, 0xbfad9881u, idx & 0x07070707u);
+        const uint32_t hi = __builtin_amdgcn_perm(0x71594535u, 0x26190d01u, idx & 0x07070707u);
+        const uint32_t m = ((idx >> 3) & 0x01010101u) * 0xffu;
+        return (hi & m) | (lo & ~m);
+    }
+    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
+        const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t al[4] = {A.lo.x, A.lo.y, A.lo.z, A.lo.w}, ah[4] = {A.hi.x, A.hi.y, A.hi.z, A.hi.w};
+        int s = 0, asum = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t v0 = qq[w] & 0x0f0f0f0fu, v1 = (qq[w] >> 4) & 0x0f0f0f0fu;
+            if (TYPE == T_IQ4_NL) { s = dot4(levels(v0), al[w], s); s = dot4(levels(v1), ah[w], s); continue; }
+            if (TYPE == T_Q5_0) {
+                v0 |= ((((qh >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4;
+                v1 |= ((((qh >> (16 + 4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4;
+            }
+            s = dot4(v0, al[w], s); s = dot4(v1, ah[w], s);
+            asum = dot4(0x01010101u, al[w], asum); asum = dot4(0x01010101u, ah[w], asum);
+        }
+        if (TYPE == T_Q4_0) { s -= 8 * asum; return ((float)s * h2f((uint16_t)dh16)) * A.yd; }      // sumi * d_x * d_y, left to right
+        if (TYPE == T_Q5_0) s -= 16 * asum;
+        return (h2f((uint16_t)dh16) * A.yd) * (float)s;                                                // (d_x * d_y) * sumi
+    }
+};
+template <> struct Raw<T_Q4_0> : RawNib32<T_Q4_0> {};
+template <> struct Raw<T_Q5_0> : RawNib32<T_Q5_0> {};
+template <> struct Raw<T_IQ4_NL> : RawNib32<T_IQ4_NL> {};
+
 template <int TYPE> __device__ __forceinline__ LaneRole make_role(int lane) {
     LaneRole L;
     L.sbl = lane >> 3; L.v = lane & 7; L.c = L.v >> 1; L.h = L.v & 1;
@@ -155,7 +203,7 @@ struct ActL { const int8_t *qs; const float *d; const int16_t *bs; };
 template <int TYPE>
 __device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const LaneRole &L) {
     ActSlice s;
-    if (TYPE == T_Q8_0) {                                  // (the block-sum region of the LDS layout holds the f32 block scales)
+    if (act_is_q80(TYPE)) {                                // (the block-sum region of the LDS layout holds the f32 block scales)
         const int8_t *a = A.qs + sb * 256 + 32 * L.v;
         s.lo = lds16(a); s.hi = lds16(a + 16);
         s.bs_lo = 0; s.bs_hi = 0;
@@ -188,7 +236,7 @@ __device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const Lane
 template <int TYPE, bool COH = false>
 __device__ __forceinline__ ActSlice global_slice(const MMVQArgs &a, int sb, const LaneRole &L) {
     ActSlice s;
-    if (TYPE == T_Q8_0) {
+    if (act_is_q80(TYPE)) {
         const int qo = sb * 256 + 32 * L.v;
         s.lo = cld16<COH>(a.aq0, qo); s.hi = cld16<COH>(a.aq0, qo + 16);
         s.bs_lo = 0; s.bs_hi = 0;
@@ -415,7 +463,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     // ---- 3. activations into place (workgroup barrier inside the LDS paths: reached by every wave)
     ActL AL{nullptr, nullptr, nullptr};
     if (!DIRECT) {
-        AL = stage_finish<KB, NT, FUSE, TYPE == T_Q8_0>(a, STAGE_REGS_ARGS, smem);
+        AL = stage_finish<KB, NT, FUSE, act_is_q80(TYPE)>(a, STAGE_REGS_ARGS, smem);
         if (ACT_REGS) {
             S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
             if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);

@@ -1379,7 +1379,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             // quantise inside the down-projection's prologue (once per CU, overlapped with its first weight loads)
             // (Q2_K / Q3_K rows go through the generic mat-vec, whose fused prologue takes whole 1024-element passes, at most eight: any other ffn_down width
             // - TinyLlama's 5632, the 8B models' 14336 - quantises in its own launch)
-            const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || L.down.type == T_Q8_0 ||
+            const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || act_is_q80(L.down.type) ||
                                                                ((L.down.type == T_Q2_K || L.down.type == T_Q3_K) && FF <= 8192 && (FF & 1023) == 0)) &&
                                    (FF % 256) == 0 && [](int kb) { return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 14; }((FF + 2047) / 2048);
             if (fuse_down) {
