@@ -40,6 +40,8 @@ __global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
         case T_Q4_K: run_fast<T_Q4_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
         case T_Q5_K: run_fast<T_Q5_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
         case T_Q6_K: run_fast<T_Q6_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
+        case T_Q2_K: run_fast<T_Q2_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
+        case T_Q3_K: run_fast<T_Q3_K, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j); break;
         case T_Q8_0:                                           // pre-quantised Q8_0 planes only in the register form (K <= 4096)
             if constexpr (FUSE != 0 || KB <= 2) run_fast<T_Q8_0, KB, NT, FUSE>(a, a.seg[s], smem, gw, nw, NoSync(), sel_j);
             break;
@@ -65,7 +67,7 @@ bool mmvq_fast_applicable(const MMVQArgs &a) {
     const int n = a.epi == EPI_SWIGLU ? 2 : a.n_seg;
     for (int s = 0; s < n; s++) {
         const int t = a.seg[s].type;
-        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && !act_is_q80(t)) return false;
+        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q2_K && t != T_Q3_K && !act_is_q80(t)) return false;
         // segments may mix K-quants and Q8_0 (8-expert files keep attn_k / attn_v in Q8_0): every workgroup stages the
         // activation in the format of ITS segment; pre-quantised planes must exist in that format
         if (a.fuse_mode == 0) {

@@ -120,6 +120,73 @@ template <> struct Raw<T_Q6_K> {
     }
 };
 
+// ---------------------------------------------------------------- Q2_K (device row planes: qs | scales | (d, dmin))
+// byte l of the 32-byte half n of a super-block holds elements 128 n + 32 j + l in bits 2 j .. 2 j + 1.  Lane (c, h) takes bytes 16 h .. 16 h + 15 of half
+// n = c >> 1 and the fields j = 2 (c & 1) (its low 16-run) and j + 1 (its high one): the activation slice of the Q4_K role (64 c + 16 h, + 32), sub-blocks
+// 4 c + h and 4 c + h + 2 (scale in the low nibble of scales[is], min in the high one)
+template <> struct Raw<T_Q2_K> {
+    u32x4_t q;
+    uint32_t dd, sc_lo, sc_hi;
+    __device__ __forceinline__ float probe() const { return (float)(q.x ^ q.y ^ q.z ^ q.w ^ dd ^ sc_lo ^ sc_hi); }
+    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
+        q = ldw(row + (size_t)sb * 64 + (L.c >> 1) * 32 + L.h * 16);
+        const uint8_t *sc = row + (size_t)nb * 64 + (size_t)sb * 16 + 4 * L.c + L.h;
+        sc_lo = sc[0]; sc_hi = sc[2];
+        dd = *reinterpret_cast<const uint32_t *>(row + (size_t)nb * 80 + (size_t)sb * 4);
+    }
+    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
+        const float d = h2f((uint16_t)(dd & 0xffff)), dmin = h2f((uint16_t)(dd >> 16));
+        const int s0 = 4 * (L.c & 1), s1 = s0 + 2;
+        int dl = 0, dh = 0;
+        dl = dot4((q.x >> s0) & 0x03030303u, A.lo.x, dl); dh = dot4((q.x >> s1) & 0x03030303u, A.hi.x, dh);
+        dl = dot4((q.y >> s0) & 0x03030303u, A.lo.y, dl); dh = dot4((q.y >> s1) & 0x03030303u, A.hi.y, dh);
+        dl = dot4((q.z >> s0) & 0x03030303u, A.lo.z, dl); dh = dot4((q.z >> s1) & 0x03030303u, A.hi.z, dh);
+        dl = dot4((q.w >> s0) & 0x03030303u, A.lo.w, dl); dh = dot4((q.w >> s1) & 0x03030303u, A.hi.w, dh);
+        const int isum = mul24((int)(sc_lo & 15), dl) + mul24((int)(sc_hi & 15), dh);
+        const int msum = mul24((int)(sc_lo >> 4), A.bs_lo) + mul24((int)(sc_hi >> 4), A.bs_hi);
+        return (d * A.yd) * (float)isum - (dmin * A.yd) * (float)msum;
+    }
+};
+
+// ---------------------------------------------------------------- Q3_K (device row planes: hmask | qs | scales | d)
+// the same element layout as Q2_K plus the high-bit mask: bit 4 n + j of hmask[l] SET means "do not subtract 4".  code = (2 bits | hbit << 2) - 4, so
+// sum code * a = dot(2 bits | hbit << 2, a) - 4 * (sum of the 16 activation codes); 6-bit scales (minus 32) unpacked from 12 bytes
+template <> struct Raw<T_Q3_K> {
+    u32x4_t q, hm;
+    uint32_t s0w, s1w, s2w, dh16;
+    __device__ __forceinline__ float probe() const { return (float)(q.x ^ q.y ^ q.z ^ q.w ^ hm.x ^ hm.y ^ hm.z ^ hm.w ^ s0w ^ s1w ^ s2w ^ dh16); }
+    __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
+        hm = ldw(row + (size_t)sb * 32 + L.h * 16);
+        q = ldw(row + (size_t)nb * 32 + (size_t)sb * 64 + (L.c >> 1) * 32 + L.h * 16);
+        const uint32_t *sc = reinterpret_cast<const uint32_t *>(row + (size_t)nb * 96 + (size_t)sb * 12);
+        s0w = sc[0]; s1w = sc[1]; s2w = sc[2];
+        dh16 = *reinterpret_cast<const uint16_t *>(row + (size_t)nb * 108 + (size_t)sb * 2);
+    }
+    __device__ __forceinline__ int scale(int is) const {       // 6-bit scale is (0..15) minus 32
+        const uint32_t lw = (is & 4) ? s1w : s0w;              // bytes 0-3 / 4-7 hold the low nibbles of scales 0-7 and, in their high nibbles, of 8-15
+        const uint32_t b = (lw >> (8 * (is & 3))) & 0xffu;
+        const int low = (is & 8) ? (int)(b >> 4) : (int)(b & 15u);
+        const int high = (int)((s2w >> (8 * (is & 3) + 2 * (is >> 2))) & 3u);
+        return (low | (high << 4)) - 32;
+    }
+    __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
+        const int n = L.c >> 1, j0 = 2 * (L.c & 1);
+        const int s0 = 2 * j0, s1 = s0 + 2, b0 = 4 * n + j0, b1 = b0 + 1;
+        int dl = 0, dh = 0;
+#define Q3L(w, hw) ((((w) >> s0) & 0x03030303u) | ((((hw) >> b0) & 0x01010101u) << 2))
+#define Q3H(w, hw) ((((w) >> s1) & 0x03030303u) | ((((hw) >> b1) & 0x01010101u) << 2))
+        dl = dot4(Q3L(q.x, hm.x), A.lo.x, dl); dh = dot4(Q3H(q.x, hm.x), A.hi.x, dh);
+        dl = dot4(Q3L(q.y, hm.y), A.lo.y, dl); dh = dot4(Q3H(q.y, hm.y), A.hi.y, dh);
+        dl = dot4(Q3L(q.z, hm.z), A.lo.z, dl); dh = dot4(Q3H(q.z, hm.z), A.hi.z, dh);
+        dl = dot4(Q3L(q.w, hm.w), A.lo.w, dl); dh = dot4(Q3H(q.w, hm.w), A.hi.w, dh);
+#undef Q3L
+#undef Q3H
+        const int is = 4 * L.c + L.h;
+        const int isum = mul24(scale(is), dl - 4 * A.bs_lo) + mul24(scale(is + 2), dh - 4 * A.bs_hi);
+        return (h2f((uint16_t)dh16) * A.yd) * (float)isum;
+    }
+};
+
 // ---------------------------------------------------------------- Q8_0 (device row planes: codes K | f16 scales K/32)
 // lane v of a super-block owns 32-block v: its 32 codes (two 16-byte pieces) and the block scale; the activation is
 // Q8_0 too (ActSlice: lo / hi = the block's 32 codes, yd = its f16 scale), dot = (float)isum * (d_w * d_a) per block

@@ -1377,10 +1377,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             prof_mark("ffn_gate_up");
             static const bool fuse_down_env = !(getenv("MI355_FUSE_DOWN") && getenv("MI355_FUSE_DOWN")[0] == '0');
             // quantise inside the down-projection's prologue (once per CU, overlapped with its first weight loads)
-            // (Q2_K / Q3_K rows go through the generic mat-vec, whose fused prologue takes whole 1024-element passes, at most eight: any other ffn_down width
-            // - TinyLlama's 5632, the 8B models' 14336 - quantises in its own launch)
+            // (the widths listed are the ones the register-ring and weight-stream kernels take; the generic mat-vec's fused prologue would refuse others)
             const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || act_is_q80(L.down.type) ||
-                                                               ((L.down.type == T_Q2_K || L.down.type == T_Q3_K) && FF <= 8192 && (FF & 1023) == 0)) &&
+                                                               L.down.type == T_Q2_K || L.down.type == T_Q3_K) &&
                                    (FF % 256) == 0 && [](int kb) { return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 14; }((FF + 2047) / 2048);
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
