@@ -23,75 +23,115 @@ namespace {
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int Q80_UNROLL = 4;
 
+// MT token tiles of 32 per wave: a workgroup covers 128 weight rows x 32 MT tokens, so every weight byte is fetched T / (32 MT) times instead of T / 32
+// (with MT = 1 an 8B-shaped prompt is bound by those re-reads out of L2: 8.5k tok/s).  The activation scales are staged per chunk of Q80_KC blocks.
+constexpr int Q80_KC = 64;
+
+template <int MT>
 __global__ __launch_bounds__(256) void mmq_q80_kernel(const uint8_t *__restrict__ W, size_t row_bytes, int n_rows, int K, int T,
                                                       const int8_t *__restrict__ aq, const uint16_t *__restrict__ ad, float *__restrict__ out,
                                                       int ld_out, const float *__restrict__ resid) {
-    extern __shared__ __attribute__((aligned(16))) float s_da[];      // [K / 32][32 tokens]
+    __shared__ __attribute__((aligned(16))) float s_da[Q80_KC * 32 * MT];      // [block of the chunk][token of the workgroup's tile]
+    constexpr int TT = 32 * MT;
     const int nb = K >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kg = lane >> 5;
-    const int t0 = blockIdx.y * 32, r0 = blockIdx.x * 128 + wave * 32;
-    for (int i = tid; i < nb * 32; i += 256) {
-        const int b = i >> 5, m = i & 31;
-        const int t = t0 + m < T ? t0 + m : T - 1;
-        s_da[i] = h2f(ad[(size_t)t * nb + b]);
-    }
-    __syncthreads();
-    if (r0 >= n_rows) return;                                          // (after the barrier: wave-uniform)
+    const int t0 = blockIdx.y * TT, r0 = blockIdx.x * 128 + wave * 32;
+    const bool rows_ok = r0 < n_rows;                                  // (wave-uniform; such a wave still takes part in the barriers)
     const int row = r0 + n < n_rows ? r0 + n : n_rows - 1;
     const uint8_t *wrow = W + (size_t)row * row_bytes + 16 * kg;
     const uint16_t *wd = reinterpret_cast<const uint16_t *>(W + (size_t)row * row_bytes + K);
-    const int tok = t0 + n < T ? t0 + n : T - 1;
-    const int8_t *arow = aq + (size_t)tok * K + 16 * kg;
-    float facc[16];
+    const int8_t *arow[MT];
 #pragma unroll
-    for (int r = 0; r < 16; r++) facc[r] = 0.0f;
+    for (int m = 0; m < MT; m++) {
+        const int tok = t0 + 32 * m + n < T ? t0 + 32 * m + n : T - 1;
+        arow[m] = aq + (size_t)tok * K + 16 * kg;
+    }
+    float facc[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) facc[m][r] = 0.0f;
     i32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; r++) z[r] = 0;
 
-    auto fold = [&](const i32x16 &c, float dw, int b) {
+    // per output and block: scale = d_w * d_a (exact: two f16 values), product = (float)isum * scale, sum += product - the CPU's three roundings in the CPU's
+    // order; written on pairs so that the multiplies and the add become v_pk_mul_f32 / v_pk_add_f32 (two outputs per instruction, same IEEE results)
+    auto fold = [&](const i32x16 &c, float dw, int bl, int m) {        // bl: block within the chunk
+        const f32x2 dw2 = {dw, dw};
 #pragma unroll
         for (int rq = 0; rq < 4; rq++) {
-            const f32x4 da4 = *reinterpret_cast<const f32x4 *>(s_da + b * 32 + 8 * rq + 4 * kg);    // tokens 8 rq + 4 kg + (0..3)
+            const f32x4 da4 = *reinterpret_cast<const f32x4 *>(s_da + bl * TT + 32 * m + 8 * rq + 4 * kg);    // tokens 8 rq + 4 kg + (0..3) of tile m
 #pragma unroll
-            for (int ri = 0; ri < 4; ri++) facc[rq * 4 + ri] += (float)c[rq * 4 + ri] * (dw * da4[ri]);
-        }
-    };
-    int b = 0;
-    for (; b + Q80_UNROLL <= nb; b += Q80_UNROLL) {                    // the loads of a group are issued before its first MFMA
-        i32x4 a[Q80_UNROLL], w[Q80_UNROLL];
-        uint16_t dh[Q80_UNROLL];
-#pragma unroll
-        for (int u = 0; u < Q80_UNROLL; u++) {
-            a[u] = *reinterpret_cast<const i32x4 *>(arow + (size_t)(b + u) * 32);
-            w[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(wrow + (size_t)(b + u) * 32));
-            dh[u] = wd[b + u];
-        }
-#pragma unroll
-        for (int u = 0; u < Q80_UNROLL; u++) {
-            const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[u], w[u], z, 0, 0, 0);
-            fold(c, h2f(dh[u]), b + u);
-        }
-    }
-    for (; b < nb; b++) {
-        const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + (size_t)b * 32);
-        const i32x4 w = *reinterpret_cast<const i32x4 *>(wrow + (size_t)b * 32);
-        const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, z, 0, 0, 0);
-        fold(c, h2f(wd[b]), b);
-    }
-    if (r0 + n < n_rows) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int t = t0 + 8 * (r >> 2) + 4 * kg + (r & 3);
-            if (t < T) {
-                const size_t o = (size_t)t * ld_out + row;
-                out[o] = resid ? resid[o] + facc[r] : facc[r];
+            for (int rp = 0; rp < 2; rp++) {
+                const f32x2 da2 = {da4[2 * rp], da4[2 * rp + 1]};
+                const f32x2 cf = {(float)c[rq * 4 + 2 * rp], (float)c[rq * 4 + 2 * rp + 1]};
+                const f32x2 sc = dw2 * da2;
+                const f32x2 pr = cf * sc;
+                f32x2 acc = {facc[m][rq * 4 + 2 * rp], facc[m][rq * 4 + 2 * rp + 1]};
+                acc = acc + pr;
+                facc[m][rq * 4 + 2 * rp] = acc.x; facc[m][rq * 4 + 2 * rp + 1] = acc.y;
             }
         }
+    };
+    for (int b0 = 0; b0 < nb; b0 += Q80_KC) {
+        const int nbc = nb - b0 < Q80_KC ? nb - b0 : Q80_KC;
+        __syncthreads();                                               // everyone is done with the previous chunk's scales
+        for (int i = tid; i < nbc * TT; i += 256) {
+            const int b = i / TT, m = i - b * TT;
+            const int t = t0 + m < T ? t0 + m : T - 1;
+            s_da[i] = h2f(ad[(size_t)t * nb + b0 + b]);
+        }
+        __syncthreads();
+        if (!rows_ok) continue;
+        int b = 0;
+        for (; b + Q80_UNROLL <= nbc; b += Q80_UNROLL) {               // the loads of a group are issued before its first MFMA
+            i32x4 w[Q80_UNROLL];
+            uint16_t dh[Q80_UNROLL];
+#pragma unroll
+            for (int u = 0; u < Q80_UNROLL; u++) {
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(wrow + (size_t)(b0 + b + u) * 32));
+                dh[u] = wd[b0 + b + u];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                i32x4 a[Q80_UNROLL];
+#pragma unroll
+                for (int u = 0; u < Q80_UNROLL; u++) a[u] = *reinterpret_cast<const i32x4 *>(arow[m] + (size_t)(b0 + b + u) * 32);
+#pragma unroll
+                for (int u = 0; u < Q80_UNROLL; u++) {
+                    const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[u], w[u], z, 0, 0, 0);
+                    fold(c, h2f(dh[u]), b + u, m);
+                }
+            }
+        }
+        for (; b < nbc; b++) {
+            const i32x4 w = *reinterpret_cast<const i32x4 *>(wrow + (size_t)(b0 + b) * 32);
+            const float dw = h2f(wd[b0 + b]);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(arow[m] + (size_t)(b0 + b) * 32);
+                const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, z, 0, 0, 0);
+                fold(c, dw, b, m);
+            }
+        }
+    }
+    if (rows_ok && r0 + n < n_rows) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = t0 + 32 * m + 8 * (r >> 2) + 4 * kg + (r & 3);
+                if (t < T) {
+                    const size_t o = (size_t)t * ld_out + row;
+                    out[o] = resid ? resid[o] + facc[m][r] : facc[m][r];
+                }
+            }
     }
 }
 
@@ -142,10 +182,18 @@ bool mmq_q80_applicable(int type, int K, int T) { return type == T_Q8_0 && T >= 
 hipError_t launch_mmq_q80(const uint8_t *W, size_t row_bytes, int n_rows, int K, int T, const ActQuant &q, float *out, int ld_out,
                           const float *resid, hipStream_t st) {
     if (!mmq_q80_applicable(T_Q8_0, K, T) || !q.qs0 || !q.d0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(K >> 5) * 32 * sizeof(float);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_q80_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((T + 31) / 32));
-    hipLaunchKernelGGL(mmq_q80_kernel, grid, dim3(256), lds, st, W, row_bytes, n_rows, K, T, q.qs0, q.d0, out, ld_out, resid);
+    // four token tiles per wave once that still leaves a workgroup per CU; each output keeps its own block order, so the result does not depend on MT
+    const long wg4 = (long)((n_rows + 127) / 128) * ((T + 127) / 128);
+    if (T >= 128 && wg4 >= num_cu()) {
+        const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((T + 127) / 128));
+        hipLaunchKernelGGL((mmq_q80_kernel<4>), grid, dim3(256), 0, st, W, row_bytes, n_rows, K, T, q.qs0, q.d0, out, ld_out, resid);
+    } else if (T >= 64 && wg4 * 2 >= num_cu()) {
+        const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((T + 63) / 64));
+        hipLaunchKernelGGL((mmq_q80_kernel<2>), grid, dim3(256), 0, st, W, row_bytes, n_rows, K, T, q.qs0, q.d0, out, ld_out, resid);
+    } else {
+        const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((T + 31) / 32));
+        hipLaunchKernelGGL((mmq_q80_kernel<1>), grid, dim3(256), 0, st, W, row_bytes, n_rows, K, T, q.qs0, q.d0, out, ld_out, resid);
+    }
     return hipGetLastError();
 }
 
