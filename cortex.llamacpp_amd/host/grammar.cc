@@ -310,6 +310,7 @@ std::shared_ptr<const Grammar> Grammar::parse(const std::string &text, std::stri
 }
 
 // ---------------------------------------------------------------------------------------------------------------- matching
+static constexpr size_t kMaxStacks = 8192;
 GrammarMatcher::GrammarMatcher(std::shared_ptr<const Grammar> g) : g_(std::move(g)) { reset(); }
 
 void GrammarMatcher::reset() {
@@ -345,6 +346,7 @@ void GrammarMatcher::settle(Stack st, std::vector<Stack> &out) const {
         return;
     }
     for (const auto &o : out) if (same(o, st)) return;
+    if (out.size() >= kMaxStacks) return;      // a pathologically ambiguous grammar: keep what there is rather than grow without bound
     out.push_back(std::move(st));
 }
 
