@@ -1234,6 +1234,26 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
 #pragma unroll
             for (int rq = 0; rq < 4; rq++) {
                 const f32x4 yd4 = *reinterpret_cast<const f32x4 *>(s_yd + tl + 8 * rq + 4 * kg);
+#ifndef MI355_P2_SCALAR_FOLD
+                // the fold's f32 operations on pairs (v_pk_mul_f32 / v_pk_fma_f32: identical IEEE results, bit-identical to the scalar form below and to the
+                // per-lane kernel; measured 1 % (Q4_K) to 3 % (Q6_K) per launch)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int rp = 0; rp < 2; rp++) {
+                    const int r0 = rq * 4 + 2 * rp, r1 = r0 + 1;
+                    const f32x2 cf = {(float)((H[t][r0] << SH) + L[t][r0]), (float)((H[t][r1] << SH) + L[t][r1])};
+                    const f32x2 yd2 = {yd4[2 * rp], yd4[2 * rp + 1]}, dd2 = {dd, dd};
+                    f32x2 acc = {facc[t][r0], facc[t][r1]};
+                    if (MINS) {
+                        const f32x2 ndm2 = {ndm, ndm}, ms2 = {ms[r0], ms[r1]};
+                        const f32x2 t0 = __builtin_elementwise_fma(dd2, cf, ndm2 * ms2);
+                        acc = __builtin_elementwise_fma(yd2, t0, acc);
+                    } else {
+                        acc = __builtin_elementwise_fma(yd2 * dd2, cf, acc);
+                    }
+                    facc[t][r0] = acc.x; facc[t][r1] = acc.y;
+                }
+#else
 #pragma unroll
                 for (int ri = 0; ri < 4; ri++) {
                     const int r = rq * 4 + ri;
@@ -1247,6 +1267,7 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
                         facc[t][r] = fmaf(yd * dd, (float)isum, facc[t][r]);
                     }
                 }
+#endif
             }
 #ifndef MI355_P2_NOFB
             __builtin_amdgcn_sched_barrier(0);                   // one tile's block-sum accumulator at a time (four at once spill)
