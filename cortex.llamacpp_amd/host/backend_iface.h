@@ -62,6 +62,9 @@ class IBackend {
     virtual int topk_max_k() const { return 0; }      // 0: no device front end
     virtual int topk_max_adj() const { return 0; }
     // llama_set_embeddings / llama_get_embeddings_ith (llama_server_context.cc:299, 1042-1044)
+    // {arch}.pooling_type of the model: 0 none (an embedding request answers with the hidden state of its last token, llama_get_embeddings_ith), 1 mean,
+    // 2 cls, 3 last (llama_get_embeddings_seq: pooled over the sequence's tokens; src/llama_server_context.cc:1041-1044)
+    virtual int pooling_type() const { return 0; }
     virtual void set_embeddings(bool on) = 0;
     virtual const float *embeddings_ith(int i) = 0;
     virtual void kv_clear() = 0;

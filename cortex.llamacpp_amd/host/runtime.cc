@@ -65,6 +65,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     hp.n_expert = (int)f.get_u(a + "expert_count", 0);
     hp.n_expert_used = (int)f.get_u(a + "expert_used_count", 0);
     hp.n_ctx_train = (int)f.get_u(a + "context_length", 0);
+    hp.pooling_type = (int)f.get_u(a + "pooling_type", 0);
     if (hp.n_embd <= 0 || hp.n_layer <= 0 || hp.n_head <= 0) { err = "missing hyper-parameters for arch " + hp.arch; status = -102; return nullptr; }
     if (hp.n_layer > 1024 || hp.n_embd > (1 << 20) || hp.n_head > 4096) { err = "implausible hyper-parameters for arch " + hp.arch; status = -102; return nullptr; }
     // the head counts size buffers and pick kernels: check them here, not at the first decode

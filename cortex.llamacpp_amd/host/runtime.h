@@ -43,6 +43,7 @@ struct HParams {
     std::string arch;
     int n_embd = 0, n_layer = 0, n_ff = 0, n_head = 0, n_head_kv = 0, n_rot = 0, n_vocab = 0;
     int n_expert = 0, n_expert_used = 0, head_dim = 0, n_ctx_train = 0;
+    int pooling_type = 0;          // {arch}.pooling_type: 0 none, 1 mean, 2 cls, 3 last (what llama_get_embeddings_seq pools over a sequence's tokens)
     float eps = 1e-5f, rope_base = 10000.0f, rope_scale = 1.0f;
     int rope_neox = 0;
     // row split: n_head, n_head_kv and n_ff above are THIS RANK's share; the file's values are kept here.

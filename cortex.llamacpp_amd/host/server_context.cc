@@ -323,7 +323,30 @@ void LlamaServerContext::SendEmbedding(LlamaClientSlot &slot, int batch_index) {
     res.id = slot.task_id; res.error = false; res.stop = true;
     const int n_embd = be_->n_embd();
     std::vector<float> embd_res((size_t)n_embd, 0.0f);
-    const float *embd = be_->embeddings_ith(batch_index);
+    // llama_get_embeddings_seq where the model pools (mean over the prompt's tokens / its first token; "last" is the flagged row itself), else
+    // llama_get_embeddings_ith of the last token (:1041-1044).  A pooled prompt had every token flagged when it was queued (UpdateSlots).
+    const int pool = be_->pooling_type();
+    const int n_rows = (pool == 1 || pool == 2) ? slot.num_prompt_tokens_processed : 1;
+    std::vector<float> pooled;
+    const float *embd = nullptr;
+    if (pool == 1 && n_rows > 0 && batch_index - n_rows + 1 >= 0) {
+        pooled.assign((size_t)n_embd, 0.0f);
+        bool ok = true;
+        for (int r = 0; r < n_rows && ok; r++) {
+            const float *e = be_->embeddings_ith(batch_index - n_rows + 1 + r);
+            if (!e) { ok = false; break; }
+            for (int i = 0; i < n_embd; i++) pooled[(size_t)i] += e[i];      // token order, f32: the order of ggml's mean pooling mat-mul over the batch rows
+        }
+        if (ok) {
+            const float inv = 1.0f / (float)n_rows;
+            for (int i = 0; i < n_embd; i++) pooled[(size_t)i] *= inv;
+            embd = pooled.data();
+        }
+    } else if (pool == 2 && batch_index - n_rows + 1 >= 0) {
+        embd = be_->embeddings_ith(batch_index - n_rows + 1);
+    } else {
+        embd = be_->embeddings_ith(batch_index);
+    }
     if (embd) {                                          // common_embd_normalize(embd, out, n, 2): Euclidean norm in double
         double sum = 0.0;
         for (int i = 0; i < n_embd; i++) sum += (double)embd[i] * (double)embd[i];
@@ -619,8 +642,8 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                     continue;
                 }
                 slot.smpl->reset();
-                if (!slot.params.cache_prompt) {
-                    slot.n_past = 0;
+                if (!slot.params.cache_prompt || (slot.embedding && (be_->pooling_type() == 1 || be_->pooling_type() == 2))) {
+                    slot.n_past = 0;                       // (a pooled embedding needs every token of the prompt in this batch)
                 } else {
                     for (int32_t t : prompt_tokens) slot.smpl->accept(t, false);
                     slot.n_past = (int32_t)common_part(slot.cache_tokens, prompt_tokens);
@@ -638,7 +661,8 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
             }
             slot.cache_tokens.resize((size_t)slot.n_past);
             for (; slot.n_past < (int)prompt_tokens.size() && n_tokens < (int)b_token_.size(); ++slot.n_past) {
-                batch_add(prompt_tokens[(size_t)slot.n_past], slot.n_past, slot.id, false);
+                // (an embedding prompt of a model that pools over the sequence needs every token's hidden state: all rows flagged)
+                batch_add(prompt_tokens[(size_t)slot.n_past], slot.n_past, slot.id, slot.embedding && (be_->pooling_type() == 1 || be_->pooling_type() == 2));
                 if (slot.params.cache_prompt) slot.cache_tokens.push_back(prompt_tokens[(size_t)slot.n_past]);
                 slot.num_prompt_tokens_processed++;
             }

@@ -94,6 +94,9 @@ struct FakeBackend : IBackend {
         return 0;
     }
     bool embd_on = false;
+    int pooling = 0;
+    int pooling_type() const override { return pooling; }
+    std::vector<std::vector<float>> embd_rows;
     std::vector<float> embd_row;
     void set_embeddings(bool on) override { embd_on = on; embd_flags.push_back(on); }
     std::vector<bool> embd_flags;
@@ -1013,6 +1016,42 @@ static void test_embeddings() {
     eng.HandleChatCompletion(chat, wait_cb);
     { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
     CHECK(status["status_code"].as_int() == 200 && body["object"].as_string() == "chat.completion");
+
+    // models whose metadata asks for pooling over the sequence (llama_get_embeddings_seq): mean of the tokens' hidden states / the first token's
+    for (int pool : {1, 2, 3}) {
+        FakeBackend *fb = nullptr;
+        LlamaEngine pe([&](const Json &, BackendInfo &, std::string &) -> std::unique_ptr<IBackend> { fb = new FakeBackend(); fb->pooling = pool; return std::unique_ptr<IBackend>(fb); });
+        Json pl = Json::object();
+        pl["llama_model_path"] = "/models/pool.gguf";
+        pe.LoadModel(pl, [&](Json &&st, Json &&) { code = (int)st["status_code"].as_int(); });
+        CHECK(code == 200 && fb);
+        Json pr = Json::object();
+        pr["model"] = "pool"; pr["input"] = "hello world";
+        done = false;
+        pe.HandleEmbedding(pr, wait_cb);
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+        CHECK(status["status_code"].as_int() == 200 && body["data"].size() == 1);
+        const std::vector<int32_t> tk = fb->calls_tokens.back();
+        CHECK(tk.size() == 3);
+        std::vector<double> want(8, 0.0);
+        auto f = [](int tok, int k) { return (double)((tok + 3 * k) % 7) - 3.0; };
+        for (int k = 0; k < 8; k++) {
+            if (pool == 1) { float acc = 0.0f; for (int32_t t : tk) acc += (float)f(t, k); want[(size_t)k] = (double)(acc * (1.0f / 3.0f)); }
+            else want[(size_t)k] = f(pool == 2 ? tk.front() : tk.back(), k);
+        }
+        double nn = 0;
+        for (double v : want) nn += v * v;
+        nn = std::sqrt(nn);
+        const Json &pe8 = body["data"].at(0)["embedding"];
+        bool same = pe8.size() == 8;
+        for (int k = 0; same && k < 8; k++) same = std::fabs(pe8.at((size_t)k).as_double() - want[(size_t)k] / nn) < 1e-6;
+        CHECK(same);
+        // every token of a pooled prompt was flagged; with "last" only the last one
+        const auto &fl = fb->last_flag_index;
+        int flagged = 0;
+        for (int v : fl) flagged += v >= 0;
+        CHECK(flagged == (pool == 3 ? 1 : 3));
+    }
 }
 
 // `host_tests --api-shapes`: runs the engine façade over the fake backend through the request kinds of the reference's surface and prints every status /

@@ -258,3 +258,49 @@ def test_grammar_and_response_format_constrain_the_text(pkg, tiny_vocab_model, t
     st, body = e.load_model(llama_model_path=tiny_vocab_model, model="other", grammar_file=str(tmp_path / "missing.gbnf"))
     assert st["status_code"] == 500
     e.close()
+
+
+def test_pooled_embeddings_follow_the_model_metadata(pkg, tmp_path):
+    """{arch}.pooling_type (llama_get_embeddings_seq, src/llama_server_context.cc:1041-1044): a model that asks for MEAN pooling answers an embedding request
+    with the L2-normalised mean of its tokens' final hidden states, CLS with the first token's.  Checked against the same weights WITHOUT the key (pooling
+    none = last token): the hidden state of token i of a causal model is the last-token state of the prompt's first i + 1 tokens."""
+    gs = pkg.gguf_synth
+    base = gs.CONFIGS["tiny-d128"]
+    import dataclasses
+    paths = {}
+    for name, extra in (("none", {}), ("mean", {"pooling_type": 1}), ("cls", {"pooling_type": 2})):
+        cfg = dataclasses.replace(base, extra=extra)
+        paths[name] = str(tmp_path / f"pool-{name}.gguf")
+        gs.write_synthetic_llama(paths[name], cfg, "q4_k_m", with_vocab=True)
+    toks = [1, 300, 301, 302, 303, 304, 305]
+
+    def embed(path, tokens):
+        e = pkg.Engine()
+        st, body = e.load_model(llama_model_path=path, ctx_len=256, model="m")
+        assert st["status_code"] == 200, (st, body)
+        out = []
+        for t in tokens:
+            st, b = e.embedding(model="m", input=[t])
+            assert st["status_code"] == 200, (st, b)
+            out.append(np.asarray(b["data"][0]["embedding"], np.float64))
+        e.close()
+        return out
+
+    # per-token hidden states (normalised) from the pooling-free file: the engine normalises, so un-normalised states are not available - compare directions:
+    # CLS must equal the first prefix's embedding; MEAN is checked through the raw C-ABI embeddings below
+    prefixes = embed(paths["none"], [toks[:i + 1] for i in range(len(toks))])
+    cls = embed(paths["cls"], [toks])[0]
+    assert np.allclose(cls, prefixes[0], atol=1e-6)
+    last = embed(paths["none"], [toks])[0]
+    assert np.allclose(last, prefixes[-1], atol=2e-3)            # (a batch of 7 and a batch of 1 take different kernels: the rounding-flip level)
+    # MEAN against the un-normalised hidden states of every token, read through the C-ABI (all rows flagged, embeddings on)
+    m = pkg.Model(paths["none"])
+    c = pkg.Context(m, n_ctx=256)
+    c.set_embeddings(True)
+    assert c.decode(toks, list(range(len(toks))), logits=np.ones(len(toks), np.int8)) == 0
+    rows = np.stack([c.embeddings(i) for i in range(len(toks))]).astype(np.float32)
+    c.close(); m.close()
+    want = rows.sum(axis=0, dtype=np.float32) * np.float32(1.0 / len(toks))
+    want = want.astype(np.float64) / np.linalg.norm(want.astype(np.float64))
+    mean = embed(paths["mean"], [toks])[0]
+    assert np.allclose(mean, want, atol=1e-6), float(np.abs(mean - want).max())
