@@ -210,7 +210,7 @@ template <> struct Raw<T_Q8_0> {
 
 // ---------------------------------------------------------------- Q4_0 / Q5_0 / IQ4_NL (device rows: nibbles K/2 | [qh K/32*4] | f16 scales K/32*2)
 // lane v of a super-block owns 32-block v as for Q8_0: its 16 nibble bytes (elements j in the low nibbles, j + 16 in the high ones: the two halves of
-// the activation slice), the fifth bits (Q5_0) and the block scale; dot products as the formats' scalar vec_dot (oracle/oq_quants.c)
+// the activation slice), the fifth bits (Q5_0) and the block scale; dot products as the formats' scalar ggml_vec_dot_*_q8_0
 template <int TYPE> struct RawNib32 {
     u32x4_t q;
     uint32_t qh, dh16;
