@@ -95,6 +95,7 @@ SYMBOLS = {
     "mi355_op_ffn_gate_up": (C.c_int, [_i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "mi355_op_rms_norm_mul": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
     "mi355_op_rope": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _i32]),
+    "mi355_op_rope_yarn": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _i32, _f32, _f32, _f32, _f32]),
     "mi355_op_get_rows": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _vp]),
     "mi355_op_swiglu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mi355_op_soft_max": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
@@ -230,6 +231,14 @@ class Backend:
         ff = None if freq_factors is None else np.ascontiguousarray(freq_factors, np.float32)
         self._chk(self.lib.mi355_op_rope(_ptr(y), n_head, head_dim, n_rot or head_dim, _ptr(pos), pos.size, base, freq_scale,
                                          _ptr(ff), int(neox)), "op_rope")
+        return y.reshape(pos.size, n_head, head_dim)
+
+    def rope_yarn(self, x: np.ndarray, n_head: int, head_dim: int, pos, base: float, freq_scale: float, ext_factor: float, attn_factor: float,
+                  corr_lo: float, corr_hi: float, neox: bool = False, n_rot=None) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, np.int32).reshape(-1)
+        y = np.array(x, np.float32, copy=True).reshape(pos.size, n_head * head_dim)
+        self._chk(self.lib.mi355_op_rope_yarn(_ptr(y), n_head, head_dim, n_rot or head_dim, _ptr(pos), pos.size, base, freq_scale, None, int(neox),
+                                              ext_factor, attn_factor, corr_lo, corr_hi), "op_rope_yarn")
         return y.reshape(pos.size, n_head, head_dim)
 
     def get_rows(self, t: int, table: np.ndarray, K: int, n_rows: int, ids) -> np.ndarray:

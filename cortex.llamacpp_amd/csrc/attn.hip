@@ -21,14 +21,20 @@ namespace mi355 {
 // ------------------------------------------------------------------------------------------
 // cos/sin table of one position: theta_0 = pos, theta_{i+1} = theta_i * theta_scale, iterated in f32
 // exactly like ggml_rope_cache_init, so the angles match the CPU path bit for bit (cosf/sinf within libm ulp).
-__device__ __forceinline__ void rope_angle(int i_pair, int32_t pos, float theta_scale, float freq_scale, const float *ff,
-                                           float &c, float &s) {
+__device__ __forceinline__ void rope_angle(int i_pair, int32_t pos, float theta_scale, const RopeArgs &ra, float &c, float &s) {
     float theta = (float)pos;
     for (int k = 0; k < i_pair; k++) theta *= theta_scale;
-    const float f = ff ? ff[i_pair] : 1.0f;
-    const float th = freq_scale * (theta / f);
-    c = cosf(th);
-    s = sinf(th);
+    const float f = ra.freq_factors ? ra.freq_factors[i_pair] : 1.0f;
+    const float extrap = theta / f;
+    float th = ra.freq_scale * extrap, m = ra.attn_factor;
+    if (ra.ext_factor != 0.0f) {     // YaRN (rope_yarn): ramp 1 below corr_lo (the original angle), 0 above corr_hi (the interpolated one)
+        const float y = ((float)i_pair - ra.corr_lo) / fmaxf(0.001f, ra.corr_hi - ra.corr_lo);
+        const float mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * ra.ext_factor;
+        th = th * (1.0f - mix) + extrap * mix;
+        m *= 1.0f + 0.1f * logf(1.0f / ra.freq_scale);
+    }
+    c = cosf(th) * m;
+    s = sinf(th) * m;
 }
 
 __device__ __forceinline__ void rope_heads_lds(float *buf, int n_head, int D, int n_rot, int neox, const float *cs, int tid, int nthr) {
@@ -95,7 +101,7 @@ __global__ void rope_table_kernel(const int32_t *tok_pos, int T, RopeArgs ra, fl
     if (idx >= T * half) return;
     const int t = idx / half, i = idx - t * half;
     float c, s;
-    rope_angle(i, tok_pos[t], theta_scale, ra.freq_scale, ra.freq_factors, c, s);
+    rope_angle(i, tok_pos[t], theta_scale, ra, c, s);
     cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
     cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
 }
@@ -123,7 +129,7 @@ __global__ void step_setup_kernel(const int32_t *tok_pos, int T, RopeArgs ra, fl
     if (idx >= T * half) return;
     const int t = idx / half, i = idx - t * half;
     float c, s;
-    rope_angle(i, tok_pos[t], theta_scale, ra.freq_scale, ra.freq_factors, c, s);
+    rope_angle(i, tok_pos[t], theta_scale, ra, c, s);
     cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
     cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
 }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void step_setup_embed_kernel(const int32_t *to
     if (lin < T * half) {
         const int t = lin / half, i = lin - t * half;
         float c, s;
-        rope_angle(i, tok_pos[t], theta_scale, ra.freq_scale, ra.freq_factors, c, s);
+        rope_angle(i, tok_pos[t], theta_scale, ra, c, s);
         cs_out[(size_t)t * ra.n_rot + 2 * i] = c;
         cs_out[(size_t)t * ra.n_rot + 2 * i + 1] = s;
     }
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(float *q, const floa
         for (int i = tid; i < ra.n_rot; i += 256) cs[i] = cs_table[(size_t)t * ra.n_rot + i];
     } else {
         const int32_t pos = tok_pos[t];
-        for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, pos, theta_scale, ra.freq_scale, ra.freq_factors, cs[2 * i], cs[2 * i + 1]);
+        for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, pos, theta_scale, ra, cs[2 * i], cs[2 * i + 1]);
     }
     if (k) for (int e = tid; e < G * D; e += 256) kbuf[e] = k[(size_t)t * G * D + e];
     __syncthreads();
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void k_shift_kernel(KVLayerView kv, int type_k
     const int32_t dl = delta[cell];
     if (dl == 0) return;
     float *cs = sm, *kbuf = sm + ra.n_rot;
-    for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, dl, theta_scale, ra.freq_scale, ra.freq_factors, cs[2 * i], cs[2 * i + 1]);
+    for (int i = tid; i < (ra.n_rot >> 1); i += 256) rope_angle(i, dl, theta_scale, ra, cs[2 * i], cs[2 * i + 1]);
     for (int e = tid; e < G * D; e += 256) {
         const int g = e / D, dd = e - g * D;
         const size_t rowi = (size_t)g * n_ctx + cell;
@@ -687,7 +693,7 @@ namespace mi355 {
 
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
-    return a.D == 128 && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 64 && a.n_kv_max <= 64 * 2048 &&
+    return (a.D == 128 || a.D == 64) && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 64 && a.n_kv_max <= 64 * 2048 &&
            (a.type_k == T_F16 || a.type_k == T_Q8_0) && (a.type_v == T_F16 || a.type_v == T_Q8_0);
 }
 int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }
@@ -702,8 +708,9 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     DecodeFuse nofz{};
     const bool store = knew && vnew && tok_cell;
     if (store) { nofz.knew = knew; nofz.vnew = vnew; nofz.tok_cell = tok_cell; }
-#define FAD(RR, TK, TV) do { if (store) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); \
-                             else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, false>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); } while (0)
+#define FAD_D(RR, TK, TV, DD) do { if (store) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, false, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); \
+                                   else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, false, false, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); } while (0)
+#define FAD(RR, TK, TV) do { if (a.D == 64) FAD_D(RR, TK, TV, 64); else FAD_D(RR, TK, TV, 128); } while (0)
 #define FAD_T(RR)                                                              \
     if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
@@ -718,6 +725,7 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     }
 #undef FAD_T
 #undef FAD
+#undef FAD_D
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nblk = (a.H * a.D) >> 8;
@@ -731,8 +739,9 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
 // Single-token step in ONE launch: K rope + KV store + attention + split merge + quantise (see DecodeFuse).
 bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
-    // (R = 1: two kv heads share a merge ticket, see attn_decode_dev.h)
-    return a.T == 1 && flash_attn_decode_applicable(a, ra) && (R == 2 || R == 4 || R == 8 || (R == 1 && a.G % 2 == 0)) && (ra.n_rot % 4) == 0 && a.splits <= 64;
+    // (R * D < 256: 256 / (R * D) neighbouring kv heads share a merge ticket, see attn_decode_dev.h)
+    const int gp = (R * a.D) % 256 == 0 ? 1 : 256 / (R * a.D);
+    return a.T == 1 && flash_attn_decode_applicable(a, ra) && a.G % gp == 0 && (ra.n_rot % 4) == 0 && a.splits <= 64;
 }
 // diagnosis: MI355_ATTN_PROBE=1 makes the fused decode attention stamp its phases (DecodeFuse::probe); the stamps of the
 // LAST launch are summarised on stderr by attn_probe_report() (called when a context is destroyed)
@@ -783,8 +792,9 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     // once serialise (tools/bench_gridbar.hip: 25 us for 512).  Measured on the 8B step: 424 -> 448 tok/s at 4000 cells.
     // MI355_ATTN_COH=0 restores the fenced form.
     static const bool coh = !(getenv("MI355_ATTN_COH") && getenv("MI355_ATTN_COH")[0] == '0');
-#define FAD(RR, TK, TV) do { if (coh && counters) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); \
-                             else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); } while (0)
+#define FAD_D(RR, TK, TV, DD) do { if (coh && counters) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, true, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); \
+                                   else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, false, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); } while (0)
+#define FAD(RR, TK, TV) do { if (a.D == 64) FAD_D(RR, TK, TV, 64); else FAD_D(RR, TK, TV, 128); } while (0)
 #define FAD_T(RR)                                                              \
     if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
@@ -799,6 +809,7 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     }
 #undef FAD_T
 #undef FAD
+#undef FAD_D
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || counters) return e;
     const int nblk = (a.H * a.D) >> 8;

@@ -35,11 +35,13 @@ struct DecodeFuse {
 // COH (decode_mega.hip): q / K / V of the token come from other workgroups of the same launch and the results go to
 // other workgroups of the same launch: those accesses are made device-coherent (dev_common.h) and the ticket is a relaxed
 // atomic, instead of an agent-scope release / acquire whose cache-wide write-back and invalidate cost microseconds.
-template <int R, int TK, int TV, bool FUSED, bool COH = false>
+// D = 128 (default) or 64: head_dim; every lane role below is derived from it
+template <int R, int TK, int TV, bool FUSED, bool COH = false, int D = 128>
 __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, int g, int sp, int t) {
-    constexpr int D = 128, C = 64, NB = 4;
-    constexpr int KP = TK == T_F16 ? 4 : 2;                 // 16-byte K pieces per thread
-    constexpr int LPC = TK == T_F16 ? 16 : 8;               // lanes per cell in the score pass
+    constexpr int C = 64, NB = D / 32;
+    constexpr int LPC = (TK == T_F16 ? 2 * D : D) / 16;     // lanes per cell in the score pass (16-byte pieces of a K row)
+    constexpr int KP = C * LPC / 256;                       // 16-byte K pieces per thread
+    constexpr int DQ = D / 4, NCG = 256 / DQ, CPG = C / NCG;   // P.V pass: DQ lanes of 4 dims, NCG cell groups of CPG cells
     __shared__ __attribute__((aligned(16))) float qf[R * D];         // rotated q (f16-rounded for an f16 cache)
     __shared__ __attribute__((aligned(16))) int8_t qc[R * D];        // q8_0 codes of q
     __shared__ float qd[R * NB];
@@ -47,7 +49,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     __shared__ float ml[R * 2];
     __shared__ int vis[C];
     __shared__ uint32_t ksc[C * NB / 2], vsc[C * NB / 2];           // f16 block scales of the chunk
-    __shared__ __attribute__((aligned(16))) float accs[8 * R * D];
+    __shared__ __attribute__((aligned(16))) float accs[NCG * R * D];
     __shared__ __attribute__((aligned(16))) uint8_t newk[D * 2], newv[D * 2];   // the token's own cache row (codes or f16)
     __shared__ uint32_t newkd[2], newvd[2];                                      // its f16 block scales, two per word
     __shared__ int last_flag;
@@ -80,14 +82,14 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
             return;
         }
     }
-    // q pairs: R*64 pairs, pair pp -> (head r = pp / 64, i = pp % 64); NORM pairing (2i, 2i+1)
-    constexpr int NPAIR = R * 64, PPT = (NPAIR + 255) / 256;
+    // q pairs: R * D / 2 pairs, pair pp -> (head r = pp / (D / 2), i = pp % (D / 2)); NORM pairing (2i, 2i+1)
+    constexpr int HP = D / 2, NPAIR = R * HP, PPT = (NPAIR + 255) / 256;
     float2 qv[PPT], csv[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
         const int pp = tid + 256 * j;
         if (pp < NPAIR) {
-            const int r = pp >> 6, i = pp & 63;
+            const int r = pp / HP, i = pp % HP;
             {
                 const coh_u32x2 qq = cld8<COH>(a.q, (int)((((size_t)t * H + (size_t)g * R + r) * D + 2 * i) * 4));
                 qv[j] = make_float2(__uint_as_float(qq.x), __uint_as_float(qq.y));
@@ -105,22 +107,22 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         if (TK == T_F16) kreg[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
         else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * D + (p % LPC) * 16);
     }
-    const int dq = tid & 31, cg = tid >> 5;
-    uint2 vreg[8];
+    const int dq = tid % DQ, cg = tid / DQ;
+    uint2 vreg[CPG];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int cell = c_lo + cg + 8 * i;
+    for (int i = 0; i < CPG; i++) {
+        int cell = c_lo + cg + NCG * i;
         if (cell >= n_ctx) cell = n_ctx - 1;
         const size_t rowi = head_row0 + cell;
         if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
         else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
     }
     uint32_t ks2 = 0, vs2 = 0;
-    if (tid < C * NB / 2) {
-        int cell = c_lo + tid / 2;
+    if (tid < C * NB / 2) {                                            // NB / 2 words (two f16 scales each) per cell
+        int cell = c_lo + tid / (NB / 2);
         if (cell >= n_ctx) cell = n_ctx - 1;
-        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid & 1) * 2);
-        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid & 1) * 2);
+        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
     }
 
     // ---- FUSED: this token's K/V row (wave 0: lanes 0..31 rotate + convert K, lanes 32..63 convert V; 4 elements each)
@@ -128,7 +130,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     if (FUSED) {
         const int cellnew = fz.tok_cell[t];                      // (t = 0 in a single-token step)
         if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
-        if (own_cl >= 0 && wave == 0) {
+        if (own_cl >= 0 && wave == 0 && (lane & 31) < DQ) {      // lanes 0 .. DQ - 1: K, lanes 32 .. 32 + DQ - 1: V (whole 8-lane groups either way)
             const bool isk = lane < 32;
             const int dd = (lane & 31) * 4;
             float4 x4;
@@ -178,9 +180,9 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     }
     __syncthreads();
     if (FUSED && own_cl >= 0) {   // workgroup-uniform: use the row just produced instead of what the cache held before
-        if (tid < 2) {
-            if (TK != T_F16) ksc[own_cl * 2 + tid] = newkd[tid];
-            if (TV != T_F16) vsc[own_cl * 2 + tid] = newvd[tid];
+        if (tid < NB / 2) {
+            if (TK != T_F16) ksc[own_cl * (NB / 2) + tid] = newkd[tid];
+            if (TV != T_F16) vsc[own_cl * (NB / 2) + tid] = newvd[tid];
         }
 #pragma unroll
         for (int j = 0; j < KP; j++) {
@@ -188,8 +190,8 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
             if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const uint4 *>(newk + (p % LPC) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (cg + 8 * i == own_cl) {
+        for (int i = 0; i < CPG; i++) {
+            if (cg + NCG * i == own_cl) {
                 if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(newv + dq * 8);
                 else { vreg[i].x = *reinterpret_cast<const uint32_t *>(newv + dq * 4); vreg[i].y = 0; }
             }
@@ -224,11 +226,12 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
                     s += h2f((uint16_t)(kw[i] & 0xffff)) * qq[2 * i];
                     s += h2f((uint16_t)(kw[i] >> 16)) * qq[2 * i + 1];
                 }
-                s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s); s += dpp_f<DPP_MIRROR>(s);
+                s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s);      // 8 lanes
+                if (LPC == 16) s += dpp_f<DPP_MIRROR>(s);
                 sc[r] = s;
             }
         } else {
-            const uint32_t kpair = ksc[cl * 2 + (piece >> 2)];
+            const uint32_t kpair = ksc[cl * (NB / 2) + (piece >> 2)];
             const float dk = h2f((uint16_t)(((piece >> 1) & 1) ? (kpair >> 16) : (kpair & 0xffff)));
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -237,7 +240,8 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
                 s = dot4(kreg[j].x, qq.x, s); s = dot4(kreg[j].y, qq.y, s); s = dot4(kreg[j].z, qq.z, s); s = dot4(kreg[j].w, qq.w, s);
                 s += dpp_i<DPP_QP_1032>(s);                    // both halves of the 32-block (integer)
                 float f = (piece & 1) ? 0.0f : (float)s * (dk * qd[r * NB + (piece >> 1)]);
-                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f); f += dpp_f<DPP_HALF_MIRROR>(f);   // 8 lanes
+                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f);                                 // 4 lanes
+                if (LPC == 8) f += dpp_f<DPP_HALF_MIRROR>(f);                                            // 8 lanes
                 sc[r] = f;
             }
         }
@@ -265,14 +269,14 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
 #pragma unroll
     for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int cl = cg + 8 * i;
+    for (int i = 0; i < CPG; i++) {
+        const int cl = cg + NCG * i;
         float v4[4];
         if (TV == T_F16) {
             v4[0] = h2f((uint16_t)(vreg[i].x & 0xffff)); v4[1] = h2f((uint16_t)(vreg[i].x >> 16));
             v4[2] = h2f((uint16_t)(vreg[i].y & 0xffff)); v4[3] = h2f((uint16_t)(vreg[i].y >> 16));
         } else {
-            const uint32_t vpair = vsc[cl * 2 + (dq >> 4)];
+            const uint32_t vpair = vsc[cl * (NB / 2) + (dq >> 4)];
             const float dv = h2f((uint16_t)(((dq >> 3) & 1) ? (vpair >> 16) : (vpair & 0xffff)));
             const uint32_t w = vreg[i].x;
             v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
@@ -292,7 +296,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         const int r = e / D, d = e - r * D;
         float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) s += accs[((size_t)j * R + r) * D + d];
+        for (int j = 0; j < NCG; j++) s += accs[((size_t)j * R + r) * D + d];
         float *dst = a.part + (((size_t)t * H + (size_t)g * R + r) * a.splits + sp) * (D + 2);
         cstf<COH>(dst + d, s);
         if (d == 0) { cstf<COH>(dst + D, ml[2 * r]); cstf<COH>(dst + D + 1, ml[2 * r + 1]); }
@@ -414,9 +418,9 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     }
 }
 
-template <int R, int TK, int TV, bool FUSED, bool COH = false>
+template <int R, int TK, int TV, bool FUSED, bool COH = false, int D = 128>
 __global__ __launch_bounds__(256) void flash_attn_decode_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz) {
-    flash_attn_decode_item<R, TK, TV, FUSED, COH>(a, cs_table, n_rot, fz, blockIdx.x, blockIdx.y, blockIdx.z);
+    flash_attn_decode_item<R, TK, TV, FUSED, COH, D>(a, cs_table, n_rot, fz, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 }  // namespace mi355

@@ -455,6 +455,22 @@ int mi355_op_rope(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, con
     return dx.down(x, nb) ? MI355_OK : MI355_ERR_HIP;
 }
 
+int mi355_op_rope_yarn(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, const int32_t *pos, int64_t T,
+                       float freq_base, float freq_scale, const float *freq_factors, int32_t neox,
+                       float ext_factor, float attn_factor, float corr_lo, float corr_hi) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    const size_t nb = (size_t)T * n_head * head_dim * 4;
+    DevBuf dx(nb), dp((size_t)T * 4), dff(freq_factors ? (size_t)n_rot * 2 : 16);
+    if (!dx.up(x, nb) || !dp.up(pos, (size_t)T * 4)) return MI355_ERR_OOM;
+    if (freq_factors) dff.up(freq_factors, (size_t)(n_rot / 2) * 4);
+    RopeArgs ra{n_rot, freq_base, freq_scale, freq_factors ? dff.as<float>() : nullptr, neox};
+    ra.ext_factor = ext_factor; ra.attn_factor = attn_factor; ra.corr_lo = corr_lo; ra.corr_hi = corr_hi;
+    hipError_t e = launch_rope_inplace(dx.as<float>(), (int)T, n_head, head_dim, dp.as<int32_t>(), ra, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "rope_yarn");
+    return dx.down(x, nb) ? MI355_OK : MI355_ERR_HIP;
+}
+
 int mi355_op_get_rows(int32_t type, const void *table, int64_t K, int64_t n_rows, const int32_t *ids, int64_t n_ids, float *dst) {
     if (!need_device()) return MI355_ERR_NO_DEVICE;
     const size_t grow = ggml_row_bytes(type, K), drow = dev_row_bytes(type, K);

@@ -220,6 +220,9 @@ struct KVLayerView {
 
 struct RopeArgs {
     int n_rot; float freq_base; float freq_scale; const float *freq_factors; int neox;
+    // YaRN: ext_factor 1 mixes the interpolated angle (freq_scale * theta) with the original one per pair, by a ramp over the pair index that falls from 1 at
+    // corr_lo to 0 at corr_hi, and multiplies cos / sin by attn_factor * (1 + 0.1 ln(1 / freq_scale)); ext_factor 0 leaves plain (linear) scaling
+    float ext_factor = 0.0f, attn_factor = 1.0f, corr_lo = 0.0f, corr_hi = 0.0f;
 };
 
 // rope(q) in place, rope(k) -> K cache, v -> V cache for T tokens

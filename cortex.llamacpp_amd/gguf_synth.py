@@ -311,8 +311,8 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
     if cfg.n_expert:
         w.add(f"{a}.expert_count", "u32", cfg.n_expert)
         w.add(f"{a}.expert_used_count", "u32", cfg.n_expert_used)
-    for k, v in cfg.extra.items():                 # e.g. {"pooling_type": 1}: extra u32 keys under the architecture prefix
-        w.add(f"{a}.{k}", "u32", int(v))
+    for k, v in cfg.extra.items():                 # e.g. {"pooling_type": 1, "rope.scaling.type": "yarn", "rope.scaling.factor": 4.0}: extra keys under the architecture prefix
+        w.add(f"{a}.{k}", "str" if isinstance(v, str) else "f32" if isinstance(v, float) else "u32", v)
     if with_vocab:
         # synthetic SentencePiece-style vocab: <unk>,<s>,</s>, 256 byte tokens, then printable pieces
         toks, scores, types = ["<unk>", "<s>", "</s>"], [0.0, 0.0, 0.0], [2, 3, 3]

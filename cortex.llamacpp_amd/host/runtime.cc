@@ -39,6 +39,14 @@ Model::~Model() {
     for (uint8_t *p : arenas) (void)hipFree(p);
 }
 
+// the rotary parameters every kernel that rotates takes (with_ff: the per-pair frequency factors of rope_freqs.weight, when the file has them)
+static RopeArgs rope_args(const Model &m, bool with_ff) {
+    const HParams &hp = m.hp;
+    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, with_ff && m.rope_freqs.valid() ? (const float *)m.rope_freqs.data : nullptr, hp.rope_neox};
+    ra.ext_factor = hp.yarn_ext; ra.attn_factor = hp.yarn_attn; ra.corr_lo = hp.yarn_lo; ra.corr_hi = hp.yarn_hi;
+    return ra;
+}
+
 static bool type_supported(int t) {
     return t == T_F32 || t == T_F16 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q2_K || t == T_Q3_K || t == T_Q4_0 || t == T_Q5_0 || t == T_IQ4_NL;
 }
@@ -84,6 +92,21 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     hp.rope_neox = hp.arch != "llama";
     const std::string scaling = f.get_s(a + "rope.scaling.type", "none");
     if (scaling == "linear") hp.rope_scale = 1.0f / (float)f.get_f(a + "rope.scaling.factor", 1.0);
+    if (scaling == "yarn") {
+        // YaRN (llama.cpp: rope_yarn / ggml_rope_yarn_corr_dims with the context defaults beta_fast 32, beta_slow 1, ext_factor 1): pairs that turn more than
+        // beta_fast times over the ORIGINAL context keep their angle, pairs that turn less than beta_slow times are interpolated by 1/factor, a linear ramp between
+        const float factor = (float)f.get_f(a + "rope.scaling.factor", 1.0);
+        if (!(factor > 0.0f)) { err = "rope.scaling.factor must be positive"; status = -102; return nullptr; }
+        const float n_orig = (float)f.get_u(a + "rope.scaling.original_context_length", f.get_u(a + "context_length", 4096));
+        hp.rope_scale = 1.0f / factor;
+        hp.yarn_ext = 1.0f;
+        hp.yarn_attn = (float)f.get_f(a + "rope.scaling.attn_factor", 1.0);
+        const float two_log_base = 2.0f * logf(hp.rope_base);
+        const float lo = floorf((float)hp.n_rot * logf(n_orig / (32.0f * 2.0f * 3.14159265358979323846f)) / two_log_base);
+        const float hi = ceilf((float)hp.n_rot * logf(n_orig / (1.0f * 2.0f * 3.14159265358979323846f)) / two_log_base);
+        hp.yarn_lo = lo > 0.0f ? lo : 0.0f;
+        hp.yarn_hi = hi < (float)(hp.n_rot - 1) ? hi : (float)(hp.n_rot - 1);
+    } else if (scaling != "none" && scaling != "linear") { err = "unsupported rope.scaling.type " + scaling; status = -102; return nullptr; }
     if (hp.head_dim != 64 && hp.head_dim != 128) { err = "unsupported head_dim " + std::to_string(hp.head_dim); status = -102; return nullptr; }
     if (hp.n_embd % 256) { err = "n_embd must be a multiple of 256"; status = -102; return nullptr; }
     // ---- row split: this rank's share of the heads and of the feed-forward width
@@ -694,7 +717,7 @@ void Context::apply_k_shift() {
     for (size_t i = 0; i < cells_.size(); i++) { delta[i] = cells_[i].delta; cells_[i].delta = 0; }
     (void)hipMemcpyAsync(d_delta_, delta.data(), delta.size() * 4, hipMemcpyHostToDevice, stream_);
     (void)hipStreamSynchronize(stream_);
-    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, model->rope_freqs.valid() ? (const float *)model->rope_freqs.data : nullptr, hp.rope_neox};
+    RopeArgs ra = rope_args(*model, true);
     for (int il = 0; il < hp.n_layer; il++)
         (void)launch_k_shift(kv_[(size_t)il], cp.type_k, hp.n_head_kv, hp.head_dim, (int)cp.n_ctx, d_delta_, ra, stream_);
     has_shift_ = false;
@@ -897,7 +920,7 @@ bool Context::mega_prepare() {
     if (!mega_env || hp.n_expert > 0 || G <= 0 || H % G != 0 || H * D != E) return false;
     const int kb_e = (E + 2047) >> 11, kb_ff = (FF + 2047) >> 11;
     if ((E % 2048) != 0 || (FF % 256) != 0 || !decode_mega_applicable(kb_e, kb_ff, H / G, cp.type_k, cp.type_v)) return false;
-    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, nullptr, hp.rope_neox};
+    RopeArgs ra = rope_args(*model, false);
     if (ra.neox || (ra.n_rot % 4) != 0 || D != 128 || !kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) return false;
     auto kq = [](int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; };
     std::vector<MegaLayer> ml((size_t)hp.n_layer);
@@ -1063,7 +1086,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
     cur_T_ = T;
     const HParams &hp = model->hp;
     const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
-    RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, model->rope_freqs.valid() ? (const float *)model->rope_freqs.data : nullptr, hp.rope_neox};
+    RopeArgs ra = rope_args(*model, true);
     const float kq_scale = 1.0f / sqrtf((float)D);
     const int n_kv_max = std::max(n_kv_cap, 1);   // upper bound of occupied cells the kernels are sized for
     att_splits_ = flash_attn_pick_splits(T, G, n_kv_max);
@@ -1136,14 +1159,21 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         aa.out_q = o_q ? &aq_o_ : nullptr; aa.out_q8k = !act_is_q80(L.wo.type); aa.out_q80 = act_is_q80(L.wo.type);   // merged + quantised in one pass
         const bool o_pl = o_q && aa.out_q8k && T >= 3;         // the batched kernels will want the block-sum planes: the merge writes them too
         if (o_pl) { aa.out_bh = mmq_bh_; aa.out_bl = mmq_bl_; }
-        if (flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra)) {
+        // (the single-launch step and the store-fused batched step write the new K / V rows themselves; only the third branch needs the fast store kernel)
+        const bool fast_store = kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra);
+        static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
+        bool fused_step = false;
+        const bool decode_attn = flash_attn_decode_applicable(aa, ra);
+        if (decode_attn) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
             if (chunk_lmax_ > 0) {                             // per-token chunk lists (decode_ubatch): batched steps, or regions in use
                 aa.tok_chunks = d_chunks_; aa.tok_nchunks = d_chunks_ + (size_t)64 * chunk_stride_; aa.chunk_stride = chunk_stride_;
                 aa.splits = std::max(chunk_cap_, chunk_lmax_);
             }
-            static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
-            if (attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra)) {
+            fused_step = attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra);
+        }
+        if (decode_attn && (fast_store || fused_step || (batch_distinct_ && store_fuse_enabled()))) {
+            if (fused_step) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch
                 HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));
             } else if (batch_distinct_ && store_fuse_enabled()) {
@@ -1515,7 +1545,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     bool lists_usable = false;                                 // only the split-per-chunk attention kernels walk the lists
     {
         const HParams &hp = model->hp;
-        RopeArgs ra{hp.n_rot, hp.rope_base, hp.rope_scale, nullptr, hp.rope_neox};
+        RopeArgs ra = rope_args(*model, false);
         AttnArgs aa{};
         aa.T = n; aa.H = hp.n_head; aa.G = hp.n_head_kv; aa.D = hp.head_dim; aa.n_kv_max = n_kv_; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
         lists_usable = n <= 64 && flash_attn_decode_applicable(aa, ra) && kv_store_fast_applicable(aa.G, aa.D, cp.type_k, cp.type_v, ra);

@@ -46,6 +46,7 @@ struct HParams {
     int pooling_type = 0;          // {arch}.pooling_type: 0 none, 1 mean, 2 cls, 3 last (what llama_get_embeddings_seq pools over a sequence's tokens)
     float eps = 1e-5f, rope_base = 10000.0f, rope_scale = 1.0f;
     int rope_neox = 0;
+    float yarn_ext = 0.0f, yarn_attn = 1.0f, yarn_lo = 0.0f, yarn_hi = 0.0f;   // rope.scaling.type "yarn" (RopeArgs, kernels.h)
     // row split: n_head, n_head_kv and n_ff above are THIS RANK's share; the file's values are kept here.
     // A shard is the same graph with fewer heads and a narrower feed-forward, attn_output and ffn_down contracting over
     // the local slice only: their partial sums are the one thing exchanged (tp_comm.h).

@@ -192,6 +192,10 @@ MI355_API int mi355_op_ffn_gate_up(int32_t type, const void *Wg, const void *Wu,
 MI355_API int mi355_op_rms_norm_mul(const float *x, const float *w, int64_t n, int64_t T, float eps, float *y);
 MI355_API int mi355_op_rope(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, const int32_t *pos, int64_t T,
                             float freq_base, float freq_scale, const float *freq_factors, int32_t neox);
+/* the same rotation with YaRN scaling ({arch}.rope.scaling.type "yarn": llama.cpp's rope_yarn; ext_factor 0 and attn_factor 1 reduce it to mi355_op_rope) */
+MI355_API int mi355_op_rope_yarn(float *x, int32_t n_head, int32_t head_dim, int32_t n_rot, const int32_t *pos, int64_t T,
+                                 float freq_base, float freq_scale, const float *freq_factors, int32_t neox,
+                                 float ext_factor, float attn_factor, float corr_lo, float corr_hi);
 MI355_API int mi355_op_get_rows(int32_t type, const void *table, int64_t row_elems, int64_t n_rows_table,
                                 const int32_t *ids, int64_t n_ids, float *dst);
 MI355_API int mi355_op_swiglu(const float *gate, const float *up, int64_t n, float *y);

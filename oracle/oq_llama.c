@@ -48,6 +48,11 @@ struct oq_model {
     int head_dim;
     float eps, rope_base, rope_scale;
     int rope_neox;
+    /* {arch}.rope.scaling.*: type "linear" divides the angles by factor; "yarn" also blends per pair (oq_ops.c rope_table) */
+    char rope_scaling[16];
+    float rope_factor, yarn_attn_factor;
+    int n_ctx_train, n_ctx_orig;
+    oq_yarn yarn;
     const oq_tensor *tok_embd, *out_norm, *output, *rope_freqs;
     oq_layer layers[MAX_LAYERS];
 };
@@ -121,6 +126,7 @@ oq_model *oq_model_load(const char *path) {
     oq_model *m = (oq_model *)calloc(1, sizeof *m);
     m->fd = fd; m->map = map; m->map_size = (size_t)st.st_size;
     m->eps = 1e-5f; m->rope_base = 10000.0f; m->rope_scale = 1.0f;
+    m->rope_factor = 1.0f; m->yarn_attn_factor = 1.0f; m->yarn.attn_factor = 1.0f;
     rd r = {map, map + st.st_size, 0};
     uint32_t magic = (uint32_t)rd_u(&r, 4), version = (uint32_t)rd_u(&r, 4);
     uint64_t n_tensors = rd_u(&r, 8), n_kv = rd_u(&r, 8);
@@ -146,6 +152,11 @@ oq_model *oq_model_load(const char *path) {
         else if (!strcmp(suf, "attention.layer_norm_rms_epsilon")) m->eps = (float)v.f;
         else if (!strcmp(suf, "rope.dimension_count")) m->n_rot = (int)v.u;
         else if (!strcmp(suf, "rope.freq_base")) m->rope_base = (float)v.f;
+        else if (!strcmp(suf, "rope.scaling.type")) snprintf(m->rope_scaling, sizeof m->rope_scaling, "%s", v.s);
+        else if (!strcmp(suf, "rope.scaling.factor")) m->rope_factor = (float)v.f;
+        else if (!strcmp(suf, "rope.scaling.attn_factor")) m->yarn_attn_factor = (float)v.f;
+        else if (!strcmp(suf, "rope.scaling.original_context_length")) m->n_ctx_orig = (int)v.u;
+        else if (!strcmp(suf, "context_length")) m->n_ctx_train = (int)v.u;
         else if (!strcmp(suf, "expert_count")) m->n_expert = (int)v.u;
         else if (!strcmp(suf, "expert_used_count")) m->n_expert_used = (int)v.u;
     }
@@ -178,6 +189,14 @@ oq_model *oq_model_load(const char *path) {
     m->head_dim = m->n_embd / m->n_head;
     if (!m->n_rot) m->n_rot = m->head_dim;
     m->rope_neox = !(strcmp(m->arch, "llama") == 0);
+    /* upstream: src/llama-model.cpp (rope scaling hparams) + src/llama-context.cpp (freq_scale = 1 / factor; yarn: ext_factor 1, beta_fast 32, beta_slow 1) */
+    if (!strcmp(m->rope_scaling, "linear") || !strcmp(m->rope_scaling, "yarn")) m->rope_scale = 1.0f / m->rope_factor;
+    if (!strcmp(m->rope_scaling, "yarn")) {
+        m->yarn.ext_factor = 1.0f;
+        m->yarn.attn_factor = m->yarn_attn_factor;
+        oq_yarn_corr_dims(m->n_rot, m->n_ctx_orig ? m->n_ctx_orig : (m->n_ctx_train ? m->n_ctx_train : 4096), m->rope_base, 32.0f, 1.0f,
+                          &m->yarn.corr_lo, &m->yarn.corr_hi);
+    }
     for (int il = 0; il < m->n_layer; il++) {
         oq_layer *L = &m->layers[il];
         L->attn_norm = layer_tensor(m, il, "attn_norm.weight");
@@ -298,8 +317,7 @@ void oq_kv_seq_add(oq_ctx *c, int seq, int p0, int p1, int delta) {
 
 static void rope_heads(const oq_model *m, float *x, int n_head, int32_t pos) {
     const float *ff = m->rope_freqs ? (const float *)m->rope_freqs->data : NULL;
-    if (m->rope_neox) oq_rope_neox(x, n_head, m->head_dim, m->n_rot, pos, m->rope_base, m->rope_scale, ff);
-    else oq_rope_norm(x, n_head, m->head_dim, m->n_rot, pos, m->rope_base, m->rope_scale, ff);
+    oq_rope_ext(x, n_head, m->head_dim, m->n_rot, pos, m->rope_base, m->rope_scale, ff, m->rope_neox, &m->yarn);
 }
 
 /* re-rotate cached K rows whose position was shifted by seq_add (upstream: K-shift graph) */

@@ -57,17 +57,37 @@ void oq_soft_max(const float *x, const float *mask, float *y, int64_t n, float s
     for (int64_t i = 0; i < n; i++) y[i] *= inv;
 }
 
-/* cos/sin table for one position: theta_0 = pos, theta_{i+1} = theta_i * theta_scale (iterated in f32) */
-static void rope_table(float *cs, int n_rot, int32_t pos, float freq_base, float freq_scale, const float *ff) {
+/* cos/sin table for one position: theta_0 = pos, theta_{i+1} = theta_i * theta_scale (iterated in f32).  y != NULL with ext_factor != 0 is YaRN
+ * (upstream: ggml/src/ggml-cpu/ops.cpp rope_yarn + rope_yarn_ramp): the interpolated angle freq_scale * theta and the original one are mixed per pair by a
+ * ramp over the pair index, and cos / sin are scaled by attn_factor * (1 + 0.1 ln(1 / freq_scale)). */
+static void rope_table(float *cs, int n_rot, int32_t pos, float freq_base, float freq_scale, const float *ff, const oq_yarn *y) {
     const float theta_scale = powf(freq_base, -2.0f / (float)n_rot);
     float theta = (float)pos;
     for (int i = 0; i < n_rot; i += 2) {
         const float f = ff ? ff[i / 2] : 1.0f;
-        const float th = freq_scale * (theta / f);
-        cs[i] = cosf(th);
-        cs[i + 1] = sinf(th);
+        const float extrap = theta / f;
+        float th = freq_scale * extrap, m = y ? y->attn_factor : 1.0f;
+        if (y && y->ext_factor != 0.0f) {
+            const float d = y->corr_hi - y->corr_lo;
+            const float r = ((float)(i / 2) - y->corr_lo) / (d > 0.001f ? d : 0.001f);
+            const float mix = (1.0f - (r < 0.0f ? 0.0f : r > 1.0f ? 1.0f : r)) * y->ext_factor;
+            th = th * (1.0f - mix) + extrap * mix;
+            m *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+        }
+        cs[i] = cosf(th) * m;
+        cs[i + 1] = sinf(th) * m;
         theta *= theta_scale;
     }
+}
+
+/* ggml_rope_yarn_corr_dims (upstream: ggml/src/ggml.c): the pair indices between which the ramp runs - a pair that turns beta_fast times over the original
+ * context keeps its angle, one that turns beta_slow times or fewer is fully interpolated */
+void oq_yarn_corr_dims(int n_rot, int n_ctx_orig, float freq_base, float beta_fast, float beta_slow, float *lo, float *hi) {
+    const float pi = 3.14159265358979323846f;
+    const float a = floorf((float)n_rot * logf((float)n_ctx_orig / (beta_fast * 2.0f * pi)) / (2.0f * logf(freq_base)));
+    const float b = ceilf((float)n_rot * logf((float)n_ctx_orig / (beta_slow * 2.0f * pi)) / (2.0f * logf(freq_base)));
+    *lo = a > 0.0f ? a : 0.0f;
+    *hi = b < (float)(n_rot - 1) ? b : (float)(n_rot - 1);
 }
 
 /* build_moe_ffn's selection (upstream: src/llama-graph.cpp): softmax over the router logits, the k largest probabilities in descending order with the
@@ -87,35 +107,30 @@ void oq_moe_route(const float *logits, int n_expert, int k, float *probs, int32_
     for (int j = 0; j < k; j++) w[j] /= wsum;
 }
 
-void oq_rope_norm(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
-                  float freq_base, float freq_scale, const float *ff) {
+void oq_rope_ext(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
+                 float freq_base, float freq_scale, const float *ff, int neox, const oq_yarn *y) {
     float cs[1024];
     if (n_rot > 1024) abort();
-    rope_table(cs, n_rot, pos, freq_base, freq_scale, ff);
+    rope_table(cs, n_rot, pos, freq_base, freq_scale, ff, y);
     for (int h = 0; h < n_head; h++) {
         float *p = x + (size_t)h * head_dim;
         for (int i = 0; i < n_rot; i += 2) {
-            const float x0 = p[i], x1 = p[i + 1];
-            p[i]     = x0 * cs[i] - x1 * cs[i + 1];
-            p[i + 1] = x0 * cs[i + 1] + x1 * cs[i];
-        }
-    }
-}
-
-void oq_rope_neox(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
-                  float freq_base, float freq_scale, const float *ff) {
-    float cs[1024];
-    if (n_rot > 1024) abort();
-    rope_table(cs, n_rot, pos, freq_base, freq_scale, ff);
-    for (int h = 0; h < n_head; h++) {
-        float *p = x + (size_t)h * head_dim;
-        for (int i = 0; i < n_rot; i += 2) {
-            const int a = i / 2, b = i / 2 + n_rot / 2;
+            const int a = neox ? i / 2 : i, b = neox ? i / 2 + n_rot / 2 : i + 1;
             const float x0 = p[a], x1 = p[b];
             p[a] = x0 * cs[i] - x1 * cs[i + 1];
             p[b] = x0 * cs[i + 1] + x1 * cs[i];
         }
     }
+}
+
+void oq_rope_norm(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
+                  float freq_base, float freq_scale, const float *ff) {
+    oq_rope_ext(x, n_head, head_dim, n_rot, pos, freq_base, freq_scale, ff, 0, NULL);
+}
+
+void oq_rope_neox(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
+                  float freq_base, float freq_scale, const float *ff) {
+    oq_rope_ext(x, n_head, head_dim, n_rot, pos, freq_base, freq_scale, ff, 1, NULL);
 }
 
 void oq_get_rows(int type, const void *table, int64_t row_elems, const int32_t *ids, int64_t n_ids, float *dst) {

@@ -91,6 +91,11 @@ void oq_add_f32(const float *a, const float *b, float *y, int64_t n);
 void oq_silu_f32(const float *x, float *y, int64_t n);
 void oq_soft_max(const float *x, const float *mask /*nullable*/, float *y, int64_t n, float scale);
 void oq_moe_route(const float *logits, int n_expert, int k, float *probs /* scratch [n_expert] */, int32_t *ids, float *w);
+/* YaRN parameters of a rotation (NULL where one is taken: none); oq_yarn_corr_dims gives corr_lo / corr_hi the way the context does (beta_fast 32, beta_slow 1) */
+typedef struct { float ext_factor, attn_factor, corr_lo, corr_hi; } oq_yarn;
+void oq_yarn_corr_dims(int n_rot, int n_ctx_orig, float freq_base, float beta_fast, float beta_slow, float *lo, float *hi);
+void oq_rope_ext(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
+                 float freq_base, float freq_scale, const float *ff, int neox, const oq_yarn *y);
 /* rope, NORM pairing (x[2i],x[2i+1]); x is [n_head][head_dim] for one token */
 void oq_rope_norm(float *x, int n_head, int head_dim, int n_rot, int32_t pos,
                   float freq_base, float freq_scale, const float *freq_factors /*nullable*/);

@@ -53,6 +53,8 @@ def lib():
         L.oq_moe_route.argtypes = [vp, i32, i32, vp, vp, vp]
         L.oq_rope_norm.argtypes = [vp, i32, i32, i32, C.c_int32, f32, f32, vp]
         L.oq_rope_neox.argtypes = [vp, i32, i32, i32, C.c_int32, f32, f32, vp]
+        L.oq_rope_ext.argtypes = [vp, i32, i32, i32, C.c_int32, f32, f32, vp, i32, vp]
+        L.oq_yarn_corr_dims.argtypes = [i32, i32, f32, f32, f32, vp, vp]
         L.oq_get_rows.argtypes = [i32, vp, i64, vp, i64, vp]
         L.oq_flash_attn_ext.argtypes = [vp, i32, i32, i32, i32, i32, vp, sz, sz, i32, vp, sz, sz, vp, i32, f32, vp]
         L.oq_model_load.restype = vp
@@ -166,6 +168,20 @@ def rope(x: np.ndarray, n_head: int, head_dim: int, pos: int, base: float, neox:
     ff = None if freq_factors is None else np.ascontiguousarray(freq_factors, dtype=np.float32)
     fn = lib().oq_rope_neox if neox else lib().oq_rope_norm
     fn(_p(y), n_head, head_dim, n_rot or head_dim, pos, base, freq_scale, None if ff is None else _p(ff))
+    return y.reshape(n_head, head_dim)
+
+
+def yarn_corr_dims(n_rot: int, n_ctx_orig: int, base: float, beta_fast: float = 32.0, beta_slow: float = 1.0) -> tuple[float, float]:
+    lo, hi = C.c_float(), C.c_float()
+    lib().oq_yarn_corr_dims(n_rot, n_ctx_orig, base, beta_fast, beta_slow, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def rope_yarn(x: np.ndarray, n_head: int, head_dim: int, pos: int, base: float, freq_scale: float, ext_factor: float, attn_factor: float,
+              corr_lo: float, corr_hi: float, neox: bool = False, n_rot: int | None = None) -> np.ndarray:
+    y = np.array(x, dtype=np.float32, copy=True).reshape(n_head * head_dim)
+    par = (C.c_float * 4)(ext_factor, attn_factor, corr_lo, corr_hi)
+    lib().oq_rope_ext(_p(y), n_head, head_dim, n_rot or head_dim, pos, base, freq_scale, None, int(neox), par)
     return y.reshape(n_head, head_dim)
 
 

@@ -540,6 +540,48 @@ def test_kv_seq_ops_match_oracle(be, pkg, tmp_models, kv):
     oq.set_fa_v_acc_f32(0)
 
 
+@pytest.mark.parametrize("cfg,kv", [("tiny-gqa4", "q8_0"), ("tiny-g8", "q8_0"), ("tiny-tl-2l", "f16")])
+@pytest.mark.parametrize("scaling", ["linear", "yarn"])
+def test_rope_scaling_from_the_file(be, pkg, tmp_path, cfg, kv, scaling):
+    """{arch}.rope.scaling.{type, factor, original_context_length, attn_factor} (read by llama.cpp when the model loads - the reference passes no rope options
+    of its own): linear and YaRN scaling through the prompt kernels, the single-token steps (cos / sin table of the step) and a context shift
+    (K rows re-rotated by the position delta), against the CPU restatement; and the scaling is really in effect (the same weights without it differ)."""
+    import dataclasses
+    base = pkg.gguf_synth.CONFIGS[cfg]
+    extra = {"rope.scaling.type": scaling, "rope.scaling.factor": 4.0}
+    if scaling == "yarn":
+        extra.update({"rope.scaling.original_context_length": 32, "rope.scaling.attn_factor": 0.9})
+    path = str(tmp_path / f"{cfg}-{scaling}.gguf"); plain = str(tmp_path / f"{cfg}-plain.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, dataclasses.replace(base, extra=extra), "q4_k_m", seed=11)
+    pkg.gguf_synth.write_synthetic_llama(plain, base, "q4_k_m", seed=11)
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
+    try:
+        m, c, om, oc = open_pair(pkg, path, 160, kv)
+        rng = np.random.default_rng(9)
+        n_prompt = 70
+        prompt = rng.integers(0, m.n_vocab, n_prompt)
+        c.decode(prompt, np.arange(n_prompt)); ref = oc.decode(prompt, np.arange(n_prompt))[0]
+        scaled = c.logits().copy()
+        assert rel_err(scaled, ref) <= FLIP_TOL
+        tok = int(ref.argmax())
+        for step in range(12):
+            c.decode([tok], [n_prompt + step]); r = oc.decode([tok], [n_prompt + step])[0]
+            assert rel_err(c.logits(), r) <= FLIP_TOL, step
+            tok = int(r.argmax())
+        for x in (c, oc):                     # context shift: drop [8, 40), slide the rest down
+            x.kv_seq_rm(0, 8, 40)
+            x.kv_seq_add(0, 40, n_prompt + 12, -32)
+        c.decode([tok], [n_prompt + 12 - 32]); r = oc.decode([tok], [n_prompt + 12 - 32])[0]
+        assert rel_err(c.logits(), r) <= FLIP_TOL
+        c.close(); m.close(); oc.close(); om.close()
+        m2 = pkg.Model(plain); c2 = pkg.Context(m2, n_ctx=160, type_k=KV[kv], type_v=KV[kv])
+        c2.decode(prompt, np.arange(n_prompt))
+        assert rel_err(c2.logits(), scaled) > 10 * FLIP_TOL      # the scaling is not a no-op on these weights
+        c2.close(); m2.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
+
+
 def test_load_errors(be, pkg, tmp_path):
     bad = tmp_path / "bad.gguf"
     bad.write_bytes(b"NOPE" + b"\0" * 64)

@@ -272,6 +272,23 @@ def test_rope(be, neox, base):
     assert (y[0] == x[0]).all()
 
 
+@pytest.mark.parametrize("neox", [False, True])
+@pytest.mark.parametrize("D,n_orig,fs", [(128, 256, 0.25), (64, 32, 0.125), (128, 8192, 0.5)])
+def test_rope_yarn(be, neox, D, n_orig, fs):
+    """rope.scaling.type "yarn": the device angle / magnitude (attn.hip rope_angle) against the CPU restatement of rope_yarn"""
+    rng = np.random.default_rng(8)
+    H, base, attn = 4, 1e4, 0.8
+    lo, hi = oq.yarn_corr_dims(D, n_orig, base)
+    pos = np.array([0, 1, 29, 1023, 6000], np.int32)
+    x = rng.standard_normal((pos.size, H, D)).astype(np.float32)
+    y = be.rope_yarn(x, H, D, pos, base, fs, 1.0, attn, lo, hi, neox=neox)
+    for i, p in enumerate(pos):
+        ref = oq.rope_yarn(x[i], H, D, int(p), base, fs, 1.0, attn, lo, hi, neox=neox)
+        assert np.abs(y[i] - ref).max() <= 4e-6, (p, np.abs(y[i] - ref).max())
+    # ext_factor 0 / attn_factor 1 is the plain entry point, bit for bit
+    assert (be.rope_yarn(x, H, D, pos, base, fs, 0.0, 1.0, lo, hi, neox=neox) == be.rope(x, H, D, pos, base, neox=neox, freq_scale=fs)).all()
+
+
 @pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K, Q8_0, F16, F32, Q2_K, Q3_K, Q4_0, Q5_0, IQ4_NL])
 def test_get_rows_bit_exact(be, t):
     rng = np.random.default_rng(4 + t)

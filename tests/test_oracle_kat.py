@@ -377,6 +377,46 @@ def test_rope_norm_vs_float64(base, pos):
     assert np.allclose(y[:, 0::2] ** 2 + y[:, 1::2] ** 2, x[:, 0::2] ** 2 + x[:, 1::2] ** 2, rtol=1e-5)
 
 
+def test_yarn_corr_dims_closed_form():
+    # n_dims * ln(n_ctx_orig / (n_rot * 2 pi)) / (2 ln base): Llama-2's 128 dims, 4096 positions, base 1e4 -> floor(20.94) = 20, ceil(45.03) = 46
+    assert oq.yarn_corr_dims(128, 4096, 1e4) == (20.0, 46.0)
+    # clamped to [0, n_dims - 1]
+    lo, hi = oq.yarn_corr_dims(64, 32, 1e4)
+    assert lo == 0.0 and hi == 6.0
+    assert oq.yarn_corr_dims(64, 1 << 30, 1e2)[1] == 63.0
+
+
+@pytest.mark.parametrize("neox", [False, True])
+@pytest.mark.parametrize("pos", [0, 3, 700])
+def test_rope_yarn_vs_float64(neox, pos):
+    """YaRN (llama.cpp rope_yarn, published formula): theta = interp * (1 - mix) + extrap * mix with mix = 1 - clamp((pair - lo) / (hi - lo)), magnitude
+    attn_factor * (1 + 0.1 ln(1 / freq_scale)); against a float64 restatement, plus its limits (no mix -> linear scaling; low pairs -> the unscaled angle)."""
+    rng = np.random.default_rng(6)
+    H, D, base, fs, attn = 3, 128, 1e4, 0.25, 0.9
+    lo, hi = oq.yarn_corr_dims(D, 256, base)
+    assert 0 < lo < hi < D // 2
+    x = rng.standard_normal((H, D)).astype(np.float32)
+    y = oq.rope_yarn(x, H, D, pos, base, fs, 1.0, attn, lo, hi, neox=neox)
+    i = np.arange(D // 2)
+    extrap = pos * np.float64(base) ** (-2.0 * i / D)
+    mix = 1.0 - np.clip((i - lo) / max(0.001, hi - lo), 0.0, 1.0)
+    th = fs * extrap * (1 - mix) + extrap * mix
+    mag = attn * (1.0 + 0.1 * np.log(1.0 / fs))
+    a, b = (x[:, :D // 2], x[:, D // 2:]) if neox else (x[:, 0::2], x[:, 1::2])
+    ya, yb = (y[:, :D // 2], y[:, D // 2:]) if neox else (y[:, 0::2], y[:, 1::2])
+    assert np.abs(ya - mag * (a * np.cos(th) - b * np.sin(th))).max() < max(2e-6, pos * 8e-5)
+    assert np.abs(yb - mag * (a * np.sin(th) + b * np.cos(th))).max() < max(2e-6, pos * 8e-5)
+    # pairs below corr_lo keep the original angle, pairs above corr_hi take the interpolated one: both up to the magnitude
+    plain = oq.rope(x, H, D, pos, base, neox=neox)
+    lin = oq.rope(x, H, D, pos, base, neox=neox, freq_scale=fs)
+    pa, la = (plain[:, :D // 2], lin[:, :D // 2]) if neox else (plain[:, 0::2], lin[:, 0::2])
+    k0, k1 = int(lo) + 1, int(hi)
+    assert np.allclose(ya[:, :k0], np.float32(mag) * pa[:, :k0], rtol=0, atol=1e-6)
+    assert np.allclose(ya[:, k1:], np.float32(mag) * la[:, k1:], rtol=0, atol=1e-6)
+    # ext_factor 0, attn_factor 1: exactly the linear-scaling rotation
+    assert (oq.rope_yarn(x, H, D, pos, base, fs, 0.0, 1.0, lo, hi, neox=neox) == lin).all()
+
+
 @pytest.mark.parametrize("tk,tv,tol", [(F16, F16, 3e-3), (Q8_0, Q8_0, 3e-5), (Q4_0, Q4_0, 3e-5)])
 def test_flash_attn_vs_float64(tk, tv, tol):
     rng = np.random.default_rng(11)
