@@ -6,6 +6,8 @@
 // reached from the reference through llama_decode (src/llama_server_context.cc:1635); rows a9, a12, a14,
 // a17 of SURVEY.md §8a.  Quantised codes and scales are bit-identical to the CPU restatement; only the
 // f64 sum-of-squares is tree-ordered instead of sequential.
+#include <algorithm>
+
 #include "kernels.h"
 #include "quant_dev.h"
 
@@ -137,6 +139,24 @@ __global__ void add_kernel(const float *a, const float *b, float *y, int64_t n) 
 }
 hipError_t launch_add(const float *a, const float *b, float *y, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, y, n);
+    return hipGetLastError();
+}
+
+// the Q / K / V bias vectors of a qwen2-style attention block added to all T rows of the three projections in one launch (a null bias skips its segment);
+// grid.y = 0, 1, 2 picks the projection
+__global__ void add_qkv_bias_kernel(float *q, float *k, float *v, const float *bq, const float *bk, const float *bv, int nq, int nkv, int T) {
+    const int sg = blockIdx.y;
+    float *x = sg == 0 ? q : sg == 1 ? k : v;
+    const float *b = sg == 0 ? bq : sg == 1 ? bk : bv;
+    const int n = sg == 0 ? nq : nkv;
+    if (!b) return;
+    const int64_t tot = (int64_t)n * T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) x[i] += b[i % n];
+}
+hipError_t launch_add_qkv_bias(float *q, float *k, float *v, const float *bq, const float *bk, const float *bv, int nq, int nkv, int T, hipStream_t st) {
+    const int64_t tot = (int64_t)(nq > nkv ? nq : nkv) * T;
+    const unsigned gx = (unsigned)std::min<int64_t>((tot + 255) / 256, 2048);
+    hipLaunchKernelGGL(add_qkv_bias_kernel, dim3(gx, 3), dim3(256), 0, st, q, k, v, bq, bk, bv, nq, nkv, T);
     return hipGetLastError();
 }
 

@@ -56,6 +56,9 @@ struct MMVQArgs {
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);
 // single-token fast path (mmvq_fast.hip): persistent, software-pipelined; K % 2048 == 0, K-quant types
 void mmvq_fast_set_threads(int nt);
+// contraction lengths the register-ring mat-vec is instantiated for, in passes of 2048 (the last pass may be partial): 1-4 hidden sizes up to 8192, the rest
+// feed-forward widths (5: Qwen2-1.5B 8960; 6: 11008; 7: 13824 / 14336; 9: 17920; 10: 18944 / 20480; 11: 22016; 14: 27648 / 28672; 15: 29568)
+inline bool mmvq_fast_kb_ok(int kb) { return (kb >= 1 && kb <= 7) || kb == 9 || kb == 10 || kb == 11 || kb == 14 || kb == 15; }
 bool mmvq_fast_applicable(const MMVQArgs &a);
 hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st);
 hipError_t launch_mmvq_ints(MMVQArgs a, int32_t *isum, int32_t *msum, hipStream_t st);
@@ -155,6 +158,8 @@ hipError_t launch_swiglu(const float *g, const float *u, float *y, int64_t n, hi
 hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
                                int8_t *bh = nullptr, int8_t *bl = nullptr);
 hipError_t launch_add(const float *a, const float *b, float *y, int64_t n, hipStream_t st);
+// x[t][i] += bias[i] for the T rows of Q (nq wide), K and V (nkv wide); null biases are skipped
+hipError_t launch_add_qkv_bias(float *q, float *k, float *v, const float *bq, const float *bk, const float *bv, int nq, int nkv, int T, hipStream_t st);
 hipError_t launch_soft_max(const float *x, const float *mask, float *y, int n, int rows, float scale, hipStream_t st);
 // pack device planes back into ggml blocks (parity tests)
 hipError_t launch_pack_q8k_blocks(const ActQuant &q, int n, int T, uint8_t *blocks, hipStream_t st);

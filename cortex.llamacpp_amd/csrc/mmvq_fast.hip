@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NT) void mmvq_fast_kernel(const MMVQArgs a) {
 bool mmvq_fast_applicable(const MMVQArgs &a) {
     if (a.T != 1 || (a.K % 256) != 0 || a.K <= 0) return false;
     const int kb = (a.K + 2047) >> 11;                         // passes of 8 super-blocks; the last one may be partial
-    if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7 && kb != 14) return false;
+    if (!mmvq_fast_kb_ok(kb)) return false;
     const int n = a.epi == EPI_SWIGLU ? 2 : a.n_seg;
     for (int s = 0; s < n; s++) {
         const int t = a.seg[s].type;
@@ -140,9 +140,9 @@ hipError_t launch_mmvq_fast(MMVQArgs a, hipStream_t st) {
         case 2: if (nt == 768) FAST_F(2, 768); else FAST_F(2, 512); break;
         case 3: FAST_F(3, 512); break;
         case 4: FAST_F(4, 512); break;
-        case 6: if (a.fuse_mode == 2) FAST(6, 512, 2); else FAST(6, 512, 0); break;
-        case 7: if (a.fuse_mode == 2) FAST(7, 512, 2); else FAST(7, 512, 0); break;
-        case 14: if (a.fuse_mode == 2) FAST(14, 512, 2); else FAST(14, 512, 0); break;
+#define FAST_W(KBV) case KBV: if (a.fuse_mode == 2) FAST(KBV, 512, 2); else FAST(KBV, 512, 0); break
+        FAST_W(5); FAST_W(6); FAST_W(7); FAST_W(9); FAST_W(10); FAST_W(11); FAST_W(14); FAST_W(15);
+#undef FAST_W
         default: return hipErrorInvalidValue;
     }
 #undef FAST_F

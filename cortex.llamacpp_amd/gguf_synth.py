@@ -146,6 +146,8 @@ class LlamaConfig:
     n_expert: int = 0
     n_expert_used: int = 0
     big_model: bool = False          # 70B-class rule: attn_v Q4_K -> Q5_K on the non-Q6_K layers
+    arch: str = "llama"              # general.architecture: "qwen2" is the same graph with NEOX rope pairing and (qkv_bias) attention biases
+    qkv_bias: bool = False
     extra: dict = field(default_factory=dict)
 
     @property
@@ -161,6 +163,8 @@ CONFIGS = {
     "mixtral-8x7b": LlamaConfig("Mixtral-8x7B-Instruct", 4096, 32, 32, 8, 14336, 32000, 1e6, 1e-5, 32768, 8, 2),
     "llama-3-70b": LlamaConfig("Llama-3-70B-Instruct", 8192, 80, 64, 8, 28672, 128256, 500000.0, 1e-5, 8192,
                                big_model=True),
+    # qwen2 architecture (NEOX rope, Q / K / V biases), 7 query heads per kv head, hidden size and feed-forward width that are no multiples of 1024
+    "qwen2-7b": LlamaConfig("Qwen2-7B-Instruct", 3584, 28, 28, 4, 18944, 152064, 1e6, 1e-6, 32768, arch="qwen2", qkv_bias=True),
     # test-sized
     "tiny": LlamaConfig("tiny-test", 256, 2, 4, 2, 512, 512, 10000.0, 1e-5, 512),
     "tiny-gqa4": LlamaConfig("tiny-gqa4", 512, 3, 8, 2, 1024, 768, 500000.0, 1e-5, 1024),
@@ -178,6 +182,11 @@ CONFIGS = {
     "tiny-8b-2l": LlamaConfig("tiny-8b-2l", 4096, 2, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
     "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
     # three layers of Llama-3-8B's geometry: two launches of the layer engine (decode_engine.hip) that hand Q | K | V on + the last one
+    # general.architecture "qwen2": NEOX rope pairing + Q / K / V biases (one of the reference's weekend test families, e2e-test-server-weekend.py:22-76).
+    # tiny-qwen2: head_dim 64; tiny-qwen2-1.5b-2l / -7b-2l: two layers of Qwen2-1.5B's (1536, 12 / 2 heads of 128, 8960) and Qwen2-7B's (3584, 28 / 4, 18944) geometry
+    "tiny-qwen2": LlamaConfig("tiny-qwen2", 512, 3, 8, 2, 1024, 768, 1e6, 1e-6, 1024, arch="qwen2", qkv_bias=True),
+    "tiny-qwen2-1.5b-2l": LlamaConfig("tiny-qwen2-1.5b-2l", 1536, 2, 12, 2, 8960, 512, 1e6, 1e-6, 1024, arch="qwen2", qkv_bias=True),
+    "tiny-qwen2-7b-2l": LlamaConfig("tiny-qwen2-7b-2l", 3584, 2, 28, 4, 18944, 512, 1e6, 1e-6, 1024, arch="qwen2", qkv_bias=True),
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 
@@ -256,6 +265,10 @@ def model_tensors(cfg: LlamaConfig, ftype: str):
         out.append((p + "attn_q.weight", (E, E), tensor_type(cfg, ftype, "attn_q", il), E))
         out.append((p + "attn_k.weight", (E, kv), tensor_type(cfg, ftype, "attn_k", il), E))
         out.append((p + "attn_v.weight", (E, kv), tensor_type(cfg, ftype, "attn_v", il), E))
+        if cfg.qkv_bias:
+            out.append((p + "attn_q.bias", (E,), F32, None))
+            out.append((p + "attn_k.bias", (kv,), F32, None))
+            out.append((p + "attn_v.bias", (kv,), F32, None))
         out.append((p + "attn_output.weight", (E, E), tensor_type(cfg, ftype, "attn_output", il), E))
         out.append((p + "ffn_norm.weight", (E,), F32, None))
         if cfg.n_expert:
@@ -294,7 +307,7 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
     if isinstance(cfg, str):
         cfg = CONFIGS[cfg]
     w = GGUFWriter()
-    a = "llama"
+    a = cfg.arch
     w.add("general.architecture", "str", a)
     w.add("general.name", "str", cfg.name + " (synthetic)")
     w.add("general.file_type", "u32", FTYPE_ID[ftype])
@@ -352,6 +365,8 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
 
         def gen(idx=idx, name=name, ne=ne, t=t, fan_in=fan_in, n=n):
             rng = np.random.default_rng([seed, idx])
+            if name.endswith(".bias"):
+                return (rng.standard_normal(n) * 0.25).astype("<f4").view(np.uint8)
             if len(ne) == 1:  # norm weights
                 return rng.uniform(0.9, 1.1, size=n).astype("<f4").view(np.uint8)
             if name == "token_embd.weight":

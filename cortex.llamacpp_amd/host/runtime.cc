@@ -62,6 +62,9 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     HParams &hp = m->hp;
     hp.arch = f.get_s("general.architecture", "");
     if (hp.arch.empty()) { err = "general.architecture missing"; status = -102; return nullptr; }
+    // the graph built here is llm_build_llama's: "llama" files (Llama, Mistral, TinyLlama, Mixtral ... all carry that name) and "qwen2"
+    // (the same op order with NEOX rope pairing and Q / K / V biases).  Gemma, Phi-3, BERT-type encoders etc. are other graphs: refused, never run as llama
+    if (hp.arch != "llama" && hp.arch != "qwen2") { err = "unsupported general.architecture '" + hp.arch + "' (this backend builds the llama graph: llama, qwen2)"; status = -102; return nullptr; }
     const std::string a = hp.arch + ".";
     hp.n_embd = (int)f.get_u(a + "embedding_length", 0);
     hp.n_layer = (int)f.get_u(a + "block_count", 0);
@@ -770,7 +773,9 @@ static void chunk_act(MMVQArgs &a, const ActQuant &aq, int K, int t0) {
 }
 
 // up to 3 quantised weight tensors sharing one activation (fused Q/K/V), or one tensor with an epilogue
-static bool can_fuse(int K, int T) { return T == 1 && K <= 8192 && (K & 1023) == 0; }
+// (any whole number of super-blocks: the register-ring kernel's prologue stops at the row's end inside its last pass; the weight stream wants K % 1024 == 0
+// and leaves the other hidden sizes - Qwen2-7B's 3584, Llama-30B's 6656 - to the register ring)
+static bool can_fuse(int K, int T) { return T == 1 && K <= 8192 && (K & 255) == 0; }
 
 static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, const ActQuant &aq, hipStream_t st, const Fuse &fz = Fuse()) {
     for (int t0 = 0; t0 < T;) {
@@ -1144,11 +1149,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         float *outs[3] = {q_, k_, v_};
         if (!(engine && il > 0)) HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
         pending_fuse_ = Fuse();
-        for (int t = 0; t < T; t++) {   // biases are rare on this architecture (one tiny launch per token when present)
-            if (L.bq.valid()) HIP_TRY(launch_add(q_ + (size_t)t * H * D, (const float *)L.bq.data, q_ + (size_t)t * H * D, (int64_t)H * D, stream_));
-            if (L.bk.valid()) HIP_TRY(launch_add(k_ + (size_t)t * G * D, (const float *)L.bk.data, k_ + (size_t)t * G * D, (int64_t)G * D, stream_));
-            if (L.bv.valid()) HIP_TRY(launch_add(v_ + (size_t)t * G * D, (const float *)L.bv.data, v_ + (size_t)t * G * D, (int64_t)G * D, stream_));
-        }
+        if (L.bq.valid() || L.bk.valid() || L.bv.valid())       // qwen2-style attention biases: all T rows of the three projections in one launch
+            HIP_TRY(launch_add_qkv_bias(q_, k_, v_, L.bq.valid() ? (const float *)L.bq.data : nullptr, L.bk.valid() ? (const float *)L.bk.data : nullptr,
+                                        L.bv.valid() ? (const float *)L.bv.data : nullptr, H * D, G * D, T, stream_));
         prof_mark("qkv");
         AttnArgs aa{};
         aa.q = q_; aa.out = att_; aa.kv = kv_[(size_t)il]; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
@@ -1322,7 +1325,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     // dense feed-forward does), else as its own launch
                     const int kbf = (FF + 2047) / 2048;
                     const bool fuse_q = (L.down_exps.type == T_Q4_K || L.down_exps.type == T_Q5_K || L.down_exps.type == T_Q6_K) && (FF % 256) == 0 &&
-                                        (kbf == 1 || kbf == 2 || kbf == 3 || kbf == 4 || kbf == 6 || kbf == 7 || kbf == 14);
+                                        mmvq_fast_kb_ok(kbf);
                     if (!fuse_q) { HIP_TRY(launch_quantize(ffn_ + (size_t)t * FF, FF, 1, aq_ff_, !act_is_q80(L.down_exps.type), act_is_q80(L.down_exps.type), stream_)); prep_owner_ = nullptr; }
                     MMVQArgs d{};
                     d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE;
@@ -1411,7 +1414,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             // (the widths listed are the ones the register-ring and weight-stream kernels take; the generic mat-vec's fused prologue would refuse others)
             const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || act_is_q80(L.down.type) ||
                                                                L.down.type == T_Q2_K || L.down.type == T_Q3_K) &&
-                                   (FF % 256) == 0 && [](int kb) { return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 14; }((FF + 2047) / 2048);
+                                   (FF % 256) == 0 && mmvq_fast_kb_ok((FF + 2047) / 2048);
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
             } else if (is_quant(L.down.type) && !swiglu_quantised) {

@@ -76,7 +76,11 @@ def rel_err(a, b):
                                           ("tiny-e2048", "q4_0", "q8_0"), ("tiny-8b-2l", "q5_0", "q8_0"),
                                           # TinyLlama-1.1B's layer geometry in the type mix of the reference's smoke model (a Q2_K file, Makefile:5) and neighbours
                                           ("tiny-tl-2l", "q2_k", "f16"), ("tiny-tl-2l", "q2_k", "q8_0"), ("tiny-tl-2l", "q3_k_m", "q8_0"), ("tiny-tl-2l", "q4_k_m", "f16"),
-                                          ("tiny-tl-2l", "q8_0", "f16"), ("tiny-tl-2l:40", "q5_0", "q8_0")])
+                                          ("tiny-tl-2l", "q8_0", "f16"), ("tiny-tl-2l:40", "q5_0", "q8_0"),
+                                          # general.architecture "qwen2" (a weekend-test family of the reference): NEOX rope pairing, Q / K / V biases; head_dim 64 and the
+                                          # layer geometries of Qwen2-1.5B (6 query heads per kv head) and Qwen2-7B (7; hidden 3584 and feed-forward 18944: no multiple of 1024)
+                                          ("tiny-qwen2", "q4_k_m", "q8_0"), ("tiny-qwen2:40", "q5_k_m", "f16"), ("tiny-qwen2", "q8_0", "q8_0"),
+                                          ("tiny-qwen2-1.5b-2l", "q4_k_m", "q8_0"), ("tiny-qwen2-7b-2l:40", "q4_k_m", "q8_0"), ("tiny-qwen2-7b-2l", "q4_0", "f16")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)
@@ -589,6 +593,17 @@ def test_load_errors(be, pkg, tmp_path):
         pkg.Model(str(bad))
     with pytest.raises(pkg.MI355Error):
         pkg.Model(str(tmp_path / "missing.gguf"))
+
+
+@pytest.mark.parametrize("arch", ["gemma2", "phi3", "nomic-bert"])
+def test_other_graphs_are_refused_by_name(be, pkg, tmp_path, arch):
+    """Only llama-graph files run (general.architecture llama / qwen2): a file of another architecture is refused when it loads, with its name in the
+    message - never evaluated as if it were a llama graph (wrong logits with status 200 is the failure this guards against)."""
+    import dataclasses
+    path = str(tmp_path / "other.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, dataclasses.replace(pkg.gguf_synth.CONFIGS["tiny"], arch=arch), "q8_0", seed=1)
+    with pytest.raises(pkg.MI355Error, match=arch):
+        pkg.Model(path)
 
 
 def _patch_u32(path, key, value):
