@@ -693,7 +693,12 @@ namespace mi355 {
 
 bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
-    return (a.D == 128 || a.D == 64) && !ra.neox && (R == 1 || R == 2 || R == 4 || R == 8) && a.T <= 64 && a.n_kv_max <= 64 * 2048 &&
+    const bool pow2 = R == 1 || R == 2 || R == 4 || R == 8;
+    // 3, 5, 6, 7 query heads per kv head (Llama-3.2-3B, Qwen2-1.5B / 7B, Yi-34B): head_dim 128 and one cache type for K and V only (fewer instantiations)
+    const bool odd = (R == 3 || R == 5 || R == 6 || R == 7) && a.D == 128 && a.type_k == a.type_v;
+    // NEOX pairing (qwen2): the kernel rotates whole heads only
+    if (ra.neox && ra.n_rot != a.D) return false;
+    return (a.D == 128 || a.D == 64) && (pow2 || odd) && a.T <= 64 && a.n_kv_max <= 64 * 2048 &&
            (a.type_k == T_F16 || a.type_k == T_Q8_0) && (a.type_v == T_F16 || a.type_v == T_Q8_0);
 }
 int flash_attn_decode_splits(int n_kv_max) { return n_kv_max > 0 ? (n_kv_max + 63) / 64 : 1; }
@@ -706,6 +711,7 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     const int R = a.H / a.G;
     const dim3 grid(a.G, a.splits, a.T);
     DecodeFuse nofz{};
+    nofz.neox = ra.neox;
     const bool store = knew && vnew && tok_cell;
     if (store) { nofz.knew = knew; nofz.vnew = vnew; nofz.tok_cell = tok_cell; }
 #define FAD_D(RR, TK, TV, DD) do { if (store) hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, false, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); \
@@ -716,13 +722,19 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
     else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
     else FAD(RR, T_F16, T_Q8_0);
+#define FAD_O(RR) if (a.type_k == T_F16) FAD_D(RR, T_F16, T_F16, 128); else FAD_D(RR, T_Q8_0, T_Q8_0, 128);
     switch (R) {
         case 1: FAD_T(1) break;
         case 2: FAD_T(2) break;
         case 4: FAD_T(4) break;
         case 8: FAD_T(8) break;
+        case 3: FAD_O(3) break;
+        case 5: FAD_O(5) break;
+        case 6: FAD_O(6) break;
+        case 7: FAD_O(7) break;
         default: return hipErrorInvalidValue;
     }
+#undef FAD_O
 #undef FAD_T
 #undef FAD
 #undef FAD_D
@@ -740,7 +752,8 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
 bool flash_attn_decode_fused_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const int R = a.H / a.G;
     // (R * D < 256: 256 / (R * D) neighbouring kv heads share a merge ticket, see attn_decode_dev.h)
-    const int gp = (R * a.D) % 256 == 0 ? 1 : 256 / (R * a.D);
+    const int rd = R * a.D;
+    const int gp = 256 / (rd % 256 == 0 ? 256 : rd % 128 == 0 ? 128 : rd % 64 == 0 ? 64 : 32);      // kv heads per merge ticket (attn_decode_dev.h)
     return a.T == 1 && flash_attn_decode_applicable(a, ra) && a.G % gp == 0 && (ra.n_rot % 4) == 0 && a.splits <= 64;
 }
 // diagnosis: MI355_ATTN_PROBE=1 makes the fused decode attention stamp its phases (DecodeFuse::probe); the stamps of the
@@ -784,6 +797,7 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     g_attn_probe_G = a.G; g_attn_probe_splits = a.splits;
     DecodeFuse fz{};
     fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters;
+    fz.neox = ra.neox;
     if (a.out_q) fz.q = *a.out_q;
     fz.want_q8k = (int)(a.out_q && a.out_q8k); fz.want_q80 = (int)(a.out_q && a.out_q80);
     fz.probe = attn_probe_buffer();
@@ -800,13 +814,19 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
     else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
     else FAD(RR, T_F16, T_Q8_0);
+#define FAD_O(RR) if (a.type_k == T_F16) FAD_D(RR, T_F16, T_F16, 128); else FAD_D(RR, T_Q8_0, T_Q8_0, 128);
     switch (R) {
         case 1: FAD_T(1) break;
         case 2: FAD_T(2) break;
         case 4: FAD_T(4) break;
         case 8: FAD_T(8) break;
+        case 3: FAD_O(3) break;
+        case 5: FAD_O(5) break;
+        case 6: FAD_O(6) break;
+        case 7: FAD_O(7) break;
         default: return hipErrorInvalidValue;
     }
+#undef FAD_O
 #undef FAD_T
 #undef FAD
 #undef FAD_D

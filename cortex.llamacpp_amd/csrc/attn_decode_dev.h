@@ -25,6 +25,7 @@ struct DecodeFuse {
     unsigned *counters;            // [G], zero between launches
     ActQuant q;
     int want_q8k, want_q80;
+    int neox;                      // rotary pairing (i, i + D / 2) instead of (2i, 2i + 1): qwen2-type files; the whole head rotates (n_rot == D)
     // diagnosis (MI355_ATTN_PROBE=1): 100 MHz wall-clock stamps.  [2 * wg], [2 * wg + 1] = start / partials-stored of every
     // workgroup (wg = sp * G + g); [4096 + 8 * g + k] = the merging workgroup of kv head g: ticket taken, weights done,
     // partials summed, outputs stored
@@ -90,7 +91,10 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         const int pp = tid + 256 * j;
         if (pp < NPAIR) {
             const int r = pp / HP, i = pp % HP;
-            {
+            if (fz.neox) {                                      // the pair's halves lie D / 2 apart
+                const int o = (int)((((size_t)t * H + (size_t)g * R + r) * D + i) * 4);
+                qv[j] = make_float2(__uint_as_float(cld4<COH>(a.q, o)), __uint_as_float(cld4<COH>(a.q, o + HP * 4)));
+            } else {
                 const coh_u32x2 qq = cld8<COH>(a.q, (int)((((size_t)t * H + (size_t)g * R + r) * D + 2 * i) * 4));
                 qv[j] = make_float2(__uint_as_float(qq.x), __uint_as_float(qq.y));
             }
@@ -138,7 +142,17 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
                 const coh_u32x4 xx = cld16<COH>(isk ? fz.knew : fz.vnew, ((t * a.G + g) * D + dd) * 4);
                 x4 = make_float4(__uint_as_float(xx.x), __uint_as_float(xx.y), __uint_as_float(xx.z), __uint_as_float(xx.w));
             }
-            if (isk && dd < n_rot) {
+            if (fz.neox) {
+                // NEOX pairing: element e < D / 2 rotates with e + D / 2, which sits DQ / 2 lanes further on (both K lanes and V lanes run the exchange)
+                const float p0 = __shfl_xor(x4.x, DQ / 2), p1 = __shfl_xor(x4.y, DQ / 2), p2 = __shfl_xor(x4.z, DQ / 2), p3 = __shfl_xor(x4.w, DQ / 2);
+                if (isk) {
+                    const bool lo = dd < HP;
+                    const float *cp = cs_table + (size_t)t * n_rot + 2 * (lo ? dd : dd - HP);              // (c, s) of pairs dd' .. dd' + 3
+                    const float4 ca = *reinterpret_cast<const float4 *>(cp), cb = *reinterpret_cast<const float4 *>(cp + 4);
+                    if (lo) { x4.x = x4.x * ca.x - p0 * ca.y; x4.y = x4.y * ca.z - p1 * ca.w; x4.z = x4.z * cb.x - p2 * cb.y; x4.w = x4.w * cb.z - p3 * cb.w; }
+                    else { x4.x = p0 * ca.y + x4.x * ca.x; x4.y = p1 * ca.w + x4.y * ca.z; x4.z = p2 * cb.y + x4.z * cb.x; x4.w = p3 * cb.w + x4.w * cb.z; }
+                }
+            } else if (isk && dd < n_rot) {
                 const float4 cs = *reinterpret_cast<const float4 *>(cs_table + (size_t)t * n_rot + dd);   // c0 s0 c1 s1
                 const float x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
                 x4.x = x0 * cs.x - x1 * cs.y; x4.y = x0 * cs.y + x1 * cs.x;
@@ -175,7 +189,8 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
             const float x0 = qv[j].x, x1 = qv[j].y, c = csv[j].x, s = csv[j].y;
             float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;
             if (TK == T_F16) { y0 = h2f(f2h(y0)); y1 = h2f(f2h(y1)); }
-            *reinterpret_cast<float2 *>(qf + 2 * pp) = make_float2(y0, y1);
+            if (fz.neox) { const int r = pp / HP, i = pp % HP; qf[r * D + i] = y0; qf[r * D + i + HP] = y1; }
+            else *reinterpret_cast<float2 *>(qf + 2 * pp) = make_float2(y0, y1);
         }
     }
     __syncthreads();
@@ -308,7 +323,8 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     // ---- FUSED: ticket; the last workgroup of this kv head merges.  The merge also quantises whole 256-element blocks of
     // the attention output, so with one 128-wide query head per kv head (R = 1, multi-head attention) TWO neighbouring kv
     // heads share a ticket and the last arriver of the pair merges both: GP kv heads per ticket, RM = GP * R heads merged.
-    constexpr int GP = (R * D) % 256 == 0 ? 1 : 256 / (R * D);
+    // (in general the smallest number of kv heads whose R * D outputs fill whole blocks: 256 / gcd(R * D, 256) - two for 3, 5 or 7 query heads of 128 per kv head)
+    constexpr int GP = 256 / ((R * D) % 256 == 0 ? 256 : (R * D) % 128 == 0 ? 128 : (R * D) % 64 == 0 ? 64 : 32);
     constexpr int RM = R * GP;
     const int gq = g / GP;                                     // ticket group
     const int hb = gq * RM;                                    // its first query head
@@ -334,7 +350,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     // sums its splits in order (the combine kernel's arithmetic), but the partials of the first 32 splits of all of this
     // thread's outputs are requested BEFORE the (m, l) pairs, so the weight computation runs under them: ticket, one trip
     // for (m, l) + 32 splits, one more per further 32 splits (it was ticket + (m, l) + one trip per 8 splits and output).
-    constexpr int NE = (RM * D + 255) / 256, UB = 32;
+    constexpr int NE = (RM * D + 255) / 256, UB = NE > 4 ? 16 : 32;     // (NE * UB partials in registers per thread)
     float macc[NE], x[NE][UB];
     const float *pp[NE];
     int wr[NE];

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
 
 bool flash_attn_prefill_applicable(const AttnArgs &a) {
     const int R = a.G > 0 ? a.H / a.G : 0;
-    return a.D == 128 && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16)) && (R == 1 || R == 2 || R == 4 || R == 8) &&
+    return a.D == 128 && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16)) && R >= 1 && R <= 8 &&
            a.n_kv_max <= MAX_CHUNKS * CK;
 }
 
@@ -602,6 +602,11 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
         case 2: if (kh == 2 && qs == 2) FAP(2, 2, 2); else if (kh == 2) FAP(2, 2, 1); else if (qs == 2) FAP(2, 1, 2); else FAP(2, 1, 1); break;
         case 4: if (kh == 2) FAP(4, 2, 1); else FAP(4, 1, 1); break;
         case 8: FAP(8, 1, 1); break;
+        // 3, 5, 6, 7 query heads per kv head (Llama-3.2-3B, Qwen2-1.5B / 7B, Yi-34B): one wave per head as for 4 and 8 (the workgroup is 3 .. 7 waves wide per half)
+        case 3: if (kh == 2) FAP(3, 2, 1); else FAP(3, 1, 1); break;
+        case 5: FAP(5, 1, 1); break;
+        case 6: FAP(6, 1, 1); break;
+        case 7: FAP(7, 1, 1); break;
         default: return hipErrorInvalidValue;
     }
 #undef FAP

@@ -187,6 +187,9 @@ CONFIGS = {
     "tiny-qwen2": LlamaConfig("tiny-qwen2", 512, 3, 8, 2, 1024, 768, 1e6, 1e-6, 1024, arch="qwen2", qkv_bias=True),
     "tiny-qwen2-1.5b-2l": LlamaConfig("tiny-qwen2-1.5b-2l", 1536, 2, 12, 2, 8960, 512, 1e6, 1e-6, 1024, arch="qwen2", qkv_bias=True),
     "tiny-qwen2-7b-2l": LlamaConfig("tiny-qwen2-7b-2l", 3584, 2, 28, 4, 18944, 512, 1e6, 1e-6, 1024, arch="qwen2", qkv_bias=True),
+    # three and five query heads of 128 per kv head (Llama-3.2-3B's 24 / 8; 40 / 8): the attention kernels' odd head ratios on prompts and steps
+    "tiny-r3": LlamaConfig("tiny-r3", 1536, 2, 12, 4, 4096, 512, 500000.0, 1e-5, 1024),
+    "tiny-r5": LlamaConfig("tiny-r5", 1280, 2, 10, 2, 3584, 512, 500000.0, 1e-5, 1024),
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 

@@ -80,7 +80,10 @@ def rel_err(a, b):
                                           # general.architecture "qwen2" (a weekend-test family of the reference): NEOX rope pairing, Q / K / V biases; head_dim 64 and the
                                           # layer geometries of Qwen2-1.5B (6 query heads per kv head) and Qwen2-7B (7; hidden 3584 and feed-forward 18944: no multiple of 1024)
                                           ("tiny-qwen2", "q4_k_m", "q8_0"), ("tiny-qwen2:40", "q5_k_m", "f16"), ("tiny-qwen2", "q8_0", "q8_0"),
-                                          ("tiny-qwen2-1.5b-2l", "q4_k_m", "q8_0"), ("tiny-qwen2-7b-2l:40", "q4_k_m", "q8_0"), ("tiny-qwen2-7b-2l", "q4_0", "f16")])
+                                          ("tiny-qwen2-1.5b-2l", "q4_k_m", "q8_0"), ("tiny-qwen2-7b-2l:40", "q4_k_m", "q8_0"), ("tiny-qwen2-7b-2l", "q4_0", "f16"),
+                                          ("tiny-qwen2-1.5b-2l:70", "q4_k_m", "f16"),
+                                          # 3 and 5 query heads per kv head: matrix-core prompt attention (40 / 70 tokens) and the single-launch decode attention, both cache types
+                                          ("tiny-r3:40", "q4_k_m", "q8_0"), ("tiny-r3:70", "q5_k_m", "f16"), ("tiny-r5:40", "q4_k_m", "f16"), ("tiny-r5:50", "q4_k_m", "q8_0")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
     path = make(pkg, tmp_models, cfg, ftype)
@@ -505,6 +508,47 @@ def test_ubatch_split_and_multi_sequence(be, pkg, tmp_models):
     c.close(); m.close(); oc.close(); om.close()
 
 
+@pytest.mark.parametrize("cfg,kv", [("tiny-qwen2-7b-2l", "q8_0"), ("tiny-qwen2", "f16"), ("tiny-qwen2-1.5b-2l", "q8_0")])
+def test_neox_batched_steps_match_oracle(be, pkg, tmp_models, cfg, kv):
+    """qwen2-type files through the continuous-batching step: three sequences of different lengths advance together (every token of another sequence: K is
+    rotated with the NEOX pairing and stored inside the attention launch), then one sequence takes two tokens in one step (the general path); against the
+    CPU restatement, sequence by sequence.  Also a context shift on one of them (K re-rotation with the NEOX pairing)."""
+    path = make(pkg, tmp_models, cfg, "q4_k_m")
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
+    try:
+        m = pkg.Model(path)
+        c = pkg.Context(m, n_ctx=512, n_seq_max=4, type_k=KV[kv], type_v=KV[kv])
+        om = oq.OracleModel(path)
+        oc = oq.OracleContext(om, 512, KV[kv], KV[kv], True, 4)
+        rng = np.random.default_rng(17)
+        lens = [70, 9, 33]
+        for sq, n in enumerate(lens):
+            p = rng.integers(0, m.n_vocab, n)
+            fl = np.zeros(n, np.int8); fl[-1] = 1
+            assert c.decode(p, np.arange(n), [sq] * n, fl) == 0
+            r = oc.decode(p, np.arange(n), [sq] * n, fl)
+            assert rel_err(c.logits(n - 1), r[0]) <= FLIP_TOL
+        toks = [3, 5, 7]
+        for step in range(8):
+            pos = [n + step for n in lens]
+            assert c.decode(toks, pos, [0, 1, 2], [1, 1, 1]) == 0
+            r = oc.decode(toks, pos, [0, 1, 2], [1, 1, 1])
+            for j in range(3):
+                assert rel_err(c.logits(j), r[j]) <= FLIP_TOL, (step, j)
+            toks = [int(x.argmax()) for x in r]
+        for x in (c, oc):                       # context shift on sequence 0: drop [4, 20), slide the rest down
+            x.kv_seq_rm(0, 4, 20)
+            x.kv_seq_add(0, 20, lens[0] + 8, -16)
+        p0 = lens[0] + 8 - 16
+        assert c.decode([toks[0], 11], [p0, p0 + 1], [0, 0], [1, 1]) == 0
+        r = oc.decode([toks[0], 11], [p0, p0 + 1], [0, 0], [1, 1])
+        for j in range(2):
+            assert rel_err(c.logits(j), r[j]) <= FLIP_TOL
+        c.close(); m.close(); oc.close(); om.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
+
+
 @pytest.mark.parametrize("kv", ["f16", "q8_0"])
 def test_kv_seq_ops_match_oracle(be, pkg, tmp_models, kv):
     """prompt-prefix reuse (seq_rm), seq_cp, and context shift (seq_rm + seq_add => K re-rotation), as
@@ -782,6 +826,7 @@ SHAPES = {
     "llama-2-13b": (5120, 40, 40, 13824),
     "llama-30b": (6656, 52, 52, 17920),
     "codellama-34b": (8192, 64, 8, 22016),
+    "gqa-5": (5120, 40, 8, 13824),             # five query heads per kv head
     "llama-3-70b": (8192, 64, 8, 28672),
 }
 
