@@ -190,6 +190,9 @@ CONFIGS = {
     # three and five query heads of 128 per kv head (Llama-3.2-3B's 24 / 8; 40 / 8): the attention kernels' odd head ratios on prompts and steps
     "tiny-r3": LlamaConfig("tiny-r3", 1536, 2, 12, 4, 4096, 512, 500000.0, 1e-5, 1024),
     "tiny-r5": LlamaConfig("tiny-r5", 1280, 2, 10, 2, 3584, 512, 500000.0, 1e-5, 1024),
+    # YaRN rope scaling read from the file (factor 4 over an original context of 32 positions, attn_factor 0.9): golden fixture + parity case
+    "tiny-yarn": LlamaConfig("tiny-yarn", 512, 3, 8, 2, 1024, 768, 500000.0, 1e-5, 1024,
+                             extra={"rope.scaling.type": "yarn", "rope.scaling.factor": 4.0, "rope.scaling.original_context_length": 32, "rope.scaling.attn_factor": 0.9}),
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 

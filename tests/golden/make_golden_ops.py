@@ -158,7 +158,9 @@ def make_ops():
     print("wrote ops_v1.npz", {k: v.shape for k, v in out.items()})
 
 
-E2E_CASES = [("tiny", "q4_k_m", "q8_0", 7), ("tiny-d128", "q5_k_m", "f16", 11), ("tiny-moe", "q4_k_m", "q8_0", 13)]
+E2E_CASES = [("tiny", "q4_k_m", "q8_0", 7), ("tiny-d128", "q5_k_m", "f16", 11), ("tiny-moe", "q4_k_m", "q8_0", 13),
+             # round 3: general.architecture qwen2 (NEOX pairing, Q / K / V biases) and YaRN rope scaling from the file's metadata
+             ("tiny-qwen2", "q4_k_m", "q8_0", 17), ("tiny-yarn", "q4_k_m", "q8_0", 19)]
 N_PROMPT, N_STEPS = 12, 32
 
 
