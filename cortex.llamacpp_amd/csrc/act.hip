@@ -160,6 +160,34 @@ hipError_t launch_add_qkv_bias(float *q, float *k, float *v, const float *bq, co
     return hipGetLastError();
 }
 
+// LayerNorm with weight and bias (ggml_norm + ggml_mul + ggml_add, build_norm(LLM_NORM): encoder models), one workgroup per row: mean and variance in double
+// (the CPU sums them in double, sequentially; here tree-ordered), y = (x - mean) * rsqrt(var + eps) * w + b with the CPU's operation order.  In place allowed.
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, const float *w, const float *b, int n, float eps, float *y) {
+    __shared__ double red[4];
+    const float *xr = x + (size_t)blockIdx.x * n;
+    float *yr = y + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)xr[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+    __syncthreads();
+    double s2 = 0.0;
+    for (int i = tid; i < n; i += 256) { const float v = xr[i] - mean; s2 += (double)(v * v); }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[wave] = s2;
+    __syncthreads();
+    const float variance = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+    const float scale = 1.0f / sqrtf(variance + eps);
+    for (int i = tid; i < n; i += 256) yr[i] = ((xr[i] - mean) * scale) * w[i] + b[i];
+}
+hipError_t launch_layer_norm(const float *x, const float *w, const float *b, int n, int T, float eps, float *y, hipStream_t st) {
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)T), dim3(256), 0, st, x, w, b, n, eps, y);
+    return hipGetLastError();
+}
+
 // row softmax: y = softmax(x*scale + mask)   (ggml_soft_max_ext, max_bias = 0)
 __global__ __launch_bounds__(256) void soft_max_kernel(const float *x, const float *mask, float *y, int n, float scale) {
     __shared__ float redf[4];

@@ -153,6 +153,8 @@ hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, fl
 // quantise f32 rows
 hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
                            int8_t *bh = nullptr, int8_t *bl = nullptr);
+// LayerNorm rows with weight and bias (encoder models): y[t] = (x[t] - mean) * rsqrt(var + eps) * w + b; y may be x
+hipError_t launch_layer_norm(const float *x, const float *w, const float *b, int n, int T, float eps, float *y, hipStream_t st);
 hipError_t launch_swiglu(const float *g, const float *u, float *y, int64_t n, hipStream_t st);
 // silu(g) * u quantised for the next mat-mul without an f32 round trip (n % 256 == 0); same blocks as launch_swiglu + launch_quantize
 hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,

@@ -193,6 +193,10 @@ CONFIGS = {
     # YaRN rope scaling read from the file (factor 4 over an original context of 32 positions, attn_factor 0.9): golden fixture + parity case
     "tiny-yarn": LlamaConfig("tiny-yarn", 512, 3, 8, 2, 1024, 768, 500000.0, 1e-5, 1024,
                              extra={"rope.scaling.type": "yarn", "rope.scaling.factor": 4.0, "rope.scaling.original_context_length": 32, "rope.scaling.attn_factor": 0.9}),
+    # general.architecture nomic-bert (the reference's embedding smoke model is nomic-embed-text-v1.5, Makefile:6): a bidirectional encoder, embeddings only.
+    # tiny-nomic: head_dim 64 as the real one; nomic-embed-2l: two layers of its geometry (768, 12 heads of 64, 3072, 30522 WordPiece tokens, rope base 1000)
+    "tiny-nomic": LlamaConfig("tiny-nomic", 256, 2, 4, 4, 512, 512, 1000.0, 1e-12, 2048, arch="nomic-bert"),
+    "nomic-embed-2l": LlamaConfig("nomic-embed-2l", 768, 2, 12, 12, 3072, 30522, 1000.0, 1e-12, 2048, arch="nomic-bert"),
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 
@@ -265,6 +269,23 @@ def model_tensors(cfg: LlamaConfig, ftype: str):
     E, F, V = cfg.n_embd, cfg.n_ff, cfg.n_vocab
     kv = cfg.n_head_kv * cfg.head_dim
     out = [("token_embd.weight", (E, V), tensor_type(cfg, ftype, "token_embd", 0), None)]
+    if cfg.arch == "nomic-bert":
+        # encoder: token-type table, LayerNorms with biases, fused Q | K | V; no output head (the reference's embedding smoke model, Makefile:6)
+        out.append(("token_types.weight", (E, 2), F32, E))
+        out.append(("token_embd_norm.weight", (E,), F32, None))
+        out.append(("token_embd_norm.bias", (E,), F32, None))
+        for il in range(cfg.n_layer):
+            p = f"blk.{il}."
+            out.append((p + "attn_qkv.weight", (E, E + 2 * kv), tensor_type(cfg, ftype, "attn_qkv", il), E))
+            out.append((p + "attn_output.weight", (E, E), tensor_type(cfg, ftype, "attn_output", il), E))
+            out.append((p + "attn_output_norm.weight", (E,), F32, None))
+            out.append((p + "attn_output_norm.bias", (E,), F32, None))
+            out.append((p + "ffn_up.weight", (E, F), tensor_type(cfg, ftype, "ffn_up", il), E))
+            out.append((p + "ffn_gate.weight", (E, F), tensor_type(cfg, ftype, "ffn_gate", il), E))
+            out.append((p + "ffn_down.weight", (F, E), tensor_type(cfg, ftype, "ffn_down", il), F))
+            out.append((p + "layer_output_norm.weight", (E,), F32, None))
+            out.append((p + "layer_output_norm.bias", (E,), F32, None))
+        return out
     for il in range(cfg.n_layer):
         p = f"blk.{il}."
         out.append((p + "attn_norm.weight", (E,), F32, None))
@@ -323,7 +344,12 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
     w.add(f"{a}.feed_forward_length", "u32", cfg.n_ff)
     w.add(f"{a}.attention.head_count", "u32", cfg.n_head)
     w.add(f"{a}.attention.head_count_kv", "u32", cfg.n_head_kv)
-    w.add(f"{a}.attention.layer_norm_rms_epsilon", "f32", cfg.eps)
+    if cfg.arch == "nomic-bert":
+        w.add(f"{a}.attention.layer_norm_epsilon", "f32", cfg.eps)
+        w.add(f"{a}.attention.causal", "bool", False)
+        w.add(f"{a}.pooling_type", "u32", 1)
+    else:
+        w.add(f"{a}.attention.layer_norm_rms_epsilon", "f32", cfg.eps)
     w.add(f"{a}.rope.dimension_count", "u32", cfg.head_dim)
     w.add(f"{a}.rope.freq_base", "f32", cfg.rope_base)
     w.add(f"{a}.vocab_size", "u32", cfg.n_vocab)
@@ -332,7 +358,39 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
         w.add(f"{a}.expert_used_count", "u32", cfg.n_expert_used)
     for k, v in cfg.extra.items():                 # e.g. {"pooling_type": 1, "rope.scaling.type": "yarn", "rope.scaling.factor": 4.0}: extra keys under the architecture prefix
         w.add(f"{a}.{k}", "str" if isinstance(v, str) else "f32" if isinstance(v, float) else "u32", v)
-    if with_vocab:
+    if with_vocab and cfg.arch == "nomic-bert":
+        # synthetic WordPiece vocabulary in the GGUF convention (word-initial pieces carry the U+2581 prefix, continuations are bare): the five BERT specials,
+        # letters / digits / punctuation in both roles, then generated multi-letter pieces
+        toks, types = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"], [3, 3, 3, 3, 3]
+        alphabet = "abcdefghijklmnopqrstuvwxyz0123456789"
+        for ch in alphabet + ".,!?'-":
+            toks += ["\u2581" + ch, ch]
+            types += [1, 1]
+        i = 0
+        while len(toks) < cfg.n_vocab:
+            s, k = "", i + 36
+            while True:
+                s = alphabet[k % 26] + s
+                k //= 26
+                if k == 0:
+                    break
+            piece = ("\u2581" + s) if i % 2 == 0 else s
+            if piece not in toks[:100] and len(s) > 1:
+                toks.append(piece)
+                types.append(1)
+            i += 1
+        w.add("tokenizer.ggml.model", "str", "bert")
+        w.add_array("tokenizer.ggml.tokens", "str", toks[: cfg.n_vocab])
+        w.add_array("tokenizer.ggml.token_type", "i32", types[: cfg.n_vocab])
+        w.add("tokenizer.ggml.token_type_count", "u32", 2)
+        w.add("tokenizer.ggml.unknown_token_id", "u32", 1)
+        w.add("tokenizer.ggml.seperator_token_id", "u32", 3)
+        w.add("tokenizer.ggml.padding_token_id", "u32", 0)
+        w.add("tokenizer.ggml.cls_token_id", "u32", 2)
+        w.add("tokenizer.ggml.mask_token_id", "u32", 4)
+        w.add("tokenizer.ggml.bos_token_id", "u32", 2)
+        w.add("tokenizer.ggml.eos_token_id", "u32", 3)
+    elif with_vocab:
         # synthetic SentencePiece-style vocab: <unk>,<s>,</s>, 256 byte tokens, then printable pieces
         toks, scores, types = ["<unk>", "<s>", "</s>"], [0.0, 0.0, 0.0], [2, 3, 3]
         for b in range(256):

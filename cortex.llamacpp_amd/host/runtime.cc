@@ -64,14 +64,16 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     if (hp.arch.empty()) { err = "general.architecture missing"; status = -102; return nullptr; }
     // the graph built here is llm_build_llama's: "llama" files (Llama, Mistral, TinyLlama, Mixtral ... all carry that name) and "qwen2"
     // (the same op order with NEOX rope pairing and Q / K / V biases).  Gemma, Phi-3, BERT-type encoders etc. are other graphs: refused, never run as llama
-    if (hp.arch != "llama" && hp.arch != "qwen2") { err = "unsupported general.architecture '" + hp.arch + "' (this backend builds the llama graph: llama, qwen2)"; status = -102; return nullptr; }
+    // "nomic-bert" (the reference's embedding smoke model, Makefile:6) is the one encoder graph: llm_build_bert's NOMIC_BERT branches (run_layers_encoder)
+    if (hp.arch != "llama" && hp.arch != "qwen2" && hp.arch != "nomic-bert") { err = "unsupported general.architecture '" + hp.arch + "' (this backend builds the llama graph - llama, qwen2 - and the nomic-bert encoder)"; status = -102; return nullptr; }
+    hp.encoder = hp.arch == "nomic-bert";
     const std::string a = hp.arch + ".";
     hp.n_embd = (int)f.get_u(a + "embedding_length", 0);
     hp.n_layer = (int)f.get_u(a + "block_count", 0);
     hp.n_ff = (int)f.get_u(a + "feed_forward_length", 0);
     hp.n_head = (int)f.get_u(a + "attention.head_count", 0);
     hp.n_head_kv = (int)f.get_u(a + "attention.head_count_kv", (uint64_t)hp.n_head);
-    hp.eps = (float)f.get_f(a + "attention.layer_norm_rms_epsilon", 1e-5);
+    hp.eps = (float)f.get_f(a + (hp.encoder ? "attention.layer_norm_epsilon" : "attention.layer_norm_rms_epsilon"), hp.encoder ? 1e-12 : 1e-5);
     hp.rope_base = (float)f.get_f(a + "rope.freq_base", 10000.0);
     hp.n_expert = (int)f.get_u(a + "expert_count", 0);
     hp.n_expert_used = (int)f.get_u(a + "expert_used_count", 0);
@@ -180,6 +182,28 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         if (dst.type == T_Q6_K || dst.type == T_Q8_0 || dst.type == T_Q2_K || dst.type == T_Q3_K || dst.type == T_Q4_0 || dst.type == T_Q5_0 || dst.type == T_IQ4_NL || dst.row_bytes != ggml_row_bytes(dst.type, dst.K)) max_stage = std::max(max_stage, pl.src_bytes);
     };
     want("token_embd.weight", m->tok_embd, true);
+    if (hp.encoder) {
+        if (P > 1) { err = "row split of encoder files is not supported"; status = -102; return nullptr; }
+        if (hp.n_expert > 0) { err = "mixture-of-experts encoder files are not supported"; status = -102; return nullptr; }
+        want("token_types.weight", m->tok_types, false);
+        want("token_embd_norm.weight", m->tok_norm, true);
+        want("token_embd_norm.bias", m->tok_norm_b, true);
+        m->layers.resize((size_t)hp.n_layer);
+        for (int il = 0; il < hp.n_layer && !fail; il++) {
+            LayerWeights &L = m->layers[(size_t)il];
+            const std::string p = "blk." + std::to_string(il) + ".";
+            want(p + "attn_qkv.weight", L.wqkv, true);
+            want(p + "attn_output.weight", L.wo, true);
+            want(p + "attn_output.bias", L.bo, false);
+            want(p + "attn_output_norm.weight", L.attn_out_norm, true);
+            want(p + "attn_output_norm.bias", L.attn_out_norm_b, true);
+            want(p + "ffn_gate.weight", L.gate, true);
+            want(p + "ffn_up.weight", L.up, true);
+            want(p + "ffn_down.weight", L.down, true);
+            want(p + "layer_output_norm.weight", L.layer_out_norm, true);
+            want(p + "layer_output_norm.bias", L.layer_out_norm_b, true);
+        }
+    } else {
     want("output_norm.weight", m->out_norm, true);
     {   // the output projection is cut by vocabulary rows when they divide evenly (logits are gathered), else every rank keeps it whole
         const GGUFTensorInfo *ot = f.tensor("output.weight");
@@ -210,6 +234,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
             want(p + "ffn_down.weight", L.down, true, SPLIT_COLS);
         }
     }
+    }
     if (fail) { status = -102; return nullptr; }
     // ---- every tensor against the shape the hyper-parameters imply (per rank under a row split).  The activation buffers
     // are sized from the hyper-parameters and the kernels write one value per weight ROW: a file whose tensors disagree
@@ -228,6 +253,25 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         };
         if (m->tok_embd.K != E || m->tok_embd.N <= 0 || m->tok_embd.n_expert != 1) { err = "token_embd.weight does not have embedding_length columns"; fail = true; }
         const int64_t V = m->tok_embd.N;
+        if (hp.encoder) {
+            if (!m->tok_types.name.empty() && (m->tok_types.K != E || m->tok_types.N < 1 || m->tok_types.type != T_F32)) { err = "token_types.weight must hold f32 rows of embedding_length"; fail = true; }
+            shape(m->tok_norm, E, 0, 0, true); shape(m->tok_norm_b, E, 0, 0, true);
+            if (hp.n_rot != D) { err = "encoder files rotate whole heads (rope.dimension_count must equal the head size)"; fail = true; }
+            int64_t FFe = 0;
+            for (int il = 0; il < hp.n_layer && !fail; il++) {
+                const LayerWeights &L = m->layers[(size_t)il];
+                if (il == 0) FFe = L.gate.N;
+                shape(L.wqkv, E, QW + 2 * KVW, 1, false); shape(L.wo, QW, E, 1, false); shape(L.bo, E, 0, 0, true);
+                shape(L.attn_out_norm, E, 0, 0, true); shape(L.attn_out_norm_b, E, 0, 0, true);
+                shape(L.layer_out_norm, E, 0, 0, true); shape(L.layer_out_norm_b, E, 0, 0, true);
+                shape(L.gate, E, FFe, 1, false); shape(L.up, E, FFe, 1, false); shape(L.down, FFe, E, 1, false);
+                if (!fail && (FFe <= 0 || (hp.n_ff_full > 0 && FFe != hp.n_ff_full))) { err = "feed-forward tensors do not match feed_forward_length"; fail = true; }
+                for (const DevTensor *t : {&L.bo, &L.attn_out_norm, &L.attn_out_norm_b, &L.layer_out_norm, &L.layer_out_norm_b})
+                    if (!fail && !t->name.empty() && t->type != T_F32) { err = "tensor " + t->name + " must be f32"; fail = true; }
+            }
+            if (!fail && (m->tok_norm.type != T_F32 || m->tok_norm_b.type != T_F32)) { err = "token_embd_norm must be f32"; fail = true; }
+            if (fail) { status = -102; return nullptr; }
+        } else {
         shape(m->out_norm, E, 0, 0, true);
         if (!m->output.name.empty()) shape(m->output, E, f.tensor("output.weight")->ne[1] % P == 0 ? V / P : V, 1, false);
         if (!m->rope_freqs.name.empty() && (m->rope_freqs.K != hp.n_rot / 2 || m->rope_freqs.type != T_F32)) { err = "rope_freqs.weight must hold rope.dimension_count / 2 f32 factors"; fail = true; }
@@ -256,6 +300,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         }
         if (!fail && m->out_norm.type != T_F32) { err = "output_norm.weight must be f32"; fail = true; }
         if (fail) { status = -102; return nullptr; }
+        }
     }
     hp.n_vocab = (int)m->tok_embd.N;
     hp.n_ff = (int)(hp.n_expert ? m->layers[0].gate_exps.N : m->layers[0].gate.N);     // this rank's width under a row split
@@ -294,6 +339,21 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     if (stage) (void)hipFree(stage);
     (void)hipStreamDestroy(st);
     if (!m->output.valid()) m->output = m->tok_embd;   // tied embeddings
+    if (hp.encoder) {
+        // Q, K and V are row ranges of the fused projection: views into its device rows (one launch each; the rows are contiguous per output)
+        for (auto &L : m->layers) {
+            const int64_t qw = (int64_t)hp.n_head * hp.head_dim, kvw = (int64_t)hp.n_head_kv * hp.head_dim;
+            auto view = [&](DevTensor &v, int64_t row0, int64_t rows, const char *what) {
+                v = L.wqkv;
+                v.name = L.wqkv.name + "[" + what + "]";
+                v.N = rows;
+                v.data = L.wqkv.data + (size_t)row0 * L.wqkv.row_bytes;
+                v.bytes = (size_t)rows * L.wqkv.row_bytes;
+                v.planes = nullptr; v.planes_bytes = 0;
+            };
+            view(L.wq, 0, qw, "q"); view(L.wk, qw, kvw, "k"); view(L.wv, qw + kvw, kvw, "v");
+        }
+    }
     m->device_bytes = total;
     m->host_bytes = 0;
 
@@ -597,7 +657,12 @@ bool Context::init(std::string &err) {
     d_embd_ = (float *)dalloc(T * E * 4);
     if (hipHostMalloc((void **)&h_embd_, T * E * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
     if (hipHostMalloc((void **)&h_argmax_, T * 4, hipHostMallocDefault) != hipSuccess) { err = "pinned alloc failed"; return false; }
-    embeddings_enabled = cp.embeddings;
+    embeddings_enabled = cp.embeddings || model->hp.encoder;      // an encoder has nothing but embeddings to give
+    if (model->hp.encoder) {
+        d_pos_open_ = (int32_t *)dalloc(T * 4);
+        std::vector<int32_t> open((size_t)T, 0x7fffffff);
+        if (!d_pos_open_ || hipMemcpy(d_pos_open_, open.data(), T * 4, hipMemcpyHostToDevice) != hipSuccess) { err = "encoder position buffer allocation failed"; return false; }
+    }
     kv_clear();
     // the zero-fills above ran on the null stream, which the context's non-blocking stream does not wait for: drain them
     // before any kernel can touch these buffers (a late fill would wipe live KV rows; seen under rocprofv3 --pmc)
@@ -1087,7 +1152,76 @@ bool Context::engine_prepare() {
 }
 
 // ------------------------------------------------------------------------------------------ the forward pass
+// nomic-bert (llm_build_bert, the NOMIC_BERT branches): token + type-0 embeddings -> LayerNorm; per layer the fused Q | K | V projection, NEOX rope on Q and K,
+// attention over ALL cells of the token's sequence (bidirectional: the attention kernels get INT_MAX as every token's position, so their causal test always
+// passes), attn_output (+ bias), residual, LayerNorm, SwiGLU feed-forward, residual, LayerNorm.  The output is the last layer's hidden state; there is no head.
+// K / V rows go through the context's cache like a prompt batch's (the whole sequence is one micro-batch: Context::decode checks that).
+hipError_t Context::run_layers_encoder(int T, int n_kv_cap) {
+    cur_T_ = T;
+    const HParams &hp = model->hp;
+    const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
+    RopeArgs ra = rope_args(*model, true);
+    const float kq_scale = 1.0f / sqrtf((float)D);
+    const int n_kv_max = std::max(n_kv_cap, 1);
+    att_splits_ = flash_attn_pick_splits(T, G, n_kv_max);
+    last_layers_mega_ = false; last_layers_engine_ = false;
+    HIP_TRY(launch_step_setup_embed(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, nullptr, nullptr, model->tok_embd.type, model->tok_embd.data, E,
+                                    d_tok_, x_, stream_));
+    if (model->tok_types.valid())      // token types are all zero: row 0 of the table on every token
+        HIP_TRY(launch_add_qkv_bias(x_, nullptr, nullptr, (const float *)model->tok_types.data, nullptr, nullptr, E, 0, T, stream_));
+    HIP_TRY(launch_layer_norm(x_, (const float *)model->tok_norm.data, (const float *)model->tok_norm_b.data, E, T, hp.eps, x_, stream_));
+    prof_mark("embed");
+    // quantised weight tensors contract against a quantised copy of their input (Q8_K for K-quants, Q8_0 otherwise), float tensors against the f32 rows
+    auto quantise_for = [&](const float *x, int K, ActQuant &aq, std::initializer_list<const DevTensor *> ws) -> hipError_t {
+        bool k = false, z = false;
+        for (const DevTensor *w : ws) if (is_quant(w->type)) { if (act_is_q80(w->type)) z = true; else k = true; }
+        if (!k && !z) return hipSuccess;
+        prep_owner_ = nullptr;
+        return launch_quantize(x, K, T, aq, k, z, stream_);
+    };
+    for (int il = 0; il < hp.n_layer; il++) {
+        const LayerWeights &L = model->layers[(size_t)il];
+        HIP_TRY(quantise_for(x_, E, aq_e_, {&L.wq, &L.wk, &L.wv}));
+        const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
+        float *outs[3] = {q_, k_, v_};
+        HIP_TRY(linear_multi(ws, outs, 3, aq_e_, x_, T));
+        prof_mark("qkv");
+        HIP_TRY(launch_rope_kv_store(q_, k_, v_, T, H, G, D, d_pos_, d_cell_, ra, kv_[(size_t)il], cp.type_k, cp.type_v, (int)cp.n_ctx, rope_cs_, stream_));
+        prof_mark("rope_kv");
+        AttnArgs aa{};
+        aa.q = q_; aa.out = att_; aa.kv = kv_[(size_t)il]; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
+        aa.T = T; aa.H = H; aa.G = G; aa.D = D; aa.n_ctx = (int)cp.n_ctx;
+        aa.cell_pos = d_cell_pos_; aa.cell_seq = d_cell_seq_; aa.tok_pos = d_pos_open_; aa.tok_seq = d_seq_;
+        aa.n_kv_dev = d_nkv_; aa.n_kv_max = n_kv_max; aa.scale = kq_scale; aa.part = att_part_;
+        aa.out_q = nullptr; aa.out_q8k = false; aa.out_q80 = false;
+        aa.splits = att_splits_;
+        aa.pf_splits = flash_attn_prefill_splits(T, H, G, D, n_kv_max);
+        while (aa.pf_splits > 1 && flash_attn_workspace_floats(T, H, D, aa.pf_splits) > att_part_floats_) aa.pf_splits >>= 1;
+        HIP_TRY(launch_flash_attn(aa, stream_));
+        prof_mark("attn");
+        HIP_TRY(quantise_for(att_, H * D, aq_o_, {&L.wo}));
+        HIP_TRY(linear(L.wo, aq_o_, att_, H * D, T, q_, E, nullptr, EPI_STORE));
+        if (L.bo.valid()) HIP_TRY(launch_add_qkv_bias(q_, nullptr, nullptr, (const float *)L.bo.data, nullptr, nullptr, E, 0, T, stream_));
+        HIP_TRY(launch_add(q_, x_, xn_, (int64_t)T * E, stream_));                       // re-add the layer input
+        HIP_TRY(launch_layer_norm(xn_, (const float *)L.attn_out_norm.data, (const float *)L.attn_out_norm_b.data, E, T, hp.eps, xn_, stream_));
+        prof_mark("attn_out");
+        HIP_TRY(quantise_for(xn_, E, aq_e_, {&L.gate, &L.up}));
+        HIP_TRY(linear(L.gate, aq_e_, xn_, E, T, ffn_, FF, nullptr, EPI_STORE));
+        HIP_TRY(linear(L.up, aq_e_, xn_, E, T, ffn_u_, FF, nullptr, EPI_STORE));
+        HIP_TRY(launch_swiglu(ffn_, ffn_u_, ffn_, (int64_t)T * FF, stream_));
+        prof_mark("ffn_gate_up");
+        HIP_TRY(quantise_for(ffn_, FF, aq_ff_, {&L.down}));
+        HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, T, q_, E, nullptr, EPI_STORE));
+        HIP_TRY(launch_add(q_, xn_, x_, (int64_t)T * E, stream_));                       // the attention output bypasses the feed-forward block
+        HIP_TRY(launch_layer_norm(x_, (const float *)L.layer_out_norm.data, (const float *)L.layer_out_norm_b.data, E, T, hp.eps, x_, stream_));
+        prof_mark("ffn_down");
+        if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
+    }
+    return hipSuccess;
+}
+
 hipError_t Context::run_layers(int T, int n_kv_cap) {
+    if (model->hp.encoder) return run_layers_encoder(T, n_kv_cap);
     cur_T_ = T;
     const HParams &hp = model->hp;
     const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, G = hp.n_head_kv, D = hp.head_dim;
@@ -1448,6 +1582,11 @@ hipError_t Context::run_output(int n_out, int out_base) {
     // (a single-token step has one row and it is the flagged one: no gather launch)
     float *const xo = cur_T_ == 1 && n_out == 1 ? x_ : xo_;
     if (xo != x_) HIP_TRY(launch_gather_rows_f32(x_, d_outrow_, n_out, E, xo_, stream_));
+    if (hp.encoder) {                                        // the embeddings ARE the last layer's rows (t_embd of llm_build_bert): no final norm, no head
+        HIP_TRY(hipMemcpyAsync(d_embd_ + (size_t)out_base * E, xo, (size_t)n_out * E * 4, hipMemcpyDeviceToDevice, stream_));
+        prof_mark("embd");
+        return hipSuccess;
+    }
     if (embeddings_enabled) {
         // embeddings mode (llama_set_embeddings): output = result_norm rows, no lm-head (pooling NONE on this architecture)
         HIP_TRY(launch_rmsnorm_quant(xo, (const float *)model->out_norm.data, E, n_out, hp.eps, d_embd_ + (size_t)out_base * E, nullptr, false, false, stream_));
@@ -1578,7 +1717,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
     const int V = model->hp.n_vocab;
-    if (n == 1) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
+    if (n == 1 && !model->hp.encoder) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
     bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
     hipError_t e = hipSuccess;
     if (graph_ok) {
@@ -1645,6 +1784,8 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
     if (n_tokens <= 0) { last_error = "empty batch"; return -1; }
     if (hipSetDevice(model->device) != hipSuccess) return -1;
     const HParams &hp = model->hp;
+    // bidirectional attention: every token of a sequence must see all the others, so a batch is never cut into micro-batches (llama.cpp asks the same: n_ubatch >= n_tokens)
+    if (hp.encoder && (size_t)n_tokens > cp.n_ubatch) { last_error = "encoder model: a batch of " + std::to_string(n_tokens) + " tokens does not fit one micro-batch (n_ubatch " + std::to_string(cp.n_ubatch) + ")"; return -1; }
     if (has_shift_) apply_k_shift();
     if (debug_taps_ && !dbg_) dbg_ = (float *)dalloc((size_t)hp.n_layer * cp.n_ubatch * hp.n_embd * 4);
 

@@ -37,6 +37,8 @@ struct LayerWeights {
     DevTensor attn_norm, wq, wk, wv, wo, bq, bk, bv;
     DevTensor ffn_norm, gate, up, down;
     DevTensor gate_inp, gate_exps, up_exps, down_exps;
+    // encoder files (nomic-bert): the fused Q | K | V projection (wq / wk / wv are row ranges of it), LayerNorms with biases after the attention and the feed-forward block
+    DevTensor wqkv, bo, attn_out_norm, attn_out_norm_b, layer_out_norm, layer_out_norm_b;
 };
 
 struct HParams {
@@ -46,6 +48,7 @@ struct HParams {
     int pooling_type = 0;          // {arch}.pooling_type: 0 none, 1 mean, 2 cls, 3 last (what llama_get_embeddings_seq pools over a sequence's tokens)
     float eps = 1e-5f, rope_base = 10000.0f, rope_scale = 1.0f;
     int rope_neox = 0;
+    bool encoder = false;          // bidirectional attention, embeddings only (general.architecture nomic-bert: llm_build_bert)
     float yarn_ext = 0.0f, yarn_attn = 1.0f, yarn_lo = 0.0f, yarn_hi = 0.0f;   // rope.scaling.type "yarn" (RopeArgs, kernels.h)
     // row split: n_head, n_head_kv and n_ff above are THIS RANK's share; the file's values are kept here.
     // A shard is the same graph with fewer heads and a narrower feed-forward, attn_output and ffn_down contracting over
@@ -63,6 +66,7 @@ struct Model {
     int device = 0;
     std::vector<uint8_t *> arenas;      // hipMalloc'd blocks
     DevTensor tok_embd, out_norm, output, rope_freqs;
+    DevTensor tok_types, tok_norm, tok_norm_b;       // encoder files: token-type table (row 0 is added to every token), LayerNorm of the embeddings
     std::vector<LayerWeights> layers;
     uint64_t device_bytes = 0, host_bytes = 0, file_tensor_bytes = 0, bytes_per_token = 0, planes_bytes = 0;
     ~Model();
@@ -151,6 +155,7 @@ class Context {
     std::vector<int> region_next_;     // per sequence: where its next cell is looked for first
     void apply_k_shift();
     hipError_t run_layers(int T, int n_kv_cap);
+    hipError_t run_layers_encoder(int T, int n_kv_cap);
     hipError_t run_output(int n_out, int out_base);
     hipError_t linear(const DevTensor &w, const ActQuant &aq, const float *x_f32, int K, int T, float *out, int ld_out,
                       const float *resid, int epi);
@@ -174,6 +179,7 @@ class Context {
     uint64_t *d_cell_seq_ = nullptr;
     int32_t *d_delta_ = nullptr;
     // per-ubatch token arrays (device) + pinned host staging
+    int32_t *d_pos_open_ = nullptr;     // encoder models: INT_MAX per token - the attention kernels' "cell position <= token position" test always passes
     int32_t *d_tok_ = nullptr, *d_pos_ = nullptr, *d_seq_ = nullptr, *d_cell_ = nullptr, *d_nkv_ = nullptr, *d_outrow_ = nullptr;
     uint64_t *d_seqmask_ = nullptr;
     uint8_t *h_stage_ = nullptr;    // pinned

@@ -72,6 +72,14 @@ bool Vocab::load(const GGUFFile &f, std::string &err) {
     add_bos_ = f.get_b("tokenizer.ggml.add_bos_token", model_ == "llama");
     add_eos_ = f.get_b("tokenizer.ggml.add_eos_token", false);
     add_space_prefix_ = f.get_b("tokenizer.ggml.add_space_prefix", true);
+    if (model_ == "bert") {
+        // (older conversions carry the classifier token as bos and the separator as eos; llama.cpp's defaults are BERT's 101 / 102 / 100)
+        cls_ = (int)(int64_t)f.get_u("tokenizer.ggml.cls_token_id", f.get_u("tokenizer.ggml.bos_token_id", 101));
+        sep_ = (int)(int64_t)f.get_u("tokenizer.ggml.seperator_token_id", f.get_u("tokenizer.ggml.eos_token_id", 102));
+        unk_ = (int)(int64_t)f.get_u("tokenizer.ggml.unknown_token_id", 100);
+        bos_ = cls_; eos_ = sep_;
+        if (cls_ < 0 || cls_ >= (int)n || sep_ < 0 || sep_ >= (int)n || unk_ < 0 || unk_ >= (int)n) { err = "bert vocabulary: cls / sep / unk token ids out of range"; return false; }
+    }
     build_index();
     return true;
 }
@@ -87,8 +95,10 @@ void Vocab::init_spm(const std::vector<std::string> &tokens, const std::vector<f
 void Vocab::build_index() {
     index_.clear();
     special_ids_.clear();
+    max_token_len_ = 0;
     for (int i = 0; i < (int)tokens_.size(); i++) {
         index_.emplace(tokens_[(size_t)i], i);
+        max_token_len_ = std::max(max_token_len_, tokens_[(size_t)i].size());
         if (types_[(size_t)i] == TT_CONTROL || types_[(size_t)i] == TT_USER_DEFINED) special_ids_.push_back(i);
         // well-known end-of-generation markers (llama-3 <|eot_id|>, chatml <|im_end|>, ...)
         const std::string &t = tokens_[(size_t)i];
@@ -267,8 +277,96 @@ void Vocab::tokenize_bpe(const std::string &text, std::vector<int32_t> &out) con
     }
 }
 
+// WordPiece (llama.cpp's llm_tokenizer_wpm): see vocab.h
+namespace {
+bool wpm_is_cjk(unsigned cp) {
+    return (cp >= 0x4E00 && cp <= 0x9FFF) || (cp >= 0x3400 && cp <= 0x4DBF) || (cp >= 0x20000 && cp <= 0x2A6DF) || (cp >= 0x2A700 && cp <= 0x2B73F) ||
+           (cp >= 0x2B740 && cp <= 0x2B81F) || (cp >= 0x2B920 && cp <= 0x2CEAF) || (cp >= 0xF900 && cp <= 0xFAFF) || (cp >= 0x2F800 && cp <= 0x2FA1F);
+}
+bool wpm_is_punct(unsigned cp) {
+    if (cp < 0x80) return (cp >= 33 && cp <= 47) || (cp >= 58 && cp <= 64) || (cp >= 91 && cp <= 96) || (cp >= 123 && cp <= 126);   // ASCII punctuation and symbols
+    return (cp >= 0x2010 && cp <= 0x2027) || (cp >= 0x2030 && cp <= 0x205E) || (cp >= 0x3001 && cp <= 0x3003) || (cp >= 0x3008 && cp <= 0x3011) ||
+           cp == 0xA1 || cp == 0xA7 || cp == 0xAB || cp == 0xB6 || cp == 0xB7 || cp == 0xBB || cp == 0xBF || (cp >= 0xFF01 && cp <= 0xFF0F);
+}
+// lower-case + base letter of the Latin-1 / Latin Extended-A range (what NFD followed by dropping the combining marks leaves)
+unsigned wpm_fold(unsigned cp) {
+    if (cp >= 'A' && cp <= 'Z') return cp + 32;
+    if (cp < 0xC0) return cp;
+    if (cp <= 0xFF) {
+        // base letter of 0xC0 .. 0xFF after canonical decomposition, lower-cased; 0 = no ASCII base (the letter keeps itself, lower-cased)
+        static const unsigned char base[64] = {97, 97, 97, 97, 97, 97, 0, 99, 101, 101, 101, 101, 105, 105, 105, 105, 0, 110, 111, 111, 111, 111, 111, 0, 0, 117, 117, 117, 117, 121, 0, 0, 97, 97, 97, 97, 97, 97, 0, 99, 101, 101, 101, 101, 105, 105, 105, 105, 0, 110, 111, 111, 111, 111, 111, 0, 0, 117, 117, 117, 117, 121, 0, 121};
+        if (base[cp - 0xC0]) return base[cp - 0xC0];
+        return (cp <= 0xDE && cp != 0xD7) ? cp + 32 : cp;
+    }
+    if (cp <= 0x17F) {
+        static const unsigned char ext[128] = {97, 97, 97, 97, 97, 97, 99, 99, 99, 99, 99, 99, 99, 99, 100, 100, 0, 0, 101, 101, 101, 101, 101, 101, 101, 101, 101, 101, 103, 103, 103, 103, 103, 103, 103, 103, 104, 104, 0, 0, 105, 105, 105, 105, 105, 105, 105, 105, 105, 0, 0, 0, 106, 106, 107, 107, 0, 108, 108, 108, 108, 108, 108, 0, 0, 0, 0, 110, 110, 110, 110, 110, 110, 0, 0, 0, 111, 111, 111, 111, 111, 111, 0, 0, 114, 114, 114, 114, 114, 114, 115, 115, 115, 115, 115, 115, 115, 115, 116, 116, 116, 116, 0, 0, 117, 117, 117, 117, 117, 117, 117, 117, 117, 117, 117, 117, 119, 119, 121, 121, 121, 122, 122, 122, 122, 122, 122, 0};         // 0x100 .. 0x17F likewise
+        if (ext[cp - 0x100]) return ext[cp - 0x100];
+        // letters without a decomposition (d / h / l / o / t with stroke, eng, ligatures): Python's str.lower() pairs, which are not all even / odd
+        switch (cp) {
+            case 0x110: return 0x111; case 0x126: return 0x127; case 0x132: return 0x133; case 0x13F: return 0x140; case 0x141: return 0x142;
+            case 0x14A: return 0x14B; case 0x152: return 0x153; case 0x166: return 0x167; default: return cp;
+        }
+    }
+    if (cp >= 0x391 && cp <= 0x3A9 && cp != 0x3A2) return cp + 32;      // Greek capitals
+    if (cp >= 0x410 && cp <= 0x42F) return cp + 32;                      // Cyrillic capitals
+    if (cp >= 0x400 && cp <= 0x40F) return cp + 80;
+    return cp;
+}
+void utf8_append(std::string &s, unsigned cp) {
+    if (cp < 0x80) s += (char)cp;
+    else if (cp < 0x800) { s += (char)(0xC0 | (cp >> 6)); s += (char)(0x80 | (cp & 0x3F)); }
+    else if (cp < 0x10000) { s += (char)(0xE0 | (cp >> 12)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+    else { s += (char)(0xF0 | (cp >> 18)); s += (char)(0x80 | ((cp >> 12) & 0x3F)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+}
+}  // namespace
+
+void Vocab::tokenize_wpm(const std::string &text, std::vector<int32_t> &out) const {
+    std::vector<std::string> words(1);
+    for (size_t off = 0; off < text.size();) {
+        const unsigned char c0 = (unsigned char)text[off];
+        size_t l = std::min(utf8_len(c0), text.size() - off);
+        unsigned cp = c0;
+        if (l == 2) cp = ((c0 & 0x1F) << 6) | ((unsigned char)text[off + 1] & 0x3F);
+        else if (l == 3) cp = ((c0 & 0x0F) << 12) | (((unsigned char)text[off + 1] & 0x3F) << 6) | ((unsigned char)text[off + 2] & 0x3F);
+        else if (l == 4) cp = ((c0 & 0x07) << 18) | (((unsigned char)text[off + 1] & 0x3F) << 12) | (((unsigned char)text[off + 2] & 0x3F) << 6) | ((unsigned char)text[off + 3] & 0x3F);
+        off += l;
+        const bool space = is_space(cp) || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) || cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+        if (space) { if (!words.back().empty()) words.emplace_back(); continue; }
+        if (cp == 0 || cp == 0xFFFD || cp < 0x20 || (cp >= 0x7F && cp < 0xA0)) continue;                 // control characters
+        if (cp >= 0x300 && cp <= 0x36F) continue;                                                          // combining marks
+        if (wpm_is_punct(cp) || wpm_is_cjk(cp)) {
+            if (!words.back().empty()) words.emplace_back();
+            utf8_append(words.back(), wpm_fold(cp));
+            words.emplace_back();
+        } else {
+            utf8_append(words.back(), wpm_fold(cp));
+        }
+    }
+    if (words.back().empty()) words.pop_back();
+    for (const std::string &word : words) {
+        if (word.empty()) continue;
+        const std::string w1 = "\xE2\x96\x81" + word;
+        const size_t n = w1.size(), mark = out.size();
+        for (size_t i = 0; i < n;) {
+            bool match = false;
+            for (size_t j = std::min(n, i + max_token_len_ + 1); j > i; j--) {
+                auto it = index_.find(w1.substr(i, j - i));
+                if (it != index_.end()) { out.push_back(it->second); match = true; i = j; break; }
+            }
+            if (!match) { out.resize(mark); break; }
+        }
+        if (out.size() == mark) out.push_back(unk_);
+    }
+}
+
 std::vector<int32_t> Vocab::tokenize(const std::string &text, bool add_special, bool parse_special) const {
     std::vector<int32_t> out;
+    if (model_ == "bert") {
+        if (add_special) out.push_back(cls_);
+        tokenize_wpm(text, out);
+        if (add_special) out.push_back(sep_);
+        return out;
+    }
     if (add_special && add_bos_ && bos_ >= 0) out.push_back(bos_);
     // split on special tokens first when asked to
     std::vector<std::pair<bool, std::string>> frags;   // (is_special_id, text) ; special carries the id as decimal string

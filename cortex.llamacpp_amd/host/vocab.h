@@ -4,6 +4,10 @@
 //   "llama" model : SentencePiece-style BPE with scores, space prefix U+2581, byte fallback <0xXX>   (Llama-2, TinyLlama, Mixtral)
 //   "gpt2"  model : byte-level BPE with merge ranks (Llama-3); the pre-tokenizer is a hand-written splitter for the
 //                   llama-bpe pattern (ASCII letter/digit classes, non-ASCII code points treated as letters).
+//   "bert"  model : WordPiece as llama.cpp's WPM tokenizer runs it (encoder / embedding models: the reference's embedding smoke model is one, Makefile:6):
+//                   lower-case, accents of Latin-1 / Latin Extended-A letters stripped, split on whitespace with every punctuation mark, ASCII symbol and CJK
+//                   ideograph a word of its own; each word gets the U+2581 prefix and is cut greedily into the longest vocabulary entries from the left, a word
+//                   with an uncovered rest becomes the unknown token; [CLS] ... [SEP] around the text when specials are asked for.
 #pragma once
 
 #include <cstdint>
@@ -46,6 +50,7 @@ class Vocab {
     void build_index();
     void tokenize_spm(const std::string &text, std::vector<int32_t> &out) const;
     void tokenize_bpe(const std::string &text, std::vector<int32_t> &out) const;
+    void tokenize_wpm(const std::string &text, std::vector<int32_t> &out) const;
     void bpe_word(const std::string &word, std::vector<int32_t> &out) const;
     int byte_token(uint8_t b) const;
 
@@ -58,6 +63,8 @@ class Vocab {
     std::vector<int> special_ids_;             // control / user-defined tokens, longest text first
     std::map<int, int> eog_extra_;
     int bos_ = -1, eos_ = -1, eot_ = -1, unk_ = 0;
+    int cls_ = -1, sep_ = -1;                  // "bert" vocabularies: the tokens put around a text
+    size_t max_token_len_ = 0;
     bool add_bos_ = true, add_eos_ = false, add_space_prefix_ = true;
 };
 

@@ -35,6 +35,8 @@ typedef struct {
     const oq_tensor *attn_norm, *wq, *wk, *wv, *wo, *bq, *bk, *bv;
     const oq_tensor *ffn_norm, *gate, *up, *down;
     const oq_tensor *gate_inp, *gate_exps, *up_exps, *down_exps;
+    /* nomic-bert (encoder): fused Q | K | V projection, LayerNorm (weight + bias) AFTER the attention and after the feed-forward block */
+    const oq_tensor *wqkv, *bo, *attn_out_norm, *attn_out_norm_b, *layer_out_norm, *layer_out_norm_b;
 } oq_layer;
 
 struct oq_model {
@@ -54,6 +56,8 @@ struct oq_model {
     int n_ctx_train, n_ctx_orig;
     oq_yarn yarn;
     const oq_tensor *tok_embd, *out_norm, *output, *rope_freqs;
+    int is_bert;                  /* general.architecture nomic-bert: bidirectional encoder, embeddings only */
+    const oq_tensor *tok_types, *tok_norm, *tok_norm_b;
     oq_layer layers[MAX_LAYERS];
 };
 
@@ -150,6 +154,7 @@ oq_model *oq_model_load(const char *path) {
         else if (!strcmp(suf, "attention.head_count")) m->n_head = (int)v.u;
         else if (!strcmp(suf, "attention.head_count_kv")) m->n_head_kv = (int)v.u;
         else if (!strcmp(suf, "attention.layer_norm_rms_epsilon")) m->eps = (float)v.f;
+        else if (!strcmp(suf, "attention.layer_norm_epsilon")) m->eps = (float)v.f;
         else if (!strcmp(suf, "rope.dimension_count")) m->n_rot = (int)v.u;
         else if (!strcmp(suf, "rope.freq_base")) m->rope_base = (float)v.f;
         else if (!strcmp(suf, "rope.scaling.type")) snprintf(m->rope_scaling, sizeof m->rope_scaling, "%s", v.s);
@@ -183,7 +188,12 @@ oq_model *oq_model_load(const char *path) {
     m->output = find_tensor(m, "output.weight");
     if (!m->output) m->output = m->tok_embd; /* tied embeddings */
     m->rope_freqs = find_tensor(m, "rope_freqs.weight");
-    if (!m->tok_embd || !m->out_norm || !m->n_head || !m->n_embd) { oq_model_free(m); return NULL; }
+    m->is_bert = !strcmp(m->arch, "nomic-bert");
+    m->tok_types = find_tensor(m, "token_types.weight");
+    m->tok_norm = find_tensor(m, "token_embd_norm.weight");
+    m->tok_norm_b = find_tensor(m, "token_embd_norm.bias");
+    if (!m->tok_embd || (!m->out_norm && !m->is_bert) || !m->n_head || !m->n_embd) { oq_model_free(m); return NULL; }
+    if (m->is_bert && (!m->tok_norm || !m->tok_norm_b)) { oq_model_free(m); return NULL; }
     m->n_vocab = (int)m->tok_embd->ne[1];
     if (!m->n_head_kv) m->n_head_kv = m->n_head;
     m->head_dim = m->n_embd / m->n_head;
@@ -211,10 +221,20 @@ oq_model *oq_model_load(const char *path) {
         L->gate = layer_tensor(m, il, "ffn_gate.weight");
         L->up = layer_tensor(m, il, "ffn_up.weight");
         L->down = layer_tensor(m, il, "ffn_down.weight");
+        L->wqkv = layer_tensor(m, il, "attn_qkv.weight");
+        L->bo = layer_tensor(m, il, "attn_output.bias");
+        L->attn_out_norm = layer_tensor(m, il, "attn_output_norm.weight");
+        L->attn_out_norm_b = layer_tensor(m, il, "attn_output_norm.bias");
+        L->layer_out_norm = layer_tensor(m, il, "layer_output_norm.weight");
+        L->layer_out_norm_b = layer_tensor(m, il, "layer_output_norm.bias");
         L->gate_inp = layer_tensor(m, il, "ffn_gate_inp.weight");
         L->gate_exps = layer_tensor(m, il, "ffn_gate_exps.weight");
         L->up_exps = layer_tensor(m, il, "ffn_up_exps.weight");
         L->down_exps = layer_tensor(m, il, "ffn_down_exps.weight");
+        if (m->is_bert) {
+            if (!L->wqkv || !L->wo || !L->attn_out_norm || !L->attn_out_norm_b || !L->layer_out_norm || !L->layer_out_norm_b || !L->gate || !L->up || !L->down) { oq_model_free(m); return NULL; }
+            continue;
+        }
         if (!L->attn_norm || !L->wq || !L->wk || !L->wv || !L->wo || !L->ffn_norm) { oq_model_free(m); return NULL; }
         if (!L->gate_inp && (!L->gate || !L->up || !L->down)) { oq_model_free(m); return NULL; }
     }
@@ -408,9 +428,96 @@ static void ffn_moe(const oq_ctx *c, const oq_layer *L, const float *h, int64_t 
     free(logits); free(probs); free(g); free(u); free(e_out);
 }
 
+/* LayerNorm with weight and bias (upstream: ggml_compute_forward_norm_f32 then ggml_mul, ggml_add in build_norm(LLM_NORM)): mean and variance summed in double */
+static void layer_norm_rows(const float *x, float *y, int64_t n, int64_t T, float eps, const oq_tensor *w, const oq_tensor *b) {
+    for (int64_t t = 0; t < T; t++) {
+        const float *xr = x + t * n;
+        float *yr = y + t * n;
+        double sum = 0.0;
+        for (int64_t i = 0; i < n; i++) sum += (double)xr[i];
+        const float mean = (float)(sum / (double)n);
+        double sum2 = 0.0;
+        for (int64_t i = 0; i < n; i++) { const float v = xr[i] - mean; yr[i] = v; sum2 += (double)(v * v); }
+        const float variance = (float)(sum2 / (double)n);
+        const float scale = 1.0f / sqrtf(variance + eps);
+        for (int64_t i = 0; i < n; i++) yr[i] *= scale;
+        oq_mul_f32(yr, (const float *)w->data, yr, n);
+        oq_add_f32(yr, (const float *)b->data, yr, n);
+    }
+}
+
+/* nomic-bert (upstream: src/llama-model.cpp llm_build_bert, the NOMIC_BERT branches): token + type-0 embeddings -> LayerNorm; per layer fused Q | K | V, NEOX
+ * rope on Q and K, BIDIRECTIONAL attention over the sequence's tokens (build_attn_inp_no_cache: every token sees every token of its sequence), attn_output,
+ * residual, LayerNorm, SwiGLU feed-forward (LLM_FFN_SILU, LLM_FFN_PAR: down(silu(gate x) * up x)), residual, LayerNorm.  The result is the hidden state of
+ * the last layer (t_embd): no output projection.  K / V rows pass through the context's cache rows (f16: what the flash path casts them to anyway). */
+static int bert_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_t *seq, int n) {
+    const oq_model *m = c->m;
+    const int D = m->n_embd, H = m->n_head, G = m->n_head_kv, hd = m->head_dim;
+    const int64_t kv_dim = (int64_t)G * hd, qkv_dim = D + 2 * kv_dim;
+    const int slot = find_slot(c, n);
+    if (slot < 0) return 1;
+    for (int i = 0; i < n; i++) {
+        c->cells[slot + i].pos = pos[i];
+        c->cells[slot + i].seqs = 1ull << (seq ? seq[i] : 0);
+        c->cells[slot + i].delta = 0;
+    }
+    c->head = slot + n;
+    if (c->head >= c->n_ctx) c->head = 0;
+    float *x = (float *)malloc(sizeof(float) * (size_t)D * n), *cur = (float *)malloc(sizeof(float) * (size_t)D * n);
+    float *qkv = (float *)malloc(sizeof(float) * (size_t)qkv_dim * n);
+    float *q = (float *)malloc(sizeof(float) * (size_t)D * n), *kk = (float *)malloc(sizeof(float) * (size_t)kv_dim * n), *vv = (float *)malloc(sizeof(float) * (size_t)kv_dim * n);
+    float *att = (float *)malloc(sizeof(float) * (size_t)D * n), *tmp = (float *)malloc(sizeof(float) * (size_t)D * n);
+    int32_t *vis = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->n_ctx);
+    oq_get_rows(m->tok_embd->type, m->tok_embd->data, D, tokens, n, x);
+    if (m->tok_types)                                      /* token types are all zero: row 0 of the type table */
+        for (int t = 0; t < n; t++) oq_add_f32(x + (size_t)t * D, (const float *)m->tok_types->data, x + (size_t)t * D, D);
+    layer_norm_rows(x, x, D, n, m->eps, m->tok_norm, m->tok_norm_b);
+    const float kq_scale = 1.0f / sqrtf((float)hd);
+    for (int il = 0; il < m->n_layer; il++) {
+        const oq_layer *L = &m->layers[il];
+        linear(c, L->wqkv, x, n, qkv);
+        for (int t = 0; t < n; t++) {
+            memcpy(q + (size_t)t * D, qkv + (size_t)t * qkv_dim, sizeof(float) * (size_t)D);
+            memcpy(kk + (size_t)t * kv_dim, qkv + (size_t)t * qkv_dim + D, sizeof(float) * (size_t)kv_dim);
+            memcpy(vv + (size_t)t * kv_dim, qkv + (size_t)t * qkv_dim + D + kv_dim, sizeof(float) * (size_t)kv_dim);
+            rope_heads(m, q + (size_t)t * D, H, pos[t]);
+            rope_heads(m, kk + (size_t)t * kv_dim, G, pos[t]);
+            oq_quantize_row(c->type_k, kk + (size_t)t * kv_dim, c->k[il] + (size_t)(slot + t) * c->k_row, kv_dim);
+            oq_quantize_row(c->type_v, vv + (size_t)t * kv_dim, c->v[il] + (size_t)(slot + t) * c->v_row, kv_dim);
+        }
+        const size_t k_head = oq_row_bytes(c->type_k, hd), v_head = oq_row_bytes(c->type_v, hd);
+        for (int t = 0; t < n; t++) {
+            const int s = seq ? seq[t] : 0;
+            int nv = 0;
+            for (int i = 0; i < c->n_ctx; i++)
+                if (c->cells[i].pos >= 0 && (c->cells[i].seqs & (1ull << s))) vis[nv++] = i;       /* no causal test */
+            oq_flash_attn_ext(q + (size_t)t * D, H, G, hd, hd, c->type_k, c->k[il], c->k_row, k_head,
+                              c->type_v, c->v[il], c->v_row, v_head, vis, nv, kq_scale, att + (size_t)t * D);
+        }
+        linear(c, L->wo, att, n, tmp);
+        add_bias(L->bo, tmp, n);
+        oq_add_f32(tmp, x, cur, (int64_t)D * n);                                    /* re-add the layer input */
+        layer_norm_rows(cur, cur, D, n, m->eps, L->attn_out_norm, L->attn_out_norm_b);
+        ffn_dense(c, L, cur, n, tmp);
+        oq_add_f32(tmp, cur, cur, (int64_t)D * n);                                  /* the attention output bypasses the feed-forward block */
+        layer_norm_rows(cur, x, D, n, m->eps, L->layer_out_norm, L->layer_out_norm_b);
+        c->dbg[il] = (float *)realloc(c->dbg[il], sizeof(float) * (size_t)D * n);
+        memcpy(c->dbg[il], x, sizeof(float) * (size_t)D * n);
+    }
+    c->dbg_tokens = n;
+    free(x); free(cur); free(qkv); free(q); free(kk); free(vv); free(att); free(tmp); free(vis);
+    return 0;
+}
+
 int oq_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_t *seq,
               const int8_t *want, int n, float *logits_out) {
     const oq_model *m = c->m;
+    if (m->is_bert) {                                          /* encoder: no logits (rows of zeros); the embeddings are the last layer's tap */
+        int rows = 0;
+        for (int t = 0; t < n; t++) rows += want ? (want[t] != 0) : (t == n - 1);
+        if (logits_out) memset(logits_out, 0, sizeof(float) * (size_t)rows * (size_t)m->n_vocab);
+        return bert_decode(c, tokens, pos, seq, n);
+    }
     const int D = m->n_embd, H = m->n_head, G = m->n_head_kv, hd = m->head_dim;
     const int64_t kv_dim = (int64_t)G * hd;
     if (c->has_shift) apply_k_shift(c);

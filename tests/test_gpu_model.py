@@ -639,15 +639,66 @@ def test_load_errors(be, pkg, tmp_path):
         pkg.Model(str(tmp_path / "missing.gguf"))
 
 
-@pytest.mark.parametrize("arch", ["gemma2", "phi3", "nomic-bert"])
+@pytest.mark.parametrize("arch", ["gemma2", "phi3", "bert"])
 def test_other_graphs_are_refused_by_name(be, pkg, tmp_path, arch):
-    """Only llama-graph files run (general.architecture llama / qwen2): a file of another architecture is refused when it loads, with its name in the
+    """Only llama-graph files and the nomic-bert encoder run (general.architecture llama / qwen2 / nomic-bert): a file of another architecture is refused when it loads, with its name in the
     message - never evaluated as if it were a llama graph (wrong logits with status 200 is the failure this guards against)."""
     import dataclasses
     path = str(tmp_path / "other.gguf")
     pkg.gguf_synth.write_synthetic_llama(path, dataclasses.replace(pkg.gguf_synth.CONFIGS["tiny"], arch=arch), "q8_0", seed=1)
     with pytest.raises(pkg.MI355Error, match=arch):
         pkg.Model(path)
+
+
+@pytest.mark.parametrize("cfg,ftype,n", [("tiny-nomic", "f16", 19), ("tiny-nomic", "q8_0", 40), ("tiny-nomic", "q4_k_m", 70), ("nomic-embed-2l", "f16", 33)])
+def test_encoder_hidden_states_match_oracle(be, pkg, tmp_models, cfg, ftype, n):
+    """general.architecture nomic-bert (the reference's embedding smoke model, Makefile:6): the bidirectional encoder graph (run_layers_encoder: LayerNorms, fused
+    Q | K | V, NEOX rope, attention over the whole sequence, SwiGLU) layer by layer against the CPU restatement, the embeddings rows (= the last layer's rows),
+    two sequences in one batch that must not see each other, and the dependence of the first token on the last (not causal)."""
+    path = make(pkg, tmp_models, cfg, ftype, seed=5)
+    oq.set_fa_v_acc_f32(1)            # f16 cache: compare with f32 accumulation of V (as for the llama graph's f16 cases)
+    try:
+        m = pkg.Model(path)
+        c = pkg.Context(m, n_ctx=256, n_seq_max=4, type_k=KV["f16"], type_v=KV["f16"])
+        om = oq.OracleModel(path); oc = oq.OracleContext(om, 256, KV["f16"], KV["f16"], True, 4)
+        rng = np.random.default_rng(6)
+        toks = rng.integers(5, m.n_vocab, n)
+        c.enable_taps(True)
+        flags = np.ones(n, np.int8)
+        assert c.decode(toks, np.arange(n), [0] * n, flags) == 0
+        oc.decode(toks, np.arange(n), [0] * n, flags)
+        for il in range(m.n_layer):
+            a, b = c.layer_out(il, n).reshape(n, -1), oc.layer_out(il, n).reshape(n, -1)
+            # LayerNorm'd rows of unit scale.  f16 files: f16 products re-associated; quantised files: a 1-ulp difference can flip one int8 rounding of an
+            # activation block (the llama graph's FLIP_TOL case) - everything else agrees to f32 round-off, which the median shows
+            assert rel_err(a, b) <= (1e-2 if ftype == "f16" else FLIP_TOL), (il, rel_err(a, b))
+            # (f16 files: the CPU rounds the activations to f16 for vec_dot_f16, the device contracts f32 activations with the f16 weights - the llama graph's f16 case)
+            # - in the FIRST layer: a flipped code there reaches every token of the next layer through the bidirectional attention
+            if il == 0:
+                assert float(np.median(np.abs(a - b))) <= (1e-3 if ftype == "f16" else 1e-4), float(np.median(np.abs(a - b)))
+        last = oc.layer_out(m.n_layer - 1, n).reshape(n, -1)
+        emb = np.stack([c.embeddings(i).copy() for i in range(n)])
+        assert rel_err(emb, last) <= (1e-2 if ftype == "f16" else FLIP_TOL)
+        assert float(np.median(np.abs(emb - last))) <= 1e-2
+        first = emb[0].copy()
+        c.enable_taps(False)
+        # a second sequence beside the first: same tokens but the last one -> its rows differ from sequence 0's, sequence 0's rows do not move
+        t2 = toks.copy(); t2[-1] = (t2[-1] + 9) % (m.n_vocab - 5) + 5
+        assert c.decode(t2, np.arange(n), [1] * n, flags) == 0
+        e2 = np.stack([c.embeddings(i).copy() for i in range(n)])
+        oc.decode(t2, np.arange(n), [1] * n, flags)
+        assert rel_err(e2, oc.layer_out(m.n_layer - 1, n).reshape(n, -1)) <= (1e-2 if ftype == "f16" else FLIP_TOL)
+        assert np.abs(e2[0] - first).max() > 1e-3            # bidirectional: token 0 saw the changed last token
+        c.kv_clear()
+        assert c.decode(toks, np.arange(n), [2] * n, flags) == 0
+        assert np.abs(c.embeddings(0) - first).max() <= 1e-5 # ... and only tokens of its own sequence
+        # a batch longer than the micro-batch cannot be cut (every token needs all the others): refused
+        c2 = pkg.Context(m, n_ctx=256, n_ubatch=16, type_k=KV["f16"], type_v=KV["f16"])
+        with pytest.raises(pkg.MI355Error, match="micro-batch"):
+            c2.decode(toks[:17], np.arange(17))
+        c2.close(); c.close(); m.close(); oc.close(); om.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
 
 
 def _patch_u32(path, key, value):
