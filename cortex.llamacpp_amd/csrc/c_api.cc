@@ -422,7 +422,11 @@ int mi355_op_mul_mat(int32_t type, const void *W, int64_t N, int64_t K, const fl
             }
         }
     } else {
-        e = launch_mmv_float(type, wdev.as<uint8_t>(), (int)N, (int)K, dx.as<float>(), (int)T, dy.as<float>(), (int)N, nullptr, nullptr);
+        // (the model path's choice: batches against f16 tensors on the matrix cores, everything else one wave per row and token)
+        if (mmf16_applicable(type, (int)N, (int)K, (int)T, wdev.p, dx.p, dy.p) && (N & 3) == 0)
+            e = launch_mmf16(wdev.as<uint8_t>(), (int)N, (int)K, dx.as<float>(), (int)T, dy.as<float>(), (int)N, nullptr, nullptr);
+        else
+            e = launch_mmv_float(type, wdev.as<uint8_t>(), (int)N, (int)K, dx.as<float>(), (int)T, dy.as<float>(), (int)N, nullptr, nullptr);
         if (e != hipSuccess) return hip_fail(e, "mmv_float");
     }
     e = hipDeviceSynchronize();

@@ -192,6 +192,9 @@ hipError_t launch_topk_rows(const float *base, int n, int n_rows, const int *row
                             hipStream_t st);
 
 // f32 / f16 weight mat-vec (router, unquantised models): y[t][r] = dot(W[r], x[t])
+// batches against F16 weights on the matrix cores (mmf.hip): y[t][n] (+ resid) = sum_k W[n][k] * f16(x[t][k]); the same products as launch_mmv_float, f32 accumulation
+bool mmf16_applicable(int type, int n_rows, int K, int T, const void *W, const void *x, const void *y);
+hipError_t launch_mmf16(const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out, const float *resid, hipStream_t st);
 hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,
                             const float *resid, hipStream_t st);
 

@@ -165,6 +165,8 @@ CONFIGS = {
                                big_model=True),
     # qwen2 architecture (NEOX rope, Q / K / V biases), 7 query heads per kv head, hidden size and feed-forward width that are no multiples of 1024
     "qwen2-7b": LlamaConfig("Qwen2-7B-Instruct", 3584, 28, 28, 4, 18944, 152064, 1e6, 1e-6, 32768, arch="qwen2", qkv_bias=True),
+    # the reference's embedding smoke model (Makefile:6): nomic-embed-text-v1.5's geometry, a bidirectional encoder (general.architecture nomic-bert)
+    "nomic-embed": LlamaConfig("nomic-embed-text-v1.5", 768, 12, 12, 12, 3072, 30522, 1000.0, 1e-12, 2048, arch="nomic-bert"),
     # test-sized
     "tiny": LlamaConfig("tiny-test", 256, 2, 4, 2, 512, 512, 10000.0, 1e-5, 512),
     "tiny-gqa4": LlamaConfig("tiny-gqa4", 512, 3, 8, 2, 1024, 768, 500000.0, 1e-5, 1024),

@@ -65,6 +65,8 @@ class IBackend {
     // {arch}.pooling_type of the model: 0 none (an embedding request answers with the hidden state of its last token, llama_get_embeddings_ith), 1 mean,
     // 2 cls, 3 last (llama_get_embeddings_seq: pooled over the sequence's tokens; src/llama_server_context.cc:1041-1044)
     virtual int pooling_type() const { return 0; }
+    // a bidirectional encoder (general.architecture nomic-bert): embeddings only, no next-token head - the engine treats it as model_type "embedding" whatever the load request said
+    virtual bool is_encoder() const { return false; }
     virtual void set_embeddings(bool on) = 0;
     virtual const float *embeddings_ith(int i) = 0;
     virtual void kv_clear() = 0;

@@ -204,6 +204,7 @@ bool LlamaEngine::LoadModelImpl(const Json &body, std::string &err) {   // :547-
     si->stop_words = body["stop"];                                            // :672
     si->model_type = body.value<std::string>("model_type", "llm");
     if (body.value<bool>("embedding", false)) si->model_type = "embedding";
+    if (si->backend->is_encoder()) si->model_type = "embedding";             // an encoder file cannot complete text: no warm-up completion, chat requests are refused
     si->ngl = body.value<int>("ngl", 300);
     si->start_time = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
     si->ctx.reset(new LlamaServerContext(si->backend.get(), sp));

@@ -72,6 +72,7 @@ class HipBackend : public IBackend {
     int topk_max_k() const override { return device_sampling_ ? TOPK_MAX_K : 0; }
     int topk_max_adj() const override { return TOPK_MAX_ADJ; }
     int pooling_type() const override { return model_->hp.pooling_type; }
+    bool is_encoder() const override { return model_->hp.encoder; }
     void set_embeddings(bool on) override { ctx_->embeddings_enabled = on || ctx_->model->hp.encoder; }
     const float *embeddings_ith(int i) override { return ctx_->embeddings_ith(i); }
     void kv_clear() override { ctx_->kv_clear(); }

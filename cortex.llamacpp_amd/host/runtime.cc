@@ -900,6 +900,8 @@ hipError_t Context::linear(const DevTensor &w, const ActQuant &aq, const float *
         MMVQSeg s = make_seg(w, out, ld_out, resid, nullptr);
         return mmvq_tokens(&s, 1, K, T, epi, aq, stream_, pending_fuse_);
     }
+    if (mmf16_applicable(w.type, (int)w.N, K, T, w.data, x_f32, out) && w.n_expert == 1 && (ld_out & 3) == 0)      // a batch against an f16 tensor: matrix cores
+        return launch_mmf16(w.data, (int)w.N, K, x_f32, T, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
     return launch_mmv_float(w.type, w.data, (int)w.N, K, x_f32, T, out, ld_out, epi == EPI_ADD ? resid : nullptr, stream_);
 }
 

@@ -69,7 +69,7 @@ bool Vocab::load(const GGUFFile &f, std::string &err) {
     eos_ = (int)(int64_t)f.get_u("tokenizer.ggml.eos_token_id", model_ == "llama" ? 2 : (uint64_t)-1);
     eot_ = (int)(int64_t)f.get_u("tokenizer.ggml.eot_token_id", (uint64_t)-1);
     unk_ = (int)(int64_t)f.get_u("tokenizer.ggml.unknown_token_id", 0);
-    add_bos_ = f.get_b("tokenizer.ggml.add_bos_token", model_ == "llama");
+    add_bos_ = f.get_b("tokenizer.ggml.add_bos_token", model_ == "llama" || model_ == "bert");   // (WordPiece vocabularies put [CLS] ... [SEP] around a text by default)
     add_eos_ = f.get_b("tokenizer.ggml.add_eos_token", false);
     add_space_prefix_ = f.get_b("tokenizer.ggml.add_space_prefix", true);
     if (model_ == "bert") {
@@ -89,6 +89,14 @@ void Vocab::init_spm(const std::vector<std::string> &tokens, const std::vector<f
     model_ = "llama";
     tokens_ = tokens; scores_ = scores; types_ = types;
     bos_ = bos; eos_ = eos; unk_ = unk; add_bos_ = add_bos; eot_ = -1;
+    build_index();
+}
+
+void Vocab::init_wpm(const std::vector<std::string> &tokens, int cls, int sep, int unk) {
+    model_ = "bert";
+    tokens_ = tokens; scores_.assign(tokens.size(), 0.0f); types_.assign(tokens.size(), TT_NORMAL);
+    for (int id : {cls, sep, unk}) if (id >= 0 && id < (int)tokens.size()) types_[(size_t)id] = TT_CONTROL;
+    cls_ = bos_ = cls; sep_ = eos_ = sep; unk_ = unk; add_bos_ = true; eot_ = -1;
     build_index();
 }
 

@@ -29,6 +29,8 @@ class Vocab {
     void init_spm(const std::vector<std::string> &tokens, const std::vector<float> &scores, const std::vector<int> &types,
                   int bos, int eos, int unk, bool add_bos);
 
+    void init_wpm(const std::vector<std::string> &tokens, int cls, int sep, int unk);      // a "bert" vocabulary (tests)
+
     int n_tokens() const { return (int)tokens_.size(); }
     int bos() const { return bos_; }
     int eos() const { return eos_; }

@@ -153,6 +153,30 @@ static void test_vocab() {
     CHECK(v.is_eog(v.eos()) && !v.is_eog(ids[1]));
 }
 
+// WordPiece as llama.cpp's WPM tokenizer runs it (vocab.h): the reference's embedding smoke model carries a "bert" vocabulary.  Known answers worked out by hand
+// from the algorithm: lower-casing, accent stripping, punctuation and CJK as words of their own, greedy longest match with the U+2581 word prefix, whole-word
+// fallback to [UNK], [CLS] ... [SEP] around the text.
+static void test_vocab_wordpiece() {
+#define W "\xE2\x96\x81"
+    const std::vector<std::string> toks = {"[PAD]", "[UNK]", "[CLS]", "[SEP]", W "hello", W "world", W "un", "aff", "able", W ",", W "!", W "cafe", W "a", "b", "##x",
+                                           W "\xE4\xB8\xAD", W "\xE6\x96\x87", W "h", "ello", W "wor", "ld", W "naive"};
+#undef W
+    Vocab v;
+    v.init_wpm(toks, 2, 3, 1);
+    typedef std::vector<int32_t> I;
+    CHECK((v.tokenize("Hello, WORLD!", true) == I{2, 4, 9, 5, 10, 3}));                 // lower-cased; the comma and the bang are words
+    CHECK((v.tokenize("hello", false) == I{4}));                                        // longest match first: not "h" + "ello"
+    CHECK((v.tokenize("unaffable", false) == I{6, 7, 8}));                              // word-initial piece, then bare continuations
+    CHECK((v.tokenize("unaffablex", false) == I{1}));                                   // an uncovered rest turns the WHOLE word into [UNK]
+    CHECK((v.tokenize("  hello\t\nworld  ", false) == I{4, 5}));                        // any whitespace separates, none survives
+    CHECK((v.tokenize("Caf\xC3\xA9 na\xC3\xAFve", false) == I{11, 21}));                 // accents stripped (e-acute, i-diaeresis), lower-cased
+    CHECK((v.tokenize("cafe\xCC\x81", false) == I{11}));                                 // a combining acute accent after the letter is dropped too
+    CHECK((v.tokenize("\xE4\xB8\xAD\xE6\x96\x87", false) == I{15, 16}));                 // CJK ideographs are words of their own
+    CHECK((v.tokenize("ab", false) == I{12, 13}) && (v.tokenize("ba", false) == I{1}));  // "b" exists only as a continuation
+    CHECK((v.tokenize("", true) == I{2, 3}));
+    CHECK(v.bos() == 2 && v.eos() == 3 && v.add_bos());
+}
+
 static void test_sampler() {
     std::vector<float> lg(100, 0.0f);
     lg[17] = 5.0f; lg[42] = 4.9f; lg[3] = 4.0f;
@@ -1110,6 +1134,7 @@ int main(int argc, char **argv) {
     if (argc == 2 && std::string(argv[1]) == "--api-shapes") return api_shapes_cli();
     test_json();
     test_vocab();
+    test_vocab_wordpiece();
     test_sampler();
     test_sampler_topk_matches_full_sort();
     test_sampler_mirostat_dynatemp();

@@ -304,3 +304,49 @@ def test_pooled_embeddings_follow_the_model_metadata(pkg, tmp_path):
     want = want.astype(np.float64) / np.linalg.norm(want.astype(np.float64))
     mean = embed(paths["mean"], [toks])[0]
     assert np.allclose(mean, want, atol=1e-6), float(np.abs(mean - want).max())
+
+
+def test_reference_smoke_flow_embedding_model_is_an_encoder(pkg, tmp_path):
+    """The second half of the reference's smoke script (.github/scripts/e2e-test-server-linux-and-mac.sh:93-120): load an embedding model - upstream a nomic-bert
+    file (Makefile:6) - with {"ctx_len": 50, "ngl": 32, "embedding": true, "model_type": "embedding"}, list the models, POST /v1/embeddings {"input": "Hello"}.
+    Here with the encoder's real layer geometry (768 wide, 12 heads of 64, 3072, 30522 WordPiece entries, two layers, f16): the reply must be the L2-normalised MEAN of
+    the hidden states of [CLS] hello [SEP] as the CPU restatement computes them, a chat completion on the encoder must be refused, and a batch of inputs works."""
+    import oracle_py as oq
+    path = str(tmp_path / "test-embedding.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, "nomic-embed-2l", "f16", seed=3, with_vocab=True)
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path=path, ctx_len=50, ngl=32, embedding=True, model_type="embedding", model="test-embedding")
+    assert st["status_code"] == 200, (st, body)
+    st, body = e.get_models()
+    assert st["status_code"] == 200 and any(m["id"] == "test-embedding" for m in body["data"]), body
+    st, b = e.embedding(model="test-embedding", input="Hello", encoding_format="float")
+    assert st["status_code"] == 200, (st, b)
+    got = np.asarray(b["data"][0]["embedding"], np.float64)
+    assert got.shape == (768,) and abs(np.linalg.norm(got) - 1.0) < 1e-5
+    # the tokens the request must have produced: [CLS] + greedy longest-match WordPiece of "hello" + [SEP]
+    be = pkg.Backend()
+    m = pkg.Model(path)
+    toks = m.tokenize("Hello", add_special=True)
+    assert toks[0] == 2 and toks[-1] == 3 and len(toks) >= 3, toks
+    assert m.tokenize("HELLO", add_special=True) == toks                     # lower-cased
+    m.close()
+    om = oq.OracleModel(path); oc = oq.OracleContext(om, 64, oq.F16, oq.F16, True, 4)
+    oq.set_fa_v_acc_f32(1)
+    try:
+        oc.decode(toks, np.arange(len(toks)), [0] * len(toks), np.ones(len(toks), np.int8))
+    finally:
+        oq.set_fa_v_acc_f32(0)
+    rows = oc.layer_out(1, len(toks)).reshape(len(toks), -1).astype(np.float64)
+    want = rows.mean(axis=0); want /= np.linalg.norm(want)
+    oc.close(); om.close()
+    assert np.abs(got - want).max() <= 2e-3, float(np.abs(got - want).max())
+    assert float(got @ want) >= 0.9999
+    # several inputs in one request; a different text gives a different vector
+    st, b = e.embedding(model="test-embedding", input=["Hello", "hello, world!", "Hello"])
+    assert st["status_code"] == 200 and len(b["data"]) == 3, (st, b)
+    v = [np.asarray(d["embedding"]) for d in b["data"]]
+    assert np.allclose(v[0], got, atol=1e-6) and np.allclose(v[2], got, atol=1e-6) and np.abs(v[1] - got).max() > 1e-3
+    # an encoder has no next-token head
+    out = e.chat_completion(model="test-embedding", messages=[{"role": "user", "content": "hi"}], max_tokens=4)
+    assert out[-1][0]["has_error"] or out[-1][0]["status_code"] != 200, out
+    e.close()

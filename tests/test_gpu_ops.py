@@ -246,6 +246,22 @@ def test_mul_mat_f32_f16_weights(be):
     assert np.abs(y - oq.mul_mat(F16, Wh.view(np.uint8), N, K, x)).max() <= 1e-5
 
 
+@pytest.mark.parametrize("N,K,T", [(768, 768, 128), (2304, 768, 70), (3072, 768, 33), (768, 3072, 200), (100, 512, 9), (36, 256, 8), (4096, 4096, 129)])
+def test_mul_mat_f16_weights_batched_on_the_matrix_cores(be, N, K, T):
+    """ggml_mul_mat with f16 weights for a batch (mmf.hip): f16-rounded activations, exact products, f32 accumulation - against the CPU restatement's vec_dot_f16
+    path; ragged sizes exercise the partial tiles.  Sums of K products of magnitude ~0.05 x 1: agreement to f32 re-association."""
+    rng = np.random.default_rng(N + K + T)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    Wh = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
+    y = be.mul_mat(F16, Wh.view(np.uint8), N, K, x)
+    ref = oq.mul_mat(F16, Wh.view(np.uint8), N, K, x)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), float(np.abs(y - ref).max())
+    # and against float64 on the same rounded operands
+    want = x.astype(np.float16).astype(np.float64) @ Wh.astype(np.float64).T
+    assert np.abs(y - want).max() <= 2e-5 * max(1.0, float(np.abs(want).max()))
+
+
 def test_rms_norm_mul(be):
     rng = np.random.default_rng(2)
     x = (rng.standard_normal((3, 4096)) * 4).astype(np.float32)
