@@ -206,3 +206,40 @@ def test_e2e_flow_over_http(pkg, tmp_path):
         assert json.loads(raw)["data"] == []
     finally:
         assert h.close() == 0
+
+
+@pytest.mark.gpu
+def test_reference_smoke_script_over_http(pkg, tmp_path):
+    """.github/scripts/e2e-test-server-linux-and-mac.sh request by request against this host: load the LLM (upstream a TinyLlama Q2_K file, Makefile:5 - here its two-layer
+    geometry in the same type mix) with ctx_len 50 / ngl 32, a streamed chat completion (max_tokens 50, temperature 0.1), unload, load the embedding model (upstream
+    nomic-embed f16, an encoder - here two layers of its geometry) with "embedding": true / "model_type": "embedding", GET /models, POST /v1/embeddings.  The
+    script's pass criterion is HTTP 200 on every step; the replies' shapes are checked too."""
+    llm = str(tmp_path / "testllm.gguf"); emb = str(tmp_path / "test-embedding.gguf")
+    pkg.gguf_synth.write_synthetic_llama(llm, "tiny-tl-2l", "q2_k", with_vocab=True)
+    pkg.gguf_synth.write_synthetic_llama(emb, "nomic-embed-2l", "f16", with_vocab=True)
+    h = Host()
+    try:
+        r, raw = h.request("POST", "/loadmodel", {"llama_model_path": llm, "model_alias": "testllm", "ctx_len": 50, "ngl": 32, "embedding": False})          # :50-58
+        assert r.status == 200, raw
+        c = h.conn()                                                                                                                                        # :66-84
+        body = {"messages": [{"content": "Hello there", "role": "assistant"}, {"content": "Write a long and sad story for me", "role": "user"}],
+                "stream": True, "model": "testllm", "max_tokens": 50, "stop": ["hello"], "frequency_penalty": 0, "presence_penalty": 0, "temperature": 0.1}
+        c.request("POST", "/v1/chat/completions", body=json.dumps(body), headers={"Content-Type": "application/json", "Accept": "text/event-stream"})
+        r = c.getresponse()
+        assert r.status == 200
+        events = [e for e in r.read().decode("utf-8", "replace").split("\n\n") if e.strip()]
+        c.close()
+        assert events[-1].strip() == "data: [DONE]" and len(events) >= 2
+        r, raw = h.request("POST", "/unloadmodel", {"llama_model_path": llm, "model": "testllm"})                                                             # :87-91
+        assert r.status == 200, raw
+        r, raw = h.request("POST", "/loadmodel", {"llama_model_path": emb, "ctx_len": 50, "ngl": 32, "embedding": True, "model_type": "embedding"})            # :94-102
+        assert r.status == 200, raw
+        r, raw = h.request("GET", "/models")                                                                                                                 # :105-107
+        assert r.status == 200 and [m["id"] for m in json.loads(raw)["data"]] == ["test-embedding"], raw
+        r, raw = h.request("POST", "/v1/embeddings", {"input": "Hello", "model": "test-embedding", "encoding_format": "float"})                              # :110-120
+        assert r.status == 200, raw
+        d = json.loads(raw)
+        v = np.asarray(d["data"][0]["embedding"], np.float64)
+        assert d["object"] == "list" and v.shape == (768,) and abs(np.linalg.norm(v) - 1.0) < 1e-5
+    finally:
+        assert h.close() == 0
