@@ -81,16 +81,18 @@ __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 
 // the iterations, and with the long tiles dispatched first the short ones fill the slots they leave: no records, no second launch.
 // QS = query sub-tiles of 32 per workgroup (R = 1: four, R = 2: two, else one - four waves per half in every case): the sub-tiles share
 // every staged chunk, which a single-head workgroup of multi-head attention otherwise stages for one wave's use.
-template <int R, bool F16, int KH, int QS>
+template <int R, bool F16, int KH, int QS, int DH = 128>
 __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel(const AttnArgs a) {
+    // head width: 128 or 64 (TinyLlama, Llama-3.2-1B, nomic-embed): everything below is written in 32-dim blocks (NB of them) and 16-dim matrix-core steps
+    constexpr int D = DH, NB = DH / 32, K_STRIDE = DH + 16, KF_STRIDE = 2 * DH + 16, NKS = DH / 16, VPL = NB * 2 * 2 * 32 * 8, NVU = 2 * DH;
 #ifdef MI355_FA_PROBE
     unsigned long long fa_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fa_t = __builtin_readcyclecounter();
     int fa_chunks = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KS = F16 ? KF_STRIDE : K_STRIDE;    // bytes per staged K row
-    constexpr int PPK = F16 ? 16 : 8;                 // 16-byte pieces per K / V row
-    constexpr int CHUNK_LDS = CK * KS + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;   // one staged chunk (launcher: one per half)
+    constexpr int PPK = F16 ? D / 8 : D / 16;         // 16-byte pieces per K / V row
+    constexpr int CHUNK_LDS = CK * KS + NB * CK * 4 + 2 * VPL * 2 + CK * 4 + CK * 8;   // one staged chunk (launcher: one per half)
     static_assert(CHUNK_LDS % 16 == 0, "chunk buffers stay 16-byte aligned");
     constexpr int NT = 64 * R * QS;                   // threads of one half: the staging roles below are per half
     const int tid_all = threadIdx.x, lane = tid_all & 63;
@@ -104,8 +106,8 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
         S.k = reinterpret_cast<int8_t *>(base);
         S.dk = reinterpret_cast<float *>(base + CK * KS);
         S.vh = reinterpret_cast<_Float16 *>(base + CK * KS + NB * CK * 4);
-        S.vl = S.vh + 4 * 2 * 2 * 32 * 8;
-        S.cpos = reinterpret_cast<int *>(S.vl + 4 * 2 * 2 * 32 * 8);
+        S.vl = S.vh + VPL;
+        S.cpos = reinterpret_cast<int *>(S.vl + VPL);
         S.cseq = reinterpret_cast<unsigned long long *>(S.cpos + CK);
         return S;
     };
@@ -149,11 +151,11 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
     //      f16 cache: round to f16, lane holds dims 16 j + 8 kg .. + 7 of K-step j
     i32x4 qc[NB];
     float dq[NB];
-    f16x8 qh[F16 ? 8 : 1];
+    f16x8 qh[F16 ? NKS : 1];
     if constexpr (F16) {
         const float *qrow = a.q + ((size_t)qt * H + h) * D;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < NKS; j++) {
             const f32x4 x0 = *reinterpret_cast<const f32x4 *>(qrow + 16 * j + 8 * kg), x1 = *reinterpret_cast<const f32x4 *>(qrow + 16 * j + 8 * kg + 4);
             qh[j][0] = (_Float16)x0.x; qh[j][1] = (_Float16)x0.y; qh[j][2] = (_Float16)x0.z; qh[j][3] = (_Float16)x0.w;
             qh[j][4] = (_Float16)x1.x; qh[j][5] = (_Float16)x1.y; qh[j][6] = (_Float16)x1.z; qh[j][7] = (_Float16)x1.w;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
     // q8_0 V: unit u = tid (+ NT) -> four consecutive keys 4 (u >> 5) .. + 3 x four dims 4 (u & 31) .. + 3: the four keys are four adjacent
     // K-slots of the transposed planes, so a dim's hi (lo) halves of the unit go out as ONE 8-byte LDS store (the key-per-thread
     // mapping wrote 32 two-byte stores per thread: the staging was 3.0 of a chunk's 8.3 kilocycles)
-    constexpr int NV = F16 ? 1 : (256 + NT - 1) / NT;
+    constexpr int NV = F16 ? 1 : (NVU + NT - 1) / NT;
     uint32_t v4[NV][4];
     float vd4[NV][4];
     int cpn = -1;
@@ -210,15 +212,15 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
                 kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D * 2 + (p % PPK) * 16);
                 vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D * 2 + (p % PPK) * 16);
             } else {
-                kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p & 7) * 16);
+                kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p % PPK) * 16);
             }
         }
         if constexpr (!F16) {
 #pragma unroll
             for (int i = 0; i < NV; i++) {
                 int u = tid + NT * i;
-                if (u >= 256) u = 255;
-                const int kgp = u >> 5, dg = u & 31;
+                if (u >= NVU) u = NVU - 1;
+                const int kgp = u / (D / 4), dg = u % (D / 4);
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     int cell = c * CK + 4 * kgp + kk;
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
 #pragma unroll
             for (int i = 0; i < NV; i++) {
                 const int u = tid + NT * i;
-                if (u >= 256) continue;
-                const int kgp = u >> 5, dg = u & 31;
+                if (u >= NVU) continue;
+                const int kgp = u / (D / 4), dg = u % (D / 4);
                 const int j = kgp >> 2, kgs = kgp & 1, slot0 = ((kgp >> 1) & 1) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -321,9 +323,9 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
     // ---- online-softmax state of this lane's query and the O^T accumulators (d = 32 db + row of the tile)
     float m_run = -INFINITY, l_run = 0.0f;
     const float scale_l2 = a.scale * 1.4426950408889634f;       // softmax scale * log2(e)
-    f32x16 O[4];
+    f32x16 O[NB];
 #pragma unroll
-    for (int db = 0; db < 4; db++)
+    for (int db = 0; db < NB; db++)
 #pragma unroll
         for (int r = 0; r < 16; r++) O[db][r] = 0.0f;
 
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
 #pragma unroll
                 for (int r = 0; r < 16; r++) sa[r] = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < NKS; j++) {
                     const f16x8 ak = *reinterpret_cast<const f16x8 *>(S.k + n * KS + (16 * j + 8 * kg) * 2);
                     sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, qh[j], sa, 0, 0, 0);
                 }
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
             m_run = m_new;
             if (!__all(alpha == 1.0f)) {                                      // (the maximum moves in the first chunks, rarely later)
 #pragma unroll
-                for (int db = 0; db < 4; db++)
+                for (int db = 0; db < NB; db++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) O[db][r] *= alpha;
             }
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
             FA_T(2);
             // ---- O^T[d][query] += V'^T . P^T
 #pragma unroll
-            for (int db = 0; db < 4; db++)
+            for (int db = 0; db < NB; db++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int o = (((db * 2 + j) * 2 + kg) * 32 + (n ^ db)) * 8;
@@ -491,22 +493,23 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
     if constexpr (KH == 2) {
         // ---- the second half's partial (O, m, l) -> LDS (the chunk buffers are done with) -> merged into the first half's: two softmax
         // partials over disjoint keys, O = O_a 2^(m_a - m) + O_b 2^(m_b - m)
-        float *mrg = reinterpret_cast<float *>(smem) + (size_t)wave * 66 * 64;       // [66][64 lanes] per head: 64 O registers, m, l
+        constexpr int MR = 16 * NB;                                                     // O registers of a lane
+        float *mrg = reinterpret_cast<float *>(smem) + (size_t)wave * (MR + 2) * 64;    // [MR + 2][64 lanes] per head: the O registers, m, l
         if (half == 1) {
 #pragma unroll
-            for (int db = 0; db < 4; db++)
+            for (int db = 0; db < NB; db++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) mrg[(db * 16 + r) * 64 + lane] = O[db][r];
-            mrg[64 * 64 + lane] = m_run; mrg[65 * 64 + lane] = l_run;
+            mrg[MR * 64 + lane] = m_run; mrg[(MR + 1) * 64 + lane] = l_run;
         }
         __syncthreads();
         if (half == 1) return;
-        const float m_b = mrg[64 * 64 + lane], l_b = mrg[65 * 64 + lane];
+        const float m_b = mrg[MR * 64 + lane], l_b = mrg[(MR + 1) * 64 + lane];
         const float m_new = fmaxf(m_run, m_b);
         const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
         const float wa = __builtin_amdgcn_exp2f(m_run - m_ref), wb = __builtin_amdgcn_exp2f(m_b - m_ref);
 #pragma unroll
-        for (int db = 0; db < 4; db++)
+        for (int db = 0; db < NB; db++)
 #pragma unroll
             for (int r = 0; r < 16; r++) O[db][r] = O[db][r] * wa + mrg[(db * 16 + r) * 64 + lane] * wb;
         l_run = l_run * wa + l_b * wb;
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
         if (q_ok) {
             float *dst = a.part + (((size_t)qt * H + h) * nsp + zsp) * (D + 2);
 #pragma unroll
-            for (int db = 0; db < 4; db++)
+            for (int db = 0; db < NB; db++)
 #pragma unroll
                 for (int rq = 0; rq < 4; rq++) {
                     float *o = dst + 32 * db + 8 * rq + 4 * kg;  // records are 8-byte aligned only ((D + 2) floats)
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
         const float inv = 1.0f / l_run;
         float *orow = a.out + ((size_t)qt * H + h) * D;
 #pragma unroll
-        for (int db = 0; db < 4; db++)
+        for (int db = 0; db < NB; db++)
 #pragma unroll
             for (int rq = 0; rq < 4; rq++) {
                 f32x4 v;
@@ -551,7 +554,9 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
 
 bool flash_attn_prefill_applicable(const AttnArgs &a) {
     const int R = a.G > 0 ? a.H / a.G : 0;
-    return a.D == 128 && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16)) && R >= 1 && R <= 8 &&
+    // head_dim 64 (TinyLlama, Llama-3.2-1B, nomic-embed): the power-of-two head ratios
+    if (a.D == 64 && !(R == 1 || R == 2 || R == 4 || R == 8)) return false;
+    return (a.D == 128 || a.D == 64) && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16)) && R >= 1 && R <= 8 &&
            a.n_kv_max <= MAX_CHUNKS * CK;
 }
 
@@ -590,13 +595,22 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
     const int nsp = (a.pf_splits > 1 && a.part) ? a.pf_splits : 1;
     const dim3 grid((unsigned)a.G, (unsigned)((a.T + QT * qs - 1) / (QT * qs)), (unsigned)nsp);
     const bool f16 = a.type_k == T_F16;
-    const size_t chunk = (size_t)CK * (f16 ? KF_STRIDE : K_STRIDE) + NB * CK * 4 + 2 * (4 * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
-    const size_t lds = kh == 2 ? std::max(4 * chunk, (size_t)R * qs * 66 * 64 * 4) : 2 * chunk;   // two chunk buffers per half, later the hand-over of the second half
-#define FAP(RR, KK, QQ) do { \
-        if (f16) { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, true, KK, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                   hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true, KK, QQ>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } \
-        else { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-               hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK, QQ>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } } while (0)
+    const int nb = a.D / 32;
+    const size_t chunk = (size_t)CK * (f16 ? 2 * a.D + 16 : a.D + 16) + nb * CK * 4 + 2 * (size_t)(nb * 2 * 2 * 32 * 8) * 2 + CK * 4 + CK * 8;
+    const size_t lds = kh == 2 ? std::max(4 * chunk, (size_t)R * qs * (16 * nb + 2) * 64 * 4) : 2 * chunk;   // two chunk buffers per half, later the hand-over of the second half
+#define FAP_D(RR, KK, QQ, DD) do { \
+        if (f16) { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, true, KK, QQ, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                   hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, true, KK, QQ, DD>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } \
+        else { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK, QQ, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK, QQ, DD>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } } while (0)
+#define FAP(RR, KK, QQ) FAP_D(RR, KK, QQ, 128)
+    if (a.D == 64) {                                            // the default wave arrangement of each head ratio only
+        if (R == 1 && kh == 2 && qs == 4) FAP_D(1, 2, 4, 64);
+        else if (R == 2 && kh == 2 && qs == 2) FAP_D(2, 2, 2, 64);
+        else if (R == 4 && kh == 2 && qs == 1) FAP_D(4, 2, 1, 64);
+        else if (R == 8 && kh == 1 && qs == 1) FAP_D(8, 1, 1, 64);
+        else return hipErrorInvalidValue;
+    } else
     switch (R) {
         case 1: if (kh == 2 && qs == 4) FAP(1, 2, 4); else if (kh == 2) FAP(1, 2, 1); else if (qs == 4) FAP(1, 1, 4); else FAP(1, 1, 1); break;
         case 2: if (kh == 2 && qs == 2) FAP(2, 2, 2); else if (kh == 2) FAP(2, 2, 1); else if (qs == 2) FAP(2, 1, 2); else FAP(2, 1, 1); break;
@@ -610,6 +624,7 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
         default: return hipErrorInvalidValue;
     }
 #undef FAP
+#undef FAP_D
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (nsp > 1) return launch_flash_attn_combine(a, nsp, st);      // merges the splits and quantises the rows when asked
