@@ -81,7 +81,10 @@ __device__ __forceinline__ int slot_key(int j, int kg, int i) { return 16 * j + 
 // the iterations, and with the long tiles dispatched first the short ones fill the slots they leave: no records, no second launch.
 // QS = query sub-tiles of 32 per workgroup (R = 1: four, R = 2: two, else one - four waves per half in every case): the sub-tiles share
 // every staged chunk, which a single-head workgroup of multi-head attention otherwise stages for one wave's use.
-template <int R, bool F16, int KH, int QS, int DH = 128>
+// Q4 (with F16 = false): a q4_0 K / V cache (cache_type "q4_0", src/llama_engine.cc:272-285).  Only the staging differs: a 16-byte piece of a K row is one
+// 32-block of nibbles, unpacked to the int8 codes nibble - 8 on its way into LDS (elements 0..15 from the low nibbles, 16..31 from the high ones), V codes
+// likewise; scores (vec_dot_q4_0_q8_0: the same integer dot with those codes), scales and the f16 hi / lo split of V' = code * d_v are the q8_0 path's.
+template <int R, bool F16, int KH, int QS, int DH = 128, bool Q4 = false>
 __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel(const AttnArgs a) {
     // head width: 128 or 64 (TinyLlama, Llama-3.2-1B, nomic-embed): everything below is written in 32-dim blocks (NB of them) and 16-dim matrix-core steps
     constexpr int D = DH, NB = DH / 32, K_STRIDE = DH + 16, KF_STRIDE = 2 * DH + 16, NKS = DH / 16, VPL = NB * 2 * 2 * 32 * 8, NVU = 2 * DH;
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
 #endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KS = F16 ? KF_STRIDE : K_STRIDE;    // bytes per staged K row
-    constexpr int PPK = F16 ? D / 8 : D / 16;         // 16-byte pieces per K / V row
+    constexpr int PPK = F16 ? D / 8 : Q4 ? D / 32 : D / 16;      // 16-byte pieces per K row
+    constexpr int KVROW = Q4 ? D / 2 : D;                         // bytes of a quantised K / V row
     constexpr int CHUNK_LDS = CK * KS + NB * CK * 4 + 2 * VPL * 2 + CK * 4 + CK * 8;   // one staged chunk (launcher: one per half)
     static_assert(CHUNK_LDS % 16 == 0, "chunk buffers stay 16-byte aligned");
     constexpr int NT = 64 * R * QS;                   // threads of one half: the staging roles below are per half
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
                 kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D * 2 + (p % PPK) * 16);
                 vq[i] = *reinterpret_cast<const u32x4 *>(a.kv.v + rowi * D * 2 + (p % PPK) * 16);
             } else {
-                kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * D + (p % PPK) * 16);
+                kq[i] = *reinterpret_cast<const u32x4 *>(a.kv.k + rowi * KVROW + (p % PPK) * 16);
             }
         }
         if constexpr (!F16) {
@@ -226,6 +230,11 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
                     int cell = c * CK + 4 * kgp + kk;
                     if (cell >= n_ctx) cell = n_ctx - 1;
                     const size_t rowi = head_row0 + cell;
+                    if constexpr (Q4) {     // dims 4 dg .. + 3 of block dg >> 3: four nibbles, the low or the high halves of four consecutive bytes; kept as 0 .. 15
+                        const int e0 = (4 * dg) & 31;
+                        const uint32_t w = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * KVROW + (dg >> 3) * 16 + (e0 & 15));
+                        v4[i][kk] = (e0 < 16 ? w : (w >> 4)) & 0x0f0f0f0fu;
+                    } else
                     v4[i][kk] = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + 4 * dg);
                     vd4[i][kk] = h2f(a.kv.vd[rowi * NB + (dg >> 3)]);
                 }
@@ -250,6 +259,17 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
             const int p = tid + NT * i;
             if (p >= CK * PPK) continue;
             const int key = p / PPK, col = p % PPK;            // q8_0: dims 16 col .. + 15; f16: dims 8 col .. + 7
+            if constexpr (Q4) {                                // piece = 32-block col: codes (nibble - 8) as int8, low nibbles first
+                u32x4 lo, hi;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t x = kq[i][w];
+                    lo[w] = (((x & 0x0f0f0f0fu) | 0x80808080u) - 0x08080808u) ^ 0x80808080u;          // per byte: n - 8 in two's complement, no borrow across bytes
+                    hi[w] = ((((x >> 4) & 0x0f0f0f0fu) | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+                }
+                *reinterpret_cast<u32x4 *>(S.k + key * KS + col * 32) = lo;
+                *reinterpret_cast<u32x4 *>(S.k + key * KS + col * 32 + 16) = hi;
+            } else
             *reinterpret_cast<u32x4 *>(S.k + key * KS + col * 16) = kq[i];
             if constexpr (F16) {                               // V is f16 already: the hi plane is V itself, there is no lo plane; written
                 const int j = key >> 4, r8 = key & 15;          // transposed in MFMA K-slot order: key = 16 j + 8 (i >> 2) + 4 kgs + (i & 3)
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
                     _Float16 hi[4], lo[4];
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
-                        const float v = (float)(int8_t)((v4[i][kk] >> (8 * e)) & 0xff) * vd4[i][kk];
+                        const float v = (Q4 ? (float)((int)((v4[i][kk] >> (8 * e)) & 0xff) - 8) : (float)(int8_t)((v4[i][kk] >> (8 * e)) & 0xff)) * vd4[i][kk];
                         hi[kk] = (_Float16)v;
                         lo[kk] = (_Float16)(v - (float)hi[kk]);
                     }
@@ -555,8 +575,9 @@ __global__ __launch_bounds__(64 * R * KH * QS, 2) void flash_attn_prefill_kernel
 bool flash_attn_prefill_applicable(const AttnArgs &a) {
     const int R = a.G > 0 ? a.H / a.G : 0;
     // head_dim 64 (TinyLlama, Llama-3.2-1B, nomic-embed): the power-of-two head ratios
-    if (a.D == 64 && !(R == 1 || R == 2 || R == 4 || R == 8)) return false;
-    return (a.D == 128 || a.D == 64) && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16)) && R >= 1 && R <= 8 &&
+    const bool pow2 = R == 1 || R == 2 || R == 4 || R == 8;
+    if (a.D == 64 && !pow2) return false;
+    return (a.D == 128 || a.D == 64) && a.T >= 32 && ((a.type_k == T_Q8_0 && a.type_v == T_Q8_0) || (a.type_k == T_F16 && a.type_v == T_F16) || (a.type_k == T_Q4_0 && a.type_v == T_Q4_0 && a.D == 128 && pow2)) && R >= 1 && R <= 8 &&
            a.n_kv_max <= MAX_CHUNKS * CK;
 }
 
@@ -604,6 +625,15 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
         else { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK, QQ, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK, QQ, DD>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } } while (0)
 #define FAP(RR, KK, QQ) FAP_D(RR, KK, QQ, 128)
+#define FAP_Q4(RR, KK, QQ) do { if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&flash_attn_prefill_kernel<RR, false, KK, QQ, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                hipLaunchKernelGGL((flash_attn_prefill_kernel<RR, false, KK, QQ, 128, true>), grid, dim3(64 * RR * KK * QQ), lds, st, a); } while (0)
+    if (a.type_k == T_Q4_0) {                                   // head_dim 128, the default wave arrangement of the power-of-two head ratios
+        if (R == 1 && kh == 2 && qs == 4) FAP_Q4(1, 2, 4);
+        else if (R == 2 && kh == 2 && qs == 2) FAP_Q4(2, 2, 2);
+        else if (R == 4 && kh == 2 && qs == 1) FAP_Q4(4, 2, 1);
+        else if (R == 8 && kh == 1 && qs == 1) FAP_Q4(8, 1, 1);
+        else return hipErrorInvalidValue;
+    } else
     if (a.D == 64) {                                            // the default wave arrangement of each head ratio only
         if (R == 1 && kh == 2 && qs == 4) FAP_D(1, 2, 4, 64);
         else if (R == 2 && kh == 2 && qs == 2) FAP_D(2, 2, 2, 64);
@@ -624,6 +654,7 @@ hipError_t launch_flash_attn_prefill(const AttnArgs &a, hipStream_t st) {
         default: return hipErrorInvalidValue;
     }
 #undef FAP
+#undef FAP_Q4
 #undef FAP_D
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
