@@ -698,6 +698,8 @@ bool flash_attn_decode_applicable(const AttnArgs &a, const RopeArgs &ra) {
     const bool odd = (R == 3 || R == 5 || R == 6 || R == 7) && a.D == 128 && a.type_k == a.type_v;
     // NEOX pairing (qwen2): the kernel rotates whole heads only
     if (ra.neox && ra.n_rot != a.D) return false;
+    // a q4_0 cache (K and V): head_dim 128, the power-of-two head ratios
+    if (a.type_k == T_Q4_0 || a.type_v == T_Q4_0) return a.type_k == a.type_v && a.D == 128 && pow2 && a.T <= 64 && a.n_kv_max <= 64 * 2048;
     return (a.D == 128 || a.D == 64) && (pow2 || odd) && a.T <= 64 && a.n_kv_max <= 64 * 2048 &&
            (a.type_k == T_F16 || a.type_k == T_Q8_0) && (a.type_v == T_F16 || a.type_v == T_Q8_0);
 }
@@ -718,7 +720,8 @@ hipError_t launch_flash_attn_decode(const AttnArgs &a, const float *cs_table, Ro
                                    else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, false, false, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, nofz); } while (0)
 #define FAD(RR, TK, TV) do { if (a.D == 64) FAD_D(RR, TK, TV, 64); else FAD_D(RR, TK, TV, 128); } while (0)
 #define FAD_T(RR)                                                              \
-    if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
+    if (a.type_k == T_Q4_0) FAD_D(RR, T_Q4_0, T_Q4_0, 128);                    \
+    else if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);    \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
     else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
     else FAD(RR, T_F16, T_Q8_0);
@@ -810,7 +813,8 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
                                    else hipLaunchKernelGGL((flash_attn_decode_kernel<RR, TK, TV, true, false, DD>), grid, dim3(256), 0, st, a, cs_table, ra.n_rot, fz); } while (0)
 #define FAD(RR, TK, TV) do { if (a.D == 64) FAD_D(RR, TK, TV, 64); else FAD_D(RR, TK, TV, 128); } while (0)
 #define FAD_T(RR)                                                              \
-    if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);         \
+    if (a.type_k == T_Q4_0) FAD_D(RR, T_Q4_0, T_Q4_0, 128);                    \
+    else if (a.type_k == T_F16 && a.type_v == T_F16) FAD(RR, T_F16, T_F16);    \
     else if (a.type_k == T_Q8_0 && a.type_v == T_Q8_0) FAD(RR, T_Q8_0, T_Q8_0); \
     else if (a.type_k == T_Q8_0) FAD(RR, T_Q8_0, T_F16);                       \
     else FAD(RR, T_F16, T_Q8_0);

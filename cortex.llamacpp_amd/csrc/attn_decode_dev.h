@@ -40,7 +40,9 @@ struct DecodeFuse {
 template <int R, int TK, int TV, bool FUSED, bool COH = false, int D = 128>
 __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, int g, int sp, int t) {
     constexpr int C = 64, NB = D / 32;
-    constexpr int LPC = (TK == T_F16 ? 2 * D : D) / 16;     // lanes per cell in the score pass (16-byte pieces of a K row)
+    // (a q4_0 cache - TK = TV = T_Q4_0, head_dim 128 - keeps 16 nibble bytes per 32-block: a piece is a whole block, four lanes per cell)
+    constexpr int KROW = TK == T_F16 ? 2 * D : TK == T_Q4_0 ? D / 2 : D, VROW = TV == T_Q4_0 ? D / 2 : D;   // bytes of a K row; bytes (halfs for f16) of a V row
+    constexpr int LPC = KROW / 16;                           // lanes per cell in the score pass (16-byte pieces of a K row)
     constexpr int KP = C * LPC / 256;                       // 16-byte K pieces per thread
     constexpr int DQ = D / 4, NCG = 256 / DQ, CPG = C / NCG;   // P.V pass: DQ lanes of 4 dims, NCG cell groups of CPG cells
     __shared__ __attribute__((aligned(16))) float qf[R * D];         // rotated q (f16-rounded for an f16 cache)
@@ -109,7 +111,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         if (cell >= n_ctx) cell = n_ctx - 1;
         const size_t rowi = head_row0 + cell;
         if (TK == T_F16) kreg[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
-        else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * D + (p % LPC) * 16);
+        else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
     }
     const int dq = tid % DQ, cg = tid / DQ;
     uint2 vreg[CPG];
@@ -119,6 +121,11 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         if (cell >= n_ctx) cell = n_ctx - 1;
         const size_t rowi = head_row0 + cell;
         if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+        else if (TV == T_Q4_0) {            // dims 4 dq .. + 3 of block dq >> 3: the low or the high nibbles of four consecutive bytes, kept one per byte
+            const int e0 = (dq * 4) & 31;
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * VROW + (dq >> 3) * 16 + (e0 & 15));
+            vreg[i].x = (e0 < 16 ? w : (w >> 4)) & 0x0f0f0f0fu; vreg[i].y = 0;
+        }
         else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
     }
     uint32_t ks2 = 0, vs2 = 0;
@@ -162,8 +169,22 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
             const size_t rowi = head_row0 + cellnew;
             const int TT = isk ? TK : TV;              // (TK, TV are compile-time; the select folds per branch below)
             uint32_t packed = 0; float dsc = 0.0f;
-            if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
-            if (TT == T_F16) {
+            if (TK == T_Q4_0) wave_quant_q40(xa, lane, packed, dsc);            // (TK = TV = T_Q4_0 only)
+            else if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
+            if (TT == T_Q4_0) {
+                const uint32_t hi = __shfl_xor(packed, 4, 64);                  // the lane four further on holds elements j + 16 of the block
+                if ((lane & 4) == 0) {
+                    const uint32_t bytes = packed | (hi << 4);
+                    const int off = (dd >> 5) * 16 + (dd & 15);
+                    *reinterpret_cast<uint32_t *>((isk ? newk : newv) + off) = bytes;
+                    *reinterpret_cast<uint32_t *>((isk ? a.kv.k : a.kv.v) + rowi * (D / 2) + off) = bytes;
+                }
+                if ((lane & 7) == 0) {
+                    const uint16_t hd = f2h(dsc);
+                    (isk ? a.kv.kd : a.kv.vd)[rowi * NB + (dd >> 5)] = hd;
+                    reinterpret_cast<uint16_t *>(isk ? newkd : newvd)[dd >> 5] = hd;
+                }
+            } else if (TT == T_F16) {
                 uint2 o; o.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); o.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
                 *reinterpret_cast<uint2 *>((isk ? newk : newv) + dd * 2) = o;
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(isk ? a.kv.k : a.kv.v) + rowi * D + dd) = o;
@@ -208,6 +229,11 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         for (int i = 0; i < CPG; i++) {
             if (cg + NCG * i == own_cl) {
                 if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(newv + dq * 8);
+                else if (TV == T_Q4_0) {
+                    const int e0 = (dq * 4) & 31;
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(newv + (dq >> 3) * 16 + (e0 & 15));
+                    vreg[i].x = (e0 < 16 ? w : (w >> 4)) & 0x0f0f0f0fu; vreg[i].y = 0;
+                }
                 else { vreg[i].x = *reinterpret_cast<const uint32_t *>(newv + dq * 4); vreg[i].y = 0; }
             }
         }
@@ -244,6 +270,23 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
                 s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s);      // 8 lanes
                 if (LPC == 16) s += dpp_f<DPP_MIRROR>(s);
                 sc[r] = s;
+            }
+        } else if (TK == T_Q4_0) {   // vec_dot_q4_0_q8_0: piece = 32-block; codes nibble - 8 against the q8_0 codes of q, low nibbles = elements 0 .. 15
+            const uint32_t kpair = ksc[cl * (NB / 2) + (piece >> 1)];
+            const float dk = h2f((uint16_t)((piece & 1) ? (kpair >> 16) : (kpair & 0xffff)));
+            const uint32_t kw[4] = {kreg[j].x, kreg[j].y, kreg[j].z, kreg[j].w};
+            uint32_t klo[4], khi[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) { klo[w] = nib_to_i8x4(kw[w] & 0x0f0f0f0fu); khi[w] = nib_to_i8x4((kw[w] >> 4) & 0x0f0f0f0fu); }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(qc + r * D + piece * 32), q1 = *reinterpret_cast<const uint4 *>(qc + r * D + piece * 32 + 16);
+                int s = 0;
+                s = dot4(klo[0], q0.x, s); s = dot4(klo[1], q0.y, s); s = dot4(klo[2], q0.z, s); s = dot4(klo[3], q0.w, s);
+                s = dot4(khi[0], q1.x, s); s = dot4(khi[1], q1.y, s); s = dot4(khi[2], q1.z, s); s = dot4(khi[3], q1.w, s);
+                float f = (float)s * (dk * qd[r * NB + piece]);
+                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f);                                 // the cell's four blocks
+                sc[r] = f;
             }
         } else {
             const uint32_t kpair = ksc[cl * (NB / 2) + (piece >> 2)];
@@ -293,7 +336,7 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
         } else {
             const uint32_t vpair = vsc[cl * (NB / 2) + (dq >> 4)];
             const float dv = h2f((uint16_t)(((dq >> 3) & 1) ? (vpair >> 16) : (vpair & 0xffff)));
-            const uint32_t w = vreg[i].x;
+            const uint32_t w = TV == T_Q4_0 ? nib_to_i8x4(vreg[i].x) : vreg[i].x;
             v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
             v4[2] = (float)(int8_t)((w >> 16) & 0xff) * dv; v4[3] = (float)(int8_t)(w >> 24) * dv;
         }

@@ -510,7 +510,9 @@ def test_ubatch_split_and_multi_sequence(be, pkg, tmp_models):
     c.close(); m.close(); oc.close(); om.close()
 
 
-@pytest.mark.parametrize("cfg,kv", [("tiny-qwen2-7b-2l", "q8_0"), ("tiny-qwen2", "f16"), ("tiny-qwen2-1.5b-2l", "q8_0")])
+@pytest.mark.parametrize("cfg,kv", [("tiny-qwen2-7b-2l", "q8_0"), ("tiny-qwen2", "f16"), ("tiny-qwen2-1.5b-2l", "q8_0"),
+                                    # (a llama-pairing file with a q4_0 cache: the same step kinds through the nibble cache - new rows quantised inside the attention launch)
+                                    ("tiny-g8", "q4_0"), ("tiny-8b-2l", "q4_0")])
 def test_neox_batched_steps_match_oracle(be, pkg, tmp_models, cfg, kv):
     """qwen2-type files through the continuous-batching step: three sequences of different lengths advance together (every token of another sequence: K is
     rotated with the NEOX pairing and stored inside the attention launch), then one sequence takes two tokens in one step (the general path); against the
