@@ -696,6 +696,17 @@ def test_encoder_hidden_states_match_oracle(be, pkg, tmp_models, cfg, ftype, n):
         c.kv_clear()
         assert c.decode(toks, np.arange(n), [2] * n, flags) == 0
         assert np.abs(c.embeddings(0) - first).max() <= 1e-5 # ... and only tokens of its own sequence
+        # one- and two-token sequences (the single-row launches), and a q8_0 cache under the same graph
+        for kvn, nn in (("f16", 1), ("f16", 2), ("q8_0", n)):
+            c3 = pkg.Context(m, n_ctx=256, type_k=KV[kvn], type_v=KV[kvn])
+            oc3 = oq.OracleContext(om, 256, KV[kvn], KV[kvn], True, 4)
+            oq.set_fa_v_acc_f32(1 if kvn == "f16" else 0)
+            assert c3.decode(toks[:nn], np.arange(nn), [0] * nn, np.ones(nn, np.int8)) == 0
+            oc3.decode(toks[:nn], np.arange(nn), [0] * nn, np.ones(nn, np.int8))
+            e3 = np.stack([c3.embeddings(i).copy() for i in range(nn)])
+            assert rel_err(e3, oc3.layer_out(m.n_layer - 1, nn).reshape(nn, -1)) <= (1e-2 if ftype == "f16" and kvn == "f16" else FLIP_TOL), (kvn, nn)
+            c3.close(); oc3.close()
+        oq.set_fa_v_acc_f32(1)
         # a batch longer than the micro-batch cannot be cut (every token needs all the others): refused
         c2 = pkg.Context(m, n_ctx=256, n_ubatch=16, type_k=KV["f16"], type_v=KV["f16"])
         with pytest.raises(pkg.MI355Error, match="micro-batch"):
