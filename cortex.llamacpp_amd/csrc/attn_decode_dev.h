@@ -6,6 +6,38 @@
 
 namespace mi355 {
 
+// quantize_row_q4_0 of a 32-block held by 8 consecutive lanes, 4 consecutive values each: the FIRST element of largest magnitude sets d = max / -8, codes
+// min(15, (int8)(x / d + 8.5)); nib4 = this lane's four codes, one per byte (0 .. 15).  The block's 16 bytes are q[j] | q[j + 16] << 4: lanes 0-3 of the group
+// hold the low nibbles, lanes 4-7 the high ones (combine with the lane 4 further on).
+__device__ __forceinline__ void wave_quant_q40(const float (&vv)[4], int lane, uint32_t &nib4, float &d) {
+    // key: |x| bits above, first-index preference below (larger key = larger magnitude, then smaller index)
+    unsigned long long key = 0ull;
+    float vbest = 0.0f;
+#pragma unroll
+    for (int i = 3; i >= 0; i--) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(fabsf(vv[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)((lane & 7) * 4 + i));
+        if (k > key) { key = k; vbest = vv[i]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned long long ok = __shfl_xor(key, o, 64);
+        const float ov = __shfl_xor(vbest, o, 64);
+        if (ok > key) { key = ok; vbest = ov; }
+    }
+    d = vbest / -8.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    nib4 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int q = (int)(int8_t)(vv[i] * id + 8.5f);
+        q = q > 15 ? 15 : q;
+        nib4 |= (uint32_t)(q & 0xff) << (8 * i);
+    }
+}
+
+// four nibbles (one per byte, 0 .. 15) -> the int8 codes nibble - 8, per byte without borrows across bytes
+__device__ __forceinline__ uint32_t nib_to_i8x4(uint32_t n) { return ((n | 0x80808080u) - 0x08080808u) ^ 0x80808080u; }
+
 // Decode attention: workgroup = (kv head g, chunk of 64 cells, token t).  The query heads of the group are read
 // un-rotated, rotated with the cos/sin table and converted to the K cache's dot type here (so no separate pass over q),
 // and K / V / scales / cell table of the chunk are all requested before the first wait.
