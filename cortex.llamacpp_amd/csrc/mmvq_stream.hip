@@ -86,7 +86,8 @@ void mmvq_stream_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_
 
 bool mmvq_stream_applicable(const MMVQArgs &a) {
     if (a.T != 1 || a.K <= 0 || (a.K % 1024) != 0) return false;
-    if (a.n_sel > 1) return false;
+    // the selected experts of one token in one launch (n_sel): one tensor or one gate | up pair, results stored per expert (no residual epilogue)
+    if (a.n_sel > 1 && (a.n_sel > 8 || (a.epi == EPI_SWIGLU ? 1 : a.n_seg) != 1 || a.epi == EPI_ADD)) return false;
     const int kb = (a.K + 2047) >> 11;
     if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7) return false;
     if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;
@@ -105,7 +106,7 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
         const MMVQSeg &g = a.seg[s];
         const int t = g.type;
         if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q8_0) return false;
-        if (g.expert_sel) return false;
+        if (g.expert_sel && (s != 0 && !(swiglu && s == 1))) return false;      // experts on segment 0 (and the up tensor of its pair) only
         if ((g.row_bytes % 16) != 0 || g.row_bytes < 1024) return false;
         if (g.row_bytes > (size_t)ST_MAX_STEP) return false;
         if (kb <= 2 && 2 * g.row_bytes > (size_t)ST_PAIR_MAX) return false;      // K <= 4096 only has the row-pair form

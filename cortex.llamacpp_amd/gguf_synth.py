@@ -199,6 +199,8 @@ CONFIGS = {
     # tiny-nomic: head_dim 64 as the real one; nomic-embed-2l: two layers of its geometry (768, 12 heads of 64, 3072, 30522 WordPiece tokens, rope base 1000)
     "tiny-nomic": LlamaConfig("tiny-nomic", 256, 2, 4, 4, 512, 512, 1000.0, 1e-12, 2048, arch="nomic-bert"),
     "nomic-embed-2l": LlamaConfig("nomic-embed-2l", 768, 2, 12, 12, 3072, 30522, 1000.0, 1e-12, 2048, arch="nomic-bert"),
+    # a mixture-of-experts file whose expert tensors are wide enough for the weight-stream mat-vec (hidden 2048, rows of >= 1 KiB): 8 experts, 2 used
+    "tiny-moe-e2048": LlamaConfig("tiny-moe-e2048", 2048, 2, 16, 4, 4096, 512, 1e6, 1e-5, 1024, 8, 2),
     "tiny-8b-3l": LlamaConfig("tiny-8b-3l", 4096, 3, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
 }
 

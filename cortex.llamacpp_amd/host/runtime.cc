@@ -1432,13 +1432,16 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 a.seg[0] = make_seg(L.gate_exps, ffn_, FF, nullptr, moe_ids_);
                 a.seg[1] = make_seg(L.up_exps, ffn_u_, FF, nullptr, moe_ids_);
                 chunk_act(a, aq_e_, E, 0);
+                // (RMSNorm + quantise again in the launch's prologue - the same arithmetic as the norm_quant launch that fed the router, so the same codes: the
+                // weight stream's gate | up form takes its activation that way, and with it the selected experts stream like the dense feed-forward does)
+                if (can_fuse(E, 1) && !act_is_q80(L.gate_exps.type)) { a.fuse_mode = 1; a.nx = x_; a.nw = (const float *)L.ffn_norm.data; a.neps = hp.eps; }
                 MMVQArgs d{};
                 d.n_seg = 1; d.K = FF; d.T = 1; d.epi = EPI_STORE; d.fuse_mode = 2; d.nx = ffn_; d.n_sel = KU; d.sel_nx_stride = FF; d.sel_out_stride = E;
                 d.seg[0] = make_seg(L.down_exps, moe_out_, E, nullptr, moe_ids_);
                 chunk_act(d, aq_ff_, FF, 0);
                 if (mmvq_fast_applicable(a) && mmvq_fast_applicable(d)) {
-                    HIP_TRY(launch_mmvq_fast(a, stream_));
-                    HIP_TRY(launch_mmvq_fast(d, stream_));
+                    HIP_TRY(launch_mmvq(a, stream_));          // the weight stream where it has a form for the shape, else the register ring (bit-identical)
+                    HIP_TRY(launch_mmvq(d, stream_));
                     experts_done = true;
                 }
             }
