@@ -40,14 +40,14 @@ namespace mi355 {
 namespace {
 
 // ---- one mat-vec per launch
-template <int KB, int FUSE>
+template <int KB, int FUSE, bool MOE = false>
 __global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef MI355_STREAM_PROBE
     const unsigned long long t_top = wall_clock64();
 #endif
     StOp a;
-    op_setup(ka, a);
+    op_setup<false, MOE>(ka, a);
     const int wave = uni(tid_now() >> 6);
     sync_init(smem);
 #ifdef MI355_STREAM_PROBE
@@ -88,6 +88,10 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
     if (a.T != 1 || a.K <= 0 || (a.K % 1024) != 0) return false;
     // the selected experts of one token in one launch (n_sel): one tensor or one gate | up pair, results stored per expert (no residual epilogue)
     if (a.n_sel > 1 && (a.n_sel > 8 || (a.epi == EPI_SWIGLU ? 1 : a.n_seg) != 1 || a.epi == EPI_ADD)) return false;
+    if (a.n_sel > 1 || a.seg[0].expert_sel) {                   // (the forms launch_mmvq_stream instantiates for expert launches)
+        const int kbm = (a.K + 2047) >> 11;
+        if (!((a.fuse_mode == 1 && (kbm == 1 || kbm == 2)) || (a.fuse_mode == 2 && (kbm == 2 || kbm == 4 || kbm == 7)))) return false;
+    }
     const int kb = (a.K + 2047) >> 11;
     if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7) return false;
     if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;
@@ -163,6 +167,23 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         else hipLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                  \
     } while (0)
 #define STREAM_F(KBV) do { if (a.fuse_mode == 0) STREAM(KBV, 0); else if (a.fuse_mode == 1) STREAM(KBV, 1); else STREAM(KBV, 2); } while (0)
+    // a mixture-of-experts step (expert index read on the device): the forms its two launches take - gate | up with the fused RMSNorm prologue over the hidden
+    // size, down with the quantise-only prologue over the feed-forward width
+#define STREAM_MOE(KBV, FZ)                                                                                              \
+    do {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mmvq_stream_kernel<KBV, FZ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ, true>), dim3(blocks), dim3(ST_NT), lds, st, a);                 \
+    } while (0)
+    if (a.n_sel > 1 || a.seg[0].expert_sel) {
+        if (a.fuse_mode == 1 && kb == 1) STREAM_MOE(1, 1);
+        else if (a.fuse_mode == 1 && kb == 2) STREAM_MOE(2, 1);
+        else if (a.fuse_mode == 2 && kb == 2) STREAM_MOE(2, 2);
+        else if (a.fuse_mode == 2 && kb == 4) STREAM_MOE(4, 2);
+        else if (a.fuse_mode == 2 && kb == 7) STREAM_MOE(7, 2);
+        else return hipErrorInvalidValue;
+        goto STREAM_DONE;
+    }
     switch (kb) {
         case 1: STREAM_F(1); break;
         case 2: STREAM_F(2); break;
@@ -172,6 +193,8 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         case 7: if (a.fuse_mode == 2) STREAM(7, 2); else if (a.fuse_mode == 0) STREAM(7, 0); else return hipErrorInvalidValue; break;
         default: return hipErrorInvalidValue;
     }
+    STREAM_DONE:
+#undef STREAM_MOE
 #undef STREAM_F
 #undef STREAM
     return hipGetLastError();

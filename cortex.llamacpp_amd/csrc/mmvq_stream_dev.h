@@ -206,7 +206,9 @@ template <class T> __device__ __forceinline__ T st_desc_get(const StDescRegs &r,
         return __builtin_bit_cast(T, w);
     }
 }
-template <bool MEM = false>
+// MOE: a mixture-of-experts step's launch (the token's n_sel selected experts share it, kernels.h MMVQArgs::n_sel); the dense kernels are built without it - its
+// seven extra argument words and the dependent read of the expert index cost every launch 0.1 - 0.25 us when they were unconditional (same-box A/B: 577 -> 570 tok/s)
+template <bool MEM = false, bool MOE = false>
 __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     StDescRegs dr{0u, 0u};
     if constexpr (MEM) dr = st_desc_load(ka);
@@ -222,9 +224,14 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     const int n0 = U(ka.seg[0].n_rows), n1 = U(ka.seg[1].n_rows), n2 = U(ka.seg[2].n_rows);
     const unsigned rb0 = (unsigned)U(ka.seg[0].row_bytes), rb1 = (unsigned)U(ka.seg[1].row_bytes), rb2 = (unsigned)U(ka.seg[2].row_bytes);
     // mixture-of-experts step: the token's n_sel selected experts share the launch (kernels.h MMVQArgs::n_sel); segment 0 (and the up tensor of a SwiGLU pair) carry them
-    const int n_sel = U(ka.n_sel), sel_os = U(ka.sel_out_stride), sel_ns = U(ka.sel_nx_stride);
-    const int32_t *es0 = U(ka.seg[0].expert_sel), *es1 = U(ka.seg[1].expert_sel);
-    const size_t est0 = U(ka.seg[0].expert_stride), est1 = U(ka.seg[1].expert_stride);
+    int n_sel = 0, sel_os = 0, sel_ns = 0;
+    const int32_t *es0 = nullptr, *es1 = nullptr;
+    size_t est0 = 0, est1 = 0;
+    if constexpr (MOE) {
+        n_sel = U(ka.n_sel); sel_os = U(ka.sel_out_stride); sel_ns = U(ka.sel_nx_stride);
+        es0 = U(ka.seg[0].expert_sel); es1 = U(ka.seg[1].expert_sel);
+        est0 = U(ka.seg[0].expert_stride); est1 = U(ka.seg[1].expert_stride);
+    }
 #undef U
     // (pinned: without a use here hipcc sinks each load to its first use again)
 #define PIN(x) asm volatile("" :: "s"(x))
@@ -232,7 +239,7 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     PIN(aq); PIN(ad); PIN(abs); PIN(nx); PIN(nw);
     PIN(w0); PIN(w1); PIN(w2); PIN(o0); PIN(o1); PIN(o2); PIN(r0); PIN(r1); PIN(r2);
     PIN(t0); PIN(t1); PIN(t2); PIN(n0); PIN(n1); PIN(n2); PIN(rb0); PIN(rb1); PIN(rb2);
-    PIN(n_sel); PIN(sel_os); PIN(sel_ns); PIN(es0); PIN(es1); PIN(est0); PIN(est1);
+    if constexpr (MOE) { PIN(n_sel); PIN(sel_os); PIN(sel_ns); PIN(es0); PIN(es1); PIN(est0); PIN(est1); }
 #undef PIN
     int s = 0;
     if (n_seg > 1 && (int)blockIdx.x >= sb1) s = 1;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     const int lo = s == 0 ? sb0 : s == 1 ? sb1 : sb2, hi = s == 0 ? sb1 : s == 1 ? sb2 : sb3;
     int nblk = hi - lo, bl = (int)blockIdx.x - lo;
     int sel_j = 0;
-    if (n_sel > 1 && nblk >= n_sel && bl >= 0 && bl < nblk) {   // an even share of the segment's workgroups per selected expert (the last one takes the remainder)
+    if (MOE && n_sel > 1 && nblk >= n_sel && bl >= 0 && bl < nblk) {   // an even share of the segment's workgroups per selected expert (the last one takes the remainder)
         const int per = nblk / n_sel;
         sel_j = bl / per < n_sel ? bl / per : n_sel - 1;
         bl -= sel_j * per;
@@ -248,12 +255,12 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     }
     o.K = K; o.epi = epi; o.nck = nck; o.neps = neps; o.aq = aq; o.ad = ad; o.abs = abs; o.nw = nw;
     o.W = s == 0 ? w0 : s == 1 ? w1 : w2; o.W1 = w1;
-    if (es0 && s == 0) {                                        // the expert's index is read on the device (written by the router launch before this one)
+    if (MOE && es0 && s == 0) {                                        // the expert's index is read on the device (written by the router launch before this one)
         o.W += (size_t)es0[sel_j] * est0;
         if (es1) o.W1 += (size_t)es1[sel_j] * est1;
     }
-    o.nx = nx + (size_t)sel_j * (size_t)sel_ns;
-    o.out = (s == 0 ? o0 : s == 1 ? o1 : o2) + (size_t)sel_j * (size_t)sel_os;
+    o.nx = nx; o.out = s == 0 ? o0 : s == 1 ? o1 : o2;
+    if constexpr (MOE) { o.nx = nx + (size_t)sel_j * (size_t)sel_ns; o.out += (size_t)sel_j * (size_t)sel_os; }
     o.resid = s == 0 ? r0 : s == 1 ? r1 : r2;
     o.type = s == 0 ? t0 : s == 1 ? t1 : t2;
     o.n_rows = s == 0 ? n0 : s == 1 ? n1 : n2;
