@@ -20,7 +20,7 @@ def find(sub):
     raise KeyError(sub)
 
 
-k21, k72, k20 = find("mmvq_stream_kernel<2, 1>"), find("mmvq_stream_kernel<7, 2>"), find("mmvq_stream_kernel<2, 0>")
+k21, k72, k20 = find("mmvq_stream_kernel<2, 1"), find("mmvq_stream_kernel<7, 2"), find("mmvq_stream_kernel<2, 0")
 tot_l = k21["launches"] + k72["launches"] + k20["launches"]
 b = lambda v: int(round(v["fetch_size_sum"] * 1024 * 2))   # noqa: E731
 per_tok = int(round((b(k21) + b(k72) + b(k20)) * 129 / tot_l))
