@@ -85,6 +85,8 @@ def rel_err(a, b):
                                           # 3 and 5 query heads per kv head: matrix-core prompt attention (40 / 70 tokens) and the single-launch decode attention, both cache types
                                           # q4_0 cache (cache_type "q4_0"): the matrix-core prompt attention unpacks the nibbles while staging (head_dim 128; ratios 4, 2, 1)
                                           ("tiny-d128:40", "q4_k_m", "q4_0"), ("tiny-g8:70", "q4_k_m", "q4_0"), ("tiny-d128-mha:40", "q5_k_m", "q4_0"), ("tiny-8b-2l:70", "q4_k_m", "q4_0"),
+                                          # two query heads of 64 per kv head on the matrix-core prompt attention (its R = 2, head_dim 64 form), both cache types
+                                          ("tiny:40", "q4_k_m", "q8_0"), ("tiny:70", "q5_k_m", "f16"),
                                           ("tiny-r3:40", "q4_k_m", "q8_0"), ("tiny-r3:70", "q5_k_m", "f16"), ("tiny-r5:40", "q4_k_m", "f16"), ("tiny-r5:50", "q4_k_m", "q8_0")])
 def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, kv):
     cfg, _, np_s = cfg.partition(":")
