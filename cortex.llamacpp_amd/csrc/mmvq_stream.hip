@@ -85,7 +85,7 @@ void mmvq_stream_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_
 #endif
 
 bool mmvq_stream_applicable(const MMVQArgs &a) {
-    if (a.T != 1 || a.K <= 0 || (a.K % 1024) != 0) return false;
+    if (a.T != 1 || a.K <= 0 || (a.K % 256) != 0) return false;      // (whole super-blocks; a partial last pass decodes zero-scale slices, as on the register ring)
     // the selected experts of one token in one launch (n_sel): one tensor or one gate | up pair, results stored per expert (no residual epilogue)
     if (a.n_sel > 1 && (a.n_sel > 8 || (a.epi == EPI_SWIGLU ? 1 : a.n_seg) != 1 || a.epi == EPI_ADD)) return false;
     if (a.n_sel > 1 || a.seg[0].expert_sel) {                   // (the forms launch_mmvq_stream instantiates for expert launches)

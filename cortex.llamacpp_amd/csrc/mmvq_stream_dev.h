@@ -481,10 +481,10 @@ __device__ __forceinline__ void loader_drain(LoaderState &st, uint8_t *smem, int
 // the first weight slot of the launch: qs [K], then d [nb * 4], then bs [K / 8]
 __device__ __forceinline__ int loader_planes(const StOp &a, uint8_t *smem, const StLayout &lay, int lane) {   // returns the DMA instructions issued
     const int nb = a.K >> 8;
-    const int nq = a.K >> 10, nbs = ((a.K >> 3) + 1023) >> 10;
+    const int nq = (a.K + 1023) >> 10, nbs = ((a.K >> 3) + 1023) >> 10;      // (K a multiple of 256: the last piece of the codes may be short)
     for (int c = 0; c < nq + 1 + nbs; c++) {
         const uint8_t *src; int size; unsigned dst;
-        if (c < nq) { src = reinterpret_cast<const uint8_t *>(a.aq) + c * 1024; size = 1024; dst = lay.qs + c * 1024; }
+        if (c < nq) { src = reinterpret_cast<const uint8_t *>(a.aq) + c * 1024; size = a.K - c * 1024; if (size > 1024) size = 1024; dst = lay.qs + c * 1024; }
         else if (c == nq) { src = reinterpret_cast<const uint8_t *>(a.ad); size = nb * 4; dst = lay.d; }
         else { const int i = c - nq - 1; src = reinterpret_cast<const uint8_t *>(a.abs) + i * 1024; size = (a.K >> 3) - i * 1024; if (size > 1024) size = 1024; dst = lay.bs + i * 1024; }
         const int o = lane * 16 < size ? lane * 16 : size - 16;

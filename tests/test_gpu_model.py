@@ -379,7 +379,9 @@ def test_layer_engine_matches_per_launch_bitwise(be, pkg, tmp_models, cfg, ftype
 @pytest.mark.parametrize("cfg,ftype,kv", [("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l", "q5_k_m", "f16"), ("tiny-e2048", "q4_k_m", "q8_0"),
                                           ("tiny-d128", "q4_k_m", "q8_0"), ("tiny-g8", "q8_0", "q8_0"),
                                           # mixture of experts: the token's two selected experts share a launch (gate | up with SwiGLU, then down), expert index read on the device
-                                          ("tiny-moe-e2048", "q4_k_m", "q8_0"), ("tiny-moe-e2048", "q5_k_m", "f16")])
+                                          ("tiny-moe-e2048", "q4_k_m", "q8_0"), ("tiny-moe-e2048", "q5_k_m", "f16"),
+                                          # contraction lengths that end inside a 2048-wide pass: TinyLlama's feed-forward width 5632, Qwen2-7B's hidden size 3584
+                                          ("tiny-tl-2l", "q4_k_m", "f16"), ("tiny-qwen2-7b-2l", "q4_k_m", "q8_0"), ("tiny-qwen2-1.5b-2l", "q5_k_m", "q8_0")])
 def test_weight_stream_matvec_matches_register_ring_bitwise(be, pkg, tmp_models, cfg, ftype, kv):
     """The single-token mat-vecs run as an LDS-DMA weight stream (mmvq_stream.hip: loader waves + consumer waves per CU);
     the register-ring kernel (mmvq_fast.hip) stays as the form for shapes the stream has none for.  Same arithmetic, same
