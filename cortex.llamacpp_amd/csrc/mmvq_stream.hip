@@ -93,7 +93,7 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
         if (!((a.fuse_mode == 1 && (kbm == 1 || kbm == 2)) || (a.fuse_mode == 2 && (kbm == 2 || kbm == 4 || kbm == 7)))) return false;
     }
     const int kb = (a.K + 2047) >> 11;
-    if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7) return false;
+    if (kb != 1 && kb != 2 && kb != 3 && kb != 4 && kb != 6 && kb != 7 && kb != 10) return false;    // (10: 18944 / 20480 - Qwen2-7B's and Yi-34B's feed-forward widths, single-row steps)
     if (a.fuse_mode < 0 || a.fuse_mode > 2) return false;
     if (a.fuse_mode == 1 && a.K > 8192) return false;
     const bool swiglu = a.epi == EPI_SWIGLU;
@@ -189,6 +189,7 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         case 2: STREAM_F(2); break;
         case 3: STREAM_F(3); break;
         case 4: STREAM_F(4); break;
+        case 10: if (a.fuse_mode == 2) STREAM(10, 2); else if (a.fuse_mode == 0) STREAM(10, 0); else return hipErrorInvalidValue; break;
         case 6: if (a.fuse_mode == 2) STREAM(6, 2); else if (a.fuse_mode == 0) STREAM(6, 0); else return hipErrorInvalidValue; break;
         case 7: if (a.fuse_mode == 2) STREAM(7, 2); else if (a.fuse_mode == 0) STREAM(7, 0); else return hipErrorInvalidValue; break;
         default: return hipErrorInvalidValue;
