@@ -172,7 +172,8 @@ hipError_t launch_pack_q80_blocks(const ActQuant &q, int n, int T, uint8_t *bloc
 hipError_t launch_repack_rows(int type, const uint8_t *src_ggml, uint8_t *dst_dev, int64_t K, int64_t n_rows, hipStream_t st);
 // dst[i][:] = dequant(table row ids[i]) from device-layout rows
 hipError_t launch_get_rows(int type, const uint8_t *table_dev, int64_t K, const int32_t *ids, int n_ids, float *dst, hipStream_t st);
-hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch /* rows*129 words, zero */, hipStream_t st);
+// scratch: cap_rows * 129 words, zero-filled once: [cap_rows ticket words | cap_rows * 64 part values | cap_rows * 64 part indices]; rows <= cap_rows
+hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch, int cap_rows, hipStream_t st);
 // ---- device-side sampling front end (reference call site common_sampler_sample, src/llama_server_context.cc:1679-1698): the k best
 // candidates of a logits row after logit_bias and the repetition / frequency / presence penalties, so that k (token, logit) pairs cross to the host
 // instead of the 513 KB row.  Order = the host sampler's (host/sampling.cc `better`): higher logit first, lower token id on ties.  Exact: the same f32

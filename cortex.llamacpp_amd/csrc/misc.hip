@@ -175,11 +175,14 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const float *x, int n,
     }
     if (tid == 0) out[row] = i2;
 }
-// scratch: rows * 64 floats + rows * 64 ints + rows ticket words (zero between launches)
-hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch, hipStream_t st) {
-    float *pv = scratch;
-    int *pi = reinterpret_cast<int *>(scratch + (size_t)rows * ARGMAX_PARTS);
-    unsigned *cnt = reinterpret_cast<unsigned *>(scratch + (size_t)rows * ARGMAX_PARTS * 2);
+// scratch: cap_rows ticket words (zero between launches) | cap_rows * 64 part values | cap_rows * 64 part indices.  The ticket words sit at the HEAD of the
+// scratch, at an address that does not depend on `rows`: behind the parts they moved with the row count, and a launch with fewer rows than its predecessor
+// found a part value of the earlier launch where its (zero) counter should be (multi-slot serving: 2 generating slots, then 1).
+hipError_t launch_argmax_rows(const float *x, int n, int rows, int32_t *out, float *scratch, int cap_rows, hipStream_t st) {
+    if (rows < 1 || rows > cap_rows) return hipErrorInvalidValue;
+    unsigned *cnt = reinterpret_cast<unsigned *>(scratch);
+    float *pv = scratch + cap_rows;
+    int *pi = reinterpret_cast<int *>(scratch + cap_rows + (size_t)cap_rows * ARGMAX_PARTS);
     hipLaunchKernelGGL(argmax_part_kernel, dim3(ARGMAX_PARTS, rows), dim3(256), 0, st, x, n, pv, pi, cnt, out);
     return hipGetLastError();
 }

@@ -179,6 +179,13 @@ bool LlamaEngine::LoadModelImpl(const Json &body, std::string &err) {   // :547-
     auto si = std::make_shared<ServerInfo>();
     const std::string path = body["llama_model_path"].is_string() ? body["llama_model_path"].as_string() : body["model_path"].str_or("");
     if (path.empty()) { err = "Missing model path in request"; return false; }
+    // `mmproj` (src/llama_engine.cc:553-562) turns the reference's context multimodal (clip / LLaVA, src/llama_server_context.cc:184-230).  This backend has no
+    // image encoder: refuse the load by name instead of serving the model as text-only behind the caller's back.
+    if (!body["mmproj"].is_null()) {
+        err = "mmproj: multimodal (LLaVA / clip) models are not supported by this backend";
+        log_line(LOG_ERROR, "%s", err.c_str());
+        return false;
+    }
     if (body["grammar_file"].is_string()) {                                   // :573-585
         FILE *gf = fopen(body["grammar_file"].as_string().c_str(), "rb");
         if (!gf) { err = "Grammar file not found"; log_line(LOG_ERROR, "Grammar file not found"); return false; }
@@ -442,6 +449,17 @@ void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734
         if (c.is_array()) { for (const Json &mc : c.items()) if (mc["type"].as_string() == "text") return mc["text"].as_string(); return ""; }
         return c.as_string();
     };
+    // `image_url` content pieces (src/llama_engine.cc:854-900: [img-N] placeholders + image_data for a multimodal context): no context of this backend is
+    // multimodal (mmproj is refused at load), so such a request is answered with the reference's error shape instead of being completed as text
+    for (const Json &msg : body["messages"].items()) {
+        if (!msg["content"].is_array()) continue;
+        for (const Json &mc : msg["content"].items()) {
+            if (mc["type"].is_string() && mc["type"].as_string() == "image_url") {
+                cb(make_status(false, true, false, k400BadRequest), message("image_url content is not supported: the model was loaded without a multimodal projector (mmproj)"));
+                return;
+            }
+        }
+    }
     if (body["prompt"].is_string() && !body["prompt"].as_string().empty()) {
         formatted = body["prompt"].as_string();
     } else {

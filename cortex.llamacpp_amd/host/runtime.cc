@@ -5,6 +5,7 @@
 #include "tp_comm.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +13,7 @@
 
 namespace mi355 {
 
+unsigned stream_error_epoch();           // error epochs opened so far in this process (Context::stream_check)
 static unsigned *stream_error_word();   // pinned, one per process: raised by a weight-stream / engine kernel whose bounded wait gave up
 
 static thread_local std::string g_err;
@@ -545,6 +547,7 @@ bool Context::init(std::string &err) {
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, model->device) == hipSuccess) set_num_cu(prop.multiProcessorCount);
+    err_epoch_seen_ = stream_error_epoch();
     if (unsigned *ew = stream_error_word()) { mmvq_stream_set_error_word(ew); decode_engine_set_error_word(ew); tp_p2p_set_error_word(ew); }   // (per device: the pointer lives in device globals)
 
     const size_t T = cp.n_ubatch, E = hp.n_embd, FF = hp.n_ff, G = hp.n_head_kv, D = hp.head_dim, NC = cp.n_ctx;
@@ -649,7 +652,7 @@ bool Context::init(std::string &err) {
     if (!att_part_ || !att_counters_) { err = "attention workspace allocation failed"; return false; }
     if (hipMemset(att_counters_, 0, 256 * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
-    argmax_scratch_ = (float *)dalloc(T * 129 * 4);     // per row: 64 part values, 64 part indices, one ticket word (zero-filled: dalloc)
+    argmax_scratch_ = (float *)dalloc(T * 129 * 4);     // T ticket words at the head, then per row 64 part values and 64 part indices (zero-filled: dalloc)
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
     chunk_stride_ = (int)((NC + 63) / 64);
     d_chunks_ = (int32_t *)dalloc((size_t)64 * (chunk_stride_ + 1) * 4);
@@ -1072,19 +1075,30 @@ static unsigned *stream_error_word() {
     return w;
 }
 
+// The word is one per process (the kernels find it through a device global), but a process may hold several contexts (the engine's server_map_): the
+// context that happens to read a raised word first is not necessarily the one whose kernel raised it.  So a raised word opens a new ERROR EPOCH, and every
+// live context fails its next check once per epoch: the step that really timed out is never returned as valid, at the price of one discarded step in the
+// bystanders.
+static std::atomic<unsigned> g_stream_err_epoch{0}, g_stream_err_code{0};
+unsigned stream_error_epoch() { return g_stream_err_epoch.load(); }
+
 bool Context::stream_check() {
     unsigned *w = stream_error_word();
-    if (!w || *w == 0u) return true;
-    const unsigned code = *w;
-    *w = 0u;
+    if (!w) return true;
+    const unsigned raised = __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED);
+    if (raised) { g_stream_err_code.store(raised); g_stream_err_epoch.fetch_add(1); }
+    const unsigned epoch = g_stream_err_epoch.load();
+    if (epoch == err_epoch_seen_) return true;
+    err_epoch_seen_ = epoch;
+    const unsigned code = g_stream_err_code.load();
     // a wait inside a weight-stream / engine kernel gave up (debugger, time-slicing, a workgroup that was not resident): the step's results are not valid.
     // Take one launch per mat-vec from here on (the engine is the only kernel that waits for OTHER workgroups) and say so.
     engine_state_ = -1;
     for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
     graphs_.clear();
     graph_exec_ = nullptr;
-    char buf[160];
-    snprintf(buf, sizeof buf, "weight-stream kernel: a bounded wait gave up (code 0x%x); results of the step discarded", code);
+    char buf[200];
+    snprintf(buf, sizeof buf, "weight-stream kernel: a bounded wait gave up in this process (code 0x%x); results of the step discarded", code);
     last_error = buf;
     return false;
 }
@@ -1635,7 +1649,7 @@ hipError_t Context::run_output(int n_out, int out_base) {
     for (int r0 = 0; r0 < n_out; r0 += (int)cp.n_ubatch) {
         const int nr = std::min((int)cp.n_ubatch, n_out - r0);
         // the winner goes straight into pinned host memory (visible once the stream has drained): no copy node
-        HIP_TRY(launch_argmax_rows(lg + (size_t)r0 * V, V, nr, h_argmax_ + out_base + r0, argmax_scratch_, stream_));
+        HIP_TRY(launch_argmax_rows(lg + (size_t)r0 * V, V, nr, h_argmax_ + out_base + r0, argmax_scratch_, (int)cp.n_ubatch, stream_));
     }
     prof_mark("argmax");
     return hipSuccess;
@@ -1917,9 +1931,6 @@ int Context::topk_rows(int n, const int *is, const int *ks, const TopkAdj *adjs,
         if (topk_scratch_) (void)hipFree(topk_scratch_);
         if (d_topk_adj_) (void)hipFree(d_topk_adj_);
         if (h_topk_) (void)hipHostFree(h_topk_);
-    if (h_topk_adj_) (void)hipHostFree(h_topk_adj_);
-    if (d_topk_adj_) (void)hipFree(d_topk_adj_);
-    if (topk_scratch_) { (void)hipFree(topk_scratch_); topk_scratch_ = nullptr; }
         if (h_topk_adj_) (void)hipHostFree(h_topk_adj_);
         topk_scratch_ = nullptr; d_topk_adj_ = nullptr; h_topk_ = nullptr; h_topk_adj_ = nullptr; topk_rows_cap_ = 0;
         const int cap = std::max(n, std::min(64, (int)cp.n_seq_max));

@@ -235,6 +235,7 @@ class Context {
     unsigned *d_engine_epoch_ = nullptr;               // step serial (incremented by step_setup)
     unsigned long long *d_engine_probe_ = nullptr;     // MI355_ENGINE_PROBE=<layer>: wall-clock stamps of that layer's launch (printed by the destructor)
     int engine_probe_layer_ = -1;
+    unsigned err_epoch_seen_ = 0;                      // stream_check: the process-wide error epoch this context has already answered for
     int engine_state_ = 0;                             // 0 = not looked at yet, 1 = ready, -1 = this model / context takes one launch per mat-vec
     bool engine_prepare();
     bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up

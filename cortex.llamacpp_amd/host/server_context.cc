@@ -329,6 +329,12 @@ void LlamaServerContext::SendEmbedding(LlamaClientSlot &slot, int batch_index) {
     const int n_rows = (pool == 1 || pool == 2) ? slot.num_prompt_tokens_processed : 1;
     std::vector<float> pooled;
     const float *embd = nullptr;
+    if ((pool == 1 || pool == 2) && (n_rows <= 0 || batch_index - n_rows + 1 < 0)) {
+        // the prompt's rows are not all in THIS batch (it was ingested over several scheduler ticks): pooling over the rows at hand would silently
+        // answer with another vector - refuse instead
+        SendError(slot, "embedding: a pooled prompt must fit one batch (raise n_batch or shorten the input)");
+        return;
+    }
     if (pool == 1 && n_rows > 0 && batch_index - n_rows + 1 >= 0) {
         pooled.assign((size_t)n_embd, 0.0f);
         bool ok = true;

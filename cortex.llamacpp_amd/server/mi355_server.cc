@@ -36,6 +36,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../host/json.h"
@@ -95,15 +96,33 @@ struct ResultQueue {
         return r;
     }
 };
-// the queue must outlive the HTTP exchange when the client leaves early: the callback owns one reference and drops it with the
-// final result (is_done or has_error)
+// The engine calls back from its own threads, possibly after the HTTP exchange is over (the client left early) and - for a cancelled stream - possibly
+// never with a final result.  So the callback's user pointer is not an owning reference but a ticket number into a registry: a callback whose ticket is
+// gone (the final result was delivered, or the connection thread has dropped the exchange) is ignored instead of touching freed memory, and an exchange that
+// never sees its final callback is dropped by the connection thread when it is done with it.
+struct CallRegistry {
+    std::mutex m;
+    std::unordered_map<uintptr_t, std::shared_ptr<ResultQueue>> live;
+    uintptr_t next = 1;
+    uintptr_t add(const std::shared_ptr<ResultQueue> &q) { std::lock_guard<std::mutex> l(m); const uintptr_t id = next++; live[id] = q; return id; }
+    std::shared_ptr<ResultQueue> find(uintptr_t id) { std::lock_guard<std::mutex> l(m); auto it = live.find(id); return it == live.end() ? nullptr : it->second; }
+    void drop(uintptr_t id) { std::lock_guard<std::mutex> l(m); live.erase(id); }
+};
+CallRegistry g_calls;
 void on_result(const char *status_json, const char *body_json, void *user) {
-    auto *ref = static_cast<std::shared_ptr<ResultQueue> *>(user);
+    const uintptr_t id = reinterpret_cast<uintptr_t>(user);
+    std::shared_ptr<ResultQueue> q = g_calls.find(id);
+    if (!q) return;                                           // a late or repeated callback of an exchange that is over
     bool last = true;
     Json st;
     if (status_json && Json::parse(status_json, st)) last = st.value<bool>("is_done", true) || st.value<bool>("has_error", false);
-    (*ref)->push(status_json, body_json);
-    if (last) delete ref;
+    if (last) g_calls.drop(id);
+    q->push(status_json, body_json);
+}
+// header values that are echoed into a response: anything with a control character (a bare LF would split the response) is dropped
+std::string echo_safe(const std::string &v) {
+    for (unsigned char c : v) if ((c < 0x20 && c != '\t') || c == 0x7f) return std::string();
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------ HTTP
@@ -209,7 +228,7 @@ const char *reason(int code) {
 std::string head_of(int code, const std::string &ctype, const std::string &origin, bool keep_alive, long content_length) {
     std::string h = "HTTP/1.1 " + std::to_string(code) + " " + reason(code) + "\r\n";
     h += "Content-Type: " + ctype + "\r\n";
-    h += "Access-Control-Allow-Origin: " + origin + "\r\n";        // (server.cc:164-165: the request's Origin, echoed)
+    h += "Access-Control-Allow-Origin: " + echo_safe(origin) + "\r\n";        // (server.cc:164-165: the request's Origin, echoed)
     if (content_length >= 0) h += "Content-Length: " + std::to_string(content_length) + "\r\n";
     else h += "Transfer-Encoding: chunked\r\nCache-Control: no-cache\r\n";
     h += keep_alive ? "Connection: keep-alive\r\n" : "Connection: close\r\n";
@@ -231,11 +250,19 @@ struct Server {
 
     typedef void (*engine_fn)(void *, const char *, engine_callback, void *);
 
-    std::shared_ptr<ResultQueue> call(engine_fn fn, const std::string &body) {
-        auto q = std::make_shared<ResultQueue>();
-        auto *ref = new std::shared_ptr<ResultQueue>(q);
-        fn(engine, body.empty() ? "{}" : body.c_str(), on_result, ref);
-        return q;
+    struct Call {                       // one engine call and its result queue; the ticket is dropped when the exchange ends, whatever the engine still does
+        std::shared_ptr<ResultQueue> q;
+        uintptr_t id = 0;
+        Call() = default;
+        Call(const Call &) = delete;
+        Call &operator=(const Call &) = delete;
+        ~Call() { if (id) g_calls.drop(id); }
+        ResultQueue *operator->() const { return q.get(); }
+    };
+    void call(Call &c, engine_fn fn, const std::string &body) {
+        c.q = std::make_shared<ResultQueue>();
+        c.id = g_calls.add(c.q);
+        fn(engine, body.empty() ? "{}" : body.c_str(), on_result, reinterpret_cast<void *>(c.id));
     }
     static int status_code(const std::string &status_json, bool *done = nullptr, bool *error = nullptr) {
         Json st;
@@ -247,13 +274,15 @@ struct Server {
 
     // one result, one JSON response (process_non_stream_res, server.cc:124-131)
     bool relay_one(int fd, const Request &rq, engine_fn fn) {
-        auto q = call(fn, rq.body);
+        Call q;
+        call(q, fn, rq.body);
         const auto r = q->pop();
         return send_json(fd, status_code(r.first), r.second, rq);
     }
     // a streaming completion: the "data" string of every callback as one chunk, until is_done / has_error (process_stream_res, server.cc:133-160)
     bool relay_stream(int fd, const Request &rq, const std::string &model_id) {
-        auto q = call(api.chat_completion, rq.body);
+        Call q;
+        call(q, api.chat_completion, rq.body);
         auto first = q->pop();
         bool done = false, error = false;
         int code = status_code(first.first, &done, &error);
@@ -283,9 +312,10 @@ struct Server {
     bool handle(int fd, const Request &rq) {
         const std::string &m = rq.method, &p = rq.path;
         if (m == "OPTIONS") {
-            std::string h = "HTTP/1.1 204 No Content\r\nAccess-Control-Allow-Origin: " + rq.header("origin") +
+            const std::string acrh = echo_safe(rq.header("access-control-request-headers"));
+            std::string h = "HTTP/1.1 204 No Content\r\nAccess-Control-Allow-Origin: " + echo_safe(rq.header("origin")) +
                             "\r\nAccess-Control-Allow-Methods: GET, POST, DELETE, OPTIONS\r\nAccess-Control-Allow-Headers: " +
-                            (rq.header("access-control-request-headers").empty() ? std::string("Content-Type, Authorization") : rq.header("access-control-request-headers")) +
+                            (acrh.empty() ? std::string("Content-Type, Authorization") : acrh) +
                             "\r\nContent-Length: 0\r\n" + (rq.keep_alive ? "Connection: keep-alive\r\n" : "Connection: close\r\n") + "\r\n";
             return send_all(fd, h);
         }
@@ -369,7 +399,7 @@ struct Server {
         }
         ::close(listen_fd);
         for (int i = 0; i < 300 && live.load() > 0; i++) std::this_thread::sleep_for(std::chrono::milliseconds(10));   // let open exchanges finish
-        return 0;
+        return live.load() > 0 ? -1 : 0;     // -1: connection threads are still inside engine calls (main must not destroy the engine under them)
     }
 };
 
@@ -417,6 +447,10 @@ int main(int argc, char **argv) {
     sigaction(SIGTERM, &sa, nullptr);
     signal(SIGPIPE, SIG_IGN);
     const int rc = s.run(host, port);
+    if (rc < 0) {                       // detached connection threads still hold the engine: leave the teardown to the process exit
+        fflush(nullptr);
+        _exit(0);
+    }
     s.api.destroy(s.engine);
     return rc;
 }

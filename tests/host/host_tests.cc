@@ -828,6 +828,14 @@ static void test_engine() {
     Json none = Json::object();
     eng.LoadModel(none, grab);
     CHECK(code == 400);
+    // `mmproj` (reference: src/llama_engine.cc:553-562 makes the context multimodal): refused by name, in the reference's load-error shape (:376-384)
+    {
+        Json mm = Json::object(); mm["llama_model_path"] = "/models/llava.gguf"; mm["mmproj"] = "/models/mmproj.gguf";
+        Json st_mm, body_mm;
+        eng.LoadModel(mm, [&](Json &&st, Json &&b) { st_mm = st; body_mm = b; });
+        CHECK(st_mm["status_code"].as_int() == 500 && st_mm["has_error"].as_bool() && body_mm["message"].as_string() == "Failed to load model");
+        CHECK(body_mm["error"].as_string().find("mmproj") != std::string::npos);
+    }
     Json models;
     eng.GetModels(Json::object(), [&](Json &&, Json &&b) { models = b; });
     CHECK(models["data"].size() == 1 && models["data"].at(0)["id"].as_string() == "tiny-test" && models["data"].at(0)["vram"].as_int() == 123);
@@ -845,6 +853,28 @@ static void test_engine() {
     CHECK(status["status_code"].as_int() == 200 && !status["has_error"].as_bool() && status["is_done"].as_bool());
     CHECK(body["object"].as_string() == "chat.completion" && body["choices"].at(0)["message"]["role"].as_string() == "assistant");
     CHECK(body["usage"]["completion_tokens"].as_int() == 6 && body["usage"]["total_tokens"].as_int() == body["usage"]["prompt_tokens"].as_int() + 6);
+
+    // an `image_url` content piece (reference: src/llama_engine.cc:854-900, multimodal contexts only): 400, synchronously, nothing generated
+    {
+        Json rq2 = req;
+        Json pieces = Json::array(), pt = Json::object(), pi = Json::object(), url = Json::object();
+        pt["type"] = "text"; pt["text"] = "what is this?";
+        url["url"] = "data:image/png;base64,AAAA"; pi["type"] = "image_url"; pi["image_url"] = url;
+        pieces.push_back(pt); pieces.push_back(pi);
+        Json mi = Json::object(); mi["role"] = "user"; mi["content"] = pieces;
+        Json ms2 = Json::array(); ms2.push_back(mi);
+        rq2["messages"] = ms2;
+        Json st_i, body_i; int calls = 0;
+        eng.HandleChatCompletion(rq2, [&](Json &&st, Json &&b) { st_i = st; body_i = b; calls++; });
+        CHECK(calls == 1 && st_i["status_code"].as_int() == 400 && st_i["has_error"].as_bool() && body_i["message"].as_string().find("image_url") != std::string::npos);
+        // text-only content arrays still work (the first text piece is the content, :816-852)
+        Json only = Json::array(); only.push_back(pt);
+        mi["content"] = only; ms2 = Json::array(); ms2.push_back(mi); rq2["messages"] = ms2;
+        done = false;
+        eng.HandleChatCompletion(rq2, [&](Json &&st, Json &&b) { std::lock_guard<std::mutex> lk(mu); status = st; body = b; done = true; cv.notify_all(); });
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+        CHECK(status["status_code"].as_int() == 200 && body["object"].as_string() == "chat.completion");
+    }
 
     // streaming
     req["stream"] = true;

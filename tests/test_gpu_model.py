@@ -925,3 +925,25 @@ def test_real_layer_geometries_by_file_type(be, pkg, tmp_path, shape, ftype):
     assert max(errs) <= FLIP_TOL, (shape, ftype, errs)
     c.close(); m.close(); oc.close(); om.close()
     os.remove(path)
+
+
+def test_device_argmax_follows_a_changing_number_of_flagged_rows(be, pkg, tmp_models):
+    """Multi-slot serving: the number of flagged rows of a step changes (4 generating slots, then 2, then 1).  The single-launch device arg-max
+    keeps one ticket word per row; those words must sit at an address that does not move with the row count (round-3 advisor finding: behind the
+    part values they did, and a launch with fewer rows found a stale part value where its zero counter should be)."""
+    path = make(pkg, tmp_models, "tiny-gqa4", "q4_k_m")
+    m = pkg.Model(path)
+    c = pkg.Context(m, n_ctx=256, type_k=KV["q8_0"], type_v=KV["q8_0"], n_seq_max=4)
+    rng = np.random.default_rng(21)
+    lens = [9, 13, 6, 11]
+    for s, n in enumerate(lens):
+        c.decode(rng.integers(0, m.n_vocab, n), np.arange(n), seq=s)
+    for step, live in enumerate([[0, 1, 2, 3], [0, 1, 2, 3], [1, 3], [3], [0, 2, 3], [2], [0, 1, 2, 3], [1]]):
+        toks = rng.integers(0, m.n_vocab, len(live))
+        pos = [lens[s] for s in live]
+        assert c.decode(toks, pos, seq=live, logits=[1] * len(live)) == 0
+        for i in range(len(live)):
+            assert c.argmax(i) == int(c.logits(i).argmax()), (step, live, i)
+        for s in live:
+            lens[s] += 1
+    c.close(); m.close()
