@@ -101,6 +101,8 @@ SYMBOLS = {
     "mi355_op_soft_max": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp]),
     "mi355_op_moe_route": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mi355_op_flash_attn": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp]),
+    "mi355_op_attn_step": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _f32, _i32, _vp, _i64, _vp, _i32,
+                                     _vp, _vp, _vp, _vp]),
     "mi355_bench_hbm_read": (C.c_double, [_sz, C.c_int]),
     "mi355_profile_last_decode": (_i32, [_vp, C.POINTER(_cp), C.POINTER(_f32), _i32]),
     "mi355_profile_enable": (None, [_vp, _i32]),
@@ -282,6 +284,20 @@ class Backend:
                                                _ptr(v_rows), cell_pos.size, _ptr(cell_pos), _ptr(q_pos), scale, _ptr(out)),
                   "op_flash_attn")
         return out
+
+    def attn_step(self, q, k_new, v_new, n_head: int, n_head_kv: int, hd: int, type_k: int, k_rows, type_v: int, v_rows, cell_pos, tok_pos: int,
+                  tok_cell: int, rope_base: float, n_rot: int, scale: float, type_o: int, W_o, n_embd: int, resid, fused: bool, k_row_bytes: int, v_row_bytes: int):
+        """One single-token attention block (mi355_op_attn_step): returns (att [H * D], out [n_embd], k_row, v_row)."""
+        q = np.ascontiguousarray(q, np.float32); k_new = np.ascontiguousarray(k_new, np.float32); v_new = np.ascontiguousarray(v_new, np.float32)
+        cell_pos = np.ascontiguousarray(cell_pos, np.int32)
+        k_rows = np.ascontiguousarray(k_rows.view(np.uint8)); v_rows = np.ascontiguousarray(v_rows.view(np.uint8))
+        W_o = np.ascontiguousarray(W_o.view(np.uint8)); resid = np.ascontiguousarray(resid, np.float32)
+        att = np.zeros(n_head * hd, np.float32); out = np.zeros(n_embd, np.float32)
+        kr = np.zeros(k_row_bytes, np.uint8); vr = np.zeros(v_row_bytes, np.uint8)
+        self._chk(self.lib.mi355_op_attn_step(_ptr(q), _ptr(k_new), _ptr(v_new), n_head, n_head_kv, hd, type_k, _ptr(k_rows), type_v, _ptr(v_rows), cell_pos.size,
+                                              _ptr(cell_pos), int(tok_pos), int(tok_cell), float(rope_base), int(n_rot), float(scale), type_o, _ptr(W_o), n_embd,
+                                              _ptr(resid), int(bool(fused)), _ptr(att), _ptr(out), _ptr(kr), _ptr(vr)), "op_attn_step")
+        return att, out, kr, vr
 
     def hbm_read_gbps(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
         return float(self.lib.mi355_bench_hbm_read(nbytes, iters))

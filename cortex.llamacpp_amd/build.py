@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [
-    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmvq_stream.hip", "csrc/decode_engine.hip", "csrc/mmq.hip", "csrc/mmq_q80.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/mmf.hip", "csrc/attn.hip", "csrc/attn_prefill.hip", "csrc/decode_mega.hip",
+    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmvq_stream.hip", "csrc/decode_engine.hip", "csrc/mmq.hip", "csrc/mmq_q80.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/mmf.hip", "csrc/attn.hip", "csrc/attn_out.hip", "csrc/attn_prefill.hip", "csrc/decode_mega.hip",
     "host/gguf.cc", "host/runtime.cc", "host/tp_comm.cc", "host/vocab.cc", "host/sampling.cc", "host/grammar.cc", "host/json_schema.cc", "host/log.cc", "host/server_context.cc", "host/engine.cc",
     "host/hip_backend.cc", "csrc/c_api.cc",
 ]

@@ -1,0 +1,663 @@
+// attn_out.hip — single-token step: the decode attention AND the attn_output mat-vec in ONE launch (round 4).
+//
+// Reference call site: llama_decode inside UpdateSlots (src/llama_server_context.cc:1635); ops: ggml_rope_ext + the KV store + ggml_flash_attn_ext +
+// ggml_mul_mat(attn_output) + the residual add of llm_build_llama.
+//
+// Why one launch.  The per-launch path ran [attention: 72 workgroups, 9.8 us] -> boundary -> [attn_output: 256 workgroups, 5.9 us for 9.4 MB] per layer.
+// The second launch spends 2.7 us between "arguments loaded" and "activation ready" (cold instruction cache, the first memory round trip for 4.6 KB of
+// ready-made codes) while its loaders fill rings nobody can decode yet, plus the ~1.5 us boundary - and the first launch leaves 184 CUs idle for 10 us.
+// Here every workgroup (one per CU, 8 waves) owns a contiguous run of W_o rows AND, if its index is below the number of (kv head, chunk) items, one
+// attention item:
+//   1. item workgroups run the attention chunk exactly as flash_attn_decode_item does (rope of q and of the new K row, KV store, scores, chunk softmax,
+//      P.V, partial record published write-through, ticket; the last arriver of a kv head merges the chunks and quantises the head group's 256-blocks);
+//      the others start at once with 2;
+//   2. the workgroup's W_o rows (36 KB at 4096 x 4096 Q4_K over 256 workgroups) are copied HBM -> LDS with the DMA form of the global load
+//      (global_load_lds_dwordx4, mmvq_stream_dev.h) - item workgroups issue it behind their ticket (hipcc's counted waits for the item's own loads, and
+//      the drain of its partial stores, must never sit behind 36 KB of DMA), the merging ones behind their flag - and are on chip before the merge ends;
+//   3. the merging workgroups publish the Q8_K codes of their blocks write-through (sc1) and raise ONE flag per kv-head group = the step's serial number
+//      (a device word the step's set-up launch increments, so a hipGraph replay needs no reset and no per-launch argument);
+//   4. every workgroup: one wave polls the flags (relaxed, bounded), then all threads fetch the 4.6 KB of codes with sc1 loads into LDS, and the eight
+//      waves decode one row pair each out of LDS with the weight stream's decoders (same lane roles, same f32 order: the mat-vec's output bits are those of
+//      mmvq_stream_kernel given the same codes) and store row + residual.
+// Nothing waits before its own items are done, so the launch cannot deadlock on itself; every spin is bounded and raises the sticky error word.
+// The attention arithmetic is that of attn_decode_dev.h with 512 threads per item instead of 256 (16 cell groups instead of 8 in the P.V pass: another
+// f32 summation order, within the parity tolerance) and, from 2049 cells on, 128-cell chunks (so that a 4096-cell context is 256 items = one
+// per workgroup and the merge sums at most 32 partials in one request round).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "attn_decode_dev.h"
+#include "mmvq_stream_dev.h"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int AO_NT = 512, AO_NW = AO_NT / 64;
+constexpr int AO_D = 128, AO_NB = AO_D / 32, AO_NCG = AO_NT / (AO_D / 4);      // 16 cell groups of 32 lanes in the P.V pass
+
+struct AOArgs {
+    const uint8_t *W; float *out; const float *resid;
+    int type, n_rows, K, epi;
+    unsigned row_bytes;
+    int rows_per_wg;
+    unsigned slice_lds;             // LDS bytes reserved for the workgroup's rows (whole 4 KiB slots)
+    unsigned *flags;                // this layer's flag words, one per merge ticket group
+    const unsigned *serial;         // device word: the step's serial number (never 0)
+    int n_flags, n_items;           // ticket groups; attention items = G * splits
+    unsigned long long *probe;      // diagnosis (MI355_AO_PROBE=1): per workgroup 8 wall-clock stamps
+};
+
+template <int R, int C> struct AOSmem {
+    alignas(16) float qf[R * AO_D];
+    alignas(16) int8_t qc[R * AO_D];
+    float qd[R * AO_NB];
+    float S[R * C];
+    float ml[R * 2];
+    int vis[C];
+    uint32_t ksc[C * AO_NB / 2], vsc[C * AO_NB / 2];
+    alignas(16) float accs[AO_NCG * R * AO_D];
+    alignas(16) uint8_t newk[AO_D * 2];
+    alignas(16) uint8_t newv[AO_D * 2];
+    uint32_t newkd[2], newvd[2];
+    int last_flag;
+};
+
+// LDS: [0, slice_lds) the W_o rows | qs [K] | d (1 KiB of room) | bs [K / 8, whole KiB] | AOSmem
+struct AOLayout { unsigned qs, d, bs, attn, total; };
+__host__ __device__ inline AOLayout ao_layout(unsigned slice_lds, int K, size_t attn_bytes) {
+    AOLayout l;
+    l.qs = slice_lds;
+    l.d = l.qs + (unsigned)K;
+    l.bs = l.d + 1024u;
+    l.attn = l.bs + (((unsigned)K / 8u + 1023u) & ~1023u);
+    l.total = l.attn + (unsigned)((attn_bytes + 15) & ~(size_t)15);
+    return l;
+}
+
+// the workgroup's rows, HBM -> LDS: wave w copies the 4 KiB slots w, w + 8, ..; the tail re-reads the run's last 16 B (as loader_op does)
+__device__ __forceinline__ void ao_issue_dma(const AOArgs &o, uint8_t *smem, int b0, int nrw, int wave, int lane) {
+    if (nrw <= 0) return;
+    const unsigned total = (unsigned)nrw * o.row_bytes, last = total - 16u;
+    const uint8_t *src = o.W + (size_t)b0 * o.row_bytes;
+    const unsigned lds0 = lds_addr(smem);
+    const int n_slots = (int)((total + ST_SLOT - 1) / ST_SLOT);
+    for (int s = wave; s < n_slots; s += AO_NW) {
+        const unsigned off = (unsigned)s * ST_SLOT;
+        if (off + ST_SLOT <= total) dma_slot(src + off + (size_t)lane * 16, lds0 + off);
+        else {
+#pragma unroll
+            for (int p = 0; p < ST_SI; p++) {
+                const unsigned x = off + (unsigned)lane * 16u + p * 1024u;
+                dma16<true>(src + (x < total ? x : last), lds0 + off + p * 1024);
+            }
+        }
+    }
+}
+
+// ---- one attention item (kv head g, chunk slot sp) on the 512 threads of the workgroup; every exit is workgroup-uniform.  `dma` (the request for the
+// workgroup's W_o rows; it does nothing after its first call) is called by every wave once the item has nothing outstanding and nobody waits for it.
+template <int R, int TK, int TV, int C, class Dma>
+__device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, unsigned serial,
+                                             int g, int sp, AOSmem<R, C> &sm, Dma dma) {
+    constexpr int D = AO_D, NB = AO_NB, NT = AO_NT;
+    constexpr int KROW = TK == T_F16 ? 2 * D : D;
+    constexpr int LPC = KROW / 16;                           // lanes per cell in the score pass
+    constexpr int KP = C * LPC / NT;                         // 16-byte K pieces per thread
+    static_assert(C * LPC % NT == 0 && KP >= 1, "chunk size");
+    constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
+    constexpr int CL = C / 64;                               // cells per lane in the softmax
+    const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
+    const int n_ctx = a.n_ctx, H = a.H;
+    int chunk = sp;
+    if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
+        if (sp >= a.tok_nchunks[0]) { dma(); return; }
+        chunk = a.tok_chunks[sp];
+    }
+    const int c_lo = chunk * C;
+    const size_t head_row0 = (size_t)g * n_ctx;
+
+    // ---- every global load of the item
+    int cpos = -1;
+    unsigned long long cseq = 0;
+    if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
+    const int32_t tpos = a.tok_pos[0];
+    const int tseq = a.tok_seq[0];
+    constexpr int HP = D / 2, NPAIR = R * HP;
+    static_assert(NPAIR <= NT, "query pairs per thread");
+    float2 qv = make_float2(0.0f, 0.0f), csv = make_float2(1.0f, 0.0f);
+    if (tid < NPAIR) {
+        const int r = tid / HP, i = tid % HP;
+        qv = *reinterpret_cast<const float2 *>(a.q + ((size_t)g * R + r) * D + 2 * i);
+        if (2 * i < n_rot) csv = *reinterpret_cast<const float2 *>(cs_table + 2 * i);
+    }
+    uint4 kreg[KP];
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + NT * j;
+        int cell = c_lo + p / LPC;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TK == T_F16) kreg[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
+        else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
+    }
+    const int dq = tid % DQ, cg = tid / DQ;
+    uint2 vreg[CPG];
+#pragma unroll
+    for (int i = 0; i < CPG; i++) {
+        int cell = c_lo + cg + NCG * i;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+        else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
+    }
+    uint32_t ks2 = 0, vs2 = 0;
+    if (tid < C * NB / 2) {
+        int cell = c_lo + tid / (NB / 2);
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+    }
+
+    // ---- this token's own K / V row (the chunk that holds its cell): rotate K, convert, write the cache row, keep the codes for the patch below
+    int own_cl = -1;
+    {
+        const int cellnew = fz.tok_cell[0];
+        if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
+        if (own_cl >= 0 && wave == 0) {                          // lanes 0 .. 31: K, lanes 32 .. 63: V; four elements each
+            const bool isk = lane < 32;
+            const int dd = (lane & 31) * 4;
+            float4 x4 = *reinterpret_cast<const float4 *>((isk ? fz.knew : fz.vnew) + g * D + dd);
+            if (isk && dd < n_rot) {
+                const float4 cs = *reinterpret_cast<const float4 *>(cs_table + dd);   // c0 s0 c1 s1
+                const float x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
+                x4.x = x0 * cs.x - x1 * cs.y; x4.y = x0 * cs.y + x1 * cs.x;
+                x4.z = x2 * cs.z - x3 * cs.w; x4.w = x2 * cs.w + x3 * cs.z;
+            }
+            const float xa[4] = {x4.x, x4.y, x4.z, x4.w};
+            const size_t rowi = head_row0 + cellnew;
+            const int TT = isk ? TK : TV;
+            uint32_t packed = 0; float dsc = 0.0f;
+            if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
+            if (TT == T_F16) {
+                uint2 ov; ov.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); ov.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
+                *reinterpret_cast<uint2 *>((isk ? sm.newk : sm.newv) + dd * 2) = ov;
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(isk ? a.kv.k : a.kv.v) + rowi * D + dd) = ov;
+            } else {
+                *reinterpret_cast<uint32_t *>((isk ? sm.newk : sm.newv) + dd) = packed;
+                *reinterpret_cast<uint32_t *>((isk ? a.kv.k : a.kv.v) + rowi * D + dd) = packed;
+                if ((lane & 7) == 0) {
+                    const uint16_t hd = f2h(dsc);
+                    (isk ? a.kv.kd : a.kv.vd)[rowi * NB + (dd >> 5)] = hd;
+                    reinterpret_cast<uint16_t *>(isk ? sm.newkd : sm.newvd)[dd >> 5] = hd;
+                }
+            }
+        }
+    }
+
+    // ---- q: rotate, convert
+    if (tid < C) sm.vis[tid] = (cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
+    if (tid < C * NB / 2) { sm.ksc[tid] = ks2; sm.vsc[tid] = vs2; }
+    if (tid < NPAIR) {
+        const float x0 = qv.x, x1 = qv.y, c = csv.x, s = csv.y;
+        float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;
+        if (TK == T_F16) { y0 = h2f(f2h(y0)); y1 = h2f(f2h(y1)); }
+        *reinterpret_cast<float2 *>(sm.qf + 2 * tid) = make_float2(y0, y1);
+    }
+    __syncthreads();
+    if (own_cl >= 0) {   // workgroup-uniform: the row just produced instead of what the cache held before
+        if (tid < NB / 2) {
+            if (TK != T_F16) sm.ksc[own_cl * (NB / 2) + tid] = sm.newkd[tid];
+            if (TV != T_F16) sm.vsc[own_cl * (NB / 2) + tid] = sm.newvd[tid];
+        }
+#pragma unroll
+        for (int j = 0; j < KP; j++) {
+            const int p = tid + NT * j;
+            if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const uint4 *>(sm.newk + (p % LPC) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < CPG; i++) {
+            if (cg + NCG * i == own_cl) {
+                if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(sm.newv + dq * 8);
+                else { vreg[i].x = *reinterpret_cast<const uint32_t *>(sm.newv + dq * 4); vreg[i].y = 0; }
+            }
+        }
+    }
+    if (TK != T_F16) {   // q8_0 of the rotated q: 4 values per thread, 8-lane groups (whole waves: R * D / 4 is a multiple of 64)
+        if (tid * 4 < R * D) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(sm.qf + tid * 4);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            uint32_t packed; float d;
+            wave_quant_q80(vv, packed, d);
+            *reinterpret_cast<uint32_t *>(sm.qc + tid * 4) = packed;
+            if ((lane & 7) == 0) sm.qd[(tid * 4) >> 5] = h2f(f2h(d));
+        }
+        __syncthreads();
+    }
+
+    // ---- scores
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + NT * j;
+        const int cl = p / LPC, piece = p % LPC;
+        float sc[R];
+        if (TK == T_F16) {
+            const uint32_t kw[4] = {kreg[j].x, kreg[j].y, kreg[j].z, kreg[j].w};
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float *qq = sm.qf + r * D + piece * 8;
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    s += h2f((uint16_t)(kw[i] & 0xffff)) * qq[2 * i];
+                    s += h2f((uint16_t)(kw[i] >> 16)) * qq[2 * i + 1];
+                }
+                s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s); s += dpp_f<DPP_MIRROR>(s);      // 16 lanes
+                sc[r] = s;
+            }
+        } else {
+            const uint32_t kpair = sm.ksc[cl * (NB / 2) + (piece >> 2)];
+            const float dk = h2f((uint16_t)(((piece >> 1) & 1) ? (kpair >> 16) : (kpair & 0xffff)));
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint4 qq = *reinterpret_cast<const uint4 *>(sm.qc + r * D + piece * 16);
+                int s = 0;
+                s = dot4(kreg[j].x, qq.x, s); s = dot4(kreg[j].y, qq.y, s); s = dot4(kreg[j].z, qq.z, s); s = dot4(kreg[j].w, qq.w, s);
+                s += dpp_i<DPP_QP_1032>(s);                    // both halves of the 32-block (integer)
+                float f = (piece & 1) ? 0.0f : (float)s * (dk * sm.qd[r * NB + (piece >> 1)]);
+                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f);                                 // 4 lanes
+                f += dpp_f<DPP_HALF_MIRROR>(f);                                                          // 8 lanes
+                sc[r] = f;
+            }
+        }
+        if (piece == 0) {
+            const bool v = sm.vis[cl] != 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) sm.S[r * C + cl] = v ? sc[r] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax of the chunk: wave w -> heads w, w + 8, ..; lane = cell (and cell + 64)
+    for (int r = wave; r < R; r += AO_NW) {
+        float s[CL], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < CL; k++) { s[k] = sm.S[r * C + 64 * k + lane]; m = fmaxf(m, s[k]); }
+        m = wave_max(m);
+        float l = 0.0f;
+#pragma unroll
+        for (int k = 0; k < CL; k++) {
+            const float p = (s[k] == -INFINITY) ? 0.0f : expf(s[k] - m);
+            sm.S[r * C + 64 * k + lane] = p;
+            l += p;
+        }
+        l = wave_sum(l);
+        if (lane == 0) { sm.ml[2 * r] = m; sm.ml[2 * r + 1] = l; }
+    }
+    __syncthreads();
+
+    // ---- P.V
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < CPG; i++) {
+        const int cl = cg + NCG * i;
+        float v4[4];
+        if (TV == T_F16) {
+            v4[0] = h2f((uint16_t)(vreg[i].x & 0xffff)); v4[1] = h2f((uint16_t)(vreg[i].x >> 16));
+            v4[2] = h2f((uint16_t)(vreg[i].y & 0xffff)); v4[3] = h2f((uint16_t)(vreg[i].y >> 16));
+        } else {
+            const uint32_t vpair = sm.vsc[cl * (NB / 2) + (dq >> 4)];
+            const float dv = h2f((uint16_t)(((dq >> 3) & 1) ? (vpair >> 16) : (vpair & 0xffff)));
+            const uint32_t w = vreg[i].x;
+            v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
+            v4[2] = (float)(int8_t)((w >> 16) & 0xff) * dv; v4[3] = (float)(int8_t)(w >> 24) * dv;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float p = sm.S[r * C + cl];
+            acc[r][0] += v4[0] * p; acc[r][1] += v4[1] * p; acc[r][2] += v4[2] * p; acc[r][3] += v4[3] * p;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        *reinterpret_cast<float4 *>(sm.accs + ((size_t)cg * R + r) * D + dq * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    __syncthreads();
+    for (int e = tid; e < R * D; e += NT) {
+        const int r = e / D, d = e - r * D;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NCG; j++) s += sm.accs[((size_t)j * R + r) * D + d];
+        float *dst = a.part + (((size_t)g * R + r) * a.splits + sp) * (D + 2);
+        cstf<true>(dst + d, s);
+        if (d == 0) { cstf<true>(dst + D, sm.ml[2 * r]); cstf<true>(dst + D + 1, sm.ml[2 * r + 1]); }
+    }
+
+    // ---- ticket; the last workgroup of this kv head (group) merges: GP kv heads per ticket, RM = GP * R heads merged (attn_decode_dev.h)
+    constexpr int GP = 256 / ((R * D) % 256 == 0 ? 256 : 128);
+    constexpr int RM = R * GP;
+    const int gq = g / GP;
+    const int hb = gq * RM;
+    const int stride_s = a.splits;
+    const int splits = a.tok_nchunks ? a.tok_nchunks[0] : a.splits;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through partial stores have left
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm.last_flag = (old == (unsigned)(splits * GP) - 1u) ? 1 : 0;
+        if (sm.last_flag) __hip_atomic_store(fz.counters + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+    // the W_o rows may queue now: nothing of this item is outstanding any more and nobody waits for this workgroup (36 KB of DMA in front of the partial
+    // stores would have sat in their drain, i.e. in every kv head's ticket); the merging workgroup requests them after it has raised its flag
+    if (!sm.last_flag) { dma(); return; }
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
+    float *merged = sm.accs;                           // [RM * D]
+    float *wgt = GP > 1 ? sm.accs + RM * D : sm.S;     // [RM][64] split weights
+    constexpr int NE = (RM * D + NT - 1) / NT, UB = 32;
+    float macc[NE], x[NE][UB];
+    const float *pp[NE];
+    int wr[NE];
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        const int e = tid + NT * j < RM * D ? tid + NT * j : 0, r = e / D, d = e - r * D;
+        pp[j] = a.part + ((size_t)hb + r) * stride_s * (D + 2) + d;
+        wr[j] = r * 64;
+        macc[j] = 0.0f;
+    }
+    auto request = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int s2 = s0 + u < splits ? s0 + u : splits - 1;              // clamped: straight-line loads
+#pragma unroll
+            for (int j = 0; j < NE; j++) x[j][u] = __hip_atomic_load(pp[j] + (size_t)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    request(0);
+    for (int r = wave; r < RM; r += AO_NW) {           // same arithmetic as flash_attn_combine_kernel
+        const float *p = a.part + ((size_t)hb + r) * stride_s * (D + 2);
+        float m = -INFINITY, l = 0.0f;
+        if (lane < splits) {
+            m = __hip_atomic_load(p + (size_t)lane * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l = __hip_atomic_load(p + (size_t)lane * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float M = wave_max(m);
+        const float w = (lane < splits && m != -INFINITY) ? expf(m - M) : 0.0f;
+        const float den = wave_sum(w * l);
+        const float inv = 1.0f / den;
+        wgt[r * 64 + lane] = w * inv;
+    }
+    __syncthreads();
+    for (int s0 = 0;;) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            if (s0 + u < splits) {                                             // workgroup-uniform
+#pragma unroll
+                for (int j = 0; j < NE; j++) macc[j] += wgt[wr[j] + s0 + u] * x[j][u];
+            }
+        }
+        s0 += UB;
+        if (s0 >= splits) break;
+        request(s0);
+    }
+    __syncthreads();                                   // (GP == 1: wgt aliases S, merged aliases accs - nothing below reads wgt)
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        const int e = tid + NT * j;
+        if (e < RM * D) { merged[e] = macc[j]; a.out[(size_t)hb * D + e] = macc[j]; }
+    }
+    __syncthreads();
+    constexpr int NBLK = (RM * D) >> 8;                // 256-blocks this ticket group owns in the H * D row
+    for (int b = wave; b < NBLK; b += AO_NW) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(merged + b * 256 + lane * 4);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int gb = ((hb * D) >> 8) + b;            // global block index
+        const int e0 = gb * 256 + lane * 4;
+        uint32_t packed; int bs; float dq8;
+        wave_quant_q8k(vv, lane, packed, bs, dq8);
+        cst4<true>(fz.q.qs + e0, packed);
+        if ((lane & 3) == 0) cst2<true>(fz.q.bsums + gb * 16 + (lane >> 2), (unsigned short)(int16_t)bs);
+        if (lane == 0) cstf<true>(fz.q.d + gb, dq8);
+    }
+    // publish: every storing wave drains its write-through stores, then ONE lane raises the group's flag to the step's serial
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(o.flags + gq, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 3] = wall_clock64();
+    dma();
+}
+
+// ---- the mat-vec part: wave w decodes the row pairs w, w + 8, .. of the workgroup's rows out of LDS (consumer_op's arithmetic: passes in order, each
+// row's lane partials summed by wave_sum, residual + value)
+template <int TYPE>
+__device__ __forceinline__ void ao_decode(const AOArgs &o, const uint8_t *slice, const ActL &AL, int b0, int nrw, int wave, int lane, float rs0, float rs1) {
+    using Rw = Raw<TYPE>;
+    const LaneRole L = make_role<TYPE>(lane);
+    const int nb = o.K >> 8, KB = (o.K + 2047) >> 11;
+    const unsigned rb = o.row_bytes;
+    const int n_steps = (nrw + 1) >> 1;
+    for (int s = wave; s < n_steps; s += AO_NW) {
+        const bool two = 2 * s + 1 < nrw;
+        const unsigned off0 = 2u * (unsigned)s * rb, off1 = two ? off0 + rb : off0;
+        float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 2
+        for (int p = 0; p < KB; p++) {
+            const ActSlice sl = read_slice_t<TYPE>(AL, p * 8 + L.sbl, nb, L);
+            int sb = p * 8 + L.sbl;
+            if (sb >= nb) sb = nb - 1;
+            Rw w0, w1;
+            ring_load<false>(w0, slice, 0u, off0, nb, sb, L);
+            ring_load<false>(w1, slice, 0u, off1, nb, sb, L);
+            acc0 += w0.dot(sl, L);
+            acc1 += w1.dot(sl, L);
+        }
+        const float v0 = wave_sum(acc0), v1 = wave_sum(acc1);
+        if (lane == 0) {
+            const int row0 = b0 + 2 * s;
+            const bool first = s == wave;
+            if (o.epi == EPI_ADD) {
+                o.out[row0] = (first ? rs0 : o.resid[row0]) + v0;
+                if (two) o.out[row0 + 1] = (first ? rs1 : o.resid[row0 + 1]) + v1;
+            } else {
+                o.out[row0] = v0;
+                if (two) o.out[row0 + 1] = v1;
+            }
+        }
+    }
+}
+
+template <int R, int TK, int TV, int C>
+__global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
+    const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>));
+    AOSmem<R, C> &sm = *reinterpret_cast<AOSmem<R, C> *>(smem + lay.attn);
+    const unsigned serial = *o.serial;
+    const int b0r = (int)blockIdx.x * o.rows_per_wg;
+    const int b0 = b0r < o.n_rows ? b0r : o.n_rows;
+    const int nrw = b0 + o.rows_per_wg <= o.n_rows ? o.rows_per_wg : o.n_rows - b0;
+    // residual of this wave's first row pair: requested now, used at the very end
+    float rs0 = 0.0f, rs1 = 0.0f;
+    if (o.epi == EPI_ADD && 2 * wave < nrw) {
+        rs0 = o.resid[b0 + 2 * wave];
+        if (2 * wave + 1 < nrw) rs1 = o.resid[b0 + 2 * wave + 1];
+    }
+    bool dma_done = false;
+    auto dma = [&]() { if (!dma_done) { ao_issue_dma(o, smem, b0, nrw, wave, lane); dma_done = true; } };
+    const int G = a.G;
+    bool had_item = false;
+    for (int it = (int)blockIdx.x; it < o.n_items; it += (int)gridDim.x) {
+        if (had_item) __syncthreads();                 // (the item's LDS is reused)
+        ao_attn_item<R, TK, TV, C>(a, cs_table, n_rot, fz, o, serial, it % G, it / G, sm, dma);
+        had_item = true;
+    }
+    dma();                                             // workgroups without an item: at once
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
+
+    // ---- the merged, quantised attention output: wait for every ticket group's flag, then fetch the planes device-coherently
+    if (wave == 0) {
+        int spins = 0;
+        for (;;) {
+            unsigned v = serial;
+            if (lane < o.n_flags) v = __hip_atomic_load(o.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v == serial)) break;
+            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+    {
+        const int K = o.K, nb = K >> 8;
+        if (tid * 16 < K) {
+            const coh_u32x4 v = cld16<true>(fz.q.qs, tid * 16);
+            *reinterpret_cast<coh_u32x4 *>(smem + lay.qs + tid * 16) = v;
+        }
+        if (tid * 16 < (K >> 3)) {
+            const coh_u32x4 v = cld16<true>(fz.q.bsums, tid * 16);
+            *reinterpret_cast<coh_u32x4 *>(smem + lay.bs + tid * 16) = v;
+        }
+        if (tid < nb) reinterpret_cast<unsigned *>(smem + lay.d)[tid] = cld4<true>(fz.q.d, tid * 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes above and this wave's share of the W_o rows (DMA) have landed
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
+    if (nrw > 0) {
+        const ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
+        switch (o.type) {
+            case T_Q4_K: ao_decode<T_Q4_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q5_K: ao_decode<T_Q5_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q6_K: ao_decode<T_Q6_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            default: break;
+        }
+    }
+    if (o.probe) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) o.probe[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
+    }
+}
+
+int g_attn_out_fused = -1;                  // -1: environment / default (on)
+unsigned long long *g_ao_probe = nullptr;
+int g_ao_probe_wgs = 0, g_ao_probe_items = 0;
+
+}  // namespace
+
+void set_attn_out_fused(int on) { g_attn_out_fused = on < 0 ? -1 : on ? 1 : 0; }
+bool attn_out_fused_enabled() {
+    static const bool env_off = getenv("MI355_ATTN_OUT_FUSED") && getenv("MI355_ATTN_OUT_FUSED")[0] == '0';
+    return g_attn_out_fused < 0 ? !env_off : g_attn_out_fused > 0;
+}
+void attn_out_set_error_word(unsigned *w) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_err_word), &w, sizeof(w)); }
+
+// chunk size the launch will use for a scan of n_kv_max cells: 64 cells while that gives every CU at most one item, 128 beyond
+int attn_out_fused_chunk(const AttnArgs &a) {
+    const int s64 = (a.n_kv_max + 63) / 64;
+    if (a.tok_chunks) return 64;                      // (the per-token chunk lists count 64-cell chunks)
+    return s64 * a.G <= num_cu() && s64 <= 64 ? 64 : 128;
+}
+int attn_out_fused_splits(const AttnArgs &a) {
+    const int C = attn_out_fused_chunk(a);
+    return a.n_kv_max > 0 ? (a.n_kv_max + C - 1) / C : 1;
+}
+
+// a.splits as attn_out_fused_splits(a) says (with chunk lists: what launch_flash_attn_decode_fused takes)
+bool attn_out_fused_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi) {
+    if (!attn_out_fused_enabled()) return false;
+    if (a.T != 1 || a.D != AO_D || ra.neox || (ra.n_rot % 4) != 0 || ra.n_rot > a.D) return false;
+    const int R = a.G > 0 ? a.H / a.G : 0;
+    if (R * a.G != a.H || !(R == 1 || R == 2 || R == 4 || R == 8)) return false;
+    const bool q8 = a.type_k == T_Q8_0 && a.type_v == T_Q8_0, f16 = a.type_k == T_F16 && a.type_v == T_F16;
+    if (!q8 && !f16) return false;
+    const int gp = (R * a.D) % 256 == 0 ? 1 : 2;
+    if (a.G % gp != 0 || a.G / gp > 64) return false;
+    if (!a.out_q || !a.out_q8k || a.out_q80) return false;
+    if (wo.type != T_Q4_K && wo.type != T_Q5_K && wo.type != T_Q6_K) return false;
+    if (K != a.H * a.D || (K % 256) != 0 || K > 8192 || wo.expert_sel) return false;
+    if ((wo.row_bytes % 16) != 0 || (reinterpret_cast<uintptr_t>(wo.W) & 15) != 0) return false;
+    if (epi != EPI_ADD && epi != EPI_STORE) return false;
+    const int C = attn_out_fused_chunk(a);
+    if (a.tok_chunks && C != 64) return false;
+    if (a.splits < 1 || a.splits > 64 || (size_t)a.splits * C < (size_t)a.n_kv_max) return false;
+    const int nwg = std::min(num_cu(), (wo.n_rows + 1) / 2);
+    if (nwg < 1) return false;
+    const int rpw = (wo.n_rows + nwg - 1) / nwg;
+    if ((size_t)rpw * wo.row_bytes > 96 * 1024) return false;                  // the workgroup's rows stay in LDS whole
+    return true;
+}
+
+void attn_out_probe_report() {
+    if (!g_ao_probe || g_ao_probe_wgs <= 0) return;
+    std::vector<unsigned long long> t((size_t)g_ao_probe_wgs * 8);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(t.data(), g_ao_probe, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < g_ao_probe_wgs; w++) if (t[(size_t)w * 8]) t0 = std::min(t0, t[(size_t)w * 8]);
+    auto stat = [&](int k, const char *name) {
+        double lo = 1e30, hi = 0, sum = 0; int n = 0;
+        for (int w = 0; w < g_ao_probe_wgs; w++) {
+            const unsigned long long v = t[(size_t)w * 8 + k];
+            if (!v) continue;
+            const double us = (double)(v - t0) * 0.01;
+            lo = std::min(lo, us); hi = std::max(hi, us); sum += us; n++;
+        }
+        if (n) fprintf(stderr, "  %-28s n=%3d  min %.2f  mean %.2f  max %.2f us\n", name, n, lo, sum / n, hi);
+    };
+    fprintf(stderr, "attn_out probe: %d workgroups, %d attention items (us since the first workgroup entered)\n", g_ao_probe_wgs, g_ao_probe_items);
+    stat(0, "entered"); stat(1, "items done / dma issued"); stat(2, "merge: ticket won"); stat(3, "merge: flag raised");
+    stat(4, "all flags seen"); stat(5, "codes + rows in LDS"); stat(6, "outputs stored");
+}
+
+hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
+                                 unsigned *counters, unsigned *flags, const unsigned *serial, const MMVQSeg &wo, int K, int epi, hipStream_t st) {
+    if (!counters || !flags || !serial || !knew || !vnew || !tok_cell) return hipErrorInvalidValue;
+    const int R = a.H / a.G;
+    const int C = attn_out_fused_chunk(a);
+    AOArgs o{};
+    o.W = wo.W; o.out = wo.out; o.resid = wo.resid; o.type = wo.type; o.n_rows = wo.n_rows; o.K = K; o.epi = epi;
+    o.row_bytes = (unsigned)wo.row_bytes;
+    const int nwg0 = std::min(num_cu(), (wo.n_rows + 1) / 2);
+    o.rows_per_wg = (wo.n_rows + nwg0 - 1) / nwg0;
+    const int nwg = (wo.n_rows + o.rows_per_wg - 1) / o.rows_per_wg;
+    o.slice_lds = (unsigned)((((size_t)o.rows_per_wg * wo.row_bytes) + ST_SLOT - 1) / ST_SLOT * ST_SLOT);
+    o.flags = flags; o.serial = serial;
+    const int gp = (R * a.D) % 256 == 0 ? 1 : 2;
+    o.n_flags = a.G / gp;
+    o.n_items = a.G * a.splits;
+    static const bool probe_on = getenv("MI355_AO_PROBE") && getenv("MI355_AO_PROBE")[0] == '1';
+    if (probe_on) {
+        if (!g_ao_probe && hipMalloc((void **)&g_ao_probe, 1024 * 8 * 8) != hipSuccess) g_ao_probe = nullptr;
+        if (g_ao_probe) { (void)hipMemsetAsync(g_ao_probe, 0, 1024 * 8 * 8, st); g_ao_probe_wgs = std::min(nwg, 1024); g_ao_probe_items = o.n_items; }
+        o.probe = g_ao_probe;
+    }
+    DecodeFuse fz{};
+    fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters; fz.neox = 0;
+    fz.q = *a.out_q; fz.want_q8k = 1; fz.want_q80 = 0;
+#define AO_LAUNCH(RR, TK, TV, CC)                                                                                                              \
+    do {                                                                                                                                       \
+        const size_t lds = ao_layout(o.slice_lds, K, sizeof(AOSmem<RR, CC>)).total;                                                            \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_out_kernel<RR, TK, TV, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                                         \
+        hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);                  \
+    } while (0)
+#define AO_C(RR, TK, TV) do { if (C == 64) AO_LAUNCH(RR, TK, TV, 64); else AO_LAUNCH(RR, TK, TV, 128); } while (0)
+#define AO_T(RR) do { if (a.type_k == T_F16) AO_C(RR, T_F16, T_F16); else AO_C(RR, T_Q8_0, T_Q8_0); } while (0)
+    switch (R) {
+        case 1: AO_T(1); break;
+        case 2: AO_T(2); break;
+        case 4: AO_T(4); break;
+        case 8: AO_T(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef AO_T
+#undef AO_C
+#undef AO_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -588,6 +588,124 @@ int mi355_op_flash_attn(const float *q, int64_t T, int32_t H, int32_t G, int32_t
     return dout.down(out, (size_t)T * H * D * 4) ? MI355_OK : MI355_ERR_HIP;
 }
 
+// The attention block of ONE single-token step exactly as the decode path launches it (test entry): rope of q
+// and of the token's K row, the K / V row quantised into the cache, attention over the visible cells, merge of the chunk partials, Q8_K quantisation and the
+// attn_output mat-vec with its residual.  fused = 1: attn_out.hip (one launch); 0: the single-launch decode attention + the weight-stream mat-vec.
+// k / v: the cache BEFORE the step as ggml-layout rows [n_cells][G * D] (the row at tok_cell is overwritten); cell_pos[tok_cell] must already be tok_pos.
+int mi355_op_attn_step(const float *q, const float *k_new, const float *v_new, int32_t H, int32_t G, int32_t D, int32_t type_k, const void *k, int32_t type_v,
+                       const void *v, int32_t n_cells, const int32_t *cell_pos, int32_t tok_pos, int32_t tok_cell, float rope_base, int32_t n_rot, float scale,
+                       int32_t type_o, const void *W_o, int64_t E, const float *resid, int32_t fused, float *att_out, float *out, void *k_row_out, void *v_row_out) {
+    if (!need_device()) return MI355_ERR_NO_DEVICE;
+    if ((D != 64 && D != 128) || G < 1 || H % G || n_cells < 1 || tok_cell < 0 || tok_cell >= n_cells) { fail("bad geometry"); return MI355_ERR_ARG; }
+    const int64_t K = (int64_t)H * D;
+    const size_t kv_dim = (size_t)G * D;
+    auto fill = [&](int type, const void *rows, std::vector<uint8_t> &codes, std::vector<uint16_t> &scales) {
+        const uint8_t *src = (const uint8_t *)rows;
+        const size_t rb = ggml_row_bytes(type, (int64_t)kv_dim);
+        if (type == T_F16) {
+            codes.resize((size_t)G * n_cells * D * 2);
+            for (int c = 0; c < n_cells; c++)
+                for (int g = 0; g < G; g++) memcpy(&codes[(((size_t)g * n_cells + c) * D) * 2], src + (size_t)c * rb + (size_t)g * D * 2, (size_t)D * 2);
+        } else {
+            const int bb = type == T_Q8_0 ? 34 : 18, cb = type == T_Q8_0 ? 32 : 16;
+            codes.resize((size_t)G * n_cells * (D / 32) * cb);
+            scales.resize((size_t)G * n_cells * (D / 32));
+            for (int c = 0; c < n_cells; c++)
+                for (int g = 0; g < G; g++)
+                    for (int b = 0; b < D / 32; b++) {
+                        const uint8_t *blk = src + (size_t)c * rb + ((size_t)g * (D / 32) + b) * bb;
+                        memcpy(&scales[((size_t)g * n_cells + c) * (D / 32) + b], blk, 2);
+                        memcpy(&codes[(((size_t)g * n_cells + c) * (D / 32) + b) * cb], blk + 2, (size_t)cb);
+                    }
+        }
+    };
+    if ((type_k != T_F16 && type_k != T_Q8_0 && type_k != T_Q4_0) || (type_v != T_F16 && type_v != T_Q8_0 && type_v != T_Q4_0)) { fail("bad cache type"); return MI355_ERR_ARG; }
+    std::vector<uint8_t> kc, vc;
+    std::vector<uint16_t> ks, vs;
+    fill(type_k, k, kc, ks);
+    fill(type_v, v, vc, vs);
+    const size_t grow = ggml_row_bytes(type_o, K), drow = dev_row_bytes(type_o, K);
+    if (!grow || K % 256) { fail("bad attn_output type / K"); return MI355_ERR_ARG; }
+    DevBuf dk(kc.size()), dks(ks.size() * 2 + 16), dv(vc.size()), dvs(vs.size() * 2 + 16);
+    DevBuf dq((size_t)K * 4), dkn(kv_dim * 4), dvn(kv_dim * 4), datt((size_t)K * 4), dcp((size_t)n_cells * 4), dcs((size_t)n_cells * 8), dtp(16), dts(16), dn(16), dcell(16);
+    DevBuf wsrc(grow * E), wdev(drow * E), dres((size_t)E * 4), dout((size_t)E * 4), dcnt(256 * 4), dflags(64 * 4), dserial(64), dcsb((size_t)std::max(n_rot, 4) * 4 + 64);
+    ActBufs ab((size_t)K, 1);
+    if (!dk.up(kc.data(), kc.size()) || !dv.up(vc.data(), vc.size()) || !dq.up(q, (size_t)K * 4) || !dkn.up(k_new, kv_dim * 4) || !dvn.up(v_new, kv_dim * 4) ||
+        !wsrc.up(W_o, grow * E) || !wdev.p || !dres.up(resid, (size_t)E * 4) || !dout.p || !ab.ok() || !datt.p) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }
+    if (!ks.empty()) dks.up(ks.data(), ks.size() * 2);
+    if (!vs.empty()) dvs.up(vs.data(), vs.size() * 2);
+    std::vector<uint64_t> seqm((size_t)n_cells, 1ull);
+    const int32_t tseq = 0, nkv = n_cells;
+    const unsigned one = 1u;
+    dcp.up(cell_pos, (size_t)n_cells * 4); dcs.up(seqm.data(), (size_t)n_cells * 8); dtp.up(&tok_pos, 4); dts.up(&tseq, 4); dn.up(&nkv, 4); dcell.up(&tok_cell, 4);
+    dserial.up(&one, 4);
+    hipError_t e = launch_repack_rows(type_o, wsrc.as<uint8_t>(), wdev.as<uint8_t>(), K, E, nullptr);
+    if (e != hipSuccess) return hip_fail(e, "repack");
+    RopeArgs ra{};
+    ra.n_rot = n_rot; ra.freq_base = rope_base; ra.freq_scale = 1.0f; ra.freq_factors = nullptr; ra.neox = 0;
+    e = launch_rope_table(dtp.as<int32_t>(), 1, ra, dcsb.as<float>(), nullptr);
+    if (e != hipSuccess) return hip_fail(e, "rope_table");
+    AttnArgs a{};
+    a.q = dq.as<float>(); a.out = datt.as<float>();
+    a.kv.k = dk.as<uint8_t>(); a.kv.kd = dks.as<uint16_t>(); a.kv.v = dv.as<uint8_t>(); a.kv.vd = dvs.as<uint16_t>();
+    a.type_k = type_k; a.type_v = type_v; a.T = 1; a.H = H; a.G = G; a.D = D; a.n_ctx = n_cells;
+    a.cell_pos = dcp.as<int32_t>(); a.cell_seq = dcs.as<uint64_t>(); a.tok_pos = dtp.as<int32_t>(); a.tok_seq = dts.as<int32_t>();
+    a.n_kv_dev = dn.as<int32_t>(); a.n_kv_max = n_cells; a.scale = scale;
+    a.out_q = &ab.q; a.out_q8k = true; a.out_q80 = false;
+    MMVQSeg so{};
+    so.W = wdev.as<uint8_t>(); so.out = dout.as<float>(); so.resid = dres.as<float>(); so.type = type_o; so.n_rows = (int)E; so.ld_out = (int)E; so.row_bytes = drow;
+    if (fused) {
+        a.splits = attn_out_fused_splits(a);
+        DevBuf part(flash_attn_workspace_floats(1, H, D, a.splits) * 4);
+        a.part = part.as<float>();
+        if (!attn_out_fused_applicable(a, ra, so, (int)K, EPI_ADD)) { fail("attn_out.hip has no form for this shape"); return MI355_ERR_ARG; }
+        e = launch_attn_out_fused(a, dcsb.as<float>(), ra, dkn.as<float>(), dvn.as<float>(), dcell.as<int32_t>(), dcnt.as<unsigned>(), dflags.as<unsigned>(),
+                                  dserial.as<unsigned>(), so, (int)K, EPI_ADD, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return hip_fail(e, "attn_out_fused");
+    } else {
+        a.splits = flash_attn_decode_splits(n_cells);
+        DevBuf part(flash_attn_workspace_floats(1, H, D, a.splits) * 4);
+        a.part = part.as<float>();
+        if (!flash_attn_decode_fused_applicable(a, ra)) { fail("the single-launch decode attention has no form for this shape"); return MI355_ERR_ARG; }
+        e = launch_flash_attn_decode_fused(a, dcsb.as<float>(), ra, dkn.as<float>(), dvn.as<float>(), dcell.as<int32_t>(), dcnt.as<unsigned>(), nullptr);
+        if (e != hipSuccess) return hip_fail(e, "flash_attn_decode_fused");
+        MMVQArgs m{};
+        m.n_seg = 1; m.K = (int)K; m.T = 1; m.epi = EPI_ADD; m.seg[0] = so;
+        m.aq = ab.q.qs; m.ad = ab.q.d; m.abs = ab.q.bsums; m.aq0 = ab.q.qs0; m.ad0 = ab.q.d0;
+        e = launch_mmvq(m, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return hip_fail(e, "attn_output mat-vec");
+    }
+    if (att_out && !datt.down(att_out, (size_t)K * 4)) return MI355_ERR_HIP;
+    if (out && !dout.down(out, (size_t)E * 4)) return MI355_ERR_HIP;
+    // the cache row the step wrote, back in ggml block layout
+    auto row_back = [&](int type, DevBuf &codes, DevBuf &scales, void *dst) -> bool {
+        if (!dst) return true;
+        uint8_t *o8 = (uint8_t *)dst;
+        for (int g = 0; g < G; g++) {
+            const size_t rowi = (size_t)g * n_cells + tok_cell;
+            if (type == T_F16) {
+                if (hipMemcpy(o8 + (size_t)g * D * 2, (uint8_t *)codes.p + rowi * D * 2, (size_t)D * 2, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            } else {
+                const int bb = type == T_Q8_0 ? 34 : 18, cb = type == T_Q8_0 ? 32 : 16;
+                std::vector<uint8_t> c((size_t)(D / 32) * cb);
+                std::vector<uint16_t> sc((size_t)D / 32);
+                if (hipMemcpy(c.data(), (uint8_t *)codes.p + rowi * (D / 32) * cb, c.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
+                if (hipMemcpy(sc.data(), (uint8_t *)scales.p + rowi * (D / 32) * 2, sc.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return false;
+                for (int b = 0; b < D / 32; b++) {
+                    uint8_t *blk = o8 + ((size_t)g * (D / 32) + b) * bb;
+                    memcpy(blk, &sc[(size_t)b], 2);
+                    memcpy(blk + 2, &c[(size_t)b * cb], (size_t)cb);
+                }
+            }
+        }
+        return true;
+    };
+    if (!row_back(type_k, dk, dks, k_row_out) || !row_back(type_v, dv, dvs, v_row_out)) return MI355_ERR_HIP;
+    return MI355_OK;
+}
+
 int mi355_debug_set_option(const char *name, int32_t value) {
     if (!name) return MI355_ERR_ARG;
     if (!strcmp(name, "mmq_planes")) { g_op_mmq_planes = value != 0; return MI355_OK; }
@@ -601,6 +719,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "decode_engine")) { set_decode_engine(value); return MI355_OK; }
     if (!strcmp(name, "tp_p2p")) { tp_p2p_use(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
+    if (!strcmp(name, "attn_out_fused")) { set_attn_out_fused(value); return MI355_OK; }     // (contexts created afterwards)
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
     if (!strcmp(name, "tp_null_group")) { tp_set_null_group(0, value); return MI355_OK; }
     fail(std::string("unknown option ") + name);

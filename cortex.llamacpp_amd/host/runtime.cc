@@ -427,6 +427,7 @@ Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
 Context::~Context() {
     attn_probe_report();
+    attn_out_probe_report();
     if (d_engine_probe_) {                                     // diagnosis: time line of the probed layer's last engine launch
         const int ncu = num_cu(), NW = 10, NS = 48;
         std::vector<unsigned long long> t((size_t)ncu * NW * NS);
@@ -548,7 +549,7 @@ bool Context::init(std::string &err) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, model->device) == hipSuccess) set_num_cu(prop.multiProcessorCount);
     err_epoch_seen_ = stream_error_epoch();
-    if (unsigned *ew = stream_error_word()) { mmvq_stream_set_error_word(ew); decode_engine_set_error_word(ew); tp_p2p_set_error_word(ew); }   // (per device: the pointer lives in device globals)
+    if (unsigned *ew = stream_error_word()) { mmvq_stream_set_error_word(ew); decode_engine_set_error_word(ew); attn_out_set_error_word(ew); tp_p2p_set_error_word(ew); }   // (per device: the pointer lives in device globals)
 
     const size_t T = cp.n_ubatch, E = hp.n_embd, FF = hp.n_ff, G = hp.n_head_kv, D = hp.head_dim, NC = cp.n_ctx;
     cells_.assign(NC, KVCell());
@@ -651,6 +652,9 @@ bool Context::init(std::string &err) {
     att_counters_ = (unsigned *)dalloc(256 * sizeof(unsigned));
     if (!att_part_ || !att_counters_) { err = "attention workspace allocation failed"; return false; }
     if (hipMemset(att_counters_, 0, 256 * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
+    d_step_serial_ = (unsigned *)dalloc(64);
+    d_ao_flags_ = (unsigned *)dalloc((size_t)std::max(1, hp.n_layer) * 64 * sizeof(unsigned));
+    if (!d_step_serial_ || !d_ao_flags_) { err = "step serial / flag allocation failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
     argmax_scratch_ = (float *)dalloc(T * 129 * 4);     // T ticket words at the head, then per row 64 part values and 64 part indices (zero-filled: dalloc)
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
@@ -1152,10 +1156,10 @@ bool Context::engine_prepare() {
     d_engine_layers_ = (EngineLayer *)dalloc(el.size() * sizeof(EngineLayer));
     const size_t gw = decode_engine_granule_words(E, FF);
     d_engine_gran_ = (unsigned long long *)dalloc(gw * 8);
-    d_engine_epoch_ = (unsigned *)dalloc(64);
+    d_engine_epoch_ = d_step_serial_;     // the step serial every set-up launch increments
     if (!d_engine_layers_ || !d_engine_gran_ || !d_engine_epoch_) return false;
     if (hipMemcpy(d_engine_layers_, el.data(), el.size() * sizeof(EngineLayer), hipMemcpyHostToDevice) != hipSuccess) return false;
-    if (hipMemset(d_engine_gran_, 0, gw * 8) != hipSuccess || hipMemset(d_engine_epoch_, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+    if (hipMemset(d_engine_gran_, 0, gw * 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
     if (const char *pl = getenv("MI355_ENGINE_PROBE")) {
         engine_probe_layer_ = atoi(pl);
         const size_t np = (size_t)num_cu() * 10 * 48;
@@ -1268,7 +1272,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
     last_layers_engine_ = engine;
     // cos / sin table, cell metadata and the tokens' embedding rows: one launch
     HIP_TRY(launch_step_setup_embed(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr,
-                                    engine ? d_engine_epoch_ : nullptr, model->tok_embd.type, model->tok_embd.data, E, d_tok_, x_, stream_));
+                                    d_step_serial_, model->tok_embd.type, model->tok_embd.data, E, d_tok_, x_, stream_));
     prof_mark("embed");
     last_layers_mega_ = mega;
     if (mega)
@@ -1315,7 +1319,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         // (the single-launch step and the store-fused batched step write the new K / V rows themselves; only the third branch needs the fast store kernel)
         const bool fast_store = kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra);
         static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
-        bool fused_step = false;
+        bool fused_step = false, attn_out_done = false;
         const bool decode_attn = flash_attn_decode_applicable(aa, ra);
         if (decode_attn) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
@@ -1327,8 +1331,22 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         }
         if (decode_attn && (fast_store || fused_step || (batch_distinct_ && store_fuse_enabled()))) {
             if (fused_step) {
-                // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch
-                HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));
+                // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch - and, where attn_out.hip has a form for the shape,
+                // the attn_output mat-vec with its residual add in that launch too
+                if (attn_mode == 2 && !engine) {
+                    const bool add = !tp || hp.tp_rank == 0;
+                    const MMVQSeg so = make_seg(L.wo, tp ? tp_part_ : x_, E, add ? x_ : nullptr, nullptr);
+                    AttnArgs af = aa;
+                    af.splits = attn_out_fused_splits(af);
+                    if (chunk_lmax_ > 0) af.splits = aa.splits;
+                    if (attn_out_fused_applicable(af, ra, so, (int)L.wo.K, add ? EPI_ADD : EPI_STORE)) {
+                        HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64, d_step_serial_, so, (int)L.wo.K,
+                                                      add ? EPI_ADD : EPI_STORE, stream_));
+                        attn_out_done = true;
+                    }
+                }
+                if (!attn_out_done)
+                    HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));
             } else if (batch_distinct_ && store_fuse_enabled()) {
                 // batched step, every token of a different sequence: K rope + KV store inside the attention launch (no token reads another's new cell)
                 HIP_TRY(launch_flash_attn_decode(aa, rope_cs_, ra, stream_, k_, v_, d_cell_));
@@ -1360,7 +1378,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             HIP_TRY(launch_decode_engine(d_engine_layers_ + il, E, FF, d_engine_gran_, d_engine_epoch_, il, il == engine_probe_layer_ ? d_engine_probe_ : nullptr, stream_));
             continue;
         }
-        if (tp) {   // this rank's partial sum (rank 0 carries the residual), then the exchange: x = sum over ranks
+        if (attn_out_done) {   // the mat-vec ran inside the attention launch (attn_out.hip)
+            if (tp) HIP_TRY(tp_reduce_into_x(T));
+        } else if (tp) {   // this rank's partial sum (rank 0 carries the residual), then the exchange: x = sum over ranks
             HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, T, tp_part_, E, hp.tp_rank == 0 ? x_ : nullptr, hp.tp_rank == 0 ? EPI_ADD : EPI_STORE));
             HIP_TRY(tp_reduce_into_x(T));
         } else {

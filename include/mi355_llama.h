@@ -209,6 +209,17 @@ MI355_API int mi355_op_flash_attn(const float *q, int64_t T, int32_t n_head, int
                                   int32_t type_k, const void *k, int32_t type_v, const void *v, int32_t n_cells,
                                   const int32_t *cell_pos, const int32_t *q_pos, float scale, float *out);
 
+/* The attention block of ONE single-token step as the decode path launches it (rope of q and of the token's K row, the K / V row quantised into the cache,
+ * flash_attn_ext over the visible cells, Q8_K quantisation, the attn_output mat-vec + residual: the ops between two llama_decode graph nodes of
+ * llm_build_llama that attn_out.hip runs as one launch; reached through llama_decode, src/llama_server_context.cc:1635).  fused = 1: the one-launch form,
+ * 0: the single-launch decode attention followed by the weight-stream mat-vec.  k / v: the cache before the step as ggml-layout rows [n_cells][n_head_kv *
+ * head_dim]; cell_pos[tok_cell] must already hold tok_pos.  att_out [n_head * head_dim], out [n_embd], k_row_out / v_row_out: the cache row the step wrote,
+ * in ggml block layout (any of the four may be NULL). */
+MI355_API int mi355_op_attn_step(const float *q, const float *k_new, const float *v_new, int32_t n_head, int32_t n_head_kv, int32_t head_dim, int32_t type_k,
+                                 const void *k, int32_t type_v, const void *v, int32_t n_cells, const int32_t *cell_pos, int32_t tok_pos, int32_t tok_cell,
+                                 float rope_base, int32_t n_rot, float scale, int32_t type_o, const void *W_o, int64_t n_embd, const float *resid, int32_t fused,
+                                 float *att_out, float *out, void *k_row_out, void *v_row_out);
+
 /* ------------------------------------------------------------------ tokenizer
  * llama_tokenize / llama_token_to_piece as reached through common_tokenize / common_token_to_piece
  * (src/llama_server_context.cc:395-410, 536, 644, 720, 936, 992) and llama_vocab_bos/eos/is_eog (:512-517, 792).

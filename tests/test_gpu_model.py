@@ -947,3 +947,67 @@ def test_device_argmax_follows_a_changing_number_of_flagged_rows(be, pkg, tmp_mo
         for s in live:
             lens[s] += 1
     c.close(); m.close()
+
+
+@pytest.mark.parametrize("cfg,ftype,kv", [("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-d128-mha", "q5_k_m", "q8_0"),
+                                          ("tiny-d128", "q6_k", "q8_0"), ("tiny-d128", "q4_k_m", "f16")])
+def test_attn_out_one_launch_agrees_with_the_two_launches(be, pkg, tmp_models, cfg, ftype, kv):
+    """Single-token steps with the decode attention and the attn_output mat-vec in ONE launch (attn_out.hip, the default) against the same steps as two
+    launches: the attention items run on 512 threads there (16 cell groups in the P.V pass instead of 8), so the comparison is f32 re-association, not
+    bits - until a 1-ulp difference flips an int8 code, which moves a logit by up to ~1e-2 (FLIP_TOL); the median step must agree to round-off."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    rows = {}
+    for fused in (1, 0):
+        be.set_option("attn_out_fused", fused)
+        try:
+            m = pkg.Model(path)
+            c = pkg.Context(m, n_ctx=512, type_k=KV[kv], type_v=KV[kv])
+            rng = np.random.default_rng(3)
+            prompt = rng.integers(0, m.n_vocab, 150)
+            c.decode(prompt, np.arange(150))
+            toks = rng.integers(0, m.n_vocab, 40)
+            out = []
+            for s, t in enumerate(toks):
+                c.decode([int(t)], [150 + s])
+                out.append(c.logits())
+            rows[fused] = np.stack(out)
+            c.close(); m.close()
+        finally:
+            be.set_option("attn_out_fused", -1)
+    errs = np.array([rel_err(a, b) for a, b in zip(rows[1], rows[0])])
+    assert float(errs.max()) <= FLIP_TOL, errs
+    assert float(np.median(errs)) <= 1e-4, errs
+
+
+@pytest.mark.parametrize("cfg,ftype,kv,n_prompt", [("tiny-8b-2l", "q4_k_m", "q8_0", 3968), ("tiny-d128", "q4_k_m", "f16", 3968), ("tiny-d128", "q4_k_m", "q4_0", 3000)])
+def test_context_filled_to_4096_matches_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt):
+    """BASELINE config 3's ctx_len = 4096 (src/llama_engine.cc:612) with the context filled: a 3968-token prompt in two micro-batches of 2048 (the second
+    one's queries attend to 2048 earlier cells through the key splits of the prompt attention), then 8 single-token steps at positions 3968 .. 3975 whose
+    attention scans ~4000 cells (128-cell items in the one-launch form; 63 chunks merged in two request rounds in the two-launch form) - logits of the
+    prompt's last token and of every step against the CPU restatement.  Two layers of Llama-3-8B's geometry keep the CPU side affordable."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
+    try:
+        m = pkg.Model(path)
+        c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=KV[kv], type_v=KV[kv])
+        om = oq.OracleModel(path)
+        oc = oq.OracleContext(om, 4096, KV[kv], KV[kv], True, min(32, os.cpu_count() or 8))
+        prompt = np.random.default_rng(41).integers(0, m.n_vocab, n_prompt)
+        assert c.decode(prompt, np.arange(n_prompt)) == 0
+        ref = oc.decode(prompt, np.arange(n_prompt))[0]
+        errs = [rel_err(c.logits(), ref)]
+        tok = int(ref.argmax())
+        for s in range(8):
+            assert c.decode([tok], [n_prompt + s]) == 0
+            r = oc.decode([tok], [n_prompt + s])[0]
+            g = c.logits()
+            errs.append(rel_err(g, r))
+            assert int(g.argmax()) == c.argmax()
+            top2 = np.sort(r)[-2:]
+            if top2[1] - top2[0] > 2 * FLIP_TOL * max(1.0, float(np.abs(r).max())):
+                assert c.argmax() == int(r.argmax()), s
+            tok = int(r.argmax())
+        assert max(errs) <= FLIP_TOL, errs
+        c.close(); m.close(); oc.close(); om.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)

@@ -396,3 +396,65 @@ def test_flash_attn_prefill_matrix_cores(be, H, G, n_cells, T, tkv, tol):
             cells = np.nonzero((cell_pos >= 0) & (cell_pos <= q_pos[i]))[0].astype(np.int32)
             ref = oq.flash_attn(q[i], H, G, D, tkv, kc, tkv, vc, cells, scale)
             assert np.abs(out[i] - ref).max() <= 2e-2 * max(1.0, float(np.abs(ref).max())), (i, np.abs(out[i] - ref).max())
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("tkv", [Q8_0, F16])
+@pytest.mark.parametrize("H,G,n_cells,t_o", [(32, 8, 4000, Q4_K),     # BASELINE config 3's geometry with the context filled (ctx_len 4096): 128-cell items, 32 per kv head
+                                             (32, 8, 2048, Q4_K),     # the last length that still takes 64-cell items (32 x 8 = 256 = one per CU)
+                                             (32, 8, 1500, Q6_K), (32, 8, 561, Q5_K),
+                                             (8, 2, 70, Q5_K), (4, 4, 300, Q4_K),             # one query head per kv head: two kv heads per merge ticket
+                                             (16, 2, 2100, Q4_K), (8, 4, 130, Q6_K)])        # 8 and 2 query heads per kv head
+def test_attn_step_decode_block(be, fused, tkv, H, G, n_cells, t_o):
+    """The attention block of a single-token step as the decode path launches it - rope of q and of the token's K row, the K / V row quantised into the cache,
+    flash_attn_ext over the visible cells (holes, cells of later positions), the merge of the chunk partials, Q8_K quantisation, attn_output mat-vec + residual -
+    against the oracle's ops chained the same way; fused = 1 is attn_out.hip (one launch), 0 the single-launch attention + the weight-stream mat-vec.
+    Up to 4000 cells: the length BASELINE's ctx_len = 4096 decodes at."""
+    D, base = 128, 500000.0
+    E = K = H * D
+    rng = np.random.default_rng(H * 1000 + n_cells + t_o)
+    kf = rng.standard_normal((n_cells, G * D)).astype(np.float32)
+    vf = (rng.standard_normal((n_cells, G * D)) * rng.uniform(0.2, 3.0, (n_cells, 1))).astype(np.float32)
+    kc = np.stack([oq.quantize(tkv, r) for r in kf])
+    vc = np.stack([oq.quantize(tkv, r) for r in vf])
+    tok_pos = n_cells + 7
+    cell_pos = rng.permutation(n_cells).astype(np.int32)           # positions scattered over the cells (a cache after shifts and reuse)
+    cell_pos[rng.random(n_cells) < 0.1] = -1                        # holes
+    cell_pos[rng.random(n_cells) < 0.03] = tok_pos + 5              # cells of later positions: not visible
+    tok_cell = int(n_cells * 0.61)
+    cell_pos[tok_cell] = tok_pos
+    q = rng.standard_normal((H, D)).astype(np.float32)
+    k_new = rng.standard_normal(G * D).astype(np.float32)
+    v_new = (rng.standard_normal(G * D) * 1.7).astype(np.float32)
+    W = rand_weights(rng, t_o, E * K)
+    resid = rng.standard_normal(E).astype(np.float32)
+    scale = 1 / np.sqrt(D)
+    rb = oq.row_bytes(tkv, G * D)
+    att, out, kr, vr = be.attn_step(q, k_new, v_new, H, G, D, tkv, kc, tkv, vc, cell_pos, tok_pos, tok_cell, base, D, scale, t_o, W, E, resid, fused, rb, rb)
+    # the oracle, op by op
+    qr = oq.rope(q, H, D, tok_pos, base)
+    kn = oq.rope(k_new, G, D, tok_pos, base).reshape(-1)
+    k_row = oq.quantize(tkv, kn)
+    v_row = oq.quantize(tkv, v_new)
+    assert (vr == v_row).all()                                      # no arithmetic before the V row's quantisation: bit-exact
+    # the K row goes through the rope first (device cosf / sinf: 4e-6): its codes may sit one step off on a rounding tie
+    dk_ref, dk_got = oq.dequantize(tkv, k_row, G * D), oq.dequantize(tkv, kr, G * D)
+    step = np.abs(kn).reshape(-1, 32).max(axis=1).repeat(32) / 127 if tkv == Q8_0 else np.abs(kn) * 2.0 ** -10
+    assert (np.abs(dk_ref - dk_got) <= 1.01 * step + 1e-7).all()
+    assert (dk_ref == dk_got).mean() >= 0.99
+    kc2, vc2 = kc.copy(), vc.copy()
+    kc2[tok_cell] = kr                                              # (the row the device wrote: what its attention saw)
+    vc2[tok_cell] = v_row
+    cells = np.nonzero((cell_pos >= 0) & (cell_pos <= tok_pos))[0].astype(np.int32)
+    oq.set_fa_v_acc_f32(1 if tkv == F16 else 0)                     # (f16 cache: the CPU accumulates V in fp16, the HIP path in f32 - see test_flash_attn)
+    try:
+        ref_att = oq.flash_attn(qr, H, G, D, tkv, kc2, tkv, vc2, cells, scale).reshape(-1)
+    finally:
+        oq.set_fa_v_acc_f32(0)
+    assert np.abs(att - ref_att).max() <= 2e-5 * max(1.0, float(np.abs(ref_att).max())), float(np.abs(att - ref_att).max())
+    # the mat-vec on the device's own attention output: the Q8_K codes are then the oracle's (bit-exact quantiser), only the f32 order differs
+    ref_out = resid + oq.mul_mat(t_o, W, E, K, att.reshape(1, -1))[0]
+    assert np.abs(out - ref_out).max() <= 2e-5 * max(1.0, float(np.abs(ref_out - resid).max())) + 1e-6, float(np.abs(out - ref_out).max())
+    # ... and end to end against the oracle's own chain: a rounding flip of one activation code moves an output by ~1e-2 of its scale at most
+    ref_e2e = resid + oq.mul_mat(t_o, W, E, K, ref_att.reshape(1, -1))[0]
+    assert np.abs(out - ref_e2e).max() <= 3e-2 * max(1.0, float(np.abs(ref_e2e - resid).max()))
