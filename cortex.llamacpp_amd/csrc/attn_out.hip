@@ -37,6 +37,9 @@ namespace {
 
 constexpr int AO_NT = 512, AO_NW = AO_NT / 64;
 constexpr int AO_D = 128, AO_NB = AO_D / 32, AO_NCG = AO_NT / (AO_D / 4);      // 16 cell groups of 32 lanes in the P.V pass
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int AO_REC = AO_D + 4;                // floats of a chunk's partial record per head: O [D] | m | l | 0 | 0 (whole 16-byte pieces)
 
 struct AOArgs {
     const uint8_t *W; float *out; const float *resid;
@@ -47,7 +50,7 @@ struct AOArgs {
     unsigned *flags;                // this layer's flag words, one per merge ticket group
     const unsigned *serial;         // device word: the step's serial number (never 0)
     int n_flags, n_items;           // ticket groups; attention items = G * splits
-    unsigned long long *probe;      // diagnosis (MI355_AO_PROBE=1): per workgroup 8 wall-clock stamps
+    unsigned long long *probe;      // diagnosis (MI355_AO_PROBE=1): per workgroup 16 wall-clock stamps
 };
 
 template <int R, int C> struct AOSmem {
@@ -99,8 +102,16 @@ __device__ __forceinline__ void ao_issue_dma(const AOArgs &o, uint8_t *smem, int
 
 // ---- one attention item (kv head g, chunk slot sp) on the 512 threads of the workgroup; every exit is workgroup-uniform.  `dma` (the request for the
 // workgroup's W_o rows; it does nothing after its first call) is called by every wave once the item has nothing outstanding and nobody waits for it.
+// the step's scalars every item needs, read in one batch of scalar loads UNDER the item's vector loads
+struct AOScalars { unsigned serial; int tpos, tseq, cellnew; };
+__device__ __forceinline__ AOScalars ao_load_scalars(const unsigned *serial, const int32_t *tpos, const int32_t *tseq, const int32_t *cell) {
+    unsigned s0; int s1, s2, s3;
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(serial), "s"(tpos), "s"(tseq), "s"(cell) : "memory");
+    return AOScalars{s0, s1, s2, s3};
+}
 template <int R, int TK, int TV, int C, class Dma>
-__device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, unsigned serial,
+__device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o,
                                              int g, int sp, AOSmem<R, C> &sm, Dma dma) {
     constexpr int D = AO_D, NB = AO_NB, NT = AO_NT;
     constexpr int KROW = TK == T_F16 ? 2 * D : D;
@@ -110,7 +121,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
     constexpr int CL = C / 64;                               // cells per lane in the softmax
     const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
-    const int n_ctx = a.n_ctx, H = a.H;
+    const int n_ctx = a.n_ctx;
     int chunk = sp;
     if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
         if (sp >= a.tok_nchunks[0]) { dma(); return; }
@@ -123,34 +134,32 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     int cpos = -1;
     unsigned long long cseq = 0;
     if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
-    const int32_t tpos = a.tok_pos[0];
-    const int tseq = a.tok_seq[0];
     constexpr int HP = D / 2, NPAIR = R * HP;
     static_assert(NPAIR <= NT, "query pairs per thread");
-    float2 qv = make_float2(0.0f, 0.0f), csv = make_float2(1.0f, 0.0f);
+    f32x2_t qv = {0.0f, 0.0f}, csv = {1.0f, 0.0f};
     if (tid < NPAIR) {
         const int r = tid / HP, i = tid % HP;
-        qv = *reinterpret_cast<const float2 *>(a.q + ((size_t)g * R + r) * D + 2 * i);
-        if (2 * i < n_rot) csv = *reinterpret_cast<const float2 *>(cs_table + 2 * i);
+        qv = *reinterpret_cast<const f32x2_t *>(a.q + ((size_t)g * R + r) * D + 2 * i);
+        if (2 * i < n_rot) csv = *reinterpret_cast<const f32x2_t *>(cs_table + 2 * i);
     }
-    uint4 kreg[KP];
+    u32x4_t kreg[KP];
 #pragma unroll
     for (int j = 0; j < KP; j++) {
         const int p = tid + NT * j;
         int cell = c_lo + p / LPC;
         if (cell >= n_ctx) cell = n_ctx - 1;
         const size_t rowi = head_row0 + cell;
-        if (TK == T_F16) kreg[j] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
-        else kreg[j] = *reinterpret_cast<const uint4 *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
+        if (TK == T_F16) kreg[j] = *reinterpret_cast<const u32x4_t *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
+        else kreg[j] = *reinterpret_cast<const u32x4_t *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
     }
     const int dq = tid % DQ, cg = tid / DQ;
-    uint2 vreg[CPG];
+    u32x2_t vreg[CPG];
 #pragma unroll
     for (int i = 0; i < CPG; i++) {
         int cell = c_lo + cg + NCG * i;
         if (cell >= n_ctx) cell = n_ctx - 1;
         const size_t rowi = head_row0 + cell;
-        if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+        if (TV == T_F16) vreg[i] = *reinterpret_cast<const u32x2_t *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
         else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
     }
     uint32_t ks2 = 0, vs2 = 0;
@@ -161,33 +170,50 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
         if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
     }
 
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+    // the token's un-rotated K / V row of this kv head: 1 KB, requested by wave 0 of EVERY item now (which chunk holds the token's cell is only known once
+    // the scalars are back; waiting for them first cost that chunk - every kv head's slowest item - a second memory round trip)
+    // (every wave, unconditionally: a load under a condition makes hipcc wait for ALL outstanding loads where the branches join)
+    // (native vector types: HIP's float4 class, modified under a condition below, is placed in scratch by hipcc)
+    f32x4_t xn4, cs4;
+    {
+        const bool isk = lane < 32;
+        const int dd = (lane & 31) * 4;
+        xn4 = *reinterpret_cast<const f32x4_t *>((isk ? fz.knew : fz.vnew) + g * D + dd);
+        cs4 = *reinterpret_cast<const f32x4_t *>(cs_table + (dd < n_rot ? dd : n_rot - 4));   // c0 s0 c1 s1 (clamped: used only where dd < n_rot)
+    }
+    // ---- the step's scalars (one batch of scalar loads, under the vector loads above)
+    const AOScalars sc = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
+    const unsigned serial = sc.serial;
+    const int tpos = sc.tpos, tseq = sc.tseq;
     // ---- this token's own K / V row (the chunk that holds its cell): rotate K, convert, write the cache row, keep the codes for the patch below
     int own_cl = -1;
     {
-        const int cellnew = fz.tok_cell[0];
+        const int cellnew = sc.cellnew;
         if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
         if (own_cl >= 0 && wave == 0) {                          // lanes 0 .. 31: K, lanes 32 .. 63: V; four elements each
             const bool isk = lane < 32;
             const int dd = (lane & 31) * 4;
-            float4 x4 = *reinterpret_cast<const float4 *>((isk ? fz.knew : fz.vnew) + g * D + dd);
+            float xa[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
             if (isk && dd < n_rot) {
-                const float4 cs = *reinterpret_cast<const float4 *>(cs_table + dd);   // c0 s0 c1 s1
-                const float x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
-                x4.x = x0 * cs.x - x1 * cs.y; x4.y = x0 * cs.y + x1 * cs.x;
-                x4.z = x2 * cs.z - x3 * cs.w; x4.w = x2 * cs.w + x3 * cs.z;
+                const float x0 = xn4.x, x1 = xn4.y, x2 = xn4.z, x3 = xn4.w;
+                xa[0] = x0 * cs4.x - x1 * cs4.y; xa[1] = x0 * cs4.y + x1 * cs4.x;
+                xa[2] = x2 * cs4.z - x3 * cs4.w; xa[3] = x2 * cs4.w + x3 * cs4.z;
             }
-            const float xa[4] = {x4.x, x4.y, x4.z, x4.w};
             const size_t rowi = head_row0 + cellnew;
             const int TT = isk ? TK : TV;
+            // (the cache planes through opaque copies: from `isk ? a.kv.k : a.kv.v` on the kernel arguments hipcc builds a two-entry pointer table in scratch)
+            uint8_t *kvk = a.kv.k, *kvv = a.kv.v;
+            asm volatile("" : "+s"(kvk), "+s"(kvv));
             uint32_t packed = 0; float dsc = 0.0f;
             if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
             if (TT == T_F16) {
-                uint2 ov; ov.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); ov.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
-                *reinterpret_cast<uint2 *>((isk ? sm.newk : sm.newv) + dd * 2) = ov;
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(isk ? a.kv.k : a.kv.v) + rowi * D + dd) = ov;
+                u32x2_t ov; ov.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); ov.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
+                *reinterpret_cast<u32x2_t *>((isk ? sm.newk : sm.newv) + dd * 2) = ov;
+                *reinterpret_cast<u32x2_t *>(reinterpret_cast<uint16_t *>(isk ? kvk : kvv) + rowi * D + dd) = ov;
             } else {
                 *reinterpret_cast<uint32_t *>((isk ? sm.newk : sm.newv) + dd) = packed;
-                *reinterpret_cast<uint32_t *>((isk ? a.kv.k : a.kv.v) + rowi * D + dd) = packed;
+                *reinterpret_cast<uint32_t *>((isk ? kvk : kvv) + rowi * D + dd) = packed;
                 if ((lane & 7) == 0) {
                     const uint16_t hd = f2h(dsc);
                     (isk ? a.kv.kd : a.kv.vd)[rowi * NB + (dd >> 5)] = hd;
@@ -204,9 +230,10 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
         const float x0 = qv.x, x1 = qv.y, c = csv.x, s = csv.y;
         float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;
         if (TK == T_F16) { y0 = h2f(f2h(y0)); y1 = h2f(f2h(y1)); }
-        *reinterpret_cast<float2 *>(sm.qf + 2 * tid) = make_float2(y0, y1);
+        { const f32x2_t yy = {y0, y1}; *reinterpret_cast<f32x2_t *>(sm.qf + 2 * tid) = yy; }
     }
     __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
     if (own_cl >= 0) {   // workgroup-uniform: the row just produced instead of what the cache held before
         if (tid < NB / 2) {
             if (TK != T_F16) sm.ksc[own_cl * (NB / 2) + tid] = sm.newkd[tid];
@@ -215,19 +242,19 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
 #pragma unroll
         for (int j = 0; j < KP; j++) {
             const int p = tid + NT * j;
-            if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const uint4 *>(sm.newk + (p % LPC) * 16);
+            if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const u32x4_t *>(sm.newk + (p % LPC) * 16);
         }
 #pragma unroll
         for (int i = 0; i < CPG; i++) {
             if (cg + NCG * i == own_cl) {
-                if (TV == T_F16) vreg[i] = *reinterpret_cast<const uint2 *>(sm.newv + dq * 8);
+                if (TV == T_F16) vreg[i] = *reinterpret_cast<const u32x2_t *>(sm.newv + dq * 8);
                 else { vreg[i].x = *reinterpret_cast<const uint32_t *>(sm.newv + dq * 4); vreg[i].y = 0; }
             }
         }
     }
     if (TK != T_F16) {   // q8_0 of the rotated q: 4 values per thread, 8-lane groups (whole waves: R * D / 4 is a multiple of 64)
         if (tid * 4 < R * D) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(sm.qf + tid * 4);
+            const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(sm.qf + tid * 4);
             const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
             uint32_t packed; float d;
             wave_quant_q80(vv, packed, d);
@@ -262,7 +289,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
             const float dk = h2f((uint16_t)(((piece >> 1) & 1) ? (kpair >> 16) : (kpair & 0xffff)));
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint4 qq = *reinterpret_cast<const uint4 *>(sm.qc + r * D + piece * 16);
+                const u32x4_t qq = *reinterpret_cast<const u32x4_t *>(sm.qc + r * D + piece * 16);
                 int s = 0;
                 s = dot4(kreg[j].x, qq.x, s); s = dot4(kreg[j].y, qq.y, s); s = dot4(kreg[j].z, qq.z, s); s = dot4(kreg[j].w, qq.w, s);
                 s += dpp_i<DPP_QP_1032>(s);                    // both halves of the 32-block (integer)
@@ -279,6 +306,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
         }
     }
     __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
 
     // ---- softmax of the chunk: wave w -> heads w, w + 8, ..; lane = cell (and cell + 64)
     for (int r = wave; r < R; r += AO_NW) {
@@ -324,16 +352,28 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     }
 #pragma unroll
     for (int r = 0; r < R; r++)
-        *reinterpret_cast<float4 *>(sm.accs + ((size_t)cg * R + r) * D + dq * 4) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        { const f32x4_t av = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]}; *reinterpret_cast<f32x4_t *>(sm.accs + ((size_t)cg * R + r) * D + dq * 4) = av; }
     __syncthreads();
-    for (int e = tid; e < R * D; e += NT) {
-        const int r = e / D, d = e - r * D;
-        float s = 0.0f;
+    // ---- the chunk's partial record per head: AO_REC floats = O [D] | m | l | 0 | 0, written through to the coherence point in 16-byte pieces (a 4-byte
+    // write-through store is one fabric write each: 520 of them per item sat in the drain in front of the ticket)
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 11] = wall_clock64();
+    {
+        const __amdgpu_buffer_rsrc_t prs = coh_rsrc(a.part);
+        if (tid * 4 < R * D) {
+            const int r = (tid * 4) / D, d = tid * 4 - r * D;
+            f32x4_t sum = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < NCG; j++) s += sm.accs[((size_t)j * R + r) * D + d];
-        float *dst = a.part + (((size_t)g * R + r) * a.splits + sp) * (D + 2);
-        cstf<true>(dst + d, s);
-        if (d == 0) { cstf<true>(dst + D, sm.ml[2 * r]); cstf<true>(dst + D + 1, sm.ml[2 * r + 1]); }
+            for (int j = 0; j < NCG; j++) {
+                const f32x4_t v = *reinterpret_cast<const f32x4_t *>(sm.accs + ((size_t)j * R + r) * D + d);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            const int off = (int)(((((size_t)g * R + r) * a.splits + sp) * AO_REC + d) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(coh_u32x4, sum), prs, off, 0, 16);
+            if (d == 0) {
+                const f32x4_t mlv = {sm.ml[2 * r], sm.ml[2 * r + 1], 0.0f, 0.0f};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(coh_u32x4, mlv), prs, off + D * 4, 0, 16);
+            }
+        }
     }
 
     // ---- ticket; the last workgroup of this kv head (group) merges: GP kv heads per ticket, RM = GP * R heads merged (attn_decode_dev.h)
@@ -345,6 +385,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     const int splits = a.tok_nchunks ? a.tok_nchunks[0] : a.splits;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through partial stores have left
     __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sm.last_flag = (old == (unsigned)(splits * GP) - 1u) ? 1 : 0;
@@ -354,65 +395,74 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     // the W_o rows may queue now: nothing of this item is outstanding any more and nobody waits for this workgroup (36 KB of DMA in front of the partial
     // stores would have sat in their drain, i.e. in every kv head's ticket); the merging workgroup requests them after it has raised its flag
     if (!sm.last_flag) { dma(); return; }
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
-    float *merged = sm.accs;                           // [RM * D]
-    float *wgt = GP > 1 ? sm.accs + RM * D : sm.S;     // [RM][64] split weights
-    constexpr int NE = (RM * D + NT - 1) / NT, UB = 32;
-    float macc[NE], x[NE][UB];
-    const float *pp[NE];
-    int wr[NE];
-#pragma unroll
-    for (int j = 0; j < NE; j++) {
-        const int e = tid + NT * j < RM * D ? tid + NT * j : 0, r = e / D, d = e - r * D;
-        pp[j] = a.part + ((size_t)hb + r) * stride_s * (D + 2) + d;
-        wr[j] = r * 64;
-        macc[j] = 0.0f;
-    }
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 2] = wall_clock64();
+    // The merge: out[h][d] = sum over the chunks of w[h][chunk] * O[h][chunk][d], w = exp(m - M) / sum(exp(m - M) * l) (flash_attn_combine_kernel's
+    // weights).  The RM * D outputs are NDG groups of four dims; the 512 threads are NPH phases x NDG groups, phase p takes the chunks p, p + NPH, ..:
+    // at most 8 (16 from 33 chunks on) 16-byte loads per thread, all requested before the (m, l) pairs so that the weights are computed under them; the
+    // phases' partial sums meet in LDS and are added in phase order (a fixed order: the same bits on every run).
+    constexpr int NDG = RM * D / 4, NPH = NT / NDG < 4 ? NT / NDG : 4, UB = 8;     // (at most four phases: threads beyond them only help with the weights)
+    static_assert(NDG % 64 == 0 && NDG * NPH <= NT, "merge phases");
+    float *psum = sm.accs;                             // [NPH][RM * D]
+    float *merged = sm.accs + NPH * RM * D;            // [RM * D]
+    static_assert((NPH + 1) * RM * D + (GP > 1 ? RM * 64 : 0) <= AO_NCG * R * D, "merge scratch");
+    static_assert(RM * 64 <= R * C || GP > 1, "weights scratch");
+    const int dg = tid % NDG, ph = tid / NDG;          // (ph is the same for all lanes of a wave: NDG is a multiple of 64)
+    const int mr = (dg * 4) / D, md = dg * 4 - mr * D;
+    const __amdgpu_buffer_rsrc_t prs = coh_rsrc(a.part);
+    const int rec0 = (int)(((((size_t)hb + mr) * stride_s) * AO_REC + md) * 4);
+    coh_u32x4 x[UB];
     auto request = [&](int s0) {
 #pragma unroll
         for (int u = 0; u < UB; u++) {
-            const int s2 = s0 + u < splits ? s0 + u : splits - 1;              // clamped: straight-line loads
-#pragma unroll
-            for (int j = 0; j < NE; j++) x[j][u] = __hip_atomic_load(pp[j] + (size_t)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int s2 = s0 + ph + NPH * u;
+            if (ph < NPH && s2 < splits) x[u] = __builtin_amdgcn_raw_buffer_load_b128(prs, rec0 + s2 * (AO_REC * 4), 0, 16);     // (wave-uniform condition)
         }
     };
     request(0);
-    for (int r = wave; r < RM; r += AO_NW) {           // same arithmetic as flash_attn_combine_kernel
-        const float *p = a.part + ((size_t)hb + r) * stride_s * (D + 2);
+    float *wg2 = GP > 1 ? sm.accs + (NPH + 1) * RM * D : sm.S;     // [RM][64] chunk weights (pairs of kv heads: S is too small for two heads' weights)
+    for (int r = wave; r < RM; r += AO_NW) {
         float m = -INFINITY, l = 0.0f;
         if (lane < splits) {
-            m = __hip_atomic_load(p + (size_t)lane * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            l = __hip_atomic_load(p + (size_t)lane * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const coh_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(prs, (int)(((((size_t)hb + r) * stride_s + lane) * AO_REC + D) * 4), 0, 16);
+            m = __uint_as_float(v.x); l = __uint_as_float(v.y);
         }
         const float M = wave_max(m);
         const float w = (lane < splits && m != -INFINITY) ? expf(m - M) : 0.0f;
         const float den = wave_sum(w * l);
         const float inv = 1.0f / den;
-        wgt[r * 64 + lane] = w * inv;
+        wg2[r * 64 + lane] = w * inv;
     }
     __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 13] = wall_clock64();
+    f32x4_t macc = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int s0 = 0;;) {
 #pragma unroll
         for (int u = 0; u < UB; u++) {
-            if (s0 + u < splits) {                                             // workgroup-uniform
-#pragma unroll
-                for (int j = 0; j < NE; j++) macc[j] += wgt[wr[j] + s0 + u] * x[j][u];
+            const int s2 = s0 + ph + NPH * u;
+            if (ph < NPH && s2 < splits) {
+                const float w = wg2[mr * 64 + s2];
+                const f32x4_t xv = __builtin_bit_cast(f32x4_t, x[u]);
+                macc.x += w * xv.x; macc.y += w * xv.y; macc.z += w * xv.z; macc.w += w * xv.w;
             }
         }
-        s0 += UB;
+        s0 += NPH * UB;
         if (s0 >= splits) break;
         request(s0);
     }
-    __syncthreads();                                   // (GP == 1: wgt aliases S, merged aliases accs - nothing below reads wgt)
+    if (ph < NPH) *reinterpret_cast<f32x4_t *>(psum + (size_t)ph * RM * D + dg * 4) = macc;      // (the item's P.V sums in accs were consumed before the ticket)
+    __syncthreads();
+    for (int e = tid; e < RM * D; e += NT) {
+        float v = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NE; j++) {
-        const int e = tid + NT * j;
-        if (e < RM * D) { merged[e] = macc[j]; a.out[(size_t)hb * D + e] = macc[j]; }
+        for (int p2 = 0; p2 < NPH; p2++) v += psum[(size_t)p2 * RM * D + e];
+        merged[e] = v;
+        a.out[(size_t)hb * D + e] = v;
     }
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 14] = wall_clock64();
     __syncthreads();
     constexpr int NBLK = (RM * D) >> 8;                // 256-blocks this ticket group owns in the H * D row
     for (int b = wave; b < NBLK; b += AO_NW) {
-        const float4 v4 = *reinterpret_cast<const float4 *>(merged + b * 256 + lane * 4);
+        const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(merged + b * 256 + lane * 4);
         const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
         const int gb = ((hb * D) >> 8) + b;            // global block index
         const int e0 = gb * 256 + lane * 4;
@@ -426,7 +476,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(o.flags + gq, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 3] = wall_clock64();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 3] = wall_clock64();
     dma();
 }
 
@@ -472,11 +522,21 @@ __device__ __forceinline__ void ao_decode(const AOArgs &o, const uint8_t *slice,
 template <int R, int TK, int TV, int C>
 __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // The kernel argument segment is cold at every launch and hipcc reads a field where it is first used: seven dependent scalar-load round trips sat in front
+    // of the first K / V request (1.4 us from entry to "loads issued", MI355_AO_PROBE).  One independent read per 64-byte line of the segment, all in flight
+    // together, makes the later field reads scalar-cache hits.
+    {
+        struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; };
+        const __attribute__((address_space(4))) unsigned *ka = (const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_kernarg_segment_ptr();
+        unsigned acc = 0;
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(KArgs) + 63) / 64); i++) acc ^= ka[i * 16];
+        asm volatile("" :: "s"(acc));
+    }
     const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
     const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>));
     AOSmem<R, C> &sm = *reinterpret_cast<AOSmem<R, C> *>(smem + lay.attn);
-    const unsigned serial = *o.serial;
     const int b0r = (int)blockIdx.x * o.rows_per_wg;
     const int b0 = b0r < o.n_rows ? b0r : o.n_rows;
     const int nrw = b0 + o.rows_per_wg <= o.n_rows ? o.rows_per_wg : o.n_rows - b0;
@@ -492,11 +552,12 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
     bool had_item = false;
     for (int it = (int)blockIdx.x; it < o.n_items; it += (int)gridDim.x) {
         if (had_item) __syncthreads();                 // (the item's LDS is reused)
-        ao_attn_item<R, TK, TV, C>(a, cs_table, n_rot, fz, o, serial, it % G, it / G, sm, dma);
+        ao_attn_item<R, TK, TV, C>(a, cs_table, n_rot, fz, o, it % G, it / G, sm, dma);
         had_item = true;
     }
     dma();                                             // workgroups without an item: at once
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
+    const unsigned serial = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell).serial;     // (a second batch for workgroups that had an item: scalar-cache hits)
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 1] = wall_clock64();
 
     // ---- the merged, quantised attention output: wait for every ticket group's flag, then fetch the planes device-coherently
     if (wave == 0) {
@@ -511,7 +572,7 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
         asm volatile("" ::: "memory");
     }
     __syncthreads();
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 4] = wall_clock64();
     {
         const int K = o.K, nb = K >> 8;
         if (tid * 16 < K) {
@@ -526,7 +587,7 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes above and this wave's share of the W_o rows (DMA) have landed
     __syncthreads();
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 5] = wall_clock64();
     if (nrw > 0) {
         const ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
         switch (o.type) {
@@ -538,7 +599,7 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
     }
     if (o.probe) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) o.probe[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
+        if (tid == 0) o.probe[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
     }
 }
 
@@ -593,15 +654,15 @@ bool attn_out_fused_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQ
 
 void attn_out_probe_report() {
     if (!g_ao_probe || g_ao_probe_wgs <= 0) return;
-    std::vector<unsigned long long> t((size_t)g_ao_probe_wgs * 8);
+    std::vector<unsigned long long> t((size_t)g_ao_probe_wgs * 16);
     (void)hipDeviceSynchronize();
     if (hipMemcpy(t.data(), g_ao_probe, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     unsigned long long t0 = ~0ull;
-    for (int w = 0; w < g_ao_probe_wgs; w++) if (t[(size_t)w * 8]) t0 = std::min(t0, t[(size_t)w * 8]);
+    for (int w = 0; w < g_ao_probe_wgs; w++) if (t[(size_t)w * 16]) t0 = std::min(t0, t[(size_t)w * 16]);
     auto stat = [&](int k, const char *name) {
         double lo = 1e30, hi = 0, sum = 0; int n = 0;
         for (int w = 0; w < g_ao_probe_wgs; w++) {
-            const unsigned long long v = t[(size_t)w * 8 + k];
+            const unsigned long long v = t[(size_t)w * 16 + k];
             if (!v) continue;
             const double us = (double)(v - t0) * 0.01;
             lo = std::min(lo, us); hi = std::max(hi, us); sum += us; n++;
@@ -609,7 +670,9 @@ void attn_out_probe_report() {
         if (n) fprintf(stderr, "  %-28s n=%3d  min %.2f  mean %.2f  max %.2f us\n", name, n, lo, sum / n, hi);
     };
     fprintf(stderr, "attn_out probe: %d workgroups, %d attention items (us since the first workgroup entered)\n", g_ao_probe_wgs, g_ao_probe_items);
-    stat(0, "entered"); stat(1, "items done / dma issued"); stat(2, "merge: ticket won"); stat(3, "merge: flag raised");
+    stat(0, "entered"); stat(8, "item: loads issued"); stat(9, "item: q rotated (loads back)"); stat(10, "item: scores done"); stat(11, "item: P.V done");
+    stat(12, "item: partial stored+drained"); stat(1, "items done / dma issued"); stat(2, "merge: ticket won"); stat(13, "merge: weights done");
+    stat(14, "merge: sums done"); stat(3, "merge: flag raised");
     stat(4, "all flags seen"); stat(5, "codes + rows in LDS"); stat(6, "outputs stored");
 }
 
@@ -631,8 +694,8 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
     o.n_items = a.G * a.splits;
     static const bool probe_on = getenv("MI355_AO_PROBE") && getenv("MI355_AO_PROBE")[0] == '1';
     if (probe_on) {
-        if (!g_ao_probe && hipMalloc((void **)&g_ao_probe, 1024 * 8 * 8) != hipSuccess) g_ao_probe = nullptr;
-        if (g_ao_probe) { (void)hipMemsetAsync(g_ao_probe, 0, 1024 * 8 * 8, st); g_ao_probe_wgs = std::min(nwg, 1024); g_ao_probe_items = o.n_items; }
+        if (!g_ao_probe && hipMalloc((void **)&g_ao_probe, 1024 * 16 * 8) != hipSuccess) g_ao_probe = nullptr;
+        if (g_ao_probe) { (void)hipMemsetAsync(g_ao_probe, 0, 1024 * 16 * 8, st); g_ao_probe_wgs = std::min(nwg, 1024); g_ao_probe_items = o.n_items; }
         o.probe = g_ao_probe;
     }
     DecodeFuse fz{};

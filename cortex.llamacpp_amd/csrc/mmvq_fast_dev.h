@@ -53,6 +53,9 @@ template <> struct Raw<T_Q4_K> {
         dl = dot4(q.z & 0x0f0f0f0f, A.lo.z, dl); dh = dot4((q.z >> 4) & 0x0f0f0f0f, A.hi.z, dh);
         dl = dot4(q.w & 0x0f0f0f0f, A.lo.w, dl); dh = dot4((q.w >> 4) & 0x0f0f0f0f, A.hi.w, dh);
         const int isum = mul24((int)(sc & 0xff), dl) + mul24((int)(sc >> 8), dh);
+#ifdef MI355_EXP_NO_MINS       // tools/build_exp_r4.sh only: a cheaper (wrong) dot, to see how far the decode time follows the instruction count
+        return (d * A.yd) * (float)isum + (float)(mn & 1);
+#endif
         const int msum = mul24((int)(mn & 0xff), A.bs_lo) + mul24((int)(mn >> 8), A.bs_hi);
         return (d * A.yd) * (float)isum - (dmin * A.yd) * (float)msum;
     }

@@ -114,7 +114,7 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
         if ((g.row_bytes % 16) != 0 || g.row_bytes < 1024) return false;
         if (g.row_bytes > (size_t)ST_MAX_STEP) return false;
         if (kb <= 2 && 2 * g.row_bytes > (size_t)ST_PAIR_MAX) return false;      // K <= 4096 only has the row-pair form
-        if (kb >= 6 && 2 * g.row_bytes <= (size_t)ST_PAIR_MAX) return false;     // K >= 10240 only the single-row form
+        if (ST_PAIR_MAX <= 12288 && kb >= 6 && 2 * g.row_bytes <= (size_t)ST_PAIR_MAX) return false;     // K >= 10240 only the single-row form
         if ((reinterpret_cast<uintptr_t>(g.W) & 15) != 0) return false;
         if (a.fuse_mode == 0 && (t == T_Q8_0 || !a.aq || !a.ad || !a.abs)) return false;
     }

@@ -10,7 +10,11 @@ namespace mi355 {
 namespace {
 
 constexpr int ST_NL = 2;                        // loader waves (the first waves of the workgroup)
-constexpr int ST_NC = 8;                        // consumer waves: the wave count the prologue of mmvq_fast is cut for
+#ifndef MI355_ST_NC
+#define MI355_ST_NC 8
+#endif
+constexpr int ST_NC = MI355_ST_NC;              // consumer waves (8: the wave count the prologue of mmvq_fast is cut for; up to 14 = a 1024-thread workgroup)
+static_assert(ST_NC >= 1 && ST_NC <= 14, "consumer waves");
 constexpr int ST_NW = ST_NL + ST_NC, ST_NT = ST_NW * 64;
 #ifndef MI355_ST_RING
 #define MI355_ST_RING 131072                    // (tools/exp_stream.hip builds a 64 KiB variant: two workgroups per CU)
@@ -30,7 +34,10 @@ constexpr int ST_D = MI355_STREAM_DEPTH;        // slots in flight per loader (4
 #endif
 constexpr int ST_THIN_D = MI355_STREAM_THIN_DEPTH;   // slots in flight per loader while a wave of the CU gathers a hand-over (decode_engine.hip)
 constexpr int ST_MAX_STEP = 16384;              // bytes one decode step may span (a row, a row pair or one row of a gate/up pair)
-constexpr int ST_PAIR_MAX = 12288;              // rows are decoded two at a time up to this many bytes per pair
+#ifndef MI355_ST_PAIR_MAX
+#define MI355_ST_PAIR_MAX 12288
+#endif
+constexpr int ST_PAIR_MAX = MI355_ST_PAIR_MAX;  // rows are decoded two at a time up to this many bytes per pair
 
 // ---- the DMA.  M0 = LDS byte address of the 64-lane destination (lane l lands at M0 + 16 l); saved and restored inside
 // the statement (hipcc does not preserve M0 around asm and does not expect it changed).
@@ -114,7 +121,7 @@ template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q8_0> &r, con
 #undef RO
 
 // ---- LDS layout (bytes from smem): sync words | reduction scratch | ring | activation of the current mat-vec
-constexpr int ST_OFF_SYNC = 0, ST_OFF_RED = 128, ST_OFF_RING = 256, ST_OFF_ACT = ST_OFF_RING + ST_RING;
+constexpr int ST_OFF_SYNC = 0, ST_OFF_RED = 256, ST_OFF_RING = 512, ST_OFF_ACT = ST_OFF_RING + ST_RING;   // (64 sync words, 16 doubles of reduction scratch)
 struct StLayout { int qs, d, bs, total; };
 __host__ __device__ inline StLayout st_layout(int kb) {
     const int Kp = kb * 2048;
@@ -642,7 +649,7 @@ __device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, 
 #define RUN(TY)                                                                                               \
     do {                                                                                                      \
         if (a.swiglu) { if constexpr (FUSE == 1 || (FUSE == 3 && KB <= 4)) consumer_op<TY, KB, FUSE, true, true, ENG>(a, smem, c, g0, lay, io); } \
-        else if (a.pair) { if constexpr (KB <= 4) consumer_op<TY, KB, FUSE, false, true, ENG>(a, smem, c, g0, lay, io); } \
+        else if (a.pair) { if constexpr (KB <= 4 || ST_PAIR_MAX > 12288) consumer_op<TY, KB, FUSE, false, true, ENG>(a, smem, c, g0, lay, io); } \
         else { if constexpr (KB >= 3) consumer_op<TY, KB, FUSE, false, false, ENG>(a, smem, c, g0, lay, io); } \
     } while (0)
     switch (a.type) {
@@ -656,7 +663,7 @@ __device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, 
 }
 
 __device__ __forceinline__ void sync_init(uint8_t *smem) {
-    if (threadIdx.x < 32) reinterpret_cast<int *>(smem + ST_OFF_SYNC)[threadIdx.x] = 0;
+    if (threadIdx.x < 64) reinterpret_cast<int *>(smem + ST_OFF_SYNC)[threadIdx.x] = 0;
     __syncthreads();
 }
 

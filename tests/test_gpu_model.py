@@ -954,7 +954,9 @@ def test_device_argmax_follows_a_changing_number_of_flagged_rows(be, pkg, tmp_mo
 def test_attn_out_one_launch_agrees_with_the_two_launches(be, pkg, tmp_models, cfg, ftype, kv):
     """Single-token steps with the decode attention and the attn_output mat-vec in ONE launch (attn_out.hip, the default) against the same steps as two
     launches: the attention items run on 512 threads there (16 cell groups in the P.V pass instead of 8), so the comparison is f32 re-association, not
-    bits - until a 1-ulp difference flips an int8 code, which moves a logit by up to ~1e-2 (FLIP_TOL); the median step must agree to round-off."""
+    bits - until a 1-ulp difference flips an int8 code, which moves a logit by up to ~1e-2 (FLIP_TOL) and, once it sits in a K / V row of the next layer,
+    stays for the rest of the run.  So: every step within FLIP_TOL, and the FIRST step after each of five prompts (no earlier flip to inherit) agrees to
+    round-off for most of them."""
     path = make(pkg, tmp_models, cfg, ftype)
     rows = {}
     for fused in (1, 0):
@@ -962,21 +964,22 @@ def test_attn_out_one_launch_agrees_with_the_two_launches(be, pkg, tmp_models, c
         try:
             m = pkg.Model(path)
             c = pkg.Context(m, n_ctx=512, type_k=KV[kv], type_v=KV[kv])
-            rng = np.random.default_rng(3)
-            prompt = rng.integers(0, m.n_vocab, 150)
-            c.decode(prompt, np.arange(150))
-            toks = rng.integers(0, m.n_vocab, 40)
             out = []
-            for s, t in enumerate(toks):
-                c.decode([int(t)], [150 + s])
-                out.append(c.logits())
+            for seed in range(5):
+                rng = np.random.default_rng(100 + seed)
+                n_p = 90 + 37 * seed
+                c.kv_clear()
+                c.decode(rng.integers(0, m.n_vocab, n_p), np.arange(n_p))
+                for s, t in enumerate(rng.integers(0, m.n_vocab, 12)):
+                    c.decode([int(t)], [n_p + s])
+                    out.append(c.logits())
             rows[fused] = np.stack(out)
             c.close(); m.close()
         finally:
             be.set_option("attn_out_fused", -1)
-    errs = np.array([rel_err(a, b) for a, b in zip(rows[1], rows[0])])
+    errs = np.array([rel_err(a, b) for a, b in zip(rows[1], rows[0])]).reshape(5, 12)
     assert float(errs.max()) <= FLIP_TOL, errs
-    assert float(np.median(errs)) <= 1e-4, errs
+    assert float(np.median(errs[:, 0])) <= 1e-5, errs[:, 0]
 
 
 @pytest.mark.parametrize("cfg,ftype,kv,n_prompt", [("tiny-8b-2l", "q4_k_m", "q8_0", 3968), ("tiny-d128", "q4_k_m", "f16", 3968), ("tiny-d128", "q4_k_m", "q4_0", 3000)])

@@ -150,6 +150,7 @@ int main(int argc, char **argv) {
     add("gateup q4k 2x14336x4096 rmsnorm swiglu", 2, {T_Q4_K, T_Q4_K}, {FF, FF}, E, EPI_SWIGLU, 1, NL);
     add("down  q4k 4096x14336 quant +resid     ", 1, {T_Q4_K}, {4096}, FF, EPI_ADD, 2, NL);
     add("down  q6k 4096x14336 quant +resid     ", 1, {T_Q6_K}, {4096}, FF, EPI_ADD, 2, NL);
+    add("down  q4k 4096x14336 PLANES +resid    ", 1, {T_Q4_K}, {4096}, FF, EPI_ADD, 0, NL);      // (round 4: what ffn_down costs without its quantisation prologue)
     add("head  q6k 128256x4096 rmsnorm         ", 1, {T_Q6_K}, {128256}, E, EPI_STORE, 1, 2);
     add("o     q5k 4096x4096 planes +resid     ", 1, {T_Q5_K}, {4096}, E, EPI_ADD, 0, 2);
     add("o     q6k 4096x4096 planes +resid     ", 1, {T_Q6_K}, {4096}, E, EPI_ADD, 0, 2);
