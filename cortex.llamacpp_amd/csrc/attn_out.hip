@@ -47,7 +47,9 @@ struct AOArgs {
     unsigned row_bytes;
     int rows_per_wg;
     unsigned slice_lds;             // LDS bytes reserved for the workgroup's rows (whole 4 KiB slots)
-    unsigned *flags;                // this layer's flag words, one per merge ticket group
+    unsigned *flags;                // this layer's flag words, one per merge ticket group: "this group's merge has its sums" (the codes follow as granules)
+    unsigned long long *gran;       // the quantised attention output as tagged granules {tag, value}: [K / 4] four codes | [K / 16] block sums | [K / 256] scales
+    int layer;                      // tag = serial * 256 + layer + 1: distinct per step and per layer (the granule buffer is shared by the layers of a step)
     const unsigned *serial;         // device word: the step's serial number (never 0)
     int n_flags, n_items;           // ticket groups; attention items = G * splits
     unsigned long long *probe;      // diagnosis (MI355_AO_PROBE=1): per workgroup 16 wall-clock stamps
@@ -121,7 +123,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
     constexpr int CL = C / 64;                               // cells per lane in the softmax
     const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
-    const int n_ctx = a.n_ctx;
+    const int n_ctx = a.n_ctx, H = a.H;
     int chunk = sp;
     if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
         if (sp >= a.tok_nchunks[0]) { dma(); return; }
@@ -456,27 +458,38 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
 #pragma unroll
         for (int p2 = 0; p2 < NPH; p2++) v += psum[(size_t)p2 * RM * D + e];
         merged[e] = v;
-        a.out[(size_t)hb * D + e] = v;
     }
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 14] = wall_clock64();
-    __syncthreads();
+    __syncthreads();                                   // (no global store is outstanding here: a barrier behind stores waits for them)
+    // The flag goes up NOW, before the codes exist: it only says "start looking".  The codes travel as 8-byte granules {tag, value} - data and validity in one
+    // store, nothing to fence or drain - and every consumer sweeps them until each carries this step's tag: its first sweep is in flight while the codes
+    // are being written.
+    const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
+    if (tid == 0) __hip_atomic_store(o.flags + gq, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int NBLK = (RM * D) >> 8;                // 256-blocks this ticket group owns in the H * D row
+    const int K = H * D;
+    const __amdgpu_buffer_rsrc_t grs = coh_rsrc(o.gran);
     for (int b = wave; b < NBLK; b += AO_NW) {
         const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(merged + b * 256 + lane * 4);
         const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
         const int gb = ((hb * D) >> 8) + b;            // global block index
-        const int e0 = gb * 256 + lane * 4;
         uint32_t packed; int bs; float dq8;
         wave_quant_q8k(vv, lane, packed, bs, dq8);
-        cst4<true>(fz.q.qs + e0, packed);
-        if ((lane & 3) == 0) cst2<true>(fz.q.bsums + gb * 16 + (lane >> 2), (unsigned short)(int16_t)bs);
-        if (lane == 0) cstf<true>(fz.q.d + gb, dq8);
+        // two granules per 16-byte write-through store (each 8-byte half carries its own tag): the even lane takes its neighbour's word
+        const uint32_t packed1 = (uint32_t)dpp_i<DPP_QP_1032>((int)packed);
+        if ((lane & 1) == 0) {
+            const coh_u32x4 g2 = {packed, tag, packed1, tag};
+            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, (gb * 64 + lane) * 8, 0, 16);
+        }
+        const int bs1 = dpp_i<0x104>(bs);             // row_shl:4 - the block sum four lanes further on (the next 16-code group)
+        if ((lane & 7) == 0) {
+            const coh_u32x4 g2 = {(unsigned)bs & 0xffffu, tag, (unsigned)bs1 & 0xffffu, tag};
+            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, ((K >> 2) + gb * 16 + (lane >> 2)) * 8, 0, 16);
+        }
+        if (lane == 0) st_store_granule(o.gran + (K >> 2) + (K >> 4) + gb, tag, __float_as_uint(dq8));
     }
-    // publish: every storing wave drains its write-through stores, then ONE lane raises the group's flag to the step's serial
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(o.flags + gq, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 3] = wall_clock64();
+    for (int e = tid; e < RM * D; e += NT) a.out[(size_t)hb * D + e] = merged[e];   // (the f32 rows: nobody in this launch reads them)
     dma();
 }
 
@@ -486,7 +499,8 @@ template <int TYPE>
 __device__ __forceinline__ void ao_decode(const AOArgs &o, const uint8_t *slice, const ActL &AL, int b0, int nrw, int wave, int lane, float rs0, float rs1) {
     using Rw = Raw<TYPE>;
     const LaneRole L = make_role<TYPE>(lane);
-    const int nb = o.K >> 8, KB = (o.K + 2047) >> 11;
+    constexpr int SBP = role_sbp<TYPE>();
+    const int nb = o.K >> 8, NP = (nb + SBP - 1) / SBP;           // passes of the wave over a row (lane role of the type: 8 or 16 super-blocks each)
     const unsigned rb = o.row_bytes;
     const int n_steps = (nrw + 1) >> 1;
     for (int s = wave; s < n_steps; s += AO_NW) {
@@ -494,9 +508,9 @@ __device__ __forceinline__ void ao_decode(const AOArgs &o, const uint8_t *slice,
         const unsigned off0 = 2u * (unsigned)s * rb, off1 = two ? off0 + rb : off0;
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll 2
-        for (int p = 0; p < KB; p++) {
-            const ActSlice sl = read_slice_t<TYPE>(AL, p * 8 + L.sbl, nb, L);
-            int sb = p * 8 + L.sbl;
+        for (int p = 0; p < NP; p++) {
+            const ActSlice sl = read_slice_t<TYPE>(AL, p * SBP + L.sbl, nb, L);
+            int sb = p * SBP + L.sbl;
             if (sb >= nb) sb = nb - 1;
             Rw w0, w1;
             ring_load<false>(w0, slice, 0u, off0, nb, sb, L);
@@ -559,33 +573,51 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
     const unsigned serial = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell).serial;     // (a second batch for workgroups that had an item: scalar-cache hits)
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 1] = wall_clock64();
 
-    // ---- the merged, quantised attention output: wait for every ticket group's flag, then fetch the planes device-coherently
+    // ---- the merged, quantised attention output: wait until every ticket group's merge has its sums (one wave polls, relaxed, bounded), then every wave
+    // sweeps its share of the granules until each carries this step's tag and puts the values where the decoders expect the Q8_K planes
+    const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
     if (wave == 0) {
         int spins = 0;
         for (;;) {
-            unsigned v = serial;
+            unsigned v = tag;
             if (lane < o.n_flags) v = __hip_atomic_load(o.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(v == serial)) break;
+            if (__all(v == tag)) break;
             if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
     }
     __syncthreads();
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 4] = wall_clock64();
     {
-        const int K = o.K, nb = K >> 8;
-        if (tid * 16 < K) {
-            const coh_u32x4 v = cld16<true>(fz.q.qs, tid * 16);
-            *reinterpret_cast<coh_u32x4 *>(smem + lay.qs + tid * 16) = v;
+        const int K = o.K, nq = K >> 2, nbs = K >> 4, ng = nq + nbs + (K >> 8), np = ng >> 1;      // (granule pairs: K is a multiple of 512 here)
+        constexpr int PPT = ((8192 / 4 + 8192 / 16 + 8192 / 256) / 2 + AO_NT - 1) / AO_NT;      // pairs per thread at the longest K the launch takes
+        const __amdgpu_buffer_rsrc_t grs = coh_rsrc(o.gran);
+        coh_u32x4 val[PPT];
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const int i = tid + AO_NT * j;
+                if (i < np) {
+                    val[j] = __builtin_amdgcn_raw_buffer_load_b128(grs, i * 16, 0, 16);
+                    ok = ok && val[j].y == tag && val[j].w == tag;
+                }
+            }
+            if (__all(ok)) break;
+            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (tid * 16 < (K >> 3)) {
-            const coh_u32x4 v = cld16<true>(fz.q.bsums, tid * 16);
-            *reinterpret_cast<coh_u32x4 *>(smem + lay.bs + tid * 16) = v;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const int i = 2 * (tid + AO_NT * j);          // first granule of the pair (nq and nbs are even: a pair never straddles two planes)
+            if (i < nq) { reinterpret_cast<unsigned *>(smem + lay.qs)[i] = val[j].x; reinterpret_cast<unsigned *>(smem + lay.qs)[i + 1] = val[j].z; }
+            else if (i < nq + nbs) reinterpret_cast<unsigned *>(smem + lay.bs)[(i - nq) >> 1] = (val[j].x & 0xffffu) | (val[j].z << 16);
+            else if (i < ng) { reinterpret_cast<unsigned *>(smem + lay.d)[i - nq - nbs] = val[j].x; reinterpret_cast<unsigned *>(smem + lay.d)[i - nq - nbs + 1] = val[j].z; }
         }
-        if (tid < nb) reinterpret_cast<unsigned *>(smem + lay.d)[tid] = cld4<true>(fz.q.d, tid * 4);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the planes above and this wave's share of the W_o rows (DMA) have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W_o rows (DMA) has landed
     __syncthreads();
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 5] = wall_clock64();
     if (nrw > 0) {
@@ -614,6 +646,7 @@ bool attn_out_fused_enabled() {
     static const bool env_off = getenv("MI355_ATTN_OUT_FUSED") && getenv("MI355_ATTN_OUT_FUSED")[0] == '0';
     return g_attn_out_fused < 0 ? !env_off : g_attn_out_fused > 0;
 }
+size_t attn_out_granule_words(int K) { return (size_t)(K / 4 + K / 16 + K / 256) + 64; }
 void attn_out_set_error_word(unsigned *w) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_err_word), &w, sizeof(w)); }
 
 // chunk size the launch will use for a scan of n_kv_max cells: 64 cells while that gives every CU at most one item, 128 beyond
@@ -639,7 +672,7 @@ bool attn_out_fused_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQ
     if (a.G % gp != 0 || a.G / gp > 64) return false;
     if (!a.out_q || !a.out_q8k || a.out_q80) return false;
     if (wo.type != T_Q4_K && wo.type != T_Q5_K && wo.type != T_Q6_K) return false;
-    if (K != a.H * a.D || (K % 256) != 0 || K > 8192 || wo.expert_sel) return false;
+    if (K != a.H * a.D || (K % 512) != 0 || K > 8192 || wo.expert_sel) return false;      // (512: the granules travel in pairs)
     if ((wo.row_bytes % 16) != 0 || (reinterpret_cast<uintptr_t>(wo.W) & 15) != 0) return false;
     if (epi != EPI_ADD && epi != EPI_STORE) return false;
     const int C = attn_out_fused_chunk(a);
@@ -672,13 +705,14 @@ void attn_out_probe_report() {
     fprintf(stderr, "attn_out probe: %d workgroups, %d attention items (us since the first workgroup entered)\n", g_ao_probe_wgs, g_ao_probe_items);
     stat(0, "entered"); stat(8, "item: loads issued"); stat(9, "item: q rotated (loads back)"); stat(10, "item: scores done"); stat(11, "item: P.V done");
     stat(12, "item: partial stored+drained"); stat(1, "items done / dma issued"); stat(2, "merge: ticket won"); stat(13, "merge: weights done");
-    stat(14, "merge: sums done"); stat(3, "merge: flag raised");
+    stat(14, "merge: sums done"); stat(3, "merge: codes stored");
     stat(4, "all flags seen"); stat(5, "codes + rows in LDS"); stat(6, "outputs stored");
 }
 
 hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
-                                 unsigned *counters, unsigned *flags, const unsigned *serial, const MMVQSeg &wo, int K, int epi, hipStream_t st) {
-    if (!counters || !flags || !serial || !knew || !vnew || !tok_cell) return hipErrorInvalidValue;
+                                 unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
+                                 hipStream_t st) {
+    if (!counters || !flags || !gran || !serial || !knew || !vnew || !tok_cell || layer < 0 || layer > 254) return hipErrorInvalidValue;
     const int R = a.H / a.G;
     const int C = attn_out_fused_chunk(a);
     AOArgs o{};
@@ -688,7 +722,7 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
     o.rows_per_wg = (wo.n_rows + nwg0 - 1) / nwg0;
     const int nwg = (wo.n_rows + o.rows_per_wg - 1) / o.rows_per_wg;
     o.slice_lds = (unsigned)((((size_t)o.rows_per_wg * wo.row_bytes) + ST_SLOT - 1) / ST_SLOT * ST_SLOT);
-    o.flags = flags; o.serial = serial;
+    o.flags = flags; o.gran = gran; o.layer = layer; o.serial = serial;
     const int gp = (R * a.D) % 256 == 0 ? 1 : 2;
     o.n_flags = a.G / gp;
     o.n_items = a.G * a.splits;

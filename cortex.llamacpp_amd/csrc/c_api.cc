@@ -659,8 +659,10 @@ int mi355_op_attn_step(const float *q, const float *k_new, const float *v_new, i
         DevBuf part(flash_attn_workspace_floats(1, H, D, a.splits) * 4);
         a.part = part.as<float>();
         if (!attn_out_fused_applicable(a, ra, so, (int)K, EPI_ADD)) { fail("attn_out.hip has no form for this shape"); return MI355_ERR_ARG; }
+        DevBuf dgran(attn_out_granule_words((int)K) * 8);
+        if (!dgran.p) return MI355_ERR_OOM;
         e = launch_attn_out_fused(a, dcsb.as<float>(), ra, dkn.as<float>(), dvn.as<float>(), dcell.as<int32_t>(), dcnt.as<unsigned>(), dflags.as<unsigned>(),
-                                  dserial.as<unsigned>(), so, (int)K, EPI_ADD, nullptr);
+                                  dgran.as<unsigned long long>(), 3, dserial.as<unsigned>(), so, (int)K, EPI_ADD, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) return hip_fail(e, "attn_out_fused");
     } else {

@@ -299,14 +299,17 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
 // K rope + KV store + attention + split merge + Q8_K quantise + W_o mat-vec (+ residual): one workgroup of 8 waves per CU owns a run of W_o rows and at most
 // one (kv head, chunk) attention item; the merged codes cross between workgroups behind one flag per kv-head group.  D = 128, NORM rope, q8_0 or f16 cache,
 // 1 / 2 / 4 / 8 query heads per kv head, W_o in Q4_K / Q5_K / Q6_K.  a.splits = attn_out_fused_splits(a); flags: one word per ticket group of THIS layer
-// (never reset: they hold the step serial); serial: device word the step's set-up launch increments (never 0).
+// (never reset: they hold the tag of the step that raised them); serial: device word the step's set-up launch increments (never 0).
 void set_attn_out_fused(int on);                          // tests / A-B runs: 0 = the two launches, 1 = fused, -1 = environment (MI355_ATTN_OUT_FUSED, default on)
 bool attn_out_fused_enabled();
 int attn_out_fused_chunk(const AttnArgs &a);              // cells per attention item: 64, or 128 from the context length on where 64 would give a CU two items
 int attn_out_fused_splits(const AttnArgs &a);
 bool attn_out_fused_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi);
+// gran: attn_out_granule_words(K) 8-byte words shared by the layers of a step (zero once); layer: 0 .. 254, part of the hand-over tag
+size_t attn_out_granule_words(int K);
 hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
-                                 unsigned *counters, unsigned *flags, const unsigned *serial, const MMVQSeg &wo, int K, int epi, hipStream_t st);
+                                 unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
+                                 hipStream_t st);
 void attn_out_set_error_word(unsigned *w);
 void attn_out_probe_report();                             // MI355_AO_PROBE=1: phase stamps of the last launch, on stderr
 

@@ -16,42 +16,73 @@ __device__ __forceinline__ u32x4_t ldw(const void *p) {   // weight stream: non-
 __device__ __forceinline__ u32x4_t lds16(const void *p) { return *reinterpret_cast<const u32x4_t *>(p); }
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
-// activation slice one lane needs for one pass (8 super-blocks per wave, lane -> (sb, 16-code piece))
+// Two lane roles (round 4).  NARROW: 8 lanes per super-block, a lane takes one 16-byte piece of the codes (32 weights), a pass of the wave covers 8
+// super-blocks = 2048 weights.  WIDE (Q4_K, Q5_K): 4 lanes per super-block, a lane takes one whole 64-weight chunk (32 bytes of qs: low nibbles = sub-block
+// 2c, high nibbles = sub-block 2c + 1 - the unit ggml's own loops walk), a pass covers 16 super-blocks = 4096 weights.  The per-lane work that does not
+// depend on the number of weights (d / dmin conversion, the 6-bit scale / min extraction, the integer -> f32 fold) is then paid once per 64 weights instead
+// of once per 32: the decode was instruction-bound (rocprofv3 --pmc: the SIMDs of ffn_down / Q | K | V issue back to back; a build with 17 % fewer dot
+// instructions ran the layer's mat-vecs 3.8 % faster), and the wide role issues ~37 % fewer instructions per weight.  Integer sums per sub-block are what
+// they were; only the f32 association over the lanes changes (one lane's term now covers 64 weights).
+template <int TYPE> constexpr bool role_wide() { return TYPE == T_Q4_K || TYPE == T_Q5_K; }
+template <int TYPE> constexpr int role_sbp() { return role_wide<TYPE>() ? 16 : 8; }                       // super-blocks per pass of a wave
+template <int TYPE, int KB> constexpr int role_passes() { return role_wide<TYPE>() ? (KB + 1) / 2 : KB; }  // passes for K <= KB * 2048
+
+// activation slice one lane needs for one pass
 struct ActSlice {
-    u32x4_t lo, hi;      // 16 + 16 int8 codes
+    u32x4_t lo, hi;      // narrow: 16 + 16 int8 codes; wide: codes 0..15 / 32..47 of the chunk
+    u32x4_t lo1, hi1;    // wide only: codes 16..31 / 48..63
     float yd;          // Q8_K block scale
-    int bs_lo, bs_hi;  // sums of the two 16-code groups
+    int bs_lo, bs_hi;  // sums of the two 16-code groups (wide: of the two 32-code sub-blocks)
 };
 
 struct LaneRole {      // constants of this lane, computed once
-    int sbl;           // super-block within the pass (0..7)
+    int sbl;           // super-block within the pass (narrow 0..7, wide 0..15)
     int v, c, h;       // piece (0..7), chunk (0..3), half (0..1)
     int sh;            // bit shift selecting this chunk's 16-bit scale pair
     bool hi_scales;    // c >= 2: 6-bit scales split across bytes
     int n, w;          // Q6_K: half (0..1) and 16-code column (0..3)
+    // the 6-bit scale / min pair of this chunk without a branch (get_scale_min_k4 for sub-blocks 2c, 2c + 1): with y, z, w = the three scale words,
+    //   sc = ((hi_scales ? w : y) >> sh & m1) | (y >> (sh + 2) & m2),   mn = ((hi_scales ? w : z) >> sh_mn & m1) | (z >> (sh + 2) & m2)
+    uint32_t m1, m2; int sh_mn;
 };
+// sub-block scales and mins of chunk c from the 12 scale bytes (words y, z, w of the block header), two 6-bit values each in bits 0..5 / 8..13
+__device__ __forceinline__ void k4_scales(uint32_t y, uint32_t z, uint32_t w, const LaneRole &L, uint32_t &sc, uint32_t &mn) {
+    const uint32_t xs = L.hi_scales ? w : y, xm = L.hi_scales ? w : z;
+    sc = ((xs >> L.sh) & L.m1) | ((y >> (L.sh + 2)) & L.m2);
+    mn = ((xm >> L.sh_mn) & L.m1) | ((z >> (L.sh + 2)) & L.m2);
+}
 
 template <int TYPE> struct Raw;
+// sum of the two int16 halves of a word (one v_dot2_i32_i16)
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sum2_i16(uint32_t w) {
+    const i16x2_t one = {1, 1};
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, w), one, 0, false);
+}
 
-// ---------------------------------------------------------------- Q4_K
+// ---------------------------------------------------------------- Q4_K (wide role: lane = (super-block, chunk c); qs bytes 32 c .. 32 c + 31)
 template <> struct Raw<T_Q4_K> {
-    u32x4_t hdr, q;
+    u32x4_t hdr, q, q1;
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
         const uint8_t *b = row + (size_t)sb * 144;
         hdr = ldw(b);
-        q = ldw(b + 16 + L.v * 16);
+        q = ldw(b + 16 + L.c * 32);
+        q1 = ldw(b + 32 + L.c * 32);
     }
-    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ hdr.y ^ hdr.z ^ hdr.w ^ q.x ^ q.y ^ q.z ^ q.w); }
+    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ hdr.y ^ hdr.z ^ hdr.w ^ q.x ^ q.y ^ q.z ^ q.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w); }
     __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
         const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
-        const uint32_t a16 = (hdr.y >> L.sh) & 0xffff, b16 = (hdr.z >> L.sh) & 0xffff, c16 = (hdr.w >> L.sh) & 0xffff;
-        const uint32_t sc = L.hi_scales ? ((c16 & 0x0f0f) | ((a16 >> 2) & 0x3030)) : (a16 & 0x3f3f);
-        const uint32_t mn = L.hi_scales ? (((c16 >> 4) & 0x0f0f) | ((b16 >> 2) & 0x3030)) : (b16 & 0x3f3f);
+        uint32_t sc, mn;
+        k4_scales(hdr.y, hdr.z, hdr.w, L, sc, mn);
         int dl = 0, dh = 0;
         dl = dot4(q.x & 0x0f0f0f0f, A.lo.x, dl); dh = dot4((q.x >> 4) & 0x0f0f0f0f, A.hi.x, dh);
         dl = dot4(q.y & 0x0f0f0f0f, A.lo.y, dl); dh = dot4((q.y >> 4) & 0x0f0f0f0f, A.hi.y, dh);
         dl = dot4(q.z & 0x0f0f0f0f, A.lo.z, dl); dh = dot4((q.z >> 4) & 0x0f0f0f0f, A.hi.z, dh);
         dl = dot4(q.w & 0x0f0f0f0f, A.lo.w, dl); dh = dot4((q.w >> 4) & 0x0f0f0f0f, A.hi.w, dh);
+        dl = dot4(q1.x & 0x0f0f0f0f, A.lo1.x, dl); dh = dot4((q1.x >> 4) & 0x0f0f0f0f, A.hi1.x, dh);
+        dl = dot4(q1.y & 0x0f0f0f0f, A.lo1.y, dl); dh = dot4((q1.y >> 4) & 0x0f0f0f0f, A.hi1.y, dh);
+        dl = dot4(q1.z & 0x0f0f0f0f, A.lo1.z, dl); dh = dot4((q1.z >> 4) & 0x0f0f0f0f, A.hi1.z, dh);
+        dl = dot4(q1.w & 0x0f0f0f0f, A.lo1.w, dl); dh = dot4((q1.w >> 4) & 0x0f0f0f0f, A.hi1.w, dh);
         const int isum = mul24((int)(sc & 0xff), dl) + mul24((int)(sc >> 8), dh);
 #ifdef MI355_EXP_NO_MINS       // tools/build_exp_r4.sh only: a cheaper (wrong) dot, to see how far the decode time follows the instruction count
         return (d * A.yd) * (float)isum + (float)(mn & 1);
@@ -61,21 +92,22 @@ template <> struct Raw<T_Q4_K> {
     }
 };
 
-// ---------------------------------------------------------------- Q5_K
+// ---------------------------------------------------------------- Q5_K (wide role; the chunk's fifth bits are bits 2 c and 2 c + 1 of the 32 qh bytes)
 template <> struct Raw<T_Q5_K> {
-    u32x4_t hdr, qh, q;
-    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ qh.x ^ q.x ^ q.y ^ q.z ^ q.w); }
+    u32x4_t hdr, qh, qh1, q, q1;
+    __device__ __forceinline__ float probe() const { return (float)(hdr.x ^ qh.x ^ qh1.x ^ q.x ^ q.y ^ q.z ^ q.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w); }
     __device__ __forceinline__ void load(const uint8_t *row, int nb, int sb, const LaneRole &L) {
         const uint8_t *b = row + (size_t)sb * 176;
         hdr = ldw(b);
-        qh = ldw(b + 16 + L.h * 16);
-        q = ldw(b + 48 + L.v * 16);
+        qh = ldw(b + 16);
+        qh1 = ldw(b + 32);
+        q = ldw(b + 48 + L.c * 32);
+        q1 = ldw(b + 64 + L.c * 32);
     }
     __device__ __forceinline__ float dot(const ActSlice &A, const LaneRole &L) const {
         const float d = h2f((uint16_t)(hdr.x & 0xffff)), dmin = h2f((uint16_t)(hdr.x >> 16));
-        const uint32_t a16 = (hdr.y >> L.sh) & 0xffff, b16 = (hdr.z >> L.sh) & 0xffff, c16 = (hdr.w >> L.sh) & 0xffff;
-        const uint32_t sc = L.hi_scales ? ((c16 & 0x0f0f) | ((a16 >> 2) & 0x3030)) : (a16 & 0x3f3f);
-        const uint32_t mn = L.hi_scales ? (((c16 >> 4) & 0x0f0f) | ((b16 >> 2) & 0x3030)) : (b16 & 0x3f3f);
+        uint32_t sc, mn;
+        k4_scales(hdr.y, hdr.z, hdr.w, L, sc, mn);
         const int s0 = 2 * L.c, s1 = s0 + 1;
         int dl = 0, dh = 0;
 #define Q5L(w, hw) (((w) & 0x0f0f0f0f) | ((((hw) >> s0) & 0x01010101u) << 4))
@@ -84,6 +116,10 @@ template <> struct Raw<T_Q5_K> {
         dl = dot4(Q5L(q.y, qh.y), A.lo.y, dl); dh = dot4(Q5H(q.y, qh.y), A.hi.y, dh);
         dl = dot4(Q5L(q.z, qh.z), A.lo.z, dl); dh = dot4(Q5H(q.z, qh.z), A.hi.z, dh);
         dl = dot4(Q5L(q.w, qh.w), A.lo.w, dl); dh = dot4(Q5H(q.w, qh.w), A.hi.w, dh);
+        dl = dot4(Q5L(q1.x, qh1.x), A.lo1.x, dl); dh = dot4(Q5H(q1.x, qh1.x), A.hi1.x, dh);
+        dl = dot4(Q5L(q1.y, qh1.y), A.lo1.y, dl); dh = dot4(Q5H(q1.y, qh1.y), A.hi1.y, dh);
+        dl = dot4(Q5L(q1.z, qh1.z), A.lo1.z, dl); dh = dot4(Q5H(q1.z, qh1.z), A.hi1.z, dh);
+        dl = dot4(Q5L(q1.w, qh1.w), A.lo1.w, dl); dh = dot4(Q5H(q1.w, qh1.w), A.hi1.w, dh);
 #undef Q5L
 #undef Q5H
         const int isum = mul24((int)(sc & 0xff), dl) + mul24((int)(sc >> 8), dh);
@@ -261,9 +297,11 @@ template <> struct Raw<T_IQ4_NL> : RawNib32<T_IQ4_NL> {};
 
 template <int TYPE> __device__ __forceinline__ LaneRole make_role(int lane) {
     LaneRole L;
-    L.sbl = lane >> 3; L.v = lane & 7; L.c = L.v >> 1; L.h = L.v & 1;
+    if (role_wide<TYPE>()) { L.sbl = lane >> 2; L.c = lane & 3; L.v = 2 * L.c; L.h = 0; }
+    else { L.sbl = lane >> 3; L.v = lane & 7; L.c = L.v >> 1; L.h = L.v & 1; }
     L.sh = (L.c & 1) * 16; L.hi_scales = L.c >= 2;
     L.n = L.v >> 2; L.w = L.v & 3;
+    L.m1 = L.hi_scales ? 0x0f0fu : 0x3f3fu; L.m2 = L.hi_scales ? 0x3030u : 0u; L.sh_mn = L.sh + (L.hi_scales ? 4 : 0);
     return L;
 }
 
@@ -280,7 +318,12 @@ __device__ __forceinline__ ActSlice read_slice(const ActL &A, int sb, const Lane
         s.yd = reinterpret_cast<const float *>(A.bs)[sb * 8 + L.v];
         return s;
     }
-    if (TYPE == T_Q6_K) {
+    if (role_wide<TYPE>()) {           // the chunk's 64 codes; block sums of its two 32-weight sub-blocks
+        const int8_t *a = A.qs + sb * 256 + 64 * L.c;
+        s.lo = lds16(a); s.lo1 = lds16(a + 16); s.hi = lds16(a + 32); s.hi1 = lds16(a + 48);
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(A.bs + sb * 16 + 4 * L.c);      // four int16 sums, 8-byte aligned
+        s.bs_lo = sum2_i16(bw[0]); s.bs_hi = sum2_i16(bw[1]);
+    } else if (TYPE == T_Q6_K) {
         const int8_t *a = A.qs + sb * 256 + 128 * L.n + 16 * L.w;
         s.lo = lds16(a); s.hi = lds16(a + 64);
         const int16_t *b = A.bs + sb * 16 + 8 * L.n + L.w;
@@ -313,7 +356,12 @@ __device__ __forceinline__ ActSlice global_slice(const MMVQArgs &a, int sb, cons
         s.yd = h2f((uint16_t)(cld2s<COH>(a.ad0, (sb * 8 + L.v) * 2) & 0xffff));
         return s;
     }
-    if (TYPE == T_Q6_K) {
+    if (role_wide<TYPE>()) {
+        const int qo = sb * 256 + 64 * L.c;
+        s.lo = cld16<COH>(a.aq, qo); s.lo1 = cld16<COH>(a.aq, qo + 16); s.hi = cld16<COH>(a.aq, qo + 32); s.hi1 = cld16<COH>(a.aq, qo + 48);
+        const int bo = (sb * 16 + 4 * L.c) * 2;
+        s.bs_lo = cld2s<COH>(a.abs, bo) + cld2s<COH>(a.abs, bo + 2); s.bs_hi = cld2s<COH>(a.abs, bo + 4) + cld2s<COH>(a.abs, bo + 6);
+    } else if (TYPE == T_Q6_K) {
         const int qo = sb * 256 + 128 * L.n + 16 * L.w;
         s.lo = cld16<COH>(a.aq, qo); s.hi = cld16<COH>(a.aq, qo + 64);
         const int bo = (sb * 16 + 8 * L.n + L.w) * 2;
@@ -471,13 +519,14 @@ struct NoSync { __device__ __forceinline__ void operator()() const {} };
 template <int TYPE, int KB, int NT, int FUSE, bool PRE = false, class Sync = NoSync>
 __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, uint8_t *smem, int gw, int nw, Sync sync = Sync(), int sel_j = 0) {
     using R = Raw<TYPE>;
-    constexpr bool ACT_REGS = KB <= 2;
+    constexpr int NP = role_passes<TYPE, KB>(), SBP = role_sbp<TYPE>();     // passes of the wave over a row, super-blocks per pass (lane role: narrow / wide)
+    constexpr bool ACT_REGS = NP <= 2;
     constexpr bool DIRECT = ACT_REGS && FUSE == 0;
     constexpr bool COH = PRE;                            // one phase of a longer kernel: what other workgroups wrote / will read is accessed device-coherently
     const int nb = a.K >> 8;                            // super-blocks per row (the last pass may be partial: K % 256 == 0)
-    constexpr int PPU = (KB % 2 == 0) ? 2 : 1;          // passes per unit
-    constexpr int NCH = KB / PPU;                       // units per row pair
-    constexpr int NSETS = 4 / PPU;                      // register sets in the ring (2 rows x PPU passes each)
+    constexpr int PPU = (NP % 2 == 0) ? 2 : 1;          // passes per unit
+    constexpr int NCH = NP / PPU;                       // units per row pair
+    constexpr int NSETS = (role_wide<TYPE>() ? 2 : 4) / PPU;   // register sets in the ring (2 rows x PPU passes each; a wide block holds twice the bytes)
     const int lane = tid_now() & 63;
     const LaneRole L = make_role<TYPE>(lane);
     const bool swiglu = a.epi == EPI_SWIGLU;
@@ -498,7 +547,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
     auto issue_act = [&]() {
         if (DIRECT) {
             S0 = global_slice_t<TYPE, COH>(a, L.sbl, nb, L);
-            if (KB > 1) S1 = global_slice_t<TYPE, COH>(a, 8 + L.sbl, nb, L);
+            if (NP > 1) S1 = global_slice_t<TYPE, COH>(a, SBP + L.sbl, nb, L);
         } else {
             stage_issue<KB, NT, FUSE, COH>(a, STAGE_REGS_ARGS, nx_off);
         }
@@ -516,11 +565,11 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
             ra = W0 + (size_t)(2 * pair) * rb0;
             rbp = (2 * pair + 1 < sg.n_rows) ? ra + rb0 : ra;       // odd tail: row b re-reads row a, result discarded
         }
-        int sb0 = ch * PPU * 8 + L.sbl;
+        int sb0 = ch * PPU * SBP + L.sbl;
         if (!real) { ra = W0; rbp = W0; sb0 = L.sbl; }              // nothing to fetch: everybody's dummy is row 0, pass 0
 #pragma unroll
         for (int p = 0; p < PPU; p++) {
-            int sb = sb0 + 8 * p;
+            int sb = sb0 + SBP * p;
             if (sb >= nb) sb = nb - 1;                  // tail of a partial last pass: any valid block, its slice scale is zero
             w[2 * p].load(ra, nb, sb, L);
             w[2 * p + 1].load(rbp, nb, sb, L);
@@ -536,7 +585,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
         AL = stage_finish<KB, NT, FUSE, act_is_q80(TYPE)>(a, STAGE_REGS_ARGS, smem);
         if (ACT_REGS) {
             S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
-            if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
+            if (NP > 1) S1 = read_slice_t<TYPE>(AL, SBP + L.sbl, nb, L);
         }
     }
 
@@ -545,7 +594,7 @@ __device__ __forceinline__ void run_fast(const MMVQArgs &a, const MMVQSeg &sg, u
         const int pi = u / NCH, ch = u - pi * NCH;
 #pragma unroll
         for (int p = 0; p < PPU; p++) {
-            const ActSlice sl = ACT_REGS ? (ch * PPU + p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, (ch * PPU + p) * 8 + L.sbl, nb, L);
+            const ActSlice sl = ACT_REGS ? (ch * PPU + p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, (ch * PPU + p) * SBP + L.sbl, nb, L);
             acc0 += w[2 * p].dot(sl, L);
             acc1 += w[2 * p + 1].dot(sl, L);
         }

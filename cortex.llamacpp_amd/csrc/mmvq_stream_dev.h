@@ -96,13 +96,16 @@ template <bool IL> __device__ __forceinline__ const uint8_t *ring_at(const uint8
 template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q4_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
     const unsigned b = row_off + (unsigned)sb * 144u;
     r.hdr = lds16(RO(b));
-    r.q = lds16(RO(b + 16u + (unsigned)L.v * 16u));
+    r.q = lds16(RO(b + 16u + (unsigned)L.c * 32u));
+    r.q1 = lds16(RO(b + 32u + (unsigned)L.c * 32u));
 }
 template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q5_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
     const unsigned b = row_off + (unsigned)sb * 176u;
     r.hdr = lds16(RO(b));
-    r.qh = lds16(RO(b + 16u + (unsigned)L.h * 16u));
-    r.q = lds16(RO(b + 48u + (unsigned)L.v * 16u));
+    r.qh = lds16(RO(b + 16u));
+    r.qh1 = lds16(RO(b + 32u));
+    r.q = lds16(RO(b + 48u + (unsigned)L.c * 32u));
+    r.q1 = lds16(RO(b + 64u + (unsigned)L.c * 32u));
 }
 template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q6_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
     r.ql = lds16(RO(row_off + (unsigned)sb * 128u + (unsigned)L.v * 16u));
@@ -511,7 +514,8 @@ __device__ __forceinline__ int loader_planes(const StOp &a, uint8_t *smem, const
 template <int TYPE, int KB, int FUSE, bool SWIGLU, bool PAIR, int ENG = 0>
 __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c, unsigned g0, const StLayout &lay, const EngIO &io = EngIO()) {
     using R = Raw<TYPE>;
-    constexpr bool ACT_REGS = KB <= 2;
+    constexpr int NP = role_passes<TYPE, KB>(), SBP = role_sbp<TYPE>();   // passes over a row and super-blocks per pass of this type's lane role
+    constexpr bool ACT_REGS = NP <= 2;
     constexpr int STEP = (SWIGLU || PAIR) ? 2 : 1;                // rows decoded together
     constexpr int UO = (PAIR && !SWIGLU) ? 2 : 1;                 // outputs per step
     const int lane = tid_now() & 63;
@@ -550,7 +554,7 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     ActSlice S0, S1;
     if (ACT_REGS) {
         S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L);
-        if (KB > 1) S1 = read_slice_t<TYPE>(AL, 8 + L.sbl, nb, L);
+        if (NP > 1) S1 = read_slice_t<TYPE>(AL, SBP + L.sbl, nb, L);
     }
 
     float res = 0.0f;                                             // lane i: output i of this wave (64 per flush) ...
@@ -599,10 +603,10 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
         float acc0 = 0.0f, acc1 = 0.0f;
         // K <= 4096: both passes in flight at once; longer rows: two passes at a time (fully unrolled, the compiler hoists
         // every pass's ring reads to the top: 246+ registers at 7 passes)
-#pragma unroll KB <= 2 ? KB : 2
-        for (int p = 0; p < KB; p++) {
-            const ActSlice sl = ACT_REGS ? (p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, p * 8 + L.sbl, nb, L);
-            int sb = p * 8 + L.sbl;
+#pragma unroll NP <= 2 ? NP : 2
+        for (int p = 0; p < NP; p++) {
+            const ActSlice sl = ACT_REGS ? (p == 0 ? S0 : S1) : read_slice_t<TYPE>(AL, p * SBP + L.sbl, nb, L);
+            int sb = p * SBP + L.sbl;
             if (sb >= nb) sb = nb - 1;                            // tail of a partial last pass: any valid block, its slice scale is zero
             R w0, w1;
             ring_load<SWIGLU>(w0, ring, base0, off0, nb, sb, L);

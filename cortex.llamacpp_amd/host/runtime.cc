@@ -654,7 +654,8 @@ bool Context::init(std::string &err) {
     if (hipMemset(att_counters_, 0, 256 * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
     d_step_serial_ = (unsigned *)dalloc(64);
     d_ao_flags_ = (unsigned *)dalloc((size_t)std::max(1, hp.n_layer) * 64 * sizeof(unsigned));
-    if (!d_step_serial_ || !d_ao_flags_) { err = "step serial / flag allocation failed"; return false; }
+    d_ao_gran_ = (unsigned long long *)dalloc(attn_out_granule_words((int)(hp.n_head * D)) * 8);
+    if (!d_step_serial_ || !d_ao_flags_ || !d_ao_gran_) { err = "step serial / flag allocation failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
     argmax_scratch_ = (float *)dalloc(T * 129 * 4);     // T ticket words at the head, then per row 64 part values and 64 part indices (zero-filled: dalloc)
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
@@ -1333,15 +1334,15 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (fused_step) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch - and, where attn_out.hip has a form for the shape,
                 // the attn_output mat-vec with its residual add in that launch too
-                if (attn_mode == 2 && !engine) {
+                if (attn_mode == 2 && !engine && il < 255) {
                     const bool add = !tp || hp.tp_rank == 0;
                     const MMVQSeg so = make_seg(L.wo, tp ? tp_part_ : x_, E, add ? x_ : nullptr, nullptr);
                     AttnArgs af = aa;
                     af.splits = attn_out_fused_splits(af);
                     if (chunk_lmax_ > 0) af.splits = aa.splits;
                     if (attn_out_fused_applicable(af, ra, so, (int)L.wo.K, add ? EPI_ADD : EPI_STORE)) {
-                        HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64, d_step_serial_, so, (int)L.wo.K,
-                                                      add ? EPI_ADD : EPI_STORE, stream_));
+                        HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64, d_ao_gran_, il, d_step_serial_, so,
+                                                      (int)L.wo.K, add ? EPI_ADD : EPI_STORE, stream_));
                         attn_out_done = true;
                     }
                 }

@@ -321,6 +321,7 @@ def test_mega_step_matches_per_launch_bitwise(be, pkg, tmp_models, kv, graphs):
 
     def run(mega, n_seq_max, seq):
         be.set_option("decode_mega", 1 if mega else 0)
+        be.set_option("attn_out_fused", 0)      # the whole-step kernel holds the two-launch attention + attn_output arithmetic: compare like with like
         try:
             c = pkg.Context(m, n_ctx=512, n_seq_max=n_seq_max, type_k=KV[kv], type_v=KV[kv], use_graphs=graphs)
             assert c.decode(prompt, np.arange(40), seq=seq) == 0
@@ -332,6 +333,7 @@ def test_mega_step_matches_per_launch_bitwise(be, pkg, tmp_models, kv, graphs):
             c.close()
         finally:
             be.set_option("decode_mega", 0)
+            be.set_option("attn_out_fused", -1)
         return np.stack(rows)
 
     for n_seq_max, seq in ((1, 0), (4, 2)):
@@ -354,6 +356,7 @@ def test_layer_engine_matches_per_launch_bitwise(be, pkg, tmp_models, cfg, ftype
 
     def run(engine):
         be.set_option("decode_engine", 1 if engine else 0)
+        be.set_option("attn_out_fused", 0)      # the engine's launch starts at attn_output: the per-launch arm must run the two-launch attention it follows
         try:
             c = pkg.Context(m, n_ctx=256, type_k=KV[kv], type_v=KV[kv], use_graphs=graphs)
             rows = []
@@ -368,6 +371,7 @@ def test_layer_engine_matches_per_launch_bitwise(be, pkg, tmp_models, cfg, ftype
             c.close()
         finally:
             be.set_option("decode_engine", -1)
+            be.set_option("attn_out_fused", -1)
         return np.stack(rows)
 
     a, b = run(True), run(False)
