@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t nib_to_i8x4(uint32_t n) { return ((n | 0x808
 struct DecodeFuse {
     const float *knew, *vnew;      // [G*D] un-rotated K and V of the token
     const int32_t *tok_cell;       // [1]
-    unsigned *counters;            // [G], zero between launches
+    unsigned *counters;            // [G] words ATT_SYNC_STRIDE apart (a 128-byte line each), zero between launches
     ActQuant q;
     int want_q8k, want_q80;
     int neox;                      // rotary pairing (i, i + D / 2) instead of (2i, 2i + 1): qwen2-type files; the whole head rotates (n_rot == D)
@@ -411,10 +411,10 @@ __device__ __forceinline__ void flash_attn_decode_item(const AttnArgs &a, const 
     __syncthreads();
     if (tid == 0) {
         // ONE release per workgroup (the barrier ordered the other waves' stores before it), then the ticket
-        const unsigned old = COH ? __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = COH ? __hip_atomic_fetch_add(fz.counters + gq * ATT_SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : __hip_atomic_fetch_add(fz.counters + gq * ATT_SYNC_STRIDE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (old == (unsigned)(splits * GP) - 1u) ? 1 : 0;
-        if (last_flag) __hip_atomic_store(fz.counters + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        if (last_flag) __hip_atomic_store(fz.counters + gq * ATT_SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     __syncthreads();
     if (!last_flag) return;

@@ -35,10 +35,17 @@ namespace mi355 {
 
 namespace {
 
+#ifndef MI355_AO_POLL_SLEEP
+#define MI355_AO_POLL_SLEEP 1
+#endif
+// Every word several workgroups poll or count on has its 128-byte line to itself (ATT_SYNC_STRIDE words apart, kernels.h): with the eight ticket counters
+// in one line and the eight flags in another the step was 2.5 % slower (context filled: 4 %) - atomics and polls of different kv heads queued on one line
+// (same-box A/B, tools/ab_libs.sh).
 constexpr int AO_NT = 512, AO_NW = AO_NT / 64;
 constexpr int AO_D = 128, AO_NB = AO_D / 32, AO_NCG = AO_NT / (AO_D / 4);      // 16 cell groups of 32 lanes in the P.V pass
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int AO_GPB = 96;                     // granules per 256-block of the quantised attention output (attn_out_granule_words)
 constexpr int AO_REC = AO_D + 4;                // floats of a chunk's partial record per head: O [D] | m | l | 0 | 0 (whole 16-byte pieces)
 
 struct AOArgs {
@@ -48,7 +55,7 @@ struct AOArgs {
     int rows_per_wg;
     unsigned slice_lds;             // LDS bytes reserved for the workgroup's rows (whole 4 KiB slots)
     unsigned *flags;                // this layer's flag words, one per merge ticket group: "this group's merge has its sums" (the codes follow as granules)
-    unsigned long long *gran;       // the quantised attention output as tagged granules {tag, value}: [K / 4] four codes | [K / 16] block sums | [K / 256] scales
+    unsigned long long *gran;       // the quantised attention output as tagged granules {tag, value}, AO_GPB per 256-block: 64 x four codes | 16 block sums | scale
     int layer;                      // tag = serial * 256 + layer + 1: distinct per step and per layer (the granule buffer is shared by the layers of a step)
     const unsigned *serial;         // device word: the step's serial number (never 0)
     int n_flags, n_items;           // ticket groups; attention items = G * splits
@@ -123,7 +130,7 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
     constexpr int CL = C / 64;                               // cells per lane in the softmax
     const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
-    const int n_ctx = a.n_ctx, H = a.H;
+    const int n_ctx = a.n_ctx;
     int chunk = sp;
     if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
         if (sp >= a.tok_nchunks[0]) { dma(); return; }
@@ -389,9 +396,9 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     __syncthreads();
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(fz.counters + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(fz.counters + gq * ATT_SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sm.last_flag = (old == (unsigned)(splits * GP) - 1u) ? 1 : 0;
-        if (sm.last_flag) __hip_atomic_store(fz.counters + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        if (sm.last_flag) __hip_atomic_store(fz.counters + gq * ATT_SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     __syncthreads();
     // the W_o rows may queue now: nothing of this item is outstanding any more and nobody waits for this workgroup (36 KB of DMA in front of the partial
@@ -465,9 +472,8 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
     // store, nothing to fence or drain - and every consumer sweeps them until each carries this step's tag: its first sweep is in flight while the codes
     // are being written.
     const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
-    if (tid == 0) __hip_atomic_store(o.flags + gq, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(o.flags + gq * ATT_SYNC_STRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int NBLK = (RM * D) >> 8;                // 256-blocks this ticket group owns in the H * D row
-    const int K = H * D;
     const __amdgpu_buffer_rsrc_t grs = coh_rsrc(o.gran);
     for (int b = wave; b < NBLK; b += AO_NW) {
         const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(merged + b * 256 + lane * 4);
@@ -477,16 +483,17 @@ __device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_
         wave_quant_q8k(vv, lane, packed, bs, dq8);
         // two granules per 16-byte write-through store (each 8-byte half carries its own tag): the even lane takes its neighbour's word
         const uint32_t packed1 = (uint32_t)dpp_i<DPP_QP_1032>((int)packed);
+        // a block's granules: [64 x four codes | 16 block sums | scale, 15 unused] = AO_GPB granules = six 128-byte lines that no other merger writes
         if ((lane & 1) == 0) {
             const coh_u32x4 g2 = {packed, tag, packed1, tag};
-            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, (gb * 64 + lane) * 8, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, (gb * AO_GPB + lane) * 8, 0, 16);
         }
         const int bs1 = dpp_i<0x104>(bs);             // row_shl:4 - the block sum four lanes further on (the next 16-code group)
         if ((lane & 7) == 0) {
             const coh_u32x4 g2 = {(unsigned)bs & 0xffffu, tag, (unsigned)bs1 & 0xffffu, tag};
-            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, ((K >> 2) + gb * 16 + (lane >> 2)) * 8, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, (gb * AO_GPB + 64 + (lane >> 2)) * 8, 0, 16);
         }
-        if (lane == 0) st_store_granule(o.gran + (K >> 2) + (K >> 4) + gb, tag, __float_as_uint(dq8));
+        if (lane == 0) st_store_granule(o.gran + gb * AO_GPB + 80, tag, __float_as_uint(dq8));
     }
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 3] = wall_clock64();
     for (int e = tid; e < RM * D; e += NT) a.out[(size_t)hb * D + e] = merged[e];   // (the f32 rows: nobody in this launch reads them)
@@ -576,33 +583,38 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
     // ---- the merged, quantised attention output: wait until every ticket group's merge has its sums (one wave polls, relaxed, bounded), then every wave
     // sweeps its share of the granules until each carries this step's tag and puts the values where the decoders expect the Q8_K planes
     const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
+    // (ONE polling wave per workgroup: four of them, a quarter of a round trip apart, noticed the flags earlier and still cost 1.3 % of the step - 1024
+    // pollers on eight words slow the mergers' own traffic down; same-box A/B, tools/ab_libs.sh)
     if (wave == 0) {
         int spins = 0;
         for (;;) {
             unsigned v = tag;
-            if (lane < o.n_flags) v = __hip_atomic_load(o.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < o.n_flags) v = __hip_atomic_load(o.flags + lane * ATT_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(v == tag)) break;
             if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(MI355_AO_POLL_SLEEP);
         }
         asm volatile("" ::: "memory");
     }
     __syncthreads();
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 4] = wall_clock64();
     {
-        const int K = o.K, nq = K >> 2, nbs = K >> 4, ng = nq + nbs + (K >> 8), np = ng >> 1;      // (granule pairs: K is a multiple of 512 here)
-        constexpr int PPT = ((8192 / 4 + 8192 / 16 + 8192 / 256) / 2 + AO_NT - 1) / AO_NT;      // pairs per thread at the longest K the launch takes
+        constexpr int PPB = 41;                        // granule pairs a block holds (32 of codes, 8 of block sums, 1 = scale + an unused word)
+        const int nb = o.K >> 8, np = nb * PPB;
+        constexpr int PPT = (32 * PPB + AO_NT - 1) / AO_NT;      // pairs per thread at the longest K the launch takes (8192)
         const __amdgpu_buffer_rsrc_t grs = coh_rsrc(o.gran);
         coh_u32x4 val[PPT];
+        int blk[PPT], w[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) { const int i = tid + AO_NT * j; blk[j] = i / PPB; w[j] = i - blk[j] * PPB; }
         int spins = 0;
         for (;;) {
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < PPT; j++) {
-                const int i = tid + AO_NT * j;
-                if (i < np) {
-                    val[j] = __builtin_amdgcn_raw_buffer_load_b128(grs, i * 16, 0, 16);
-                    ok = ok && val[j].y == tag && val[j].w == tag;
+                if (tid + AO_NT * j < np) {
+                    val[j] = __builtin_amdgcn_raw_buffer_load_b128(grs, (blk[j] * AO_GPB + 2 * w[j]) * 8, 0, 16);
+                    ok = ok && val[j].y == tag && (val[j].w == tag || w[j] == PPB - 1);
                 }
             }
             if (__all(ok)) break;
@@ -611,10 +623,10 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
         }
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-            const int i = 2 * (tid + AO_NT * j);          // first granule of the pair (nq and nbs are even: a pair never straddles two planes)
-            if (i < nq) { reinterpret_cast<unsigned *>(smem + lay.qs)[i] = val[j].x; reinterpret_cast<unsigned *>(smem + lay.qs)[i + 1] = val[j].z; }
-            else if (i < nq + nbs) reinterpret_cast<unsigned *>(smem + lay.bs)[(i - nq) >> 1] = (val[j].x & 0xffffu) | (val[j].z << 16);
-            else if (i < ng) { reinterpret_cast<unsigned *>(smem + lay.d)[i - nq - nbs] = val[j].x; reinterpret_cast<unsigned *>(smem + lay.d)[i - nq - nbs + 1] = val[j].z; }
+            if (tid + AO_NT * j >= np) continue;
+            if (w[j] < 32) { unsigned *q = reinterpret_cast<unsigned *>(smem + lay.qs) + blk[j] * 64 + 2 * w[j]; q[0] = val[j].x; q[1] = val[j].z; }
+            else if (w[j] < 40) reinterpret_cast<unsigned *>(smem + lay.bs)[blk[j] * 8 + (w[j] - 32)] = (val[j].x & 0xffffu) | (val[j].z << 16);
+            else reinterpret_cast<unsigned *>(smem + lay.d)[blk[j]] = val[j].x;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W_o rows (DMA) has landed
@@ -646,7 +658,7 @@ bool attn_out_fused_enabled() {
     static const bool env_off = getenv("MI355_ATTN_OUT_FUSED") && getenv("MI355_ATTN_OUT_FUSED")[0] == '0';
     return g_attn_out_fused < 0 ? !env_off : g_attn_out_fused > 0;
 }
-size_t attn_out_granule_words(int K) { return (size_t)(K / 4 + K / 16 + K / 256) + 64; }
+size_t attn_out_granule_words(int K) { return (size_t)(K / 256) * AO_GPB + 64; }
 void attn_out_set_error_word(unsigned *w) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_err_word), &w, sizeof(w)); }
 
 // chunk size the launch will use for a scan of n_kv_max cells: 64 cells while that gives every CU at most one item, 128 beyond
@@ -672,7 +684,7 @@ bool attn_out_fused_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQ
     if (a.G % gp != 0 || a.G / gp > 64) return false;
     if (!a.out_q || !a.out_q8k || a.out_q80) return false;
     if (wo.type != T_Q4_K && wo.type != T_Q5_K && wo.type != T_Q6_K) return false;
-    if (K != a.H * a.D || (K % 512) != 0 || K > 8192 || wo.expert_sel) return false;      // (512: the granules travel in pairs)
+    if (K != a.H * a.D || (K % 256) != 0 || K > 8192 || wo.expert_sel) return false;
     if ((wo.row_bytes % 16) != 0 || (reinterpret_cast<uintptr_t>(wo.W) & 15) != 0) return false;
     if (epi != EPI_ADD && epi != EPI_STORE) return false;
     const int C = attn_out_fused_chunk(a);

@@ -628,7 +628,7 @@ int mi355_op_attn_step(const float *q, const float *k_new, const float *v_new, i
     if (!grow || K % 256) { fail("bad attn_output type / K"); return MI355_ERR_ARG; }
     DevBuf dk(kc.size()), dks(ks.size() * 2 + 16), dv(vc.size()), dvs(vs.size() * 2 + 16);
     DevBuf dq((size_t)K * 4), dkn(kv_dim * 4), dvn(kv_dim * 4), datt((size_t)K * 4), dcp((size_t)n_cells * 4), dcs((size_t)n_cells * 8), dtp(16), dts(16), dn(16), dcell(16);
-    DevBuf wsrc(grow * E), wdev(drow * E), dres((size_t)E * 4), dout((size_t)E * 4), dcnt(256 * 4), dflags(64 * 4), dserial(64), dcsb((size_t)std::max(n_rot, 4) * 4 + 64);
+    DevBuf wsrc(grow * E), wdev(drow * E), dres((size_t)E * 4), dout((size_t)E * 4), dcnt(64 * ATT_SYNC_STRIDE * 4), dflags(64 * ATT_SYNC_STRIDE * 4), dserial(64), dcsb((size_t)std::max(n_rot, 4) * 4 + 64);
     ActBufs ab((size_t)K, 1);
     if (!dk.up(kc.data(), kc.size()) || !dv.up(vc.data(), vc.size()) || !dq.up(q, (size_t)K * 4) || !dkn.up(k_new, kv_dim * 4) || !dvn.up(v_new, kv_dim * 4) ||
         !wsrc.up(W_o, grow * E) || !wdev.p || !dres.up(resid, (size_t)E * 4) || !dout.p || !ab.ok() || !datt.p) { fail("device alloc/copy failed"); return MI355_ERR_OOM; }

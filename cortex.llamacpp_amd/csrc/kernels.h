@@ -220,6 +220,8 @@ hipError_t launch_moe_gather_act(const ActQuant &src, const int32_t *tok_of, int
 hipError_t launch_moe_scatter_combine(float *x, const float *y, const float *w, const int32_t *slot_of, int T, int E, int k, hipStream_t st);
 
 // ---------------------------------------------------------------- attention side (attn.hip)
+// words between two merge-ticket counters / hand-over flags of the decode attention kernels (attn_decode_dev.h, attn_out.hip): one 128-byte line each
+constexpr int ATT_SYNC_STRIDE = 32;
 struct KVLayerView {
     // head-major cache planes of one layer: cell c of kv-head g
     //   f16 : k + ((g*n_ctx + c) * D) * 2

@@ -66,10 +66,13 @@ __global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
         int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
         LoaderState st{0, 0, 0, (unsigned)ST_RING_SLOTS, 0};
         if (FUSE == 0 && wave == 0) st.pre = loader_planes(a, smem, st_layout(KB), lane);
-        // the consumers' own requests go first: a load queued behind this wave's 60 KiB waits for all of it
-        ST_SPIN_WHILE(ld_sync(sy + SY_GO) < ST_NC, 0);
+        // the consumers' own requests go first: a load queued behind this wave's 60 KiB waits for all of it.  A launch bound by its stream (its share
+        // of the weights exceeds the ring, and the prologue reads two 16 KB vectors: gate | up, the output head) lets the stream have a head start of
+        // ST_EARLY slots per loader first
+        const int early = (FUSE == 1 && a.ns_pad > ST_RING_SLOTS) ? ST_EARLY : 0;
+        if (early == 0) ST_SPIN_WHILE(ld_sync(sy + SY_GO) < ST_NC, 0);
         ST_STAMP(2);
-        loader_op(st, a, smem, wave, 0u, lane);
+        loader_op(st, a, smem, wave, 0u, lane, early);
         ST_STAMP(1);
         loader_drain(st, smem, wave);
         ST_STAMP(5);

@@ -32,6 +32,10 @@ constexpr int ST_D = MI355_STREAM_DEPTH;        // slots in flight per loader (4
 #ifndef MI355_STREAM_THIN_DEPTH
 #define MI355_STREAM_THIN_DEPTH 2
 #endif
+#ifndef MI355_STREAM_EARLY
+#define MI355_STREAM_EARLY 0
+#endif
+constexpr int ST_EARLY = MI355_STREAM_EARLY;    // slots a loader of a stream-bound launch requests before the consumers' own requests are queued (0 = none)
 constexpr int ST_THIN_D = MI355_STREAM_THIN_DEPTH;   // slots in flight per loader while a wave of the CU gathers a hand-over (decode_engine.hip)
 constexpr int ST_MAX_STEP = 16384;              // bytes one decode step may span (a row, a row pair or one row of a gate/up pair)
 #ifndef MI355_ST_PAIR_MAX
@@ -433,9 +437,13 @@ __device__ __forceinline__ void loader_publish(LoaderState &st, int *sy, int q) 
     const int landed = done <= st.pre ? 0 : (done - st.pre) / ST_SI;
     if (landed > st.published) { st.published = landed; st_sync(sy + SY_LANDED + q, landed); }
 }
+// early_slots > 0 (a launch whose share of the weights exceeds the ring: it is bound by its stream, not by its prologue): this loader requests that many
+// slots BEFORE the consumers' own requests are queued ([SY_GO]) - a head start of the stream worth what it moves, for a bounded delay of those requests -
+// and waits for [SY_GO] only then
 template <bool THIN = false>
-__device__ __forceinline__ void loader_op(LoaderState &st, const StOp &a, uint8_t *smem, int q, unsigned g0, int lane) {
+__device__ __forceinline__ void loader_op(LoaderState &st, const StOp &a, uint8_t *smem, int q, unsigned g0, int lane, int early_slots = 0) {
     int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
+    bool go = early_slots <= 0;
     if (a.ns_pad == 0) return;
     const unsigned ring_lds = lds_addr(smem + ST_OFF_RING);
     const uint8_t *W = (a.swiglu && q == 1 ? a.W1 : a.W) + (size_t)a.b0 * a.row_bytes;
@@ -445,6 +453,7 @@ __device__ __forceinline__ void loader_op(LoaderState &st, const StOp &a, uint8_
     const uint8_t *pl = W + run_off + (size_t)lane * 16;                         // this lane's 16 B of it
     const int n_mine = a.ns_pad / 2;                                             // slots of this loader in the mat-vec
     for (int i = 0; i < n_mine;) {
+        if (!go && i >= early_slots) { ST_SPIN_WHILE(ld_sync(sy + SY_GO) < ST_NC, 0); go = true; }
         loader_publish(st, sy, q);
         const unsigned g = g0 + 2u * (unsigned)i + (unsigned)q;                  // global slot
         int depth = ST_D * ST_SI + st.pre <= 60 ? ST_D : (60 - st.pre) / ST_SI;   // (the counter read by vm_outstanding() saturates at 63)

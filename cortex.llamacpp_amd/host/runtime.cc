@@ -649,11 +649,11 @@ bool Context::init(std::string &err) {
         ws = std::max(ws, flash_attn_workspace_floats(t, hp.n_head, (int)D, flash_attn_prefill_splits(t, hp.n_head, (int)G, (int)D, (int)NC)));
     att_part_ = (float *)dalloc(ws * 4);
     att_part_floats_ = ws;
-    att_counters_ = (unsigned *)dalloc(256 * sizeof(unsigned));
+    att_counters_ = (unsigned *)dalloc(64 * ATT_SYNC_STRIDE * sizeof(unsigned));
     if (!att_part_ || !att_counters_) { err = "attention workspace allocation failed"; return false; }
-    if (hipMemset(att_counters_, 0, 256 * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
+    if (hipMemset(att_counters_, 0, 64 * ATT_SYNC_STRIDE * sizeof(unsigned)) != hipSuccess) { err = "hipMemset failed"; return false; }
     d_step_serial_ = (unsigned *)dalloc(64);
-    d_ao_flags_ = (unsigned *)dalloc((size_t)std::max(1, hp.n_layer) * 64 * sizeof(unsigned));
+    d_ao_flags_ = (unsigned *)dalloc((size_t)std::max(1, hp.n_layer) * 64 * ATT_SYNC_STRIDE * sizeof(unsigned));
     d_ao_gran_ = (unsigned long long *)dalloc(attn_out_granule_words((int)(hp.n_head * D)) * 8);
     if (!d_step_serial_ || !d_ao_flags_ || !d_ao_gran_) { err = "step serial / flag allocation failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
@@ -1341,7 +1341,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                     af.splits = attn_out_fused_splits(af);
                     if (chunk_lmax_ > 0) af.splits = aa.splits;
                     if (attn_out_fused_applicable(af, ra, so, (int)L.wo.K, add ? EPI_ADD : EPI_STORE)) {
-                        HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64, d_ao_gran_, il, d_step_serial_, so,
+                        HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64 * ATT_SYNC_STRIDE, d_ao_gran_, il, d_step_serial_, so,
                                                       (int)L.wo.K, add ? EPI_ADD : EPI_STORE, stream_));
                         attn_out_done = true;
                     }

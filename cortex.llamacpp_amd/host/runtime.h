@@ -242,7 +242,7 @@ class Context {
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     unsigned *d_step_serial_ = nullptr;  // device word: serial number of the step (incremented by the step's set-up launch; the hand-over tags / flags of attn_out.hip and decode_engine.hip)
     unsigned long long *d_ao_gran_ = nullptr;   // attn_out.hip: the quantised attention output as tagged granules (shared by the layers of a step)
-    unsigned *d_ao_flags_ = nullptr;     // attn_out.hip: [n_layer][64] flag words, one per merge ticket group (they hold the serial of the step that raised them)
+    unsigned *d_ao_flags_ = nullptr;     // attn_out.hip: [n_layer][64 * ATT_SYNC_STRIDE] flag words, one per merge ticket group (they hold the serial of the step that raised them)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;
     void *topk_scratch_ = nullptr;                     // launch_topk_rows workspace (own allocation, sized for topk_rows_cap_ rows on first use)
     uint8_t *d_topk_adj_ = nullptr, *h_topk_adj_ = nullptr;   // [cap] TopkAdj + [cap] row numbers: device copy and its pinned staging

@@ -1,0 +1,25 @@
+#!/bin/bash
+# same-box A/B of decode tok/s between builds of the library: tools/ab_libs.sh name=path.so [name=path.so ...]; alternates REPS times, prints every run
+# and the medians (first number: context 512 + steps, second: context filled to 3968)
+REPS=${REPS:-3}
+mkdir -p gpurun_out
+OUT=gpurun_out/ab_libs.txt
+: > $OUT
+python3 tools/time_decode.py 8 > /dev/null 2>&1      # writes the model file once
+for rep in $(seq 1 $REPS); do
+  for spec in "$@"; do
+    name=${spec%%=*}; lib=${spec#*=}
+    r=$(MI355_LLAMA_LIB=$PWD/$lib python3 tools/time_decode.py 192 2>/dev/null | tail -1)
+    echo "$name $r" | tee -a $OUT
+  done
+done
+python3 - <<'PY' | tee -a gpurun_out/ab_libs.txt
+import statistics, collections
+d = collections.defaultdict(list)
+for l in open('gpurun_out/ab_libs.txt'):
+    p = l.split()
+    if len(p) == 3:
+        d[p[0]].append((float(p[1]), float(p[2])))
+for k, v in d.items():
+    print(f"median {k}: {statistics.median(x[0] for x in v):.1f}  {statistics.median(x[1] for x in v):.1f}   ({len(v)} runs)")
+PY

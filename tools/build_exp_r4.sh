@@ -21,6 +21,8 @@ for v in "$@"; do
     nc14pair) build nc14pair "-DMI355_ST_NC=14 -DMI355_ST_PAIR_MAX=24576" & ;;
     probe) build probe "-DMI355_STREAM_PROBE" & ;;
     nomins) build nomins "-DMI355_EXP_NO_MINS" & ;;
+    early0) build early0 "-DMI355_STREAM_EARLY=0" & ;;
+    early4) build early4 "-DMI355_STREAM_EARLY=4" & ;;
     nc14probe) build nc14probe "-DMI355_ST_NC=14 -DMI355_STREAM_PROBE" & ;;
     *) echo "unknown variant $v"; exit 1 ;;
   esac
