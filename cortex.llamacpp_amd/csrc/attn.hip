@@ -842,8 +842,8 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     return hipGetLastError();
 }
 
-// (D + 4 floats per record: what attn_out.hip keeps per head and chunk; the other kernels use D + 2 of them)
-size_t flash_attn_workspace_floats(int T, int H, int D, int splits) { return (size_t)T * H * splits * (D + 4); }
+// (D + 32 floats per record: what attn_out.hip keeps per head and chunk - whole 128-byte lines; the other kernels use D + 2 of them)
+size_t flash_attn_workspace_floats(int T, int H, int D, int splits) { return (size_t)T * H * splits * (D + 32); }
 
 hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t st) {
     if (a.D != 64 && a.D != 128) return hipErrorInvalidValue;

@@ -38,6 +38,9 @@ namespace {
 #ifndef MI355_AO_POLL_SLEEP
 #define MI355_AO_POLL_SLEEP 1
 #endif
+#ifndef MI355_AO_SWEEP_SLEEP
+#define MI355_AO_SWEEP_SLEEP 1
+#endif
 // Every word several workgroups poll or count on has its 128-byte line to itself (ATT_SYNC_STRIDE words apart, kernels.h): with the eight ticket counters
 // in one line and the eight flags in another the step was 2.5 % slower (context filled: 4 %) - atomics and polls of different kv heads queued on one line
 // (same-box A/B, tools/ab_libs.sh).
@@ -46,7 +49,10 @@ constexpr int AO_D = 128, AO_NB = AO_D / 32, AO_NCG = AO_NT / (AO_D / 4);      /
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int AO_GPB = 96;                     // granules per 256-block of the quantised attention output (attn_out_granule_words)
-constexpr int AO_REC = AO_D + 4;                // floats of a chunk's partial record per head: O [D] | m | l | 0 | 0 (whole 16-byte pieces)
+#ifndef MI355_AO_REC
+#define MI355_AO_REC (AO_D + 4)
+#endif
+constexpr int AO_REC = MI355_AO_REC;            // floats of a chunk's partial record per head: O [D] | m | l | 0 | 0 (whole 16-byte pieces; padding the record to whole 128-byte lines measured no gain)
 
 struct AOArgs {
     const uint8_t *W; float *out; const float *resid;
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
             }
             if (__all(ok)) break;
             if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(MI355_AO_SWEEP_SLEEP);
         }
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
@@ -665,6 +671,9 @@ void attn_out_set_error_word(unsigned *w) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g
 int attn_out_fused_chunk(const AttnArgs &a) {
     const int s64 = (a.n_kv_max + 63) / 64;
     if (a.tok_chunks) return 64;                      // (the per-token chunk lists count 64-cell chunks)
+#ifdef MI355_AO_FORCE_C
+    if (MI355_AO_FORCE_C == 128 || MI355_AO_FORCE_C == 64) return (MI355_AO_FORCE_C == 64 && s64 > 64) ? 128 : MI355_AO_FORCE_C;   // (tools: A/B of the chunk size)
+#endif
     return s64 * a.G <= num_cu() && s64 <= 64 ? 64 : 128;
 }
 int attn_out_fused_splits(const AttnArgs &a) {
@@ -689,7 +698,8 @@ bool attn_out_fused_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQ
     if (epi != EPI_ADD && epi != EPI_STORE) return false;
     const int C = attn_out_fused_chunk(a);
     if (a.tok_chunks && C != 64) return false;
-    if (a.splits < 1 || a.splits > 64 || (size_t)a.splits * C < (size_t)a.n_kv_max) return false;
+    // (with per-token chunk lists the lists say which chunks matter: the scan length does not bound them)
+    if (a.splits < 1 || a.splits > 64 || (!a.tok_chunks && (size_t)a.splits * C < (size_t)a.n_kv_max)) return false;
     const int nwg = std::min(num_cu(), (wo.n_rows + 1) / 2);
     if (nwg < 1) return false;
     const int rpw = (wo.n_rows + nwg - 1) / nwg;
