@@ -424,9 +424,9 @@ def main() -> int:
                     "decode_hbm_fraction_of_8TBps": round((model.bytes_per_token + kv_l) * (long_host or n_l / dt_l) / (HBM_PEAK_GBPS * 1e9), 4)}
 
     # ---- roofline of the dominant kernel (quantised mat-vec), HIP events on the kernel's own stream
-    sweep_us, sweep_bytes = ctx.weight_sweep_us(iters=5)
-    n_launch = cfg.n_layer * 4 + 1                        # qkv, attn_output, gate+up, down per layer (all selected experts of a
-                                                          # mixture-of-experts layer share the two launches) + lm-head
+    # the launches of the weight-stream kernel as the step issues them: qkv, gate+up, down per layer (all selected experts of a mixture-of-experts layer
+    # share the two launches) + lm-head; attn_output is one of them only where it does not run inside the attention launch (attn_out.hip, round 4)
+    sweep_us, sweep_bytes, n_launch = ctx.weight_sweep(iters=5)
     achieved = sweep_bytes / (sweep_us * 1e-6) / 1e9
     hbm_read = pkg.Backend().hbm_read_gbps(2 << 30, 5)
 
@@ -494,9 +494,10 @@ def main() -> int:
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
             "traffic_source": traffic_note,
-            "method": "the step's own fused single-token launches of every weight tensor (129 for this model), replayed from a hipGraph, HIP events on the "
-                      "context's stream; achieved = algorithmic weight bytes / sweep time, so launch boundaries count as kernel time (rounds 2-3; round 1 "
-                      "swept unfused eager launches: its 0.441 is not comparable)",
+            "method": "the step's own launches of the weight-stream kernel (Q|K|V, gate|up, ffn_down of every layer + the output head: 97 for this model; "
+                      "attn_output runs inside the attention launch since round 4 and is neither launched nor counted here), replayed from a hipGraph, HIP "
+                      "events on the context's stream; achieved = algorithmic weight bytes of those launches / sweep time, so launch boundaries count as "
+                      "kernel time",
             "bytes_per_sweep": int(sweep_bytes),
             "launches_per_sweep": n_launch,
             "avg_launch_us": round(sweep_us / n_launch, 3),

@@ -107,6 +107,7 @@ SYMBOLS = {
     "mi355_profile_last_decode": (_i32, [_vp, C.POINTER(_cp), C.POINTER(_f32), _i32]),
     "mi355_profile_enable": (None, [_vp, _i32]),
     "mi355_bench_weight_sweep": (C.c_double, [_vp, C.c_int, C.POINTER(_u64)]),
+    "mi355_bench_weight_sweep2": (C.c_double, [_vp, C.c_int, C.POINTER(_u64), C.POINTER(C.c_int32)]),
     "mi355_tokenize": (_i32, [_vp, _cp, _i32, C.POINTER(C.c_int32), _i32, _i32, _i32]),
     "mi355_token_to_piece": (_i32, [_vp, _i32, C.c_char_p, _i32, _i32]),
     "mi355_token_bos": (_i32, [_vp]),
@@ -570,6 +571,12 @@ class Context:
         b = _u64(0)
         us = self.lib.mi355_bench_weight_sweep(self.h, iters, C.byref(b))
         return float(us), int(b.value)
+
+    def weight_sweep(self, iters: int = 5):
+        """(us per sweep, weight bytes per sweep, mat-vec launches per sweep) of the step's own weight-stream launches."""
+        b, n = _u64(0), C.c_int32(0)
+        us = self.lib.mi355_bench_weight_sweep2(self.h, iters, C.byref(b), C.byref(n))
+        return float(us), int(b.value), int(n.value)
 
     def close(self):
         if self._b is not None:

@@ -262,6 +262,12 @@ int32_t mi355_profile_last_decode(mi355_context *ctx, const char **names, float 
     return n;
 }
 double mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep) { return ctx->c->bench_weight_sweep(iters, bytes_per_sweep); }
+double mi355_bench_weight_sweep2(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep, int32_t *launches_per_sweep) {
+    int n = 0;
+    const double us = ctx->c->bench_weight_sweep(iters, bytes_per_sweep, &n);
+    if (launches_per_sweep) *launches_per_sweep = n;
+    return us;
+}
 
 }  // extern "C"
 

@@ -2010,11 +2010,21 @@ int Context::debug_layer_out(int il, float *dst, size_t cap) {
 }
 
 // every weight tensor once, as one decoded token reads them (no attention, no norms): the dominant kernel
-double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
+// launches_out: mat-vec launches per sweep.  Where the step runs attn_output inside its attention launch (attn_out.hip) the sweep holds no attn_output
+// launch either: it times the launches of the dominant kernel class as the step issues them, and counts their bytes only.
+double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches_out) {
     const HParams &hp = model->hp;
     const int E = hp.n_embd, FF = hp.n_ff;
     (void)hipMemsetAsync(x_, 0, (size_t)E * 4, stream_);
     uint64_t bytes = 0;
+    int launches = 0;
+    auto wo_in_attention = [&](const LayerWeights &L) {
+        AttnArgs af{};
+        af.type_k = cp.type_k; af.type_v = cp.type_v; af.T = 1; af.H = hp.n_head; af.G = hp.n_head_kv; af.D = hp.head_dim; af.n_ctx = (int)cp.n_ctx;
+        af.n_kv_max = 64; af.splits = 1; af.out_q = &aq_o_; af.out_q8k = !act_is_q80(L.wo.type); af.out_q80 = act_is_q80(L.wo.type);
+        const MMVQSeg so = make_seg(L.wo, x_, E, x_, nullptr);
+        return !hp.tp_exchange && is_quant(L.wo.type) && attn_out_fused_applicable(af, rope_args(*model, true), so, (int)L.wo.K, EPI_ADD);
+    };
     auto sweep = [&](bool count) -> hipError_t {
         for (int il = 0; il < hp.n_layer; il++) {
             const LayerWeights &L = model->layers[(size_t)il];
@@ -2029,7 +2039,8 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
                 pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
                 HIP_TRY(linear_multi(wsm, outm, 3, aq_e_, xn_, 1));
                 pending_fuse_ = Fuse();
-                HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, nullptr, EPI_STORE));
+                const bool wo_fused = wo_in_attention(L);
+                if (!wo_fused) HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, nullptr, EPI_STORE));
                 MMVQArgs a{};
                 a.n_seg = 2; a.K = E; a.T = 1; a.epi = EPI_SWIGLU; a.n_sel = KU; a.sel_out_stride = FF;
                 a.seg[0] = make_seg(L.gate_exps, ffn_, FF, nullptr, moe_ids_);
@@ -2042,8 +2053,11 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
                 if (!mmvq_fast_applicable(a) || !mmvq_fast_applicable(d)) continue;
                 HIP_TRY(launch_mmvq_fast(a, stream_));
                 HIP_TRY(launch_mmvq_fast(d, stream_));
-                if (count) bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + L.wo.ggml_bytes +
-                                    (L.gate_exps.ggml_bytes + L.up_exps.ggml_bytes + L.down_exps.ggml_bytes) / (uint64_t)L.gate_exps.n_expert * (uint64_t)KU;
+                if (count) {
+                    bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + (wo_fused ? 0 : L.wo.ggml_bytes) +
+                             (L.gate_exps.ggml_bytes + L.up_exps.ggml_bytes + L.down_exps.ggml_bytes) / (uint64_t)L.gate_exps.n_expert * (uint64_t)KU;
+                    launches += wo_fused ? 3 : 4;
+                }
                 continue;
             }
             // the launches of a single-token step as run_layers issues them (same fused prologues, same epilogues)
@@ -2053,7 +2067,8 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
             if (qkv_q && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps; }
             HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
             pending_fuse_ = Fuse();
-            HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, xo_, EPI_ADD));
+            const bool wo_fused = wo_in_attention(L);
+            if (!wo_fused) HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, xo_, EPI_ADD));
             if (is_quant(L.gate.type) && L.gate.type == L.up.type) {
                 MMVQSeg segs[2] = {make_seg(L.gate, ffn_, FF, nullptr, nullptr), make_seg(L.up, ffn_u_, FF, nullptr, nullptr)};
                 Fuse fz;
@@ -2063,12 +2078,15 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
             if (is_quant(L.down.type) && (FF % 256) == 0) { pending_fuse_.mode = 2; pending_fuse_.x = ffn_; }
             HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, xo_, EPI_ADD));
             pending_fuse_ = Fuse();
-            if (count) bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + L.wo.ggml_bytes + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
+            if (count) {
+                bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + (wo_fused ? 0 : L.wo.ggml_bytes) + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
+                launches += wo_fused ? 3 : 4;
+            }
         }
         if (is_quant(model->output.type) && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps; }
         HIP_TRY(linear(model->output, aq_e_, xn_, E, 1, d_logits_, (int)model->output.N, nullptr, EPI_STORE));
         pending_fuse_ = Fuse();
-        if (count) bytes += model->output.ggml_bytes;
+        if (count) { bytes += model->output.ggml_bytes; launches += 1; }
         return hipSuccess;
     };
     if (!d_logits_) { d_logits_ = (float *)dalloc((size_t)hp.n_vocab * 4); logits_cap_rows_ = 0; }
@@ -2098,6 +2116,7 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out) {
     if (ge) (void)hipGraphExecDestroy(ge);
     if (g) (void)hipGraphDestroy(g);
     if (bytes_out) *bytes_out = bytes;
+    if (launches_out) *launches_out = launches;
     return (double)ms * 1000.0 / iters;
 }
 

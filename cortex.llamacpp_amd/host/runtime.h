@@ -136,7 +136,7 @@ class Context {
     void set_debug_taps(bool on) { debug_taps_ = on; }
     void set_profile(bool on) { profile_ = on; }
     const std::vector<ProfileEntry> &last_profile() const { return last_profile_; }
-    double bench_weight_sweep(int iters, uint64_t *bytes);
+    double bench_weight_sweep(int iters, uint64_t *bytes, int *launches = nullptr);
 
     Model *model;
     ContextParams cp;

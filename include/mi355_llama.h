@@ -316,6 +316,9 @@ MI355_API void    mi355_profile_enable(mi355_context *ctx, int32_t enabled);
  * `iters` times on the context's stream, timed with HIP events; returns mean microseconds per sweep and
  * writes the algorithmic bytes of one sweep. */
 MI355_API double  mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep);
+/* ... and the number of mat-vec launches the sweep holds (the step's own launches of the weight-stream kernel: where attn_output runs inside the attention
+ * launch - attn_out.hip - it is not among them, and its bytes are not counted) */
+MI355_API double  mi355_bench_weight_sweep2(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep, int32_t *launches_per_sweep);
 
 #ifdef __cplusplus
 }
