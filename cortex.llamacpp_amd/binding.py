@@ -106,6 +106,7 @@ SYMBOLS = {
     "mi355_bench_hbm_read": (C.c_double, [_sz, C.c_int]),
     "mi355_profile_last_decode": (_i32, [_vp, C.POINTER(_cp), C.POINTER(_f32), _i32]),
     "mi355_profile_enable": (None, [_vp, _i32]),
+    "mi355_debug_force_moe_ids": (C.c_int, [_vp, _vp, _i32, _i32, _i32]),
     "mi355_bench_weight_sweep": (C.c_double, [_vp, C.c_int, C.POINTER(_u64)]),
     "mi355_bench_weight_sweep2": (C.c_double, [_vp, C.c_int, C.POINTER(_u64), C.POINTER(C.c_int32)]),
     "mi355_tokenize": (_i32, [_vp, _cp, _i32, C.POINTER(C.c_int32), _i32, _i32, _i32]),
@@ -566,6 +567,13 @@ class Context:
         us = (_f32 * 64)()
         n = self.lib.mi355_profile_last_decode(self.h, names, us, 64)
         return {names[i].decode(): float(us[i]) for i in range(n)}
+
+    def force_moe_ids(self, ids: np.ndarray) -> None:
+        """ids [n_layer][T][k]: the experts the NEXT decode call takes instead of its router's selection (test hook)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        rc = self.lib.mi355_debug_force_moe_ids(self.h, _ptr(ids), ids.shape[0], ids.shape[1], ids.shape[2])
+        if rc != 0:
+            raise MI355Error(f"mi355_debug_force_moe_ids failed ({rc}): {_err(self.lib)}")
 
     def weight_sweep_us(self, iters: int = 5):
         b = _u64(0)

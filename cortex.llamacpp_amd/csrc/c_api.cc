@@ -261,6 +261,11 @@ int32_t mi355_profile_last_decode(mi355_context *ctx, const char **names, float 
     }
     return n;
 }
+int mi355_debug_force_moe_ids(mi355_context *ctx, const int32_t *ids, int32_t n_layer, int32_t n_tokens, int32_t k) {
+    if (!ctx || !ctx->c) return MI355_ERR_ARG;
+    if (ctx->c->force_moe_ids(ids, n_layer, n_tokens, k) != 0) { fail(ctx->c->last_error.empty() ? "force_moe_ids failed" : ctx->c->last_error); return MI355_ERR_ARG; }
+    return MI355_OK;
+}
 double mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep) { return ctx->c->bench_weight_sweep(iters, bytes_per_sweep); }
 double mi355_bench_weight_sweep2(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep, int32_t *launches_per_sweep) {
     int n = 0;

@@ -200,10 +200,11 @@ hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const
                             const float *resid, hipStream_t st);
 
 // MoE router: softmax over n_expert logits per token, top-k (first index wins ties), weights renormalised
-hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, hipStream_t st);
+// forced (nullable, tests): [T][k] expert ids to take instead of the k most probable (weights = this side's probabilities of them, renormalised)
+hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, hipStream_t st, const int32_t *forced = nullptr);
 // the two above in one launch (f32 / f16 gate_inp), same arithmetic; logits_out may be null
 hipError_t launch_moe_router(int type, const uint8_t *W, int n_expert, int K, const float *x, int T, int k, float *logits_out, int32_t *ids, float *w,
-                             hipStream_t st);
+                             hipStream_t st, const int32_t *forced = nullptr);
 // x[t][d] += sum_j eo[j][t][d] * w[t][j]   (experts added in rank order, then the residual)
 hipError_t launch_moe_combine(float *x, const float *eo, const float *w, int T, int E, int k, size_t eo_stride, hipStream_t st);
 hipError_t launch_gather_rows_f32(const float *src, const int32_t *rows, int n_rows, int n, float *dst, hipStream_t st);

@@ -325,7 +325,9 @@ hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const
 }
 
 // ---------------------------------------------------------------- MoE routing (build_moe_ffn: softmax -> top-k -> renormalise)
-__global__ void moe_route_kernel(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w) {
+// forced (test hook, mi355_debug_force_moe_ids): the experts of token t are forced[t * k + j] instead of the k most probable; the weights are still this
+// side's probabilities of those experts, renormalised
+__global__ void moe_route_kernel(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, const int32_t *forced) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const float *x = logits + (size_t)t * n_expert;
@@ -342,6 +344,7 @@ __global__ void moe_route_kernel(const float *logits, int T, int n_expert, int k
         int best = -1;
         for (int e = 0; e < n_expert; e++)
             if (!((used >> e) & 1ull) && (best < 0 || p[e] > p[best])) best = e;
+        if (forced) { best = forced[(size_t)t * k + j]; best = best < 0 ? 0 : best >= n_expert ? n_expert - 1 : best; }
         used |= 1ull << best;
         ids[(size_t)t * k + j] = best;
         w[(size_t)t * k + j] = p[best];
@@ -349,16 +352,16 @@ __global__ void moe_route_kernel(const float *logits, int T, int n_expert, int k
     }
     for (int j = 0; j < k; j++) w[(size_t)t * k + j] /= wsum;
 }
-hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, hipStream_t st) {
+hipError_t launch_moe_route(const float *logits, int T, int n_expert, int k, int32_t *ids, float *w, hipStream_t st, const int32_t *forced) {
     if (n_expert > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(moe_route_kernel, dim3((T + 63) / 64), dim3(64), 0, st, logits, T, n_expert, k, ids, w);
+    hipLaunchKernelGGL(moe_route_kernel, dim3((T + 63) / 64), dim3(64), 0, st, logits, T, n_expert, k, ids, w, forced);
     return hipGetLastError();
 }
 // Router of a mixture-of-experts layer in ONE launch: logits = gate_inp . x (the arithmetic of mmv_float_kernel: lane l adds
 // the products k = l, l + 64, ... in a double, waves reduced the same way), then the selection of moe_route_kernel, per
 // token.  Workgroup = token; wave w computes experts w, w + 4, ...; thread 0 selects.  Same bits as the two launches.
 __global__ __launch_bounds__(256) void moe_router_kernel(int type, const uint8_t *W, int n_expert, int K, const float *x, int k, float *logits_out,
-                                                         int32_t *ids, float *w) {
+                                                         int32_t *ids, float *w, const int32_t *forced) {
     __shared__ float lg[64];
     const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *xr = x + (size_t)t * K;
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(256) void moe_router_kernel(int type, const uint8_t
         int best = -1;
         for (int e = 0; e < n_expert; e++)
             if (!((used >> e) & 1ull) && (best < 0 || p[e] > p[best])) best = e;
+        if (forced) { best = forced[(size_t)t * k + j]; best = best < 0 ? 0 : best >= n_expert ? n_expert - 1 : best; }
         used |= 1ull << best;
         ids[(size_t)t * k + j] = best;
         w[(size_t)t * k + j] = p[best];
@@ -410,9 +414,9 @@ __global__ __launch_bounds__(256) void moe_router_kernel(int type, const uint8_t
     for (int j = 0; j < k; j++) w[(size_t)t * k + j] /= wsum;
 }
 hipError_t launch_moe_router(int type, const uint8_t *W, int n_expert, int K, const float *x, int T, int k, float *logits_out, int32_t *ids, float *w,
-                             hipStream_t st) {
+                             hipStream_t st, const int32_t *forced) {
     if (n_expert > 64 || (type != T_F32 && type != T_F16) || T <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(moe_router_kernel, dim3(T), dim3(256), 0, st, type, W, n_expert, K, x, k, logits_out, ids, w);
+    hipLaunchKernelGGL(moe_router_kernel, dim3(T), dim3(256), 0, st, type, W, n_expert, K, x, k, logits_out, ids, w, forced);
     return hipGetLastError();
 }
 __global__ void moe_combine_kernel(float *x, const float *eo, const float *w, int T, int E, int k, size_t eo_stride) {

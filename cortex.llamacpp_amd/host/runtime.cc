@@ -1396,10 +1396,12 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             prep_owner_ = nullptr;
             prof_mark("norm_quant");
             if (L.gate_inp.type == T_F32 || L.gate_inp.type == T_F16) {
-                HIP_TRY(launch_moe_router(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, hp.n_expert_used, router_, moe_ids_, moe_w_, stream_));
+                HIP_TRY(launch_moe_router(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, hp.n_expert_used, router_, moe_ids_, moe_w_, stream_,
+                                          moe_forced_T_ == T ? d_moe_forced_ + (size_t)il * T * hp.n_expert_used : nullptr));
             } else {
                 HIP_TRY(launch_mmv_float(L.gate_inp.type, L.gate_inp.data, hp.n_expert, E, xn_, T, router_, hp.n_expert, nullptr, stream_));
-                HIP_TRY(launch_moe_route(router_, T, hp.n_expert, hp.n_expert_used, moe_ids_, moe_w_, stream_));
+                HIP_TRY(launch_moe_route(router_, T, hp.n_expert, hp.n_expert_used, moe_ids_, moe_w_, stream_,
+                                         moe_forced_T_ == T ? d_moe_forced_ + (size_t)il * T * hp.n_expert_used : nullptr));
             }
             prof_mark("moe_route");
             const int KU = hp.n_expert_used;
@@ -1758,7 +1760,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
 
     const int V = model->hp.n_vocab;
     if (n == 1 && !model->hp.encoder) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
-    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled;
+    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled && moe_forced_T_ == 0;
     hipError_t e = hipSuccess;
     if (graph_ok) {
         // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
@@ -1890,10 +1892,27 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
         }
         for (int i = 0; i < n; i++) out_base += flags[(size_t)(i0 + i)] ? 1 : 0;
     }
+    moe_forced_T_ = 0;      // (force_moe_ids arms one call)
     return 0;
 }
 
 void Context::synchronize() { (void)hipStreamSynchronize(stream_); }
+
+int Context::force_moe_ids(const int32_t *ids, int n_layer, int T, int k) {
+    const HParams &hp = model->hp;
+    if (!ids || hp.n_expert <= 0 || n_layer != hp.n_layer || k != hp.n_expert_used || T < 1 || T > (int)cp.n_ubatch) { last_error = "force_moe_ids: shape does not match the model"; return -1; }
+    const int n = n_layer * T * k;
+    if (hipSetDevice(model->device) != hipSuccess) return -1;
+    if (n > moe_forced_cap_) {
+        (void)hipStreamSynchronize(stream_);
+        d_moe_forced_ = (int32_t *)dalloc((size_t)n * 4);
+        if (!d_moe_forced_) { moe_forced_cap_ = 0; return -1; }
+        moe_forced_cap_ = n;
+    }
+    if (hipMemcpyAsync(d_moe_forced_, ids, (size_t)n * 4, hipMemcpyHostToDevice, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess) return -1;
+    moe_forced_T_ = T;
+    return 0;
+}
 
 float *Context::logits_ith(int i) {
     if (last_was_embd_) return nullptr;            // embeddings mode computes no logits

@@ -120,6 +120,9 @@ class Context {
     // produced for the flagged tokens of the last decode while embeddings_enabled is set (then no logits are computed)
     float *embeddings_ith(int i);
     int32_t argmax_ith(int i);
+    // test hook (mixture-of-experts files): the NEXT decode call (one micro-batch of T tokens) takes these experts, ids [n_layer][T][n_expert_used], instead of
+    // its router's selection; the weights stay this side's probabilities of them.  One call, then routing is free again.  No graphs while it is armed.
+    int force_moe_ids(const int32_t *ids, int n_layer, int T, int k);
     // device-side sampling front end: the k best (token, logit) candidates of batch row i after the adjustments (kernels.h launch_topk_rows), best
     // first; returns the count written (k) or < 0
     int topk_ith(int i, int k, const TopkAdj &adj, int32_t *toks, float *logits);
@@ -239,6 +242,8 @@ class Context {
     int engine_state_ = 0;                             // 0 = not looked at yet, 1 = ready, -1 = this model / context takes one launch per mat-vec
     bool engine_prepare();
     bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up
+    int32_t *d_moe_forced_ = nullptr;    // force_moe_ids: [n_layer][T][k] on the device (armed while moe_forced_T_ > 0)
+    int moe_forced_T_ = 0, moe_forced_cap_ = 0;
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     unsigned *d_step_serial_ = nullptr;  // device word: serial number of the step (incremented by the step's set-up launch; the hand-over tags / flags of attn_out.hip and decode_engine.hip)
     unsigned long long *d_ao_gran_ = nullptr;   // attn_out.hip: the quantised attention output as tagged granules (shared by the layers of a step)

@@ -315,6 +315,11 @@ MI355_API void    mi355_profile_enable(mi355_context *ctx, int32_t enabled);
 /* Runs the dominant decode kernel (quantised mat-vec over every weight tensor of the model, one token)
  * `iters` times on the context's stream, timed with HIP events; returns mean microseconds per sweep and
  * writes the algorithmic bytes of one sweep. */
+/* test hook for mixture-of-experts files (build_moe_ffn's top-k): the NEXT mi355_decode call (one micro-batch of n_tokens tokens) takes the
+ * experts ids[layer][token][rank] instead of its own router's selection (the weights stay this side's router probabilities of those experts, renormalised).
+ * Parity tests hand over the CPU restatement's selection so that a rounding flip on a near tie of the router cannot send a token to another expert on one
+ * side only.  Arms one call. */
+MI355_API int     mi355_debug_force_moe_ids(mi355_context *ctx, const int32_t *ids, int32_t n_layer, int32_t n_tokens, int32_t k);
 MI355_API double  mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep);
 /* ... and the number of mat-vec launches the sweep holds (the step's own launches of the weight-stream kernel: where attn_output runs inside the attention
  * launch - attn_out.hip - it is not among them, and its bytes are not counted) */

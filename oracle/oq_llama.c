@@ -395,6 +395,22 @@ static void ffn_dense(const oq_ctx *c, const oq_layer *L, const float *h, int64_
     free(g); free(u);
 }
 
+/* test hook: the expert ids the router selected, appended in call order (decode call -> layer -> token -> rank), so that a test can hand the same routing
+   to the implementation under test (a rounding flip on a near tie of the router otherwise sends a token to another expert on one side only) */
+static int32_t *g_moe_rec = NULL;
+static size_t g_moe_rec_n = 0, g_moe_rec_cap = 0;
+void oq_moe_record_start(size_t cap) {
+    free(g_moe_rec);
+    g_moe_rec = cap ? (int32_t *)malloc(cap * sizeof(int32_t)) : NULL;
+    g_moe_rec_cap = g_moe_rec ? cap : 0;
+    g_moe_rec_n = 0;
+}
+size_t oq_moe_record_get(int32_t *out, size_t cap) {
+    const size_t n = g_moe_rec_n < cap ? g_moe_rec_n : cap;
+    if (out && n) memcpy(out, g_moe_rec, n * sizeof(int32_t));
+    return g_moe_rec_n;
+}
+
 /* MoE: softmax router, top-k by probability, renormalised weights, experts summed in rank order */
 static void ffn_moe(const oq_ctx *c, const oq_layer *L, const float *h, int64_t T, float *out) {
     const oq_model *m = c->m;
@@ -411,6 +427,7 @@ static void ffn_moe(const oq_ctx *c, const oq_layer *L, const float *h, int64_t 
         linear(c, L->gate_inp, x, 1, logits);
         int ids[16]; float wts[16];
         oq_moe_route(logits, E, KU, probs, ids, wts);
+        for (int k = 0; k < KU && g_moe_rec_n < g_moe_rec_cap; k++) g_moe_rec[g_moe_rec_n++] = ids[k];
         float *o = out + t * D;
         for (int k = 0; k < KU; k++) {
             const int e = ids[k];

@@ -126,6 +126,9 @@ int       oq_model_n_embd(const oq_model *m);
 int       oq_model_n_layer(const oq_model *m);
 
 /* type_k/type_v: OQ_TYPE_F16 / Q8_0 / Q4_0; flash_attn 0 => softmax(KQ)V path (f16 only) */
+/* test hook (mixture-of-experts files): record the expert ids the router selects from now on, in call order (decode call -> layer -> token -> rank) */
+void   oq_moe_record_start(size_t cap);
+size_t oq_moe_record_get(int32_t *out, size_t cap);     /* returns the number recorded so far */
 oq_ctx *oq_ctx_new(oq_model *m, int n_ctx, int type_k, int type_v, int flash_attn, int n_threads);
 void    oq_ctx_free(oq_ctx *c);
 /* llama_decode equivalent: appends n tokens of sequence seq at pos[]; writes logits rows

@@ -161,21 +161,31 @@ def make_ops():
 E2E_CASES = [("tiny", "q4_k_m", "q8_0", 7), ("tiny-d128", "q5_k_m", "f16", 11), ("tiny-moe", "q4_k_m", "q8_0", 13),
              # round 3: general.architecture qwen2 (NEOX pairing, Q / K / V biases) and YaRN rope scaling from the file's metadata
              ("tiny-qwen2", "q4_k_m", "q8_0", 17), ("tiny-yarn", "q4_k_m", "q8_0", 19)]
+# round 4 (e2e_v2.npz; v1 stays frozen): the type mix of the reference's smoke model (a Q2_K file of TinyLlama's layer geometry, /root/reference Makefile:5-6),
+# a Q8_0 file with a q8_0 cache (BASELINE config 1's file type), a q4_0 cache (cache_type "q4_0", src/llama_engine.cc:272-285)
+E2E_CASES_V2 = [("tiny-tl-2l", "q2_k", "f16", 23), ("tiny", "q8_0", "q8_0", 29), ("tiny-gqa4", "q4_k_m", "q4_0", 31)]
+# ... and the encoder graph of the reference's embedding smoke model (nomic-bert): the last layer's hidden states of one 24-token sequence
+ENC_CASE = ("tiny-nomic", "f16", 37, 24)
 N_PROMPT, N_STEPS = 12, 32
 
 
-def make_e2e():
+def _load_synth():
     import importlib.util
-    import oracle_py as oq
     spec = importlib.util.spec_from_file_location("gguf_synth", os.path.join(ROOT, "cortex.llamacpp_amd", "gguf_synth.py"))
     gs = importlib.util.module_from_spec(spec); sys.modules["gguf_synth"] = gs; spec.loader.exec_module(gs)
+    return gs
+
+
+def make_e2e(cases=None, fname="e2e_v1.npz", with_encoder=False):
+    import oracle_py as oq
+    gs = _load_synth()
     out = {}
-    for cfg, ftype, kv, seed in E2E_CASES:
+    for cfg, ftype, kv, seed in (E2E_CASES if cases is None else cases):
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "m.gguf")
             gs.write_synthetic_llama(path, cfg, ftype, seed=seed)
             om = oq.OracleModel(path)
-            tkv = oq.Q8_0 if kv == "q8_0" else oq.F16
+            tkv = {"q8_0": oq.Q8_0, "f16": oq.F16, "q4_0": oq.Q4_0}[kv]
             oc = oq.OracleContext(om, 64, tkv, tkv, True, 2)
             n_vocab = gs.CONFIGS[cfg].n_vocab
             prompt = np.random.default_rng(seed).integers(0, n_vocab, N_PROMPT).astype(np.int32)
@@ -193,8 +203,27 @@ def make_e2e():
             out[f"{key}.top2_gap"] = (top2[:, 1] - top2[:, 0]).astype(np.float32)
             out[f"{key}.seed"] = np.array([seed], np.int32)
             oc.close(); om.close()
-    np.savez_compressed(os.path.join(HERE, "e2e_v1.npz"), **out)
-    print("wrote e2e_v1.npz", {k: v.shape for k, v in out.items()})
+    if with_encoder:
+        cfg, ftype, seed, n = ENC_CASE
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "m.gguf")
+            gs.write_synthetic_llama(path, cfg, ftype, seed=seed)
+            om = oq.OracleModel(path)
+            oq.set_fa_v_acc_f32(1)         # (the f32-accumulating form of the restatement: what the HIP kernels are held to tightly)
+            try:
+                oc = oq.OracleContext(om, 64, oq.F16, oq.F16, True, 2)
+                toks = np.random.default_rng(seed).integers(5, gs.CONFIGS[cfg].n_vocab, n).astype(np.int32)
+                oc.decode(toks, np.arange(n), [0] * n, np.ones(n, np.int8))
+                n_layer = gs.CONFIGS[cfg].n_layer
+                out[f"{cfg}.{ftype}.enc.tokens"] = toks
+                out[f"{cfg}.{ftype}.enc.hidden"] = oc.layer_out(n_layer - 1, n).reshape(n, -1).astype(np.float32)
+                out[f"{cfg}.{ftype}.enc.seed"] = np.array([seed], np.int32)
+                oc.close()
+            finally:
+                oq.set_fa_v_acc_f32(0)
+            om.close()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print("wrote", fname, {k: v.shape for k, v in out.items()})
 
 
 def make_api_shapes():
@@ -247,4 +276,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "e2e", "api"]
     if "ops" in which: make_ops()
     if "e2e" in which: make_e2e()
+    if "e2e2" in which: make_e2e(E2E_CASES_V2, "e2e_v2.npz", with_encoder=True)
     if "api" in which: make_api_shapes()

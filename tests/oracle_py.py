@@ -76,6 +76,9 @@ def lib():
         L.oq_debug_layer_out.restype = C.POINTER(C.c_float)
         L.oq_debug_layer_out.argtypes = [vp, i32]
         L.oq_set_assoc_variant.argtypes = [i32]
+        L.oq_moe_record_start.argtypes = [C.c_size_t]
+        L.oq_moe_record_get.argtypes = [vp, C.c_size_t]
+        L.oq_moe_record_get.restype = C.c_size_t
         L.oq_set_fa_v_acc_f32.argtypes = [i32]
     return _lib
 
@@ -196,6 +199,18 @@ def flash_attn(q: np.ndarray, n_head: int, n_head_kv: int, hd: int, type_k: int,
     out = np.empty((n_head, hd), dtype=np.float32)
     lib().oq_flash_attn_ext(_p(q), n_head, n_head_kv, hd, hd, type_k, _p(k_cache), kh * n_head_kv, kh,
                             type_v, _p(v_cache), vh * n_head_kv, vh, _p(cells), cells.size, scale, _p(out))
+    return out
+
+
+def moe_record_start(cap: int = 1 << 20):
+    """Record the expert ids the oracle's router selects from now on (call order: decode call -> layer -> token -> rank)."""
+    lib().oq_moe_record_start(cap)
+
+
+def moe_record_get() -> np.ndarray:
+    n = lib().oq_moe_record_get(None, 0)
+    out = np.zeros(n, np.int32)
+    lib().oq_moe_record_get(_p(out), n)
     return out
 
 

@@ -16,10 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GD = os.path.join(HERE, "golden")
 OPS = np.load(os.path.join(GD, "ops_v1.npz"))
-E2E = np.load(os.path.join(GD, "e2e_v1.npz"))
+E2E = {**np.load(os.path.join(GD, "e2e_v1.npz")), **np.load(os.path.join(GD, "e2e_v2.npz"))}      # (v2: the cases round 4 added; v1 stays frozen)
+KVT = {"q8_0": oq.Q8_0, "f16": oq.F16, "q4_0": oq.Q4_0}
 API = json.load(open(os.path.join(GD, "api_shapes_v1.json"), encoding="utf-8"))
 sys.path.insert(0, GD)
 import make_golden_ops as gen  # noqa: E402  (E2E_CASES, N_PROMPT, N_STEPS)
+
+ALL_E2E = gen.E2E_CASES + gen.E2E_CASES_V2
 
 FLIP_TOL = 3e-2          # of the logit scale: one int8 rounding flip of an activation / cache code (tests/test_oracle_sensitivity.py)
 ID_GAP = 6e-2            # a greedy id is compared where the recorded top-2 gap exceeds this fraction of the logit scale
@@ -83,13 +86,13 @@ def test_oracle_attention_matches_golden(name, tol):
 
 
 # ------------------------------------------------------------------------------------------------ e2e: the oracle wrote it, it must still write it
-@pytest.mark.parametrize("cfg,ftype,kv,seed", gen.E2E_CASES)
+@pytest.mark.parametrize("cfg,ftype,kv,seed", ALL_E2E)
 def test_oracle_reproduces_e2e_golden_bit_for_bit(pkg, tmp_path, cfg, ftype, kv, seed):
     path = str(tmp_path / "m.gguf")
     pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
     key = f"{cfg}.{ftype}.{kv}"
     om = oq.OracleModel(path)
-    tkv = oq.Q8_0 if kv == "q8_0" else oq.F16
+    tkv = KVT[kv]
     oc = oq.OracleContext(om, 64, tkv, tkv, True, 2)
     prompt = E2E[f"{key}.prompt"]
     assert np.array_equal(prompt, np.random.default_rng(seed).integers(0, om.n_vocab if hasattr(om, "n_vocab") else pkg.gguf_synth.CONFIGS[cfg].n_vocab, gen.N_PROMPT))
@@ -100,6 +103,25 @@ def test_oracle_reproduces_e2e_golden_bit_for_bit(pkg, tmp_path, cfg, ftype, kv,
         assert tok == int(E2E[f"{key}.ids"][s]), s
         row = oc.decode([tok], [gen.N_PROMPT + s])[0]
     oc.close(); om.close()
+
+
+def test_oracle_reproduces_encoder_golden_bit_for_bit(pkg, tmp_path):
+    """The encoder graph of the reference's embedding smoke model (nomic-bert, /root/reference Makefile:6): the last layer's hidden states of one sequence."""
+    cfg, ftype, seed, n = gen.ENC_CASE
+    path = str(tmp_path / "m.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
+    om = oq.OracleModel(path)
+    oq.set_fa_v_acc_f32(1)
+    try:
+        oc = oq.OracleContext(om, 64, oq.F16, oq.F16, True, 2)
+        toks = E2E[f"{cfg}.{ftype}.enc.tokens"]
+        oc.decode(toks, np.arange(n), [0] * n, np.ones(n, np.int8))
+        got = oc.layer_out(pkg.gguf_synth.CONFIGS[cfg].n_layer - 1, n).reshape(n, -1)
+        assert np.array_equal(got.astype(np.float32), E2E[f"{cfg}.{ftype}.enc.hidden"])
+        oc.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
+    om.close()
 
 
 # ------------------------------------------------------------------------------------------------ API shapes
@@ -188,7 +210,7 @@ def test_hip_ops_match_golden(pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,ftype,kv,seed", gen.E2E_CASES)
+@pytest.mark.parametrize("cfg,ftype,kv,seed", ALL_E2E)
 def test_hip_e2e_matches_golden(pkg, tmp_path, cfg, ftype, kv, seed):
     """12-token prompt + 32 teacher-forced greedy steps against the committed oracle run: every logits row within FLIP_TOL of the logit scale, the best rows
     within 2e-5 (f32 re-association only: before the first int8 rounding flip HIP == CPU), and the greedy id equal wherever the recorded gap between the two
@@ -198,7 +220,7 @@ def test_hip_e2e_matches_golden(pkg, tmp_path, cfg, ftype, kv, seed):
     key = f"{cfg}.{ftype}.{kv}"
     pkg.Backend()
     m = pkg.Model(path)
-    tkv = pkg.binding.Q8_0 if kv == "q8_0" else pkg.binding.F16
+    tkv = {"q8_0": pkg.binding.Q8_0, "f16": pkg.binding.F16, "q4_0": 2}[kv]
     c = pkg.Context(m, n_ctx=64, type_k=tkv, type_v=tkv)
     prompt = E2E[f"{key}.prompt"]
     assert c.decode(prompt, np.arange(gen.N_PROMPT)) == 0
@@ -216,4 +238,24 @@ def test_hip_e2e_matches_golden(pkg, tmp_path, cfg, ftype, kv, seed):
     assert checked >= gen.N_STEPS // 2
     if kv != "f16":                                            # (f16 cache: the CPU's fp16 V accumulation is in the recorded rows)
         assert min(errs) <= 2e-5, min(errs)
+    c.close(); m.close()
+
+
+@pytest.mark.gpu
+def test_hip_encoder_matches_golden(pkg, tmp_path):
+    """nomic-bert encoder (the reference's embedding smoke model): the embeddings rows of one 24-token sequence against the committed hidden states of the
+    CPU restatement's last layer (f16 weights: the CPU rounds the activations to f16 for vec_dot_f16, the device contracts f32 activations - 1e-2 on unit-scale
+    rows, the typical element far closer)."""
+    cfg, ftype, seed, n = gen.ENC_CASE
+    path = str(tmp_path / "m.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
+    pkg.Backend()
+    m = pkg.Model(path)
+    c = pkg.Context(m, n_ctx=64, n_seq_max=1, type_k=pkg.binding.F16, type_v=pkg.binding.F16)
+    toks = E2E[f"{cfg}.{ftype}.enc.tokens"]
+    assert c.decode(toks, np.arange(n), [0] * n, np.ones(n, np.int8)) == 0
+    emb = np.stack([c.embeddings(i).copy() for i in range(n)])
+    ref = E2E[f"{cfg}.{ftype}.enc.hidden"]
+    assert float(np.abs(emb - ref).max()) / max(1.0, float(np.abs(ref).max())) <= 1e-2
+    assert float(np.median(np.abs(emb - ref))) <= 1e-3
     c.close(); m.close()

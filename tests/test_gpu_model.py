@@ -1020,3 +1020,42 @@ def test_context_filled_to_4096_matches_oracle(be, pkg, tmp_models, cfg, ftype, 
         c.close(); m.close(); oc.close(); om.close()
     finally:
         oq.set_fa_v_acc_f32(0)
+
+
+def test_moe_forced_routing_hook(be, pkg, tmp_models):
+    """mi355_debug_force_moe_ids: the next decode call takes the experts it is handed instead of its router's selection.  With the CPU restatement's own
+    selections handed over, prompt and steps agree with it within FLIP_TOL on every row (no token can be sent to another expert by a rounding flip on a near
+    tie of the router); with a deliberately different selection the logits move - the hook is live; and it arms exactly one call."""
+    path = make(pkg, tmp_models, "tiny-moe", "q4_k_m")
+    m, c, om, oc = open_pair(pkg, path, 128, "q8_0")
+    rng = np.random.default_rng(17)
+    prompt = rng.integers(0, m.n_vocab, 21)
+    oq.moe_record_start()
+    ref = [oc.decode(prompt, np.arange(21))[0]]
+    routes = [oq.moe_record_get().reshape(m.n_layer, 21, -1)]
+    toks = []
+    for s in range(6):
+        toks.append(int(ref[-1].argmax()))
+        oq.moe_record_start()
+        ref.append(oc.decode([toks[-1]], [21 + s])[0])
+        routes.append(oq.moe_record_get().reshape(m.n_layer, 1, -1))
+    oq.moe_record_start(0)
+    c.force_moe_ids(routes[0])
+    assert c.decode(prompt, np.arange(21)) == 0
+    errs = [rel_err(c.logits(), ref[0])]
+    for s in range(6):
+        c.force_moe_ids(routes[s + 1])
+        assert c.decode([toks[s]], [21 + s]) == 0
+        errs.append(rel_err(c.logits(), ref[s + 1]))
+    assert max(errs) <= FLIP_TOL, errs
+    # the hook is live: other experts, other logits; and the call after it routes freely again
+    free = c.logits().copy()
+    c.kv_seq_rm(0, 26, -1)
+    wrong = (routes[6] + 3) % 8
+    c.force_moe_ids(wrong)
+    assert c.decode([toks[5]], [26]) == 0
+    assert rel_err(c.logits(), free) > 1e-3
+    c.kv_seq_rm(0, 26, -1)
+    assert c.decode([toks[5]], [26]) == 0
+    assert rel_err(c.logits(), ref[6]) <= FLIP_TOL
+    c.close(); m.close(); oc.close(); om.close()
