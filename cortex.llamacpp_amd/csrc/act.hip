@@ -65,18 +65,32 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict
     }
 }
 
+// workgroups per row: a wave quantises the blocks b, b + 4 * splits, .. of its row, one after the other - a chain of wave-level steps per block that waits on
+// itself - so a row of 16 .. 56 blocks is cut until a wave holds one or two of them (the row scale is re-derived per workgroup: the row sits in L2)
+#ifndef MI355_QUANT_SPLIT_BLOCKS
+#define MI355_QUANT_SPLIT_BLOCKS 8
+#endif
+static int quant_splits(int T, int n) {
+    if (T < 8) return ((n >> 8) + 3) / 4;
+    const int nblk = n >> 8;
+    int s = (nblk + MI355_QUANT_SPLIT_BLOCKS - 1) / MI355_QUANT_SPLIT_BLOCKS;      // blocks per workgroup <= 8 (two per wave)
+    if (T < 64 && s < 2) s = 2;
+    while (s > 1 && (long long)T * s > 16384) s >>= 1;
+    return s < 1 ? 1 : s;
+}
+
 hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, float eps, float *y_f32,
                                 const ActQuant *q, bool want_q8k, bool want_q80, hipStream_t st, int8_t *bh, int8_t *bl) {
     ActQuant qq;
     if (q) qq = *q;
-    const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
+    const int splits = quant_splits(T, n);
     hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, w, n, eps, 1, y_f32, qq,
                        (int)(q && want_q8k), (int)(q && want_q80), (q && want_q8k) ? bh : nullptr, bl);
     return hipGetLastError();
 }
 
 hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st, int8_t *bh, int8_t *bl) {
-    const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
+    const int splits = quant_splits(T, n);
     hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, (const float *)nullptr, n, 0.0f, 0,
                        (float *)nullptr, q, (int)want_q8k, (int)want_q80, want_q8k ? bh : nullptr, bl);
     return hipGetLastError();
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const float *__restri
 hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
                                int8_t *bh, int8_t *bl) {
     if ((n % 256) != 0 || T <= 0) return hipErrorInvalidValue;
-    const int splits = T >= 64 ? 1 : (T >= 8 ? 2 : ((n >> 8) + 3) / 4);
+    const int splits = quant_splits(T, n);
     hipLaunchKernelGGL(swiglu_quant_kernel, dim3(T, splits), dim3(256), 0, st, g, u, n, q, (int)want_q8k, (int)want_q80, want_q8k ? bh : nullptr, bl);
     return hipGetLastError();
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of decode tok/s between builds of the library: tools/ab_libs.sh name=path.so [name=path.so ...]; alternates REPS times, prints every run
-# and the medians (first number: context 512 + steps, second: context filled to 3968)
+# and the medians (decode tok/s at context 512, with the context filled to 3968, 512-token prompt tok/s)
 REPS=${REPS:-3}
 mkdir -p gpurun_out
 OUT=gpurun_out/ab_libs.txt
@@ -18,8 +18,8 @@ import statistics, collections
 d = collections.defaultdict(list)
 for l in open('gpurun_out/ab_libs.txt'):
     p = l.split()
-    if len(p) == 3:
-        d[p[0]].append((float(p[1]), float(p[2])))
+    if len(p) == 4:
+        d[p[0]].append((float(p[1]), float(p[2]), float(p[3])))
 for k, v in d.items():
-    print(f"median {k}: {statistics.median(x[0] for x in v):.1f}  {statistics.median(x[1] for x in v):.1f}   ({len(v)} runs)")
+    print(f"median {k}: decode {statistics.median(x[0] for x in v):.1f}  filled {statistics.median(x[1] for x in v):.1f}  prefill512 {statistics.median(x[2] for x in v):.0f}   ({len(v)} runs)")
 PY

@@ -37,7 +37,20 @@ def run(n_p, n_steps):
     return n_steps / (time.perf_counter() - t0)
 
 
+def prefill(n_p, reps=5):
+    prompt = np.random.default_rng(99).integers(0, model.n_vocab, n_p)
+    ts = []
+    for _ in range(reps):
+        ctx.kv_clear(); ctx.synchronize()
+        t0 = time.perf_counter()
+        assert ctx.decode(prompt, np.arange(n_p)) == 0
+        ctx.logits_ready()
+        ts.append(time.perf_counter() - t0)
+    return n_p / sorted(ts)[len(ts) // 2]
+
+
 a = run(n_prompt, steps)
 b = run(3968, min(steps, 96))
-print(f"{a:.1f} {b:.1f}")
+p = prefill(512)
+print(f"{a:.1f} {b:.1f} {p:.0f}")
 ctx.close(); model.close()
