@@ -87,6 +87,11 @@ __global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
 void mmvq_stream_set_probe(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stream_probe), &p, sizeof(p)); }
 #endif
 
+#ifndef MI355_STREAM_Q80_MIN_MB
+#define MI355_STREAM_Q80_MIN_MB 16
+#endif
+static constexpr size_t STREAM_Q80_MIN_BYTES = (size_t)MI355_STREAM_Q80_MIN_MB << 20;   // launches of Q8_0 tensors only: below this the register ring (TinyLlama: 850 vs 816 tok/s)
+
 bool mmvq_stream_applicable(const MMVQArgs &a) {
     if (a.T != 1 || a.K <= 0 || (a.K % 256) != 0) return false;      // (whole super-blocks; a partial last pass decodes zero-scale slices, as on the register ring)
     // the selected experts of one token in one launch (n_sel): one tensor or one gate | up pair, results stored per expert (no residual epilogue)
@@ -106,20 +111,22 @@ bool mmvq_stream_applicable(const MMVQArgs &a) {
     // Q8_0 tensors: 1.06 B per weight through LDS and no shorter decode; measured on TinyLlama-1.1B Q8_0 the register ring is 4 %
     // faster (850 vs 816 tok/s), so launches made of Q8_0 tensors only stay there (a Q8_0 attn_k / attn_v beside a K-quant attn_q
     // of an 8-expert file streams with it)
+    // (round 4: from STREAM_Q80_MIN_BYTES on they stream too - at Llama-3-8B's sizes the launch is bound by its bytes like any other)
     bool all_q80 = true;
-    for (int s = 0; s < (swiglu ? 2 : n); s++) all_q80 = all_q80 && a.seg[s].type == T_Q8_0;
-    if (all_q80) return false;
+    size_t launch_bytes = 0;
+    for (int s = 0; s < (swiglu ? 2 : n); s++) { all_q80 = all_q80 && a.seg[s].type == T_Q8_0; launch_bytes += (size_t)a.seg[s].n_rows * a.seg[s].row_bytes; }
+    if (all_q80 && launch_bytes < STREAM_Q80_MIN_BYTES) return false;
     for (int s = 0; s < (swiglu ? 2 : n); s++) {
         const MMVQSeg &g = a.seg[s];
         const int t = g.type;
-        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q8_0) return false;
+        if (t != T_Q4_K && t != T_Q5_K && t != T_Q6_K && t != T_Q8_0 && t != T_Q2_K && t != T_Q3_K && t != T_Q4_0 && t != T_Q5_0 && t != T_IQ4_NL) return false;
         if (g.expert_sel && (s != 0 && !(swiglu && s == 1))) return false;      // experts on segment 0 (and the up tensor of its pair) only
-        if ((g.row_bytes % 16) != 0 || g.row_bytes < 1024) return false;
+        if ((g.row_bytes % 16) != 0 || g.row_bytes < 512) return false;         // (512: a Q2_K row of K = 2048 - TinyLlama's hidden size in the smoke model's file - is 672 B)
         if (g.row_bytes > (size_t)ST_MAX_STEP) return false;
         if (kb <= 2 && 2 * g.row_bytes > (size_t)ST_PAIR_MAX) return false;      // K <= 4096 only has the row-pair form
-        if (ST_PAIR_MAX <= 12288 && kb >= 6 && 2 * g.row_bytes <= (size_t)ST_PAIR_MAX) return false;     // K >= 10240 only the single-row form
+        // (K >= 10240: rows of the 2- and 3-bit formats are short enough for the row-pair form too - Q2_K at K = 14336: 4704 B)
         if ((reinterpret_cast<uintptr_t>(g.W) & 15) != 0) return false;
-        if (a.fuse_mode == 0 && (t == T_Q8_0 || !a.aq || !a.ad || !a.abs)) return false;
+        if (a.fuse_mode == 0 && (act_is_q80(t) || !a.aq || !a.ad || !a.abs)) return false;
     }
     if (a.fuse_mode == 0 && (((uintptr_t)a.aq | (uintptr_t)a.ad | (uintptr_t)a.abs) & 15) != 0) return false;
     if (a.fuse_mode != 0 && (reinterpret_cast<uintptr_t>(a.nx) & 15) != 0) return false;

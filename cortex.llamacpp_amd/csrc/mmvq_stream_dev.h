@@ -125,6 +125,38 @@ template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q8_0> &r, con
     r.q1 = lds16(RO(b + 16u));
     r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + (unsigned)nb * 256u + ((unsigned)sb * 8u + (unsigned)L.v) * 2u));
 }
+// Q2_K / Q3_K device rows (planes: qs | scales | d, dmin  and  hmask | qs | scales | d) and the 32-element formats (nibbles | [qh] | scales): the fields of
+// Raw<>::load in mmvq_fast_dev.h, read out of the ring
+template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q2_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
+    r.q = lds16(RO(row_off + (unsigned)sb * 64u + (unsigned)(L.c >> 1) * 32u + (unsigned)L.h * 16u));
+    const unsigned so = row_off + (unsigned)nb * 64u + (unsigned)sb * 16u + 4u * (unsigned)L.c + (unsigned)L.h;
+    r.sc_lo = *RO(so);
+    r.sc_hi = *RO(so + 2u);
+    r.dd = *reinterpret_cast<const uint32_t *>(RO(row_off + (unsigned)nb * 80u + (unsigned)sb * 4u));
+}
+template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q3_K> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
+    r.hm = lds16(RO(row_off + (unsigned)sb * 32u + (unsigned)L.h * 16u));
+    r.q = lds16(RO(row_off + (unsigned)nb * 32u + (unsigned)sb * 64u + (unsigned)(L.c >> 1) * 32u + (unsigned)L.h * 16u));
+    const unsigned so = row_off + (unsigned)nb * 96u + (unsigned)sb * 12u;
+    r.s0w = *reinterpret_cast<const uint32_t *>(RO(so));
+    r.s1w = *reinterpret_cast<const uint32_t *>(RO(so + 4u));
+    r.s2w = *reinterpret_cast<const uint32_t *>(RO(so + 8u));
+    r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + (unsigned)nb * 108u + (unsigned)sb * 2u));
+}
+template <bool IL, int TYPE> __device__ __forceinline__ void ring_load_nib32(RawNib32<TYPE> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) {
+    const unsigned blk = (unsigned)sb * 8u + (unsigned)L.v, half = (unsigned)nb * 128u, nblk = (unsigned)nb * 8u;
+    r.q = lds16(RO(row_off + blk * 16u));
+    if (TYPE == T_Q5_0) {
+        r.qh = *reinterpret_cast<const uint32_t *>(RO(row_off + half + blk * 4u));
+        r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + half + nblk * 4u + blk * 2u));
+    } else {
+        r.qh = 0;
+        r.dh16 = *reinterpret_cast<const uint16_t *>(RO(row_off + half + blk * 2u));
+    }
+}
+template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q4_0> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) { ring_load_nib32<IL, T_Q4_0>(r, ring, base, row_off, nb, sb, L); }
+template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_Q5_0> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) { ring_load_nib32<IL, T_Q5_0>(r, ring, base, row_off, nb, sb, L); }
+template <bool IL> __device__ __forceinline__ void ring_load(Raw<T_IQ4_NL> &r, const uint8_t *ring, unsigned base, unsigned row_off, int nb, int sb, const LaneRole &L) { ring_load_nib32<IL, T_IQ4_NL>(r, ring, base, row_off, nb, sb, L); }
 #undef RO
 
 // ---- LDS layout (bytes from smem): sync words | reduction scratch | ring | activation of the current mat-vec
@@ -547,7 +579,7 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     if (rsd_regs && lane < n_rows_wg) rsd = a.resid[b0 + lane];
 
     // ---- activation into LDS (fused modes: by the consumers themselves; planes: DMA'd by loader 0 ahead of its first slot)
-    if (FUSE == 1 || FUSE == 2) consumer_prologue<KB, FUSE, TYPE == T_Q8_0, ENG == 1>(a, smem, lay, c, lane, io);
+    if (FUSE == 1 || FUSE == 2) consumer_prologue<KB, FUSE, act_is_q80(TYPE), ENG == 1>(a, smem, lay, c, lane, io);
     else if (FUSE == 3) {
         ST_SPIN_WHILE(ld_sync(sy + SY_READY) < io.ready_round && ld_sync(sy + SY_ABORT) == 0, 1);
     } else {
@@ -662,7 +694,7 @@ __device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, 
 #define RUN(TY)                                                                                               \
     do {                                                                                                      \
         if (a.swiglu) { if constexpr (FUSE == 1 || (FUSE == 3 && KB <= 4)) consumer_op<TY, KB, FUSE, true, true, ENG>(a, smem, c, g0, lay, io); } \
-        else if (a.pair) { if constexpr (KB <= 4 || ST_PAIR_MAX > 12288) consumer_op<TY, KB, FUSE, false, true, ENG>(a, smem, c, g0, lay, io); } \
+        else if (a.pair) { if constexpr (KB <= 4 || ENG == 0) consumer_op<TY, KB, FUSE, false, true, ENG>(a, smem, c, g0, lay, io); } \
         else { if constexpr (KB >= 3) consumer_op<TY, KB, FUSE, false, false, ENG>(a, smem, c, g0, lay, io); } \
     } while (0)
     switch (a.type) {
@@ -670,6 +702,12 @@ __device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, 
         case T_Q5_K: RUN(T_Q5_K); break;
         case T_Q6_K: RUN(T_Q6_K); break;
         case T_Q8_0: if constexpr (FUSE == 1 || FUSE == 2) RUN(T_Q8_0); break;
+        // round 4 (one mat-vec per launch only: the layer engine keeps to the types it was built with)
+        case T_Q2_K: if constexpr (ENG == 0) RUN(T_Q2_K); break;
+        case T_Q3_K: if constexpr (ENG == 0) RUN(T_Q3_K); break;
+        case T_Q4_0: if constexpr (ENG == 0 && (FUSE == 1 || FUSE == 2)) RUN(T_Q4_0); break;
+        case T_Q5_0: if constexpr (ENG == 0 && (FUSE == 1 || FUSE == 2)) RUN(T_Q5_0); break;
+        case T_IQ4_NL: if constexpr (ENG == 0 && (FUSE == 1 || FUSE == 2)) RUN(T_IQ4_NL); break;
         default: break;
     }
 #undef RUN

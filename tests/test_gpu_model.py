@@ -387,7 +387,11 @@ def test_layer_engine_matches_per_launch_bitwise(be, pkg, tmp_models, cfg, ftype
                                           # mixture of experts: the token's two selected experts share a launch (gate | up with SwiGLU, then down), expert index read on the device
                                           ("tiny-moe-e2048", "q4_k_m", "q8_0"), ("tiny-moe-e2048", "q5_k_m", "f16"),
                                           # contraction lengths that end inside a 2048-wide pass: TinyLlama's feed-forward width 5632, Qwen2-7B's hidden size 3584
-                                          ("tiny-tl-2l", "q4_k_m", "f16"), ("tiny-qwen2-7b-2l", "q4_k_m", "q8_0"), ("tiny-qwen2-1.5b-2l", "q5_k_m", "q8_0")])
+                                          ("tiny-tl-2l", "q4_k_m", "f16"), ("tiny-qwen2-7b-2l", "q4_k_m", "q8_0"), ("tiny-qwen2-1.5b-2l", "q5_k_m", "q8_0"),
+                                          # round 4: Q2_K / Q3_K tensors (the smoke model's mix at TinyLlama's geometry: 672- and 880-byte rows; Llama-3-8B's: row pairs
+                                          # at K = 14336), the 32-element formats (Q8_0 activation blocks in the prologue) and launches of Q8_0 tensors only
+                                          ("tiny-tl-2l", "q2_k", "f16"), ("tiny-tl-2l", "q3_k_m", "q8_0"), ("tiny-8b-2l", "q2_k", "q8_0"), ("tiny-8b-2l", "q3_k_s", "q8_0"),
+                                          ("tiny-e2048", "q4_0", "q8_0"), ("tiny-8b-2l", "q5_0", "q8_0"), ("tiny-8b-2l", "iq4_nl", "f16"), ("tiny-8b-2l", "q8_0", "q8_0")])
 def test_weight_stream_matvec_matches_register_ring_bitwise(be, pkg, tmp_models, cfg, ftype, kv):
     """The single-token mat-vecs run as an LDS-DMA weight stream (mmvq_stream.hip: loader waves + consumer waves per CU);
     the register-ring kernel (mmvq_fast.hip) stays as the form for shapes the stream has none for.  Same arithmetic, same
