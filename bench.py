@@ -127,7 +127,8 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
     if world > 1 and not args.no_p2p:
         ok, why = 1, ""
         try:
-            pkg.binding.tp_p2p_enable(rank, world, local_rank, 16384)
+            pkg.binding.tp_p2p_enable(rank, world, local_rank, 16384, prompt_floats=model.n_embd * min(args.prompt, N_UBATCH))
+            pkg.Backend().set_option("tp_p2p_prompt", 0)       # (its own phase below: this one keeps RCCL for the prompt batches)
         except Exception as e:  # noqa: BLE001 - reported in the record
             ok, why = 0, f"{type(e).__name__}: {e}"[:200]
         flag = torch.tensor([ok], dtype=torch.int64, device=f"cuda:{local_rank}")
@@ -148,6 +149,24 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
                 res["parallelism"] = (f"row split over {world} GPUs (attn_output / ffn_down partial sums all-reduced twice per layer: one-shot peer-to-peer kernel "
                                       f"over IPC-mapped buffers for the decode steps, RCCL for prompt batches; logits gathered)")
             partial.pop("p2p_error", None)
+            partial.update(res)
+            # ---- the prompt batches' exchanges as ONE reduce-scatter + all-gather kernel over all links (host/tp_comm.cc p2p_rsag_kernel); prefill only
+            partial["rsag_error"] = "the reduce-scatter + all-gather phase did not finish"
+            pkg.Backend().set_option("tp_p2p_prompt", 1)
+            new_context()
+            prefill()
+            sync_all()
+            t_rs, tok_rs = prefill()
+            holder["ctx"].synchronize()
+            tt = torch.tensor([t_rs], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res["prefill_tok_s_rccl"] = res["prefill_tok_s"]
+            res["prefill_tok_s_rsag"] = round(args.prompt / float(tt[0].item()), 1)
+            res["rsag_exchanges"] = int(pkg.binding.tp_p2p_prompt_exchanges())
+            res["rsag_ranks_agree_on_first_token"] = agree(tok_rs)
+            if res["rsag_exchanges"] > 0 and res["rsag_ranks_agree_on_first_token"] and res["prefill_tok_s_rsag"] > res["prefill_tok_s"]:
+                res["prefill_tok_s"] = res["prefill_tok_s_rsag"]
+            partial.pop("rsag_error", None)
         else:
             pkg.Backend().set_option("tp_p2p", 0)
             res["p2p_error"] = why or "another rank could not map its peers' buffers"

@@ -130,6 +130,8 @@ SYMBOLS = {
     "mi355_engine_set_log_level": (None, [_vp, _i32]),
     "mi355_engine_set_log_callback": (None, [_vp, _vp, _vp]),
     "mi355_tp_p2p_local_handle": (C.c_int, [_vp, _sz, _sz]),
+    "mi355_tp_p2p_local_handle2": (C.c_int, [_vp, _sz, _sz, _sz]),
+    "mi355_tp_p2p_prompt_exchanges": (C.c_int64, []),
     "mi355_tp_p2p_enable": (C.c_int, [_vp, _sz]),
     "mi355_tp_p2p_exchanges": (C.c_int64, []),
     "mi355_tp_unique_id": (C.c_int, [_vp, _sz]),
@@ -334,15 +336,16 @@ def gloo_exchange(group=None):
 _tp_keepalive = []
 
 
-def tp_p2p_enable(rank: int, size: int, device: int, max_floats: int, group=None):
+def tp_p2p_enable(rank: int, size: int, device: int, max_floats: int, group=None, prompt_floats: int = 0):
     """One-shot peer-to-peer all-reduce for messages of up to max_floats floats (mi355_tp_p2p_*): every rank exports its exchange buffer, the 64-byte
-    IPC handles are all-gathered over torch.distributed, every rank maps its peers' buffers."""
+    IPC handles are all-gathered over torch.distributed, every rank maps its peers' buffers.  prompt_floats > max_floats: messages up to that size
+    take the reduce-scatter + all-gather kernel (mi355_tp_p2p_local_handle2)."""
     import torch
     import torch.distributed as dist
     lib = load_library()
     hb = (C.c_uint8 * 64)()
-    if lib.mi355_tp_p2p_local_handle(hb, 64, max_floats) != 64:
-        raise MI355Error(f"mi355_tp_p2p_local_handle failed: {_err(lib)}")
+    if lib.mi355_tp_p2p_local_handle2(hb, 64, max_floats, prompt_floats) != 64:
+        raise MI355Error(f"mi355_tp_p2p_local_handle2 failed: {_err(lib)}")
     backend = dist.get_backend(group)
     dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
     mine = torch.tensor(list(bytes(hb)), dtype=torch.uint8, device=dev)
@@ -357,11 +360,16 @@ def tp_p2p_exchanges() -> int:
     return int(load_library().mi355_tp_p2p_exchanges())
 
 
-def tp_init(rank: int, size: int, device: int = 0, transport: str = "rccl", group=None, p2p_floats: int = 0):
+def tp_p2p_prompt_exchanges() -> int:
+    return int(load_library().mi355_tp_p2p_prompt_exchanges())
+
+
+def tp_init(rank: int, size: int, device: int = 0, transport: str = "rccl", group=None, p2p_floats: int = 0, p2p_prompt_floats: int = 0):
     """Forms the process's row-split group (include/mi355_llama.h, mi355_tp_*).  transport "rccl": rank 0 makes the RCCL
     id, torch.distributed (any backend) carries it to the others, every rank calls mi355_tp_init on its device.
     transport "host": the exchange goes through gloo_exchange(group) (ranks sharing one GPU; validation only).
-    p2p_floats > 0: all-reduces of up to that many floats (the decode steps' exchanges) take the one-shot peer-to-peer kernel."""
+    p2p_floats > 0: all-reduces of up to that many floats (the decode steps' exchanges) take the one-shot peer-to-peer kernel;
+    p2p_prompt_floats > p2p_floats: larger ones up to that size (prompt batches) the reduce-scatter + all-gather kernel."""
     lib = load_library()
     if transport == "host":
         cb = TP_HOST_EXCHANGE(gloo_exchange(group))
@@ -369,7 +377,7 @@ def tp_init(rank: int, size: int, device: int = 0, transport: str = "rccl", grou
         if lib.mi355_tp_set_host_exchange(C.cast(cb, C.c_void_p), None, rank, size) != 0:
             raise MI355Error(f"mi355_tp_set_host_exchange failed: {_err(lib)}")
         if p2p_floats > 0 and size > 1:
-            tp_p2p_enable(rank, size, device, p2p_floats, group)
+            tp_p2p_enable(rank, size, device, p2p_floats, group, p2p_prompt_floats)
         return
     buf = (C.c_uint8 * TP_ID_BYTES)()
     if size > 1:
@@ -388,7 +396,7 @@ def tp_init(rank: int, size: int, device: int = 0, transport: str = "rccl", grou
     if lib.mi355_tp_init(device, rank, size, buf, TP_ID_BYTES) != 0:
         raise MI355Error(f"mi355_tp_init failed: {_err(lib)}")
     if p2p_floats > 0 and size > 1:
-        tp_p2p_enable(rank, size, device, p2p_floats, group)
+        tp_p2p_enable(rank, size, device, p2p_floats, group, p2p_prompt_floats)
 
 
 def tp_shutdown():

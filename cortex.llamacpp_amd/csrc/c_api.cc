@@ -731,6 +731,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
     if (!strcmp(name, "decode_engine")) { set_decode_engine(value); return MI355_OK; }
     if (!strcmp(name, "tp_p2p")) { tp_p2p_use(value != 0); return MI355_OK; }
+    if (!strcmp(name, "tp_p2p_prompt")) { tp_p2p_use_prompt(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "attn_out_fused")) { set_attn_out_fused(value); return MI355_OK; }     // (contexts created afterwards)
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
@@ -764,13 +765,14 @@ int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t ra
     return MI355_OK;
 }
 
-int mi355_tp_p2p_local_handle(void *out, size_t cap, size_t max_floats) {
+int mi355_tp_p2p_local_handle2(void *out, size_t cap, size_t max_floats, size_t prompt_floats) {
     if (!need_device()) return MI355_ERR_NO_DEVICE;
     std::string err;
-    const int n = tp_p2p_local_handle(out, cap, max_floats, err);
+    const int n = tp_p2p_local_handle(out, cap, max_floats, prompt_floats, err);
     if (n < 0) { fail(err); return MI355_ERR_ARG; }
     return n;
 }
+int mi355_tp_p2p_local_handle(void *out, size_t cap, size_t max_floats) { return mi355_tp_p2p_local_handle2(out, cap, max_floats, 0); }
 int mi355_tp_p2p_enable(const void *handles, size_t len) {
     if (!need_device()) return MI355_ERR_NO_DEVICE;
     std::string err;
@@ -778,6 +780,7 @@ int mi355_tp_p2p_enable(const void *handles, size_t len) {
     return MI355_OK;
 }
 int64_t mi355_tp_p2p_exchanges(void) { return tp_p2p_exchanges(); }
+int64_t mi355_tp_p2p_prompt_exchanges(void) { return tp_p2p_prompt_exchanges(); }
 
 double mi355_bench_hbm_read(size_t bytes, int iters) {
     if (!need_device()) return -1.0;

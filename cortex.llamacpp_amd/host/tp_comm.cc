@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types and enums only: the functions are looked up in the library at run time
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -38,6 +39,7 @@ std::mutex g_mu;
 
 // ---- peer-to-peer exchange state (see tp_comm.h)
 constexpr int P2P_MAX_RANKS = 8, P2P_WGS = 16, P2P_SPIN_LIMIT = 1 << 22;
+constexpr int RSAG_MAX_WGS = 256;      // flag rows are laid out for this many slices; the launch uses g_p2p.rsag_wgs of them
 struct P2PDev {                        // by value into the kernel
     float *data[P2P_MAX_RANKS];        // base of every rank's slot area: [2 sets][P slots][max_floats]
     unsigned *flags[P2P_MAX_RANKS];    // base of every rank's flag area: [2 sets][P][P2P_WGS]
@@ -45,6 +47,11 @@ struct P2PDev {                        // by value into the kernel
     unsigned *err;                     // nullable: pinned host word
     int rank, size;
     size_t max_floats;
+    // prompt-sized messages (p2p_rsag_kernel): per rank [2 sets][P sources][seg_max] partial segments, then [2 sets][P owners][seg_max] reduced segments
+    float *big[P2P_MAX_RANKS];
+    unsigned *bflags[P2P_MAX_RANKS];   // [2 sets][2 phases][P][RSAG_MAX_WGS]
+    unsigned *bepoch;                  // private [RSAG_MAX_WGS]
+    size_t seg_max;                    // floats per segment slot (a multiple of 4)
 };
 struct P2PState {
     bool on = false;
@@ -54,6 +61,11 @@ struct P2PState {
     unsigned *epoch = nullptr, *err = nullptr;
     size_t max_floats = 0;
     int64_t exchanges = 0;
+    size_t big_off = 0, bflags_off = 0, prompt_floats = 0;
+    unsigned *bepoch = nullptr;
+    bool prompt_on = false;
+    int rsag_wgs = 64;
+    int64_t prompt_exchanges = 0;
     P2PDev dev{};
 };
 P2PState g_p2p;
@@ -95,6 +107,91 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
         recv[i] = acc;
     }
     if (tid == 0) a.epoch[w] = e;
+}
+
+// ---- prompt-sized messages: reduce-scatter + all-gather on all links at once (no reference counterpart: upstream copies whole
+// activations between peers).  The message is cut into P segments, rank r owns segment r.  Phase 1: every rank stores its part of segment q
+// straight into rank q's buffer (slot = source rank) - P - 1 peer streams leaving on P - 1 different links, (P - 1) / P of the message in total.
+// Phase 2: the owner adds the P parts of its segment in rank order (the same association as the one-shot kernel above, and p0 + p1 for two ranks)
+// and stores the sum into every rank's buffer; each rank copies the P - 1 foreign segments from its own buffer into `recv`.  A ring all-reduce
+// moves 2 (P - 1) / P of the message over ONE link direction per rank; this moves the same bytes over seven.
+// A workgroup owns the same sub-slice of every segment from start to finish and waits only for the workgroups of the same index on the other
+// ranks: no device-wide step, no co-residency requirement.  Two buffer sets alternate as above.  Remote data is stored write-through (sc0 sc1) and
+// read back past the L2 (the lines were written by other devices); flags are system-scope atomics behind a system fence.
+typedef unsigned int tp_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tp_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tp_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
+}
+constexpr int TP_SYS = 17;             // cache policy bits sc0 | sc1: system scope
+__device__ __forceinline__ tp_f32x4 tp_ld_sys(__amdgpu_buffer_rsrc_t r, int float_off) {
+    return __builtin_bit_cast(tp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, TP_SYS));
+}
+__device__ __forceinline__ void tp_st_sys(__amdgpu_buffer_rsrc_t r, int float_off, tp_f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tp_u32x4, v), r, float_off * 4, 0, TP_SYS);
+}
+__device__ __forceinline__ void rsag_signal_and_wait(const P2PDev &a, size_t set, int phase, int w, unsigned e) {
+    const int tid = (int)threadIdx.x, P = a.size;
+    __threadfence_system();                               // every thread: its stores have reached their owners before the flags leave
+    __syncthreads();
+    const size_t row = (set * 2 + (size_t)phase) * (size_t)P;
+    if (tid < P && tid != a.rank) {
+        __hip_atomic_store(a.bflags[tid] + (row + (size_t)a.rank) * RSAG_MAX_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned *f = a.bflags[a.rank] + (row + (size_t)tid) * RSAG_MAX_WGS + w;
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            if (++spins >= P2P_SPIN_LIMIT) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float *recv, int n, const P2PDev a) {
+    __shared__ unsigned e_sh;
+    const int tid = (int)threadIdx.x, w = (int)blockIdx.x, G = (int)gridDim.x, P = a.size, R = a.rank;
+    if (tid == 0) e_sh = a.bepoch[w] + 1u;
+    __syncthreads();
+    const unsigned e = e_sh;
+    const size_t set = e & 1u;
+    const int seg = ((n / 4 + P - 1) / P) * 4;                       // floats per segment (the last one may be shorter, or empty)
+    const int per = ((seg / 4 + G - 1) / G) * 4;                     // floats of a segment that one workgroup carries
+    const int s_lo = w * per, s_hi = s_lo + per < seg ? s_lo + per : seg;
+    const size_t slot = a.seg_max, half = 2 * (size_t)P * slot;      // [partials: 2 sets][reduced: 2 sets]
+    // 1. my part of every foreign segment into its owner's buffer, slot R; the nearest owner first so that the P ranks start on P different links
+    for (int d = 1; d < P; d++) {
+        const int q = R + d < P ? R + d : R + d - P;
+        const int hi = q * seg + s_hi < n ? s_hi : n - q * seg;
+        const __amdgpu_buffer_rsrc_t dst = tp_rsrc(a.big[q] + (set * (size_t)P + (size_t)R) * slot);
+        const tp_f32x4 *src = reinterpret_cast<const tp_f32x4 *>(send + (size_t)q * seg);
+        for (int i = s_lo + tid * 4; i < hi; i += 1024) tp_st_sys(dst, i, src[i >> 2]);
+    }
+    rsag_signal_and_wait(a, set, 0, w, e);
+    // 2. my segment: the P parts in rank order; the sum to `recv` and into every rank's reduced area, slot R
+    {
+        const int hi = R * seg + s_hi < n ? s_hi : n - R * seg;
+        const tp_f32x4 *own = reinterpret_cast<const tp_f32x4 *>(send + (size_t)R * seg);
+        tp_f32x4 *out = reinterpret_cast<tp_f32x4 *>(recv + (size_t)R * seg);
+        const float *parts = a.big[R] + set * (size_t)P * slot;
+        for (int i = s_lo + tid * 4; i < hi; i += 1024) {
+            tp_f32x4 acc = R == 0 ? own[i >> 2] : tp_ld_sys(tp_rsrc(parts), i);
+            for (int q = 1; q < P; q++) acc += q == R ? own[i >> 2] : tp_ld_sys(tp_rsrc(parts + (size_t)q * slot), i);
+            out[i >> 2] = acc;
+            for (int d = 1; d < P; d++) {
+                const int q = R + d < P ? R + d : R + d - P;
+                tp_st_sys(tp_rsrc(a.big[q] + half + (set * (size_t)P + (size_t)R) * slot), i, acc);
+            }
+        }
+    }
+    rsag_signal_and_wait(a, set, 1, w, e);
+    // 3. the foreign segments out of my own buffer
+    for (int d = 1; d < P; d++) {
+        const int q = R + d < P ? R + d : R + d - P;
+        const int hi = q * seg + s_hi < n ? s_hi : n - q * seg;
+        const __amdgpu_buffer_rsrc_t src = tp_rsrc(a.big[R] + half + (set * (size_t)P + (size_t)q) * slot);
+        tp_f32x4 *out = reinterpret_cast<tp_f32x4 *>(recv + (size_t)q * seg);
+        for (int i = s_lo + tid * 4; i < hi; i += 1024) out[i >> 2] = tp_ld_sys(src, i);
+    }
+    if (tid == 0) a.bepoch[w] = e;
 }
 
 bool load_rccl(std::string &err) {
@@ -176,7 +273,7 @@ void tp_set_null_group(int rank, int size) {
     g_grp.null_group = size >= 1; g_grp.rank = rank; g_grp.size = size >= 1 ? size : 1;
 }
 
-int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, std::string &err) {
+int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, size_t prompt_floats, std::string &err) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!out || cap < (size_t)TP_P2P_HANDLE_BYTES) { err = "handle buffer must hold 64 bytes"; return -1; }
     if (!(g_grp.comm || g_grp.host_fn) || g_grp.size < 2 || g_grp.size > P2P_MAX_RANKS) { err = "peer-to-peer exchange needs a row-split group of 2..8 ranks first"; return -1; }
@@ -185,12 +282,24 @@ int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, std::string &e
     P2PState &p = g_p2p;
     if (!p.local) {
         const size_t P = (size_t)g_grp.size;
+        if (prompt_floats & 3) { err = "prompt_floats must be a multiple of 4"; return -1; }
         p.flags_off = (2 * P * max_floats * sizeof(float) + 255) & ~(size_t)255;
         p.bytes = p.flags_off + 2 * P * P2P_WGS * sizeof(unsigned);
-        if (hipMalloc((void **)&p.local, p.bytes) != hipSuccess || hipMalloc((void **)&p.epoch, P2P_WGS * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc of the exchange buffer failed"; return -1; }
-        if (hipMemset(p.local, 0, p.bytes) != hipSuccess || hipMemset(p.epoch, 0, P2P_WGS * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { err = "clearing the exchange buffer failed"; return -1; }
+        size_t seg_max = 0;
+        if (prompt_floats > max_floats) {                  // the prompt-sized area: 4 P segment slots (2 sets x {partials, reduced}) + its flag rows
+            seg_max = ((prompt_floats / 4 + P - 1) / P) * 4;
+            if (4 * P * seg_max * sizeof(float) >= ((size_t)1 << 31)) { err = "prompt_floats: the exchange area must stay below 2 GB"; return -1; }
+            p.big_off = (p.bytes + 255) & ~(size_t)255;
+            p.bflags_off = p.big_off + 4 * P * seg_max * sizeof(float);
+            p.bytes = p.bflags_off + 4 * P * RSAG_MAX_WGS * sizeof(unsigned);
+        }
+        if (hipMalloc((void **)&p.local, p.bytes) != hipSuccess || hipMalloc((void **)&p.epoch, (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc of the exchange buffer failed"; return -1; }
+        if (hipMemset(p.local, 0, p.bytes) != hipSuccess || hipMemset(p.epoch, 0, (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { err = "clearing the exchange buffer failed"; return -1; }
         p.max_floats = max_floats;
-    } else if (p.max_floats != max_floats) { err = "the exchange buffer exists with another size"; return -1; }
+        p.prompt_floats = seg_max ? prompt_floats : 0;
+        p.bepoch = p.epoch + P2P_WGS;
+        p.dev.seg_max = seg_max;
+    } else if (p.max_floats != max_floats || (prompt_floats > max_floats ? prompt_floats : 0) != p.prompt_floats) { err = "the exchange buffer exists with another size"; return -1; }
     hipIpcMemHandle_t h;
     const hipError_t e = hipIpcGetMemHandle(&h, p.local);
     if (e != hipSuccess) { err = std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e); return -1; }
@@ -214,16 +323,23 @@ int tp_p2p_enable(const void *handles, size_t len, std::string &err) {
         p.peer[q] = ptr;
     }
     P2PDev d{};
-    for (int q = 0; q < P; q++) { d.data[q] = (float *)p.peer[q]; d.flags[q] = (unsigned *)((uint8_t *)p.peer[q] + p.flags_off); }
-    d.epoch = p.epoch; d.err = p.err; d.rank = g_grp.rank; d.size = P; d.max_floats = p.max_floats;
+    for (int q = 0; q < P; q++) {
+        d.data[q] = (float *)p.peer[q]; d.flags[q] = (unsigned *)((uint8_t *)p.peer[q] + p.flags_off);
+        d.big[q] = (float *)((uint8_t *)p.peer[q] + p.big_off); d.bflags[q] = (unsigned *)((uint8_t *)p.peer[q] + p.bflags_off);
+    }
+    d.epoch = p.epoch; d.bepoch = p.bepoch; d.err = p.err; d.rank = g_grp.rank; d.size = P; d.max_floats = p.max_floats; d.seg_max = p.dev.seg_max;
     p.dev = d;
     p.on = true;
+    p.prompt_on = p.prompt_floats > 0;
+    if (const char *ev = getenv("MI355_TP_RSAG_WGS")) { const int v = atoi(ev); if (v >= 1 && v <= RSAG_MAX_WGS) p.rsag_wgs = v; }
     return 0;
 }
 bool tp_p2p_active() { return g_p2p.on; }
 void tp_p2p_use(bool on) { g_p2p.on = on && g_p2p.peer[g_grp.rank] != nullptr; }
+void tp_p2p_use_prompt(bool on) { g_p2p.prompt_on = on && g_p2p.prompt_floats > 0 && g_p2p.peer[g_grp.rank] != nullptr; }
 void tp_p2p_set_error_word(unsigned *w) { g_p2p.err = w; g_p2p.dev.err = w; }
 int64_t tp_p2p_exchanges() { return g_p2p.exchanges; }
+int64_t tp_p2p_prompt_exchanges() { return g_p2p.prompt_exchanges; }
 
 void tp_shutdown() {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -249,6 +365,11 @@ hipError_t tp_all_reduce_sum(const float *send, float *recv, size_t n, hipStream
     if (g_p2p.on && n <= g_p2p.max_floats && n >= 4) {          // decode-sized message: the one-shot peer-to-peer kernel
         g_p2p.exchanges++;
         hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(P2P_WGS), dim3(256), 0, st, send, recv, (int)n, g_p2p.dev);
+        return hipGetLastError();
+    }
+    if (g_p2p.on && g_p2p.prompt_on && n > g_p2p.max_floats && n <= g_p2p.prompt_floats && !(n & 3)) {   // prompt-sized: reduce-scatter + all-gather over all links
+        g_p2p.prompt_exchanges++;
+        hipLaunchKernelGGL(p2p_rsag_kernel, dim3(g_p2p.rsag_wgs), dim3(256), 0, st, send, recv, (int)n, g_p2p.dev);
         return hipGetLastError();
     }
     if (g.host_fn) return host_exchange(const_cast<float *>(send), recv, n, n, 0, n, 0, st);

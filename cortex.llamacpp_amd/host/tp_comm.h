@@ -41,12 +41,17 @@ bool tp_uses_host();      // host transport: no stream capture
 // Bootstrap: tp_p2p_local_handle on every rank -> all-gather the 64-byte handles over any side channel (the one that carried the RCCL id) ->
 // tp_p2p_enable with all of them, after tp_init / tp_set_host_exchange.
 constexpr int TP_P2P_HANDLE_BYTES = 64;
-int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, std::string &err);   // returns TP_P2P_HANDLE_BYTES or < 0
+// prompt_floats > max_floats additionally sizes the buffer for the reduce-scatter + all-gather kernel (tp_comm.cc p2p_rsag_kernel): messages of
+// (max_floats, prompt_floats] floats - the prompt batches' n_embd x n_ubatch partial sums - are cut into one segment per rank, every rank stores its
+// part of segment q into rank q's buffer (all links busy at once), the owner adds in rank order and stores the sum back to everybody.
+int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, size_t prompt_floats, std::string &err);   // returns TP_P2P_HANDLE_BYTES or < 0
 int tp_p2p_enable(const void *handles, size_t len, std::string &err);                  // len = size * TP_P2P_HANDLE_BYTES, rank-major
 bool tp_p2p_active();
 void tp_p2p_use(bool on);                            // measurement: route the small all-reduces back to the base transport (contexts created afterwards)
 void tp_p2p_set_error_word(unsigned *host_word);     // pinned host word ORed with 32 when a bounded wait of the exchange kernel gives up
+void tp_p2p_use_prompt(bool on);                     // the prompt-sized kernel alone (on after tp_p2p_enable when the buffer was sized for it)
 int64_t tp_p2p_exchanges();                          // diagnosis: all-reduces that took the peer-to-peer kernel
+int64_t tp_p2p_prompt_exchanges();                   // ... the reduce-scatter + all-gather kernel
 
 // recv[i] = sum over ranks of send[i]; send may equal recv
 hipError_t tp_all_reduce_sum(const float *send, float *recv, size_t n, hipStream_t st);

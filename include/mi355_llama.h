@@ -302,6 +302,13 @@ MI355_API int32_t mi355_tp_size(void);
 MI355_API int mi355_tp_p2p_local_handle(void *out, size_t cap, size_t max_floats);   /* returns bytes written or < 0 */
 MI355_API int mi355_tp_p2p_enable(const void *handles, size_t len);
 MI355_API int64_t mi355_tp_p2p_exchanges(void);                                      /* diagnosis: all-reduces that took the peer-to-peer kernel */
+/* The same bootstrap with a second size: all-reduces of (max_floats, prompt_floats] floats - the n_embd x n_ubatch partial sums of a prompt batch - run
+ * as ONE reduce-scatter + all-gather kernel over all xGMI links at once (host/tp_comm.cc p2p_rsag_kernel: the message is cut into one segment per rank,
+ * every rank stores its part of segment q into rank q's buffer, the owner adds the parts in rank order and stores the sum into everybody's buffer).  A
+ * ring all-reduce keeps one link direction per rank busy; the reference has no counterpart (it copies activations between peers,
+ * SURVEY.md §8e).  Option "tp_p2p_prompt" = 0 (mi355_debug_set_option) routes these messages back to RCCL. */
+MI355_API int mi355_tp_p2p_local_handle2(void *out, size_t cap, size_t max_floats, size_t prompt_floats);
+MI355_API int64_t mi355_tp_p2p_prompt_exchanges(void);                               /* diagnosis: all-reduces that took the reduce-scatter + all-gather kernel */
 typedef int (*mi355_tp_host_exchange)(void *user, float *buf, size_t n, int32_t op);
 MI355_API int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t rank, int32_t size);
 

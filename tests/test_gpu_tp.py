@@ -59,7 +59,7 @@ def run_ranks(world, plan_path, out_path, timeout=600):
     return np.load(out_path)
 
 
-def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n_tail=3, seed=21, p2p_floats=0):
+def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n_tail=3, seed=21, p2p_floats=0, p2p_prompt_floats=0):
     path = str(tmp_models / f"tp-{cfg}-{ftype}.gguf")
     if not os.path.exists(path):
         pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
@@ -81,9 +81,9 @@ def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n
     ref.extend(oc.decode(tail, np.arange(pos, pos + n_tail), want_logits=np.ones(n_tail, np.int8)))
     oq.set_fa_v_acc_f32(0)
     oc.close(); om.close()
-    plan_path = str(tmp_models / f"tp-plan-{cfg}-{ftype}-{kv}-{n_prompt}-{transport}-{p2p_floats}.npz")
+    plan_path = str(tmp_models / f"tp-plan-{cfg}-{ftype}-{kv}-{n_prompt}-{transport}-{p2p_floats}-{p2p_prompt_floats}.npz")
     np.savez(plan_path, path=path, kv=KV[kv], transport=transport, n_ctx=256, n_ubatch=64, prompt=prompt,
-             steps=np.asarray(steps, np.int32), tail=tail, p2p_floats=p2p_floats)
+             steps=np.asarray(steps, np.int32), tail=tail, p2p_floats=p2p_floats, p2p_prompt_floats=p2p_prompt_floats)
     return path, plan_path, np.stack(ref)
 
 
@@ -169,6 +169,39 @@ def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg,
         again = run_ranks(world, plan_p2p, str(tmp_models / f"tp-out-p2p2-{cfg}-{world}.npz"))
         assert np.array_equal(p2p["logits"], again["logits"])
         assert max(rel_err(a, b) for a, b in zip(p2p["logits"], host["logits"])) <= FLIP_TOL
+
+
+@pytest.mark.parametrize("cfg,ftype,kv,world,wgs", [("tiny-e2048", "q4_k_m", "q8_0", 2, 0), ("tiny-8b-2l", "q4_k_m", "q8_0", 2, 7), ("tiny-e2048", "q4_k_m", "q8_0", 4, 0),
+                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5)])
+def test_prompt_sized_exchange_as_reduce_scatter_all_gather(pkg, tmp_models, cfg, ftype, kv, world, wgs, monkeypatch):
+    """Prompt batches: the n_embd x n_ubatch partial sums go through ONE reduce-scatter + all-gather kernel (host/tp_comm.cc p2p_rsag_kernel:
+    a segment per rank, every rank stores its part of segment q into rank q's IPC-mapped buffer, the owner adds in rank order and stores the sum
+    into everybody's buffer) instead of the base transport.  A 100-token prompt in micro-batches of 64 = messages of 64 E and 36 E floats, twice
+    per layer; the single-token steps keep the one-shot kernel.  Two ranks: bit-identical to the pure host-exchange run (p0 + p1 either way);
+    four ranks: the rank-order sum is the one-shot kernel's association - oracle bound, the host run within the flip tolerance, the same bits
+    again on a second run.  `wgs` cuts the segments into an odd number of slices (ragged last slice)."""
+    pkg.Backend()
+    if wgs:
+        monkeypatch.setenv("MI355_TP_RSAG_WGS", str(wgs))
+    C_ = pkg.gguf_synth.CONFIGS[cfg]
+    E, n_layer = C_.n_embd, C_.n_layer
+    path, plan_host, ref = make_plan(pkg, tmp_models, cfg, ftype, kv, 100, "host")
+    _, plan_rs, _ = make_plan(pkg, tmp_models, cfg, ftype, kv, 100, "host", p2p_floats=4 * E, p2p_prompt_floats=64 * E)
+    host = run_ranks(world, plan_host, str(tmp_models / f"tp-out-host100-{cfg}-{ftype}-{world}.npz"))
+    rs = run_ranks(world, plan_rs, str(tmp_models / f"tp-out-rsag-{cfg}-{ftype}-{world}.npz"))
+    assert int(host["p2p_prompt_exchanges"]) == 0
+    assert int(rs["p2p_prompt_exchanges"]) == 2 * n_layer * 2         # two micro-batches
+    assert int(rs["p2p_exchanges"]) >= 2 * n_layer * 6
+    errs = [rel_err(a, b) for a, b in zip(rs["logits"], ref)]
+    assert max(errs) <= FLIP_TOL, errs
+    if world == 2:
+        assert np.array_equal(rs["logits"], host["logits"])
+        assert np.array_equal(rs["taps"], host["taps"])
+    else:
+        again = run_ranks(world, plan_rs, str(tmp_models / f"tp-out-rsag2-{cfg}-{ftype}-{world}.npz"))
+        assert np.array_equal(rs["logits"], again["logits"])
+        assert np.array_equal(rs["taps"], again["taps"])
+        assert max(rel_err(a, b) for a, b in zip(rs["logits"], host["logits"])) <= FLIP_TOL
 
 
 def test_rccl_group_of_one_captured_in_graphs_is_bit_identical(pkg, tmp_models):

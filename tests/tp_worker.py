@@ -27,7 +27,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg.Backend()
     p2p = int(plan["p2p_floats"]) if "p2p_floats" in plan.files else 0
-    pkg.binding.tp_init(rank, world, device=0, transport=transport, p2p_floats=p2p)
+    p2p_prompt = int(plan["p2p_prompt_floats"]) if "p2p_prompt_floats" in plan.files else 0
+    pkg.binding.tp_init(rank, world, device=0, transport=transport, p2p_floats=p2p, p2p_prompt_floats=p2p_prompt)
     model = pkg.Model(str(plan["path"]), tp_rank=rank, tp_size=world)
     ctx = pkg.Context(model, n_ctx=int(plan["n_ctx"]), type_k=int(plan["kv"]), type_v=int(plan["kv"]), n_ubatch=int(plan["n_ubatch"]))
     rows = []
@@ -35,7 +36,8 @@ def main():
     ctx.enable_taps(True)                          # residual stream after every layer, for the prompt
     assert ctx.decode(prompt, np.arange(prompt.size)) == 0
     rows.append(ctx.logits())
-    taps = np.stack([ctx.layer_out(il, prompt.size).reshape(prompt.size, -1) for il in range(model.n_layer)])
+    # (the taps hold the last micro-batch of a prompt that was cut into several)
+    taps = np.stack([ctx.layer_out(il, prompt.size).reshape(-1, model.n_embd) for il in range(model.n_layer)])
     ctx.enable_taps(False)
     pos = prompt.size
     for tok in plan["steps"]:
@@ -52,7 +54,8 @@ def main():
         np.savez(sys.argv[2] + f".rank{rank}.npz", logits=np.stack(rows))
     if rank == 0:
         np.savez(sys.argv[2], logits=np.stack(rows), taps=taps, n_head=model.n_head, n_head_kv=model.n_head_kv,
-                 bytes_per_token=model.bytes_per_token, p2p_exchanges=pkg.binding.tp_p2p_exchanges())
+                 bytes_per_token=model.bytes_per_token, p2p_exchanges=pkg.binding.tp_p2p_exchanges(),
+                 p2p_prompt_exchanges=pkg.binding.tp_p2p_prompt_exchanges())
     ctx.close(); model.close()
     pkg.binding.tp_shutdown()
     if world > 1:
