@@ -35,7 +35,8 @@ MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 / fp8 matrix-core peak of MI355X (M
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
-KERNEL_SOURCES = ("mmvq_stream.hip", "mmvq_stream_dev.h", "mmvq_fast.hip", "mmvq_fast_dev.h", "mmvq.hip", "quant_dev.h", "dev_common.h")
+KERNEL_SOURCES = ("mmvq_stream.hip", "mmvq_stream_dev.h", "mmvq_fast.hip", "mmvq_fast_dev.h", "mmvq.hip", "quant_dev.h", "dev_common.h",
+                  "attn_out.hip", "attn_decode_dev.h")
 
 
 def kernel_sources_sha256(root: str) -> str:
@@ -453,19 +454,35 @@ def main() -> int:
     # note of the microarchitecture guide); null when the profile is absent or is for another workload
     traffic, traffic_note = None, "no PMC profile for this workload"
     root = os.path.dirname(os.path.abspath(__file__))
-    tpath = os.path.join(root, "profiles", "r3_pmc_decode_traffic.json")
+    tpath = os.path.join(root, "profiles", "r4_pmc_decode_traffic.json")
+    sha_now = kernel_sources_sha256(root)
     if os.path.exists(tpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
             with open(tpath) as f:
                 tj = json.load(f)
             # the profile names the kernel sources it was taken from (sha256 over the mat-vec kernel files): a kernel change since then makes the
             # figure stale, and it is withheld rather than repeated
-            if tj.get("kernel_sources_sha256") == kernel_sources_sha256(root):
-                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), "profiles/r3_pmc_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
+            if tj.get("kernel_sources_sha256") == sha_now:
+                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), "profiles/r4_pmc_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
             else:
-                traffic_note = "profiles/r3_pmc_decode_traffic.json was taken from other kernel sources than this tree's: withheld"
+                traffic_note = "profiles/r4_pmc_decode_traffic.json was taken from other kernel sources than this tree's: withheld"
         except (OSError, ValueError, KeyError):
             traffic = None
+    # the same fraction from the TRACED durations of the committed rocprofv3 summary (eager launches, per-kernel averages) instead of the graph sweep
+    frac_rocprof, frac_rocprof_note = None, "no rocprofv3 summary for this workload"
+    rpath = os.path.join(root, "profiles", "r4_rocprof_decode_roofline.json")
+    if os.path.exists(rpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
+        try:
+            with open(rpath) as f:
+                rj = json.load(f)
+            if rj.get("kernel_sources_sha256") == sha_now:
+                frac_rocprof = float(rj["frac_rocprof"])
+                frac_rocprof_note = (f"profiles/r4_rocprof_decode_roofline.json: {rj['stream_weight_bytes_per_token']} B / {rj['stream_us_per_token']} us of traced "
+                                     f"mmvq_stream_kernel time per token ({rj['stream_avg_launch_us']} us per launch)")
+            else:
+                frac_rocprof_note = "profiles/r4_rocprof_decode_roofline.json was taken from other kernel sources than this tree's: withheld"
+        except (OSError, ValueError, KeyError):
+            frac_rocprof = None
 
     # prompt processing against the matrix-core peak: 2 * (projection weights) * tokens, int8 MFMA dense peak
     E, FF, L_, GD = cfg.n_embd, cfg.n_ff, cfg.n_layer, cfg.n_head_kv * cfg.head_dim
@@ -511,6 +528,8 @@ def main() -> int:
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "frac_rocprof": frac_rocprof,
+            "frac_rocprof_source": frac_rocprof_note,
             "traffic": traffic,
             "traffic_source": traffic_note,
             "method": "the step's own launches of the weight-stream kernel (Q|K|V, gate|up, ffn_down of every layer + the output head: 97 for this model; "
