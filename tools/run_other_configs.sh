@@ -1,7 +1,7 @@
 #!/bin/bash
-# bench lines of the other BASELINE configurations on one GPU (and the reference's smoke-model type mix), one JSON line each under gpurun_out/r3cfg/
+# bench lines of the other BASELINE configurations on one GPU (and the reference's smoke-model type mix), one JSON line each under gpurun_out/r4cfg/
 cd "$(dirname "$0")/.."
-O=gpurun_out/r3cfg; mkdir -p $O
+O=gpurun_out/r4cfg; mkdir -p $O
 run() { name=$1; shift; timeout 900 python bench.py "$@" --no-cpu-baseline > $O/$name.json 2> $O/$name.err; tail -c 300 $O/$name.json | head -c 0; python - "$O/$name.json" <<'PY'
 import json, sys
 try:
@@ -11,6 +11,7 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 }
+run llama-3-8b-q8_0 --config llama-3-8b --ftype q8_0
 run llama-2-7b --config llama-2-7b --ftype q5_k_m --cache-type f16
 run tinyllama-1.1b --config tinyllama-1.1b --ftype q8_0 --cache-type f16
 run tinyllama-1.1b-q2_k --config tinyllama-1.1b --ftype q2_k --cache-type f16
