@@ -38,6 +38,16 @@ def rel_err(a, b):
 
 
 def run_ranks(world, plan_path, out_path, timeout=600):
+    """One process per rank.  A rank that dies (rendezvous, a peer's exit) is an infrastructure failure, not a result: the launch is repeated ONCE and the
+    first attempt's output goes to stderr; wrong numbers are never retried - the callers compare what the second attempt returns like any other."""
+    try:
+        return _run_ranks_once(world, plan_path, out_path, timeout)
+    except AssertionError as e:
+        print(f"run_ranks: first attempt failed, repeating once\n{e}", file=sys.stderr)
+        return _run_ranks_once(world, plan_path, out_path, timeout)
+
+
+def _run_ranks_once(world, plan_path, out_path, timeout):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = []
@@ -54,8 +64,9 @@ def run_ranks(world, plan_path, out_path, timeout=600):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    if any(p.returncode != 0 for p in procs):                 # (a rank that fails takes its peers' exchanges down with it: show every rank's last lines)
+        tails = "\n".join(f"---- rank {r} (exit {p.returncode})\n{outs[r][-1500:]}" for r, p in enumerate(procs))
+        raise AssertionError(f"{sum(p.returncode != 0 for p in procs)} of {world} ranks failed:\n{tails}")
     return np.load(out_path)
 
 
@@ -115,6 +126,7 @@ def unsplit_logits(pkg, plan_path):
     ("tiny-e2048", "q5_k_m", "q8_0", 40, 2),      # 40-token prompt: the MFMA prompt path on a slice; fused prologues on the steps
     ("tiny-e2048", "q4_k_m", "q8_0", 8, 4),       # four ranks: one KV head each
     ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 2),       # Llama-3-8B's layer geometry
+    ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 8),       # north_star's rank count: 4 query heads + 1 KV head and 1792 = 7 x 256 feed-forward columns per rank
 ])
 def test_ranks_sharing_one_gpu_match_oracle_and_unsplit(pkg, tmp_models, cfg, ftype, kv, n_prompt, world):
     pkg.Backend()
@@ -172,7 +184,7 @@ def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg,
 
 
 @pytest.mark.parametrize("cfg,ftype,kv,world,wgs", [("tiny-e2048", "q4_k_m", "q8_0", 2, 0), ("tiny-8b-2l", "q4_k_m", "q8_0", 2, 7), ("tiny-e2048", "q4_k_m", "q8_0", 4, 0),
-                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5)])
+                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5), ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 0)])
 def test_prompt_sized_exchange_as_reduce_scatter_all_gather(pkg, tmp_models, cfg, ftype, kv, world, wgs, monkeypatch):
     """Prompt batches: the n_embd x n_ubatch partial sums go through ONE reduce-scatter + all-gather kernel (host/tp_comm.cc p2p_rsag_kernel:
     a segment per rank, every rank stores its part of segment q into rank q's IPC-mapped buffer, the owner adds in rank order and stores the sum
