@@ -183,6 +183,8 @@ CONFIGS = {
     # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads), two layers: the whole-step kernel's shape
     "tiny-8b-2l": LlamaConfig("tiny-8b-2l", 4096, 2, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
     "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
+    # Llama-3-70B's feed-forward width on a narrow model: 28672 has no weight-stream form, its single-token ffn_down runs as two column halves of 14336
+    "tiny-ff28k": LlamaConfig("tiny-ff28k", 1024, 2, 8, 2, 28672, 512, 500000.0, 1e-5, 1024),
     # three layers of Llama-3-8B's geometry: two launches of the layer engine (decode_engine.hip) that hand Q | K | V on + the last one
     # general.architecture "qwen2": NEOX rope pairing + Q / K / V biases (one of the reference's weekend test families, e2e-test-server-weekend.py:22-76).
     # tiny-qwen2: head_dim 64; tiny-qwen2-1.5b-2l / -7b-2l: two layers of Qwen2-1.5B's (1536, 12 / 2 heads of 128, 8960) and Qwen2-7B's (3584, 28 / 4, 18944) geometry

@@ -136,11 +136,12 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     // where a tensor's bytes come from: the whole tensor, or this rank's rows (a contiguous range), or this rank's
     // columns (the same block range of every row: a strided copy)
     enum { SPLIT_NONE = 0, SPLIT_ROWS = 1, SPLIT_COLS = 2 };
-    struct Plan { const GGUFTensorInfo *ti; DevTensor *dst; size_t off; size_t src_off, src_pitch, src_width; int64_t src_rows; size_t src_bytes; };
+    struct Plan { const GGUFTensorInfo *ti; DevTensor *dst; size_t off; size_t src_off, src_pitch, src_width; int64_t src_rows; size_t src_bytes; bool extra_copy; };
     std::vector<Plan> plan;
     size_t total = 0, max_stage = 0;
     bool fail = false;
-    auto want = [&](const std::string &name, DevTensor &dst, bool required, int split = SPLIT_NONE) {
+    // cpart / cparts: column part cpart of cparts of THIS RANK's tensor as a tensor of its own (a second copy for the single-token steps, see LayerWeights::down_lo)
+    auto want = [&](const std::string &name, DevTensor &dst, bool required, int split = SPLIT_NONE, int cpart = 0, int cparts = 1) {
         const GGUFTensorInfo *ti = f.tensor(name);
         if (!ti) {
             if (required) { err = "missing tensor " + name; fail = true; }
@@ -158,7 +159,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
         dst.n_expert = ti->ne[2];
         if (ggml_block_elems(dst.type) > 1 && dst.K % ggml_block_elems(dst.type)) { err = "tensor " + name + ": row length not a block multiple"; fail = true; return; }
         const size_t full_row = ggml_row_bytes(dst.type, dst.K);
-        Plan pl{ti, &dst, total, 0, full_row, full_row, ti->n_dims == 1 ? 1 : dst.N * dst.n_expert, (size_t)ti->bytes};
+        Plan pl{ti, &dst, total, 0, full_row, full_row, ti->n_dims == 1 ? 1 : dst.N * dst.n_expert, (size_t)ti->bytes, cparts > 1};
         if (P > 1 && split != SPLIT_NONE) {
             const int64_t blk = std::max<int64_t>(ggml_block_elems(dst.type), 1);
             if (ti->n_dims == 1 || split == SPLIT_COLS) {          // a bias vector is cut like the rows it is added to
@@ -173,6 +174,13 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
                 pl.src_rows = dst.N;
                 pl.src_off = (size_t)R * (size_t)dst.N * full_row;
             }
+            pl.src_bytes = pl.src_width * (size_t)pl.src_rows;
+        }
+        if (cparts > 1) {                                          // (on 256-element boundaries, checked by the caller)
+            dst.name = name + "[cols " + std::to_string(cpart) + "/" + std::to_string(cparts) + "]";
+            dst.K /= cparts;
+            pl.src_width = ggml_row_bytes(dst.type, dst.K);
+            pl.src_off += (size_t)cpart * pl.src_width;
             pl.src_bytes = pl.src_width * (size_t)pl.src_rows;
         }
         dst.row_bytes = ti->n_dims == 1 ? ggml_row_bytes(dst.type, dst.K) : dev_row_bytes(dst.type, dst.K);
@@ -234,6 +242,15 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
             want(p + "ffn_gate.weight", L.gate, true, SPLIT_ROWS);
             want(p + "ffn_up.weight", L.up, true, SPLIT_ROWS);
             want(p + "ffn_down.weight", L.down, true, SPLIT_COLS);
+            // a contraction length without a weight-stream form whose half has one (mmvq_stream_applicable: 1, 2, 3, 4, 6, 7 or 10 passes of 2048):
+            // Llama-3-70B's 28672 -> 2 x 14336
+            static const bool halves_on = !(getenv("MI355_DOWN_HALVES") && getenv("MI355_DOWN_HALVES")[0] == '0');
+            auto kb_ok = [](int64_t K) { const int64_t kb = (K + 2047) >> 11; return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 7 || kb == 10; };
+            const int64_t Kd = L.down.K;
+            if (halves_on && !fail && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K) && !kb_ok(Kd) && Kd % 512 == 0 && kb_ok(Kd / 2)) {
+                want(p + "ffn_down.weight", L.down_lo, true, SPLIT_COLS, 0, 2);
+                want(p + "ffn_down.weight", L.down_hi, true, SPLIT_COLS, 1, 2);
+            }
         }
     }
     }
@@ -336,7 +353,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
             (void)hipStreamDestroy(st);
             return nullptr;
         }
-        m->file_tensor_bytes += pl.src_bytes;
+        if (!pl.extra_copy) m->file_tensor_bytes += pl.src_bytes;
     }
     if (stage) (void)hipFree(stage);
     (void)hipStreamDestroy(st);
@@ -407,6 +424,7 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
     // algorithmic bytes per decoded token: each tensor once, one embedding row, used experts only
     uint64_t bpt = 0;
     for (const Plan &pl : plan) {
+        if (pl.extra_copy) continue;                               // (the column halves of ffn_down: the same bytes a second time)
         const DevTensor &d = *pl.dst;
         uint64_t b = pl.src_bytes;
         if (&d == &m->tok_embd) b = ggml_row_bytes(d.type, d.K);
@@ -1591,6 +1609,18 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             const bool fuse_down = fuse_down_env && T == 1 && (L.down.type == T_Q4_K || L.down.type == T_Q5_K || L.down.type == T_Q6_K || act_is_q80(L.down.type) ||
                                                                L.down.type == T_Q2_K || L.down.type == T_Q3_K) &&
                                    (FF % 256) == 0 && mmvq_fast_kb_ok((FF + 2047) / 2048);
+            if (fuse_down && !tp && L.down_lo.valid() && L.down_hi.valid()) {
+                // the column halves of ffn_down, each quantising its half of the SwiGLU output in its prologue: x += W_lo a_lo; x += W_hi a_hi
+                const int Kh = (int)L.down_lo.K;
+                pending_fuse_.mode = 2; pending_fuse_.x = ffn_;
+                HIP_TRY(linear(L.down_lo, aq_ff_, ffn_, Kh, T, x_, E, x_, EPI_ADD));
+                pending_fuse_.mode = 2; pending_fuse_.x = ffn_ + Kh;
+                HIP_TRY(linear(L.down_hi, aq_ff_, ffn_ + Kh, Kh, T, x_, E, x_, EPI_ADD));
+                pending_fuse_ = Fuse();
+                prof_mark("ffn_down");
+                if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
+                continue;
+            }
             if (fuse_down) {
                 pending_fuse_.mode = 2; pending_fuse_.x = ffn_;       // quantise inside the mat-vec prologue
             } else if (is_quant(L.down.type) && !swiglu_quantised) {
@@ -2094,12 +2124,21 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches
                 if (can_fuse(E, 1)) { fz.mode = 1; fz.x = x_; fz.w = (const float *)L.ffn_norm.data; fz.eps = hp.eps; }
                 HIP_TRY(mmvq_tokens(segs, 2, E, 1, EPI_SWIGLU, aq_e_, stream_, fz));
             }
-            if (is_quant(L.down.type) && (FF % 256) == 0) { pending_fuse_.mode = 2; pending_fuse_.x = ffn_; }
-            HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, xo_, EPI_ADD));
+            const bool halves = L.down_lo.valid() && L.down_hi.valid() && !hp.tp_exchange;      // (run_layers: the column halves, two launches)
+            if (halves) {
+                const int Kh = (int)L.down_lo.K;
+                pending_fuse_.mode = 2; pending_fuse_.x = ffn_;
+                HIP_TRY(linear(L.down_lo, aq_ff_, ffn_, Kh, 1, xo_, E, xo_, EPI_ADD));
+                pending_fuse_.mode = 2; pending_fuse_.x = ffn_ + Kh;
+                HIP_TRY(linear(L.down_hi, aq_ff_, ffn_ + Kh, Kh, 1, xo_, E, xo_, EPI_ADD));
+            } else {
+                if (is_quant(L.down.type) && (FF % 256) == 0) { pending_fuse_.mode = 2; pending_fuse_.x = ffn_; }
+                HIP_TRY(linear(L.down, aq_ff_, ffn_, FF, 1, xo_, E, xo_, EPI_ADD));
+            }
             pending_fuse_ = Fuse();
             if (count) {
                 bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + (wo_fused ? 0 : L.wo.ggml_bytes) + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
-                launches += wo_fused ? 3 : 4;
+                launches += (wo_fused ? 3 : 4) + (halves ? 1 : 0);
             }
         }
         if (is_quant(model->output.type) && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps; }

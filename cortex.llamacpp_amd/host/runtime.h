@@ -36,6 +36,10 @@ struct DevTensor {
 struct LayerWeights {
     DevTensor attn_norm, wq, wk, wv, wo, bq, bk, bv;
     DevTensor ffn_norm, gate, up, down;
+    // single-token steps of a feed-forward width the weight stream has no form for (K = 28672: a 16 KB row does not fit the ring pairwise) while half of
+    // it has one: the column halves of ffn_down as two tensors of their own, contracted by two launches (x += W_lo a_lo; x += W_hi a_hi).  A second copy
+    // of the tensor in HBM; prompt batches keep the whole tensor (and its planes).  Empty otherwise.
+    DevTensor down_lo, down_hi;
     DevTensor gate_inp, gate_exps, up_exps, down_exps;
     // encoder files (nomic-bert): the fused Q | K | V projection (wq / wk / wv are row ranges of it), LayerNorms with biases after the attention and the feed-forward block
     DevTensor wqkv, bo, attn_out_norm, attn_out_norm_b, layer_out_norm, layer_out_norm_b;

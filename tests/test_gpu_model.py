@@ -63,6 +63,8 @@ def rel_err(a, b):
                                           ("tiny-g8", "q4_k_m", "q8_0"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-g8:70", "q4_k_m", "q8_0"),
                                           # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads)
                                           ("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l:70", "q5_k_m", "f16"),
+                                          # Llama-3-70B's feed-forward width (28672): the single-token ffn_down as two column halves on the weight stream (Q4_K and Q6_K halves)
+                                          ("tiny-ff28k", "q4_k_m", "q8_0"), ("tiny-ff28k:40", "q6_k", "q8_0"),
                                           # f16 cache, 40-token prompts: the matrix-core prompt attention with f16 K / V (GQA 4:1 and MHA)
                                           ("tiny-d128:40", "q4_k_m", "f16"), ("tiny-d128-mha:40", "q5_k_m", "f16"),
                                           # Q2_K / Q3_K_M files (Q2_K + Q3_K + Q4_K / Q5_K + Q6_K tensors side by side): the type mix of the reference's smoke model
