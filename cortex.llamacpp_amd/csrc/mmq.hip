@@ -1084,6 +1084,12 @@ __device__ __forceinline__ void dma4_s(const void *gbase, unsigned voff, unsigne
 __device__ unsigned long long *g_p2_probe = nullptr;
 #define P2_STAMP() __builtin_readcyclecounter()
 #endif
+#ifndef MI355_P2_PRIO
+#define MI355_P2_PRIO 0      // tools: s_setprio level of a wave inside its MFMA phase (0 = no instruction)
+#endif
+#ifndef MI355_P2_LATE_DMA
+#define MI355_P2_LATE_DMA 0  // tools: 1 = a stage's DMA issued behind the issuing half's MFMAs instead of in front of them
+#endif
 #ifndef MI355_P2_EXP
 #define MI355_P2_EXP 0       // tools: 1 = no fold, 2 = no DMA, 3 = no MFMA (timing experiments; results are garbage)
 #endif
@@ -1296,6 +1302,9 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
     // every other group, the planes of the next K-step) are requested before the MFMAs of group g are issued: a lone wave
     // otherwise waits out the LDS latency once per group with its matrix-core slot empty
     auto mma_stage = [&](int h, bool first) {
+#if MI355_P2_PRIO
+        __builtin_amdgcn_s_setprio(MI355_P2_PRIO);              // tools: the wave in its MFMA phase ahead of the SIMD's other wave (folding / issuing DMA)
+#endif
         const uint8_t *bs = smem + h * P2_BUF + rw * 8192 + lane * 16;
         const uint8_t *as = smem + h * P2_BUF + P2_A + a_lane;
         auto ld_a = [&](int t, int j) {
@@ -1330,6 +1339,9 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
             __builtin_amdgcn_sched_barrier(0);
             a0 = n0; a1 = n1; bh = nbh; bl = nbl;
         }
+#if MI355_P2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     issue_v(0, wave);
@@ -1353,20 +1365,37 @@ __device__ __forceinline__ void planes2_body(const uint8_t *planes, const uint8_
 #ifdef MI355_P2_PROBE
         pr_kind = 0;
 #endif
+#if MI355_P2_LATE_DMA
+        // tools: the issuing half runs its MFMAs FIRST and issues the next stage's DMA behind them (the folding half's MFMAs then find the pipe free);
+        // the DMA has less of the stage left to land in
+        convert_bs(sb);
+        if (tw == 1 && sb > 0) fold_all((sb - 1) & 1);
+        mma_stage(0, true);
+        issue(2 * sb + 1, issuer0);
+        stage_end();
+#else
         issue(2 * sb + 1, issuer0);
         convert_bs(sb);
         if (tw == 1 && sb > 0) fold_all((sb - 1) & 1);
         mma_stage(0, true);
         stage_end();
+#endif
         // ---- second half (buffer 1).  The words of super-block sb + 1 go to the other parity, which waves 4-7 finished
         // reading in the stage just ended; waves 0-3 fold sb at the end of this one.
 #ifdef MI355_P2_PROBE
         pr_kind = 1;
 #endif
+#if MI355_P2_LATE_DMA
+        mma_stage(1, false);
+        if (sb + 1 < nb) { issue(2 * sb + 2, issuer1); issue_sb(sb + 1, issuer1); }
+        if (tw == 0 || sb + 1 == nb) fold_all(sb & 1);
+        stage_end();
+#else
         if (sb + 1 < nb) { issue(2 * sb + 2, issuer1); issue_sb(sb + 1, issuer1); }
         mma_stage(1, false);
         if (tw == 0 || sb + 1 == nb) fold_all(sb & 1);
         stage_end();
+#endif
     }
     if (MI355_P2_EXP == 1) {
 #pragma unroll
