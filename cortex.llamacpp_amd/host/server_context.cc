@@ -398,71 +398,76 @@ void LlamaServerContext::ProcessTasks() {   // :1152-1237
     for (auto &t : deferred) queue_tasks_.push_back(std::move(t));
 }
 
-size_t LlamaServerContext::FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot) {   // :682-714
-    size_t stop_pos = std::string::npos;
-    for (const std::string &word : slot.params.antiprompt) {
-        size_t pos;
-        if (full) {
-            const size_t tmp = word.size() + last_token_size;
-            const size_t from_pos = text.size() > tmp ? text.size() - tmp : 0;
-            pos = text.find(word, from_pos);
-        } else {
-            // partial: does the text end with a prefix of the stop word?
-            pos = std::string::npos;
-            if (!text.empty() && !word.empty()) {
-                const char last = text.back();
-                for (long ci = (long)word.size() - 1; ci >= 0; ci--) {
-                    if (word[(size_t)ci] == last) {
-                        const std::string cur = word.substr(0, (size_t)ci + 1);
-                        if (text.size() >= cur.size() && text.compare(text.size() - cur.size(), cur.size(), cur) == 0) { pos = text.size() - cur.size(); break; }
-                    }
-                }
-            }
-        }
-        if (pos != std::string::npos && (stop_pos == std::string::npos || pos < stop_pos)) {
-            if (full) { slot.stopped_word = true; slot.stopping_word = word; slot.has_next_token = false; }
-            stop_pos = pos;
-        }
+// ---- text leaving a slot.  Behaviour of the reference's process_token / find_stopping_strings (:682-813) - a stop string never leaves, text that may still
+// become one is held back, a character cut by a token boundary is held back whole - written as three questions about the UNSENT tail of the generated text.
+namespace {
+
+// bytes at the end of `s` that open a UTF-8 sequence whose continuation bytes have not all arrived (0: the text ends on a character boundary)
+size_t utf8_pending_bytes(const std::string &s) {
+    const size_t n = s.size();
+    for (size_t back = 1; back <= 4 && back <= n; back++) {
+        const unsigned char c = (unsigned char)s[n - back];
+        if ((c & 0xC0) == 0x80) continue;                      // a continuation byte: its lead byte is further back
+        const size_t need = (c & 0xE0) == 0xC0 ? 2 : (c & 0xF0) == 0xE0 ? 3 : (c & 0xF8) == 0xF0 ? 4 : 1;
+        return need > back ? back : 0;
     }
-    return stop_pos;
+    return 0;
+}
+
+struct StopHit { size_t at = std::string::npos; const std::string *word = nullptr; };
+
+// earliest start of a COMPLETE stop string in `tail`, looking only where the newest piece (its last `fresh` bytes) can have completed one; the first
+// word of the list wins a tie
+StopHit first_complete_stop(const std::string &tail, size_t fresh, const std::vector<std::string> &stops) {
+    StopHit hit;
+    for (const std::string &w : stops) {
+        const size_t window = w.size() + fresh;
+        const size_t at = tail.find(w, tail.size() > window ? tail.size() - window : 0);
+        if (at != std::string::npos && at < hit.at) { hit.at = at; hit.word = &w; }
+    }
+    return hit;
+}
+
+// earliest position from which the END of `tail` is the beginning of some stop string (the longest such beginning per word); npos: none
+size_t first_open_stop(const std::string &tail, const std::vector<std::string> &stops) {
+    size_t best = std::string::npos;
+    for (const std::string &w : stops)
+        for (size_t len = std::min(w.size(), tail.size()); len >= 1; len--)
+            if (tail.compare(tail.size() - len, len, w, 0, len) == 0) { best = std::min(best, tail.size() - len); break; }
+    return best;
+}
+
+}  // namespace
+
+size_t LlamaServerContext::FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot) {   // (kept for callers of the reference's name)
+    if (!full) return first_open_stop(text, slot.params.antiprompt);
+    const StopHit hit = first_complete_stop(text, last_token_size, slot.params.antiprompt);
+    if (hit.word) { slot.stopped_word = true; slot.stopping_word = *hit.word; slot.has_next_token = false; }
+    return hit.at;
 }
 
 bool LlamaServerContext::ProcessToken(CompletionTokenOutput &result, LlamaClientSlot &slot) {   // :716-813
-    const std::string token_str = be_->vocab().token_to_piece(result.tok, true);
+    const std::string piece = be_->vocab().token_to_piece(result.tok, true);
     slot.sampled = result.tok;
-    slot.generated_text += token_str;
+    slot.generated_text += piece;
     slot.has_next_token = true;
-    // hold back an incomplete UTF-8 sequence at the end of the text
-    bool incomplete = false;
-    for (unsigned i = 1; i < 5 && i <= slot.generated_text.size(); ++i) {
-        const unsigned char c = (unsigned char)slot.generated_text[slot.generated_text.size() - i];
-        if ((c & 0xC0) == 0x80) continue;
-        if ((c & 0xE0) == 0xC0) incomplete = i < 2;
-        else if ((c & 0xF0) == 0xE0) incomplete = i < 3;
-        else if ((c & 0xF8) == 0xF0) incomplete = i < 4;
-        break;
-    }
-    if (!incomplete) {
-        size_t pos = std::min(slot.sent_count, slot.generated_text.size());
-        const std::string str_test = slot.generated_text.substr(pos);
-        bool is_stop_full = false;
-        size_t stop_pos = FindStoppingStrings(str_test, token_str.size(), true, slot);
-        if (stop_pos != std::string::npos) {
-            is_stop_full = true;
-            slot.generated_text.erase(slot.generated_text.begin() + (long)(pos + stop_pos), slot.generated_text.end());
-            pos = std::min(slot.sent_count, slot.generated_text.size());
-        } else {
-            stop_pos = FindStoppingStrings(str_test, token_str.size(), false, slot);
-        }
-        if (stop_pos == std::string::npos || (!slot.has_next_token && !is_stop_full && stop_pos > 0)) {
-            result.text_to_send = slot.generated_text.substr(pos);
-            slot.sent_count += result.text_to_send.size();
+    if (utf8_pending_bytes(slot.generated_text) == 0) {         // (else: nothing is searched, sent or counted until the character is whole)
+        const size_t sent = std::min(slot.sent_count, slot.generated_text.size());
+        const std::string tail = slot.generated_text.substr(sent);
+        const StopHit hit = first_complete_stop(tail, piece.size(), slot.params.antiprompt);
+        if (hit.word) {
+            // the stop string and everything behind it are dropped; what stood in front of it is not sent as a partial any more (the final response of a
+            // non-streaming request carries the whole text)
+            slot.stopped_word = true; slot.stopping_word = *hit.word; slot.has_next_token = false;
+            slot.generated_text.resize(sent + hit.at);
+        } else if (first_open_stop(tail, slot.params.antiprompt) == std::string::npos) {
+            result.text_to_send = tail;
+            slot.sent_count += tail.size();
         }
         slot.AddTokenString(result);
         if (slot.params.stream) SendPartialResponse(slot, result);
         else slot.sent_token_probs_index++;
     }
-    if (incomplete) slot.has_next_token = true;
     if (slot.n_decoded > 2 && slot.has_next_token && !slot.HasBudget(params)) { slot.stopped_limit = true; slot.has_next_token = false; }
     if (be_->vocab().is_eog(result.tok)) { slot.stopped_eos = true; slot.has_next_token = false; }
     return slot.has_next_token;
@@ -500,26 +505,35 @@ Json LlamaServerContext::GetFormatedGeneration(const LlamaClientSlot &slot) cons
     return g;
 }
 
+// a result leaves for the waiting caller (NextResult)
+void LlamaServerContext::PostResult(TaskResult &&res) {
+    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
+    condition_results_.notify_all();
+}
+
+// the token probabilities [from, to) of a slot as the response carries them
+Json LlamaServerContext::ProbsSlice(const LlamaClientSlot &slot, size_t from, size_t to) const {
+    const size_t n = slot.generated_token_probs.size();
+    from = std::min(from, n); to = std::min(to, n);
+    std::vector<CompletionTokenOutput> part;
+    if (from < to) part.assign(slot.generated_token_probs.begin() + (long)from, slot.generated_token_probs.begin() + (long)to);
+    return ProbsToJson(part);
+}
+
 void LlamaServerContext::SendPartialResponse(LlamaClientSlot &slot, const CompletionTokenOutput &tkn) {   // :920-962
     TaskResult res;
     res.id = slot.task_id; res.error = false; res.stop = false;
-    res.result_json = Json::object();
-    res.result_json["content"] = tkn.text_to_send;
-    res.result_json["stop"] = false;
-    res.result_json["slot_id"] = slot.id;
-    res.result_json["multimodal"] = false;
-    if (slot.sparams.n_probs > 0) {
-        const auto to_send = be_->vocab().tokenize(tkn.text_to_send, false);
-        const size_t p0 = std::min(slot.sent_token_probs_index, slot.generated_token_probs.size());
-        const size_t p1 = std::min(slot.sent_token_probs_index + to_send.size(), slot.generated_token_probs.size());
-        std::vector<CompletionTokenOutput> po;
-        if (p0 < p1) po.assign(slot.generated_token_probs.begin() + (long)p0, slot.generated_token_probs.begin() + (long)p1);
-        slot.sent_token_probs_index = p1;
-        res.result_json["completion_probabilities"] = ProbsToJson(po);
+    Json &j = res.result_json;
+    j = Json::object();
+    j["content"] = tkn.text_to_send; j["stop"] = false; j["slot_id"] = slot.id; j["multimodal"] = false;
+    if (slot.sparams.n_probs > 0) {                         // the probabilities of as many tokens as the text just released re-tokenises to
+        const size_t from = std::min(slot.sent_token_probs_index, slot.generated_token_probs.size());
+        const size_t to = std::min(slot.sent_token_probs_index + be_->vocab().tokenize(tkn.text_to_send, false).size(), slot.generated_token_probs.size());
+        j["completion_probabilities"] = ProbsSlice(slot, from, to);
+        slot.sent_token_probs_index = to;
     }
-    if (slot.oaicompat) { res.result_json["oaicompat_token_ctr"] = slot.n_decoded; res.result_json["model"] = slot.oaicompat_model; }
-    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
-    condition_results_.notify_all();
+    if (slot.oaicompat) { j["oaicompat_token_ctr"] = slot.n_decoded; j["model"] = slot.oaicompat_model; }
+    PostResult(std::move(res));
 }
 
 void LlamaServerContext::SendFinalResponse(LlamaClientSlot &slot) {   // :964-1024
@@ -527,7 +541,8 @@ void LlamaServerContext::SendFinalResponse(LlamaClientSlot &slot) {   // :964-10
     res.id = slot.task_id; res.error = false; res.stop = true;
     Json &j = res.result_json;
     j = Json::object();
-    j["content"] = !slot.params.stream ? slot.generated_text : "";
+    const bool whole = !slot.params.stream;                  // a streaming request has had its text already
+    j["content"] = whole ? slot.generated_text : "";
     j["slot_id"] = slot.id; j["stop"] = true; j["model"] = params.model_alias;
     j["tokens_predicted"] = slot.n_decoded; j["tokens_evaluated"] = slot.num_prompt_tokens;
     j["generation_settings"] = GetFormatedGeneration(slot);
@@ -536,16 +551,13 @@ void LlamaServerContext::SendFinalResponse(LlamaClientSlot &slot) {   // :964-10
     j["stopping_word"] = slot.stopping_word; j["tokens_cached"] = slot.n_past;
     j["timings"] = slot.GetFormatedTimings();
     if (slot.sparams.n_probs > 0) {
-        std::vector<CompletionTokenOutput> probs;
-        if (!slot.params.stream && slot.stopped_word && !slot.generated_token_probs.empty())
-            probs.assign(slot.generated_token_probs.begin(), slot.generated_token_probs.end() - 1);
-        else
-            probs.assign(slot.generated_token_probs.begin(), slot.generated_token_probs.begin() + (long)std::min(slot.sent_token_probs_index, slot.generated_token_probs.size()));
-        j["completion_probabilities"] = !slot.params.stream ? ProbsToJson(probs) : Json();
+        // all tokens but the one that completed a stop string (non-streaming), else the ones whose text has been sent
+        const size_t n = slot.generated_token_probs.size();
+        const size_t to = (whole && slot.stopped_word && n > 0) ? n - 1 : std::min(slot.sent_token_probs_index, n);
+        j["completion_probabilities"] = whole ? ProbsSlice(slot, 0, to) : Json();
     }
     if (slot.oaicompat) { j["oaicompat_token_ctr"] = slot.n_decoded; j["model"] = slot.oaicompat_model; }
-    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
-    condition_results_.notify_all();
+    PostResult(std::move(res));
 }
 
 void LlamaServerContext::SendError(LlamaClientSlot &slot, const std::string &err) {   // :840-853
@@ -553,8 +565,7 @@ void LlamaServerContext::SendError(LlamaClientSlot &slot, const std::string &err
     res.id = slot.task_id; res.stop = false; res.error = true;
     res.result_json = Json::object();
     res.result_json["content"] = err;
-    { std::lock_guard<std::mutex> lock(mutex_results_); queue_results_.push_back(std::move(res)); }
-    condition_results_.notify_all();
+    PostResult(std::move(res));
 }
 
 static size_t common_part(const std::vector<int32_t> &a, const std::vector<int32_t> &b) {

@@ -130,12 +130,15 @@ class LlamaServerContext {
     std::vector<uint8_t> grammar_eog_;
     void ProcessTasks();
     bool ProcessToken(CompletionTokenOutput &result, LlamaClientSlot &slot);
-    size_t FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot);
     void SendPartialResponse(LlamaClientSlot &slot, const CompletionTokenOutput &tkn);
     void SendFinalResponse(LlamaClientSlot &slot);
+    void PostResult(TaskResult &&res);
+    Json ProbsSlice(const LlamaClientSlot &slot, size_t from, size_t to) const;
     void SendError(LlamaClientSlot &slot, const std::string &err);
     Json GetFormatedGeneration(const LlamaClientSlot &slot) const;
   public:
+    // (public for the host tests: the stop-string questions ProcessToken asks, under the reference's name)
+    size_t FindStoppingStrings(const std::string &text, size_t last_token_size, bool full, LlamaClientSlot &slot);
     Json GetModelProps() const { return slots.empty() ? Json::object() : GetFormatedGeneration(slots[0]); }   // llama_server_context.cc:291-293
   private:
     Json ProbsToJson(const std::vector<CompletionTokenOutput> &probs) const;

@@ -577,6 +577,34 @@ static void test_sampler_with_grammar() {
     CHECK(s2.sample(lg2.data(), 3) == 0);
 }
 
+// the questions ProcessToken asks about the unsent text (host/server_context.cc), through the reference's entry name
+static void test_stop_string_scan() {
+    FakeBackend be;
+    ServerParams sp;
+    LlamaServerContext ctx(&be, sp);
+    ctx.Initialize();
+    LlamaClientSlot slot;
+    slot.params.antiprompt = {"User:", "</s>", "Use"};
+    const size_t npos = std::string::npos;
+    // a complete stop string: the earliest one wins, the first of the list on a tie; the search window is the stop string plus the newest piece
+    CHECK(ctx.FindStoppingStrings("Hello User: hi", 8, true, slot) == 6 && slot.stopped_word && slot.stopping_word == "User:" && !slot.has_next_token);
+    slot.stopped_word = false; slot.has_next_token = true; slot.stopping_word.clear();
+    CHECK(ctx.FindStoppingStrings("Hello User: and a long tail", 2, true, slot) == npos && !slot.stopped_word && slot.has_next_token);   // outside the window
+    CHECK(ctx.FindStoppingStrings("xx</s>yyUse", 3, true, slot) == 8 && slot.stopping_word == "Use");                                  // "</s>" lies outside, "Use" inside
+    slot.stopped_word = false; slot.has_next_token = true;
+    CHECK(ctx.FindStoppingStrings("", 0, true, slot) == npos);
+    // text that may still become a stop string: the longest beginning of a word the text ends with, the earliest over the words
+    CHECK(ctx.FindStoppingStrings("Hello Us", 2, false, slot) == 6);
+    CHECK(ctx.FindStoppingStrings("Hello <", 1, false, slot) == 6);
+    CHECK(ctx.FindStoppingStrings("Hello </", 1, false, slot) == 6);
+    CHECK(ctx.FindStoppingStrings("Hello", 1, false, slot) == npos);
+    CHECK(ctx.FindStoppingStrings("U", 1, false, slot) == 0);
+    CHECK(ctx.FindStoppingStrings("", 0, false, slot) == npos);
+    CHECK(!slot.stopped_word && slot.has_next_token);          // the open-stop question changes nothing
+    slot.params.antiprompt.clear();
+    CHECK(ctx.FindStoppingStrings("anything", 3, true, slot) == npos && ctx.FindStoppingStrings("anything", 3, false, slot) == npos);
+}
+
 static void test_slot_loop() {
     FakeBackend be;
     ServerParams sp;
@@ -1172,6 +1200,7 @@ int main(int argc, char **argv) {
     test_grammar_parse_and_match();
     test_json_schema_grammar();
     test_sampler_with_grammar();
+    test_stop_string_scan();
     test_slot_loop();
     test_prompt_cache_and_shift();
     test_kv_full_error();
