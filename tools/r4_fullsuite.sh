@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-(timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -n 40) > gpurun_out/r4_fullsuite.log
-tail -n 40 gpurun_out/r4_fullsuite.log
+(timeout 3000 python -m pytest tests -m gpu -q --durations=40 2>&1 | tail -n 70) > gpurun_out/r4_fullsuite.log
+tail -n 70 gpurun_out/r4_fullsuite.log
