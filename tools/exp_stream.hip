@@ -264,7 +264,7 @@ int main(int argc, char **argv) {
     }
 #ifdef MI355_STREAM_PROBE
     {   // timeline of the stream kernels of one layer in the middle of a 3-layer chain (100 MHz wall clock)
-        Op &qkv = ops[0], &o = ops[2], &gu = ops[3], &dn = ops[4];
+        Op &qkv = ops[0], &o = ops[2], &gu = ops[3], &dn = ops[argc > 2 ? 6 : 4];   // (argv[2] given: ffn_down with ready-made codes)
         const int NK = 12;
         unsigned long long *probe; const int WPW = 2 + 8, WPK = 256 * WPW;   // waves per kernel (loaders + 8 consumers per workgroup)
         const size_t pn = (size_t)NK * WPK * 8;
@@ -282,6 +282,7 @@ int main(int argc, char **argv) {
         unsigned long long base = ~0ull;
         for (int w = 0; w < WPK; w++) { const unsigned long long t = h[((size_t)4 * WPK + w) * 8]; if (t && t < base) base = t; }
         printf("\nstream kernel timeline, layer 2 of 3 (eager launches), us since the first wave of its qkv entered; min / median / max over waves\n");
+        printf("(down = \"%s\", fuse mode %d)\n", dn.name.c_str(), dn.fuse);
         printf("%-8s %-18s %-18s %-18s %-18s %-18s | %-18s %-18s %-18s %-18s %-18s | %-16s %-16s\n", "kernel", "loader: top", "args loaded", "go", "all issued", "all landed",
                "consumers: top", "args loaded", "activation ready", "last decoded", "outputs stored", "sum wait-slot", "sum decode");
         for (int k = 4; k < 9; k++) {
