@@ -65,7 +65,7 @@ __global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
         const int lane = tid_now() & 63;
         int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
         LoaderState st{0, 0, 0, (unsigned)ST_RING_SLOTS, 0};
-        if (FUSE == 0 && wave == 0) st.pre = loader_planes(a, smem, st_layout(KB), lane);
+        // (FUSE == 0: the consumers fetch the ready-made activation planes themselves, mmvq_stream_dev.h consumer_op)
         // the consumers' own requests go first: a load queued behind this wave's 60 KiB waits for all of it.  A launch bound by its stream (its share
         // of the weights exceeds the ring, and the prologue reads two 16 KB vectors: gate | up, the output head) lets the stream have a head start of
         // ST_EARLY slots per loader first

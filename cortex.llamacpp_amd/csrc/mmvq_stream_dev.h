@@ -582,6 +582,33 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     if (FUSE == 1 || FUSE == 2) consumer_prologue<KB, FUSE, act_is_q80(TYPE), ENG == 1>(a, smem, lay, c, lane, io);
     else if (FUSE == 3) {
         ST_SPIN_WHILE(ld_sync(sy + SY_READY) < io.ready_round && ld_sync(sy + SY_ABORT) == 0, 1);
+    } else if (ENG == 0) {
+        // ready-made planes (codes [K] | scales [K / 256] | block sums [K / 16]): the eight consumer waves fetch them themselves, 16 bytes per lane and
+        // request, all requests in flight before the loaders are let go.  (Round 4: as 17 LDS-DMA pieces in front of loader 0's first weight slot - and
+        // counted as landed with that slot - they held that loader back by 1.8 us and were usable 5.4 us into an ffn_down-sized launch, no sooner than
+        // the quantising prologue's; tools/exp_stream.hip time line.)
+        const int tix = c * 64 + lane, nq16 = a.K >> 4, nbs16 = a.K >> 7, nb4 = a.K >> 8;
+        constexpr int NQ = (KB * 2048 / 16 + ST_NC * 64 - 1) / (ST_NC * 64);
+        u32x4_t cq[NQ], cb = {0u, 0u, 0u, 0u};
+        float cd = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            int j = tix + i * ST_NC * 64;
+            if (j >= nq16) j = nq16 - 1;                                   // clamped: a valid address, stored only where it belongs
+            cq[i] = *reinterpret_cast<const u32x4_t *>(a.aq + (size_t)j * 16);
+        }
+        cb = *reinterpret_cast<const u32x4_t *>(reinterpret_cast<const uint8_t *>(a.abs) + (size_t)(tix < nbs16 ? tix : nbs16 - 1) * 16);
+        cd = a.ad[tix < nb4 ? tix : nb4 - 1];
+        asm volatile("" ::: "memory");
+        if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const int j = tix + i * ST_NC * 64;
+            if (j < nq16) *reinterpret_cast<u32x4_t *>(smem + lay.qs + (size_t)j * 16) = cq[i];
+        }
+        if (tix < nbs16) *reinterpret_cast<u32x4_t *>(smem + lay.bs + (size_t)tix * 16) = cb;
+        if (tix < nb4) reinterpret_cast<float *>(smem + lay.d)[tix] = cd;
+        consumers_rendezvous(sy + SY_PRO2, lane, io.round);
     } else {
         asm volatile("" ::: "memory");
         if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
