@@ -419,6 +419,7 @@ __device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, 
         // block's quantisation is a chain of wave-level steps (max -> first lane holding it -> its value -> 1 / scale -> codes -> sums) that waits on
         // itself, so two or more of them interleave (decode_engine.hip's probe: 0.84 us for two blocks, most of it latency)
         uint32_t packed[NJW]; int bsum[NJW]; float dq[NJW];
+        float vv[NJW][4];
 #pragma unroll
         for (int i = 0; i < NJW; i++) {
             f32x4_t x = rxv[i];
@@ -426,9 +427,9 @@ __device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, 
                 const f32x4_t ww = rwv[i];
                 x.x = (x.x * scale) * ww.x; x.y = (x.y * scale) * ww.y; x.z = (x.z * scale) * ww.z; x.w = (x.w * scale) * ww.w;
             }
-            const float vv[4] = {x.x, x.y, x.z, x.w};
-            wave_quant_q8k(vv, lane, packed[i], bsum[i], dq[i]);
+            vv[i][0] = x.x; vv[i][1] = x.y; vv[i][2] = x.z; vv[i][3] = x.w;
         }
+        wave_quant_q8k_batch<NJW>(vv, lane, packed, bsum, dq);      // (the blocks' two divisions each done once, lane-parallel: quant_dev.h)
 #pragma unroll
         for (int i = 0; i < NJW; i++) {
             const int b = c + ST_NC * i;

@@ -38,6 +38,49 @@ __device__ __forceinline__ void wave_quant_q8k(const float (&vv)[4], int lane, u
     bsum16 = bs;
 }
 
+// N blocks of one wave at once (the weight stream's quantising prologue: up to ten 256-blocks per wave).  The same arithmetic block by block; the two IEEE
+// divisions per block (-127 / max, 1 / iscale: ~10 instructions each, wave-uniform operands) are done ONCE for all blocks, block i's operand in lane i, and
+// the quotients come back through v_readlane - the prologue is instruction-bound (8 waves x 7 blocks x ~80 instructions on an ffn_down launch).
+template <int N>
+__device__ __forceinline__ void wave_quant_q8k_batch(const float (&vv)[N][4], int lane, uint32_t (&packed)[N], int (&bsum16)[N], float (&d)[N]) {
+    static_assert(N >= 1 && N <= 64, "one lane per block");
+    bool nz[N];
+    float vmax_l = 1.0f;                                       // lane i: block i's first element of the largest magnitude (1 where there is none)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float a0 = fabsf(vv[i][0]), a1 = fabsf(vv[i][1]), a2 = fabsf(vv[i][2]), a3 = fabsf(vv[i][3]);
+        const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+        const bool m0 = a0 == amax, m1 = a1 == amax, m2 = a2 == amax, m3 = a3 == amax;
+        const float vsrc = m0 ? vv[i][0] : m1 ? vv[i][1] : m2 ? vv[i][2] : vv[i][3];
+        const unsigned long long hit = __ballot(m0 || m1 || m2 || m3);
+        const int src_lane = hit ? __builtin_ctzll(hit) : 0;
+        const float vmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vsrc), src_lane));
+        nz[i] = amax != 0.0f;
+        if (lane == i && nz[i]) vmax_l = vmax;
+    }
+    const float iscale_l = -127.0f / vmax_l;
+    const float d_l = 1.0f / iscale_l;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        int qi[4] = {0, 0, 0, 0};
+        d[i] = 0.0f;
+        if (nz[i]) {                                           // (wave-uniform)
+            const float iscale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(iscale_l), i));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = __float2int_rn(iscale * vv[i][k]);
+                qi[k] = t > 127 ? 127 : t;
+            }
+            d[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_l), i));
+        }
+        packed[i] = (uint32_t)(qi[0] & 0xff) | ((uint32_t)(qi[1] & 0xff) << 8) | ((uint32_t)(qi[2] & 0xff) << 16) | ((uint32_t)(qi[3] & 0xff) << 24);
+        int bs = qi[0] + qi[1] + qi[2] + qi[3];
+        bs += dpp_i<DPP_QP_1032>(bs);
+        bs += dpp_i<DPP_QP_2301>(bs);
+        bsum16[i] = bs;
+    }
+}
+
 // Q8_0: per 32 elements (8 lanes): d = amax/127, codes = roundf(x/d); d returned as f32 (store as f16)
 __device__ __forceinline__ void wave_quant_q80(const float (&vv)[4], uint32_t &packed, float &d) {
     float am = fmaxf(fmaxf(fabsf(vv[0]), fabsf(vv[1])), fmaxf(fabsf(vv[2]), fabsf(vv[3])));
