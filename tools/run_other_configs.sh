@@ -17,4 +17,4 @@ run tinyllama-1.1b --config tinyllama-1.1b --ftype q8_0 --cache-type f16
 run tinyllama-1.1b-q2_k --config tinyllama-1.1b --ftype q2_k --cache-type f16
 run tinyllama-1.1b-q4_k_m --config tinyllama-1.1b --ftype q4_k_m --cache-type f16
 run mixtral-8x7b --config mixtral-8x7b --ftype q5_k_m
-run llama-3-70b --config llama-3-70b --ftype q4_k_m
+# (llama-3-70b: profiles/r4_bench_llama-3-70b.json is refreshed by hand)
