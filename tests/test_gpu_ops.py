@@ -337,7 +337,8 @@ def test_swiglu_softmax(be):
 
 
 @pytest.mark.parametrize("tk,tv,tol", [(F16, F16, 3e-3), (Q8_0, Q8_0, 2e-5), (Q4_0, Q4_0, 2e-5), (Q8_0, F16, 3e-3)])
-@pytest.mark.parametrize("H,G,D,n_cells", [(8, 2, 128, 70), (32, 4, 64, 33), (4, 4, 128, 300), (32, 8, 128, 1500)])
+@pytest.mark.parametrize("H,G,D,n_cells", [(8, 2, 128, 70), (32, 4, 64, 33), (4, 4, 128, 300), (32, 8, 128, 1500),
+                                           (32, 8, 128, 4000)])    # BASELINE's ctx_len = 4096 with the context filled: 63 chunks per kv head, merged in two request rounds
 def test_flash_attn(be, tk, tv, tol, H, G, D, n_cells):
     rng = np.random.default_rng(H * 1000 + n_cells)
     kf = rng.standard_normal((n_cells, G * D)).astype(np.float32)
@@ -396,6 +397,36 @@ def test_flash_attn_prefill_matrix_cores(be, H, G, n_cells, T, tkv, tol):
             cells = np.nonzero((cell_pos >= 0) & (cell_pos <= q_pos[i]))[0].astype(np.int32)
             ref = oq.flash_attn(q[i], H, G, D, tkv, kc, tkv, vc, cells, scale)
             assert np.abs(out[i] - ref).max() <= 2e-2 * max(1.0, float(np.abs(ref).max())), (i, np.abs(out[i] - ref).max())
+
+
+@pytest.mark.parametrize("tkv,tol", [(Q8_0, 2e-5), (F16, 2e-5), (Q4_0, 2e-5)])
+def test_flash_attn_prefill_second_micro_batch_of_a_filled_context(be, tkv, tol):
+    """The prompt attention as the SECOND micro-batch of a 3968-token prompt runs it (BASELINE's ctx_len = 4096): 200 queries whose positions start
+    at cell 2048, over a cache that holds 3968 cells - every tile walks 64 .. 124 key chunks, split across workgroups, and its causal frontier lies deep
+    inside the cache."""
+    H, G, D, n_cells, T = 32, 8, 128, 3968, 200
+    rng = np.random.default_rng(4096)
+    kf = rng.standard_normal((n_cells, G * D)).astype(np.float32)
+    vf = (rng.standard_normal((n_cells, G * D)) * rng.uniform(0.2, 3.0, (n_cells, 1))).astype(np.float32)
+    kc = np.stack([oq.quantize(tkv, r) for r in kf])
+    vc = np.stack([oq.quantize(tkv, r) for r in vf])
+    cell_pos = np.arange(n_cells, dtype=np.int32)
+    cell_pos[rng.random(n_cells) < 0.05] = -1            # holes
+    cell_pos[0] = 0
+    q_pos = np.sort(rng.integers(2048, n_cells, T)).astype(np.int32)
+    q_pos[0] = 2048
+    q_pos[-1] = n_cells - 1
+    q = rng.standard_normal((T, H, D)).astype(np.float32)
+    scale = 1 / np.sqrt(D)
+    out = be.flash_attn(q, H, G, D, tkv, kc, tkv, vc, cell_pos, q_pos, scale)
+    oq.set_fa_v_acc_f32(1 if tkv == F16 else 0)
+    try:
+        for i in list(range(0, T, 9)) + [T - 1]:
+            cells = np.nonzero((cell_pos >= 0) & (cell_pos <= q_pos[i]))[0].astype(np.int32)
+            ref = oq.flash_attn(q[i], H, G, D, tkv, kc, tkv, vc, cells, scale)
+            assert np.abs(out[i] - ref).max() <= tol * max(1.0, float(np.abs(ref).max())), (i, np.abs(out[i] - ref).max())
+    finally:
+        oq.set_fa_v_acc_f32(0)
 
 
 @pytest.mark.parametrize("fused", [1, 0])
