@@ -87,9 +87,10 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
         torch.cuda.synchronize()
 
     def timed():
-        """prefill, warm-up, K timed single-token steps; (seconds, prefill seconds, last token) with the MAX over ranks"""
+        """prefill, warm-up, K timed single-token steps; (seconds, prefill seconds, last token, first token) with the MAX over ranks"""
         ctx = holder["ctx"]
         t_pf, tok = prefill()
+        tok_first = tok
         pos = args.prompt
         for _ in range(args.warmup):
             assert ctx.decode([tok], [pos]) == 0
@@ -104,7 +105,7 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
         sync_all()
         tt = torch.tensor([dt_, t_pf], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt[0].item()), float(tt[1].item()), tok
+        return float(tt[0].item()), float(tt[1].item()), tok, tok_first
 
     def agree(tok):
         toks = torch.tensor([tok], dtype=torch.int64, device=f"cuda:{local_rank}")
@@ -116,7 +117,7 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
     new_context()
     prefill()
     sync_all()
-    dt_rccl, t_prefill, tok_rccl = timed()
+    dt_rccl, t_prefill, tok_rccl, tok_first_rccl = timed()
     res = {"parallelism": f"row split over {world} GPUs (attn_output / ffn_down partial sums all-reduced twice per layer through RCCL; logits gathered)",
            "scaling": "strong", "ranks": int(pkg.binding.load_library().mi355_tp_size()), "decode_tok_s": round(args.steps / dt_rccl, 2),
            "ms_per_step": round(dt_rccl / args.steps * 1e3, 4), "decode_tok_s_p2p": None, "p2p_exchanges": 0,
@@ -139,7 +140,7 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
             new_context()                                  # new graphs: the exchange is part of them
             prefill()
             sync_all()
-            dt_p2p, _, tok_p2p = timed()
+            dt_p2p, _, tok_p2p, _ = timed()
             used = int(pkg.binding.tp_p2p_exchanges())
             res["decode_tok_s_p2p"] = round(args.steps / dt_p2p, 2)
             res["p2p_exchanges"] = used
@@ -168,7 +169,13 @@ def row_split_section(args, pkg, path, KV, rank, local_rank, world, dist, torch,
                 res["prefill_tok_s_rsag"] = round(args.prompt / float(tt[0].item()), 1)
                 res["rsag_exchanges"] = int(pkg.binding.tp_p2p_prompt_exchanges())
                 res["rsag_ranks_agree_on_first_token"] = agree(tok_rs)
-                if res["rsag_exchanges"] > 0 and res["rsag_ranks_agree_on_first_token"] and res["prefill_tok_s_rsag"] > res["prefill_tok_s"]:
+                # every rank receives the OWNER's sum in a reduce-scatter + all-gather, so the ranks agree with each other even when that sum is wrong (a stale
+                # line at the owner): the figure is only adopted when the first token is also the one the RCCL prefill produced, on every rank
+                same = torch.tensor([1 if tok_rs == tok_first_rccl else 0], dtype=torch.int64, device=f"cuda:{local_rank}")
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                res["rsag_matches_rccl"] = bool(int(same.item()) == 1)
+                if (res["rsag_exchanges"] > 0 and res["rsag_ranks_agree_on_first_token"] and res["rsag_matches_rccl"]
+                        and res["prefill_tok_s_rsag"] > res["prefill_tok_s"]):
                     res["prefill_tok_s"] = res["prefill_tok_s_rsag"]
                 partial.pop("rsag_error", None)
             except Exception as e:  # noqa: BLE001 - reported in the record
@@ -211,7 +218,7 @@ def simulate(args) -> int:
         out = {"metric": "decode tok/s (simulated step)", "unit": "tok/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "simulated",
                "config": {"workload": "sleep-based stand-in for the decode step", "parallelism": f"{world} replicas, no collective"},
-               "roofline": None, "cpu_baseline": None}
+               "roofline": None, "cpu_baseline": None, "ranks_seen": dist.get_world_size() if dist is not None else 1}
         out.update(aggregate(args.gpus, args.steps, dt))
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -242,6 +249,23 @@ def main() -> int:
                     help="no GPU: the same rank bookkeeping (rendezvous over gloo, barriers, MAX over ranks, rank-0 JSON) around a "
                          "sleep standing in for the decode step; used by the two-rank CPU test")
     args = ap.parse_args()
+    # --gpus N must mean N ranks.  Started without a launcher (no WORLD_SIZE) and N > 1: start N FRESH child processes under torch.distributed.run - as the
+    # very first thing, before any import that could initialise the GPU (never an exec of a process that has) - and relay their output (rank 0 prints the
+    # line); started under a launcher whose world size is not N: refuse.  One rank printing "n_gpus": N can then not happen.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.run(cmd).returncode
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks: refusing to report a line for {args.gpus} GPUs",
+              file=sys.stderr, flush=True)
+        return 2
     if args.simulate:
         return simulate(args)
 
@@ -530,7 +554,7 @@ def main() -> int:
         "decode_hbm_fraction_of_8TBps": round(decode_frac, 4),
         "roofline": {
             "bound": "hbm",
-            "kernel": "mmvq_stream_kernel (single-token quantised mat-vec as an LDS-DMA weight stream, every weight tensor of one token)",
+            "kernel": "mmvq_stream_kernel (single-token quantised mat-vec as an LDS-DMA weight stream: Q|K|V, gate|up, ffn_down of every layer and the output head; attn_output runs inside the attention launch and is excluded)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -559,6 +583,7 @@ def main() -> int:
             "planes_bytes": int(model.planes_bytes),
         },
         "long_context": long_ctx,
+        "ranks_seen": int(dist.get_world_size()) if dist is not None else 1,    # ranks of the process group this line was measured over (== n_gpus by construction)
         "load_s": round(t_load, 2),
         "synth_s": round(t_gen, 2),
     }

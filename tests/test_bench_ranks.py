@@ -40,3 +40,24 @@ def test_single_rank_simulated_line():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and 2.0 <= out["ms_per_step"] <= 4.0
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher must not print a 2-GPU line from ONE rank: it starts two fresh ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1", "--simulate"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == out["ranks_seen"] == 2, out
+    assert 4.0 <= out["ms_per_step"] <= 8.0, out            # the slower simulated rank (4 ms per step) sets the time: both ranks really ran
+
+
+def test_world_size_that_contradicts_gpus_is_refused():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--simulate"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
