@@ -30,6 +30,22 @@ def test_host_logic_program(host_exe):
     assert "all host-logic checks passed" in r.stdout
 
 
+# The same program under the sanitizers (CPU builds only: no GPU sanitizers on this pool).  SURVEY.md §5: the reference documents races around its slot loop
+# (src/llama_engine.cc:1269-1276); the host mirror's queues, slot states and the engine's model map are exercised by the multi-threaded checks of the program
+# (parallel requests, stop / unload during generation), so a data race or a lifetime bug fails HERE instead of on a serving box.
+@pytest.mark.parametrize("name,flags", [("tsan", ["-fsanitize=thread"]), ("asan_ubsan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])])
+def test_host_logic_program_under_sanitizers(tmp_path, name, flags):
+    exe = str(tmp_path / f"host_tests_{name}")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-Wall", "-pthread", *flags, *SRCS, "-o", exe],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
+    assert "all host-logic checks passed" in r.stdout
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-6000:]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Tokenizer parity against HF `tokenizers` (an independent implementation of the same published algorithms): a small
 # byte-level BPE is trained here with the Llama-3 pre-tokenizer pattern, written into a GGUF (tokenizer.ggml.model =
