@@ -485,7 +485,7 @@ def main() -> int:
     # note of the microarchitecture guide); null when the profile is absent or is for another workload
     traffic, traffic_note = None, "no PMC profile for this workload"
     root = os.path.dirname(os.path.abspath(__file__))
-    tpath = os.path.join(root, "profiles", "r4_pmc_decode_traffic.json")
+    tpath = os.path.join(root, "profiles", "r5_pmc_decode_traffic.json")
     sha_now = kernel_sources_sha256(root)
     if os.path.exists(tpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
@@ -494,24 +494,25 @@ def main() -> int:
             # the profile names the kernel sources it was taken from (sha256 over the mat-vec kernel files): a kernel change since then makes the
             # figure stale, and it is withheld rather than repeated
             if tj.get("kernel_sources_sha256") == sha_now:
-                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), "profiles/r4_pmc_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
+                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), "profiles/r5_pmc_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
             else:
-                traffic_note = "profiles/r4_pmc_decode_traffic.json was taken from other kernel sources than this tree's: withheld"
+                traffic_note = "profiles/r5_pmc_decode_traffic.json was taken from other kernel sources than this tree's: withheld"
         except (OSError, ValueError, KeyError):
             traffic = None
     # the same fraction from the TRACED durations of the committed rocprofv3 summary (eager launches, per-kernel averages) instead of the graph sweep
-    frac_rocprof, frac_rocprof_note = None, "no rocprofv3 summary for this workload"
-    rpath = os.path.join(root, "profiles", "r4_rocprof_decode_roofline.json")
+    frac_rocprof, frac_rocprof_note, roles_rocprof = None, "no rocprofv3 summary for this workload", None
+    rpath = os.path.join(root, "profiles", "r5_rocprof_decode_roofline.json")
     if os.path.exists(rpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
             with open(rpath) as f:
                 rj = json.load(f)
             if rj.get("kernel_sources_sha256") == sha_now:
                 frac_rocprof = float(rj["frac_rocprof"])
-                frac_rocprof_note = (f"profiles/r4_rocprof_decode_roofline.json: {rj['stream_weight_bytes_per_token']} B / {rj['stream_us_per_token']} us of traced "
+                roles_rocprof = rj.get("roles")
+                frac_rocprof_note = (f"profiles/r5_rocprof_decode_roofline.json: {rj['stream_weight_bytes_per_token']} B / {rj['stream_us_per_token']} us of traced "
                                      f"mmvq_stream_kernel time per token ({rj['stream_avg_launch_us']} us per launch)")
             else:
-                frac_rocprof_note = "profiles/r4_rocprof_decode_roofline.json was taken from other kernel sources than this tree's: withheld"
+                frac_rocprof_note = "profiles/r5_rocprof_decode_roofline.json was taken from other kernel sources than this tree's: withheld"
         except (OSError, ValueError, KeyError):
             frac_rocprof = None
 
@@ -555,12 +556,18 @@ def main() -> int:
         "roofline": {
             "bound": "hbm",
             "kernel": "mmvq_stream_kernel (single-token quantised mat-vec as an LDS-DMA weight stream: Q|K|V, gate|up, ffn_down of every layer and the output head; attn_output runs inside the attention launch and is excluded)",
-            "achieved": round(achieved, 1),
+            # `achieved` / `frac`: from the TRACED durations of the committed rocprofv3 summary of these kernel sources where there is one (per-launch averages of
+            # eager launches, one row per role: `roles`), else from the live hipGraph sweep below; the sweep is always reported beside it
+            "achieved": round(frac_rocprof * HBM_PEAK_GBPS, 1) if frac_rocprof is not None else round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "frac": frac_rocprof if frac_rocprof is not None else round(achieved / HBM_PEAK_GBPS, 4),
+            "frac_source": "rocprofv3 trace (profiles/)" if frac_rocprof is not None else "live hipGraph sweep (no committed trace of these kernel sources)",
+            "frac_graph_sweep": round(achieved / HBM_PEAK_GBPS, 4),
+            "achieved_graph_sweep": round(achieved, 1),
             "frac_rocprof": frac_rocprof,
             "frac_rocprof_source": frac_rocprof_note,
+            "roles": roles_rocprof,
             "traffic": traffic,
             "traffic_source": traffic_note,
             "method": "the step's own launches of the weight-stream kernel (Q|K|V, gate|up, ffn_down of every layer + the output head: 97 for this model; "

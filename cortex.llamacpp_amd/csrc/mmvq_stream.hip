@@ -40,8 +40,8 @@ namespace mi355 {
 namespace {
 
 // ---- one mat-vec per launch
-template <int KB, int FUSE, bool MOE = false>
-__global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
+template <int KB, int FUSE, bool MOE>
+__device__ __forceinline__ void stream_body(const MMVQArgs &ka) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef MI355_STREAM_PROBE
     const unsigned long long t_top = wall_clock64();
@@ -80,6 +80,18 @@ __global__ __launch_bounds__(ST_NT) void mmvq_stream_kernel(const MMVQArgs ka) {
     }
     consumer_dispatch<KB, FUSE>(a, smem, wave - ST_NL, 0u, st_layout(KB));
 }
+// The same body under one kernel NAME per role a decode step launches it in (round 5): a kernel trace (rocprofv3 --kernel-trace --stats) then carries one row
+// per role - Q | K | V, gate | up, ffn_down, the output head - and the achieved bytes per second of each can be worked out from profiles/ alone
+// (tools/assemble_profiles_r5.py); launches of any other shape (attn_output where it is a launch of its own, expert launches, ..) keep the plain name.
+#define MI355_ST_KERNEL(NAME)                                                                                 \
+    template <int KB, int FUSE, bool MOE = false>                                                             \
+    __global__ __launch_bounds__(ST_NT) void NAME(const MMVQArgs ka) { stream_body<KB, FUSE, MOE>(ka); }
+MI355_ST_KERNEL(mmvq_stream_kernel)
+MI355_ST_KERNEL(mmvq_stream_qkv)
+MI355_ST_KERNEL(mmvq_stream_gate_up)
+MI355_ST_KERNEL(mmvq_stream_ffn_down)
+MI355_ST_KERNEL(mmvq_stream_head)
+#undef MI355_ST_KERNEL
 
 }  // namespace
 
@@ -168,15 +180,35 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     mmvq_stream_plan(a, num_cu());
     const int blocks = a.seg_block0[3];
     const size_t lds = (size_t)st_layout(kb).total;
-#define STREAM(KBV, FZ)                                                                                                  \
+    // the role of the launch in a decode step, told from its shape (only the kernel's NAME depends on it): Q | K | V = two or three segments behind the fused
+    // RMSNorm; gate | up = the SwiGLU pair; ffn_down = one segment that quantises its input and adds the residual; the head = one long segment behind the norm
+    enum { ROLE_ANY, ROLE_QKV, ROLE_GATE_UP, ROLE_DOWN, ROLE_HEAD };
+    int role = ROLE_ANY;
+    if (a.n_sel <= 1 && !a.seg[0].expert_sel) {
+        if (a.fuse_mode == 1 && a.epi == EPI_SWIGLU) role = ROLE_GATE_UP;
+        else if (a.fuse_mode == 1 && a.epi == EPI_STORE && a.n_seg >= 2) role = ROLE_QKV;
+        else if (a.fuse_mode == 1 && a.epi == EPI_STORE && a.n_seg == 1 && a.seg[0].n_rows >= 16384) role = ROLE_HEAD;
+        else if (a.fuse_mode == 2 && a.epi == EPI_ADD && a.n_seg == 1) role = ROLE_DOWN;
+    }
+#define STREAM_K(KERNEL, KBV, FZ)                                                                                        \
     do {                                                                                                                 \
         /* (per launch: the attribute is per device, and a process may hold contexts on several) */                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mmvq_stream_kernel<KBV, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<KBV, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                   \
-        if (g_stream_anyorder) hipExtLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a); \
-        else hipLaunchKernelGGL((mmvq_stream_kernel<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                  \
+        if (g_stream_anyorder) hipExtLaunchKernelGGL((KERNEL<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a); \
+        else hipLaunchKernelGGL((KERNEL<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                              \
     } while (0)
-#define STREAM_F(KBV) do { if (a.fuse_mode == 0) STREAM(KBV, 0); else if (a.fuse_mode == 1) STREAM(KBV, 1); else STREAM(KBV, 2); } while (0)
+    // (one macro per prologue form, so that only the kernels a form can take are instantiated)
+#define STREAM0(KBV) STREAM_K(mmvq_stream_kernel, KBV, 0)
+#define STREAM1(KBV)                                                                                                     \
+    do {                                                                                                                 \
+        if (role == ROLE_QKV) STREAM_K(mmvq_stream_qkv, KBV, 1);                                                         \
+        else if (role == ROLE_GATE_UP) STREAM_K(mmvq_stream_gate_up, KBV, 1);                                            \
+        else if (role == ROLE_HEAD) STREAM_K(mmvq_stream_head, KBV, 1);                                                  \
+        else STREAM_K(mmvq_stream_kernel, KBV, 1);                                                                       \
+    } while (0)
+#define STREAM2(KBV) do { if (role == ROLE_DOWN) STREAM_K(mmvq_stream_ffn_down, KBV, 2); else STREAM_K(mmvq_stream_kernel, KBV, 2); } while (0)
+#define STREAM_F(KBV) do { if (a.fuse_mode == 0) STREAM0(KBV); else if (a.fuse_mode == 1) STREAM1(KBV); else STREAM2(KBV); } while (0)
     // a mixture-of-experts step (expert index read on the device): the forms its two launches take - gate | up with the fused RMSNorm prologue over the hidden
     // size, down with the quantise-only prologue over the feed-forward width
 #define STREAM_MOE(KBV, FZ)                                                                                              \
@@ -199,15 +231,18 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         case 2: STREAM_F(2); break;
         case 3: STREAM_F(3); break;
         case 4: STREAM_F(4); break;
-        case 10: if (a.fuse_mode == 2) STREAM(10, 2); else if (a.fuse_mode == 0) STREAM(10, 0); else return hipErrorInvalidValue; break;
-        case 6: if (a.fuse_mode == 2) STREAM(6, 2); else if (a.fuse_mode == 0) STREAM(6, 0); else return hipErrorInvalidValue; break;
-        case 7: if (a.fuse_mode == 2) STREAM(7, 2); else if (a.fuse_mode == 0) STREAM(7, 0); else return hipErrorInvalidValue; break;
+        case 10: if (a.fuse_mode == 2) STREAM2(10); else if (a.fuse_mode == 0) STREAM0(10); else return hipErrorInvalidValue; break;
+        case 6: if (a.fuse_mode == 2) STREAM2(6); else if (a.fuse_mode == 0) STREAM0(6); else return hipErrorInvalidValue; break;
+        case 7: if (a.fuse_mode == 2) STREAM2(7); else if (a.fuse_mode == 0) STREAM0(7); else return hipErrorInvalidValue; break;
         default: return hipErrorInvalidValue;
     }
     STREAM_DONE:
 #undef STREAM_MOE
 #undef STREAM_F
-#undef STREAM
+#undef STREAM0
+#undef STREAM1
+#undef STREAM2
+#undef STREAM_K
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ common_init_from_params (src/llama_server_context.cc:207).
 """
 from __future__ import annotations
 
+import os
 import struct
 from dataclasses import dataclass, field
 
@@ -121,12 +122,31 @@ class GGUFWriter:
                 f.write(struct.pack("<IQ", t, o))
             pos = f.tell()
             f.write(b"\0" * ((-pos) % al))
-            for (name, ne, t, data), sz in zip(self.tensors, sizes):
-                buf = data() if callable(data) else data
-                buf = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
-                assert buf.size == sz, (name, buf.size, sz)
-                f.write(memoryview(buf))
-                f.write(b"\0" * ((-sz) % al))
+            # lazy tensors are generated by a few threads running ahead of the writer (numpy's generators release the GIL on bulk draws; every tensor has its
+            # own seeded generator, so the bytes do not depend on who draws them or when), a bounded window of them in memory at a time
+            from concurrent.futures import ThreadPoolExecutor
+            n_workers = max(1, min(8, (os.cpu_count() or 2) - 1))
+            window = 2 * n_workers
+            with ThreadPoolExecutor(max_workers=n_workers) as ex:
+                pending = {}
+
+                def submit(i):
+                    d = self.tensors[i][3]
+                    pending[i] = ex.submit(d) if callable(d) else None
+
+                nt = len(self.tensors)
+                for i in range(min(window, nt)):
+                    submit(i)
+                for i, ((name, ne, t, data), sz) in enumerate(zip(self.tensors, sizes)):
+                    fut = pending.pop(i)
+                    buf = fut.result() if fut is not None else data
+                    if i + window < nt:
+                        submit(i + window)
+                    buf = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
+                    assert buf.size == sz, (name, buf.size, sz)
+                    f.write(memoryview(buf))
+                    f.write(b"\0" * ((-sz) % al))
+                    del buf
             return f.tell()
 
 
@@ -182,6 +202,12 @@ CONFIGS = {
     # store + split attention + merge) and the chunk-list batched steps are built for — Llama-3-8B's own KV geometry
     # Llama-3-8B's layer geometry (4096 / 14336, 32 heads over 8 KV heads), two layers: the whole-step kernel's shape
     "tiny-8b-2l": LlamaConfig("tiny-8b-2l", 4096, 2, 32, 8, 14336, 512, 500000.0, 1e-5, 1024),
+    # Llama-3-8B's ATTENTION geometry (4096, 32 heads over 8 kv heads) with a narrow feed-forward: the ctx-4096 parity case needs a 3968-token prompt on the
+    # CPU side, and four fifths of a layer's CPU time are its feed-forward, which does not depend on the context length (tests/test_gpu_model.py)
+    "tiny-8b-attn-2l": LlamaConfig("tiny-8b-attn-2l", 4096, 2, 32, 8, 2048, 512, 500000.0, 1e-5, 4096),
+    # two layers of Llama-3-70B's geometry (BASELINE config 5): split over 8 ranks a rank holds 8 query heads on ONE kv head, attn_output columns of 1024 = 4
+    # super-blocks, ffn_down columns of 3584 = 14 super-blocks (and the 28672-wide ffn_down's column halves meet the column slicing)
+    "tiny-70b-2l": LlamaConfig("tiny-70b-2l", 8192, 2, 64, 8, 28672, 512, 500000.0, 1e-5, 1024),
     "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
     # Llama-3-70B's feed-forward width on a narrow model: 28672 has no weight-stream form, its single-token ffn_down runs as two column halves of 14336
     "tiny-ff28k": LlamaConfig("tiny-ff28k", 1024, 2, 8, 2, 28672, 512, 500000.0, 1e-5, 1024),

@@ -1103,25 +1103,44 @@ static unsigned *stream_error_word() {
 // live context fails its next check once per epoch: the step that really timed out is never returned as valid, at the price of one discarded step in the
 // bystanders.
 static std::atomic<unsigned> g_stream_err_epoch{0}, g_stream_err_code{0};
+// who can have raised it: every step launch of the process takes a serial; an epoch remembers the last serial handed out when it was opened; a context is a
+// suspect if it has an unchecked launch from before that moment
+static std::atomic<unsigned long long> g_launch_serial{0}, g_epoch_launch_serial{0};
+unsigned long long next_launch_serial() { return g_launch_serial.fetch_add(1) + 1; }
 unsigned stream_error_epoch() { return g_stream_err_epoch.load(); }
+// tests (mi355_debug_set_option("raise_stream_error", code)): what a kernel's bounded wait does when it gives up
+void debug_raise_stream_error(unsigned code) {
+    unsigned *w = stream_error_word();
+    if (w && code) __atomic_fetch_or(w, code, __ATOMIC_RELAXED);
+}
 
 bool Context::stream_check() {
     unsigned *w = stream_error_word();
     if (!w) return true;
     const unsigned raised = __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED);
-    if (raised) { g_stream_err_code.store(raised); g_stream_err_epoch.fetch_add(1); }
+    if (raised) { g_stream_err_code.store(raised); g_epoch_launch_serial.store(g_launch_serial.load()); g_stream_err_epoch.fetch_add(1); }
     const unsigned epoch = g_stream_err_epoch.load();
+    const unsigned long long first = first_unchecked_launch_;
+    first_unchecked_launch_ = 0;                         // (every caller has just synchronised the context's stream: nothing of this context is in flight)
     if (epoch == err_epoch_seen_) return true;
     err_epoch_seen_ = epoch;
+    // The word is raised by SOME kernel of the process.  A context with no unchecked launch from before the epoch was opened cannot be the one: it takes note
+    // of the epoch and carries on - a time-out in one model's kernel then does not abort the requests of the other models a server holds, unless they were in
+    // flight at the same moment (those discard one step each: the word cannot say whose kernel raised it).
+    if (first == 0 || first > g_epoch_launch_serial.load()) return true;
     const unsigned code = g_stream_err_code.load();
-    // a wait inside a weight-stream / engine kernel gave up (debugger, time-slicing, a workgroup that was not resident): the step's results are not valid.
-    // Take one launch per mat-vec from here on (the engine is the only kernel that waits for OTHER workgroups) and say so.
+    // a wait inside a kernel that waits for OTHER workgroups gave up (debugger, time-slicing, a workgroup that was not resident): the step's results are not
+    // valid.  Two kernels wait that way - the layer engine and the one-launch attention + attn_output (attn_out.hip) - and both are left from here on: this
+    // context takes one launch per mat-vec and the wait-free attention launch + linear(attn_output), so that a cause that persists (CU oversubscription from a
+    // second stream, a debugger) cannot make every later step time out the same way.  The weight-stream kernels' own waits are inside one workgroup.
     engine_state_ = -1;
+    attn_out_off_ = true;
     for (auto &ge : graphs_) (void)hipGraphExecDestroy(ge.second);
     graphs_.clear();
     graph_exec_ = nullptr;
-    char buf[200];
-    snprintf(buf, sizeof buf, "weight-stream kernel: a bounded wait gave up in this process (code 0x%x); results of the step discarded", code);
+    char buf[240];
+    snprintf(buf, sizeof buf, "weight-stream / attention kernel: a bounded wait gave up in this process (code 0x%x); results of the step discarded, this context "
+                              "continues on the wait-free launches", code);
     last_error = buf;
     return false;
 }
@@ -1352,7 +1371,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (fused_step) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch - and, where attn_out.hip has a form for the shape,
                 // the attn_output mat-vec with its residual add in that launch too
-                if (attn_mode == 2 && !engine && il < 255) {
+                if (attn_mode == 2 && !engine && il < 255 && !attn_out_off_) {
                     const bool add = !tp || hp.tp_rank == 0;
                     const MMVQSeg so = make_seg(L.wo, tp ? tp_part_ : x_, E, add ? x_ : nullptr, nullptr);
                     AttnArgs af = aa;
@@ -1710,6 +1729,7 @@ hipError_t Context::run_output(int n_out, int out_base) {
 
 int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
                            const int8_t *flags, int out_base) {
+    { const unsigned long long ls = next_launch_serial(); if (!first_unchecked_launch_) first_unchecked_launch_ = ls; }   // (stream_check: who is a suspect)
     cur_max_pos_ = 0;
     for (int i = 0; i < n; i++) cur_max_pos_ = std::max(cur_max_pos_, (int)pos[i]);
     std::vector<int> tcell;

@@ -87,6 +87,7 @@ struct KVCell {
     uint64_t seqs = 0;
 };
 
+void debug_raise_stream_error(unsigned code);        // tests: raise the sticky error word of the cross-workgroup kernels as a timed-out wait would
 struct ContextParams {
     uint32_t n_ctx = 512, n_batch = 2048, n_ubatch = 512, n_seq_max = 1;
     int type_k = T_F16, type_v = T_F16;
@@ -243,6 +244,8 @@ class Context {
     unsigned long long *d_engine_probe_ = nullptr;     // MI355_ENGINE_PROBE=<layer>: wall-clock stamps of that layer's launch (printed by the destructor)
     int engine_probe_layer_ = -1;
     unsigned err_epoch_seen_ = 0;                      // stream_check: the process-wide error epoch this context has already answered for
+    unsigned long long first_unchecked_launch_ = 0;    // process-wide serial of this context's first step launch since its last stream_check (0: none)
+    bool attn_out_off_ = false;                        // after an answered error epoch: the two-launch attention path (nothing in it waits for another workgroup)
     int engine_state_ = 0;                             // 0 = not looked at yet, 1 = ready, -1 = this model / context takes one launch per mat-vec
     bool engine_prepare();
     bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up

@@ -15,6 +15,16 @@ F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
 Q5_0, Q2_K, Q3_K, IQ4_NL = 6, 10, 11, 20
 
 
+def threads(cap: int = 32) -> int:
+    """OpenMP threads for the oracle's heavier runs: the cores this process may use, at most `cap` (the restatement is parallel over weight rows / heads: the
+    thread count never changes a bit of its results)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
 def build_oracle(force: bool = False) -> str:
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oq_quants.c", "oq_ops.c", "oq_llama.c", "oracle.h")]
     if force or not os.path.exists(LIB_PATH) or any(

@@ -330,7 +330,7 @@ def test_reference_smoke_flow_embedding_model_is_an_encoder(pkg, tmp_path):
     assert toks[0] == 2 and toks[-1] == 3 and len(toks) >= 3, toks
     assert m.tokenize("HELLO", add_special=True) == toks                     # lower-cased
     m.close()
-    om = oq.OracleModel(path); oc = oq.OracleContext(om, 64, oq.F16, oq.F16, True, 4)
+    om = oq.OracleModel(path); oc = oq.OracleContext(om, 64, oq.F16, oq.F16, True, oq.threads())
     oq.set_fa_v_acc_f32(1)
     try:
         oc.decode(toks, np.arange(len(toks)), [0] * len(toks), np.ones(len(toks), np.int8))

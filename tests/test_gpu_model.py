@@ -18,6 +18,14 @@ def be(pkg):
     return pkg.Backend()
 
 
+# test_prefill_layers_logits_and_greedy_ids: the cases whose 24 teacher-forced steps hold TWO near ties of the CPU logits that the HIP path resolves the other
+# way (every other case: at most one) -> the largest relative top-2 gap such a flip may have (measured gaps in the comment; FLIP_TOL bounds any flip at 6e-2)
+TWO_FLIP_CASES = {
+    ("tiny-qwen2-1.5b-2l:70", "q4_k_m", "f16"): 1e-2,      # steps 6 and 15: gaps 7.8e-3 and 4.4e-3 of the logit scale (round 5, gpurun_out/r5_flips.txt)
+    ("tiny-r3:40", "q4_k_m", "q8_0"): 1e-2,                # steps 5 and 7: gaps 2.5e-4 and 4.8e-3
+}
+
+
 def make(pkg, tmp_models, cfg, ftype, seed=11):
     path = str(tmp_models / f"{cfg}-{ftype}-{seed}.gguf")
     pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
@@ -28,7 +36,7 @@ def open_pair(pkg, path, n_ctx, kv, use_graphs=True, n_ubatch=512):
     m = pkg.Model(path)
     c = pkg.Context(m, n_ctx=n_ctx, type_k=KV[kv], type_v=KV[kv], use_graphs=use_graphs, n_ubatch=n_ubatch)
     om = oq.OracleModel(path)
-    oc = oq.OracleContext(om, n_ctx, KV[kv], KV[kv], True, 4)
+    oc = oq.OracleContext(om, n_ctx, KV[kv], KV[kv], True, oq.threads())
     return m, c, om, oc
 
 
@@ -117,6 +125,7 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
         tok = int(ref.argmax())
         step_err = [errs[-1]]
         mism = 0
+        gaps = []
         for step in range(24):          # single-token steps run through the captured hipGraph; teacher-forced with the CPU token
             c.decode([tok], [n_prompt + step])
             r = oc.decode([tok], [n_prompt + step])[0]
@@ -127,6 +136,7 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
                 top2 = np.sort(r)[-2:]
                 assert top2[1] - top2[0] <= 2 * FLIP_TOL * max(1.0, np.abs(r).max()), (step, top2)
                 mism += 1
+                gaps.append((step, float((top2[1] - top2[0]) / max(1.0, np.abs(r).max()))))
             assert int(g.argmax()) == c.argmax()
         assert max(step_err) <= FLIP_TOL, step_err
         if kv != "f16" and ftype != "f16":   # f16 weights / f16 K rows add an f16 rounding per element: never flip-free
@@ -141,8 +151,16 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
                 assert float(np.median(tok_err0)) <= TIGHT_TOL, (errs, step_err, tok_err0)
                 assert int((tok_err0 <= TIGHT_TOL).sum()) * 3 >= 2 * n_prompt, (errs, step_err, tok_err0)
         # every mismatch was checked above to be a near tie of the CPU logits (gap <= 2 FLIP_TOL); with 512-entry random vocabularies such ties are common,
-        # and which of them flip depends on the f32 association (round 4's 64-weight lane terms moved one case from one flip to two)
-        assert mism <= 2, mism
+        # and which of them flip depends on the f32 association.  At most ONE per run - except the cases named in TWO_FLIP_CASES, each with the steps and
+        # the relative top-2 gaps of the CPU logits measured when it was listed (a case that starts to flip elsewhere, or more often, fails here)
+        if os.environ.get("MI355_TEST_RECORD_FLIPS") and mism:
+            with open(os.environ["MI355_TEST_RECORD_FLIPS"], "a") as f:
+                f.write(f"{cfg}:{np_s} {ftype} {kv} mism={mism} gaps={gaps}\n")
+        allowed = TWO_FLIP_CASES.get((f"{cfg}:{np_s}" if np_s else cfg, ftype, kv))
+        if allowed is None:
+            assert mism <= 1, (mism, gaps)
+        else:
+            assert mism <= 2 and all(g <= allowed for _, g in gaps), (mism, gaps)
         c.close(); m.close(); oc.close(); om.close()
     finally:
         oq.set_fa_v_acc_f32(0)
@@ -503,6 +521,41 @@ def test_graph_and_eager_agree_bitwise(be, pkg, tmp_models, cfg):
     m.close()
 
 
+def test_a_timed_out_wait_fails_the_step_in_flight_and_nothing_else(be, pkg, tmp_models):
+    """The sticky error word of the cross-workgroup kernels (a bounded in-kernel wait that gives up raises it; here the test's hook does): the context whose
+    step was in flight discards that step ONCE, says why, leaves the kernels that wait for other workgroups (the one-launch attention + attn_output, the layer
+    engine) and carries on with the same results from the wait-free launches; a context of the same process that had nothing in flight is not touched."""
+    path = make(pkg, tmp_models, "tiny-d128", "q4_k_m")
+    m = pkg.Model(path)
+    a = pkg.Context(m, n_ctx=64, type_k=8, type_v=8)
+    b = pkg.Context(m, n_ctx=64, type_k=8, type_v=8)
+    prompt = [5, 6, 7, 8, 9]
+    for c in (a, b):
+        assert c.decode(prompt, np.arange(5)) == 0
+    ref0 = b.logits().copy()                                  # (b is checked and idle from here on)
+    assert np.array_equal(a.logits(), ref0)
+    t = int(ref0.argmax())
+    assert b.decode([t], [5]) == 0
+    ref1 = b.logits().copy()
+    t2 = int(ref1.argmax())
+    assert a.decode([t], [5]) == 0                           # a's step is in flight ...
+    be.set_option("raise_stream_error", 1)                   # ... when some kernel's wait "gives up"
+    with pytest.raises(pkg.binding.MI355Error):
+        a.logits()
+    # the bystander: nothing launched since its last check - it takes note and carries on
+    assert b.decode([t2], [6]) == 0
+    ref2 = b.logits().copy()
+    # the context that answered: the step is repeated (its cell is overwritten), now on the two-launch attention path - the same arithmetic up to the order in
+    # which a kv head's partial records are merged
+    assert a.kv_seq_rm(0, 5, -1)
+    assert a.decode([t], [5]) == 0
+    got1 = a.logits().copy()
+    assert rel_err(got1, ref1) <= 1e-5, rel_err(got1, ref1)
+    assert a.decode([t2], [6]) == 0
+    assert rel_err(a.logits(), ref2) <= 1e-5
+    a.close(); b.close(); m.close()
+
+
 def test_ubatch_split_and_multi_sequence(be, pkg, tmp_models):
     """n_tokens > n_ubatch is processed in micro-batches; two sequences share one batch (continuous batching)."""
     path = make(pkg, tmp_models, "tiny", "q4_k_m")
@@ -541,7 +594,7 @@ def test_neox_batched_steps_match_oracle(be, pkg, tmp_models, cfg, kv):
         m = pkg.Model(path)
         c = pkg.Context(m, n_ctx=512, n_seq_max=4, type_k=KV[kv], type_v=KV[kv])
         om = oq.OracleModel(path)
-        oc = oq.OracleContext(om, 512, KV[kv], KV[kv], True, 4)
+        oc = oq.OracleContext(om, 512, KV[kv], KV[kv], True, oq.threads())
         rng = np.random.default_rng(17)
         lens = [70, 9, 33]
         for sq, n in enumerate(lens):
@@ -682,7 +735,7 @@ def test_encoder_hidden_states_match_oracle(be, pkg, tmp_models, cfg, ftype, n):
     try:
         m = pkg.Model(path)
         c = pkg.Context(m, n_ctx=256, n_seq_max=4, type_k=KV["f16"], type_v=KV["f16"])
-        om = oq.OracleModel(path); oc = oq.OracleContext(om, 256, KV["f16"], KV["f16"], True, 4)
+        om = oq.OracleModel(path); oc = oq.OracleContext(om, 256, KV["f16"], KV["f16"], True, oq.threads())
         rng = np.random.default_rng(6)
         toks = rng.integers(5, m.n_vocab, n)
         c.enable_taps(True)
@@ -717,7 +770,7 @@ def test_encoder_hidden_states_match_oracle(be, pkg, tmp_models, cfg, ftype, n):
         # one- and two-token sequences (the single-row launches), and a q8_0 cache under the same graph
         for kvn, nn in (("f16", 1), ("f16", 2), ("q8_0", n)):
             c3 = pkg.Context(m, n_ctx=256, type_k=KV[kvn], type_v=KV[kvn])
-            oc3 = oq.OracleContext(om, 256, KV[kvn], KV[kvn], True, 4)
+            oc3 = oq.OracleContext(om, 256, KV[kvn], KV[kvn], True, oq.threads())
             oq.set_fa_v_acc_f32(1 if kvn == "f16" else 0)
             assert c3.decode(toks[:nn], np.arange(nn), [0] * nn, np.ones(nn, np.int8)) == 0
             oc3.decode(toks[:nn], np.arange(nn), [0] * nn, np.ones(nn, np.int8))
@@ -827,7 +880,7 @@ def test_moe_prompt_batches_grouped_by_expert(be, pkg, tmp_models, ftype, kv, n_
     rng = np.random.default_rng(9)
     prompt = rng.integers(0, 512, n_prompt)
     om = oq.OracleModel(path)
-    oc = oq.OracleContext(om, 512, KV[kv], KV[kv], True, 4)
+    oc = oq.OracleContext(om, 512, KV[kv], KV[kv], True, oq.threads())
     ref = oc.decode(prompt, np.arange(n_prompt))[0]
     ref_layers = [oc.layer_out(il, n_prompt) for il in range(2)]
     outs = {}
@@ -994,19 +1047,22 @@ def test_attn_out_one_launch_agrees_with_the_two_launches(be, pkg, tmp_models, c
     assert float(np.median(errs[:, 0])) <= 1e-5, errs[:, 0]
 
 
-@pytest.mark.parametrize("cfg,ftype,kv,n_prompt", [("tiny-8b-2l", "q4_k_m", "q8_0", 3968), ("tiny-d128", "q4_k_m", "f16", 3968), ("tiny-d128", "q4_k_m", "q4_0", 3000)])
+@pytest.mark.parametrize("cfg,ftype,kv,n_prompt", [("tiny-8b-2l", "q4_k_m", "q8_0", 3968), ("tiny-8b-attn-2l", "q4_k_m", "q8_0", 3968), ("tiny-d128", "q4_k_m", "f16", 3968),
+                                                   ("tiny-d128", "q4_k_m", "q4_0", 3000)])
 def test_context_filled_to_4096_matches_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt):
     """BASELINE config 3's ctx_len = 4096 (src/llama_engine.cc:612) with the context filled: a 3968-token prompt in two micro-batches of 2048 (the second
     one's queries attend to 2048 earlier cells through the key splits of the prompt attention), then 8 single-token steps at positions 3968 .. 3975 whose
     attention scans ~4000 cells (128-cell items in the one-launch form; 63 chunks merged in two request rounds in the two-launch form) - logits of the
-    prompt's last token and of every step against the CPU restatement.  Two layers of Llama-3-8B's geometry keep the CPU side affordable."""
+    prompt's last token and of every step against the CPU restatement.  Two layers of Llama-3-8B's geometry keep the CPU side affordable (round 5: the CPU
+    restatement on every core the box has and built -O3 -mavx2 - same bits, tests/test_golden*.py - takes this case from 184 s to about 120); tiny-8b-attn-2l is
+    the same attention geometry (4096 wide, 32 query heads over 8 kv heads of 128) with a 2048-wide feed-forward: a second weight set at a fifth of the CPU time."""
     path = make(pkg, tmp_models, cfg, ftype)
     oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
     try:
         m = pkg.Model(path)
         c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=KV[kv], type_v=KV[kv])
         om = oq.OracleModel(path)
-        oc = oq.OracleContext(om, 4096, KV[kv], KV[kv], True, min(32, os.cpu_count() or 8))
+        oc = oq.OracleContext(om, 4096, KV[kv], KV[kv], True, oq.threads())
         prompt = np.random.default_rng(41).integers(0, m.n_vocab, n_prompt)
         assert c.decode(prompt, np.arange(n_prompt)) == 0
         ref = oc.decode(prompt, np.arange(n_prompt))[0]

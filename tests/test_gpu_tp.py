@@ -37,13 +37,24 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
+INFRA_SIGNATURES = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "connect() timed out", "rendezvous", "store is not available",
+                    "Broken pipe", "socket", "NCCL", "ProcessGroup")
+NEVER_RETRY = ("bounded wait gave up", "MI355Error", "AssertionError", "assert ", "mismatch", "Traceback (most recent call last):\n  File \"" + os.path.join(ROOT, "tests", "tp_worker.py"))
+
+
 def run_ranks(world, plan_path, out_path, timeout=600):
-    """One process per rank.  A rank that dies (rendezvous, a peer's exit) is an infrastructure failure, not a result: the launch is repeated ONCE and the
-    first attempt's output goes to stderr; wrong numbers are never retried - the callers compare what the second attempt returns like any other."""
+    """One process per rank.  A launch is repeated ONCE, and only when its failure carries the signature of the test's own plumbing (a port taken between
+    _free_port() and the bind, the gloo rendezvous) and nothing of the product's: a bounded in-kernel wait that gave up, an MI355Error, an assertion of
+    tp_worker or any wrong number is a result and fails the test at once - a rank that dies from a real intermittent defect gets no second chance.  A retry is
+    reported as a warning, so flakiness stays visible."""
     try:
         return _run_ranks_once(world, plan_path, out_path, timeout)
     except AssertionError as e:
-        print(f"run_ranks: first attempt failed, repeating once\n{e}", file=sys.stderr)
+        msg = str(e)
+        if any(k in msg for k in NEVER_RETRY[:5]) or not any(k in msg for k in INFRA_SIGNATURES):
+            raise
+        import warnings
+        warnings.warn(f"run_ranks: infrastructure failure, launch repeated once: {msg[-600:]}")
         return _run_ranks_once(world, plan_path, out_path, timeout)
 
 
@@ -75,7 +86,7 @@ def make_plan(pkg, tmp_models, cfg, ftype, kv, n_prompt, transport, n_steps=6, n
     if not os.path.exists(path):
         pkg.gguf_synth.write_synthetic_llama(path, cfg, ftype, seed=seed)
     om = oq.OracleModel(path)
-    oc = oq.OracleContext(om, 256, KV[kv], KV[kv], True, 4)
+    oc = oq.OracleContext(om, 256, KV[kv], KV[kv], True, oq.threads())
     if kv == "f16":
         oq.set_fa_v_acc_f32(1)
     rng = np.random.default_rng(5)
@@ -127,6 +138,10 @@ def unsplit_logits(pkg, plan_path):
     ("tiny-e2048", "q4_k_m", "q8_0", 8, 4),       # four ranks: one KV head each
     ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 2),       # Llama-3-8B's layer geometry
     ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 8),       # north_star's rank count: 4 query heads + 1 KV head and 1792 = 7 x 256 feed-forward columns per rank
+    # BASELINE config 5's per-rank geometry (Llama-3-70B over 8 GPUs): 8 query heads on ONE kv head, attn_output columns of 1024 = 4 super-blocks, ffn_down
+    # columns of 3584 = 14 super-blocks of the 28672-wide tensor (whose single-GPU form is two column halves: the slicing must not meet them); and over 4
+    ("tiny-70b-2l", "q4_k_m", "q8_0", 8, 8),
+    ("tiny-70b-2l", "q4_k_m", "q8_0", 8, 4),
 ])
 def test_ranks_sharing_one_gpu_match_oracle_and_unsplit(pkg, tmp_models, cfg, ftype, kv, n_prompt, world):
     pkg.Backend()
@@ -157,7 +172,7 @@ def test_ranks_sharing_one_gpu_match_oracle_and_unsplit(pkg, tmp_models, cfg, ft
             assert int(a.argmax()) == int(b.argmax())
 
 
-@pytest.mark.parametrize("cfg,ftype,kv,world", [("tiny-e2048", "q4_k_m", "q8_0", 2), ("tiny-8b-2l", "q4_k_m", "q8_0", 2), ("tiny-e2048", "q4_k_m", "q8_0", 4)])
+@pytest.mark.parametrize("cfg,ftype,kv,world", [("tiny-e2048", "q4_k_m", "q8_0", 2), ("tiny-e2048", "q4_k_m", "q8_0", 4), ("tiny-70b-2l", "q4_k_m", "q8_0", 8)])
 def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg, ftype, kv, world):
     """The one-shot peer-to-peer all-reduce (host/tp_comm.cc: every rank writes its partial into slot `rank` of every rank's IPC-mapped buffer, flags,
     rank-order sum) takes the decode-sized exchanges; the prompt batch and the logits gather keep the host transport.  IPC mapping works between
@@ -183,8 +198,8 @@ def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg,
         assert max(rel_err(a, b) for a, b in zip(p2p["logits"], host["logits"])) <= FLIP_TOL
 
 
-@pytest.mark.parametrize("cfg,ftype,kv,world,wgs", [("tiny-e2048", "q4_k_m", "q8_0", 2, 0), ("tiny-8b-2l", "q4_k_m", "q8_0", 2, 7), ("tiny-e2048", "q4_k_m", "q8_0", 4, 0),
-                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5), ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 0)])
+@pytest.mark.parametrize("cfg,ftype,kv,world,wgs", [("tiny-e2048", "q4_k_m", "q8_0", 2, 7), ("tiny-e2048", "q4_k_m", "q8_0", 4, 0),
+                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5), ("tiny-70b-2l", "q4_k_m", "q8_0", 8, 0)])
 def test_prompt_sized_exchange_as_reduce_scatter_all_gather(pkg, tmp_models, cfg, ftype, kv, world, wgs, monkeypatch):
     """Prompt batches: the n_embd x n_ubatch partial sums go through ONE reduce-scatter + all-gather kernel (host/tp_comm.cc p2p_rsag_kernel:
     a segment per rank, every rank stores its part of segment q into rank q's IPC-mapped buffer, the owner adds in rank order and stores the sum
