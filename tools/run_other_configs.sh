@@ -1,7 +1,7 @@
 #!/bin/bash
-# bench lines of the other BASELINE configurations on one GPU (and the reference's smoke-model type mix), one JSON line each under gpurun_out/r4cfg/
+# bench lines of the other BASELINE configurations on one GPU (and the reference's smoke-model type mix), one JSON line each under gpurun_out/r5cfg/
 cd "$(dirname "$0")/.."
-O=gpurun_out/r4cfg; mkdir -p $O
+O=gpurun_out/r5cfg; mkdir -p $O
 run() { name=$1; shift; timeout 900 python bench.py "$@" --no-cpu-baseline > $O/$name.json 2> $O/$name.err; tail -c 300 $O/$name.json | head -c 0; python - "$O/$name.json" <<'PY'
 import json, sys
 try:
@@ -17,4 +17,4 @@ run tinyllama-1.1b --config tinyllama-1.1b --ftype q8_0 --cache-type f16
 run tinyllama-1.1b-q2_k --config tinyllama-1.1b --ftype q2_k --cache-type f16
 run tinyllama-1.1b-q4_k_m --config tinyllama-1.1b --ftype q4_k_m --cache-type f16
 run mixtral-8x7b --config mixtral-8x7b --ftype q5_k_m
-# (llama-3-70b: profiles/r4_bench_llama-3-70b.json is refreshed by hand)
+run llama-3-70b --config llama-3-70b --ftype q4_k_m
