@@ -51,6 +51,9 @@ struct MMVQArgs {
     // launch — the workgroups are divided evenly among them; expert j reads expert_sel[j], writes out + j * sel_out_stride
     // and (fuse_mode 2) quantises nx + j * sel_nx_stride (all strides in floats).  0 / 1 = one expert (expert_sel[0]).
     int n_sel, sel_out_stride, sel_nx_stride;
+    // single-token weight-stream launches with ONE segment (the output head): every result is also stored at out_host[row] - pinned host memory the device can
+    // write (nullptr: no copy).  The logits row then crosses PCIe under the launch instead of in a copy behind it.
+    float *out_host;
 };
 
 hipError_t launch_mmvq(MMVQArgs a, hipStream_t st);

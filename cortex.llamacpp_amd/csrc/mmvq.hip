@@ -872,6 +872,15 @@ hipError_t launch_mmvq(MMVQArgs a, hipStream_t st) {
     static const bool fast_on = !(getenv("MI355_MMVQ_FAST") && getenv("MI355_MMVQ_FAST")[0] == '0');   // diagnosis switch
     // single-token steps: the weight-stream kernel (LDS-DMA loader / consumer waves) where it has a form, else the register ring
     if (fast_on && g_stream_on && mmvq_stream_applicable(a)) return launch_mmvq_stream(a, st);
+    if (a.out_host) {
+        // only the weight stream stores the second copy itself: any other kernel is followed by a copy of the finished row (same contract, one node more)
+        float *oh = a.out_host;
+        a.out_host = nullptr;
+        if (a.n_seg != 1 || a.T != 1) return hipErrorInvalidValue;
+        const hipError_t e = launch_mmvq(a, st);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(oh, a.seg[0].out, (size_t)a.seg[0].n_rows * 4, hipMemcpyDeviceToHost, st);
+    }
     if (fast_on && mmvq_fast_applicable(a)) return launch_mmvq_fast(a, st);
     if ((a.T == 16 || a.T == 8) && a.fuse_mode == 0) {
         bool moe = false;

@@ -106,6 +106,7 @@ static constexpr size_t STREAM_Q80_MIN_BYTES = (size_t)MI355_STREAM_Q80_MIN_MB <
 
 bool mmvq_stream_applicable(const MMVQArgs &a) {
     if (a.T != 1 || a.K <= 0 || (a.K % 256) != 0) return false;      // (whole super-blocks; a partial last pass decodes zero-scale slices, as on the register ring)
+    if (a.out_host && (a.n_seg != 1 || a.epi != EPI_STORE || a.n_sel > 1 || a.seg[0].expert_sel)) return false;   // the host copy: one plain segment only
     // the selected experts of one token in one launch (n_sel): one tensor or one gate | up pair, results stored per expert (no residual epilogue)
     if (a.n_sel > 1 && (a.n_sel > 8 || (a.epi == EPI_SWIGLU ? 1 : a.n_seg) != 1 || a.epi == EPI_ADD)) return false;
     if (a.n_sel > 1 || a.seg[0].expert_sel) {                   // (the forms launch_mmvq_stream instantiates for expert launches)

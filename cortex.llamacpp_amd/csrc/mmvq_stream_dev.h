@@ -211,6 +211,7 @@ struct StOp {
     const float *nx, *nw;
     const uint8_t *W, *W1;        // this workgroup's segment; SwiGLU: W1 = the up tensor
     float *out; const float *resid;
+    float *out2;                  // a second copy of every result (segment 0 of a one-segment launch: the logits row into pinned host memory), or nullptr
     unsigned row_bytes, total;    // total = bytes of the workgroup's run of rows, per tensor
     bool swiglu, pair;
     int ns_raw, ns_pad;           // ring slots of the workgroup's share (gate / up slots alternate), and padded to an even count
@@ -264,7 +265,7 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
     const float neps = U(ka.neps);
     const int8_t *aq = U(ka.aq); const float *ad = U(ka.ad); const int16_t *abs = U(ka.abs); const float *nx = U(ka.nx), *nw = U(ka.nw);
     const uint8_t *w0 = U(ka.seg[0].W), *w1 = U(ka.seg[1].W), *w2 = U(ka.seg[2].W);
-    float *o0 = U(ka.seg[0].out), *o1 = U(ka.seg[1].out), *o2 = U(ka.seg[2].out);
+    float *o0 = U(ka.seg[0].out), *o1 = U(ka.seg[1].out), *o2 = U(ka.seg[2].out), *oh = U(ka.out_host);
     const float *r0 = U(ka.seg[0].resid), *r1 = U(ka.seg[1].resid), *r2 = U(ka.seg[2].resid);
     const int t0 = U(ka.seg[0].type), t1 = U(ka.seg[1].type), t2 = U(ka.seg[2].type);
     const int n0 = U(ka.seg[0].n_rows), n1 = U(ka.seg[1].n_rows), n2 = U(ka.seg[2].n_rows);
@@ -283,7 +284,7 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
 #define PIN(x) asm volatile("" :: "s"(x))
     PIN(n_seg); PIN(sb0); PIN(sb1); PIN(sb2); PIN(sb3); PIN(K); PIN(epi); PIN(nck); PIN(neps);
     PIN(aq); PIN(ad); PIN(abs); PIN(nx); PIN(nw);
-    PIN(w0); PIN(w1); PIN(w2); PIN(o0); PIN(o1); PIN(o2); PIN(r0); PIN(r1); PIN(r2);
+    PIN(w0); PIN(w1); PIN(w2); PIN(o0); PIN(o1); PIN(o2); PIN(oh); PIN(r0); PIN(r1); PIN(r2);
     PIN(t0); PIN(t1); PIN(t2); PIN(n0); PIN(n1); PIN(n2); PIN(rb0); PIN(rb1); PIN(rb2);
     if constexpr (MOE) { PIN(n_sel); PIN(sel_os); PIN(sel_ns); PIN(es0); PIN(es1); PIN(est0); PIN(est1); }
 #undef PIN
@@ -306,6 +307,7 @@ __device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
         if (es1) o.W1 += (size_t)es1[sel_j] * est1;
     }
     o.nx = nx; o.out = s == 0 ? o0 : s == 1 ? o1 : o2;
+    o.out2 = n_seg == 1 ? oh : nullptr;
     if constexpr (MOE) { o.nx = nx + (size_t)sel_j * (size_t)sel_ns; o.out += (size_t)sel_j * (size_t)sel_os; }
     o.resid = s == 0 ? r0 : s == 1 ? r1 : r2;
     o.type = s == 0 ? t0 : s == 1 ? t1 : t2;
@@ -640,7 +642,10 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
             if (ENG != 0 && io.gran) {
                 st_store_granule(io.gran + row, io.tag, __float_as_uint(v));
                 if (io.plain) io.plain[row] = v;
-            } else a.out[row] = v;
+            } else {
+                a.out[row] = v;
+                if (ENG == 0 && a.out2) a.out2[row] = v;
+            }
         }
         flushed = upto;
     };

@@ -874,6 +874,7 @@ static hipError_t mmvq_tokens(MMVQSeg *segs, int n_seg, int K, int T, int epi, c
         MMVQArgs a{};
         a.n_seg = n_seg; a.K = K; a.T = nt; a.epi = epi;
         a.fuse_mode = fz.mode; a.nx = fz.x; a.nw = fz.w; a.neps = fz.eps;
+        a.out_host = nt == 1 && T == 1 ? fz.out_host : nullptr;
         for (int s = 0; s < n_seg; s++) {
             a.seg[s] = segs[s];
             a.seg[s].out = segs[s].out + (size_t)t0 * segs[s].ld_out;
@@ -1667,6 +1668,7 @@ hipError_t Context::tp_reduce_into_x(int T) {
 }
 
 hipError_t Context::run_output(int n_out, int out_base) {
+    logits_on_host_ = false;
     if (n_out <= 0) return hipSuccess;
     const HParams &hp = model->hp;
     const int E = hp.n_embd, V = hp.n_vocab;
@@ -1685,6 +1687,10 @@ hipError_t Context::run_output(int n_out, int out_base) {
         return hipSuccess;
     }
     const bool oq = is_quant(model->output.type);
+    // a single-token step whose logits row is wanted on the host: the head's launch stores it into the pinned row itself (the row crosses PCIe under the
+    // launch; a copy node behind it cost 9 - 12 us of every step, tools/host_gap.py)
+    static const bool zc_env = !(getenv("MI355_LOGITS_ZERO_COPY") && getenv("MI355_LOGITS_ZERO_COPY")[0] == '0');
+    logits_on_host_ = zc_env && oq && cur_T_ == 1 && n_out == 1 && cp.logits_to_host && !hp.tp_exchange && h_logits_ != nullptr;
     if (oq && can_fuse(E, n_out)) {
         pending_fuse_.mode = 1; pending_fuse_.x = xo; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps;
     } else {
@@ -1714,6 +1720,7 @@ hipError_t Context::run_output(int n_out, int out_base) {
             HIP_TRY(hipMemcpy2DAsync(lg + (size_t)r * VL, (size_t)V * 4, tp_logits_ + (size_t)r * n_out * VL, (size_t)VL * 4, (size_t)VL * 4, (size_t)n_out,
                                      hipMemcpyDeviceToDevice, stream_));
     } else {
+        if (logits_on_host_) pending_fuse_.out_host = h_logits_ + (size_t)out_base * V;
         HIP_TRY(linear(model->output, aq_e_, xn_, E, n_out, lg, V, nullptr, EPI_STORE));
     }
     pending_fuse_ = Fuse();
@@ -1830,7 +1837,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
                 last_error.clear();
                 hipError_t e2 = run_layers(1, bucket > 0 ? bucket : std::min((int)cp.n_ctx, chunk_cap_ * 64));
                 if (e2 == hipSuccess) e2 = run_output(1, 0);
-                if (e2 == hipSuccess && cp.logits_to_host) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
+                if (e2 == hipSuccess && cp.logits_to_host && !logits_on_host_) e2 = hipMemcpyAsync(h_logits_, d_logits_, (size_t)V * 4, hipMemcpyDeviceToHost, stream_);
                 if (e2 != hipSuccess) inner = last_error;
                 e = hipStreamEndCapture(stream_, &g);
                 if (e2 != hipSuccess) e = e2;
@@ -1860,7 +1867,7 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
         e = run_layers(n, n_kv_);
         if (e == hipSuccess) e = run_output(n_out, out_base);
         if (profiler_safe) (void)hipStreamSynchronize(stream_);
-        if (e == hipSuccess && n_out > 0 && cp.logits_to_host && !embeddings_enabled)
+        if (e == hipSuccess && n_out > 0 && cp.logits_to_host && !embeddings_enabled && !logits_on_host_)
             e = hipMemcpyAsync(h_logits_ + (size_t)out_base * V, d_logits_ + (size_t)out_base * V, (size_t)n_out * V * 4, hipMemcpyDeviceToHost, stream_);
         prof_end();
     }

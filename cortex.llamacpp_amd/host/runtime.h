@@ -101,6 +101,7 @@ struct Fuse {   // fused activation prologue of the single-token mat-vec (mmvq.h
     int mode = 0;
     const float *x = nullptr, *w = nullptr;
     float eps = 0.0f;
+    float *out_host = nullptr;   // the launch also stores its results here (pinned host memory; the output head of a single-token step) - weight stream only
 };
 
 void set_moe_group_min(int tokens);   // tests: batch size from which a mixture-of-experts feed-forward is grouped by expert
@@ -245,6 +246,7 @@ class Context {
     int engine_probe_layer_ = -1;
     unsigned err_epoch_seen_ = 0;                      // stream_check: the process-wide error epoch this context has already answered for
     unsigned long long first_unchecked_launch_ = 0;    // process-wide serial of this context's first step launch since its last stream_check (0: none)
+    bool logits_on_host_ = false;                      // run_output: the head's launch stored the flagged row into h_logits_ itself (no copy node behind the step)
     bool attn_out_off_ = false;                        // after an answered error epoch: the two-launch attention path (nothing in it waits for another workgroup)
     int engine_state_ = 0;                             // 0 = not looked at yet, 1 = ready, -1 = this model / context takes one launch per mat-vec
     bool engine_prepare();
