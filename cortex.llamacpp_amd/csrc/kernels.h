@@ -110,6 +110,14 @@ hipError_t launch_mmq_expand(int type, const uint8_t *W, size_t row_bytes, int n
 struct MMQWorkspace { float *p = nullptr; size_t bytes = 0; };
 void mmq_set_split(int n);                                 // tools: force the K split (0 = by shape)
 void mmq_set_lds_form(int on);                             // tools: 0 = never the 128 x 256 LDS kernel, 1 = by shape, -1 = environment / default
+// ggml_mul_mat_id on a prompt batch as one launch per projection (mmq.hip, round 5): every expert's grouped batch through the 128 x 256 LDS kernel, the (expert,
+// token tile) of a workgroup found on the device from moe_group_kernel's meta words (counts at [0, NE), first grouped rows at [NE, 2 NE)); rows_max = rows of
+// the grouped arrays; plane_stride = bytes between two experts' plane sets
+bool mmq_planes_moe_ok(int type, int n_rows, int K);
+hipError_t launch_mmq_planes_swiglu_moe(int type, const uint8_t *planes_gate, const uint8_t *planes_up, size_t plane_stride, int n_expert, const int32_t *meta,
+                                        int n_rows, int K, int rows_max, const ActQuant &q, float *out, int ld_out, hipStream_t st);
+hipError_t launch_mmq_planes_moe(int type, const uint8_t *planes, size_t plane_stride, int n_expert, const int32_t *meta, int n_rows, int K, int rows_max,
+                                 const ActQuant &q, float *out, int ld_out, hipStream_t st);
 hipError_t launch_mmq_planes(int type, const uint8_t *planes, int n_rows, int K, int T, const ActQuant &q, const int8_t *bh, const int8_t *bl,
                              float *out, int ld_out, const float *resid, hipStream_t st, MMQWorkspace wsp = MMQWorkspace());
 // small batches (continuous-batching decode steps, 8 <= T <= 64): K split over the waves of a workgroup, GGUF-form weights

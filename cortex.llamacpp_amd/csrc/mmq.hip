@@ -1509,6 +1509,51 @@ __global__ __launch_bounds__(NTHREADS) void mmq_planes2_swiglu_kernel(const uint
     planes2_body<MINS, true>(planes_gate, planes_up, n_rows, K, T, n_row_tiles, n_tok_tiles, aq, ad, absum, po, nullptr, nullptr, 1, row_tile, tok_tile, 0);
 }
 
+// ---- ggml_mul_mat_id on a prompt batch as ONE launch per projection (round 5).  The (token, rank) pairs of the batch are sorted by expert (moe_group_kernel: expert
+// e owns rows [meta[NE + e], + meta[e]) of the grouped activation / result arrays); a workgroup is (row tile, token-tile slot j): slot j is the j-th 256-token tile
+// of the concatenation of the experts' batches, found by walking the per-expert counts ON THE DEVICE - no host synchronisation to size per-expert launches, and
+// eight half-empty launches of ~128 tokens become one that fills the chip.  The body is planes2_body unchanged: the wrapper hands it the expert's planes, the
+// batch's rows as "the" token range (pointers offset to the batch's first row, T = the batch's length) and the tile index within the batch.
+struct MoeTiles { const int32_t *meta; int n_expert; size_t plane_stride; };     // meta: [0, NE) tokens per expert, [NE, 2 NE) first grouped row
+__device__ __forceinline__ bool moe_tile_of(const MoeTiles &m, int j, int &e_out, int &tile_out, int &r0_out, int &n_out) {
+    for (int e = 0; e < m.n_expert; e++) {                      // (scalar: the counts are a few words of one cache line)
+        const int n_e = m.meta[e];
+        const int tiles = (n_e + P2_TOK - 1) / P2_TOK;
+        if (j < tiles) { e_out = e; tile_out = j; r0_out = m.meta[m.n_expert + e]; n_out = n_e; return true; }
+        j -= tiles;
+    }
+    return false;
+}
+template <bool MINS>
+__global__ __launch_bounds__(NTHREADS) void mmq_planes2_swiglu_moe_kernel(const uint8_t *planes_gate, const uint8_t *planes_up, int n_rows, int K, int n_row_tiles,
+                                                                          int n_tile_slots, const int8_t *aq, const float *ad, const int16_t *absum, PlanesOut po,
+                                                                          const MoeTiles mt) {
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int slot = loc % n_tile_slots;
+    const int row_tile = (loc / n_tile_slots) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;                       // workgroup-uniform
+    int e, tile, r0, n_e;
+    if (!moe_tile_of(mt, slot, e, tile, r0, n_e)) return;
+    const size_t nb = (size_t)(K >> 8);
+    po.out[0] += (size_t)r0 * po.ld[0];
+    planes2_body<MINS, true>(planes_gate + (size_t)e * mt.plane_stride, planes_up + (size_t)e * mt.plane_stride, n_rows, K, n_e, n_row_tiles, (n_e + P2_TOK - 1) / P2_TOK,
+                             aq + (size_t)r0 * K, ad + (size_t)r0 * nb, absum + (size_t)r0 * (K >> 4), po, nullptr, nullptr, 1, row_tile, tile, 0);
+}
+template <bool MINS>
+__global__ __launch_bounds__(NTHREADS) void mmq_planes2_moe_kernel(const uint8_t *planes, int n_rows, int K, int n_row_tiles, int n_tile_slots,
+                                                                   const int8_t *aq, const float *ad, const int16_t *absum, PlanesOut po, const MoeTiles mt) {
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int slot = loc % n_tile_slots;
+    const int row_tile = (loc / n_tile_slots) * 8 + xcd;
+    if (row_tile >= n_row_tiles) return;
+    int e, tile, r0, n_e;
+    if (!moe_tile_of(mt, slot, e, tile, r0, n_e)) return;
+    const size_t nb = (size_t)(K >> 8);
+    po.out[0] += (size_t)r0 * po.ld[0];
+    planes2_body<MINS, false>(planes + (size_t)e * mt.plane_stride, nullptr, n_rows, K, n_e, n_row_tiles, (n_e + P2_TOK - 1) / P2_TOK,
+                              aq + (size_t)r0 * K, ad + (size_t)r0 * nb, absum + (size_t)r0 * (K >> 4), po, nullptr, nullptr, 1, row_tile, tile, 0);
+}
+
 // out[t][row] = (resid) + ws[0][t][row] + ws[1][t][row] + ... in split order (fixed, so results do not depend on timing)
 __global__ __launch_bounds__(256) void mmq_splitk_reduce_kernel(const float *ws, int n_split, int T, int n_rows, const PlanesOut po, const float *resid) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x, per_tok = (size_t)n_rows >> 2;      // n_rows % 4 == 0 (launcher)
@@ -1726,6 +1771,46 @@ hipError_t launch_mmq_planes_swiglu(int type, const uint8_t *planes_gate, const 
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_swiglu_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
         hipLaunchKernelGGL((mmq_planes2_swiglu_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes_gate, planes_up, n_rows, K, T, nrt, ntt, q.qs, q.d, q.bsums, po);
+    }
+    return hipGetLastError();
+}
+
+// the grouped (all experts, one launch) forms: `rows_max` = rows of the grouped arrays (tokens x experts used), meta = moe_group_kernel's counts and offsets
+bool mmq_planes_moe_ok(int type, int n_rows, int K) {
+    static const bool env_on = !(getenv("MI355_MOE_GROUPED_LAUNCH") && getenv("MI355_MOE_GROUPED_LAUNCH")[0] == '0');
+    return env_on && (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K) && mmq_planes_bytes(type, n_rows, K) != 0 && (n_rows % 128) == 0 && (K % 256) == 0;
+}
+hipError_t launch_mmq_planes_swiglu_moe(int type, const uint8_t *planes_gate, const uint8_t *planes_up, size_t plane_stride, int n_expert, const int32_t *meta,
+                                        int n_rows, int K, int rows_max, const ActQuant &q, float *out, int ld_out, hipStream_t st) {
+    if (!mmq_planes_moe_ok(type, n_rows, K) || n_expert < 1 || !meta || !q.qs || !q.d || !q.bsums) return hipErrorInvalidValue;
+    PlanesOut po{};
+    po.n_seg = 1; po.out[0] = out; po.ld[0] = ld_out; po.row_end[0] = n_rows;
+    const int nrt = (n_rows + 63) / 64, slots = (rows_max + P2_TOK - 1) / P2_TOK + n_expert;     // every expert may end in a partial tile
+    const dim3 grid((unsigned)(((nrt + 7) / 8) * slots * 8));
+    const MoeTiles mt{meta, n_expert, plane_stride};
+    if (planes_have_mins(type)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_swiglu_moe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        hipLaunchKernelGGL((mmq_planes2_swiglu_moe_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes_gate, planes_up, n_rows, K, nrt, slots, q.qs, q.d, q.bsums, po, mt);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_swiglu_moe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        hipLaunchKernelGGL((mmq_planes2_swiglu_moe_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes_gate, planes_up, n_rows, K, nrt, slots, q.qs, q.d, q.bsums, po, mt);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_mmq_planes_moe(int type, const uint8_t *planes, size_t plane_stride, int n_expert, const int32_t *meta, int n_rows, int K, int rows_max,
+                                 const ActQuant &q, float *out, int ld_out, hipStream_t st) {
+    if (!mmq_planes_moe_ok(type, n_rows, K) || n_expert < 1 || !meta || !q.qs || !q.d || !q.bsums) return hipErrorInvalidValue;
+    PlanesOut po{};
+    po.n_seg = 1; po.out[0] = out; po.ld[0] = ld_out; po.row_end[0] = n_rows;
+    const int nrt = (n_rows + P2_ROWS - 1) / P2_ROWS, slots = (rows_max + P2_TOK - 1) / P2_TOK + n_expert;
+    const dim3 grid((unsigned)(((nrt + 7) / 8) * slots * 8));
+    const MoeTiles mt{meta, n_expert, plane_stride};
+    if (planes_have_mins(type)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_moe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        hipLaunchKernelGGL((mmq_planes2_moe_kernel<true>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, nrt, slots, q.qs, q.d, q.bsums, po, mt);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mmq_planes2_moe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        hipLaunchKernelGGL((mmq_planes2_moe_kernel<false>), grid, dim3(NTHREADS), (size_t)P2_LDS, st, planes, n_rows, K, nrt, slots, q.qs, q.d, q.bsums, po, mt);
     }
     return hipGetLastError();
 }

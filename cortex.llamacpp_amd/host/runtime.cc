@@ -1450,6 +1450,24 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 // expert (its weights are read once per batch, through the same batched kernels as the dense projections)
                 const int NE = hp.n_expert, GR = T * KU;
                 HIP_TRY(launch_moe_group(moe_ids_, T, KU, NE, moe_meta_, moe_slot_, moe_tok_, stream_));
+                // round 5: every expert's batch in ONE launch per projection (the workgroups find their expert and token tile from the counts on the device):
+                // no host synchronisation in the layer, and ~128-token batches that half-fill a launch each become one launch that fills the chip
+                const bool grouped = T >= 32 && L.gate_exps.planes && L.up_exps.planes && L.down_exps.planes && L.gate_exps.type == L.up_exps.type &&
+                                     L.gate_exps.N == L.up_exps.N && mmq_planes_moe_ok(L.gate_exps.type, (int)L.gate_exps.N, E) &&
+                                     mmq_planes_moe_ok(L.down_exps.type, (int)L.down_exps.N, FF) && (L.gate_exps.N % 64) == 0;
+                if (grouped) {
+                    HIP_TRY(launch_moe_gather_act(aq_e_, moe_tok_, GR, E, aq_eg_, stream_));
+                    prep_owner_ = nullptr;
+                    const size_t ps_gu = L.gate_exps.planes_bytes / (size_t)L.gate_exps.n_expert, ps_d = L.down_exps.planes_bytes / (size_t)L.down_exps.n_expert;
+                    HIP_TRY(launch_mmq_planes_swiglu_moe(L.gate_exps.type, L.gate_exps.planes, L.up_exps.planes, ps_gu, NE, moe_meta_, (int)L.gate_exps.N, E, GR, aq_eg_,
+                                                         ffn_g_, FF, stream_));
+                    HIP_TRY(launch_quantize(ffn_g_, FF, GR, aq_ffg_, true, false, stream_));
+                    HIP_TRY(launch_mmq_planes_moe(L.down_exps.type, L.down_exps.planes, ps_d, NE, moe_meta_, (int)L.down_exps.N, FF, GR, aq_ffg_, y_g_, E, stream_));
+                    HIP_TRY(launch_moe_scatter_combine(x_, y_g_, moe_w_, moe_slot_, T, E, KU, stream_));
+                    prof_mark("moe_ffn");
+                    if (debug_taps_ && dbg_) HIP_TRY(hipMemcpyAsync(dbg_ + (size_t)il * cp.n_ubatch * E, x_, (size_t)T * E * 4, hipMemcpyDeviceToDevice, stream_));
+                    continue;
+                }
                 HIP_TRY(hipMemcpyAsync(h_moe_meta_, moe_meta_, (size_t)(2 * NE + 1) * 4, hipMemcpyDeviceToHost, stream_));
                 HIP_TRY(launch_moe_gather_act(aq_e_, moe_tok_, GR, E, aq_eg_, stream_));
                 prep_owner_ = nullptr;                             // the grouped rows were just rewritten
