@@ -27,6 +27,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 
+# per-file flags.  Kernel-argument preload (gfx950: up to 14 dwords of the FIRST scalar arguments of a kernel arrive in SGPRs with the wave): the stream-bound
+# roles of the weight-stream kernel start their stream from them before the argument segment has been read (csrc/mmvq_stream.hip stream_body_fast)
+EXTRA = {
+    "csrc/mmvq_stream.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -49,7 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        rel = os.path.relpath(src, HERE)
+        cmd = [hipcc] + FLAGS + EXTRA.get(rel, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -80,6 +80,93 @@ __device__ __forceinline__ void stream_body(const MMVQArgs &ka) {
     }
     consumer_dispatch<KB, FUSE>(a, smem, wave - ST_NL, 0u, st_layout(KB));
 }
+// ---- the STREAM-BOUND roles (gate | up, the output head): the launch ends when its stream does, so the stream's first request is what counts (round 5).
+// The launch's geometry is packed once more into the kernel's FIRST 14 argument dwords - scalars the hardware preloads into SGPRs (build.py:
+// -amdgpu-kernarg-preload-count=14; tools/preload_probe shows the preload is live on this box), usable in the wave's first instruction while the argument
+// struct is cold (0.45 us per round trip):
+//   * every wave requests the consumers' activation and norm weights at once (early_issue; the loaders' copies are never looked at: under a condition hipcc
+//     waits for the loads where the branches join);
+//   * behind the workgroup's first barrier the loaders work out their run of rows from the packed geometry and start the stream - no argument read, no wait
+//     for the consumers; the consumers read the argument struct THEN (its round trip is hidden behind a stream that would not have been decoded yet anyway).
+// Measured in the harness (tools/exp_stream.hip): gate | up 13.7 -> 13.1 us.  Only for these roles: a launch that is bound by its prologue (ffn_down) or ends
+// one decode step behind a short stream (Q | K | V) LOSES when its consumers' argument read and residual request queue behind the stream (6.25 -> 6.8 us and
+// 9.97 -> 11.4 us: profiles/r5_exp_fast_start_harness.txt) - those keep the order "all small requests, then the stream".
+// kf: K >> 8 (8 bits) | first workgroup of segment 1 (10) | of segment 2 (10) | segments (2) | SwiGLU pair (1) | valid (1).  sg[s]: rows per workgroup (11
+// bits) | workgroups that take that many (10) | rows of the next one (11).  rb01 / rb2: row bytes of the segments (16 bits each).  The weights and the norm
+// weights as 16-byte units above `wbase` (one arena: 32 bits reach 64 GB).
+struct StFast { const float *nx; const uint8_t *wbase; unsigned ow0, ow1, ow2, onw, kf, sg0, sg1, sg2, rb01, rb2; };
+// the loader's view of the workgroup's run from the packed geometry: the fields loader_op reads (W, W1, b0, row_bytes, total, swiglu, ns_pad) - the same
+// numbers op_setup derives from the argument struct (a consumer checks that: a mismatch raises the sticky error word)
+__device__ __forceinline__ void st_fast_setup(StFast f, StOp &o) {
+    // (every packed word through an opaque copy: hipcc otherwise sees adjacent kernel arguments selected by one index and builds the selection as a table in
+    // scratch memory - 32 bytes per lane and a scratch round trip on the loaders' way to their first request)
+    asm volatile("" : "+s"(f.ow0), "+s"(f.ow1), "+s"(f.ow2), "+s"(f.sg0), "+s"(f.sg1), "+s"(f.sg2), "+s"(f.rb01), "+s"(f.rb2));
+    const unsigned kf = f.kf;
+    const int nseg = (int)((kf >> 28) & 3u), lo1 = (int)((kf >> 8) & 1023u), lo2 = (int)((kf >> 18) & 1023u);
+    const bool swiglu = ((kf >> 30) & 1u) != 0;
+    const int b = (int)blockIdx.x;
+    unsigned g = f.sg0, rb = f.rb01 & 0xffffu, ow = f.ow0;
+    int lo = 0;
+    if (nseg > 1 && b >= lo1) { g = f.sg1; rb = f.rb01 >> 16; ow = f.ow1; lo = lo1; }
+    if (nseg > 2 && b >= lo2) { g = f.sg2; rb = f.rb2 & 0xffffu; ow = f.ow2; lo = lo2; }
+    const int rpb = (int)(g & 2047u), full = (int)((g >> 11) & 1023u), rem = (int)(g >> 21);
+    const int bl = b - lo;
+    const int rows = bl < full ? rpb : bl == full ? rem : 0;
+    o.W = f.wbase + ((size_t)ow << 4);
+    o.W1 = f.wbase + ((size_t)f.ow1 << 4);
+    o.b0 = bl * rpb; o.n_rows_wg = rows; o.row_bytes = rb;
+    o.swiglu = swiglu;
+    o.total = (unsigned)rows * rb;
+    const int per_tensor = (int)((o.total + ST_SLOT - 1) / ST_SLOT);
+    o.ns_raw = swiglu ? 2 * per_tensor : per_tensor;
+    o.ns_pad = (o.ns_raw + 1) & ~1;
+}
+
+template <int KB>
+__device__ __forceinline__ void stream_body_fast(const StFast &fa) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = uni(tid_now() >> 6), lane = tid_now() & 63;
+    EarlyAct<KB> ea;
+    early_issue<KB, 1>(fa.nx, reinterpret_cast<const float *>(fa.wbase + ((size_t)fa.onw << 4)), (int)(fa.kf & 255u) << 8, wave >= ST_NL ? wave - ST_NL : 0, lane, ea);
+    sync_init(smem);
+    if (wave < ST_NL) {                                         // the stream starts here
+        StOp a;
+        st_fast_setup(fa, a);
+        if (a.n_rows_wg <= 0) return;
+        LoaderState st{0, 0, 0, (unsigned)ST_RING_SLOTS, 0};
+        loader_op(st, a, smem, wave, 0u, lane, 0);
+        loader_drain(st, smem, wave);
+        return;
+    }
+    // the argument struct, read through the segment pointer laundered BEHIND the barrier: hipcc otherwise hoists op_setup's scalar loads (and the wait between
+    // its batches) to the top of the kernel, in front of the early requests
+    typedef const __attribute__((address_space(4))) MMVQArgs *KArgP;
+    static_assert(alignof(MMVQArgs) == 8, "kernel argument layout: 14 preloaded dwords, then MMVQArgs at byte 56");
+    const __attribute__((address_space(4))) char *kseg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kseg) :: "memory");
+    const __attribute__((address_space(4))) MMVQArgs &ka = *(KArgP)(kseg + 56);
+    StOp a;
+    op_setup<false, false>(ka, a);
+    if (wave == ST_NL && lane == 0) {                           // the packed geometry must describe the run op_setup describes
+        StOp la;
+        st_fast_setup(fa, la);
+        const uint8_t *w_arg = a.W;
+        if (la.n_rows_wg != a.n_rows_wg || (a.n_rows_wg > 0 && (la.W != w_arg || la.b0 != a.b0 || la.total != a.total || la.row_bytes != a.row_bytes || la.ns_pad != a.ns_pad ||
+                                                                 (a.swiglu && la.W1 != a.W1)))) st_timeout(ST_ERR_LOADER);
+    }
+    if (a.n_rows_wg <= 0) return;
+    consumer_dispatch<KB, 1, 0, true>(a, smem, wave - ST_NL, 0u, st_layout(KB), EngIO(), &ea);
+}
+#define MI355_ST_KERNEL_FAST(NAME)                                                                            \
+    template <int KB>                                                                                         \
+    __global__ __launch_bounds__(ST_NT) void NAME(const float *f_nx, const uint8_t *f_wbase, unsigned f_ow0, unsigned f_ow1, unsigned f_ow2, unsigned f_onw, unsigned f_kf, \
+                                                  unsigned f_sg0, unsigned f_sg1, unsigned f_sg2, unsigned f_rb01, unsigned f_rb2, const MMVQArgs ka_by_value) {            \
+        stream_body_fast<KB>(StFast{f_nx, f_wbase, f_ow0, f_ow1, f_ow2, f_onw, f_kf, f_sg0, f_sg1, f_sg2, f_rb01, f_rb2});                                                \
+    }
+MI355_ST_KERNEL_FAST(mmvq_stream_gate_up_fast)
+MI355_ST_KERNEL_FAST(mmvq_stream_head_fast)
+#undef MI355_ST_KERNEL_FAST
+
 // The same body under one kernel NAME per role a decode step launches it in (round 5): a kernel trace (rocprofv3 --kernel-trace --stats) then carries one row
 // per role - Q | K | V, gate | up, ffn_down, the output head - and the achieved bytes per second of each can be worked out from profiles/ alone
 // (tools/assemble_profiles_r5.py); launches of any other shape (attn_output where it is a launch of its own, expert launches, ..) keep the plain name.
@@ -175,6 +262,37 @@ void mmvq_stream_plan(MMVQArgs &a, int max_blocks) {
 static bool g_stream_anyorder = false;
 void mmvq_stream_set_anyorder_for_timing(bool on) { g_stream_anyorder = on; }
 
+// the packed geometry of a planned launch (StFast); kf == 0 (not valid) where a field does not fit - the launch then takes the plain kernel
+static StFast st_fast_pack(const MMVQArgs &a, int blocks) {
+    StFast f{};
+    const bool swiglu = a.epi == EPI_SWIGLU;
+    const int nseg = a.n_seg;                                    // (after mmvq_stream_plan: 1 for a SwiGLU pair)
+    if (a.n_sel > 1 || a.seg[0].expert_sel || a.fuse_mode != 1 || !a.nx || !a.nw || nseg < 1 || nseg > 3 || (a.K >> 8) > 255 || a.out_host) return f;
+    uintptr_t lo = ~(uintptr_t)0, hi = 0;
+    const void *ptrs[4] = {a.seg[0].W, nseg > 1 || swiglu ? (const void *)a.seg[1].W : (const void *)a.seg[0].W, nseg > 2 ? a.seg[2].W : a.seg[0].W, (const void *)a.nw};
+    for (int i = 0; i < 4; i++) { const uintptr_t p = (uintptr_t)ptrs[i]; if (p & 15) return f; lo = p < lo ? p : lo; hi = p > hi ? p : hi; }
+    if (((hi - lo) >> 4) > 0xffffffffull) return f;
+    f.nx = a.nx; f.wbase = reinterpret_cast<const uint8_t *>(lo);
+    f.ow0 = (unsigned)(((uintptr_t)ptrs[0] - lo) >> 4); f.ow1 = (unsigned)(((uintptr_t)ptrs[1] - lo) >> 4);
+    f.ow2 = (unsigned)(((uintptr_t)ptrs[2] - lo) >> 4); f.onw = (unsigned)(((uintptr_t)ptrs[3] - lo) >> 4);
+    unsigned sg[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+    for (int s = 0; s < nseg; s++) {
+        const int nblk = a.seg_block0[s + 1] - a.seg_block0[s];
+        if (nblk <= 0 || a.seg[s].row_bytes > 0xffffu) return f;
+        const int rpb = (a.seg[s].n_rows + nblk - 1) / nblk;     // (op_setup's deal of the rows)
+        const int full = a.seg[s].n_rows / rpb, rem = a.seg[s].n_rows - full * rpb;
+        if (rpb > 2047 || full > 1023 || rem > 2047) return f;
+        sg[s] = (unsigned)rpb | ((unsigned)full << 11) | ((unsigned)rem << 21);
+        rb[s] = (unsigned)a.seg[s].row_bytes;
+    }
+    if (a.seg_block0[0] != 0 || a.seg_block0[1] > 1023 || a.seg_block0[2] > 1023 || blocks != a.seg_block0[3]) return f;
+    if (swiglu && (a.seg[1].row_bytes != a.seg[0].row_bytes || a.seg[1].n_rows != a.seg[0].n_rows)) return f;
+    f.sg0 = sg[0]; f.sg1 = sg[1]; f.sg2 = sg[2]; f.rb01 = rb[0] | (rb[1] << 16); f.rb2 = rb[2];
+    f.kf = (unsigned)(a.K >> 8) | ((unsigned)(nseg > 1 ? a.seg_block0[1] : 0) << 8) | ((unsigned)(nseg > 2 ? a.seg_block0[2] : 0) << 18) | ((unsigned)nseg << 28) |
+           (swiglu ? 1u << 30 : 0u) | (1u << 31);
+    return f;
+}
+
 hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     if (!mmvq_stream_applicable(a)) return hipErrorInvalidValue;
     const int kb = (a.K + 2047) >> 11;
@@ -191,6 +309,10 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         else if (a.fuse_mode == 1 && a.epi == EPI_STORE && a.n_seg == 1 && a.seg[0].n_rows >= 16384) role = ROLE_HEAD;
         else if (a.fuse_mode == 2 && a.epi == EPI_ADD && a.n_seg == 1) role = ROLE_DOWN;
     }
+    // the stream-bound roles start their stream from preloaded geometry where the packing fits (stream_body_fast)
+    static const bool fast_off = getenv("MI355_STREAM_FAST_START") && getenv("MI355_STREAM_FAST_START")[0] == '0';
+    const StFast fp = (role == ROLE_GATE_UP || role == ROLE_HEAD) && !fast_off && !g_stream_anyorder ? st_fast_pack(a, blocks) : StFast{};
+    const bool fast_ok = (fp.kf >> 31) != 0;
 #define STREAM_K(KERNEL, KBV, FZ)                                                                                        \
     do {                                                                                                                 \
         /* (per launch: the attribute is per device, and a process may hold contexts on several) */                      \
@@ -201,10 +323,18 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     } while (0)
     // (one macro per prologue form, so that only the kernels a form can take are instantiated)
 #define STREAM0(KBV) STREAM_K(mmvq_stream_kernel, KBV, 0)
+#define STREAM_FAST(KERNEL, KBV)                                                                                         \
+    do {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<KBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipLaunchKernelGGL((KERNEL<KBV>), dim3(blocks), dim3(ST_NT), lds, st, fp.nx, fp.wbase, fp.ow0, fp.ow1, fp.ow2, fp.onw, fp.kf, fp.sg0, fp.sg1, fp.sg2, fp.rb01, fp.rb2, a); \
+    } while (0)
 #define STREAM1(KBV)                                                                                                     \
     do {                                                                                                                 \
         if (role == ROLE_QKV) STREAM_K(mmvq_stream_qkv, KBV, 1);                                                         \
+        else if (role == ROLE_GATE_UP && fast_ok) STREAM_FAST(mmvq_stream_gate_up_fast, KBV);                            \
         else if (role == ROLE_GATE_UP) STREAM_K(mmvq_stream_gate_up, KBV, 1);                                            \
+        else if (role == ROLE_HEAD && fast_ok) STREAM_FAST(mmvq_stream_head_fast, KBV);                                  \
         else if (role == ROLE_HEAD) STREAM_K(mmvq_stream_head, KBV, 1);                                                  \
         else STREAM_K(mmvq_stream_kernel, KBV, 1);                                                                       \
     } while (0)
@@ -243,6 +373,7 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
 #undef STREAM0
 #undef STREAM1
 #undef STREAM2
+#undef STREAM_FAST
 #undef STREAM_K
     return hipGetLastError();
 }

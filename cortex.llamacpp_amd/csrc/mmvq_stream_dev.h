@@ -255,11 +255,11 @@ template <class T> __device__ __forceinline__ T st_desc_get(const StDescRegs &r,
 }
 // MOE: a mixture-of-experts step's launch (the token's n_sel selected experts share it, kernels.h MMVQArgs::n_sel); the dense kernels are built without it - its
 // seven extra argument words and the dependent read of the expert index cost every launch 0.1 - 0.25 us when they were unconditional (same-box A/B: 577 -> 570 tok/s)
-template <bool MEM = false, bool MOE = false>
-__device__ __forceinline__ void op_setup(const MMVQArgs &ka, StOp &o) {
+template <bool MEM = false, bool MOE = false, class KA = MMVQArgs>
+__device__ __forceinline__ void op_setup(const KA &ka, StOp &o) {
     StDescRegs dr{0u, 0u};
-    if constexpr (MEM) dr = st_desc_load(ka);
-#define U(x) (MEM ? st_desc_get<decltype(st_uni<false>(x))>(dr, (size_t)(reinterpret_cast<const char *>(&(x)) - reinterpret_cast<const char *>(&ka))) : (x))
+    if constexpr (MEM) dr = st_desc_load(*reinterpret_cast<const MMVQArgs *>(&ka));
+#define U(x) (MEM ? st_desc_get<decltype(st_uni<false>(x))>(dr, (size_t)((uintptr_t)&(x) - (uintptr_t)&ka)) : (x))
     const int n_seg = U(ka.n_seg), sb0 = U(ka.seg_block0[0]), sb1 = U(ka.seg_block0[1]), sb2 = U(ka.seg_block0[2]), sb3 = U(ka.seg_block0[3]);
     const int K = U(ka.K), epi = U(ka.epi), nck = U(ka.nck);
     const float neps = U(ka.neps);
@@ -349,9 +349,26 @@ __device__ __forceinline__ void st_store_granule(unsigned long long *g, unsigned
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Round 5 (the stream-bound roles, mmvq_stream.hip stream_body_fast): the consumers' activation / norm-weight requests issued in the kernel's first instructions
+// from PRELOADED kernel arguments (scalars that arrive in SGPRs with the wave), before the argument struct has been read
+template <int KB> struct EarlyAct {
+    static constexpr int NJW = (KB * 8 + ST_NC - 1) / ST_NC;
+    f32x4_t x[NJW], w[NJW];
+};
+template <int KB, int FUSE>
+__device__ __forceinline__ void early_issue(const float *nx, const float *nw, int K, int c, int lane, EarlyAct<KB> &ea) {
+    const int nbt = K >> 8;
+#pragma unroll
+    for (int i = 0; i < EarlyAct<KB>::NJW; i++) {
+        const int b = c + ST_NC * i;
+        const int bc = b < nbt ? b : (nbt > 0 ? nbt - 1 : 0);  // clamped as in consumer_prologue
+        ea.x[i] = *reinterpret_cast<const f32x4_t *>(nx + bc * 256 + lane * 4);
+        if (FUSE == 1) ea.w[i] = *reinterpret_cast<const f32x4_t *>(nw + bc * 256 + lane * 4);
+    }
+}
 // XLDS (engine): the f32 vector is read from LDS (io.xf) once [SY_READY] says it has been gathered; the norm weights are requested before that wait
-template <int KB, int FUSE, bool Q80, bool XLDS = false>
-__device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, const StLayout &lay, int c, int lane, const EngIO &io = EngIO()) {
+template <int KB, int FUSE, bool Q80, bool XLDS = false, bool EARLY = false>
+__device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, const StLayout &lay, int c, int lane, const EngIO &io = EngIO(), const EarlyAct<KB> *ea = nullptr) {
     constexpr int NJW = (KB * 8 + ST_NC - 1) / ST_NC;
     const int nbt = a.K >> 8;
     int8_t *qs = reinterpret_cast<int8_t *>(smem + lay.qs);
@@ -364,6 +381,7 @@ __device__ __forceinline__ void consumer_prologue(const StOp &a, uint8_t *smem, 
     for (int i = 0; i < NJW; i++) {
         const int b = c + ST_NC * i;
         const int bc = b < nbt ? b : nbt - 1;                  // clamped: always a valid address, result unused when b is out of range
+        if (EARLY) { rxv[i] = ea->x[i]; if (FUSE == 1) rwv[i] = ea->w[i]; continue; }     // requested at the top of the kernel (early_issue)
         if (!XLDS) rxv[i] = *reinterpret_cast<const f32x4_t *>(a.nx + bc * 256 + lane * 4);
         if (FUSE == 1) rwv[i] = *reinterpret_cast<const f32x4_t *>(a.nw + bc * 256 + lane * 4);
     }
@@ -555,8 +573,8 @@ __device__ __forceinline__ int loader_planes(const StOp &a, uint8_t *smem, const
 // ENG (decode_engine.hip): 0 = one mat-vec per launch; 1 = the activation arrives through LDS as io says (FUSE 1: f32 vector -> RMSNorm -> Q8_K by the
 // consumers; FUSE 2: f32 vector -> Q8_K; FUSE 3: the Q8_K planes are already in LDS at `lay`), 2 = FUSE 0 as in a launch of its own (planes by DMA); with
 // ENG != 0 the results go where io says.  The arithmetic is the same in every form.
-template <int TYPE, int KB, int FUSE, bool SWIGLU, bool PAIR, int ENG = 0>
-__device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c, unsigned g0, const StLayout &lay, const EngIO &io = EngIO()) {
+template <int TYPE, int KB, int FUSE, bool SWIGLU, bool PAIR, int ENG = 0, bool EARLY = false>
+__device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c, unsigned g0, const StLayout &lay, const EngIO &io = EngIO(), const EarlyAct<KB> *ea = nullptr) {
     using R = Raw<TYPE>;
     constexpr int NP = role_passes<TYPE, KB>(), SBP = role_sbp<TYPE>();   // passes over a row and super-blocks per pass of this type's lane role
     constexpr bool ACT_REGS = NP <= 2;
@@ -582,7 +600,7 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
     if (rsd_regs && lane < n_rows_wg) rsd = a.resid[b0 + lane];
 
     // ---- activation into LDS (fused modes: by the consumers themselves; planes: DMA'd by loader 0 ahead of its first slot)
-    if (FUSE == 1 || FUSE == 2) consumer_prologue<KB, FUSE, act_is_q80(TYPE), ENG == 1>(a, smem, lay, c, lane, io);
+    if (FUSE == 1 || FUSE == 2) consumer_prologue<KB, FUSE, act_is_q80(TYPE), ENG == 1, EARLY>(a, smem, lay, c, lane, io, ea);
     else if (FUSE == 3) {
         ST_SPIN_WHILE(ld_sync(sy + SY_READY) < io.ready_round && ld_sync(sy + SY_ABORT) == 0, 1);
     } else if (ENG == 0) {
@@ -722,13 +740,13 @@ __device__ __forceinline__ void consumer_op(const StOp &a, uint8_t *smem, int c,
 }
 // forms that exist: SwiGLU pairs only with the fused RMSNorm prologue (gate/up), row pairs up to K = 8192, single rows
 // from K = 6144 (mmvq_stream_applicable agrees)
-template <int KB, int FUSE, int ENG = 0>
-__device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, int c, unsigned g0, const StLayout &lay, const EngIO &io = EngIO()) {
+template <int KB, int FUSE, int ENG = 0, bool EARLY = false>
+__device__ __forceinline__ void consumer_dispatch(const StOp &a, uint8_t *smem, int c, unsigned g0, const StLayout &lay, const EngIO &io = EngIO(), const EarlyAct<KB> *ea = nullptr) {
 #define RUN(TY)                                                                                               \
     do {                                                                                                      \
-        if (a.swiglu) { if constexpr (FUSE == 1 || (FUSE == 3 && KB <= 4)) consumer_op<TY, KB, FUSE, true, true, ENG>(a, smem, c, g0, lay, io); } \
-        else if (a.pair) { if constexpr (KB <= 4 || ENG == 0) consumer_op<TY, KB, FUSE, false, true, ENG>(a, smem, c, g0, lay, io); } \
-        else { if constexpr (KB >= 3) consumer_op<TY, KB, FUSE, false, false, ENG>(a, smem, c, g0, lay, io); } \
+        if (a.swiglu) { if constexpr (FUSE == 1 || (FUSE == 3 && KB <= 4)) consumer_op<TY, KB, FUSE, true, true, ENG, EARLY>(a, smem, c, g0, lay, io, ea); } \
+        else if (a.pair) { if constexpr (KB <= 4 || ENG == 0) consumer_op<TY, KB, FUSE, false, true, ENG, EARLY>(a, smem, c, g0, lay, io, ea); } \
+        else { if constexpr (KB >= 3) consumer_op<TY, KB, FUSE, false, false, ENG, EARLY>(a, smem, c, g0, lay, io, ea); } \
     } while (0)
     switch (a.type) {
         case T_Q4_K: RUN(T_Q4_K); break;
