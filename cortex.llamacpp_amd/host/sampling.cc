@@ -155,12 +155,13 @@ int32_t Sampler::sample_chain(const float *logits, int n_vocab) {
         top_k_pass(front_k(n_vocab), c);
         return finish(c);
     }
-    std::uniform_real_distribution<double> u01(0.0, 1.0);
+    // the draw itself is the standard library's std::discrete_distribution over the final candidates' probabilities on a std::mt19937 seeded with the request's
+    // seed - the class and generator llama_sampler_dist uses upstream (a draw consumes two 32-bit outputs: generate_canonical<double, 53>)
     auto draw = [&](const std::vector<TokenProb> &cc) -> size_t {
-        const double r = u01(rng_);
-        double cum = 0.0;
-        for (size_t i = 0; i < cc.size(); i++) { cum += cc[i].p; if (r < cum) return i; }
-        return cc.size() - 1;
+        probs_.resize(cc.size());
+        for (size_t i = 0; i < cc.size(); i++) probs_[i] = cc[i].p;
+        std::discrete_distribution<int> dist(probs_.begin(), probs_.end());
+        return (size_t)dist(rng_);
     };
     if (p_.mirostat == 1 || p_.mirostat == 2) {
         // temperature over the whole vocabulary, then the mirostat truncation (no top_k / top_p / min_p in this chain)
@@ -246,12 +247,13 @@ int32_t Sampler::finish(std::vector<TokenProb> &c) {
         else cand_.push_back({best, 1.0f});
         return best;
     }
-    std::uniform_real_distribution<double> u01(0.0, 1.0);
+    // the draw itself is the standard library's std::discrete_distribution over the final candidates' probabilities on a std::mt19937 seeded with the request's
+    // seed - the class and generator llama_sampler_dist uses upstream (a draw consumes two 32-bit outputs: generate_canonical<double, 53>)
     auto draw = [&](const std::vector<TokenProb> &cc) -> size_t {
-        const double r = u01(rng_);
-        double cum = 0.0;
-        for (size_t i = 0; i < cc.size(); i++) { cum += cc[i].p; if (r < cum) return i; }
-        return cc.size() - 1;
+        probs_.resize(cc.size());
+        for (size_t i = 0; i < cc.size(); i++) probs_[i] = cc[i].p;
+        std::discrete_distribution<int> dist(probs_.begin(), probs_.end());
+        return (size_t)dist(rng_);
     };
     softmax_sorted(c);
     // typical_p

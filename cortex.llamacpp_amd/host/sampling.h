@@ -77,6 +77,7 @@ class Sampler {
     std::vector<int32_t> prev_;     // ring of accepted tokens (penalty window)
     std::vector<TokenProb> cand_;
     std::mt19937 rng_;
+    std::vector<float> probs_;       // (scratch of the draw)
     float mu_ = 0.0f;               // mirostat: running surprise target (starts at 2 tau)
 };
 

@@ -259,6 +259,22 @@ static void test_sampler_mirostat_dynatemp() {
         Sampler d2(p);
         for (int i = 0; i < 20; i++) CHECK(d2.sample(l3.data(), 50) == 7);
     }
+    {   // the seeded draw IS std::discrete_distribution over the candidates' probabilities on std::mt19937(seed) - what llama_sampler_dist does: an
+        // independent generator fed the sampler's own candidate lists must name the same tokens, draw after draw
+        std::vector<float> l4(64);
+        for (int i = 0; i < 64; i++) l4[i] = 0.05f * (float)((i * 37) % 64);
+        SamplingParams p; p.temp = 0.9f; p.top_k = 12; p.top_p = 0.95f; p.min_p = 0.01f; p.seed = 4242;
+        Sampler s(p);
+        std::mt19937 ref(4242);
+        for (int i = 0; i < 64; i++) {
+            const int tok = s.sample(l4.data(), 64);
+            const auto c = s.candidates();
+            std::vector<float> pr;
+            for (const auto &e : c) pr.push_back(e.p);
+            std::discrete_distribution<int> dist(pr.begin(), pr.end());
+            CHECK(c[(size_t)dist(ref)].tok == tok);
+        }
+    }
     {   // repeat_last_n = -1: the window is the context, not "off"
         std::vector<float> l4(100, 0.0f); l4[17] = 5.0f; l4[42] = 4.9f;
         SamplingParams p; p.temp = 0.0f; p.penalty_repeat = 2.0f; p.penalty_last_n = -1; p.penalty_n_ctx = 256;
