@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
 #include "kernels.h"
 #include "quant_dev.h"
 
@@ -880,7 +881,146 @@ static hipError_t launch_fa(const AttnArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- opt-in: an f16 cache read with the arithmetic of the reference's CPU path (ggml_compute_forward_flash_attn_ext_f16 as oracle/oq_ops.c restates it;
+// the reference's default cache is f16: /root/reference/src/llama_engine.cc:628-637).  That path visits the visible cells ONE AT A TIME in cell order: the score
+// is a double-precision sum of the 128 f16 x f16 products in element order, the online softmax rescales the accumulator whenever the running maximum moves, and
+// V is accumulated in FP16 - every `acc += v * p` and every rescale rounds to half precision.  The kernels above accumulate V in f32 over chunks in parallel,
+// so their f16-cache output sits ~1e-2 from the CPU's (the noise of 4096 half-precision roundings), while matching its f32-accumulating restatement to 1e-6.
+// This kernel reproduces the CPU sequence itself; it is three phases per 2048-cell stretch of the cache, one workgroup per (head, token):
+//   1. scores: a thread owns whole cells - the same double accumulation in the same element order as the CPU, hence the same bits;
+//   2. the online-softmax factors of every cell (ms: what the accumulator is scaled by, vs: the weight of the cell's V row) by a prefix maximum over the
+//      visible cells - they depend on the scores only, not on the accumulator;
+//   3. the accumulation proper, sequential in the cell index, one thread per output element: acc = half(float(acc) * ms); acc = half(float(acc) + v * vs),
+//      V staged through LDS 64 cells at a time.
+// What can still differ from the CPU is expf (the device's against the host libm's, both within an ulp of f32): a flip of the last f32 bit of a weight moves a
+// half-precision rounding once in ~10^4 operations.  Cost: phase 3 is a dependent chain of two roundings per cell - 27 us per layer at 4096 cells, against 13
+// for the parallel kernels - so this is a parity mode (MI355_FA_V_ACC=f16 or the debug option "fa_v_acc_f16"), not the default.
+static int g_fa_v16 = -1;
+void set_fa_v_acc_f16(int on) { g_fa_v16 = on; }
+bool fa_v_acc_f16_enabled() {
+    static const bool env = getenv("MI355_FA_V_ACC") && !strcmp(getenv("MI355_FA_V_ACC"), "f16");
+    return g_fa_v16 >= 0 ? g_fa_v16 != 0 : env;
+}
+constexpr int V16_CHUNK = 2048;
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_v16_kernel(AttnArgs a) {
+    __shared__ float s_vs[V16_CHUNK];            // phase 1: score (NaN = not visible); phase 2 on: vs
+    __shared__ float s_ms[V16_CHUNK];            // ms
+    __shared__ float s_tmax[256];
+    __shared__ __attribute__((aligned(16))) uint16_t s_q[D];
+    __shared__ __attribute__((aligned(16))) uint16_t s_v[64 * D];     // phase 3: 64 cells of this kv head's V rows
+    const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const int g = h / (a.H / a.G);
+    int n_kv = *a.n_kv_dev;
+    if (n_kv > a.n_kv_max) n_kv = a.n_kv_max;
+    const int tpos = a.tok_pos[t], tseq = a.tok_seq[t];
+    if (tid < D) s_q[tid] = f2h(a.q[((size_t)t * a.H + h) * D + tid]);      // the query row in K's vec_dot type: f16, round to nearest even
+    __syncthreads();
+    const uint16_t *kbase = reinterpret_cast<const uint16_t *>(a.kv.k) + (size_t)g * a.n_ctx * D;
+    const uint16_t *vbase = reinterpret_cast<const uint16_t *>(a.kv.v) + (size_t)g * a.n_ctx * D;
+    float M = -INFINITY, S = 0.0f;               // (every thread carries them: the same values everywhere)
+    uint16_t acc = 0;                            // thread d < D: element d of the accumulator, as fp16 bits
+    for (int c0 = 0; c0 < n_kv; c0 += V16_CHUNK) {
+        const int nc = min(V16_CHUNK, n_kv - c0);
+        // ---- 1. scores
+        for (int i = tid; i < nc; i += 256) {
+            const int c = c0 + i;
+            const int cp = a.cell_pos[c];
+            const bool vis = cp >= 0 && cp <= tpos && ((a.cell_seq[c] >> tseq) & 1ull);
+            float sc = __builtin_nanf("");
+            if (vis) {
+                const uint4 *kr = reinterpret_cast<const uint4 *>(kbase + (size_t)c * D);
+                double sum = 0.0;
+#pragma unroll 4
+                for (int e8 = 0; e8 < D / 8; e8++) {
+                    const uint4 kv = kr[e8];
+                    const uint4 qv = *reinterpret_cast<const uint4 *>(s_q + e8 * 8);
+                    const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        sum += (double)(h2f((uint16_t)(kw[w] & 0xffffu)) * h2f((uint16_t)(qw[w] & 0xffffu)));
+                        sum += (double)(h2f((uint16_t)(kw[w] >> 16)) * h2f((uint16_t)(qw[w] >> 16)));
+                    }
+                }
+                sc = (float)sum * a.scale;
+            }
+            s_vs[i] = sc;
+        }
+        __syncthreads();
+        // ---- 2. softmax factors.  Thread tid owns cells [tid * per, +per): its maximum, the maxima before it, then its cells in order
+        const int per = (nc + 255) / 256;
+        const int i0 = min(tid * per, nc), i1 = min(i0 + per, nc);
+        float lm = -INFINITY;
+        for (int i = i0; i < i1; i++) { const float sc = s_vs[i]; if (sc == sc) lm = fmaxf(lm, sc); }
+        s_tmax[tid] = lm;
+        __syncthreads();
+        float Mp = M;                            // maximum over the visible cells before this thread's first
+        for (int j = 0; j < tid; j++) Mp = fmaxf(Mp, s_tmax[j]);
+        float Mall = M;
+        for (int j = 0; j < 256; j++) Mall = fmaxf(Mall, s_tmax[j]);
+        for (int i = i0; i < i1; i++) {
+            const float sc = s_vs[i];
+            float ms = 1.0f, vs = 0.0f;                             // (not visible: leaves the accumulator and the sum as they are)
+            if (sc == sc) {
+                if (sc > Mp) { ms = expf(Mp - sc); vs = 1.0f; Mp = sc; }
+                else { ms = 1.0f; vs = expf(sc - Mp); }
+            }
+            s_ms[i] = ms; s_vs[i] = vs;
+        }
+        M = Mall;
+        __syncthreads();
+        // ---- 3. the accumulation, in cell order.  V reaches LDS 64 cells at a time (all 256 threads, 16-byte loads; the next 64 cells are in flight while
+        // the chain works through the current ones: a chain that waited for its own 2-byte loads took 2 ms per layer at 4000 cells)
+        constexpr int SUB = 64, NV4 = SUB * D * 2 / 16 / 256;       // uint4 per thread and sub-chunk (D = 128: 4, D = 64: 2)
+        const uint4 *vg = reinterpret_cast<const uint4 *>(vbase + (size_t)c0 * D);
+        const int n_v4 = nc * D * 2 / 16;                           // uint4 of this stretch
+        uint4 stage[NV4];
+#pragma unroll
+        for (int k = 0; k < NV4; k++) { const int j = k * 256 + tid; stage[k] = j < n_v4 ? vg[j] : uint4{0, 0, 0, 0}; }
+        for (int i0s = 0; i0s < nc; i0s += SUB) {
+#pragma unroll
+            for (int k = 0; k < NV4; k++) reinterpret_cast<uint4 *>(s_v)[k * 256 + tid] = stage[k];
+            __syncthreads();
+            if (i0s + SUB < nc) {
+                const int base = (i0s + SUB) * D * 2 / 16;
+#pragma unroll
+                for (int k = 0; k < NV4; k++) { const int j = base + k * 256 + tid; stage[k] = j < n_v4 ? vg[j] : uint4{0, 0, 0, 0}; }
+            }
+            if (tid < D) {
+                const int ne = min(SUB, nc - i0s);
+                // (no branch in the chain, so that the LDS reads of the next cells are issued ahead of it: a cell that is not visible has ms = 1, vs = 0 and
+                // contributes +0 - x * 1 and x + 0 are x itself)
+#pragma unroll 8
+                for (int u = 0; u < ne; u++) {
+                    const float ms = s_ms[i0s + u], vs = s_vs[i0s + u];
+                    const float vv = h2f(s_v[u * D + tid]);
+                    acc = f2h(h2f(acc) * ms);                        // (ms == 1: the value itself)
+                    const float prod = vs != 0.0f ? vv * vs : 0.0f;  // (a hole may hold anything, Inf included)
+                    acc = f2h(h2f(acc) + prod);
+                    const float Sm = S * ms;
+                    S = Sm + vs;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < D) {
+        const float inv = 1.0f / S;
+        a.out[((size_t)t * a.H + h) * D + tid] = h2f(acc) * inv;
+    }
+}
+static hipError_t launch_fa_v16(const AttnArgs &a, hipStream_t st) {
+    if (a.type_k != T_F16 || a.type_v != T_F16 || (a.D != 128 && a.D != 64) || a.H % a.G) return hipErrorInvalidValue;
+    if (a.D == 128) hipLaunchKernelGGL(flash_attn_v16_kernel<128>, dim3(a.H, a.T), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(flash_attn_v16_kernel<64>, dim3(a.H, a.T), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.out_q) return launch_quantize(a.out, a.H * a.D, a.T, *a.out_q, a.out_q8k, a.out_q80, st, a.out_bh, a.out_bl);
+    return hipSuccess;
+}
+
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st) {
+    if (fa_v_acc_f16_enabled() && a.type_k == T_F16 && a.type_v == T_F16) return launch_fa_v16(a, st);
     static const bool mfma_prefill = !(getenv("MI355_ATTN_PREFILL_MFMA") && getenv("MI355_ATTN_PREFILL_MFMA")[0] == '0');
     if (mfma_prefill && flash_attn_prefill_applicable(a)) return launch_flash_attn_prefill(a, st);   // prompt processing: matrix cores
     const int R = a.H / a.G;

@@ -735,6 +735,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "attn_out_fused")) { set_attn_out_fused(value); return MI355_OK; }     // (contexts created afterwards)
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
+    if (!strcmp(name, "fa_v_acc_f16")) { set_fa_v_acc_f16(value); return MI355_OK; }              // f16 cache: the CPU path's fp16 V accumulation (parity mode)
     if (!strcmp(name, "raise_stream_error")) { debug_raise_stream_error((unsigned)value); return MI355_OK; }   // tests: what a timed-out in-kernel wait does
     if (!strcmp(name, "tp_null_group")) { tp_set_null_group(0, value); return MI355_OK; }
     fail(std::string("unknown option ") + name);

@@ -292,6 +292,9 @@ struct AttnArgs {
     int8_t *out_bh = nullptr, *out_bl = nullptr;   // nullable (with out_q, Q8_K): the block sums also as the int8 planes the MFMA kernels take (launch_mmq_prep's)
 };
 hipError_t launch_flash_attn(const AttnArgs &a, hipStream_t st);
+// parity mode for an f16 K / V cache: the reference CPU path's cell-by-cell arithmetic with V accumulated in fp16 (attn.hip); 1 / 0, -1 = MI355_FA_V_ACC=f16
+void set_fa_v_acc_f16(int on);
+bool fa_v_acc_f16_enabled();
 // prompt processing on the matrix cores (attn_prefill.hip): D = 128, q8_0 K / V, T >= 32; q already rotated
 bool flash_attn_prefill_applicable(const AttnArgs &a);
 int flash_attn_prefill_splits(int T, int H, int G, int D, int n_kv_max);

@@ -1359,7 +1359,9 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         const bool fast_store = kv_store_fast_applicable(G, D, cp.type_k, cp.type_v, ra);
         static const int attn_mode = getenv("MI355_ATTN_MODE") ? atoi(getenv("MI355_ATTN_MODE")) : 2;
         bool fused_step = false, attn_out_done = false;
-        const bool decode_attn = flash_attn_decode_applicable(aa, ra);
+        // (parity mode for an f16 cache: the generic launch below dispatches to the cell-by-cell kernel with fp16 V accumulation)
+        const bool v16 = fa_v_acc_f16_enabled() && cp.type_k == T_F16 && cp.type_v == T_F16;
+        const bool decode_attn = !v16 && flash_attn_decode_applicable(aa, ra);
         if (decode_attn) {
             aa.splits = flash_attn_decode_splits(n_kv_max);
             if (chunk_lmax_ > 0) {                             // per-token chunk lists (decode_ubatch): batched steps, or regions in use

@@ -166,6 +166,46 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
         oq.set_fa_v_acc_f32(0)
 
 
+@pytest.mark.parametrize("cfg,ftype,n_prompt", [("tiny-d128", "q4_k_m", 40), ("tiny-8b-2l", "q4_k_m", 70), ("tiny-tl-2l", "q8_0", 21), ("tiny-d128-mha", "q5_k_m", 300)])
+def test_f16_cache_parity_mode_follows_the_stock_cpu_path(be, pkg, tmp_models, cfg, ftype, n_prompt):
+    """The reference's default cache is f16 (llama_engine.cc:628-637) and its CPU path accumulates V in FP16, cell by cell.  Every other f16-cache test compares
+    with the oracle's f32-accumulating restatement (tight) and with the stock mode loosely; this one switches the HIP side to the cell-by-cell kernel (option
+    "fa_v_acc_f16", attn.hip flash_attn_v16_kernel) and compares with the oracle in its STOCK mode: the prompt's logits and 12 teacher-forced steps, through
+    the context API (prompt batches and graph-captured single-token steps both take the kernel).  The tight evidence for the kernel is per op
+    (test_flash_attn_f16_cache_parity_mode: <= 8e-5 where the parallel kernels sit at 2e-3 .. 4e-3): end to end, an attention output that is off by 1e-5 still
+    flips Q8_K codes of the attn_output input, and a flip moves these tiny models' logits by ~1e-2 whatever its cause - so the logits are held to the flip
+    tolerance and must be no further from the stock CPU path than the default kernels' (measured medians 0.0075 - 0.011 against 0.012 - 0.013)."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    oq.set_fa_v_acc_f32(0)
+    prompt = np.random.default_rng(11).integers(0, 512, n_prompt)
+
+    def run(mode):
+        be.set_option("fa_v_acc_f16", mode)
+        try:
+            m, c, om, oc = open_pair(pkg, path, 512, "f16")
+            errs = []
+            c.decode(prompt, np.arange(n_prompt))
+            ref = oc.decode(prompt, np.arange(n_prompt))[0]
+            errs.append(rel_err(c.logits(), ref))
+            tok = int(ref.argmax())
+            for step in range(12):
+                c.decode([tok], [n_prompt + step])
+                r = oc.decode([tok], [n_prompt + step])[0]
+                errs.append(rel_err(c.logits(), r))
+                tok = int(r.argmax())
+            c.close(); m.close(); oc.close(); om.close()
+            return errs
+        finally:
+            be.set_option("fa_v_acc_f16", -1)
+    e_par = run(1)
+    e_def = run(0)
+    if os.environ.get("MI355_TEST_RECORD_FLIPS"):
+        with open(os.environ["MI355_TEST_RECORD_FLIPS"], "a") as f:
+            f.write(f"f16 parity mode {cfg} {ftype} {n_prompt}: parity max {max(e_par):.3g} median {float(np.median(e_par)):.3g}   default max {max(e_def):.3g} median {float(np.median(e_def)):.3g}\n")
+    assert max(e_par) <= FLIP_TOL and max(e_def) <= FLIP_TOL, (e_par, e_def)
+    assert float(np.median(e_par)) <= 1.1 * float(np.median(e_def)), (e_par, e_def)
+
+
 @pytest.mark.parametrize("cfg,ftype,kv,n_prompt,ubatch", [("tiny-d128", "q4_k_m", "q8_0", 300, 512), ("tiny-d128-mha", "q5_k_m", "f16", 300, 512),
                                                           ("tiny-g8", "q4_k_m", "q8_0", 330, 512), ("tiny-d128", "q4_k_m", "q8_0", 300, 128),
                                                           ("tiny-d128-mha", "q4_k_m", "q8_0", 200, 64),
