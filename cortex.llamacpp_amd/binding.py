@@ -499,6 +499,29 @@ class Context:
             raise MI355Error(f"mi355_decode failed ({rc}): {_err(self.lib)}")
         return rc
 
+    def decode_embd(self, embd, pos, seq=None, logits=None) -> int:
+        """llama_decode on a batch of embedding rows [n][n_embd] (llama_batch.embd: how image embeddings reach the model)."""
+        embd = np.ascontiguousarray(embd, np.float32)
+        pos = np.asarray(pos, np.int32).reshape(-1)
+        n = pos.size
+        if embd.shape != (n, self.model.n_embd):
+            raise ValueError(f"embd must be [{n}][{self.model.n_embd}]")
+        b = self.lib.mi355_batch_init(n, self.model.n_embd, 1)
+        try:
+            b.n_tokens = n
+            C.memmove(b.embd, embd.ctypes.data, embd.nbytes)
+            C.memmove(b.pos, pos.ctypes.data, 4 * n)
+            for i in range(n):
+                b.n_seq_id[i] = 1
+                b.seq_id[i][0] = 0 if seq is None else int(seq[i] if np.ndim(seq) else seq)
+                b.logits[i] = (1 if i == n - 1 else 0) if logits is None else int(bool(logits[i]))
+            rc = self.lib.mi355_decode(self.h, b)
+        finally:
+            self.lib.mi355_batch_free(b)
+        if rc < 0:
+            raise MI355Error(f"mi355_decode failed ({rc}): {_err(self.lib)}")
+        return rc
+
     def logits(self, i: int = -1) -> np.ndarray:
         p = self.lib.mi355_get_logits_ith(self.h, i)
         if not p:

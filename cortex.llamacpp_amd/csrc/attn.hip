@@ -881,7 +881,7 @@ static hipError_t launch_fa(const AttnArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---- opt-in: an f16 cache read with the arithmetic of the reference's CPU path (ggml_compute_forward_flash_attn_ext_f16 as oracle/oq_ops.c restates it;
+// ---- opt-in: an f16 cache read with the arithmetic of the reference's CPU path (ggml_compute_forward_flash_attn_ext_f16;
 // the reference's default cache is f16: /root/reference/src/llama_engine.cc:628-637).  That path visits the visible cells ONE AT A TIME in cell order: the score
 // is a double-precision sum of the 128 f16 x f16 products in element order, the online softmax rescales the accumulator whenever the running maximum moves, and
 // V is accumulated in FP16 - every `acc += v * p` and every rescale rounds to half precision.  The kernels above accumulate V in f32 over chunks in parallel,

@@ -181,8 +181,9 @@ uint64_t mi355_context_device_bytes(const mi355_context *ctx) { return ctx->c->d
 
 mi355_batch mi355_batch_init(int32_t n_tokens, int32_t embd, int32_t n_seq_max) {
     mi355_batch b{};
-    (void)embd;
-    b.token = (mi355_token *)calloc((size_t)n_tokens, sizeof(mi355_token));
+    // llama_batch_init: embd != 0 allocates n_tokens x embd floats and NO token array
+    if (embd > 0) b.embd = (float *)calloc((size_t)n_tokens * (size_t)embd, sizeof(float));
+    else b.token = (mi355_token *)calloc((size_t)n_tokens, sizeof(mi355_token));
     b.pos = (mi355_pos *)calloc((size_t)n_tokens, sizeof(mi355_pos));
     b.n_seq_id = (int32_t *)calloc((size_t)n_tokens, sizeof(int32_t));
     b.seq_id = (mi355_seq_id **)calloc((size_t)n_tokens + 1, sizeof(mi355_seq_id *));
@@ -192,7 +193,7 @@ mi355_batch mi355_batch_init(int32_t n_tokens, int32_t embd, int32_t n_seq_max) 
     return b;
 }
 void mi355_batch_free(mi355_batch b) {
-    free(b.token); free(b.pos); free(b.n_seq_id); free(b.logits);
+    free(b.token); free(b.embd); free(b.pos); free(b.n_seq_id); free(b.logits);
     if (b.seq_id) {
         for (int i = 0; b.seq_id[i]; i++) free(b.seq_id[i]);
         free(b.seq_id);
@@ -202,7 +203,8 @@ void mi355_batch_free(mi355_batch b) {
 int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
     if (!ctx) return MI355_ERR_ARG;
     MI355_GUARD(return MI355_ERR_ARG,
-        const int rc = ctx->c->decode(batch.n_tokens, batch.token, batch.pos, batch.n_seq_id, batch.seq_id, batch.logits);
+        // (llama_batch: token ids, or - image embeddings - rows of n_embd floats in embd with token == NULL)
+        const int rc = ctx->c->decode(batch.n_tokens, batch.embd ? nullptr : batch.token, batch.pos, batch.n_seq_id, batch.seq_id, batch.logits, batch.embd);
         if (rc < 0) fail(ctx->c->last_error);
         return rc;
     )

@@ -1290,7 +1290,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
     att_splits_ = flash_attn_pick_splits(T, G, n_kv_max);
 
     // single-token step on a dense K-quant model: all layers in one launch (decode_mega.hip)
-    bool mega = T == 1 && !profile_ && !debug_taps_ && mega_prepare();
+    bool mega = T == 1 && !profile_ && !debug_taps_ && !ub_embd_ && mega_prepare();
     AttnArgs ma{};
     if (mega) {
         ma.q = q_; ma.out = att_; ma.type_k = cp.type_k; ma.type_v = cp.type_v;
@@ -1307,11 +1307,13 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         mega = flash_attn_decode_fused_applicable(ma, ra);      // (more than 64 chunks: the per-launch path merges them)
     }
     // ... or one persistent launch per layer for the mat-vecs between two attention calls (decode_engine.hip)
-    const bool engine = T == 1 && !mega && !profile_ && !debug_taps_ && engine_prepare();
+    const bool engine = T == 1 && !mega && !profile_ && !debug_taps_ && !ub_embd_ && engine_prepare();
     last_layers_engine_ = engine;
     // cos / sin table, cell metadata and the tokens' embedding rows: one launch
     HIP_TRY(launch_step_setup_embed(d_pos_, T, ra, rope_cs_, d_cell_pos_, d_cell_seq_, d_cell_, d_seqmask_, mega ? d_mega_sync_ : nullptr,
                                     d_step_serial_, model->tok_embd.type, model->tok_embd.data, E, d_tok_, x_, stream_));
+    // an embeddings batch: the caller's rows take the place of the looked-up ones (never inside a captured graph: decode_ubatch)
+    if (ub_embd_) HIP_TRY(hipMemcpyAsync(x_, ub_embd_, (size_t)T * E * sizeof(float), hipMemcpyHostToDevice, stream_));
     prof_mark("embed");
     last_layers_mega_ = mega;
     if (mega)
@@ -1836,8 +1838,8 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     if (stage_event_) (void)hipEventRecord(stage_event_, stream_);
 
     const int V = model->hp.n_vocab;
-    if (n == 1 && !model->hp.encoder) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
-    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled && moe_forced_T_ == 0;
+    if (n == 1 && !model->hp.encoder && !ub_embd_) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
+    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled && moe_forced_T_ == 0 && !ub_embd_;
     hipError_t e = hipSuccess;
     if (graph_ok) {
         // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
@@ -1899,8 +1901,17 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
 }
 
 int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, const int32_t *n_seq_id, int32_t *const *seq_id,
-                    const int8_t *logits_flags) {
+                    const int8_t *logits_flags, const float *embd) {
     if (n_tokens <= 0) { last_error = "empty batch"; return -1; }
+    // llama_batch.embd: the rows ARE the layer stack's input (the image embeddings of a LLaVA request, llama_server_context.cc:1093-1107); no token ids then
+    std::vector<int32_t> no_tokens;
+    if (embd) {
+        if (model->hp.encoder) { last_error = "an encoder model takes token ids, not embeddings"; return -1; }
+        if (tokens) { last_error = "a batch carries token ids or embeddings, not both"; return -1; }
+        if (!pos) { last_error = "an embeddings batch needs positions"; return -1; }
+        no_tokens.assign((size_t)n_tokens, 0);
+        tokens = no_tokens.data();
+    } else if (!tokens) { last_error = "batch without tokens"; return -1; }
     if (hipSetDevice(model->device) != hipSuccess) return -1;
     const HParams &hp = model->hp;
     // bidirectional attention: every token of a sequence must see all the others, so a batch is never cut into micro-batches (llama.cpp asks the same: n_ubatch >= n_tokens)
@@ -1962,7 +1973,9 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
     int out_base = 0;
     for (int i0 = 0; i0 < n_tokens; i0 += (int)cp.n_ubatch) {
         const int n = std::min((int)cp.n_ubatch, n_tokens - i0);
+        ub_embd_ = embd ? embd + (size_t)i0 * (size_t)hp.n_embd : nullptr;
         const int rc = decode_ubatch(n, tokens + i0, pos + i0, seq.data() + i0, mask.data() + i0, flags.data() + i0, out_base);
+        ub_embd_ = nullptr;
         if (rc != 0) {
             cells_ = saved; head_ = saved_head; meta_dirty_ = true; region_next_.clear();
             return rc;

@@ -119,8 +119,9 @@ class Context {
     bool init(std::string &err);
 
     // llama_decode semantics: 0 ok, 1 no KV slot, <0 error
+    // embd != nullptr: rows of n_embd floats in place of token ids (llama_batch.embd; tokens must then be nullptr)
     int decode(int n_tokens, const int32_t *tokens, const int32_t *pos, const int32_t *n_seq_id, int32_t *const *seq_id,
-               const int8_t *logits_flags);
+               const int8_t *logits_flags, const float *embd = nullptr);
     float *logits_ith(int i);
     // llama_get_embeddings_ith: the final-norm hidden state of batch row i (n_embd floats, host memory); rows are
     // produced for the flagged tokens of the last decode while embeddings_enabled is set (then no logits are computed)
@@ -155,6 +156,7 @@ class Context {
 
   private:
     struct Bufs;
+    const float *ub_embd_ = nullptr;   // host rows of the micro-batch being decoded when the batch carries embeddings
     int decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, const int32_t *seq, const uint64_t *seqmask,
                       const int8_t *flags, int out_base);
     int find_slot(int n);

@@ -124,7 +124,8 @@ MI355_API uint64_t mi355_context_device_bytes(const mi355_context *ctx); /* KV +
 typedef struct mi355_batch {
     int32_t        n_tokens;
     mi355_token   *token;     /* [n_tokens] */
-    float         *embd;      /* unused (NULL) on this path */
+    float         *embd;      /* NULL, or [n_tokens][n_embd] rows that take the place of the token embeddings (then token is NULL): how the
+                               * reference feeds image embeddings to the model (llava_embd_batch, llama_server_context.cc:1093-1107) */
     mi355_pos     *pos;       /* [n_tokens] */
     int32_t       *n_seq_id;  /* [n_tokens] */
     mi355_seq_id **seq_id;    /* [n_tokens][n_seq_id] */

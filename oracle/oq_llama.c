@@ -526,6 +526,19 @@ static int bert_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, con
     return 0;
 }
 
+/* llama_decode on a batch whose rows are embeddings (llama_batch.embd: the image embeddings of a LLaVA request,
+ * /root/reference/src/llama_server_context.cc:1093-1107): the rows replace the token-embedding lookup, everything else is oq_decode */
+static const float *g_embd_rows = NULL;
+int oq_decode_embd(oq_ctx *c, const float *embd, const int32_t *pos, const int32_t *seq, const int8_t *want, int n, float *logits_out) {
+    if (c->m->is_bert || !embd) return -1;
+    int32_t *zeros = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    g_embd_rows = embd;
+    const int rc = oq_decode(c, zeros, pos, seq, want, n, logits_out);
+    g_embd_rows = NULL;
+    free(zeros);
+    return rc;
+}
+
 int oq_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_t *seq,
               const int8_t *want, int n, float *logits_out) {
     const oq_model *m = c->m;
@@ -556,7 +569,8 @@ int oq_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_
     float *att = (float *)malloc(sizeof(float) * (size_t)D * n);
     float *tmp = (float *)malloc(sizeof(float) * (size_t)D * n);
     int32_t *vis = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->n_ctx);
-    oq_get_rows(m->tok_embd->type, m->tok_embd->data, D, tokens, n, x);
+    if (g_embd_rows) memcpy(x, g_embd_rows, sizeof(float) * (size_t)D * n);
+    else oq_get_rows(m->tok_embd->type, m->tok_embd->data, D, tokens, n, x);
     const float kq_scale = 1.0f / sqrtf((float)hd);
 
     for (int il = 0; il < m->n_layer; il++) {

@@ -135,6 +135,9 @@ void    oq_ctx_free(oq_ctx *c);
  * for tokens with want_logits[i] != 0 (NULL: last only), packed in order.  0 ok, 1 no KV space. */
 int     oq_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_t *seq,
                   const int8_t *want_logits, int n, float *logits_out);
+/* the same with embedding rows [n][n_embd] in place of token ids (llama_batch.embd) */
+int     oq_decode_embd(oq_ctx *c, const float *embd, const int32_t *pos, const int32_t *seq,
+                       const int8_t *want_logits, int n, float *logits_out);
 void    oq_kv_clear(oq_ctx *c);
 int     oq_kv_seq_rm(oq_ctx *c, int seq, int p0, int p1);
 void    oq_kv_seq_cp(oq_ctx *c, int seq_src, int seq_dst, int p0, int p1);

@@ -78,6 +78,8 @@ def lib():
         L.oq_ctx_free.argtypes = [vp]
         L.oq_decode.restype = i32
         L.oq_decode.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+        L.oq_decode_embd.restype = i32
+        L.oq_decode_embd.argtypes = [vp, vp, vp, vp, vp, i32, vp]
         L.oq_kv_clear.argtypes = [vp]
         L.oq_kv_seq_rm.restype = i32
         L.oq_kv_seq_rm.argtypes = [vp, i32, i32, i32]
@@ -267,6 +269,21 @@ class OracleContext:
                              None if want is None else _p(want), n, _p(out))
         if rc != 0:
             raise RuntimeError(f"oracle decode rc={rc}")
+        return out
+
+    def decode_embd(self, embd, pos, seq=None, want_logits=None) -> np.ndarray:
+        embd = np.ascontiguousarray(embd, dtype=np.float32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        n = pos.size
+        assert embd.shape == (n, self.model.n_embd)
+        seq_a = None if seq is None else np.ascontiguousarray(seq, dtype=np.int32)
+        want = None if want_logits is None else np.ascontiguousarray(want_logits, dtype=np.int8)
+        n_out = 1 if want is None else int((want != 0).sum())
+        out = np.empty((n_out, self.model.n_vocab), dtype=np.float32)
+        rc = lib().oq_decode_embd(self.h, _p(embd), _p(pos), None if seq_a is None else _p(seq_a),
+                                  None if want is None else _p(want), n, _p(out))
+        if rc != 0:
+            raise RuntimeError(f"oracle decode_embd rc={rc}")
         return out
 
     def layer_out(self, il: int, n_tokens: int) -> np.ndarray:

@@ -166,6 +166,46 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
         oq.set_fa_v_acc_f32(0)
 
 
+@pytest.mark.parametrize("cfg,ftype,kv,n_img,ubatch", [("tiny-d128", "q4_k_m", "q8_0", 70, 512), ("tiny-8b-2l", "q4_k_m", "q8_0", 300, 128), ("tiny-gqa4", "q5_k_m", "f16", 33, 512),
+                                                       ("tiny-d128", "q4_k_m", "q8_0", 1, 512)])
+def test_embeddings_batch_matches_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_img, ubatch):
+    """llama_batch.embd: a batch whose rows are embeddings instead of token ids - how the reference hands image embeddings to the model between the prefix and
+    the suffix of a LLaVA prompt (llama_server_context.cc:1093-1107: llava_embd_batch at positions n_past ..).  A token prefix, n_img embedding rows (one
+    micro-batch, several micro-batches of 128, a single row), a token suffix and teacher-forced steps, against the oracle fed the same rows."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    oq.set_fa_v_acc_f32(1 if kv == "f16" else 0)
+    try:
+        m, c, om, oc = open_pair(pkg, path, 512, kv, n_ubatch=ubatch)
+        rng = np.random.default_rng(n_img)
+        prefix = rng.integers(0, m.n_vocab, 9)
+        suffix = rng.integers(0, m.n_vocab, 6)
+        img = (rng.standard_normal((n_img, m.n_embd)) * 0.05).astype(np.float32)
+        c.decode(prefix, np.arange(9)); oc.decode(prefix, np.arange(9))
+        pos = np.arange(9, 9 + n_img)
+        c.decode_embd(img, pos)
+        ref = oc.decode_embd(img, pos)[0]
+        errs = [rel_err(c.logits(), ref)]
+        p0 = 9 + n_img
+        c.decode(suffix, np.arange(p0, p0 + 6))
+        ref = oc.decode(suffix, np.arange(p0, p0 + 6))[0]
+        errs.append(rel_err(c.logits(), ref))
+        tok = int(ref.argmax())
+        for step in range(6):
+            c.decode([tok], [p0 + 6 + step])
+            r = oc.decode([tok], [p0 + 6 + step])[0]
+            errs.append(rel_err(c.logits(), r))
+            tok = int(r.argmax())
+        assert max(errs) <= FLIP_TOL, errs
+        if n_img == 1:                                                        # few enough roundings for a flip-free pass: f32 round-off
+            assert min(errs) <= TIGHT_TOL, errs
+        # a batch is token ids or embeddings; an encoder takes ids only; rows must be n_embd wide
+        with pytest.raises(ValueError):
+            c.decode_embd(img[:, :-1], pos)
+        c.close(); m.close(); oc.close(); om.close()
+    finally:
+        oq.set_fa_v_acc_f32(0)
+
+
 @pytest.mark.parametrize("cfg,ftype,n_prompt", [("tiny-d128", "q4_k_m", 40), ("tiny-8b-2l", "q4_k_m", 70), ("tiny-tl-2l", "q8_0", 21), ("tiny-d128-mha", "q5_k_m", 300)])
 def test_f16_cache_parity_mode_follows_the_stock_cpu_path(be, pkg, tmp_models, cfg, ftype, n_prompt):
     """The reference's default cache is f16 (llama_engine.cc:628-637) and its CPU path accumulates V in FP16, cell by cell.  Every other f16-cache test compares
