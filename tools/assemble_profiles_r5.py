@@ -74,7 +74,8 @@ rows = stats_rows(f"{O}/r5_rocprof_decode_kernel_stats.txt")
 
 
 def role_rows(tag):
-    return [(n, c, t, a) for n, c, t, a in rows if f"mmvq_stream_{tag}<" in n]
+    # (gate | up and the head also run as mmvq_stream_<role>_fast: the form that starts its stream from preloaded kernel arguments)
+    return [(n, c, t, a) for n, c, t, a in rows if f"mmvq_stream_{tag}<" in n or f"mmvq_stream_{tag}_fast<" in n]
 
 
 down = role_rows("ffn_down")
@@ -128,7 +129,7 @@ steps16 = sum(v["launches"] for k, v in ks.items() if "mmvq_stream_ffn_down<" in
 per_role = {}
 per_tok = 0
 for tag in ("qkv", "gate_up", "ffn_down", "head"):
-    kk = {k: v for k, v in ks.items() if f"mmvq_stream_{tag}<" in k}
+    kk = {k: v for k, v in ks.items() if f"mmvq_stream_{tag}<" in k or f"mmvq_stream_{tag}_fast<" in k}
     n_l = sum(v["launches"] for v in kk.values())
     if n_l == 0:
         continue
