@@ -471,3 +471,99 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
 
         w.add_tensor(name, ne, t, gen)
     return w.write(path)
+
+
+# ---------------------------------------------------------------- LLaVA projector files ("mmproj": general.architecture clip)
+@dataclass
+class ClipConfig:
+    """The vision tower + projector of a LLaVA-1.5 style mmproj file as llama.cpp's convert_image_encoder_to_gguf.py writes it: CLIP ViT (pre-LN, learned position
+    embeddings, class token, quick-GELU MLP) cut after its second-to-last layer (block_count = layers - 1), and the two-layer MLP projector mm.0 / mm.2."""
+    name: str
+    image_size: int
+    patch_size: int
+    n_embd: int          # vision hidden size
+    n_head: int
+    n_ff: int
+    n_layer: int         # blocks in the file
+    proj_dim: int        # the language model's n_embd
+    eps: float = 1e-5
+    use_gelu: bool = False
+    mean: tuple = (0.48145466, 0.4578275, 0.40821073)
+    std: tuple = (0.26862954, 0.26130258, 0.27577711)
+
+    @property
+    def n_patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+
+CLIP_CONFIGS = {
+    # ViT-L/14-336 as LLaVA-1.5-7B uses it (576 patches -> 576 rows of 4096)
+    "clip-vit-l-336": ClipConfig("clip-vit-large-patch14-336", 336, 14, 1024, 16, 4096, 23, 4096),
+    # the same graph at test size: 56 x 56 pixels = 16 patches of 14 x 14, head_dim 64 like the real tower (d128: 36 patches, 4 heads, 3 blocks)
+    "tiny-clip": ClipConfig("tiny-clip", 56, 14, 128, 2, 256, 2, 256),
+    "tiny-clip-d128": ClipConfig("tiny-clip-d128", 84, 14, 256, 4, 512, 3, 512),
+    "tiny-clip-gelu": ClipConfig("tiny-clip-gelu", 56, 14, 128, 2, 256, 2, 4096, use_gelu=True),
+}
+
+
+def clip_tensors(cfg: ClipConfig):
+    """(name, ne, type, fan_in); ne in ggml order (fastest dimension first).  The feed-forward names are the converter's: `ffn_down` is the FIRST projection
+    (n_embd -> n_ff) and `ffn_up` the second - clip.cpp reads them that way round."""
+    E, FF, P = cfg.n_embd, cfg.n_ff, cfg.patch_size
+    out = [("v.class_embd", (E,), F32, 1),
+           ("v.patch_embd.weight", (P, P, 3, E), F16, 3 * P * P),
+           ("v.position_embd.weight", (E, cfg.n_patches + 1), F16, 1),
+           ("v.pre_ln.weight", (E,), F32, 1), ("v.pre_ln.bias", (E,), F32, 1)]
+    for il in range(cfg.n_layer):
+        p = f"v.blk.{il}."
+        for nm in ("attn_q", "attn_k", "attn_v", "attn_out"):
+            out += [(p + nm + ".weight", (E, E), F16, E), (p + nm + ".bias", (E,), F32, 1)]
+        out += [(p + "ln1.weight", (E,), F32, 1), (p + "ln1.bias", (E,), F32, 1)]
+        out += [(p + "ffn_down.weight", (E, FF), F16, E), (p + "ffn_down.bias", (FF,), F32, 1)]
+        out += [(p + "ffn_up.weight", (FF, E), F16, FF), (p + "ffn_up.bias", (E,), F32, 1)]
+        out += [(p + "ln2.weight", (E,), F32, 1), (p + "ln2.bias", (E,), F32, 1)]
+    out += [("mm.0.weight", (E, cfg.proj_dim), F16, E), ("mm.0.bias", (cfg.proj_dim,), F32, 1),
+            ("mm.2.weight", (cfg.proj_dim, cfg.proj_dim), F16, cfg.proj_dim), ("mm.2.bias", (cfg.proj_dim,), F32, 1)]
+    return out
+
+
+def write_synthetic_clip(path: str, cfg: ClipConfig | str, seed: int = 0xC11F) -> int:
+    """A random-weight mmproj file of the given geometry (same container, keys and tensor names as a converted LLaVA-1.5 projector)."""
+    if isinstance(cfg, str):
+        cfg = CLIP_CONFIGS[cfg]
+    w = GGUFWriter()
+    w.add("general.architecture", "str", "clip")
+    w.add("general.name", "str", cfg.name)
+    w.add("general.file_type", "u32", 1)
+    w.add("clip.has_text_encoder", "bool", False)
+    w.add("clip.has_vision_encoder", "bool", True)
+    w.add("clip.has_llava_projector", "bool", True)
+    w.add("clip.projector_type", "str", "mlp")
+    w.add("clip.use_gelu", "bool", cfg.use_gelu)
+    w.add("clip.vision.image_size", "u32", cfg.image_size)
+    w.add("clip.vision.patch_size", "u32", cfg.patch_size)
+    w.add("clip.vision.embedding_length", "u32", cfg.n_embd)
+    w.add("clip.vision.feed_forward_length", "u32", cfg.n_ff)
+    w.add("clip.vision.projection_dim", "u32", cfg.proj_dim)
+    w.add("clip.vision.attention.head_count", "u32", cfg.n_head)
+    w.add("clip.vision.attention.layer_norm_epsilon", "f32", cfg.eps)
+    w.add("clip.vision.block_count", "u32", cfg.n_layer)
+    w.add_array("clip.vision.image_mean", "f32", list(cfg.mean))
+    w.add_array("clip.vision.image_std", "f32", list(cfg.std))
+    for idx, (name, ne, t, fan_in) in enumerate(clip_tensors(cfg)):
+        n = int(np.prod(ne))
+
+        def gen(idx=idx, name=name, ne=ne, t=t, fan_in=fan_in, n=n):
+            rng = np.random.default_rng([seed, idx])
+            if name.endswith(".bias"):
+                return (rng.standard_normal(n) * 0.1).astype("<f4").view(np.uint8)
+            if name in ("v.class_embd",):
+                return (rng.standard_normal(n) * 0.5).astype("<f4").view(np.uint8)
+            if len(ne) == 1:      # LayerNorm weights
+                return rng.uniform(0.9, 1.1, size=n).astype("<f4").view(np.uint8)
+            if name == "v.position_embd.weight":
+                return (rng.standard_normal(n) * 0.3).astype("<f2").view(np.uint8)
+            return (rng.standard_normal(n) * (1.4 / np.sqrt(fan_in))).astype("<f2").view(np.uint8)
+
+        w.add_tensor(name, ne, t, gen)
+    return w.write(path)
