@@ -5,4 +5,4 @@ is the ctypes view of it used by tests, bench.py and the smoke entry point.  The
 fallback: importing works anywhere, but every compute call raises without the library and a GPU.
 """
 from . import binding, gguf_synth  # noqa: F401
-from .binding import Backend, Context, Engine, Model, MI355Error, lib_path, load_library  # noqa: F401
+from .binding import Backend, Clip, Context, Engine, Model, MI355Error, lib_path, load_library  # noqa: F401

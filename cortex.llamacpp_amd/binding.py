@@ -129,6 +129,15 @@ SYMBOLS = {
     "mi355_engine_set_file_logger": (None, [_vp, _i32, _cp]),
     "mi355_engine_set_log_level": (None, [_vp, _i32]),
     "mi355_engine_set_log_callback": (None, [_vp, _vp, _vp]),
+    "mi355_clip_model_load": (_vp, [_cp, _i32]),
+    "mi355_clip_free": (None, [_vp]),
+    "mi355_clip_n_mmproj_embd": (_i32, [_vp]),
+    "mi355_clip_n_patches": (_i32, [_vp]),
+    "mi355_clip_image_size": (_i32, [_vp]),
+    "mi355_clip_image_load_from_bytes": (_i32, [_vp, _sz, C.POINTER(_i32), C.POINTER(_i32), _vp, _sz]),
+    "mi355_clip_image_preprocess": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "mi355_clip_image_encode": (_i32, [_vp, _vp, _vp]),
+    "mi355_llava_image_embed_from_bytes": (_i32, [_vp, _vp, _sz, _vp, _sz]),
     "mi355_tp_p2p_local_handle": (C.c_int, [_vp, _sz, _sz]),
     "mi355_tp_p2p_local_handle2": (C.c_int, [_vp, _sz, _sz, _sz]),
     "mi355_tp_p2p_prompt_exchanges": (C.c_int64, []),
@@ -402,6 +411,57 @@ def tp_init(rank: int, size: int, device: int = 0, transport: str = "rccl", grou
 def tp_shutdown():
     load_library().mi355_tp_shutdown()
     _tp_keepalive.clear()
+
+
+class Clip:
+    """The image side of a LLaVA request (clip_model_load / clip_image_load_from_bytes / clip_image_preprocess / clip_image_encode)."""
+
+    def __init__(self, path: str, main_gpu: int = 0):
+        self.lib = load_library()
+        self.h = self.lib.mi355_clip_model_load(path.encode(), main_gpu)
+        if not self.h:
+            raise MI355Error(f"mi355_clip_model_load({path}) failed: {_err(self.lib)}")
+        self.n_embd = self.lib.mi355_clip_n_mmproj_embd(self.h)
+        self.n_patches = self.lib.mi355_clip_n_patches(self.h)
+        self.image_size = self.lib.mi355_clip_image_size(self.h)
+
+    def load_image(self, data: bytes) -> np.ndarray:
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        nx, ny = C.c_int32(0), C.c_int32(0)
+        if self.lib.mi355_clip_image_load_from_bytes(buf, len(data), C.byref(nx), C.byref(ny), None, 0) != 0:
+            raise MI355Error(f"image: {_err(self.lib)}")
+        rgb = np.empty((ny.value, nx.value, 3), np.uint8)
+        if self.lib.mi355_clip_image_load_from_bytes(buf, len(data), C.byref(nx), C.byref(ny), rgb.ctypes.data, rgb.nbytes) != 0:
+            raise MI355Error(f"image: {_err(self.lib)}")
+        return rgb
+
+    def preprocess(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        ny, nx, _ = rgb.shape
+        out = np.empty((3, self.image_size, self.image_size), np.float32)
+        if self.lib.mi355_clip_image_preprocess(self.h, rgb.ctypes.data, nx, ny, out.ctypes.data) != 0:
+            raise MI355Error(f"preprocess: {_err(self.lib)}")
+        return out
+
+    def encode(self, img: np.ndarray) -> np.ndarray:
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.empty((self.n_patches, self.n_embd), np.float32)
+        if self.lib.mi355_clip_image_encode(self.h, img.ctypes.data, out.ctypes.data) != 0:
+            raise MI355Error(f"encode: {_err(self.lib)}")
+        return out
+
+    def embed_bytes(self, data: bytes) -> np.ndarray:
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        out = np.empty((self.n_patches, self.n_embd), np.float32)
+        n = self.lib.mi355_llava_image_embed_from_bytes(self.h, buf, len(data), out.ctypes.data, out.size)
+        if n < 0:
+            raise MI355Error(f"llava_image_embed: {_err(self.lib)}")
+        return out[:n]
+
+    def close(self):
+        if self.h:
+            self.lib.mi355_clip_free(self.h)
+            self.h = None
 
 
 class Model:

@@ -13,9 +13,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [
-    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmvq_stream.hip", "csrc/decode_engine.hip", "csrc/mmq.hip", "csrc/mmq_q80.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/mmf.hip", "csrc/attn.hip", "csrc/attn_out.hip", "csrc/attn_prefill.hip", "csrc/decode_mega.hip",
+    "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmvq_stream.hip", "csrc/decode_engine.hip", "csrc/mmq.hip", "csrc/mmq_q80.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/mmf.hip", "csrc/attn.hip", "csrc/attn_out.hip", "csrc/attn_prefill.hip", "csrc/decode_mega.hip", "csrc/clip.hip",
     "host/gguf.cc", "host/runtime.cc", "host/tp_comm.cc", "host/vocab.cc", "host/sampling.cc", "host/grammar.cc", "host/json_schema.cc", "host/log.cc", "host/server_context.cc", "host/engine.cc",
-    "host/hip_backend.cc", "csrc/c_api.cc",
+    "host/hip_backend.cc", "host/clip.cc", "host/image_decode.cc", "csrc/c_api.cc",
 ]
 HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "csrc/mmvq_fast_dev.h", "csrc/mmvq_stream_dev.h", "csrc/attn_decode_dev.h", "host/gguf.h", "host/runtime.h", "host/tp_comm.h", "host/json.h", "host/vocab.h",
         "host/sampling.h", "host/grammar.h", "host/log.h", "host/backend_iface.h", "host/server_context.h", "host/engine.h", "host/hip_backend.h",

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "../host/clip.h"
 #include "../host/engine.h"
 #include "../host/hip_backend.h"
 #include "../host/log.h"
@@ -29,6 +30,7 @@ struct mi355_model {
     bool vocab_tried = false, vocab_ok = false;
 };
 struct mi355_engine { LlamaEngine eng{make_hip_backend}; };
+struct mi355_clip { ClipModel m; };
 struct mi355_context {
     Context *c;
     std::vector<const char *> prof_names;
@@ -226,6 +228,68 @@ int64_t mi355_debug_engine_steps(const mi355_context *ctx) { return ctx->c->engi
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0 || ctx->c->model->hp.encoder; }
 float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
+
+// ---- LLaVA image path (host/clip.h)
+mi355_clip *mi355_clip_model_load(const char *path, int32_t main_gpu) {
+    if (!path) { fail("clip_model_load: no path"); return nullptr; }
+    MI355_GUARD(return nullptr,
+        std::unique_ptr<mi355_clip> c(new mi355_clip);
+        const std::string err = c->m.load(path, main_gpu < 0 ? 0 : main_gpu);
+        if (!err.empty()) { fail(err); return nullptr; }
+        return c.release();
+    )
+}
+void mi355_clip_free(mi355_clip *clip) { delete clip; }
+int32_t mi355_clip_n_mmproj_embd(const mi355_clip *clip) { return clip ? clip->m.proj_dim : 0; }
+int32_t mi355_clip_n_patches(const mi355_clip *clip) { return clip ? clip->m.n_patches() : 0; }
+int32_t mi355_clip_image_size(const mi355_clip *clip) { return clip ? clip->m.image_size : 0; }
+int32_t mi355_clip_image_load_from_bytes(const uint8_t *bytes, size_t n_bytes, int32_t *nx, int32_t *ny, uint8_t *rgb_out, size_t rgb_cap) {
+    MI355_GUARD(return MI355_ERR_ARG,
+        ClipImageU8 img;
+        const std::string err = clip_image_load_from_bytes(bytes, n_bytes, img);
+        if (!err.empty()) { fail(err); return MI355_ERR_ARG; }
+        if (nx) *nx = img.nx;
+        if (ny) *ny = img.ny;
+        if (rgb_out) {
+            if (rgb_cap < img.rgb.size()) { fail("clip_image_load_from_bytes: rgb_cap too small"); return MI355_ERR_ARG; }
+            memcpy(rgb_out, img.rgb.data(), img.rgb.size());
+        }
+        return MI355_OK;
+    )
+}
+int32_t mi355_clip_image_preprocess(const mi355_clip *clip, const uint8_t *rgb, int32_t nx, int32_t ny, float *out) {
+    if (!clip || !rgb || !out || nx <= 0 || ny <= 0) { fail("clip_image_preprocess: bad arguments"); return MI355_ERR_ARG; }
+    MI355_GUARD(return MI355_ERR_ARG,
+        ClipImageU8 img;
+        img.nx = nx; img.ny = ny; img.rgb.assign(rgb, rgb + (size_t)3 * nx * ny);
+        std::vector<float> f;
+        clip->m.preprocess(img, f);
+        memcpy(out, f.data(), f.size() * sizeof(float));
+        return MI355_OK;
+    )
+}
+int32_t mi355_clip_image_encode(mi355_clip *clip, const float *img, float *out) {
+    if (!clip || !img || !out) { fail("clip_image_encode: bad arguments"); return MI355_ERR_ARG; }
+    MI355_GUARD(return MI355_ERR_ARG,
+        const std::string err = clip->m.encode(img, out);
+        if (!err.empty()) { fail(err); return MI355_ERR_ARG; }
+        return MI355_OK;
+    )
+}
+int32_t mi355_llava_image_embed_from_bytes(mi355_clip *clip, const uint8_t *bytes, size_t n_bytes, float *out, size_t out_floats) {
+    if (!clip || !bytes || !out) { fail("llava_image_embed: bad arguments"); return MI355_ERR_ARG; }
+    MI355_GUARD(return MI355_ERR_ARG,
+        if (out_floats < (size_t)clip->m.n_patches() * (size_t)clip->m.proj_dim) { fail("llava_image_embed: output buffer too small"); return MI355_ERR_ARG; }
+        ClipImageU8 img;
+        std::string err = clip_image_load_from_bytes(bytes, n_bytes, img);
+        if (!err.empty()) { fail(err); return MI355_ERR_ARG; }
+        std::vector<float> f;
+        clip->m.preprocess(img, f);
+        err = clip->m.encode(f.data(), out);
+        if (!err.empty()) { fail(err); return MI355_ERR_ARG; }
+        return clip->m.n_patches();
+    )
+}
 
 void mi355_kv_cache_clear(mi355_context *ctx) { ctx->c->kv_clear(); }
 // sequence ids index a 64-bit mask per cell: anything outside [0, 64) is refused here (seq < 0 = "every sequence" only

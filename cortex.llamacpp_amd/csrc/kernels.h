@@ -205,6 +205,12 @@ hipError_t launch_topk_rows(const float *base, int n, int n_rows, const int *row
 
 // f32 / f16 weight mat-vec (router, unquantised models): y[t][r] = dot(W[r], x[t])
 // batches against F16 weights on the matrix cores (mmf.hip): y[t][n] (+ resid) = sum_k W[n][k] * f16(x[t][k]); the same products as launch_mmv_float, f32 accumulation
+// ---------------------------------------------------------------- LLaVA image encoder (clip.hip): the tower's small kernels; the projections run on launch_mmf16
+hipError_t launch_clip_im2col(const float *img, int S, int P, int ld, float *patches, hipStream_t st);            // [n_patches][ld], columns (c, ky, kx), zero padded
+hipError_t launch_clip_embed(const float *patch, const float *cls, const float *pos, int E, int T, float *emb, hipStream_t st);   // [class ; patches] + positions
+hipError_t launch_clip_bias(float *x, const float *b, int n, int T, float scale, bool do_scale, hipStream_t st);  // x = (x + b) [* scale]
+hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, hipStream_t st);     // unmasked, q pre-scaled
+hipError_t launch_clip_gelu(float *x, size_t n, bool quick, hipStream_t st);                                      // ggml's f16-table GELU / quick-GELU
 bool mmf16_applicable(int type, int n_rows, int K, int T, const void *W, const void *x, const void *y);
 hipError_t launch_mmf16(const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out, const float *resid, hipStream_t st);
 hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,

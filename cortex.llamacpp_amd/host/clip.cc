@@ -1,0 +1,214 @@
+// clip.cc — see clip.h.  The tower runs as a short sequence of launches per block (LayerNorm, three projections, bias / scale, attention, projection, residual,
+// LayerNorm, two projections around the GELU, residual): f16 weights on the matrix cores (mmf.hip: activations rounded to f16 as the CPU's f16 dot does),
+// everything else f32.  One image is one pass; nothing here is on the token path.
+#include "clip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../csrc/kernels.h"
+#include "gguf.h"
+
+namespace mi355 {
+
+#define CLIP_TRY(x)                                                                                      \
+    do {                                                                                                 \
+        const hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) return std::string(#x) + ": " + hipGetErrorString(e_);                     \
+    } while (0)
+
+ClipModel::~ClipModel() {
+    for (void *p : allocs_) (void)hipFree(p);
+    if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
+}
+void *ClipModel::dalloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    allocs_.push_back(p);
+    device_bytes += bytes;
+    return p;
+}
+
+static uint16_t f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float f16_bits_to_f32(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+std::string ClipModel::load(const std::string &path, int device) {
+    GGUFFile f;
+    const std::string err = f.open(path);
+    if (!err.empty()) return err;
+    if (f.get_s("general.architecture", "") != "clip") return "not a projector file: general.architecture is '" + f.get_s("general.architecture", "") + "', expected 'clip'";
+    if (!f.get_b("clip.has_vision_encoder", false)) return "projector file without a vision encoder";
+    if (!f.get_b("clip.has_llava_projector", false)) return "projector file without a LLaVA projector (clip.has_llava_projector)";
+    const std::string ptype = f.get_s("clip.projector_type", "mlp");
+    if (ptype != "mlp") return "projector type '" + ptype + "' is not supported (mlp only: LLaVA-1.5)";
+    image_size = (int)f.get_u("clip.vision.image_size", 0); patch_size = (int)f.get_u("clip.vision.patch_size", 0);
+    n_embd = (int)f.get_u("clip.vision.embedding_length", 0); n_ff = (int)f.get_u("clip.vision.feed_forward_length", 0);
+    n_head = (int)f.get_u("clip.vision.attention.head_count", 0); n_layer = (int)f.get_u("clip.vision.block_count", 0);
+    eps = (float)f.get_f("clip.vision.attention.layer_norm_epsilon", 1e-5);
+    use_gelu = f.get_b("clip.use_gelu", false);
+    if (image_size <= 0 || patch_size <= 0 || image_size % patch_size || n_embd <= 0 || n_ff <= 0 || n_head <= 0 || n_layer <= 0 || n_embd % n_head)
+        return "projector file: bad vision geometry";
+    const int D = n_embd / n_head;
+    if (D != 32 && D != 64 && D != 80 && D != 128) return "projector file: head size " + std::to_string(D) + " is not supported";
+    if ((n_embd % 16) || (n_ff % 16)) return "projector file: widths must be multiples of 16";
+    for (int k = 0; k < 3; k++) { mean[k] = 0.0f; stdv[k] = 1.0f; }
+    if (const GGUFValue *v = f.find("clip.vision.image_mean")) if (v->type == GV_ARR && v->elem_type == GV_F32 && v->u >= 3 && v->raw) memcpy(mean, v->raw, 12);
+    if (const GGUFValue *v = f.find("clip.vision.image_std")) if (v->type == GV_ARR && v->elem_type == GV_F32 && v->u >= 3 && v->raw) memcpy(stdv, v->raw, 12);
+    if (f.find("clip.vision.image_grid_pinpoints")) return "projector file with an image grid (LLaVA-1.6) is not supported";
+
+    device_ = device;
+    if (hipSetDevice(device) != hipSuccess) return "hipSetDevice failed";
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return "stream creation failed";
+    stream_ = st;
+
+    std::string bad;
+    // a weight matrix [rows][K]: f16 in the file (what the converter writes); uploaded with rows of ld >= K halves (zero padded)
+    auto up_w = [&](const std::string &name, int rows, int K, int ld) -> void * {
+        const GGUFTensorInfo *t = f.tensor(name);
+        if (!t) { bad = "projector file: tensor " + name + " is missing"; return nullptr; }
+        int64_t n = 1;
+        for (int d = 0; d < t->n_dims; d++) n *= t->ne[d];
+        if (n != (int64_t)rows * K) { bad = "projector file: tensor " + name + " has the wrong shape"; return nullptr; }
+        if (t->type != 1) { bad = "projector file: tensor " + name + " is " + ggml_type_name(t->type) + "; f16 weights only"; return nullptr; }
+        std::vector<uint16_t> h((size_t)rows * ld, 0);
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(t->data);
+        for (int r = 0; r < rows; r++) memcpy(h.data() + (size_t)r * ld, src + (size_t)r * K, (size_t)K * 2);
+        void *d = dalloc(h.size() * 2);
+        if (!d || hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { bad = "device upload failed"; return nullptr; }
+        return d;
+    };
+    // a vector / table of floats: f32 or f16 in the file, f32 on the device
+    auto up_f = [&](const std::string &name, size_t n) -> float * {
+        const GGUFTensorInfo *t = f.tensor(name);
+        if (!t) { bad = "projector file: tensor " + name + " is missing"; return nullptr; }
+        int64_t m = 1;
+        for (int d = 0; d < t->n_dims; d++) m *= t->ne[d];
+        if ((size_t)m != n || (t->type != 0 && t->type != 1)) { bad = "projector file: tensor " + name + " has the wrong shape or type"; return nullptr; }
+        std::vector<float> h(n);
+        if (t->type == 0) memcpy(h.data(), t->data, n * 4);
+        else for (size_t i = 0; i < n; i++) h[i] = f16_bits_to_f32(reinterpret_cast<const uint16_t *>(t->data)[i]);
+        float *d = (float *)dalloc(n * 4);
+        if (!d || hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { bad = "device upload failed"; return nullptr; }
+        return d;
+    };
+    const int E = n_embd, FF = n_ff, KP = 3 * patch_size * patch_size, T = n_patches() + 1;
+    kp_pad_ = (KP + 15) & ~15;
+    const GGUFTensorInfo *mm2 = f.tensor("mm.2.weight");
+    if (!mm2 || mm2->n_dims != 2) return "projector file: tensor mm.2.weight is missing";
+    proj_dim = (int)mm2->ne[1];
+    if (proj_dim < 32 || (proj_dim % 16)) return "projector file: bad projection width";
+    class_ = up_f("v.class_embd", (size_t)E);
+    patch_w_ = up_w("v.patch_embd.weight", E, KP, kp_pad_);
+    pos_ = up_f("v.position_embd.weight", (size_t)T * E);
+    pre_w_ = up_f("v.pre_ln.weight", (size_t)E); pre_b_ = up_f("v.pre_ln.bias", (size_t)E);
+    mm0w_ = up_w("mm.0.weight", proj_dim, E, E); mm0b_ = up_f("mm.0.bias", (size_t)proj_dim);
+    mm2w_ = up_w("mm.2.weight", proj_dim, proj_dim, proj_dim); mm2b_ = up_f("mm.2.bias", (size_t)proj_dim);
+    if (!bad.empty()) return bad;
+    layers_.resize((size_t)n_layer);
+    for (int il = 0; il < n_layer; il++) {
+        const std::string p = "v.blk." + std::to_string(il) + ".";
+        ClipLayerDev &L = layers_[(size_t)il];
+        L.wq = up_w(p + "attn_q.weight", E, E, E); L.bq = up_f(p + "attn_q.bias", (size_t)E);
+        L.wk = up_w(p + "attn_k.weight", E, E, E); L.bk = up_f(p + "attn_k.bias", (size_t)E);
+        L.wv = up_w(p + "attn_v.weight", E, E, E); L.bv = up_f(p + "attn_v.bias", (size_t)E);
+        L.wo = up_w(p + "attn_out.weight", E, E, E); L.bo = up_f(p + "attn_out.bias", (size_t)E);
+        L.ln1w = up_f(p + "ln1.weight", (size_t)E); L.ln1b = up_f(p + "ln1.bias", (size_t)E);
+        L.ln2w = up_f(p + "ln2.weight", (size_t)E); L.ln2b = up_f(p + "ln2.bias", (size_t)E);
+        // the converter's names: "ffn_down" is the FIRST projection (n_embd -> n_ff), "ffn_up" the second
+        L.ff_i = up_w(p + "ffn_down.weight", FF, E, E); L.ff_i_b = up_f(p + "ffn_down.bias", (size_t)FF);
+        L.ff_o = up_w(p + "ffn_up.weight", E, FF, FF); L.ff_o_b = up_f(p + "ffn_up.bias", (size_t)E);
+        if (!bad.empty()) return bad;
+    }
+    const int NP = n_patches();
+    d_img_ = (float *)dalloc((size_t)3 * image_size * image_size * 4);
+    d_patches_ = (float *)dalloc((size_t)NP * kp_pad_ * 4);
+    d_pe_ = (float *)dalloc((size_t)NP * E * 4);
+    d_emb_ = (float *)dalloc((size_t)T * E * 4); d_cur_ = (float *)dalloc((size_t)T * E * 4);
+    d_q_ = (float *)dalloc((size_t)T * E * 4); d_k_ = (float *)dalloc((size_t)T * E * 4); d_v_ = (float *)dalloc((size_t)T * E * 4);
+    d_att_ = (float *)dalloc((size_t)T * E * 4); d_ff_ = (float *)dalloc((size_t)T * FF * 4);
+    d_h1_ = (float *)dalloc((size_t)NP * proj_dim * 4); d_out_ = (float *)dalloc((size_t)NP * proj_dim * 4);
+    if (!d_img_ || !d_patches_ || !d_pe_ || !d_emb_ || !d_cur_ || !d_q_ || !d_k_ || !d_v_ || !d_att_ || !d_ff_ || !d_h1_ || !d_out_) return "out of device memory";
+    if (NP < 8) return "projector file: fewer than 8 patches";
+    return "";
+}
+
+// clip_image_preprocess, the LLaVA-1.5 branch: pad to a square with the mean colour (top-left aligned), bilinear resample with the half-pixel mapping, round to
+// a byte, normalise; planar output
+void ClipModel::preprocess(const ClipImageU8 &img, std::vector<float> &out) const {
+    const int S = image_size;
+    out.assign((size_t)3 * S * S, 0.0f);
+    int tn = img.nx, tny = img.ny;
+    std::vector<uint8_t> sq;
+    const uint8_t *src = img.rgb.data();
+    if (img.nx != img.ny) {
+        const int L = std::max(img.nx, img.ny);
+        sq.resize((size_t)3 * L * L);
+        static const uint8_t bc[3] = {122, 116, 104};
+        for (size_t i = 0; i < (size_t)L * L; i++) { sq[3 * i] = bc[0]; sq[3 * i + 1] = bc[1]; sq[3 * i + 2] = bc[2]; }
+        for (int y = 0; y < img.ny; y++) memcpy(sq.data() + (size_t)3 * y * L, img.rgb.data() + (size_t)3 * y * img.nx, (size_t)3 * img.nx);
+        src = sq.data(); tn = L; tny = L;
+    }
+    const float scale = (float)std::max(tn, tny) / (float)S;
+    for (int y = 0; y < S; y++)
+        for (int x = 0; x < S; x++)
+            for (int k = 0; k < 3; k++) {
+                const float sx = ((float)x + 0.5f) * scale - 0.5f, sy = ((float)y + 0.5f) * scale - 0.5f;
+                const int x0 = std::max(0, (int)floorf(sx)), y0 = std::max(0, (int)floorf(sy));
+                const int x1 = std::min(x0 + 1, tn - 1), y1 = std::min(y0 + 1, tny - 1);
+                const float dx = sx - (float)x0, dy = sy - (float)y0;
+                const float v00 = src[3 * ((size_t)y0 * tn + x0) + k], v01 = src[3 * ((size_t)y0 * tn + x1) + k];
+                const float v10 = src[3 * ((size_t)y1 * tn + x0) + k], v11 = src[3 * ((size_t)y1 * tn + x1) + k];
+                const float v0 = v00 * (1.0f - dx) + v01 * dx, v1 = v10 * (1.0f - dx) + v11 * dx;
+                const float v = v0 * (1.0f - dy) + v1 * dy;
+                const uint8_t v2 = (uint8_t)std::min(std::max(roundf(v), 0.0f), 255.0f);
+                out[(size_t)k * S * S + (size_t)y * S + x] = (((float)v2 / 255.0f) - mean[k]) / stdv[k];
+            }
+}
+
+std::string ClipModel::encode(const float *img, float *out) {
+    if (hipSetDevice(device_) != hipSuccess) return "hipSetDevice failed";
+    hipStream_t st = (hipStream_t)stream_;
+    const int S = image_size, E = n_embd, FF = n_ff, H = n_head, D = E / H, NP = n_patches(), T = NP + 1;
+    CLIP_TRY(hipMemcpyAsync(d_img_, img, (size_t)3 * S * S * 4, hipMemcpyHostToDevice, st));
+    CLIP_TRY(launch_clip_im2col(d_img_, S, patch_size, kp_pad_, d_patches_, st));
+    CLIP_TRY(launch_mmf16((const uint8_t *)patch_w_, E, kp_pad_, d_patches_, NP, d_pe_, E, nullptr, st));
+    CLIP_TRY(launch_clip_embed(d_pe_, class_, pos_, E, T, d_emb_, st));
+    CLIP_TRY(launch_layer_norm(d_emb_, pre_w_, pre_b_, E, T, eps, d_emb_, st));
+    const float qs = 1.0f / sqrtf((float)D);
+    for (int il = 0; il < n_layer; il++) {
+        const ClipLayerDev &L = layers_[(size_t)il];
+        CLIP_TRY(launch_layer_norm(d_emb_, L.ln1w, L.ln1b, E, T, eps, d_cur_, st));
+        CLIP_TRY(launch_mmf16((const uint8_t *)L.wq, E, E, d_cur_, T, d_q_, E, nullptr, st));
+        CLIP_TRY(launch_clip_bias(d_q_, L.bq, E, T, qs, true, st));
+        CLIP_TRY(launch_mmf16((const uint8_t *)L.wk, E, E, d_cur_, T, d_k_, E, nullptr, st));
+        CLIP_TRY(launch_clip_bias(d_k_, L.bk, E, T, 1.0f, false, st));
+        CLIP_TRY(launch_mmf16((const uint8_t *)L.wv, E, E, d_cur_, T, d_v_, E, nullptr, st));
+        CLIP_TRY(launch_clip_bias(d_v_, L.bv, E, T, 1.0f, false, st));
+        CLIP_TRY(launch_clip_attn(d_q_, d_k_, d_v_, T, H, D, d_att_, st));
+        CLIP_TRY(launch_mmf16((const uint8_t *)L.wo, E, E, d_att_, T, d_cur_, E, nullptr, st));
+        CLIP_TRY(launch_clip_bias(d_cur_, L.bo, E, T, 1.0f, false, st));
+        CLIP_TRY(launch_add(d_cur_, d_emb_, d_emb_, (int64_t)T * E, st));
+        CLIP_TRY(launch_layer_norm(d_emb_, L.ln2w, L.ln2b, E, T, eps, d_cur_, st));
+        CLIP_TRY(launch_mmf16((const uint8_t *)L.ff_i, FF, E, d_cur_, T, d_ff_, FF, nullptr, st));
+        CLIP_TRY(launch_clip_bias(d_ff_, L.ff_i_b, FF, T, 1.0f, false, st));
+        CLIP_TRY(launch_clip_gelu(d_ff_, (size_t)T * FF, !use_gelu, st));
+        CLIP_TRY(launch_mmf16((const uint8_t *)L.ff_o, E, FF, d_ff_, T, d_cur_, E, nullptr, st));
+        CLIP_TRY(launch_clip_bias(d_cur_, L.ff_o_b, E, T, 1.0f, false, st));
+        CLIP_TRY(launch_add(d_emb_, d_cur_, d_emb_, (int64_t)T * E, st));
+    }
+    // the projector on the patch rows (the class row, row 0, is dropped)
+    CLIP_TRY(launch_mmf16((const uint8_t *)mm0w_, proj_dim, E, d_emb_ + E, NP, d_h1_, proj_dim, nullptr, st));
+    CLIP_TRY(launch_clip_bias(d_h1_, mm0b_, proj_dim, NP, 1.0f, false, st));
+    CLIP_TRY(launch_clip_gelu(d_h1_, (size_t)NP * proj_dim, false, st));
+    CLIP_TRY(launch_mmf16((const uint8_t *)mm2w_, proj_dim, proj_dim, d_h1_, NP, d_out_, proj_dim, nullptr, st));
+    CLIP_TRY(launch_clip_bias(d_out_, mm2b_, proj_dim, NP, 1.0f, false, st));
+    CLIP_TRY(hipMemcpyAsync(out, d_out_, (size_t)NP * proj_dim * 4, hipMemcpyDeviceToHost, st));
+    CLIP_TRY(hipStreamSynchronize(st));
+    return "";
+}
+
+}  // namespace mi355

@@ -333,6 +333,26 @@ MI355_API double  mi355_bench_weight_sweep(mi355_context *ctx, int iters, uint64
  * launch - attn_out.hip - it is not among them, and its bytes are not counted) */
 MI355_API double  mi355_bench_weight_sweep2(mi355_context *ctx, int iters, uint64_t *bytes_per_sweep, int32_t *launches_per_sweep);
 
+/* ------------------------------------------------------------------ LLaVA image path (projector file "mmproj"; llama.cpp examples/llava behind the reference)
+ * The reference: clip_model_load (llama_server_context.cc:187), clip_n_mmproj_embd (:217), clip_image_load_from_bytes (:568),
+ * llava_image_embed_make_with_clip_img (:820, = clip_image_preprocess + clip_image_encode); the rows then enter the model as llama_batch.embd (:1093-1107).
+ * LLaVA-1.5 style files (CLIP ViT tower, MLP projector, f16 weights); image grids (LLaVA-1.6) are refused at load. */
+typedef struct mi355_clip mi355_clip;
+MI355_API mi355_clip *mi355_clip_model_load(const char *path, int32_t main_gpu);       /* clip_model_load; NULL + mi355_last_error on failure */
+MI355_API void        mi355_clip_free(mi355_clip *clip);                                /* clip_free */
+MI355_API int32_t     mi355_clip_n_mmproj_embd(const mi355_clip *clip);                 /* clip_n_mmproj_embd: must equal the model's n_embd */
+MI355_API int32_t     mi355_clip_n_patches(const mi355_clip *clip);                     /* clip_n_patches: embedding rows per image */
+MI355_API int32_t     mi355_clip_image_size(const mi355_clip *clip);
+/* clip_image_load_from_bytes: PNG / JPEG (baseline) / BMP / binary PNM bytes -> 8-bit RGB [ny][nx][3].  rgb_out may be NULL to query the size.
+ * Returns 0, or < 0 with the reason in mi355_last_error (unknown format, truncated data, rgb_cap too small). */
+MI355_API int32_t     mi355_clip_image_load_from_bytes(const uint8_t *bytes, size_t n_bytes, int32_t *nx, int32_t *ny, uint8_t *rgb_out, size_t rgb_cap);
+/* clip_image_preprocess (LLaVA-1.5: pad to a square with the mean colour, bilinear resample, normalise): rgb [ny][nx][3] -> out [3][S][S], S = image_size */
+MI355_API int32_t     mi355_clip_image_preprocess(const mi355_clip *clip, const uint8_t *rgb, int32_t nx, int32_t ny, float *out);
+/* clip_image_encode: img [3][S][S] -> out [n_patches][n_mmproj_embd] (host memory) */
+MI355_API int32_t     mi355_clip_image_encode(mi355_clip *clip, const float *img, float *out);
+/* llava_image_embed_make_with_clip_img on encoded image bytes: decode + preprocess + encode.  Returns the number of rows written (n_patches) or < 0. */
+MI355_API int32_t     mi355_llava_image_embed_from_bytes(mi355_clip *clip, const uint8_t *bytes, size_t n_bytes, float *out, size_t out_floats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,18 @@ void    oq_kv_seq_add(oq_ctx *c, int seq, int p0, int p1, int delta);
 /* debugging taps: copy of the residual stream after layer il for the last decoded batch */
 const float *oq_debug_layer_out(oq_ctx *c, int il);
 
+/* ---- LLaVA image path (oq_clip.c): clip_image_preprocess + clip_image_encode of a LLaVA-1.5 style projector file ---- */
+typedef struct oq_clip oq_clip;
+oq_clip *oq_clip_load(const char *path);
+void     oq_clip_free(oq_clip *c);
+int      oq_clip_image_size(const oq_clip *c);
+int      oq_clip_n_patches(const oq_clip *c);
+int      oq_clip_n_mmproj_embd(const oq_clip *c);
+/* rgb: [ny][nx][3] bytes -> out: [3][S][S] normalised floats */
+void     oq_clip_preprocess(const oq_clip *c, const uint8_t *rgb, int nx, int ny, float *out);
+/* img: [3][S][S] -> out: [n_patches][n_mmproj_embd] */
+int      oq_clip_encode(const oq_clip *c, const float *img, float *out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

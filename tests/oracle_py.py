@@ -78,6 +78,15 @@ def lib():
         L.oq_ctx_free.argtypes = [vp]
         L.oq_decode.restype = i32
         L.oq_decode.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+        L.oq_clip_load.restype = vp
+        L.oq_clip_load.argtypes = [C.c_char_p]
+        L.oq_clip_free.argtypes = [vp]
+        for nm in ("oq_clip_image_size", "oq_clip_n_patches", "oq_clip_n_mmproj_embd"):
+            getattr(L, nm).restype = i32
+            getattr(L, nm).argtypes = [vp]
+        L.oq_clip_preprocess.argtypes = [vp, vp, i32, i32, vp]
+        L.oq_clip_encode.restype = i32
+        L.oq_clip_encode.argtypes = [vp, vp, vp, i32]
         L.oq_decode_embd.restype = i32
         L.oq_decode_embd.argtypes = [vp, vp, vp, vp, vp, i32, vp]
         L.oq_kv_clear.argtypes = [vp]
@@ -305,4 +314,38 @@ class OracleContext:
     def close(self):
         if self.h:
             lib().oq_ctx_free(self.h)
+            self.h = None
+
+
+class OracleClip:
+    """clip_model_load + clip_image_preprocess + clip_image_encode of the CPU restatement (oracle/oq_clip.c)."""
+
+    def __init__(self, path: str):
+        self.h = lib().oq_clip_load(path.encode())
+        if not self.h:
+            raise RuntimeError(f"oracle: cannot load projector file {path}")
+        self.image_size = lib().oq_clip_image_size(self.h)
+        self.n_patches = lib().oq_clip_n_patches(self.h)
+        self.n_embd = lib().oq_clip_n_mmproj_embd(self.h)
+
+    def preprocess(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        ny, nx, ch = rgb.shape
+        assert ch == 3
+        out = np.empty((3, self.image_size, self.image_size), np.float32)
+        lib().oq_clip_preprocess(self.h, _p(rgb), nx, ny, _p(out))
+        return out
+
+    def encode(self, img: np.ndarray) -> np.ndarray:
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        assert img.shape == (3, self.image_size, self.image_size)
+        out = np.empty((self.n_patches, self.n_embd), np.float32)
+        rc = lib().oq_clip_encode(self.h, _p(img), _p(out), threads())
+        if rc != 0:
+            raise RuntimeError(f"oracle clip encode rc={rc}")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().oq_clip_free(self.h)
             self.h = None
