@@ -503,6 +503,8 @@ CLIP_CONFIGS = {
     "tiny-clip": ClipConfig("tiny-clip", 56, 14, 128, 2, 256, 2, 256),
     "tiny-clip-d128": ClipConfig("tiny-clip-d128", 84, 14, 256, 4, 512, 3, 512),
     "tiny-clip-gelu": ClipConfig("tiny-clip-gelu", 56, 14, 128, 2, 256, 2, 4096, use_gelu=True),
+    # a projector as wide as the tiny language models of the engine tests (n_embd 1024): 16 rows per image
+    "tiny-clip-1024": ClipConfig("tiny-clip-1024", 56, 14, 128, 2, 256, 2, 1024),
 }
 
 

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "vocab.h"
@@ -69,6 +70,14 @@ class IBackend {
     virtual bool is_encoder() const { return false; }
     virtual void set_embeddings(bool on) = 0;
     virtual const float *embeddings_ith(int i) = 0;
+    // ---- LLaVA: a projector file ("mmproj") was loaded beside the model (llama_server_context.cc:184-230)
+    virtual bool multimodal() const { return false; }
+    // clip_image_load_from_bytes (:568): can these bytes be decoded as an image - if not, why
+    virtual bool image_check(const uint8_t *bytes, size_t n, std::string &err) { (void)bytes; (void)n; err = "no multimodal projector loaded"; return false; }
+    // llava_image_embed_make_with_clip_img (:820): the image's embedding rows [n][n_embd]; returns n, or < 0 with err set
+    virtual int image_embed(const uint8_t *bytes, size_t n, std::vector<float> &rows, std::string &err) { (void)bytes; (void)n; (void)rows; err = "no multimodal projector loaded"; return -1; }
+    // llama_decode on a llava_embd_batch (:1093-1107): n embedding rows at positions pos0 .. of sequence seq, no logits.  0 ok, 1 no KV slot, < 0 error
+    virtual int decode_embd(const float *rows, int n, int pos0, int seq) { (void)rows; (void)n; (void)pos0; (void)seq; return -1; }
     virtual void kv_clear() = 0;
     virtual bool kv_seq_rm(int seq, int p0, int p1) = 0;
     virtual void kv_seq_add(int seq, int p0, int p1, int delta) = 0;

@@ -179,12 +179,11 @@ bool LlamaEngine::LoadModelImpl(const Json &body, std::string &err) {   // :547-
     auto si = std::make_shared<ServerInfo>();
     const std::string path = body["llama_model_path"].is_string() ? body["llama_model_path"].as_string() : body["model_path"].str_or("");
     if (path.empty()) { err = "Missing model path in request"; return false; }
-    // `mmproj` (src/llama_engine.cc:553-562) turns the reference's context multimodal (clip / LLaVA, src/llama_server_context.cc:184-230).  This backend has no
-    // image encoder: refuse the load by name instead of serving the model as text-only behind the caller's back.
+    // `mmproj` (src/llama_engine.cc:553-562) turns the context multimodal (LLaVA: src/llama_server_context.cc:184-230): the backend factory loads the projector
+    // file beside the model (hip_backend.cc) and fails the load when it cannot
     if (!body["mmproj"].is_null()) {
-        err = "mmproj: multimodal (LLaVA / clip) models are not supported by this backend";
-        log_line(LOG_ERROR, "%s", err.c_str());
-        return false;
+        if (!body["mmproj"].is_string() || body["mmproj"].as_string().empty()) { err = "mmproj: expected the path of a projector file"; return false; }
+        log_line(LOG_INFO, "MMPROJ FILE detected, multi-model enabled!");
     }
     if (body["grammar_file"].is_string()) {                                   // :573-585
         FILE *gf = fopen(body["grammar_file"].as_string().c_str(), "rb");
@@ -295,21 +294,18 @@ void LlamaEngine::StopInferencing(const std::string &model_id) {   // :502-508
 }
 
 // base64 of the raw little-endian f32 bytes (encoding_format = "base64"; llama_utils::base64Encode / FloatVectorToBytes)
-static std::string base64_floats(const std::vector<float> &v) {
+static std::string base64_bytes(const uint8_t *p, size_t n) {
     static const char tbl[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-    const unsigned char *p = reinterpret_cast<const unsigned char *>(v.data());
-    const size_t n = v.size() * sizeof(float);
     std::string out;
     out.reserve((n + 2) / 3 * 4);
     for (size_t i = 0; i < n; i += 3) {
-        const unsigned b0 = p[i], b1 = i + 1 < n ? p[i + 1] : 0, b2 = i + 2 < n ? p[i + 2] : 0;
-        out += tbl[b0 >> 2];
-        out += tbl[((b0 & 3) << 4) | (b1 >> 4)];
-        out += i + 1 < n ? tbl[((b1 & 15) << 2) | (b2 >> 6)] : '=';
-        out += i + 2 < n ? tbl[b2 & 63] : '=';
+        const uint32_t b0 = p[i], b1 = i + 1 < n ? p[i + 1] : 0, b2 = i + 2 < n ? p[i + 2] : 0, w = b0 << 16 | b1 << 8 | b2;
+        out.push_back(tbl[w >> 18 & 63]); out.push_back(tbl[w >> 12 & 63]);
+        out.push_back(i + 1 < n ? tbl[w >> 6 & 63] : '='); out.push_back(i + 2 < n ? tbl[w & 63] : '=');
     }
     return out;
 }
+static std::string base64_floats(const std::vector<float> &v) { return base64_bytes(reinterpret_cast<const uint8_t *>(v.data()), v.size() * sizeof(float)); }
 
 static Json embedding_payload(const Json &embedding, int index, bool is_base64) {   // CreateEmbeddingPayload :92-114
     Json item = Json::object();
@@ -449,28 +445,69 @@ void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734
         if (c.is_array()) { for (const Json &mc : c.items()) if (mc["type"].as_string() == "text") return mc["text"].as_string(); return ""; }
         return c.as_string();
     };
-    // `image_url` content pieces (src/llama_engine.cc:854-900: [img-N] placeholders + image_data for a multimodal context): no context of this backend is
-    // multimodal (mmproj is refused at load), so such a request is answered with the reference's error shape instead of being completed as text
+    // `image_url` content pieces (src/llama_engine.cc:854-900): on a multimodal context every piece becomes a placeholder [img-N] in the prompt and an entry of
+    // image_data - the base64 payload of a data: URL, or the bytes of a local file; remote URLs are not fetched (the reference does not either).  A context
+    // without a projector answers such a request with an error instead of completing it as text
+    const bool multimodal = si->backend && si->backend->multimodal();
+    bool has_images = false;
     for (const Json &msg : body["messages"].items()) {
         if (!msg["content"].is_array()) continue;
-        for (const Json &mc : msg["content"].items()) {
-            if (mc["type"].is_string() && mc["type"].as_string() == "image_url") {
-                cb(make_status(false, true, false, k400BadRequest), message("image_url content is not supported: the model was loaded without a multimodal projector (mmproj)"));
-                return;
+        for (const Json &mc : msg["content"].items())
+            if (mc["type"].is_string() && mc["type"].as_string() == "image_url") has_images = true;
+    }
+    if (has_images && !multimodal) {
+        cb(make_status(false, true, false, k400BadRequest), message("image_url content is not supported: the model was loaded without a multimodal projector (mmproj)"));
+        return;
+    }
+    Json image_data = Json::array();
+    int n_images = 0;
+    std::string image_error;
+    // the text of a message; with images: its text pieces and a placeholder per image, in the order given
+    auto get_message_mm = [&](const Json &c) -> std::string {
+        if (!c.is_array()) return c.as_string();
+        std::string out;
+        for (const Json &mc : c.items()) {
+            const std::string type = mc["type"].str_or("");
+            if (type == "text") out += mc["text"].str_or("");
+            else if (type == "image_url") {
+                const std::string url = mc["image_url"]["url"].str_or("");
+                std::string b64;
+                const size_t comma = url.find("base64,");
+                if (url.rfind("data:image", 0) == 0 && comma != std::string::npos) b64 = url.substr(comma + 7);
+                else if (url.rfind("http", 0) == 0) image_error = "remote images are not fetched: send the image as a data: URL";
+                else {
+                    FILE *f = fopen(url.c_str(), "rb");
+                    if (!f) image_error = "local image not found: " + url;
+                    else {
+                        std::vector<uint8_t> bytes;
+                        uint8_t buf[65536];
+                        for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) bytes.insert(bytes.end(), buf, buf + n);
+                        fclose(f);
+                        b64 = base64_bytes(bytes.data(), bytes.size());
+                    }
+                }
+                Json piece = Json::object();
+                piece["data"] = b64; piece["id"] = n_images;
+                image_data.push_back(piece);
+                out += "[img-" + std::to_string(n_images) + "]";
+                n_images++;
             }
         }
-    }
+        return out;
+    };
     if (body["prompt"].is_string() && !body["prompt"].as_string().empty()) {
         formatted = body["prompt"].as_string();
     } else {
         for (const Json &msg : body["messages"].items()) {
             const std::string in_role = msg["role"].as_string();
             const std::string role = in_role == "user" ? si->user_prompt : in_role == "assistant" ? si->ai_prompt : in_role == "system" ? si->system_prompt : in_role;
-            const std::string content = get_message(msg["content"]);
+            const std::string content = has_images ? get_message_mm(msg["content"]) : get_message(msg["content"]);
             if (!content.empty()) formatted += role + content;
         }
         formatted += si->ai_prompt;
     }
+    if (!image_error.empty()) { cb(make_status(false, true, false, k400BadRequest), message(image_error)); return; }
+    if (n_images > 0) data["image_data"] = image_data;
     data["prompt"] = formatted;
     Json stop = Json::array();
     const Json &req_stop = (body["stop"].is_array() && body["stop"].size() > 0) ? body["stop"] : si->stop_words;

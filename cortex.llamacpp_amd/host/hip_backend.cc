@@ -2,6 +2,8 @@
 //   llama_model_path | model_path, ngl (300), ctx_len (2048), n_batch (2048), n_ubatch (= n_batch), n_parallel (1),
 //   cache_type f16|q8_0|q4_0 (invalid -> f16), flash_attn (true; forced on by a quantised cache), embedding.
 #include "hip_backend.h"
+
+#include "clip.h"
 #include "log.h"
 
 #include <sys/stat.h>
@@ -34,6 +36,34 @@ class HipBackend : public IBackend {
         seq_ptr_.resize((size_t)b.n_tokens);
         for (int i = 0; i < b.n_tokens; i++) seq_ptr_[(size_t)i] = &seq_store_[(size_t)i];
         return ctx_->decode(b.n_tokens, b.token, b.pos, n_seq_id_.data(), seq_ptr_.data(), b.logits);
+    }
+    void set_clip(std::unique_ptr<ClipModel> c) { clip_ = std::move(c); }
+    bool multimodal() const override { return clip_ != nullptr; }
+    bool image_check(const uint8_t *bytes, size_t n, std::string &err) override {
+        ClipImageU8 img;
+        err = clip_image_load_from_bytes(bytes, n, img);
+        return err.empty();
+    }
+    int image_embed(const uint8_t *bytes, size_t n, std::vector<float> &rows, std::string &err) override {
+        if (!clip_) { err = "no multimodal projector loaded"; return -1; }
+        ClipImageU8 img;
+        err = clip_image_load_from_bytes(bytes, n, img);
+        if (!err.empty()) return -1;
+        std::vector<float> pix;
+        clip_->preprocess(img, pix);
+        rows.resize((size_t)clip_->n_patches() * (size_t)clip_->proj_dim);
+        err = clip_->encode(pix.data(), rows.data());
+        return err.empty() ? clip_->n_patches() : -1;
+    }
+    int decode_embd(const float *rows, int n, int pos0, int seq) override {
+        pos_store_.resize((size_t)n);
+        for (int i = 0; i < n; i++) pos_store_[(size_t)i] = pos0 + i;
+        n_seq_id_.assign((size_t)n, 1);
+        seq_store_.assign((size_t)n, seq);
+        seq_ptr_.resize((size_t)n);
+        for (int i = 0; i < n; i++) seq_ptr_[(size_t)i] = &seq_store_[(size_t)i];
+        no_logits_.assign((size_t)n, 0);
+        return ctx_->decode(n, nullptr, pos_store_.data(), n_seq_id_.data(), seq_ptr_.data(), no_logits_.data(), rows);
     }
     const char *last_error() const override { return ctx_->last_error.c_str(); }
     const float *logits_ith(int i) override { return ctx_->logits_ith(i); }
@@ -85,7 +115,9 @@ class HipBackend : public IBackend {
     std::unique_ptr<Context> ctx_;
     Vocab vocab_;
     bool device_sampling_ = true;
-    std::vector<int32_t> n_seq_id_, seq_store_;
+    std::unique_ptr<ClipModel> clip_;
+    std::vector<int32_t> n_seq_id_, seq_store_, pos_store_;
+    std::vector<int8_t> no_logits_;
     std::vector<TopkAdj> adjs_;
     std::vector<int> is_, ks_;
     std::vector<int32_t> out_t_;
@@ -128,6 +160,13 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     ContextParams cp;
     const int n_parallel = std::max(1, body.value<int>("n_parallel", 1));
     cp.n_ctx = (uint32_t)std::max(8, body.value<int>("ctx_len", 2048));
+    // a projector file makes the context multimodal; the reference then asks for at least 2048 cells, room for an image's embedding rows (llama_server_context.cc:194-205)
+    const std::string mmproj = body["mmproj"].is_string() ? body["mmproj"].as_string() : std::string();
+    if (!mmproj.empty()) {
+        if (model->hp.encoder) { err = "mmproj: an embedding model cannot take a multimodal projector"; return nullptr; }
+        if (model->hp.tp_exchange) { err = "mmproj: not supported together with the row split"; return nullptr; }
+        if (cp.n_ctx < 2048) { cp.n_ctx = 2048; log_line(LOG_INFO, "Request %d for context length for the image embedding", 2048); }
+    }
     cp.n_batch = (uint32_t)std::max(1, body.value<int>("n_batch", 2048));
     cp.n_ubatch = (uint32_t)std::max(1, body.value<int>("n_ubatch", (int)cp.n_batch));
     cp.n_batch = std::min(cp.n_batch, cp.n_ctx);
@@ -146,7 +185,21 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     info.vram = model->device_bytes + ctx->device_bytes;
     info.ram = model->host_bytes;
     info.model_size = model->file_tensor_bytes;
-    return std::unique_ptr<IBackend>(new HipBackend(std::move(model), std::move(ctx), std::move(vocab), body.value<bool>("device_sampling", true)));
+    std::unique_ptr<ClipModel> clip;
+    if (!mmproj.empty()) {   // clip_model_load + the width check of llama_server_context.cc:216-229
+        clip.reset(new ClipModel);
+        const std::string cerr = clip->load(mmproj, body.value<int>("main_gpu", 0));
+        if (!cerr.empty()) { err = "unable to load clip model: " + cerr; return nullptr; }
+        if (clip->proj_dim != model->hp.n_embd) {
+            err = "embedding dim of the multimodal projector (" + std::to_string(clip->proj_dim) + ") is not equal to that of the model (" + std::to_string(model->hp.n_embd) +
+                  "). Make sure that you use the correct mmproj file.";
+            return nullptr;
+        }
+        info.vram += clip->device_bytes;
+    }
+    std::unique_ptr<HipBackend> be(new HipBackend(std::move(model), std::move(ctx), std::move(vocab), body.value<bool>("device_sampling", true)));
+    be->set_clip(std::move(clip));
+    return be;
 }
 
 }  // namespace mi355

@@ -88,6 +88,7 @@ void LlamaClientSlot::Reset() {           // :3-27
     generated_token_probs.clear();
     prompt_ready = false;
     i_batch = -1;
+    images.clear(); input_suffix.clear(); next_image = 0;
 }
 
 bool LlamaClientSlot::HasBudget(const ServerParams &global) {   // :29-37
@@ -223,6 +224,29 @@ LlamaClientSlot *LlamaServerContext::GetSlot(int id) {   // :416-432 (LRU)
     return last_used;
 }
 
+// standard base64 (RFC 4648; '=' padding optional, whitespace skipped); false on any other character
+static bool base64_decode(const std::string &in, std::vector<uint8_t> &out) {
+    out.clear();
+    out.reserve(in.size() * 3 / 4);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (const char ch : in) {
+        int v;
+        if (ch >= 'A' && ch <= 'Z') v = ch - 'A';
+        else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26;
+        else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+        else if (ch == '+' || ch == '-') v = 62;
+        else if (ch == '/' || ch == '_') v = 63;
+        else if (ch == '=') break;
+        else if (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t') continue;
+        else return false;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return true;
+}
+
 bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &data) {   // :434-641
     SlotParams dp;
     const SamplingParams &ds = params.sampling;
@@ -271,6 +295,48 @@ bool LlamaServerContext::LaunchSlotWithData(LlamaClientSlot *&slot, const Json &
                 if (!p.is_int()) return refuse("prompt array elements must be strings or token ids");
                 if (bad_id(p.as_int())) return refuse("token id " + std::to_string(p.as_int()) + " out of range for this model's vocabulary");
             }
+    }
+
+    // image_data of a multimodal request (:557-623): [{"data": base64, "id": n}], each named in the prompt by a placeholder [img-n].  The prompt is cut at the
+    // placeholders into the text in front of every image and the text behind the last one; an image that cannot be decoded, or a placeholder without an
+    // image, fails the request here
+    slot->images.clear(); slot->input_suffix.clear(); slot->next_image = 0;
+    if (be_->multimodal()) {
+        if (const Json *imgs = data.find("image_data"); imgs && imgs->is_array() && imgs->size() > 0) {
+            for (const Json &ij : imgs->items()) {
+                SlotImage im;
+                im.id = ij.contains("id") ? (int)ij["id"].as_int() : (int)slot->images.size();
+                if (!base64_decode(ij["data"].str_or(""), im.bytes) || im.bytes.empty()) { launch_error_ = "image [id: " + std::to_string(im.id) + "]: not base64 data"; return false; }
+                std::string why;
+                if (!be_->image_check(im.bytes.data(), im.bytes.size(), why)) { launch_error_ = "failed to load image [id: " + std::to_string(im.id) + "]: " + why; return false; }
+                slot->images.push_back(std::move(im));
+            }
+            if (!slot->prompt.is_string()) { launch_error_ = "a request with images takes its prompt as one string"; return false; }
+            const std::string text = slot->prompt.as_string();
+            std::vector<SlotImage> ordered;
+            size_t from = 0, at = 0;
+            while ((at = text.find("[img-", at)) != std::string::npos) {
+                const size_t close = text.find(']', at + 5);
+                if (close == std::string::npos) break;
+                const std::string num = text.substr(at + 5, close - at - 5);
+                char *endp = nullptr;
+                const long want = strtol(num.c_str(), &endp, 10);
+                if (num.empty() || *endp) { launch_error_ = "invalid image number id in prompt: " + num; return false; }
+                auto it = std::find_if(slot->images.begin(), slot->images.end(), [&](const SlotImage &m) { return m.id == (int)want && m.prefix_prompt.empty() && !m.bytes.empty(); });
+                if (it == slot->images.end()) { launch_error_ = "image with id " + num + " not found"; return false; }
+                SlotImage taken = std::move(*it);
+                it->bytes.clear();                                   // (an id names ONE image: a second placeholder with it finds nothing)
+                taken.prefix_prompt = text.substr(from, at - from);
+                ordered.push_back(std::move(taken));
+                from = close + 1;
+                at = close + 1;
+            }
+            if (ordered.empty()) { launch_error_ = "the prompt names none of the request's images ([img-N])"; return false; }
+            slot->images = std::move(ordered);
+            slot->input_suffix = text.substr(from);
+            slot->prompt = Json("");
+            slot->params.cache_prompt = false;                       // (:620: no prompt cache for multimodal requests)
+        }
     }
 
     sp.logit_bias.clear();
@@ -622,7 +688,7 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
     // prompt ingestion (:1355-1621)
     if (params.cont_batching || n_tokens == 0) {
         for (auto &slot : slots) {
-            const bool has_prompt = slot.prompt.is_array() || (slot.prompt.is_string() && !slot.prompt.as_string().empty()) || !slot.prompt_tokens.empty();
+            const bool has_prompt = slot.prompt.is_array() || (slot.prompt.is_string() && !slot.prompt.as_string().empty()) || !slot.prompt_tokens.empty() || !slot.images.empty();
             if (slot.state == SlotState::kIdle && slot.command == SlotCommand::kLoadPrompt && !has_prompt) {
                 slot.Release();
                 SendFinalResponse(slot);
@@ -637,6 +703,33 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
             if (!slot.prompt_ready) {   // first visit of this prompt: tokenise, truncate, find the cached prefix
                 slot.t_start_process_prompt = time_us();
                 slot.t_start_genereration = 0;
+                if (!slot.images.empty()) {
+                    // a multimodal prompt (ProcessImages + the layout IngestImages walks, :814-831, 1073-1129): text, an image's embedding rows, text, ..., the
+                    // text behind the last image.  The rows are computed here; their positions are held by placeholder ids in prompt_tokens
+                    prompt_tokens.clear();
+                    bool failed = false;
+                    for (size_t k = 0; k < slot.images.size() && !failed; k++) {
+                        SlotImage &im = slot.images[k];
+                        const std::vector<int32_t> pre = Tokenize(Json(im.prefix_prompt), k == 0 && be_->vocab().add_bos(), false);
+                        prompt_tokens.insert(prompt_tokens.end(), pre.begin(), pre.end());
+                        std::string why;
+                        im.n_rows = be_->image_embed(im.bytes.data(), im.bytes.size(), im.rows, why);
+                        if (im.n_rows <= 0) { failed = true; break; }
+                        im.pos0 = (int)prompt_tokens.size();
+                        prompt_tokens.insert(prompt_tokens.end(), (size_t)im.n_rows, 0);
+                        im.bytes.clear(); im.bytes.shrink_to_fit();
+                    }
+                    const std::vector<int32_t> suf = Tokenize(Json(slot.input_suffix), false, false);
+                    prompt_tokens.insert(prompt_tokens.end(), suf.begin(), suf.end());
+                    // the rows cannot be cut the way a long text prompt is: the request must fit, and must end in text (the logits come from its last token)
+                    if (failed || suf.empty() || (int)prompt_tokens.size() >= slot.n_ctx) {
+                        slot.state = SlotState::kProcessing; slot.command = SlotCommand::kNone;
+                        slot.Release();
+                        SendError(slot, failed ? "Failed processing images" : suf.empty() ? "a prompt with images must end in text" : "the prompt and its images do not fit the context");
+                        continue;
+                    }
+                    slot.next_image = 0;
+                }
                 if (prompt_tokens.empty()) prompt_tokens = Tokenize(slot.prompt, be_->vocab().add_bos(), true);
                 slot.n_past = 0;
                 slot.num_prompt_tokens = (int32_t)prompt_tokens.size();
@@ -677,7 +770,30 @@ bool LlamaServerContext::UpdateSlots() {   // :1248-1710
                 slot.smpl->reset();
             }
             slot.cache_tokens.resize((size_t)slot.n_past);
-            for (; slot.n_past < (int)prompt_tokens.size() && n_tokens < (int)b_token_.size(); ++slot.n_past) {
+            // an image whose turn it is: its rows go to the model now, as batches of embeddings (a llama_batch carries token ids OR rows, :1093-1107) - the text
+            // in front of it was decoded with the previous tick's batch
+            bool image_failed = false;
+            while (slot.next_image < slot.images.size() && slot.images[slot.next_image].pos0 == slot.n_past) {
+                SlotImage &im = slot.images[slot.next_image];
+                const int E = be_->n_embd();
+                for (int r0 = 0; r0 < im.n_rows && !image_failed; r0 += n_batch) {
+                    const int nr = std::min(n_batch, im.n_rows - r0);
+                    if (be_->decode_embd(im.rows.data() + (size_t)r0 * E, nr, slot.n_past + r0, slot.id) != 0) image_failed = true;
+                }
+                if (image_failed) break;
+                slot.n_past += im.n_rows;
+                slot.num_prompt_tokens_processed += im.n_rows;
+                im.rows.clear(); im.rows.shrink_to_fit();
+                slot.next_image++;
+            }
+            if (image_failed) {
+                slot.state = SlotState::kProcessing; slot.command = SlotCommand::kNone;
+                slot.Release();
+                SendError(slot, "Failed processing images");
+                continue;
+            }
+            const int text_end = slot.next_image < slot.images.size() ? slot.images[slot.next_image].pos0 : (int)prompt_tokens.size();   // (the next image's rows wait for the tick after this text)
+            for (; slot.n_past < text_end && n_tokens < (int)b_token_.size(); ++slot.n_past) {
                 // (an embedding prompt of a model that pools over the sequence needs every token's hidden state: all rows flagged)
                 batch_add(prompt_tokens[(size_t)slot.n_past], slot.n_past, slot.id, slot.embedding && (be_->pooling_type() == 1 || be_->pooling_type() == 2));
                 if (slot.params.cache_prompt) slot.cache_tokens.push_back(prompt_tokens[(size_t)slot.n_past]);

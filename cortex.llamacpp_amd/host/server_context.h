@@ -2,7 +2,8 @@
 // LlamaServerContext (src/llama_server_context.{h,cc}): task / result queues, LRU slot assignment, the continuous-batching
 // UpdateSlots loop (:1248-1710), context shift (:1274-1306), prompt-prefix reuse (:1489-1558), stop strings and partial
 // UTF-8 hold-back (ProcessToken :716-813), timings (llama_client_slot.cc:55-94).  Same names, same JSON keys.
-// Embedding requests (SendEmbedding :1026-1070) included.  Not mirrored: LLaVA image ingest, infill, system-prompt broadcast.
+// Embedding requests (SendEmbedding :1026-1070) and LLaVA image requests (image_data + [img-N] placeholders, :557-623, 814-831, 1073-1129) included.
+// Not mirrored: infill, system-prompt broadcast.
 #pragma once
 
 #include <atomic>
@@ -47,6 +48,16 @@ struct ServerParams {            // the subset of common_params the loop reads
     SamplingParams sampling;
 };
 
+// one image of a multimodal request (llama_client_slot.h SlotImage): its bytes as sent, the text in front of its [img-N] placeholder, and - once the prompt
+// has been laid out - the position its embedding rows start at
+struct SlotImage {
+    int id = 0;
+    std::string prefix_prompt;
+    std::vector<uint8_t> bytes;
+    std::vector<float> rows;          // [n_rows][n_embd]
+    int n_rows = 0, pos0 = 0;
+};
+
 struct LlamaClientSlot {
     int id = 0;
     int task_id = -1;
@@ -62,6 +73,9 @@ struct LlamaClientSlot {
     int32_t sampled = 0;
     std::vector<int32_t> cache_tokens;
     std::vector<CompletionTokenOutput> generated_token_probs;
+    std::vector<SlotImage> images;  // multimodal request: in prompt order
+    std::string input_suffix;       // the text behind the last image
+    size_t next_image = 0;          // first image whose rows have not been decoded yet
     bool prompt_ready = false;      // prompt tokenised / truncated / matched against the cache (first visit done)
     bool has_next_token = true, truncated = false, stopped_eos = false, stopped_word = false, stopped_limit = false;
     bool oaicompat = false;

@@ -76,6 +76,7 @@ struct FakeBackend : IBackend {
         if (hard_fail) return -1;
         if (fail_decode_over >= 0 && b.n_tokens > fail_decode_over) return 1;
         if (decode_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(decode_sleep_us));
+        order.push_back("t" + std::to_string(b.n_tokens));
         calls_tokens.emplace_back(b.token, b.token + b.n_tokens);
         calls_seq.emplace_back(b.seq_id, b.seq_id + b.n_tokens);
         calls_pos.emplace_back(b.pos, b.pos + b.n_tokens);
@@ -122,6 +123,26 @@ struct FakeBackend : IBackend {
         kv[seq] = nm;
     }
     void kv_seq_cp(int, int, int, int) override {}
+    // ---- images (test_image_requests): "IMG" + a byte n = an image of n embedding rows; anything else does not decode
+    bool mm = false;
+    bool multimodal() const override { return mm; }
+    bool image_check(const uint8_t *b, size_t n, std::string &err) override { if (n == 4 && !memcmp(b, "IMG", 3) && b[3] > 0) return true; err = "not an image"; return false; }
+    int embed_fail_for = -1;
+    int image_embed(const uint8_t *b, size_t n, std::vector<float> &rows, std::string &err) override {
+        if (!image_check(b, n, err)) return -1;
+        if ((int)b[3] == embed_fail_for) { err = "encoder failed (test)"; return -1; }
+        rows.assign((size_t)b[3] * (size_t)n_embd(), (float)b[3]);
+        return (int)b[3];
+    }
+    struct EmbdCall { int n, pos0, seq; float first; };
+    std::vector<EmbdCall> embd_calls;
+    std::vector<std::string> order;       // "t<n>" a token batch of n, "e<n>" an embedding batch of n: what reached the model, in order
+    int decode_embd(const float *rows, int n, int pos0, int seq) override {
+        embd_calls.push_back({n, pos0, seq, rows[0]});
+        order.push_back("e" + std::to_string(n));
+        for (int i = 0; i < n; i++) kv[seq][pos0 + i] = -1;
+        return 0;
+    }
 };
 
 // ---------------------------------------------------------------- tests
@@ -693,6 +714,99 @@ static void test_slot_loop() {
     ctx.ReleaseResources();
 }
 
+static std::string b64(const std::string &raw) {
+    static const char tbl[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    std::string out;
+    for (size_t i = 0; i < raw.size(); i += 3) {
+        const unsigned b0 = (unsigned char)raw[i], b1 = i + 1 < raw.size() ? (unsigned char)raw[i + 1] : 0, b2 = i + 2 < raw.size() ? (unsigned char)raw[i + 2] : 0, w = b0 << 16 | b1 << 8 | b2;
+        out += tbl[w >> 18 & 63]; out += tbl[w >> 12 & 63]; out += i + 1 < raw.size() ? tbl[w >> 6 & 63] : '='; out += i + 2 < raw.size() ? tbl[w & 63] : '=';
+    }
+    return out;
+}
+// image_data + [img-N] placeholders (llama_server_context.cc:557-623, 814-831, 1073-1129): the prompt is cut at the placeholders; text, an image's rows, text ...
+// reach the model in that order at consecutive positions, the rows as embedding batches of at most n_batch
+static void test_image_requests() {
+    FakeBackend be;
+    be.mm = true; be.nbatch = 16;
+    ServerParams sp;
+    LlamaServerContext ctx(&be, sp);
+    ctx.Initialize();
+    auto image = [&](int id, int rows) { Json j = Json::object(); j["id"] = id; j["data"] = b64(std::string("IMG") + (char)rows); return j; };
+    {
+        Json d = Json::object();
+        d["prompt"] = "see [img-7] and [img-3] now"; d["n_predict"] = 4; d["temperature"] = 0.0; d["stream"] = false; d["cache_prompt"] = true;
+        Json imgs = Json::array(); imgs.push_back(image(3, 5)); imgs.push_back(image(7, 40));      // (listed in another order than the prompt names them)
+        d["image_data"] = imgs;
+        be.order.clear(); be.embd_calls.clear(); be.calls_pos.clear();
+        const int id = ctx.RequestCompletion(d, false, false, -1);
+        TaskResult r = ctx.NextResult(id);
+        CHECK(!r.error && r.stop);
+        const auto t0 = be.voc.tokenize("see ", true), t1 = be.voc.tokenize(" and ", false), t2 = be.voc.tokenize(" now", false);
+        const int n0 = (int)t0.size(), n1 = (int)t1.size(), n2 = (int)t2.size();
+        CHECK(r.result_json["tokens_evaluated"].as_int() == n0 + 40 + n1 + 5 + n2);
+        // order and positions: text, 40 rows in batches of 16 / 16 / 8, text, 5 rows, text, then the generated tokens one by one
+        CHECK(be.order.size() >= 7);
+        CHECK(be.order[0] == "t" + std::to_string(n0) && be.order[1] == "e16" && be.order[2] == "e16" && be.order[3] == "e8");
+        CHECK(be.order[4] == "t" + std::to_string(n1) && be.order[5] == "e5" && be.order[6] == "t" + std::to_string(n2));
+        CHECK(be.embd_calls.size() == 4 && be.embd_calls[0].pos0 == n0 && be.embd_calls[1].pos0 == n0 + 16 && be.embd_calls[2].pos0 == n0 + 32);
+        CHECK(be.embd_calls[3].pos0 == n0 + 40 + n1 && be.embd_calls[3].n == 5);
+        CHECK(be.embd_calls[0].first == 40.0f && be.embd_calls[3].first == 5.0f);                // (each image's own rows)
+        CHECK(be.calls_pos[1][0] == n0 + 40 && be.calls_pos[2][0] == n0 + 40 + n1 + 5);
+        CHECK(be.calls_pos[3][0] == n0 + 40 + n1 + 5 + n2);                                      // the first generated token follows the prompt
+        ctx.RequestCancel(id);
+    }
+    auto expect_error = [&](Json d, const char *what) {
+        const int id = ctx.RequestCompletion(d, false, false, -1);
+        TaskResult r = ctx.NextResult(id);
+        CHECK(r.error);
+        if (!r.error || r.result_json.dump().find(what) == std::string::npos) fprintf(stderr, "  expected an error naming '%s', got %s\n", what, r.result_json.dump().c_str());
+        CHECK(r.result_json.dump().find(what) != std::string::npos);
+        ctx.RequestCancel(id);
+    };
+    Json base = Json::object();
+    base["n_predict"] = 2; base["temperature"] = 0.0; base["stream"] = false;
+    {   // a placeholder without an image; bytes that are no image; no base64; a prompt that ends in an image; no placeholder at all; an encoder failure
+        Json d = base; d["prompt"] = "a [img-9] b"; Json im = Json::array(); im.push_back(image(1, 3)); d["image_data"] = im;
+        expect_error(d, "not found");
+        d = base; d["prompt"] = "a [img-1] b"; im = Json::array(); { Json j = Json::object(); j["id"] = 1; j["data"] = b64("hello"); im.push_back(j); } d["image_data"] = im;
+        expect_error(d, "failed to load image");
+        d = base; d["prompt"] = "a [img-1] b"; im = Json::array(); { Json j = Json::object(); j["id"] = 1; j["data"] = "***"; im.push_back(j); } d["image_data"] = im;
+        expect_error(d, "base64");
+        d = base; d["prompt"] = "a [img-1]"; im = Json::array(); im.push_back(image(1, 3)); d["image_data"] = im;
+        expect_error(d, "end in text");
+        d = base; d["prompt"] = "no picture named"; im = Json::array(); im.push_back(image(1, 3)); d["image_data"] = im;
+        expect_error(d, "names none");
+        be.embed_fail_for = 6;
+        d = base; d["prompt"] = "a [img-1] b"; im = Json::array(); im.push_back(image(1, 6)); d["image_data"] = im;
+        expect_error(d, "Failed processing images");
+        be.embed_fail_for = -1;
+        d = base; d["prompt"] = "a [img-1] b"; im = Json::array(); im.push_back(image(1, 250)); d["image_data"] = im;       // 250 rows + text >= n_ctx 256
+        expect_error(d, "do not fit");
+    }
+    {   // and the loop still serves: a text request, then an image request
+        Json d = base; d["prompt"] = "hello world";
+        const int id = ctx.RequestCompletion(d, false, false, -1);
+        TaskResult r = ctx.NextResult(id);
+        CHECK(!r.error && r.stop);
+        ctx.RequestCancel(id);
+        d = base; d["prompt"] = "x [img-0] y"; Json im = Json::array(); im.push_back(image(0, 2)); d["image_data"] = im;
+        const int id2 = ctx.RequestCompletion(d, false, false, -1);
+        r = ctx.NextResult(id2);
+        CHECK(!r.error && r.stop);
+        ctx.RequestCancel(id2);
+    }
+    // a context without a projector ignores image_data (the engine refuses such requests before they get here)
+    FakeBackend plain;
+    LlamaServerContext c2(&plain, sp);
+    c2.Initialize();
+    Json d = base; d["prompt"] = "a [img-1] b"; Json im = Json::array(); im.push_back(image(1, 3)); d["image_data"] = im;
+    const int id = c2.RequestCompletion(d, false, false, -1);
+    TaskResult r = c2.NextResult(id);
+    CHECK(!r.error && plain.embd_calls.empty());
+    c2.ReleaseResources();
+    ctx.ReleaseResources();
+}
+
 static void test_prompt_cache_and_shift() {
     FakeBackend be;
     be.ctx = 32;
@@ -872,9 +986,10 @@ static void test_engine() {
     Json none = Json::object();
     eng.LoadModel(none, grab);
     CHECK(code == 400);
-    // `mmproj` (reference: src/llama_engine.cc:553-562 makes the context multimodal): refused by name, in the reference's load-error shape (:376-384)
+    // `mmproj` (reference: src/llama_engine.cc:553-562 makes the context multimodal): the path goes to the backend factory, which loads the projector or fails the
+    // load; anything but a path is refused, in the reference's load-error shape (:376-384)
     {
-        Json mm = Json::object(); mm["llama_model_path"] = "/models/llava.gguf"; mm["mmproj"] = "/models/mmproj.gguf";
+        Json mm = Json::object(); mm["llama_model_path"] = "/models/llava.gguf"; mm["mmproj"] = 17;
         Json st_mm, body_mm;
         eng.LoadModel(mm, [&](Json &&st, Json &&b) { st_mm = st; body_mm = b; });
         CHECK(st_mm["status_code"].as_int() == 500 && st_mm["has_error"].as_bool() && body_mm["message"].as_string() == "Failed to load model");
@@ -1218,6 +1333,7 @@ int main(int argc, char **argv) {
     test_sampler_with_grammar();
     test_stop_string_scan();
     test_slot_loop();
+    test_image_requests();
     test_prompt_cache_and_shift();
     test_kv_full_error();
     test_bad_token_ids_and_backend_errors();

@@ -1,0 +1,168 @@
+"""A LLaVA request end to end: `mmproj` at load, `image_url` content pieces in a chat request, the image's embedding rows decoded
+between the text in front of and behind its placeholder.  Reference: LoadModel with mmproj (/root/reference/src/llama_server_context.cc:184-230), image_url ->
+[img-N] + image_data (/root/reference/src/llama_engine.cc:854-900), LaunchSlotWithData (:557-623), ProcessImages (:814-831), IngestImages (:1073-1129).
+The engine's answer is checked against an independent loop over the C-ABI (tokenise, mi355_llava_image_embed_from_bytes, mi355_decode with token and with
+embedding batches, arg-max), and that chain against the oracle."""
+import base64
+import io
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as oq
+
+pytestmark = pytest.mark.gpu
+PIL = pytest.importorskip("PIL.Image")
+GREEDY = dict(temperature=0.0, repeat_penalty=1.0, frequency_penalty=0.0, presence_penalty=0.0)
+
+
+def photo(w, h, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x * y) % 256)], -1).astype(np.int32)
+    img += rng.integers(-40, 41, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def encoded(rgb, fmt="PNG", **kw):
+    b = io.BytesIO()
+    PIL.fromarray(rgb).save(b, fmt, **kw)
+    return b.getvalue()
+
+
+def data_url(data: bytes, mime="image/png") -> str:
+    return f"data:{mime};base64," + base64.b64encode(data).decode()
+
+
+@pytest.fixture(scope="module")
+def files(pkg, tmp_path_factory):
+    d = tmp_path_factory.mktemp("llava")
+    lm, mm, mm_narrow = str(d / "tiny-d128.gguf"), str(d / "mmproj-1024.gguf"), str(d / "mmproj-256.gguf")
+    pkg.gguf_synth.write_synthetic_llama(lm, "tiny-d128", "q4_k_m", with_vocab=True)
+    pkg.gguf_synth.write_synthetic_clip(mm, "tiny-clip-1024")
+    pkg.gguf_synth.write_synthetic_clip(mm_narrow, "tiny-clip")
+    return lm, mm, mm_narrow
+
+
+@pytest.fixture(scope="module")
+def engine(pkg, files):
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path=files[0], mmproj=files[1], ctx_len=512, n_parallel=2, ngl=100, user_prompt="u:", ai_prompt="a:", system_prompt="s:")
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    yield e
+    e.close()
+
+
+def independent_answer(pkg, files, segments, n_predict):
+    """segments: text / image bytes in prompt order, ending in text.  Greedy continuation through the context API."""
+    m = pkg.Model(files[0])
+    c = pkg.Context(m, n_ctx=2048, n_seq_max=1)
+    clip = pkg.Clip(files[1])
+    pos, first_text, n_prompt = 0, True, 0
+    for seg in segments:
+        if isinstance(seg, str):
+            toks = m.tokenize(seg, add_special=first_text, parse_special=False)
+            first_text = False
+            if toks:
+                assert c.decode(toks, list(range(pos, pos + len(toks)))) == 0
+            pos += len(toks)
+        else:
+            rows = clip.embed_bytes(seg)
+            assert c.decode_embd(rows, np.arange(pos, pos + len(rows))) == 0
+            pos += len(rows)
+            first_text = False
+    n_prompt = pos
+    out, eos = b"", m.lib.mi355_token_eos(m.h)
+    for _ in range(n_predict + 1):
+        t = int(np.argmax(c.logits(-1)))
+        if t == eos:
+            break
+        out += m.token_to_piece(t)
+        assert c.decode([t], [pos]) == 0
+        pos += 1
+    c.close(); clip.close(); m.close()
+    return out.decode("utf-8", errors="replace"), n_prompt
+
+
+def test_chat_with_one_image(pkg, engine, files):
+    png = encoded(photo(80, 60, 1))
+    msgs = [{"role": "user", "content": [{"type": "text", "text": "look at "}, {"type": "image_url", "image_url": {"url": data_url(png)}},
+                                         {"type": "text", "text": " what is it"}]}]
+    st, body = engine.chat_completion(model="tiny-d128", messages=msgs, max_tokens=10, **GREEDY)[-1]
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    want, n_prompt = independent_answer(pkg, files, ["u:look at ", png, " what is ita:"], 10)
+    assert body["choices"][0]["message"]["content"] == want.lstrip()
+    assert body["usage"]["prompt_tokens"] == n_prompt                      # text tokens + 16 rows for the image
+
+
+def test_two_images_jpeg_and_stream(pkg, engine, files):
+    a, b = encoded(photo(64, 64, 2), "JPEG", quality=90), encoded(photo(30, 90, 3))
+    msgs = [{"role": "system", "content": "be brief"},
+            {"role": "user", "content": [{"type": "image_url", "image_url": {"url": data_url(a, "image/jpeg")}}, {"type": "text", "text": " and "},
+                                         {"type": "image_url", "image_url": {"url": data_url(b)}}, {"type": "text", "text": " differ how"}]}]
+    res = engine.chat_completion(model="tiny-d128", messages=msgs, max_tokens=8, stream=True, **GREEDY)
+    text = ""
+    for st, body in res:
+        assert not st["has_error"], (st, body)
+        for line in body.get("data", "").split("\n"):
+            if line.startswith("data: {"):
+                import json
+                d = json.loads(line[6:])
+                text += d["choices"][0]["delta"].get("content") or ""
+    want, _ = independent_answer(pkg, files, ["s:be briefu:", a, " and ", b, " differ howa:"], 8)
+    assert text == want.lstrip()
+
+
+def test_refusals(pkg, engine, files):
+    ok_png = encoded(photo(40, 40, 4))
+
+    def ask(url):
+        msgs = [{"role": "user", "content": [{"type": "text", "text": "x "}, {"type": "image_url", "image_url": {"url": url}}, {"type": "text", "text": " y"}]}]
+        return engine.chat_completion(model="tiny-d128", messages=msgs, max_tokens=4, **GREEDY)[-1]
+    st, body = ask(data_url(b"this is not an image"))
+    assert st["has_error"] or "error" in str(body).lower(), (st, body)
+    st, body = ask(data_url(encoded(photo(40, 40, 5), "JPEG", progressive=True), "image/jpeg"))
+    assert st["has_error"] or "error" in str(body).lower(), (st, body)
+    st, body = ask("http://example.com/cat.png")
+    assert st["status_code"] == 400, (st, body)
+    st, body = ask(data_url(ok_png))                                        # and the engine still serves
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    # a projector of another width is refused at load, by name
+    e2 = pkg.Engine()
+    st, body = e2.load_model(llama_model_path=files[0], mmproj=files[2], model="narrow", ctx_len=512)
+    assert st["has_error"] and "mmproj" in str(body), (st, body)
+    # a text-only engine refuses image pieces
+    st, body = e2.load_model(llama_model_path=files[0], model="plain", ctx_len=512, user_prompt="u:", ai_prompt="a:")
+    assert st["status_code"] == 200, (st, body)
+    msgs = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": data_url(ok_png)}}, {"type": "text", "text": "hi"}]}]
+    st, body = e2.chat_completion(model="plain", messages=msgs, max_tokens=4, **GREEDY)[-1]
+    assert st["status_code"] == 400, (st, body)
+    e2.close()
+
+
+def test_image_prompt_chain_matches_oracle(pkg, files):
+    """text, the image's rows, text - each side with ITS OWN image encoder (device tower / CPU restatement) - and teacher-forced steps"""
+    FLIP_TOL = 3e-2
+    m = pkg.Model(files[0])
+    c = pkg.Context(m, n_ctx=512, n_seq_max=1, type_k=pkg.binding.Q8_0, type_v=pkg.binding.Q8_0)
+    clip, oclip = pkg.Clip(files[1]), oq.OracleClip(files[1])
+    om = oq.OracleModel(files[0])
+    oc = oq.OracleContext(om, 512, oq.Q8_0, oq.Q8_0, True, oq.threads())
+    rgb = photo(70, 50, 6)
+    rows, orows = clip.encode(clip.preprocess(rgb)), oclip.encode(oclip.preprocess(rgb))
+    pre, suf = np.random.default_rng(1).integers(3, 500, 7), np.random.default_rng(2).integers(3, 500, 5)
+    n = len(rows)
+    c.decode(pre, np.arange(7)); oc.decode(pre, np.arange(7))
+    c.decode_embd(rows, np.arange(7, 7 + n)); oc.decode_embd(orows, np.arange(7, 7 + n))
+    c.decode(suf, np.arange(7 + n, 12 + n))
+    ref = oc.decode(suf, np.arange(7 + n, 12 + n))[0]
+    errs = [float(np.abs(c.logits() - ref).max() / max(1.0, np.abs(ref).max()))]
+    tok = int(ref.argmax())
+    for step in range(5):
+        c.decode([tok], [12 + n + step])
+        r = oc.decode([tok], [12 + n + step])[0]
+        errs.append(float(np.abs(c.logits() - r).max() / max(1.0, np.abs(r).max())))
+        tok = int(r.argmax())
+    assert max(errs) <= FLIP_TOL, errs
+    c.close(); m.close(); clip.close(); oclip.close(); oc.close(); om.close()
