@@ -18,6 +18,9 @@
 namespace mi355 {
 namespace {
 
+// the bytes come from a request: a header may not make the server allocate gigabytes (48 M pixels = an 8000 x 6000 photograph; the tower sees 336 x 336 of it)
+constexpr int64_t MAX_PIXELS = 48ll << 20;
+
 // ------------------------------------------------------------------------------------------------ inflate
 struct BitReader {
     const uint8_t *p, *end;
@@ -163,7 +166,7 @@ std::string load_png(const uint8_t *d, size_t n, ClipImageU8 &out) {
         else if (!memcmp(tag, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || w <= 0 || h <= 0 || w > 16384 || h > 16384) return "PNG: bad dimensions";
+    if (!have_ihdr || w <= 0 || h <= 0 || w > 16384 || h > 16384 || (int64_t)w * h > MAX_PIXELS) return "PNG: bad dimensions";
     if (interlace) return "PNG: interlaced images are not supported";
     int ch;
     switch (ctype) {
@@ -226,7 +229,7 @@ std::string load_bmp(const uint8_t *d, size_t n, ClipImageU8 &out) {
     if (hsz < 40 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3) || w <= 0 || h == 0 || w > 16384) return "BMP: only uncompressed 24 / 32-bit images are supported";
     const bool top_down = h < 0;
     if (top_down) h = -h;
-    if (h > 16384) return "BMP: bad dimensions";
+    if (h > 16384 || (int64_t)w * h > MAX_PIXELS) return "BMP: bad dimensions";
     const size_t stride = (((size_t)w * bpp / 8) + 3) & ~(size_t)3;
     if ((size_t)off + stride * (size_t)h > n) return "BMP: truncated pixel data";
     out.nx = w; out.ny = h; out.rgb.resize((size_t)3 * w * h);
@@ -255,7 +258,7 @@ std::string load_pnm(const uint8_t *d, size_t n, ClipImageU8 &out) {
     if (got < 3 || pos >= n) return "PNM: bad header";
     pos++;                                                       // the single whitespace byte behind maxval
     const int w = vals[0], h = vals[1];
-    if (w <= 0 || h <= 0 || w > 16384 || h > 16384 || vals[2] <= 0 || vals[2] > 255) return "PNM: unsupported dimensions or maxval";
+    if (w <= 0 || h <= 0 || w > 16384 || h > 16384 || (int64_t)w * h > MAX_PIXELS || vals[2] <= 0 || vals[2] > 255) return "PNM: unsupported dimensions or maxval";
     if (pos + (size_t)w * h * ch > n) return "PNM: truncated pixel data";
     out.nx = w; out.ny = h; out.rgb.resize((size_t)3 * w * h);
     for (size_t i = 0; i < (size_t)w * h; i++)
@@ -385,7 +388,7 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
             if (sl < 6 || s[0] != 8) return "JPEG: only 8-bit samples are supported";
             H = s[1] << 8 | s[2]; W = s[3] << 8 | s[4];
             const int nc = s[5];
-            if ((nc != 1 && nc != 3) || sl < (size_t)6 + 3 * nc || W <= 0 || H <= 0 || W > 16384 || H > 16384) return "JPEG: unsupported frame";
+            if ((nc != 1 && nc != 3) || sl < (size_t)6 + 3 * nc || W <= 0 || H <= 0 || W > 16384 || H > 16384 || (int64_t)W * H > MAX_PIXELS) return "JPEG: unsupported frame";
             comps.resize((size_t)nc);
             for (int i = 0; i < nc; i++) {
                 comps[i].id = s[6 + 3 * i]; comps[i].h = s[7 + 3 * i] >> 4; comps[i].v = s[7 + 3 * i] & 15; comps[i].tq = s[8 + 3 * i];

@@ -108,3 +108,30 @@ def test_refusals(pkg):
         decode(pkg, b"GIF89a" + bytes(64))
     with pytest.raises(RuntimeError):
         decode(pkg, raw[:8] + bytes(100))
+
+
+def test_decoders_survive_mutated_files_under_sanitizers(tmp_path):
+    """The bytes come from requests.  host/image_decode.cc built with AddressSanitizer + UBSan; every sample file and 400 seeded mutations of each (bit flips,
+    truncations, garbage runs, 0xff runs over length fields, insertions, zero runs) must come back as an image or as a refusal - no out-of-bounds access, no
+    overflow, no crash."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "image_fuzz")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(root, "cortex.llamacpp_amd", "host"),
+                    os.path.join(root, "tests", "host", "image_fuzz.cc"), os.path.join(root, "cortex.llamacpp_amd", "host", "image_decode.cc"), "-o", exe], check=True)
+    files = []
+    a = picture(61, 47, 3)
+    for name, fmt, mode, kw in [("rgb.png", "PNG", "RGB", {}), ("pal.png", "PNG", "P", {}), ("la.png", "PNG", "LA", {}), ("bit.png", "PNG", "1", {}), ("stored.png", "PNG", "RGB", {"compress_level": 0}),
+                                ("q90.jpg", "JPEG", "RGB", {"quality": 90, "subsampling": 0}), ("q70_420.jpg", "JPEG", "RGB", {"quality": 70, "subsampling": 2}),
+                                ("grey.jpg", "JPEG", "L", {"quality": 80}), ("rst.jpg", "JPEG", "RGB", {"quality": 85, "restart_marker_blocks": 2}),
+                                ("refuse_progressive.jpg", "JPEG", "RGB", {"progressive": True}), ("x.bmp", "BMP", "RGB", {}), ("x.ppm", "PPM", "RGB", {}), ("x.pgm", "PPM", "L", {})]:
+        p = str(tmp_path / name)
+        PIL.fromarray(a).convert(mode).save(p, fmt, **kw)
+        files.append(p)
+    r = subprocess.run([exe, "400"] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "mutations decoded" in r.stdout
