@@ -7,6 +7,7 @@
 // a17 of SURVEY.md §8a.  Quantised codes and scales are bit-identical to the CPU restatement; only the
 // f64 sum-of-squares is tree-ordered instead of sequential.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "quant_dev.h"
@@ -65,6 +66,101 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float *__restrict
     }
 }
 
+// Prompt batches (hundreds of rows): ONE wave per 256-block, up to 16 waves per workgroup, the block in registers from the first load to the codes - the kernel above
+// reads a row twice (scale, then quantise) and walks a wave through its blocks one after the other, 7.8 us per launch at 512 x 4096 where the data moves in 3.
+// do_norm: the row's sum of squares must come out with the bits of the kernel above (whose thread tid adds the squares of float4 tid, tid + 256, tid + 512 ..
+// to ONE double, element by element): every thread leaves its products in LDS and the first 256 threads add them up in exactly that order, then the same wave sums
+// and the same four partial sums.  grid = (rows, parts): a part is 16 blocks of the row; do_norm needs the whole row in one workgroup (n <= 16 * 256 * NV).
+template <int NV>
+__global__ __launch_bounds__(1024) void norm_quant_wide_kernel(const float *__restrict__ x, const float *__restrict__ w, int n, float eps, int do_norm,
+                                                                float *__restrict__ yf, ActQuant q, int want_q8k, int want_q80, int8_t *__restrict__ bh, int8_t *__restrict__ bl) {
+    extern __shared__ float prod[];                       // do_norm: [n] squares, float4 index major
+    __shared__ double red[4];
+    __shared__ float s_scale;
+    const int row = blockIdx.x, u = threadIdx.x, lane = u & 63, wave = u >> 6, nw = blockDim.x >> 6;
+    const int nblk = n >> 8;
+    const float *xr = x + (size_t)row * n;
+    float4 v[NV];
+    int blk[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        blk[j] = (do_norm ? 0 : blockIdx.y * 16 * NV) + wave + nw * j;
+        const int bc = blk[j] < nblk ? blk[j] : nblk - 1;
+        v[j] = *reinterpret_cast<const float4 *>(xr + bc * 256 + lane * 4);
+    }
+    float scale = 1.0f;
+    if (do_norm) {
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            if (blk[j] < nblk) *reinterpret_cast<float4 *>(prod + ((size_t)blk[j] * 64 + lane) * 4) = float4{v[j].x * v[j].x, v[j].y * v[j].y, v[j].z * v[j].z, v[j].w * v[j].w};
+        __syncthreads();
+        if (u < 256) {
+            double s = 0.0;
+            for (int i4 = u; i4 < (n >> 2); i4 += 256) {
+                const float4 p = *reinterpret_cast<const float4 *>(prod + (size_t)i4 * 4);
+                s += (double)p.x; s += (double)p.y; s += (double)p.z; s += (double)p.w;
+            }
+            s = wave_sum(s);
+            if (lane == 0) red[wave] = s;
+        }
+        __syncthreads();
+        if (u == 0) {
+            const double tot = red[0] + red[1] + red[2] + red[3];
+            const float mean = (float)(tot / (double)n);
+            s_scale = 1.0f / sqrtf(mean + eps);
+        }
+        __syncthreads();
+        scale = s_scale;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int b = blk[j];
+        if (b >= nblk) continue;                           // wave-uniform
+        const int e0 = b * 256 + lane * 4;
+        float4 t = v[j];
+        if (do_norm) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + e0);
+            t.x = (t.x * scale) * ww.x; t.y = (t.y * scale) * ww.y; t.z = (t.z * scale) * ww.z; t.w = (t.w * scale) * ww.w;
+        }
+        if (yf) *reinterpret_cast<float4 *>(yf + (size_t)row * n + e0) = t;
+        const float vv[4] = {t.x, t.y, t.z, t.w};
+        if (want_q8k) {
+            uint32_t packed; int bs; float dq;
+            wave_quant_q8k(vv, lane, packed, bs, dq);
+            *reinterpret_cast<uint32_t *>(q.qs + (size_t)row * n + e0) = packed;
+            if ((lane & 3) == 0) {
+                const size_t bi = (size_t)row * (n >> 4) + b * 16 + (lane >> 2);
+                q.bsums[bi] = (int16_t)bs;
+                if (bh) { const int hi = bs >> 6; bh[bi] = (int8_t)hi; bl[bi] = (int8_t)(bs - 64 * hi); }
+            }
+            if (lane == 0) q.d[(size_t)row * nblk + b] = dq;
+        }
+        if (want_q80) {
+            uint32_t packed; float d;
+            wave_quant_q80(vv, packed, d);
+            *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)row * n + e0) = packed;
+            if ((lane & 7) == 0) q.d0[(size_t)row * (n >> 5) + b * 8 + (lane >> 3)] = f2h(d);
+        }
+    }
+}
+// true: launched.  Rows of a prompt batch only (T >= 32); with the norm the row must fit one workgroup
+static bool launch_wide(const float *x, const float *w, int n, int T, float eps, int do_norm, float *yf, const ActQuant &qq, int k, int z, int8_t *bh, int8_t *bl, hipStream_t st) {
+    static const bool off = getenv("MI355_QUANT_WIDE") && getenv("MI355_QUANT_WIDE")[0] == '0';
+    const int nblk = n >> 8;
+    if (off || T < 32 || (n & 255) || nblk < 1) return false;
+    if (do_norm) {
+        if (nblk > 32 || (n & 1023)) return false;
+        const int nv = nblk > 16 ? 2 : 1, nwv = (nblk + nv - 1) / nv;
+        const size_t lds = (size_t)n * sizeof(float);
+        if (nv == 1) hipLaunchKernelGGL(norm_quant_wide_kernel<1>, dim3(T, 1), dim3(64 * nwv), lds, st, x, w, n, eps, 1, yf, qq, k, z, bh, bl);
+        else hipLaunchKernelGGL(norm_quant_wide_kernel<2>, dim3(T, 1), dim3(64 * nwv), lds, st, x, w, n, eps, 1, yf, qq, k, z, bh, bl);
+        return true;
+    }
+    const int parts = (nblk + 15) / 16, nwv = nblk < 16 ? nblk : 16;
+    hipLaunchKernelGGL(norm_quant_wide_kernel<1>, dim3(T, parts), dim3(64 * nwv), 0, st, x, w, n, eps, 0, yf, qq, k, z, bh, bl);
+    return true;
+}
+
 // workgroups per row: a wave quantises the blocks b, b + 4 * splits, .. of its row, one after the other - a chain of wave-level steps per block that waits on
 // itself - so a row of 16 .. 56 blocks is cut until a wave holds one or two of them (the row scale is re-derived per workgroup: the row sits in L2)
 #ifndef MI355_QUANT_SPLIT_BLOCKS
@@ -83,6 +179,7 @@ hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, fl
                                 const ActQuant *q, bool want_q8k, bool want_q80, hipStream_t st, int8_t *bh, int8_t *bl) {
     ActQuant qq;
     if (q) qq = *q;
+    if (launch_wide(x, w, n, T, eps, 1, y_f32, qq, (int)(q && want_q8k), (int)(q && want_q80), (q && want_q8k) ? bh : nullptr, bl, st)) return hipGetLastError();
     const int splits = quant_splits(T, n);
     hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, w, n, eps, 1, y_f32, qq,
                        (int)(q && want_q8k), (int)(q && want_q80), (q && want_q8k) ? bh : nullptr, bl);
@@ -90,6 +187,7 @@ hipError_t launch_rmsnorm_quant(const float *x, const float *w, int n, int T, fl
 }
 
 hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st, int8_t *bh, int8_t *bl) {
+    if (launch_wide(x, nullptr, n, T, 0.0f, 0, nullptr, q, (int)want_q8k, (int)want_q80, want_q8k ? bh : nullptr, bl, st)) return hipGetLastError();
     const int splits = quant_splits(T, n);
     hipLaunchKernelGGL(norm_quant_kernel, dim3(T, splits), dim3(256), 0, st, x, (const float *)nullptr, n, 0.0f, 0,
                        (float *)nullptr, q, (int)want_q8k, (int)want_q80, want_q8k ? bh : nullptr, bl);
