@@ -843,6 +843,66 @@ hipError_t launch_flash_attn_decode_fused(const AttnArgs &a, const float *cs_tab
     return hipGetLastError();
 }
 
+// The same merge with ONE wave per 256-element block of the output row, for prompt batches (round 5): the kernel above spends a 256-thread workgroup, three
+// barrier phases and an LDS round trip on 3 KB of data - 8192 such workgroups for a 512-token prompt, 17 us.  Here a wave computes the softmax weights of its
+// block's heads the same way (lane = split: the same wave_max / wave_sum, so the same bits), hands them to its lanes with readlane, sums the partial rows four
+// elements per lane in split order and quantises the block it holds - no barrier, no LDS.  Up to 64 splits.
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_combine_wave_kernel(const float *__restrict__ part, float *__restrict__ out, int H, int splits, int nblk,
+                                                                      ActQuant q, int want_q8k, int want_q80, int8_t *__restrict__ bh, int8_t *__restrict__ bl) {
+    constexpr int HPB = 256 / D;
+    const int t = blockIdx.y, lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;                                       // wave-uniform
+    const int E = H * D, h0 = b * HPB;
+    float wv[HPB];                                               // lane s: the weight of split s, per head of the block
+#pragma unroll
+    for (int hh = 0; hh < HPB; hh++) {
+        const float *p = part + ((size_t)t * H + h0 + hh) * splits * (D + 2);
+        const float m = lane < splits ? p[(size_t)lane * (D + 2) + D] : -INFINITY;
+        const float M = fmaxf(-INFINITY, wave_max(m));
+        float w = 0.0f, l = 0.0f;
+        if (lane < splits) {
+            l = p[(size_t)lane * (D + 2) + D + 1];
+            w = (m == -INFINITY) ? 0.0f : expf(m - M);
+        }
+        float den = 0.0f;
+        den += wave_sum(w * l);
+        const float inv = 1.0f / den;
+        wv[hh] = w * inv;
+    }
+    const int e = lane * 4, hl = e / D, d = e - hl * D;
+    const float *pr = part + ((size_t)t * H + h0 + hl) * splits * (D + 2) + d;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < splits; s++) {
+        float w = 0.0f;
+#pragma unroll
+        for (int hh = 0; hh < HPB; hh++) { const float wh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[hh]), s)); if (hh == hl) w = wh; }
+        if (w != 0.0f) {                                         // chunks with no visible cell publish only (m, l)
+            const float2 a0 = *reinterpret_cast<const float2 *>(pr + (size_t)s * (D + 2)), a1 = *reinterpret_cast<const float2 *>(pr + (size_t)s * (D + 2) + 2);
+            acc[0] += w * a0.x; acc[1] += w * a0.y; acc[2] += w * a1.x; acc[3] += w * a1.y;
+        }
+    }
+    const int e0 = b * 256 + e;
+    *reinterpret_cast<float4 *>(out + (size_t)t * E + e0) = float4{acc[0], acc[1], acc[2], acc[3]};
+    if (want_q8k) {
+        uint32_t packed; int bs; float dq;
+        wave_quant_q8k(acc, lane, packed, bs, dq);
+        *reinterpret_cast<uint32_t *>(q.qs + (size_t)t * E + e0) = packed;
+        if ((lane & 3) == 0) {
+            const size_t bi = (size_t)t * (E >> 4) + b * 16 + (lane >> 2);
+            q.bsums[bi] = (int16_t)bs;
+            if (bh) { const int hi = bs >> 6; bh[bi] = (int8_t)hi; bl[bi] = (int8_t)(bs - 64 * hi); }
+        }
+        if (lane == 0) q.d[(size_t)t * nblk + b] = dq;
+    }
+    if (want_q80) {
+        uint32_t packed; float dd;
+        wave_quant_q80(acc, packed, dd);
+        *reinterpret_cast<uint32_t *>(q.qs0 + (size_t)t * E + e0) = packed;
+        if ((lane & 7) == 0) q.d0[(size_t)t * (E >> 5) + b * 8 + (lane >> 3)] = f2h(dd);
+    }
+}
+
 // (D + 32 floats per record: what attn_out.hip keeps per head and chunk - whole 128-byte lines; the other kernels use D + 2 of them)
 size_t flash_attn_workspace_floats(int T, int H, int D, int splits) { return (size_t)T * H * splits * (D + 32); }
 
@@ -851,6 +911,15 @@ hipError_t launch_flash_attn_combine(const AttnArgs &a, int splits, hipStream_t 
     const int nblk = (a.H * a.D) >> 8;
     ActQuant qq;
     if (a.out_q) qq = *a.out_q;
+    static const bool wave_off = getenv("MI355_ATTN_COMBINE_WAVE") && getenv("MI355_ATTN_COMBINE_WAVE")[0] == '0';
+    if (!wave_off && a.T >= 32 && splits <= 64) {                 // prompt batches: one wave per block
+        const dim3 grid((unsigned)((nblk + 3) / 4), (unsigned)a.T);
+        if (a.D == 128) hipLaunchKernelGGL(flash_attn_combine_wave_kernel<128>, grid, dim3(256), 0, st, a.part, a.out, a.H, splits, nblk, qq, (int)(a.out_q && a.out_q8k),
+                                           (int)(a.out_q && a.out_q80), a.out_q ? a.out_bh : nullptr, a.out_q ? a.out_bl : nullptr);
+        else hipLaunchKernelGGL(flash_attn_combine_wave_kernel<64>, grid, dim3(256), 0, st, a.part, a.out, a.H, splits, nblk, qq, (int)(a.out_q && a.out_q8k),
+                                (int)(a.out_q && a.out_q80), a.out_q ? a.out_bh : nullptr, a.out_q ? a.out_bl : nullptr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(flash_attn_combine_kernel, dim3(nblk, a.T), dim3(256), (size_t)(256 / a.D) * splits * 4, st, a.part, a.out, a.H, a.D, splits,
                        qq, (int)(a.out_q && a.out_q8k), (int)(a.out_q && a.out_q80), (const int32_t *)nullptr, a.out_q ? a.out_bh : nullptr, a.out_q ? a.out_bl : nullptr);
     return hipGetLastError();
