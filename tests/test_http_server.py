@@ -243,3 +243,42 @@ def test_reference_smoke_script_over_http(pkg, tmp_path):
         assert d["object"] == "list" and v.shape == (768,) and abs(np.linalg.norm(v) - 1.0) < 1e-5
     finally:
         assert h.close() == 0
+
+
+@pytest.mark.gpu
+def test_image_request_over_http(pkg, tmp_path):
+    """POST /loadmodel with `mmproj`, then a chat request whose user message carries an `image_url` piece (a data: URL): the answer over the socket is the one
+    the engine surface gives for the same body (tests/test_gpu_llava.py checks that one against an independent decode loop and the oracle)."""
+    import base64
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    lm, mm = str(tmp_path / "tiny-d128.gguf"), str(tmp_path / "mmproj.gguf")
+    pkg.gguf_synth.write_synthetic_llama(lm, "tiny-d128", "q4_k_m", with_vocab=True)
+    pkg.gguf_synth.write_synthetic_clip(mm, "tiny-clip-1024")
+    b = io.BytesIO()
+    PIL.fromarray((np.random.default_rng(5).integers(0, 256, (50, 70, 3))).astype(np.uint8)).save(b, "PNG")
+    url = "data:image/png;base64," + base64.b64encode(b.getvalue()).decode()
+    req = {"model": "tiny", "messages": [{"role": "user", "content": [{"type": "text", "text": "what is in "}, {"type": "image_url", "image_url": {"url": url}}, {"type": "text", "text": " ?"}]}],
+           "max_tokens": 8, "temperature": 0.0, "repeat_penalty": 1.0, "frequency_penalty": 0.0, "presence_penalty": 0.0}
+    load = {"llama_model_path": lm, "mmproj": mm, "model": "tiny", "ctx_len": 512, "ngl": 100, "user_prompt": "u:", "ai_prompt": "a:", "system_prompt": "s:"}
+    h = Host()
+    try:
+        r, raw = h.request("POST", "/loadmodel", load)
+        assert r.status == 200, raw
+        r, raw = h.request("POST", "/v1/chat/completions", req)
+        assert r.status == 200, raw
+        over_http = json.loads(raw)
+        assert over_http["usage"]["prompt_tokens"] > 16                      # the image's 16 rows count as prompt positions
+        r, raw = h.request("POST", "/v1/chat/completions", dict(req, messages=[{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "data:image/png;base64,AAAA"}},
+                                                                                                           {"type": "text", "text": "x"}]}]))
+        assert r.status != 200 or "error" in raw.decode().lower(), raw       # bytes that are no image fail the request, not the server
+        r, raw = h.request("POST", "/v1/chat/completions", req)
+        assert r.status == 200 and json.loads(raw)["choices"][0]["message"]["content"] == over_http["choices"][0]["message"]["content"]
+    finally:
+        h.close()
+    e = pkg.Engine()
+    st, body = e.load_model(**load)
+    assert st["status_code"] == 200, (st, body)
+    st, body = e.chat_completion(**req)[-1]
+    assert body["choices"][0]["message"]["content"] == over_http["choices"][0]["message"]["content"]
+    e.close()
