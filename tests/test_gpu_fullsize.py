@@ -324,3 +324,38 @@ def test_other_configs_determinism_graph_equals_eager(pkg, other):
     assert np.array_equal(a, run(True))                      # same calls, same bits
     assert np.array_equal(a, run(False))                     # hipGraph replay == eager launches
     m.close()
+
+
+def test_fullsize_image_rows_through_the_prompt_kernels(pkg, big, tmp_models):
+    """A LLaVA-1.5 prompt at full size: CLIP ViT-L/14-336 (576 rows of 4096) in front of the 8B model.  Text, the image's 576 embedding rows as ONE llama_batch.embd
+    batch (the prompt kernels at 576 tokens), text - and the same with the rows cut into two batches (300 + 276: other tile counts, other kernels for the second
+    one): both orders of evaluation must give the same next-token distribution within the flip band, and finite logits."""
+    pkg.Backend()
+    mm = os.path.join(str(tmp_models), "mmproj-clip-vit-l-336.gguf")
+    if not os.path.exists(mm):
+        pkg.gguf_synth.write_synthetic_clip(mm, "clip-vit-l-336")
+    clip = pkg.Clip(mm)
+    m = pkg.Model(big)
+    assert clip.n_embd == m.n_embd and clip.n_patches == 576
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (480, 640, 3)).astype(np.uint8)
+    rows = clip.encode(clip.preprocess(rgb))
+    assert np.isfinite(rows).all()
+    rows = rows * (0.02 / max(1e-9, float(np.abs(rows).mean())))           # (random projector weights: bring the rows to the scale of token embeddings)
+    pre, suf = rng.integers(0, m.n_vocab, 7), rng.integers(0, m.n_vocab, 5)
+
+    def run(cuts):
+        c = pkg.Context(m, n_ctx=2048, n_batch=2048, n_ubatch=2048, type_k=8, type_v=8)
+        assert c.decode(pre, np.arange(7)) == 0
+        at = 7
+        for a0, a1 in cuts:
+            assert c.decode_embd(rows[a0:a1], np.arange(at, at + (a1 - a0))) == 0
+            at += a1 - a0
+        assert c.decode(suf, np.arange(at, at + 5)) == 0
+        lg = c.logits()
+        c.close()
+        return lg
+    one, two = run([(0, 576)]), run([(0, 300), (300, 576)])
+    assert np.isfinite(one).all() and np.isfinite(two).all()
+    assert rel_err(one, two) <= FLIP_TOL, rel_err(one, two)
+    clip.close(); m.close()
