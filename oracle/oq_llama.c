@@ -589,6 +589,12 @@ int oq_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_
             oq_quantize_row(c->type_v, vv + (size_t)t * kv_dim, c->v[il] + (size_t)(slot + t) * c->v_row, kv_dim);
         }
         const size_t k_head = oq_row_bytes(c->type_k, hd), v_head = oq_row_bytes(c->type_v, hd);
+        /* every K / V row of the batch is in the cache: the tokens' attention calls are independent of each other (each reads the cache and writes its own
+         * output row), so a prompt batch spreads them over the threads - the same calls, the same bits; a 3968-token prompt otherwise spends half an hour here */
+#pragma omp parallel num_threads(c->nth) if (n > 1)
+        {
+        int32_t *vis = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->n_ctx);
+#pragma omp for schedule(dynamic, 1)
         for (int t = 0; t < n; t++) {
             const int s = seq ? seq[t] : 0;
             int nv = 0;
@@ -617,6 +623,8 @@ int oq_decode(oq_ctx *c, const int32_t *tokens, const int32_t *pos, const int32_
                 }
                 free(sc); free(q16); free(p16); free(vcol);
             }
+        }
+        free(vis);
         }
         linear(c, L->wo, att, n, tmp);
         oq_add_f32(x, tmp, x, (int64_t)D * n);

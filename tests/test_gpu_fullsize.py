@@ -359,3 +359,28 @@ def test_fullsize_image_rows_through_the_prompt_kernels(pkg, big, tmp_models):
     assert np.isfinite(one).all() and np.isfinite(two).all()
     assert rel_err(one, two) <= FLIP_TOL, rel_err(one, two)
     clip.close(); m.close()
+
+
+def test_fullsize_context_filled_matches_committed_oracle_logits(pkg, big):
+    """The headline model at BASELINE's ctx_len: a 3968-token prompt (two micro-batches of 2048) and one step on the 32-layer synthetic Llama-3-8B file, q8_0 cache,
+    against the CPU oracle's logits for exactly that file and prompt - computed once (tests/golden/make_golden_fullsize_ctx.py: minutes on 192 threads, far too long
+    for a test run) and committed as tests/golden/fullsize_ctx4096_v1.npz.  Same band as the other full-size comparisons; the top token must agree unless the
+    oracle's own top two are within the band of each other."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_ctx4096_v1.npz"))
+    n = int(g["n_prompt"])
+    pkg.Backend()
+    m = pkg.Model(big)
+    c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=8, type_v=8)
+    prompt = np.random.default_rng(int(g["seed"])).integers(0, m.n_vocab, n).astype(np.int32)
+    for i0 in range(0, n, 2048):
+        assert c.decode(prompt[i0:i0 + 2048], np.arange(i0, min(n, i0 + 2048))) == 0
+    rows = [c.logits()]
+    assert c.decode([int(g["tok_prompt"])], [n]) == 0
+    rows.append(c.logits())
+    for got, key in zip(rows, ("row_prompt", "row_step")):
+        ref = g[key]
+        assert rel_err(got, ref) <= FLIP_TOL, (key, rel_err(got, ref))
+        if int(got.argmax()) != int(ref.argmax()):
+            top2 = np.sort(ref)[-2:]
+            assert top2[1] - top2[0] <= 2 * FLIP_TOL * max(1.0, float(np.abs(ref).max())), (key, top2)
+    c.close(); m.close()
