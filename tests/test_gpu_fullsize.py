@@ -384,3 +384,43 @@ def test_fullsize_context_filled_matches_committed_oracle_logits(pkg, big):
             top2 = np.sort(ref)[-2:]
             assert top2[1] - top2[0] <= 2 * FLIP_TOL * max(1.0, float(np.abs(ref).max())), (key, top2)
     c.close(); m.close()
+
+
+def test_fullsize_f16_cache_context_filled_against_the_stock_cpu_path(pkg, tmp_models):
+    """BASELINE config 2 (Llama-2-7B Q5_K_M, the reference's default f16 cache) with the context filled: a 3968-token prompt + one step against the oracle's logits in
+    its STOCK mode - V accumulated in fp16 cell by cell, as the reference's CPU path does - computed once and committed (tests/golden/fullsize_ctx4096_c2_v1.npz).
+    The default kernels accumulate V in f32; the opt-in parity mode (option "fa_v_acc_f16") walks the cells the way the CPU does.  Both must sit
+    in the flip band, with the oracle's top token (or a near tie); the measured figures are recorded in DESIGN.md."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_ctx4096_c2_v1.npz"))
+    n = int(g["n_prompt"])
+    path = os.path.join(str(tmp_models), "llama-2-7b-q5_k_m.gguf")
+    if not os.path.exists(path):
+        pkg.gguf_synth.write_synthetic_llama(path, "llama-2-7b", "q5_k_m", seed=0xC0FFEE, with_vocab=False)
+    be = pkg.Backend()
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(int(g["seed"])).integers(0, m.n_vocab, n).astype(np.int32)
+    report = {}
+    for mode in (0, 1):
+        be.set_option("fa_v_acc_f16", mode)
+        try:
+            c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=1, type_v=1)
+            for i0 in range(0, n, 2048):
+                assert c.decode(prompt[i0:i0 + 2048], np.arange(i0, min(n, i0 + 2048))) == 0
+            rows = [c.logits()]
+            assert c.decode([int(g["tok_prompt"])], [n]) == 0
+            rows.append(c.logits())
+            c.close()
+        finally:
+            be.set_option("fa_v_acc_f16", -1)
+        for got, key in zip(rows, ("row_prompt", "row_step")):
+            ref = g[key]
+            e = rel_err(got, ref)
+            report[(mode, key)] = e
+            assert e <= FLIP_TOL, (mode, key, e)
+            if int(got.argmax()) != int(ref.argmax()):
+                top2 = np.sort(ref)[-2:]
+                assert top2[1] - top2[0] <= 2 * FLIP_TOL * max(1.0, float(np.abs(ref).max())), (mode, key, top2)
+    if os.environ.get("MI355_TEST_RECORD_FLIPS"):
+        with open(os.environ["MI355_TEST_RECORD_FLIPS"], "a") as f:
+            f.write(f"C2 filled context vs stock oracle: {report}\n")
+    m.close()
