@@ -75,6 +75,7 @@ SYMBOLS = {
     "mi355_batch_init": (Batch, [_i32, _i32, _i32]),
     "mi355_batch_free": (None, [Batch]),
     "mi355_decode": (_i32, [_vp, Batch]),
+    "mi355_greedy_steps": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355_get_logits_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_get_argmax_ith": (_i32, [_vp, _i32]),
     "mi355_get_topk_ith": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp]),
@@ -581,6 +582,14 @@ class Context:
         if rc < 0:
             raise MI355Error(f"mi355_decode failed ({rc}): {_err(self.lib)}")
         return rc
+
+    def greedy_steps(self, first: int, pos0: int, n: int, seq: int = 0) -> np.ndarray:
+        """n greedy single-token steps (decode, logits row host-visible, arg-max fed back) in one C call; returns the n tokens"""
+        out = np.empty(n, np.int32)
+        done = self.lib.mi355_greedy_steps(self.h, int(first), int(pos0), int(seq), int(n), out.ctypes.data)
+        if done != n:
+            raise MI355Error(f"mi355_greedy_steps stopped after {done} of {n}: {_err(self.lib)}")
+        return out
 
     def logits(self, i: int = -1) -> np.ndarray:
         p = self.lib.mi355_get_logits_ith(self.h, i)

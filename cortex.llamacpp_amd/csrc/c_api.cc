@@ -211,6 +211,26 @@ int32_t mi355_decode(mi355_context *ctx, mi355_batch batch) {
         return rc;
     )
 }
+// n greedy single-token steps in one call: llama_decode, the logits row made host-visible (llama_get_logits_ith), the arg-max fed back - the inner loop of a
+// generation as the reference's C++ slot loop runs it, without a scripting caller's per-call overhead in every step
+int32_t mi355_greedy_steps(mi355_context *ctx, mi355_token first, mi355_pos pos0, mi355_seq_id seq, int32_t n, mi355_token *out_tokens) {
+    if (!ctx || n < 0) return MI355_ERR_ARG;
+    MI355_GUARD(return MI355_ERR_ARG,
+        int32_t tok = first, one = 1, sid = seq;
+        int32_t *sp = &sid;
+        const int8_t flag = 1;
+        for (int32_t i = 0; i < n; i++) {
+            int32_t pos = pos0 + i;
+            const int rc = ctx->c->decode(1, &tok, &pos, &one, &sp, &flag);
+            if (rc != 0) { if (rc < 0) fail(ctx->c->last_error); return i; }
+            if (!ctx->c->logits_ith(0)) { fail("no logits row"); return i; }
+            tok = ctx->c->argmax_ith(0);
+            if (tok < 0) { fail(ctx->c->last_error.empty() ? "arg-max failed" : ctx->c->last_error); return i; }
+            if (out_tokens) out_tokens[i] = tok;
+        }
+        return n;
+    )
+}
 float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
 int32_t mi355_get_topk_ith(mi355_context *ctx, int32_t i, int32_t k, int32_t n_adj, const int32_t *adj_tok, const float *adj_bias, const int32_t *adj_count,

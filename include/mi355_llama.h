@@ -139,6 +139,10 @@ MI355_API void        mi355_batch_free(mi355_batch batch);
  * Returns 0 on success, 1 if no KV slot could be found for the batch (caller halves n_batch and
  * retries, ctx.cc:1636-1663), < 0 on a fatal error.  Logits rows are host-visible afterwards. */
 MI355_API int32_t mi355_decode(mi355_context *ctx, mi355_batch batch);
+/* n greedy steps of one sequence in one call - per step: llama_decode of the previous step's token at pos0 + i, its logits row made host-visible
+ * (llama_get_logits_ith), the arg-max as the next token (the greedy end of the sampler chain): the inner loop of the reference's UpdateSlots for a temperature-0
+ * request (llama_server_context.cc:1628-1707), on the C side.  out_tokens (nullable) [n].  Returns the steps done (n, or fewer with the reason in mi355_last_error). */
+MI355_API int32_t mi355_greedy_steps(mi355_context *ctx, mi355_token first, mi355_pos pos0, mi355_seq_id seq, int32_t n, mi355_token *out_tokens);
 /* llama_get_logits_ith as used through common_sampler_sample(ctx, idx) (ctx.cc:1679-1680).
  * i indexes the batch of the last mi355_decode; NULL if that row had logits[i] == 0. */
 MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);

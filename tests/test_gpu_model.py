@@ -166,6 +166,31 @@ def test_prefill_layers_logits_and_greedy_ids(be, pkg, tmp_models, cfg, ftype, k
         oq.set_fa_v_acc_f32(0)
 
 
+def test_greedy_steps_in_one_call_equal_the_step_by_step_loop(be, pkg, tmp_models):
+    """mi355_greedy_steps (decode, logits row host-visible, arg-max fed back, n times on the C side) names the tokens of the same loop driven call by call"""
+    path = make(pkg, tmp_models, "tiny-d128", "q4_k_m")
+    m = pkg.Model(path)
+    prompt = np.random.default_rng(3).integers(0, m.n_vocab, 30)
+    outs = []
+    for mode in ("calls", "one"):
+        c = pkg.Context(m, n_ctx=256, type_k=KV["q8_0"], type_v=KV["q8_0"])
+        assert c.decode(prompt, np.arange(30)) == 0
+        tok = c.argmax()
+        if mode == "one":
+            toks = [int(t) for t in c.greedy_steps(tok, 30, 40)]
+        else:
+            toks = []
+            for i in range(40):
+                assert c.decode([tok], [30 + i]) == 0
+                c.logits_ready()
+                tok = c.argmax()
+                toks.append(int(tok))
+        outs.append(toks)
+        c.close()
+    assert outs[0] == outs[1]
+    m.close()
+
+
 @pytest.mark.parametrize("cfg,ftype,kv,n_img,ubatch", [("tiny-d128", "q4_k_m", "q8_0", 70, 512), ("tiny-8b-2l", "q4_k_m", "q8_0", 300, 128), ("tiny-gqa4", "q5_k_m", "f16", 33, 512),
                                                        ("tiny-d128", "q4_k_m", "q8_0", 1, 512)])
 def test_embeddings_batch_matches_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_img, ubatch):
