@@ -166,3 +166,32 @@ def test_image_prompt_chain_matches_oracle(pkg, files):
         tok = int(r.argmax())
     assert max(errs) <= FLIP_TOL, errs
     c.close(); m.close(); clip.close(); oclip.close(); oc.close(); om.close()
+
+
+def test_two_image_requests_at_once(pkg, engine, files):
+    """n_parallel = 2: two image requests in flight together - one slot's embedding batches go to the model between ticks in which the other slot generates -
+    and each answers what it answers alone"""
+    import threading
+    pngs = [encoded(photo(64, 48, 11)), encoded(photo(48, 64, 12))]
+    reqs = [[{"role": "user", "content": [{"type": "text", "text": f"picture {k} "}, {"type": "image_url", "image_url": {"url": data_url(p)}}, {"type": "text", "text": " go"}]}]
+            for k, p in enumerate(pngs)]
+    alone = []
+    for msgs in reqs:
+        st, body = engine.chat_completion(model="tiny-d128", messages=msgs, max_tokens=24, **GREEDY)[-1]
+        assert st["status_code"] == 200 and not st["has_error"], (st, body)
+        alone.append(body["choices"][0]["message"]["content"])
+    together = [None, None]
+
+    def ask(i):
+        st, body = engine.chat_completion(model="tiny-d128", messages=reqs[i], max_tokens=24, **GREEDY)[-1]
+        together[i] = (st, body)
+    for _ in range(3):
+        th = [threading.Thread(target=ask, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for i in range(2):
+            st, body = together[i]
+            assert st["status_code"] == 200 and not st["has_error"], (st, body)
+            assert body["choices"][0]["message"]["content"] == alone[i]
