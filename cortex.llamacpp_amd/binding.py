@@ -135,6 +135,8 @@ SYMBOLS = {
     "mi355_clip_n_mmproj_embd": (_i32, [_vp]),
     "mi355_clip_n_patches": (_i32, [_vp]),
     "mi355_clip_image_size": (_i32, [_vp]),
+    "mi355_clip_max_image_rows": (_i32, [_vp]),
+    "mi355_clip_image_preprocess_grid": (_i32, [_vp, _vp, _i32, _i32, _vp, _sz, _vp, _vp]),
     "mi355_clip_image_load_from_bytes": (_i32, [_vp, _sz, C.POINTER(_i32), C.POINTER(_i32), _vp, _sz]),
     "mi355_clip_image_preprocess": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "mi355_clip_image_encode": (_i32, [_vp, _vp, _vp]),
@@ -425,6 +427,7 @@ class Clip:
         self.n_embd = self.lib.mi355_clip_n_mmproj_embd(self.h)
         self.n_patches = self.lib.mi355_clip_n_patches(self.h)
         self.image_size = self.lib.mi355_clip_image_size(self.h)
+        self.max_image_rows = self.lib.mi355_clip_max_image_rows(self.h)
 
     def load_image(self, data: bytes) -> np.ndarray:
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
@@ -444,6 +447,18 @@ class Clip:
             raise MI355Error(f"preprocess: {_err(self.lib)}")
         return out
 
+    def preprocess_grid(self, rgb: np.ndarray):
+        """Every image the encoder sees for one picture (LLaVA-1.6: overview + tiles): ([n, 3, S, S], grid_w, grid_h)."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        ny, nx, _ = rgb.shape
+        cap = self.max_image_rows // self.n_patches
+        out = np.empty((cap, 3, self.image_size, self.image_size), np.float32)
+        gw, gh = C.c_int32(0), C.c_int32(0)
+        n = self.lib.mi355_clip_image_preprocess_grid(self.h, rgb.ctypes.data, nx, ny, out.ctypes.data, out.size, C.byref(gw), C.byref(gh))
+        if n < 0:
+            raise MI355Error(f"preprocess_grid: {_err(self.lib)}")
+        return out[:n], gw.value, gh.value
+
     def encode(self, img: np.ndarray) -> np.ndarray:
         img = np.ascontiguousarray(img, np.float32)
         out = np.empty((self.n_patches, self.n_embd), np.float32)
@@ -453,7 +468,7 @@ class Clip:
 
     def embed_bytes(self, data: bytes) -> np.ndarray:
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
-        out = np.empty((self.n_patches, self.n_embd), np.float32)
+        out = np.empty((self.max_image_rows, self.n_embd), np.float32)
         n = self.lib.mi355_llava_image_embed_from_bytes(self.h, buf, len(data), out.ctypes.data, out.size)
         if n < 0:
             raise MI355Error(f"llava_image_embed: {_err(self.lib)}")

@@ -263,6 +263,23 @@ void mi355_clip_free(mi355_clip *clip) { delete clip; }
 int32_t mi355_clip_n_mmproj_embd(const mi355_clip *clip) { return clip ? clip->m.proj_dim : 0; }
 int32_t mi355_clip_n_patches(const mi355_clip *clip) { return clip ? clip->m.n_patches() : 0; }
 int32_t mi355_clip_image_size(const mi355_clip *clip) { return clip ? clip->m.image_size : 0; }
+int32_t mi355_clip_max_image_rows(const mi355_clip *clip) { return clip ? clip->m.max_image_rows() : 0; }
+int32_t mi355_clip_image_preprocess_grid(const mi355_clip *clip, const uint8_t *rgb, int32_t nx, int32_t ny, float *out, size_t out_floats, int32_t *grid_w, int32_t *grid_h) {
+    if (!clip || !rgb || !out || nx <= 0 || ny <= 0) { fail("clip_image_preprocess_grid: bad arguments"); return MI355_ERR_ARG; }
+    MI355_GUARD(return MI355_ERR_ARG,
+        ClipImageU8 img;
+        img.nx = nx; img.ny = ny; img.rgb.assign(rgb, rgb + (size_t)3 * nx * ny);
+        std::vector<std::vector<float>> imgs;
+        int gw = 0, gh = 0;
+        clip->m.preprocess_all(img, imgs, gw, gh);
+        const size_t per = (size_t)3 * clip->m.image_size * clip->m.image_size;
+        if (out_floats < per * imgs.size()) { fail("clip_image_preprocess_grid: output buffer too small"); return MI355_ERR_ARG; }
+        for (size_t i = 0; i < imgs.size(); i++) memcpy(out + i * per, imgs[i].data(), per * sizeof(float));
+        if (grid_w) *grid_w = gw;
+        if (grid_h) *grid_h = gh;
+        return (int32_t)imgs.size();
+    )
+}
 int32_t mi355_clip_image_load_from_bytes(const uint8_t *bytes, size_t n_bytes, int32_t *nx, int32_t *ny, uint8_t *rgb_out, size_t rgb_cap) {
     MI355_GUARD(return MI355_ERR_ARG,
         ClipImageU8 img;
@@ -299,15 +316,16 @@ int32_t mi355_clip_image_encode(mi355_clip *clip, const float *img, float *out) 
 int32_t mi355_llava_image_embed_from_bytes(mi355_clip *clip, const uint8_t *bytes, size_t n_bytes, float *out, size_t out_floats) {
     if (!clip || !bytes || !out) { fail("llava_image_embed: bad arguments"); return MI355_ERR_ARG; }
     MI355_GUARD(return MI355_ERR_ARG,
-        if (out_floats < (size_t)clip->m.n_patches() * (size_t)clip->m.proj_dim) { fail("llava_image_embed: output buffer too small"); return MI355_ERR_ARG; }
         ClipImageU8 img;
         std::string err = clip_image_load_from_bytes(bytes, n_bytes, img);
         if (!err.empty()) { fail(err); return MI355_ERR_ARG; }
-        std::vector<float> f;
-        clip->m.preprocess(img, f);
-        err = clip->m.encode(f.data(), out);
+        std::vector<float> rows;
+        int n_rows = 0;
+        err = clip->m.embed(img, rows, n_rows);
         if (!err.empty()) { fail(err); return MI355_ERR_ARG; }
-        return clip->m.n_patches();
+        if (out_floats < rows.size()) { fail("llava_image_embed: output buffer too small (" + std::to_string(n_rows) + " rows; size it with mi355_clip_max_image_rows)"); return MI355_ERR_ARG; }
+        memcpy(out, rows.data(), rows.size() * sizeof(float));
+        return n_rows;
     )
 }
 

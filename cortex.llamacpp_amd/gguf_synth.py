@@ -490,6 +490,9 @@ class ClipConfig:
     use_gelu: bool = False
     mean: tuple = (0.48145466, 0.4578275, 0.40821073)
     std: tuple = (0.26862954, 0.26130258, 0.27577711)
+    # LLaVA-1.6: the (width, height) canvases of the image grid, flattened, and the merge type that turns the grid on
+    pinpoints: tuple = ()
+    merge_type: str = ""
 
     @property
     def n_patches(self) -> int:
@@ -505,6 +508,14 @@ CLIP_CONFIGS = {
     "tiny-clip-gelu": ClipConfig("tiny-clip-gelu", 56, 14, 128, 2, 256, 2, 4096, use_gelu=True),
     # a projector as wide as the tiny language models of the engine tests (n_embd 1024): 16 rows per image
     "tiny-clip-1024": ClipConfig("tiny-clip-1024", 56, 14, 128, 2, 256, 2, 1024),
+    # LLaVA-1.6: ViT-L/14-336 with the image grid of llava-v1.6 (an overview + up to four tiles: 2880 rows a picture), and the same at test size
+    "clip-vit-l-336-grid": ClipConfig("llava-v1.6-clip", 336, 14, 1024, 16, 4096, 23, 4096, pinpoints=(336, 672, 672, 336, 672, 672, 1008, 336, 336, 1008),
+                                      merge_type="spatial_unpad"),
+    "tiny-clip-grid": ClipConfig("tiny-clip-grid", 56, 14, 128, 2, 256, 2, 256, pinpoints=(56, 112, 112, 56, 112, 112, 168, 56, 56, 168), merge_type="spatial_unpad"),
+    "tiny-clip-grid-1024": ClipConfig("tiny-clip-grid-1024", 56, 14, 128, 2, 256, 2, 1024, pinpoints=(56, 112, 112, 56, 112, 112, 168, 56, 56, 168),
+                                      merge_type="spatial_unpad"),
+    # a grid in the file but the merge type "flat": only the overview is encoded
+    "tiny-clip-grid-flat": ClipConfig("tiny-clip-grid-flat", 56, 14, 128, 2, 256, 2, 256, pinpoints=(56, 112, 112, 56, 112, 112), merge_type="flat"),
 }
 
 
@@ -526,6 +537,8 @@ def clip_tensors(cfg: ClipConfig):
         out += [(p + "ln2.weight", (E,), F32, 1), (p + "ln2.bias", (E,), F32, 1)]
     out += [("mm.0.weight", (E, cfg.proj_dim), F16, E), ("mm.0.bias", (cfg.proj_dim,), F32, 1),
             ("mm.2.weight", (cfg.proj_dim, cfg.proj_dim), F16, cfg.proj_dim), ("mm.2.bias", (cfg.proj_dim,), F32, 1)]
+    if cfg.pinpoints:      # LLaVA-1.6 files carry the row separator of the original model; llama.cpp's layout ("without newline tokens") never reads it
+        out += [("model.image_newline", (cfg.proj_dim,), F32, 1)]
     return out
 
 
@@ -552,6 +565,10 @@ def write_synthetic_clip(path: str, cfg: ClipConfig | str, seed: int = 0xC11F) -
     w.add("clip.vision.block_count", "u32", cfg.n_layer)
     w.add_array("clip.vision.image_mean", "f32", list(cfg.mean))
     w.add_array("clip.vision.image_std", "f32", list(cfg.std))
+    if cfg.pinpoints:
+        w.add_array("clip.vision.image_grid_pinpoints", "i32", list(cfg.pinpoints))
+    if cfg.merge_type:
+        w.add("clip.vision.mm_patch_merge_type", "str", cfg.merge_type)
     for idx, (name, ne, t, fan_in) in enumerate(clip_tensors(cfg)):
         n = int(np.prod(ne))
 

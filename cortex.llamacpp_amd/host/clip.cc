@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 
 #include "../csrc/kernels.h"
@@ -57,7 +59,18 @@ std::string ClipModel::load(const std::string &path, int device) {
     for (int k = 0; k < 3; k++) { mean[k] = 0.0f; stdv[k] = 1.0f; }
     if (const GGUFValue *v = f.find("clip.vision.image_mean")) if (v->type == GV_ARR && v->elem_type == GV_F32 && v->u >= 3 && v->raw) memcpy(mean, v->raw, 12);
     if (const GGUFValue *v = f.find("clip.vision.image_std")) if (v->type == GV_ARR && v->elem_type == GV_F32 && v->u >= 3 && v->raw) memcpy(stdv, v->raw, 12);
-    if (f.find("clip.vision.image_grid_pinpoints")) return "projector file with an image grid (LLaVA-1.6) is not supported";
+    pinpoints.clear();
+    if (const GGUFValue *v = f.find("clip.vision.image_grid_pinpoints")) {
+        if (v->type != GV_ARR || (v->elem_type != GV_I32 && v->elem_type != GV_U32) || !v->raw || (v->u % 2) || v->u > 128) return "projector file: bad clip.vision.image_grid_pinpoints";
+        const int32_t *pp = reinterpret_cast<const int32_t *>(v->raw);
+        for (uint64_t i = 0; i + 1 < v->u; i += 2) {
+            // every canvas is a whole number of tiles, and small enough that the rows of one picture stay a sane prompt (at most 64 tiles)
+            if (pp[i] <= 0 || pp[i + 1] <= 0 || pp[i] % image_size || pp[i + 1] % image_size || (int64_t)(pp[i] / image_size) * (pp[i + 1] / image_size) > 64)
+                return "projector file: clip.vision.image_grid_pinpoints entry " + std::to_string(pp[i]) + "x" + std::to_string(pp[i + 1]) + " is not a grid of " + std::to_string(image_size) + "-pixel tiles";
+            pinpoints.emplace_back(pp[i], pp[i + 1]);
+        }
+    }
+    merge_type = f.get_s("clip.vision.mm_patch_merge_type", "flat");
 
     device_ = device;
     if (hipSetDevice(device) != hipSuccess) return "hipSetDevice failed";
@@ -167,6 +180,126 @@ void ClipModel::preprocess(const ClipImageU8 &img, std::vector<float> &out) cons
                 const uint8_t v2 = (uint8_t)std::min(std::max(roundf(v), 0.0f), 255.0f);
                 out[(size_t)k * S * S + (size_t)y * S + x] = (((float)v2 / 255.0f) - mean[k]) / stdv[k];
             }
+}
+
+int ClipModel::max_image_rows() const {
+    int tiles = 0;
+    if (merge_type == "spatial_unpad")
+        for (const auto &p : pinpoints) tiles = std::max(tiles, (p.first / image_size) * (p.second / image_size));
+    return n_patches() * (1 + tiles);
+}
+
+// ---- LLaVA-1.6 preprocessing (clip.cpp: bicubic_resize, select_best_resolution, resize_and_pad_image, divide_to_patches_u8)
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+// the cubic through four samples with Catmull-Rom style coefficients, evaluated separably (rows first, then the column), the source index truncated (not
+// half-pixel centred), edges clamped, the result rounded and clamped to a byte
+static void bicubic_resize(const ClipImageU8 &img, ClipImageU8 &dst, int tw, int th) {
+    const int nx = img.nx, ny = img.ny;
+    dst.nx = tw; dst.ny = th;
+    dst.rgb.assign((size_t)3 * tw * th, 0);
+    const float tx = (float)nx / (float)tw, ty = (float)ny / (float)th;
+    for (int i = 0; i < th; i++)
+        for (int j = 0; j < tw; j++) {
+            const int x = (int)(tx * (float)j), y = (int)(ty * (float)i);
+            const float dx = tx * (float)j - (float)x, dy = ty * (float)i - (float)y;
+            for (int k = 0; k < 3; k++) {
+                float C[4];
+                for (int jj = 0; jj <= 3; jj++) {
+                    const uint8_t *row = img.rgb.data() + (size_t)3 * clampi(y - 1 + jj, 0, ny - 1) * nx;
+                    const float a0 = row[3 * clampi(x, 0, nx - 1) + k];
+                    const float d0 = (float)row[3 * clampi(x - 1, 0, nx - 1) + k] - a0;
+                    const float d2 = (float)row[3 * clampi(x + 1, 0, nx - 1) + k] - a0;
+                    const float d3 = (float)row[3 * clampi(x + 2, 0, nx - 1) + k] - a0;
+                    const float a1 = (float)(-1.0 / 3 * d0 + d2 - 1.0 / 6 * d3);        // (the coefficients in double, rounded to float; the polynomial in float)
+                    const float a2 = (float)(1.0 / 2 * d0 + 1.0 / 2 * d2);
+                    const float a3 = (float)(-1.0 / 6 * d0 - 1.0 / 2 * d2 + 1.0 / 6 * d3);
+                    C[jj] = a0 + a1 * dx + a2 * dx * dx + a3 * dx * dx * dx;
+                }
+                const float a0 = C[1], d0 = C[0] - C[1], d2 = C[2] - C[1], d3 = C[3] - C[1];
+                const float a1 = (float)(-1.0 / 3 * d0 + d2 - 1.0 / 6 * d3);
+                const float a2 = (float)(1.0 / 2 * d0 + 1.0 / 2 * d2);
+                const float a3 = (float)(-1.0 / 6 * d0 - 1.0 / 2 * d2 + 1.0 / 6 * d3);
+                const float Cc = a0 + a1 * dy + a2 * dy * dy + a3 * dy * dy * dy;
+                dst.rgb[(size_t)3 * ((size_t)i * tw + j) + k] = (uint8_t)std::min(std::max(roundf(Cc), 0.0f), 255.0f);
+            }
+        }
+}
+
+// the canvas that keeps the most of the picture's pixels after an aspect-preserving fit; among equals, the one that wastes the least area
+static std::pair<int, int> select_best_resolution(int ow, int oh, const std::vector<std::pair<int, int>> &cands) {
+    std::pair<int, int> best = cands.front();
+    int max_eff = 0, min_waste = INT32_MAX;
+    for (const auto &r : cands) {
+        const float scale = std::min((float)r.first / (float)ow, (float)r.second / (float)oh);
+        const int dw = (int)((float)ow * scale), dh = (int)((float)oh * scale);
+        const int eff = (int)std::min((int64_t)dw * dh, (int64_t)ow * oh);
+        const int waste = r.first * r.second - eff;
+        if (eff > max_eff || (eff == max_eff && waste < min_waste)) { max_eff = eff; min_waste = waste; best = r; }
+    }
+    return best;
+}
+
+// aspect-preserving bicubic fit, centred on a black canvas
+static void resize_and_pad(const ClipImageU8 &img, ClipImageU8 &out, int tw, int th) {
+    const float sw = (float)tw / (float)img.nx, sh = (float)th / (float)img.ny;
+    int nw, nh;
+    if (sw < sh) { nw = tw; nh = std::min((int)ceilf((float)img.ny * sw), th); }
+    else { nh = th; nw = std::min((int)ceilf((float)img.nx * sh), tw); }
+    ClipImageU8 rs;
+    bicubic_resize(img, rs, nw, nh);
+    out.nx = tw; out.ny = th;
+    out.rgb.assign((size_t)3 * tw * th, 0);
+    const int ox = (tw - nw) / 2, oy = (th - nh) / 2;
+    for (int y = 0; y < nh; y++) memcpy(out.rgb.data() + (size_t)3 * ((size_t)(y + oy) * tw + ox), rs.rgb.data() + (size_t)3 * y * nw, (size_t)3 * nw);
+}
+
+void ClipModel::preprocess_all(const ClipImageU8 &img, std::vector<std::vector<float>> &out, int &grid_w, int &grid_h) const {
+    out.clear();
+    grid_w = grid_h = 0;
+    if (!has_grid()) { out.emplace_back(); preprocess(img, out.back()); return; }
+    const int S = image_size;
+    auto normalise = [&](const ClipImageU8 &im, int x0, int y0, std::vector<float> &f) {       // the S x S window at (x0, y0) -> planar, normalised
+        f.resize((size_t)3 * S * S);
+        for (int k = 0; k < 3; k++)
+            for (int y = 0; y < S; y++)
+                for (int x = 0; x < S; x++)
+                    f[(size_t)k * S * S + (size_t)y * S + x] = ((float)im.rgb[(size_t)3 * ((size_t)(y + y0) * im.nx + (x + x0)) + k] / 255.0f - mean[k]) / stdv[k];
+    };
+    ClipImageU8 overview;
+    bicubic_resize(img, overview, S, S);          // (the whole picture, aspect not kept)
+    out.emplace_back();
+    normalise(overview, 0, 0, out.back());
+    if (merge_type != "spatial_unpad") return;
+    const std::pair<int, int> best = select_best_resolution(img.nx, img.ny, pinpoints);
+    ClipImageU8 canvas;
+    resize_and_pad(img, canvas, best.first, best.second);
+    grid_w = best.first / S; grid_h = best.second / S;
+    for (int gy = 0; gy < grid_h; gy++)
+        for (int gx = 0; gx < grid_w; gx++) { out.emplace_back(); normalise(canvas, gx * S, gy * S, out.back()); }
+}
+
+std::string ClipModel::embed(const ClipImageU8 &img, std::vector<float> &rows, int &n_rows) {
+    std::vector<std::vector<float>> imgs;
+    int gw = 0, gh = 0;
+    preprocess_all(img, imgs, gw, gh);
+    const int NP = n_patches(), E = proj_dim, G = image_size / patch_size;
+    n_rows = NP * (int)imgs.size();
+    rows.assign((size_t)n_rows * E, 0.0f);
+    std::string err = encode(imgs[0].data(), rows.data());
+    if (!err.empty() || imgs.size() == 1) return err;
+    // clip_llava_handle_patches: the tiles' rows, each tile G x G row-major, re-ordered to the canvas' (grid_h * G) x (grid_w * G) row-major order
+    std::vector<float> tile((size_t)NP * E);
+    for (int gy = 0; gy < gh; gy++)
+        for (int gx = 0; gx < gw; gx++) {
+            err = encode(imgs[(size_t)(1 + gy * gw + gx)].data(), tile.data());
+            if (!err.empty()) return err;
+            for (int py = 0; py < G; py++) {
+                const size_t dst_row = (size_t)NP + ((size_t)(gy * G + py) * gw + gx) * G;
+                memcpy(rows.data() + dst_row * E, tile.data() + (size_t)py * G * E, (size_t)G * E * sizeof(float));
+            }
+        }
+    return "";
 }
 
 std::string ClipModel::encode(const float *img, float *out) {

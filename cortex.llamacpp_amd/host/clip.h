@@ -1,5 +1,6 @@
-// clip.h — the image side of a LLaVA request: projector file ("mmproj", general.architecture clip) on the device, image bytes -> RGB, the LLaVA-1.5
-// preprocessing, and the encoder (CLIP ViT tower + MLP projector) -> n_patches rows of the language model's n_embd.
+// clip.h — the image side of a LLaVA request: projector file ("mmproj", general.architecture clip) on the device, image bytes -> RGB, the LLaVA-1.5 and
+// LLaVA-1.6 ("anyres" image grid) preprocessing, and the encoder (CLIP ViT tower + MLP projector) -> n_patches rows of the language model's n_embd per
+// encoded image (one for LLaVA-1.5; an overview + the tiles of the chosen grid for LLaVA-1.6).
 //
 // Replaces what the reference takes from llama.cpp's examples/llava for this path (clip.cpp / llava.cpp; the submodule is not in the mount):
 //   clip_model_load            /root/reference/src/llama_server_context.cc:187
@@ -10,6 +11,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace mi355 {
@@ -33,9 +35,22 @@ class ClipModel {
     int image_size = 0, patch_size = 0, n_embd = 0, n_ff = 0, n_head = 0, n_layer = 0, proj_dim = 0;
     bool use_gelu = false;
     float eps = 1e-5f, mean[3] = {0, 0, 0}, stdv[3] = {1, 1, 1};
+    // LLaVA-1.6: clip.vision.image_grid_pinpoints = the (width, height) canvases a picture may be fitted to, clip.vision.mm_patch_merge_type ("spatial_unpad"
+    // turns the grid on; anything else encodes the overview only)
+    std::vector<std::pair<int, int>> pinpoints;
+    std::string merge_type = "flat";
+    bool has_grid() const { return !pinpoints.empty(); }
     int n_patches() const { const int g = image_size / patch_size; return g * g; }
+    // the most rows one picture can produce: n_patches for LLaVA-1.5, n_patches * (1 + the tiles of the largest canvas) with a grid
+    int max_image_rows() const;
     // clip_image_preprocess (LLaVA-1.5): [3][S][S] floats
     void preprocess(const ClipImageU8 &img, std::vector<float> &out) const;
+    // clip_image_preprocess, every image the encoder is to see for one picture: LLaVA-1.5 the one above; with a grid the overview (the whole picture resized to
+    // S x S) followed by the S x S tiles of the fitted canvas, row-major; grid_w x grid_h = tiles across / down (0 x 0 without a grid)
+    void preprocess_all(const ClipImageU8 &img, std::vector<std::vector<float>> &out, int &grid_w, int &grid_h) const;
+    // llava_image_embed_make_with_clip_img: rows [n_rows][proj_dim] of one picture - preprocess_all, encode each, and with a grid the tiles' rows re-ordered into
+    // whole-canvas row-major order behind the overview's.  Empty string on success.
+    std::string embed(const ClipImageU8 &img, std::vector<float> &rows, int &n_rows);
     // clip_image_encode: img [3][S][S] (host) -> out [n_patches][proj_dim] (host).  Empty string on success.
     std::string encode(const float *img, float *out);
     uint64_t device_bytes = 0;

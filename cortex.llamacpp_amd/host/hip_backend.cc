@@ -50,10 +50,9 @@ class HipBackend : public IBackend {
         err = clip_image_load_from_bytes(bytes, n, img);
         if (!err.empty()) return -1;
         std::vector<float> pix;
-        clip_->preprocess(img, pix);
-        rows.resize((size_t)clip_->n_patches() * (size_t)clip_->proj_dim);
-        err = clip_->encode(pix.data(), rows.data());
-        return err.empty() ? clip_->n_patches() : -1;
+        int n_rows = 0;
+        err = clip_->embed(img, rows, n_rows);
+        return err.empty() ? n_rows : -1;
     }
     int decode_embd(const float *rows, int n, int pos0, int seq) override {
         pos_store_.resize((size_t)n);
@@ -162,10 +161,24 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     cp.n_ctx = (uint32_t)std::max(8, body.value<int>("ctx_len", 2048));
     // a projector file makes the context multimodal; the reference then asks for at least 2048 cells, room for an image's embedding rows (llama_server_context.cc:194-205)
     const std::string mmproj = body["mmproj"].is_string() ? body["mmproj"].as_string() : std::string();
+    std::unique_ptr<ClipModel> clip;
     if (!mmproj.empty()) {
         if (model->hp.encoder) { err = "mmproj: an embedding model cannot take a multimodal projector"; return nullptr; }
         if (model->hp.tp_exchange) { err = "mmproj: not supported together with the row split"; return nullptr; }
-        if (cp.n_ctx < 2048) { cp.n_ctx = 2048; log_line(LOG_INFO, "Request %d for context length for the image embedding", 2048); }
+        // clip_model_load + the width check of llama_server_context.cc:216-229
+        clip.reset(new ClipModel);
+        const std::string cerr = clip->load(mmproj, body.value<int>("main_gpu", 0));
+        if (!cerr.empty()) { err = "unable to load clip model: " + cerr; return nullptr; }
+        if (clip->proj_dim != model->hp.n_embd) {
+            err = "embedding dim of the multimodal projector (" + std::to_string(clip->proj_dim) + ") is not equal to that of the model (" + std::to_string(model->hp.n_embd) +
+                  "). Make sure that you use the correct mmproj file.";
+            return nullptr;
+        }
+        // LLaVA-1.6 (an image grid: up to five encoded images a picture) needs more room than LLaVA-1.5; the reference tells the two apart by the model's
+        // file name (IsLlava_1_6, :170-175, :195) - here the projector file's own image grid counts as well
+        const bool v16 = path.find("llava-v1.6") != std::string::npos || clip->max_image_rows() > clip->n_patches();
+        if (v16 && cp.n_ctx < 4096) { cp.n_ctx = 4096; log_line(LOG_INFO, "Request %d for context length for llava-1.6", 4096); }
+        else if (cp.n_ctx < 2048) { cp.n_ctx = 2048; log_line(LOG_INFO, "Request %d for context length for the image embedding", 2048); }
     }
     cp.n_batch = (uint32_t)std::max(1, body.value<int>("n_batch", 2048));
     cp.n_ubatch = (uint32_t)std::max(1, body.value<int>("n_ubatch", (int)cp.n_batch));
@@ -185,18 +198,7 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     info.vram = model->device_bytes + ctx->device_bytes;
     info.ram = model->host_bytes;
     info.model_size = model->file_tensor_bytes;
-    std::unique_ptr<ClipModel> clip;
-    if (!mmproj.empty()) {   // clip_model_load + the width check of llama_server_context.cc:216-229
-        clip.reset(new ClipModel);
-        const std::string cerr = clip->load(mmproj, body.value<int>("main_gpu", 0));
-        if (!cerr.empty()) { err = "unable to load clip model: " + cerr; return nullptr; }
-        if (clip->proj_dim != model->hp.n_embd) {
-            err = "embedding dim of the multimodal projector (" + std::to_string(clip->proj_dim) + ") is not equal to that of the model (" + std::to_string(model->hp.n_embd) +
-                  "). Make sure that you use the correct mmproj file.";
-            return nullptr;
-        }
-        info.vram += clip->device_bytes;
-    }
+    if (clip) info.vram += clip->device_bytes;
     std::unique_ptr<HipBackend> be(new HipBackend(std::move(model), std::move(ctx), std::move(vocab), body.value<bool>("device_sampling", true)));
     be->set_clip(std::move(clip));
     return be;

@@ -340,21 +340,30 @@ MI355_API double  mi355_bench_weight_sweep2(mi355_context *ctx, int iters, uint6
 /* ------------------------------------------------------------------ LLaVA image path (projector file "mmproj"; llama.cpp examples/llava behind the reference)
  * The reference: clip_model_load (llama_server_context.cc:187), clip_n_mmproj_embd (:217), clip_image_load_from_bytes (:568),
  * llava_image_embed_make_with_clip_img (:820, = clip_image_preprocess + clip_image_encode); the rows then enter the model as llama_batch.embd (:1093-1107).
- * LLaVA-1.5 style files (CLIP ViT tower, MLP projector, f16 weights); image grids (LLaVA-1.6) are refused at load. */
+ * LLaVA-1.5 and LLaVA-1.6 style files (CLIP ViT tower, MLP projector, f16 weights; LLaVA-1.6 = clip.vision.image_grid_pinpoints with
+ * clip.vision.mm_patch_merge_type "spatial_unpad": a picture becomes an overview plus the tiles of the best-fitting canvas). */
 typedef struct mi355_clip mi355_clip;
 MI355_API mi355_clip *mi355_clip_model_load(const char *path, int32_t main_gpu);       /* clip_model_load; NULL + mi355_last_error on failure */
 MI355_API void        mi355_clip_free(mi355_clip *clip);                                /* clip_free */
 MI355_API int32_t     mi355_clip_n_mmproj_embd(const mi355_clip *clip);                 /* clip_n_mmproj_embd: must equal the model's n_embd */
 MI355_API int32_t     mi355_clip_n_patches(const mi355_clip *clip);                     /* clip_n_patches: embedding rows per image */
 MI355_API int32_t     mi355_clip_image_size(const mi355_clip *clip);
+/* the most rows mi355_llava_image_embed_from_bytes can write for one picture: n_patches (LLaVA-1.5) or n_patches * (1 + tiles of the largest canvas) */
+MI355_API int32_t     mi355_clip_max_image_rows(const mi355_clip *clip);
 /* clip_image_load_from_bytes: PNG / JPEG (baseline) / BMP / binary PNM bytes -> 8-bit RGB [ny][nx][3].  rgb_out may be NULL to query the size.
  * Returns 0, or < 0 with the reason in mi355_last_error (unknown format, truncated data, rgb_cap too small). */
 MI355_API int32_t     mi355_clip_image_load_from_bytes(const uint8_t *bytes, size_t n_bytes, int32_t *nx, int32_t *ny, uint8_t *rgb_out, size_t rgb_cap);
 /* clip_image_preprocess (LLaVA-1.5: pad to a square with the mean colour, bilinear resample, normalise): rgb [ny][nx][3] -> out [3][S][S], S = image_size */
 MI355_API int32_t     mi355_clip_image_preprocess(const mi355_clip *clip, const uint8_t *rgb, int32_t nx, int32_t ny, float *out);
+/* clip_image_preprocess, every image the encoder sees for one picture: one (as above) without an image grid; with one, the overview (bicubic resize of the whole
+ * picture to S x S) then the S x S tiles, row-major, of the picture fitted (aspect kept, bicubic, centred on black) to the best canvas of the grid.
+ * out [n][3][S][S]; returns n (<= 1 + max tiles) or < 0; grid_w x grid_h = tiles across / down (0 x 0 without a grid). */
+MI355_API int32_t     mi355_clip_image_preprocess_grid(const mi355_clip *clip, const uint8_t *rgb, int32_t nx, int32_t ny, float *out, size_t out_floats,
+                                                       int32_t *grid_w, int32_t *grid_h);
 /* clip_image_encode: img [3][S][S] -> out [n_patches][n_mmproj_embd] (host memory) */
 MI355_API int32_t     mi355_clip_image_encode(mi355_clip *clip, const float *img, float *out);
-/* llava_image_embed_make_with_clip_img on encoded image bytes: decode + preprocess + encode.  Returns the number of rows written (n_patches) or < 0. */
+/* llava_image_embed_make_with_clip_img on encoded image bytes: decode + preprocess + encode (+ with an image grid, the tiles' rows re-ordered to the canvas'
+ * row-major order behind the overview's: clip_llava_handle_patches).  Returns the number of rows written (<= mi355_clip_max_image_rows) or < 0. */
 MI355_API int32_t     mi355_llava_image_embed_from_bytes(mi355_clip *clip, const uint8_t *bytes, size_t n_bytes, float *out, size_t out_floats);
 
 #ifdef __cplusplus

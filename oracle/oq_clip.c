@@ -1,12 +1,18 @@
 /*
  * oracle/oq_clip.c — CPU restatement of the LLaVA image path: clip_image_preprocess + clip_image_encode of a LLaVA-1.5 style projector file
- * (general.architecture "clip": CLIP ViT tower cut after its second-to-last block, two-layer MLP projector).
+ * (general.architecture "clip": CLIP ViT tower cut after its second-to-last block, two-layer MLP projector), and the LLaVA-1.6 image grid on top of it.
  *
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: the code restated here is llama.cpp's examples/llava/clip.cpp (submodule `llama.cpp`, an empty
  * directory in /root/reference); the reference reaches it through clip_model_load (/root/reference/src/llama_server_context.cc:187),
  * clip_image_load_from_bytes (:568) and llava_image_embed_make_with_clip_img (:820), and holds no vector for it.  Restated from the published graph:
  *   preprocess (LLaVA-1.5: no image grid): pad to a square with the mean colour (122, 116, 104), top-left aligned; bilinear resample to image_size with
  *     the half-pixel mapping sx = (x + 0.5) * scale - 0.5; round to a byte; (v / 255 - mean[c]) / std[c]; planar [3][S][S].
+ *   preprocess (LLaVA-1.6: clip.vision.image_grid_pinpoints present): image 0 = the whole picture resized to S x S with clip.cpp's bicubic_resize (source index
+ *     truncated, Catmull-Rom style cubic, separable, edges clamped, rounded to a byte); with clip.vision.mm_patch_merge_type "spatial_unpad" followed by the
+ *     S x S tiles, row-major, of the picture fitted to the best canvas (select_best_resolution: most kept pixels, then least waste; resize_and_pad_image:
+ *     aspect-preserving bicubic resize, centred on black); every image normalised (v / 255 - mean) / std without further resampling.
+ *   embed (llava.cpp encode_image_with_clip + clip_llava_handle_patches): encode every image; the overview's rows first, then the tiles' rows re-ordered from
+ *     tile-by-tile to the canvas' row-major order ("without newline tokens": model.image_newline is not used).
  *   encode: patch embedding = 2-d convolution, stride = patch (im2col in f16 x f16 kernel); [class ; patches] + position embeddings; pre-LayerNorm; per block:
  *     LN1 -> Q (scaled by 1 / sqrt(d_head) after its bias), K, V with biases -> softmax(K^T Q) -> V -> output projection + bias -> residual ->
  *     LN2 -> ffn_down tensor (n_embd -> n_ff; the converter's names are swapped) + bias -> quick-GELU (or GELU: clip.use_gelu) -> ffn_up tensor + bias ->
@@ -36,6 +42,7 @@ struct oq_clip {
     int n_tensors; ct *tensors;
     int image_size, patch_size, n_embd, n_ff, n_head, n_layer, proj_dim, use_gelu;
     float eps, mean[3], std[3];
+    int n_pin, pin[128], spatial_unpad;           /* (width, height) pairs */
     const ct *class_embd, *patch_w, *pos_embd, *pre_ln_w, *pre_ln_b, *mm0w, *mm0b, *mm2w, *mm2b;
     clayer layers[CLIP_MAX_LAYERS];
 };
@@ -98,17 +105,21 @@ oq_clip *oq_clip_load(const char *path) {
         if (type == 8) {
             rd_str(&r, sval, sizeof sval);
             if (!strcmp(key, "general.architecture")) is_clip = !strcmp(sval, "clip");
+            if (!strcmp(key, "clip.vision.mm_patch_merge_type")) c->spatial_unpad = !strcmp(sval, "spatial_unpad");
             continue;
         }
         if (type == 9) {
             const int et = (int)rd_u(&r, 4);
             const uint64_t n = rd_u(&r, 8);
             float *dst = !strcmp(key, "clip.vision.image_mean") ? c->mean : !strcmp(key, "clip.vision.image_std") ? c->std : NULL;
+            const int is_pin = !strcmp(key, "clip.vision.image_grid_pinpoints") && (et == 4 || et == 5) && n <= 128 && n % 2 == 0;
+            if (is_pin) c->n_pin = (int)n / 2;
             for (uint64_t j = 0; j < n && !r.bad; j++) {
                 if (et == 8) { const uint64_t l = rd_u(&r, 8); if (r.p + l > r.end) r.bad = 1; else r.p += l; }
                 else if (et >= 0 && et < 13 && scalar_size[et]) {
                     const uint64_t raw = rd_u(&r, scalar_size[et]);
                     if (dst && et == 6 && j < 3) { const uint32_t b = (uint32_t)raw; memcpy(&dst[j], &b, 4); }
+                    if (is_pin) c->pin[j] = (int)(int32_t)(uint32_t)raw;
                 } else r.bad = 1;
             }
             continue;
@@ -204,6 +215,120 @@ void oq_clip_preprocess(const oq_clip *c, const uint8_t *rgb, int nx, int ny, fl
                 out[(size_t)k * S * S + (size_t)y * S + x] = (((float)v2 / 255.0f) - c->mean[k]) / c->std[k];
             }
     free(tmp);
+}
+
+/* ---- LLaVA-1.6 */
+int oq_clip_max_image_rows(const oq_clip *c) {
+    int tiles = 0;
+    if (c->spatial_unpad)
+        for (int i = 0; i < c->n_pin; i++) {
+            const int t = (c->pin[2 * i] / c->image_size) * (c->pin[2 * i + 1] / c->image_size);
+            if (t > tiles) tiles = t;
+        }
+    return oq_clip_n_patches(c) * (1 + tiles);
+}
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+static float cubic(float p0, float p1, float p2, float p3, float t) {
+    /* the cubic of clip.cpp's bicubic_resize around p1: differences to the three neighbours, coefficients formed in double and stored as floats */
+    const float d0 = p0 - p1, d2 = p2 - p1, d3 = p3 - p1, a0 = p1;
+    const float a1 = (float)(-1.0 / 3 * d0 + d2 - 1.0 / 6 * d3);
+    const float a2 = (float)(1.0 / 2 * d0 + 1.0 / 2 * d2);
+    const float a3 = (float)(-1.0 / 6 * d0 - 1.0 / 2 * d2 + 1.0 / 6 * d3);
+    return a0 + a1 * t + a2 * t * t + a3 * t * t * t;
+}
+static uint8_t *bicubic(const uint8_t *src, int nx, int ny, int tw, int th) {
+    uint8_t *dst = (uint8_t *)malloc((size_t)3 * tw * th);
+    const float tx = (float)nx / (float)tw, ty = (float)ny / (float)th;
+    for (int i = 0; i < th; i++)
+        for (int j = 0; j < tw; j++) {
+            const int x = (int)(tx * j), y = (int)(ty * i);
+            const float dx = tx * j - x, dy = ty * i - y;
+            for (int k = 0; k < 3; k++) {
+                float col[4];
+                for (int jj = 0; jj < 4; jj++) {
+                    const size_t row = (size_t)clampi(y - 1 + jj, 0, ny - 1) * nx;
+                    col[jj] = cubic(src[(row + clampi(x - 1, 0, nx - 1)) * 3 + k], src[(row + clampi(x, 0, nx - 1)) * 3 + k],
+                                    src[(row + clampi(x + 1, 0, nx - 1)) * 3 + k], src[(row + clampi(x + 2, 0, nx - 1)) * 3 + k], dx);
+                }
+                float v = roundf(cubic(col[0], col[1], col[2], col[3], dy));
+                if (v < 0.0f) v = 0.0f;
+                if (v > 255.0f) v = 255.0f;
+                dst[((size_t)i * tw + j) * 3 + k] = (uint8_t)v;
+            }
+        }
+    return dst;
+}
+static void best_canvas(const oq_clip *c, int ow, int oh, int *bw, int *bh) {
+    int max_eff = 0, min_waste = 0x7fffffff;
+    *bw = c->pin[0]; *bh = c->pin[1];
+    for (int i = 0; i < c->n_pin; i++) {
+        const int w = c->pin[2 * i], h = c->pin[2 * i + 1];
+        const float sw = (float)w / ow, sh = (float)h / oh, scale = sw < sh ? sw : sh;
+        const int dw = (int)(ow * scale), dh = (int)(oh * scale);
+        const long long full = (long long)ow * oh, down = (long long)dw * dh;
+        const int eff = (int)(down < full ? down : full), waste = w * h - eff;
+        if (eff > max_eff || (eff == max_eff && waste < min_waste)) { max_eff = eff; min_waste = waste; *bw = w; *bh = h; }
+    }
+}
+static void window_to_planar(const oq_clip *c, const uint8_t *img, int nx, int x0, int y0, float *out) {
+    const int S = c->image_size;
+    for (int k = 0; k < 3; k++)
+        for (int y = 0; y < S; y++)
+            for (int x = 0; x < S; x++)
+                out[(size_t)k * S * S + (size_t)y * S + x] = ((float)img[((size_t)(y + y0) * nx + (x + x0)) * 3 + k] / 255.0f - c->mean[k]) / c->std[k];
+}
+int oq_clip_preprocess_all(const oq_clip *c, const uint8_t *rgb, int nx, int ny, float *out, int cap_images, int *grid_w, int *grid_h) {
+    const int S = c->image_size;
+    const size_t per = (size_t)3 * S * S;
+    *grid_w = *grid_h = 0;
+    if (cap_images < 1) return -1;
+    if (c->n_pin == 0) { oq_clip_preprocess(c, rgb, nx, ny, out); return 1; }
+    uint8_t *ov = bicubic(rgb, nx, ny, S, S);
+    window_to_planar(c, ov, S, 0, 0, out);
+    free(ov);
+    if (!c->spatial_unpad) return 1;
+    int tw, th;
+    best_canvas(c, nx, ny, &tw, &th);
+    const float sw = (float)tw / nx, sh = (float)th / ny;
+    int nw, nh;
+    if (sw < sh) { nw = tw; nh = (int)ceilf(ny * sw); if (nh > th) nh = th; }
+    else { nh = th; nw = (int)ceilf(nx * sh); if (nw > tw) nw = tw; }
+    uint8_t *rs = bicubic(rgb, nx, ny, nw, nh);
+    uint8_t *canvas = (uint8_t *)calloc((size_t)3 * tw * th, 1);
+    const int ox = (tw - nw) / 2, oy = (th - nh) / 2;
+    for (int y = 0; y < nh; y++)
+        for (int x = 0; x < nw; x++)
+            for (int k = 0; k < 3; k++) canvas[((size_t)(y + oy) * tw + (x + ox)) * 3 + k] = rs[((size_t)y * nw + x) * 3 + k];
+    free(rs);
+    const int gw = tw / S, gh = th / S;
+    int n = 1;
+    if (1 + gw * gh > cap_images) { free(canvas); return -1; }
+    for (int gy = 0; gy < gh; gy++)
+        for (int gx = 0; gx < gw; gx++) window_to_planar(c, canvas, tw, gx * S, gy * S, out + per * (size_t)n++);
+    free(canvas);
+    *grid_w = gw; *grid_h = gh;
+    return n;
+}
+int oq_clip_embed(const oq_clip *c, const uint8_t *rgb, int nx, int ny, float *out, int cap_rows, int nth) {
+    const int S = c->image_size, G = S / c->patch_size, NP = G * G, E = c->proj_dim, cap_images = oq_clip_max_image_rows(c) / NP;
+    float *imgs = (float *)malloc(sizeof(float) * (size_t)3 * S * S * cap_images);
+    int gw, gh;
+    const int n = oq_clip_preprocess_all(c, rgb, nx, ny, imgs, cap_images, &gw, &gh);
+    if (n < 1 || n * NP > cap_rows) { free(imgs); return -1; }
+    oq_clip_encode(c, imgs, out, nth);
+    float *tile = (float *)malloc(sizeof(float) * (size_t)NP * E);
+    for (int t = 1; t < n; t++) {
+        oq_clip_encode(c, imgs + (size_t)t * 3 * S * S, tile, nth);
+        const int gy = (t - 1) / gw, gx = (t - 1) % gw;
+        /* token (py, px) of tile (gy, gx) sits at canvas position (gy * G + py, gx * G + px) of a (gh * G) x (gw * G) row-major sheet */
+        for (int py = 0; py < G; py++)
+            for (int px = 0; px < G; px++) {
+                const size_t dst = (size_t)NP + (size_t)(gy * G + py) * ((size_t)gw * G) + (size_t)(gx * G + px);
+                memcpy(out + dst * E, tile + ((size_t)py * G + px) * E, sizeof(float) * (size_t)E);
+            }
+    }
+    free(tile); free(imgs);
+    return n * NP;
 }
 
 static void ln_rows(const float *x, float *y, int64_t n, int64_t T, float eps, const ct *w, const ct *b) {

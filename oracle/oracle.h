@@ -152,6 +152,11 @@ void     oq_clip_free(oq_clip *c);
 int      oq_clip_image_size(const oq_clip *c);
 int      oq_clip_n_patches(const oq_clip *c);
 int      oq_clip_n_mmproj_embd(const oq_clip *c);
+/* LLaVA-1.6 (image grid): the most rows a picture can yield; every image the encoder sees for a picture (out [n][3][S][S], returns n, grid_w x grid_h tiles);
+ * and the rows of a picture (overview first, then the tiles' rows in the canvas' row-major order; returns the row count or < 0) */
+int      oq_clip_max_image_rows(const oq_clip *c);
+int      oq_clip_preprocess_all(const oq_clip *c, const uint8_t *rgb, int nx, int ny, float *out, int cap_images, int *grid_w, int *grid_h);
+int      oq_clip_embed(const oq_clip *c, const uint8_t *rgb, int nx, int ny, float *out, int cap_rows, int n_threads);
 /* rgb: [ny][nx][3] bytes -> out: [3][S][S] normalised floats */
 void     oq_clip_preprocess(const oq_clip *c, const uint8_t *rgb, int nx, int ny, float *out);
 /* img: [3][S][S] -> out: [n_patches][n_mmproj_embd] */

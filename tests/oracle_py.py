@@ -85,6 +85,12 @@ def lib():
             getattr(L, nm).restype = i32
             getattr(L, nm).argtypes = [vp]
         L.oq_clip_preprocess.argtypes = [vp, vp, i32, i32, vp]
+        L.oq_clip_max_image_rows.restype = i32
+        L.oq_clip_max_image_rows.argtypes = [vp]
+        L.oq_clip_preprocess_all.restype = i32
+        L.oq_clip_preprocess_all.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+        L.oq_clip_embed.restype = i32
+        L.oq_clip_embed.argtypes = [vp, vp, i32, i32, vp, i32, i32]
         L.oq_clip_encode.restype = i32
         L.oq_clip_encode.argtypes = [vp, vp, vp, i32]
         L.oq_decode_embd.restype = i32
@@ -327,6 +333,30 @@ class OracleClip:
         self.image_size = lib().oq_clip_image_size(self.h)
         self.n_patches = lib().oq_clip_n_patches(self.h)
         self.n_embd = lib().oq_clip_n_mmproj_embd(self.h)
+        self.max_image_rows = lib().oq_clip_max_image_rows(self.h)
+
+    def preprocess_all(self, rgb: np.ndarray):
+        """LLaVA-1.6: ([n, 3, S, S], grid_w, grid_h)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        ny, nx, ch = rgb.shape
+        assert ch == 3
+        cap = self.max_image_rows // self.n_patches
+        out = np.empty((cap, 3, self.image_size, self.image_size), np.float32)
+        gw, gh = C.c_int32(0), C.c_int32(0)
+        n = lib().oq_clip_preprocess_all(self.h, _p(rgb), nx, ny, _p(out), cap, C.byref(gw), C.byref(gh))
+        if n < 1:
+            raise RuntimeError(f"oracle clip preprocess_all rc={n}")
+        return out[:n], gw.value, gh.value
+
+    def embed(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        ny, nx, ch = rgb.shape
+        assert ch == 3
+        out = np.empty((self.max_image_rows, self.n_embd), np.float32)
+        n = lib().oq_clip_embed(self.h, _p(rgb), nx, ny, _p(out), self.max_image_rows, threads())
+        if n < 1:
+            raise RuntimeError(f"oracle clip embed rc={n}")
+        return out[:n]
 
     def preprocess(self, rgb: np.ndarray) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

@@ -83,6 +83,38 @@ def test_image_bytes_to_embedding_rows(be, pkg, tmp_models):
     c.close()
 
 
+@pytest.mark.parametrize("w,h", [(150, 60), (40, 170), (100, 100), (9, 6), (640, 480), (56, 56)])
+def test_image_grid_matches_oracle(be, pkg, tmp_models, w, h):
+    """LLaVA-1.6: the overview + the tiles of the best canvas are the CPU restatement's images bit for bit, the grid shape is the same, and the rows of the
+    picture follow the restatement's (same tolerance as one encode) in the same order"""
+    path = make_clip(pkg, tmp_models, "tiny-clip-grid")
+    c, o = pkg.Clip(path), oq.OracleClip(path)
+    assert c.max_image_rows == o.max_image_rows == 80
+    rgb = photo(w, h, w * 7 + h)
+    (gi, gw, gh), (oi, ow, oh) = c.preprocess_grid(rgb), o.preprocess_all(rgb)
+    assert (gw, gh) == (ow, oh) and np.array_equal(gi, oi)
+    PIL = pytest.importorskip("PIL.Image")
+    b = io.BytesIO()
+    PIL.fromarray(rgb).save(b, "PNG")
+    got, ref = c.embed_bytes(b.getvalue()), o.embed(rgb)
+    assert got.shape == ref.shape == (16 * (1 + gw * gh), c.n_embd)
+    err = np.abs(got - ref) / float(np.abs(ref).max())
+    assert err.max() <= 2e-3 and np.median(err) <= 2e-4, (err.max(), np.median(err))
+    c.close(); o.close()
+
+
+def test_image_grid_with_flat_merge_encodes_the_overview_only(be, pkg, tmp_models):
+    """a grid in the file but clip.vision.mm_patch_merge_type "flat": one image a picture - the bicubic overview"""
+    path = make_clip(pkg, tmp_models, "tiny-clip-grid-flat")
+    c, o = pkg.Clip(path), oq.OracleClip(path)
+    assert c.max_image_rows == o.max_image_rows == 16
+    rgb = photo(150, 60, 5)
+    (gi, gw, gh), (oi, ow, oh) = c.preprocess_grid(rgb), o.preprocess_all(rgb)
+    assert (gw, gh) == (ow, oh) == (0, 0) and gi.shape[0] == 1 and np.array_equal(gi, oi)
+    assert not np.array_equal(gi[0], c.preprocess(rgb))         # (not the LLaVA-1.5 pad-and-bilinear image)
+    c.close(); o.close()
+
+
 def test_load_refusals(be, pkg, tmp_models):
     """a language-model file is not a projector file; a missing file names itself"""
     lm = os.path.join(tmp_models, "tiny-for-clip.gguf")

@@ -361,6 +361,55 @@ def test_fullsize_image_rows_through_the_prompt_kernels(pkg, big, tmp_models):
     clip.close(); m.close()
 
 
+def test_fullsize_image_grid_picture_fills_a_4096_context(pkg, big, tmp_models):
+    """A LLaVA-1.6 prompt at full size: ViT-L/14-336 with the llava-v1.6 grid; a 1000 x 700 picture is fitted to the 672 x 672 canvas = overview + four tiles =
+    2880 rows of 4096 (the reason the reference asks for a 4096 context, llama_server_context.cc:194-198).  The five images are the CPU restatement's bit for bit;
+    the picture's rows are the per-image encodes in the canvas' row-major order; and text + 2880 rows (batches of 2048 + 832) + text decodes to finite logits that
+    do not depend on where the rows are cut."""
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    pkg.Backend()
+    mm = os.path.join(str(tmp_models), "mmproj-clip-vit-l-336-grid.gguf")
+    if not os.path.exists(mm):
+        pkg.gguf_synth.write_synthetic_clip(mm, "clip-vit-l-336-grid")
+    clip, o = pkg.Clip(mm), oq.OracleClip(mm)
+    m = pkg.Model(big)
+    assert clip.n_embd == m.n_embd and clip.n_patches == 576 and clip.max_image_rows == o.max_image_rows == 2880
+    rng = np.random.default_rng(16)
+    y, x = np.mgrid[0:700, 0:1000]
+    rgb = np.clip(np.stack([x * 255 // 999, y * 255 // 699, (x + y) % 256], -1) + rng.integers(-30, 31, (700, 1000, 3)), 0, 255).astype(np.uint8)
+    (imgs, gw, gh), (oimgs, ow, oh) = clip.preprocess_grid(rgb), o.preprocess_all(rgb)
+    assert (gw, gh) == (ow, oh) == (2, 2) and np.array_equal(imgs, oimgs)
+    b = io.BytesIO()
+    PIL.fromarray(rgb).save(b, "PNG")
+    rows = clip.embed_bytes(b.getvalue())
+    assert rows.shape == (2880, 4096) and np.isfinite(rows).all()
+    per = [clip.encode(i) for i in imgs]
+    assert np.array_equal(rows[:576], per[0])
+    sheet = rows[576:].reshape(48, 48, 4096)                                # (the canvas: 2 x 2 tiles of 24 x 24 rows)
+    for t in range(4):
+        gy, gx = divmod(t, 2)
+        assert np.array_equal(sheet[gy * 24:(gy + 1) * 24, gx * 24:(gx + 1) * 24].reshape(576, 4096), per[1 + t])
+    rows = rows * (0.02 / max(1e-9, float(np.abs(rows).mean())))
+    pre, suf = rng.integers(0, m.n_vocab, 7), rng.integers(0, m.n_vocab, 5)
+
+    def run(cuts):
+        c = pkg.Context(m, n_ctx=4096, n_batch=2048, n_ubatch=2048, type_k=8, type_v=8)
+        assert c.decode(pre, np.arange(7)) == 0
+        at = 7
+        for a0, a1 in cuts:
+            assert c.decode_embd(rows[a0:a1], np.arange(at, at + (a1 - a0))) == 0
+            at += a1 - a0
+        assert c.decode(suf, np.arange(at, at + 5)) == 0
+        lg = c.logits()
+        c.close()
+        return lg
+    one, two = run([(0, 2048), (2048, 2880)]), run([(0, 576), (576, 1728), (1728, 2880)])
+    assert np.isfinite(one).all() and np.isfinite(two).all()
+    assert rel_err(one, two) <= FLIP_TOL, rel_err(one, two)
+    clip.close(); o.close(); m.close()
+
+
 def test_fullsize_context_filled_matches_committed_oracle_logits(pkg, big):
     """The headline model at BASELINE's ctx_len: a 3968-token prompt (two micro-batches of 2048) and one step on the 32-layer synthetic Llama-3-8B file, q8_0 cache,
     against the CPU oracle's logits for exactly that file and prompt - computed once (tests/golden/make_golden_fullsize_ctx.py: minutes on 192 threads, far too long

@@ -195,3 +195,24 @@ def test_two_image_requests_at_once(pkg, engine, files):
             st, body = together[i]
             assert st["status_code"] == 200 and not st["has_error"], (st, body)
             assert body["choices"][0]["message"]["content"] == alone[i]
+
+
+def test_image_grid_model(pkg, files, tmp_path_factory):
+    """LLaVA-1.6: a projector file with an image grid - a 150 x 60 picture becomes an overview + three tiles = 64 rows (16 with the LLaVA-1.5 file); the answer is
+    the greedy continuation of the same rows through the context API"""
+    mm = str(tmp_path_factory.mktemp("llava16") / "mmproj-grid-1024.gguf")
+    pkg.gguf_synth.write_synthetic_clip(mm, "tiny-clip-grid-1024")
+    e = pkg.Engine()
+    st, body = e.load_model(llama_model_path=files[0], mmproj=mm, ctx_len=512, n_parallel=1, ngl=100, user_prompt="u:", ai_prompt="a:", system_prompt="s:")
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    png = encoded(photo(150, 60, 9))
+    msgs = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": data_url(png)}}, {"type": "text", "text": " describe"}]}]
+    st, body = e.chat_completion(model="tiny-d128", messages=msgs, max_tokens=8, **GREEDY)[-1]
+    assert st["status_code"] == 200 and not st["has_error"], (st, body)
+    want, n_prompt = independent_answer(pkg, (files[0], mm), ["u:", png, " describea:"], 8)
+    assert body["choices"][0]["message"]["content"] == want.lstrip()
+    assert body["usage"]["prompt_tokens"] == n_prompt
+    clip = pkg.Clip(mm)
+    assert len(clip.embed_bytes(png)) == 64
+    clip.close()
+    e.close()
