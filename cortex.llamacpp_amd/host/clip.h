@@ -5,7 +5,7 @@
 // Replaces what the reference takes from llama.cpp's examples/llava for this path (clip.cpp / llava.cpp; the submodule is not in the mount):
 //   clip_model_load            /root/reference/src/llama_server_context.cc:187
 //   clip_n_mmproj_embd         :216
-//   clip_image_load_from_bytes :568      (stb_image there; PNG / BMP / PNM / baseline JPEG decoders here)
+//   clip_image_load_from_bytes :568      (stb_image there; PNG / BMP / PNM / JPEG decoders here)
 //   llava_image_embed_make_with_clip_img :820   (= clip_image_preprocess + clip_image_encode)
 #pragma once
 
@@ -18,7 +18,7 @@ namespace mi355 {
 
 struct ClipImageU8 { int nx = 0, ny = 0; std::vector<uint8_t> rgb; };      // [ny][nx][3]
 
-// PNG (8-bit grey / RGB / palette, with or without alpha, non-interlaced), BMP (24 / 32 bit), binary PNM (P5 / P6), baseline JPEG (8-bit, Huffman, any
+// PNG (8-bit grey / RGB / palette, with or without alpha, interlaced or not), BMP (24 / 32 bit), binary PNM (P5 / P6), JPEG (sequential or progressive, 8-bit, Huffman, any
 // sampling factors, restart intervals).  Returns an empty string on success, else why not.
 std::string clip_image_load_from_bytes(const uint8_t *data, size_t n, ClipImageU8 &out);
 

@@ -1,10 +1,11 @@
 // image_decode.cc — image bytes -> 8-bit RGB for the LLaVA path (clip.h clip_image_load_from_bytes; the reference calls stb_image through
 // clip_image_load_from_bytes, /root/reference/src/llama_server_context.cc:568).  Own decoders, written from the format specifications:
 //   PNG  (RFC 2083 + zlib / deflate RFC 1950 / 1951): 8-bit grey, grey + alpha, RGB, RGBA, palette (1 / 2 / 4 / 8 bit); 16-bit samples keep their high byte;
-//        non-interlaced; alpha is dropped (stb_image's 3-channel request does the same)
+//        non-interlaced or Adam7; alpha is dropped (stb_image's 3-channel request does the same)
 //   BMP  uncompressed 24 / 32 bit, bottom-up or top-down
 //   PNM  binary P5 / P6, maxval < 256
-//   JPEG baseline sequential DCT (SOF0 / SOF1 8-bit), Huffman, 1 or 3 components with any sampling factors, restart intervals; progressive files are refused
+//   JPEG Huffman-coded sequential (SOF0 / SOF1) and progressive (SOF2) DCT, 8-bit, 1 or 3 components with any sampling factors, any number of scans
+//        (interleaved or not), restart intervals; lossless / hierarchical / arithmetic-coded files are refused
 // Lossless formats decode to the bytes any decoder produces.  JPEG: the inverse DCT here is the float reference transform rounded to nearest, 2:1 subsampled
 // chroma goes through libjpeg's triangle filter; stb_image uses a fixed-point transform and its own variant of that filter, so its bytes can differ from these by
 // a few units (as two conforming JPEG decoders do).
@@ -167,7 +168,7 @@ std::string load_png(const uint8_t *d, size_t n, ClipImageU8 &out) {
         pos += 12 + (size_t)len;
     }
     if (!have_ihdr || w <= 0 || h <= 0 || w > 16384 || h > 16384 || (int64_t)w * h > MAX_PIXELS) return "PNG: bad dimensions";
-    if (interlace) return "PNG: interlaced images are not supported";
+    if (interlace > 1) return "PNG: unknown interlace method";
     int ch;
     switch (ctype) {
         case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break;
@@ -176,43 +177,61 @@ std::string load_png(const uint8_t *d, size_t n, ClipImageU8 &out) {
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return "PNG: unsupported bit depth";
     if (ctype == 3 && (depth == 16 || pal.empty())) return "PNG: palette image without a palette";
     const int bpp_bits = ch * depth, bpp = (bpp_bits + 7) / 8;
-    const size_t stride = ((size_t)w * bpp_bits + 7) / 8;
+    // the picture is one pass of w x h pixels, or (Adam7) seven reduced pictures - pass p holds the pixels (x0 + i * dx, y0 + j * dy) - each filtered on its own
+    struct Pass { int x0, y0, dx, dy, pw, ph; size_t stride; };
+    static const int A7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    std::vector<Pass> passes;
+    size_t need = 0;
+    for (int p = 0; p < (interlace ? 7 : 1); p++) {
+        Pass ps;
+        if (interlace) { ps.x0 = A7[p][0]; ps.y0 = A7[p][1]; ps.dx = A7[p][2]; ps.dy = A7[p][3]; }
+        else { ps.x0 = ps.y0 = 0; ps.dx = ps.dy = 1; }
+        ps.pw = (w - ps.x0 + ps.dx - 1) / ps.dx; ps.ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (ps.pw <= 0 || ps.ph <= 0) continue;
+        ps.stride = ((size_t)ps.pw * bpp_bits + 7) / 8;
+        need += (ps.stride + 1) * (size_t)ps.ph;
+        passes.push_back(ps);
+    }
     std::vector<uint8_t> raw;
-    if (!inflate_zlib(idat.data(), idat.size(), raw, (stride + 1) * (size_t)h) || raw.size() < (stride + 1) * (size_t)h) return "PNG: bad compressed data";
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    if (!inflate_zlib(idat.data(), idat.size(), raw, need) || raw.size() < need) return "PNG: bad compressed data";
     out.nx = w; out.ny = h; out.rgb.assign((size_t)3 * w * h, 0);
-    for (int y = 0; y < h; y++) {
-        const uint8_t *line = raw.data() + (size_t)y * (stride + 1);
-        const int ft = line[0];
-        if (ft > 4) return "PNG: bad filter type";
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-            int pred = 0;
-            switch (ft) {
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) >> 1; break;
-                case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-                default: break;
+    const uint8_t *line = raw.data();
+    for (const Pass &ps : passes) {
+        const size_t stride = ps.stride;
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (int y = 0; y < ps.ph; y++, line += stride + 1) {
+            const int ft = line[0];
+            if (ft > 4) return "PNG: bad filter type";
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                switch (ft) {
+                    case 1: pred = a; break;
+                    case 2: pred = b; break;
+                    case 3: pred = (a + b) >> 1; break;
+                    case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                    default: break;
+                }
+                cur[i] = (uint8_t)(line[1 + i] + pred);
             }
-            cur[i] = (uint8_t)(line[1 + i] + pred);
+            uint8_t *orow = out.rgb.data() + (size_t)3 * (size_t)(ps.y0 + y * ps.dy) * w;
+            for (int x = 0; x < ps.pw; x++) {
+                auto sample = [&](int k) -> int {                     // sample k of pixel x of this pass, reduced to 8 bits
+                    if (depth == 8) return cur[(size_t)x * ch + k];
+                    if (depth == 16) return cur[((size_t)x * ch + k) * 2];
+                    const int bit = x * depth, v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                    return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+                };
+                uint8_t *o = orow + (size_t)3 * (size_t)(ps.x0 + x * ps.dx);
+                if (ctype == 3) {
+                    const size_t idx = (size_t)sample(0);
+                    if (idx * 3 + 2 >= pal.size()) return "PNG: palette index out of range";
+                    o[0] = pal[idx * 3]; o[1] = pal[idx * 3 + 1]; o[2] = pal[idx * 3 + 2];
+                } else if (ch <= 2) { const uint8_t g = (uint8_t)sample(0); o[0] = g; o[1] = g; o[2] = g; }
+                else { o[0] = (uint8_t)sample(0); o[1] = (uint8_t)sample(1); o[2] = (uint8_t)sample(2); }
+            }
+            prev.swap(cur);
         }
-        uint8_t *o = out.rgb.data() + (size_t)3 * y * w;
-        for (int x = 0; x < w; x++) {
-            auto sample = [&](int k) -> int {                     // sample k of pixel x, reduced to 8 bits
-                if (depth == 8) return cur[(size_t)x * ch + k];
-                if (depth == 16) return cur[((size_t)x * ch + k) * 2];
-                const int bit = x * depth, v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-                return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
-            };
-            if (ctype == 3) {
-                const size_t idx = (size_t)sample(0);
-                if (idx * 3 + 2 >= pal.size()) return "PNG: palette index out of range";
-                o[3 * x] = pal[idx * 3]; o[3 * x + 1] = pal[idx * 3 + 1]; o[3 * x + 2] = pal[idx * 3 + 2];
-            } else if (ch <= 2) { const uint8_t g = (uint8_t)sample(0); o[3 * x] = g; o[3 * x + 1] = g; o[3 * x + 2] = g; }
-            else { o[3 * x] = (uint8_t)sample(0); o[3 * x + 1] = (uint8_t)sample(1); o[3 * x + 2] = (uint8_t)sample(2); }
-        }
-        prev.swap(cur);
     }
     return "";
 }
@@ -266,7 +285,7 @@ std::string load_pnm(const uint8_t *d, size_t n, ClipImageU8 &out) {
     return "";
 }
 
-// ------------------------------------------------------------------------------------------------ JPEG (baseline)
+// ------------------------------------------------------------------------------------------------ JPEG
 struct JHuff {
     uint8_t bits[17] = {0}, vals[256] = {0};
     int mincode[17], maxcode[18], valptr[17];
@@ -282,7 +301,13 @@ struct JHuff {
         maxcode[17] = 0x7fffffff;
     }
 };
-struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0, stride = 0, rows = 0; std::vector<uint8_t> plane; };
+struct JComp {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0, stride = 0, rows = 0, bw = 0, bh = 0;     // bw x bh blocks (whole MCUs)
+    uint16_t q[64] = {0};
+    bool q_latched = false;
+    std::vector<int16_t> coef;             // [bh][bw][64], natural order, not yet dequantised
+    std::vector<uint8_t> plane;
+};
 struct JBits {
     const uint8_t *p, *end;
     uint32_t buf = 0;
@@ -342,13 +367,92 @@ void idct8x8(const float *in, uint8_t *out, int stride) {          // the refere
             out[y * stride + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
         }
 }
+// one block of a progressive scan (ITU T.81 annex G): spectral selection [Ss, Se], successive approximation (Ah = the bit position of the previous scan over these
+// coefficients, 0 in a first scan; Al = this scan's).  coef in natural (row-major) order; eobrun = blocks still covered by an end-of-band run
+struct JScan { int Ss = 0, Se = 63, Ah = 0, Al = 0, eobrun = 0; };
+const uint8_t JZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const char *jblock_sequential(JBits &br, const JHuff &dc, const JHuff &ac, int &pred, int16_t *coef) {
+    const int t = jdecode(br, dc);
+    if (t > 11) return "JPEG: bad DC code";
+    pred += jextend(br.get(t), t);
+    coef[0] = (int16_t)pred;
+    for (int k = 1; k < 64;) {
+        const int rs = jdecode(br, ac), r = rs >> 4, sz = rs & 15;
+        if (br.bad) return "JPEG: bad Huffman code";
+        if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+        k += r;
+        if (k > 63) return "JPEG: coefficient index out of range";
+        coef[JZZ[k]] = (int16_t)jextend(br.get(sz), sz);
+        k++;
+    }
+    return nullptr;
+}
+const char *jblock_progressive(JBits &br, const JHuff &dc, const JHuff &ac, int &pred, int16_t *coef, JScan &sc) {
+    if (sc.Ss == 0) {                       // DC scan
+        if (sc.Ah == 0) {
+            const int t = jdecode(br, dc);
+            if (t > 11) return "JPEG: bad DC code";
+            pred += jextend(br.get(t), t);
+            coef[0] = (int16_t)(pred * (1 << sc.Al));
+        } else if (br.get(1)) coef[0] = (int16_t)(coef[0] | (1 << sc.Al));
+        return nullptr;
+    }
+    if (sc.Ah == 0) {                       // AC, first scan over this band
+        if (sc.eobrun > 0) { sc.eobrun--; return nullptr; }
+        for (int k = sc.Ss; k <= sc.Se;) {
+            const int rs = jdecode(br, ac), r = rs >> 4, sz = rs & 15;
+            if (br.bad) return "JPEG: bad Huffman code";
+            if (sz == 0) {
+                if (r < 15) { sc.eobrun = (1 << r) - 1; if (r) sc.eobrun += br.get(r); break; }
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > sc.Se) return "JPEG: coefficient index out of range";
+            coef[JZZ[k]] = (int16_t)(jextend(br.get(sz), sz) * (1 << sc.Al));
+            k++;
+        }
+        return nullptr;
+    }
+    // AC refinement: one more bit for every coefficient that is already non-zero, and new +-1 << Al coefficients placed by runs counted over the zero ones
+    const int p1 = 1 << sc.Al, m1 = -(1 << sc.Al);
+    auto refine = [&](int16_t &c) {
+        if (br.get(1) && (c & p1) == 0) c = (int16_t)(c + (c >= 0 ? p1 : m1));
+    };
+    int k = sc.Ss;
+    if (sc.eobrun == 0) {
+        for (; k <= sc.Se; k++) {
+            const int rs = jdecode(br, ac), sz = rs & 15;
+            int r = rs >> 4, val = 0;
+            if (br.bad) return "JPEG: bad Huffman code";
+            if (sz == 0) {
+                if (r < 15) { sc.eobrun = 1 << r; if (r) sc.eobrun += br.get(r); break; }
+            } else {
+                if (sz != 1) return "JPEG: bad refinement code";
+                val = br.get(1) ? p1 : m1;
+            }
+            for (; k <= sc.Se; k++) {
+                int16_t &c = coef[JZZ[k]];
+                if (c != 0) refine(c);
+                else if (--r < 0) break;                      // the zero coefficient the run ends on
+            }
+            if (val && k <= sc.Se) coef[JZZ[k]] = (int16_t)val;
+        }
+    }
+    if (sc.eobrun > 0) {
+        for (; k <= sc.Se; k++) { int16_t &c = coef[JZZ[k]]; if (c != 0) refine(c); }
+        sc.eobrun--;
+    }
+    return nullptr;
+}
+
 std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
-    static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
     uint16_t qt[4][64] = {{0}};
     JHuff hdc[4], hac[4];
     std::vector<JComp> comps;
-    int W = 0, H = 0, restart = 0, hmax = 1, vmax = 1;
+    int W = 0, H = 0, restart = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, n_scans = 0;
+    bool progressive = false;
     size_t pos = 2;
     while (pos + 4 <= n) {
         if (d[pos] != 0xff) return "JPEG: marker expected";
@@ -367,7 +471,7 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
                 const int pq = s[o] >> 4, tq = s[o] & 15;
                 o++;
                 if (tq > 3 || o + (size_t)64 * (pq ? 2 : 1) > sl) return "JPEG: bad quantisation table";
-                for (int i = 0; i < 64; i++) { qt[tq][zz[i]] = pq ? (uint16_t)(s[o] << 8 | s[o + 1]) : s[o]; o += pq ? 2 : 1; }
+                for (int i = 0; i < 64; i++) { qt[tq][JZZ[i]] = pq ? (uint16_t)(s[o] << 8 | s[o + 1]) : s[o]; o += pq ? 2 : 1; }
             }
         } else if (m == 0xc4) {
             size_t o = 0;
@@ -384,8 +488,10 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
                 h.build();
                 h.present = true;
             }
-        } else if (m == 0xc0 || m == 0xc1) {
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {
+            if (!comps.empty()) return "JPEG: more than one frame";
             if (sl < 6 || s[0] != 8) return "JPEG: only 8-bit samples are supported";
+            progressive = m == 0xc2;
             H = s[1] << 8 | s[2]; W = s[3] << 8 | s[4];
             const int nc = s[5];
             if ((nc != 1 && nc != 3) || sl < (size_t)6 + 3 * nc || W <= 0 || H <= 0 || W > 16384 || H > 16384 || (int64_t)W * H > MAX_PIXELS) return "JPEG: unsupported frame";
@@ -395,105 +501,147 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
                 if (comps[i].h < 1 || comps[i].h > 4 || comps[i].v < 1 || comps[i].v > 4 || comps[i].tq > 3) return "JPEG: bad component";
                 hmax = std::max(hmax, comps[i].h); vmax = std::max(vmax, comps[i].v);
             }
-            // (a scan of ONE component is not interleaved: its unit is a single block whatever the sampling factors say)
+            // (a frame of ONE component is never interleaved: its unit is a single block whatever the sampling factors say)
             if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
-        } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-            return "JPEG: progressive / lossless / arithmetic-coded files are not supported (baseline only)";
+            mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            // the coefficients of the whole picture: scans (one for a baseline file as encoders write it, ten or so for a progressive one) fill them in
+            for (auto &c : comps) {
+                c.bw = mcux * c.h; c.bh = mcuy * c.v;
+                c.stride = c.bw * 8; c.rows = c.bh * 8;
+                c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+            }
+        } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+            return "JPEG: lossless / hierarchical / arithmetic-coded files are not supported (Huffman-coded sequential and progressive DCT only)";
         } else if (m == 0xdd) {
             if (sl >= 2) restart = s[0] << 8 | s[1];
         } else if (m == 0xda) {
             if (comps.empty() || sl < 1) return "JPEG: scan before frame";
             const int ns = s[0];
-            if (ns != (int)comps.size() || sl < (size_t)1 + 2 * ns + 3) return "JPEG: non-interleaved scans are not supported";
+            if (ns < 1 || ns > (int)comps.size() || sl < (size_t)1 + 2 * ns + 3) return "JPEG: bad scan header";
+            std::vector<JComp *> sc_comps;
             for (int i = 0; i < ns; i++) {
                 JComp *c = nullptr;
                 for (auto &cc : comps) if (cc.id == s[1 + 2 * i]) c = &cc;
                 if (!c) return "JPEG: scan names an unknown component";
                 c->td = s[2 + 2 * i] >> 4; c->ta = s[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !hdc[c->td].present || !hac[c->ta].present) return "JPEG: scan uses a missing Huffman table";
+                if (c->td > 3 || c->ta > 3) return "JPEG: bad table selector";
+                c->pred = 0;
+                sc_comps.push_back(c);
             }
-            const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
-            for (auto &c : comps) { c.stride = mcux * c.h * 8; c.rows = mcuy * c.v * 8; c.plane.assign((size_t)c.stride * c.rows, 128); c.pred = 0; }
+            JScan sc;
+            sc.Ss = s[1 + 2 * ns]; sc.Se = s[2 + 2 * ns]; sc.Ah = s[3 + 2 * ns] >> 4; sc.Al = s[3 + 2 * ns] & 15;
+            if (progressive) {
+                if (sc.Ss > sc.Se || sc.Se > 63 || sc.Ah > 13 || sc.Al > 13 || (sc.Ss == 0 && sc.Se != 0) || (sc.Ss > 0 && ns != 1)) return "JPEG: bad progressive scan parameters";
+            } else if (sc.Ss != 0 || sc.Se != 63 || sc.Ah != 0 || sc.Al != 0) return "JPEG: bad scan parameters";
+            for (JComp *c : sc_comps) {
+                const bool need_dc = !progressive || (sc.Ss == 0 && sc.Ah == 0), need_ac = !progressive || sc.Ss > 0;
+                if ((need_dc && !hdc[c->td].present) || (need_ac && !hac[c->ta].present)) return "JPEG: scan uses a missing Huffman table";
+                if (!c->q_latched) { memcpy(c->q, qt[c->tq], sizeof c->q); c->q_latched = true; }     // (the table in force at the component's first scan)
+            }
             JBits br{d + pos + len, d + n};
             int until_restart = restart;
-            for (int my = 0; my < mcuy; my++)
-                for (int mx = 0; mx < mcux; mx++) {
-                    if (restart && until_restart == 0) {
-                        // the RSTn marker: already consumed by the bit reader (it feeds zeros behind a marker), or still ahead
-                        if (!(br.marker >= 0xd0 && br.marker <= 0xd7)) {
-                            while (br.p + 1 < br.end && !(br.p[0] == 0xff && br.p[1] >= 0xd0 && br.p[1] <= 0xd7)) br.p++;
-                            if (br.p + 1 < br.end) br.p += 2;
-                        }
-                        br.reset();
-                        for (auto &c : comps) c.pred = 0;
-                        until_restart = restart;
-                    }
-                    for (auto &c : comps)
-                        for (int by = 0; by < c.v; by++)
-                            for (int bx = 0; bx < c.h; bx++) {
-                                float blk[64] = {0};
-                                const int t = jdecode(br, hdc[c.td]);
-                                if (t > 11) return "JPEG: bad DC code";
-                                c.pred += jextend(br.get(t), t);
-                                blk[0] = (float)(c.pred * (int)qt[c.tq][0]);
-                                for (int k = 1; k < 64;) {
-                                    const int rs = jdecode(br, hac[c.ta]), r = rs >> 4, sz = rs & 15;
-                                    if (br.bad) return "JPEG: bad Huffman code";
-                                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                                    k += r;
-                                    if (k > 63) return "JPEG: coefficient index out of range";
-                                    blk[zz[k]] = (float)(jextend(br.get(sz), sz) * (int)qt[c.tq][zz[k]]);
-                                    k++;
-                                }
-                                idct8x8(blk, c.plane.data() + (size_t)((my * c.v + by) * 8) * c.stride + (size_t)(mx * c.h + bx) * 8, c.stride);
-                            }
-                    if (restart) until_restart--;
+            auto at_restart = [&]() {
+                // the RSTn marker: already consumed by the bit reader (it feeds zeros behind a marker), or still ahead
+                if (!(br.marker >= 0xd0 && br.marker <= 0xd7)) {
+                    while (br.p + 1 < br.end && !(br.p[0] == 0xff && br.p[1] >= 0xd0 && br.p[1] <= 0xd7)) br.p++;
+                    if (br.p + 1 < br.end) br.p += 2;
                 }
-            // full-resolution planes.  2:1 horizontally (and vertically) subsampled components go through the triangle filter every mainstream decoder
-            // applies ("fancy upsampling", libjpeg jdsample.c h2v1 / h2v2: 3/4 nearer + 1/4 farther sample per direction); other ratios are replicated
-            std::vector<std::vector<uint8_t>> full(comps.size());
-            for (size_t ci = 0; ci < comps.size(); ci++) {
-                const JComp &c = comps[ci];
-                std::vector<uint8_t> &f = full[ci];
-                f.resize((size_t)W * H);
-                const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax;      // valid extent of the component
-                const bool h2 = hmax == 2 * c.h, v1 = vmax == c.v, v2 = vmax == 2 * c.v;
-                if (h2 && (v1 || v2) && cw >= 1) {
-                    for (int y = 0; y < H; y++) {
-                        const int r = v2 ? y >> 1 : y;
-                        int rf = v2 ? ((y & 1) ? r + 1 : r - 1) : r;                                 // the farther row of the pair
-                        if (rf < 0) rf = 0;
-                        if (rf > chh - 1) rf = chh - 1;
-                        const uint8_t *nr = c.plane.data() + (size_t)std::min(r, chh - 1) * c.stride, *fr = c.plane.data() + (size_t)rf * c.stride;
-                        uint8_t *o = f.data() + (size_t)y * W;
-                        auto colsum = [&](int i) { return v2 ? 3 * (int)nr[i] + (int)fr[i] : 4 * (int)nr[i]; };      // (x 4 of the vertical blend)
-                        for (int i = 0; i < cw; i++) {
-                            const int cur = colsum(i), prev = colsum(i > 0 ? i - 1 : 0), next = colsum(i + 1 < cw ? i + 1 : cw - 1);
-                            const int x0 = 2 * i, x1 = 2 * i + 1;
-                            const int a = i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + prev + 8) >> 4;
-                            const int b = i == cw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + next + 7) >> 4;
-                            if (x0 < W) o[x0] = (uint8_t)a;
-                            if (x1 < W) o[x1] = (uint8_t)b;
-                        }
+                br.reset();
+                for (JComp *c : sc_comps) c->pred = 0;
+                sc.eobrun = 0;
+                until_restart = restart;
+            };
+            auto block = [&](JComp &c, int bx, int by) -> const char * {
+                int16_t *coef = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+                return progressive ? jblock_progressive(br, hdc[c.td], hac[c.ta], c.pred, coef, sc) : jblock_sequential(br, hdc[c.td], hac[c.ta], c.pred, coef);
+            };
+            if (ns == 1) {
+                // a scan of one component is not interleaved: its blocks in raster order over the component's own extent
+                JComp &c = *sc_comps[0];
+                const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax, nbx = (cw + 7) / 8, nby = (chh + 7) / 8;
+                for (int by = 0; by < nby; by++)
+                    for (int bx = 0; bx < nbx; bx++) {
+                        if (restart && until_restart == 0) at_restart();
+                        if (const char *e = block(c, bx, by)) return e;
+                        if (br.bad) return "JPEG: bad Huffman code";
+                        if (restart) until_restart--;
                     }
-                } else {
-                    for (int y = 0; y < H; y++)
-                        for (int x = 0; x < W; x++) f[(size_t)y * W + x] = c.plane[(size_t)(y * c.v / vmax) * c.stride + (size_t)(x * c.h / hmax)];
-                }
+            } else {
+                for (int my = 0; my < mcuy; my++)
+                    for (int mx = 0; mx < mcux; mx++) {
+                        if (restart && until_restart == 0) at_restart();
+                        for (JComp *c : sc_comps)
+                            for (int by = 0; by < c->v; by++)
+                                for (int bx = 0; bx < c->h; bx++)
+                                    if (const char *e = block(*c, mx * c->h + bx, my * c->v + by)) return e;
+                        if (br.bad) return "JPEG: bad Huffman code";
+                        if (restart) until_restart--;
+                    }
             }
-            out.nx = W; out.ny = H; out.rgb.resize((size_t)3 * W * H);
-            for (size_t i = 0; i < (size_t)W * H; i++) {
-                uint8_t *o = out.rgb.data() + 3 * i;
-                if (comps.size() == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
-                const float Y = (float)full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
-                const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
-                for (int k = 0; k < 3; k++) { const float r = roundf(rgb[k]); o[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r); }
-            }
-            return "";
+            n_scans++;
+            // the next marker segment: behind the entropy-coded bytes (stuffed zeros and restart markers belong to them)
+            size_t q = pos + len;
+            while (q + 1 < n && !(d[q] == 0xff && d[q + 1] != 0 && d[q + 1] != 0xff && !(d[q + 1] >= 0xd0 && d[q + 1] <= 0xd7))) q++;
+            if (q + 1 >= n) break;                 // (no end-of-image marker: render what the scans gave)
+            pos = q;
+            continue;
         }
         pos += len;
     }
-    return "JPEG: no image data";
+    if (n_scans == 0) return "JPEG: no image data";
+    // dequantise + inverse transform, block by block
+    for (auto &c : comps) {
+        c.plane.assign((size_t)c.stride * c.rows, 128);
+        float blk[64];
+        for (int by = 0; by < c.bh; by++)
+            for (int bx = 0; bx < c.bw; bx++) {
+                const int16_t *coef = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+                for (int i = 0; i < 64; i++) blk[i] = (float)((int)coef[i] * (int)c.q[i]);
+                idct8x8(blk, c.plane.data() + (size_t)(by * 8) * c.stride + (size_t)bx * 8, c.stride);
+            }
+        std::vector<int16_t>().swap(c.coef);
+    }
+    // full-resolution planes.  2:1 horizontally (and vertically) subsampled components go through the triangle filter every mainstream decoder
+    // applies ("fancy upsampling", libjpeg jdsample.c h2v1 / h2v2: 3/4 nearer + 1/4 farther sample per direction); other ratios are replicated
+    std::vector<std::vector<uint8_t>> full(comps.size());
+    for (size_t ci = 0; ci < comps.size(); ci++) {
+        const JComp &c = comps[ci];
+        std::vector<uint8_t> &f = full[ci];
+        f.resize((size_t)W * H);
+        const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax;      // valid extent of the component
+        const bool h2 = hmax == 2 * c.h, v1 = vmax == c.v, v2 = vmax == 2 * c.v;
+        if (h2 && (v1 || v2) && cw >= 1) {
+            for (int y = 0; y < H; y++) {
+                const int r = v2 ? y >> 1 : y;
+                int rf = v2 ? ((y & 1) ? r + 1 : r - 1) : r;                                 // the farther row of the pair
+                if (rf < 0) rf = 0;
+                if (rf > chh - 1) rf = chh - 1;
+                const uint8_t *nr = c.plane.data() + (size_t)std::min(r, chh - 1) * c.stride, *fr = c.plane.data() + (size_t)rf * c.stride;
+                uint8_t *o = f.data() + (size_t)y * W;
+                auto colsum = [&](int i) { return v2 ? 3 * (int)nr[i] + (int)fr[i] : 4 * (int)nr[i]; };      // (x 4 of the vertical blend)
+                for (int i = 0; i < cw; i++) {
+                    const int cur = colsum(i), prev = colsum(i > 0 ? i - 1 : 0), next = colsum(i + 1 < cw ? i + 1 : cw - 1);
+                    const int x0 = 2 * i, x1 = 2 * i + 1;
+                    const int a = i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + prev + 8) >> 4;
+                    const int b = i == cw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + next + 7) >> 4;
+                    if (x0 < W) o[x0] = (uint8_t)a;
+                    if (x1 < W) o[x1] = (uint8_t)b;
+                }
+            }
+        } else {
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) f[(size_t)y * W + x] = c.plane[(size_t)(y * c.v / vmax) * c.stride + (size_t)(x * c.h / hmax)];
+        }
+    }
+    out.nx = W; out.ny = H; out.rgb.resize((size_t)3 * W * H);
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        uint8_t *o = out.rgb.data() + 3 * i;
+        if (comps.size() == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
+        const float Y = (float)full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
+        const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
+        for (int k = 0; k < 3; k++) { const float r = roundf(rgb[k]); o[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r); }
+    }
+    return "";
 }
 
 }  // namespace

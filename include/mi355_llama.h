@@ -350,7 +350,7 @@ MI355_API int32_t     mi355_clip_n_patches(const mi355_clip *clip);             
 MI355_API int32_t     mi355_clip_image_size(const mi355_clip *clip);
 /* the most rows mi355_llava_image_embed_from_bytes can write for one picture: n_patches (LLaVA-1.5) or n_patches * (1 + tiles of the largest canvas) */
 MI355_API int32_t     mi355_clip_max_image_rows(const mi355_clip *clip);
-/* clip_image_load_from_bytes: PNG / JPEG (baseline) / BMP / binary PNM bytes -> 8-bit RGB [ny][nx][3].  rgb_out may be NULL to query the size.
+/* clip_image_load_from_bytes: PNG / JPEG (Huffman-coded sequential or progressive) / BMP / binary PNM bytes -> 8-bit RGB [ny][nx][3].  rgb_out may be NULL to query the size.
  * Returns 0, or < 0 with the reason in mi355_last_error (unknown format, truncated data, rgb_cap too small). */
 MI355_API int32_t     mi355_clip_image_load_from_bytes(const uint8_t *bytes, size_t n_bytes, int32_t *nx, int32_t *ny, uint8_t *rgb_out, size_t rgb_cap);
 /* clip_image_preprocess (LLaVA-1.5: pad to a square with the mean colour, bilinear resample, normalise): rgb [ny][nx][3] -> out [3][S][S], S = image_size */

@@ -72,10 +72,78 @@ def test_bmp_and_pnm_match_pillow(pkg, fmt, mode):
     assert np.array_equal(decode(pkg, b.getvalue()), np.asarray(im.convert("RGB")))
 
 
+def adam7_png(a: np.ndarray, depth: int = 8, palette=None) -> bytes:
+    """An interlaced PNG of `a` ([h][w] grey / palette indices or [h][w][3|4]) written here (Pillow reads Adam7 but does not write it): seven reduced pictures, rows
+    filtered with a type that changes from row to row (none / sub / up / average / Paeth)"""
+    import struct
+    import zlib
+    h, w = a.shape[:2]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    ctype = 3 if palette is not None else {1: 0, 3: 2, 4: 6}[ch]
+    bpp = max(1, ch * depth // 8)
+    raw = b""
+    for p, (x0, y0, dx, dy) in enumerate([(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]):
+        sub = a[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for y in range(sub.shape[0]):
+            row = sub[y].reshape(-1)
+            if depth < 8:
+                bits = "".join(format(int(v), f"0{depth}b") for v in row)
+                bits += "0" * (-len(bits) % 8)
+                line = np.frombuffer(int(bits, 2).to_bytes(len(bits) // 8, "big"), np.uint8).astype(np.int32)
+            else:
+                line = row.astype(np.int32)
+            up = prev if prev is not None else np.zeros_like(line)
+            left = np.concatenate([np.zeros(bpp, np.int32), line[:-bpp]]) if len(line) > bpp else np.zeros_like(line)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if len(line) > bpp else np.zeros_like(line)
+            ft = (y + p) % 5
+            if ft == 0:
+                f = line
+            elif ft == 1:
+                f = line - left
+            elif ft == 2:
+                f = line - up
+            elif ft == 3:
+                f = line - ((left + up) >> 1)
+            else:
+                pp = left + up - upleft
+                pa, pb, pc = np.abs(pp - left), np.abs(pp - up), np.abs(pp - upleft)
+                f = line - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
+            raw += bytes([ft]) + (f & 255).astype(np.uint8).tobytes()
+            prev = line
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    z = zlib.compress(raw, 6)
+    return out + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("w,h", [(33, 21), (8, 8), (1, 1), (3, 2), (5, 1), (2, 9), (64, 64)])
+def test_interlaced_png_matches_pillow(pkg, w, h):
+    """Adam7 (pictures narrower than a pass's offset have empty passes): RGB, RGBA, grey, a 4-bit palette, 1-bit grey"""
+    a = picture(max(w, 2), max(h, 2), w * 13 + h)[:h, :w]
+    rng = np.random.default_rng(w + h)
+    pal = rng.integers(0, 256, (16, 3)).astype(np.uint8)
+    cases = [adam7_png(a), adam7_png(np.dstack([a, a[:, :, :1]])), adam7_png(a[:, :, 0]), adam7_png(a[:, :, 1] >> 4, depth=4, palette=pal), adam7_png(a[:, :, 2] >> 7, depth=1)]
+    for i, data in enumerate(cases):
+        want = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+        assert np.array_equal(decode(pkg, data), want), (i, w, h)
+    assert np.array_equal(decode(pkg, cases[0]), a)
+
+
 @pytest.mark.parametrize("kw", [dict(quality=90, subsampling=0), dict(quality=75, subsampling=2), dict(quality=60, subsampling=1), dict(quality=95, subsampling=0, restart_marker_blocks=3),
                                 dict(quality=85, subsampling=2, restart_marker_rows=1)])
+@pytest.mark.parametrize("progressive", [False, True])
 @pytest.mark.parametrize("w,h,grey", [(64, 48, False), (37, 29, False), (50, 50, True)])
-def test_baseline_jpeg_is_close_to_pillow(pkg, kw, w, h, grey):
+def test_jpeg_is_close_to_pillow(pkg, kw, w, h, grey, progressive):
+    """sequential (one interleaved scan) and progressive (Pillow's script: DC first, per-component AC bands, successive-approximation refinements - the
+    non-interleaved scans, end-of-band runs and refinement passes of annex G) files of the same picture"""
+    kw = dict(kw, progressive=True) if progressive else kw
     a = picture(w, h, w + h)
     im = PIL.fromarray(a).convert("L" if grey else "RGB")
     b = io.BytesIO()
@@ -93,12 +161,32 @@ def test_baseline_jpeg_is_close_to_pillow(pkg, kw, w, h, grey):
     assert np.abs(got - np.asarray(im.convert("RGB")).astype(np.int32)).mean() <= np.abs(want - np.asarray(im.convert("RGB")).astype(np.int32)).mean() + 1.0
 
 
+def test_progressive_jpeg_decodes_to_the_sequential_files_pixels(pkg):
+    """the same quantised coefficients reach the decoder through ten scans instead of one: the pixels must be the sequential file's, bit for bit (a larger picture,
+    4:2:0, with restart intervals; and a high-quality one, whose refinement scans carry many non-zero coefficients)"""
+    for w, h, kw in [(203, 157, dict(quality=80, subsampling=2)), (96, 64, dict(quality=98, subsampling=0)), (131, 77, dict(quality=50, subsampling=1, restart_marker_rows=1)),
+                     (64, 64, dict(quality=100, subsampling=0))]:
+        im = PIL.fromarray(picture(w, h, w))
+        a, b = io.BytesIO(), io.BytesIO()
+        im.save(a, "JPEG", **kw)
+        im.save(b, "JPEG", progressive=True, **kw)
+        assert b"\xff\xc2" in b.getvalue() and b"\xff\xc2" not in a.getvalue()[:600]
+        assert np.array_equal(decode(pkg, a.getvalue()), decode(pkg, b.getvalue())), (w, h, kw)
+    g = PIL.fromarray(picture(70, 90, 5)).convert("L")
+    a, b = io.BytesIO(), io.BytesIO()
+    g.save(a, "JPEG", quality=85)
+    g.save(b, "JPEG", quality=85, progressive=True)
+    assert np.array_equal(decode(pkg, a.getvalue()), decode(pkg, b.getvalue()))
+
+
 def test_refusals(pkg):
     a = PIL.fromarray(picture(40, 40))
     b = io.BytesIO()
-    a.save(b, "JPEG", progressive=True)
-    with pytest.raises(RuntimeError, match="progressive"):
-        decode(pkg, b.getvalue())
+    a.save(b, "JPEG")
+    raw = b.getvalue()
+    i = raw.index(b"\xff\xc0")
+    with pytest.raises(RuntimeError, match="arithmetic"):
+        decode(pkg, raw[:i] + b"\xff\xc9" + raw[i + 2:])          # (a frame header that announces arithmetic coding)
     b = io.BytesIO()
     a.save(b, "PNG")
     raw = b.getvalue()
@@ -128,9 +216,14 @@ def test_decoders_survive_mutated_files_under_sanitizers(tmp_path):
     for name, fmt, mode, kw in [("rgb.png", "PNG", "RGB", {}), ("pal.png", "PNG", "P", {}), ("la.png", "PNG", "LA", {}), ("bit.png", "PNG", "1", {}), ("stored.png", "PNG", "RGB", {"compress_level": 0}),
                                 ("q90.jpg", "JPEG", "RGB", {"quality": 90, "subsampling": 0}), ("q70_420.jpg", "JPEG", "RGB", {"quality": 70, "subsampling": 2}),
                                 ("grey.jpg", "JPEG", "L", {"quality": 80}), ("rst.jpg", "JPEG", "RGB", {"quality": 85, "restart_marker_blocks": 2}),
-                                ("refuse_progressive.jpg", "JPEG", "RGB", {"progressive": True}), ("x.bmp", "BMP", "RGB", {}), ("x.ppm", "PPM", "RGB", {}), ("x.pgm", "PPM", "L", {})]:
+                                ("progressive.jpg", "JPEG", "RGB", {"progressive": True, "quality": 85, "subsampling": 2}),
+                                ("progressive_rst.jpg", "JPEG", "RGB", {"progressive": True, "quality": 95, "subsampling": 0, "restart_marker_blocks": 3}), ("x.bmp", "BMP", "RGB", {}), ("x.ppm", "PPM", "RGB", {}), ("x.pgm", "PPM", "L", {})]:
         p = str(tmp_path / name)
         PIL.fromarray(a).convert(mode).save(p, fmt, **kw)
+        files.append(p)
+    for name, data in [("adam7.png", adam7_png(a)), ("adam7_pal.png", adam7_png(a[:, :, 0] >> 4, depth=4, palette=np.arange(48, dtype=np.uint8).reshape(16, 3)))]:
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
         files.append(p)
     r = subprocess.run([exe, "400"] + files, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
