@@ -257,7 +257,9 @@ static void resize_and_pad(const ClipImageU8 &img, ClipImageU8 &out, int tw, int
 void ClipModel::preprocess_all(const ClipImageU8 &img, std::vector<std::vector<float>> &out, int &grid_w, int &grid_h) const {
     out.clear();
     grid_w = grid_h = 0;
-    if (!has_grid()) { out.emplace_back(); preprocess(img, out.back()); return; }
+    // (clip_image_preprocess pads to a square unless the merge type is "spatial_unpad", and reaches the grid branch only when it did NOT pad: a file with a grid
+    // but another merge type treats a non-square picture the LLaVA-1.5 way and a square one as its bicubic overview)
+    if (!has_grid() || (merge_type != "spatial_unpad" && img.nx != img.ny)) { out.emplace_back(); preprocess(img, out.back()); return; }
     const int S = image_size;
     auto normalise = [&](const ClipImageU8 &im, int x0, int y0, std::vector<float> &f) {       // the S x S window at (x0, y0) -> planar, normalised
         f.resize((size_t)3 * S * S);

@@ -36,7 +36,7 @@ class ClipModel {
     bool use_gelu = false;
     float eps = 1e-5f, mean[3] = {0, 0, 0}, stdv[3] = {1, 1, 1};
     // LLaVA-1.6: clip.vision.image_grid_pinpoints = the (width, height) canvases a picture may be fitted to, clip.vision.mm_patch_merge_type ("spatial_unpad"
-    // turns the grid on; anything else encodes the overview only)
+    // turns the grid on; with anything else a non-square picture is padded the LLaVA-1.5 way and a square one becomes its bicubic overview)
     std::vector<std::pair<int, int>> pinpoints;
     std::string merge_type = "flat";
     bool has_grid() const { return !pinpoints.empty(); }

@@ -9,6 +9,7 @@
  *     the half-pixel mapping sx = (x + 0.5) * scale - 0.5; round to a byte; (v / 255 - mean[c]) / std[c]; planar [3][S][S].
  *   preprocess (LLaVA-1.6: clip.vision.image_grid_pinpoints present): image 0 = the whole picture resized to S x S with clip.cpp's bicubic_resize (source index
  *     truncated, Catmull-Rom style cubic, separable, edges clamped, rounded to a byte); with clip.vision.mm_patch_merge_type "spatial_unpad" followed by the
+ *     (without that merge type a non-square picture takes the LLaVA-1.5 branch - pad_to_square - and only a square one reaches the overview)
  *     S x S tiles, row-major, of the picture fitted to the best canvas (select_best_resolution: most kept pixels, then least waste; resize_and_pad_image:
  *     aspect-preserving bicubic resize, centred on black); every image normalised (v / 255 - mean) / std without further resampling.
  *   embed (llava.cpp encode_image_with_clip + clip_llava_handle_patches): encode every image; the overview's rows first, then the tiles' rows re-ordered from
@@ -282,7 +283,8 @@ int oq_clip_preprocess_all(const oq_clip *c, const uint8_t *rgb, int nx, int ny,
     const size_t per = (size_t)3 * S * S;
     *grid_w = *grid_h = 0;
     if (cap_images < 1) return -1;
-    if (c->n_pin == 0) { oq_clip_preprocess(c, rgb, nx, ny, out); return 1; }
+    /* pad_to_square = merge type is not "spatial_unpad"; the grid branch is the else of (pad_to_square && nx != ny) */
+    if (c->n_pin == 0 || (!c->spatial_unpad && nx != ny)) { oq_clip_preprocess(c, rgb, nx, ny, out); return 1; }
     uint8_t *ov = bicubic(rgb, nx, ny, S, S);
     window_to_planar(c, ov, S, 0, 0, out);
     free(ov);

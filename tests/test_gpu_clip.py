@@ -104,14 +104,16 @@ def test_image_grid_matches_oracle(be, pkg, tmp_models, w, h):
 
 
 def test_image_grid_with_flat_merge_encodes_the_overview_only(be, pkg, tmp_models):
-    """a grid in the file but clip.vision.mm_patch_merge_type "flat": one image a picture - the bicubic overview"""
+    """a grid in the file but clip.vision.mm_patch_merge_type "flat": one image a picture - a non-square one padded the LLaVA-1.5 way, a square one resized
+    with the bicubic filter (clip_image_preprocess pads unless the merge type is "spatial_unpad", and enters the grid branch only when it did not pad)"""
     path = make_clip(pkg, tmp_models, "tiny-clip-grid-flat")
     c, o = pkg.Clip(path), oq.OracleClip(path)
     assert c.max_image_rows == o.max_image_rows == 16
-    rgb = photo(150, 60, 5)
-    (gi, gw, gh), (oi, ow, oh) = c.preprocess_grid(rgb), o.preprocess_all(rgb)
-    assert (gw, gh) == (ow, oh) == (0, 0) and gi.shape[0] == 1 and np.array_equal(gi, oi)
-    assert not np.array_equal(gi[0], c.preprocess(rgb))         # (not the LLaVA-1.5 pad-and-bilinear image)
+    for w, h, padded in ((150, 60, True), (90, 90, False)):
+        rgb = photo(w, h, 5)
+        (gi, gw, gh), (oi, ow, oh) = c.preprocess_grid(rgb), o.preprocess_all(rgb)
+        assert (gw, gh) == (ow, oh) == (0, 0) and gi.shape[0] == 1 and np.array_equal(gi, oi)
+        assert np.array_equal(gi[0], c.preprocess(rgb)) == padded
     c.close(); o.close()
 
 
