@@ -41,16 +41,33 @@ struct BitReader {
 };
 struct Huff {
     uint16_t count[16] = {0}, symbol[288] = {0};
+    uint16_t fast[512];                    // the next 9 bits of the stream -> (length << 9 | symbol) of a code of at most 9 bits; 0 = a longer code, or none
     void build(const uint8_t *len, int n) {
         memset(count, 0, sizeof count);
+        memset(fast, 0, sizeof fast);
         for (int i = 0; i < n; i++) count[len[i]]++;
         count[0] = 0;
         uint16_t offs[16];
+        uint32_t next[16];
         offs[1] = 0;
         for (int i = 1; i < 15; i++) offs[i + 1] = (uint16_t)(offs[i] + count[i]);
-        for (int i = 0; i < n; i++) if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+        uint32_t code = 0;
+        for (int l = 1; l <= 15; l++) { next[l] = code; code = (code + count[l]) << 1; }
+        for (int i = 0; i < n; i++) {
+            const int l = len[i];
+            if (!l) continue;
+            symbol[offs[l]++] = (uint16_t)i;
+            const uint32_t c = next[l]++;
+            if (l > 9 || c >= (1u << l)) continue;
+            uint32_t rev = 0;                                   // (codes are packed starting from their most significant bit, the stream is read from bit 0)
+            for (int b = 0; b < l; b++) rev |= ((c >> b) & 1u) << (l - 1 - b);
+            for (uint32_t j = rev; j < 512; j += 1u << l) fast[j] = (uint16_t)(l << 9 | i);
+        }
     }
     int decode(BitReader &br) const {
+        while (br.cnt < 9 && br.p < br.end) { br.buf |= (uint32_t)(*br.p++) << br.cnt; br.cnt += 8; }
+        const uint16_t f = fast[br.buf & 511u];
+        if (f && (f >> 9) <= br.cnt) { const int l = f >> 9; br.buf >>= l; br.cnt -= l; return f & 511; }
         int code = 0, first = 0, index = 0;
         for (int l = 1; l <= 15; l++) {
             code |= br.bits(1);
@@ -290,10 +307,17 @@ struct JHuff {
     uint8_t bits[17] = {0}, vals[256] = {0};
     int mincode[17], maxcode[18], valptr[17];
     bool present = false;
+    uint16_t fast[512];                    // the next 9 bits -> (length << 8 | value) of a code of at most 9 bits, 0 = longer code (or none)
     void build() {
         int code = 0, k = 0;
+        memset(fast, 0, sizeof fast);
         for (int l = 1; l <= 16; l++) {
             valptr[l] = k; mincode[l] = code;
+            if (l <= 9)
+                for (int i = 0; i < bits[l] && code + i < (1 << l); i++) {
+                    const int first = (code + i) << (9 - l);
+                    for (int j = 0; j < (1 << (9 - l)); j++) fast[first + j] = (uint16_t)(l << 8 | vals[k + i]);
+                }
             code += bits[l]; k += bits[l];
             maxcode[l] = bits[l] ? code - 1 : -1;
             code <<= 1;
@@ -339,6 +363,9 @@ struct JBits {
     void reset() { buf = 0; cnt = 0; marker = 0; }
 };
 int jdecode(JBits &br, const JHuff &h) {
+    if (br.cnt < 9) br.fill();
+    const uint16_t f = h.fast[br.buf >> 23];
+    if (f) { const int l = f >> 8; br.buf <<= l; br.cnt -= l; return f & 255; }
     int code = 0;
     for (int l = 1; l <= 16; l++) {
         code = (code << 1) | br.get(1);
@@ -348,6 +375,7 @@ int jdecode(JBits &br, const JHuff &h) {
     return 0;
 }
 int jextend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
+inline uint8_t to_byte(float v) { return (uint8_t)(v < 0.0f ? 0 : v > 255.0f ? 255 : (int)(v + 0.5f)); }      // round to nearest, clamp
 void idct8x8(const float *in, uint8_t *out, int stride) {          // the reference (separable, float) inverse transform, level shift, round, clamp
     static float c[8][8];
     static bool init = false;
@@ -356,16 +384,34 @@ void idct8x8(const float *in, uint8_t *out, int stride) {          // the refere
             for (int u = 0; u < 8; u++) c[x][u] = (u == 0 ? (float)M_SQRT1_2 : 1.0f) * 0.5f * cosf((2 * x + 1) * u * (float)M_PI / 16.0f);
         init = true;
     }
+    // most of a block's coefficients are zero (the high frequencies of both directions): the sums run over the occupied corner only, eight outputs of a row at
+    // a time (the inner loops are over x: contiguous, vector width)
+    static float ct[8][8];                 // ct[u][x] = c[x][u]
+    static bool init2 = false;
+    if (!init2) {
+        for (int x = 0; x < 8; x++)
+            for (int u = 0; u < 8; u++) ct[u][x] = c[x][u];
+        init2 = true;
+    }
+    int vmax = -1, umax = 0;
+    for (int v = 0; v < 8; v++)
+        for (int u = 0; u < 8; u++)
+            if (in[v * 8 + u] != 0.0f) { vmax = v; if (u > umax) umax = u; }
+    if (vmax < 0) {
+        for (int y = 0; y < 8; y++) memset(out + y * stride, 128, 8);
+        return;
+    }
     float tmp[64];
-    for (int y = 0; y < 8; y++)
-        for (int x = 0; x < 8; x++) { float s = 0; for (int u = 0; u < 8; u++) s += c[x][u] * in[y * 8 + u]; tmp[y * 8 + x] = s; }
-    for (int x = 0; x < 8; x++)
-        for (int y = 0; y < 8; y++) {
-            float s = 0;
-            for (int v = 0; v < 8; v++) s += c[y][v] * tmp[v * 8 + x];
-            const float r = roundf(s + 128.0f);
-            out[y * stride + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
-        }
+    for (int v = 0; v <= vmax; v++) {
+        float acc[8] = {0};
+        for (int u = 0; u <= umax; u++) { const float a = in[v * 8 + u]; for (int x = 0; x < 8; x++) acc[x] += ct[u][x] * a; }
+        for (int x = 0; x < 8; x++) tmp[v * 8 + x] = acc[x];
+    }
+    for (int y = 0; y < 8; y++) {
+        float acc[8] = {0};
+        for (int v = 0; v <= vmax; v++) { const float a = c[y][v]; for (int x = 0; x < 8; x++) acc[x] += a * tmp[v * 8 + x]; }
+        for (int x = 0; x < 8; x++) out[y * stride + x] = to_byte(acc[x] + 128.0f);
+    }
 }
 // one block of a progressive scan (ITU T.81 annex G): spectral selection [Ss, Se], successive approximation (Ah = the bit position of the previous scan over these
 // coefficients, 0 in a first scan; Al = this scan's).  coef in natural (row-major) order; eobrun = blocks still covered by an end-of-band run
@@ -639,7 +685,7 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
         if (comps.size() == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
         const float Y = (float)full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
         const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
-        for (int k = 0; k < 3; k++) { const float r = roundf(rgb[k]); o[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r); }
+        for (int k = 0; k < 3; k++) o[k] = to_byte(rgb[k]);
     }
     return "";
 }
