@@ -3,8 +3,10 @@
 // GELU / quick-GELU with ggml's f16-table semantics.
 //
 // Stands in for the graph clip_image_encode builds (llama.cpp examples/llava/clip.cpp, reached from the reference through
-// llava_image_embed_make_with_clip_img, /root/reference/src/llama_server_context.cc:820) — SURVEY.md §8 row f4.  One image is 577 rows of 1024: none of this is
-// bandwidth- or matrix-bound work worth tuning; the kernels are written for clarity and run once per image.
+// llava_image_embed_make_with_clip_img, /root/reference/src/llama_server_context.cc:820) — SURVEY.md §8 row f4.  One image is 577 rows of 1024, once per picture
+// (five times with a LLaVA-1.6 image grid): small launches; the attention is tiled through LDS (clip_attn_tiled_kernel), the rest is written for clarity.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "dev_common.h"
 
@@ -92,7 +94,163 @@ __global__ __launch_bounds__(256) void clip_attn_kernel(const float *__restrict_
         }
     }
 }
+// The same attention, QT = 40 queries of one head per workgroup (15 x 16 workgroups for the 577 rows of ViT-L/14-336: one round of the 256 CUs): Q tile, a
+// 64-key chunk of K (then of V) and the QT x T probabilities live in LDS; a thread owns one key (scores) or one output element (P.V) for QT / 4 (QT D / 256)
+// queries, so an LDS operand feeds several sums; the LDS reads of step i + 1 are issued before the arithmetic of step i.  Every sum runs over the same index in
+// the same order as in clip_attn_kernel (d ascending for a score, the keys ascending for an output; the soft-max is the same code): the two agree bit for bit.
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void clip_attn_tiled_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                                                                          const float *__restrict__ v, int T, int H, float *__restrict__ out) {
+    constexpr int QT = 40, KC = 64, LDK = D + 4, D4 = D / 4, SQ = QT / 4;
+    constexpr int NQ = QT * D / 256, QSTEP = 256 / D;           // P.V: a thread's queries are qb + QSTEP * j, j < NQ, all for output element d
+    static_assert(256 % D == 0 && (QT * D) % 256 == 0, "head size");
+    extern __shared__ float sm[];
+    const int Tp = (T + KC - 1) / KC * KC;
+    float *sQ = sm, *sKV = sQ + QT * D, *sS = sKV + KC * LDK;   // [QT][D], [KC][LDK], [QT][Tp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, q0 = blockIdx.x * QT, E = H * D;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < QT * D4; i += 256) {
+        const int r = i / D4, c4 = i - r * D4, tq = q0 + r < T ? q0 + r : T - 1;          // (rows past the end repeat the last one; never stored)
+        *reinterpret_cast<f4 *>(sQ + r * D + 4 * c4) = *reinterpret_cast<const f4 *>(q + (size_t)tq * E + (size_t)h * D + 4 * c4);
+    }
+    // a chunk of K (then V) travels global -> registers -> LDS; the loads of chunk c + 1 are in flight while chunk c is being used
+    constexpr int NST = KC * D4 / 256;                          // 16-byte pieces per thread and chunk
+    f4 pre[NST];
+    auto fetch = [&](const float *src, int c) {
+#pragma unroll
+        for (int s = 0; s < NST; s++) {
+            const int i = tid + 256 * s, r = i / D4, c4 = i - r * D4, tk = c * KC + r;
+            f4 val = {0.0f, 0.0f, 0.0f, 0.0f};                  // (rows past T are zero)
+            if (tk < T) val = *reinterpret_cast<const f4 *>(src + (size_t)tk * E + (size_t)h * D + 4 * c4);
+            pre[s] = val;
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int s = 0; s < NST; s++) {
+            const int i = tid + 256 * s, r = i / D4, c4 = i - r * D4;
+            *reinterpret_cast<f4 *>(sKV + r * LDK + 4 * c4) = pre[s];
+        }
+    };
+    const int NC = Tp / KC;
+    fetch(k, 0);
+    for (int c = 0; c < NC; c++) {
+        __syncthreads();
+        put();
+        __syncthreads();
+        if (c + 1 < NC) fetch(k, c + 1); else fetch(v, 0);
+        float acc[SQ];
+#pragma unroll
+        for (int j = 0; j < SQ; j++) acc[j] = 0.0f;
+        const float *kr = sKV + lane * LDK, *qr = sQ + wave * D;
+        f4 kv = *reinterpret_cast<const f4 *>(kr), qv[SQ];
+#pragma unroll
+        for (int j = 0; j < SQ; j++) qv[j] = *reinterpret_cast<const f4 *>(qr + 4 * j * D);
+        for (int d = 0; d < D; d += 4) {
+            const int dn = d + 4 < D ? d + 4 : d;               // (the last step re-reads itself: no branch in the pipeline)
+            const f4 kn = *reinterpret_cast<const f4 *>(kr + dn);
+            f4 qn[SQ];
+#pragma unroll
+            for (int j = 0; j < SQ; j++) qn[j] = *reinterpret_cast<const f4 *>(qr + 4 * j * D + dn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < SQ; j++) { acc[j] += kv.x * qv[j].x; acc[j] += kv.y * qv[j].y; acc[j] += kv.z * qv[j].z; acc[j] += kv.w * qv[j].w; }
+            __builtin_amdgcn_sched_barrier(0);
+            kv = kn;
+#pragma unroll
+            for (int j = 0; j < SQ; j++) qv[j] = qn[j];
+        }
+        const int tk = c * KC + lane;
+#pragma unroll
+        for (int j = 0; j < SQ; j++) sS[(wave + 4 * j) * Tp + tk] = acc[j];
+    }
+    __syncthreads();
+    for (int j = 0; j < SQ; j++) {                              // soft-max of row wave + 4 j, as clip_attn_kernel does it
+        float *pr = sS + (wave + 4 * j) * Tp;
+        float mx = -INFINITY;
+        for (int tk = lane; tk < T; tk += 64) mx = fmaxf(mx, pr[tk]);
+        mx = wave_max(mx);
+        float sum = 0.0f;
+        for (int tk = lane; tk < T; tk += 64) { const float e = expf(pr[tk] - mx); pr[tk] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int tk = lane; tk < T; tk += 64) pr[tk] *= inv;
+        for (int tk = T + lane; tk < Tp; tk += 64) pr[tk] = 0.0f;
+    }
+    const int d = tid % D, qb = tid / D;
+    float o[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) o[j] = 0.0f;
+    for (int c = 0; c < NC; c++) {
+        __syncthreads();
+        put();
+        __syncthreads();
+        if (c + 1 < NC) fetch(v, c + 1);
+        const int nk = T - c * KC < KC ? T - c * KC : KC;       // (keys past T hold zeros on both sides; skipping them keeps the sums those of the short loop)
+        const int nk4 = nk & ~3;
+        const float *vr = sKV + d, *pr = sS + qb * Tp + c * KC;
+        float vv[4];
+        f4 p[NQ];
+        if (nk4 > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) vv[e] = vr[e * LDK];
+#pragma unroll
+            for (int j = 0; j < NQ; j++) p[j] = *reinterpret_cast<const f4 *>(pr + QSTEP * j * Tp);
+        }
+        for (int tk = 0; tk < nk4; tk += 4) {
+            const int tn = tk + 4 < nk4 ? tk + 4 : tk;
+            float vn[4];
+            f4 pn[NQ];
+#pragma unroll
+            for (int e = 0; e < 4; e++) vn[e] = vr[(tn + e) * LDK];
+#pragma unroll
+            for (int j = 0; j < NQ; j++) pn[j] = *reinterpret_cast<const f4 *>(pr + QSTEP * j * Tp + tn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NQ; j++) { o[j] += vv[0] * p[j].x; o[j] += vv[1] * p[j].y; o[j] += vv[2] * p[j].z; o[j] += vv[3] * p[j].w; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) vv[e] = vn[e];
+#pragma unroll
+            for (int j = 0; j < NQ; j++) p[j] = pn[j];
+        }
+        for (int tk = nk4; tk < nk; tk++) {                      // (the last chunk's odd keys)
+            const float v0 = vr[tk * LDK];
+#pragma unroll
+            for (int j = 0; j < NQ; j++) o[j] += v0 * pr[QSTEP * j * Tp + tk];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+        const int tq = q0 + qb + QSTEP * j;
+        if (tq < T) out[(size_t)tq * E + (size_t)h * D + d] = o[j];
+    }
+}
+template <int D>
+static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, float *out, size_t lds, hipStream_t st) {
+    static bool raised = false;
+    if (lds > 65536 && !raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clip_attn_tiled_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(clip_attn_tiled_kernel<D>, dim3((unsigned)((T + 39) / 40), (unsigned)H), dim3(256), lds, st, q, k, v, T, H, out);
+    return hipGetLastError();
+}
 hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, hipStream_t st) {
+    const char *sw = getenv("MI355_CLIP_ATTN_TILED");           // (read at every launch - a few dozen an image - so that a test can compare the two kernels)
+    const bool tiled = !(sw && atoi(sw) == 0);
+    if (tiled && (D == 32 || D == 64 || D == 128)) {
+        const size_t Tp = (size_t)(T + 63) / 64 * 64, lds = ((size_t)40 * D + (size_t)64 * (D + 4) + (size_t)40 * Tp) * sizeof(float);
+        if (lds <= 160 * 1024) {
+            switch (D) {
+                case 32: return launch_clip_attn_tiled<32>(q, k, v, T, H, out, lds, st);
+                case 64: return launch_clip_attn_tiled<64>(q, k, v, T, H, out, lds, st);
+                default: return launch_clip_attn_tiled<128>(q, k, v, T, H, out, lds, st);
+            }
+        }
+    }
     const dim3 grid((unsigned)((T + 3) / 4), (unsigned)H);
     const size_t lds = (size_t)4 * T * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;

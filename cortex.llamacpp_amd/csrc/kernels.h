@@ -213,6 +213,11 @@ hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int 
 hipError_t launch_clip_gelu(float *x, size_t n, bool quick, hipStream_t st);                                      // ggml's f16-table GELU / quick-GELU
 bool mmf16_applicable(int type, int n_rows, int K, int T, const void *W, const void *x, const void *y);
 hipError_t launch_mmf16(const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out, const float *resid, hipStream_t st);
+// the same with the activation rows rounded to f16 beforehand (once per row instead of once per workgroup that reads it): xh [T][K] halves
+hipError_t launch_f32_to_f16(const float *x, void *y, size_t n, hipStream_t st);
+// y = resid + (W xh + bias) * scale - bias [n_rows], the scale and resid [T][ld_out] each optional (resid may be y itself)
+hipError_t launch_mmf16_xh(const uint8_t *W, int n_rows, int K, const void *xh, int T, float *y, int ld_out, const float *resid, const float *bias, float scale, bool do_scale,
+                           hipStream_t st);
 hipError_t launch_mmv_float(int type, const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out,
                             const float *resid, hipStream_t st);
 

@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../csrc/kernels.h"
@@ -144,7 +145,8 @@ std::string ClipModel::load(const std::string &path, int device) {
     d_q_ = (float *)dalloc((size_t)T * E * 4); d_k_ = (float *)dalloc((size_t)T * E * 4); d_v_ = (float *)dalloc((size_t)T * E * 4);
     d_att_ = (float *)dalloc((size_t)T * E * 4); d_ff_ = (float *)dalloc((size_t)T * FF * 4);
     d_h1_ = (float *)dalloc((size_t)NP * proj_dim * 4); d_out_ = (float *)dalloc((size_t)NP * proj_dim * 4);
-    if (!d_img_ || !d_patches_ || !d_pe_ || !d_emb_ || !d_cur_ || !d_q_ || !d_k_ || !d_v_ || !d_att_ || !d_ff_ || !d_h1_ || !d_out_) return "out of device memory";
+    d_xh_ = dalloc((size_t)T * std::max(std::max(FF, E), std::max(proj_dim, kp_pad_)) * 2);
+    if (!d_img_ || !d_patches_ || !d_pe_ || !d_emb_ || !d_cur_ || !d_q_ || !d_k_ || !d_v_ || !d_att_ || !d_ff_ || !d_h1_ || !d_out_ || !d_xh_) return "out of device memory";
     if (NP < 8) return "projector file: fewer than 8 patches";
     return "";
 }
@@ -310,37 +312,47 @@ std::string ClipModel::encode(const float *img, float *out) {
     const int S = image_size, E = n_embd, FF = n_ff, H = n_head, D = E / H, NP = n_patches(), T = NP + 1;
     CLIP_TRY(hipMemcpyAsync(d_img_, img, (size_t)3 * S * S * 4, hipMemcpyHostToDevice, st));
     CLIP_TRY(launch_clip_im2col(d_img_, S, patch_size, kp_pad_, d_patches_, st));
-    CLIP_TRY(launch_mmf16((const uint8_t *)patch_w_, E, kp_pad_, d_patches_, NP, d_pe_, E, nullptr, st));
+    // Every projection reads its activation rows as f16 (what the CPU's f16 dot product does to them): rounded once per row here, not once per tile in the GEMM;
+    // bias, the scale of Q and the residual row are the GEMM's epilogue.  MI355_CLIP_XH=0 runs the unfused form (f32 rows into the GEMM, bias and residual as
+    // launches of their own) - the same values in the same order, kept so that a test can hold the two against each other.
+    const char *sw = getenv("MI355_CLIP_XH");
+    const bool xh = !(sw && atoi(sw) == 0);
+    const float *last_x = nullptr;
+    // y = resid + (W x + bias) * scale; x == nullptr: the rows of the projection before; tmp: [T_][rows] scratch of the unfused form when resid is given
+    auto proj = [&](const void *w, const float *bias, int rows, int K, const float *x, int T_, float *y, float scale, bool do_scale, const float *resid, float *tmp) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (xh) {
+            if (x && (e = launch_f32_to_f16(x, d_xh_, (size_t)T_ * K, st)) != hipSuccess) return e;
+            return launch_mmf16_xh((const uint8_t *)w, rows, K, d_xh_, T_, y, rows, resid, bias, scale, do_scale, st);
+        }
+        if (x) last_x = x;
+        float *dst = resid ? tmp : y;
+        if ((e = launch_mmf16((const uint8_t *)w, rows, K, last_x, T_, dst, rows, nullptr, st)) != hipSuccess) return e;
+        if (bias && (e = launch_clip_bias(dst, bias, rows, T_, scale, do_scale, st)) != hipSuccess) return e;
+        if (resid) e = launch_add(resid, dst, y, (int64_t)T_ * rows, st);
+        return e;
+    };
+    CLIP_TRY(proj(patch_w_, nullptr, E, kp_pad_, d_patches_, NP, d_pe_, 1.0f, false, nullptr, nullptr));
     CLIP_TRY(launch_clip_embed(d_pe_, class_, pos_, E, T, d_emb_, st));
     CLIP_TRY(launch_layer_norm(d_emb_, pre_w_, pre_b_, E, T, eps, d_emb_, st));
     const float qs = 1.0f / sqrtf((float)D);
     for (int il = 0; il < n_layer; il++) {
         const ClipLayerDev &L = layers_[(size_t)il];
         CLIP_TRY(launch_layer_norm(d_emb_, L.ln1w, L.ln1b, E, T, eps, d_cur_, st));
-        CLIP_TRY(launch_mmf16((const uint8_t *)L.wq, E, E, d_cur_, T, d_q_, E, nullptr, st));
-        CLIP_TRY(launch_clip_bias(d_q_, L.bq, E, T, qs, true, st));
-        CLIP_TRY(launch_mmf16((const uint8_t *)L.wk, E, E, d_cur_, T, d_k_, E, nullptr, st));
-        CLIP_TRY(launch_clip_bias(d_k_, L.bk, E, T, 1.0f, false, st));
-        CLIP_TRY(launch_mmf16((const uint8_t *)L.wv, E, E, d_cur_, T, d_v_, E, nullptr, st));
-        CLIP_TRY(launch_clip_bias(d_v_, L.bv, E, T, 1.0f, false, st));
+        CLIP_TRY(proj(L.wq, L.bq, E, E, d_cur_, T, d_q_, qs, true, nullptr, nullptr));
+        CLIP_TRY(proj(L.wk, L.bk, E, E, nullptr, T, d_k_, 1.0f, false, nullptr, nullptr));
+        CLIP_TRY(proj(L.wv, L.bv, E, E, nullptr, T, d_v_, 1.0f, false, nullptr, nullptr));
         CLIP_TRY(launch_clip_attn(d_q_, d_k_, d_v_, T, H, D, d_att_, st));
-        CLIP_TRY(launch_mmf16((const uint8_t *)L.wo, E, E, d_att_, T, d_cur_, E, nullptr, st));
-        CLIP_TRY(launch_clip_bias(d_cur_, L.bo, E, T, 1.0f, false, st));
-        CLIP_TRY(launch_add(d_cur_, d_emb_, d_emb_, (int64_t)T * E, st));
+        CLIP_TRY(proj(L.wo, L.bo, E, E, d_att_, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
         CLIP_TRY(launch_layer_norm(d_emb_, L.ln2w, L.ln2b, E, T, eps, d_cur_, st));
-        CLIP_TRY(launch_mmf16((const uint8_t *)L.ff_i, FF, E, d_cur_, T, d_ff_, FF, nullptr, st));
-        CLIP_TRY(launch_clip_bias(d_ff_, L.ff_i_b, FF, T, 1.0f, false, st));
+        CLIP_TRY(proj(L.ff_i, L.ff_i_b, FF, E, d_cur_, T, d_ff_, 1.0f, false, nullptr, nullptr));
         CLIP_TRY(launch_clip_gelu(d_ff_, (size_t)T * FF, !use_gelu, st));
-        CLIP_TRY(launch_mmf16((const uint8_t *)L.ff_o, E, FF, d_ff_, T, d_cur_, E, nullptr, st));
-        CLIP_TRY(launch_clip_bias(d_cur_, L.ff_o_b, E, T, 1.0f, false, st));
-        CLIP_TRY(launch_add(d_emb_, d_cur_, d_emb_, (int64_t)T * E, st));
+        CLIP_TRY(proj(L.ff_o, L.ff_o_b, E, FF, d_ff_, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
     }
     // the projector on the patch rows (the class row, row 0, is dropped)
-    CLIP_TRY(launch_mmf16((const uint8_t *)mm0w_, proj_dim, E, d_emb_ + E, NP, d_h1_, proj_dim, nullptr, st));
-    CLIP_TRY(launch_clip_bias(d_h1_, mm0b_, proj_dim, NP, 1.0f, false, st));
+    CLIP_TRY(proj(mm0w_, mm0b_, proj_dim, E, d_emb_ + E, NP, d_h1_, 1.0f, false, nullptr, nullptr));
     CLIP_TRY(launch_clip_gelu(d_h1_, (size_t)NP * proj_dim, false, st));
-    CLIP_TRY(launch_mmf16((const uint8_t *)mm2w_, proj_dim, proj_dim, d_h1_, NP, d_out_, proj_dim, nullptr, st));
-    CLIP_TRY(launch_clip_bias(d_out_, mm2b_, proj_dim, NP, 1.0f, false, st));
+    CLIP_TRY(proj(mm2w_, mm2b_, proj_dim, proj_dim, d_h1_, NP, d_out_, 1.0f, false, nullptr, nullptr));
     CLIP_TRY(hipMemcpyAsync(out, d_out_, (size_t)NP * proj_dim * 4, hipMemcpyDeviceToHost, st));
     CLIP_TRY(hipStreamSynchronize(st));
     return "";

@@ -65,6 +65,7 @@ class ClipModel {
     // scratch
     float *d_img_ = nullptr, *d_patches_ = nullptr, *d_pe_ = nullptr, *d_emb_ = nullptr, *d_cur_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_v_ = nullptr,
           *d_att_ = nullptr, *d_ff_ = nullptr, *d_h1_ = nullptr, *d_out_ = nullptr;
+    void *d_xh_ = nullptr;                 // the activation rows of the projection at hand, rounded to f16
     void *dalloc(size_t bytes);
 };
 

@@ -117,6 +117,27 @@ def test_image_grid_with_flat_merge_encodes_the_overview_only(be, pkg, tmp_model
     c.close(); o.close()
 
 
+@pytest.mark.parametrize("cfg", ["tiny-clip", "tiny-clip-d128", "clip-vit-l-336"])
+def test_tiled_attention_and_small_gemm_tiles_change_no_bit(be, pkg, tmp_models, cfg, monkeypatch):
+    """the tower's LDS-tiled attention against the one-wave-per-query kernel, the LDS-staged f16 GEMM against the direct one and its 64 x 64 workgroup tiles against the 128 x 128 ones, and activation
+    rows rounded to f16 once per projection against the rounding inside the GEMM: the same sums in the same order - the embedding rows must be identical (head size 64 and 128; 17, 37 and 577 rows: part tiles, padded key chunks)"""
+    path = make_clip(pkg, tmp_models, cfg)
+    c = pkg.Clip(path)
+    img = c.preprocess(photo(90, 60, 11))
+    new = c.encode(img)
+    monkeypatch.setenv("MI355_CLIP_ATTN_TILED", "0")
+    assert np.array_equal(c.encode(img), new)
+    monkeypatch.setenv("MI355_MMF16_LDS", "0")                   # the projections straight from global memory instead of through LDS
+    assert np.array_equal(c.encode(img), new)
+    monkeypatch.setenv("MI355_MMF16_TILE", "128")
+    assert np.array_equal(c.encode(img), new)
+    monkeypatch.setenv("MI355_CLIP_XH", "0")                     # the activation rows rounded to f16 inside the GEMM instead of beforehand
+    assert np.array_equal(c.encode(img), new)
+    monkeypatch.delenv("MI355_MMF16_TILE")
+    assert np.array_equal(c.encode(img), new)
+    c.close()
+
+
 def test_load_refusals(be, pkg, tmp_models):
     """a language-model file is not a projector file; a missing file names itself"""
     lm = os.path.join(tmp_models, "tiny-for-clip.gguf")
