@@ -274,7 +274,8 @@ hipError_t launch_add_qkv_bias(float *q, float *k, float *v, const float *bq, co
 
 // LayerNorm with weight and bias (ggml_norm + ggml_mul + ggml_add, build_norm(LLM_NORM): encoder models), one workgroup per row: mean and variance in double
 // (the CPU sums them in double, sequentially; here tree-ordered), y = (x - mean) * rsqrt(var + eps) * w + b with the CPU's operation order.  In place allowed.
-__global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, const float *w, const float *b, int n, float eps, float *y) {
+// yh (optional): the same row rounded to f16, for a consumer that reads it that way (the f16 GEMM of the LLaVA tower).
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, const float *w, const float *b, int n, float eps, float *y, _Float16 *yh) {
     __shared__ double red[4];
     const float *xr = x + (size_t)blockIdx.x * n;
     float *yr = y + (size_t)blockIdx.x * n;
@@ -293,10 +294,18 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, const f
     __syncthreads();
     const float variance = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
     const float scale = 1.0f / sqrtf(variance + eps);
-    for (int i = tid; i < n; i += 256) yr[i] = ((xr[i] - mean) * scale) * w[i] + b[i];
+    for (int i = tid; i < n; i += 256) {
+        const float v = ((xr[i] - mean) * scale) * w[i] + b[i];
+        yr[i] = v;
+        if (yh) yh[(size_t)blockIdx.x * n + i] = (_Float16)v;
+    }
 }
 hipError_t launch_layer_norm(const float *x, const float *w, const float *b, int n, int T, float eps, float *y, hipStream_t st) {
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)T), dim3(256), 0, st, x, w, b, n, eps, y);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)T), dim3(256), 0, st, x, w, b, n, eps, y, (_Float16 *)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_layer_norm_h(const float *x, const float *w, const float *b, int n, int T, float eps, float *y, void *yh, hipStream_t st) {
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)T), dim3(256), 0, st, x, w, b, n, eps, y, reinterpret_cast<_Float16 *>(yh));
     return hipGetLastError();
 }
 

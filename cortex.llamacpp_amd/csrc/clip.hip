@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void clip_attn_kernel(const float *__restrict_
 // the same order as in clip_attn_kernel (d ascending for a score, the keys ascending for an output; the soft-max is the same code): the two agree bit for bit.
 template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void clip_attn_tiled_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                                                                          const float *__restrict__ v, int T, int H, float *__restrict__ out) {
+                                                                                                          const float *__restrict__ v, int T, int H, float *__restrict__ out,
+                                                                                                          _Float16 *__restrict__ outh) {
     constexpr int QT = 40, KC = 64, LDK = D + 4, D4 = D / 4, SQ = QT / 4;
     constexpr int NQ = QT * D / 256, QSTEP = 256 / D;           // P.V: a thread's queries are qb + QSTEP * j, j < NQ, all for output element d
     static_assert(256 % D == 0 && (QT * D) % 256 == 0, "head size");
@@ -224,30 +225,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int j = 0; j < NQ; j++) {
         const int tq = q0 + qb + QSTEP * j;
-        if (tq < T) out[(size_t)tq * E + (size_t)h * D + d] = o[j];
+        if (tq < T) {
+            out[(size_t)tq * E + (size_t)h * D + d] = o[j];
+            if (outh) outh[(size_t)tq * E + (size_t)h * D + d] = (_Float16)o[j];
+        }
     }
 }
 template <int D>
-static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, float *out, size_t lds, hipStream_t st) {
+static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
     static bool raised = false;
     if (lds > 65536 && !raised) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clip_attn_tiled_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(clip_attn_tiled_kernel<D>, dim3((unsigned)((T + 39) / 40), (unsigned)H), dim3(256), lds, st, q, k, v, T, H, out);
+    hipLaunchKernelGGL(clip_attn_tiled_kernel<D>, dim3((unsigned)((T + 39) / 40), (unsigned)H), dim3(256), lds, st, q, k, v, T, H, out, outh);
     return hipGetLastError();
 }
-hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, hipStream_t st) {
+// out_h (optional): the output rows once more, rounded to f16
+hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, hipStream_t st) {
+    _Float16 *outh = reinterpret_cast<_Float16 *>(out_h);
     const char *sw = getenv("MI355_CLIP_ATTN_TILED");           // (read at every launch - a few dozen an image - so that a test can compare the two kernels)
     const bool tiled = !(sw && atoi(sw) == 0);
     if (tiled && (D == 32 || D == 64 || D == 128)) {
         const size_t Tp = (size_t)(T + 63) / 64 * 64, lds = ((size_t)40 * D + (size_t)64 * (D + 4) + (size_t)40 * Tp) * sizeof(float);
         if (lds <= 160 * 1024) {
             switch (D) {
-                case 32: return launch_clip_attn_tiled<32>(q, k, v, T, H, out, lds, st);
-                case 64: return launch_clip_attn_tiled<64>(q, k, v, T, H, out, lds, st);
-                default: return launch_clip_attn_tiled<128>(q, k, v, T, H, out, lds, st);
+                case 32: return launch_clip_attn_tiled<32>(q, k, v, T, H, out, outh, lds, st);
+                case 64: return launch_clip_attn_tiled<64>(q, k, v, T, H, out, outh, lds, st);
+                default: return launch_clip_attn_tiled<128>(q, k, v, T, H, out, outh, lds, st);
             }
         }
     }
@@ -261,12 +267,14 @@ hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int 
         case 128: hipLaunchKernelGGL(clip_attn_kernel<128>, grid, dim3(256), lds, st, q, k, v, T, H, out); break;
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !out_h) return e;
+    return launch_f32_to_f16(out, out_h, (size_t)T * H * D, st);
 }
 
 // ggml_gelu / ggml_gelu_quick as the CPU backend evaluates them: through tables indexed by the f16 bits of x, holding f16 results - y = half(f(half(x)));
 // GELU leaves the table for |x| >= 10 (0 below, x above)
-__global__ void clip_gelu_kernel(float *__restrict__ x, size_t n, int quick) {
+__global__ void clip_gelu_kernel(float *__restrict__ x, size_t n, int quick, _Float16 *__restrict__ xh) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
@@ -281,9 +289,10 @@ __global__ void clip_gelu_kernel(float *__restrict__ x, size_t n, int quick) {
         y = h2f(f2h(0.5f * xh * (1.0f + tanhf(0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh)))));
     }
     x[i] = y;
+    if (xh) xh[i] = (_Float16)y;
 }
-hipError_t launch_clip_gelu(float *x, size_t n, bool quick, hipStream_t st) {
-    hipLaunchKernelGGL(clip_gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, (int)quick);
+hipError_t launch_clip_gelu(float *x, size_t n, bool quick, void *xh, hipStream_t st) {
+    hipLaunchKernelGGL(clip_gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, (int)quick, reinterpret_cast<_Float16 *>(xh));
     return hipGetLastError();
 }
 

@@ -166,6 +166,8 @@ hipError_t launch_quantize(const float *x, int n, int T, const ActQuant &q, bool
                            int8_t *bh = nullptr, int8_t *bl = nullptr);
 // LayerNorm rows with weight and bias (encoder models): y[t] = (x[t] - mean) * rsqrt(var + eps) * w + b; y may be x
 hipError_t launch_layer_norm(const float *x, const float *w, const float *b, int n, int T, float eps, float *y, hipStream_t st);
+// the same, and the rows once more rounded to f16 ([T][n] halves)
+hipError_t launch_layer_norm_h(const float *x, const float *w, const float *b, int n, int T, float eps, float *y, void *yh, hipStream_t st);
 hipError_t launch_swiglu(const float *g, const float *u, float *y, int64_t n, hipStream_t st);
 // silu(g) * u quantised for the next mat-mul without an f32 round trip (n % 256 == 0); same blocks as launch_swiglu + launch_quantize
 hipError_t launch_swiglu_quant(const float *g, const float *u, int n, int T, const ActQuant &q, bool want_q8k, bool want_q80, hipStream_t st,
@@ -209,8 +211,9 @@ hipError_t launch_topk_rows(const float *base, int n, int n_rows, const int *row
 hipError_t launch_clip_im2col(const float *img, int S, int P, int ld, float *patches, hipStream_t st);            // [n_patches][ld], columns (c, ky, kx), zero padded
 hipError_t launch_clip_embed(const float *patch, const float *cls, const float *pos, int E, int T, float *emb, hipStream_t st);   // [class ; patches] + positions
 hipError_t launch_clip_bias(float *x, const float *b, int n, int T, float scale, bool do_scale, hipStream_t st);  // x = (x + b) [* scale]
-hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, hipStream_t st);     // unmasked, q pre-scaled
-hipError_t launch_clip_gelu(float *x, size_t n, bool quick, hipStream_t st);                                      // ggml's f16-table GELU / quick-GELU
+// (out_h / xh, optional: the result once more, rounded to f16 - what the f16 GEMM that consumes it reads)
+hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, hipStream_t st);     // unmasked, q pre-scaled
+hipError_t launch_clip_gelu(float *x, size_t n, bool quick, void *xh, hipStream_t st);                            // ggml's f16-table GELU / quick-GELU
 bool mmf16_applicable(int type, int n_rows, int K, int T, const void *W, const void *x, const void *y);
 hipError_t launch_mmf16(const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out, const float *resid, hipStream_t st);
 // the same with the activation rows rounded to f16 beforehand (once per row instead of once per workgroup that reads it): xh [T][K] halves

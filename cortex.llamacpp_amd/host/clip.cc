@@ -317,42 +317,43 @@ std::string ClipModel::encode(const float *img, float *out) {
     // launches of their own) - the same values in the same order, kept so that a test can hold the two against each other.
     const char *sw = getenv("MI355_CLIP_XH");
     const bool xh = !(sw && atoi(sw) == 0);
-    const float *last_x = nullptr;
-    // y = resid + (W x + bias) * scale; x == nullptr: the rows of the projection before; tmp: [T_][rows] scratch of the unfused form when resid is given
-    auto proj = [&](const void *w, const float *bias, int rows, int K, const float *x, int T_, float *y, float scale, bool do_scale, const float *resid, float *tmp) -> hipError_t {
+    // y = resid + (W x + bias) * scale; have_h: d_xh_ already holds these rows as f16 (the producer wrote them, or the projection before read the same rows);
+    // tmp: [T_][rows] scratch of the unfused form when resid is given
+    auto proj = [&](const void *w, const float *bias, int rows, int K, const float *x, bool have_h, int T_, float *y, float scale, bool do_scale, const float *resid,
+                    float *tmp) -> hipError_t {
         hipError_t e = hipSuccess;
         if (xh) {
-            if (x && (e = launch_f32_to_f16(x, d_xh_, (size_t)T_ * K, st)) != hipSuccess) return e;
+            if (!have_h && (e = launch_f32_to_f16(x, d_xh_, (size_t)T_ * K, st)) != hipSuccess) return e;
             return launch_mmf16_xh((const uint8_t *)w, rows, K, d_xh_, T_, y, rows, resid, bias, scale, do_scale, st);
         }
-        if (x) last_x = x;
         float *dst = resid ? tmp : y;
-        if ((e = launch_mmf16((const uint8_t *)w, rows, K, last_x, T_, dst, rows, nullptr, st)) != hipSuccess) return e;
+        if ((e = launch_mmf16((const uint8_t *)w, rows, K, x, T_, dst, rows, nullptr, st)) != hipSuccess) return e;
         if (bias && (e = launch_clip_bias(dst, bias, rows, T_, scale, do_scale, st)) != hipSuccess) return e;
         if (resid) e = launch_add(resid, dst, y, (int64_t)T_ * rows, st);
         return e;
     };
-    CLIP_TRY(proj(patch_w_, nullptr, E, kp_pad_, d_patches_, NP, d_pe_, 1.0f, false, nullptr, nullptr));
+    void *const h = xh ? d_xh_ : nullptr;                       // where the producers leave the f16 copy of their rows
+    CLIP_TRY(proj(patch_w_, nullptr, E, kp_pad_, d_patches_, false, NP, d_pe_, 1.0f, false, nullptr, nullptr));
     CLIP_TRY(launch_clip_embed(d_pe_, class_, pos_, E, T, d_emb_, st));
     CLIP_TRY(launch_layer_norm(d_emb_, pre_w_, pre_b_, E, T, eps, d_emb_, st));
     const float qs = 1.0f / sqrtf((float)D);
     for (int il = 0; il < n_layer; il++) {
         const ClipLayerDev &L = layers_[(size_t)il];
-        CLIP_TRY(launch_layer_norm(d_emb_, L.ln1w, L.ln1b, E, T, eps, d_cur_, st));
-        CLIP_TRY(proj(L.wq, L.bq, E, E, d_cur_, T, d_q_, qs, true, nullptr, nullptr));
-        CLIP_TRY(proj(L.wk, L.bk, E, E, nullptr, T, d_k_, 1.0f, false, nullptr, nullptr));
-        CLIP_TRY(proj(L.wv, L.bv, E, E, nullptr, T, d_v_, 1.0f, false, nullptr, nullptr));
-        CLIP_TRY(launch_clip_attn(d_q_, d_k_, d_v_, T, H, D, d_att_, st));
-        CLIP_TRY(proj(L.wo, L.bo, E, E, d_att_, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
-        CLIP_TRY(launch_layer_norm(d_emb_, L.ln2w, L.ln2b, E, T, eps, d_cur_, st));
-        CLIP_TRY(proj(L.ff_i, L.ff_i_b, FF, E, d_cur_, T, d_ff_, 1.0f, false, nullptr, nullptr));
-        CLIP_TRY(launch_clip_gelu(d_ff_, (size_t)T * FF, !use_gelu, st));
-        CLIP_TRY(proj(L.ff_o, L.ff_o_b, E, FF, d_ff_, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
+        CLIP_TRY(launch_layer_norm_h(d_emb_, L.ln1w, L.ln1b, E, T, eps, d_cur_, h, st));
+        CLIP_TRY(proj(L.wq, L.bq, E, E, d_cur_, true, T, d_q_, qs, true, nullptr, nullptr));
+        CLIP_TRY(proj(L.wk, L.bk, E, E, d_cur_, true, T, d_k_, 1.0f, false, nullptr, nullptr));
+        CLIP_TRY(proj(L.wv, L.bv, E, E, d_cur_, true, T, d_v_, 1.0f, false, nullptr, nullptr));
+        CLIP_TRY(launch_clip_attn(d_q_, d_k_, d_v_, T, H, D, d_att_, h, st));
+        CLIP_TRY(proj(L.wo, L.bo, E, E, d_att_, true, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
+        CLIP_TRY(launch_layer_norm_h(d_emb_, L.ln2w, L.ln2b, E, T, eps, d_cur_, h, st));
+        CLIP_TRY(proj(L.ff_i, L.ff_i_b, FF, E, d_cur_, true, T, d_ff_, 1.0f, false, nullptr, nullptr));
+        CLIP_TRY(launch_clip_gelu(d_ff_, (size_t)T * FF, !use_gelu, h, st));
+        CLIP_TRY(proj(L.ff_o, L.ff_o_b, E, FF, d_ff_, true, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
     }
     // the projector on the patch rows (the class row, row 0, is dropped)
-    CLIP_TRY(proj(mm0w_, mm0b_, proj_dim, E, d_emb_ + E, NP, d_h1_, 1.0f, false, nullptr, nullptr));
-    CLIP_TRY(launch_clip_gelu(d_h1_, (size_t)NP * proj_dim, false, st));
-    CLIP_TRY(proj(mm2w_, mm2b_, proj_dim, proj_dim, d_h1_, NP, d_out_, 1.0f, false, nullptr, nullptr));
+    CLIP_TRY(proj(mm0w_, mm0b_, proj_dim, E, d_emb_ + E, false, NP, d_h1_, 1.0f, false, nullptr, nullptr));
+    CLIP_TRY(launch_clip_gelu(d_h1_, (size_t)NP * proj_dim, false, h, st));
+    CLIP_TRY(proj(mm2w_, mm2b_, proj_dim, proj_dim, d_h1_, true, NP, d_out_, 1.0f, false, nullptr, nullptr));
     CLIP_TRY(hipMemcpyAsync(out, d_out_, (size_t)NP * proj_dim * 4, hipMemcpyDeviceToHost, st));
     CLIP_TRY(hipStreamSynchronize(st));
     return "";
