@@ -14,6 +14,7 @@
 
 #include "../csrc/kernels.h"
 #include "gguf.h"
+#include "parallel_rows.h"
 
 namespace mi355 {
 
@@ -201,7 +202,8 @@ static void bicubic_resize(const ClipImageU8 &img, ClipImageU8 &dst, int tw, int
     dst.nx = tw; dst.ny = th;
     dst.rgb.assign((size_t)3 * tw * th, 0);
     const float tx = (float)nx / (float)tw, ty = (float)ny / (float)th;
-    for (int i = 0; i < th; i++)
+    parallel_rows(th, (int64_t)tw * th, [&](int i0, int i1) {
+    for (int i = i0; i < i1; i++)
         for (int j = 0; j < tw; j++) {
             const int x = (int)(tx * (float)j), y = (int)(ty * (float)i);
             const float dx = tx * (float)j - (float)x, dy = ty * (float)i - (float)y;
@@ -226,6 +228,7 @@ static void bicubic_resize(const ClipImageU8 &img, ClipImageU8 &dst, int tw, int
                 dst.rgb[(size_t)3 * ((size_t)i * tw + j) + k] = (uint8_t)std::min(std::max(roundf(Cc), 0.0f), 255.0f);
             }
         }
+    });
 }
 
 // the canvas that keeps the most of the picture's pixels after an aspect-preserving fit; among equals, the one that wastes the least area

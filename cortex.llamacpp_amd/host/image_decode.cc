@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "clip.h"
+#include "parallel_rows.h"
 
 namespace mi355 {
 namespace {
@@ -636,15 +637,22 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
     }
     if (n_scans == 0) return "JPEG: no image data";
     // dequantise + inverse transform, block by block
+    {
+        const float warm[64] = {0};
+        uint8_t sink[64];
+        idct8x8(warm, sink, 8);                                  // (the transform's tables are built on first use: once, before the threads)
+    }
     for (auto &c : comps) {
         c.plane.assign((size_t)c.stride * c.rows, 128);
-        float blk[64];
-        for (int by = 0; by < c.bh; by++)
-            for (int bx = 0; bx < c.bw; bx++) {
-                const int16_t *coef = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
-                for (int i = 0; i < 64; i++) blk[i] = (float)((int)coef[i] * (int)c.q[i]);
-                idct8x8(blk, c.plane.data() + (size_t)(by * 8) * c.stride + (size_t)bx * 8, c.stride);
-            }
+        parallel_rows(c.bh, (int64_t)c.stride * c.rows, [&](int b0, int b1) {
+            float blk[64];
+            for (int by = b0; by < b1; by++)
+                for (int bx = 0; bx < c.bw; bx++) {
+                    const int16_t *coef = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+                    for (int i = 0; i < 64; i++) blk[i] = (float)((int)coef[i] * (int)c.q[i]);
+                    idct8x8(blk, c.plane.data() + (size_t)(by * 8) * c.stride + (size_t)bx * 8, c.stride);
+                }
+        });
         std::vector<int16_t>().swap(c.coef);
     }
     // full-resolution planes.  2:1 horizontally (and vertically) subsampled components go through the triangle filter every mainstream decoder
@@ -657,7 +665,8 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
         const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax;      // valid extent of the component
         const bool h2 = hmax == 2 * c.h, v1 = vmax == c.v, v2 = vmax == 2 * c.v;
         if (h2 && (v1 || v2) && cw >= 1) {
-            for (int y = 0; y < H; y++) {
+            parallel_rows(H, (int64_t)W * H, [&](int y0, int y1) {
+            for (int y = y0; y < y1; y++) {
                 const int r = v2 ? y >> 1 : y;
                 int rf = v2 ? ((y & 1) ? r + 1 : r - 1) : r;                                 // the farther row of the pair
                 if (rf < 0) rf = 0;
@@ -674,19 +683,24 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
                     if (x1 < W) o[x1] = (uint8_t)b;
                 }
             }
+            });
         } else {
-            for (int y = 0; y < H; y++)
-                for (int x = 0; x < W; x++) f[(size_t)y * W + x] = c.plane[(size_t)(y * c.v / vmax) * c.stride + (size_t)(x * c.h / hmax)];
+            parallel_rows(H, (int64_t)W * H, [&](int y0, int y1) {
+                for (int y = y0; y < y1; y++)
+                    for (int x = 0; x < W; x++) f[(size_t)y * W + x] = c.plane[(size_t)(y * c.v / vmax) * c.stride + (size_t)(x * c.h / hmax)];
+            });
         }
     }
     out.nx = W; out.ny = H; out.rgb.resize((size_t)3 * W * H);
-    for (size_t i = 0; i < (size_t)W * H; i++) {
-        uint8_t *o = out.rgb.data() + 3 * i;
-        if (comps.size() == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
-        const float Y = (float)full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
-        const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
-        for (int k = 0; k < 3; k++) o[k] = to_byte(rgb[k]);
-    }
+    parallel_rows(H, (int64_t)W * H, [&](int y0, int y1) {
+        for (size_t i = (size_t)y0 * W; i < (size_t)y1 * W; i++) {
+            uint8_t *o = out.rgb.data() + 3 * i;
+            if (comps.size() == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
+            const float Y = (float)full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
+            const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
+            for (int k = 0; k < 3; k++) o[k] = to_byte(rgb[k]);
+        }
+    });
     return "";
 }
 
