@@ -144,9 +144,15 @@ void LlamaServerContext::ReleaseResources() {   // :366-380
         fprintf(stderr, "[loop] %ld decode calls, %.1f tokens each: decode+logits %.3f ms, sampling %.3f ms, post-processing %.3f ms per call\n",
                 n_ticks_, (double)n_tick_tokens_ / (double)n_ticks_, t_decode_us_ / 1e3 / (double)n_ticks_, t_sample_us_ / 1e3 / (double)n_ticks_,
                 t_post_us_ / 1e3 / (double)n_ticks_);
-    if (model_loaded_external.exchange(false)) {
+    // The flag is part of both waits' predicates: it changes under the waiters' mutexes.  Flipped outside them, the loop thread could read it (true) in its
+    // predicate, lose the notification sent before it blocks, and sleep for ever - the join below with it (seen as a rare hang of the host-logic program
+    // under load); the same for a caller inside NextResult.
+    bool was;
+    { std::lock_guard<std::mutex> lk(mutex_tasks_); was = model_loaded_external.exchange(false); }
+    if (was) {
         condition_tasks_.notify_all();
         if (bgr_thread_.joinable()) bgr_thread_.join();
+        { std::lock_guard<std::mutex> lk(mutex_results_); }
         condition_results_.notify_all();
     }
 }

@@ -1,6 +1,7 @@
 // tests/host/host_tests.cc — CPU unit tests of the host-side mirror (JSON, tokenizer, sampler, slot loop, engine façade)
 // against a deterministic fake arithmetic backend.  Built and run by tests/test_host_logic.py with g++ (no HIP, no GPU).
 #include <cassert>
+#include <csignal>
 #include <cstdio>
 #include <chrono>
 #include <cmath>
@@ -1318,29 +1319,34 @@ static int api_shapes_cli() {
     return 0;
 }
 
+static const char *volatile g_stage = "start";
+
 int main(int argc, char **argv) {
     if (argc == 4 && std::string(argv[1]) == "--tokenize") return tokenize_cli(argv[2], argv[3]);
     if (argc == 2 && std::string(argv[1]) == "--api-shapes") return api_shapes_cli();
-    test_json();
-    test_vocab();
-    test_vocab_wordpiece();
-    test_sampler();
-    test_sampler_topk_matches_full_sort();
-    test_sampler_mirostat_dynatemp();
-    test_sampler_front_plan_matches_full_chain();
-    test_grammar_parse_and_match();
-    test_json_schema_grammar();
-    test_sampler_with_grammar();
-    test_stop_string_scan();
-    test_slot_loop();
-    test_image_requests();
-    test_prompt_cache_and_shift();
-    test_kv_full_error();
-    test_bad_token_ids_and_backend_errors();
-    test_gguf_hardening();
-    test_engine();
-    test_engine_grammar_requests();
-    test_embeddings();
+    // a run that hangs is ended from outside (timeout's SIGTERM): say which group of checks it was in
+    signal(SIGTERM, [](int) { const char *m = g_stage; if (write(2, "hung in: ", 9) < 0 || write(2, m, strlen(m)) < 0 || write(2, "\n", 1) < 0) {} _exit(124); });
+#define STAGE(f) do { g_stage = #f; f(); } while (0)
+    STAGE(test_json);
+    STAGE(test_vocab);
+    STAGE(test_vocab_wordpiece);
+    STAGE(test_sampler);
+    STAGE(test_sampler_topk_matches_full_sort);
+    STAGE(test_sampler_mirostat_dynatemp);
+    STAGE(test_sampler_front_plan_matches_full_chain);
+    STAGE(test_grammar_parse_and_match);
+    STAGE(test_json_schema_grammar);
+    STAGE(test_sampler_with_grammar);
+    STAGE(test_stop_string_scan);
+    STAGE(test_slot_loop);
+    STAGE(test_image_requests);
+    STAGE(test_prompt_cache_and_shift);
+    STAGE(test_kv_full_error);
+    STAGE(test_bad_token_ids_and_backend_errors);
+    STAGE(test_gguf_hardening);
+    STAGE(test_engine);
+    STAGE(test_engine_grammar_requests);
+    STAGE(test_embeddings);
     if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }
     printf("all host-logic checks passed\n");
     return 0;
