@@ -505,6 +505,8 @@ CLIP_CONFIGS = {
     # the same graph at test size: 56 x 56 pixels = 16 patches of 14 x 14, head_dim 64 like the real tower (d128: 36 patches, 4 heads, 3 blocks)
     "tiny-clip": ClipConfig("tiny-clip", 56, 14, 128, 2, 256, 2, 256),
     "tiny-clip-d128": ClipConfig("tiny-clip-d128", 84, 14, 256, 4, 512, 3, 512),
+    # head size 128 at the real tower's 577 rows (the tiled attention's largest LDS footprint: 157 KB)
+    "clip-d128-336": ClipConfig("clip-d128-336", 336, 14, 256, 2, 512, 2, 256),
     "tiny-clip-gelu": ClipConfig("tiny-clip-gelu", 56, 14, 128, 2, 256, 2, 4096, use_gelu=True),
     # a projector as wide as the tiny language models of the engine tests (n_embd 1024): 16 rows per image
     "tiny-clip-1024": ClipConfig("tiny-clip-1024", 56, 14, 128, 2, 256, 2, 1024),

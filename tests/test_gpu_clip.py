@@ -43,7 +43,7 @@ def test_preprocess_is_the_cpu_paths(be, pkg, tmp_models, w, h):
     c.close(); o.close()
 
 
-@pytest.mark.parametrize("cfg", ["tiny-clip", "tiny-clip-d128", "tiny-clip-gelu"])
+@pytest.mark.parametrize("cfg", ["tiny-clip", "tiny-clip-d128", "tiny-clip-gelu", "clip-d128-336"])
 def test_encode_matches_oracle(be, pkg, tmp_models, cfg):
     """The tower + projector on three geometries (head size 64 with quick-GELU, 4 heads x 3 blocks, the GELU variant with a 4096-wide projector).  The projections
     round their activations to f16 on both sides; what differs is the f32 summation order and - rarely - an f16 table entry of the GELU picked one step apart:
@@ -117,7 +117,7 @@ def test_image_grid_with_flat_merge_encodes_the_overview_only(be, pkg, tmp_model
     c.close(); o.close()
 
 
-@pytest.mark.parametrize("cfg", ["tiny-clip", "tiny-clip-d128", "clip-vit-l-336"])
+@pytest.mark.parametrize("cfg", ["tiny-clip", "tiny-clip-d128", "clip-d128-336", "clip-vit-l-336"])
 def test_tiled_attention_and_small_gemm_tiles_change_no_bit(be, pkg, tmp_models, cfg, monkeypatch):
     """the tower's LDS-tiled attention against the one-wave-per-query kernel, the LDS-staged f16 GEMM against the direct one and its 64 x 64 workgroup tiles against the 128 x 128 ones, and activation
     rows rounded to f16 once per projection against the rounding inside the GEMM: the same sums in the same order - the embedding rows must be identical (head size 64 and 128; 17, 37 and 577 rows: part tiles, padded key chunks)"""
