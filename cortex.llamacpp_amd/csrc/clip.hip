@@ -110,6 +110,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     float *sQ = sm, *sKV = sQ + QT * D, *sS = sKV + KC * LDK;   // [QT][D], [KC][LDK], [QT][Tp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y, q0 = blockIdx.x * QT, E = H * D;
+    {                                                           // blockIdx.z: one of several images' rows, T apart
+        const size_t img = (size_t)blockIdx.z * T * E;
+        q += img; k += img; v += img; out += img;
+        if (outh) outh += img;
+    }
     typedef float f4 __attribute__((ext_vector_type(4)));
     for (int i = tid; i < QT * D4; i += 256) {
         const int r = i / D4, c4 = i - r * D4, tq = q0 + r < T ? q0 + r : T - 1;          // (rows past the end repeat the last one; never stored)
@@ -232,18 +237,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 }
 template <int D>
-static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
+static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, int n_img, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
     static bool raised = false;
     if (lds > 65536 && !raised) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clip_attn_tiled_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(clip_attn_tiled_kernel<D>, dim3((unsigned)((T + 39) / 40), (unsigned)H), dim3(256), lds, st, q, k, v, T, H, out, outh);
+    hipLaunchKernelGGL(clip_attn_tiled_kernel<D>, dim3((unsigned)((T + 39) / 40), (unsigned)H, (unsigned)n_img), dim3(256), lds, st, q, k, v, T, H, out, outh);
     return hipGetLastError();
 }
-// out_h (optional): the output rows once more, rounded to f16
-hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, hipStream_t st) {
+// out_h (optional): the output rows once more, rounded to f16.  n_img images of T rows each, one after the other in every buffer: attention within an image.
+hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, int n_img, hipStream_t st) {
     _Float16 *outh = reinterpret_cast<_Float16 *>(out_h);
     const char *sw = getenv("MI355_CLIP_ATTN_TILED");           // (read at every launch - a few dozen an image - so that a test can compare the two kernels)
     const bool tiled = !(sw && atoi(sw) == 0);
@@ -251,25 +256,28 @@ hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int 
         const size_t Tp = (size_t)(T + 63) / 64 * 64, lds = ((size_t)40 * D + (size_t)64 * (D + 4) + (size_t)40 * Tp) * sizeof(float);
         if (lds <= 160 * 1024) {
             switch (D) {
-                case 32: return launch_clip_attn_tiled<32>(q, k, v, T, H, out, outh, lds, st);
-                case 64: return launch_clip_attn_tiled<64>(q, k, v, T, H, out, outh, lds, st);
-                default: return launch_clip_attn_tiled<128>(q, k, v, T, H, out, outh, lds, st);
+                case 32: return launch_clip_attn_tiled<32>(q, k, v, T, H, n_img, out, outh, lds, st);
+                case 64: return launch_clip_attn_tiled<64>(q, k, v, T, H, n_img, out, outh, lds, st);
+                default: return launch_clip_attn_tiled<128>(q, k, v, T, H, n_img, out, outh, lds, st);
             }
         }
     }
     const dim3 grid((unsigned)((T + 3) / 4), (unsigned)H);
     const size_t lds = (size_t)4 * T * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    switch (D) {
-        case 32: hipLaunchKernelGGL(clip_attn_kernel<32>, grid, dim3(256), lds, st, q, k, v, T, H, out); break;
-        case 64: hipLaunchKernelGGL(clip_attn_kernel<64>, grid, dim3(256), lds, st, q, k, v, T, H, out); break;
-        case 80: hipLaunchKernelGGL(clip_attn_kernel<80>, grid, dim3(256), lds, st, q, k, v, T, H, out); break;
-        case 128: hipLaunchKernelGGL(clip_attn_kernel<128>, grid, dim3(256), lds, st, q, k, v, T, H, out); break;
-        default: return hipErrorInvalidValue;
+    for (int im = 0; im < n_img; im++) {
+        const size_t o = (size_t)im * T * H * D;
+        switch (D) {
+            case 32: hipLaunchKernelGGL(clip_attn_kernel<32>, grid, dim3(256), lds, st, q + o, k + o, v + o, T, H, out + o); break;
+            case 64: hipLaunchKernelGGL(clip_attn_kernel<64>, grid, dim3(256), lds, st, q + o, k + o, v + o, T, H, out + o); break;
+            case 80: hipLaunchKernelGGL(clip_attn_kernel<80>, grid, dim3(256), lds, st, q + o, k + o, v + o, T, H, out + o); break;
+            case 128: hipLaunchKernelGGL(clip_attn_kernel<128>, grid, dim3(256), lds, st, q + o, k + o, v + o, T, H, out + o); break;
+            default: return hipErrorInvalidValue;
+        }
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess || !out_h) return e;
-    return launch_f32_to_f16(out, out_h, (size_t)T * H * D, st);
+    return launch_f32_to_f16(out, out_h, (size_t)n_img * T * H * D, st);
 }
 
 // ggml_gelu / ggml_gelu_quick as the CPU backend evaluates them: through tables indexed by the f16 bits of x, holding f16 results - y = half(f(half(x)));

@@ -212,7 +212,7 @@ hipError_t launch_clip_im2col(const float *img, int S, int P, int ld, float *pat
 hipError_t launch_clip_embed(const float *patch, const float *cls, const float *pos, int E, int T, float *emb, hipStream_t st);   // [class ; patches] + positions
 hipError_t launch_clip_bias(float *x, const float *b, int n, int T, float scale, bool do_scale, hipStream_t st);  // x = (x + b) [* scale]
 // (out_h / xh, optional: the result once more, rounded to f16 - what the f16 GEMM that consumes it reads)
-hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, hipStream_t st);     // unmasked, q pre-scaled
+hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, int n_img, hipStream_t st);     // unmasked, q pre-scaled; n_img images of T rows
 hipError_t launch_clip_gelu(float *x, size_t n, bool quick, void *xh, hipStream_t st);                            // ggml's f16-table GELU / quick-GELU
 bool mmf16_applicable(int type, int n_rows, int K, int T, const void *W, const void *x, const void *y);
 hipError_t launch_mmf16(const uint8_t *W, int n_rows, int K, const float *x, int T, float *y, int ld_out, const float *resid, hipStream_t st);

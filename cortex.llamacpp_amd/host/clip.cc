@@ -139,14 +139,17 @@ std::string ClipModel::load(const std::string &path, int device) {
         if (!bad.empty()) return bad;
     }
     const int NP = n_patches();
-    d_img_ = (float *)dalloc((size_t)3 * image_size * image_size * 4);
-    d_patches_ = (float *)dalloc((size_t)NP * kp_pad_ * 4);
-    d_pe_ = (float *)dalloc((size_t)NP * E * 4);
-    d_emb_ = (float *)dalloc((size_t)T * E * 4); d_cur_ = (float *)dalloc((size_t)T * E * 4);
-    d_q_ = (float *)dalloc((size_t)T * E * 4); d_k_ = (float *)dalloc((size_t)T * E * 4); d_v_ = (float *)dalloc((size_t)T * E * 4);
-    d_att_ = (float *)dalloc((size_t)T * E * 4); d_ff_ = (float *)dalloc((size_t)T * FF * 4);
-    d_h1_ = (float *)dalloc((size_t)NP * proj_dim * 4); d_out_ = (float *)dalloc((size_t)NP * proj_dim * 4);
-    d_xh_ = dalloc((size_t)T * std::max(std::max(FF, E), std::max(proj_dim, kp_pad_)) * 2);
+    // scratch for every image of one picture at once (one for LLaVA-1.5; the overview + the tiles of the largest canvas with an image grid)
+    const size_t MI = (size_t)(max_image_rows() / NP);
+    max_images_ = (int)MI;
+    d_img_ = (float *)dalloc(MI * 3 * image_size * image_size * 4);
+    d_patches_ = (float *)dalloc(MI * NP * kp_pad_ * 4);
+    d_pe_ = (float *)dalloc(MI * NP * E * 4);
+    d_emb_ = (float *)dalloc(MI * T * E * 4); d_cur_ = (float *)dalloc(MI * T * E * 4);
+    d_q_ = (float *)dalloc(MI * T * E * 4); d_k_ = (float *)dalloc(MI * T * E * 4); d_v_ = (float *)dalloc(MI * T * E * 4);
+    d_att_ = (float *)dalloc(MI * T * E * 4); d_ff_ = (float *)dalloc(MI * T * FF * 4);
+    d_h1_ = (float *)dalloc(MI * T * proj_dim * 4); d_out_ = (float *)dalloc(MI * T * proj_dim * 4);
+    d_xh_ = dalloc(MI * T * std::max(std::max(FF, E), std::max(proj_dim, kp_pad_)) * 2);
     if (!d_img_ || !d_patches_ || !d_pe_ || !d_emb_ || !d_cur_ || !d_q_ || !d_k_ || !d_v_ || !d_att_ || !d_ff_ || !d_h1_ || !d_out_ || !d_xh_) return "out of device memory";
     if (NP < 8) return "projector file: fewer than 8 patches";
     return "";
@@ -290,31 +293,29 @@ std::string ClipModel::embed(const ClipImageU8 &img, std::vector<float> &rows, i
     std::vector<std::vector<float>> imgs;
     int gw = 0, gh = 0;
     preprocess_all(img, imgs, gw, gh);
-    const int NP = n_patches(), E = proj_dim, G = image_size / patch_size;
-    n_rows = NP * (int)imgs.size();
-    rows.assign((size_t)n_rows * E, 0.0f);
-    std::string err = encode(imgs[0].data(), rows.data());
-    if (!err.empty() || imgs.size() == 1) return err;
-    // clip_llava_handle_patches: the tiles' rows, each tile G x G row-major, re-ordered to the canvas' (grid_h * G) x (grid_w * G) row-major order
-    std::vector<float> tile((size_t)NP * E);
-    for (int gy = 0; gy < gh; gy++)
-        for (int gx = 0; gx < gw; gx++) {
-            err = encode(imgs[(size_t)(1 + gy * gw + gx)].data(), tile.data());
-            if (!err.empty()) return err;
-            for (int py = 0; py < G; py++) {
-                const size_t dst_row = (size_t)NP + ((size_t)(gy * G + py) * gw + gx) * G;
-                memcpy(rows.data() + dst_row * E, tile.data() + (size_t)py * G * E, (size_t)G * E * sizeof(float));
-            }
-        }
-    return "";
+    n_rows = n_patches() * (int)imgs.size();
+    rows.resize((size_t)n_rows * proj_dim);
+    if (imgs.size() == 1) return encode(imgs[0].data(), rows.data());
+    // all images of the picture through the tower together (the projections see n x 577 rows: more workgroups than CUs; attention stays within an image)
+    const size_t per = (size_t)3 * image_size * image_size;
+    std::vector<float> flat(per * imgs.size());
+    for (size_t i = 0; i < imgs.size(); i++) memcpy(flat.data() + i * per, imgs[i].data(), per * sizeof(float));
+    // clip_llava_handle_patches: the overview's rows, then the tiles' rows - each tile G x G row-major - re-ordered to the canvas' (grid_h * G) x (grid_w * G)
+    // row-major order: the copies out of device memory land there directly
+    return encode_batch(flat.data(), (int)imgs.size(), rows.data(), gw);
 }
 
-std::string ClipModel::encode(const float *img, float *out) {
+std::string ClipModel::encode(const float *img, float *out) { return encode_batch(img, 1, out, 0); }
+
+// n images [n][3][S][S] -> out [n][n_patches][proj_dim]: every row-wise step runs over the n x T rows at once, attention within each image.  grid_w > 0: images
+// 1 .. n - 1 are the tiles, row-major, of a canvas grid_w tiles wide, and their rows are written in the canvas' row-major order behind image 0's.
+std::string ClipModel::encode_batch(const float *img, int n, float *out, int grid_w) {
+    if (n < 1 || n > max_images_) return "clip encode: bad image count";
     if (hipSetDevice(device_) != hipSuccess) return "hipSetDevice failed";
     hipStream_t st = (hipStream_t)stream_;
-    const int S = image_size, E = n_embd, FF = n_ff, H = n_head, D = E / H, NP = n_patches(), T = NP + 1;
-    CLIP_TRY(hipMemcpyAsync(d_img_, img, (size_t)3 * S * S * 4, hipMemcpyHostToDevice, st));
-    CLIP_TRY(launch_clip_im2col(d_img_, S, patch_size, kp_pad_, d_patches_, st));
+    const int S = image_size, E = n_embd, FF = n_ff, H = n_head, D = E / H, NP = n_patches(), T1 = NP + 1, T = n * T1;
+    CLIP_TRY(hipMemcpyAsync(d_img_, img, (size_t)n * 3 * S * S * 4, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < n; i++) CLIP_TRY(launch_clip_im2col(d_img_ + (size_t)i * 3 * S * S, S, patch_size, kp_pad_, d_patches_ + (size_t)i * NP * kp_pad_, st));
     // Every projection reads its activation rows as f16 (what the CPU's f16 dot product does to them): rounded once per row here, not once per tile in the GEMM;
     // bias, the scale of Q and the residual row are the GEMM's epilogue.  MI355_CLIP_XH=0 runs the unfused form (f32 rows into the GEMM, bias and residual as
     // launches of their own) - the same values in the same order, kept so that a test can hold the two against each other.
@@ -336,8 +337,8 @@ std::string ClipModel::encode(const float *img, float *out) {
         return e;
     };
     void *const h = xh ? d_xh_ : nullptr;                       // where the producers leave the f16 copy of their rows
-    CLIP_TRY(proj(patch_w_, nullptr, E, kp_pad_, d_patches_, false, NP, d_pe_, 1.0f, false, nullptr, nullptr));
-    CLIP_TRY(launch_clip_embed(d_pe_, class_, pos_, E, T, d_emb_, st));
+    CLIP_TRY(proj(patch_w_, nullptr, E, kp_pad_, d_patches_, false, n * NP, d_pe_, 1.0f, false, nullptr, nullptr));
+    for (int i = 0; i < n; i++) CLIP_TRY(launch_clip_embed(d_pe_ + (size_t)i * NP * E, class_, pos_, E, T1, d_emb_ + (size_t)i * T1 * E, st));
     CLIP_TRY(launch_layer_norm(d_emb_, pre_w_, pre_b_, E, T, eps, d_emb_, st));
     const float qs = 1.0f / sqrtf((float)D);
     for (int il = 0; il < n_layer; il++) {
@@ -346,18 +347,33 @@ std::string ClipModel::encode(const float *img, float *out) {
         CLIP_TRY(proj(L.wq, L.bq, E, E, d_cur_, true, T, d_q_, qs, true, nullptr, nullptr));
         CLIP_TRY(proj(L.wk, L.bk, E, E, d_cur_, true, T, d_k_, 1.0f, false, nullptr, nullptr));
         CLIP_TRY(proj(L.wv, L.bv, E, E, d_cur_, true, T, d_v_, 1.0f, false, nullptr, nullptr));
-        CLIP_TRY(launch_clip_attn(d_q_, d_k_, d_v_, T, H, D, d_att_, h, st));
+        CLIP_TRY(launch_clip_attn(d_q_, d_k_, d_v_, T1, H, D, d_att_, h, n, st));
         CLIP_TRY(proj(L.wo, L.bo, E, E, d_att_, true, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
         CLIP_TRY(launch_layer_norm_h(d_emb_, L.ln2w, L.ln2b, E, T, eps, d_cur_, h, st));
         CLIP_TRY(proj(L.ff_i, L.ff_i_b, FF, E, d_cur_, true, T, d_ff_, 1.0f, false, nullptr, nullptr));
         CLIP_TRY(launch_clip_gelu(d_ff_, (size_t)T * FF, !use_gelu, h, st));
         CLIP_TRY(proj(L.ff_o, L.ff_o_b, E, FF, d_ff_, true, T, d_emb_, 1.0f, false, d_emb_, d_cur_));
     }
-    // the projector on the patch rows (the class row, row 0, is dropped)
-    CLIP_TRY(proj(mm0w_, mm0b_, proj_dim, E, d_emb_ + E, false, NP, d_h1_, 1.0f, false, nullptr, nullptr));
-    CLIP_TRY(launch_clip_gelu(d_h1_, (size_t)NP * proj_dim, false, h, st));
-    CLIP_TRY(proj(mm2w_, mm2b_, proj_dim, proj_dim, d_h1_, true, NP, d_out_, 1.0f, false, nullptr, nullptr));
-    CLIP_TRY(hipMemcpyAsync(out, d_out_, (size_t)NP * proj_dim * 4, hipMemcpyDeviceToHost, st));
+    // the projector on the patch rows (the class row, row 0 of an image, is dropped: one image projects its 576 rows; several project every row and leave
+    // the class rows behind when the result is copied out)
+    const float *px = n == 1 ? d_emb_ + E : d_emb_;
+    const int PT = n == 1 ? NP : T;
+    CLIP_TRY(proj(mm0w_, mm0b_, proj_dim, E, px, false, PT, d_h1_, 1.0f, false, nullptr, nullptr));
+    CLIP_TRY(launch_clip_gelu(d_h1_, (size_t)PT * proj_dim, false, h, st));
+    CLIP_TRY(proj(mm2w_, mm2b_, proj_dim, proj_dim, d_h1_, true, PT, d_out_, 1.0f, false, nullptr, nullptr));
+    if (n == 1) CLIP_TRY(hipMemcpyAsync(out, d_out_, (size_t)NP * proj_dim * 4, hipMemcpyDeviceToHost, st));
+    else {
+        const int G = image_size / patch_size;
+        for (int i = 0; i < n; i++) {
+            const float *src = d_out_ + ((size_t)i * T1 + 1) * proj_dim;
+            if (i == 0 || grid_w <= 0) { CLIP_TRY(hipMemcpyAsync(out + (size_t)i * NP * proj_dim, src, (size_t)NP * proj_dim * 4, hipMemcpyDeviceToHost, st)); continue; }
+            const int gy = (i - 1) / grid_w, gx = (i - 1) % grid_w;
+            for (int py = 0; py < G; py++) {
+                const size_t dst_row = (size_t)NP + ((size_t)(gy * G + py) * grid_w + gx) * G;
+                CLIP_TRY(hipMemcpyAsync(out + dst_row * proj_dim, src + (size_t)py * G * proj_dim, (size_t)G * proj_dim * 4, hipMemcpyDeviceToHost, st));
+            }
+        }
+    }
     CLIP_TRY(hipStreamSynchronize(st));
     return "";
 }

@@ -53,10 +53,13 @@ class ClipModel {
     std::string embed(const ClipImageU8 &img, std::vector<float> &rows, int &n_rows);
     // clip_image_encode: img [3][S][S] (host) -> out [n_patches][proj_dim] (host).  Empty string on success.
     std::string encode(const float *img, float *out);
+    // the same for n images at once (n <= the images of one picture): img [n][3][S][S] -> out [n][n_patches][proj_dim]
+    // grid_w > 0: images 1 .. are the tiles of a canvas grid_w wide; their rows come out in the canvas' row-major order (clip_llava_handle_patches)
+    std::string encode_batch(const float *img, int n, float *out, int grid_w = 0);
     uint64_t device_bytes = 0;
 
   private:
-    int device_ = 0, kp_pad_ = 0;
+    int device_ = 0, kp_pad_ = 0, max_images_ = 1;
     void *stream_ = nullptr;
     std::vector<void *> allocs_;
     void *patch_w_ = nullptr, *mm0w_ = nullptr, *mm2w_ = nullptr;
