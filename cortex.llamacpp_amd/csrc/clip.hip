@@ -4,7 +4,7 @@
 //
 // Stands in for the graph clip_image_encode builds (llama.cpp examples/llava/clip.cpp, reached from the reference through
 // llava_image_embed_make_with_clip_img, /root/reference/src/llama_server_context.cc:820) — SURVEY.md §8 row f4.  One image is 577 rows of 1024, once per picture
-// (five times with a LLaVA-1.6 image grid): small launches; the attention is tiled through LDS (clip_attn_tiled_kernel), the rest is written for clarity.
+// (five times with a LLaVA-1.6 image grid): small launches; the attention runs on the f32 matrix cores (clip_attn_mfma_kernel; LDS-tiled VALU kernel for other head sizes), the rest is written for clarity.
 #include <cstdlib>
 
 #include "kernels.h"
@@ -236,6 +236,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
     }
 }
+// The tower's attention on the f32 matrix cores (head size 64): 32 queries of one head per workgroup; S = Q K^T as 32 x 32 tiles of v_mfma_f32_32x32x2_f32 (a
+// wave per 32 keys of a 128-key chunk), the soft-max of clip_attn_kernel on the rows in LDS, O = P V as two 32 x 32 tiles per half of a chunk's keys (four waves:
+// output half x key half; the two key halves are added at the end).  All operands are f32 and every product is exact in the f32 accumulators' sense; what
+// differs from the other two kernels is the order of the f32 additions inside a dot product (the matrix core's, and the final pair) - a few 1e-7 relative.
+__global__ __launch_bounds__(256) void clip_attn_mfma_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v, int T, int H,
+                                                             float *__restrict__ out, _Float16 *__restrict__ outh) {
+    constexpr int D = 64, QT = 32, KC = 128, LD = D + 1, D4 = D / 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    extern __shared__ float sm[];
+    const int Tp = (T + KC - 1) / KC * KC, LS = Tp + 1;         // (odd row length: lanes that read a column of P hit 32 banks)
+    float *sQ = sm, *sKV = sQ + QT * LD, *sS = sKV + KC * LD;   // [QT][LD], [KC][LD], [QT][LS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, q0 = blockIdx.x * QT, E = H * D;
+    {
+        const size_t img = (size_t)blockIdx.z * T * E;
+        q += img; k += img; v += img; out += img;
+        if (outh) outh += img;
+    }
+    for (int i = tid; i < QT * D4; i += 256) {
+        const int r = i / D4, c4 = i - r * D4, tq = q0 + r < T ? q0 + r : T - 1;
+        const f4 val = *reinterpret_cast<const f4 *>(q + (size_t)tq * E + (size_t)h * D + 4 * c4);
+        float *d = sQ + r * LD + 4 * c4;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    constexpr int NST = KC * D4 / 256;
+    f4 pre[NST];
+    auto fetch = [&](const float *src, int c) {
+#pragma unroll
+        for (int s = 0; s < NST; s++) {
+            const int i = tid + 256 * s, r = i / D4, c4 = i - r * D4, tk = c * KC + r;
+            const int tc = tk < T ? tk : T - 1;                  // (no branch around the load; rows past T are zeroed when they are written to LDS)
+            pre[s] = *reinterpret_cast<const f4 *>(src + (size_t)tc * E + (size_t)h * D + 4 * c4);
+        }
+    };
+    auto put = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < NST; s++) {
+            const int i = tid + 256 * s, r = i / D4, c4 = i - r * D4;
+            const bool in = c * KC + r < T;
+            float *d = sKV + r * LD + 4 * c4;
+            d[0] = in ? pre[s].x : 0.0f; d[1] = in ? pre[s].y : 0.0f; d[2] = in ? pre[s].z : 0.0f; d[3] = in ? pre[s].w : 0.0f;
+        }
+    };
+    const int NC = Tp / KC;
+    fetch(k, 0);
+    for (int c = 0; c < NC; c++) {
+        __syncthreads();
+        put(c);
+        __syncthreads();
+        if (c + 1 < NC) fetch(k, c + 1); else fetch(v, 0);
+        f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        const float *qa = sQ + l31 * LD + lh, *kb = sKV + (32 * wave + l31) * LD + lh;
+#pragma unroll 8
+        for (int s = 0; s < D / 2; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s], kb[2 * s], acc, 0, 0, 0);
+        // register r: query (r & 3) + 8 (r >> 2) + 4 lh of the tile, key = 32 wave + (lane & 31) of the chunk
+        float *sd = sS + c * KC + 32 * wave + l31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sd[((r & 3) + 8 * (r >> 2) + 4 * lh) * LS] = acc[r];
+    }
+    __syncthreads();
+    for (int j = 0; j < QT / 4; j++) {                           // soft-max of row wave + 4 j, as clip_attn_kernel does it
+        float *pr = sS + (wave + 4 * j) * LS;
+        float mx = -INFINITY;
+        for (int tk = lane; tk < T; tk += 64) mx = fmaxf(mx, pr[tk]);
+        mx = wave_max(mx);
+        float sum = 0.0f;
+        for (int tk = lane; tk < T; tk += 64) { const float e = expf(pr[tk] - mx); pr[tk] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int tk = lane; tk < T; tk += 64) pr[tk] *= inv;
+        for (int tk = T + lane; tk < Tp; tk += 64) pr[tk] = 0.0f;
+    }
+    const int dt = wave & 1, kh = wave >> 1;                    // this wave's output half (32 of the 64 elements) and half of every chunk's keys
+    f16v o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.0f;
+    for (int c = 0; c < NC; c++) {
+        __syncthreads();
+        put(c);
+        __syncthreads();
+        if (c + 1 < NC) fetch(v, c + 1);
+        const float *pa = sS + l31 * LS + c * KC + kh * 64 + lh, *vb = sKV + (kh * 64 + lh) * LD + dt * 32 + l31;
+#pragma unroll 8
+        for (int s = 0; s < 32; s++) o = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s], vb[2 * s * LD], o, 0, 0, 0);
+    }
+    __syncthreads();                                            // (sKV is free: the second key half's sums go through it)
+    float *red = sKV + (size_t)dt * 1024;
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[r * 64 + lane] = o[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float val = o[r] + red[r * 64 + lane];
+            const int tq = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (tq < T) {
+                const size_t at = (size_t)tq * E + (size_t)h * D + dt * 32 + l31;
+                out[at] = val;
+                if (outh) outh[at] = (_Float16)val;
+            }
+        }
+    }
+}
+static hipError_t launch_clip_attn_mfma(const float *q, const float *k, const float *v, int T, int H, int n_img, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
+    static bool raised = false;
+    if (lds > 65536 && !raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clip_attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(clip_attn_mfma_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)H, (unsigned)n_img), dim3(256), lds, st, q, k, v, T, H, out, outh);
+    return hipGetLastError();
+}
 template <int D>
 static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, int n_img, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
     static bool raised = false;
@@ -250,8 +368,13 @@ static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const f
 // out_h (optional): the output rows once more, rounded to f16.  n_img images of T rows each, one after the other in every buffer: attention within an image.
 hipError_t launch_clip_attn(const float *q, const float *k, const float *v, int T, int H, int D, float *out, void *out_h, int n_img, hipStream_t st) {
     _Float16 *outh = reinterpret_cast<_Float16 *>(out_h);
-    const char *sw = getenv("MI355_CLIP_ATTN_TILED");           // (read at every launch - a few dozen an image - so that a test can compare the two kernels)
+    const char *sw = getenv("MI355_CLIP_ATTN_TILED");           // (read at every launch - a few dozen an image - so that a test can compare the kernels)
     const bool tiled = !(sw && atoi(sw) == 0);
+    const char *sm_ = getenv("MI355_CLIP_ATTN_MFMA");           // "0": the f32 VALU kernels only
+    if (tiled && D == 64 && !(sm_ && atoi(sm_) == 0)) {
+        const size_t Tp = (size_t)(T + 127) / 128 * 128, lds = ((size_t)32 * 65 + (size_t)128 * 65 + (size_t)32 * (Tp + 1)) * sizeof(float);
+        if (lds <= 160 * 1024) return launch_clip_attn_mfma(q, k, v, T, H, n_img, out, outh, lds, st);
+    }
     if (tiled && (D == 32 || D == 64 || D == 128)) {
         const size_t Tp = (size_t)(T + 63) / 64 * 64, lds = ((size_t)40 * D + (size_t)64 * (D + 4) + (size_t)40 * Tp) * sizeof(float);
         if (lds <= 160 * 1024) {
