@@ -609,13 +609,13 @@ class Context:
     def logits(self, i: int = -1) -> np.ndarray:
         p = self.lib.mi355_get_logits_ith(self.h, i)
         if not p:
-            raise MI355Error("no logits for that batch row")
+            raise MI355Error(f"no logits for that batch row: {_err(self.lib)}")
         return np.ctypeslib.as_array(p, shape=(self.model.n_vocab,)).copy()
 
     def logits_ready(self, i: int = -1) -> None:
         """Block until the logits row is host-visible (no numpy copy)."""
         if not self.lib.mi355_get_logits_ith(self.h, i):
-            raise MI355Error("no logits for that batch row")
+            raise MI355Error(f"no logits for that batch row: {_err(self.lib)}")
 
     def set_embeddings(self, on: bool = True) -> None:
         self.lib.mi355_set_embeddings(self.h, int(on))

@@ -231,7 +231,11 @@ int32_t mi355_greedy_steps(mi355_context *ctx, mi355_token first, mi355_pos pos0
         return n;
     )
 }
-float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) { return ctx->c->logits_ith(i); }
+float *mi355_get_logits_ith(mi355_context *ctx, int32_t i) {
+    float *p = ctx->c->logits_ith(i);
+    if (!p) fail(ctx->c->last_error.empty() ? "no logits for that batch row" : ctx->c->last_error);      // (why: a step an in-kernel wait gave up on says so here)
+    return p;
+}
 int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i) { return ctx->c->argmax_ith(i); }
 int32_t mi355_get_topk_ith(mi355_context *ctx, int32_t i, int32_t k, int32_t n_adj, const int32_t *adj_tok, const float *adj_bias, const int32_t *adj_count,
                            float penalty_repeat, float penalty_freq, float penalty_present, int32_t *toks_out, float *logits_out) {
