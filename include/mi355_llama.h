@@ -144,7 +144,8 @@ MI355_API int32_t mi355_decode(mi355_context *ctx, mi355_batch batch);
  * request (llama_server_context.cc:1628-1707), on the C side.  out_tokens (nullable) [n].  Returns the steps done (n, or fewer with the reason in mi355_last_error). */
 MI355_API int32_t mi355_greedy_steps(mi355_context *ctx, mi355_token first, mi355_pos pos0, mi355_seq_id seq, int32_t n, mi355_token *out_tokens);
 /* llama_get_logits_ith as used through common_sampler_sample(ctx, idx) (ctx.cc:1679-1680).
- * i indexes the batch of the last mi355_decode; NULL if that row had logits[i] == 0. */
+ * i indexes the batch of the last mi355_decode; NULL if that row had logits[i] == 0, in embeddings mode, or when the step's results were discarded
+ * (an in-kernel wait that gave up, a failed copy) - mi355_last_error then says which. */
 MI355_API float  *mi355_get_logits_ith(mi355_context *ctx, int32_t i);
 /* device-side greedy front end: argmax token of row i without copying the row */
 MI355_API int32_t mi355_get_argmax_ith(mi355_context *ctx, int32_t i);
