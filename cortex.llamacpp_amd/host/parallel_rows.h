@@ -14,8 +14,12 @@ inline void parallel_rows(int n, int64_t work, F f) {
     const int nt = work < (1 << 16) ? 1 : (int)std::min<int64_t>(8, std::min<int64_t>((int64_t)std::thread::hardware_concurrency(), n / 16));
     if (nt <= 1) { f(0, n); return; }
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(f, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+    int started = 1;                                            // ranges [n t / nt, n (t + 1) / nt): range 0 is the caller's
+    try {
+        for (; started < nt; started++) th.emplace_back(f, (int)((int64_t)n * started / nt), (int)((int64_t)n * (started + 1) / nt));
+    } catch (...) {}                                            // (no more threads to be had: the caller does the rest)
     f(0, (int)((int64_t)n / nt));
+    if (started < nt) f((int)((int64_t)n * started / nt), n);
     for (auto &t : th) t.join();
 }
 
