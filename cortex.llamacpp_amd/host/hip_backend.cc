@@ -3,6 +3,8 @@
 //   cache_type f16|q8_0|q4_0 (invalid -> f16), flash_attn (true; forced on by a quantised cache), embedding.
 #include "hip_backend.h"
 
+#include <exception>
+
 #include "clip.h"
 #include "log.h"
 
@@ -39,20 +41,24 @@ class HipBackend : public IBackend {
     }
     void set_clip(std::unique_ptr<ClipModel> c) { clip_ = std::move(c); }
     bool multimodal() const override { return clip_ != nullptr; }
+    // (the bytes are a request's: whatever goes wrong with them - a picture too large to hold included - is that request's error, not the loop thread's end)
     bool image_check(const uint8_t *bytes, size_t n, std::string &err) override {
-        ClipImageU8 img;
-        err = clip_image_load_from_bytes(bytes, n, img);
+        try {
+            ClipImageU8 img;
+            err = clip_image_load_from_bytes(bytes, n, img);
+        } catch (const std::exception &e) { err = std::string("image: ") + e.what(); }
         return err.empty();
     }
     int image_embed(const uint8_t *bytes, size_t n, std::vector<float> &rows, std::string &err) override {
         if (!clip_) { err = "no multimodal projector loaded"; return -1; }
-        ClipImageU8 img;
-        err = clip_image_load_from_bytes(bytes, n, img);
-        if (!err.empty()) return -1;
-        std::vector<float> pix;
-        int n_rows = 0;
-        err = clip_->embed(img, rows, n_rows);
-        return err.empty() ? n_rows : -1;
+        try {
+            ClipImageU8 img;
+            err = clip_image_load_from_bytes(bytes, n, img);
+            if (!err.empty()) return -1;
+            int n_rows = 0;
+            err = clip_->embed(img, rows, n_rows);
+            return err.empty() ? n_rows : -1;
+        } catch (const std::exception &e) { err = std::string("image: ") + e.what(); return -1; }
     }
     int decode_embd(const float *rows, int n, int pos0, int seq) override {
         pos_store_.resize((size_t)n);
