@@ -117,6 +117,7 @@ SYMBOLS = {
     "mi355_token_is_eog": (_i32, [_vp, _i32]),
     "mi355_engine_create": (_vp, []),
     "mi355_engine_destroy": (None, [_vp]),
+    "mi355_engine_set_release_callback": (None, [_vp, _vp]),
     "mi355_engine_load_model": (None, [_vp, _cp, ENGINE_CB, _vp]),
     "mi355_engine_unload_model": (None, [_vp, _cp, ENGINE_CB, _vp]),
     "mi355_engine_get_model_status": (None, [_vp, _cp, ENGINE_CB, _vp]),

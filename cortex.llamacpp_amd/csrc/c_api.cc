@@ -1,6 +1,7 @@
 // c_api.cc — the C-ABI declared in include/mi355_llama.h, over host/runtime.{h,cc}.
 #include "../../include/mi355_llama.h"
 
+#include <atomic>
 #include <memory>
 #include <new>
 #include <chrono>
@@ -29,7 +30,11 @@ struct mi355_model {
     Vocab vocab;            // loaded on first tokenizer call
     bool vocab_tried = false, vocab_ok = false;
 };
-struct mi355_engine { LlamaEngine eng{make_hip_backend}; };
+typedef void (*mi355_release_fn)(void *);
+struct mi355_engine {
+    LlamaEngine eng{make_hip_backend};
+    std::atomic<mi355_release_fn> release{nullptr};     // mi355_engine_set_release_callback
+};
 struct mi355_clip { ClipModel m; };
 struct mi355_context {
     Context *c;
@@ -836,8 +841,12 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "mmq_ksplit")) { g_op_mmq_ksplit = value != 0; return MI355_OK; }
     if (!strcmp(name, "attn_store_fuse")) { set_attn_store_fuse(value != 0); return MI355_OK; }
     if (!strcmp(name, "rope_fast")) { set_rope_fast(value != 0); return MI355_OK; }
-    if (!strcmp(name, "decode_mega")) { set_decode_mega(value != 0); return MI355_OK; }
-    if (!strcmp(name, "decode_engine")) { set_decode_engine(value); return MI355_OK; }
+    if (!strcmp(name, "decode_mega") || !strcmp(name, "decode_engine")) {
+        // the whole-step kernel and the layer engine are experiments that lost their A/Bs: only a library built with MI355_BUILD_EXPERIMENTS=1 holds them
+        if (value > 0 && !experiments_built()) { fail(std::string(name) + ": the experiment kernels are not in this build (MI355_BUILD_EXPERIMENTS=1 python cortex.llamacpp_amd/build.py --force)"); return MI355_ERR_ARG; }
+        if (name[7] == 'm') set_decode_mega(value != 0); else set_decode_engine(value);
+        return MI355_OK;
+    }
     if (!strcmp(name, "tp_p2p")) { tp_p2p_use(value != 0); return MI355_OK; }
     if (!strcmp(name, "tp_p2p_prompt")) { tp_p2p_use_prompt(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
@@ -944,8 +953,13 @@ static bool parse_body(const char *txt, Json &j, mi355_engine_callback cb, void 
     }
     return false;
 }
-static LlamaEngine::Callback wrap_cb(mi355_engine_callback cb, void *user) {
-    return [cb, user](Json &&st, Json &&body) {
+// The engine copies the callback into whatever outlives the call (a queued stream task); every copy shares `guard`, so the host's release function runs
+// exactly once per request, after the last callback the request will ever make - also for a request that ends without a terminal callback (a stream
+// cancelled by StopInferencing: src/llama_engine.cc:950-955 breaks out of the loop without one)
+static LlamaEngine::Callback wrap_cb(mi355_engine *e, mi355_engine_callback cb, void *user) {
+    const mi355_release_fn rel = e->release.load();
+    std::shared_ptr<void> guard(user, [rel](void *u) { if (rel) rel(u); });
+    return [cb, user, guard](Json &&st, Json &&body) {
         if (!cb) return;
         const std::string s = st.dump(), b = body.dump();
         cb(s.c_str(), b.c_str(), user);
@@ -971,8 +985,10 @@ void mi355_engine_destroy(mi355_engine *e) { delete e; }
     void cname(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user) {              \
         try {                                                                                               \
             Json j;                                                                                         \
-            if (!e || !parse_body(body_json, j, cb, user)) return;                                          \
-            e->eng.Method(j, wrap_cb(cb, user));                                                            \
+            if (!e) return;                                                                                 \
+            LlamaEngine::Callback w = wrap_cb(e, cb, user);   /* from here on `user` is released with w */   \
+            if (!parse_body(body_json, j, cb, user)) return;                                                \
+            e->eng.Method(j, std::move(w));                                                                 \
         } catch (const std::exception &ex) {                                                                \
             engine_exception(cb, user, ex.what());                                                          \
         } catch (...) {                                                                                     \
@@ -986,6 +1002,7 @@ MI355_ENGINE_FWD(mi355_engine_get_models, GetModels)
 MI355_ENGINE_FWD(mi355_engine_handle_chat_completion, HandleChatCompletion)
 MI355_ENGINE_FWD(mi355_engine_handle_embedding, HandleEmbedding)
 #undef MI355_ENGINE_FWD
+void mi355_engine_set_release_callback(mi355_engine *e, void (*release)(void *user)) { if (e) e->release.store(release); }
 int32_t mi355_engine_is_supported(mi355_engine *e, const char *feature) { return e && feature && e->eng.IsSupported(feature) ? 1 : 0; }
 void mi355_engine_stop_inferencing(mi355_engine *e, const char *model_id) { if (e && model_id) e->eng.StopInferencing(model_id); }
 void mi355_engine_load(mi355_engine *e, const char *engine_path, const char *deps_path, int32_t is_custom_engine_path, const char *log_path, int32_t max_log_lines,

@@ -345,22 +345,18 @@ __global__ __launch_bounds__(256) void clip_attn_mfma_kernel(const float *__rest
     }
 }
 static hipError_t launch_clip_attn_mfma(const float *q, const float *k, const float *v, int T, int H, int n_img, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
-    static bool raised = false;
-    if (lds > 65536 && !raised) {
+    if (lds > 65536) {      // the attribute belongs to the DEVICE's copy of the kernel: set on every such launch (a flag per process was wrong for a second GPU, and raced)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clip_attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
     }
     hipLaunchKernelGGL(clip_attn_mfma_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)H, (unsigned)n_img), dim3(256), lds, st, q, k, v, T, H, out, outh);
     return hipGetLastError();
 }
 template <int D>
 static hipError_t launch_clip_attn_tiled(const float *q, const float *k, const float *v, int T, int H, int n_img, float *out, _Float16 *outh, size_t lds, hipStream_t st) {
-    static bool raised = false;
-    if (lds > 65536 && !raised) {
+    if (lds > 65536) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clip_attn_tiled_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
     }
     hipLaunchKernelGGL(clip_attn_tiled_kernel<D>, dim3((unsigned)((T + 39) / 40), (unsigned)H, (unsigned)n_img), dim3(256), lds, st, q, k, v, T, H, out, outh);
     return hipGetLastError();

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(MEGA_NT, 2) void decode_mega_kernel(const MegaLayer
 
 }  // namespace
 
+bool experiments_built() { return true; }      // (this file and decode_engine.hip are compiled together or not at all: build.py)
 int mega_blocks() { return 2 * num_cu(); }
 
 bool decode_mega_applicable(int kb_e, int kb_ff, int R, int type_k, int type_v) {

@@ -79,7 +79,9 @@ void mmvq_stream_plan(MMVQArgs &a, int blocks);
 // the sticky error word of the weight-stream kernels (pinned host memory, or nullptr): a bounded wait that gives up ORs a code into it
 void mmvq_stream_set_error_word(unsigned *w);
 
-// ---------------------------------------------------------------- one decoder layer's mat-vecs in one persistent launch (decode_engine.hip)
+// the two experiment translation units below (decode_engine.hip, decode_mega.hip) are in this library (build.py, MI355_BUILD_EXPERIMENTS=1); false: experiments_absent.cc
+bool experiments_built();
+// ---------------------------------------------------------------- one decoder layer's mat-vecs in one persistent launch (decode_engine.hip; experiment, see above)
 // attn_output -> gate | up -> down -> the next layer's Q | K | V, hand-overs through tagged granules; descriptors in device memory, each planned with
 // mmvq_stream_plan(.., num_cu()).  has_qkv = 0: the launch ends behind ffn_down (last layer).
 struct EngineLayer {

@@ -160,17 +160,12 @@ std::string ClipModel::load(const std::string &path, int device) {
 void ClipModel::preprocess(const ClipImageU8 &img, std::vector<float> &out) const {
     const int S = image_size;
     out.assign((size_t)3 * S * S, 0.0f);
-    int tn = img.nx, tny = img.ny;
-    std::vector<uint8_t> sq;
-    const uint8_t *src = img.rgb.data();
-    if (img.nx != img.ny) {
-        const int L = std::max(img.nx, img.ny);
-        sq.resize((size_t)3 * L * L);
-        static const uint8_t bc[3] = {122, 116, 104};
-        for (size_t i = 0; i < (size_t)L * L; i++) { sq[3 * i] = bc[0]; sq[3 * i + 1] = bc[1]; sq[3 * i + 2] = bc[2]; }
-        for (int y = 0; y < img.ny; y++) memcpy(sq.data() + (size_t)3 * y * L, img.rgb.data() + (size_t)3 * y * img.nx, (size_t)3 * img.nx);
-        src = sq.data(); tn = L; tny = L;
-    }
+    // the square is never built (a 16384 x 1 picture would ask for 805 MB of it): a pixel outside the picture IS the pad colour
+    static const uint8_t bc[3] = {122, 116, 104};
+    const int tn = std::max(img.nx, img.ny), tny = tn;
+    const int nx = img.nx, ny = img.ny;
+    const uint8_t *rgb = img.rgb.data();
+    auto px = [&](int y, int x, int k) -> float { return (float)(x < nx && y < ny ? rgb[3 * ((size_t)y * nx + x) + k] : bc[k]); };
     const float scale = (float)std::max(tn, tny) / (float)S;
     for (int y = 0; y < S; y++)
         for (int x = 0; x < S; x++)
@@ -179,8 +174,8 @@ void ClipModel::preprocess(const ClipImageU8 &img, std::vector<float> &out) cons
                 const int x0 = std::max(0, (int)floorf(sx)), y0 = std::max(0, (int)floorf(sy));
                 const int x1 = std::min(x0 + 1, tn - 1), y1 = std::min(y0 + 1, tny - 1);
                 const float dx = sx - (float)x0, dy = sy - (float)y0;
-                const float v00 = src[3 * ((size_t)y0 * tn + x0) + k], v01 = src[3 * ((size_t)y0 * tn + x1) + k];
-                const float v10 = src[3 * ((size_t)y1 * tn + x0) + k], v11 = src[3 * ((size_t)y1 * tn + x1) + k];
+                const float v00 = px(y0, x0, k), v01 = px(y0, x1, k);
+                const float v10 = px(y1, x0, k), v11 = px(y1, x1, k);
                 const float v0 = v00 * (1.0f - dx) + v01 * dx, v1 = v10 * (1.0f - dx) + v11 * dx;
                 const float v = v0 * (1.0f - dy) + v1 * dy;
                 const uint8_t v2 = (uint8_t)std::min(std::max(roundf(v), 0.0f), 255.0f);

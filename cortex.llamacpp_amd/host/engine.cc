@@ -522,6 +522,7 @@ void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734
             LlamaServerContext &llama = *si->ctx;
             const int task_id = llama.RequestCompletion(data, false, false, -1);
             bool first = true;
+            bool terminal = false;                  // the stream has had its last callback (is_done, or the error chunk)
             while (llama.model_loaded_external) {
                 {
                     std::lock_guard<std::mutex> lk(stop_mutex_);
@@ -549,6 +550,7 @@ void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734
                         Json last = Json::object();
                         last["data"] = "data: " + chunk_json("", Json("stop"), include_usage, include_usage ? &usage : nullptr, Json()) + "\n\n" + "data: [DONE]" + "\n\n";
                         cb(make_status(true, false, true, k200OK), std::move(last));
+                        terminal = true;
                         break;
                     }
                 } else {   // :1017-1024
@@ -556,8 +558,18 @@ void LlamaEngine::HandleInferenceImpl(const Json &body, Callback cb) {   // :734
                     Json resp = Json::object();
                     resp["data"] = std::string();
                     cb(make_status(false, true, true, k200OK), std::move(resp));
+                    terminal = true;
                     break;
                 }
+            }
+            // :1028-1041 - the loop ended because the model was unloaded under the stream (between two results, or before this task ever ran): the
+            // provider is still waiting, so it gets the error chunk {data: "", has_error, is_stream} as its last callback.  (A stream that already had its
+            // terminal callback gets nothing more: the reference would call back once more behind is_done when an unload follows a finished stream at once.)
+            if (!terminal && !llama.model_loaded_external) {
+                log_line(LOG_WARN, "Model unloaded during inference");
+                Json resp = Json::object();
+                resp["data"] = std::string();
+                cb(make_status(false, true, true, k200OK), std::move(resp));
             }
         });
     } else {   // :1044-1112

@@ -96,6 +96,9 @@ bool inflate_zlib(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_
         const int type = br.bits(2);
         if (br.bad) return false;
         if (type == 0) {
+            // a stored block starts at the next byte boundary of the STREAM: the Huffman decoder of a preceding block looks up to 16 bits ahead, so whole
+            // bytes (LEN / NLEN) may already sit in the bit buffer - hand them back before dropping the partial byte
+            br.p -= (br.cnt >> 3);
             br.buf = 0; br.cnt = 0;
             if (br.p + 4 > br.end) return false;
             const unsigned len = br.p[0] | br.p[1] << 8, nlen = br.p[2] | br.p[3] << 8;
@@ -422,7 +425,7 @@ const uint8_t JZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
 const char *jblock_sequential(JBits &br, const JHuff &dc, const JHuff &ac, int &pred, int16_t *coef) {
     const int t = jdecode(br, dc);
     if (t > 11) return "JPEG: bad DC code";
-    pred += jextend(br.get(t), t);
+    pred = (int)((unsigned)pred + (unsigned)jextend(br.get(t), t));
     coef[0] = (int16_t)pred;
     for (int k = 1; k < 64;) {
         const int rs = jdecode(br, ac), r = rs >> 4, sz = rs & 15;
@@ -440,8 +443,8 @@ const char *jblock_progressive(JBits &br, const JHuff &dc, const JHuff &ac, int 
         if (sc.Ah == 0) {
             const int t = jdecode(br, dc);
             if (t > 11) return "JPEG: bad DC code";
-            pred += jextend(br.get(t), t);
-            coef[0] = (int16_t)(pred * (1 << sc.Al));
+            pred = (int)((unsigned)pred + (unsigned)jextend(br.get(t), t));     // (hostile input: wraps instead of overflowing)
+            coef[0] = (int16_t)((unsigned)pred << sc.Al);
         } else if (br.get(1)) coef[0] = (int16_t)(coef[0] | (1 << sc.Al));
         return nullptr;
     }
@@ -551,6 +554,13 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
             // (a frame of ONE component is never interleaved: its unit is a single block whatever the sampling factors say)
             if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
             mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            // a coded block takes at least one bit of entropy data (a DC-only progressive scan of one-bit codes): a file too short for its own frame is a
+            // header that asks for hundreds of MB of coefficients and planes with nothing behind it
+            {
+                int64_t blocks = 0;
+                for (const auto &c : comps) blocks += (int64_t)mcux * c.h * mcuy * c.v;
+                if (blocks > (int64_t)8 * (int64_t)n) return "JPEG: fewer bytes than the frame has blocks";
+            }
             // the coefficients of the whole picture: scans (one for a baseline file as encoders write it, ten or so for a progressive one) fill them in
             for (auto &c : comps) {
                 c.bw = mcux * c.h; c.bh = mcuy * c.v;
@@ -625,7 +635,7 @@ std::string load_jpeg(const uint8_t *d, size_t n, ClipImageU8 &out) {
                         if (restart) until_restart--;
                     }
             }
-            n_scans++;
+            if (++n_scans > 64) return "JPEG: more than 64 scans";      // (encoders write about ten; every scan walks all blocks of its components)
             // the next marker segment: behind the entropy-coded bytes (stuffed zeros and restart markers belong to them)
             size_t q = pos + len;
             while (q + 1 < n && !(d[q] == 0xff && d[q + 1] != 0 && d[q + 1] != 0xff && !(d[q + 1] >= 0xd0 && d[q + 1] <= 0xd7))) q++;

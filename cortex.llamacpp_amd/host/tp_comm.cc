@@ -5,9 +5,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types and enums only: the functions are looked up in the library at run time
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
+#include <vector>
 
 namespace mi355 {
 
@@ -52,6 +55,8 @@ struct P2PDev {                        // by value into the kernel
     unsigned *bflags[P2P_MAX_RANKS];   // [2 sets][2 phases][P][RSAG_MAX_WGS]
     unsigned *bepoch;                  // private [RSAG_MAX_WGS]
     size_t seg_max;                    // floats per segment slot (a multiple of 4)
+    unsigned long long *trace;         // nullable (MI355_TP_TRACE=1): per launch of either kernel 4 stamps of the 100 MHz wall clock, written by workgroup 0
+    unsigned trace_slot;               // ... at trace[4 * trace_slot ..]: entered, own flags out, first wait over, done
 };
 struct P2PState {
     bool on = false;
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
     __shared__ unsigned e_sh;
     const int tid = (int)threadIdx.x, w = (int)blockIdx.x, P = a.size;
     if (tid == 0) e_sh = a.epoch[w] + 1u;
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
     __syncthreads();
     const unsigned e = e_sh;
     const size_t set = e & 1u;
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
     __threadfence_system();                               // every thread: its stores have left for their owners before the flags do
     __syncthreads();
     if (tid < P) __hip_atomic_store(a.flags[tid] + (set * (size_t)P + (size_t)a.rank) * P2P_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 1] = wall_clock64();
     // 2. everybody's slice w has arrived in MY buffer once my P flags of this set carry e
     if (tid < P) {
         const unsigned *f = a.flags[a.rank] + (set * (size_t)P + (size_t)tid) * P2P_WGS + w;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
         }
     }
     __syncthreads();
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 2] = wall_clock64();
     // 3. the P slots added in rank order (system-scope loads: the lines were written by other devices)
     const float *mine = a.data[a.rank] + set * (size_t)P * a.max_floats;
     for (int i = lo + tid; i < hi; i += 256) {
@@ -107,6 +115,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
         recv[i] = acc;
     }
     if (tid == 0) a.epoch[w] = e;
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 3] = wall_clock64();
 }
 
 // ---- prompt-sized messages: reduce-scatter + all-gather on all links at once (no reference counterpart: upstream copies whole
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
     __shared__ unsigned e_sh;
     const int tid = (int)threadIdx.x, w = (int)blockIdx.x, G = (int)gridDim.x, P = a.size, R = a.rank;
     if (tid == 0) e_sh = a.bepoch[w] + 1u;
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
     __syncthreads();
     const unsigned e = e_sh;
     const size_t set = e & 1u;
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
         for (int i = s_lo + tid * 4; i < hi; i += 1024) tp_st_sys(dst, i, src[i >> 2]);
     }
     rsag_signal_and_wait(a, set, 0, w, e);
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 1] = wall_clock64();
     // 2. my segment: the P parts in rank order; the sum to `recv` and into every rank's reduced area, slot R
     {
         const int hi = R * seg + s_hi < n ? s_hi : n - R * seg;
@@ -183,6 +194,7 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
         }
     }
     rsag_signal_and_wait(a, set, 1, w, e);
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 2] = wall_clock64();
     // 3. the foreign segments out of my own buffer
     for (int d = 1; d < P; d++) {
         const int q = R + d < P ? R + d : R + d - P;
@@ -192,6 +204,43 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
         for (int i = s_lo + tid * 4; i < hi; i += 1024) out[i >> 2] = tp_ld_sys(src, i);
     }
     if (tid == 0) a.bepoch[w] = e;
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 3] = wall_clock64();
+}
+
+// ---- MI355_TP_TRACE=1: when each exchange was launched (host clock) and when its kernel entered / signalled / stopped waiting / ended (the device's 100 MHz
+// wall clock, one counter for every process on the GPU), printed per rank at exit - who is late for whom, and whether the host or the device held it back
+constexpr int TRACE_MAX = 4096;
+struct TraceRec { double host_us; int n; int kind; };
+std::vector<TraceRec> g_trace;
+unsigned long long *g_trace_dev = nullptr;       // pinned host memory, device-visible
+bool g_trace_on = false, g_trace_init = false;
+double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3; }
+void trace_dump() {
+    if (!g_trace_dev || g_trace.empty()) return;
+    (void)hipDeviceSynchronize();
+    const double h0 = g_trace[0].host_us;
+    fprintf(stderr, "[tp trace] rank %d of %d: %zu exchanges (host us since the first launch | device wall clock us: entered, signalled, waited, done)\n", g_grp.rank, g_grp.size, g_trace.size());
+    for (size_t i = 0; i < g_trace.size() && i < (size_t)TRACE_MAX; i++) {
+        const unsigned long long *t = g_trace_dev + 4 * i;
+        const bool slow = (t[3] - t[0]) > 100ull * 1000 || (i > 0 && g_trace[i].host_us - g_trace[i - 1].host_us > 50e3);   // > 1 ms in the kernel, or > 50 ms between two launches
+        if (i < 8 || slow)
+            fprintf(stderr, "[tp trace] rank %d #%zu %s n=%d host %.0f | dev %.2f %+.2f %+.2f %+.2f%s\n", g_grp.rank, i, g_trace[i].kind ? "rsag" : "p2p", g_trace[i].n, g_trace[i].host_us - h0,
+                    (double)t[0] / 100.0, (double)(t[1] - t[0]) / 100.0, (double)(t[2] - t[0]) / 100.0, (double)(t[3] - t[0]) / 100.0, slow ? "  <-- slow" : "");
+    }
+}
+unsigned trace_next(int n, int kind) {
+    if (!g_trace_init) {
+        g_trace_init = true;
+        const char *ev = getenv("MI355_TP_TRACE");
+        if (ev && ev[0] == '1' && hipHostMalloc((void **)&g_trace_dev, (size_t)TRACE_MAX * 4 * 8, hipHostMallocDefault) == hipSuccess) {
+            memset(g_trace_dev, 0, (size_t)TRACE_MAX * 4 * 8);
+            g_trace_on = true;
+            atexit(trace_dump);
+        }
+    }
+    if (!g_trace_on || g_trace.size() >= (size_t)TRACE_MAX) return 0;
+    g_trace.push_back({now_us(), n, kind});
+    return (unsigned)g_trace.size() - 1;
 }
 
 bool load_rccl(std::string &err) {
@@ -364,11 +413,13 @@ hipError_t tp_all_reduce_sum(const float *send, float *recv, size_t n, hipStream
     Group &g = g_grp;
     if (g_p2p.on && n <= g_p2p.max_floats && n >= 4) {          // decode-sized message: the one-shot peer-to-peer kernel
         g_p2p.exchanges++;
+        g_p2p.dev.trace_slot = trace_next((int)n, 0); g_p2p.dev.trace = g_trace_on && g_trace.size() < (size_t)TRACE_MAX ? g_trace_dev : nullptr;
         hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(P2P_WGS), dim3(256), 0, st, send, recv, (int)n, g_p2p.dev);
         return hipGetLastError();
     }
     if (g_p2p.on && g_p2p.prompt_on && n > g_p2p.max_floats && n <= g_p2p.prompt_floats && !(n & 3)) {   // prompt-sized: reduce-scatter + all-gather over all links
         g_p2p.prompt_exchanges++;
+        g_p2p.dev.trace_slot = trace_next((int)n, 1); g_p2p.dev.trace = g_trace_on && g_trace.size() < (size_t)TRACE_MAX ? g_trace_dev : nullptr;
         hipLaunchKernelGGL(p2p_rsag_kernel, dim3(g_p2p.rsag_wgs), dim3(256), 0, st, send, recv, (int)n, g_p2p.dev);
         return hipGetLastError();
     }

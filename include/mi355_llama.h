@@ -247,6 +247,11 @@ typedef struct mi355_engine mi355_engine;
 typedef void (*mi355_engine_callback)(const char *status_json, const char *body_json, void *user);
 MI355_API mi355_engine *mi355_engine_create(void);                 /* get_engine()  (src/llama_engine.cc:1300-1304) */
 MI355_API void mi355_engine_destroy(mi355_engine *e);
+/* Lifetime of `user`: the reference's callback is a std::function that dies with the request (it is captured by value in the queued task,
+   src/llama_engine.cc:946-948); a C callback has no destructor, so a host that allocates per-request state registers one function here and the library calls
+   it exactly once per request with that request's `user`, after the LAST callback the request will ever make - also when the request ends without a terminal
+   (is_done / has_error) callback, as a stream stopped by StopInferencing does (:950-955).  Set it before the first request; NULL (default) = nothing is called. */
+MI355_API void mi355_engine_set_release_callback(mi355_engine *e, void (*release)(void *user));
 MI355_API void mi355_engine_load_model(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
 MI355_API void mi355_engine_unload_model(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);
 MI355_API void mi355_engine_get_model_status(mi355_engine *e, const char *body_json, mi355_engine_callback cb, void *user);

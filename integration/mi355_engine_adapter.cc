@@ -27,10 +27,11 @@ void Tramp(const char* status_json, const char* body_json, void* user) {
   Json::Reader reader;
   reader.parse(status_json, status);
   reader.parse(body_json, body);
-  const bool last = status["is_done"].asBool() || status["has_error"].asBool();
   (*cb)(std::move(status), std::move(body));
-  if (last) delete cb;
 }
+// the library is through with a request (its last callback has returned - or it ends without a terminal one: a stream stopped by StopInferencing, a
+// stream whose model was unloaded before its task ran): the std::function dies here, as the reference's dies with its queued task
+void Release(void* user) { delete static_cast<Cb*>(user); }
 
 std::string Dump(const std::shared_ptr<Json::Value>& j) { return j ? Json::FastWriter().write(*j) : std::string("{}"); }
 
@@ -49,7 +50,7 @@ void LogBridge(int level, const char* line, void*) {
 
 class Mi355Engine : public EngineI {
  public:
-  Mi355Engine() : e_(mi355_engine_create()) {}
+  Mi355Engine() : e_(mi355_engine_create()) { mi355_engine_set_release_callback(e_, Release); }
   ~Mi355Engine() override { mi355_engine_destroy(e_); }
 
   void Load(EngineLoadOption opts) final {

@@ -1060,6 +1060,67 @@ static void test_engine() {
     CHECK(code == 409);
 }
 
+// A model unloaded under a running stream, and under a stream still queued behind it (reference: src/llama_engine.cc:1028-1041 - the loop over
+// model_loaded_external ends and the provider gets {data: "", has_error: true, is_stream: true} as its last callback); a stream stopped by StopInferencing
+// ends without a terminal callback (:950-955) and its callback object is destroyed with the task.
+static void test_engine_unload_mid_stream() {
+    LlamaEngine eng([](const Json &, BackendInfo &, std::string &) -> std::unique_ptr<IBackend> {
+        auto *fb = new FakeBackend(); fb->decode_sleep_us = 2000; return std::unique_ptr<IBackend>(fb);
+    });
+    Json load = Json::object();
+    load["llama_model_path"] = "/models/slow.gguf"; load["ctx_len"] = 256; load["n_parallel"] = 1;
+    int code = 0;
+    auto grab = [&](Json &&st, Json &&) { code = (int)st["status_code"].as_int(); };
+    Json req = Json::object();
+    req["model"] = "slow"; req["max_tokens"] = 200; req["temperature"] = 0.0; req["stream"] = true;
+    Json msgs = Json::array(), m1 = Json::object();
+    m1["role"] = "user"; m1["content"] = "hello world";
+    msgs.push_back(m1);
+    req["messages"] = msgs;
+    struct Seen { std::mutex mu; std::condition_variable cv; int chunks = 0, terminal = 0, after_terminal = 0; Json last_status, last_body; };
+    auto watch = [](std::shared_ptr<Seen> s, std::shared_ptr<int> token) {
+        return [s, token](Json &&st, Json &&b) {
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (s->terminal) s->after_terminal++;
+            if (st["is_done"].as_bool() || st["has_error"].as_bool()) { s->terminal++; s->last_status = st; s->last_body = b; }
+            else s->chunks++;
+            s->cv.notify_all();
+        };
+    };
+    for (int round = 0; round < 2; round++) {       // 0: unload under the streams; 1: StopInferencing
+        eng.LoadModel(load, grab);
+        CHECK(code == 200);
+        auto a = std::make_shared<Seen>(), b = std::make_shared<Seen>();
+        auto ta = std::make_shared<int>(0), tb = std::make_shared<int>(0);
+        std::weak_ptr<int> wa = ta, wb = tb;
+        eng.HandleChatCompletion(req, watch(a, std::move(ta)));
+        if (round == 0) eng.HandleChatCompletion(req, watch(b, std::move(tb)));   // one worker (n_parallel 1): waits in the queue behind the first
+        else tb.reset();
+        { std::unique_lock<std::mutex> lk(a->mu); CHECK(a->cv.wait_for(lk, std::chrono::seconds(20), [&] { return a->chunks >= 2; })); }
+        Json un = Json::object(); un["model"] = "slow";
+        if (round == 0) {
+            eng.UnloadModel(un, grab);                // joins the workers: both streams have had their last callback when it returns
+            CHECK(code == 200);
+            for (auto &s : {a, b}) {
+                std::lock_guard<std::mutex> lk(s->mu);
+                CHECK(s->terminal == 1 && s->after_terminal == 0);
+                CHECK(s->last_status["has_error"].as_bool() && s->last_status["is_stream"].as_bool() && !s->last_status["is_done"].as_bool());
+                CHECK(s->last_status["status_code"].as_int() == 200 && s->last_body["data"].is_string() && s->last_body["data"].as_string().empty());
+            }
+            { std::lock_guard<std::mutex> lk(b->mu); CHECK(b->chunks == 0); }
+            CHECK(a->chunks < 200);
+            CHECK(wa.expired() && wb.expired());      // nothing holds the callbacks any more
+        } else {
+            eng.StopInferencing("slow");
+            for (int i = 0; i < 2000 && !wa.expired(); i++) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            CHECK(wa.expired());                      // the task ended and let go of its callback ...
+            { std::lock_guard<std::mutex> lk(a->mu); CHECK(a->terminal == 0 && a->chunks < 200); }   // ... without a terminal chunk, as the reference
+            eng.UnloadModel(un, grab);
+            CHECK(code == 200);
+        }
+    }
+}
+
 // `host_tests --tokenize model.gguf cases.json` : tokenizes every string of the JSON array with the GGUF's tokenizer and
 // prints {"ids": [[...], ...], "pieces": [[...], ...], "bos":, "eos":} — compared against HF `tokenizers` by test_host_logic.py
 static int tokenize_cli(const char *gguf, const char *cases) {
@@ -1345,6 +1406,7 @@ int main(int argc, char **argv) {
     STAGE(test_bad_token_ids_and_backend_errors);
     STAGE(test_gguf_hardening);
     STAGE(test_engine);
+    STAGE(test_engine_unload_mid_stream);
     STAGE(test_engine_grammar_requests);
     STAGE(test_embeddings);
     if (g_fail) { printf("%d check(s) failed\n", g_fail); return 1; }

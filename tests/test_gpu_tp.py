@@ -37,21 +37,29 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
-INFRA_SIGNATURES = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "connect() timed out", "rendezvous", "store is not available",
-                    "Broken pipe", "socket", "NCCL", "ProcessGroup")
-NEVER_RETRY = ("bounded wait gave up", "MI355Error", "AssertionError", "assert ", "mismatch", "Traceback (most recent call last):\n  File \"" + os.path.join(ROOT, "tests", "tp_worker.py"))
+# what the test's OWN plumbing leaves behind when it fails: the port taken between _free_port() and the bind, the gloo store / rendezvous timing out.  Nothing
+# broader ("socket", "NCCL", "ProcessGroup", "Broken pipe", "Connection reset": the strings a rank's PEERS print when it segfaults or aborts in product code)
+INFRA_SIGNATURES = ("Address already in use", "EADDRINUSE", "connect() timed out", "store is not available", "Timed out waiting for clients", "DistStoreError")
+PRODUCT_SIGNATURES = ("bounded wait gave up", "MI355Error", "AssertionError", "assert ", "mismatch", "Segmentation fault", "core dumped", "Aborted", "hipError", "HSA_STATUS")
+
+
+class RanksFailed(AssertionError):
+    def __init__(self, msg, returncodes):
+        super().__init__(msg)
+        self.returncodes = list(returncodes)
 
 
 def run_ranks(world, plan_path, out_path, timeout=600):
-    """One process per rank.  A launch is repeated ONCE, and only when its failure carries the signature of the test's own plumbing (a port taken between
-    _free_port() and the bind, the gloo rendezvous) and nothing of the product's: a bounded in-kernel wait that gave up, an MI355Error, an assertion of
-    tp_worker or any wrong number is a result and fails the test at once - a rank that dies from a real intermittent defect gets no second chance.  A retry is
-    reported as a warning, so flakiness stays visible."""
+    """One process per rank.  A launch is repeated ONCE, and only when (1) its output carries the signature of the test's own plumbing (a port taken between
+    _free_port() and the bind, the gloo store timing out), (2) none of the product's (a bounded in-kernel wait that gave up, an MI355Error, an assertion of
+    tp_worker, a device error, any wrong number) and (3) NO rank was ended by a signal: a rank that segfaults or aborts makes its peers print connection
+    errors, and must not buy a second run with them.  A retry is reported as a warning, so flakiness stays visible."""
     try:
         return _run_ranks_once(world, plan_path, out_path, timeout)
-    except AssertionError as e:
+    except RanksFailed as e:
         msg = str(e)
-        if any(k in msg for k in NEVER_RETRY[:5]) or not any(k in msg for k in INFRA_SIGNATURES):
+        by_signal = any(rc is None or rc < 0 for rc in e.returncodes)
+        if by_signal or any(k in msg for k in PRODUCT_SIGNATURES) or not any(k in msg for k in INFRA_SIGNATURES):
             raise
         import warnings
         warnings.warn(f"run_ranks: infrastructure failure, launch repeated once: {msg[-600:]}")
@@ -75,9 +83,14 @@ def _run_ranks_once(world, plan_path, out_path, timeout):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if os.environ.get("MI355_TP_TRACE") == "1":               # diagnosis (tools/r6_tp_coldstart.sh): every rank's [tp trace] lines, passed or not
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "tp_trace_" + os.path.basename(out_path) + ".log"), "a") as f:
+            for r, o in enumerate(outs):
+                f.write(f"==== rank {r} exit {procs[r].returncode}\n" + "\n".join(l for l in o.splitlines() if "[tp trace]" in l or "gave up" in l or "Error" in l) + "\n")
     if any(p.returncode != 0 for p in procs):                 # (a rank that fails takes its peers' exchanges down with it: show every rank's last lines)
         tails = "\n".join(f"---- rank {r} (exit {p.returncode})\n{outs[r][-1500:]}" for r, p in enumerate(procs))
-        raise AssertionError(f"{sum(p.returncode != 0 for p in procs)} of {world} ranks failed:\n{tails}")
+        raise RanksFailed(f"{sum(p.returncode != 0 for p in procs)} of {world} ranks failed:\n{tails}", [p.returncode for p in procs])
     return np.load(out_path)
 
 
@@ -172,7 +185,7 @@ def test_ranks_sharing_one_gpu_match_oracle_and_unsplit(pkg, tmp_models, cfg, ft
             assert int(a.argmax()) == int(b.argmax())
 
 
-@pytest.mark.parametrize("cfg,ftype,kv,world", [("tiny-e2048", "q4_k_m", "q8_0", 2), ("tiny-e2048", "q4_k_m", "q8_0", 4), ("tiny-70b-2l", "q4_k_m", "q8_0", 8)])
+@pytest.mark.parametrize("cfg,ftype,kv,world", [("tiny-e2048", "q4_k_m", "q8_0", 2), ("tiny-8b-2l", "q4_k_m", "q8_0", 2), ("tiny-e2048", "q4_k_m", "q8_0", 4), ("tiny-70b-2l", "q4_k_m", "q8_0", 8)])
 def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg, ftype, kv, world):
     """The one-shot peer-to-peer all-reduce (host/tp_comm.cc: every rank writes its partial into slot `rank` of every rank's IPC-mapped buffer, flags,
     rank-order sum) takes the decode-sized exchanges; the prompt batch and the logits gather keep the host transport.  IPC mapping works between
@@ -198,8 +211,8 @@ def test_peer_to_peer_all_reduce_matches_the_host_exchange(pkg, tmp_models, cfg,
         assert max(rel_err(a, b) for a, b in zip(p2p["logits"], host["logits"])) <= FLIP_TOL
 
 
-@pytest.mark.parametrize("cfg,ftype,kv,world,wgs", [("tiny-e2048", "q4_k_m", "q8_0", 2, 7), ("tiny-e2048", "q4_k_m", "q8_0", 4, 0),
-                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5), ("tiny-70b-2l", "q4_k_m", "q8_0", 8, 0)])
+@pytest.mark.parametrize("cfg,ftype,kv,world,wgs", [("tiny-e2048", "q4_k_m", "q8_0", 2, 0), ("tiny-8b-2l", "q4_k_m", "q8_0", 2, 7), ("tiny-e2048", "q4_k_m", "q8_0", 4, 0),
+                                                    ("tiny-e2048", "q5_k_m", "f16", 4, 5), ("tiny-8b-2l", "q4_k_m", "q8_0", 8, 0), ("tiny-70b-2l", "q4_k_m", "q8_0", 8, 0)])
 def test_prompt_sized_exchange_as_reduce_scatter_all_gather(pkg, tmp_models, cfg, ftype, kv, world, wgs, monkeypatch):
     """Prompt batches: the n_embd x n_ubatch partial sums go through ONE reduce-scatter + all-gather kernel (host/tp_comm.cc p2p_rsag_kernel:
     a segment per rank, every rank stores its part of segment q into rank q's IPC-mapped buffer, the owner adds in rank order and stores the sum

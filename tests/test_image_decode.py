@@ -64,6 +64,48 @@ def test_png_compression_levels_and_sixteen_bit(pkg):
     assert np.array_equal(got[..., 0], (g16 >> 8).astype(np.uint8)) and np.array_equal(got[..., 0], got[..., 2])
 
 
+def _png_from_zlib_stream(rgb: np.ndarray, idat: bytes) -> bytes:
+    """a PNG around a hand-made IDAT stream (filter type 0 rows)"""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    h, w, _ = rgb.shape
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("flush", ["sync", "full"])
+def test_png_with_flushed_streams_mixing_stored_and_huffman_blocks(pkg, flush):
+    """An encoder that flushes (Z_SYNC_FLUSH / Z_FULL_FLUSH) ends a Huffman block and emits an EMPTY STORED block, byte-aligned, in the middle of the stream: the
+    stored block's LEN / NLEN may already sit in the Huffman decoder's look-ahead when the end-of-block code is at most 5 bits long (without the
+    hand-back in inflate_zlib about a quarter of these files are refused).  200 files per flush mode, plus streams that alternate level-0 (stored) and level-9 sections."""
+    import zlib
+    mode = zlib.Z_SYNC_FLUSH if flush == "sync" else zlib.Z_FULL_FLUSH
+    bad = []
+    for i in range(200):
+        rng = np.random.default_rng(1000 + i)
+        a = picture(64, 64, i)
+        a[:48] = a[0, 0]                                     # a flat band: the first section is a few dozen long matches, a code with few symbols, a short end-of-block code
+        raw = b"".join(b"\x00" + a[y].tobytes() for y in range(64))
+        co = zlib.compressobj(9)
+        cut = int(rng.integers(2000, 9000)) if i % 4 else int(rng.integers(1, 400))
+        stream = co.compress(raw[:cut]) + co.flush(mode)
+        if i % 3 == 0:                                       # a second flush further on, and a switch to stored blocks for the tail
+            cut2 = cut + int(rng.integers(1, 3000))
+            stream += co.compress(raw[cut:cut2]) + co.flush(mode)
+            cut = cut2
+        stream += co.compress(raw[cut:]) + co.flush()
+        assert zlib.decompress(stream) == raw
+        try:
+            got = decode(pkg, _png_from_zlib_stream(a, stream))
+        except RuntimeError as e:
+            bad.append((i, str(e)))
+            continue
+        assert np.array_equal(got, a), i
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("fmt,mode", [("BMP", "RGB"), ("PPM", "RGB"), ("PPM", "L")])
 def test_bmp_and_pnm_match_pillow(pkg, fmt, mode):
     im = PIL.fromarray(picture(53, 31, 9)).convert(mode)
