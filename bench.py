@@ -407,6 +407,50 @@ def main() -> int:
         finish_rank(None)
         return 0
 
+    # ---- the same per-role figures measured LIVE in this run: eager single-token steps with one HIP event per role boundary on the
+    # context's stream (mi355_profile_enable / mi355_profile_last_decode), algorithmic weight bytes of each role from the file's type mix.  The event between two
+    # launches costs a little (its own interval is measured on an empty pair and reported: `event_gap_us`, NOT subtracted), so these durations sit slightly above
+    # the rocprofv3 kernel durations; `roles` / `frac_rocprof` (the committed trace) are the cross-check
+    roles_live, frac_live = None, None
+    if world == 1 and cfg.n_expert == 0:
+        gs = pkg.gguf_synth
+        rb = {"qkv": 0, "attn_out": 0, "ffn_gate_up": 0, "ffn_down": 0, "lm_head": 0}
+        for name, ne, t, _ in gs.model_tensors(cfg, args.ftype):
+            nbytes = gs.row_bytes(t, ne[0]) * (int(np.prod(ne)) // ne[0])
+            for key, role in (("attn_q.", "qkv"), ("attn_k.", "qkv"), ("attn_v.", "qkv"), ("attn_output.", "attn_out"), ("ffn_gate.", "ffn_gate_up"), ("ffn_up.", "ffn_gate_up"),
+                              ("ffn_down.", "ffn_down"), ("output.weight", "lm_head")):
+                if key in name and name.endswith("weight"):
+                    rb[role] += nbytes
+        n_prof = 16
+        acc = {}
+        ctx.profile(True)
+        try:
+            pos_p, tok_p = pos, tok
+            for _ in range(n_prof):
+                if pos_p >= args.ctx - 1:
+                    break
+                ctx.decode([tok_p], [pos_p]); tok_p = ctx.argmax(); pos_p += 1
+                for k, v in ctx.last_profile().items():
+                    acc[k] = acc.get(k, 0.0) + v
+            n_done = pos_p - pos
+        finally:
+            ctx.profile(False)
+        if n_done > 0 and all(k in acc for k in ("qkv", "ffn_gate_up", "ffn_down", "lm_head")):
+            L_n = cfg.n_layer
+            roles_live = {}
+            for role, n_l in (("qkv", L_n), ("attn_out", L_n), ("ffn_gate_up", L_n), ("ffn_down", L_n), ("lm_head", 1)):
+                us_tok = (acc.get(role, 0.0) + (acc.get("attn", 0.0) + acc.get("rope_kv", 0.0) if role == "attn_out" else 0.0)) / n_done
+                if us_tok <= 0:
+                    continue
+                roles_live[role] = {"launches_per_token": n_l, "avg_us": round(us_tok / n_l, 3), "us_per_token": round(us_tok, 2), "weight_bytes_per_token": int(rb[role]),
+                                    "GBps": round(rb[role] / (us_tok * 1e-6) / 1e9, 1), "frac_of_8TBps": round(rb[role] / (us_tok * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+            st_b = sum(rb[r] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
+            st_us = sum(roles_live[r]["us_per_token"] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
+            frac_live = round(st_b / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+            roles_live["_note"] = (f"{n_done} eager single-token steps at pos {pos}.., HIP events between the roles on the context's stream; attn_out = rope / KV store + attention + "
+                                   f"attn_output (one launch) with attn_output's weight bytes only; other per-token time: " +
+                                   ", ".join(f"{k} {v / n_done:.1f} us" for k, v in sorted(acc.items()) if k not in ("qkv", "attn", "rope_kv", "attn_out", "ffn_gate_up", "ffn_down", "lm_head")))
+
     # ---- the long-context point of the same config under the SAME contract as the headline (logits row host-visible after every step): context
     # filled to 3968 of 4096, then greedy decode
     long_host = None
@@ -568,6 +612,9 @@ def main() -> int:
             "frac_rocprof": frac_rocprof,
             "frac_rocprof_source": frac_rocprof_note,
             "roles": roles_rocprof,
+            "roles_live": roles_live,
+            "frac_live": frac_live,
+            "frac_live_over_rocprof": round(frac_live / frac_rocprof, 4) if (frac_live and frac_rocprof) else None,
             "traffic": traffic,
             "traffic_source": traffic_note,
             "method": "the step's own launches of the weight-stream kernel (Q|K|V, gate|up, ffn_down of every layer + the output head: 97 for this model; "

@@ -477,7 +477,8 @@ def write_synthetic_llama(path: str, cfg: LlamaConfig | str, ftype: str = "q4_k_
 @dataclass
 class ClipConfig:
     """The vision tower + projector of a LLaVA-1.5 style mmproj file as llama.cpp's convert_image_encoder_to_gguf.py writes it: CLIP ViT (pre-LN, learned position
-    embeddings, class token, quick-GELU MLP) cut after its second-to-last layer (block_count = layers - 1), and the two-layer MLP projector mm.0 / mm.2."""
+    embeddings, class token, quick-GELU MLP) cut after its second-to-last layer (block_count = layers - 1), and the two-layer MLP projector mm.0 / mm.2.
+    clip.cpp then runs block_count - 1 of the file's blocks for a LLaVA projector (get_deepest_feature_layer): the file's last block is dead weight."""
     name: str
     image_size: int
     patch_size: int
@@ -503,21 +504,21 @@ CLIP_CONFIGS = {
     # ViT-L/14-336 as LLaVA-1.5-7B uses it (576 patches -> 576 rows of 4096)
     "clip-vit-l-336": ClipConfig("clip-vit-large-patch14-336", 336, 14, 1024, 16, 4096, 23, 4096),
     # the same graph at test size: 56 x 56 pixels = 16 patches of 14 x 14, head_dim 64 like the real tower (d128: 36 patches, 4 heads, 3 blocks)
-    "tiny-clip": ClipConfig("tiny-clip", 56, 14, 128, 2, 256, 2, 256),
-    "tiny-clip-d128": ClipConfig("tiny-clip-d128", 84, 14, 256, 4, 512, 3, 512),
+    "tiny-clip": ClipConfig("tiny-clip", 56, 14, 128, 2, 256, 3, 256),
+    "tiny-clip-d128": ClipConfig("tiny-clip-d128", 84, 14, 256, 4, 512, 4, 512),
     # head size 128 at the real tower's 577 rows (the tiled attention's largest LDS footprint: 157 KB)
     "clip-d128-336": ClipConfig("clip-d128-336", 336, 14, 256, 2, 512, 2, 256),
-    "tiny-clip-gelu": ClipConfig("tiny-clip-gelu", 56, 14, 128, 2, 256, 2, 4096, use_gelu=True),
+    "tiny-clip-gelu": ClipConfig("tiny-clip-gelu", 56, 14, 128, 2, 256, 3, 4096, use_gelu=True),
     # a projector as wide as the tiny language models of the engine tests (n_embd 1024): 16 rows per image
-    "tiny-clip-1024": ClipConfig("tiny-clip-1024", 56, 14, 128, 2, 256, 2, 1024),
+    "tiny-clip-1024": ClipConfig("tiny-clip-1024", 56, 14, 128, 2, 256, 3, 1024),
     # LLaVA-1.6: ViT-L/14-336 with the image grid of llava-v1.6 (an overview + up to four tiles: 2880 rows a picture), and the same at test size
     "clip-vit-l-336-grid": ClipConfig("llava-v1.6-clip", 336, 14, 1024, 16, 4096, 23, 4096, pinpoints=(336, 672, 672, 336, 672, 672, 1008, 336, 336, 1008),
                                       merge_type="spatial_unpad"),
-    "tiny-clip-grid": ClipConfig("tiny-clip-grid", 56, 14, 128, 2, 256, 2, 256, pinpoints=(56, 112, 112, 56, 112, 112, 168, 56, 56, 168), merge_type="spatial_unpad"),
-    "tiny-clip-grid-1024": ClipConfig("tiny-clip-grid-1024", 56, 14, 128, 2, 256, 2, 1024, pinpoints=(56, 112, 112, 56, 112, 112, 168, 56, 56, 168),
+    "tiny-clip-grid": ClipConfig("tiny-clip-grid", 56, 14, 128, 2, 256, 3, 256, pinpoints=(56, 112, 112, 56, 112, 112, 168, 56, 56, 168), merge_type="spatial_unpad"),
+    "tiny-clip-grid-1024": ClipConfig("tiny-clip-grid-1024", 56, 14, 128, 2, 256, 3, 1024, pinpoints=(56, 112, 112, 56, 112, 112, 168, 56, 56, 168),
                                       merge_type="spatial_unpad"),
     # a grid in the file but the merge type "flat": only the overview is encoded
-    "tiny-clip-grid-flat": ClipConfig("tiny-clip-grid-flat", 56, 14, 128, 2, 256, 2, 256, pinpoints=(56, 112, 112, 56, 112, 112), merge_type="flat"),
+    "tiny-clip-grid-flat": ClipConfig("tiny-clip-grid-flat", 56, 14, 128, 2, 256, 3, 256, pinpoints=(56, 112, 112, 56, 112, 112), merge_type="flat"),
 }
 
 

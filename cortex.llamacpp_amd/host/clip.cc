@@ -336,7 +336,11 @@ std::string ClipModel::encode_batch(const float *img, int n, float *out, int gri
     for (int i = 0; i < n; i++) CLIP_TRY(launch_clip_embed(d_pe_ + (size_t)i * NP * E, class_, pos_, E, T1, d_emb_ + (size_t)i * T1 * E, st));
     CLIP_TRY(launch_layer_norm(d_emb_, pre_w_, pre_b_, E, T, eps, d_emb_, st));
     const float qs = 1.0f / sqrtf((float)D);
-    for (int il = 0; il < n_layer; il++) {
+    // clip.cpp runs the tower up to the feature layer a LLaVA projector reads: block_count - 1 blocks (get_deepest_feature_layer: `hparams.n_layer - 1`, + 1
+    // only for the minicpmv / glm / qwen2vl projectors).  The converter has already dropped the tower's last block and written block_count = layers - 1, so of a
+    // ViT-L/14-336's 24 blocks the file holds 23 and 22 run; the file's last block is loaded and unused, as upstream.  (Rounds 4-5 ran all of the file's blocks.)
+    const int n_run = n_layer - 1;
+    for (int il = 0; il < n_run; il++) {
         const ClipLayerDev &L = layers_[(size_t)il];
         CLIP_TRY(launch_layer_norm_h(d_emb_, L.ln1w, L.ln1b, E, T, eps, d_cur_, h, st));
         CLIP_TRY(proj(L.wq, L.bq, E, E, d_cur_, true, T, d_q_, qs, true, nullptr, nullptr));

@@ -1376,7 +1376,11 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             if (fused_step) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch - and, where attn_out.hip has a form for the shape,
                 // the attn_output mat-vec with its residual add in that launch too
-                if (attn_mode == 2 && !engine && il < 255 && !attn_out_off_) {
+                // (not where the ranks of a row split exchange through the host callback - the transport of a rig whose ranks SHARE one device: this kernel's
+                // workgroups wait for each other (consumers for the item workgroups' flags), and two processes' copies placed on the same CUs at the same time can
+                // hold each other's item workgroups out - every wait then runs into its bound (round 6: 0x8 on three of eight ranks behind one MI355X at the first
+                // single-token step, profiles/r6_tp_shared_device_trace.txt).  A rank that owns its GPU has the chip to itself.)
+                if (attn_mode == 2 && !engine && il < 255 && !attn_out_off_ && !(tp && tp_uses_host())) {
                     const bool add = !tp || hp.tp_rank == 0;
                     const MMVQSeg so = make_seg(L.wo, tp ? tp_part_ : x_, E, add ? x_ : nullptr, nullptr);
                     AttnArgs af = aa;

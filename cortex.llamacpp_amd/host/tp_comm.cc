@@ -41,7 +41,10 @@ Group g_grp;
 std::mutex g_mu;
 
 // ---- peer-to-peer exchange state (see tp_comm.h)
-constexpr int P2P_MAX_RANKS = 8, P2P_WGS = 16, P2P_SPIN_LIMIT = 1 << 22;
+constexpr int P2P_MAX_RANKS = 8, P2P_WGS = 16;
+// A wait for a PEER is bounded in time, not in polls (the 100 MHz wall clock every process on the device shares): ranks reach an exchange together because one
+// driver steps them in lock-step, so seconds of skew mean a dead peer - but a poll count meant 1.4 s or 4 s depending on what else used the memory system
+constexpr unsigned long long P2P_WAIT_TICKS = 10ull * 100000000ull;      // 10 s
 constexpr int RSAG_MAX_WGS = 256;      // flag rows are laid out for this many slices; the launch uses g_p2p.rsag_wgs of them
 struct P2PDev {                        // by value into the kernel
     float *data[P2P_MAX_RANKS];        // base of every rank's slot area: [2 sets][P slots][max_floats]
@@ -99,9 +102,10 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
     // 2. everybody's slice w has arrived in MY buffer once my P flags of this set carry e
     if (tid < P) {
         const unsigned *f = a.flags[a.rank] + (set * (size_t)P + (size_t)tid) * P2P_WGS + w;
+        const unsigned long long t0 = wall_clock64();
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            if (++spins >= P2P_SPIN_LIMIT) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if ((++spins & 255) == 0 && wall_clock64() - t0 > P2P_WAIT_TICKS) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
@@ -147,9 +151,10 @@ __device__ __forceinline__ void rsag_signal_and_wait(const P2PDev &a, size_t set
     if (tid < P && tid != a.rank) {
         __hip_atomic_store(a.bflags[tid] + (row + (size_t)a.rank) * RSAG_MAX_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned *f = a.bflags[a.rank] + (row + (size_t)tid) * RSAG_MAX_WGS + w;
+        const unsigned long long t0 = wall_clock64();
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            if (++spins >= P2P_SPIN_LIMIT) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if ((++spins & 255) == 0 && wall_clock64() - t0 > P2P_WAIT_TICKS) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }

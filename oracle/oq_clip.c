@@ -390,7 +390,8 @@ int oq_clip_encode(const oq_clip *c, const float *img, float *out, int nth) {
     }
     ln_rows(emb, emb, E, T, c->eps, c->pre_ln_w, c->pre_ln_b);
     const float qs = 1.0f / sqrtf((float)D);
-    for (int il = 0; il < c->n_layer; il++) {
+    /* clip.cpp: a LLaVA projector reads the output of block_count - 1 blocks (get_deepest_feature_layer); the file's last block stays unused */
+    for (int il = 0; il < c->n_layer - 1; il++) {
         const clayer *L = &c->layers[il];
         ln_rows(emb, cur, E, T, c->eps, L->ln1w, L->ln1b);
         lin(L->wq, L->bq, cur, T, q, nth);

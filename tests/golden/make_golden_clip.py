@@ -137,7 +137,7 @@ def encode(t, kv, img):
     emb = np.concatenate([t["v.class_embd"].astype(np.float64)[None, :], h16(patches) @ wpe.T], 0)
     emb = emb + t["v.position_embd.weight"].astype(np.float64)
     emb = ln(emb, "v.pre_ln.weight", "v.pre_ln.bias")
-    for il in range(NL):
+    for il in range(NL - 1):                                             # clip.cpp: block_count - 1 blocks feed a LLaVA projector (the file's last block is unused)
         p = f"v.blk.{il}."
         cur = ln(emb, p + "ln1.weight", p + "ln1.bias")
         q = lin(cur, p + "attn_q.weight", p + "attn_q.bias") * (1.0 / np.sqrt(np.float32(D)))

@@ -244,6 +244,18 @@ def test_prompt_sized_exchange_as_reduce_scatter_all_gather(pkg, tmp_models, cfg
         assert max(rel_err(a, b) for a, b in zip(rs["logits"], host["logits"])) <= FLIP_TOL
 
 
+def test_eight_rank_reduce_scatter_case_in_a_fresh_process():
+    """The 8-rank reduce-scatter + all-gather case as the FIRST and ONLY multi-rank test of its own pytest process: its colour must not depend on what ran
+    before it (it was red whenever it ran alone - cold box or warm - and green in file order).  Round 6 found two causes, neither in the exchange kernel:
+    the ranks of this rig reached their first exchange seconds apart (nothing stepped them in lock-step: tests/tp_worker.py now meets at a barrier, as a row
+    split's driver does), and the one-launch attention + attn_output kernel - workgroups that wait for each other - ran in eight processes on ONE device
+    (host/runtime.cc keeps it off now where the ranks exchange through the host callback, i.e. share a device).  profiles/r6_tp_shared_device_trace.txt."""
+    case = "tests/test_gpu_tp.py::test_prompt_sized_exchange_as_reduce_scatter_all_gather[tiny-70b-2l-q4_k_m-q8_0-8-0]"
+    r = subprocess.run([sys.executable, "-m", "pytest", case, "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
+    assert "1 passed" in r.stdout
+
+
 def test_rccl_group_of_one_captured_in_graphs_is_bit_identical(pkg, tmp_models):
     pkg.Backend()
     path, plan_path, ref = make_plan(pkg, tmp_models, "tiny-e2048", "q4_k_m", "q8_0", 8, "rccl", n_steps=12)

@@ -33,6 +33,11 @@ def main():
     ctx = pkg.Context(model, n_ctx=int(plan["n_ctx"]), type_k=int(plan["kv"]), type_v=int(plan["kv"]), n_ubatch=int(plan["n_ubatch"]))
     rows = []
     prompt = plan["prompt"]
+    if world > 1:
+        # what a row split's driver provides in production: the ranks are stepped in lock-step (rank 0 hands every rank the batch), so they reach an exchange
+        # together.  Eight python processes that each import torch, load a shard and build a context on one shared box are SECONDS apart at their first batch
+        # (round 6 trace: 3.5 s) - more than an in-kernel wait for a peer should ever sit out
+        dist.barrier()
     ctx.enable_taps(True)                          # residual stream after every layer, for the prompt
     assert ctx.decode(prompt, np.arange(prompt.size)) == 0
     rows.append(ctx.logits())
