@@ -408,17 +408,21 @@ def main() -> int:
         return 0
 
     # ---- the same per-role figures measured LIVE in this run: eager single-token steps with one HIP event per role boundary on the
-    # context's stream (mi355_profile_enable / mi355_profile_last_decode), algorithmic weight bytes of each role from the file's type mix.  The event between two
-    # launches costs a little (its own interval is measured on an empty pair and reported: `event_gap_us`, NOT subtracted), so these durations sit slightly above
-    # the rocprofv3 kernel durations; `roles` / `frac_rocprof` (the committed trace) are the cross-check
+    # context's stream (mi355_profile_enable / mi355_profile_last_decode) AND, for the weight-stream and attention launches, the dispatch's own begin / end
+    # timestamps (hipExtLaunchKernelGGL start / stop events, host/runtime.cc KTimer): the latter is the quantity rocprofv3's kernel trace reports and is what
+    # `roles_live` / `frac_live` are computed from; the event intervals (which include the marker's cost and the launch boundary) are kept beside them.
+    # `roles` / `frac_rocprof` (the committed trace) are the cross-check
     roles_live, frac_live = None, None
     if world == 1 and cfg.n_expert == 0:
         gs = pkg.gguf_synth
         rb = {"qkv": 0, "attn_out": 0, "ffn_gate_up": 0, "ffn_down": 0, "lm_head": 0}
         for name, ne, t, _ in gs.model_tensors(cfg, args.ftype):
             nbytes = gs.row_bytes(t, ne[0]) * (int(np.prod(ne)) // ne[0])
-            for key, role in (("attn_q.", "qkv"), ("attn_k.", "qkv"), ("attn_v.", "qkv"), ("attn_output.", "attn_out"), ("ffn_gate.", "ffn_gate_up"), ("ffn_up.", "ffn_gate_up"),
-                              ("ffn_down.", "ffn_down"), ("output.weight", "lm_head")):
+            if name == "output.weight":
+                rb["lm_head"] += nbytes
+                continue
+            for key, role in ((".attn_q.", "qkv"), (".attn_k.", "qkv"), (".attn_v.", "qkv"), (".attn_output.", "attn_out"), (".ffn_gate.", "ffn_gate_up"), (".ffn_up.", "ffn_gate_up"),
+                              (".ffn_down.", "ffn_down")):
                 if key in name and name.endswith("weight"):
                     rb[role] += nbytes
         n_prof = 16
@@ -435,6 +439,11 @@ def main() -> int:
             n_done = pos_p - pos
         finally:
             ctx.profile(False)
+        # kernel begin / end timestamps of the stream and attention launches themselves ("k:<role>" = us, "n:<role>" = launches; hipExtLaunchKernelGGL's start / stop
+        # events: what rocprofv3's kernel trace reports, no marker between two launches involved)
+        kroles = {"qkv": "qkv", "gate_up": "ffn_gate_up", "ffn_down": "ffn_down", "head": "lm_head", "attn_out": "attn_out"}
+        kernel_us = {kroles[k[2:]]: v / n_done for k, v in acc.items() if k.startswith("k:") and k[2:] in kroles} if n_done > 0 else {}
+        kernel_n = {kroles[k[2:]]: v / n_done for k, v in acc.items() if k.startswith("n:") and k[2:] in kroles} if n_done > 0 else {}
         if n_done > 0 and all(k in acc for k in ("qkv", "ffn_gate_up", "ffn_down", "lm_head")):
             L_n = cfg.n_layer
             roles_live = {}
@@ -442,8 +451,13 @@ def main() -> int:
                 us_tok = (acc.get(role, 0.0) + (acc.get("attn", 0.0) + acc.get("rope_kv", 0.0) if role == "attn_out" else 0.0)) / n_done
                 if us_tok <= 0:
                     continue
+                ev_us = us_tok                            # interval between the role's HIP events (includes the marker's own cost and the launch boundary)
+                if role in kernel_us and kernel_us[role] > 0:
+                    us_tok = kernel_us[role]              # the kernels' own durations
                 roles_live[role] = {"launches_per_token": n_l, "avg_us": round(us_tok / n_l, 3), "us_per_token": round(us_tok, 2), "weight_bytes_per_token": int(rb[role]),
-                                    "GBps": round(rb[role] / (us_tok * 1e-6) / 1e9, 1), "frac_of_8TBps": round(rb[role] / (us_tok * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+                                    "GBps": round(rb[role] / (us_tok * 1e-6) / 1e9, 1), "frac_of_8TBps": round(rb[role] / (us_tok * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                                    "source": "kernel begin/end timestamps" if role in kernel_us else "HIP event interval", "event_interval_us_per_token": round(ev_us, 2),
+                                    "timed_launches_per_token": round(kernel_n.get(role, 0.0), 2)}
             st_b = sum(rb[r] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
             st_us = sum(roles_live[r]["us_per_token"] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
             frac_live = round(st_b / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)

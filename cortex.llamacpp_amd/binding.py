@@ -150,6 +150,7 @@ SYMBOLS = {
     "mi355_tp_unique_id": (C.c_int, [_vp, _sz]),
     "mi355_tp_init": (C.c_int, [_i32, _i32, _i32, _vp, _sz]),
     "mi355_tp_shutdown": (None, []),
+    "mi355_tp_worker_main": (C.c_int, [C.c_int]),
     "mi355_tp_rank": (_i32, []),
     "mi355_tp_size": (_i32, []),
     "mi355_tp_set_host_exchange": (C.c_int, [_vp, _vp, _i32, _i32]),

@@ -19,12 +19,13 @@ SRC = [
     "csrc/mmvq.hip", "csrc/mmvq_fast.hip", "csrc/mmvq_stream.hip", "csrc/mmq.hip", "csrc/mmq_q80.hip", "csrc/act.hip", "csrc/misc.hip", "csrc/mmf.hip", "csrc/attn.hip", "csrc/attn_out.hip", "csrc/attn_prefill.hip", "csrc/clip.hip",
 ] + (["csrc/decode_engine.hip", "csrc/decode_mega.hip"] if EXPERIMENTS else ["csrc/experiments_absent.cc"]) + [
     "host/gguf.cc", "host/runtime.cc", "host/tp_comm.cc", "host/vocab.cc", "host/sampling.cc", "host/grammar.cc", "host/json_schema.cc", "host/log.cc", "host/server_context.cc", "host/engine.cc",
-    "host/hip_backend.cc", "host/clip.cc", "host/image_decode.cc", "csrc/c_api.cc",
+    "host/hip_backend.cc", "host/tp_split.cc", "host/clip.cc", "host/image_decode.cc", "csrc/c_api.cc",
 ]
 HDRS = ["csrc/dev_common.h", "csrc/kernels.h", "csrc/quant_dev.h", "csrc/mmvq_fast_dev.h", "csrc/mmvq_stream_dev.h", "csrc/attn_decode_dev.h", "host/gguf.h", "host/runtime.h", "host/tp_comm.h", "host/json.h", "host/vocab.h",
-        "host/sampling.h", "host/grammar.h", "host/log.h", "host/backend_iface.h", "host/server_context.h", "host/engine.h", "host/hip_backend.h", "host/clip.h", "host/parallel_rows.h",
+        "host/sampling.h", "host/grammar.h", "host/log.h", "host/backend_iface.h", "host/server_context.h", "host/engine.h", "host/hip_backend.h", "host/clip.h", "host/parallel_rows.h", "host/tp_split.h", "host/shm_exchange.h",
         "../include/mi355_llama.h"]
 LIB = os.path.join(HERE, "lib", "libmi355_llama.so")
+TP_WORKER = os.path.join(HERE, "bin", "mi355_tp_worker")  # a further rank of an engine-formed row split (server/mi355_tp_worker.cc; started by host/tp_split.cc)
 SERVER = os.path.join(HERE, "bin", "mi355_server")          # the HTTP host: plain C++, dlopen()s LIB at run time (server/mi355_server.cc)
 # -ffp-contract=off: the CPU restatement this backend is checked against does not fuse mul+add
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
@@ -97,6 +98,12 @@ def build_server(force: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"server build failed:\n{r.stderr}")
+    wsrc = os.path.join(HERE, "server", "mi355_tp_worker.cc")
+    if force or not os.path.exists(TP_WORKER) or os.path.getmtime(TP_WORKER) < os.path.getmtime(wsrc):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", wsrc, "-o", TP_WORKER, "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"worker build failed:\n{r.stderr}")
     return SERVER
 
 

@@ -762,7 +762,10 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
         const size_t lds = ao_layout(o.slice_lds, K, sizeof(AOSmem<RR, CC>)).total;                                                            \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_out_kernel<RR, TK, TV, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                                         \
-        hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);                  \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                                             \
+        if (kernel_timer() && kernel_timer()->next("attn_out", &ev0_, &ev1_))                                                                  \
+            hipExtLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o); \
+        else hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);             \
     } while (0)
 #define AO_C(RR, TK, TV) do { if (C == 64) AO_LAUNCH(RR, TK, TV, 64); else AO_LAUNCH(RR, TK, TV, 128); } while (0)
 #define AO_T(RR) do { if (a.type_k == T_F16) AO_C(RR, T_F16, T_F16); else AO_C(RR, T_Q8_0, T_Q8_0); } while (0)

@@ -17,6 +17,7 @@
 #include "../host/log.h"
 #include "../host/runtime.h"
 #include "../host/tp_comm.h"
+#include "../host/tp_split.h"
 #include "../host/vocab.h"
 
 namespace mi355 {
@@ -876,6 +877,15 @@ int mi355_tp_init(int32_t device, int32_t rank, int32_t size, const void *id, si
     return MI355_OK;
 }
 void mi355_tp_shutdown(void) { tp_shutdown(); }
+int mi355_tp_worker_main(int sock_fd) {
+    try {
+        if (!g_backend_ok && mi355_backend_init() != MI355_OK) return 66;
+        return tp_split_worker_main(sock_fd);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "mi355_tp_worker: %s\n", e.what());
+        return 70;
+    } catch (...) { return 70; }
+}
 int32_t mi355_tp_rank(void) { return tp_rank(); }
 int32_t mi355_tp_size(void) { return tp_size(); }
 int mi355_tp_set_host_exchange(mi355_tp_host_exchange fn, void *user, int32_t rank, int32_t size) {

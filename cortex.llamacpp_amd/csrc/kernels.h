@@ -78,6 +78,15 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st);
 void mmvq_stream_plan(MMVQArgs &a, int blocks);
 // the sticky error word of the weight-stream kernels (pinned host memory, or nullptr): a bounded wait that gives up ORs a code into it
 void mmvq_stream_set_error_word(unsigned *w);
+// Measurement aid (bench.py `roles_live`): while a timer is set, every launch of the weight-stream kernel and of the attention + attn_output kernel is made with
+// hipExtLaunchKernelGGL's start / stop events - the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports - taken from the timer by role
+// ("qkv", "gate_up", "ffn_down", "head", "stream" for any other shape, "attn_out").  Process-wide and not synchronised: set it around a profiled step only.
+struct KernelTimer {
+    virtual ~KernelTimer() = default;
+    virtual bool next(const char *role, hipEvent_t *start, hipEvent_t *stop) = 0;     // false: launch untimed
+};
+void set_kernel_timer(KernelTimer *t);
+KernelTimer *kernel_timer();
 
 // the two experiment translation units below (decode_engine.hip, decode_mega.hip) are in this library (build.py, MI355_BUILD_EXPERIMENTS=1); false: experiments_absent.cc
 bool experiments_built();

@@ -259,6 +259,9 @@ void mmvq_stream_plan(MMVQArgs &a, int max_blocks) {
 // tools/exp_stream.hip ONLY: dispatch without the barrier behind the previous launch of the stream.  Nothing makes a launch wait for the
 // results of its predecessor then - the harness uses it to price what overlapping a launch's ramp with its predecessor's tail could gain
 // at most (the numbers it computes that way are garbage).
+static KernelTimer *g_kernel_timer = nullptr;
+void set_kernel_timer(KernelTimer *t) { g_kernel_timer = t; }
+KernelTimer *kernel_timer() { return g_kernel_timer; }
 static bool g_stream_anyorder = false;
 void mmvq_stream_set_anyorder_for_timing(bool on) { g_stream_anyorder = on; }
 
@@ -309,6 +312,8 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         else if (a.fuse_mode == 1 && a.epi == EPI_STORE && a.n_seg == 1 && a.seg[0].n_rows >= 16384) role = ROLE_HEAD;
         else if (a.fuse_mode == 2 && a.epi == EPI_ADD && a.n_seg == 1) role = ROLE_DOWN;
     }
+    const char *const role_name = role == ROLE_QKV ? "qkv" : role == ROLE_GATE_UP ? "gate_up" : role == ROLE_DOWN ? "ffn_down" : role == ROLE_HEAD ? "head" : "stream";
+    (void)role_name;
     // the stream-bound roles start their stream from preloaded geometry where the packing fits (stream_body_fast)
     static const bool fast_off = getenv("MI355_STREAM_FAST_START") && getenv("MI355_STREAM_FAST_START")[0] == '0';
     const StFast fp = (role == ROLE_GATE_UP || role == ROLE_HEAD) && !fast_off && !g_stream_anyorder ? st_fast_pack(a, blocks) : StFast{};
@@ -318,7 +323,9 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         /* (per launch: the attribute is per device, and a process may hold contexts on several) */                      \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<KBV, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                   \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                       \
         if (g_stream_anyorder) hipExtLaunchKernelGGL((KERNEL<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, a); \
+        else if (g_kernel_timer && g_kernel_timer->next(role_name, &ev0_, &ev1_)) hipExtLaunchKernelGGL((KERNEL<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, ev0_, ev1_, 0, a); \
         else hipLaunchKernelGGL((KERNEL<KBV, FZ>), dim3(blocks), dim3(ST_NT), lds, st, a);                              \
     } while (0)
     // (one macro per prologue form, so that only the kernels a form can take are instantiated)
@@ -327,7 +334,10 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     do {                                                                                                                 \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<KBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                   \
-        hipLaunchKernelGGL((KERNEL<KBV>), dim3(blocks), dim3(ST_NT), lds, st, fp.nx, fp.wbase, fp.ow0, fp.ow1, fp.ow2, fp.onw, fp.kf, fp.sg0, fp.sg1, fp.sg2, fp.rb01, fp.rb2, a); \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                       \
+        if (g_kernel_timer && g_kernel_timer->next(role_name, &ev0_, &ev1_))                                             \
+            hipExtLaunchKernelGGL((KERNEL<KBV>), dim3(blocks), dim3(ST_NT), lds, st, ev0_, ev1_, 0, fp.nx, fp.wbase, fp.ow0, fp.ow1, fp.ow2, fp.onw, fp.kf, fp.sg0, fp.sg1, fp.sg2, fp.rb01, fp.rb2, a); \
+        else hipLaunchKernelGGL((KERNEL<KBV>), dim3(blocks), dim3(ST_NT), lds, st, fp.nx, fp.wbase, fp.ow0, fp.ow1, fp.ow2, fp.onw, fp.kf, fp.sg0, fp.sg1, fp.sg2, fp.rb01, fp.rb2, a); \
     } while (0)
 #define STREAM1(KBV)                                                                                                     \
     do {                                                                                                                 \

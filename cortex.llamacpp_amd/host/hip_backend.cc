@@ -15,6 +15,7 @@
 #include "../csrc/dev_common.h"
 #include "gguf.h"
 #include "runtime.h"
+#include "tp_split.h"
 
 namespace mi355 {
 namespace {
@@ -139,6 +140,8 @@ int cache_type_from_str(const std::string &s) {   // llama_engine.cc:29-55 (IsVa
 }  // namespace
 
 std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, std::string &err) {
+    // "split_mode": "row" - this process becomes rank 0 of a row split it forms itself (tp_split.cc); the shard it loads comes back through here without the key
+    if (tp_split_requested(body)) return make_split_backend(body, info, err);
     std::string path = body.value<std::string>("llama_model_path", "");
     if (path.empty()) path = body.value<std::string>("model_path", "");
     if (path.empty()) { err = "Missing model path in request"; return nullptr; }

@@ -2,6 +2,8 @@
 // (op order of upstream llm_build_llama / build_attn / build_ffn / build_moe_ffn).
 // Reference caller: LlamaServerContext::UpdateSlots -> llama_decode (src/llama_server_context.cc:1628-1635).
 #include "runtime.h"
+
+#include <dlfcn.h>
 #include "tp_comm.h"
 
 #include <algorithm>
@@ -443,7 +445,25 @@ Model *model_load(const std::string &path, int main_gpu, std::string &err, int &
 // ------------------------------------------------------------------------------------------ context
 Context::Context(Model *m, const ContextParams &p) : model(m), cp(p) {}
 
+// the dispatches' own begin / end timestamps, by role (kernels.h KernelTimer): events are created on demand and reused from step to step
+struct Context::KTimer : KernelTimer {
+    struct Rec { const char *role; hipEvent_t a, b; };
+    std::vector<Rec> pool;
+    size_t used = 0;
+    bool next(const char *role, hipEvent_t *start, hipEvent_t *stop) override {
+        if (used == pool.size()) {
+            Rec r{role, nullptr, nullptr};
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
+            pool.push_back(r);
+        }
+        Rec &r = pool[used++];
+        r.role = role; *start = r.a; *stop = r.b;
+        return true;
+    }
+    ~KTimer() override { for (auto &r : pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); } }
+};
 Context::~Context() {
+    if (ktimer_) { if (kernel_timer() == ktimer_) set_kernel_timer(nullptr); delete ktimer_; ktimer_ = nullptr; }
     attn_probe_report();
     attn_out_probe_report();
     if (d_engine_probe_) {                                     // diagnosis: time line of the probed layer's last engine launch
@@ -822,6 +842,9 @@ void Context::prof_begin() {
     if (!profile_) return;
     for (auto &pe : prof_events_) (void)hipEventDestroy(pe.second);
     prof_events_.clear();
+    if (!ktimer_) ktimer_ = new KTimer;
+    ktimer_->used = 0;
+    set_kernel_timer(ktimer_);
     prof_mark("begin");
 }
 void Context::prof_mark(const char *name) {
@@ -833,8 +856,21 @@ void Context::prof_mark(const char *name) {
 }
 void Context::prof_end() {
     if (!profile_) return;
+    set_kernel_timer(nullptr);
     (void)hipStreamSynchronize(stream_);
     last_profile_.clear();
+    if (ktimer_) {     // "k:<role>" = sum of the role's kernel durations in this step, "n:<role>" = its launches
+        for (size_t i = 0; i < ktimer_->used; i++) {
+            const KTimer::Rec &r = ktimer_->pool[i];
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+            const std::string kn = std::string("k:") + r.role, nn = std::string("n:") + r.role;
+            bool fk = false, fn = false;
+            for (auto &e : last_profile_) { if (e.name == kn) { e.us += ms * 1000.0f; fk = true; } else if (e.name == nn) { e.us += 1.0f; fn = true; } }
+            if (!fk) last_profile_.push_back({kn, ms * 1000.0f});
+            if (!fn) last_profile_.push_back({nn, 1.0f});
+        }
+    }
     for (size_t i = 1; i < prof_events_.size(); i++) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, prof_events_[i - 1].second, prof_events_[i].second);
@@ -1904,9 +1940,44 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
     return 0;
 }
 
+// GPU-side trace ranges (tracing row): with MI355_ROCTX=1 every decode call is a roctx range - "mi355_decode prompt n=512" / "mi355_decode step
+// n=1" - so a rocprofv3 --marker-trace run shows where the batches begin and end between the kernels.  The marker library is looked up at run time
+// (librocprofiler-sdk-roctx, then the legacy libroctx64); absent or switched off, a range costs one branch.
+namespace {
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char *ev = getenv("MI355_ROCTX");
+        if (!ev || ev[0] != '1') return;
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+struct TraceRange {
+    static RoctxApi &api() { static RoctxApi a; return a; }
+    bool on = false;
+    TraceRange(const char *what, int n) {
+        if (!api().push) return;
+        char buf[96];
+        snprintf(buf, sizeof buf, "mi355_decode %s n=%d", what, n);
+        api().push(buf);
+        on = true;
+    }
+    ~TraceRange() { if (on) api().pop(); }
+};
+}  // namespace
+
 int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, const int32_t *n_seq_id, int32_t *const *seq_id,
                     const int8_t *logits_flags, const float *embd) {
     if (n_tokens <= 0) { last_error = "empty batch"; return -1; }
+    const TraceRange trace_range(embd ? "embeddings" : n_tokens == 1 ? "step" : n_tokens <= 64 ? "steps" : "prompt", n_tokens);
     // llama_batch.embd: the rows ARE the layer stack's input (the image embeddings of a LLaVA request, llama_server_context.cc:1093-1107); no token ids then
     std::vector<int32_t> no_tokens;
     if (embd) {

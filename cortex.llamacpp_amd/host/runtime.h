@@ -283,6 +283,8 @@ class Context {
     bool profile_ = false;
     std::vector<std::pair<std::string, hipEvent_t>> prof_events_;
     std::vector<ProfileEntry> last_profile_;
+    struct KTimer;                                     // profile mode: per-kernel begin / end events of the stream and attention launches (set_kernel_timer)
+    KTimer *ktimer_ = nullptr;
     int n_kv_ = 0;
 };
 

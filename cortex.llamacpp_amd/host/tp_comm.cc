@@ -58,6 +58,14 @@ struct P2PDev {                        // by value into the kernel
     unsigned *bflags[P2P_MAX_RANKS];   // [2 sets][2 phases][P][RSAG_MAX_WGS]
     unsigned *bepoch;                  // private [RSAG_MAX_WGS]
     size_t seg_max;                    // floats per segment slot (a multiple of 4)
+    // "yield" form (ranks that SHARE a device - the host-callback rigs - or MI355_TP_YIELD=1): a wait for a peer gives up after yield_polls polls, the workgroup
+    // notes how far it got (state[w]: 0 fresh, 1 = its part is out and signalled, 2 = reduce-scatter: its reduced segment is out and signalled), counts itself in
+    // *pending and ENDS; the host re-enqueues the kernel until nothing is pending.  A kernel that spins for a peer holds the device, and whether another
+    // process's kernel gets in beside it is the hardware scheduler's decision (round 6: eight processes behind one MI355X went eight for ten into the wait's
+    // bound, profiles/r6_tp_shared_device_trace.txt) - a launch that ends lets everybody run.  yield_polls == 0: one launch, waits bounded in time (production).
+    unsigned *state;                   // [P2P_WGS + RSAG_MAX_WGS] resume states (this rank's private memory)
+    unsigned *pending;                 // pinned host word: workgroups of the current launch that left unfinished
+    int yield_polls;
     unsigned long long *trace;         // nullable (MI355_TP_TRACE=1): per launch of either kernel 4 stamps of the 100 MHz wall clock, written by workgroup 0
     unsigned trace_slot;               // ... at trace[4 * trace_slot ..]: entered, own flags out, first wait over, done
 };
@@ -71,6 +79,7 @@ struct P2PState {
     int64_t exchanges = 0;
     size_t big_off = 0, bflags_off = 0, prompt_floats = 0;
     unsigned *bepoch = nullptr;
+    unsigned *state = nullptr, *pending = nullptr;      // the yield form's resume states (device) and its pending word (pinned host)
     bool prompt_on = false;
     int rsag_wgs = 64;
     int64_t prompt_exchanges = 0;
@@ -78,38 +87,57 @@ struct P2PState {
 };
 P2PState g_p2p;
 
-// one workgroup = one slice of the message, start to finish: no device-wide step inside the kernel
-__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, float *recv, int n, const P2PDev a) {
-    __shared__ unsigned e_sh;
-    const int tid = (int)threadIdx.x, w = (int)blockIdx.x, P = a.size;
-    if (tid == 0) e_sh = a.epoch[w] + 1u;
-    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
+// a wait for the P flags `f(q)` of this workgroup to carry e: true when they all do.  yield_polls > 0: gives up after that many polls (the caller ends the
+// launch); else bounded in time, and the error word is raised when the bound runs out (the caller goes on: what it computes is discarded with the step)
+template <class F>
+__device__ __forceinline__ bool p2p_wait_flags(const P2PDev &a, unsigned e, F flag_of) {
+    __shared__ int gave_up;
+    const int tid = (int)threadIdx.x, P = a.size;
+    if (tid == 0) gave_up = 0;
     __syncthreads();
-    const unsigned e = e_sh;
-    const size_t set = e & 1u;
-    const int per = (((n + 3) / 4 + (int)gridDim.x - 1) / (int)gridDim.x) * 4;
-    const int lo = w * per, hi = lo + per < n ? lo + per : n;
-    // 1. this rank's slice into slot `rank` of every rank's buffer (peer stores over xGMI; the own copy too), then one flag per peer
-    const size_t my_slot = (set * (size_t)P + (size_t)a.rank) * a.max_floats;
-    for (int i = lo + tid; i < hi; i += 256) {
-        const float v = send[i];
-        for (int q = 0; q < P; q++) __hip_atomic_store(a.data[q] + my_slot + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();                               // every thread: its stores have left for their owners before the flags do
-    __syncthreads();
-    if (tid < P) __hip_atomic_store(a.flags[tid] + (set * (size_t)P + (size_t)a.rank) * P2P_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 1] = wall_clock64();
-    // 2. everybody's slice w has arrived in MY buffer once my P flags of this set carry e
     if (tid < P) {
-        const unsigned *f = a.flags[a.rank] + (set * (size_t)P + (size_t)tid) * P2P_WGS + w;
+        const unsigned *f = flag_of(tid);
         const unsigned long long t0 = wall_clock64();
         int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            if ((++spins & 255) == 0 && wall_clock64() - t0 > P2P_WAIT_TICKS) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        while (f && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            ++spins;
+            if (a.yield_polls > 0) { if (spins >= a.yield_polls) { gave_up = 1; break; } }
+            else if ((spins & 255) == 0 && wall_clock64() - t0 > P2P_WAIT_TICKS) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
+    return gave_up == 0;
+}
+// one workgroup = one slice of the message, start to finish: no device-wide step inside the kernel
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, float *recv, int n, const P2PDev a) {
+    __shared__ unsigned e_sh, st_sh;
+    const int tid = (int)threadIdx.x, w = (int)blockIdx.x, P = a.size;
+    if (tid == 0) { e_sh = a.epoch[w] + 1u; st_sh = a.yield_polls > 0 ? a.state[w] : 0u; }
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
+    __syncthreads();
+    const unsigned e = e_sh, stt = st_sh;
+    const size_t set = e & 1u;
+    const int per = (((n + 3) / 4 + (int)gridDim.x - 1) / (int)gridDim.x) * 4;
+    const int lo = w * per, hi = lo + per < n ? lo + per : n;
+    if (stt == 0) {
+        // 1. this rank's slice into slot `rank` of every rank's buffer (peer stores over xGMI; the own copy too), then one flag per peer
+        const size_t my_slot = (set * (size_t)P + (size_t)a.rank) * a.max_floats;
+        for (int i = lo + tid; i < hi; i += 256) {
+            const float v = send[i];
+            for (int q = 0; q < P; q++) __hip_atomic_store(a.data[q] + my_slot + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence_system();                               // every thread: its stores have left for their owners before the flags do
+        __syncthreads();
+        if (tid < P) __hip_atomic_store(a.flags[tid] + (set * (size_t)P + (size_t)a.rank) * P2P_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.yield_polls > 0 && tid == 0) a.state[w] = 1u;
+    }
+    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 1] = wall_clock64();
+    // 2. everybody's slice w has arrived in MY buffer once my P flags of this set carry e
+    if (!p2p_wait_flags(a, e, [&](int q) { return a.flags[a.rank] + (set * (size_t)P + (size_t)q) * P2P_WGS + w; })) {
+        if (tid == 0) __hip_atomic_fetch_add(a.pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;                                               // (the epoch stays: the next launch resumes this exchange)
+    }
     if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 2] = wall_clock64();
     // 3. the P slots added in rank order (system-scope loads: the lines were written by other devices)
     const float *mine = a.data[a.rank] + set * (size_t)P * a.max_floats;
@@ -118,7 +146,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
         for (int q = 1; q < P; q++) acc += __hip_atomic_load(mine + (size_t)q * a.max_floats + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         recv[i] = acc;
     }
-    if (tid == 0) a.epoch[w] = e;
+    if (tid == 0) { a.epoch[w] = e; if (a.yield_polls > 0) a.state[w] = 0u; }
     if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 3] = wall_clock64();
 }
 
@@ -143,44 +171,45 @@ __device__ __forceinline__ tp_f32x4 tp_ld_sys(__amdgpu_buffer_rsrc_t r, int floa
 __device__ __forceinline__ void tp_st_sys(__amdgpu_buffer_rsrc_t r, int float_off, tp_f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tp_u32x4, v), r, float_off * 4, 0, TP_SYS);
 }
-__device__ __forceinline__ void rsag_signal_and_wait(const P2PDev &a, size_t set, int phase, int w, unsigned e) {
+__device__ __forceinline__ void rsag_signal(const P2PDev &a, size_t set, int phase, int w, unsigned e) {
     const int tid = (int)threadIdx.x, P = a.size;
     __threadfence_system();                               // every thread: its stores have reached their owners before the flags leave
     __syncthreads();
     const size_t row = (set * 2 + (size_t)phase) * (size_t)P;
-    if (tid < P && tid != a.rank) {
-        __hip_atomic_store(a.bflags[tid] + (row + (size_t)a.rank) * RSAG_MAX_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned *f = a.bflags[a.rank] + (row + (size_t)tid) * RSAG_MAX_WGS + w;
-        const unsigned long long t0 = wall_clock64();
-        int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            if ((++spins & 255) == 0 && wall_clock64() - t0 > P2P_WAIT_TICKS) { if (a.err) __hip_atomic_fetch_or(a.err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    __syncthreads();
+    if (tid < P && tid != a.rank) __hip_atomic_store(a.bflags[tid] + (row + (size_t)a.rank) * RSAG_MAX_WGS + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool rsag_wait(const P2PDev &a, size_t set, int phase, int w, unsigned e) {
+    const size_t row = (set * 2 + (size_t)phase) * (size_t)a.size;
+    return p2p_wait_flags(a, e, [&](int q) -> const unsigned * { return q == a.rank ? nullptr : a.bflags[a.rank] + (row + (size_t)q) * RSAG_MAX_WGS + w; });
 }
 __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float *recv, int n, const P2PDev a) {
-    __shared__ unsigned e_sh;
+    __shared__ unsigned e_sh, st_sh;
     const int tid = (int)threadIdx.x, w = (int)blockIdx.x, G = (int)gridDim.x, P = a.size, R = a.rank;
-    if (tid == 0) e_sh = a.bepoch[w] + 1u;
+    unsigned *const st_w = a.state + P2P_WGS + w;
+    if (tid == 0) { e_sh = a.bepoch[w] + 1u; st_sh = a.yield_polls > 0 ? *st_w : 0u; }
     if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
     __syncthreads();
-    const unsigned e = e_sh;
+    const unsigned e = e_sh, stt = st_sh;
+    auto leave = [&]() { if (tid == 0) __hip_atomic_fetch_add(a.pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     const size_t set = e & 1u;
     const int seg = ((n / 4 + P - 1) / P) * 4;                       // floats per segment (the last one may be shorter, or empty)
     const int per = ((seg / 4 + G - 1) / G) * 4;                     // floats of a segment that one workgroup carries
     const int s_lo = w * per, s_hi = s_lo + per < seg ? s_lo + per : seg;
     const size_t slot = a.seg_max, half = 2 * (size_t)P * slot;      // [partials: 2 sets][reduced: 2 sets]
     // 1. my part of every foreign segment into its owner's buffer, slot R; the nearest owner first so that the P ranks start on P different links
-    for (int d = 1; d < P; d++) {
-        const int q = R + d < P ? R + d : R + d - P;
-        const int hi = q * seg + s_hi < n ? s_hi : n - q * seg;
-        const __amdgpu_buffer_rsrc_t dst = tp_rsrc(a.big[q] + (set * (size_t)P + (size_t)R) * slot);
-        const tp_f32x4 *src = reinterpret_cast<const tp_f32x4 *>(send + (size_t)q * seg);
-        for (int i = s_lo + tid * 4; i < hi; i += 1024) tp_st_sys(dst, i, src[i >> 2]);
+    if (stt == 0) {
+        for (int d = 1; d < P; d++) {
+            const int q = R + d < P ? R + d : R + d - P;
+            const int hi = q * seg + s_hi < n ? s_hi : n - q * seg;
+            const __amdgpu_buffer_rsrc_t dst = tp_rsrc(a.big[q] + (set * (size_t)P + (size_t)R) * slot);
+            const tp_f32x4 *src = reinterpret_cast<const tp_f32x4 *>(send + (size_t)q * seg);
+            for (int i = s_lo + tid * 4; i < hi; i += 1024) tp_st_sys(dst, i, src[i >> 2]);
+        }
+        rsag_signal(a, set, 0, w, e);
+        if (a.yield_polls > 0 && tid == 0) *st_w = 1u;
     }
-    rsag_signal_and_wait(a, set, 0, w, e);
+    if (stt <= 1) {
+    if (!rsag_wait(a, set, 0, w, e)) { leave(); return; }
     if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 1] = wall_clock64();
     // 2. my segment: the P parts in rank order; the sum to `recv` and into every rank's reduced area, slot R
     {
@@ -198,7 +227,10 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
             }
         }
     }
-    rsag_signal_and_wait(a, set, 1, w, e);
+    rsag_signal(a, set, 1, w, e);
+    if (a.yield_polls > 0 && tid == 0) *st_w = 2u;
+    }
+    if (!rsag_wait(a, set, 1, w, e)) { leave(); return; }
     if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 2] = wall_clock64();
     // 3. the foreign segments out of my own buffer
     for (int d = 1; d < P; d++) {
@@ -208,7 +240,7 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
         tp_f32x4 *out = reinterpret_cast<tp_f32x4 *>(recv + (size_t)q * seg);
         for (int i = s_lo + tid * 4; i < hi; i += 1024) out[i >> 2] = tp_ld_sys(src, i);
     }
-    if (tid == 0) a.bepoch[w] = e;
+    if (tid == 0) { a.bepoch[w] = e; if (a.yield_polls > 0) *st_w = 0u; }
     if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot + 3] = wall_clock64();
 }
 
@@ -286,6 +318,31 @@ hipError_t host_exchange(float *dev_send, float *dev_recv, size_t n_total, size_
     return e;
 }
 
+// the yield form's launch: the kernel again and again until no workgroup left unfinished.  Every launch ends within a few milliseconds whatever the peers do, so
+// the processes that share the device all get to run; the exchange as a whole is bounded in time (MI355_TP_YIELD_TIMEOUT_S, default 60) and raises the error
+// word when the bound runs out.  Only where the stream may be drained inside a step (the host-callback transport does that for its own exchanges anyway).
+hipError_t p2p_launch_until_done(bool rsag, const float *send, float *recv, int n, hipStream_t st) {
+    static const double limit_s = [] { const char *e = getenv("MI355_TP_YIELD_TIMEOUT_S"); const double v = e ? atof(e) : 60.0; return v > 0.0 ? v : 60.0; }();
+    const double t0 = now_us();
+    for (int attempt = 0;; attempt++) {
+        *g_p2p.pending = 0;
+        if (rsag) hipLaunchKernelGGL(p2p_rsag_kernel, dim3(g_p2p.rsag_wgs), dim3(256), 0, st, send, recv, n, g_p2p.dev);
+        else hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(P2P_WGS), dim3(256), 0, st, send, recv, n, g_p2p.dev);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        if (*reinterpret_cast<volatile unsigned *>(g_p2p.pending) == 0) return hipSuccess;
+        if ((now_us() - t0) * 1e-6 > limit_s) {
+            if (g_p2p.err) __atomic_fetch_or(g_p2p.err, 32u, __ATOMIC_RELAXED);
+            (void)hipMemsetAsync(g_p2p.state, 0, (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned), st);      // (the step is lost; what follows must not resume it)
+            return hipSuccess;
+        }
+        g_p2p.dev.trace = nullptr;                         // (the first launch carries the stamps)
+        struct timespec ts = {0, attempt < 20 ? 50000 : 500000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 }  // namespace
 
 int tp_unique_id(void *out, size_t cap, std::string &err) {
@@ -347,8 +404,11 @@ int tp_p2p_local_handle(void *out, size_t cap, size_t max_floats, size_t prompt_
             p.bflags_off = p.big_off + 4 * P * seg_max * sizeof(float);
             p.bytes = p.bflags_off + 4 * P * RSAG_MAX_WGS * sizeof(unsigned);
         }
-        if (hipMalloc((void **)&p.local, p.bytes) != hipSuccess || hipMalloc((void **)&p.epoch, (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc of the exchange buffer failed"; return -1; }
-        if (hipMemset(p.local, 0, p.bytes) != hipSuccess || hipMemset(p.epoch, 0, (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { err = "clearing the exchange buffer failed"; return -1; }
+        if (hipMalloc((void **)&p.local, p.bytes) != hipSuccess || hipMalloc((void **)&p.epoch, 2 * (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc of the exchange buffer failed"; return -1; }
+        if (hipMemset(p.local, 0, p.bytes) != hipSuccess || hipMemset(p.epoch, 0, 2 * (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { err = "clearing the exchange buffer failed"; return -1; }
+        p.state = p.epoch + (P2P_WGS + RSAG_MAX_WGS);
+        if (!p.pending && hipHostMalloc((void **)&p.pending, 64, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc of the exchange's pending word failed"; return -1; }
+        *p.pending = 0;
         p.max_floats = max_floats;
         p.prompt_floats = seg_max ? prompt_floats : 0;
         p.bepoch = p.epoch + P2P_WGS;
@@ -382,6 +442,9 @@ int tp_p2p_enable(const void *handles, size_t len, std::string &err) {
         d.big[q] = (float *)((uint8_t *)p.peer[q] + p.big_off); d.bflags[q] = (unsigned *)((uint8_t *)p.peer[q] + p.bflags_off);
     }
     d.epoch = p.epoch; d.bepoch = p.bepoch; d.err = p.err; d.rank = g_grp.rank; d.size = P; d.max_floats = p.max_floats; d.seg_max = p.dev.seg_max;
+    d.state = p.state; d.pending = p.pending;
+    // ranks that exchange through the host callback share a device: their waits for a peer must END the launch instead of holding the device (P2PDev::state)
+    { const char *ev = getenv("MI355_TP_YIELD"); d.yield_polls = (ev ? ev[0] == '1' : g_grp.host_fn != nullptr) ? 4096 : 0; }
     p.dev = d;
     p.on = true;
     p.prompt_on = p.prompt_floats > 0;
@@ -402,6 +465,7 @@ void tp_shutdown() {
         for (int q = 0; q < P2P_MAX_RANKS; q++) if (g_p2p.peer[q] && g_p2p.peer[q] != g_p2p.local) (void)hipIpcCloseMemHandle(g_p2p.peer[q]);
         (void)hipFree(g_p2p.local);
         if (g_p2p.epoch) (void)hipFree(g_p2p.epoch);
+        if (g_p2p.pending) (void)hipHostFree(g_p2p.pending);
     }
     g_p2p = P2PState();
     if (g_grp.comm && g_api.CommDestroy) (void)g_api.CommDestroy(g_grp.comm);
@@ -419,12 +483,14 @@ hipError_t tp_all_reduce_sum(const float *send, float *recv, size_t n, hipStream
     if (g_p2p.on && n <= g_p2p.max_floats && n >= 4) {          // decode-sized message: the one-shot peer-to-peer kernel
         g_p2p.exchanges++;
         g_p2p.dev.trace_slot = trace_next((int)n, 0); g_p2p.dev.trace = g_trace_on && g_trace.size() < (size_t)TRACE_MAX ? g_trace_dev : nullptr;
+        if (g_p2p.dev.yield_polls > 0) return p2p_launch_until_done(false, send, recv, (int)n, st);
         hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(P2P_WGS), dim3(256), 0, st, send, recv, (int)n, g_p2p.dev);
         return hipGetLastError();
     }
     if (g_p2p.on && g_p2p.prompt_on && n > g_p2p.max_floats && n <= g_p2p.prompt_floats && !(n & 3)) {   // prompt-sized: reduce-scatter + all-gather over all links
         g_p2p.prompt_exchanges++;
         g_p2p.dev.trace_slot = trace_next((int)n, 1); g_p2p.dev.trace = g_trace_on && g_trace.size() < (size_t)TRACE_MAX ? g_trace_dev : nullptr;
+        if (g_p2p.dev.yield_polls > 0) return p2p_launch_until_done(true, send, recv, (int)n, st);
         hipLaunchKernelGGL(p2p_rsag_kernel, dim3(g_p2p.rsag_wgs), dim3(256), 0, st, send, recv, (int)n, g_p2p.dev);
         return hipGetLastError();
     }

@@ -300,6 +300,12 @@ MI355_API int mi355_debug_set_option(const char *name, int32_t value);
 MI355_API int mi355_tp_unique_id(void *id_out, size_t cap);                         /* returns bytes written or < 0 */
 MI355_API int mi355_tp_init(int32_t device, int32_t rank, int32_t size, const void *id, size_t id_len);
 MI355_API void mi355_tp_shutdown(void);
+/* ONE /loadmodel for the row split (what a user of the reference sees: its engine drives every visible device from one call, src/llama_engine.cc:609-611).
+ * A load body with "split_mode": "row" (+ "tensor_split": even shares only, "main_gpu", "split_ranks": see host/tp_split.cc) given to
+ * mi355_engine_load_model makes the calling process rank 0 of a group it forms itself: it starts bin/mi355_tp_worker once per further rank, hands it the RCCL id
+ * (or, where ranks share a device, a shared-memory exchange segment) over a socket pair, and steps the workers in lock-step with every batch and KV operation.
+ * None of the calls above is needed then.  mi355_tp_worker_main is that worker program's body: `sock_fd` is the inherited socket; returns the exit code. */
+MI355_API int mi355_tp_worker_main(int sock_fd);
 MI355_API int32_t mi355_tp_rank(void);
 MI355_API int32_t mi355_tp_size(void);
 /* Validation transport for boxes where the ranks share one GPU (RCCL refuses that): the exchange goes through this

@@ -1096,7 +1096,14 @@ static void test_engine_unload_mid_stream() {
         eng.HandleChatCompletion(req, watch(a, std::move(ta)));
         if (round == 0) eng.HandleChatCompletion(req, watch(b, std::move(tb)));   // one worker (n_parallel 1): waits in the queue behind the first
         else tb.reset();
-        { std::unique_lock<std::mutex> lk(a->mu); CHECK(a->cv.wait_for(lk, std::chrono::seconds(20), [&] { return a->chunks >= 2; })); }
+        {   // (polled: gcc 11's ThreadSanitizer does not see the unlock inside condition_variable::wait_for's pthread_cond_clockwait and reports the next lock)
+            bool got = false;
+            for (int i = 0; i < 4000 && !got; i++) {
+                { std::lock_guard<std::mutex> lk(a->mu); got = a->chunks >= 2; }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+            CHECK(got);
+        }
         Json un = Json::object(); un["model"] = "slow";
         if (round == 0) {
             eng.UnloadModel(un, grab);                // joins the workers: both streams have had their last callback when it returns
