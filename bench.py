@@ -543,8 +543,20 @@ def main() -> int:
     # note of the microarchitecture guide); null when the profile is absent or is for another workload
     traffic, traffic_note = None, "no PMC profile for this workload"
     root = os.path.dirname(os.path.abspath(__file__))
-    tpath = os.path.join(root, "profiles", "r5_pmc_decode_traffic.json")
     sha_now = kernel_sources_sha256(root)
+
+    def committed_profile(suffix):
+        """the newest profiles/r<N>_<suffix> (by round number); the caller checks its kernel_sources_sha256 against this tree's"""
+        import glob
+        import re
+        best = None
+        for f in glob.glob(os.path.join(root, "profiles", "r*_" + suffix)):
+            m = re.match(r"r(\d+)_", os.path.basename(f))
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), f)
+        return best[1] if best else os.path.join(root, "profiles", "r0_" + suffix)
+    tpath = committed_profile("pmc_decode_traffic.json")
+    tname = "profiles/" + os.path.basename(tpath)
     if os.path.exists(tpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
             with open(tpath) as f:
@@ -552,14 +564,15 @@ def main() -> int:
             # the profile names the kernel sources it was taken from (sha256 over the mat-vec kernel files): a kernel change since then makes the
             # figure stale, and it is withheld rather than repeated
             if tj.get("kernel_sources_sha256") == sha_now:
-                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), "profiles/r5_pmc_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
+                traffic, traffic_note = int(tj["matvec_hbm_read_bytes_per_token"]), tname + " (rocprofv3 --pmc FETCH_SIZE, x2 per the gfx950 note)"
             else:
-                traffic_note = "profiles/r5_pmc_decode_traffic.json was taken from other kernel sources than this tree's: withheld"
+                traffic_note = tname + " was taken from other kernel sources than this tree's: withheld"
         except (OSError, ValueError, KeyError):
             traffic = None
     # the same fraction from the TRACED durations of the committed rocprofv3 summary (eager launches, per-kernel averages) instead of the graph sweep
     frac_rocprof, frac_rocprof_note, roles_rocprof = None, "no rocprofv3 summary for this workload", None
-    rpath = os.path.join(root, "profiles", "r5_rocprof_decode_roofline.json")
+    rpath = committed_profile("rocprof_decode_roofline.json")
+    rname = "profiles/" + os.path.basename(rpath)
     if os.path.exists(rpath) and args.config == "llama-3-8b" and args.ftype == "q4_k_m":
         try:
             with open(rpath) as f:
@@ -567,10 +580,10 @@ def main() -> int:
             if rj.get("kernel_sources_sha256") == sha_now:
                 frac_rocprof = float(rj["frac_rocprof"])
                 roles_rocprof = rj.get("roles")
-                frac_rocprof_note = (f"profiles/r5_rocprof_decode_roofline.json: {rj['stream_weight_bytes_per_token']} B / {rj['stream_us_per_token']} us of traced "
+                frac_rocprof_note = (f"{rname}: {rj['stream_weight_bytes_per_token']} B / {rj['stream_us_per_token']} us of traced "
                                      f"mmvq_stream_kernel time per token ({rj['stream_avg_launch_us']} us per launch)")
             else:
-                frac_rocprof_note = "profiles/r5_rocprof_decode_roofline.json was taken from other kernel sources than this tree's: withheld"
+                frac_rocprof_note = rname + " was taken from other kernel sources than this tree's: withheld"
         except (OSError, ValueError, KeyError):
             frac_rocprof = None
 

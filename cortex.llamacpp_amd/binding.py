@@ -81,6 +81,7 @@ SYMBOLS = {
     "mi355_get_topk_ith": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp]),
     "mi355_debug_mega_steps": (C.c_int64, [_vp]),
     "mi355_debug_engine_steps": (C.c_int64, [_vp]),
+    "mi355_debug_fused_skipped_steps": (C.c_int64, [_vp]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
     "mi355_get_embeddings_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_synchronize": (None, [_vp]),
@@ -643,6 +644,9 @@ class Context:
         if r != k:
             raise MI355Error(f"mi355_get_topk_ith failed: {_err(self.lib)}")
         return toks, lg
+
+    def fused_skipped_steps(self) -> int:
+        return int(self.lib.mi355_debug_fused_skipped_steps(self.h))
 
     def engine_steps(self) -> int:
         """Single-token steps that ran through the layer engine (one persistent launch per layer; diagnosis)."""

@@ -255,6 +255,7 @@ int32_t mi355_get_topk_ith(mi355_context *ctx, int32_t i, int32_t k, int32_t n_a
 }
 int64_t mi355_debug_mega_steps(const mi355_context *ctx) { return ctx->c->mega_steps; }
 int64_t mi355_debug_engine_steps(const mi355_context *ctx) { return ctx->c->engine_steps; }
+int64_t mi355_debug_fused_skipped_steps(const mi355_context *ctx) { return ctx->c->fused_skipped_steps; }
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0 || ctx->c->model->hp.encoder; }
 float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }

@@ -463,6 +463,7 @@ struct Context::KTimer : KernelTimer {
     ~KTimer() override { for (auto &r : pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); } }
 };
 Context::~Context() {
+    if (holds_fused_) { (void)hipStreamSynchronize(stream_); fused_release(); }
     if (ktimer_) { if (kernel_timer() == ktimer_) set_kernel_timer(nullptr); delete ktimer_; ktimer_ = nullptr; }
     attn_probe_report();
     attn_out_probe_report();
@@ -1151,7 +1152,20 @@ void debug_raise_stream_error(unsigned code) {
     if (w && code) __atomic_fetch_or(w, code, __ATOMIC_RELAXED);
 }
 
+static std::atomic<int> g_fused_owner_count[64];      // per device: 1 while a context holds the cross-workgroup-wait launches
+static bool fused_gate_on() { static const bool off = getenv("MI355_FUSED_GATE") && getenv("MI355_FUSED_GATE")[0] == '0'; return !off; }
+bool Context::fused_acquire() {
+    if (!fused_gate_on() || holds_fused_) return true;
+    int expected = 0;
+    if (g_fused_owner_count[model->device & 63].compare_exchange_strong(expected, 1)) { holds_fused_ = true; return true; }
+    return false;
+}
+void Context::fused_release() {
+    if (holds_fused_) { holds_fused_ = false; g_fused_owner_count[model->device & 63].store(0); }
+}
+
 bool Context::stream_check() {
+    fused_release();                                     // (every caller has just synchronised the context's stream)
     unsigned *w = stream_error_word();
     if (!w) return true;
     const unsigned raised = __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED);
@@ -1416,7 +1430,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
                 // workgroups wait for each other (consumers for the item workgroups' flags), and two processes' copies placed on the same CUs at the same time can
                 // hold each other's item workgroups out - every wait then runs into its bound (round 6: 0x8 on three of eight ranks behind one MI355X at the first
                 // single-token step, profiles/r6_tp_shared_device_trace.txt).  A rank that owns its GPU has the chip to itself.)
-                if (attn_mode == 2 && !engine && il < 255 && !attn_out_off_ && !(tp && tp_uses_host())) {
+                if (attn_mode == 2 && !engine && il < 255 && !attn_out_off_ && !attn_out_skip_step_ && !(tp && tp_uses_host())) {
                     const bool add = !tp || hp.tp_rank == 0;
                     const MMVQSeg so = make_seg(L.wo, tp ? tp_part_ : x_, E, add ? x_ : nullptr, nullptr);
                     AttnArgs af = aa;
@@ -1879,7 +1893,11 @@ int Context::decode_ubatch(int n, const int32_t *tokens, const int32_t *pos, con
 
     const int V = model->hp.n_vocab;
     if (n == 1 && !model->hp.encoder && !ub_embd_) { (void)mega_prepare(); (void)engine_prepare(); }   // allocate and upload on first use: must not happen inside a stream capture
-    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled && moe_forced_T_ == 0 && !ub_embd_;
+    // a single-token step would launch the attention + attn_output kernel whose workgroups wait for each other: only while no other context of this device has
+    // such a step in flight (runtime.h fused_acquire); otherwise this step takes the wait-free launches, eagerly (the captured graphs hold the fused kernel)
+    attn_out_skip_step_ = n == 1 && !attn_out_off_ && !model->hp.encoder && !fused_acquire();
+    if (attn_out_skip_step_) fused_skipped_steps++;
+    bool graph_ok = cp.use_graphs && n == 1 && n_out == 1 && out_base == 0 && !profile_ && !debug_taps_ && !embeddings_enabled && moe_forced_T_ == 0 && !ub_embd_ && !attn_out_skip_step_;
     hipError_t e = hipSuccess;
     if (graph_ok) {
         // the attention grid is sized for an upper bound of occupied cells; one captured graph per 256-cell bucket
@@ -2061,7 +2079,7 @@ int Context::decode(int n_tokens, const int32_t *tokens, const int32_t *pos, con
     return 0;
 }
 
-void Context::synchronize() { (void)hipStreamSynchronize(stream_); }
+void Context::synchronize() { (void)hipStreamSynchronize(stream_); fused_release(); }
 
 int Context::force_moe_ids(const int32_t *ids, int n_layer, int T, int k) {
     const HParams &hp = model->hp;

@@ -113,6 +113,7 @@ void set_decode_mega(bool on);   // tests: compare the whole-step kernel with th
 class Context {
   public:
     int64_t engine_steps = 0;          // single-token steps issued through the layer engine (graph replays included)
+    int64_t fused_skipped_steps = 0;   // single-token steps that took the wait-free launches because another context of the device held the cross-workgroup-wait kernel
     int64_t mega_steps = 0;            // single-token steps issued as one whole-step launch (graph replays included)
     Context(Model *m, const ContextParams &p);
     ~Context();
@@ -252,6 +253,12 @@ class Context {
     bool attn_out_off_ = false;                        // after an answered error epoch: the two-launch attention path (nothing in it waits for another workgroup)
     int engine_state_ = 0;                             // 0 = not looked at yet, 1 = ready, -1 = this model / context takes one launch per mat-vec
     bool engine_prepare();
+    // One context at a time per device may have a step with the cross-workgroup-wait attention kernel in flight: two such kernels placed on the same CUs at the
+    // same time can hold each other's item workgroups out (attn_out.hip; seen between PROCESSES in round 6, profiles/r6_tp_shared_device_trace.txt - two models
+    // of one server decoding concurrently are the in-process form of it).  A context that finds the device taken runs that step on the wait-free launches.
+    bool fused_acquire();
+    void fused_release();                              // called wherever this context has just drained its stream
+    bool holds_fused_ = false, attn_out_skip_step_ = false;
     bool stream_check();                               // after a stream sync: false (and last_error set) if a bounded wait of a stream / engine kernel gave up
     int32_t *d_moe_forced_ = nullptr;    // force_moe_ids: [n_layer][T][k] on the device (armed while moe_forced_T_ > 0)
     int moe_forced_T_ = 0, moe_forced_cap_ = 0;

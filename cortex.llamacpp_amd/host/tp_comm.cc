@@ -66,6 +66,7 @@ struct P2PDev {                        // by value into the kernel
     unsigned *state;                   // [P2P_WGS + RSAG_MAX_WGS] resume states (this rank's private memory)
     unsigned *pending;                 // pinned host word: workgroups of the current launch that left unfinished
     int yield_polls;
+    unsigned target_e;                 // yield form: the serial of THIS exchange (= exchanges of its kind so far); a workgroup whose epoch has reached it is done and must not start the next one when the launch is repeated for the others
     unsigned long long *trace;         // nullable (MI355_TP_TRACE=1): per launch of either kernel 4 stamps of the 100 MHz wall clock, written by workgroup 0
     unsigned trace_slot;               // ... at trace[4 * trace_slot ..]: entered, own flags out, first wait over, done
 };
@@ -114,9 +115,10 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const float *send, f
     __shared__ unsigned e_sh, st_sh;
     const int tid = (int)threadIdx.x, w = (int)blockIdx.x, P = a.size;
     if (tid == 0) { e_sh = a.epoch[w] + 1u; st_sh = a.yield_polls > 0 ? a.state[w] : 0u; }
-    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
+    if (a.trace && w == 0 && tid == 0 && a.trace[4 * a.trace_slot] == 0) a.trace[4 * a.trace_slot] = wall_clock64();
     __syncthreads();
     const unsigned e = e_sh, stt = st_sh;
+    if (a.yield_polls > 0 && e > a.target_e) return;          // (a repeated launch: this workgroup finished the exchange in an earlier one)
     const size_t set = e & 1u;
     const int per = (((n + 3) / 4 + (int)gridDim.x - 1) / (int)gridDim.x) * 4;
     const int lo = w * per, hi = lo + per < n ? lo + per : n;
@@ -187,9 +189,10 @@ __global__ __launch_bounds__(256) void p2p_rsag_kernel(const float *send, float 
     const int tid = (int)threadIdx.x, w = (int)blockIdx.x, G = (int)gridDim.x, P = a.size, R = a.rank;
     unsigned *const st_w = a.state + P2P_WGS + w;
     if (tid == 0) { e_sh = a.bepoch[w] + 1u; st_sh = a.yield_polls > 0 ? *st_w : 0u; }
-    if (a.trace && w == 0 && tid == 0) a.trace[4 * a.trace_slot] = wall_clock64();
+    if (a.trace && w == 0 && tid == 0 && a.trace[4 * a.trace_slot] == 0) a.trace[4 * a.trace_slot] = wall_clock64();
     __syncthreads();
     const unsigned e = e_sh, stt = st_sh;
+    if (a.yield_polls > 0 && e > a.target_e) return;          // (a repeated launch: this workgroup finished the exchange in an earlier one)
     auto leave = [&]() { if (tid == 0) __hip_atomic_fetch_add(a.pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     const size_t set = e & 1u;
     const int seg = ((n / 4 + P - 1) / P) * 4;                       // floats per segment (the last one may be shorter, or empty)
@@ -318,12 +321,40 @@ hipError_t host_exchange(float *dev_send, float *dev_recv, size_t n_total, size_
     return e;
 }
 
+// an exchange that ran out of time: which peers' flags never arrived here (this rank's own flag area and counters, read back), on stderr
+void p2p_report_missing(bool rsag, int attempts) {
+    const int P = g_grp.size, R = g_grp.rank;
+    const int n_wg = rsag ? g_p2p.rsag_wgs : P2P_WGS, stride = rsag ? RSAG_MAX_WGS : P2P_WGS;
+    std::vector<unsigned> ep((size_t)(P2P_WGS + RSAG_MAX_WGS) * 2), fl;
+    if (hipMemcpy(ep.data(), g_p2p.epoch, ep.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+    const unsigned *epoch = ep.data() + (rsag ? P2P_WGS : 0), *state = ep.data() + (P2P_WGS + RSAG_MAX_WGS) + (rsag ? P2P_WGS : 0);
+    const size_t fl_words = rsag ? (size_t)4 * P * RSAG_MAX_WGS : (size_t)2 * P * P2P_WGS;
+    fl.resize(fl_words);
+    if (hipMemcpy(fl.data(), g_p2p.local + (rsag ? g_p2p.bflags_off : g_p2p.flags_off), fl_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::string line = "[tp] rank " + std::to_string(R) + ": " + (rsag ? "reduce-scatter" : "all-reduce") + " exchange abandoned after " + std::to_string(attempts + 1) + " launches;";
+    for (int w = 0; w < n_wg && w < 4; w++) {
+        const unsigned e = epoch[w] + 1u, set = e & 1u;
+        line += " wg" + std::to_string(w) + " epoch " + std::to_string(e) + " state " + std::to_string(state[w]) + " flags";
+        const int phases = rsag ? 2 : 1;
+        for (int ph = 0; ph < phases; ph++) {
+            line += ph ? " | " : " ";
+            for (int q = 0; q < P; q++) {
+                const size_t row = rsag ? ((size_t)set * 2 + ph) * P + q : (size_t)set * P + q;
+                line += (q == R && rsag ? std::string("-") : std::to_string(fl[row * stride + w])) + (q + 1 < P ? "," : "");
+            }
+        }
+        line += ";";
+    }
+    fprintf(stderr, "%s\n", line.c_str());
+}
+
 // the yield form's launch: the kernel again and again until no workgroup left unfinished.  Every launch ends within a few milliseconds whatever the peers do, so
 // the processes that share the device all get to run; the exchange as a whole is bounded in time (MI355_TP_YIELD_TIMEOUT_S, default 60) and raises the error
 // word when the bound runs out.  Only where the stream may be drained inside a step (the host-callback transport does that for its own exchanges anyway).
 hipError_t p2p_launch_until_done(bool rsag, const float *send, float *recv, int n, hipStream_t st) {
     static const double limit_s = [] { const char *e = getenv("MI355_TP_YIELD_TIMEOUT_S"); const double v = e ? atof(e) : 60.0; return v > 0.0 ? v : 60.0; }();
     const double t0 = now_us();
+    g_p2p.dev.target_e = (unsigned)(rsag ? g_p2p.prompt_exchanges : g_p2p.exchanges);      // (counted by the caller before it came here)
     for (int attempt = 0;; attempt++) {
         *g_p2p.pending = 0;
         if (rsag) hipLaunchKernelGGL(p2p_rsag_kernel, dim3(g_p2p.rsag_wgs), dim3(256), 0, st, send, recv, n, g_p2p.dev);
@@ -334,10 +365,10 @@ hipError_t p2p_launch_until_done(bool rsag, const float *send, float *recv, int 
         if (*reinterpret_cast<volatile unsigned *>(g_p2p.pending) == 0) return hipSuccess;
         if ((now_us() - t0) * 1e-6 > limit_s) {
             if (g_p2p.err) __atomic_fetch_or(g_p2p.err, 32u, __ATOMIC_RELAXED);
+            p2p_report_missing(rsag, attempt);
             (void)hipMemsetAsync(g_p2p.state, 0, (P2P_WGS + RSAG_MAX_WGS) * sizeof(unsigned), st);      // (the step is lost; what follows must not resume it)
             return hipSuccess;
         }
-        g_p2p.dev.trace = nullptr;                         // (the first launch carries the stamps)
         struct timespec ts = {0, attempt < 20 ? 50000 : 500000};
         nanosleep(&ts, nullptr);
     }

@@ -161,6 +161,9 @@ MI355_API int64_t mi355_debug_mega_steps(const mi355_context *ctx);
 /* diagnosis: single-token steps this context ran through the layer engine (decode_engine.hip: one persistent launch per layer for the mat-vecs between two
    attention calls; opt-in: mi355_debug_set_option "decode_engine" 1 or MI355_ENGINE=1) */
 MI355_API int64_t mi355_debug_engine_steps(const mi355_context *ctx);
+/* single-token steps of this context that took the wait-free launches because another context of the device had the one-launch attention + attn_output kernel
+   (workgroups that wait for each other) in flight: two models of one server decoding at the same time never run that kernel beside each other */
+MI355_API int64_t mi355_debug_fused_skipped_steps(const mi355_context *ctx);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
 /* llama_get_embeddings_ith (ctx.cc:1042-1044): final-norm hidden state (n_embd floats, host memory) of batch row i of the

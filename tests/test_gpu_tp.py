@@ -87,7 +87,7 @@ def _run_ranks_once(world, plan_path, out_path, timeout):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "tp_trace_" + os.path.basename(out_path) + ".log"), "a") as f:
             for r, o in enumerate(outs):
-                f.write(f"==== rank {r} exit {procs[r].returncode}\n" + "\n".join(l for l in o.splitlines() if "[tp trace]" in l or "gave up" in l or "Error" in l) + "\n")
+                f.write(f"==== rank {r} exit {procs[r].returncode}\n" + "\n".join(l for l in o.splitlines() if "[tp" in l or "gave up" in l or "Error" in l) + "\n")
     if any(p.returncode != 0 for p in procs):                 # (a rank that fails takes its peers' exchanges down with it: show every rank's last lines)
         tails = "\n".join(f"---- rank {r} (exit {p.returncode})\n{outs[r][-1500:]}" for r, p in enumerate(procs))
         raise RanksFailed(f"{sum(p.returncode != 0 for p in procs)} of {world} ranks failed:\n{tails}", [p.returncode for p in procs])
