@@ -103,7 +103,8 @@ def test_one_loadmodel_splits_the_rows_and_answers_as_the_unsplit_engine(pkg, mo
         th = [threading.Thread(target=ask, args=(i,)) for i in range(2)]
         [t.start() for t in th]
         [t.join() for t in th]
-        assert [r[0] for r in res] == [g[0] for g in got]         # each answers what it answers alone
+        for r, g in zip(res, got):                                # each answers what it answers alone (a slot that generates beside another one takes the
+            _same_up_to_near_ties(r, g)                           # batched-step kernels: steps may part at a near-tie, nowhere else)
         stream = e.chat_completion(model="tiny-70b-2l", messages=MSGS[0], max_tokens=12, stream=True, **GREEDY)
         assert stream[-1][0]["is_done"] and "".join(_delta(b) for _, b in stream) == got[0][0]
         # a second row-split model in the same process is refused (one group per process), in the reference's load-error shape
@@ -120,9 +121,11 @@ def test_one_loadmodel_splits_the_rows_and_answers_as_the_unsplit_engine(pkg, mo
 
 
 def e2_chat(e, msgs):
-    st, body = e.chat_completion(model="tiny-70b-2l", messages=msgs, max_tokens=12, **GREEDY)[-1]
+    st, body = e.chat_completion(model="tiny-70b-2l", messages=msgs, max_tokens=12, n_probs=2, **GREEDY)[-1]
     assert st["status_code"] == 200 and not st["has_error"], (st, body)
-    return (body["choices"][0]["message"]["content"],)
+    ch = body["choices"][0]
+    steps = [(t["content"], [(c["tok_str"], float(c["prob"])) for c in t["probs"]]) for t in (ch.get("logprobs") or [])]
+    return (ch["message"]["content"], body["usage"]["prompt_tokens"], body["usage"]["completion_tokens"], steps)
 
 
 def test_a_rank_that_dies_fails_the_request_in_bounded_time_and_names_itself(pkg, model_70b, monkeypatch):
