@@ -8,7 +8,8 @@ mkdir -p tools/bin/libs /tmp/libvar_$name
 B=cortex.llamacpp_amd/build
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -x hip"
 objs=""
-for o in $B/*.o; do
+# (the objects the tree's library was linked from: build.py writes the list - the build directory may hold objects of the other experiments setting)
+for o in $(cat $B/linked_objects.txt); do
   keep=1
   for s in "$@"; do
     if [ "$(basename $o)" = "$(echo $s | sed 's|/|_|g').o" ]; then keep=0; fi
