@@ -152,3 +152,35 @@ def test_a_rank_that_dies_fails_the_request_in_bounded_time_and_names_itself(pkg
         assert st["status_code"] == 200 and not st["has_error"]
     finally:
         e.close()
+
+
+def test_prompt_cache_and_context_shift_travel_to_every_rank(pkg, tmp_path_factory):
+    """The slot loop's KV operations over the split: a second request that shares the first one's prompt prefix (prompt cache: seq_rm of the tail), and a
+    generation longer than the context (context shift: seq_rm + seq_add, i.e. the K re-rotation on every rank's cache).  Every rank must apply the same
+    operations in the same order, or the ranks' caches part and the partial sums stop meaning anything: the answers are compared step by step with the unsplit
+    engine's under the same requests."""
+    path = str(tmp_path_factory.mktemp("splitkv") / "tiny-e2048.gguf")
+    pkg.gguf_synth.write_synthetic_llama(path, "tiny-e2048", "q4_k_m", with_vocab=True)
+    long_msg = [{"role": "user", "content": "one two three four five six seven eight nine ten eleven twelve"}]
+    longer = [{"role": "user", "content": "one two three four five six seven eight nine ten eleven twelve thirteen"}]
+
+    def run(**extra):
+        e = pkg.Engine()
+        try:
+            st, body = e.load_model(llama_model_path=path, model="kv", ctx_len=96, n_parallel=1, cache_type="q8_0", **extra)
+            assert st["status_code"] == 200, (st, body)
+            out = []
+            for msgs, n in ((long_msg, 8), (longer, 8), (long_msg, 120)):      # the third one generates past the 96-cell context
+                st, body = e.chat_completion(model="kv", messages=msgs, max_tokens=n, n_probs=2, **GREEDY)[-1]
+                assert st["status_code"] == 200 and not st["has_error"], (st, body)
+                ch = body["choices"][0]
+                steps = [(t["content"], [(c["tok_str"], float(c["prob"])) for c in t["probs"]]) for t in (ch.get("logprobs") or [])]
+                out.append((ch["message"]["content"], body["usage"]["prompt_tokens"], body["usage"]["completion_tokens"], steps))
+            return out
+        finally:
+            e.close()
+    want = run()
+    got = run(split_mode="row", split_ranks=2)
+    same = [_same_up_to_near_ties(g, w) for g, w in zip(got, want)]
+    assert same[0] >= 4 and same[1] >= 4, same
+    assert got[2][2] == want[2][2] == 120                        # both generated through the shift
