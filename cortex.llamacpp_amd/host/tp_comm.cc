@@ -21,6 +21,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -296,6 +297,7 @@ bool load_rccl(std::string &err) {
     SYM(GetUniqueId, "ncclGetUniqueId")
     SYM(CommInitRank, "ncclCommInitRank")
     SYM(CommDestroy, "ncclCommDestroy")
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
     SYM(GetErrorString, "ncclGetErrorString")
     SYM(AllReduce, "ncclAllReduce")
     SYM(AllGather, "ncclAllGather")
@@ -502,6 +504,13 @@ void tp_shutdown() {
     if (g_grp.comm && g_api.CommDestroy) (void)g_api.CommDestroy(g_grp.comm);
     if (g_grp.pinned) (void)hipHostFree(g_grp.pinned);
     g_grp = Group();
+}
+
+// A peer of the group is gone (the engine-formed row split, tp_split.cc): collectives already queued on this rank's stream would wait for it for ever - RCCL has no
+// time-out of its own - and so would everything that drains the stream afterwards (the context's destructor).  ncclCommAbort ends them with an error.
+void tp_abort() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_grp.comm && g_api.CommAbort) { (void)g_api.CommAbort(g_grp.comm); g_grp.comm = nullptr; }
 }
 
 bool tp_active() { return g_grp.comm != nullptr || g_grp.host_fn != nullptr || g_grp.null_group; }

@@ -27,6 +27,7 @@ void tp_set_host_exchange(tp_host_exchange_fn fn, void *user, int rank, int size
 // this rank's own part (results are NOT the model's; timings are this rank's compute without communication).
 void tp_set_null_group(int rank, int size);
 void tp_shutdown();
+void tp_abort();            // a peer is gone: end this rank's queued RCCL collectives with an error (ncclCommAbort) instead of waiting for it for ever
 int tp_rank();
 bool tp_active();         // a group exists (possibly of one rank)
 int tp_size();            // 1 = no group, or a group of one

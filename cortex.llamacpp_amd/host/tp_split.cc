@@ -205,6 +205,7 @@ class SplitBackend : public IBackend {
         err_ = why;
         log_line(LOG_ERROR, "%s", why.c_str());
         if (shm) shm->mark_dead();
+        else tp_abort();                                // (RCCL: what this rank has queued must not wait for a peer that is gone)
         for (auto &w : workers) if (!w.exited && w.pid > 0) kill(w.pid, SIGKILL);
     }
     bool collect(std::vector<int32_t> &rcs) {          // one reply per worker, bounded; a missing one fails the backend and names the rank

@@ -1,7 +1,7 @@
 #!/bin/bash
-# bench lines of the other BASELINE configurations on one GPU (and the reference's smoke-model type mix), one JSON line each under gpurun_out/r5cfg/
+# bench lines of the other BASELINE configurations on one GPU (and the reference's smoke-model type mix), one JSON line each under gpurun_out/r6cfg/
 cd "$(dirname "$0")/.."
-O=gpurun_out/r5cfg; mkdir -p $O
+O=gpurun_out/r6cfg; mkdir -p $O
 run() { name=$1; shift; timeout 900 python bench.py "$@" --no-cpu-baseline > $O/$name.json 2> $O/$name.err; tail -c 300 $O/$name.json | head -c 0; python - "$O/$name.json" <<'PY'
 import json, sys
 try:
