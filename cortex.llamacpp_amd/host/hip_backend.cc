@@ -4,6 +4,7 @@
 #include "hip_backend.h"
 
 #include <exception>
+#include <mutex>
 
 #include "clip.h"
 #include "log.h"
@@ -43,10 +44,13 @@ class HipBackend : public IBackend {
     void set_clip(std::unique_ptr<ClipModel> c) { clip_ = std::move(c); }
     bool multimodal() const override { return clip_ != nullptr; }
     // (the bytes are a request's: whatever goes wrong with them - a picture too large to hold included - is that request's error, not the loop thread's end)
+    // (the picture decoded here is kept for image_embed: a request's image is checked when the request arrives and embedded when its slot first visits the
+    // prompt - the same bytes, and a large JPEG costs tens of milliseconds to decode.  A handful of pictures, at most 64 MB of pixels)
     bool image_check(const uint8_t *bytes, size_t n, std::string &err) override {
         try {
             ClipImageU8 img;
             err = clip_image_load_from_bytes(bytes, n, img);
+            if (err.empty()) keep_decoded(bytes, n, std::move(img));
         } catch (const std::exception &e) { err = std::string("image: ") + e.what(); }
         return err.empty();
     }
@@ -54,7 +58,7 @@ class HipBackend : public IBackend {
         if (!clip_) { err = "no multimodal projector loaded"; return -1; }
         try {
             ClipImageU8 img;
-            err = clip_image_load_from_bytes(bytes, n, img);
+            if (!take_decoded(bytes, n, img)) err = clip_image_load_from_bytes(bytes, n, img);
             if (!err.empty()) return -1;
             int n_rows = 0;
             err = clip_->embed(img, rows, n_rows);
@@ -117,6 +121,29 @@ class HipBackend : public IBackend {
     void kv_seq_cp(int src, int dst, int p0, int p1) override { ctx_->kv_seq_cp(src, dst, p0, p1); }
 
   private:
+    static uint64_t bytes_key(const uint8_t *b, size_t n) {           // FNV-1a over the bytes
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+        return h ^ (uint64_t)n;
+    }
+    void keep_decoded(const uint8_t *b, size_t n, ClipImageU8 &&img) {
+        const size_t px = img.rgb.size();
+        if (px > ((size_t)64 << 20)) return;
+        std::lock_guard<std::mutex> lk(decoded_mu_);
+        while (!decoded_.empty() && (decoded_.size() >= 8 || decoded_bytes_ + px > ((size_t)64 << 20))) { decoded_bytes_ -= decoded_.front().second.rgb.size(); decoded_.erase(decoded_.begin()); }
+        decoded_bytes_ += px;
+        decoded_.emplace_back(bytes_key(b, n), std::move(img));
+    }
+    bool take_decoded(const uint8_t *b, size_t n, ClipImageU8 &img) {
+        const uint64_t k = bytes_key(b, n);
+        std::lock_guard<std::mutex> lk(decoded_mu_);
+        for (size_t i = 0; i < decoded_.size(); i++)
+            if (decoded_[i].first == k) { img = std::move(decoded_[i].second); decoded_bytes_ -= img.rgb.size(); decoded_.erase(decoded_.begin() + (long)i); return true; }
+        return false;
+    }
+    std::mutex decoded_mu_;
+    std::vector<std::pair<uint64_t, ClipImageU8>> decoded_;
+    size_t decoded_bytes_ = 0;
     std::unique_ptr<Model> model_;
     std::unique_ptr<Context> ctx_;
     Vocab vocab_;

@@ -110,15 +110,20 @@ struct FakeBackend : IBackend {
         return embd_row.data();
     }
     const float *logits_ith(int i) override { return (i >= 0 && i < (int)last_flag_index.size() && last_flag_index[(size_t)i] >= 0) ? last_logits[(size_t)last_flag_index[(size_t)i]].data() : nullptr; }
-    void kv_clear() override { kv.clear(); kv_ops.push_back("clear"); }
+    // (the op log is written by the loop thread - an idle loop clears the cache on its own - and read / cleared by the test's thread: under a mutex)
+    std::mutex ops_mu;
+    void log_op(std::string op) { std::lock_guard<std::mutex> lk(ops_mu); kv_ops.push_back(std::move(op)); }
+    void clear_ops() { std::lock_guard<std::mutex> lk(ops_mu); kv_ops.clear(); }
+    std::vector<std::string> ops_snapshot() { std::lock_guard<std::mutex> lk(ops_mu); return kv_ops; }
+    void kv_clear() override { kv.clear(); log_op("clear"); }
     bool kv_seq_rm(int seq, int p0, int p1) override {
-        kv_ops.push_back("rm " + std::to_string(seq) + " " + std::to_string(p0) + " " + std::to_string(p1));
+        log_op("rm " + std::to_string(seq) + " " + std::to_string(p0) + " " + std::to_string(p1));
         auto &m = kv[seq];
         for (auto it = m.begin(); it != m.end();) { if (it->first >= (p0 < 0 ? 0 : p0) && (p1 < 0 || it->first < p1)) it = m.erase(it); else ++it; }
         return true;
     }
     void kv_seq_add(int seq, int p0, int p1, int d) override {
-        kv_ops.push_back("add " + std::to_string(seq) + " " + std::to_string(p0) + " " + std::to_string(p1) + " " + std::to_string(d));
+        log_op("add " + std::to_string(seq) + " " + std::to_string(p0) + " " + std::to_string(p1) + " " + std::to_string(d));
         std::map<int, int> nm;
         for (auto &e : kv[seq]) nm[(e.first >= p0 && e.first < p1) ? e.first + d : e.first] = e.second;
         kv[seq] = nm;
@@ -819,7 +824,7 @@ static void test_prompt_cache_and_shift() {
     TaskResult r1 = ctx.NextResult(ctx.RequestCompletion(d, false, false, -1));
     CHECK(r1.stop);
     const size_t ncalls = be.calls_tokens.size();
-    be.kv_ops.clear();
+    be.clear_ops();
     d["prompt"] = "hello world hello world";          // shares the first 4 tokens (BOS + 3 words) with the cached sequence
     TaskResult r2 = ctx.NextResult(ctx.RequestCompletion(d, false, false, -1));
     CHECK(r2.stop);
@@ -828,12 +833,12 @@ static void test_prompt_cache_and_shift() {
     // only the non-cached suffix was decoded as prompt: first new call holds 1 prompt token (the 5th), not 5
     CHECK(be.calls_tokens[ncalls].size() == 1 && be.calls_tokens[ncalls][0] == p2.back() && be.calls_pos[ncalls][0] == 4);
     bool rm4 = false;
-    for (const auto &op : be.kv_ops) if (op == "rm 0 4 -1") rm4 = true;
+    for (const auto &op : be.ops_snapshot()) if (op == "rm 0 4 -1") rm4 = true;
     CHECK(rm4);
     CHECK(r2.result_json["tokens_evaluated"].as_int() == (int64_t)p2.size());
 
     // context shift: generate past the slot context
-    be.kv_ops.clear();
+    be.clear_ops();
     Json g = Json::object();
     g["prompt"] = "hello"; g["n_predict"] = 45; g["temperature"] = 0.0; g["n_keep"] = 1;
     TaskResult r3 = ctx.NextResult(ctx.RequestCompletion(g, false, false, -1));
