@@ -200,7 +200,6 @@ std::unique_ptr<IBackend> make_hip_backend(const Json &body, BackendInfo &info, 
     std::unique_ptr<ClipModel> clip;
     if (!mmproj.empty()) {
         if (model->hp.encoder) { err = "mmproj: an embedding model cannot take a multimodal projector"; return nullptr; }
-        if (model->hp.tp_exchange) { err = "mmproj: not supported together with the row split"; return nullptr; }
         // clip_model_load + the width check of llama_server_context.cc:216-229
         clip.reset(new ClipModel);
         const std::string cerr = clip->load(mmproj, body.value<int>("main_gpu", 0));

@@ -34,7 +34,7 @@ extern char **environ;
 namespace mi355 {
 namespace {
 
-enum Cmd : uint32_t { C_INIT = 1, C_DECODE, C_KV_CLEAR, C_KV_SEQ_RM, C_KV_SEQ_ADD, C_KV_SEQ_CP, C_SET_EMBD, C_QUIT, C_REPLY };
+enum Cmd : uint32_t { C_INIT = 1, C_DECODE, C_KV_CLEAR, C_KV_SEQ_RM, C_KV_SEQ_ADD, C_KV_SEQ_CP, C_SET_EMBD, C_QUIT, C_REPLY, C_DECODE_EMBD, C_LOAD };
 
 bool write_all(int fd, const void *p, size_t n) {
     const uint8_t *b = static_cast<const uint8_t *>(p);
@@ -72,7 +72,7 @@ bool send_msg(int fd, uint32_t type, const void *payload, size_t len) {
 bool recv_msg(int fd, uint32_t &type, std::vector<uint8_t> &payload, long timeout_ms) {
     uint32_t h[2];
     if (!read_all(fd, h, sizeof h, timeout_ms)) return false;
-    if (h[1] > (1u << 28)) return false;
+    if (h[1] > (1u << 30)) return false;
     type = h[0];
     payload.resize(h[1]);
     return h[1] == 0 || read_all(fd, payload.data(), h[1], timeout_ms);
@@ -151,6 +151,27 @@ class SplitBackend : public IBackend {
         if (!collect(rcs)) return -1;
         for (size_t i = 0; i < rcs.size(); i++)
             if (rcs[i] != rc) { fail("row split: rank " + std::to_string(workers[i].rank) + " answered a batch with " + std::to_string(rcs[i]) + ", rank 0 with " + std::to_string(rc)); return -1; }
+        return rc;
+    }
+    // LLaVA over the split: the projector file is rank 0's (the image tower is one pass of small launches per picture, nothing of it is on the token path); the
+    // picture's embedding rows - replicated rows of the residual stream, like every rank's copy of an embedding-table row - travel to the workers with the batch
+    bool multimodal() const override { return local->multimodal(); }
+    bool image_check(const uint8_t *bytes, size_t n, std::string &err) override { return local->image_check(bytes, n, err); }
+    int image_embed(const uint8_t *bytes, size_t n, std::vector<float> &rows, std::string &err) override { return dead_ ? -1 : local->image_embed(bytes, n, rows, err); }
+    int decode_embd(const float *rows, int n, int pos0, int seq) override {
+        if (dead_ || n <= 0) return -1;
+        const size_t E = (size_t)local->n_embd();
+        msg_.resize(12 + (size_t)n * E * 4);
+        const int32_t h[3] = {n, pos0, seq};
+        memcpy(msg_.data(), h, 12);
+        memcpy(msg_.data() + 12, rows, (size_t)n * E * 4);
+        if (!broadcast(C_DECODE_EMBD, msg_.data(), msg_.size())) return -1;
+        const int rc = local->decode_embd(rows, n, pos0, seq);
+        if (shm && shm->dead()) { fail("row split: " + (shm->error().empty() ? std::string("an exchange was abandoned") : shm->error()) + describe_exits()); return -1; }
+        std::vector<int32_t> rcs;
+        if (!collect(rcs)) return -1;
+        for (size_t i = 0; i < rcs.size(); i++)
+            if (rcs[i] != rc) { fail("row split: rank " + std::to_string(workers[i].rank) + " answered an embeddings batch with " + std::to_string(rcs[i]) + ", rank 0 with " + std::to_string(rc)); return -1; }
         return rc;
     }
     const float *logits_ith(int i) override { return dead_ ? nullptr : local->logits_ith(i); }
@@ -342,18 +363,30 @@ std::unique_ptr<IBackend> make_split_backend(const Json &body, BackendInfo &info
         w.pid = pid; w.fd = sv[0]; w.rank = r;
         sb->workers.push_back(w);
         Json init = Json::object();
-        Json wb = body;
-        wb["split_mode"] = "none"; wb["tp_rank"] = r; wb["tp_size"] = ranks; wb["main_gpu"] = (main_gpu + r) % devices; wb["logits_to_host"] = false;
         init["rank"] = r; init["size"] = ranks; init["device"] = (main_gpu + r) % devices;
         init["transport"] = shared ? "shm" : "rccl";
         init["shm_fd"] = shared ? sb->shm->fd() : -1;
         init["shm_cap"] = (int64_t)shm_cap;
         init["timeout_ms"] = (int64_t)step_timeout_ms();
         init["rccl_id"] = hex(id, sizeof id);
-        init["body"] = wb;
         const std::string text = init.dump();
         if (!send_msg(w.fd, C_INIT, text.data(), text.size())) { err = "split_mode row: rank " + std::to_string(r) + " did not take its instructions"; return nullptr; }
     }
+    // what a worker loads: this request's body for its rank and device.  The projector file is rank 0's alone (the image tower is nothing of the token path), but
+    // its presence raises the context (hip_backend.cc: 2048 cells, 4096 for an image grid) - the workers must hold the same number of cells, so with `mmproj`
+    // they are told what to load only once rank 0 knows its own context
+    const bool has_mmproj = body["mmproj"].is_string() && !body["mmproj"].as_string().empty();
+    auto send_loads = [&](int n_ctx_of_rank0) -> bool {
+        for (auto &w : sb->workers) {
+            Json wb = body;
+            wb["split_mode"] = "none"; wb["tp_rank"] = w.rank; wb["tp_size"] = ranks; wb["main_gpu"] = (main_gpu + w.rank) % devices; wb["logits_to_host"] = false;
+            if (has_mmproj) { wb["mmproj"] = Json(); wb["ctx_len"] = n_ctx_of_rank0; }
+            const std::string text = wb.dump();
+            if (!send_msg(w.fd, C_LOAD, text.data(), text.size())) { err = "split_mode row: rank " + std::to_string(w.rank) + " did not take its load request"; return false; }
+        }
+        return true;
+    };
+    if (!has_mmproj && !send_loads(0)) { sb->fail(err); return nullptr; }
     // ---- this process = rank 0
     if (shared) tp_set_host_exchange(&ShmExchange::callback, sb->shm.get(), 0, ranks);
     else {
@@ -365,7 +398,9 @@ std::unique_ptr<IBackend> make_split_backend(const Json &body, BackendInfo &info
     BackendInfo li;
     std::string lerr;
     sb->local = make_hip_backend(lb, li, lerr);
-    // ---- every worker's answer to its load (also when this rank's own load failed: they are told to go in ~SplitBackend)
+    if (!sb->local) { err = lerr.empty() ? "split_mode row: rank 0 failed to load" : lerr; sb->fail(err); return nullptr; }      // (the workers are ended: nobody waits for their loads)
+    if (has_mmproj && !send_loads(sb->local->n_ctx())) { sb->fail(err); return nullptr; }
+    // ---- every worker's answer to its load
     std::string werr;
     uint64_t vram = li.vram;
     for (auto &w : sb->workers) {
@@ -384,7 +419,6 @@ std::unique_ptr<IBackend> make_split_backend(const Json &body, BackendInfo &info
         if (!rep["ok"].as_bool()) { if (werr.empty()) werr = "rank " + std::to_string(w.rank) + ": " + rep["error"].str_or("load failed"); continue; }
         vram += (uint64_t)rep["vram"].as_int();
     }
-    if (!sb->local) { err = lerr.empty() ? "split_mode row: rank 0 failed to load" : lerr; sb->fail(err); return nullptr; }
     if (!werr.empty()) { err = "split_mode row: " + werr; sb->fail(err); return nullptr; }
     info = li;
     info.vram = vram;
@@ -419,8 +453,11 @@ int tp_split_worker_main(int fd) {
         if (!unhex(init["rccl_id"].str_or(""), id) || id.size() != 128) { reply_load(false, "bad RCCL id", 0); return 3; }
         if (tp_init(rank, size, id.data(), id.size(), err) != 0) { reply_load(false, err, 0); return 3; }
     }
+    if (!recv_msg(fd, type, pl, -1) || type != C_LOAD) { tp_set_host_exchange(nullptr, nullptr, 0, 1); tp_shutdown(); return type == C_QUIT ? 0 : 2; }   // (rank 0's own load failed: told to go)
+    Json load_body;
+    if (!Json::parse(std::string(pl.begin(), pl.end()), load_body)) { reply_load(false, "bad load request", 0); return 3; }
     BackendInfo info;
-    std::unique_ptr<IBackend> be = make_hip_backend(init["body"], info, err);
+    std::unique_ptr<IBackend> be = make_hip_backend(load_body, info, err);
     if (!be) { reply_load(false, err, 0); tp_set_host_exchange(nullptr, nullptr, 0, 1); tp_shutdown(); return 3; }
     reply_load(true, "", info.vram);
 
@@ -445,6 +482,14 @@ int tp_split_worker_main(int fd) {
                 b.n_tokens = n; b.token = a + 1; b.pos = a + 1 + n; b.seq_id = a + 1 + 2 * n;
                 b.logits = reinterpret_cast<const int8_t *>(pl.data() + 4 + (size_t)n * 12);
                 const int rc = be->decode(b);
+                sent = reply_rc(rc, be->last_error());
+                break;
+            }
+            case C_DECODE_EMBD: {
+                if (pl.size() < 12) { code = 5; break; }
+                const int32_t n = a[0];
+                if (n <= 0 || pl.size() != 12 + (size_t)n * (size_t)be->n_embd() * 4) { code = 5; break; }
+                const int rc = be->decode_embd(reinterpret_cast<const float *>(pl.data() + 12), n, a[1], a[2]);
                 sent = reply_rc(rc, be->last_error());
                 break;
             }

@@ -221,3 +221,31 @@ def test_image_grid_model(pkg, files, tmp_path_factory):
     assert len(clip.embed_bytes(png)) == 64
     clip.close()
     e.close()
+
+
+def test_image_request_over_a_row_split(pkg, files):
+    """`mmproj` together with `"split_mode": "row"` (round 6): the projector file is rank 0's, the picture's embedding rows travel to the worker ranks as an
+    embeddings batch, every rank holds the context the projector asks for - the answer is the unsplit engine's for the same request, step by step up to near-ties."""
+    png = encoded(photo(64, 48, 31))
+    msgs = [{"role": "user", "content": [{"type": "text", "text": "look "}, {"type": "image_url", "image_url": {"url": data_url(png)}}, {"type": "text", "text": " and say"}]}]
+
+    def ask(**extra):
+        e = pkg.Engine()
+        try:
+            st, body = e.load_model(llama_model_path=files[0], mmproj=files[1], model="mm", ctx_len=512, n_parallel=1, user_prompt="u:", ai_prompt="a:", system_prompt="s:", **extra)
+            assert st["status_code"] == 200 and not st["has_error"], (st, body)
+            st, body = e.chat_completion(model="mm", messages=msgs, max_tokens=10, n_probs=2, **GREEDY)[-1]
+            assert st["status_code"] == 200 and not st["has_error"], (st, body)
+            ch = body["choices"][0]
+            return ([(t["content"], [float(c["prob"]) for c in t["probs"]]) for t in ch["logprobs"]], body["usage"]["prompt_tokens"])
+        finally:
+            e.close()
+    (want, want_pt), (got, got_pt) = ask(), ask(split_mode="row", split_ranks=2)
+    assert got_pt == want_pt and want_pt > 16                    # the image's rows count as prompt tokens on both
+    n = 0
+    for (gp, _), (wp, wprobs) in zip(got, want):
+        if gp != wp:
+            assert len(wprobs) >= 2 and wprobs[1] >= 0.6 * wprobs[0], (n, gp, wp, wprobs)
+            break
+        n += 1
+    assert n >= 3, n
