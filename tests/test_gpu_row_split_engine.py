@@ -184,3 +184,23 @@ def test_prompt_cache_and_context_shift_travel_to_every_rank(pkg, tmp_path_facto
     same = [_same_up_to_near_ties(g, w) for g, w in zip(got, want)]
     assert same[0] >= 4 and same[1] >= 4, same
     assert got[2][2] == want[2][2] == 120                        # both generated through the shift
+
+
+def test_embeddings_over_the_split(pkg, model_70b):
+    """/v1/embeddings over the split: llama_set_embeddings reaches every rank, the pooled hidden state (the residual stream is replicated) is rank 0's - the
+    unsplit engine's vector up to the flip tolerance"""
+    import numpy as np
+
+    def emb(**extra):
+        e = pkg.Engine()
+        try:
+            st, body = e.load_model(llama_model_path=model_70b, model="emb", ctx_len=256, n_parallel=1, cache_type="q8_0", **extra)
+            assert st["status_code"] == 200, (st, body)
+            st, body = e.embedding(model="emb", input=["hello world", "the quick brown fox"])
+            assert st["status_code"] == 200 and not st["has_error"], (st, body)
+            return np.asarray([d["embedding"] for d in body["data"]], np.float64)
+        finally:
+            e.close()
+    want, got = emb(), emb(split_mode="row", split_ranks=4)
+    assert want.shape == got.shape and np.isfinite(got).all()
+    assert float(np.abs(got - want).max() / max(1.0, np.abs(want).max())) <= 3e-2
