@@ -8,7 +8,7 @@ CASE='tests/test_gpu_tp.py::test_prompt_sized_exchange_as_reduce_scatter_all_gat
 : > gpurun_out/r6_tp_isolated10.txt
 for i in $(seq 1 $N); do
   s=$(date +%s)
-  MI355_TP_TRACE=1 MI355_TP_YIELD_TIMEOUT_S=8 timeout 600 python -m pytest "$CASE" -x -q -p no:cacheprovider > gpurun_out/r6_tp_diag_$i.log 2>&1
+  MI355_TP_TRACE=1 MI355_TP_YIELD_TIMEOUT_S=8 MI355_TP_FRESH_PROCESS=1 timeout 600 python -m pytest "$CASE" -x -q -p no:cacheprovider > gpurun_out/r6_tp_diag_$i.log 2>&1
   rc=$?
   echo "run $i rc=$rc $(tail -1 gpurun_out/r6_tp_diag_$i.log) wall $(( $(date +%s) - s )) s" | tee -a gpurun_out/r6_tp_isolated10.txt
   if [ $rc -ne 0 ]; then break; fi

@@ -6,7 +6,7 @@ CASE='tests/test_gpu_tp.py::test_prompt_sized_exchange_as_reduce_scatter_all_gat
 : > gpurun_out/r6_tp_isolated10.txt
 for i in 1 2 3 4 5 6 7 8 9 10; do
   s=$(date +%s)
-  timeout 600 python -m pytest "$CASE" -x -q -p no:cacheprovider > gpurun_out/r6_tp_iso_$i.log 2>&1
+  MI355_TP_FRESH_PROCESS=1 timeout 600 python -m pytest "$CASE" -x -q -p no:cacheprovider > gpurun_out/r6_tp_iso_$i.log 2>&1
   rc=$?
   e=$(date +%s)
   echo "run $i: rc=$rc $(tail -1 gpurun_out/r6_tp_iso_$i.log) wall $((e - s)) s" | tee -a gpurun_out/r6_tp_isolated10.txt
