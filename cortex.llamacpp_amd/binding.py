@@ -82,6 +82,7 @@ SYMBOLS = {
     "mi355_debug_mega_steps": (C.c_int64, [_vp]),
     "mi355_debug_engine_steps": (C.c_int64, [_vp]),
     "mi355_debug_fused_skipped_steps": (C.c_int64, [_vp]),
+    "mi355_debug_qkv_attn_launches": (C.c_int64, [_vp]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
     "mi355_get_embeddings_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_synchronize": (None, [_vp]),
@@ -647,6 +648,9 @@ class Context:
 
     def fused_skipped_steps(self) -> int:
         return int(self.lib.mi355_debug_fused_skipped_steps(self.h))
+
+    def qkv_attn_launches(self) -> int:
+        return int(self.lib.mi355_debug_qkv_attn_launches(self.h))
 
     def engine_steps(self) -> int:
         """Single-token steps that ran through the layer engine (one persistent launch per layer; diagnosis)."""

@@ -83,11 +83,27 @@ template <int R, int C> struct AOSmem {
     int last_flag;
 };
 
-// LDS: [0, slice_lds) the W_o rows | qs [K] | d (1 KiB of room) | bs [K / 8, whole KiB] | AOSmem
-struct AOLayout { unsigned qs, d, bs, attn, total; };
-__host__ __device__ inline AOLayout ao_layout(unsigned slice_lds, int K, size_t attn_bytes) {
+// Round 6, QF (KB > 0): Q | K | V of the layer inside this launch (see qf_* below and the note in front of ao_body).  The three tensors as the weight
+// stream would plan them (mmvq_stream_plan: workgroups per tensor in proportion to its bytes, a workgroup's rows are of ONE tensor, contiguous).
+struct QFArgs {
+    const uint8_t *W0, *W1, *W2;
+    unsigned rb0, rb1, rb2;
+    int t0, t1, t2, n0, n1, n2;
+    int blk1, blk2, blk3;            // first workgroup of tensor 1, of tensor 2, and one past the last workgroup with rows
+    const float *nx, *nw; float neps; int K;     // the layer's input row, the attn_norm weights; K = n_embd (== H * D here)
+    unsigned long long *gran;         // the token's q | k | v as tagged granules {tag, f32 bits}: H * D + 2 * G * D of them, shared by the layers of a step (the tag names the layer)
+    int n_q, n_kv;                    // H * D, G * D
+    unsigned qkv_lds;                 // LDS bytes reserved for the workgroup's Q | K | V rows (whole 4 KiB slots)
+};
+constexpr unsigned AO_QF_HDR = 512;   // QF: the weight stream's sync words and reduction scratch in front of everything (mmvq_stream_dev.h ST_OFF_SYNC, ST_OFF_RED)
+
+// LDS: [QF: 512 B of sync words] | [.., + slice_lds) the W_o rows | [QF: the Q | K | V rows] | qs [K] | d (1 KiB of room) | bs [K / 8, whole KiB] | AOSmem
+struct AOLayout { unsigned wo, qkv, qs, d, bs, attn, total; };
+__host__ __device__ inline AOLayout ao_layout(unsigned slice_lds, int K, size_t attn_bytes, unsigned hdr = 0, unsigned qkv_lds = 0) {
     AOLayout l;
-    l.qs = slice_lds;
+    l.wo = hdr;
+    l.qkv = hdr + slice_lds;
+    l.qs = l.qkv + qkv_lds;
     l.d = l.qs + (unsigned)K;
     l.bs = l.d + 1024u;
     l.attn = l.bs + (((unsigned)K / 8u + 1023u) & ~1023u);
@@ -115,6 +131,89 @@ __device__ __forceinline__ void ao_issue_dma(const AOArgs &o, uint8_t *smem, int
     }
 }
 
+// What an item requests from memory before it can compute anything.  QF: the part that does not depend on this launch's Q | K | V (cell metadata, the chunk's
+// K / V rows and scales, the rope table) is requested BEFORE the workgroup's share of the projections is computed and sits in registers meanwhile; q and the token's
+// K / V row arrive later as granules.
+template <int R, int TK, int TV, int C> struct AOItemLd {
+    static constexpr int KROW = TK == T_F16 ? 2 * AO_D : AO_D, LPC = KROW / 16, KP = C * LPC / AO_NT, CPG = C / AO_NCG;
+    int chunk; bool skip;
+    int cpos; unsigned long long cseq;
+    f32x2_t qv, csv;
+    u32x4_t kreg[KP];
+    u32x2_t vreg[CPG];
+    uint32_t ks2, vs2;
+    f32x4_t xn4, cs4;
+};
+template <int R, int TK, int TV, int C, bool QF>
+__device__ __forceinline__ void ao_item_issue(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, int g, int sp, AOItemLd<R, TK, TV, C> &ld) {
+    constexpr int D = AO_D, NB = AO_NB, NT = AO_NT;
+    constexpr int KROW = TK == T_F16 ? 2 * D : D;
+    constexpr int LPC = KROW / 16;                           // lanes per cell in the score pass
+    constexpr int KP = C * LPC / NT;                         // 16-byte K pieces per thread
+    static_assert(C * LPC % NT == 0 && KP >= 1, "chunk size");
+    constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
+    const int tid = tid_now(), lane = tid & 63;
+    const int n_ctx = a.n_ctx;
+    ld.chunk = sp; ld.skip = false;
+    if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
+        if (sp >= a.tok_nchunks[0]) { ld.skip = true; return; }
+        ld.chunk = a.tok_chunks[sp];
+    }
+    const int c_lo = ld.chunk * C;
+    const size_t head_row0 = (size_t)g * n_ctx;
+
+    // ---- every global load of the item
+    ld.cpos = -1;
+    ld.cseq = 0;
+    if (tid < C && c_lo + tid < n_ctx) { ld.cpos = a.cell_pos[c_lo + tid]; ld.cseq = a.cell_seq[c_lo + tid]; }
+    constexpr int HP = D / 2, NPAIR = R * HP;
+    static_assert(NPAIR <= NT, "query pairs per thread");
+    ld.qv = f32x2_t{0.0f, 0.0f}; ld.csv = f32x2_t{1.0f, 0.0f};
+    if (tid < NPAIR) {
+        const int r = tid / HP, i = tid % HP;
+        if (!QF) ld.qv = *reinterpret_cast<const f32x2_t *>(a.q + ((size_t)g * R + r) * D + 2 * i);
+        if (2 * i < n_rot) ld.csv = *reinterpret_cast<const f32x2_t *>(cs_table + 2 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + NT * j;
+        int cell = c_lo + p / LPC;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TK == T_F16) ld.kreg[j] = *reinterpret_cast<const u32x4_t *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
+        else ld.kreg[j] = *reinterpret_cast<const u32x4_t *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
+    }
+    const int dq = tid % DQ, cg = tid / DQ;
+#pragma unroll
+    for (int i = 0; i < CPG; i++) {
+        int cell = c_lo + cg + NCG * i;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TV == T_F16) ld.vreg[i] = *reinterpret_cast<const u32x2_t *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+        else { ld.vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); ld.vreg[i].y = 0; }
+    }
+    ld.ks2 = 0; ld.vs2 = 0;
+    if (tid < C * NB / 2) {
+        int cell = c_lo + tid / (NB / 2);
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        if (TK != T_F16) ld.ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+        if (TV != T_F16) ld.vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+    }
+
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+    // the token's un-rotated K / V row of this kv head: 1 KB, requested by wave 0 of EVERY item now (which chunk holds the token's cell is only known once
+    // the scalars are back; waiting for them first cost that chunk - every kv head's slowest item - a second memory round trip)
+    // (every wave, unconditionally: a load under a condition makes hipcc wait for ALL outstanding loads where the branches join)
+    // (native vector types: HIP's float4 class, modified under a condition below, is placed in scratch by hipcc)
+    {
+        const bool isk = lane < 32;
+        const int dd = (lane & 31) * 4;
+        if (!QF) ld.xn4 = *reinterpret_cast<const f32x4_t *>((isk ? fz.knew : fz.vnew) + g * D + dd);
+        else ld.xn4 = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        ld.cs4 = *reinterpret_cast<const f32x4_t *>(cs_table + (dd < n_rot ? dd : n_rot - 4));   // c0 s0 c1 s1 (clamped: used only where dd < n_rot)
+    }
+}
+
 // ---- one attention item (kv head g, chunk slot sp) on the 512 threads of the workgroup; every exit is workgroup-uniform.  `dma` (the request for the
 // workgroup's W_o rows; it does nothing after its first call) is called by every wave once the item has nothing outstanding and nobody waits for it.
 // the step's scalars every item needs, read in one batch of scalar loads UNDER the item's vector loads
@@ -125,82 +224,63 @@ __device__ __forceinline__ AOScalars ao_load_scalars(const unsigned *serial, con
                  : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(serial), "s"(tpos), "s"(tseq), "s"(cell) : "memory");
     return AOScalars{s0, s1, s2, s3};
 }
-template <int R, int TK, int TV, int C, class Dma>
-__device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o,
-                                             int g, int sp, AOSmem<R, C> &sm, Dma dma) {
+// qf (QF only): the launch's own Q | K | V granules and the step's scalars, read at the top of the launch
+template <int R, int TK, int TV, int C, bool QF, class Dma>
+__device__ __forceinline__ void ao_item_run(const AttnArgs &a, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f, const AOScalars *pre,
+                                            int g, int sp, AOSmem<R, C> &sm, AOItemLd<R, TK, TV, C> &ld, Dma dma) {
     constexpr int D = AO_D, NB = AO_NB, NT = AO_NT;
     constexpr int KROW = TK == T_F16 ? 2 * D : D;
     constexpr int LPC = KROW / 16;                           // lanes per cell in the score pass
     constexpr int KP = C * LPC / NT;                         // 16-byte K pieces per thread
-    static_assert(C * LPC % NT == 0 && KP >= 1, "chunk size");
     constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
     constexpr int CL = C / 64;                               // cells per lane in the softmax
+    constexpr int HP = D / 2, NPAIR = R * HP;
     const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
     const int n_ctx = a.n_ctx;
-    int chunk = sp;
-    if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
-        if (sp >= a.tok_nchunks[0]) { dma(); return; }
-        chunk = a.tok_chunks[sp];
-    }
-    const int c_lo = chunk * C;
+    if (ld.skip) { dma(); return; }
+    const int c_lo = ld.chunk * C;
     const size_t head_row0 = (size_t)g * n_ctx;
-
-    // ---- every global load of the item
-    int cpos = -1;
-    unsigned long long cseq = 0;
-    if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
-    constexpr int HP = D / 2, NPAIR = R * HP;
-    static_assert(NPAIR <= NT, "query pairs per thread");
-    f32x2_t qv = {0.0f, 0.0f}, csv = {1.0f, 0.0f};
-    if (tid < NPAIR) {
-        const int r = tid / HP, i = tid % HP;
-        qv = *reinterpret_cast<const f32x2_t *>(a.q + ((size_t)g * R + r) * D + 2 * i);
-        if (2 * i < n_rot) csv = *reinterpret_cast<const f32x2_t *>(cs_table + 2 * i);
-    }
+    const int cpos = ld.cpos;
+    const unsigned long long cseq = ld.cseq;
+    const uint32_t ks2 = ld.ks2, vs2 = ld.vs2;
+    const f32x2_t csv = ld.csv;
+    const f32x4_t cs4 = ld.cs4;
     u32x4_t kreg[KP];
-#pragma unroll
-    for (int j = 0; j < KP; j++) {
-        const int p = tid + NT * j;
-        int cell = c_lo + p / LPC;
-        if (cell >= n_ctx) cell = n_ctx - 1;
-        const size_t rowi = head_row0 + cell;
-        if (TK == T_F16) kreg[j] = *reinterpret_cast<const u32x4_t *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
-        else kreg[j] = *reinterpret_cast<const u32x4_t *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
-    }
-    const int dq = tid % DQ, cg = tid / DQ;
     u32x2_t vreg[CPG];
 #pragma unroll
-    for (int i = 0; i < CPG; i++) {
-        int cell = c_lo + cg + NCG * i;
-        if (cell >= n_ctx) cell = n_ctx - 1;
-        const size_t rowi = head_row0 + cell;
-        if (TV == T_F16) vreg[i] = *reinterpret_cast<const u32x2_t *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
-        else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
-    }
-    uint32_t ks2 = 0, vs2 = 0;
-    if (tid < C * NB / 2) {
-        int cell = c_lo + tid / (NB / 2);
-        if (cell >= n_ctx) cell = n_ctx - 1;
-        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
-        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
-    }
-
-    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
-    // the token's un-rotated K / V row of this kv head: 1 KB, requested by wave 0 of EVERY item now (which chunk holds the token's cell is only known once
-    // the scalars are back; waiting for them first cost that chunk - every kv head's slowest item - a second memory round trip)
-    // (every wave, unconditionally: a load under a condition makes hipcc wait for ALL outstanding loads where the branches join)
-    // (native vector types: HIP's float4 class, modified under a condition below, is placed in scratch by hipcc)
-    f32x4_t xn4, cs4;
-    {
-        const bool isk = lane < 32;
-        const int dd = (lane & 31) * 4;
-        xn4 = *reinterpret_cast<const f32x4_t *>((isk ? fz.knew : fz.vnew) + g * D + dd);
-        cs4 = *reinterpret_cast<const f32x4_t *>(cs_table + (dd < n_rot ? dd : n_rot - 4));   // c0 s0 c1 s1 (clamped: used only where dd < n_rot)
-    }
-    // ---- the step's scalars (one batch of scalar loads, under the vector loads above)
-    const AOScalars sc = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
+    for (int j = 0; j < KP; j++) kreg[j] = ld.kreg[j];
+#pragma unroll
+    for (int i = 0; i < CPG; i++) vreg[i] = ld.vreg[i];
+    const int dq = tid % DQ, cg = tid / DQ;
+    // ---- the step's scalars (one batch of scalar loads, under the vector loads above; QF: read at the top of the launch)
+    const AOScalars sc = QF ? *pre : ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
     const unsigned serial = sc.serial;
     const int tpos = sc.tpos, tseq = sc.tseq;
+    f32x2_t qv = ld.qv;
+    f32x4_t xn4 = ld.xn4;
+    if constexpr (QF) {
+        // q of this kv head's R query heads and (wave 0) the token's K / V row of this kv head, as the projections' workgroups published them: tagged
+        // granules, swept until every one carries this step's and this layer's tag (data and validity in one 8-byte store: nothing to fence)
+        const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
+        const __amdgpu_buffer_rsrc_t qrs = coh_rsrc(f.gran);
+        const bool isk = lane < 32;
+        const int dd = (lane & 31) * 4;
+        const int qoff = (int)((((size_t)g * R + (tid < NPAIR ? tid / HP : 0)) * D + 2 * (tid % HP)) * 8);
+        const int koff = (int)(((size_t)f.n_q + (isk ? 0 : (size_t)f.n_kv) + (size_t)g * D + dd) * 8);
+        coh_u32x4 qg = {0u, tag, 0u, tag}, k0 = {0u, tag, 0u, tag}, k1 = {0u, tag, 0u, tag};
+        int spins = 0;
+        for (;;) {
+            if (tid < NPAIR) qg = __builtin_amdgcn_raw_buffer_load_b128(qrs, qoff, 0, 16);                 // (wave-uniform: NPAIR is a multiple of 64)
+            if (wave == 0) { k0 = __builtin_amdgcn_raw_buffer_load_b128(qrs, koff, 0, 16); k1 = __builtin_amdgcn_raw_buffer_load_b128(qrs, koff + 16, 0, 16); }
+            const bool ok = qg.y == tag && qg.w == tag && k0.y == tag && k0.w == tag && k1.y == tag && k1.w == tag;
+            if (__all(ok)) break;
+            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        qv = f32x2_t{__uint_as_float(qg.x), __uint_as_float(qg.z)};
+        xn4 = f32x4_t{__uint_as_float(k0.x), __uint_as_float(k0.z), __uint_as_float(k1.x), __uint_as_float(k1.z)};
+        if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
+    }
     // ---- this token's own K / V row (the chunk that holds its cell): rotate K, convert, write the cache row, keep the codes for the patch below
     int own_cl = -1;
     {
@@ -546,44 +626,186 @@ __device__ __forceinline__ void ao_decode(const AOArgs &o, const uint8_t *slice,
     }
 }
 
-template <int R, int TK, int TV, int C>
-__global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // The kernel argument segment is cold at every launch and hipcc reads a field where it is first used: seven dependent scalar-load round trips sat in front
-    // of the first K / V request (1.4 us from entry to "loads issued", MI355_AO_PROBE).  One independent read per 64-byte line of the segment, all in flight
-    // together, makes the later field reads scalar-cache hits.
-    {
-        struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; };
-        const __attribute__((address_space(4))) unsigned *ka = (const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_kernarg_segment_ptr();
-        unsigned acc = 0;
-#pragma unroll
-        for (int i = 0; i < (int)((sizeof(KArgs) + 63) / 64); i++) acc ^= ka[i * 16];
-        asm volatile("" :: "s"(acc));
+// ================================================================= QF: the layer's Q | K | V inside the same launch (round 6)
+// The per-launch path ran [Q | K | V: weight stream, 6.8 us for 14.7 MB] -> boundary -> [this kernel: 13 us] per layer, and the second launch's first 2 us are
+// spent waiting for its own K / V cache rows, which do not depend on the first launch at all.  Both launches' weights fit in LDS at once (Q | K | V: ~58 KB per
+// workgroup, W_o: 37 KB), so: ten waves per workgroup; waves 8 and 9 are LOADERS (mmvq_stream_dev.h's division of labour: only they ever sit in the memory queue) -
+// they copy the workgroup's Q | K | V rows and then its W_o rows HBM -> LDS by DMA, publish what has landed and END (a barrier only counts live waves); waves 0 - 7:
+//   1. request the layer input and the norm weights (early_issue), an item workgroup also its chunk's K / V rows, scales and cell metadata - into registers, where
+//      they wait for q -, then the step's scalars; only then are the loaders let go ([SY_GO]: a small request queued behind the stream waits for all of it);
+//   2. RMSNorm * w -> Q8_K exactly as the weight stream's prologue does (consumer_prologue: same code, same bits), decode the workgroup's rows out of LDS with the
+//      stream's decoders as the slots land, and publish every result as ONE 8-byte granule {tag, f32 bits} written through to the coherence point;
+//   3. item workgroups sweep the granules of their kv head (q: 2 KB, the K / V row: 1 KB) until each carries the tag and carry on as before; W_o is on chip long
+//      before the merged codes arrive.
+// One launch and one boundary less per layer, and the attention's first memory round trip under the projections.  Outputs are bit-identical to the two launches.
+struct QFRun { const uint8_t *W; unsigned rb, total; int type, b0, nrw, grow0, ns; };     // grow0: granule index of row b0; ns: 4 KiB slots of the run
+__device__ __forceinline__ QFRun qf_setup(QFArgs f) {
+    // (through opaque copies: from adjacent kernel arguments selected by one index hipcc builds a table in scratch memory)
+    asm volatile("" : "+s"(f.rb0), "+s"(f.rb1), "+s"(f.rb2), "+s"(f.t0), "+s"(f.t1), "+s"(f.t2), "+s"(f.n0), "+s"(f.n1), "+s"(f.n2));
+    const int b = (int)blockIdx.x;
+    const int s = b >= f.blk2 ? 2 : b >= f.blk1 ? 1 : 0;
+    const int lo = s == 0 ? 0 : s == 1 ? f.blk1 : f.blk2, hi = s == 0 ? f.blk1 : s == 1 ? f.blk2 : f.blk3;
+    QFRun q;
+    q.W = s == 0 ? f.W0 : s == 1 ? f.W1 : f.W2;
+    q.rb = s == 0 ? f.rb0 : s == 1 ? f.rb1 : f.rb2;
+    q.type = s == 0 ? f.t0 : s == 1 ? f.t1 : f.t2;
+    const int n_rows = s == 0 ? f.n0 : s == 1 ? f.n1 : f.n2;
+    const int nblk = hi - lo, bl = b - lo;
+    int b0 = 0, b1 = 0;
+    if (nblk > 0 && b < f.blk3) {                                 // (op_setup's deal of a tensor's rows over its workgroups)
+        const int rpb = (n_rows + nblk - 1) / nblk;
+        b0 = bl * rpb; b1 = b0 + rpb;
+        if (b0 > n_rows) b0 = n_rows;
+        if (b1 > n_rows) b1 = n_rows;
     }
+    q.b0 = b0; q.nrw = b1 - b0;
+    q.grow0 = (s == 0 ? 0 : s == 1 ? f.n_q : f.n_q + f.n_kv) + b0;
+    q.total = (unsigned)q.nrw * q.rb;
+    q.ns = (int)((q.total + ST_SLOT - 1) / ST_SLOT);
+    return q;
+}
+// a loader wave (lq = 0, 1): global slot j of the workgroup = slot j of its Q | K | V run, then the slots of its W_o run; loader lq copies the slots j = lq mod 2
+// and publishes how many of ITS slots have landed ([SY_LANDED + lq]; they land in order).  At most 15 slots = 60 DMA instructions per loader: what the wave's
+// vector-memory counter can count (the launcher checks the sum).
+__device__ __forceinline__ void qf_loader(const QFRun &q, const AOArgs &o, uint8_t *smem, const AOLayout &lay, int b0o, int nrwo, int lq, int lane) {
+    int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
+    ST_SPIN_WHILE(ld_sync(sy + SY_GO) < AO_NW, 0);
+    const unsigned total_o = nrwo > 0 ? (unsigned)nrwo * o.row_bytes : 0u;
+    const int nso = (int)((total_o + ST_SLOT - 1) / ST_SLOT);
+    const uint8_t *src_q = q.W + (size_t)q.b0 * q.rb, *src_o = o.W + (size_t)b0o * o.row_bytes;
+    const unsigned lds_q = lds_addr(smem + lay.qkv), lds_o = lds_addr(smem + lay.wo);
+    int issued = 0, published = 0;
+    auto publish = [&]() {
+        const int landed = (ST_SI * issued - vm_outstanding()) / ST_SI;
+        if (landed > published) { published = landed; st_sync(sy + SY_LANDED + lq, landed); }
+    };
+    for (int j = lq; j < q.ns + nso; j += 2) {
+        const bool isq = j < q.ns;
+        const uint8_t *src = isq ? src_q : src_o;
+        const unsigned total = isq ? q.total : total_o, last = total - 16u;
+        const unsigned off = (unsigned)(isq ? j : j - q.ns) * ST_SLOT;
+        const unsigned dst = (isq ? lds_q : lds_o) + off;
+        if (off + ST_SLOT <= total) dma_slot(src + off + (size_t)lane * 16, dst);
+        else {
+#pragma unroll
+            for (int p = 0; p < ST_SI; p++) {
+                const unsigned x = off + (unsigned)lane * 16u + p * 1024u;       // past the end: every such lane re-reads the run's last 16 B
+                dma16<true>(src + (x < total ? x : last), dst + p * 1024);
+            }
+        }
+        issued++;
+        publish();
+    }
+    int polls = 0;
+    while (published < issued) {
+        if (++polls >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_DRAIN); break; }
+        publish(); __builtin_amdgcn_s_sleep(1);
+    }
+}
+// waves 0 - 7: row pairs w, w + 8, .. of the workgroup's Q | K | V rows out of LDS (consumer_op's arithmetic, as ao_decode below), each result one granule
+template <int TYPE>
+__device__ __forceinline__ void qf_decode(const QFRun &q, const QFArgs &f, const uint8_t *slice, const ActL &AL, int *sy, unsigned tag, int wave, int lane) {
+    using Rw = Raw<TYPE>;
+    const LaneRole L = make_role<TYPE>(lane);
+    constexpr int SBP = role_sbp<TYPE>();
+    const int nb = f.K >> 8, NP = (nb + SBP - 1) / SBP;
+    const unsigned rb = q.rb;
+    const int n_steps = (q.nrw + 1) >> 1;
+    for (int s = wave; s < n_steps; s += AO_NW) {
+        const bool two = 2 * s + 1 < q.nrw;
+        const unsigned off0 = 2u * (unsigned)s * rb, off1 = two ? off0 + rb : off0;
+        const unsigned n = (off0 + (two ? 2u : 1u) * rb + ST_SLOT - 1) / ST_SLOT;       // slots [0, n) of the run hold the step's rows
+        const int need0 = (int)((n + 1u) >> 1), need1 = (int)(n >> 1);
+        ST_SPIN_WHILE(ld_sync(sy + SY_LANDED) < need0 || ld_sync(sy + SY_LANDED + 1) < need1, 1);
+        float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 2
+        for (int p = 0; p < NP; p++) {
+            const ActSlice sl = read_slice_t<TYPE>(AL, p * SBP + L.sbl, nb, L);
+            int sb = p * SBP + L.sbl;
+            if (sb >= nb) sb = nb - 1;
+            Rw w0, w1;
+            ring_load<false>(w0, slice, 0u, off0, nb, sb, L);
+            ring_load<false>(w1, slice, 0u, off1, nb, sb, L);
+            acc0 += w0.dot(sl, L);
+            acc1 += w1.dot(sl, L);
+        }
+        const float v0 = wave_sum(acc0), v1 = wave_sum(acc1);
+        if (lane == 0) {
+            const int gr = q.grow0 + 2 * s;
+            st_store_granule(f.gran + gr, tag, __float_as_uint(v0));
+            if (two) st_store_granule(f.gran + gr + 1, tag, __float_as_uint(v1));
+        }
+    }
+}
+
+template <int R, int TK, int TV, int C, int KB>
+__device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr bool QF = KB > 0;
     const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
+    if constexpr (QF) sync_init(smem);                 // (all ten waves)
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
-    const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>));
+    const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>), QF ? AO_QF_HDR : 0u, QF ? f.qkv_lds : 0u);
     AOSmem<R, C> &sm = *reinterpret_cast<AOSmem<R, C> *>(smem + lay.attn);
     const int b0r = (int)blockIdx.x * o.rows_per_wg;
     const int b0 = b0r < o.n_rows ? b0r : o.n_rows;
     const int nrw = b0 + o.rows_per_wg <= o.n_rows ? o.rows_per_wg : o.n_rows - b0;
+    QFRun qr{};
+    if constexpr (QF) {
+        qr = qf_setup(f);
+        if (wave >= AO_NW) { qf_loader(qr, o, smem, lay, b0, nrw, wave - AO_NW, lane); return; }
+    }
     // residual of this wave's first row pair: requested now, used at the very end
     float rs0 = 0.0f, rs1 = 0.0f;
     if (o.epi == EPI_ADD && 2 * wave < nrw) {
         rs0 = o.resid[b0 + 2 * wave];
         if (2 * wave + 1 < nrw) rs1 = o.resid[b0 + 2 * wave + 1];
     }
-    bool dma_done = false;
-    auto dma = [&]() { if (!dma_done) { ao_issue_dma(o, smem, b0, nrw, wave, lane); dma_done = true; } };
+    bool dma_done = QF;                                // (QF: the loaders bring the W_o rows)
+    auto dma = [&]() { if (!dma_done) { ao_issue_dma(o, smem + lay.wo, b0, nrw, wave, lane); dma_done = true; } };
     const int G = a.G;
+    int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
+    AOScalars scal{};
     bool had_item = false;
-    for (int it = (int)blockIdx.x; it < o.n_items; it += (int)gridDim.x) {
+    int it0 = (int)blockIdx.x;
+    if constexpr (QF) {
+        static_assert(ST_NC == AO_NW, "the weight stream's prologue is cut for eight consumer waves");
+        EarlyAct<KB> ea;
+        early_issue<KB, 1>(f.nx, f.nw, f.K, wave, lane, ea);
+        const bool pre_item = it0 < o.n_items;         // (workgroup-uniform)
+        AOItemLd<R, TK, TV, C> ld0;
+        if (pre_item) ao_item_issue<R, TK, TV, C, true>(a, cs_table, n_rot, fz, o, it0 % G, it0 / G, ld0);
+        scal = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
+        StOp pa{};
+        pa.K = f.K; pa.neps = f.neps; pa.nx = f.nx; pa.nw = f.nw;
+        const StLayout stl{(int)lay.qs, (int)lay.d, (int)lay.bs, 0};
+        consumer_prologue<KB, 1, false, false, true>(pa, smem, stl, wave, lane, EngIO(), &ea);      // ([SY_GO] goes up inside, behind this wave's requests)
+        if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 7] = wall_clock64();
+        if (qr.nrw > 0) {
+            const unsigned tag = scal.serial * 256u + (unsigned)o.layer + 1u;
+            const ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
+            switch (qr.type) {
+                case T_Q4_K: qf_decode<T_Q4_K>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                case T_Q5_K: qf_decode<T_Q5_K>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                case T_Q6_K: qf_decode<T_Q6_K>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                default: break;
+            }
+        }
+        if (pre_item) {                                // the workgroup's first item: its cache rows have been in registers since the top of the launch
+            ao_item_run<R, TK, TV, C, true>(a, n_rot, fz, o, f, &scal, it0 % G, it0 / G, sm, ld0, dma);
+            had_item = true;
+            it0 += (int)gridDim.x;
+        }
+    }
+    for (int it = it0; it < o.n_items; it += (int)gridDim.x) {
         if (had_item) __syncthreads();                 // (the item's LDS is reused)
-        ao_attn_item<R, TK, TV, C>(a, cs_table, n_rot, fz, o, it % G, it / G, sm, dma);
+        AOItemLd<R, TK, TV, C> ld;
+        ao_item_issue<R, TK, TV, C, QF>(a, cs_table, n_rot, fz, o, it % G, it / G, ld);
+        ao_item_run<R, TK, TV, C, QF>(a, n_rot, fz, o, f, QF ? &scal : nullptr, it % G, it / G, sm, ld, dma);
         had_item = true;
     }
     dma();                                             // workgroups without an item: at once
-    const unsigned serial = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell).serial;     // (a second batch for workgroups that had an item: scalar-cache hits)
+    const unsigned serial = QF ? scal.serial : ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell).serial;     // (a second batch for workgroups that had an item: scalar-cache hits)
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 1] = wall_clock64();
 
     // ---- the merged, quantised attention output: wait until every ticket group's merge has its sums (one wave polls, relaxed, bounded), then every wave
@@ -635,15 +857,18 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
             else reinterpret_cast<unsigned *>(smem + lay.d)[blk[j]] = val[j].x;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W_o rows (DMA) has landed
+    if constexpr (QF) {                                // every slot of the workgroup (the W_o rows are the last ones) has landed
+        const int nt = qr.ns + (int)(((nrw > 0 ? (unsigned)nrw * o.row_bytes : 0u) + ST_SLOT - 1) / ST_SLOT);
+        ST_SPIN_WHILE(ld_sync(sy + SY_LANDED) < ((nt + 1) >> 1) || ld_sync(sy + SY_LANDED + 1) < (nt >> 1), 1);
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W_o rows (DMA) has landed
     __syncthreads();
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 5] = wall_clock64();
     if (nrw > 0) {
         const ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
         switch (o.type) {
-            case T_Q4_K: ao_decode<T_Q4_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
-            case T_Q5_K: ao_decode<T_Q5_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
-            case T_Q6_K: ao_decode<T_Q6_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q4_K: ao_decode<T_Q4_K>(o, smem + lay.wo, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q5_K: ao_decode<T_Q5_K>(o, smem + lay.wo, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q6_K: ao_decode<T_Q6_K>(o, smem + lay.wo, AL, b0, nrw, wave, lane, rs0, rs1); break;
             default: break;
         }
     }
@@ -651,6 +876,30 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) o.probe[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
     }
+}
+
+// The kernel argument segment is cold at every launch and hipcc reads a field where it is first used: seven dependent scalar-load round trips sat in front
+// of the first K / V request (1.4 us from entry to "loads issued", MI355_AO_PROBE).  One independent read per 64-byte line of the segment, all in flight
+// together, makes the later field reads scalar-cache hits.
+template <size_t BYTES> __device__ __forceinline__ void ao_touch_kernargs() {
+    const __attribute__((address_space(4))) unsigned *ka = (const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < (int)((BYTES + 63) / 64); i++) acc ^= ka[i * 16];
+    asm volatile("" :: "s"(acc));
+}
+template <int R, int TK, int TV, int C>
+__global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o) {
+    struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; };
+    ao_touch_kernargs<sizeof(KArgs)>();
+    ao_body<R, TK, TV, C, 0>(a, cs_table, n_rot, fz, o, QFArgs{});
+}
+constexpr int AO_QF_NT = AO_NT + 128;                   // QF: two loader waves behind the eight
+template <int R, int TK, int TV, int C, int KB>
+__global__ __launch_bounds__(AO_QF_NT) void qkv_attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o, const QFArgs f) {
+    struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; QFArgs f; };
+    ao_touch_kernargs<sizeof(KArgs)>();
+    ao_body<R, TK, TV, C, KB>(a, cs_table, n_rot, fz, o, f);
 }
 
 int g_attn_out_fused = -1;                  // -1: environment / default (on)
@@ -725,16 +974,19 @@ void attn_out_probe_report() {
         if (n) fprintf(stderr, "  %-28s n=%3d  min %.2f  mean %.2f  max %.2f us\n", name, n, lo, sum / n, hi);
     };
     fprintf(stderr, "attn_out probe: %d workgroups, %d attention items (us since the first workgroup entered)\n", g_ao_probe_wgs, g_ao_probe_items);
-    stat(0, "entered"); stat(8, "item: loads issued"); stat(9, "item: q rotated (loads back)"); stat(10, "item: scores done"); stat(11, "item: P.V done");
+    stat(0, "entered"); stat(7, "qkv: activation ready"); stat(15, "item: q / k / v granules seen"); stat(8, "item: loads issued"); stat(9, "item: q rotated (loads back)"); stat(10, "item: scores done"); stat(11, "item: P.V done");
     stat(12, "item: partial stored+drained"); stat(1, "items done / dma issued"); stat(2, "merge: ticket won"); stat(13, "merge: weights done");
     stat(14, "merge: sums done"); stat(3, "merge: codes stored");
     stat(4, "all flags seen"); stat(5, "codes + rows in LDS"); stat(6, "outputs stored");
 }
 
-hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
-                                 unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
-                                 hipStream_t st) {
-    if (!counters || !flags || !gran || !serial || !knew || !vnew || !tok_cell || layer < 0 || layer > 254) return hipErrorInvalidValue;
+// the launch of either form: qf == nullptr: the attention + attn_output kernel; else the layer's Q | K | V in front of it in the same launch
+struct QFPlan { QFArgs f; int blocks; int kb; size_t lds_qkv; int slots; };
+static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
+                            unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
+                            const QFPlan *qf, hipStream_t st) {
+    if (!counters || !flags || !gran || !serial || !tok_cell || layer < 0 || layer > 254) return hipErrorInvalidValue;
+    if (!qf && (!knew || !vnew)) return hipErrorInvalidValue;
     const int R = a.H / a.G;
     const int C = attn_out_fused_chunk(a);
     AOArgs o{};
@@ -757,6 +1009,7 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
     DecodeFuse fz{};
     fz.knew = knew; fz.vnew = vnew; fz.tok_cell = tok_cell; fz.counters = counters; fz.neox = 0;
     fz.q = *a.out_q; fz.want_q8k = 1; fz.want_q80 = 0;
+    if (qf && qf->blocks != nwg) return hipErrorInvalidValue;
 #define AO_LAUNCH(RR, TK, TV, CC)                                                                                                              \
     do {                                                                                                                                       \
         const size_t lds = ao_layout(o.slice_lds, K, sizeof(AOSmem<RR, CC>)).total;                                                            \
@@ -767,8 +1020,23 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
             hipExtLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o); \
         else hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);             \
     } while (0)
-#define AO_C(RR, TK, TV) do { if (C == 64) AO_LAUNCH(RR, TK, TV, 64); else AO_LAUNCH(RR, TK, TV, 128); } while (0)
+#define QF_LAUNCH(RR, TK, TV, CC, KBV)                                                                                                         \
+    do {                                                                                                                                       \
+        const size_t lds = ao_layout(o.slice_lds, K, sizeof(AOSmem<RR, CC>), AO_QF_HDR, qf->f.qkv_lds).total;                                  \
+        if (lds > 160 * 1024) return hipErrorInvalidValue;                                                                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                                         \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                                             \
+        if (kernel_timer() && kernel_timer()->next("qkv_attn_out", &ev0_, &ev1_))                                                              \
+            hipExtLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o, qf->f); \
+        else hipLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, a, cs_table, ra.n_rot, fz, o, qf->f); \
+    } while (0)
+#define AO_K(RR, TK, TV, CC) do { if (!qf) AO_LAUNCH(RR, TK, TV, CC); else if (qf->kb == 1) QF_LAUNCH(RR, TK, TV, CC, 1); else QF_LAUNCH(RR, TK, TV, CC, 2); } while (0)
+#define AO_C(RR, TK, TV) do { if (C == 64) AO_K(RR, TK, TV, 64); else AO_K(RR, TK, TV, 128); } while (0)
 #define AO_T(RR) do { if (a.type_k == T_F16) AO_C(RR, T_F16, T_F16); else AO_C(RR, T_Q8_0, T_Q8_0); } while (0)
+#ifdef MI355_AO_DEV      // (development builds: one form only, seconds to compile)
+    if (R == 4 && a.type_k == T_Q8_0 && C == 64) AO_K(4, T_Q8_0, T_Q8_0, 64); else return hipErrorInvalidValue;
+#else
     switch (R) {
         case 1: AO_T(1); break;
         case 2: AO_T(2); break;
@@ -776,10 +1044,89 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
         case 8: AO_T(8); break;
         default: return hipErrorInvalidValue;
     }
+#endif
 #undef AO_T
 #undef AO_C
+#undef AO_K
+#undef QF_LAUNCH
 #undef AO_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
+                                 unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
+                                 hipStream_t st) {
+    return launch_ao(a, cs_table, ra, knew, vnew, tok_cell, counters, flags, gran, layer, serial, wo, K, epi, nullptr, st);
+}
+
+// ---- QF, host side
+static int g_qkv_attn_fused = -1;           // -1: environment / default (on)
+void set_qkv_attn_fused(int on) { g_qkv_attn_fused = on < 0 ? -1 : on ? 1 : 0; }
+bool qkv_attn_fused_enabled() {
+    static const bool env_off = getenv("MI355_QKV_ATTN_FUSED") && getenv("MI355_QKV_ATTN_FUSED")[0] == '0';
+    return g_qkv_attn_fused < 0 ? !env_off : g_qkv_attn_fused > 0;
+}
+size_t qkv_attn_granule_words(int n_q, int n_kv) { return (size_t)n_q + 2 * (size_t)n_kv + 64; }
+
+// the plan of the three projections over the launch's workgroups (mmvq_stream_plan's: per tensor in proportion to its bytes), or blocks == 0 where the shape has no form
+static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse &q) {
+    QFPlan p{};
+    if (!qkv_attn_fused_enabled() || !q.nx || !q.nw || !q.gran) return p;
+    if (q.K != K || q.K != a.H * a.D || (q.K % 256) != 0 || q.K > 4096) return p;                  // (one activation region in LDS serves both mat-vecs)
+    if (q.seg[0].n_rows != a.H * a.D || q.seg[1].n_rows != a.G * a.D || q.seg[2].n_rows != a.G * a.D) return p;
+    if ((reinterpret_cast<uintptr_t>(q.nx) & 15) != 0 || (reinterpret_cast<uintptr_t>(q.nw) & 15) != 0) return p;
+    for (int s = 0; s < 3; s++) {
+        const MMVQSeg &g = q.seg[s];
+        if (g.type != T_Q4_K && g.type != T_Q5_K && g.type != T_Q6_K) return p;
+        if (g.expert_sel || (g.row_bytes % 16) != 0 || g.row_bytes > 0xffffffffull || (reinterpret_cast<uintptr_t>(g.W) & 15) != 0) return p;
+    }
+    const int nwg0 = std::min(num_cu(), (wo.n_rows + 1) / 2);
+    if (nwg0 < 3) return p;
+    const int rpw = (wo.n_rows + nwg0 - 1) / nwg0;
+    const int nwg = (wo.n_rows + rpw - 1) / rpw;
+    MMVQArgs m{};
+    m.n_seg = 3; m.K = q.K; m.T = 1; m.epi = EPI_STORE;
+    for (int s = 0; s < 3; s++) m.seg[s] = q.seg[s];
+    mmvq_stream_plan(m, nwg);
+    if (m.seg_block0[3] > nwg || m.seg_block0[1] <= 0 || m.seg_block0[2] <= m.seg_block0[1] || m.seg_block0[3] <= m.seg_block0[2]) return p;
+    size_t run = 0;
+    for (int s = 0; s < 3; s++) {
+        const int nblk = m.seg_block0[s + 1] - m.seg_block0[s];
+        const int rpb = (q.seg[s].n_rows + nblk - 1) / nblk;
+        run = std::max(run, (size_t)rpb * q.seg[s].row_bytes);
+    }
+    p.lds_qkv = (run + ST_SLOT - 1) / ST_SLOT * ST_SLOT;
+    const size_t wo_lds = ((size_t)rpw * wo.row_bytes + ST_SLOT - 1) / ST_SLOT * ST_SLOT;
+    p.slots = (int)((p.lds_qkv + wo_lds) / ST_SLOT);
+    if (p.slots > 30) return p;                                                                    // 15 slots = 60 DMA instructions per loader wave
+    QFArgs &f = p.f;
+    f.W0 = q.seg[0].W; f.W1 = q.seg[1].W; f.W2 = q.seg[2].W;
+    f.rb0 = (unsigned)q.seg[0].row_bytes; f.rb1 = (unsigned)q.seg[1].row_bytes; f.rb2 = (unsigned)q.seg[2].row_bytes;
+    f.t0 = q.seg[0].type; f.t1 = q.seg[1].type; f.t2 = q.seg[2].type;
+    f.n0 = q.seg[0].n_rows; f.n1 = q.seg[1].n_rows; f.n2 = q.seg[2].n_rows;
+    f.blk1 = m.seg_block0[1]; f.blk2 = m.seg_block0[2]; f.blk3 = m.seg_block0[3];
+    f.nx = q.nx; f.nw = q.nw; f.neps = q.neps; f.K = q.K;
+    f.gran = q.gran; f.n_q = a.H * a.D; f.n_kv = a.G * a.D;
+    f.qkv_lds = (unsigned)p.lds_qkv;
+    p.kb = (q.K + 2047) >> 11;
+    // the kernel's LDS at the largest attention scratch of the forms (R, chunk) it may take
+    const int R = a.H / a.G, C = attn_out_fused_chunk(a);
+    size_t attn_bytes = 0;
+#define QF_SZ(RR) attn_bytes = C == 64 ? sizeof(AOSmem<RR, 64>) : sizeof(AOSmem<RR, 128>)
+    switch (R) { case 1: QF_SZ(1); break; case 2: QF_SZ(2); break; case 4: QF_SZ(4); break; case 8: QF_SZ(8); break; default: return p; }
+#undef QF_SZ
+    if (ao_layout((unsigned)wo_lds, K, attn_bytes, AO_QF_HDR, f.qkv_lds).total > 160 * 1024) return p;
+    p.blocks = nwg;
+    return p;
+}
+bool qkv_attn_out_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi, const QKVFuse &q) {
+    return attn_out_fused_applicable(a, ra, wo, K, epi) && qf_plan(a, wo, K, q).blocks > 0;
+}
+hipError_t launch_qkv_attn_out(const AttnArgs &a, const float *cs_table, RopeArgs ra, const int32_t *tok_cell, unsigned *counters, unsigned *flags, unsigned long long *gran,
+                               int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi, const QKVFuse &q, hipStream_t st) {
+    const QFPlan p = qf_plan(a, wo, K, q);
+    if (p.blocks <= 0) return hipErrorInvalidValue;
+    return launch_ao(a, cs_table, ra, nullptr, nullptr, tok_cell, counters, flags, gran, layer, serial, wo, K, epi, &p, st);
 }
 
 }  // namespace mi355

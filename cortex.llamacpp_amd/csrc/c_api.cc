@@ -256,6 +256,7 @@ int32_t mi355_get_topk_ith(mi355_context *ctx, int32_t i, int32_t k, int32_t n_a
 int64_t mi355_debug_mega_steps(const mi355_context *ctx) { return ctx->c->mega_steps; }
 int64_t mi355_debug_engine_steps(const mi355_context *ctx) { return ctx->c->engine_steps; }
 int64_t mi355_debug_fused_skipped_steps(const mi355_context *ctx) { return ctx->c->fused_skipped_steps; }
+int64_t mi355_debug_qkv_attn_launches(const mi355_context *ctx) { return ctx->c->qkv_attn_launches; }
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0 || ctx->c->model->hp.encoder; }
 float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }
@@ -853,6 +854,7 @@ int mi355_debug_set_option(const char *name, int32_t value) {
     if (!strcmp(name, "tp_p2p_prompt")) { tp_p2p_use_prompt(value != 0); return MI355_OK; }
     if (!strcmp(name, "mmvq_stream")) { mmvq_set_stream(value != 0); return MI355_OK; }
     if (!strcmp(name, "attn_out_fused")) { set_attn_out_fused(value); return MI355_OK; }     // (contexts created afterwards)
+    if (!strcmp(name, "qkv_attn_fused")) { set_qkv_attn_fused(value); return MI355_OK; }     // Q | K | V inside the attention launch (applies from the next step's launches on; graphs captured earlier keep their form)
     if (!strcmp(name, "moe_group_min")) { set_moe_group_min(value); return MI355_OK; }
     if (!strcmp(name, "fa_v_acc_f16")) { set_fa_v_acc_f16(value); return MI355_OK; }              // f16 cache: the CPU path's fp16 V accumulation (parity mode)
     if (!strcmp(name, "raise_stream_error")) { debug_raise_stream_error((unsigned)value); return MI355_OK; }   // tests: what a timed-out in-kernel wait does

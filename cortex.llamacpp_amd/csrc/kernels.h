@@ -353,6 +353,17 @@ hipError_t launch_attn_out_fused(const AttnArgs &a, const float *cs_table, RopeA
                                  unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
                                  hipStream_t st);
 void attn_out_set_error_word(unsigned *w);
+// Round 6: the layer's Q | K | V mat-vecs (RMSNorm -> Q8_K prologue included) in front of the attention in the SAME launch - one launch per layer for
+// [Q | K | V, rope, KV store, attention, merge, Q8_K, attn_output + residual].  seg: attn_q, attn_k, attn_v (Q4_K / Q5_K / Q6_K, device-layout rows; `out` unused:
+// the results travel inside the launch); nx: the layer input, nw: attn_norm; K = n_embd = H * D <= 4096; gran: qkv_attn_granule_words(H * D, G * D) 8-byte words
+// shared by the layers of a step (zero once).  Outputs are bit-identical to launch_mmvq_stream + launch_attn_out_fused.
+struct QKVFuse { MMVQSeg seg[3]; const float *nx, *nw; float neps; int K; unsigned long long *gran; };
+void set_qkv_attn_fused(int on);                          // 0 = Q | K | V as a launch of its own, 1 = fused, -1 = environment (MI355_QKV_ATTN_FUSED, default on)
+bool qkv_attn_fused_enabled();
+size_t qkv_attn_granule_words(int n_q, int n_kv);
+bool qkv_attn_out_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi, const QKVFuse &q);
+hipError_t launch_qkv_attn_out(const AttnArgs &a, const float *cs_table, RopeArgs ra, const int32_t *tok_cell, unsigned *counters, unsigned *flags, unsigned long long *gran,
+                               int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi, const QKVFuse &q, hipStream_t st);
 void attn_out_probe_report();                             // MI355_AO_PROBE=1: phase stamps of the last launch, on stderr
 
 // ---------------------------------------------------------------- whole decode step in one launch (decode_mega.hip)

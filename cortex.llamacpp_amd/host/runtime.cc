@@ -694,7 +694,8 @@ bool Context::init(std::string &err) {
     d_step_serial_ = (unsigned *)dalloc(64);
     d_ao_flags_ = (unsigned *)dalloc((size_t)std::max(1, hp.n_layer) * 64 * ATT_SYNC_STRIDE * sizeof(unsigned));
     d_ao_gran_ = (unsigned long long *)dalloc(attn_out_granule_words((int)(hp.n_head * D)) * 8);
-    if (!d_step_serial_ || !d_ao_flags_ || !d_ao_gran_) { err = "step serial / flag allocation failed"; return false; }
+    d_qkv_gran_ = (unsigned long long *)dalloc(qkv_attn_granule_words((int)(hp.n_head * D), (int)(hp.n_head_kv * D)) * 8);
+    if (!d_step_serial_ || !d_ao_flags_ || !d_ao_gran_ || !d_qkv_gran_) { err = "step serial / flag allocation failed"; return false; }
     d_argmax_ = (int32_t *)dalloc(T * 4);
     argmax_scratch_ = (float *)dalloc(T * 129 * 4);     // T ticket words at the head, then per row 64 part values and 64 part indices (zero-filled: dalloc)
     rope_cs_ = (float *)dalloc(T * (size_t)hp.n_rot * 4);
@@ -1378,26 +1379,7 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
         const bool need_k = is_quant(L.wq.type) && !act_is_q80(L.wq.type) || is_quant(L.wk.type) && !act_is_q80(L.wk.type) || is_quant(L.wv.type) && !act_is_q80(L.wv.type);
         const bool need_0 = act_is_q80(L.wq.type) || act_is_q80(L.wk.type) || act_is_q80(L.wv.type);
         const bool fuse_attn = !any_f && can_fuse(E, T);
-        if (engine && il > 0) {
-            // Q | K | V of this layer were computed at the end of the previous layer's engine launch
-        } else if (fuse_attn) {
-            pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
-        } else {
-            const bool pl = need_k && T >= 3;                  // the batched kernels will want the block-sum planes
-            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_,
-                                         pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
-            prep_owner_ = nullptr;
-            if (pl) prep_written(aq_e_, E, T);
-            prof_mark("norm_quant");
-        }
-        const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
-        float *outs[3] = {q_, k_, v_};
-        if (!(engine && il > 0)) HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
-        pending_fuse_ = Fuse();
-        if (L.bq.valid() || L.bk.valid() || L.bv.valid())       // qwen2-style attention biases: all T rows of the three projections in one launch
-            HIP_TRY(launch_add_qkv_bias(q_, k_, v_, L.bq.valid() ? (const float *)L.bq.data : nullptr, L.bk.valid() ? (const float *)L.bk.data : nullptr,
-                                        L.bv.valid() ? (const float *)L.bv.data : nullptr, H * D, G * D, T, stream_));
-        prof_mark("qkv");
+        // the attention launch's description first: where attn_out.hip takes Q | K | V as well (round 6), no projection launch is made at all
         AttnArgs aa{};
         aa.q = q_; aa.out = att_; aa.kv = kv_[(size_t)il]; aa.type_k = cp.type_k; aa.type_v = cp.type_v;
         aa.T = T; aa.H = H; aa.G = G; aa.D = D; aa.n_ctx = (int)cp.n_ctx;
@@ -1422,25 +1404,68 @@ hipError_t Context::run_layers(int T, int n_kv_cap) {
             }
             fused_step = attn_mode > 0 && flash_attn_decode_fused_applicable(aa, ra);
         }
-        if (decode_attn && (fast_store || fused_step || (batch_distinct_ && store_fuse_enabled()))) {
+        // single-token step: attention + attn_output in one launch (attn_out.hip) where it has a form for the shape
+        // (not where the ranks of a row split exchange through the host callback - the transport of a rig whose ranks SHARE one device: this kernel's
+        // workgroups wait for each other (consumers for the item workgroups' flags), and two processes' copies placed on the same CUs at the same time can
+        // hold each other's item workgroups out - every wait then runs into its bound (round 6: 0x8 on three of eight ranks behind one MI355X at the first
+        // single-token step, profiles/r6_tp_shared_device_trace.txt).  A rank that owns its GPU has the chip to itself.)
+        const bool ao_add = !tp || hp.tp_rank == 0;
+        const MMVQSeg ao_seg = make_seg(L.wo, tp ? tp_part_ : x_, E, ao_add ? x_ : nullptr, nullptr);
+        AttnArgs af = aa;
+        bool ao_form = false;
+        if (decode_attn && fused_step && attn_mode == 2 && !engine && il < 255 && !attn_out_off_ && !attn_out_skip_step_ && !(tp && tp_uses_host())) {
+            af.splits = attn_out_fused_splits(af);
+            if (chunk_lmax_ > 0) af.splits = aa.splits;
+            ao_form = attn_out_fused_applicable(af, ra, ao_seg, (int)L.wo.K, ao_add ? EPI_ADD : EPI_STORE);
+        }
+        // ... and the layer's Q | K | V in front of it in that launch: the RMSNorm -> Q8_K prologue, the three mat-vecs, rope, KV store, attention, merge,
+        // Q8_K and attn_output + residual are ONE launch per layer (outputs bit-identical to the two launches)
+        bool qkv_in_attn = false;
+        if (ao_form && fuse_attn && !tp && d_qkv_gran_ && !(L.bq.valid() || L.bk.valid() || L.bv.valid())) {
+            QKVFuse qf{};
+            qf.seg[0] = make_seg(L.wq, q_, (int)L.wq.N, nullptr, nullptr);
+            qf.seg[1] = make_seg(L.wk, k_, (int)L.wk.N, nullptr, nullptr);
+            qf.seg[2] = make_seg(L.wv, v_, (int)L.wv.N, nullptr, nullptr);
+            qf.nx = x_; qf.nw = (const float *)L.attn_norm.data; qf.neps = hp.eps; qf.K = E; qf.gran = d_qkv_gran_;
+            if (qkv_attn_out_applicable(af, ra, ao_seg, (int)L.wo.K, EPI_ADD, qf)) {
+                HIP_TRY(launch_qkv_attn_out(af, rope_cs_, ra, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64 * ATT_SYNC_STRIDE, d_ao_gran_, il, d_step_serial_, ao_seg,
+                                            (int)L.wo.K, EPI_ADD, qf, stream_));
+                qkv_in_attn = true; attn_out_done = true; qkv_attn_launches++;
+                prof_mark("qkv");
+            }
+        }
+        if (qkv_in_attn) {
+            // nothing to launch
+        } else if (engine && il > 0) {
+            // Q | K | V of this layer were computed at the end of the previous layer's engine launch
+        } else if (fuse_attn) {
+            pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
+        } else {
+            const bool pl = need_k && T >= 3;                  // the batched kernels will want the block-sum planes
+            HIP_TRY(launch_rmsnorm_quant(x_, (const float *)L.attn_norm.data, E, T, hp.eps, any_f ? xn_ : nullptr, &aq_e_, need_k, need_0, stream_,
+                                         pl ? mmq_bh_ : nullptr, pl ? mmq_bl_ : nullptr));
+            prep_owner_ = nullptr;
+            if (pl) prep_written(aq_e_, E, T);
+            prof_mark("norm_quant");
+        }
+        const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
+        float *outs[3] = {q_, k_, v_};
+        if (!(engine && il > 0) && !qkv_in_attn) HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, T));
+        pending_fuse_ = Fuse();
+        if (!qkv_in_attn && (L.bq.valid() || L.bk.valid() || L.bv.valid()))       // qwen2-style attention biases: all T rows of the three projections in one launch
+            HIP_TRY(launch_add_qkv_bias(q_, k_, v_, L.bq.valid() ? (const float *)L.bq.data : nullptr, L.bk.valid() ? (const float *)L.bk.data : nullptr,
+                                        L.bv.valid() ? (const float *)L.bv.data : nullptr, H * D, G * D, T, stream_));
+        if (!qkv_in_attn) prof_mark("qkv");
+        if (qkv_in_attn) {
+            // the whole block ran in the launch above
+        } else if (decode_attn && (fast_store || fused_step || (batch_distinct_ && store_fuse_enabled()))) {
             if (fused_step) {
                 // single-token step: K rope + KV store + attention + split merge + quantise in ONE launch - and, where attn_out.hip has a form for the shape,
                 // the attn_output mat-vec with its residual add in that launch too
-                // (not where the ranks of a row split exchange through the host callback - the transport of a rig whose ranks SHARE one device: this kernel's
-                // workgroups wait for each other (consumers for the item workgroups' flags), and two processes' copies placed on the same CUs at the same time can
-                // hold each other's item workgroups out - every wait then runs into its bound (round 6: 0x8 on three of eight ranks behind one MI355X at the first
-                // single-token step, profiles/r6_tp_shared_device_trace.txt).  A rank that owns its GPU has the chip to itself.)
-                if (attn_mode == 2 && !engine && il < 255 && !attn_out_off_ && !attn_out_skip_step_ && !(tp && tp_uses_host())) {
-                    const bool add = !tp || hp.tp_rank == 0;
-                    const MMVQSeg so = make_seg(L.wo, tp ? tp_part_ : x_, E, add ? x_ : nullptr, nullptr);
-                    AttnArgs af = aa;
-                    af.splits = attn_out_fused_splits(af);
-                    if (chunk_lmax_ > 0) af.splits = aa.splits;
-                    if (attn_out_fused_applicable(af, ra, so, (int)L.wo.K, add ? EPI_ADD : EPI_STORE)) {
-                        HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64 * ATT_SYNC_STRIDE, d_ao_gran_, il, d_step_serial_, so,
-                                                      (int)L.wo.K, add ? EPI_ADD : EPI_STORE, stream_));
-                        attn_out_done = true;
-                    }
+                if (ao_form) {
+                    HIP_TRY(launch_attn_out_fused(af, rope_cs_, ra, k_, v_, d_cell_, att_counters_, d_ao_flags_ + (size_t)il * 64 * ATT_SYNC_STRIDE, d_ao_gran_, il, d_step_serial_, ao_seg,
+                                                  (int)L.wo.K, ao_add ? EPI_ADD : EPI_STORE, stream_));
+                    attn_out_done = true;
                 }
                 if (!attn_out_done)
                     HIP_TRY(launch_flash_attn_decode_fused(aa, rope_cs_, ra, k_, v_, d_cell_, attn_mode == 2 ? att_counters_ : nullptr, stream_));

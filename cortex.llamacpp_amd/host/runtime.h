@@ -113,6 +113,7 @@ void set_decode_mega(bool on);   // tests: compare the whole-step kernel with th
 class Context {
   public:
     int64_t engine_steps = 0;          // single-token steps issued through the layer engine (graph replays included)
+    int64_t qkv_attn_launches = 0;     // launches that ran a layer's Q | K | V inside its attention + attn_output launch (attn_out.hip QF)
     int64_t fused_skipped_steps = 0;   // single-token steps that took the wait-free launches because another context of the device held the cross-workgroup-wait kernel
     int64_t mega_steps = 0;            // single-token steps issued as one whole-step launch (graph replays included)
     Context(Model *m, const ContextParams &p);
@@ -264,6 +265,7 @@ class Context {
     int moe_forced_T_ = 0, moe_forced_cap_ = 0;
     unsigned *att_counters_ = nullptr;   // per-kv-head arrival tickets of the fused decode attention (zero between launches)
     unsigned *d_step_serial_ = nullptr;  // device word: serial number of the step (incremented by the step's set-up launch; the hand-over tags / flags of attn_out.hip and decode_engine.hip)
+    unsigned long long *d_qkv_gran_ = nullptr;  // attn_out.hip QF (round 6): the token's q | k | v as tagged granules inside the one launch per layer's attention block
     unsigned long long *d_ao_gran_ = nullptr;   // attn_out.hip: the quantised attention output as tagged granules (shared by the layers of a step)
     unsigned *d_ao_flags_ = nullptr;     // attn_out.hip: [n_layer][64 * ATT_SYNC_STRIDE] flag words, one per merge ticket group (they hold the serial of the step that raised them)
     float *argmax_scratch_ = nullptr, *rope_cs_ = nullptr;

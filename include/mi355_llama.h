@@ -164,6 +164,10 @@ MI355_API int64_t mi355_debug_engine_steps(const mi355_context *ctx);
 /* single-token steps of this context that took the wait-free launches because another context of the device had the one-launch attention + attn_output kernel
    (workgroups that wait for each other) in flight: two models of one server decoding at the same time never run that kernel beside each other */
 MI355_API int64_t mi355_debug_fused_skipped_steps(const mi355_context *ctx);
+/* diagnosis: launches of this context that ran a layer's Q | K | V mat-vecs INSIDE its attention + attn_output launch (csrc/attn_out.hip QF, round 6: one launch
+   per layer for the whole attention block of a single-token step; "qkv_attn_fused" 0 / MI355_QKV_ATTN_FUSED=0 keeps Q | K | V a launch of its own).  Counts
+   launches issued eagerly or while a graph was captured, not graph replays. */
+MI355_API int64_t mi355_debug_qkv_attn_launches(const mi355_context *ctx);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
 /* llama_get_embeddings_ith (ctx.cc:1042-1044): final-norm hidden state (n_embd floats, host memory) of batch row i of the

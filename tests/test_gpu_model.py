@@ -1211,6 +1211,37 @@ def test_attn_out_one_launch_agrees_with_the_two_launches(be, pkg, tmp_models, c
     assert float(np.median(errs[:, 0])) <= 1e-5, errs[:, 0]
 
 
+@pytest.mark.parametrize("cfg,ftype,kv", [("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l", "q5_k_m", "f16"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-d128-mha", "q5_k_m", "q8_0"),
+                                          ("tiny-d128", "q6_k", "q8_0"), ("tiny-e2048", "q4_k_m", "q8_0")])
+def test_qkv_inside_the_attention_launch_is_bitwise_the_separate_launch(be, pkg, tmp_models, cfg, ftype, kv):
+    """Round 6: a single-token step's Q | K | V mat-vecs (RMSNorm -> Q8_K prologue included) run INSIDE the attention + attn_output launch (attn_out.hip QF: ten
+    waves per workgroup, two of them DMA loaders; q / k / v travel between workgroups as tagged granules) - one launch per layer's attention block instead of two.
+    The arithmetic is the weight stream's and the attention kernel's own, so the logits must equal the two-launch form's BIT FOR BIT: after prompts of five
+    lengths (1 .. 32 attention items per kv head; the last run crosses 2048 cells, where the items become 128-cell chunks), twelve steps each."""
+    path = make(pkg, tmp_models, cfg, ftype)
+    rows = {}
+    for fused in (1, 0):
+        be.set_option("qkv_attn_fused", fused)
+        try:
+            m = pkg.Model(path)
+            c = pkg.Context(m, n_ctx=2304, type_k=KV[kv], type_v=KV[kv])
+            out = []
+            for seed, n_p in enumerate((3, 64, 127, 300, 2040)):
+                rng = np.random.default_rng(300 + seed)
+                c.kv_clear()
+                c.decode(rng.integers(0, m.n_vocab, n_p), np.arange(n_p))
+                for s, t in enumerate(rng.integers(0, m.n_vocab, 12)):
+                    assert c.decode([int(t)], [n_p + s]) == 0
+                    out.append(c.logits().copy())
+            rows[fused] = np.stack(out)
+            assert (c.qkv_attn_launches() > 0) == bool(fused), c.qkv_attn_launches()     # the form under test really ran (and really did not)
+            c.close(); m.close()
+        finally:
+            be.set_option("qkv_attn_fused", -1)
+    assert np.isfinite(rows[1]).all()
+    assert np.array_equal(rows[1], rows[0]), float(np.abs(rows[1] - rows[0]).max())
+
+
 @pytest.mark.parametrize("cfg,ftype,kv,n_prompt", [("tiny-8b-2l", "q4_k_m", "q8_0", 3968), ("tiny-8b-attn-2l", "q4_k_m", "q8_0", 3968), ("tiny-d128", "q4_k_m", "f16", 3968),
                                                    ("tiny-d128", "q4_k_m", "q4_0", 3000)])
 def test_context_filled_to_4096_matches_oracle(be, pkg, tmp_models, cfg, ftype, kv, n_prompt):
