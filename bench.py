@@ -441,14 +441,24 @@ def main() -> int:
             ctx.profile(False)
         # kernel begin / end timestamps of the stream and attention launches themselves ("k:<role>" = us, "n:<role>" = launches; hipExtLaunchKernelGGL's start / stop
         # events: what rocprofv3's kernel trace reports, no marker between two launches involved)
-        kroles = {"qkv": "qkv", "gate_up": "ffn_gate_up", "ffn_down": "ffn_down", "head": "lm_head", "attn_out": "attn_out"}
+        kroles = {"qkv": "qkv", "gate_up": "ffn_gate_up", "ffn_down": "ffn_down", "head": "lm_head", "attn_out": "attn_out", "qkv_attn_out": "qkv_attn_out"}
         kernel_us = {kroles[k[2:]]: v / n_done for k, v in acc.items() if k.startswith("k:") and k[2:] in kroles} if n_done > 0 else {}
         kernel_n = {kroles[k[2:]]: v / n_done for k, v in acc.items() if k.startswith("n:") and k[2:] in kroles} if n_done > 0 else {}
+        # round 6: where the step runs Q | K | V inside its attention + attn_output launch (csrc/attn_out.hip QF) there is ONE launch per layer for the whole attention
+        # block - role "qkv_attn_out", weight bytes = attn_q + attn_k + attn_v + attn_output - and the weight-stream launches of a token are gate | up, ffn_down, head
+        qf = kernel_us.get("qkv_attn_out", 0.0) > 0
+        if qf:
+            rb["qkv_attn_out"] = rb["qkv"] + rb["attn_out"]
+        stream_roles = ("ffn_gate_up", "ffn_down", "lm_head") if qf else ("qkv", "ffn_gate_up", "ffn_down", "lm_head")
         if n_done > 0 and all(k in acc for k in ("qkv", "ffn_gate_up", "ffn_down", "lm_head")):
             L_n = cfg.n_layer
             roles_live = {}
-            for role, n_l in (("qkv", L_n), ("attn_out", L_n), ("ffn_gate_up", L_n), ("ffn_down", L_n), ("lm_head", 1)):
-                us_tok = (acc.get(role, 0.0) + (acc.get("attn", 0.0) + acc.get("rope_kv", 0.0) if role == "attn_out" else 0.0)) / n_done
+            role_list = ((("qkv_attn_out", L_n),) if qf else (("qkv", L_n), ("attn_out", L_n))) + (("ffn_gate_up", L_n), ("ffn_down", L_n), ("lm_head", 1))
+            for role, n_l in role_list:
+                if role == "qkv_attn_out":
+                    us_tok = (acc.get("qkv", 0.0) + acc.get("attn", 0.0) + acc.get("rope_kv", 0.0) + acc.get("attn_out", 0.0)) / n_done
+                else:
+                    us_tok = (acc.get(role, 0.0) + (acc.get("attn", 0.0) + acc.get("rope_kv", 0.0) if role == "attn_out" else 0.0)) / n_done
                 if us_tok <= 0:
                     continue
                 ev_us = us_tok                            # interval between the role's HIP events (includes the marker's own cost and the launch boundary)
@@ -458,14 +468,22 @@ def main() -> int:
                                     "GBps": round(rb[role] / (us_tok * 1e-6) / 1e9, 1), "frac_of_8TBps": round(rb[role] / (us_tok * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                     "source": "kernel begin/end timestamps" if role in kernel_us else "HIP event interval", "event_interval_us_per_token": round(ev_us, 2),
                                     "timed_launches_per_token": round(kernel_n.get(role, 0.0), 2)}
-            st_b = sum(rb[r] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
-            st_us = sum(roles_live[r]["us_per_token"] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
+            st_b = sum(rb[r] for r in stream_roles)
+            st_us = sum(roles_live[r]["us_per_token"] for r in stream_roles)
             frac_live = round(st_b / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
-            live_launches = sum(roles_live[r]["launches_per_token"] for r in ("qkv", "ffn_gate_up", "ffn_down", "lm_head"))
+            live_launches = sum(roles_live[r]["launches_per_token"] for r in stream_roles)
             roles_live["_stream"] = {"launches_per_token": live_launches, "us_per_token": round(st_us, 2), "avg_launch_us": round(st_us / live_launches, 3),
-                                     "weight_bytes_per_token": int(st_b)}
-            roles_live["_note"] = (f"{n_done} eager single-token steps at pos {pos}.., HIP events between the roles on the context's stream; attn_out = rope / KV store + attention + "
-                                   f"attn_output (one launch) with attn_output's weight bytes only; other per-token time: " +
+                                     "weight_bytes_per_token": int(st_b), "roles": list(stream_roles)}
+            # every launch of a token that reads weights, the attention block included: all weight bytes / the sum of those kernels' own durations
+            all_roles = [r for r in roles_live if not r.startswith("_")]
+            all_b = sum(rb[r] for r in all_roles)
+            all_us = sum(roles_live[r]["us_per_token"] for r in all_roles)
+            roles_live["_all_weight_launches"] = {"launches_per_token": sum(roles_live[r]["launches_per_token"] for r in all_roles), "us_per_token": round(all_us, 2),
+                                                  "weight_bytes_per_token": int(all_b), "frac_of_8TBps": round(all_b / (all_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+            roles_live["_note"] = (f"{n_done} eager single-token steps at pos {pos}.., HIP events between the roles on the context's stream; " +
+                                   ("qkv_attn_out = RMSNorm / Q8_K + Q | K | V + rope / KV store + attention + attn_output in ONE launch per layer (round 6), weight bytes of the four "
+                                    "projections; " if qf else "attn_out = rope / KV store + attention + attn_output (one launch) with attn_output's weight bytes only; ") +
+                                   "other per-token time: " +
                                    ", ".join(f"{k} {v / n_done:.1f} us" for k, v in sorted(acc.items()) if k not in ("qkv", "attn", "rope_kv", "attn_out", "ffn_gate_up", "ffn_down", "lm_head")))
 
     # ---- the long-context point of the same config under the SAME contract as the headline (logits row host-visible after every step): context
@@ -629,7 +647,8 @@ def main() -> int:
         "decode_hbm_fraction_of_8TBps": round(decode_frac, 4),
         "roofline": {
             "bound": "hbm",
-            "kernel": "mmvq_stream_kernel (single-token quantised mat-vec as an LDS-DMA weight stream: Q|K|V, gate|up, ffn_down of every layer and the output head; attn_output runs inside the attention launch and is excluded)",
+            "kernel": "mmvq_stream_kernel (single-token quantised mat-vec as an LDS-DMA weight stream: gate|up, ffn_down of every layer and the output head; Q|K|V and attn_output run inside the "
+                      "attention launch since round 6 / 4 - role qkv_attn_out of roles_live, and roles_live._all_weight_launches prices every weight byte of a token against every such launch)",
             # `achieved` / `frac`: measured LIVE in this run - algorithmic weight bytes of the stream launches of a token / the sum of those kernels' own durations
             # (begin / end timestamps of every dispatch, `roles_live`), averaged over the profiled steps; the committed rocprofv3 trace of the same kernel sources
             # (`frac_rocprof`, `roles`) is the cross-check and `frac_live_over_rocprof` their ratio; the hipGraph sweep (launch boundaries counted as kernel time) beside them
@@ -649,8 +668,8 @@ def main() -> int:
             "frac_live_over_rocprof": round(frac_live / frac_rocprof, 4) if (frac_live and frac_rocprof) else None,
             "traffic": traffic,
             "traffic_source": traffic_note,
-            "method": "the step's own launches of the weight-stream kernel (Q|K|V, gate|up, ffn_down of every layer + the output head: 97 for this model; "
-                      "attn_output runs inside the attention launch since round 4 and is neither launched nor counted here), replayed from a hipGraph, HIP "
+            "method": "the step's own launches of the weight-stream kernel (gate|up, ffn_down of every layer + the output head: 65 for this model; Q|K|V and "
+                      "attn_output run inside the attention launch since rounds 6 / 4 and are neither launched nor counted here), replayed from a hipGraph, HIP "
                       "events on the context's stream; achieved = algorithmic weight bytes of those launches / sweep time, so launch boundaries count as "
                       "kernel time",
             "bytes_per_sweep": int(sweep_bytes),

@@ -2252,6 +2252,19 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches
         const MMVQSeg so = make_seg(L.wo, x_, E, x_, nullptr);
         return !hp.tp_exchange && is_quant(L.wo.type) && attn_out_fused_applicable(af, rope_args(*model, true), so, (int)L.wo.K, EPI_ADD);
     };
+    // round 6: ... and Q | K | V too where attn_out.hip takes them (run_layers): the sweep then holds neither
+    auto qkv_in_attention = [&](const LayerWeights &L) {
+        if (!wo_in_attention(L) || !d_qkv_gran_ || L.bq.valid() || L.bk.valid() || L.bv.valid()) return false;
+        if (!is_quant(L.wq.type) || !is_quant(L.wk.type) || !is_quant(L.wv.type) || !can_fuse(E, 1)) return false;
+        AttnArgs af{};
+        af.type_k = cp.type_k; af.type_v = cp.type_v; af.T = 1; af.H = hp.n_head; af.G = hp.n_head_kv; af.D = hp.head_dim; af.n_ctx = (int)cp.n_ctx;
+        af.n_kv_max = 64; af.splits = 1; af.out_q = &aq_o_; af.out_q8k = !act_is_q80(L.wo.type); af.out_q80 = act_is_q80(L.wo.type);
+        const MMVQSeg so = make_seg(L.wo, x_, E, x_, nullptr);
+        QKVFuse qf{};
+        qf.seg[0] = make_seg(L.wq, q_, (int)L.wq.N, nullptr, nullptr); qf.seg[1] = make_seg(L.wk, k_, (int)L.wk.N, nullptr, nullptr); qf.seg[2] = make_seg(L.wv, v_, (int)L.wv.N, nullptr, nullptr);
+        qf.nx = x_; qf.nw = (const float *)L.attn_norm.data; qf.neps = hp.eps; qf.K = E; qf.gran = d_qkv_gran_;
+        return qkv_attn_out_applicable(af, rope_args(*model, true), so, (int)L.wo.K, EPI_ADD, qf);
+    };
     auto sweep = [&](bool count) -> hipError_t {
         for (int il = 0; il < hp.n_layer; il++) {
             const LayerWeights &L = model->layers[(size_t)il];
@@ -2263,8 +2276,9 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches
                 if (count) { std::vector<int32_t> ids((size_t)KU); for (int j = 0; j < KU; j++) ids[(size_t)j] = j; HIP_TRY(hipMemcpy(moe_ids_, ids.data(), ids.size() * 4, hipMemcpyHostToDevice)); }
                 const DevTensor *wsm[3] = {&L.wq, &L.wk, &L.wv};
                 float *outm[3] = {q_, k_, v_};
+                const bool qkv_fused = qkv_in_attention(L);
                 pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps;
-                HIP_TRY(linear_multi(wsm, outm, 3, aq_e_, xn_, 1));
+                if (!qkv_fused) HIP_TRY(linear_multi(wsm, outm, 3, aq_e_, xn_, 1));
                 pending_fuse_ = Fuse();
                 const bool wo_fused = wo_in_attention(L);
                 if (!wo_fused) HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, nullptr, EPI_STORE));
@@ -2281,9 +2295,9 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches
                 HIP_TRY(launch_mmvq_fast(a, stream_));
                 HIP_TRY(launch_mmvq_fast(d, stream_));
                 if (count) {
-                    bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + (wo_fused ? 0 : L.wo.ggml_bytes) +
+                    bytes += (qkv_fused ? 0 : L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes) + (wo_fused ? 0 : L.wo.ggml_bytes) +
                              (L.gate_exps.ggml_bytes + L.up_exps.ggml_bytes + L.down_exps.ggml_bytes) / (uint64_t)L.gate_exps.n_expert * (uint64_t)KU;
-                    launches += wo_fused ? 3 : 4;
+                    launches += (wo_fused ? 3 : 4) - (qkv_fused ? 1 : 0);
                 }
                 continue;
             }
@@ -2291,8 +2305,9 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches
             const DevTensor *ws[3] = {&L.wq, &L.wk, &L.wv};
             float *outs[3] = {q_, k_, v_};
             const bool qkv_q = is_quant(L.wq.type) && is_quant(L.wk.type) && is_quant(L.wv.type);
+            const bool qkv_fused = qkv_in_attention(L);
             if (qkv_q && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)L.attn_norm.data; pending_fuse_.eps = hp.eps; }
-            HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
+            if (!qkv_fused) HIP_TRY(linear_multi(ws, outs, 3, aq_e_, xn_, 1));
             pending_fuse_ = Fuse();
             const bool wo_fused = wo_in_attention(L);
             if (!wo_fused) HIP_TRY(linear(L.wo, aq_o_, att_, (int)L.wo.K, 1, xo_, E, xo_, EPI_ADD));
@@ -2315,8 +2330,8 @@ double Context::bench_weight_sweep(int iters, uint64_t *bytes_out, int *launches
             }
             pending_fuse_ = Fuse();
             if (count) {
-                bytes += L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes + (wo_fused ? 0 : L.wo.ggml_bytes) + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
-                launches += (wo_fused ? 3 : 4) + (halves ? 1 : 0);
+                bytes += (qkv_fused ? 0 : L.wq.ggml_bytes + L.wk.ggml_bytes + L.wv.ggml_bytes) + (wo_fused ? 0 : L.wo.ggml_bytes) + L.gate.ggml_bytes + L.up.ggml_bytes + L.down.ggml_bytes;
+                launches += (wo_fused ? 3 : 4) - (qkv_fused ? 1 : 0) + (halves ? 1 : 0);
             }
         }
         if (is_quant(model->output.type) && can_fuse(E, 1)) { pending_fuse_.mode = 1; pending_fuse_.x = x_; pending_fuse_.w = (const float *)model->out_norm.data; pending_fuse_.eps = hp.eps; }
