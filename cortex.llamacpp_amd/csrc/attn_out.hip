@@ -95,6 +95,7 @@ struct QFArgs {
     int n_q, n_kv;                    // H * D, G * D
     unsigned qkv_lds;                 // LDS bytes reserved for the workgroup's Q | K | V rows (whole 4 KiB slots)
 };
+constexpr int SY_QF_GO = 40;          // QF sync word: waves whose activation requests are queued (the loaders start behind them)
 constexpr unsigned AO_QF_HDR = 512;   // QF: the weight stream's sync words and reduction scratch in front of everything (mmvq_stream_dev.h ST_OFF_SYNC, ST_OFF_RED)
 
 // LDS: [QF: 512 B of sync words] | [.., + slice_lds) the W_o rows | [QF: the Q | K | V rows] | qs [K] | d (1 KiB of room) | bs [K / 8, whole KiB] | AOSmem
@@ -664,16 +665,49 @@ __device__ __forceinline__ QFRun qf_setup(QFArgs f) {
     q.ns = (int)((q.total + ST_SLOT - 1) / ST_SLOT);
     return q;
 }
+// The launch's geometry once more, packed into the kernel's FIRST 13 argument dwords - scalars the hardware preloads into SGPRs (as mmvq_stream.hip's StFast): the
+// loaders work out their two runs from them and start the stream right behind the workgroup's first barrier, while the argument segment is still cold (the launch
+// ends one decode step + the attention chain behind the landing of the Q | K | V rows: the stream's first request is what counts).  All weights and the norm weights
+// as 16-byte units above `wbase`.  kf: K >> 8 (5 bits) | first workgroup of attn_k (9) | of attn_v (9) | W_o rows per workgroup (8) | valid (1); every
+// workgroup of the launch has rows of a projection (blk3 == gridDim.x), attn_q has K rows, attn_k / attn_v n_kv rows, W_o K rows.
+struct QFFast { const float *nx; const uint8_t *wbase; unsigned onw, owq, owk, owv, owo, kf, rb01, rb2o, nkv; };
+struct QFWoRun { int b0, nrw; const uint8_t *W; unsigned rb; };
+__device__ __forceinline__ void qf_fast_setup(QFFast p, QFRun &q, QFWoRun &w) {
+    asm volatile("" : "+s"(p.owq), "+s"(p.owk), "+s"(p.owv), "+s"(p.owo), "+s"(p.rb01), "+s"(p.rb2o));     // (opaque copies: no selection table in scratch)
+    const unsigned kf = p.kf;
+    const int K = (int)(kf & 31u) << 8, blk1 = (int)((kf >> 5) & 511u), blk2 = (int)((kf >> 14) & 511u), rpw = (int)((kf >> 23) & 255u);
+    const int b = (int)blockIdx.x, nwg = (int)gridDim.x;
+    const int s = b >= blk2 ? 2 : b >= blk1 ? 1 : 0;
+    const int lo = s == 0 ? 0 : s == 1 ? blk1 : blk2, hi = s == 0 ? blk1 : s == 1 ? blk2 : nwg;
+    const int n_rows = s == 0 ? K : (int)p.nkv;
+    const unsigned ow = s == 0 ? p.owq : s == 1 ? p.owk : p.owv;
+    q.W = p.wbase + ((size_t)ow << 4);
+    q.rb = s == 0 ? (p.rb01 & 0xffffu) : s == 1 ? (p.rb01 >> 16) : (p.rb2o & 0xffffu);
+    q.type = 0;                                                    // (the loaders do not decode)
+    const int nblk = hi - lo, bl = b - lo;
+    const int rpb = (n_rows + nblk - 1) / nblk;
+    int b0 = bl * rpb, b1 = b0 + rpb;
+    if (b0 > n_rows) b0 = n_rows;
+    if (b1 > n_rows) b1 = n_rows;
+    q.b0 = b0; q.nrw = b1 - b0;
+    q.grow0 = (s == 0 ? 0 : s == 1 ? K : K + (int)p.nkv) + b0;
+    q.total = (unsigned)q.nrw * q.rb;
+    q.ns = (int)((q.total + ST_SLOT - 1) / ST_SLOT);
+    const int b0r = b * rpw;
+    w.b0 = b0r < K ? b0r : K;
+    w.nrw = w.b0 + rpw <= K ? rpw : K - w.b0;
+    w.W = p.wbase + ((size_t)p.owo << 4);
+    w.rb = p.rb2o >> 16;
+}
 // a loader wave (lq = 0, 1): global slot j of the workgroup = slot j of its Q | K | V run, then the slots of its W_o run; loader lq copies the slots j = lq mod 2
 // and publishes how many of ITS slots have landed ([SY_LANDED + lq]; they land in order).  At most 15 slots = 60 DMA instructions per loader: what the wave's
 // vector-memory counter can count (the launcher checks the sum).
-__device__ __forceinline__ void qf_loader(const QFRun &q, const AOArgs &o, uint8_t *smem, const AOLayout &lay, int b0o, int nrwo, int lq, int lane) {
+__device__ __forceinline__ void qf_loader(const QFRun &q, const QFWoRun &wo, uint8_t *smem, unsigned lds_q, unsigned lds_o, bool wait_go, int lq, int lane) {
     int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
-    ST_SPIN_WHILE(ld_sync(sy + SY_GO) < AO_NW, 0);
-    const unsigned total_o = nrwo > 0 ? (unsigned)nrwo * o.row_bytes : 0u;
+    if (wait_go) ST_SPIN_WHILE(ld_sync(sy + SY_QF_GO) < AO_NW, 0);
+    const unsigned total_o = wo.nrw > 0 ? (unsigned)wo.nrw * wo.rb : 0u;
     const int nso = (int)((total_o + ST_SLOT - 1) / ST_SLOT);
-    const uint8_t *src_q = q.W + (size_t)q.b0 * q.rb, *src_o = o.W + (size_t)b0o * o.row_bytes;
-    const unsigned lds_q = lds_addr(smem + lay.qkv), lds_o = lds_addr(smem + lay.wo);
+    const uint8_t *src_q = q.W + (size_t)q.b0 * q.rb, *src_o = wo.W + (size_t)wo.b0 * wo.rb;
     int issued = 0, published = 0;
     auto publish = [&]() {
         const int landed = (ST_SI * issued - vm_outstanding()) / ST_SI;
@@ -702,15 +736,19 @@ __device__ __forceinline__ void qf_loader(const QFRun &q, const AOArgs &o, uint8
         publish(); __builtin_amdgcn_s_sleep(1);
     }
 }
-// waves 0 - 7: row pairs w, w + 8, .. of the workgroup's Q | K | V rows out of LDS (consumer_op's arithmetic, as ao_decode below), each result one granule
-template <int TYPE>
+// waves 0 - 7: row pairs w, w + 8, .. of the workgroup's Q | K | V rows out of LDS (consumer_op's arithmetic, as ao_decode below), each result one granule.
+// (Measured, same box: a contiguous run of three rows per wave decoded side by side - equal work for every wave - is 0.6 us SLOWER: the phase ends one decode
+// step behind the landing of the run's last slot, and a pair is the shortest step.)
+template <int TYPE, int KB>
 __device__ __forceinline__ void qf_decode(const QFRun &q, const QFArgs &f, const uint8_t *slice, const ActL &AL, int *sy, unsigned tag, int wave, int lane) {
     using Rw = Raw<TYPE>;
     const LaneRole L = make_role<TYPE>(lane);
-    constexpr int SBP = role_sbp<TYPE>();
-    const int nb = f.K >> 8, NP = (nb + SBP - 1) / SBP;
+    constexpr int SBP = role_sbp<TYPE>(), NP = role_passes<TYPE, KB>();   // (K <= 4096: one pass of the wide lane roles, two of the others; a partial last pass decodes zero-scale slices)
+    static_assert(NP <= 2, "activation slices in registers");
+    const int nb = f.K >> 8;
     const unsigned rb = q.rb;
     const int n_steps = (q.nrw + 1) >> 1;
+    const ActSlice S0 = read_slice_t<TYPE>(AL, L.sbl, nb, L), S1 = NP > 1 ? read_slice_t<TYPE>(AL, SBP + L.sbl, nb, L) : S0;
     for (int s = wave; s < n_steps; s += AO_NW) {
         const bool two = 2 * s + 1 < q.nrw;
         const unsigned off0 = 2u * (unsigned)s * rb, off1 = two ? off0 + rb : off0;
@@ -718,9 +756,9 @@ __device__ __forceinline__ void qf_decode(const QFRun &q, const QFArgs &f, const
         const int need0 = (int)((n + 1u) >> 1), need1 = (int)(n >> 1);
         ST_SPIN_WHILE(ld_sync(sy + SY_LANDED) < need0 || ld_sync(sy + SY_LANDED + 1) < need1, 1);
         float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 2
+#pragma unroll
         for (int p = 0; p < NP; p++) {
-            const ActSlice sl = read_slice_t<TYPE>(AL, p * SBP + L.sbl, nb, L);
+            const ActSlice sl = p == 0 ? S0 : S1;
             int sb = p * SBP + L.sbl;
             if (sb >= nb) sb = nb - 1;
             Rw w0, w1;
@@ -738,12 +776,24 @@ __device__ __forceinline__ void qf_decode(const QFRun &q, const QFArgs &f, const
     }
 }
 
+// ea (QF): the layer input and the norm weights, requested in the kernel's first instructions from PRELOADED arguments (qkv_attn_out_kernel)
 template <int R, int TK, int TV, int C, int KB>
-__device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f) {
+__device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f,
+                                        const EarlyAct<(KB > 0 ? KB : 1)> *eap = nullptr, const QFFast *fast = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool QF = KB > 0;
     const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
-    if constexpr (QF) sync_init(smem);                 // (all ten waves)
+    if constexpr (QF) {
+        sync_init(smem);                               // (all ten waves)
+        if (wave >= AO_NW && (fast->kf >> 31) != 0) {  // the stream starts here: geometry from preloaded arguments, the LDS layout from them too (slots of the two runs)
+            QFRun fq; QFWoRun fw;
+            qf_fast_setup(*fast, fq, fw);
+            const unsigned rpw = (fast->kf >> 23) & 255u;
+            const unsigned slice = (rpw * fw.rb + ST_SLOT - 1) / ST_SLOT * ST_SLOT;     // (o.slice_lds: the W_o rows of a full workgroup in whole slots)
+            qf_loader(fq, fw, smem, lds_addr(smem + AO_QF_HDR + slice), lds_addr(smem + AO_QF_HDR), false, wave - AO_NW, lane);
+            return;
+        }
+    }
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
     const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>), QF ? AO_QF_HDR : 0u, QF ? f.qkv_lds : 0u);
     AOSmem<R, C> &sm = *reinterpret_cast<AOSmem<R, C> *>(smem + lay.attn);
@@ -753,7 +803,19 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
     QFRun qr{};
     if constexpr (QF) {
         qr = qf_setup(f);
-        if (wave >= AO_NW) { qf_loader(qr, o, smem, lay, b0, nrw, wave - AO_NW, lane); return; }
+        if (wave >= AO_NW) {
+            const QFWoRun wr{b0, nrw, o.W, o.row_bytes};
+            qf_loader(qr, wr, smem, lds_addr(smem + lay.qkv), lds_addr(smem + lay.wo), true, wave - AO_NW, lane);
+            return;
+        }
+        if ((fast->kf >> 31) != 0 && wave == 0 && lane == 0) {     // the packed geometry must describe the runs the arguments describe
+            QFRun fq; QFWoRun fw;
+            qf_fast_setup(*fast, fq, fw);
+            const unsigned rpw = (fast->kf >> 23) & 255u;
+            const unsigned slice = (rpw * fw.rb + ST_SLOT - 1) / ST_SLOT * ST_SLOT;
+            if (fq.W != qr.W || fq.rb != qr.rb || fq.b0 != qr.b0 || fq.nrw != qr.nrw || fq.ns != qr.ns || fw.b0 != b0 || fw.nrw != nrw || fw.W != o.W || fw.rb != o.row_bytes ||
+                slice != o.slice_lds || AO_QF_HDR + slice != lay.qkv) st_timeout(ST_ERR_LOADER);
+        }
     }
     // residual of this wave's first row pair: requested now, used at the very end
     float rs0 = 0.0f, rs1 = 0.0f;
@@ -770,8 +832,12 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
     int it0 = (int)blockIdx.x;
     if constexpr (QF) {
         static_assert(ST_NC == AO_NW, "the weight stream's prologue is cut for eight consumer waves");
-        EarlyAct<KB> ea;
-        early_issue<KB, 1>(f.nx, f.nw, f.K, wave, lane, ea);
+#ifndef MI355_QF_LATE_GO
+        // the loaders go NOW: only the activation's requests must be ahead of the stream (the launch's first dependent step waits for the Q | K | V rows to land,
+        // not for the prologue); the item's cache rows, queued behind the stream, are not needed before q exists
+        asm volatile("" ::: "memory");
+        if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_QF_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         const bool pre_item = it0 < o.n_items;         // (workgroup-uniform)
         AOItemLd<R, TK, TV, C> ld0;
         if (pre_item) ao_item_issue<R, TK, TV, C, true>(a, cs_table, n_rot, fz, o, it0 % G, it0 / G, ld0);
@@ -779,15 +845,18 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
         StOp pa{};
         pa.K = f.K; pa.neps = f.neps; pa.nx = f.nx; pa.nw = f.nw;
         const StLayout stl{(int)lay.qs, (int)lay.d, (int)lay.bs, 0};
-        consumer_prologue<KB, 1, false, false, true>(pa, smem, stl, wave, lane, EngIO(), &ea);      // ([SY_GO] goes up inside, behind this wave's requests)
+#ifdef MI355_QF_LATE_GO
+        if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_QF_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+        consumer_prologue<KB, 1, false, false, true>(pa, smem, stl, wave, lane, EngIO(), eap);
         if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 7] = wall_clock64();
         if (qr.nrw > 0) {
             const unsigned tag = scal.serial * 256u + (unsigned)o.layer + 1u;
             const ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
             switch (qr.type) {
-                case T_Q4_K: qf_decode<T_Q4_K>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
-                case T_Q5_K: qf_decode<T_Q5_K>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
-                case T_Q6_K: qf_decode<T_Q6_K>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                case T_Q4_K: qf_decode<T_Q4_K, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                case T_Q5_K: qf_decode<T_Q5_K, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                case T_Q6_K: qf_decode<T_Q6_K, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
                 default: break;
             }
         }
@@ -895,11 +964,23 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
     ao_body<R, TK, TV, C, 0>(a, cs_table, n_rot, fz, o, QFArgs{});
 }
 constexpr int AO_QF_NT = AO_NT + 128;                   // QF: two loader waves behind the eight
+// The first 13 argument dwords repeat what the launch's first instructions need (QFFast): the first dwords of a kernel's argument segment arrive in SGPRs with the
+// wave (build.py: -amdgpu-kernarg-preload-count for this file), so the activation's requests are queued in the kernel's first instructions and the loaders start
+// the stream behind the first barrier - before the cold argument segment has answered its first read (0.45 us)
 template <int R, int TK, int TV, int C, int KB>
-__global__ __launch_bounds__(AO_QF_NT) void qkv_attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o, const QFArgs f) {
-    struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; QFArgs f; };
+__global__ __launch_bounds__(AO_QF_NT) void qkv_attn_out_kernel(const float *p_nx, const uint8_t *p_wbase, unsigned p_onw, unsigned p_owq, unsigned p_owk, unsigned p_owv, unsigned p_owo,
+                                                                unsigned p_kf, unsigned p_rb01, unsigned p_rb2o, unsigned p_nkv, const AttnArgs a, const float *cs_table, int n_rot,
+                                                                const DecodeFuse fz, const AOArgs o, const QFArgs f) {
+    const QFFast fast{p_nx, p_wbase, p_onw, p_owq, p_owk, p_owv, p_owo, p_kf, p_rb01, p_rb2o, p_nkv};
+    EarlyAct<KB> ea;
+    {
+        const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
+        // (the loaders' copies are never looked at: a request under a condition makes hipcc wait where the branches join)
+        early_issue<KB, 1>(p_nx, reinterpret_cast<const float *>(p_wbase + ((size_t)p_onw << 4)), (int)(p_kf & 31u) << 8, wave < AO_NW ? wave : 0, lane, ea);
+    }
+    struct KArgs { QFFast p; AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; QFArgs f; };
     ao_touch_kernargs<sizeof(KArgs)>();
-    ao_body<R, TK, TV, C, KB>(a, cs_table, n_rot, fz, o, f);
+    ao_body<R, TK, TV, C, KB>(a, cs_table, n_rot, fz, o, f, &ea, &fast);
 }
 
 int g_attn_out_fused = -1;                  // -1: environment / default (on)
@@ -981,7 +1062,7 @@ void attn_out_probe_report() {
 }
 
 // the launch of either form: qf == nullptr: the attention + attn_output kernel; else the layer's Q | K | V in front of it in the same launch
-struct QFPlan { QFArgs f; int blocks; int kb; size_t lds_qkv; int slots; };
+struct QFPlan { QFArgs f; QFFast p; int blocks; int kb; size_t lds_qkv; int slots; };
 static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
                             unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
                             const QFPlan *qf, hipStream_t st) {
@@ -1020,6 +1101,7 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
             hipExtLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o); \
         else hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);             \
     } while (0)
+#define QF_FAST_ARGS qf->p.nx, qf->p.wbase, qf->p.onw, qf->p.owq, qf->p.owk, qf->p.owv, qf->p.owo, qf->p.kf, qf->p.rb01, qf->p.rb2o, qf->p.nkv
 #define QF_LAUNCH(RR, TK, TV, CC, KBV)                                                                                                         \
     do {                                                                                                                                       \
         const size_t lds = ao_layout(o.slice_lds, K, sizeof(AOSmem<RR, CC>), AO_QF_HDR, qf->f.qkv_lds).total;                                  \
@@ -1028,8 +1110,8 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
         if (e != hipSuccess) return e;                                                                                                         \
         hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                                             \
         if (kernel_timer() && kernel_timer()->next("qkv_attn_out", &ev0_, &ev1_))                                                              \
-            hipExtLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o, qf->f); \
-        else hipLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, a, cs_table, ra.n_rot, fz, o, qf->f); \
+            hipExtLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, ev0_, ev1_, 0, QF_FAST_ARGS, a, cs_table, ra.n_rot, fz, o, qf->f); \
+        else hipLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, QF_FAST_ARGS, a, cs_table, ra.n_rot, fz, o, qf->f); \
     } while (0)
 #define AO_K(RR, TK, TV, CC) do { if (!qf) AO_LAUNCH(RR, TK, TV, CC); else if (qf->kb == 1) QF_LAUNCH(RR, TK, TV, CC, 1); else QF_LAUNCH(RR, TK, TV, CC, 2); } while (0)
 #define AO_C(RR, TK, TV) do { if (C == 64) AO_K(RR, TK, TV, 64); else AO_K(RR, TK, TV, 128); } while (0)
@@ -1049,6 +1131,7 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
 #undef AO_C
 #undef AO_K
 #undef QF_LAUNCH
+#undef QF_FAST_ARGS
 #undef AO_LAUNCH
     return hipGetLastError();
 }
@@ -1117,6 +1200,30 @@ static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse
 #undef QF_SZ
     if (ao_layout((unsigned)wo_lds, K, attn_bytes, AO_QF_HDR, f.qkv_lds).total > 160 * 1024) return p;
     p.blocks = nwg;
+    // the packed geometry of the loaders' fast start (QFFast); kf == 0 (not valid) where a field does not fit - the loaders then read the argument segment.
+    // OFF unless MI355_QF_FAST_START=1: measured on the bench model (same box, tools/ab_libs.sh) the launch is bound by its PROLOGUE, not by the landing of its rows - with
+    // the stream started 0.7 us earlier the consumers' small requests sit behind it ("activation ready" 2.8 -> 3.05 us, worst workgroup 3.9 -> 4.9) and the step
+    // loses 1.4 % (660 vs 670 tok/s) - what mmvq_stream.hip found for its prologue-bound roles
+    static const bool fast_off = !(getenv("MI355_QF_FAST_START") && getenv("MI355_QF_FAST_START")[0] == '1');
+    QFFast &pf = p.p;
+    pf.nx = q.nx;
+    const void *ptrs[5] = {q.nw, q.seg[0].W, q.seg[1].W, q.seg[2].W, wo.W};
+    uintptr_t lo = ~(uintptr_t)0, hi = 0;
+    bool fits = !fast_off;
+    for (int i = 0; i < 5; i++) { const uintptr_t x = (uintptr_t)ptrs[i]; if (x & 15) fits = false; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
+    if (((hi - lo) >> 4) > 0xffffffffull) fits = false;
+    if (f.blk3 != nwg || f.blk1 > 511 || f.blk2 > 511 || rpw > 255 || (q.K >> 8) > 31 || wo.n_rows != q.K || f.n0 != q.K || f.n1 != f.n2) fits = false;
+    if (f.rb0 > 0xffffu || f.rb1 > 0xffffu || f.rb2 > 0xffffu || wo.row_bytes > 0xffffu) fits = false;
+    pf.wbase = reinterpret_cast<const uint8_t *>(lo);
+    if (fits) {
+        pf.onw = (unsigned)(((uintptr_t)ptrs[0] - lo) >> 4); pf.owq = (unsigned)(((uintptr_t)ptrs[1] - lo) >> 4); pf.owk = (unsigned)(((uintptr_t)ptrs[2] - lo) >> 4);
+        pf.owv = (unsigned)(((uintptr_t)ptrs[3] - lo) >> 4); pf.owo = (unsigned)(((uintptr_t)ptrs[4] - lo) >> 4);
+        pf.rb01 = f.rb0 | (f.rb1 << 16); pf.rb2o = f.rb2 | ((unsigned)wo.row_bytes << 16); pf.nkv = (unsigned)f.n1;
+        pf.kf = (unsigned)(q.K >> 8) | ((unsigned)f.blk1 << 5) | ((unsigned)f.blk2 << 14) | ((unsigned)rpw << 23) | (1u << 31);
+    } else {
+        // (the activation's early requests still come from the first arguments: nx, and the norm weights as an offset above wbase = themselves)
+        pf.wbase = reinterpret_cast<const uint8_t *>(q.nw); pf.onw = 0; pf.kf = (unsigned)(q.K >> 8);
+    }
     return p;
 }
 bool qkv_attn_out_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi, const QKVFuse &q) {
