@@ -56,7 +56,7 @@ with_header(f"{O}/r6_rocprof_kernel_stats.txt", f"{P}/r6_rocprof_kernel_stats.tx
     "round 6: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 128 --warmup 16 --no-cpu-baseline (tools/run_profiles_r6.sh step 1)",
     "MI355_NO_GRAPHS=1 MI355_PROFILER_SAFE=1: eager launches (rocprofv3 7.2 crashes while tracing hipGraph replays); Llama-3-8B Q4_K_M synthetic, cache q8_0,",
     "512-token prompt, decode at pos 512..., then the 3968-token fill and the steps at pos ~3976 (long_context), the device-greedy loop and the sweep.",
-    "attn_out_kernel = decode attention + attn_output mat-vec in one launch (csrc/attn_out.hip); mmvq_stream_qkv / _gate_up / _ffn_down / _head = the weight-stream kernel by role",
+    "qkv_attn_out_kernel = Q|K|V + decode attention + attn_output mat-vec in one launch (csrc/attn_out.hip, round 6); mmvq_stream_gate_up / _ffn_down / _head = the weight-stream kernel by role",
     f"kernel_sources_sha256 {sha}",
 ])
 with_header(f"{O}/r6_rocprof_prefill_kernel_stats.txt", f"{P}/r6_rocprof_prefill_kernel_stats.txt", [
@@ -66,7 +66,8 @@ with_header(f"{O}/r6_rocprof_prefill_kernel_stats.txt", f"{P}/r6_rocprof_prefill
 ])
 with_header(f"{O}/r6_rocprof_decode_kernel_stats.txt", f"{P}/r6_rocprof_decode_kernel_stats.txt", [
     "round 6: rocprofv3 --kernel-trace --stats -- python3 tools/decode_loop.py 64 (tools/run_profiles_r6.sh step 2): a 512-token prompt, then 64 single-token steps at pos 512..575; eager launches",
-    "one row per role of the weight-stream kernel: mmvq_stream_qkv (Q|K|V behind the fused RMSNorm), _gate_up (SwiGLU pair), _ffn_down (quantising prologue + residual), _head (output head)",
+    "one row per role of the weight-stream kernel: mmvq_stream_gate_up (SwiGLU pair), _ffn_down (quantising prologue + residual), _head (output head); Q|K|V run inside",
+    "qkv_attn_out_kernel since round 6 (one launch per layer: RMSNorm -> Q8_K, Q|K|V, rope, KV store, attention, merge, Q8_K, attn_output + residual)",
     f"kernel_sources_sha256 {sha}",
 ])
 
@@ -95,8 +96,12 @@ for tag in ("qkv", "gate_up", "ffn_down", "head"):
     st_us_tok += us_tok
     st_bytes_tok += b_tok
 ao = [(n, c, t, a) for n, c, t, a in rows if "attn_out_kernel" in n]
+# round 6: where the step runs Q | K | V inside its attention + attn_output launch (qkv_attn_out_kernel, csrc/attn_out.hip QF) the trace has no mmvq_stream_qkv row and
+# the attention launch reads attn_q / attn_k / attn_v as well
+QF = any("qkv_attn_out_kernel" in n for n, _, _, _ in ao)
+AO_BYTES = WO_BYTES + (ROLE_BYTES["qkv"] if QF else 0)
 ao_us_tok = sum(t for _, _, t, _ in ao) / max(1, n_steps)
-per_tok_launches = sum(ROLE_LAUNCHES.values())
+per_tok_launches = sum(ROLE_LAUNCHES[t] for t in roles)
 roof = {
     "source": "profiles/r6_rocprof_decode_kernel_stats.txt (rocprofv3 --kernel-trace --stats, eager launches, 64 steps at pos 512..575)",
     "kernel_sources_sha256": sha,
@@ -110,9 +115,12 @@ roof = {
     "frac_rocprof": round(st_bytes_tok / st_us_tok / 1e3 / 8000.0, 4),
     "attn_out_us_per_token": round(ao_us_tok, 2),
     "attn_out_avg_launch_us": round(ao_us_tok / N_LAYER, 3),
-    "attn_out_weight_bytes_per_token": int(WO_BYTES),
-    "all_matvec_GBps": round((st_bytes_tok + WO_BYTES) / (st_us_tok + ao_us_tok) / 1e3, 1),
-    "frac_rocprof_with_attention_launch": round((st_bytes_tok + WO_BYTES) / (st_us_tok + ao_us_tok) / 1e3 / 8000.0, 4),
+    "attn_out_kernel": "qkv_attn_out_kernel (RMSNorm -> Q8_K, Q | K | V, rope, KV store, attention, merge, Q8_K, attn_output + residual: one launch per layer)" if QF
+                       else "attn_out_kernel (rope, KV store, attention, merge, Q8_K, attn_output + residual)",
+    "attn_out_weight_bytes_per_token": int(AO_BYTES),
+    "attn_out_frac_of_8TBps": round(AO_BYTES / ao_us_tok / 1e3 / 8000.0, 4),
+    "all_matvec_GBps": round((st_bytes_tok + AO_BYTES) / (st_us_tok + ao_us_tok) / 1e3, 1),
+    "frac_rocprof_with_attention_launch": round((st_bytes_tok + AO_BYTES) / (st_us_tok + ao_us_tok) / 1e3 / 8000.0, 4),
 }
 json.dump(roof, open(f"{P}/r6_rocprof_decode_roofline.json", "w"), indent=1)
 print("traced stream", roof["stream_us_per_token"], "us/token ->", roof["stream_GBps"], "GB/s, frac", roof["frac_rocprof"])
@@ -152,9 +160,9 @@ out = {
     "algorithmic_weight_bytes_per_token": int(st_bytes_tok),
     "ratio": round(per_tok / st_bytes_tok, 4),
     "attn_out_hbm_read_bytes_per_token": ao_tok,
-    "attn_out_algorithmic_bytes_per_token": int(WO_BYTES),
-    "note": "per role: traced HBM read bytes per launch against the tensor's bytes; attn_output's 302 MB per token are read inside attn_out_kernel (with the KV cells of "
-            "the step) and listed separately",
+    "attn_out_algorithmic_bytes_per_token": int(AO_BYTES),
+    "note": "per role: traced HBM read bytes per launch against the tensor's bytes; attn_output's 302 MB per token (and, round 6, the 470 MB of attn_q / attn_k / attn_v) are "
+            "read inside the attention launch (with the KV cells of the step) and listed separately",
 }
 json.dump(out, open(f"{P}/r6_pmc_decode_traffic.json", "w"), indent=1)
 print("traffic per token", int(per_tok), "ratio", out["ratio"], "attn_out", ao_tok, "sha", sha[:12])
