@@ -174,6 +174,8 @@ def load_library(path: str | None = None):
         raise MI355Error(f"{p} not found: build it with `python cortex.llamacpp_amd/build.py` (hipcc, gfx950)")
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
+        if name.startswith("mi355_debug_") and os.environ.get("MI355_LLAMA_LIB") and not hasattr(lib, name):
+            continue                     # (tools/ab_libs.sh: an older build of the library under MI355_LLAMA_LIB may lack a diagnosis getter)
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -82,6 +82,19 @@ template <int R, int C> struct AOSmem {
     uint32_t newkd[2], newvd[2];
     int last_flag;
 };
+template <int R, int C> struct AOSmemQ {   // QF: AOSmem without the P.V / merge scratch `accs` (AO_NCG * R * D floats), which lives in the space of the Q | K | V rows once they have been decoded
+    alignas(16) float qf[R * AO_D];
+    alignas(16) int8_t qc[R * AO_D];
+    float qd[R * AO_NB];
+    float S[R * C];
+    float ml[R * 2];
+    int vis[C];
+    uint32_t ksc[C * AO_NB / 2], vsc[C * AO_NB / 2];
+    alignas(16) uint8_t newk[AO_D * 2];
+    alignas(16) uint8_t newv[AO_D * 2];
+    uint32_t newkd[2], newvd[2];
+    int last_flag;
+};
 
 // Round 6, QF (KB > 0): Q | K | V of the layer inside this launch (see qf_* below and the note in front of ao_body).  The three tensors as the weight
 // stream would plan them (mmvq_stream_plan: workgroups per tensor in proportion to its bytes, a workgroup's rows are of ONE tensor, contiguous).
@@ -94,6 +107,7 @@ struct QFArgs {
     unsigned long long *gran;         // the token's q | k | v as tagged granules {tag, f32 bits}: H * D + 2 * G * D of them, shared by the layers of a step (the tag names the layer)
     int n_q, n_kv;                    // H * D, G * D
     unsigned qkv_lds;                 // LDS bytes reserved for the workgroup's Q | K | V rows (whole 4 KiB slots)
+    unsigned accs_off;                // LDS byte offset of the attention's P.V / merge scratch (AO_NCG * R * D floats)
 };
 constexpr int SY_QF_GO = 40;          // QF sync word: waves whose activation requests are queued (the loaders start behind them)
 constexpr unsigned AO_QF_HDR = 512;   // QF: the weight stream's sync words and reduction scratch in front of everything (mmvq_stream_dev.h ST_OFF_SYNC, ST_OFF_RED)
@@ -225,63 +239,88 @@ __device__ __forceinline__ AOScalars ao_load_scalars(const unsigned *serial, con
                  : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(serial), "s"(tpos), "s"(tseq), "s"(cell) : "memory");
     return AOScalars{s0, s1, s2, s3};
 }
-// qf (QF only): the launch's own Q | K | V granules and the step's scalars, read at the top of the launch
-template <int R, int TK, int TV, int C, bool QF, class Dma>
-__device__ __forceinline__ void ao_item_run(const AttnArgs &a, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f, const AOScalars *pre,
-                                            int g, int sp, AOSmem<R, C> &sm, AOItemLd<R, TK, TV, C> &ld, Dma dma) {
+// ---- one attention item of the launch WITHOUT Q | K | V (attn_out_kernel), as round 4 wrote it: requests and their uses in one straight-line function.  (The
+// split form below - ao_item_issue / ao_item_run, which the fused launch needs - compiled 16 more registers and a scratch frame into this kernel and cost
+// Llama-2-7B's steps 3.4 % on the same box, tools/ab_libs.sh; the two forms hold the same arithmetic.)
+// (kv head g, chunk slot sp) on the 512 threads of the workgroup; every exit is workgroup-uniform.  `dma` (the request for the
+// workgroup's W_o rows; it does nothing after its first call) is called by every wave once the item has nothing outstanding and nobody waits for it.
+// the step's scalars every item needs, read in one batch of scalar loads UNDER the item's vector loads
+template <int R, int TK, int TV, int C, class Dma>
+__device__ __forceinline__ void ao_attn_item(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o,
+                                             int g, int sp, AOSmem<R, C> &sm, Dma dma) {
     constexpr int D = AO_D, NB = AO_NB, NT = AO_NT;
     constexpr int KROW = TK == T_F16 ? 2 * D : D;
     constexpr int LPC = KROW / 16;                           // lanes per cell in the score pass
     constexpr int KP = C * LPC / NT;                         // 16-byte K pieces per thread
+    static_assert(C * LPC % NT == 0 && KP >= 1, "chunk size");
     constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
     constexpr int CL = C / 64;                               // cells per lane in the softmax
-    constexpr int HP = D / 2, NPAIR = R * HP;
     const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
     const int n_ctx = a.n_ctx;
-    if (ld.skip) { dma(); return; }
-    const int c_lo = ld.chunk * C;
+    int chunk = sp;
+    if (a.tok_chunks) {                                      // (C == 64 only: the lists count 64-cell chunks)
+        if (sp >= a.tok_nchunks[0]) { dma(); return; }
+        chunk = a.tok_chunks[sp];
+    }
+    const int c_lo = chunk * C;
     const size_t head_row0 = (size_t)g * n_ctx;
-    const int cpos = ld.cpos;
-    const unsigned long long cseq = ld.cseq;
-    const uint32_t ks2 = ld.ks2, vs2 = ld.vs2;
-    const f32x2_t csv = ld.csv;
-    const f32x4_t cs4 = ld.cs4;
+
+    // ---- every global load of the item
+    int cpos = -1;
+    unsigned long long cseq = 0;
+    if (tid < C && c_lo + tid < n_ctx) { cpos = a.cell_pos[c_lo + tid]; cseq = a.cell_seq[c_lo + tid]; }
+    constexpr int HP = D / 2, NPAIR = R * HP;
+    static_assert(NPAIR <= NT, "query pairs per thread");
+    f32x2_t qv = {0.0f, 0.0f}, csv = {1.0f, 0.0f};
+    if (tid < NPAIR) {
+        const int r = tid / HP, i = tid % HP;
+        qv = *reinterpret_cast<const f32x2_t *>(a.q + ((size_t)g * R + r) * D + 2 * i);
+        if (2 * i < n_rot) csv = *reinterpret_cast<const f32x2_t *>(cs_table + 2 * i);
+    }
     u32x4_t kreg[KP];
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + NT * j;
+        int cell = c_lo + p / LPC;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TK == T_F16) kreg[j] = *reinterpret_cast<const u32x4_t *>(reinterpret_cast<const uint16_t *>(a.kv.k) + rowi * D + (p % LPC) * 8);
+        else kreg[j] = *reinterpret_cast<const u32x4_t *>(a.kv.k + rowi * KROW + (p % LPC) * 16);
+    }
+    const int dq = tid % DQ, cg = tid / DQ;
     u32x2_t vreg[CPG];
 #pragma unroll
-    for (int j = 0; j < KP; j++) kreg[j] = ld.kreg[j];
-#pragma unroll
-    for (int i = 0; i < CPG; i++) vreg[i] = ld.vreg[i];
-    const int dq = tid % DQ, cg = tid / DQ;
-    // ---- the step's scalars (one batch of scalar loads, under the vector loads above; QF: read at the top of the launch)
-    const AOScalars sc = QF ? *pre : ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
-    const unsigned serial = sc.serial;
-    const int tpos = sc.tpos, tseq = sc.tseq;
-    f32x2_t qv = ld.qv;
-    f32x4_t xn4 = ld.xn4;
-    if constexpr (QF) {
-        // q of this kv head's R query heads and (wave 0) the token's K / V row of this kv head, as the projections' workgroups published them: tagged
-        // granules, swept until every one carries this step's and this layer's tag (data and validity in one 8-byte store: nothing to fence)
-        const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
-        const __amdgpu_buffer_rsrc_t qrs = coh_rsrc(f.gran);
+    for (int i = 0; i < CPG; i++) {
+        int cell = c_lo + cg + NCG * i;
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        const size_t rowi = head_row0 + cell;
+        if (TV == T_F16) vreg[i] = *reinterpret_cast<const u32x2_t *>(reinterpret_cast<const uint16_t *>(a.kv.v) + rowi * D + dq * 4);
+        else { vreg[i].x = *reinterpret_cast<const uint32_t *>(a.kv.v + rowi * D + dq * 4); vreg[i].y = 0; }
+    }
+    uint32_t ks2 = 0, vs2 = 0;
+    if (tid < C * NB / 2) {
+        int cell = c_lo + tid / (NB / 2);
+        if (cell >= n_ctx) cell = n_ctx - 1;
+        if (TK != T_F16) ks2 = *reinterpret_cast<const uint32_t *>(a.kv.kd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+        if (TV != T_F16) vs2 = *reinterpret_cast<const uint32_t *>(a.kv.vd + (head_row0 + cell) * NB + (tid % (NB / 2)) * 2);
+    }
+
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+    // the token's un-rotated K / V row of this kv head: 1 KB, requested by wave 0 of EVERY item now (which chunk holds the token's cell is only known once
+    // the scalars are back; waiting for them first cost that chunk - every kv head's slowest item - a second memory round trip)
+    // (every wave, unconditionally: a load under a condition makes hipcc wait for ALL outstanding loads where the branches join)
+    // (native vector types: HIP's float4 class, modified under a condition below, is placed in scratch by hipcc)
+    f32x4_t xn4, cs4;
+    {
         const bool isk = lane < 32;
         const int dd = (lane & 31) * 4;
-        const int qoff = (int)((((size_t)g * R + (tid < NPAIR ? tid / HP : 0)) * D + 2 * (tid % HP)) * 8);
-        const int koff = (int)(((size_t)f.n_q + (isk ? 0 : (size_t)f.n_kv) + (size_t)g * D + dd) * 8);
-        coh_u32x4 qg = {0u, tag, 0u, tag}, k0 = {0u, tag, 0u, tag}, k1 = {0u, tag, 0u, tag};
-        int spins = 0;
-        for (;;) {
-            if (tid < NPAIR) qg = __builtin_amdgcn_raw_buffer_load_b128(qrs, qoff, 0, 16);                 // (wave-uniform: NPAIR is a multiple of 64)
-            if (wave == 0) { k0 = __builtin_amdgcn_raw_buffer_load_b128(qrs, koff, 0, 16); k1 = __builtin_amdgcn_raw_buffer_load_b128(qrs, koff + 16, 0, 16); }
-            const bool ok = qg.y == tag && qg.w == tag && k0.y == tag && k0.w == tag && k1.y == tag && k1.w == tag;
-            if (__all(ok)) break;
-            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        qv = f32x2_t{__uint_as_float(qg.x), __uint_as_float(qg.z)};
-        xn4 = f32x4_t{__uint_as_float(k0.x), __uint_as_float(k0.z), __uint_as_float(k1.x), __uint_as_float(k1.z)};
-        if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
+        xn4 = *reinterpret_cast<const f32x4_t *>((isk ? fz.knew : fz.vnew) + g * D + dd);
+        cs4 = *reinterpret_cast<const f32x4_t *>(cs_table + (dd < n_rot ? dd : n_rot - 4));   // c0 s0 c1 s1 (clamped: used only where dd < n_rot)
     }
+    // ---- the step's scalars (one batch of scalar loads, under the vector loads above)
+    const AOScalars sc = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
+    const unsigned serial = sc.serial;
+    const int tpos = sc.tpos, tseq = sc.tseq;
     // ---- this token's own K / V row (the chunk that holds its cell): rotate K, convert, write the cache row, keep the codes for the patch below
     int own_cl = -1;
     {
@@ -587,6 +626,368 @@ __device__ __forceinline__ void ao_item_run(const AttnArgs &a, int n_rot, const 
     dma();
 }
 
+// qf (QF only): the launch's own Q | K | V granules and the step's scalars, read at the top of the launch
+template <int R, int TK, int TV, int C, bool QF, class Dma>
+__device__ __forceinline__ void ao_item_run(const AttnArgs &a, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f, const AOScalars *pre,
+                                            int g, int sp, AOSmemQ<R, C> &sm, float *accs, AOItemLd<R, TK, TV, C> &ld, Dma dma) {
+    constexpr int D = AO_D, NB = AO_NB, NT = AO_NT;
+    constexpr int KROW = TK == T_F16 ? 2 * D : D;
+    constexpr int LPC = KROW / 16;                           // lanes per cell in the score pass
+    constexpr int KP = C * LPC / NT;                         // 16-byte K pieces per thread
+    constexpr int DQ = D / 4, NCG = AO_NCG, CPG = C / NCG;   // P.V pass: 32 lanes of 4 dims, 16 cell groups of CPG cells
+    constexpr int CL = C / 64;                               // cells per lane in the softmax
+    constexpr int HP = D / 2, NPAIR = R * HP;
+    const int tid = tid_now(), lane = tid & 63, wave = tid >> 6;
+    const int n_ctx = a.n_ctx;
+    if (ld.skip) { dma(); return; }
+    const int c_lo = ld.chunk * C;
+    const size_t head_row0 = (size_t)g * n_ctx;
+    const int cpos = ld.cpos;
+    const unsigned long long cseq = ld.cseq;
+    const uint32_t ks2 = ld.ks2, vs2 = ld.vs2;
+    const f32x2_t csv = ld.csv;
+    const f32x4_t cs4 = ld.cs4;
+    u32x4_t kreg[KP];
+    u32x2_t vreg[CPG];
+#pragma unroll
+    for (int j = 0; j < KP; j++) kreg[j] = ld.kreg[j];
+#pragma unroll
+    for (int i = 0; i < CPG; i++) vreg[i] = ld.vreg[i];
+    const int dq = tid % DQ, cg = tid / DQ;
+    // ---- the step's scalars (one batch of scalar loads, under the vector loads above; QF: read at the top of the launch)
+    const AOScalars sc = QF ? *pre : ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
+    const unsigned serial = sc.serial;
+    const int tpos = sc.tpos, tseq = sc.tseq;
+    f32x2_t qv = ld.qv;
+    f32x4_t xn4 = ld.xn4;
+    if constexpr (QF) {
+        // q of this kv head's R query heads and (wave 0) the token's K / V row of this kv head, as the projections' workgroups published them: tagged
+        // granules, swept until every one carries this step's and this layer's tag (data and validity in one 8-byte store: nothing to fence)
+        const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
+        const __amdgpu_buffer_rsrc_t qrs = coh_rsrc(f.gran);
+        const bool isk = lane < 32;
+        const int dd = (lane & 31) * 4;
+        const int qoff = (int)((((size_t)g * R + (tid < NPAIR ? tid / HP : 0)) * D + 2 * (tid % HP)) * 8);
+        const int koff = (int)(((size_t)f.n_q + (isk ? 0 : (size_t)f.n_kv) + (size_t)g * D + dd) * 8);
+        coh_u32x4 qg = {0u, tag, 0u, tag}, k0 = {0u, tag, 0u, tag}, k1 = {0u, tag, 0u, tag};
+        int spins = 0;
+        for (;;) {
+            if (tid < NPAIR) qg = __builtin_amdgcn_raw_buffer_load_b128(qrs, qoff, 0, 16);                 // (wave-uniform: NPAIR is a multiple of 64)
+            if (wave == 0) { k0 = __builtin_amdgcn_raw_buffer_load_b128(qrs, koff, 0, 16); k1 = __builtin_amdgcn_raw_buffer_load_b128(qrs, koff + 16, 0, 16); }
+            const bool ok = qg.y == tag && qg.w == tag && k0.y == tag && k0.w == tag && k1.y == tag && k1.w == tag;
+            if (__all(ok)) break;
+            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        qv = f32x2_t{__uint_as_float(qg.x), __uint_as_float(qg.z)};
+        xn4 = f32x4_t{__uint_as_float(k0.x), __uint_as_float(k0.z), __uint_as_float(k1.x), __uint_as_float(k1.z)};
+        if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
+    }
+    // ---- this token's own K / V row (the chunk that holds its cell): rotate K, convert, write the cache row, keep the codes for the patch below
+    int own_cl = -1;
+    {
+        const int cellnew = sc.cellnew;
+        if (cellnew >= c_lo && cellnew < c_lo + C) own_cl = cellnew - c_lo;
+        if (own_cl >= 0 && wave == 0) {                          // lanes 0 .. 31: K, lanes 32 .. 63: V; four elements each
+            const bool isk = lane < 32;
+            const int dd = (lane & 31) * 4;
+            float xa[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
+            if (isk && dd < n_rot) {
+                const float x0 = xn4.x, x1 = xn4.y, x2 = xn4.z, x3 = xn4.w;
+                xa[0] = x0 * cs4.x - x1 * cs4.y; xa[1] = x0 * cs4.y + x1 * cs4.x;
+                xa[2] = x2 * cs4.z - x3 * cs4.w; xa[3] = x2 * cs4.w + x3 * cs4.z;
+            }
+            const size_t rowi = head_row0 + cellnew;
+            const int TT = isk ? TK : TV;
+            // (the cache planes through opaque copies: from `isk ? a.kv.k : a.kv.v` on the kernel arguments hipcc builds a two-entry pointer table in scratch)
+            uint8_t *kvk = a.kv.k, *kvv = a.kv.v;
+            asm volatile("" : "+s"(kvk), "+s"(kvv));
+            uint32_t packed = 0; float dsc = 0.0f;
+            if (TK != T_F16 || TV != T_F16) wave_quant_q80(xa, packed, dsc);   // whole wave takes part (8-lane groups)
+            if (TT == T_F16) {
+                u32x2_t ov; ov.x = (uint32_t)f2h(xa[0]) | ((uint32_t)f2h(xa[1]) << 16); ov.y = (uint32_t)f2h(xa[2]) | ((uint32_t)f2h(xa[3]) << 16);
+                *reinterpret_cast<u32x2_t *>((isk ? sm.newk : sm.newv) + dd * 2) = ov;
+                *reinterpret_cast<u32x2_t *>(reinterpret_cast<uint16_t *>(isk ? kvk : kvv) + rowi * D + dd) = ov;
+            } else {
+                *reinterpret_cast<uint32_t *>((isk ? sm.newk : sm.newv) + dd) = packed;
+                *reinterpret_cast<uint32_t *>((isk ? kvk : kvv) + rowi * D + dd) = packed;
+                if ((lane & 7) == 0) {
+                    const uint16_t hd = f2h(dsc);
+                    (isk ? a.kv.kd : a.kv.vd)[rowi * NB + (dd >> 5)] = hd;
+                    reinterpret_cast<uint16_t *>(isk ? sm.newkd : sm.newvd)[dd >> 5] = hd;
+                }
+            }
+        }
+    }
+
+    // ---- q: rotate, convert
+    if (tid < C) sm.vis[tid] = (cpos >= 0 && cpos <= tpos && ((cseq >> tseq) & 1ull)) ? 1 : 0;
+    if (tid < C * NB / 2) { sm.ksc[tid] = ks2; sm.vsc[tid] = vs2; }
+    if (tid < NPAIR) {
+        const float x0 = qv.x, x1 = qv.y, c = csv.x, s = csv.y;
+        float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;
+        if (TK == T_F16) { y0 = h2f(f2h(y0)); y1 = h2f(f2h(y1)); }
+        { const f32x2_t yy = {y0, y1}; *reinterpret_cast<f32x2_t *>(sm.qf + 2 * tid) = yy; }
+    }
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
+    if (own_cl >= 0) {   // workgroup-uniform: the row just produced instead of what the cache held before
+        if (tid < NB / 2) {
+            if (TK != T_F16) sm.ksc[own_cl * (NB / 2) + tid] = sm.newkd[tid];
+            if (TV != T_F16) sm.vsc[own_cl * (NB / 2) + tid] = sm.newvd[tid];
+        }
+#pragma unroll
+        for (int j = 0; j < KP; j++) {
+            const int p = tid + NT * j;
+            if (p / LPC == own_cl) kreg[j] = *reinterpret_cast<const u32x4_t *>(sm.newk + (p % LPC) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < CPG; i++) {
+            if (cg + NCG * i == own_cl) {
+                if (TV == T_F16) vreg[i] = *reinterpret_cast<const u32x2_t *>(sm.newv + dq * 8);
+                else { vreg[i].x = *reinterpret_cast<const uint32_t *>(sm.newv + dq * 4); vreg[i].y = 0; }
+            }
+        }
+    }
+    if (TK != T_F16) {   // q8_0 of the rotated q: 4 values per thread, 8-lane groups (whole waves: R * D / 4 is a multiple of 64)
+        if (tid * 4 < R * D) {
+            const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(sm.qf + tid * 4);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            uint32_t packed; float d;
+            wave_quant_q80(vv, packed, d);
+            *reinterpret_cast<uint32_t *>(sm.qc + tid * 4) = packed;
+            if ((lane & 7) == 0) sm.qd[(tid * 4) >> 5] = h2f(f2h(d));
+        }
+        __syncthreads();
+    }
+
+    // ---- scores
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+        const int p = tid + NT * j;
+        const int cl = p / LPC, piece = p % LPC;
+        float sc[R];
+        if (TK == T_F16) {
+            const uint32_t kw[4] = {kreg[j].x, kreg[j].y, kreg[j].z, kreg[j].w};
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float *qq = sm.qf + r * D + piece * 8;
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    s += h2f((uint16_t)(kw[i] & 0xffff)) * qq[2 * i];
+                    s += h2f((uint16_t)(kw[i] >> 16)) * qq[2 * i + 1];
+                }
+                s += dpp_f<DPP_QP_1032>(s); s += dpp_f<DPP_QP_2301>(s); s += dpp_f<DPP_HALF_MIRROR>(s); s += dpp_f<DPP_MIRROR>(s);      // 16 lanes
+                sc[r] = s;
+            }
+        } else {
+            const uint32_t kpair = sm.ksc[cl * (NB / 2) + (piece >> 2)];
+            const float dk = h2f((uint16_t)(((piece >> 1) & 1) ? (kpair >> 16) : (kpair & 0xffff)));
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u32x4_t qq = *reinterpret_cast<const u32x4_t *>(sm.qc + r * D + piece * 16);
+                int s = 0;
+                s = dot4(kreg[j].x, qq.x, s); s = dot4(kreg[j].y, qq.y, s); s = dot4(kreg[j].z, qq.z, s); s = dot4(kreg[j].w, qq.w, s);
+                s += dpp_i<DPP_QP_1032>(s);                    // both halves of the 32-block (integer)
+                float f = (piece & 1) ? 0.0f : (float)s * (dk * sm.qd[r * NB + (piece >> 1)]);
+                f += dpp_f<DPP_QP_1032>(f); f += dpp_f<DPP_QP_2301>(f);                                 // 4 lanes
+                f += dpp_f<DPP_HALF_MIRROR>(f);                                                          // 8 lanes
+                sc[r] = f;
+            }
+        }
+        if (piece == 0) {
+            const bool v = sm.vis[cl] != 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) sm.S[r * C + cl] = v ? sc[r] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
+
+    // ---- softmax of the chunk: wave w -> heads w, w + 8, ..; lane = cell (and cell + 64)
+    for (int r = wave; r < R; r += AO_NW) {
+        float s[CL], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < CL; k++) { s[k] = sm.S[r * C + 64 * k + lane]; m = fmaxf(m, s[k]); }
+        m = wave_max(m);
+        float l = 0.0f;
+#pragma unroll
+        for (int k = 0; k < CL; k++) {
+            const float p = (s[k] == -INFINITY) ? 0.0f : expf(s[k] - m);
+            sm.S[r * C + 64 * k + lane] = p;
+            l += p;
+        }
+        l = wave_sum(l);
+        if (lane == 0) { sm.ml[2 * r] = m; sm.ml[2 * r + 1] = l; }
+    }
+    __syncthreads();
+
+    // ---- P.V
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < CPG; i++) {
+        const int cl = cg + NCG * i;
+        float v4[4];
+        if (TV == T_F16) {
+            v4[0] = h2f((uint16_t)(vreg[i].x & 0xffff)); v4[1] = h2f((uint16_t)(vreg[i].x >> 16));
+            v4[2] = h2f((uint16_t)(vreg[i].y & 0xffff)); v4[3] = h2f((uint16_t)(vreg[i].y >> 16));
+        } else {
+            const uint32_t vpair = sm.vsc[cl * (NB / 2) + (dq >> 4)];
+            const float dv = h2f((uint16_t)(((dq >> 3) & 1) ? (vpair >> 16) : (vpair & 0xffff)));
+            const uint32_t w = vreg[i].x;
+            v4[0] = (float)(int8_t)(w & 0xff) * dv; v4[1] = (float)(int8_t)((w >> 8) & 0xff) * dv;
+            v4[2] = (float)(int8_t)((w >> 16) & 0xff) * dv; v4[3] = (float)(int8_t)(w >> 24) * dv;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float p = sm.S[r * C + cl];
+            acc[r][0] += v4[0] * p; acc[r][1] += v4[1] * p; acc[r][2] += v4[2] * p; acc[r][3] += v4[3] * p;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        { const f32x4_t av = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]}; *reinterpret_cast<f32x4_t *>(accs + ((size_t)cg * R + r) * D + dq * 4) = av; }
+    __syncthreads();
+    // ---- the chunk's partial record per head: AO_REC floats = O [D] | m | l | 0 | 0, written through to the coherence point in 16-byte pieces (a 4-byte
+    // write-through store is one fabric write each: 520 of them per item sat in the drain in front of the ticket)
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 11] = wall_clock64();
+    {
+        const __amdgpu_buffer_rsrc_t prs = coh_rsrc(a.part);
+        if (tid * 4 < R * D) {
+            const int r = (tid * 4) / D, d = tid * 4 - r * D;
+            f32x4_t sum = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < NCG; j++) {
+                const f32x4_t v = *reinterpret_cast<const f32x4_t *>(accs + ((size_t)j * R + r) * D + d);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            const int off = (int)(((((size_t)g * R + r) * a.splits + sp) * AO_REC + d) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(coh_u32x4, sum), prs, off, 0, 16);
+            if (d == 0) {
+                const f32x4_t mlv = {sm.ml[2 * r], sm.ml[2 * r + 1], 0.0f, 0.0f};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(coh_u32x4, mlv), prs, off + D * 4, 0, 16);
+            }
+        }
+    }
+
+    // ---- ticket; the last workgroup of this kv head (group) merges: GP kv heads per ticket, RM = GP * R heads merged (attn_decode_dev.h)
+    constexpr int GP = 256 / ((R * D) % 256 == 0 ? 256 : 128);
+    constexpr int RM = R * GP;
+    const int gq = g / GP;
+    const int hb = gq * RM;
+    const int stride_s = a.splits;
+    const int splits = a.tok_nchunks ? a.tok_nchunks[0] : a.splits;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through partial stores have left
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(fz.counters + gq * ATT_SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm.last_flag = (old == (unsigned)(splits * GP) - 1u) ? 1 : 0;
+        if (sm.last_flag) __hip_atomic_store(fz.counters + gq * ATT_SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+    // the W_o rows may queue now: nothing of this item is outstanding any more and nobody waits for this workgroup (36 KB of DMA in front of the partial
+    // stores would have sat in their drain, i.e. in every kv head's ticket); the merging workgroup requests them after it has raised its flag
+    if (!sm.last_flag) { dma(); return; }
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 2] = wall_clock64();
+    // The merge: out[h][d] = sum over the chunks of w[h][chunk] * O[h][chunk][d], w = exp(m - M) / sum(exp(m - M) * l) (flash_attn_combine_kernel's
+    // weights).  The RM * D outputs are NDG groups of four dims; the 512 threads are NPH phases x NDG groups, phase p takes the chunks p, p + NPH, ..:
+    // at most 8 (16 from 33 chunks on) 16-byte loads per thread, all requested before the (m, l) pairs so that the weights are computed under them; the
+    // phases' partial sums meet in LDS and are added in phase order (a fixed order: the same bits on every run).
+    constexpr int NDG = RM * D / 4, NPH = NT / NDG < 4 ? NT / NDG : 4, UB = 8;     // (at most four phases: threads beyond them only help with the weights)
+    static_assert(NDG % 64 == 0 && NDG * NPH <= NT, "merge phases");
+    float *psum = accs;                             // [NPH][RM * D]
+    float *merged = accs + NPH * RM * D;            // [RM * D]
+    static_assert((NPH + 1) * RM * D + (GP > 1 ? RM * 64 : 0) <= AO_NCG * R * D, "merge scratch");
+    static_assert(RM * 64 <= R * C || GP > 1, "weights scratch");
+    const int dg = tid % NDG, ph = tid / NDG;          // (ph is the same for all lanes of a wave: NDG is a multiple of 64)
+    const int mr = (dg * 4) / D, md = dg * 4 - mr * D;
+    const __amdgpu_buffer_rsrc_t prs = coh_rsrc(a.part);
+    const int rec0 = (int)(((((size_t)hb + mr) * stride_s) * AO_REC + md) * 4);
+    coh_u32x4 x[UB];
+    auto request = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int s2 = s0 + ph + NPH * u;
+            if (ph < NPH && s2 < splits) x[u] = __builtin_amdgcn_raw_buffer_load_b128(prs, rec0 + s2 * (AO_REC * 4), 0, 16);     // (wave-uniform condition)
+        }
+    };
+    request(0);
+    float *wg2 = GP > 1 ? accs + (NPH + 1) * RM * D : sm.S;     // [RM][64] chunk weights (pairs of kv heads: S is too small for two heads' weights)
+    for (int r = wave; r < RM; r += AO_NW) {
+        float m = -INFINITY, l = 0.0f;
+        if (lane < splits) {
+            const coh_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(prs, (int)(((((size_t)hb + r) * stride_s + lane) * AO_REC + D) * 4), 0, 16);
+            m = __uint_as_float(v.x); l = __uint_as_float(v.y);
+        }
+        const float M = wave_max(m);
+        const float w = (lane < splits && m != -INFINITY) ? expf(m - M) : 0.0f;
+        const float den = wave_sum(w * l);
+        const float inv = 1.0f / den;
+        wg2[r * 64 + lane] = w * inv;
+    }
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 13] = wall_clock64();
+    f32x4_t macc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s0 = 0;;) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int s2 = s0 + ph + NPH * u;
+            if (ph < NPH && s2 < splits) {
+                const float w = wg2[mr * 64 + s2];
+                const f32x4_t xv = __builtin_bit_cast(f32x4_t, x[u]);
+                macc.x += w * xv.x; macc.y += w * xv.y; macc.z += w * xv.z; macc.w += w * xv.w;
+            }
+        }
+        s0 += NPH * UB;
+        if (s0 >= splits) break;
+        request(s0);
+    }
+    if (ph < NPH) *reinterpret_cast<f32x4_t *>(psum + (size_t)ph * RM * D + dg * 4) = macc;      // (the item's P.V sums in accs were consumed before the ticket)
+    __syncthreads();
+    for (int e = tid; e < RM * D; e += NT) {
+        float v = 0.0f;
+#pragma unroll
+        for (int p2 = 0; p2 < NPH; p2++) v += psum[(size_t)p2 * RM * D + e];
+        merged[e] = v;
+    }
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 14] = wall_clock64();
+    __syncthreads();                                   // (no global store is outstanding here: a barrier behind stores waits for them)
+    // The flag goes up NOW, before the codes exist: it only says "start looking".  The codes travel as 8-byte granules {tag, value} - data and validity in one
+    // store, nothing to fence or drain - and every consumer sweeps them until each carries this step's tag: its first sweep is in flight while the codes
+    // are being written.
+    const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
+    if (tid == 0) __hip_atomic_store(o.flags + gq * ATT_SYNC_STRIDE, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int NBLK = (RM * D) >> 8;                // 256-blocks this ticket group owns in the H * D row
+    const __amdgpu_buffer_rsrc_t grs = coh_rsrc(o.gran);
+    for (int b = wave; b < NBLK; b += AO_NW) {
+        const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(merged + b * 256 + lane * 4);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int gb = ((hb * D) >> 8) + b;            // global block index
+        uint32_t packed; int bs; float dq8;
+        wave_quant_q8k(vv, lane, packed, bs, dq8);
+        // two granules per 16-byte write-through store (each 8-byte half carries its own tag): the even lane takes its neighbour's word
+        const uint32_t packed1 = (uint32_t)dpp_i<DPP_QP_1032>((int)packed);
+        // a block's granules: [64 x four codes | 16 block sums | scale, 15 unused] = AO_GPB granules = six 128-byte lines that no other merger writes
+        if ((lane & 1) == 0) {
+            const coh_u32x4 g2 = {packed, tag, packed1, tag};
+            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, (gb * AO_GPB + lane) * 8, 0, 16);
+        }
+        const int bs1 = dpp_i<0x104>(bs);             // row_shl:4 - the block sum four lanes further on (the next 16-code group)
+        if ((lane & 7) == 0) {
+            const coh_u32x4 g2 = {(unsigned)bs & 0xffffu, tag, (unsigned)bs1 & 0xffffu, tag};
+            __builtin_amdgcn_raw_buffer_store_b128(g2, grs, (gb * AO_GPB + 64 + (lane >> 2)) * 8, 0, 16);
+        }
+        if (lane == 0) st_store_granule(o.gran + gb * AO_GPB + 80, tag, __float_as_uint(dq8));
+    }
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 3] = wall_clock64();
+    for (int e = tid; e < RM * D; e += NT) a.out[(size_t)hb * D + e] = merged[e];   // (the f32 rows: nobody in this launch reads them)
+    dma();
+}
+
 // ---- the mat-vec part: wave w decodes the row pairs w, w + 8, .. of the workgroup's rows out of LDS (consumer_op's arithmetic: passes in order, each
 // row's lane partials summed by wave_sum, residual + value)
 template <int TYPE>
@@ -795,8 +1196,11 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
         }
     }
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
-    const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>), QF ? AO_QF_HDR : 0u, QF ? f.qkv_lds : 0u);
-    AOSmem<R, C> &sm = *reinterpret_cast<AOSmem<R, C> *>(smem + lay.attn);
+    const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmemQ<R, C>), QF ? AO_QF_HDR : 0u, QF ? f.qkv_lds : 0u);
+    AOSmemQ<R, C> &sm = *reinterpret_cast<AOSmemQ<R, C> *>(smem + lay.attn);
+    // the P.V / merge scratch: in the space of the workgroup's Q | K | V rows where it fits there (they are dead once decoded; the first write is behind the item's
+    // first workgroup barrier, which every wave reaches after its last row), behind everything else otherwise (f.accs_off: the launcher's choice)
+    float *accs = reinterpret_cast<float *>(smem + f.accs_off);
     const int b0r = (int)blockIdx.x * o.rows_per_wg;
     const int b0 = b0r < o.n_rows ? b0r : o.n_rows;
     const int nrw = b0 + o.rows_per_wg <= o.n_rows ? o.rows_per_wg : o.n_rows - b0;
@@ -861,7 +1265,7 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
             }
         }
         if (pre_item) {                                // the workgroup's first item: its cache rows have been in registers since the top of the launch
-            ao_item_run<R, TK, TV, C, true>(a, n_rot, fz, o, f, &scal, it0 % G, it0 / G, sm, ld0, dma);
+            ao_item_run<R, TK, TV, C, true>(a, n_rot, fz, o, f, &scal, it0 % G, it0 / G, sm, accs, ld0, dma);
             had_item = true;
             it0 += (int)gridDim.x;
         }
@@ -870,7 +1274,7 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
         if (had_item) __syncthreads();                 // (the item's LDS is reused)
         AOItemLd<R, TK, TV, C> ld;
         ao_item_issue<R, TK, TV, C, QF>(a, cs_table, n_rot, fz, o, it % G, it / G, ld);
-        ao_item_run<R, TK, TV, C, QF>(a, n_rot, fz, o, f, QF ? &scal : nullptr, it % G, it / G, sm, ld, dma);
+        ao_item_run<R, TK, TV, C, QF>(a, n_rot, fz, o, f, QF ? &scal : nullptr, it % G, it / G, sm, accs, ld, dma);
         had_item = true;
     }
     dma();                                             // workgroups without an item: at once
@@ -959,10 +1363,111 @@ template <size_t BYTES> __device__ __forceinline__ void ao_touch_kernargs() {
 }
 template <int R, int TK, int TV, int C>
 __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz, const AOArgs o) {
-    struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; };
-    ao_touch_kernargs<sizeof(KArgs)>();
-    ao_body<R, TK, TV, C, 0>(a, cs_table, n_rot, fz, o, QFArgs{});
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // The kernel argument segment is cold at every launch and hipcc reads a field where it is first used: seven dependent scalar-load round trips sat in front
+    // of the first K / V request (1.4 us from entry to "loads issued", MI355_AO_PROBE).  One independent read per 64-byte line of the segment, all in flight
+    // together, makes the later field reads scalar-cache hits.
+    {
+        struct KArgs { AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; };
+        const __attribute__((address_space(4))) unsigned *ka = (const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_kernarg_segment_ptr();
+        unsigned acc = 0;
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(KArgs) + 63) / 64); i++) acc ^= ka[i * 16];
+        asm volatile("" :: "s"(acc));
+    }
+    const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
+    const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmem<R, C>));
+    AOSmem<R, C> &sm = *reinterpret_cast<AOSmem<R, C> *>(smem + lay.attn);
+    const int b0r = (int)blockIdx.x * o.rows_per_wg;
+    const int b0 = b0r < o.n_rows ? b0r : o.n_rows;
+    const int nrw = b0 + o.rows_per_wg <= o.n_rows ? o.rows_per_wg : o.n_rows - b0;
+    // residual of this wave's first row pair: requested now, used at the very end
+    float rs0 = 0.0f, rs1 = 0.0f;
+    if (o.epi == EPI_ADD && 2 * wave < nrw) {
+        rs0 = o.resid[b0 + 2 * wave];
+        if (2 * wave + 1 < nrw) rs1 = o.resid[b0 + 2 * wave + 1];
+    }
+    bool dma_done = false;
+    auto dma = [&]() { if (!dma_done) { ao_issue_dma(o, smem, b0, nrw, wave, lane); dma_done = true; } };
+    const int G = a.G;
+    bool had_item = false;
+    for (int it = (int)blockIdx.x; it < o.n_items; it += (int)gridDim.x) {
+        if (had_item) __syncthreads();                 // (the item's LDS is reused)
+        ao_attn_item<R, TK, TV, C>(a, cs_table, n_rot, fz, o, it % G, it / G, sm, dma);
+        had_item = true;
+    }
+    dma();                                             // workgroups without an item: at once
+    const unsigned serial = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell).serial;     // (a second batch for workgroups that had an item: scalar-cache hits)
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 1] = wall_clock64();
+
+    // ---- the merged, quantised attention output: wait until every ticket group's merge has its sums (one wave polls, relaxed, bounded), then every wave
+    // sweeps its share of the granules until each carries this step's tag and puts the values where the decoders expect the Q8_K planes
+    const unsigned tag = serial * 256u + (unsigned)o.layer + 1u;
+    // (ONE polling wave per workgroup: four of them, a quarter of a round trip apart, noticed the flags earlier and still cost 1.3 % of the step - 1024
+    // pollers on eight words slow the mergers' own traffic down; same-box A/B, tools/ab_libs.sh)
+    if (wave == 0) {
+        int spins = 0;
+        for (;;) {
+            unsigned v = tag;
+            if (lane < o.n_flags) v = __hip_atomic_load(o.flags + lane * ATT_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v == tag)) break;
+            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
+            __builtin_amdgcn_s_sleep(MI355_AO_POLL_SLEEP);
+        }
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 4] = wall_clock64();
+    {
+        constexpr int PPB = 41;                        // granule pairs a block holds (32 of codes, 8 of block sums, 1 = scale + an unused word)
+        const int nb = o.K >> 8, np = nb * PPB;
+        constexpr int PPT = (32 * PPB + AO_NT - 1) / AO_NT;      // pairs per thread at the longest K the launch takes (8192)
+        const __amdgpu_buffer_rsrc_t grs = coh_rsrc(o.gran);
+        coh_u32x4 val[PPT];
+        int blk[PPT], w[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) { const int i = tid + AO_NT * j; blk[j] = i / PPB; w[j] = i - blk[j] * PPB; }
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                if (tid + AO_NT * j < np) {
+                    val[j] = __builtin_amdgcn_raw_buffer_load_b128(grs, (blk[j] * AO_GPB + 2 * w[j]) * 8, 0, 16);
+                    ok = ok && val[j].y == tag && (val[j].w == tag || w[j] == PPB - 1);
+                }
+            }
+            if (__all(ok)) break;
+            if (++spins >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_GATHER); break; }
+            __builtin_amdgcn_s_sleep(MI355_AO_SWEEP_SLEEP);
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            if (tid + AO_NT * j >= np) continue;
+            if (w[j] < 32) { unsigned *q = reinterpret_cast<unsigned *>(smem + lay.qs) + blk[j] * 64 + 2 * w[j]; q[0] = val[j].x; q[1] = val[j].z; }
+            else if (w[j] < 40) reinterpret_cast<unsigned *>(smem + lay.bs)[blk[j] * 8 + (w[j] - 32)] = (val[j].x & 0xffffu) | (val[j].z << 16);
+            else reinterpret_cast<unsigned *>(smem + lay.d)[blk[j]] = val[j].x;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the W_o rows (DMA) has landed
+    __syncthreads();
+    if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 5] = wall_clock64();
+    if (nrw > 0) {
+        const ActL AL{reinterpret_cast<const int8_t *>(smem + lay.qs), reinterpret_cast<const float *>(smem + lay.d), reinterpret_cast<const int16_t *>(smem + lay.bs)};
+        switch (o.type) {
+            case T_Q4_K: ao_decode<T_Q4_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q5_K: ao_decode<T_Q5_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            case T_Q6_K: ao_decode<T_Q6_K>(o, smem, AL, b0, nrw, wave, lane, rs0, rs1); break;
+            default: break;
+        }
+    }
+    if (o.probe) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) o.probe[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
+    }
 }
+
 constexpr int AO_QF_NT = AO_NT + 128;                   // QF: two loader waves behind the eight
 // The first 13 argument dwords repeat what the launch's first instructions need (QFFast): the first dwords of a kernel's argument segment arrive in SGPRs with the
 // wave (build.py: -amdgpu-kernarg-preload-count for this file), so the activation's requests are queued in the kernel's first instructions and the loaders start
@@ -1062,7 +1567,7 @@ void attn_out_probe_report() {
 }
 
 // the launch of either form: qf == nullptr: the attention + attn_output kernel; else the layer's Q | K | V in front of it in the same launch
-struct QFPlan { QFArgs f; QFFast p; int blocks; int kb; size_t lds_qkv; int slots; };
+struct QFPlan { QFArgs f; QFFast p; int blocks; int kb; size_t lds_qkv, lds_total; int slots; };
 static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
                             unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
                             const QFPlan *qf, hipStream_t st) {
@@ -1104,8 +1609,8 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
 #define QF_FAST_ARGS qf->p.nx, qf->p.wbase, qf->p.onw, qf->p.owq, qf->p.owk, qf->p.owv, qf->p.owo, qf->p.kf, qf->p.rb01, qf->p.rb2o, qf->p.nkv
 #define QF_LAUNCH(RR, TK, TV, CC, KBV)                                                                                                         \
     do {                                                                                                                                       \
-        const size_t lds = ao_layout(o.slice_lds, K, sizeof(AOSmem<RR, CC>), AO_QF_HDR, qf->f.qkv_lds).total;                                  \
-        if (lds > 160 * 1024) return hipErrorInvalidValue;                                                                                     \
+        const size_t lds = qf->lds_total;                                                                                                      \
+        if (lds > 160 * 1024 || o.slice_lds + AO_QF_HDR > qf->f.accs_off) return hipErrorInvalidValue;                                                                                     \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                                         \
         hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                                             \
@@ -1195,10 +1700,14 @@ static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse
     // the kernel's LDS at the largest attention scratch of the forms (R, chunk) it may take
     const int R = a.H / a.G, C = attn_out_fused_chunk(a);
     size_t attn_bytes = 0;
-#define QF_SZ(RR) attn_bytes = C == 64 ? sizeof(AOSmem<RR, 64>) : sizeof(AOSmem<RR, 128>)
+#define QF_SZ(RR) attn_bytes = C == 64 ? sizeof(AOSmemQ<RR, 64>) : sizeof(AOSmemQ<RR, 128>)
     switch (R) { case 1: QF_SZ(1); break; case 2: QF_SZ(2); break; case 4: QF_SZ(4); break; case 8: QF_SZ(8); break; default: return p; }
 #undef QF_SZ
-    if (ao_layout((unsigned)wo_lds, K, attn_bytes, AO_QF_HDR, f.qkv_lds).total > 160 * 1024) return p;
+    const AOLayout ql = ao_layout((unsigned)wo_lds, K, attn_bytes, AO_QF_HDR, f.qkv_lds);
+    const size_t accs_bytes = (size_t)AO_NCG * R * AO_D * 4;
+    f.accs_off = accs_bytes <= f.qkv_lds ? ql.qkv : ql.total;
+    p.lds_total = accs_bytes <= f.qkv_lds ? ql.total : ql.total + accs_bytes;
+    if (p.lds_total > 160 * 1024) return p;
     p.blocks = nwg;
     // the packed geometry of the loaders' fast start (QFFast); kf == 0 (not valid) where a field does not fit - the loaders then read the argument segment.
     // OFF unless MI355_QF_FAST_START=1: measured on the bench model (same box, tools/ab_libs.sh) the launch is bound by its PROLOGUE, not by the landing of its rows - with
