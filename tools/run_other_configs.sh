@@ -18,3 +18,5 @@ run tinyllama-1.1b-q2_k --config tinyllama-1.1b --ftype q2_k --cache-type f16
 run tinyllama-1.1b-q4_k_m --config tinyllama-1.1b --ftype q4_k_m --cache-type f16
 run mixtral-8x7b --config mixtral-8x7b --ftype q5_k_m
 run llama-3-70b --config llama-3-70b --ftype q4_k_m
+# (a leased box keeps /tmp between calls: the 70B and Mixtral files are 75 GB of an 80 GB disk)
+rm -f /tmp/mi355-bench-llama-3-70b* /tmp/mi355-bench-mixtral* /tmp/mi355-bench-tinyllama* /tmp/mi355-bench-llama-2-7b* /tmp/mi355-bench-llama-3-8b-q8_0*
