@@ -167,6 +167,41 @@ MI355_ST_KERNEL_FAST(mmvq_stream_gate_up_fast)
 MI355_ST_KERNEL_FAST(mmvq_stream_head_fast)
 #undef MI355_ST_KERNEL_FAST
 
+// ---- ffn_down (round 6): a PROLOGUE-bound role - its launch ends one decode pass behind "activation ready", and the activation's requests (57 KB of SwiGLU outputs per
+// workgroup) are the head of that chain.  They are issued in the kernel's first instructions from two preloaded argument words (the vector's address, K >> 8), 0.45 us
+// before the cold argument segment answers its first read; everything else keeps the order of stream_body ("all small requests, then the stream": the loaders wait for
+// [SY_GO] as before - the early STREAM start of the roles above loses here, profiles/r5_exp_fast_start_harness.txt).
+template <int KB>
+__device__ __forceinline__ void stream_body_early(const float *f_nx, unsigned f_k8) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = uni(tid_now() >> 6), lane = tid_now() & 63;
+    EarlyAct<KB> ea;
+    early_issue<KB, 2>(f_nx, nullptr, (int)f_k8 << 8, wave >= ST_NL ? wave - ST_NL : 0, lane, ea);   // (the loaders' copies are never looked at)
+    sync_init(smem);
+    typedef const __attribute__((address_space(4))) MMVQArgs *KArgP;
+    const __attribute__((address_space(4))) char *kseg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kseg) :: "memory");                   // (behind the barrier: hipcc otherwise hoists op_setup's scalar loads in front of the early requests)
+    const __attribute__((address_space(4))) MMVQArgs &ka = *(KArgP)(kseg + 16);
+    StOp a;
+    op_setup<false, false>(ka, a);
+    if (a.n_rows_wg <= 0) return;
+    if (wave < ST_NL) {
+        int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
+        LoaderState st{0, 0, 0, (unsigned)ST_RING_SLOTS, 0};
+        ST_SPIN_WHILE(ld_sync(sy + SY_GO) < ST_NC, 0);
+        loader_op(st, a, smem, wave, 0u, lane, 0);
+        loader_drain(st, smem, wave);
+        return;
+    }
+    if (wave == ST_NL && lane == 0 && (a.nx != f_nx || (unsigned)(a.K >> 8) != f_k8)) st_timeout(ST_ERR_LOADER);   // the preloaded words must describe the launch's activation
+    consumer_dispatch<KB, 2, 0, true>(a, smem, wave - ST_NL, 0u, st_layout(KB), EngIO(), &ea);
+}
+template <int KB>
+__global__ __launch_bounds__(ST_NT) void mmvq_stream_ffn_down_early(const float *f_nx, unsigned f_k8, const MMVQArgs ka_by_value) {
+    static_assert(alignof(MMVQArgs) == 8, "kernel argument layout: two preloaded words (12 bytes), then MMVQArgs at byte 16");
+    stream_body_early<KB>(f_nx, f_k8);
+}
+
 // The same body under one kernel NAME per role a decode step launches it in (round 5): a kernel trace (rocprofv3 --kernel-trace --stats) then carries one row
 // per role - Q | K | V, gate | up, ffn_down, the output head - and the achieved bytes per second of each can be worked out from profiles/ alone
 // (tools/assemble_profiles_r5.py); launches of any other shape (attn_output where it is a launch of its own, expert launches, ..) keep the plain name.
@@ -318,6 +353,8 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
     static const bool fast_off = getenv("MI355_STREAM_FAST_START") && getenv("MI355_STREAM_FAST_START")[0] == '0';
     const StFast fp = (role == ROLE_GATE_UP || role == ROLE_HEAD) && !fast_off && !g_stream_anyorder ? st_fast_pack(a, blocks) : StFast{};
     const bool fast_ok = (fp.kf >> 31) != 0;
+    static const bool down_early_off = getenv("MI355_STREAM_DOWN_EARLY") && getenv("MI355_STREAM_DOWN_EARLY")[0] == '0';
+    const bool down_early = !down_early_off && !g_stream_anyorder && a.nx && !a.out_host;
 #define STREAM_K(KERNEL, KBV, FZ)                                                                                        \
     do {                                                                                                                 \
         /* (per launch: the attribute is per device, and a process may hold contexts on several) */                      \
@@ -348,7 +385,20 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
         else if (role == ROLE_HEAD) STREAM_K(mmvq_stream_head, KBV, 1);                                                  \
         else STREAM_K(mmvq_stream_kernel, KBV, 1);                                                                       \
     } while (0)
-#define STREAM2(KBV) do { if (role == ROLE_DOWN) STREAM_K(mmvq_stream_ffn_down, KBV, 2); else STREAM_K(mmvq_stream_kernel, KBV, 2); } while (0)
+#define STREAM_EARLY(KBV)                                                                                                \
+    do {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mmvq_stream_ffn_down_early<KBV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                       \
+        if (g_kernel_timer && g_kernel_timer->next(role_name, &ev0_, &ev1_))                                             \
+            hipExtLaunchKernelGGL((mmvq_stream_ffn_down_early<KBV>), dim3(blocks), dim3(ST_NT), lds, st, ev0_, ev1_, 0, a.nx, (unsigned)(a.K >> 8), a); \
+        else hipLaunchKernelGGL((mmvq_stream_ffn_down_early<KBV>), dim3(blocks), dim3(ST_NT), lds, st, a.nx, (unsigned)(a.K >> 8), a); \
+    } while (0)
+#define STREAM2(KBV)                                                                                                     \
+    do {                                                                                                                 \
+        if constexpr (KBV == 6 || KBV == 7) { if (role == ROLE_DOWN && down_early) { STREAM_EARLY(KBV); break; } }       \
+        if (role == ROLE_DOWN) STREAM_K(mmvq_stream_ffn_down, KBV, 2); else STREAM_K(mmvq_stream_kernel, KBV, 2);        \
+    } while (0)
 #define STREAM_F(KBV) do { if (a.fuse_mode == 0) STREAM0(KBV); else if (a.fuse_mode == 1) STREAM1(KBV); else STREAM2(KBV); } while (0)
     // a mixture-of-experts step (expert index read on the device): the forms its two launches take - gate | up with the fused RMSNorm prologue over the hidden
     // size, down with the quantise-only prologue over the feed-forward width
@@ -383,6 +433,7 @@ hipError_t launch_mmvq_stream(MMVQArgs a, hipStream_t st) {
 #undef STREAM0
 #undef STREAM1
 #undef STREAM2
+#undef STREAM_EARLY
 #undef STREAM_FAST
 #undef STREAM_K
     return hipGetLastError();
