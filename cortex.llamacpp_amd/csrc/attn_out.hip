@@ -1101,8 +1101,8 @@ __device__ __forceinline__ void qf_fast_setup(QFFast p, QFRun &q, QFWoRun &w) {
     w.rb = p.rb2o >> 16;
 }
 // a loader wave (lq = 0, 1): global slot j of the workgroup = slot j of its Q | K | V run, then the slots of its W_o run; loader lq copies the slots j = lq mod 2
-// and publishes how many of ITS slots have landed ([SY_LANDED + lq]; they land in order).  At most 15 slots = 60 DMA instructions per loader: what the wave's
-// vector-memory counter can count (the launcher checks the sum).
+// and publishes how many of ITS slots have landed ([SY_LANDED + lq]; they land in order), never more than 15 slots = 60 DMA instructions in flight: what the wave's
+// vector-memory counter can count.
 __device__ __forceinline__ void qf_loader(const QFRun &q, const QFWoRun &wo, uint8_t *smem, unsigned lds_q, unsigned lds_o, bool wait_go, int lq, int lane) {
     int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
     if (wait_go) ST_SPIN_WHILE(ld_sync(sy + SY_QF_GO) < AO_NW, 0);
@@ -1115,6 +1115,12 @@ __device__ __forceinline__ void qf_loader(const QFRun &q, const QFWoRun &wo, uin
         if (landed > published) { published = landed; st_sync(sy + SY_LANDED + lq, landed); }
     };
     for (int j = lq; j < q.ns + nso; j += 2) {
+        // at most 15 slots = 60 DMA instructions of this wave in flight: what its vector-memory counter can count (a run of more slots waits for landings here)
+        int polls = 0;
+        while (issued - published >= 15) {
+            if (++polls >= ST_SPIN_LIMIT) { st_timeout(ST_ERR_LOADER); return; }
+            publish(); __builtin_amdgcn_s_sleep(1);
+        }
         const bool isq = j < q.ns;
         const uint8_t *src = isq ? src_q : src_o;
         const unsigned total = isq ? q.total : total_o, last = total - 16u;
@@ -1252,7 +1258,9 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
 #ifdef MI355_QF_LATE_GO
         if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_QF_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-        consumer_prologue<KB, 1, false, false, true>(pa, smem, stl, wave, lane, EngIO(), eap);
+        // (the activation in the format THIS workgroup's tensor contracts with: Q8_K planes, or Q8_0 codes + block scales for a Q8_0 tensor; workgroup-uniform)
+        if (act_is_q80(qr.type)) consumer_prologue<KB, 1, true, false, true>(pa, smem, stl, wave, lane, EngIO(), eap);
+        else consumer_prologue<KB, 1, false, false, true>(pa, smem, stl, wave, lane, EngIO(), eap);
         if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 7] = wall_clock64();
         if (qr.nrw > 0) {
             const unsigned tag = scal.serial * 256u + (unsigned)o.layer + 1u;
@@ -1261,6 +1269,7 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
                 case T_Q4_K: qf_decode<T_Q4_K, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
                 case T_Q5_K: qf_decode<T_Q5_K, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
                 case T_Q6_K: qf_decode<T_Q6_K, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
+                case T_Q8_0: qf_decode<T_Q8_0, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
                 default: break;
             }
         }
@@ -1665,7 +1674,7 @@ static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse
     if ((reinterpret_cast<uintptr_t>(q.nx) & 15) != 0 || (reinterpret_cast<uintptr_t>(q.nw) & 15) != 0) return p;
     for (int s = 0; s < 3; s++) {
         const MMVQSeg &g = q.seg[s];
-        if (g.type != T_Q4_K && g.type != T_Q5_K && g.type != T_Q6_K) return p;
+        if (g.type != T_Q4_K && g.type != T_Q5_K && g.type != T_Q6_K && g.type != T_Q8_0) return p;    // (Q8_0: attn_k / attn_v of 8-expert files)
         if (g.expert_sel || (g.row_bytes % 16) != 0 || g.row_bytes > 0xffffffffull || (reinterpret_cast<uintptr_t>(g.W) & 15) != 0) return p;
     }
     const int nwg0 = std::min(num_cu(), (wo.n_rows + 1) / 2);
@@ -1686,7 +1695,7 @@ static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse
     p.lds_qkv = (run + ST_SLOT - 1) / ST_SLOT * ST_SLOT;
     const size_t wo_lds = ((size_t)rpw * wo.row_bytes + ST_SLOT - 1) / ST_SLOT * ST_SLOT;
     p.slots = (int)((p.lds_qkv + wo_lds) / ST_SLOT);
-    if (p.slots > 30) return p;                                                                    // 15 slots = 60 DMA instructions per loader wave
+    if (p.slots > 60) return p;
     QFArgs &f = p.f;
     f.W0 = q.seg[0].W; f.W1 = q.seg[1].W; f.W2 = q.seg[2].W;
     f.rb0 = (unsigned)q.seg[0].row_bytes; f.rb1 = (unsigned)q.seg[1].row_bytes; f.rb2 = (unsigned)q.seg[2].row_bytes;
