@@ -209,6 +209,9 @@ CONFIGS = {
     # super-blocks, ffn_down columns of 3584 = 14 super-blocks (and the 28672-wide ffn_down's column halves meet the column slicing)
     "tiny-70b-2l": LlamaConfig("tiny-70b-2l", 8192, 2, 64, 8, 28672, 512, 500000.0, 1e-5, 1024),
     "tiny-g8": LlamaConfig("tiny-g8", 2048, 2, 16, 8, 4096, 512, 500000.0, 1e-5, 1024),
+    # Llama-2-7B's ATTENTION geometry (4096, 32 heads, 32 kv heads: BASELINE config 2) with a narrow feed-forward, two layers: a workgroup's share of the 12288 Q | K | V
+    # rows is 140 KB - more than the fused attention-block launch (csrc/attn_out.hip) can hold: the two launches (tools/r6_qf_ring.patch streamed it through a ring: slower)
+    "tiny-7b-attn-2l": LlamaConfig("tiny-7b-attn-2l", 4096, 2, 32, 32, 2048, 512, 10000.0, 1e-5, 1024),
     # Llama-3-70B's feed-forward width on a narrow model: 28672 has no weight-stream form, its single-token ffn_down runs as two column halves of 14336
     "tiny-ff28k": LlamaConfig("tiny-ff28k", 1024, 2, 8, 2, 28672, 512, 500000.0, 1e-5, 1024),
     # three layers of Llama-3-8B's geometry: two launches of the layer engine (decode_engine.hip) that hand Q | K | V on + the last one

@@ -1212,13 +1212,15 @@ def test_attn_out_one_launch_agrees_with_the_two_launches(be, pkg, tmp_models, c
 
 
 @pytest.mark.parametrize("cfg,ftype,kv", [("tiny-8b-2l", "q4_k_m", "q8_0"), ("tiny-8b-2l", "q5_k_m", "f16"), ("tiny-g8", "q4_k_m", "f16"), ("tiny-d128-mha", "q5_k_m", "q8_0"),
-                                          ("tiny-d128", "q6_k", "q8_0"), ("tiny-e2048", "q4_k_m", "q8_0"), ("tiny-moe-e2048", "q4_k_m", "q8_0")])
+                                          ("tiny-d128", "q6_k", "q8_0"), ("tiny-e2048", "q4_k_m", "q8_0"), ("tiny-moe-e2048", "q4_k_m", "q8_0"),
+                                          ("tiny-8b-2l", "q6_k", "q8_0")])
 def test_qkv_inside_the_attention_launch_is_bitwise_the_separate_launch(be, pkg, tmp_models, cfg, ftype, kv):
     """Round 6: a single-token step's Q | K | V mat-vecs (RMSNorm -> Q8_K prologue included) run INSIDE the attention + attn_output launch (attn_out.hip QF: ten
     waves per workgroup, two of them DMA loaders; q / k / v travel between workgroups as tagged granules) - one launch per layer's attention block instead of two.
     The arithmetic is the weight stream's and the attention kernel's own, so the logits must equal the two-launch form's BIT FOR BIT: after prompts of five
     lengths (1 .. 32 attention items per kv head; the last run crosses 2048 cells, where the items become 128-cell chunks), twelve steps each.  tiny-moe-e2048: an
-    8-expert file keeps attn_k / attn_v in Q8_0 - those workgroups quantise the layer input to Q8_0 blocks, the attn_q ones to Q8_K."""
+    8-expert file keeps attn_k / attn_v in Q8_0 - those workgroups quantise the layer input to Q8_0 blocks, the attn_q ones to Q8_K.  tiny-8b-2l q6_k: 80 KB of
+    Q | K | V rows per workgroup, more slots than a loader wave may have in flight."""
     path = make(pkg, tmp_models, cfg, ftype)
     rows = {}
     for fused in (1, 0):
