@@ -83,6 +83,7 @@ SYMBOLS = {
     "mi355_debug_engine_steps": (C.c_int64, [_vp]),
     "mi355_debug_fused_skipped_steps": (C.c_int64, [_vp]),
     "mi355_debug_qkv_attn_launches": (C.c_int64, [_vp]),
+    "mi355_debug_qkv_attn_plan": (C.c_int64, [C.c_int32] * 10 + [C.POINTER(C.c_int32)]),
     "mi355_set_embeddings": (None, [_vp, _i32]),
     "mi355_get_embeddings_ith": (C.POINTER(C.c_float), [_vp, _i32]),
     "mi355_synchronize": (None, [_vp]),

@@ -1744,6 +1744,31 @@ static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse
     }
     return p;
 }
+// host logic only (no device call): LDS bytes of the fused launch for a layer of this geometry at a context of n_kv cells, 0 where the step takes the two launches
+size_t qkv_attn_out_plan_lds(int type_q, int type_k, int type_v, int type_o, int n_embd, int n_head, int n_head_kv, int head_dim, int type_kv, int n_kv, int *slots_out) {
+    static float dummy[4];                                      // (addresses are only checked for alignment here)
+    if (slots_out) *slots_out = 0;
+    if (n_head < 1 || n_head_kv < 1 || head_dim < 1 || n_embd < 256) return 0;
+    AttnArgs a{};
+    a.type_k = type_kv; a.type_v = type_kv; a.T = 1; a.H = n_head; a.G = n_head_kv; a.D = head_dim; a.n_ctx = n_kv; a.n_kv_max = n_kv;
+    ActQuant aq{};
+    a.out_q = &aq; a.out_q8k = true; a.out_q80 = false;
+    a.splits = attn_out_fused_splits(a);
+    RopeArgs ra{};
+    ra.n_rot = head_dim; ra.neox = 0;
+    const int K = n_head * head_dim;
+    const uint8_t *w = reinterpret_cast<const uint8_t *>(dummy);
+    auto seg = [&](int type, int rows, int k) { MMVQSeg g{}; g.W = w; g.type = type; g.n_rows = rows; g.ld_out = rows; g.row_bytes = dev_row_bytes(type, k); return g; };
+    const MMVQSeg wo = seg(type_o, n_embd, K);
+    QKVFuse q{};
+    q.seg[0] = seg(type_q, n_head * head_dim, n_embd); q.seg[1] = seg(type_k, n_head_kv * head_dim, n_embd); q.seg[2] = seg(type_v, n_head_kv * head_dim, n_embd);
+    q.nx = dummy; q.nw = dummy; q.neps = 1e-5f; q.K = n_embd; q.gran = reinterpret_cast<unsigned long long *>(dummy);
+    if (!attn_out_fused_applicable(a, ra, wo, K, EPI_ADD)) return 0;
+    const QFPlan p = qf_plan(a, wo, K, q);
+    if (p.blocks <= 0) return 0;
+    if (slots_out) *slots_out = p.slots;
+    return p.lds_total;
+}
 bool qkv_attn_out_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi, const QKVFuse &q) {
     return attn_out_fused_applicable(a, ra, wo, K, epi) && qf_plan(a, wo, K, q).blocks > 0;
 }

@@ -257,6 +257,13 @@ int64_t mi355_debug_mega_steps(const mi355_context *ctx) { return ctx->c->mega_s
 int64_t mi355_debug_engine_steps(const mi355_context *ctx) { return ctx->c->engine_steps; }
 int64_t mi355_debug_fused_skipped_steps(const mi355_context *ctx) { return ctx->c->fused_skipped_steps; }
 int64_t mi355_debug_qkv_attn_launches(const mi355_context *ctx) { return ctx->c->qkv_attn_launches; }
+int64_t mi355_debug_qkv_attn_plan(int32_t type_q, int32_t type_k, int32_t type_v, int32_t type_o, int32_t n_embd, int32_t n_head, int32_t n_head_kv, int32_t head_dim,
+                                  int32_t type_kv, int32_t n_kv, int32_t *slots_out) {
+    int slots = 0;
+    const size_t lds = qkv_attn_out_plan_lds(type_q, type_k, type_v, type_o, n_embd, n_head, n_head_kv, head_dim, type_kv, n_kv, &slots);
+    if (slots_out) *slots_out = slots;
+    return (int64_t)lds;
+}
 void mi355_set_embeddings(mi355_context *ctx, int32_t enabled) { ctx->c->embeddings_enabled = enabled != 0 || ctx->c->model->hp.encoder; }
 float *mi355_get_embeddings_ith(mi355_context *ctx, int32_t i) { return ctx->c->embeddings_ith(i); }
 void mi355_synchronize(mi355_context *ctx) { ctx->c->synchronize(); }

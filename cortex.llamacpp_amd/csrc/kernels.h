@@ -361,6 +361,8 @@ struct QKVFuse { MMVQSeg seg[3]; const float *nx, *nw; float neps; int K; unsign
 void set_qkv_attn_fused(int on);                          // 0 = Q | K | V as a launch of its own, 1 = fused, -1 = environment (MI355_QKV_ATTN_FUSED, default on)
 bool qkv_attn_fused_enabled();
 size_t qkv_attn_granule_words(int n_q, int n_kv);
+// host logic only: LDS bytes (and DMA slots) of the fused launch for a layer of this geometry at a context of n_kv cells; 0 = the two launches
+size_t qkv_attn_out_plan_lds(int type_q, int type_k, int type_v, int type_o, int n_embd, int n_head, int n_head_kv, int head_dim, int type_kv, int n_kv, int *slots_out);
 bool qkv_attn_out_applicable(const AttnArgs &a, const RopeArgs &ra, const MMVQSeg &wo, int K, int epi, const QKVFuse &q);
 hipError_t launch_qkv_attn_out(const AttnArgs &a, const float *cs_table, RopeArgs ra, const int32_t *tok_cell, unsigned *counters, unsigned *flags, unsigned long long *gran,
                                int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi, const QKVFuse &q, hipStream_t st);

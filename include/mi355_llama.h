@@ -168,6 +168,11 @@ MI355_API int64_t mi355_debug_fused_skipped_steps(const mi355_context *ctx);
    per layer for the whole attention block of a single-token step; "qkv_attn_fused" 0 / MI355_QKV_ATTN_FUSED=0 keeps Q | K | V a launch of its own).  Counts
    launches issued eagerly or while a graph was captured, not graph replays. */
 MI355_API int64_t mi355_debug_qkv_attn_launches(const mi355_context *ctx);
+/* host logic only (no GPU needed): would a single-token step of a layer with these tensor types (MI355_TYPE_*) and this geometry run its Q | K | V inside the attention
+   launch at a context of n_kv cells?  Returns the launch's LDS bytes per workgroup (<= 163840) and, in *slots_out, the 4 KiB DMA slots of a workgroup's rows; 0 = the two
+   launches (types without a form, n_embd != n_head * head_dim or > 4096, head_dim != 128, rows that do not fit beside W_o: Llama-2-7B) */
+MI355_API int64_t mi355_debug_qkv_attn_plan(int32_t type_q, int32_t type_k, int32_t type_v, int32_t type_o, int32_t n_embd, int32_t n_head, int32_t n_head_kv, int32_t head_dim,
+                                            int32_t type_kv, int32_t n_kv, int32_t *slots_out);
 /* llama_set_embeddings (ctx.cc:299) */
 MI355_API void    mi355_set_embeddings(mi355_context *ctx, int32_t enabled);
 /* llama_get_embeddings_ith (ctx.cc:1042-1044): final-norm hidden state (n_embd floats, host memory) of batch row i of the

@@ -53,3 +53,33 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".cc", ".h", ".hip")):
                 txt = open(os.path.join(base, f), errors="replace").read()
                 assert "oracle" not in txt.lower() or f == "build.py", os.path.join(base, f)
+
+
+def test_fused_attention_block_plan_by_geometry(pkg):
+    """Round 6 host logic (no GPU): which layers run their Q | K | V inside the attention + attn_output launch (csrc/attn_out.hip QF).  The plan is a
+    question of LDS: the workgroup's rows of attn_q | attn_k | attn_v and of attn_output, the activation planes and the attention's scratch in <= 160 KB.
+    Llama-3-8B's geometry fits for Q4_K_M, Q5_K_M and an all-Q6_K file; an 8-expert file's Q8_0 attn_k / attn_v fit too; Llama-2-7B's 12288 Q | K | V rows (140 KB per
+    workgroup), the 70B's 8192-wide rows, head size 64, a Q8_0 attn_q / attn_output and n_embd != n_head * head_dim do not and keep the two launches."""
+    import ctypes as C
+    lib = pkg.load_library()
+    Q40, Q80, Q4K, Q5K, Q6K = 2, 8, 12, 13, 14
+
+    def plan(tq, tk, tv, to, E, H, G, D=128, kv=8, n_kv=576):
+        slots = C.c_int32(0)
+        lds = int(lib.mi355_debug_qkv_attn_plan(tq, tk, tv, to, E, H, G, D, kv, n_kv, C.byref(slots)))
+        return lds, int(slots.value)
+
+    lds, slots = plan(Q4K, Q4K, Q6K, Q4K, 4096, 32, 8)                 # Llama-3-8B Q4_K_M ("more bits" layer: attn_v in Q6_K)
+    assert 100 * 1024 < lds <= 160 * 1024 and 20 <= slots <= 30, (lds, slots)
+    lds4k, _ = plan(Q4K, Q4K, Q4K, Q4K, 4096, 32, 8, n_kv=4096)        # the context filled: 128-cell items, one per workgroup
+    assert 0 < lds4k <= 160 * 1024
+    assert plan(Q5K, Q5K, Q6K, Q5K, 4096, 32, 8)[0] > lds              # Q5_K_M: more bytes per row, still one launch
+    assert 0 < plan(Q6K, Q6K, Q6K, Q6K, 4096, 32, 8)[0] <= 160 * 1024
+    assert plan(Q5K, Q80, Q80, Q5K, 4096, 32, 8)[1] > 30               # Mixtral's attention tensors: more slots than a loader wave may have in flight - capped, not refused
+    assert plan(Q5K, Q5K, Q6K, Q5K, 4096, 32, 32, kv=1)[0] == 0        # Llama-2-7B: 140 KB of Q | K | V rows per workgroup
+    assert plan(Q4K, Q4K, Q6K, Q4K, 8192, 64, 8)[0] == 0               # Llama-3-70B on one GPU
+    assert plan(Q4K, Q4K, Q4K, Q4K, 2048, 32, 4, D=64)[0] == 0         # TinyLlama: head size 64
+    assert plan(Q80, Q80, Q80, Q80, 4096, 32, 8)[0] == 0               # a Q8_0 file: attn_output has no form in this launch
+    assert plan(Q40, Q4K, Q4K, Q4K, 4096, 32, 8)[0] == 0
+    assert plan(Q4K, Q4K, Q4K, Q4K, 3584, 32, 8)[0] == 0               # n_embd != n_head * head_dim
+    assert plan(Q4K, Q4K, Q4K, Q4K, 1024, 8, 2)[0] > 0                 # the tiny test models' geometry (tests/test_gpu_model.py)
