@@ -76,7 +76,8 @@ rows = stats_rows(f"{O}/r6_rocprof_decode_kernel_stats.txt")
 
 def role_rows(tag):
     # (gate | up and the head also run as mmvq_stream_<role>_fast: the form that starts its stream from preloaded kernel arguments)
-    return [(n, c, t, a) for n, c, t, a in rows if f"mmvq_stream_{tag}<" in n or f"mmvq_stream_{tag}_fast<" in n]
+    # (ffn_down also runs as mmvq_stream_ffn_down_early: its activation requested from preloaded arguments)
+    return [(n, c, t, a) for n, c, t, a in rows if f"mmvq_stream_{tag}<" in n or f"mmvq_stream_{tag}_fast<" in n or f"mmvq_stream_{tag}_early<" in n]
 
 
 down = role_rows("ffn_down")
@@ -133,11 +134,11 @@ fs = json.load(open(f"{O}/r6_pmc_fetch_size_by_kernel.json"))
 b = lambda v: int(round(v["fetch_size_sum"] * 1024 * 2))   # noqa: E731
 ks = {k: v for k, v in fs.items() if "mmvq_stream_" in k}
 ka = {k: v for k, v in fs.items() if "attn_out_kernel" in k}
-steps16 = sum(v["launches"] for k, v in ks.items() if "mmvq_stream_ffn_down<" in k) // N_LAYER
+steps16 = sum(v["launches"] for k, v in ks.items() if "mmvq_stream_ffn_down<" in k or "mmvq_stream_ffn_down_early<" in k) // N_LAYER
 per_role = {}
 per_tok = 0
 for tag in ("qkv", "gate_up", "ffn_down", "head"):
-    kk = {k: v for k, v in ks.items() if f"mmvq_stream_{tag}<" in k or f"mmvq_stream_{tag}_fast<" in k}
+    kk = {k: v for k, v in ks.items() if f"mmvq_stream_{tag}<" in k or f"mmvq_stream_{tag}_fast<" in k or f"mmvq_stream_{tag}_early<" in k}
     n_l = sum(v["launches"] for v in kk.values())
     if n_l == 0:
         continue
