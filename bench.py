@@ -347,6 +347,17 @@ def main() -> int:
     ctx.synchronize()
     dt = time.perf_counter() - t0
     sync_all()
+    # the same K steps under the same contract (mi355_decode of one token, its logits row host-visible, the arg-max fed back) driven from the C side
+    # (mi355_greedy_steps: the inner loop of the reference's C++ slot loop) instead of from this script - `value` stays the script-driven loop; the difference is
+    # the per-step cost of the scripting caller (numpy marshalling + three ctypes calls), which the C++ host of north_star does not pay
+    c_loop_tok_s = None
+    pos_timed_end = pos                                    # (the headline's timed steps end here)
+    if pos + args.steps < args.ctx - 1:
+        t0c = time.perf_counter()
+        toks_c = ctx.greedy_steps(tok, pos, args.steps)
+        ctx.synchronize()
+        c_loop_tok_s = args.steps / (time.perf_counter() - t0c)
+        tok, pos = int(toks_c[-1]), pos + args.steps
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -636,7 +647,7 @@ def main() -> int:
         "data": "synthetic",
         "config": {
             "workload": f"{cfg.name} {args.ftype.upper()} synthetic GGUF, flash_attn, cache_type={args.cache_type}, "
-                        f"n_ctx={args.ctx}, prompt={args.prompt}, greedy decode at pos {args.prompt + args.warmup}..{pos}",
+                        f"n_ctx={args.ctx}, prompt={args.prompt}, greedy decode at pos {args.prompt + args.warmup}..{pos_timed_end}",
             "parallelism": "single GPU" if n_gpus == 1 else f"{n_gpus} replicas (one sequence per GPU, no collective)",
             "weight_bytes_per_token": int(model.bytes_per_token),
             "kv_bytes_per_token_mid": int(kv_bytes),
@@ -644,6 +655,8 @@ def main() -> int:
         "prefill_tok_s": round(args.prompt / t_prefill, 1),
         "prefill_ms": round(t_prefill * 1e3, 2),
         "decode_tok_s_device_greedy": round(args.steps / dt_greedy, 2),
+        # K more steps of the headline's contract (logits row host-visible every step) with the loop on the C side (mi355_greedy_steps); not `value`
+        "decode_tok_s_c_loop": round(c_loop_tok_s, 2) if c_loop_tok_s else None,
         "decode_hbm_fraction_of_8TBps": round(decode_frac, 4),
         "roofline": {
             "bound": "hbm",
