@@ -36,9 +36,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # roles of the weight-stream kernel start their stream from them before the argument segment has been read (csrc/mmvq_stream.hip stream_body_fast)
 EXTRA = {
     "csrc/mmvq_stream.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
-    # (round 6: the fused Q | K | V + attention + attn_output kernel requests the layer input and starts its weight stream from its first 13 argument dwords,
-    # csrc/attn_out.hip qkv_attn_out_kernel / QFFast)
-    "csrc/attn_out.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=13"],
+    # (round 6: the fused Q | K | V + attention + attn_output kernel requests the layer input from its first five argument dwords,
+    # csrc/attn_out.hip qkv_attn_out_kernel)
+    "csrc/attn_out.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=5"],
 }
 
 

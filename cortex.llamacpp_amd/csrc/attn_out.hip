@@ -1066,46 +1066,13 @@ __device__ __forceinline__ QFRun qf_setup(QFArgs f) {
     q.ns = (int)((q.total + ST_SLOT - 1) / ST_SLOT);
     return q;
 }
-// The launch's geometry once more, packed into the kernel's FIRST 13 argument dwords - scalars the hardware preloads into SGPRs (as mmvq_stream.hip's StFast): the
-// loaders work out their two runs from them and start the stream right behind the workgroup's first barrier, while the argument segment is still cold (the launch
-// ends one decode step + the attention chain behind the landing of the Q | K | V rows: the stream's first request is what counts).  All weights and the norm weights
-// as 16-byte units above `wbase`.  kf: K >> 8 (5 bits) | first workgroup of attn_k (9) | of attn_v (9) | W_o rows per workgroup (8) | valid (1); every
-// workgroup of the launch has rows of a projection (blk3 == gridDim.x), attn_q has K rows, attn_k / attn_v n_kv rows, W_o K rows.
-struct QFFast { const float *nx; const uint8_t *wbase; unsigned onw, owq, owk, owv, owo, kf, rb01, rb2o, nkv; };
-struct QFWoRun { int b0, nrw; const uint8_t *W; unsigned rb; };
-__device__ __forceinline__ void qf_fast_setup(QFFast p, QFRun &q, QFWoRun &w) {
-    asm volatile("" : "+s"(p.owq), "+s"(p.owk), "+s"(p.owv), "+s"(p.owo), "+s"(p.rb01), "+s"(p.rb2o));     // (opaque copies: no selection table in scratch)
-    const unsigned kf = p.kf;
-    const int K = (int)(kf & 31u) << 8, blk1 = (int)((kf >> 5) & 511u), blk2 = (int)((kf >> 14) & 511u), rpw = (int)((kf >> 23) & 255u);
-    const int b = (int)blockIdx.x, nwg = (int)gridDim.x;
-    const int s = b >= blk2 ? 2 : b >= blk1 ? 1 : 0;
-    const int lo = s == 0 ? 0 : s == 1 ? blk1 : blk2, hi = s == 0 ? blk1 : s == 1 ? blk2 : nwg;
-    const int n_rows = s == 0 ? K : (int)p.nkv;
-    const unsigned ow = s == 0 ? p.owq : s == 1 ? p.owk : p.owv;
-    q.W = p.wbase + ((size_t)ow << 4);
-    q.rb = s == 0 ? (p.rb01 & 0xffffu) : s == 1 ? (p.rb01 >> 16) : (p.rb2o & 0xffffu);
-    q.type = 0;                                                    // (the loaders do not decode)
-    const int nblk = hi - lo, bl = b - lo;
-    const int rpb = (n_rows + nblk - 1) / nblk;
-    int b0 = bl * rpb, b1 = b0 + rpb;
-    if (b0 > n_rows) b0 = n_rows;
-    if (b1 > n_rows) b1 = n_rows;
-    q.b0 = b0; q.nrw = b1 - b0;
-    q.grow0 = (s == 0 ? 0 : s == 1 ? K : K + (int)p.nkv) + b0;
-    q.total = (unsigned)q.nrw * q.rb;
-    q.ns = (int)((q.total + ST_SLOT - 1) / ST_SLOT);
-    const int b0r = b * rpw;
-    w.b0 = b0r < K ? b0r : K;
-    w.nrw = w.b0 + rpw <= K ? rpw : K - w.b0;
-    w.W = p.wbase + ((size_t)p.owo << 4);
-    w.rb = p.rb2o >> 16;
-}
+struct QFWoRun { int b0, nrw; const uint8_t *W; unsigned rb; };     // the workgroup's run of W_o rows
 // a loader wave (lq = 0, 1): global slot j of the workgroup = slot j of its Q | K | V run, then the slots of its W_o run; loader lq copies the slots j = lq mod 2
 // and publishes how many of ITS slots have landed ([SY_LANDED + lq]; they land in order), never more than 15 slots = 60 DMA instructions in flight: what the wave's
 // vector-memory counter can count.
-__device__ __forceinline__ void qf_loader(const QFRun &q, const QFWoRun &wo, uint8_t *smem, unsigned lds_q, unsigned lds_o, bool wait_go, int lq, int lane) {
+__device__ __forceinline__ void qf_loader(const QFRun &q, const QFWoRun &wo, uint8_t *smem, unsigned lds_q, unsigned lds_o, int lq, int lane) {
     int *sy = reinterpret_cast<int *>(smem + ST_OFF_SYNC);
-    if (wait_go) ST_SPIN_WHILE(ld_sync(sy + SY_QF_GO) < AO_NW, 0);
+    ST_SPIN_WHILE(ld_sync(sy + SY_QF_GO) < AO_NW, 0);              // the consumers' activation requests are queued: a small request behind the stream waits for all of it
     const unsigned total_o = wo.nrw > 0 ? (unsigned)wo.nrw * wo.rb : 0u;
     const int nso = (int)((total_o + ST_SLOT - 1) / ST_SLOT);
     const uint8_t *src_q = q.W + (size_t)q.b0 * q.rb, *src_o = wo.W + (size_t)wo.b0 * wo.rb;
@@ -1186,21 +1153,11 @@ __device__ __forceinline__ void qf_decode(const QFRun &q, const QFArgs &f, const
 // ea (QF): the layer input and the norm weights, requested in the kernel's first instructions from PRELOADED arguments (qkv_attn_out_kernel)
 template <int R, int TK, int TV, int C, int KB>
 __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table, int n_rot, const DecodeFuse &fz, const AOArgs &o, const QFArgs &f,
-                                        const EarlyAct<(KB > 0 ? KB : 1)> *eap = nullptr, const QFFast *fast = nullptr) {
+                                        const EarlyAct<(KB > 0 ? KB : 1)> *eap = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool QF = KB > 0;
     const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
-    if constexpr (QF) {
-        sync_init(smem);                               // (all ten waves)
-        if (wave >= AO_NW && (fast->kf >> 31) != 0) {  // the stream starts here: geometry from preloaded arguments, the LDS layout from them too (slots of the two runs)
-            QFRun fq; QFWoRun fw;
-            qf_fast_setup(*fast, fq, fw);
-            const unsigned rpw = (fast->kf >> 23) & 255u;
-            const unsigned slice = (rpw * fw.rb + ST_SLOT - 1) / ST_SLOT * ST_SLOT;     // (o.slice_lds: the W_o rows of a full workgroup in whole slots)
-            qf_loader(fq, fw, smem, lds_addr(smem + AO_QF_HDR + slice), lds_addr(smem + AO_QF_HDR), false, wave - AO_NW, lane);
-            return;
-        }
-    }
+    if constexpr (QF) sync_init(smem);                 // (all ten waves)
     if (o.probe && tid == 0) o.probe[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
     const AOLayout lay = ao_layout(o.slice_lds, o.K, sizeof(AOSmemQ<R, C>), QF ? AO_QF_HDR : 0u, QF ? f.qkv_lds : 0u);
     AOSmemQ<R, C> &sm = *reinterpret_cast<AOSmemQ<R, C> *>(smem + lay.attn);
@@ -1215,16 +1172,8 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
         qr = qf_setup(f);
         if (wave >= AO_NW) {
             const QFWoRun wr{b0, nrw, o.W, o.row_bytes};
-            qf_loader(qr, wr, smem, lds_addr(smem + lay.qkv), lds_addr(smem + lay.wo), true, wave - AO_NW, lane);
+            qf_loader(qr, wr, smem, lds_addr(smem + lay.qkv), lds_addr(smem + lay.wo), wave - AO_NW, lane);
             return;
-        }
-        if ((fast->kf >> 31) != 0 && wave == 0 && lane == 0) {     // the packed geometry must describe the runs the arguments describe
-            QFRun fq; QFWoRun fw;
-            qf_fast_setup(*fast, fq, fw);
-            const unsigned rpw = (fast->kf >> 23) & 255u;
-            const unsigned slice = (rpw * fw.rb + ST_SLOT - 1) / ST_SLOT * ST_SLOT;
-            if (fq.W != qr.W || fq.rb != qr.rb || fq.b0 != qr.b0 || fq.nrw != qr.nrw || fq.ns != qr.ns || fw.b0 != b0 || fw.nrw != nrw || fw.W != o.W || fw.rb != o.row_bytes ||
-                slice != o.slice_lds || AO_QF_HDR + slice != lay.qkv) st_timeout(ST_ERR_LOADER);
         }
     }
     // residual of this wave's first row pair: requested now, used at the very end
@@ -1478,23 +1427,21 @@ __global__ __launch_bounds__(AO_NT) void attn_out_kernel(const AttnArgs a, const
 }
 
 constexpr int AO_QF_NT = AO_NT + 128;                   // QF: two loader waves behind the eight
-// The first 13 argument dwords repeat what the launch's first instructions need (QFFast): the first dwords of a kernel's argument segment arrive in SGPRs with the
-// wave (build.py: -amdgpu-kernarg-preload-count for this file), so the activation's requests are queued in the kernel's first instructions and the loaders start
-// the stream behind the first barrier - before the cold argument segment has answered its first read (0.45 us)
+// The first three arguments repeat f.nx, f.nw, f.K: the first dwords of a kernel's argument segment arrive in SGPRs with the wave (build.py: -amdgpu-kernarg-preload-count
+// for this file), so the activation's requests - the head of the launch's dependent chain - are queued in the kernel's first instructions, before the cold argument
+// segment has answered its first read (0.45 us).  (The loaders started from preloaded, packed geometry as well - tools/r6_qf_fast_start.patch - lose 1.4 %: the launch is
+// bound by its prologue, and an earlier stream delays the consumers' small requests.)
 template <int R, int TK, int TV, int C, int KB>
-__global__ __launch_bounds__(AO_QF_NT) void qkv_attn_out_kernel(const float *p_nx, const uint8_t *p_wbase, unsigned p_onw, unsigned p_owq, unsigned p_owk, unsigned p_owv, unsigned p_owo,
-                                                                unsigned p_kf, unsigned p_rb01, unsigned p_rb2o, unsigned p_nkv, const AttnArgs a, const float *cs_table, int n_rot,
-                                                                const DecodeFuse fz, const AOArgs o, const QFArgs f) {
-    const QFFast fast{p_nx, p_wbase, p_onw, p_owq, p_owk, p_owv, p_owo, p_kf, p_rb01, p_rb2o, p_nkv};
+__global__ __launch_bounds__(AO_QF_NT) void qkv_attn_out_kernel(const float *p_nx, const float *p_nw, int p_K, const AttnArgs a, const float *cs_table, int n_rot, const DecodeFuse fz,
+                                                                const AOArgs o, const QFArgs f) {
     EarlyAct<KB> ea;
     {
         const int tid = tid_now(), lane = tid & 63, wave = uni(tid >> 6);
-        // (the loaders' copies are never looked at: a request under a condition makes hipcc wait where the branches join)
-        early_issue<KB, 1>(p_nx, reinterpret_cast<const float *>(p_wbase + ((size_t)p_onw << 4)), (int)(p_kf & 31u) << 8, wave < AO_NW ? wave : 0, lane, ea);
+        early_issue<KB, 1>(p_nx, p_nw, p_K, wave < AO_NW ? wave : 0, lane, ea);      // (the loaders' copies are never looked at: a request under a condition makes hipcc wait where the branches join)
     }
-    struct KArgs { QFFast p; AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; QFArgs f; };
+    struct KArgs { const float *nx, *nw; int K; AttnArgs a; const float *cs; int n_rot; DecodeFuse fz; AOArgs o; QFArgs f; };
     ao_touch_kernargs<sizeof(KArgs)>();
-    ao_body<R, TK, TV, C, KB>(a, cs_table, n_rot, fz, o, f, &ea, &fast);
+    ao_body<R, TK, TV, C, KB>(a, cs_table, n_rot, fz, o, f, &ea);
 }
 
 int g_attn_out_fused = -1;                  // -1: environment / default (on)
@@ -1576,7 +1523,7 @@ void attn_out_probe_report() {
 }
 
 // the launch of either form: qf == nullptr: the attention + attn_output kernel; else the layer's Q | K | V in front of it in the same launch
-struct QFPlan { QFArgs f; QFFast p; int blocks; int kb; size_t lds_qkv, lds_total; int slots; };
+struct QFPlan { QFArgs f; int blocks; int kb; size_t lds_qkv, lds_total; int slots; };
 static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs ra, const float *knew, const float *vnew, const int32_t *tok_cell,
                             unsigned *counters, unsigned *flags, unsigned long long *gran, int layer, const unsigned *serial, const MMVQSeg &wo, int K, int epi,
                             const QFPlan *qf, hipStream_t st) {
@@ -1615,7 +1562,7 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
             hipExtLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o); \
         else hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);             \
     } while (0)
-#define QF_FAST_ARGS qf->p.nx, qf->p.wbase, qf->p.onw, qf->p.owq, qf->p.owk, qf->p.owv, qf->p.owo, qf->p.kf, qf->p.rb01, qf->p.rb2o, qf->p.nkv
+#define QF_FAST_ARGS qf->f.nx, qf->f.nw, qf->f.K
 #define QF_LAUNCH(RR, TK, TV, CC, KBV)                                                                                                         \
     do {                                                                                                                                       \
         const size_t lds = qf->lds_total;                                                                                                      \
@@ -1718,30 +1665,6 @@ static QFPlan qf_plan(const AttnArgs &a, const MMVQSeg &wo, int K, const QKVFuse
     p.lds_total = accs_bytes <= f.qkv_lds ? ql.total : ql.total + accs_bytes;
     if (p.lds_total > 160 * 1024) return p;
     p.blocks = nwg;
-    // the packed geometry of the loaders' fast start (QFFast); kf == 0 (not valid) where a field does not fit - the loaders then read the argument segment.
-    // OFF unless MI355_QF_FAST_START=1: measured on the bench model (same box, tools/ab_libs.sh) the launch is bound by its PROLOGUE, not by the landing of its rows - with
-    // the stream started 0.7 us earlier the consumers' small requests sit behind it ("activation ready" 2.8 -> 3.05 us, worst workgroup 3.9 -> 4.9) and the step
-    // loses 1.4 % (660 vs 670 tok/s) - what mmvq_stream.hip found for its prologue-bound roles
-    static const bool fast_off = !(getenv("MI355_QF_FAST_START") && getenv("MI355_QF_FAST_START")[0] == '1');
-    QFFast &pf = p.p;
-    pf.nx = q.nx;
-    const void *ptrs[5] = {q.nw, q.seg[0].W, q.seg[1].W, q.seg[2].W, wo.W};
-    uintptr_t lo = ~(uintptr_t)0, hi = 0;
-    bool fits = !fast_off;
-    for (int i = 0; i < 5; i++) { const uintptr_t x = (uintptr_t)ptrs[i]; if (x & 15) fits = false; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
-    if (((hi - lo) >> 4) > 0xffffffffull) fits = false;
-    if (f.blk3 != nwg || f.blk1 > 511 || f.blk2 > 511 || rpw > 255 || (q.K >> 8) > 31 || wo.n_rows != q.K || f.n0 != q.K || f.n1 != f.n2) fits = false;
-    if (f.rb0 > 0xffffu || f.rb1 > 0xffffu || f.rb2 > 0xffffu || wo.row_bytes > 0xffffu) fits = false;
-    pf.wbase = reinterpret_cast<const uint8_t *>(lo);
-    if (fits) {
-        pf.onw = (unsigned)(((uintptr_t)ptrs[0] - lo) >> 4); pf.owq = (unsigned)(((uintptr_t)ptrs[1] - lo) >> 4); pf.owk = (unsigned)(((uintptr_t)ptrs[2] - lo) >> 4);
-        pf.owv = (unsigned)(((uintptr_t)ptrs[3] - lo) >> 4); pf.owo = (unsigned)(((uintptr_t)ptrs[4] - lo) >> 4);
-        pf.rb01 = f.rb0 | (f.rb1 << 16); pf.rb2o = f.rb2 | ((unsigned)wo.row_bytes << 16); pf.nkv = (unsigned)f.n1;
-        pf.kf = (unsigned)(q.K >> 8) | ((unsigned)f.blk1 << 5) | ((unsigned)f.blk2 << 14) | ((unsigned)rpw << 23) | (1u << 31);
-    } else {
-        // (the activation's early requests still come from the first arguments: nx, and the norm weights as an offset above wbase = themselves)
-        pf.wbase = reinterpret_cast<const uint8_t *>(q.nw); pf.onw = 0; pf.kf = (unsigned)(q.K >> 8);
-    }
     return p;
 }
 // host logic only (no device call): LDS bytes of the fused launch for a layer of this geometry at a context of n_kv cells, 0 where the step takes the two launches
