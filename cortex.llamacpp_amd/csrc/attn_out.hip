@@ -23,6 +23,10 @@
 // The attention arithmetic is that of attn_decode_dev.h with 512 threads per item instead of 256 (16 cell groups instead of 8 in the P.V pass: another
 // f32 summation order, within the parity tolerance) and, from 2049 cells on, 128-cell chunks (so that a 4096-cell context is 256 items = one
 // per workgroup and the merge sums at most 32 partials in one request round).
+//
+// Round 6: where the layer's attn_q | attn_k | attn_v rows fit in LDS beside the W_o rows, the Q | K | V mat-vecs (with their RMSNorm -> Q8_K prologue) run in front
+// of all this IN THE SAME LAUNCH (qkv_attn_out_kernel; the note in front of qf_setup below): one launch per layer for the whole attention block of a
+// single-token step.  attn_out_kernel stays the form for every other shape, unchanged.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -1562,7 +1566,7 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
             hipExtLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, ev0_, ev1_, 0, a, cs_table, ra.n_rot, fz, o); \
         else hipLaunchKernelGGL((attn_out_kernel<RR, TK, TV, CC>), dim3(nwg), dim3(AO_NT), lds, st, a, cs_table, ra.n_rot, fz, o);             \
     } while (0)
-#define QF_FAST_ARGS qf->f.nx, qf->f.nw, qf->f.K
+#define QF_EARLY_ARGS qf->f.nx, qf->f.nw, qf->f.K     /* (repeated as the kernel's first, preloaded arguments) */
 #define QF_LAUNCH(RR, TK, TV, CC, KBV)                                                                                                         \
     do {                                                                                                                                       \
         const size_t lds = qf->lds_total;                                                                                                      \
@@ -1571,8 +1575,8 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
         if (e != hipSuccess) return e;                                                                                                         \
         hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                                             \
         if (kernel_timer() && kernel_timer()->next("qkv_attn_out", &ev0_, &ev1_))                                                              \
-            hipExtLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, ev0_, ev1_, 0, QF_FAST_ARGS, a, cs_table, ra.n_rot, fz, o, qf->f); \
-        else hipLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, QF_FAST_ARGS, a, cs_table, ra.n_rot, fz, o, qf->f); \
+            hipExtLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, ev0_, ev1_, 0, QF_EARLY_ARGS, a, cs_table, ra.n_rot, fz, o, qf->f); \
+        else hipLaunchKernelGGL((qkv_attn_out_kernel<RR, TK, TV, CC, KBV>), dim3(nwg), dim3(AO_QF_NT), lds, st, QF_EARLY_ARGS, a, cs_table, ra.n_rot, fz, o, qf->f); \
     } while (0)
 #define AO_K(RR, TK, TV, CC) do { if (!qf) AO_LAUNCH(RR, TK, TV, CC); else if (qf->kb == 1) QF_LAUNCH(RR, TK, TV, CC, 1); else QF_LAUNCH(RR, TK, TV, CC, 2); } while (0)
 #define AO_C(RR, TK, TV) do { if (C == 64) AO_K(RR, TK, TV, 64); else AO_K(RR, TK, TV, 128); } while (0)
@@ -1592,7 +1596,7 @@ static hipError_t launch_ao(const AttnArgs &a, const float *cs_table, RopeArgs r
 #undef AO_C
 #undef AO_K
 #undef QF_LAUNCH
-#undef QF_FAST_ARGS
+#undef QF_EARLY_ARGS
 #undef AO_LAUNCH
     return hipGetLastError();
 }
