@@ -150,9 +150,7 @@ __device__ __forceinline__ void ao_issue_dma(const AOArgs &o, uint8_t *smem, int
     }
 }
 
-// What an item requests from memory before it can compute anything.  QF: the part that does not depend on this launch's Q | K | V (cell metadata, the chunk's
-// K / V rows and scales, the rope table) is requested BEFORE the workgroup's share of the projections is computed and sits in registers meanwhile; q and the token's
-// K / V row arrive later as granules.
+// What an item requests from memory before it can compute anything (QF: q and the token's K / V row arrive as granules instead - ao_item_run).
 template <int R, int TK, int TV, int C> struct AOItemLd {
     static constexpr int KROW = TK == T_F16 ? 2 * AO_D : AO_D, LPC = KROW / 16, KP = C * LPC / AO_NT, CPG = C / AO_NCG;
     int chunk; bool skip;
@@ -1037,13 +1035,14 @@ __device__ __forceinline__ void ao_decode(const AOArgs &o, const uint8_t *slice,
 // spent waiting for its own K / V cache rows, which do not depend on the first launch at all.  Both launches' weights fit in LDS at once (Q | K | V: ~58 KB per
 // workgroup, W_o: 37 KB), so: ten waves per workgroup; waves 8 and 9 are LOADERS (mmvq_stream_dev.h's division of labour: only they ever sit in the memory queue) -
 // they copy the workgroup's Q | K | V rows and then its W_o rows HBM -> LDS by DMA, publish what has landed and END (a barrier only counts live waves); waves 0 - 7:
-//   1. request the layer input and the norm weights (early_issue), an item workgroup also its chunk's K / V rows, scales and cell metadata - into registers, where
-//      they wait for q -, then the step's scalars; only then are the loaders let go ([SY_GO]: a small request queued behind the stream waits for all of it);
+//   1. request the layer input and the norm weights in the kernel's first instructions (early_issue, from preloaded arguments), then the step's scalars; behind those
+//      requests the loaders are let go ([SY_QF_GO]: a small request queued behind the stream waits for all of it);
 //   2. RMSNorm * w -> Q8_K exactly as the weight stream's prologue does (consumer_prologue: same code, same bits), decode the workgroup's rows out of LDS with the
 //      stream's decoders as the slots land, and publish every result as ONE 8-byte granule {tag, f32 bits} written through to the coherence point;
-//   3. item workgroups sweep the granules of their kv head (q: 2 KB, the K / V row: 1 KB) until each carries the tag and carry on as before; W_o is on chip long
-//      before the merged codes arrive.
-// One launch and one boundary less per layer, and the attention's first memory round trip under the projections.  Outputs are bit-identical to the two launches.
+//   3. item workgroups request their chunk's K / V rows, scales and cell metadata (behind the projections: in front of them those requests - megabytes with the context
+//      filled - hold the prologue and the stream back), sweep the granules of their kv head (q: 2 KB, the K / V row: 1 KB) until each carries the tag and carry on as
+//      before; W_o is on chip long before the merged codes arrive.
+// One launch, one boundary and one ramp less per layer.  Outputs are bit-identical to the two launches.
 struct QFRun { const uint8_t *W; unsigned rb, total; int type, b0, nrw, grow0, ns; };     // grow0: granule index of row b0; ns: 4 KiB slots of the run
 __device__ __forceinline__ QFRun qf_setup(QFArgs f) {
     // (through opaque copies: from adjacent kernel arguments selected by one index hipcc builds a table in scratch memory)
@@ -1196,14 +1195,13 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
     if constexpr (QF) {
         static_assert(ST_NC == AO_NW, "the weight stream's prologue is cut for eight consumer waves");
 #ifndef MI355_QF_LATE_GO
-        // the loaders go NOW: only the activation's requests must be ahead of the stream (the launch's first dependent step waits for the Q | K | V rows to land,
-        // not for the prologue); the item's cache rows, queued behind the stream, are not needed before q exists
+        // the loaders go NOW: only the activation's requests must be ahead of the stream
         asm volatile("" ::: "memory");
         if (lane == 0) (void)__hip_atomic_fetch_add(sy + SY_QF_GO, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-        const bool pre_item = it0 < o.n_items;         // (workgroup-uniform)
-        AOItemLd<R, TK, TV, C> ld0;
-        if (pre_item) ao_item_issue<R, TK, TV, C, true>(a, cs_table, n_rot, fz, o, it0 % G, it0 / G, ld0);
+        // (an item's cache rows are requested BEHIND the projections, as part of the item: requested here, to wait in registers for q, they sit in the memory queue in
+        // front of the projections' stream and hold the prologue and the rows back - activation ready 2.8 -> 4.6 us with the context filled (256 items x 34 KB);
+        // same box: 622 -> 645 tok/s filled, 683 -> 687 at pos 512)
         scal = ao_load_scalars(o.serial, a.tok_pos, a.tok_seq, fz.tok_cell);
         StOp pa{};
         pa.K = f.K; pa.neps = f.neps; pa.nx = f.nx; pa.nw = f.nw;
@@ -1225,11 +1223,6 @@ __device__ __forceinline__ void ao_body(const AttnArgs &a, const float *cs_table
                 case T_Q8_0: qf_decode<T_Q8_0, KB>(qr, f, smem + lay.qkv, AL, sy, tag, wave, lane); break;
                 default: break;
             }
-        }
-        if (pre_item) {                                // the workgroup's first item: its cache rows have been in registers since the top of the launch
-            ao_item_run<R, TK, TV, C, true>(a, n_rot, fz, o, f, &scal, it0 % G, it0 / G, sm, accs, ld0, dma);
-            had_item = true;
-            it0 += (int)gridDim.x;
         }
     }
     for (int it = it0; it < o.n_items; it += (int)gridDim.x) {
